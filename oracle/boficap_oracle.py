@@ -1,0 +1,348 @@
+"""CPU oracle for the BoFiCap bound+fill hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a plain float32 restatement (torch CPU tensors, functional style, dense masks) of the
+reference's algorithm.  It is the checker for ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; nothing in ``boficap_amd/`` may import it, and the product
+path never routes through it.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` imports the real reference in the build
+container, runs it on weights from ``boficap_amd.weights.make_state_dict`` and asserts that this
+oracle reproduces every tensor; the outputs are committed under ``tests/golden/`` and
+``tests/test_oracle_golden.py`` re-checks the oracle against them without the reference.
+
+Every function cites the reference lines it restates (paths relative to ``/root/reference``;
+TM = captioning/models/TransformerModel.py, AM = captioning/models/AttModel.py,
+CM = captioning/models/CaptionModel.py).  Weights are a flat dict keyed like the reference's
+``state_dict()``.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+LENGTH_DIM, SYN_DIM, SYN_LOWER, SYN_UPPER = 20, 10, 4, 6      # TM:329-332 / TM:39-42
+NEG_INF = float("-inf")
+
+Weights = Dict[str, torch.Tensor]
+
+
+def as_torch(sd) -> Weights:
+    return {k: (v if torch.is_tensor(v) else torch.from_numpy(v)).float() for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------- building blocks
+def layer_norm(x, w: Weights, p: str, eps: float = 1e-6):
+    """TM:1346-1349 -- unbiased std, eps added to std (NOT nn.LayerNorm)."""
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)
+    return w[p + ".a_2"] * (x - mean) / (std + eps) + w[p + ".b_2"]
+
+
+def linear(x, w: Weights, p: str):
+    return F.linear(x, w[p + ".weight"], w[p + ".bias"])
+
+
+def attention(w: Weights, p: str, q_in, kv_in, mask, h: int):
+    """TM:1446-1467 + TM:1421-1432.  mask: bool [B,1|Lq,Lk], True = may attend."""
+    B, Lq, d = q_in.shape
+    dk = d // h
+    q = linear(q_in, w, p + ".linears.0").view(B, -1, h, dk).transpose(1, 2)
+    k = linear(kv_in, w, p + ".linears.1").view(B, -1, h, dk).transpose(1, 2)
+    v = linear(kv_in, w, p + ".linears.2").view(B, -1, h, dk).transpose(1, 2)
+    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
+    scores = scores.masked_fill(mask.unsqueeze(1) == 0, NEG_INF)
+    p_attn = F.softmax(scores, dim=-1)          # a fully masked row is NaN, as in the reference
+    ctx = torch.matmul(p_attn, v).transpose(1, 2).contiguous().view(B, Lq, d)
+    return linear(ctx, w, p + ".linears.3")
+
+
+def feed_forward(w: Weights, p: str, x):
+    """TM:1477-1478 (dropout off)."""
+    return linear(F.relu(linear(x, w, p + ".w_1")), w, p + ".w_2")
+
+
+def embed(w: Weights, p: str, ids, d: int):
+    """TM:1486-1487."""
+    return w[p + ".lut.weight"][ids] * math.sqrt(d)
+
+
+def add_pe(w: Weights, x):
+    """TM:1505-1507 (dropout off)."""
+    return x + w["model.pos_embed.pe"][:, : x.size(1)]
+
+
+# ----------------------------------------------------------------------------- encoder (a1, a2)
+def prepare_feature(w: Weights, cfg, att_feats, att_masks: Optional[torch.Tensor]):
+    """TM:1674-1690 + AM:113-120 + AM:46-51.  Returns (embedded regions, src mask [B,1,R])."""
+    if att_masks is not None:
+        max_len = int(att_masks.long().sum(1).max())
+        att_feats = att_feats[:, :max_len].contiguous()
+        att_masks = att_masks[:, :max_len].contiguous()
+    x = F.relu(linear(att_feats, w, "att_embed.0"))
+    if att_masks is not None:
+        # pack_padded_sequence -> module -> pad_packed_sequence: rows past each image's length
+        # come back as exact zeros (AM:46-49), not relu(bias)
+        lens = att_masks.long().sum(1)
+        keep = torch.arange(x.size(1))[None, :] < lens[:, None]
+        x = x * keep.unsqueeze(-1).to(x.dtype)
+        src_mask = att_masks.bool().unsqueeze(-2)
+    else:
+        src_mask = torch.ones(x.shape[:2], dtype=torch.bool).unsqueeze(-2)
+    return x, src_mask
+
+
+def encode(w: Weights, cfg, x, src_mask):
+    """TM:1332-1336, 1374-1377."""
+    for l in range(cfg.N_enc):
+        p = f"model.encoder.layers.{l}"
+        n = layer_norm(x, w, p + ".sublayer.0.norm")
+        x = x + attention(w, p + ".self_attn", n, n, src_mask, cfg.h)
+        x = x + feed_forward(w, p + ".feed_forward", layer_norm(x, w, p + ".sublayer.1.norm"))
+    return layer_norm(x, w, "model.encoder.norm")
+
+
+def memory_of(w: Weights, cfg, att_feats, att_masks=None):
+    x, src_mask = prepare_feature(w, cfg, att_feats, att_masks)
+    return encode(w, cfg, x, src_mask), src_mask
+
+
+# ----------------------------------------------------------------------------- bounding network (a7, a8)
+def bound_row0(w: Weights, cfg, input_embed, memory, src_mask, tgt_mask):
+    """Bound layers + final norm, row 0 ([LEN]) only is returned (TM:367-375; layer TM:1025-1029)."""
+    lp = "model.length_predictor"
+    x = input_embed
+    for l in range(cfg.N_len):
+        p = f"{lp}.LengthPredictor.{l}"
+        n = layer_norm(x, w, p + ".sublayer.0.norm")
+        x = x + attention(w, p + ".self_attn", n, n, tgt_mask, cfg.h)
+        n = layer_norm(x, w, p + ".sublayer.1.norm")
+        x = x + attention(w, p + ".src_attn", n, memory, src_mask, cfg.h)
+        x = x + feed_forward(w, p + ".ff", layer_norm(x, w, p + ".sublayer.2.norm"))
+    return layer_norm(x, w, lp + ".norm")[:, 0, :]
+
+
+def bound_heads(w: Weights, out):
+    """TM:376-383 (dropout off): two 2-layer heads, log-softmax, first-max argmax."""
+    lp = "model.length_predictor"
+    len_logp = F.log_softmax(linear(F.relu(linear(out, w, lp + ".Length_classifier1")), w, lp + ".Length_classifier2"), dim=-1)
+    syn_logp = F.log_softmax(linear(F.relu(linear(out, w, lp + ".Syntactic_classifier1")), w, lp + ".Syntactic_classifier2"), dim=-1)
+    len_n = torch.max(len_logp, 1)[1].int()
+    syn_n = torch.max(syn_logp, 1)[1].long()
+    return len_n, len_logp, syn_n, syn_logp
+
+
+def bound_step(w: Weights, cfg, input_embed, memory, src_mask, tgt_mask):
+    """LengthPredictor_UIC.forward TM:357-383 with N_len >= 1."""
+    return bound_heads(w, bound_row0(w, cfg, input_embed, memory, src_mask, tgt_mask))
+
+
+def bound_step_na(w, cfg, extend_phrase_syn, memory, src_mask, tgt_mask):
+    """TM:567-568."""
+    return bound_step(w, cfg, add_pe(w, embed(w, "model.syn_embed", extend_phrase_syn, cfg.d_model)),
+                      memory, src_mask, tgt_mask)
+
+
+def bound_step_sa(w, cfg, word_seq, memory, src_mask, tgt_mask):
+    """TM:515-518."""
+    return bound_step(w, cfg, add_pe(w, embed(w, "model.tgt_embed", word_seq, cfg.d_model)),
+                      memory, src_mask, tgt_mask)
+
+
+# ----------------------------------------------------------------------------- decoder (a10)
+def decode(w: Weights, cfg, x, memory, src_mask, tgt_mask):
+    """TM:1386-1396, 1408-1413."""
+    for l in range(cfg.N_dec):
+        p = f"model.decoder.layers.{l}"
+        n = layer_norm(x, w, p + ".sublayer.0.norm")
+        x = x + attention(w, p + ".self_attn", n, n, tgt_mask, cfg.h)
+        n = layer_norm(x, w, p + ".sublayer.1.norm")
+        x = x + attention(w, p + ".src_attn", n, memory, src_mask, cfg.h)
+        x = x + feed_forward(w, p + ".feed_forward", layer_norm(x, w, p + ".sublayer.2.norm"))
+    return layer_norm(x, w, "model.decoder.norm")
+
+
+def decode_na(w, cfg, memory, syn_seq, src_mask, tgt_mask, glat_input=None):
+    """TM:570-587, input mode 'add'."""
+    word_seq = torch.full(syn_seq.shape, cfg.bos_idx, dtype=torch.long) if glat_input is None else glat_input
+    x = add_pe(w, embed(w, "model.tgt_embed", word_seq, cfg.d_model) + embed(w, "model.syn_embed", syn_seq, cfg.d_model))
+    return decode(w, cfg, x, memory, src_mask, tgt_mask)
+
+
+def decode_sa(w, cfg, memory, word_seq, syn_seq, src_mask, tgt_mask):
+    """TM:520-530, input mode 'add'."""
+    x = add_pe(w, embed(w, "model.tgt_embed", word_seq, cfg.d_model) + embed(w, "model.syn_embed", syn_seq, cfg.d_model))
+    return decode(w, cfg, x, memory, src_mask, tgt_mask)
+
+
+def logit(w, x):
+    """TM:1668-1669."""
+    return linear(x, w, "model.generator.proj")
+
+
+# ----------------------------------------------------------------------------- NAIC bound loop (a9)
+def core_naic(w: Weights, cfg, memory, src_mask, *, fix_q1: bool = False, trace=None):
+    """TM:1823-1876, including quirk Q1 (the fill mask of EVERY row uses the last row's length,
+    TM:1872-1873) unless ``fix_q1``.  Returns the fill output and the slot layout, plus
+    diagnostics (iterations executed, ``last`` per image)."""
+    B = memory.size(0)
+    S = cfg.seq_length
+    L = S + 2
+    phrase_num = torch.zeros(B, dtype=torch.int)
+    phrase_length = torch.zeros(B, L, dtype=torch.int)
+    phrase_syn = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    ext_syn = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    tgt_mask = torch.zeros(B, L, L, dtype=torch.bool)
+    last = torch.zeros(B, dtype=torch.int)
+    finished = torch.zeros(B, dtype=torch.bool)
+    reason = ["maxiter"] * B                                 # diagnostics only
+    iters = 0
+    for i in range(S):
+        if i == 0:
+            ext_syn[:, 0] = cfg.len_idx
+            tgt_mask[:, :, 0] = True
+            last[:] = 1
+        out0 = bound_row0(w, cfg, add_pe(w, embed(w, "model.syn_embed", ext_syn, cfg.d_model)), memory, src_mask, tgt_mask)
+        len_n, len_logp, syn_n, syn_logp = bound_heads(w, out0)                      # == TM:567-568
+        if trace is not None:
+            trace.append(dict(out0=out0.clone(), len_logp=len_logp.clone(), syn_logp=syn_logp.clone(),
+                              active=~finished.clone(), ext_syn=ext_syn.clone(), last=last.clone()))
+        iters += 1
+        for j in range(B):
+            if finished[j]:
+                continue
+            ln, sn, la = int(len_n[j]), int(syn_n[j]), int(last[j])
+            if ln == 0 or sn < SYN_LOWER or sn > SYN_UPPER:
+                finished[j] = True
+                reason[j] = "len0" if ln == 0 else "syn"
+                continue
+            if ln + la >= S + 1:
+                ln = S + 1 - la
+                finished[j] = True
+                reason[j] = "trunc"
+            phrase_length[j, i] = ln
+            phrase_syn[j, i] = sn
+            phrase_num[j] += 1
+            ext_syn[j, la:la + ln] = sn
+            tgt_mask[j, la:, :la + ln] = True
+            last[j] = la + ln
+            tgt_mask[j, 0, :la + ln] = True
+        if bool(finished.all()):
+            break
+    syn_mask = torch.zeros(B, S, S, dtype=torch.bool)
+    for i in range(B):
+        n = int(last[i] if fix_q1 else last[B - 1]) - 1      # Q1: stale loop variable j == B-1
+        syn_mask[i, :, :max(n, 0)] = True
+    phrase = decode_na(w, cfg, memory, ext_syn[:, 1:-1], src_mask, syn_mask)
+    return phrase, phrase_num, phrase_length[:, :-2], phrase_syn[:, :-2], dict(iters=iters, last=last.clone(), ext_syn=ext_syn.clone(), reason=reason)
+
+
+def sample_naic(w: Weights, cfg, att_feats, att_masks=None, *, output_logsoftmax: int = 1,
+                fix_q1: bool = False):
+    """AM:307-338, 419-429 + AM:203-210 + CM:388-390, greedy, sample_n = 1.
+    Returns the reference's 6-tuple (the last element is elapsed seconds)."""
+    memory, src_mask = memory_of(w, cfg, att_feats, att_masks)
+    t0 = time.time()
+    phrase, phrase_num, phrase_length, phrase_syn, _ = core_naic(w, cfg, memory, src_mask, fix_q1=fix_q1)
+    lg = logit(w, phrase)
+    seq_logprob = F.log_softmax(lg, dim=2) if output_logsoftmax else lg
+    seq = torch.max(seq_logprob, 2)[1].long()
+    for b in range(seq.size(0)):
+        seq[b, int(phrase_length[b].sum()):] = cfg.pad_idx
+    return seq, seq_logprob, phrase_num, phrase_length, phrase_syn, time.time() - t0
+
+
+# ----------------------------------------------------------------------------- SAIC (a16, next row f1)
+def core_saic(w: Weights, cfg, memory, src_mask, *, output_logsoftmax: int = 1):
+    """TM:1878-1986, greedy."""
+    B = memory.size(0)
+    S = cfg.seq_length
+    L = S + 2
+    V = w["model.generator.proj.weight"].size(0)
+    phrase_num = torch.zeros(B, dtype=torch.int)
+    phrase_length = torch.zeros(B, L, dtype=torch.int)
+    phrase_syn = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    seq = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    seq_logprobs = torch.zeros(B, L, V)
+    ext_len = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    ext_phrase = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    ext_syn = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    len_mask = torch.zeros(B, L, L, dtype=torch.bool)
+    phrase_mask = torch.zeros(B, L, L, dtype=torch.bool)
+    finished = torch.zeros(B, dtype=torch.bool)
+    seq_last = torch.zeros(B, dtype=torch.int)
+    phrase_last = torch.zeros(B, dtype=torch.int)
+    iters = 0
+    for i in range(1, S + 1):
+        if i == 1:
+            seq[:, 0] = cfg.bos_idx
+            phrase_length[:, 0] = 1
+            ext_len[:, 0] = cfg.len_idx
+            len_mask[:, :, 0] = True
+            phrase_last[:] = 1
+        len_n, _, syn_n, _ = bound_step_sa(w, cfg, ext_len.clone(), memory, src_mask, len_mask)
+        iters += 1
+        for j in range(B):
+            if finished[j]:
+                continue
+            ln, sn, pl = int(len_n[j]), int(syn_n[j]), int(phrase_last[j])
+            if ln == 0 or sn < SYN_LOWER or sn > SYN_UPPER:
+                finished[j] = True
+                continue
+            if ln + pl >= S + 1:
+                ln = S + 1 - pl
+                finished[j] = True
+            phrase_length[j, i] = ln
+            phrase_syn[j, i] = sn
+            phrase_num[j] += 1
+        for j in range(B):
+            cur = int(phrase_length[j, i])
+            if cur == 0:
+                continue
+            pl, sl, prev = int(phrase_last[j]), int(seq_last[j]), int(phrase_length[j, i - 1])
+            ext_syn[j, pl:pl + cur] = phrase_syn[j, i]
+            if cur <= prev:                                   # TM:1934-1936
+                pre_pad = prev - cur
+                ext_phrase[j, pl:pl + cur] = seq[j, sl + pre_pad: sl + pre_pad + cur]
+            else:                                             # TM:1937-1947 positionwise stretch
+                pre_less = prev - (cur % prev)
+                times = cur // prev
+                copied = 0
+                for k in range(prev):
+                    n = times if k < pre_less else times + 1
+                    ext_phrase[j, pl + copied: pl + copied + n] = seq[j, sl + k]
+                    copied += n
+            phrase_mask[j, pl:, :pl + cur] = True
+        phrase = decode_sa(w, cfg, memory, ext_phrase.clone()[:, 1:-1], ext_syn.clone()[:, 1:-1],
+                           src_mask, phrase_mask[:, 1:-1, 1:-1])
+        lg = logit(w, phrase)
+        phrase_logprobs = F.log_softmax(lg, dim=2) if output_logsoftmax else lg
+        if bool(phrase_logprobs.isnan().any()):               # TM:1956-1958
+            return seq[:, 1:-1], seq_logprobs[:, 1:-1, :], phrase_num, phrase_length[:, 1:-1], phrase_syn[:, 1:-1], dict(iters=iters, nan=True)
+        tok = torch.max(phrase_logprobs, 2)[1].long()
+        for j in range(B):
+            cur = int(phrase_length[j, i])
+            if cur == 0:
+                continue
+            pl = int(phrase_last[j])
+            seq[j, pl:pl + cur] = tok[j, pl - 1: pl - 1 + cur]
+            seq_logprobs[j, pl:pl + cur] = phrase_logprobs[j, pl - 1: pl - 1 + cur]
+            ext_len[j, pl:pl + cur] = tok[j, pl - 1: pl - 1 + cur]
+            len_mask[j, pl:, :pl + cur] = True
+            phrase_last[j] = pl + cur
+            len_mask[j, 0, :pl + cur] = True
+            seq_last[j] += int(phrase_length[j, i - 1])
+        if bool(finished.all()):
+            break
+    return seq[:, 1:-1], seq_logprobs[:, 1:-1, :], phrase_num, phrase_length[:, 1:-1], phrase_syn[:, 1:-1], dict(iters=iters, nan=False)
+
+
+def sample_saic(w: Weights, cfg, att_feats, att_masks=None, *, output_logsoftmax: int = 1):
+    """AM:430-437."""
+    memory, src_mask = memory_of(w, cfg, att_feats, att_masks)
+    t0 = time.time()
+    seq, lp, pn, pl, ps, _ = core_saic(w, cfg, memory, src_mask, output_logsoftmax=output_logsoftmax)
+    return seq, lp, pn, pl, ps, time.time() - t0

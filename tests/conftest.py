@@ -1,0 +1,51 @@
+"""pytest configuration: the ``gpu`` marker and shared fixture loaders."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+TINY_CASES = ["tiny_mix", "tiny_q1_last_shortest", "tiny_q1_last_empty_nan", "tiny_single",
+              "tiny_ragged", "tiny_ragged_short"]
+
+
+@pytest.fixture(scope="session")
+def weight_cache():
+    """state dicts are regenerated from seeds (and checked against the fixture digests)."""
+    from boficap_amd import weights as W
+    from boficap_amd.config import FULL, TINY
+    cache = {}
+
+    def get(config_name, seed, gen_scale, digest=None):
+        key = (config_name, seed, gen_scale)
+        if key not in cache:
+            cfg = {"TINY": TINY, "FULL": FULL}[config_name]
+            sd = W.make_state_dict(cfg, seed=seed, gen_scale=gen_scale)
+            if digest is not None:
+                assert W.digest(sd) == digest, "regenerated weights differ from the ones the fixture was made with"
+            cache[key] = (cfg, sd)
+        return cache[key]
+    return get
