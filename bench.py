@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Benchmark of the NAIC bound+fill decode hot path on MI355X (BASELINE.json metric).
+
+A step = one greedy bound+fill decode (encoder -> bounding loop -> filling pass -> vocabulary
+projection / log-softmax / argmax) of one batch of 64 images x 36 regions x 2048 features, bf16,
+features resident in HBM, ids + slot layout + the [B,20,V] log-prob tensor written to HBM exactly as
+the reference's ``_sample`` returns them.  One process per GPU; images shard across ranks with no
+collective (weak scaling: every rank decodes its own 64-image batch per step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--dtype bf16|f32]
+                    [--ids-only] [--no-graph] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0 (contract in the task brief): metric/value/unit, roofline (MFMA
+bound, algorithmic FLOPs of SURVEY.md §8d over the HIP-event time of the decode launches) and
+cpu_baseline (the CPU oracle timed on this host's cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ATT_SEED = 1235      # seed 1234 puts an image with zero phrases last: quirk Q1 then NaNs the whole batch
+MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense TFLOP/s, MI355X_MICROARCH.md
+
+
+def f_alg(T: float, cfg) -> float:
+    """Algorithmic FLOPs per image for T bound iterations, from the config."""
+    d, dff, F, R, S, L, V = cfg.d_model, cfg.d_ff, cfg.att_feat_size, 36, cfg.seq_length, cfg.seq_length + 2, cfg.tgt_vocab
+    att_embed = 2 * R * F * d
+    enc_layer = 2 * R * (4 * d * d + 2 * d * dff) + 4 * R * R * d
+    dec_layer = 2 * S * (4 * d * d + 2 * d * d + 2 * d * dff) + 2 * R * 2 * d * d + 4 * S * S * d + 4 * S * R * d
+    vocab = 2 * S * d * V
+    bound_once = 2 * (L + R) * 2 * d * d                      # K/V of the 22 slot rows and the 36 memory rows
+    # row-0 work per iteration as SURVEY.md §8d prices it (4 d^2 projections; the build precomputes
+    # the constant row-0 query, so it executes slightly less than it is charged for)
+    bound_iter = 2 * (4 * d * d + 2 * d * dff + 2 * 100 * d + 100 * 30) + 4 * (L + R) * d
+    return att_embed + cfg.N_enc * enc_layer + cfg.N_dec * dec_layer + vocab + bound_once + T * bound_iter
+
+
+def cpu_baseline(cfg, sd, batch, seed, budget_s=20.0):
+    """The CPU oracle (kind 'port': a restatement pinned to the reference by tests/golden) on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import boficap_oracle as O
+    from boficap_amd import weights as W
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = O.as_torch(sd)
+    att = torch.from_numpy(W.synthetic_att_feats(batch, 36, cfg.att_feat_size, seed=seed))
+    O.sample_naic(w, cfg, att)                                 # warm-up
+    times, t_end = [], time.time() + budget_s
+    while len(times) < 5 and (time.time() < t_end or not times):
+        t0 = time.time()
+        O.sample_naic(w, cfg, att)
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} x one batch of {batch} images, fp32 torch-CPU oracle, median, {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--ids-only", action="store_true", help="do not materialise the [B,20,V] log-prob tensor")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from boficap_amd import weights as W
+    from boficap_amd.config import FULL as cfg
+    from boficap_amd.engine import BofiEngine
+
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    sd = W.make_state_dict(cfg, seed=0)
+    eng = BofiEngine(cfg, tdt, max_batch=args.batch, max_regions=36, device=dev)
+    eng.load_state_dict(sd)
+    # every rank decodes its own shard of images (different seed per rank), already resident in HBM
+    att = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev).to(tdt).contiguous()
+    graph = not args.no_graph
+    out = eng.decode_naic(att, want_logprob=not args.ids_only, graph=graph)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.decode_naic(att, graph=graph, out=out)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        eng.decode_naic(att, graph=graph, out=out)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps            # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    T = int(out["bound_iters"].item())
+    ntok = float(out["phrase_length"].sum(1).float().mean().item())
+    nan = bool(out["seq_logprob"].isnan().any().item()) if out["seq_logprob"] is not None else False
+    if rank == 0:
+        images = args.batch * world * args.steps
+        flops_launch = f_alg(T, cfg) * args.batch
+        achieved = flops_launch / (dev_ms * 1e-3) / 1e12
+        res = {
+            "metric": "images/sec NAR bound+fill greedy decode (NAIC _sample)",
+            "value": round(images / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"batch={args.batch} NAR bound+fill inference, 36x2048 regions, d_model=512 6+6 layers(+1 bound layer), {args.dtype}",
+                       "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
+                       "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
+                       "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
+                       "att_feats_seed": ATT_SEED, "nan_in_output": nan, "sharding": "images by rank, no collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None,
+                         "kernel": "whole decode = one hipGraph launch of the path's kernels" if graph else "whole decode (eager launches)",
+                         "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
+                         "note": "algorithmic FLOPs F_alg(T)*batch (SURVEY.md 8d) / HIP-event time per decode on the launch stream"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, args.batch, ATT_SEED)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+// Internal C++ launch API shared by the translation units of libboficap_hip.so.
+// The public C ABI is include/boficap_hip.h; these are the same operations with typed streams.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bofi {
+
+int launch_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows, int d,
+                     hipStream_t st);
+
+struct LinearArgs {
+    const void* x; int x_dtype; int ldx;
+    const void* w; int w_dtype;
+    const float* bias;
+    const float* residual; int ldr;
+    void* y; int y_dtype; int ldy;
+    int M, N, K;
+    int relu;
+    const int* row_len; int rows_per_group;
+    // optional fused LayerNorm on the rows of x (x must be float32, K == d_model): the A tile is
+    // normalised while it is staged into LDS
+    const float* ln_gain; const float* ln_bias;
+    // optional early-out word: the kernel returns at once when *skip_if_ge >= skip_threshold
+    const int* skip_if_ge; int skip_threshold;
+};
+int launch_linear(const LinearArgs& a, hipStream_t st);
+
+struct AttnArgs {
+    const void* q; int ldq;
+    const void* k; int ldk;
+    const void* v; int ldv;
+    void* out; int ldo;
+    int dtype;
+    int B, H, Lq, Lk;
+    const int* klen; int klen_sb, klen_sq;
+    int klen_bias;            // effective length = klen[...] + klen_bias (e.g. -1 for last-1)
+    int klen_shared_last;     // quirk Q1: use entry (B-1) of klen for every batch item
+    const int* skip_if_ge; int skip_threshold;
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);
+
+int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
+                          int pad_idx, int64_t* seq, hipStream_t st);
+
+}  // namespace bofi

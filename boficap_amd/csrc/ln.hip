@@ -1,0 +1,94 @@
+// BoFiCap LayerNorm (reference captioning/models/TransformerModel.py:1346-1349):
+//   y = a_2 * (x - mean) / (std + eps) + b_2,  std = sqrt(sum((x-mean)^2) / (d-1)),  eps = 1e-6.
+// One wavefront per row: the row (d <= 2048 floats) lives in registers, two wave reductions.
+// HBM-bound: 4 B read + 2|4 B written per element.
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+template <typename OT, int PER_LANE>   // d = 64 * PER_LANE
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ gain,
+                                                 const float* __restrict__ bias, OT* __restrict__ y, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int D = 64 * PER_LANE;
+    const float* xr = x + (size_t)row * D;
+    float v[PER_LANE];
+    float s = 0.f;
+    // lane owns 4-float chunks: chunk c covers columns c*256 + lane*4 .. +3 (coalesced 16-B loads)
+    if constexpr (PER_LANE % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < PER_LANE / 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + c * 256 + lane * 4);
+            v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
+            s += (t.x + t.y) + (t.z + t.w);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) { v[c] = xr[c * 64 + lane]; s += v[c]; }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < PER_LANE; ++c) { const float t = v[c] - mean; q += t * t; }
+    const float stdv = sqrtf(wave_sum(q) / (float)(D - 1));
+    const float denom = stdv + 1e-6f;
+    OT* yr = y + (size_t)row * D;
+    if constexpr (PER_LANE % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < PER_LANE / 4; ++c) {
+            const int col = c * 256 + lane * 4;
+            const float4 g = *reinterpret_cast<const float4*>(gain + col);
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            float o0 = g.x * (v[c * 4 + 0] - mean) / denom + b.x;
+            float o1 = g.y * (v[c * 4 + 1] - mean) / denom + b.y;
+            float o2 = g.z * (v[c * 4 + 2] - mean) / denom + b.z;
+            float o3 = g.w * (v[c * 4 + 3] - mean) / denom + b.w;
+            if constexpr (sizeof(OT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + col) = make_float4(o0, o1, o2, o3);
+            } else {
+                ushort4 p;
+                p.x = f32_to_bf16(o0); p.y = f32_to_bf16(o1); p.z = f32_to_bf16(o2); p.w = f32_to_bf16(o3);
+                *reinterpret_cast<ushort4*>(reinterpret_cast<bf16_t*>(yr) + col) = p;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            const int col = c * 64 + lane;
+            const float o = gain[col] * (v[c] - mean) / denom + bias[col];
+            ElemOps<OT>::store(yr + col, o);
+        }
+    }
+}
+
+template <typename OT>
+static int launch_ln_t(const float* x, const float* g, const float* b, OT* y, int rows, int d, hipStream_t st) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (d / 64) {
+#define BOFI_LN_CASE(P) case P: hipLaunchKernelGGL((ln_kernel<OT, P>), grid, block, 0, st, x, g, b, y, rows); break;
+        BOFI_LN_CASE(1) BOFI_LN_CASE(2) BOFI_LN_CASE(4) BOFI_LN_CASE(8) BOFI_LN_CASE(12) BOFI_LN_CASE(16) BOFI_LN_CASE(32)
+#undef BOFI_LN_CASE
+        default: return BOFI_ERR_ARG;
+    }
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+int launch_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows, int d,
+                     hipStream_t st) {
+    if (!x || !gain || !bias || !y || rows < 0 || d <= 0 || d % 64) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    if (y_dtype == BOFI_DT_F32) return launch_ln_t<float>(x, gain, bias, (float*)y, rows, d, st);
+    if (y_dtype == BOFI_DT_BF16) return launch_ln_t<bf16_t>(x, gain, bias, (bf16_t*)y, rows, d, st);
+    return BOFI_ERR_ARG;
+}
+
+}  // namespace bofi
+
+extern "C" int bofi_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows,
+                              int d, void* stream) {
+    return bofi::launch_layernorm(x, gain, bias, y, y_dtype, rows, d, (hipStream_t)stream);
+}

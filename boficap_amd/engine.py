@@ -1,0 +1,113 @@
+"""Python handle on the C++/HIP decode engine (``bofi_engine_*`` in include/boficap_hip.h).
+
+One engine = one model replica's packed weights + workspace in the HBM of the current device.
+PyTorch is only used here to own device buffers and to name the HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import hip
+from .config import BofiConfig
+
+
+class BofiEngine:
+    def __init__(self, cfg: BofiConfig, dtype: torch.dtype = torch.bfloat16, max_batch: int = 64,
+                 max_regions: int = 36, device: Optional[torch.device] = None):
+        cfg.validate()
+        if cfg.d_k != 64:
+            raise hip.BofiHipError("the HIP attention kernel is specialised for head dim 64 (d_model / num_att_heads)")
+        if not torch.cuda.is_available():
+            raise hip.BofiHipError("no HIP device: the decode engine has no CPU fallback")
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.max_batch, self.max_regions = max_batch, max_regions
+        self._lib = hip.lib()
+        c = hip.BofiConfigC(
+            vocab=cfg.tgt_vocab, feat=cfg.att_feat_size, d_model=cfg.d_model, d_ff=cfg.d_ff, heads=cfg.h,
+            n_enc=cfg.N_enc, n_dec=cfg.N_dec, seq_length=cfg.seq_length, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx,
+            eos_idx=cfg.eos_idx, len_idx=cfg.len_idx, head_hidden=cfg.head_hidden, max_batch=max_batch,
+            max_regions=max_regions, dtype={torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[dtype])
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            hip.check(self._lib.bofi_engine_create(C.byref(c), C.byref(self._h)), "bofi_engine_create")
+        self._finalized = False
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.bofi_engine_destroy(h)
+            except Exception:
+                pass
+
+    # ---------------------------------------------------------------- weights
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        """``sd``: reference-schema state dict (torch tensors on any device, or numpy arrays)."""
+        for name, v in sd.items():
+            a = v.detach().to("cpu", torch.float32).contiguous().numpy() if torch.is_tensor(v) else np.ascontiguousarray(v, np.float32)
+            hip.check(self._lib.bofi_engine_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size),
+                      f"set_weight({name})")
+        with torch.cuda.device(self.device):
+            hip.check(self._lib.bofi_engine_finalize(self._h), "bofi_engine_finalize")
+        self._finalized = True
+
+    # ---------------------------------------------------------------- calls
+    def _check_feats(self, att_feats, att_len):
+        if att_feats.dim() != 3 or att_feats.size(2) != self.cfg.att_feat_size:
+            raise hip.BofiHipError(f"att_feats must be [B, R, {self.cfg.att_feat_size}], got {tuple(att_feats.shape)}")
+        if not att_feats.is_cuda or not att_feats.is_contiguous():
+            raise hip.BofiHipError("att_feats must be a contiguous tensor on the HIP device")
+        if att_len is not None and (att_len.dtype != torch.int32 or not att_len.is_cuda or att_len.numel() != att_feats.size(0)):
+            raise hip.BofiHipError("att_len must be an int32 device tensor of B elements")
+
+    def decode_naic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, strict_q1: bool = True,
+                    want_logprob: bool = True, want_memory: bool = False, raw_logits: bool = False, graph: bool = False,
+                    out: Optional[dict] = None) -> dict:
+        """Greedy NAIC bound+fill decode.  Returns a dict of device tensors: seq [B,S] int64,
+        seq_logprob [B,S,V] float32 (or None), phrase_num [B] int32, phrase_length [B,S] int32,
+        phrase_syn [B,S] int64, bound_iters [1] int32, memory [B,R,d] float32 (or None).
+        Pass the previous result as ``out`` to reuse its buffers (required for graph replay)."""
+        self._check_feats(att_feats, att_len)
+        B, R, _ = att_feats.shape
+        S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
+        if out is None:
+            out = dict(
+                seq=torch.empty(B, S, dtype=torch.int64, device=dev),
+                seq_logprob=torch.empty(B, S, V, dtype=torch.float32, device=dev) if want_logprob else None,
+                phrase_num=torch.empty(B, dtype=torch.int32, device=dev),
+                phrase_length=torch.empty(B, S, dtype=torch.int32, device=dev),
+                phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
+                bound_iters=torch.empty(1, dtype=torch.int32, device=dev),
+                memory=torch.empty(B, R, self.cfg.d_model, dtype=torch.float32, device=dev) if want_memory else None)
+        flags = (hip.FLAG_STRICT_Q1 if strict_q1 else 0) | (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0)
+        hip.check(self._lib.bofi_engine_decode_naic(
+            self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, flags, hip.ptr(out["seq"]),
+            hip.ptr(out["seq_logprob"]), hip.ptr(out["phrase_num"]), hip.ptr(out["phrase_length"]), hip.ptr(out["phrase_syn"]),
+            hip.ptr(out["memory"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_naic")
+        return out
+
+    def encode(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Encoder output (float32 [B, R, d]); also leaves memory + cross K/V in the engine workspace."""
+        self._check_feats(att_feats, att_len)
+        B, R, _ = att_feats.shape
+        mem = torch.empty(B, R, self.cfg.d_model, dtype=torch.float32, device=att_feats.device)
+        hip.check(self._lib.bofi_engine_encode(self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R,
+                                               hip.ptr(mem), hip.stream_ptr()), "bofi_engine_encode")
+        return mem
+
+    def bound_step(self, ext_syn: torch.Tensor, last: torch.Tensor, R: int, att_len: Optional[torch.Tensor] = None):
+        """One bounding step on the memory of the preceding ``encode``: (len_logp [B,20], syn_logp [B,10])."""
+        B = ext_syn.size(0)
+        if ext_syn.dtype != torch.int32 or last.dtype != torch.int32 or ext_syn.size(1) != self.cfg.bound_len:
+            raise hip.BofiHipError("ext_syn must be int32 [B, S+2] and last int32 [B]")
+        llp = torch.empty(B, 20, dtype=torch.float32, device=ext_syn.device)
+        slp = torch.empty(B, 10, dtype=torch.float32, device=ext_syn.device)
+        hip.check(self._lib.bofi_engine_bound_step(self._h, hip.ptr(ext_syn.contiguous()), hip.ptr(last.contiguous()), B, R,
+                                                   hip.ptr(att_len), hip.ptr(llp), hip.ptr(slp), hip.stream_ptr()), "bofi_engine_bound_step")
+        return llp, slp

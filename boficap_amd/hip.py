@@ -1,0 +1,91 @@
+"""ctypes binding of libboficap_hip.so (C ABI: include/boficap_hip.h).
+
+The HIP library is the product path.  There is no CPU fallback: importing this module without the
+built library raises, and every non-zero status from the library raises ``BofiHipError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libboficap_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
+ABI_VERSION = 1
+
+
+class BofiHipError(RuntimeError):
+    pass
+
+
+class BofiConfigC(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "vocab", "feat", "d_model", "d_ff", "heads", "n_enc", "n_dec", "seq_length",
+        "pad_idx", "bos_idx", "eos_idx", "len_idx", "head_hidden", "max_batch", "max_regions", "dtype")]
+
+
+_P, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/boficap_hip.h one to one
+SIGNATURES = {
+    "bofi_abi_version": (_I, []),
+    "bofi_last_error": (C.c_char_p, []),
+    "bofi_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "bofi_linear": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "bofi_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "bofi_vocab_finalize": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
+    "bofi_engine_destroy": (None, [_P]),
+    "bofi_engine_set_weight": (_I, [_P, C.c_char_p, _P, _I64]),
+    "bofi_engine_finalize": (_I, [_P]),
+    "bofi_engine_decode_naic": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "bofi_engine_encode": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "bofi_engine_bound_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python -m boficap_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BofiHipError(
+                f"{LIB_PATH} is missing: build it with `python -m boficap_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the decode path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if l.bofi_abi_version() != ABI_VERSION:
+            raise BofiHipError(f"ABI version {l.bofi_abi_version()} != binding version {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().bofi_last_error()
+        raise BofiHipError(f"{what or 'libboficap_hip'}: status {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def dtype_code(t) -> int:
+    import torch
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise BofiHipError(f"unsupported dtype {t.dtype}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

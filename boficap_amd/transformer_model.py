@@ -1,0 +1,167 @@
+"""Drop-in module for the reference's ``captioning.models.TransformerModel`` (UIC bound+fill model).
+
+Contract mirrored from the reference:
+  * ``TransformerModel(opt)`` reads the same ``opt`` attributes (AttModel.py:56-79,
+    TransformerModel.py:1631-1640) and exposes ``vocab, seq_length, ss_prob, d_model, train_mode``;
+  * ``state_dict()`` has the reference's 311 entries, same names / shapes / order, so a
+    ``model.pth`` written by either side loads into the other with ``strict=True``;
+  * ``model(*args, mode='sample'|'forward', **kw)`` dispatches to ``_sample`` / ``_forward``
+    (CaptionModel.py:42-46); ``_sample`` returns the reference's 6-tuple (AttModel.py:429).
+The arithmetic runs in libboficap_hip.so (HIP, gfx950).  This class holds no torch compute for the
+decode path and refuses to run without the HIP library and a HIP device.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .config import BofiConfig
+from .weights import schema
+
+bad_endings = ['a', 'an', 'the', 'in', 'for', 'at', 'of', 'with', 'before', 'after', 'on', 'upon', 'near', 'to', 'is', 'are', 'am', 'the']
+
+
+def _build_param_tree(root: nn.Module, cfg: BofiConfig) -> None:
+    """Register parameters/buffers under the reference's dotted names, in the reference's order."""
+    for name, shape in schema(cfg).items():
+        parts = name.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        if name == "model.pos_embed.pe":
+            mod.register_buffer(parts[-1], torch.zeros(shape))
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape)))
+
+
+class TransformerModel(nn.Module):
+    def __init__(self, opt, *, compute_dtype: Optional[torch.dtype] = None, max_batch: Optional[int] = None,
+                 max_regions: Optional[int] = None, strict_reference: bool = True):
+        super().__init__()
+        self.opt = opt
+        self.cfg = BofiConfig.from_opt(opt)
+        cfg = self.cfg
+        # attributes callers read (tools/train.py:100,162; utils/misc.py:250; eval_utils.py)
+        self.vocab_size, self.tgt_vocab = cfg.vocab_size, cfg.tgt_vocab
+        self.seq_length, self.max_length = cfg.seq_length, cfg.seq_length
+        self.d_model, self.d_ff, self.h = cfg.d_model, cfg.d_ff, cfg.h
+        self.N_enc, self.N_dec, self.N_len = cfg.N_enc, cfg.N_dec, cfg.N_len
+        self.train_mode = cfg.train_mode
+        self.pad_idx, self.bos_idx, self.eos_idx, self.len_idx = cfg.pad_idx, cfg.bos_idx, cfg.eos_idx, cfg.len_idx
+        self.ss_prob = 0.0
+        self.vocab = opt.vocab
+        self.bad_endings_ix = [int(k) for k, v in self.vocab.items() if v in bad_endings]
+        # engine knobs (not part of the reference's opt; read with defaults so a reference opt works)
+        self.compute_dtype = compute_dtype or getattr(opt, "bofi_compute_dtype", torch.float32)
+        self.max_batch = max_batch or getattr(opt, "bofi_max_batch", 64)
+        self.max_regions = max_regions or getattr(opt, "bofi_max_regions", getattr(opt, "max_boxes", 100))
+        self.strict_reference = strict_reference       # reproduce quirk Q1 (TransformerModel.py:1872-1873)
+        _build_param_tree(self, cfg)
+        self.reset_parameters()
+        self._engine = None
+        self._engine_key = None
+
+    # ------------------------------------------------------------------ init / weights
+    def reset_parameters(self) -> None:
+        """Glorot for matrices (TransformerModel.py:1621-1623), nn.Linear-style biases, LN (1, 0)."""
+        from .weights import positional_table
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith(".a_2"):
+                    p.fill_(1.0)
+                elif name.endswith(".b_2"):
+                    p.zero_()
+                elif p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+                else:
+                    fan_in = dict(self.named_parameters())[name[:-4] + "weight"].shape[1]
+                    bound = 1.0 / fan_in ** 0.5
+                    p.uniform_(-bound, bound)
+            self.model.pos_embed.pe.copy_(torch.from_numpy(positional_table(self.cfg.max_pe, self.cfg.d_model)))
+
+    def _weights_key(self):
+        return (sum(p._version for p in self.parameters()), self.compute_dtype, self.max_batch, self.max_regions,
+                next(self.parameters()).device)
+
+    def engine(self):
+        """The HIP engine holding this module's current weights (rebuilt when they change)."""
+        from .engine import BofiEngine
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise hip.BofiHipError("the model must be on a HIP device (model.cuda()); there is no CPU decode path")
+        key = self._weights_key()
+        if self._engine is None or self._engine_key != key:
+            if self._engine is None or self._engine_key[1:] != key[1:]:
+                self._engine = BofiEngine(self.cfg, self.compute_dtype, self.max_batch, self.max_regions, device=dev)
+            self._engine.load_state_dict(self.state_dict())
+            self._engine_key = key
+        return self._engine
+
+    # ------------------------------------------------------------------ reference call convention
+    def forward(self, *args, **kwargs):
+        mode = kwargs.pop("mode", "forward")                      # CaptionModel.py:42-46
+        return getattr(self, "_" + mode)(*args, **kwargs)
+
+    @staticmethod
+    def _att_len(att_masks):
+        return None if att_masks is None else att_masks.long().sum(1).to(torch.int32).contiguous()
+
+    def _prepare_feature(self, fc_feats, att_feats, att_masks):
+        """TransformerModel.py:1674-1679: (fc[...,:0], att[...,:0], memory, att_masks[B,1,R])."""
+        eng = self.engine()
+        if att_masks is not None:                                 # clip_att, AttModel.py:113-120
+            max_len = int(att_masks.long().sum(1).max())
+            att_feats = att_feats[:, :max_len].contiguous()
+            att_masks = att_masks[:, :max_len].contiguous()
+        memory = eng.encode(self._as_input(att_feats), self._att_len(att_masks))
+        if att_masks is None:
+            att_masks = torch.ones(att_feats.shape[:2], dtype=torch.bool, device=att_feats.device)
+        return fc_feats[..., :0], att_feats[..., :0], memory, att_masks.unsqueeze(-2)
+
+    def _as_input(self, att_feats):
+        if att_feats.dtype not in (torch.float32, self.compute_dtype):
+            att_feats = att_feats.float()
+        return att_feats.contiguous()
+
+    def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
+        """AttModel.py:307-338, 419-429 for train_mode 'NAIC' (the bound+fill decode)."""
+        sample_method = opt.get("sample_method", "greedy")
+        beam_size = opt.get("beam_size", 1)
+        sample_n = int(opt.get("sample_n", 1))
+        group_size = opt.get("group_size", 1)
+        output_logsoftmax = opt.get("output_logsoftmax", 1)
+        train_mode = opt.get("train_mode", "AIC")
+        if beam_size > 1 or group_size > 1:
+            raise NotImplementedError("beam / diverse sampling are AR-only host-side paths (out of scope, SURVEY.md §2 row 10)")
+        if train_mode != "NAIC":
+            raise NotImplementedError(f"inference mode {train_mode!r}: only 'NAIC' (bound+fill) is built so far")
+        if sample_method != "greedy":
+            raise NotImplementedError(f"sample_method {sample_method!r}: only greedy decode is built so far")
+        eng = self.engine()
+        torch.cuda.synchronize()                                  # the reference does (AttModel.py:337)
+        start = time.time()
+        r = eng.decode_naic(self._as_input(att_feats), self._att_len(att_masks), strict_q1=self.strict_reference,
+                            raw_logits=not output_logsoftmax)
+        torch.cuda.synchronize()
+        end = time.time()
+        outs = [r["seq"], r["seq_logprob"], r["phrase_num"], r["phrase_length"], r["phrase_syn"]]
+        if sample_n > 1:                                          # greedy: n identical copies (models/utils.py:3-14)
+            outs = [o.repeat_interleave(sample_n, dim=0) for o in outs]
+        return (*outs, end - start)
+
+    def _forward(self, *args, **kwargs):
+        raise NotImplementedError("the XE training forward (TransformerModel.py:1713-1775) is the next row of the "
+                                  "scope table; this round builds the NAIC decode path")
+
+
+def setup(opt):
+    """captioning/models/__init__.py:14-24."""
+    if getattr(opt, "caption_model", "transformer") != "transformer":
+        raise Exception("Caption model not supported: {}".format(opt.caption_model))
+    return TransformerModel(opt)

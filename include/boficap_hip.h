@@ -1,0 +1,151 @@
+/*
+ * boficap_hip.h -- C ABI of libboficap_hip.so, the MI355X (gfx950) implementation of BoFiCap's
+ * bound+fill caption decoder hot path.
+ *
+ * The reference (ChangxinWang/BoFiCap) is pure Python/PyTorch and has no FFI layer; its hot path
+ * is a chain of stock torch ops.  Each entry point below therefore names the reference function
+ * (file:line under /root/reference) whose arithmetic it replaces.  All pointers are DEVICE
+ * pointers unless a name ends in _host; all sizes are element counts; `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  Every function returns 0 on success and a
+ * BOFI_ERR_* code otherwise; nothing here allocates or synchronises except the engine
+ * constructor/finaliser.  Thread-safety: one engine per host thread / per GPU process (the
+ * reference is single-threaded per replica, tools/train.py:99-101).
+ *
+ * dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit).  "compute dtype" is the type GEMM and
+ * attention operands are held in; accumulation, softmax, LayerNorm statistics and the residual
+ * stream are always float32.
+ */
+#ifndef BOFICAP_HIP_H
+#define BOFICAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BOFI_OK 0
+#define BOFI_ERR_ARG 1    /* bad shape / dtype / NULL pointer */
+#define BOFI_ERR_HIP 2    /* a HIP runtime call failed */
+#define BOFI_ERR_STATE 3  /* engine used before finalize, missing weight, ... */
+
+#define BOFI_DT_F32 0
+#define BOFI_DT_BF16 1
+
+/* version of this ABI; bumped on any signature change */
+int bofi_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operator level (stateless).  Used by the engine and by the per-kernel parity tests.
+ * ------------------------------------------------------------------------------------------- */
+
+/* BoFiCap LayerNorm: y = gain * (x - mean) / (std_unbiased + 1e-6) + bias, per row.
+ * Replaces captioning/models/TransformerModel.py:1346-1349 (NOT nn.LayerNorm: N-1 variance, eps
+ * added to std).  x: float32 [rows, d];  y: y_dtype [rows, d];  d % 64 == 0, d <= 2048. */
+int bofi_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype,
+                   int rows, int d, void* stream);
+
+/* y = act(x . w^T + bias) [+ residual], the nn.Linear of TransformerModel.py:1454-1456,1467
+ * (attention projections), :1477-1478 (FFN), :1642-1645 (att_embed Linear+ReLU), :1316-1319
+ * (generator.proj).
+ *   x: x_dtype [M, K] row stride ldx (x_dtype = w_dtype, or float32 converted on load)
+ *   w: w_dtype [N, K] contiguous (the nn.Linear weight as stored);  bias: float32 [N] or NULL
+ *   residual: float32 [M, N] row stride ldr or NULL, added AFTER bias/activation
+ *             (SublayerConnection, TransformerModel.py:1361-1363)
+ *   y: y_dtype [M, N] row stride ldy (float32 or w_dtype)
+ *   relu: 0/1.   row_len/rows_per_group: if row_len != NULL, output row m is forced to exact 0
+ *   when (m % rows_per_group) >= row_len[m / rows_per_group]  (pack_padded/pad_packed semantics of
+ *   AttModel.py:46-51).   K % 64 == 0 for bf16, K % 32 == 0 for float32. */
+int bofi_linear(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias,
+                const float* residual, int ldr, void* y, int y_dtype, int ldy, int M, int N, int K,
+                int relu, const int* row_len, int rows_per_group, void* stream);
+
+/* Multi-head scaled-dot-product attention core, softmax(q k^T / sqrt(64) masked) v, head dim 64.
+ * Replaces attention() TransformerModel.py:1421-1432 for prefix-structured masks: query row i of
+ * batch item b may attend keys j < klen[b*klen_sb + i*klen_sq] (every mask the reference builds
+ * for this path has that form).  A row with klen 0 yields NaN like the reference's
+ * softmax over all -inf.  klen == NULL means all Lk keys.
+ *   q: dtype, row (b,i) at q + (b*Lq+i)*ldq, head h at column h*64;  k, v likewise with Lk, ldk, ldv
+ *   out: dtype [B*Lq, H*64] row stride ldo.    Lq, Lk <= 128. */
+int bofi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
+                   int ldo, int dtype, int B, int H, int Lq, int Lk, const int* klen, int klen_sb,
+                   int klen_sq, void* stream);
+
+/* log_softmax over the vocabulary + greedy pick + pad-after-length, one row per (image, position).
+ * Replaces F.log_softmax(self.logit(phrase), dim=2) AttModel.py:206-207, torch.max(logprobs, 2)
+ * CaptionModel.py:388-390 (first maximal index; a NaN wins and the first NaN is returned, as
+ * torch.max does on CPU) and seq[b, sum(phrase_length[b]):] = pad AttModel.py:422-423.
+ *   logits: float32 [rows, V], overwritten in place with log-probabilities when log_softmax != 0
+ *   ntok: int32 [rows / S] valid token count per image or NULL;  seq: int64 [rows]. */
+int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok,
+                        int pad_idx, int64_t* seq, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine level: the whole NAIC bound+fill decode as one call.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct bofi_engine bofi_engine_t;
+
+typedef struct bofi_config {
+    int vocab;        /* tgt_vocab = vocab_size + 4 (AttModel.py:79) */
+    int feat;         /* att_feat_size (2048) */
+    int d_model;      /* 512; d_model / heads must be 64 */
+    int d_ff;         /* 2048 */
+    int heads;        /* 8 */
+    int n_enc;        /* 6 */
+    int n_dec;        /* 6 */
+    int seq_length;   /* 20 (S); the bound sequence has S+2 positions */
+    int pad_idx, bos_idx, eos_idx, len_idx;   /* 0 1 2 3 */
+    int head_hidden;  /* 100: width of Length/Syntactic_classifier1 */
+    int max_batch;    /* workspace is sized for this many images per call */
+    int max_regions;  /* and this many regions per image (<= 128) */
+    int dtype;        /* compute dtype: BOFI_DT_F32 (parity) or BOFI_DT_BF16 (throughput) */
+} bofi_config_t;
+
+/* Allocates device weights + workspace for one model replica on the current HIP device. */
+int bofi_engine_create(const bofi_config_t* cfg, bofi_engine_t** out);
+void bofi_engine_destroy(bofi_engine_t* e);
+
+/* Hands the engine one state_dict entry by its reference name (the 311-key schema of
+ * TransformerModel.state_dict()), float32 on the HOST.  The engine keeps a copy. */
+int bofi_engine_set_weight(bofi_engine_t* e, const char* name, const float* data_host, int64_t numel);
+
+/* Packs/convert the weights for the kernels (fused QKV, stacked cross-attention K/V, bf16 copies)
+ * and precomputes the input-independent tables of the bound network.  Must follow the last
+ * set_weight and precede decode; may be called again after weights change.  Synchronises. */
+int bofi_engine_finalize(bofi_engine_t* e);
+
+#define BOFI_FLAG_STRICT_Q1 1      /* reproduce TransformerModel.py:1872-1873: every image's fill mask
+                                      uses the LAST image's length.  Default ON in the Python wrapper. */
+#define BOFI_FLAG_RAW_LOGITS 2     /* output_logsoftmax = 0 (AttModel.py:208-209) */
+#define BOFI_FLAG_GRAPH 4          /* replay the call from a captured hipGraph when possible */
+
+/* model(fc, att, att_masks, opt={'train_mode':'NAIC','sample_method':'greedy'}, mode='sample'):
+ * AttModel._sample AttModel.py:307-338,419-429 -> _prepare_feature TransformerModel.py:1674-1690
+ * -> Encoder :1332-1336 -> core_NAIC :1823-1876 (bound loop + decode_NA :570-587) -> logit/
+ * log_softmax AttModel.py:203-210 -> greedy pick CaptionModel.py:388-390 -> pad tail.
+ *   att_feats: feats_dtype [B, R, feat] contiguous;  att_len: int32 [B] regions per image or NULL
+ *   seq: int64 [B, S];  seq_logprob: float32 [B, S, vocab] or NULL (then only ids are produced);
+ *   phrase_num: int32 [B];  phrase_length: int32 [B, S];  phrase_syn: int64 [B, S];
+ *   memory_out: float32 [B, R, d_model] or NULL (encoder output, for _prepare_feature parity);
+ *   bound_iters: int32 [1] or NULL (number of bound iterations in which some image was active). */
+int bofi_engine_decode_naic(bofi_engine_t* e, const void* att_feats, int feats_dtype, const int* att_len,
+                            int B, int R, int flags, int64_t* seq, float* seq_logprob, int* phrase_num,
+                            int* phrase_length, int64_t* phrase_syn, float* memory_out, int* bound_iters,
+                            void* stream);
+
+/* Stages of the call above, exposed for module-level parity tests (SURVEY.md §4 pyramid level 2). */
+int bofi_engine_encode(bofi_engine_t* e, const void* att_feats, int feats_dtype, const int* att_len,
+                       int B, int R, float* memory_out, void* stream);
+/* One bound step from a given slot layout: ext_syn int32 [B, S+2], last int32 [B] ->
+ * len_logp float32 [B, 20], syn_logp float32 [B, 10] (LengthPredictor_UIC.forward
+ * TransformerModel.py:357-383 on the memory of the preceding bofi_engine_encode). */
+int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last, int B, int R,
+                           const int* att_len, float* len_logp, float* syn_logp, void* stream);
+
+/* Last HIP error string seen by this library on the calling thread (for exceptions in the host). */
+const char* bofi_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOFICAP_HIP_H */

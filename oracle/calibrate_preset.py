@@ -73,7 +73,7 @@ def row0_features(w, cfg, mem, sm, rng, n_layouts: int = 4):
 # layer's two attention output projections (makes row 0 depend more on history and image), the
 # target spread of the head logits, and the priors of the two EOS classes.
 KNOBS = {
-    "tiny": dict(attn_gain=1.0, std=1.5, len0=0.0, syn1=-2.0),
+    "tiny": dict(attn_gain=2.0, std=1.5, len0=0.8, syn1=-0.4),
     "full": dict(attn_gain=2.0, std=1.5, len0=0.8, syn1=-1.2),
 }
 

@@ -1,0 +1,161 @@
+"""Per-kernel parity on the MI355X: each C-ABI operator against the CPU oracle's restatement."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import boficap_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from boficap_amd import hip
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    hip.lib()
+    return hip
+
+
+def _rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("d", [128, 512, 2048])
+@pytest.mark.parametrize("out", ["f32", "bf16"])
+def test_layernorm(H, d, out):
+    g = _rng(1)
+    x = torch.randn(77, d, generator=g) * 3 + 0.5
+    a, b = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    ref = O.layer_norm(x, {"n.a_2": a, "n.b_2": b}, "n")
+    y = torch.empty(77, d, dtype=torch.float32 if out == "f32" else torch.bfloat16, device="cuda")
+    xc, ac, bc = x.cuda(), a.cuda(), b.cuda()            # keep the device copies alive across the launch
+    H.check(H.lib().bofi_layernorm(H.ptr(xc), H.ptr(ac), H.ptr(bc), H.ptr(y), H.dtype_code(y), 77, d, H.stream_ptr()))
+    torch.cuda.synchronize()
+    if out == "f32":
+        assert (y.cpu() - ref).abs().max() < 2e-5
+    else:
+        assert torch.equal(y.cpu().float(), _bf(ref)) or (y.cpu().float() - _bf(ref)).abs().max() < 4e-2  # 1 bf16 ulp at |x|<8
+
+
+def _linear(H, x, w, bias, residual, y_dtype, relu=0, row_len=None, rpg=0, ldr=None):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=y_dtype, device="cuda")
+    H.check(H.lib().bofi_linear(H.ptr(x), H.dtype_code(x), K, H.ptr(w), H.dtype_code(w), H.ptr(bias), H.ptr(residual),
+                                (N if ldr is None else ldr), H.ptr(y), H.dtype_code(y), N, M, N, K, relu, H.ptr(row_len), rpg, H.stream_ptr()))
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", [(2304, 512, 2048), (1280, 1536, 512), (64, 512, 512), (64, 2048, 512), (130, 9491, 512),
+                                   (1, 512, 512), (300, 100, 128), (72, 64, 64)])
+def test_linear_f32(H, M, N, K):
+    g = _rng(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = r + torch.relu(torch.nn.functional.linear(x.double(), w.double(), b.double())).float()
+    y = _linear(H, x.cuda(), w.cuda(), b.cuda(), r.cuda(), torch.float32, relu=1)
+    assert (y.cpu() - ref).abs().max() < 2e-5 * math.sqrt(K)
+    # exact-zero rows past each group's length, no bias/residual
+    lens = torch.tensor([(i * 7 + 5) % 37 for i in range((M + 35) // 36)], dtype=torch.int32)
+    y = _linear(H, x.cuda(), w.cuda(), None, None, torch.float32, row_len=lens.cuda(), rpg=36)
+    ref = torch.nn.functional.linear(x, w)
+    keep = (torch.arange(M) % 36) < lens[torch.arange(M) // 36]
+    assert (y.cpu()[~keep] == 0).all()
+    assert (y.cpu()[keep] - ref[keep]).abs().max() < 2e-5 * math.sqrt(K)
+
+
+@pytest.mark.parametrize("M,N,K", [(2304, 512, 2048), (1280, 2048, 512), (64, 512, 2048), (130, 9491, 512), (50, 96, 128)])
+@pytest.mark.parametrize("xdt", ["bf16", "f32"])
+def test_linear_bf16(H, M, N, K, xdt):
+    g = _rng(M * 3 + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = (r.double() + torch.nn.functional.linear(_bf(x).double(), _bf(w).double(), b.double())).float()
+    xin = x.cuda().to(torch.bfloat16) if xdt == "bf16" else x.cuda()
+    y = _linear(H, xin, w.cuda().to(torch.bfloat16), b.cuda(), r.cuda(), torch.float32)
+    assert (y.cpu() - ref).abs().max() < 1e-4 * math.sqrt(K)          # fp32 accumulation of exact bf16 products
+    yb = _linear(H, xin, w.cuda().to(torch.bfloat16), b.cuda(), None, torch.bfloat16, relu=1)
+    refb = torch.relu(ref - r)
+    assert (yb.cpu().float() - refb).abs().max() < 0.02 * max(1.0, float(refb.abs().max()))
+
+
+def test_linear_broadcast_residual(H):
+    g = _rng(5)
+    x, w, r = torch.randn(64, 512, generator=g), torch.randn(512, 512, generator=g) / 22, torch.randn(512, generator=g)
+    y = _linear(H, x.cuda(), w.cuda(), None, r.cuda(), torch.float32, ldr=0)
+    assert (y.cpu() - (r[None] + x @ w.T)).abs().max() < 1e-3
+
+
+def _attention_ref(q, k, v, klen, h):
+    """oracle attention() core on already-projected q/k/v, dense mask from per-row prefix lengths"""
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    mask = torch.arange(Lk)[None, None, :] < klen[:, :, None]
+    qh, kh, vh = (t.view(B, -1, h, 64).transpose(1, 2) for t in (q, k, v))
+    s = torch.matmul(qh, kh.transpose(-2, -1)) / math.sqrt(64)
+    s = s.masked_fill(mask.unsqueeze(1) == 0, float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), vh).transpose(1, 2).reshape(B, Lq, d)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,h,Lq,Lk", [(5, 8, 36, 36), (3, 8, 20, 20), (4, 2, 22, 22), (6, 8, 20, 36), (7, 8, 1, 36), (2, 8, 100, 100), (2, 4, 20, 90)])
+def test_attention(H, dt, B, h, Lq, Lk):
+    g = _rng(B * 100 + Lq + Lk)
+    d = h * 64
+    q, k, v = (torch.randn(B, L, d, generator=g) for L in (Lq, Lk, Lk))
+    klen = torch.randint(1, Lk + 1, (B, Lq), generator=g).to(torch.int32)
+    klen[0, 0] = 0                                     # fully masked row -> NaN like softmax(all -inf)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    if dt == "bf16":
+        q, k, v = _bf(q), _bf(k), _bf(v)
+    ref = _attention_ref(q, k, v, klen.long(), h)
+    out = torch.empty(B, Lq, d, dtype=tdt, device="cuda")
+    qc, kc, vc = (t.cuda().to(tdt).contiguous() for t in (q, k, v))
+    klc = klen.cuda()
+    H.check(H.lib().bofi_attention(H.ptr(qc), d, H.ptr(kc), d, H.ptr(vc), d, H.ptr(out), d, H.dtype_code(out), B, h, Lq, Lk,
+                                   H.ptr(klc), Lq, 1, H.stream_ptr()))
+    torch.cuda.synchronize()
+    o = out.cpu().float()
+    assert torch.isnan(o[0, 0]).all() and torch.isnan(ref[0, 0]).all()
+    o[0, 0], ref[0, 0] = 0, 0
+    assert not torch.isnan(o).any()
+    assert (o - ref).abs().max() < (2e-5 if dt == "f32" else 3e-2)
+
+
+def test_vocab_finalize(H):
+    g = _rng(9)
+    S, V, B = 20, 9491, 3
+    lg = torch.randn(B * S, V, generator=g) * 3
+    lg[5, 100] = lg[5, 7000] = lg[5].max() + 1.0           # tie: the lower index must win
+    lg[7, 33] = float("nan")                                 # NaN row: index 0 after log_softmax
+    lg[9, :] = float("-inf"); lg[9, 1234] = 0.5              # one finite entry
+    ntok = torch.tensor([20, 4, 0], dtype=torch.int32)
+    ref_lp = torch.log_softmax(lg, dim=1)
+    ref_id = torch.max(ref_lp, 1)[1]
+    for b in range(B):
+        ref_id[b * S + int(ntok[b]):(b + 1) * S] = 0
+    x = lg.clone().cuda()
+    seq = torch.empty(B * S, dtype=torch.int64, device="cuda")
+    ntc = ntok.cuda()
+    H.check(H.lib().bofi_vocab_finalize(H.ptr(x), B * S, V, S, 1, H.ptr(ntc), 0, H.ptr(seq), H.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(seq.cpu(), ref_id)
+    assert ref_id[5] == 100 and ref_id[7] == 0
+    got = x.cpu()
+    assert torch.isnan(got[7]).all()
+    m = ~torch.isnan(ref_lp) & ~torch.isinf(ref_lp)
+    assert (got[m] - ref_lp[m]).abs().max() < 2e-5
+    assert (got[9][torch.isinf(ref_lp[9])] == float("-inf")).all()
+    # raw-logit mode: values untouched, first NaN index returned
+    x = lg.clone().cuda()
+    H.check(H.lib().bofi_vocab_finalize(H.ptr(x), B * S, V, S, 0, None, 0, H.ptr(seq), H.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu()[~torch.isnan(lg)], lg[~torch.isnan(lg)])
+    assert seq[7].item() == 33 and seq[5].item() == 100

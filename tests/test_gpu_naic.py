@@ -1,0 +1,175 @@
+"""End-to-end NAIC bound+fill parity on the MI355X through the C ABI / the drop-in module."""
+import numpy as np
+import pytest
+import torch
+
+import boficap_oracle as O
+from conftest import TINY_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines(weight_cache, manifest):
+    from boficap_amd.engine import BofiEngine
+    cache = {}
+
+    def get(case, dtype, max_batch=64):
+        m = manifest[case]
+        key = (m["config"], m["seed"], m["gen_scale"], dtype, max_batch)
+        if key not in cache:
+            cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+            e = BofiEngine(cfg, dtype, max_batch=max_batch, max_regions=36)
+            e.load_state_dict(sd)
+            cache[key] = (cfg, sd, e)
+        return cache[key]
+    return get
+
+
+def _inputs(g, device="cuda"):
+    att = torch.from_numpy(g["att_feats"]).to(device)
+    att_len = torch.from_numpy(g["att_masks"]).sum(1).to(torch.int32).to(device) if "att_masks" in g else None
+    return att, att_len
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert a.shape == b.shape
+    assert (np.isnan(a) == np.isnan(b)).all(), "NaN pattern differs"
+    m = ~np.isnan(a) & ~np.isinf(a)
+    return float(np.abs(a[m] - b[m]).max()) if m.any() else 0.0
+
+
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_golden_tiny_f32(name, engines):
+    """fp32 engine vs vectors recorded from the reference: ids and slots bit-exact, logits <= 1e-3."""
+    cfg, sd, eng = engines(name, torch.float32)
+    g = load_golden(name)
+    att, att_len = _inputs(g)
+    mem = eng.encode(att, att_len)
+    R = g["memory"].shape[1]                            # the reference clips to the longest image
+    assert _close(mem.cpu().numpy()[:, :R], g["memory"], 0) < 1e-4
+    B = att.size(0)
+    ext = torch.zeros(B, cfg.bound_len, dtype=torch.int32, device="cuda"); ext[:, 0] = cfg.len_idx
+    last = torch.ones(B, dtype=torch.int32, device="cuda")
+    llp, slp = eng.bound_step(ext, last, att.size(1), att_len)
+    assert _close(llp.cpu().numpy(), g["step0_len_logp"], 0) < 1e-4
+    assert _close(slp.cpu().numpy(), g["step0_syn_logp"], 0) < 1e-4
+    for graph in (False, True, True):
+        r = eng.decode_naic(att, att_len, graph=graph, out=None if not graph else r)
+        torch.cuda.synchronize()
+        assert (r["phrase_num"].cpu().numpy() == g["naic_phrase_num"]).all()
+        assert (r["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all()
+        assert (r["phrase_syn"].cpu().numpy() == g["naic_phrase_syn"]).all()
+        assert (r["seq"].cpu().numpy() == g["naic_seq"]).all()
+        assert int(r["bound_iters"]) == int(g["naic_iters"])
+        assert _close(r["seq_logprob"].cpu().numpy(), g["naic_logprob"], 0) < 1e-3
+        assert r["seq"].dtype == torch.int64 and r["phrase_num"].dtype == torch.int32
+        assert r["phrase_length"].dtype == torch.int32 and r["phrase_syn"].dtype == torch.int64
+
+
+def test_golden_full_f32(engines, manifest):
+    from boficap_amd import weights as W
+    cfg, sd, eng = engines("full_b8", torch.float32)
+    m, g = manifest["full_b8"], load_golden("full_b8")
+    att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
+    r = eng.decode_naic(att, want_memory=True)
+    torch.cuda.synchronize()
+    assert _close(r["memory"].cpu().numpy()[:2], g["memory"], 0) < 1e-4
+    assert (r["phrase_num"].cpu().numpy() == g["naic_phrase_num"]).all()
+    assert (r["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all()
+    assert (r["phrase_syn"].cpu().numpy() == g["naic_phrase_syn"]).all()
+    assert (r["seq"].cpu().numpy() == g["naic_seq"]).all()
+    lp = r["seq_logprob"].cpu()
+    assert _close(lp[:2, :3].numpy(), g["naic_logprob_rows"], 0) < 1e-3
+    top = torch.topk(lp, 2, dim=2)
+    assert _close(top[0].numpy(), g["naic_top2_val"], 0) < 1e-3
+
+
+@pytest.mark.parametrize("config_name,tol", [("FULL", 2e-2), ("TINY", 6e-2)])
+def test_bf16_within_tolerance(config_name, tol, weight_cache):
+    """bf16 engine vs the fp32 CPU oracle, natural (Xavier) generator scale.
+
+    north_star: logits within 2e-2 for bf16.  That figure is for the reference-sized model, whose
+    logits have std 0.33; the TINY model's logits have std 1.37 (4.1x), hence its 6e-2.
+    bf16 rounding can flip a near-tie in the bounding pass, which changes that image's slot
+    layout; with the per-row fill mask (strict_q1=False / fix_q1) images are independent, so the
+    logits are compared on the images whose layout agrees and the agreement rate is bounded."""
+    from boficap_amd import weights as W
+    from boficap_amd.engine import BofiEngine
+    cfg, sd = weight_cache(config_name, 0, 1.0)
+    w = O.as_torch(sd)
+    B = 32
+    att_np = W.synthetic_att_feats(B, 36, cfg.att_feat_size, seed=99)
+    oseq, olp, opn, opl, ops, _ = O.sample_naic(w, cfg, torch.from_numpy(att_np), fix_q1=True)
+    eng = BofiEngine(cfg, torch.bfloat16, max_batch=B, max_regions=36)
+    eng.load_state_dict(sd)
+    for feats in (torch.from_numpy(att_np).cuda(), torch.from_numpy(att_np).cuda().to(torch.bfloat16)):
+        r = eng.decode_naic(feats, strict_q1=False, want_memory=True)
+        torch.cuda.synchronize()
+        same = (r["phrase_length"].cpu() == opl).all(1) & (r["phrase_syn"].cpu() == ops).all(1)
+        assert int(same.sum()) >= 0.7 * B, f"only {int(same.sum())}/{B} slot layouts survive bf16"
+        lp = r["seq_logprob"].cpu()
+        assert torch.equal(lp[same].isnan(), olp[same].isnan())
+        err = float((lp[same] - olp[same]).nan_to_num().abs().max())
+        assert err < tol, err
+        agree = float((r["seq"].cpu()[same] == oseq[same]).float().mean())
+        assert agree > 0.95, agree
+
+
+def test_full_batch_properties(engines, weight_cache):
+    """B = 64 at the benchmark shape: oracle parity on the slots, and size-independent properties:
+    idempotence, graph == eager, per-image determinism of the bounding pass (Q2) and, with the
+    Q1 fix, batch-composition independence of the ids."""
+    from boficap_amd import weights as W
+    cfg, sd, eng = engines("full_b8", torch.float32)
+    att_np = W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=77)
+    att = torch.from_numpy(att_np).cuda()
+    a = eng.decode_naic(att)
+    b = eng.decode_naic(att, graph=True)
+    c = eng.decode_naic(att, graph=True, out=b)
+    torch.cuda.synchronize()
+    for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k])
+    assert torch.equal(a["seq_logprob"].isnan(), b["seq_logprob"].isnan())
+    assert (a["seq_logprob"] - b["seq_logprob"]).nan_to_num().abs().max() == 0
+    # slots are a per-image function: any sub-batch gives the same rows
+    sub = eng.decode_naic(att[16:48].contiguous())
+    for k in ("phrase_num", "phrase_length", "phrase_syn"):
+        assert torch.equal(sub[k], a[k][16:48])
+    # with the per-row fill mask the ids are per-image too
+    f_all = eng.decode_naic(att, strict_q1=False)
+    f_sub = eng.decode_naic(att[16:48].contiguous(), strict_q1=False)
+    assert torch.equal(f_sub["seq"], f_all["seq"][16:48])
+    # oracle on the same batch (CPU, a few seconds): slot layout bit-exact; ids where the gap allows
+    w = O.as_torch(sd)
+    seq, lp, pn, pl, ps, _ = O.sample_naic(w, cfg, torch.from_numpy(att_np))
+    assert torch.equal(a["phrase_num"].cpu(), pn) and torch.equal(a["phrase_length"].cpu(), pl) and torch.equal(a["phrase_syn"].cpu(), ps)
+    if not lp.isnan().any():
+        top = torch.topk(lp, 2, dim=2)[0]
+        safe = (top[..., 0] - top[..., 1]) > 1e-3
+        assert torch.equal(a["seq"].cpu()[safe], seq[safe])
+        assert (a["seq_logprob"].cpu() - lp).abs().max() < 1e-3
+
+
+def test_drop_in_module_sample(weight_cache, manifest):
+    """captioning.models.setup(opt) -> load_state_dict -> model(..., mode='sample'): the 6-tuple."""
+    import captioning.models as models
+    m = manifest["tiny_mix"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    g = load_golden("tiny_mix")
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    att = torch.from_numpy(g["att_feats"]).cuda()
+    fc = torch.zeros(att.size(0), 0, device="cuda")
+    with torch.no_grad():
+        seq, lp, pn, pl, ps, secs = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "greedy", "sample_n": 1}, mode="sample")
+        _, _, memory, masks = model._prepare_feature(fc, att, None)
+    assert (seq.cpu().numpy() == g["naic_seq"]).all() and (pl.cpu().numpy() == g["naic_phrase_length"]).all()
+    assert (pn.cpu().numpy() == g["naic_phrase_num"]).all() and (ps.cpu().numpy() == g["naic_phrase_syn"]).all()
+    assert _close(lp.cpu().numpy(), g["naic_logprob"], 0) < 1e-3
+    assert isinstance(secs, float) and masks.shape == (att.size(0), 1, 36)
+    assert _close(memory.cpu().numpy(), g["memory"], 0) < 1e-4
+    with pytest.raises(NotImplementedError):
+        model(fc, att, None, opt={"train_mode": "SAIC"}, mode="sample")
