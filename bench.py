@@ -48,7 +48,8 @@ def cpu_baseline(cfg, sd, batch, seed, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import boficap_oracle as O
     from boficap_amd import weights as W
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores), whatever os.cpu_count() says
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("BOFI_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     w = O.as_torch(sd)
     att = torch.from_numpy(W.synthetic_att_feats(batch, 36, cfg.att_feat_size, seed=seed))
@@ -90,15 +91,22 @@ def main():
     from boficap_amd.config import FULL as cfg
     from boficap_amd.engine import BofiEngine
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    log("building weights")
     sd = W.make_state_dict(cfg, seed=0)
     eng = BofiEngine(cfg, tdt, max_batch=args.batch, max_regions=36, device=dev)
     eng.load_state_dict(sd)
     # every rank decodes its own shard of images (different seed per rank), already resident in HBM
     att = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev).to(tdt).contiguous()
     graph = not args.no_graph
+    log("engine ready; first decode (graph capture)")
     out = eng.decode_naic(att, want_logprob=not args.ids_only, graph=graph)
     torch.cuda.synchronize()
+    log("warm-up + timed steps")
 
     def barrier():
         if world > 1:
@@ -145,6 +153,7 @@ def main():
                          "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
                          "note": "algorithmic FLOPs F_alg(T)*batch (SURVEY.md 8d) / HIP-event time per decode on the launch stream"},
         }
+        log(f"gpu done: {res['value']} images/sec; timing the CPU oracle")
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, args.batch, ATT_SEED)
         print(json.dumps(res), flush=True)

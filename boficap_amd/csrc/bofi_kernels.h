@@ -7,7 +7,7 @@
 namespace bofi {
 
 int launch_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows, int d,
-                     hipStream_t st);
+                     hipStream_t st, const int* skip_if_ge = nullptr, int skip_threshold = 0);
 
 struct LinearArgs {
     const void* x; int x_dtype; int ldx;
@@ -25,6 +25,7 @@ struct LinearArgs {
     const int* skip_if_ge; int skip_threshold;
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
+int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible
 
 struct AttnArgs {
     const void* q; int ldq;

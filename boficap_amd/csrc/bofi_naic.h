@@ -19,7 +19,7 @@ struct BoundState {
 
 struct BoundHeadWeights {   // float32
     const float* norm_gain; const float* norm_bias;      // length_predictor.norm
-    const float* w1; const float* b1;                    // [2*hh, d]: Length_classifier1 over Syntactic_classifier1
+    const float* w1t; const float* b1;                   // TRANSPOSED [d, 2*hh]: Length_classifier1 | Syntactic_classifier1
     const float* len_w2; const float* len_b2;            // [20, hh]
     const float* syn_w2; const float* syn_b2;            // [10, hh]
 };
@@ -27,10 +27,14 @@ struct BoundHeadWeights {   // float32
 int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_idx, hipStream_t s);
 int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_num, int* phrase_length,
                         int64_t* phrase_syn, int* iters, hipStream_t s);
-int launch_bound_selfattn(const void* q0, const void* kvtab, int dtype, const BoundState& st, const int* ext_syn,
-                          const int* last, int B, int L, int d, int H, void* ctx, bool early_out, hipStream_t s);
-int launch_bound_heads(const float* y, const BoundHeadWeights& w, const BoundState& st, int B, int L, int S, int d, int hh,
-                       int update, float* len_logp, float* syn_logp, hipStream_t s);
+// flags of launch_bound_tail
+#define BOUND_HEADS 1    /* final norm + heads + argmax on y */
+#define BOUND_UPDATE 2   /* apply the slot bookkeeping (needs BOUND_HEADS) */
+#define BOUND_ATTN 4     /* row-0 self-attention of the next iteration -> ctx */
+#define BOUND_EARLY 8    /* return at once when every image is finished */
+int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
+                      const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
+                      float* len_logp, float* syn_logp, hipStream_t s);
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,
                       int B, int S, int L, int d, int bos_idx, float* x, hipStream_t s);
 

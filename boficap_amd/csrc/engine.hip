@@ -145,6 +145,15 @@ struct bofi_engine {
     // ---- kernels -------------------------------------------------------------------------------
     int linear(const void* x, int x_dtype, int ldx, const Lin& l, const float* residual, int ldr, void* y, int y_dtype,
                int ldy, int M, int relu, const Norm* ln, const int* row_len, int rpg, bool early, hipStream_t s) {
+        if (ln) {
+            // pre-norm of SublayerConnection (TransformerModel.py:1361-1363): LayerNorm kernel into the
+            // compute-dtype scratch, then the LDS-DMA GEMM reads it
+            if (x_dtype != BOFI_DT_F32 || ldx != l.K) return BOFI_ERR_ARG;
+            int rc = bofi::launch_layernorm((const float*)x, ln->g, ln->b, xn, cfg.dtype, M, l.K, s,
+                                            early ? st.counters : nullptr, cur_B);
+            if (rc != BOFI_OK) return rc;
+            x = xn; x_dtype = cfg.dtype; ln = nullptr;
+        }
         bofi::LinearArgs a{};
         a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = l.w; a.w_dtype = cfg.dtype; a.bias = l.b;
         a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy;
@@ -190,9 +199,10 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
 
 int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update,
                                     float* len_logp, float* syn_logp, bool early, hipStream_t s) {
+    // One bounding iteration AFTER the row-0 self-attention context (bctx) has been produced by the
+    // previous launch_bound_tail(..., BOUND_ATTN).
     const int d = cfg.d_model, dt = cfg.dtype;
     cur_B = B;
-    ENG_OK(bofi::launch_bound_selfattn(b_q0, b_kvtab, dt, st, ext_syn, last, B, L, d, cfg.heads, bctx, early, s));
     // y1 = x0 + (Wo ctx + bo): the row-0 residual input is the same vector for every image (ldr = 0)
     ENG_OK(linear(bctx, dt, d, b_o_self, b_x0, 0, by1, BOFI_DT_F32, d, B, 0, nullptr, nullptr, 0, early, s));
     ENG_OK(linear(by1, BOFI_DT_F32, d, b_q_src, nullptr, 0, bq2, dt, d, B, 0, &b_n1, nullptr, 0, early, s));
@@ -205,7 +215,10 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     ENG_OK(linear(bctx2, dt, d, b_o_src, by1, d, by2, BOFI_DT_F32, d, B, 0, nullptr, nullptr, 0, early, s));
     ENG_OK(linear(by2, BOFI_DT_F32, d, b_w1, nullptr, 0, bh, dt, cfg.d_ff, B, 1, &b_n2, nullptr, 0, early, s));
     ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by2, d, by3, BOFI_DT_F32, d, B, 0, nullptr, nullptr, 0, early, s));
-    ENG_OK(bofi::launch_bound_heads(by3, heads, st, B, L, cfg.seq_length, d, cfg.head_hidden, update, len_logp, syn_logp, s));
+    // heads + bookkeeping, fused with the next iteration's row-0 self-attention
+    const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
+    ENG_OK(bofi::launch_bound_tail(by3, heads, st, update ? nullptr : ext_syn, update ? nullptr : last, b_q0, b_kvtab, bctx, dt, B, L,
+                                   cfg.seq_length, d, cfg.head_hidden, cfg.heads, flags, len_logp, syn_logp, s));
     return BOFI_OK;
 }
 
@@ -216,6 +229,8 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, memory_out, s));
     // ---- bounding pass (core_NAIC TransformerModel.py:1833-1870)
     ENG_OK(bofi::launch_bound_init(st, B, L, cfg.pad_idx, cfg.len_idx, s));
+    ENG_OK(bofi::launch_bound_tail(nullptr, heads, st, nullptr, nullptr, b_q0, b_kvtab, bctx, dt, B, L, S, d, cfg.head_hidden,
+                                   cfg.heads, BOUND_ATTN, nullptr, nullptr, s));
     for (int it = 0; it < S; ++it)
         ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     // ---- filling pass (decode_NA :570-587)
@@ -366,8 +381,12 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         const auto *lw2 = e->get(lp + ".Length_classifier2.weight", (size_t)20 * hh), *lb2 = e->get(lp + ".Length_classifier2.bias", 20);
         const auto *sw2 = e->get(lp + ".Syntactic_classifier2.weight", (size_t)10 * hh), *sb2 = e->get(lp + ".Syntactic_classifier2.bias", 10);
         if (!lw1 || !lb1 || !sw1 || !sb1 || !lw2 || !lb2 || !sw2 || !sb2) return BOFI_ERR_STATE;
-        std::vector<float> w1(*lw1), b1(*lb1);
-        w1.insert(w1.end(), sw1->begin(), sw1->end());
+        std::vector<float> w1((size_t)d * 2 * hh), b1(*lb1);          // transposed: [d][2*hh]
+        for (int j = 0; j < hh; ++j)
+            for (int k = 0; k < d; ++k) {
+                w1[(size_t)k * 2 * hh + j] = (*lw1)[(size_t)j * d + k];
+                w1[(size_t)k * 2 * hh + hh + j] = (*sw1)[(size_t)j * d + k];
+            }
         b1.insert(b1.end(), sb1->begin(), sb1->end());
         float *p_w1, *p_b1, *p_lw2, *p_lb2, *p_sw2, *p_sb2;
         ENG_OK(e->upload_f32(&p_w1, w1)); ENG_OK(e->upload_f32(&p_b1, b1));
@@ -388,6 +407,7 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     ENG_OK(e->dalloc((char**)&e->mem, Bm * Rm * d, e->tsz));
     ENG_OK(e->dalloc((char**)&e->kv, Bm * Rm * (size_t)e->kv_all.N, e->tsz));
     ENG_OK(e->dalloc((char**)&e->qs, Bm * Sq * d, e->tsz));
+    ENG_OK(e->dalloc((char**)&e->xn, (rows > (size_t)L * 10 ? rows : (size_t)L * 10) * d, e->tsz));
     ENG_OK(e->dalloc(&e->by1, Bm * d)); ENG_OK(e->dalloc(&e->by2, Bm * d)); ENG_OK(e->dalloc(&e->by3, Bm * d));
     ENG_OK(e->dalloc((char**)&e->bctx, Bm * d, e->tsz)); ENG_OK(e->dalloc((char**)&e->bq2, Bm * d, e->tsz));
     ENG_OK(e->dalloc((char**)&e->bctx2, Bm * d, e->tsz)); ENG_OK(e->dalloc((char**)&e->bh, Bm * dff, e->tsz));
@@ -449,6 +469,9 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
     g_err.clear();
     ENG_OK(check_call(e, B, R));
     if (!ext_syn || !last || !len_logp || !syn_logp) return fail(BOFI_ERR_ARG, "null argument");
+    ENG_OK(bofi::launch_bound_tail(nullptr, e->heads, e->st, ext_syn, last, e->b_q0, e->b_kvtab, e->bctx, e->cfg.dtype, B, e->L,
+                                   e->cfg.seq_length, e->cfg.d_model, e->cfg.head_hidden, e->cfg.heads, BOUND_ATTN, nullptr, nullptr,
+                                   (hipStream_t)stream));
     return e->enqueue_bound_iter(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, false, (hipStream_t)stream);
 }
 

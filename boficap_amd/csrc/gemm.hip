@@ -288,6 +288,10 @@ int launch_linear(const LinearArgs& a, hipStream_t st) {
     if (a.ldx < a.K || (a.ldx * xel) % 16 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return BOFI_ERR_ARG;
     if (a.ldy < a.N || (a.residual && a.ldr != 0 && a.ldr < a.N)) return BOFI_ERR_ARG;   // ldr == 0 broadcasts one row
     if (a.row_len && a.rows_per_group <= 0) return BOFI_ERR_ARG;
+    {
+        const int rc = launch_linear_glds(a, st);          // operands already in the compute dtype: LDS-DMA kernel
+        if (rc >= 0) return rc;
+    }
     const bool ln = a.ln_gain != nullptr;
     if (ln && (a.x_dtype != BOFI_DT_F32 || !a.ln_bias || a.K % 8)) return BOFI_ERR_ARG;
     GemmParams p;

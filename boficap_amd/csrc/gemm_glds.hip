@@ -1,0 +1,308 @@
+// y = act(x . w^T + bias) [+ residual] with both operands already in the compute dtype.
+// This is the hot GEMM of the bound+fill path (reference nn.Linear layers, see gemm.hip).
+//
+// gfx950 structure:
+//   * 4 wavefronts (2x2) per workgroup, BM x BN output tile, 16x16 MFMA tiles, f32 accumulate
+//     (v_mfma_f32_16x16x32_bf16, or four exact v_mfma_f32_16x16x4_f32 per 16-byte fragment).
+//   * K is walked in 128-byte slabs (64 bf16 / 32 f32).  Slabs are copied global -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4: no VGPR staging) into an NS-deep ring; the loads of the
+//     next NS-1 slabs stay in flight across the single barrier of each K step, retired by a
+//     COUNTED s_waitcnt vmcnt (never 0 inside the loop).
+//   * LDS-DMA writes lane-linearly (1 KiB = 8 rows of 128 B per wave instruction), so rows cannot
+//     be padded; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle
+//     applied to the per-lane SOURCE address (chunk c of row r is stored at chunk c ^ (r & 7))
+//     and undone in the fragment read.
+//   * Epilogue: accumulators -> LDS (reusing the ring) -> bias / ReLU / padded-row zeroing /
+//     float32 residual -> global, one full 256-byte row segment per wave instruction.
+#include <cstdio>
+#include <cstdlib>
+
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+template <typename T> struct GMma;
+template <> struct GMma<bf16_t> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct GMma<float> {
+    typedef float4 Frag;     // lane quarter q holds k = 16g + 4q + s for step s, in A and in B alike
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+        return c;
+    }
+};
+
+struct Gemm2Params {
+    const void* x; int ldx;
+    const void* w;
+    const float* bias;
+    const float* residual; int ldr;
+    void* y; int ldy; int y_is_f32;
+    int M, N, K;
+    int relu;
+    const int* row_len; int rows_per_group;
+    const int* skip_if_ge; int skip_threshold;
+    int vec_ok;               // N, ldy, ldr multiples of 4 and y/bias/residual 16-byte aligned
+    int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
+    constexpr int EPC = 16 / sizeof(T);                 // elements per 16-byte chunk
+    constexpr int BK = 8 * EPC;                         // one 128-byte slab row
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;              // bytes per ring slot
+    constexpr int LA = BM / 32, LB = BN / 32;           // LDS-DMA instructions per wave per slab (A, B)
+    constexpr int LPS = LA + LB;
+    constexpr int EPI = BM * (BN + 4) * 4;              // epilogue staging, float32, +4 columns pad
+    constexpr int SMEM = (NS * STAGE > EPI) ? NS * STAGE : EPI;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+    if (p.skip_if_ge && *p.skip_if_ge >= p.skip_threshold) return;
+    if (p.dbg & 4) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // LDS-DMA source pointers: wave-instruction j of this wave covers tile rows (wave*L + j)*8 .. +7;
+    // lane i -> row +(i>>3), LDS chunk (i&7) <- global chunk (i&7) ^ (i>>3)   (XOR swizzle on the source)
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    const T* asrc[LA];
+    const T* bsrc[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        int m = m0 + (wave * LA + j) * 8 + lrow;
+        m = m < p.M ? m : p.M - 1;                      // clamp: rows past M are computed and dropped
+        asrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * EPC;
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        int n = n0 + (wave * LB + j) * 8 + lrow;
+        n = n < p.N ? n : p.N - 1;
+        bsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * EPC;
+    }
+    auto issue = [&](int slot, int kt) {
+        if (p.dbg & 1) return;
+        unsigned char* sa = smem + slot * STAGE + wave * LA * 1024;
+        unsigned char* sb = smem + slot * STAGE + BM * 128 + wave * LB * 1024;
+#pragma unroll
+        for (int j = 0; j < LA; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + (size_t)kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sb + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    // fragment read offsets: tile row R = base + (lane & 15), wanted chunk g = 4*grp + (lane >> 4),
+    // stored at chunk g ^ (R & 7); (base is a multiple of 16, so R & 7 == lane & 7)
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire slab kt: at most min(NS-2, nk-1-kt) younger slabs may stay in flight
+        const int younger = nk - 1 - kt;
+        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (NS > 3 && younger == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, kt + NS - 1);
+        if (p.dbg & 2) continue;
+        const unsigned char* sa = smem + (kt % NS) * STAGE + (wr * (BM / 2) + frow) * 128;
+        const unsigned char* sb = smem + (kt % NS) * STAGE + BM * 128 + (wc * (BN / 2) + frow) * 128;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int coff = (((g * 4 + fq) ^ fx) << 4);
+            typename GMma<T>::Frag fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const typename GMma<T>::Frag*>(sa + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const typename GMma<T>::Frag*>(sb + j * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = GMma<T>::mma(fb[j], fa[i], acc[i][j]);   // D[n][m]: W is the MFMA "A"
+        }
+    }
+
+    // ---- epilogue.  With W as the MFMA row operand the C/D fragment of tile (i, j) holds, per lane,
+    // output row m = i*16 + (lane & 15) and the FOUR CONSECUTIVE columns n = j*16 + (lane >> 4)*4 + r.
+    // Stores straight from that layout would be 32..64-byte pieces (measured: ~1 TB/s); the tile is
+    // staged in LDS (reusing the ring) and written back as whole row segments, 16 B per lane.
+    const int mrow = wr * (BM / 2) + (lane & 15), ncol = wc * (BN / 2) + (lane >> 4) * 4;
+    if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = 1.f; return; }
+    __syncthreads();
+    float* es = reinterpret_cast<float*>(smem);
+    constexpr int ES = BN + 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<float4*>(&es[(mrow + i * 16) * ES + ncol + j * 16]) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __syncthreads();
+    // All loads (bias, residual, region counts) are issued BEFORE the first store: vmcnt counts stores
+    // too on gfx950, so a load behind a store would wait for that store's round trip.
+    if (p.vec_ok) {
+        constexpr int LPR = BN / 4;                    // lanes per output row (4 columns each)
+        constexpr int RPI = 64 / LPR;                  // rows per wave instruction
+        constexpr int NR = BM / (4 * RPI);             // rows per lane
+        const int lr = lane / LPR, lc = (lane % LPR) * 4;
+        const int n = n0 + lc;
+        const bool ncol_ok = n < p.N;                  // N % 4 == 0: the four columns are in or out together
+        const float4 bv = (p.bias && ncol_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 rv[NR];
+        bool live[NR], zero[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
+            live[u] = m < p.M && ncol_ok;
+            rv[u] = (p.residual && live[u]) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            zero[u] = false;
+            if (p.row_len && live[u]) {
+                const int grp = m / p.rows_per_group;
+                zero[u] = (m - grp * p.rows_per_group) >= p.row_len[grp];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
+            float4 v = *reinterpret_cast<const float4*>(&es[r * ES + lc]);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (zero[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = rv[u].x + v.x; v.y = rv[u].y + v.y; v.z = rv[u].z + v.z; v.w = rv[u].w + v.w;
+            if (!live[u]) continue;
+            if (p.y_is_f32) {
+                *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)m * p.ldy + n) = v;
+            } else if constexpr (sizeof(T) == 2) {
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + (size_t)m * p.ldy + n) = o;
+            }
+        }
+        return;
+    }
+    // general case (e.g. the vocabulary projection, N = 9491, rows not 16-byte aligned): one float per lane
+    constexpr int NC = (BN + 63) / 64;
+    constexpr int NRS = BM / 4;
+    float bv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int n = n0 + c * 64 + lane;
+        bv[c] = (p.bias && c * 64 + lane < BN && n < p.N) ? p.bias[n] : 0.f;
+    }
+    float rv[NRS][NC];
+    bool zero[NRS];
+#pragma unroll
+    for (int u = 0; u < NRS; ++u) {
+        const int m = m0 + wave + 4 * u;
+        zero[u] = false;
+        if (p.row_len && m < p.M) {
+            const int grp = m / p.rows_per_group;
+            zero[u] = (m - grp * p.rows_per_group) >= p.row_len[grp];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int n = n0 + c * 64 + lane;
+            rv[u][c] = (p.residual && m < p.M && c * 64 + lane < BN && n < p.N) ? p.residual[(size_t)m * p.ldr + n] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NRS; ++u) {
+        const int r = wave + 4 * u, m = m0 + r;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int n = n0 + c * 64 + lane;
+            float v = es[r * ES + c * 64 + lane] + bv[c];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (zero[u]) v = 0.f;
+            v = rv[u][c] + v;
+            if (m >= p.M || c * 64 + lane >= BN || n >= p.N) continue;
+            if (p.y_is_f32) static_cast<float*>(p.y)[(size_t)m * p.ldy + n] = v;
+            else ElemOps<T>::store(static_cast<T*>(p.y) + (size_t)m * p.ldy + n, v);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int NS>
+static void launch_one(const Gemm2Params& p, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS>), dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(256), 0, st, p);
+}
+
+template <typename T>
+static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
+    // developer override: BOFI_GEMM_TILE=<BM>x<BN>x<NS>
+    int bm = 0, bn = 0, ns = 0;
+    if (const char* t = getenv("BOFI_GEMM_TILE")) sscanf(t, "%dx%dx%d", &bm, &bn, &ns);
+    if (!bm) {
+        // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
+        // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop
+        const long t = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+        if (p.M <= 64) { bm = 64; bn = 32; ns = 4; }
+        else if (t >= 400) { bm = 128; bn = 64; ns = 2; }
+        else if (p.K >= 2048) { bm = 64; bn = 64; ns = 3; }
+        else { bm = 64; bn = 64; ns = 2; }
+    }
+    const int key = bm * 10000 + bn * 10 + ns;
+    switch (key) {
+        case 1281282: launch_one<T, 128, 128, 2>(p, st); break;
+        case 1281283: launch_one<T, 128, 128, 3>(p, st); break;
+        case 1281284: launch_one<T, 128, 128, 4>(p, st); break;
+        case 1280642: launch_one<T, 128, 64, 2>(p, st); break;
+        case 1280643: launch_one<T, 128, 64, 3>(p, st); break;
+        case 640642: launch_one<T, 64, 64, 2>(p, st); break;
+        case 640643: launch_one<T, 64, 64, 3>(p, st); break;
+        case 640644: launch_one<T, 64, 64, 4>(p, st); break;
+        case 640322: launch_one<T, 64, 32, 2>(p, st); break;
+        case 640324: launch_one<T, 64, 32, 4>(p, st); break;
+        default: return BOFI_ERR_ARG;
+    }
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// Operands in the compute dtype, no fused LayerNorm: the LDS-DMA kernel.  Returns -1 if the call
+// is not eligible (the caller then uses the register-staged kernel of gemm.hip).
+int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
+    if (a.x_dtype != a.w_dtype || a.ln_gain) return -1;
+    const int el = a.w_dtype == BOFI_DT_F32 ? 4 : 2;
+    const int bk = 128 / el;
+    if (a.K % bk || (a.ldx * el) % 16 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return -1;
+    Gemm2Params p;
+    p.x = a.x; p.ldx = a.ldx; p.w = a.w; p.bias = a.bias; p.residual = a.residual; p.ldr = a.ldr;
+    p.y = a.y; p.ldy = a.ldy; p.y_is_f32 = a.y_dtype == BOFI_DT_F32; p.M = a.M; p.N = a.N; p.K = a.K;
+    p.relu = a.relu; p.row_len = a.row_len; p.rows_per_group = a.rows_per_group;
+    p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
+    { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }
+    const int yel = p.y_is_f32 ? 4 : el;
+    p.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && ((uintptr_t)a.y * 0 + (size_t)a.ldy * yel) % 8 == 0 &&
+               (!a.bias || (uintptr_t)a.bias % 16 == 0) &&
+               (!a.residual || (((uintptr_t)a.residual % 16 == 0) && (a.ldr % 4 == 0)));
+    return el == 4 ? launch_glds_t<float>(p, st) : launch_glds_t<bf16_t>(p, st);
+}
+
+}  // namespace bofi

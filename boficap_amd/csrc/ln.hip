@@ -9,7 +9,9 @@ namespace bofi {
 
 template <typename OT, int PER_LANE>   // d = 64 * PER_LANE
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ gain,
-                                                 const float* __restrict__ bias, OT* __restrict__ y, int rows) {
+                                                 const float* __restrict__ bias, OT* __restrict__ y, int rows,
+                                                 const int* skip_if_ge, int skip_threshold) {
+    if (skip_if_ge && *skip_if_ge >= skip_threshold) return;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -65,10 +67,11 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
 }
 
 template <typename OT>
-static int launch_ln_t(const float* x, const float* g, const float* b, OT* y, int rows, int d, hipStream_t st) {
+static int launch_ln_t(const float* x, const float* g, const float* b, OT* y, int rows, int d, hipStream_t st,
+                       const int* skip, int thr) {
     const dim3 grid((rows + 3) / 4), block(256);
     switch (d / 64) {
-#define BOFI_LN_CASE(P) case P: hipLaunchKernelGGL((ln_kernel<OT, P>), grid, block, 0, st, x, g, b, y, rows); break;
+#define BOFI_LN_CASE(P) case P: hipLaunchKernelGGL((ln_kernel<OT, P>), grid, block, 0, st, x, g, b, y, rows, skip, thr); break;
         BOFI_LN_CASE(1) BOFI_LN_CASE(2) BOFI_LN_CASE(4) BOFI_LN_CASE(8) BOFI_LN_CASE(12) BOFI_LN_CASE(16) BOFI_LN_CASE(32)
 #undef BOFI_LN_CASE
         default: return BOFI_ERR_ARG;
@@ -78,11 +81,11 @@ static int launch_ln_t(const float* x, const float* g, const float* b, OT* y, in
 }
 
 int launch_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows, int d,
-                     hipStream_t st) {
+                     hipStream_t st, const int* skip, int thr) {
     if (!x || !gain || !bias || !y || rows < 0 || d <= 0 || d % 64) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    if (y_dtype == BOFI_DT_F32) return launch_ln_t<float>(x, gain, bias, (float*)y, rows, d, st);
-    if (y_dtype == BOFI_DT_BF16) return launch_ln_t<bf16_t>(x, gain, bias, (bf16_t*)y, rows, d, st);
+    if (y_dtype == BOFI_DT_F32) return launch_ln_t<float>(x, gain, bias, (float*)y, rows, d, st, skip, thr);
+    if (y_dtype == BOFI_DT_BF16) return launch_ln_t<bf16_t>(x, gain, bias, (bf16_t*)y, rows, d, st, skip, thr);
     return BOFI_ERR_ARG;
 }
 

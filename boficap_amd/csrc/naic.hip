@@ -51,35 +51,152 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row-0 self-attention of the bound layer.  Exact for a one-layer bound network:
-// the layer input at position p is lut_syn[label_p]*sqrt(d) + pe[p], a function of (p, label) only,
-// so K and V of every possible row are tabulated once per model ("kvtab", [L*10, 2d]) and the
-// query of row 0 ([LEN] at position 0) is a constant vector q0.  Row 0 sees keys p < last[b]
+// Per-image tail of one bounding iteration, fused with the head of the next one:
+//   (HEADS) final norm of row 0 -> two 2-layer heads -> log-softmax -> first-max argmax
+//           (LengthPredictor_UIC.forward TransformerModel.py:375-383)
+//   (UPDATE) slot bookkeeping of core_NAIC (TransformerModel.py:1843-1869)
+//   (ATTN)  row-0 self-attention of the bound layer for the NEXT iteration.
+// The self-attention is exact for a one-layer bound network: the layer input at
+// position p is lut_syn[label_p]*sqrt(d) + pe[p], a function of (p, label) only, so K and V of
+// every possible row are tabulated once per model ("kvtab", [L*10, 2d]) and the query of row 0
+// ([LEN] at position 0) is a constant vector q0.  Row 0 sees keys p < last[b]
 // (tgt_mask[j, 0, :last] = True, TransformerModel.py:1859/1867).
-// One workgroup per image, one wavefront per head (looping if H > 4).
+// One workgroup (256 threads) per image; heads in float32 (0.1 M parameters, stored transposed so
+// that consecutive lanes read consecutive outputs with 16-byte loads).
 template <typename T>
-__global__ __launch_bounds__(256) void bound_selfattn_kernel(const T* __restrict__ q0, const T* __restrict__ kvtab,
-                                                             BoundState st, const int* ext_syn, const int* last, int L,
-                                                             int d, int H, T* __restrict__ ctx, int B) {
-    if (st.counters && st.counters[0] >= B) return;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = min(last[b], L);
+__global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict__ y, BoundHeadWeights w, BoundState st,
+                                                         const int* ext_syn_in, const int* last_in, const T* __restrict__ q0,
+                                                         const T* __restrict__ kvtab, T* __restrict__ ctx, int B, int L, int S,
+                                                         int d, int hh, int H, int flags, float* len_logp_out, float* syn_logp_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((flags & BOUND_EARLY) && st.counters[0] >= B) return;
+    const int nh = 2 * hh;
+    float* xs = smem;                 // [d] normalised row
+    float* part = xs + d;             // [4][nh] partial hidden sums
+    float* hid = part + 4 * nh;       // [nh]
+    float* lg = hid + nh;             // [32] logits: 0..19 length, 20..29 label
+    float* red = lg + 32;             // [8]
+    int* sint = reinterpret_cast<int*>(red + 8);   // [0] = last, [1] = finished, [2..2+L) = ext_syn row
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* ext_src = ext_syn_in ? ext_syn_in : st.ext_syn;
+    const int* last_src = last_in ? last_in : st.last;
+    if (tid < L) sint[2 + tid] = ext_src[b * L + tid];
+    if (tid == 0) { sint[0] = last_src[b]; sint[1] = (flags & BOUND_UPDATE) ? st.finished[b] : 0; }
+
+    if (flags & BOUND_HEADS) {
+        const float* yr = y + (size_t)b * d;
+        float s = 0.f;
+        for (int k = tid; k < d; k += 256) s += yr[k];
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)d;
+        float q = 0.f;
+        for (int k = tid; k < d; k += 256) { const float t = yr[k] - mean; q += t * t; }
+        q = wave_sum(q);
+        if (lane == 0) red[4 + wave] = q;
+        __syncthreads();
+        const float den = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)(d - 1)) + 1e-6f;
+        for (int k = tid; k < d; k += 256) xs[k] = w.norm_gain[k] * (yr[k] - mean) / den + w.norm_bias[k];
+        __syncthreads();
+        // hidden layer of both heads: thread (slice, group) sums 4 outputs over a quarter of K
+        const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng;
+        if (slice < 4) {
+            const int k0 = slice * (d / 4), k1 = k0 + d / 4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) {
+                const float4 wv = *reinterpret_cast<const float4*>(w.w1t + (size_t)k * nh + grp * 4);
+                const float xv = xs[k];
+                acc.x = fmaf(wv.x, xv, acc.x); acc.y = fmaf(wv.y, xv, acc.y);
+                acc.z = fmaf(wv.z, xv, acc.z); acc.w = fmaf(wv.w, xv, acc.w);
+            }
+            *reinterpret_cast<float4*>(part + slice * nh + grp * 4) = acc;
+        }
+        __syncthreads();
+        if (tid < nh) hid[tid] = fmaxf(((part[tid] + part[nh + tid]) + (part[2 * nh + tid] + part[3 * nh + tid])) + w.b1[tid], 0.f);
+        __syncthreads();
+        if (tid < 30) {
+            const bool is_len = tid < 20;
+            const float* wr = is_len ? (w.len_w2 + tid * hh) : (w.syn_w2 + (tid - 20) * hh);
+            const float* hv = is_len ? hid : (hid + hh);
+            float acc = 0.f;
+            for (int k = 0; k < hh; ++k) acc = fmaf(wr[k], hv[k], acc);
+            lg[tid] = acc + (is_len ? w.len_b2[tid] : w.syn_b2[tid - 20]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int pick[2];
+            for (int head = 0; head < 2; ++head) {
+                const int n = head ? 10 : 20;
+                float* v = lg + (head ? 20 : 0);
+                float m = v[0];
+                for (int i = 1; i < n; ++i) m = fmaxf(m, v[i]);
+                float sum = 0.f;
+                for (int i = 0; i < n; ++i) sum += expf(v[i] - m);
+                const float lse = logf(sum);
+                int best = 0;
+                float bv = -INFINITY;
+                float* out = head ? (syn_logp_out ? syn_logp_out + (size_t)b * 10 : nullptr)
+                                  : (len_logp_out ? len_logp_out + (size_t)b * 20 : nullptr);
+                for (int i = 0; i < n; ++i) {
+                    const float lp = (v[i] - m) - lse;
+                    if (out) out[i] = lp;
+                    if (lp > bv || (lp != lp && bv == bv)) { bv = lp; best = i; }     // first max; a NaN wins once
+                }
+                pick[head] = best;
+            }
+            if (flags & BOUND_UPDATE) {
+                if (b == 0) st.counters[1] += 1;              // iterations in which some image was active
+                if (!sint[1]) {
+                    int ln = pick[0];
+                    const int sn = pick[1], la = sint[0];
+                    bool fin = false;
+                    if (ln == 0 || sn < 4 || sn > 6) {        // EOS (TransformerModel.py:1846-1849)
+                        fin = true;
+                    } else {
+                        if (ln + la >= S + 1) { ln = S + 1 - la; fin = true; }      // truncate (:1850-1855)
+                        const int slot = st.phrase_num[b];    // == iteration index while unfinished (Q3)
+                        st.phrase_length[b * L + slot] = ln;
+                        st.phrase_syn[b * L + slot] = sn;
+                        st.phrase_num[b] = slot + 1;
+                        for (int p = la; p < la + ln; ++p) { st.ext_syn[b * L + p] = sn; sint[2 + p] = sn; }
+                        st.last[b] = la + ln;
+                        sint[0] = la + ln;
+                    }
+                    if (fin) { st.finished[b] = 1; sint[1] = 1; atomicAdd(&st.counters[0], 1); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!(flags & BOUND_ATTN) || sint[1]) return;           // a finished image's state is frozen: no further steps matter
+
+    // ---- row-0 self-attention over the (position, label) table, one wavefront per head
+    constexpr int EPC = 16 / sizeof(T);
+    const int n = min(sint[0], L);
     for (int h = wave; h < H; h += 4) {
-        float s = -INFINITY;
+        float sc = -INFINITY;
         int row = 0;
         if (lane < n) {
-            row = lane * 10 + ext_syn[b * L + lane];
+            row = lane * 10 + sint[2 + lane];
             const T* kr = kvtab + (size_t)row * 2 * d + h * 64;
             const T* qr = q0 + h * 64;
             float acc = 0.f;
-#pragma unroll 8
-            for (int i = 0; i < 64; ++i) acc = fmaf(ElemOps<T>::to_f32(qr[i]), ElemOps<T>::to_f32(kr[i]), acc);
-            s = acc * 0.125f;
+#pragma unroll
+            for (int c = 0; c < 64 / EPC; ++c) {
+                union { u32x4 v; T e[EPC]; } ku, qu;
+                ku.v = *reinterpret_cast<const u32x4*>(kr + c * EPC);
+                qu.v = *reinterpret_cast<const u32x4*>(qr + c * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc = fmaf(ElemOps<T>::to_f32(qu.e[e]), ElemOps<T>::to_f32(ku.e[e]), acc);
+            }
+            sc = acc * 0.125f;
         }
-        const float m = wave_max(s);
-        float e = (lane < n) ? expf(s - m) : 0.f;
+        const float m = wave_max(sc);
+        const float e = (lane < n) ? expf(sc - m) : 0.f;
         const float sum = wave_sum(e);
-        float pr = ElemOps<T>::to_f32(ElemOps<T>::from_f32(e / sum));     // P is held in compute dtype, as in attn.hip
+        const float pr = ElemOps<T>::to_f32(ElemOps<T>::from_f32(e / sum));     // P is held in compute dtype, as in attn.hip
         float o = 0.f;
         for (int j = 0; j < n; ++j) {
             const float pj = __shfl(pr, j, 64);
@@ -90,108 +207,17 @@ __global__ __launch_bounds__(256) void bound_selfattn_kernel(const T* __restrict
     }
 }
 
-int launch_bound_selfattn(const void* q0, const void* kvtab, int dtype, const BoundState& st, const int* ext_syn,
-                          const int* last, int B, int L, int d, int H, void* ctx, bool early_out, hipStream_t s) {
-    BoundState s2 = st;
-    if (!early_out) s2.counters = nullptr;
+int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
+                      const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
+                      float* len_logp, float* syn_logp, hipStream_t s) {
+    if ((2 * hh) % 4 || d % 4 || 2 * hh * 4 / 4 > 256 * 4 || L > 60) return BOFI_ERR_ARG;
+    const size_t shm = (size_t)(d + 4 * 2 * hh + 2 * hh + 32 + 8 + 64) * sizeof(float);
     if (dtype == BOFI_DT_F32)
-        hipLaunchKernelGGL((bound_selfattn_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)q0, (const float*)kvtab, s2,
-                           ext_syn, last, L, d, H, (float*)ctx, B);
+        hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(256), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
+                           (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
     else
-        hipLaunchKernelGGL((bound_selfattn_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)q0, (const bf16_t*)kvtab,
-                           s2, ext_syn, last, L, d, H, (bf16_t*)ctx, B);
-    BOFI_CHECK_LAUNCH();
-    return BOFI_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Final norm of row 0 -> two 2-layer heads -> log-softmax -> first-max argmax -> slot bookkeeping.
-// One workgroup per image; everything in float32 (the heads are 0.1 M parameters).
-__global__ __launch_bounds__(256) void bound_heads_kernel(const float* __restrict__ y, BoundHeadWeights w, BoundState st, int B,
-                                                          int L, int S, int d, int hh, int update, float* len_logp_out,
-                                                          float* syn_logp_out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (update && st.counters[0] >= B) return;
-    float* xs = smem;                 // [d] normalised row
-    float* hid = xs + d;              // [2*hh]
-    float* lg = hid + 2 * hh;         // [32] logits: 0..19 length, 20..29 label
-    float* stat = lg + 32;            // [2]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* yr = y + (size_t)b * d;
-    if (wave == 0) {
-        float s = 0.f;
-        for (int k = lane; k < d; k += 64) s += yr[k];
-        const float mean = wave_sum(s) / (float)d;
-        float q = 0.f;
-        for (int k = lane; k < d; k += 64) { const float t = yr[k] - mean; q += t * t; }
-        q = wave_sum(q);
-        if (lane == 0) { stat[0] = mean; stat[1] = sqrtf(q / (float)(d - 1)) + 1e-6f; }
-    }
-    __syncthreads();
-    for (int k = tid; k < d; k += 256) xs[k] = w.norm_gain[k] * (yr[k] - stat[0]) / stat[1] + w.norm_bias[k];
-    __syncthreads();
-    for (int j = wave; j < 2 * hh; j += 4) {
-        const float* wr = w.w1 + (size_t)j * d;
-        float acc = 0.f;
-        for (int k = lane; k < d; k += 64) acc = fmaf(wr[k], xs[k], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) hid[j] = fmaxf(acc + w.b1[j], 0.f);
-    }
-    __syncthreads();
-    if (tid < 30) {
-        const bool is_len = tid < 20;
-        const float* wr = is_len ? (w.len_w2 + tid * hh) : (w.syn_w2 + (tid - 20) * hh);
-        const float* hv = is_len ? hid : (hid + hh);
-        float acc = 0.f;
-        for (int k = 0; k < hh; ++k) acc = fmaf(wr[k], hv[k], acc);
-        lg[tid] = acc + (is_len ? w.len_b2[tid] : w.syn_b2[tid - 20]);
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    int pick[2];
-    for (int head = 0; head < 2; ++head) {
-        const int n = head ? 10 : 20;
-        float* v = lg + (head ? 20 : 0);
-        float m = v[0];
-        for (int i = 1; i < n; ++i) m = fmaxf(m, v[i]);
-        float sum = 0.f;
-        for (int i = 0; i < n; ++i) sum += expf(v[i] - m);
-        const float lse = logf(sum);
-        int best = 0;
-        float bv = -INFINITY;
-        float* out = head ? (syn_logp_out ? syn_logp_out + (size_t)b * 10 : nullptr)
-                          : (len_logp_out ? len_logp_out + (size_t)b * 20 : nullptr);
-        for (int i = 0; i < n; ++i) {
-            const float lp = (v[i] - m) - lse;
-            if (out) out[i] = lp;
-            if (lp > bv || (lp != lp && bv == bv)) { bv = lp; best = i; }     // first max; a NaN wins once
-        }
-        pick[head] = best;
-    }
-    if (!update) return;
-    if (b == 0) st.counters[1] += 1;                      // iterations in which some image was active
-    if (st.finished[b]) return;
-    int ln = pick[0];
-    const int sn = pick[1], la = st.last[b];
-    bool fin = false;
-    if (ln == 0 || sn < 4 || sn > 6) {                    // EOS (TransformerModel.py:1846-1849)
-        fin = true;
-    } else {
-        if (ln + la >= S + 1) { ln = S + 1 - la; fin = true; }          // truncate (:1850-1855)
-        const int slot = st.phrase_num[b];                // == iteration index while unfinished (Q3)
-        st.phrase_length[b * L + slot] = ln;
-        st.phrase_syn[b * L + slot] = sn;
-        st.phrase_num[b] = slot + 1;
-        for (int p = la; p < la + ln; ++p) st.ext_syn[b * L + p] = sn;
-        st.last[b] = la + ln;
-    }
-    if (fin) { st.finished[b] = 1; atomicAdd(&st.counters[0], 1); }
-}
-
-int launch_bound_heads(const float* y, const BoundHeadWeights& w, const BoundState& st, int B, int L, int S, int d, int hh,
-                       int update, float* len_logp, float* syn_logp, hipStream_t s) {
-    const size_t shm = (size_t)(d + 2 * hh + 32 + 2) * sizeof(float);
-    hipLaunchKernelGGL(bound_heads_kernel, dim3(B), dim3(256), shm, s, y, w, st, B, L, S, d, hh, update, len_logp, syn_logp);
+        hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(B), dim3(256), shm, s, y, w, st, ext_syn_in, last_in, (const bf16_t*)q0,
+                           (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

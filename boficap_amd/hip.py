@@ -56,7 +56,15 @@ def lib():
             raise BofiHipError(
                 f"{LIB_PATH} is missing: build it with `python -m boficap_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the decode path.")
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be loaded BEFORE this
+        # library so that both resolve to ONE HIP runtime; loaded the other way round the process
+        # ends up with two runtimes and the second sees no device.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
+        with open("/proc/self/maps") as f:
+            copies = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
+        if len(copies) > 1:
+            raise BofiHipError(f"two HIP runtimes are loaded ({sorted(copies)}); import torch before boficap_amd.hip")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
