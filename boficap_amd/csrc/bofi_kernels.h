@@ -9,6 +9,8 @@ namespace bofi {
 int launch_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows, int d,
                      hipStream_t st, const int* skip_if_ge = nullptr, int skip_threshold = 0);
 
+int launch_cast_bf16(const float* x, void* y, size_t n, hipStream_t st);
+
 struct LinearArgs {
     const void* x; int x_dtype; int ldx;
     const void* w; int w_dtype;
@@ -23,6 +25,13 @@ struct LinearArgs {
     const float* ln_gain; const float* ln_bias;
     // optional early-out word: the kernel returns at once when *skip_if_ge >= skip_threshold
     const int* skip_if_ge; int skip_threshold;
+    // LayerNorm folded into the GEMM (LDS-DMA kernel only): x is the raw residual stream in the compute
+    // dtype, w already carries the LN gain, bias carries c[n] = bias[n] + sum_k b_ln[k] W[n][k];
+    // ln_stats: float2 [M][K/32] partial (sum, sumsq) of the rows of the fp32 residual stream,
+    // ln_colsum: float [N] column sums of the (rounded) scaled weight
+    const float* ln_stats; const float* ln_colsum;
+    float* stats_out;         // write partial (sum, sumsq) of the OUTPUT rows: float2 [M][N/32]
+    void* y2; int ldy2;       // second copy of the output in the compute dtype (feeds the next folded GEMM)
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
 int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible

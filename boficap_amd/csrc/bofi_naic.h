@@ -36,6 +36,6 @@ int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundStat
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
                       float* len_logp, float* syn_logp, hipStream_t s);
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,
-                      int B, int S, int L, int d, int bos_idx, float* x, hipStream_t s);
+                      int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s);
 
 }  // namespace bofi

@@ -39,7 +39,7 @@ uint16_t host_bf16(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-struct Lin { void* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; };   // cs: column sums when a LayerNorm is folded in
 struct Norm { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, w1, w2; Norm n0, n1; };
 struct DecLayer { Lin qkv, o, q_src, o_src, w1, w2; Norm n0, n1, n2; };
@@ -77,6 +77,9 @@ struct bofi_engine {
     // workspace
     float *x_enc = nullptr, *x_fill = nullptr, *logits = nullptr;
     void *qkv = nullptr, *ctx = nullptr, *hdn = nullptr, *mem = nullptr, *kv = nullptr, *qs = nullptr, *xn = nullptr;
+    void* feats_t = nullptr;                                          // bf16 copy of float32 input features
+    void *xb_enc = nullptr, *xb_fill = nullptr, *byb = nullptr;       // compute-dtype copies of the residual streams
+    float *st_enc = nullptr, *st_fill = nullptr, *st_b = nullptr;     // row partial sums [rows][d/32][2]
     float *by1 = nullptr, *by2 = nullptr, *by3 = nullptr;
     void *bctx = nullptr, *bq2 = nullptr, *bctx2 = nullptr, *bh = nullptr;
     bofi::BoundState st{};
@@ -117,8 +120,11 @@ struct bofi_engine {
         }
         return &it->second;
     }
-    // stack several [n_i, K] matrices (and their biases) into one Lin
-    int make_lin(Lin* out, const std::vector<std::string>& prefixes, int n_each, int K) {
+    // stack several [n_i, K] matrices (and their biases) into one Lin.  With fold_norm the pre-norm
+    // LayerNorm that feeds this layer is folded in (gemm_glds.hip): w <- w * a_2 (per input column),
+    // bias <- bias + w . b_2, cs[n] <- sum_k of the ROUNDED scaled weight (so that the mean term of
+    // the epilogue cancels exactly what the MFMA accumulated).
+    int make_lin(Lin* out, const std::vector<std::string>& prefixes, int n_each, int K, const std::string& fold_norm = "") {
         std::vector<float> w, b;
         for (const auto& p : prefixes) {
             const auto* pw = get(p + ".weight", (size_t)n_each * K);
@@ -129,6 +135,26 @@ struct bofi_engine {
         }
         out->N = n_each * (int)prefixes.size();
         out->K = K;
+        if (!fold_norm.empty()) {
+            const auto* g = get(fold_norm + ".a_2", K);
+            const auto* bb = get(fold_norm + ".b_2", K);
+            if (!g || !bb) return BOFI_ERR_STATE;
+            std::vector<float> cs(out->N);
+            for (int n = 0; n < out->N; ++n) {
+                double c = b[n], s = 0.0;
+                float* row = w.data() + (size_t)n * K;
+                for (int k = 0; k < K; ++k) {
+                    c += (double)(*bb)[k] * (double)row[k];
+                    row[k] = row[k] * (*g)[k];
+                    float r = row[k];
+                    if (cfg.dtype == BOFI_DT_BF16) { uint32_t u = (uint32_t)host_bf16(r) << 16; std::memcpy(&r, &u, 4); }
+                    s += (double)r;
+                }
+                b[n] = (float)c;
+                cs[n] = (float)s;
+            }
+            ENG_OK(upload_f32(&out->cs, cs));
+        }
         ENG_OK(upload_t(&out->w, w));
         ENG_OK(upload_f32(&out->b, b));
         return BOFI_OK;
@@ -143,26 +169,70 @@ struct bofi_engine {
     }
 
     // ---- kernels -------------------------------------------------------------------------------
-    int linear(const void* x, int x_dtype, int ldx, const Lin& l, const float* residual, int ldr, void* y, int y_dtype,
-               int ldy, int M, int relu, const Norm* ln, const int* row_len, int rpg, bool early, hipStream_t s) {
-        if (ln) {
-            // pre-norm of SublayerConnection (TransformerModel.py:1361-1363): LayerNorm kernel into the
-            // compute-dtype scratch, then the LDS-DMA GEMM reads it
+    struct LinOpt {
+        const float* residual = nullptr; int ldr = 0;
+        int relu = 0;
+        const int* row_len = nullptr; int rpg = 0;
+        bool early = false;
+        const Norm* ln = nullptr;            // explicit LayerNorm kernel on x first (setup-time use only)
+        const float* ln_stats = nullptr;     // LayerNorm folded into the GEMM (Lin built with fold_norm)
+        float* stats_out = nullptr;          // emit row partial sums of the output
+        void* y2 = nullptr;                  // compute-dtype copy of the output
+    };
+    int linear(const void* x, int x_dtype, int ldx, const Lin& l, void* y, int y_dtype, int ldy, int M, const LinOpt& o, hipStream_t s) {
+        if (o.ln) {
             if (x_dtype != BOFI_DT_F32 || ldx != l.K) return BOFI_ERR_ARG;
-            int rc = bofi::launch_layernorm((const float*)x, ln->g, ln->b, xn, cfg.dtype, M, l.K, s,
-                                            early ? st.counters : nullptr, cur_B);
+            int rc = bofi::launch_layernorm((const float*)x, o.ln->g, o.ln->b, xn, cfg.dtype, M, l.K, s, nullptr, 0);
             if (rc != BOFI_OK) return rc;
-            x = xn; x_dtype = cfg.dtype; ln = nullptr;
+            x = xn; x_dtype = cfg.dtype;
         }
+        if (o.ln_stats && !l.cs) return BOFI_ERR_STATE;
         bofi::LinearArgs a{};
         a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = l.w; a.w_dtype = cfg.dtype; a.bias = l.b;
-        a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy;
-        a.M = M; a.N = l.N; a.K = l.K; a.relu = relu; a.row_len = row_len; a.rows_per_group = rpg;
-        if (ln) { a.ln_gain = ln->g; a.ln_bias = ln->b; }
-        if (early) { a.skip_if_ge = st.counters; a.skip_threshold = cur_B; }
+        a.residual = o.residual; a.ldr = o.ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy;
+        a.M = M; a.N = l.N; a.K = l.K; a.relu = o.relu; a.row_len = o.row_len; a.rows_per_group = o.rpg;
+        a.ln_stats = o.ln_stats; a.ln_colsum = o.ln_stats ? l.cs : nullptr;
+        a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N;
+        if (o.early) { a.skip_if_ge = st.counters; a.skip_threshold = cur_B; }
         return bofi::launch_linear(a, s);
     }
+    // residual stream in the compute dtype: the fp32 engine reads the stream itself
+    const void* stream_t(const float* x32, const void* xt) const { return cfg.dtype == BOFI_DT_F32 ? (const void*)x32 : xt; }
+    void* copy_t(void* xt) const { return cfg.dtype == BOFI_DT_F32 ? nullptr : xt; }
     int cur_B = 0;
+    bool is_fork = false;
+    size_t n_weight_allocs = 0;          // allocs[0 .. n) are weights (owned by the parent), the rest workspace
+
+    // workspace of one in-flight decode (a forked engine has its own, and shares the weights)
+    int alloc_workspace() {
+    const bofi_config_t& c = cfg;
+    const size_t Bm = c.max_batch, Rm = c.max_regions, Sq = c.seq_length;
+    const int d = c.d_model, dff = c.d_ff;
+    const size_t rows = Bm * (Rm > Sq ? Rm : Sq);
+    ENG_OK(dalloc(&x_enc, Bm * Rm * d));
+    ENG_OK(dalloc(&x_fill, Bm * Sq * d));
+    ENG_OK(dalloc(&logits, Bm * Sq * c.vocab));
+    ENG_OK(dalloc((char**)&qkv, rows * 3 * d, tsz));
+    ENG_OK(dalloc((char**)&ctx, rows * d, tsz));
+    ENG_OK(dalloc((char**)&hdn, rows * dff, tsz));
+    ENG_OK(dalloc((char**)&mem, Bm * Rm * d, tsz));
+    ENG_OK(dalloc((char**)&kv, Bm * Rm * (size_t)kv_all.N, tsz));
+    ENG_OK(dalloc((char**)&qs, Bm * Sq * d, tsz));
+    ENG_OK(dalloc((char**)&xn, (rows > (size_t)L * 10 ? rows : (size_t)L * 10) * d, tsz));
+    ENG_OK(dalloc((char**)&xb_enc, Bm * Rm * d, tsz)); ENG_OK(dalloc((char**)&xb_fill, Bm * Sq * d, tsz));
+    ENG_OK(dalloc((char**)&byb, Bm * d, tsz));
+    if (c.dtype == BOFI_DT_BF16) ENG_OK(dalloc((char**)&feats_t, Bm * Rm * (size_t)c.feat, 2));
+    ENG_OK(dalloc(&st_enc, Bm * Rm * (d / 32) * 2)); ENG_OK(dalloc(&st_fill, Bm * Sq * (d / 32) * 2));
+    ENG_OK(dalloc(&st_b, Bm * (d / 32) * 2));
+    ENG_OK(dalloc(&by1, Bm * d)); ENG_OK(dalloc(&by2, Bm * d)); ENG_OK(dalloc(&by3, Bm * d));
+    ENG_OK(dalloc((char**)&bctx, Bm * d, tsz)); ENG_OK(dalloc((char**)&bq2, Bm * d, tsz));
+    ENG_OK(dalloc((char**)&bctx2, Bm * d, tsz)); ENG_OK(dalloc((char**)&bh, Bm * dff, tsz));
+    ENG_OK(dalloc(&st.last, Bm)); ENG_OK(dalloc(&st.finished, Bm)); ENG_OK(dalloc(&st.phrase_num, Bm));
+    ENG_OK(dalloc(&st.phrase_length, Bm * L)); ENG_OK(dalloc(&st.phrase_syn, Bm * L));
+    ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 4));
+
+        return BOFI_OK;
+    }
 
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
@@ -177,23 +247,35 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
                                 hipStream_t s) {
     const int d = cfg.d_model, dt = cfg.dtype, M = B * R;
     cur_B = B;
-    // att_embed: Linear + ReLU, rows past an image's region count forced to 0 (AttModel.py:46-51)
-    ENG_OK(linear(feats, feats_dtype, cfg.feat, att_embed, nullptr, 0, x_enc, BOFI_DT_F32, d, M, 1, nullptr, att_len, R, false, s));
+    // The residual stream x_enc stays float32; every GEMM that closes a sublayer also writes a copy in
+    // the compute dtype (xb_enc) and per-row partial sums (st_enc), from which the next pre-norm
+    // LayerNorm is applied inside the consuming GEMM's epilogue (no LayerNorm launches).
+    if (feats_dtype != dt) {                         // float32 features into a bf16 engine: one conversion pass
+        ENG_OK(bofi::launch_cast_bf16((const float*)feats, feats_t, (size_t)M * cfg.feat, s));
+        feats = feats_t; feats_dtype = dt;
+    }
+    {   // att_embed: Linear + ReLU, rows past an image's region count forced to 0 (AttModel.py:46-51)
+        LinOpt o; o.relu = 1; o.row_len = att_len; o.rpg = R; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
+        ENG_OK(linear(feats, feats_dtype, cfg.feat, att_embed, x_enc, BOFI_DT_F32, d, M, o, s));
+    }
+    const void* xa = stream_t(x_enc, xb_enc);
     for (auto& l : enc) {
-        ENG_OK(linear(x_enc, BOFI_DT_F32, d, l.qkv, nullptr, 0, qkv, dt, 3 * d, M, 0, &l.n0, nullptr, 0, false, s));
+        { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
         a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
         ENG_OK(bofi::launch_attention(a, s));
-        ENG_OK(linear(ctx, dt, d, l.o, x_enc, d, x_enc, BOFI_DT_F32, d, M, 0, nullptr, nullptr, 0, false, s));
-        ENG_OK(linear(x_enc, BOFI_DT_F32, d, l.w1, nullptr, 0, hdn, dt, cfg.d_ff, M, 1, &l.n1, nullptr, 0, false, s));
-        ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_enc, d, x_enc, BOFI_DT_F32, d, M, 0, nullptr, nullptr, 0, false, s));
+        { LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
+          ENG_OK(linear(ctx, dt, d, l.o, x_enc, BOFI_DT_F32, d, M, o, s)); }
+        { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+        { LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
+          ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_enc, BOFI_DT_F32, d, M, o, s)); }
     }
-    ENG_OK(bofi::launch_layernorm(x_enc, enc_norm.g, enc_norm.b, mem, dt, M, d, s));
     if (memory_out) ENG_OK(bofi::launch_layernorm(x_enc, enc_norm.g, enc_norm.b, memory_out, BOFI_DT_F32, M, d, s));
-    // cross-attention K|V of the bound layer and of every decoder layer in one GEMM
-    ENG_OK(linear(mem, dt, d, kv_all, nullptr, 0, kv, dt, kv_all.N, M, 0, nullptr, nullptr, 0, false, s));
+    // cross-attention K|V of the bound layer and of every decoder layer in one GEMM on memory =
+    // encoder.norm(x_enc), the norm folded in
+    { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, kv_all, kv, dt, kv_all.N, M, o, s)); }
     return BOFI_OK;
 }
 
@@ -203,18 +285,21 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     // previous launch_bound_tail(..., BOUND_ATTN).
     const int d = cfg.d_model, dt = cfg.dtype;
     cur_B = B;
-    // y1 = x0 + (Wo ctx + bo): the row-0 residual input is the same vector for every image (ldr = 0)
-    ENG_OK(linear(bctx, dt, d, b_o_self, b_x0, 0, by1, BOFI_DT_F32, d, B, 0, nullptr, nullptr, 0, early, s));
-    ENG_OK(linear(by1, BOFI_DT_F32, d, b_q_src, nullptr, 0, bq2, dt, d, B, 0, &b_n1, nullptr, 0, early, s));
+    {   // y1 = x0 + (Wo ctx + bo): the row-0 residual input is the same vector for every image (ldr = 0)
+        LinOpt o; o.residual = b_x0; o.ldr = 0; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
+        ENG_OK(linear(bctx, dt, d, b_o_self, by1, BOFI_DT_F32, d, B, o, s));
+    }
+    { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
     bofi::AttnArgs a{};
     a.q = bq2; a.ldq = d; a.k = kv; a.v = (char*)kv + (size_t)d * tsz; a.ldk = a.ldv = kv_all.N;
     a.out = bctx2; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = R;
     a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
     if (early) { a.skip_if_ge = st.counters; a.skip_threshold = B; }
     ENG_OK(bofi::launch_attention(a, s));
-    ENG_OK(linear(bctx2, dt, d, b_o_src, by1, d, by2, BOFI_DT_F32, d, B, 0, nullptr, nullptr, 0, early, s));
-    ENG_OK(linear(by2, BOFI_DT_F32, d, b_w1, nullptr, 0, bh, dt, cfg.d_ff, B, 1, &b_n2, nullptr, 0, early, s));
-    ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by2, d, by3, BOFI_DT_F32, d, B, 0, nullptr, nullptr, 0, early, s));
+    { LinOpt o; o.residual = by1; o.ldr = d; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
+      ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
+    { LinOpt o; o.relu = 1; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
+    { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
     // heads + bookkeeping, fused with the next iteration's row-0 self-attention
     const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
     ENG_OK(bofi::launch_bound_tail(by3, heads, st, update ? nullptr : ext_syn, update ? nullptr : last, b_q0, b_kvtab, bctx, dt, B, L,
@@ -234,10 +319,12 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     for (int it = 0; it < S; ++it)
         ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     // ---- filling pass (decode_NA :570-587)
-    ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, nullptr, B, S, L, d, cfg.bos_idx, x_fill, s));
+    ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
+                                   st_fill, s));
+    const void* xa = stream_t(x_fill, xb_fill);
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
-        ENG_OK(linear(x_fill, BOFI_DT_F32, d, l.qkv, nullptr, 0, qkv, dt, 3 * d, M, 0, &l.n0, nullptr, 0, false, s));
+        { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
@@ -245,21 +332,24 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
         a.klen = st.last; a.klen_sb = 1; a.klen_sq = 0; a.klen_bias = -1;
         a.klen_shared_last = (flags & BOFI_FLAG_STRICT_Q1) ? 1 : 0;
         ENG_OK(bofi::launch_attention(a, s));
-        ENG_OK(linear(ctx, dt, d, l.o, x_fill, d, x_fill, BOFI_DT_F32, d, M, 0, nullptr, nullptr, 0, false, s));
-        ENG_OK(linear(x_fill, BOFI_DT_F32, d, l.q_src, nullptr, 0, qs, dt, d, M, 0, &l.n1, nullptr, 0, false, s));
+        { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+          ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s)); }
+        { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
         bofi::AttnArgs c{};
         c.q = qs; c.ldq = d;
         c.k = (char*)kv + (size_t)(1 + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(1 + li) * 2 * d + d) * tsz;
         c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
         c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0;
         ENG_OK(bofi::launch_attention(c, s));
-        ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, d, x_fill, BOFI_DT_F32, d, M, 0, nullptr, nullptr, 0, false, s));
-        ENG_OK(linear(x_fill, BOFI_DT_F32, d, l.w1, nullptr, 0, hdn, dt, cfg.d_ff, M, 1, &l.n2, nullptr, 0, false, s));
-        ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, d, x_fill, BOFI_DT_F32, d, M, 0, nullptr, nullptr, 0, false, s));
+        { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+          ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, BOFI_DT_F32, d, M, o, s)); }
+        { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+        { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+          ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
     }
-    // ---- vocabulary projection, log-softmax, greedy pick, pad tail
+    // ---- vocabulary projection (decoder.norm folded in), log-softmax, greedy pick, pad tail
     float* lg = seq_logprob ? seq_logprob : logits;
-    ENG_OK(linear(x_fill, BOFI_DT_F32, d, gen, nullptr, 0, lg, BOFI_DT_F32, cfg.vocab, M, 0, &dec_norm, nullptr, 0, false, s));
+    { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s)); }
     ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s));
     ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
     return BOFI_OK;
@@ -275,7 +365,7 @@ int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
     if (!c || !out) return fail(BOFI_ERR_ARG, "null argument");
     if (c->dtype != BOFI_DT_F32 && c->dtype != BOFI_DT_BF16) return fail(BOFI_ERR_ARG, "dtype must be 0 (f32) or 1 (bf16)");
     if (c->heads <= 0 || c->d_model != c->heads * 64) return fail(BOFI_ERR_ARG, "d_model / heads must be 64");
-    if (c->d_model % 64 || c->d_ff % 64 || c->feat % 64) return fail(BOFI_ERR_ARG, "d_model, d_ff, feat must be multiples of 64");
+    if (c->d_model % 128 || c->d_ff % 64 || c->feat % 64) return fail(BOFI_ERR_ARG, "d_model must be a multiple of 128, d_ff and feat of 64");
     if (c->seq_length <= 0 || c->seq_length + 2 > 64) return fail(BOFI_ERR_ARG, "seq_length must be in 1..62");
     if (c->max_batch <= 0 || c->max_regions <= 0 || c->max_regions > 128) return fail(BOFI_ERR_ARG, "max_batch > 0, 0 < max_regions <= 128");
     if (c->vocab <= 0 || c->n_enc < 0 || c->n_dec < 0 || c->head_hidden <= 0) return fail(BOFI_ERR_ARG, "bad layer/vocab counts");
@@ -298,8 +388,27 @@ void bofi_engine_destroy(bofi_engine_t* e) {
     delete e;
 }
 
+int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
+    g_err.clear();
+    if (!parent || !out) return fail(BOFI_ERR_ARG, "null argument");
+    if (!parent->finalized) return fail(BOFI_ERR_STATE, "fork needs a finalized engine");
+    auto* e = new bofi_engine(*parent);          // copies config and every weight pointer
+    e->host.clear();
+    e->allocs.clear();                           // owns nothing of the parent's
+    e->graphs.clear();
+    e->cap_stream = nullptr;
+    e->is_fork = true;
+    e->st = bofi::BoundState{};
+    int rc = e->alloc_workspace();
+    if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
+    if (rc != BOFI_OK) { bofi_engine_destroy(e); return rc; }
+    *out = e;
+    return BOFI_OK;
+}
+
 int bofi_engine_set_weight(bofi_engine_t* e, const char* name, const float* data, int64_t numel) {
     if (!e || !name || !data || numel < 0) return fail(BOFI_ERR_ARG, "null argument");
+    if (e->is_fork) return fail(BOFI_ERR_STATE, "weights belong to the parent engine");
     e->host[name].assign(data, data + numel);
     e->finalized = false;
     return BOFI_OK;
@@ -308,6 +417,7 @@ int bofi_engine_set_weight(bofi_engine_t* e, const char* name, const float* data
 int bofi_engine_finalize(bofi_engine_t* e) {
     if (!e) return fail(BOFI_ERR_ARG, "null engine");
     g_err.clear();
+    if (e->is_fork) return fail(BOFI_ERR_STATE, "finalize the parent engine, then fork again");
     const bofi_config_t& c = e->cfg;
     const int d = c.d_model, dff = c.d_ff, L = e->L, hh = c.head_hidden;
     // drop everything from a previous finalize (weights may have changed)
@@ -324,9 +434,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     for (int l = 0; l < c.n_enc; ++l) {
         auto& E = e->enc[l];
         const std::string p = S("model.encoder.layers.%d", l);
-        ENG_OK(e->make_lin(&E.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d));
+        ENG_OK(e->make_lin(&E.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
         ENG_OK(e->make_lin(&E.o, {p + ".self_attn.linears.3"}, d, d));
-        ENG_OK(e->make_lin(&E.w1, {p + ".feed_forward.w_1"}, dff, d));
+        ENG_OK(e->make_lin(&E.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.1.norm"));
         ENG_OK(e->make_lin(&E.w2, {p + ".feed_forward.w_2"}, d, dff));
         ENG_OK(e->make_norm(&E.n0, p + ".sublayer.0.norm", d));
         ENG_OK(e->make_norm(&E.n1, p + ".sublayer.1.norm", d));
@@ -337,11 +447,11 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     for (int l = 0; l < c.n_dec; ++l) {
         auto& D = e->dec[l];
         const std::string p = S("model.decoder.layers.%d", l);
-        ENG_OK(e->make_lin(&D.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d));
+        ENG_OK(e->make_lin(&D.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
         ENG_OK(e->make_lin(&D.o, {p + ".self_attn.linears.3"}, d, d));
-        ENG_OK(e->make_lin(&D.q_src, {p + ".src_attn.linears.0"}, d, d));
+        ENG_OK(e->make_lin(&D.q_src, {p + ".src_attn.linears.0"}, d, d, p + ".sublayer.1.norm"));
         ENG_OK(e->make_lin(&D.o_src, {p + ".src_attn.linears.3"}, d, d));
-        ENG_OK(e->make_lin(&D.w1, {p + ".feed_forward.w_1"}, dff, d));
+        ENG_OK(e->make_lin(&D.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.2.norm"));
         ENG_OK(e->make_lin(&D.w2, {p + ".feed_forward.w_2"}, d, dff));
         ENG_OK(e->make_norm(&D.n0, p + ".sublayer.0.norm", d));
         ENG_OK(e->make_norm(&D.n1, p + ".sublayer.1.norm", d));
@@ -350,8 +460,8 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         kvs.push_back(p + ".src_attn.linears.2");
     }
     ENG_OK(e->make_norm(&e->dec_norm, "model.decoder.norm", d));
-    ENG_OK(e->make_lin(&e->kv_all, kvs, d, d));
-    ENG_OK(e->make_lin(&e->gen, {"model.generator.proj"}, c.vocab, d));
+    ENG_OK(e->make_lin(&e->kv_all, kvs, d, d, "model.encoder.norm"));
+    ENG_OK(e->make_lin(&e->gen, {"model.generator.proj"}, c.vocab, d, "model.decoder.norm"));
     {
         const auto* ls = e->get("model.syn_embed.lut.weight", (size_t)10 * d);
         const auto* lt = e->get("model.tgt_embed.lut.weight", (size_t)c.vocab * d);
@@ -365,9 +475,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     }
     // bound layer
     ENG_OK(e->make_lin(&e->b_o_self, {bl + ".self_attn.linears.3"}, d, d));
-    ENG_OK(e->make_lin(&e->b_q_src, {bl + ".src_attn.linears.0"}, d, d));
+    ENG_OK(e->make_lin(&e->b_q_src, {bl + ".src_attn.linears.0"}, d, d, bl + ".sublayer.1.norm"));
     ENG_OK(e->make_lin(&e->b_o_src, {bl + ".src_attn.linears.3"}, d, d));
-    ENG_OK(e->make_lin(&e->b_w1, {bl + ".ff.w_1"}, dff, d));
+    ENG_OK(e->make_lin(&e->b_w1, {bl + ".ff.w_1"}, dff, d, bl + ".sublayer.2.norm"));
     ENG_OK(e->make_lin(&e->b_w2, {bl + ".ff.w_2"}, d, dff));
     ENG_OK(e->make_norm(&e->b_n0, bl + ".sublayer.0.norm", d));
     ENG_OK(e->make_norm(&e->b_n1, bl + ".sublayer.1.norm", d));
@@ -395,25 +505,8 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         e->heads = bofi::BoundHeadWeights{nf.g, nf.b, p_w1, p_b1, p_lw2, p_lb2, p_sw2, p_sb2};
     }
 
-    // workspace
-    const size_t Bm = c.max_batch, Rm = c.max_regions, Sq = c.seq_length;
-    const size_t rows = Bm * (Rm > Sq ? Rm : Sq);
-    ENG_OK(e->dalloc(&e->x_enc, Bm * Rm * d));
-    ENG_OK(e->dalloc(&e->x_fill, Bm * Sq * d));
-    ENG_OK(e->dalloc(&e->logits, Bm * Sq * c.vocab));
-    ENG_OK(e->dalloc((char**)&e->qkv, rows * 3 * d, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->ctx, rows * d, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->hdn, rows * dff, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->mem, Bm * Rm * d, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->kv, Bm * Rm * (size_t)e->kv_all.N, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->qs, Bm * Sq * d, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->xn, (rows > (size_t)L * 10 ? rows : (size_t)L * 10) * d, e->tsz));
-    ENG_OK(e->dalloc(&e->by1, Bm * d)); ENG_OK(e->dalloc(&e->by2, Bm * d)); ENG_OK(e->dalloc(&e->by3, Bm * d));
-    ENG_OK(e->dalloc((char**)&e->bctx, Bm * d, e->tsz)); ENG_OK(e->dalloc((char**)&e->bq2, Bm * d, e->tsz));
-    ENG_OK(e->dalloc((char**)&e->bctx2, Bm * d, e->tsz)); ENG_OK(e->dalloc((char**)&e->bh, Bm * dff, e->tsz));
-    ENG_OK(e->dalloc(&e->st.last, Bm)); ENG_OK(e->dalloc(&e->st.finished, Bm)); ENG_OK(e->dalloc(&e->st.phrase_num, Bm));
-    ENG_OK(e->dalloc(&e->st.phrase_length, Bm * L)); ENG_OK(e->dalloc(&e->st.phrase_syn, Bm * L));
-    ENG_OK(e->dalloc(&e->st.ext_syn, Bm * L)); ENG_OK(e->dalloc(&e->st.counters, 4));
+    e->n_weight_allocs = e->allocs.size();      // everything allocated so far is weights (shared with forks)
+    ENG_OK(e->alloc_workspace());
 
     // input-independent tables of the bound layer: layer input at (position p, label s) is
     // lut_syn[s]*sqrt(d) + pe[p]; K|V of all L*10 rows and the query of row 0 ([LEN] at position 0)
@@ -434,8 +527,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->make_lin(&qself, {bl + ".self_attn.linears.0"}, d, d));
         ENG_OK(e->dalloc((char**)&e->b_kvtab, (size_t)L * 10 * 2 * d, e->tsz));
         ENG_OK(e->dalloc((char**)&e->b_q0, (size_t)d, e->tsz));
-        ENG_OK(e->linear(d_xt, BOFI_DT_F32, d, kvself, nullptr, 0, e->b_kvtab, c.dtype, 2 * d, L * 10, 0, &e->b_n0, nullptr, 0, false, nullptr));
-        ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, qself, nullptr, 0, e->b_q0, c.dtype, d, 1, 0, &e->b_n0, nullptr, 0, false, nullptr));
+        bofi_engine::LinOpt o; o.ln = &e->b_n0;
+        ENG_OK(e->linear(d_xt, BOFI_DT_F32, d, kvself, e->b_kvtab, c.dtype, 2 * d, L * 10, o, nullptr));
+        ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, qself, e->b_q0, c.dtype, d, 1, o, nullptr));
         ENG_HIP(hipDeviceSynchronize());
     }
     if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));

@@ -50,6 +50,12 @@ struct Gemm2Params {
     int relu;
     const int* row_len; int rows_per_group;
     const int* skip_if_ge; int skip_threshold;
+    // folded pre-norm LayerNorm of the consumer: x is the RAW residual stream, w = W * gain, bias = c,
+    // y = rstd[m] * (acc - mean[m] * colsum[n]) + c[n]; mean/rstd come from per-32-column partial
+    // (sum, sum of squares) pairs written by the producer's epilogue
+    const float* ln_stats; const float* ln_colsum;
+    float* stats_out;         // this GEMM is a producer: partial (sum, sumsq) of its OUTPUT rows, [M][N/32][2]
+    void* y2; int ldy2;       // optional second copy of the output in the compute dtype
     int vec_ok;               // N, ldy, ldr multiples of 4 and y/bias/residual 16-byte aligned
     int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
 };
@@ -65,8 +71,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     constexpr int LA = BM / 32, LB = BN / 32;           // LDS-DMA instructions per wave per slab (A, B)
     constexpr int LPS = LA + LB;
     constexpr int EPI = BM * (BN + 4) * 4;              // epilogue staging, float32, +4 columns pad
-    constexpr int SMEM = (NS * STAGE > EPI) ? NS * STAGE : EPI;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    constexpr int SMEM_MAIN = (NS * STAGE > EPI) ? NS * STAGE : EPI;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_MAIN + BM * 8];
 
     if (p.skip_if_ge && *p.skip_if_ge >= p.skip_threshold) return;
     if (p.dbg & 4) return;
@@ -117,6 +123,25 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
+
+    // folded LayerNorm: row mean / 1/(std+eps) from the producer's partial sums.  Done first so that the
+    // L2 round trip overlaps the K loop; the two small arrays live past the ring and the epilogue tile.
+    float* s_mean = reinterpret_cast<float*>(smem + SMEM_MAIN);
+    float* s_rstd = s_mean + BM;
+    if (p.ln_stats && tid < BM) {
+        const int m = m0 + tid;
+        float sm = 0.f, sq = 0.f;
+        if (m < p.M) {
+            const int np4 = p.K >> 6;                  // two (sum, sumsq) pairs per 16-byte load
+            const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)m * np4;
+            for (int i = 0; i < np4; ++i) { const float4 t = sp[i]; sm += t.x + t.z; sq += t.y + t.w; }
+        }
+        const float mean = sm / (float)p.K;
+        const float var = fmaxf((sq - sm * mean) / (float)(p.K - 1), 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = 1.0f / (sqrtf(var) + 1e-6f);
+    }
+
 
     // fragment read offsets: tile row R = base + (lane & 15), wanted chunk g = 4*grp + (lane >> 4),
     // stored at chunk g ^ (R & 7); (base is a multiple of 16, so R & 7 == lane & 7)
@@ -173,6 +198,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
         const int n = n0 + lc;
         const bool ncol_ok = n < p.N;                  // N % 4 == 0: the four columns are in or out together
         const float4 bv = (p.bias && ncol_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 cs = (p.ln_stats && ncol_ok) ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 rv[NR];
         bool live[NR], zero[NR];
 #pragma unroll
@@ -190,11 +216,33 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
         for (int u = 0; u < NR; ++u) {
             const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
             float4 v = *reinterpret_cast<const float4*>(&es[r * ES + lc]);
+            if (p.ln_stats) {
+                const float mu = s_mean[r], rs = s_rstd[r];
+                v.x = rs * (v.x - mu * cs.x); v.y = rs * (v.y - mu * cs.y); v.z = rs * (v.z - mu * cs.z); v.w = rs * (v.w - mu * cs.w);
+            }
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (zero[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
             v.x = rv[u].x + v.x; v.y = rv[u].y + v.y; v.z = rv[u].z + v.z; v.w = rv[u].w + v.w;
+            if (p.stats_out) {                         // partial sums over this lane's aligned 32-column group (8 lanes)
+                float ps = live[u] ? (v.x + v.y) + (v.z + v.w) : 0.f;
+                float pq = live[u] ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+                if (live[u] && (lane & 7) == 0)
+                    reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 5) + (n >> 5)] = make_float2(ps, pq);
+            }
             if (!live[u]) continue;
+            if (p.y2) {
+                if constexpr (sizeof(T) == 2) {
+                    uint2 o;
+                    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y2) + (size_t)m * p.ldy2 + n) = o;
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(p.y2) + (size_t)m * p.ldy2 + n) = v;
+                }
+            }
             if (p.y_is_f32) {
                 *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)m * p.ldy + n) = v;
             } else if constexpr (sizeof(T) == 2) {
@@ -209,11 +257,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     // general case (e.g. the vocabulary projection, N = 9491, rows not 16-byte aligned): one float per lane
     constexpr int NC = (BN + 63) / 64;
     constexpr int NRS = BM / 4;
-    float bv[NC];
+    float bv[NC], cs[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int n = n0 + c * 64 + lane;
-        bv[c] = (p.bias && c * 64 + lane < BN && n < p.N) ? p.bias[n] : 0.f;
+        const bool ok = c * 64 + lane < BN && n < p.N;
+        bv[c] = (p.bias && ok) ? p.bias[n] : 0.f;
+        cs[c] = (p.ln_stats && ok) ? p.ln_colsum[n] : 0.f;
     }
     float rv[NRS][NC];
     bool zero[NRS];
@@ -237,7 +287,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int n = n0 + c * 64 + lane;
-            float v = es[r * ES + c * 64 + lane] + bv[c];
+            float v = es[r * ES + c * 64 + lane];
+            if (p.ln_stats) v = s_rstd[r] * (v - s_mean[r] * cs[c]);
+            v += bv[c];
             if (p.relu) v = fmaxf(v, 0.f);
             if (zero[u]) v = 0.f;
             v = rv[u][c] + v;
@@ -289,6 +341,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
 // is not eligible (the caller then uses the register-staged kernel of gemm.hip).
 int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     if (a.x_dtype != a.w_dtype || a.ln_gain) return -1;
+    if (a.ln_stats && (!a.ln_colsum || a.K % 64 || (uintptr_t)a.ln_stats % 16)) return BOFI_ERR_ARG;
     const int el = a.w_dtype == BOFI_DT_F32 ? 4 : 2;
     const int bk = 128 / el;
     if (a.K % bk || (a.ldx * el) % 16 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return -1;
@@ -297,11 +350,14 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.y = a.y; p.ldy = a.ldy; p.y_is_f32 = a.y_dtype == BOFI_DT_F32; p.M = a.M; p.N = a.N; p.K = a.K;
     p.relu = a.relu; p.row_len = a.row_len; p.rows_per_group = a.rows_per_group;
     p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
+    p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
     { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }
     const int yel = p.y_is_f32 ? 4 : el;
     p.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && ((uintptr_t)a.y * 0 + (size_t)a.ldy * yel) % 8 == 0 &&
                (!a.bias || (uintptr_t)a.bias % 16 == 0) &&
-               (!a.residual || (((uintptr_t)a.residual % 16 == 0) && (a.ldr % 4 == 0)));
+               (!a.residual || (((uintptr_t)a.residual % 16 == 0) && (a.ldr % 4 == 0))) &&
+               (!a.ln_colsum || (uintptr_t)a.ln_colsum % 16 == 0) && (!a.y2 || (((uintptr_t)a.y2 % 16 == 0) && a.ldy2 % 4 == 0));
+    if ((a.stats_out || a.y2) && (!p.vec_ok || a.N % 32)) return BOFI_ERR_ARG;
     return el == 4 ? launch_glds_t<float>(p, st) : launch_glds_t<bf16_t>(p, st);
 }
 

@@ -89,6 +89,25 @@ int launch_layernorm(const float* x, const float* gain, const float* bias, void*
     return BOFI_ERR_ARG;
 }
 
+// float32 -> bf16 copy (region features handed over in float32 to a bf16 engine); n % 4 == 0
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        ushort4 o;
+        o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+        reinterpret_cast<ushort4*>(y)[i] = o;
+    }
+}
+
+int launch_cast_bf16(const float* x, void* y, size_t n, hipStream_t st) {
+    if (!x || !y || n % 4) return BOFI_ERR_ARG;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, x, (bf16_t*)y, n4);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 }  // namespace bofi
 
 extern "C" int bofi_layernorm(const float* x, const float* gain, const float* bias, void* y, int y_dtype, int rows,

@@ -104,12 +104,18 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
         if (slice < 4) {
             const int k0 = slice * (d / 4), k1 = k0 + d / 4;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k) {
-                const float4 wv = *reinterpret_cast<const float4*>(w.w1t + (size_t)k * nh + grp * 4);
-                const float xv = xs[k];
-                acc.x = fmaf(wv.x, xv, acc.x); acc.y = fmaf(wv.y, xv, acc.y);
-                acc.z = fmaf(wv.z, xv, acc.z); acc.w = fmaf(wv.w, xv, acc.w);
+            // latency-bound weight stream: keep 32 independent 16-byte loads in flight per thread
+            for (int kb = k0; kb < k1; kb += 32) {
+                float4 wv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    wv[u] = (kb + u < k1) ? *reinterpret_cast<const float4*>(w.w1t + (size_t)(kb + u) * nh + grp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const float xv = (kb + u < k1) ? xs[kb + u] : 0.f;
+                    acc.x = fmaf(wv[u].x, xv, acc.x); acc.y = fmaf(wv[u].y, xv, acc.y);
+                    acc.z = fmaf(wv[u].z, xv, acc.z); acc.w = fmaf(wv[u].w, xv, acc.w);
+                }
             }
             *reinterpret_cast<float4*>(part + slice * nh + grp * 4) = acc;
         }
@@ -225,9 +231,11 @@ int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundStat
 // ------------------------------------------------------------------------------------------------
 // Fill-pass input: pos_embed(tgt_embed(word) + syn_embed(label)), each Embeddings scaled by sqrt(d)
 // (TransformerModel.py:576-577, 1486-1487, 1505-1507).  word = BOS everywhere unless tok != NULL.
-__global__ void embed_fill_kernel(const float* __restrict__ lut_tok, const float* __restrict__ lut_syn,
-                                  const float* __restrict__ pe, const int* __restrict__ ext_syn, const int64_t* tok, int B,
-                                  int S, int L, int d, int bos_idx, float sqrt_d, float* __restrict__ x) {
+template <typename T>
+__global__ __launch_bounds__(128) void embed_fill_kernel(const float* __restrict__ lut_tok, const float* __restrict__ lut_syn,
+                                                         const float* __restrict__ pe, const int* __restrict__ ext_syn,
+                                                         const int64_t* tok, int B, int S, int L, int d, int bos_idx, float sqrt_d,
+                                                         float* __restrict__ x, T* __restrict__ xt, float* __restrict__ stats) {
     const int row = blockIdx.x;                       // (b, t)
     const int b = row / S, t = row - b * S;
     const int syn = ext_syn[b * L + t + 1];           // extend_phrase_syn[:, 1:-1]
@@ -235,14 +243,29 @@ __global__ void embed_fill_kernel(const float* __restrict__ lut_tok, const float
     const float* tr = lut_tok + (size_t)word * d;
     const float* sr = lut_syn + (size_t)syn * d;
     const float* pr = pe + (size_t)t * d;
-    for (int k = threadIdx.x; k < d; k += blockDim.x) x[(size_t)row * d + k] = (tr[k] * sqrt_d + sr[k] * sqrt_d) + pr[k];
+    for (int k = threadIdx.x; k < d; k += 128) {      // d % 128 == 0: every 32-lane half handles one 32-column group
+        const float v = (tr[k] * sqrt_d + sr[k] * sqrt_d) + pr[k];
+        x[(size_t)row * d + k] = v;
+        if (xt) ElemOps<T>::store(xt + (size_t)row * d + k, v);
+        if (stats) {                                  // partial (sum, sumsq) per 32 columns, as the GEMM epilogues write them
+            float ps = v, pq = v * v;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+            if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
+        }
+    }
 }
 
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,
-                      int B, int S, int L, int d, int bos_idx, float* x, hipStream_t s) {
+                      int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s) {
+    if (d % 128) return BOFI_ERR_ARG;
     const float sqrt_d = (float)sqrt((double)d);
-    hipLaunchKernelGGL(embed_fill_kernel, dim3(B * S), dim3(128), 0, s, lut_tok, lut_syn, pe, ext_syn, tok, B, S, L, d, bos_idx,
-                       sqrt_d, x);
+    if (dtype == BOFI_DT_F32)
+        hipLaunchKernelGGL((embed_fill_kernel<float>), dim3(B * S), dim3(128), 0, s, lut_tok, lut_syn, pe, ext_syn, tok, B, S, L, d,
+                           bos_idx, sqrt_d, x, (float*)xt, stats);
+    else
+        hipLaunchKernelGGL((embed_fill_kernel<bf16_t>), dim3(B * S), dim3(128), 0, s, lut_tok, lut_syn, pe, ext_syn, tok, B, S, L, d,
+                           bos_idx, sqrt_d, x, (bf16_t*)xt, stats);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

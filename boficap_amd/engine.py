@@ -38,6 +38,18 @@ class BofiEngine:
             hip.check(self._lib.bofi_engine_create(C.byref(c), C.byref(self._h)), "bofi_engine_create")
         self._finalized = False
 
+    def fork(self) -> "BofiEngine":
+        """A second engine sharing this one's weights with its own workspace (one per in-flight batch)."""
+        if not self._finalized:
+            raise hip.BofiHipError("fork() needs loaded weights")
+        f = object.__new__(BofiEngine)
+        f.cfg, f.dtype, f.device, f.max_batch, f.max_regions = self.cfg, self.dtype, self.device, self.max_batch, self.max_regions
+        f._lib, f._finalized, f._parent = self._lib, True, self        # keeps the parent (weights) alive
+        f._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            hip.check(self._lib.bofi_engine_fork(self._h, C.byref(f._h)), "bofi_engine_fork")
+        return f
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

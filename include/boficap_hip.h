@@ -114,6 +114,12 @@ int bofi_engine_set_weight(bofi_engine_t* e, const char* name, const float* data
  * set_weight and precede decode; may be called again after weights change.  Synchronises. */
 int bofi_engine_finalize(bofi_engine_t* e);
 
+/* A second engine that SHARES the parent's packed weights and has its own workspace, so that several
+ * decodes can be in flight on different streams (the bounding loop is a latency chain that leaves most
+ * CUs idle; a batch in another stream fills them).  The parent must outlive its forks and must not be
+ * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
+int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
+
 #define BOFI_FLAG_STRICT_Q1 1      /* reproduce TransformerModel.py:1872-1873: every image's fill mask
                                       uses the LAST image's length.  Default ON in the Python wrapper. */
 #define BOFI_FLAG_RAW_LOGITS 2     /* output_logsoftmax = 0 (AttModel.py:208-209) */

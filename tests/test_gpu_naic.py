@@ -152,6 +152,30 @@ def test_full_batch_properties(engines, weight_cache):
         assert (a["seq_logprob"].cpu() - lp).abs().max() < 1e-3
 
 
+def test_forked_engines_in_flight(engines):
+    """Several decodes in flight on separate streams (engine forks sharing the weights) give exactly
+    the results of one-at-a-time decodes, for equal and for different inputs."""
+    from boficap_amd import weights as W
+    cfg, sd, eng = engines("full_b8", torch.bfloat16)
+    atts = [torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=500 + i)).cuda().to(torch.bfloat16) for i in range(3)]
+    ref = [eng.decode_naic(a) for a in atts]
+    torch.cuda.synchronize()
+    forks = [eng, eng.fork(), eng.fork()]
+    streams = [torch.cuda.Stream() for _ in forks]
+    outs = [None] * 3
+    for rep in range(4):                                   # first round captures the graphs, later ones replay
+        for k, (e, st) in enumerate(zip(forks, streams)):
+            with torch.cuda.stream(st):
+                outs[k] = e.decode_naic(atts[k], graph=True, out=outs[k])
+    torch.cuda.synchronize()
+    for r, o in zip(ref, outs):
+        for key in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
+            assert torch.equal(r[key], o[key]), key
+        assert torch.equal(r["seq_logprob"].isnan(), o["seq_logprob"].isnan())
+        assert (r["seq_logprob"] - o["seq_logprob"]).nan_to_num().abs().max() == 0
+    del forks, outs
+
+
 def test_drop_in_module_sample(weight_cache, manifest):
     """captioning.models.setup(opt) -> load_state_dict -> model(..., mode='sample'): the 6-tuple."""
     import captioning.models as models
