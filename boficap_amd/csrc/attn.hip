@@ -10,6 +10,8 @@
 // QK^T and PV run on MFMA (16x16x32 bf16, or exact-f32 16x16x4), the softmax runs in float32 with
 // 4 lanes per row and wave shuffles.  A row whose length is 0 produces NaN, as softmax over all
 // -inf does in the reference (this is what quirk Q1's empty-last-row batch relies on).
+#include <cstdlib>
+
 #include "bofi_common.h"
 #include "bofi_kernels.h"
 
@@ -198,6 +200,10 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     if (a.dtype != BOFI_DT_F32 && a.dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
     if ((a.ldq * el) % 16 || (a.ldk * el) % 16 || (a.ldv * el) % 16) return BOFI_ERR_ARG;
     if (((uintptr_t)a.q % 16) || ((uintptr_t)a.k % 16) || ((uintptr_t)a.v % 16)) return BOFI_ERR_ARG;
+    if (!getenv("BOFI_ATTN_GENERIC")) {                 // bf16, <= 64 keys: the register-resident kernel
+        const int rc = launch_attention_bf16(a, st);
+        if (rc >= 0) return rc;
+    }
     AttnParams p;
     p.q = a.q; p.ldq = a.ldq; p.k = a.k; p.ldk = a.ldk; p.v = a.v; p.ldv = a.ldv; p.out = a.out; p.ldo = a.ldo;
     p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;

@@ -1,0 +1,204 @@
+// bf16 attention core for the short sequences of the bound+fill path -- the throughput kernel
+// (attn.hip is the generic one: f32 engine, > 64 keys).  Same contract as attn.hip:
+//   softmax(q k^T / 8, key-prefix mask per query row) v,  d_k = 64,  NaN for a fully masked row
+// (reference attention() captioning/models/TransformerModel.py:1421-1432).
+//
+// One wavefront per (image, head, <=48-query block); everything between the staging loads and the
+// output store stays in registers:
+//   * S^T = K Q^T on MFMA with the KEY on the accumulator rows ("swapped QK^T"): a lane then holds,
+//     for its query column, 4 keys per 16-key tile, so the row softmax is an in-register reduction
+//     plus two cross-lane steps (xor 16, 32) -- no score matrix in LDS.
+//   * The probabilities feed the second MFMA straight from those registers: O^T = V^T P^T, where the
+//     k index of the instruction is mapped to keys exactly as the accumulator holds them
+//     (slot j of lane group g = key 16*(2s + j/4) + 4g + j%4), and the V^T fragments come from the
+//     row-major V tile with the transposing LDS read ds_read_b64_tr_b16 (no transposed staging).
+//   * Output: a lane holds 4 consecutive d of one query row -> one 8-byte store.
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+struct AttnParamsB {
+    const bf16_t* q; int ldq;
+    const bf16_t* k; int ldk;
+    const bf16_t* v; int ldv;
+    bf16_t* out; int ldo;
+    int B, H, Lq, Lk;
+    const int* klen; int klen_sb, klen_sq, klen_bias, klen_shared_last;
+    const int* skip_if_ge; int skip_threshold;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int AROW = 72;          // LDS row stride in elements: 64 + 8 pad (144 B: conflict-free b128 fragment reads)
+
+template <int NQT, int NKT>       // 16-row query tiles per block, 16-key tiles (even)
+__global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
+    static_assert(NKT % 2 == 0, "keys are consumed 32 at a time");
+    __shared__ __attribute__((aligned(16))) bf16_t sq[NQT * 16 * AROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sk[NKT * 16 * AROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sv[NKT * 16 * AROW];
+
+    if (p.skip_if_ge && *p.skip_if_ge >= p.skip_threshold) return;
+    const int lane = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.y * (NQT * 16);
+    const int nq = min(NQT * 16, p.Lq - q0);
+    const int Lk = p.Lk;
+
+    // ---- stage Q, K, V head slices (16-byte chunks; rows past the data are zero)
+    const bf16_t* qg = p.q + ((size_t)b * p.Lq + q0) * p.ldq + h * 64;
+    const bf16_t* kg = p.k + (size_t)b * Lk * p.ldk + h * 64;
+    const bf16_t* vg = p.v + (size_t)b * Lk * p.ldv + h * 64;
+    const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = lane; c < NQT * 16 * 8; c += 64) {
+        const int r = c >> 3, ch = c & 7;
+        *reinterpret_cast<u32x4*>(&sq[r * AROW + ch * 8]) = r < nq ? *reinterpret_cast<const u32x4*>(qg + (size_t)r * p.ldq + ch * 8) : zero4;
+    }
+#pragma unroll
+    for (int c = lane; c < NKT * 16 * 8; c += 64) {
+        const int r = c >> 3, ch = c & 7;
+        const bool ok = r < Lk;
+        *reinterpret_cast<u32x4*>(&sk[r * AROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(kg + (size_t)r * p.ldk + ch * 8) : zero4;
+        *reinterpret_cast<u32x4*>(&sv[r * AROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * p.ldv + ch * 8) : zero4;
+    }
+    __syncthreads();
+
+    const int l15 = lane & 15, g = lane >> 4;
+    // ---- S^T[key][q] = K Q^T: A = K rows (key on the MFMA row), B = Q rows (query on the column)
+    bf16x8 bq[NQT][2];
+#pragma unroll
+    for (int qi = 0; qi < NQT; ++qi)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bq[qi][s] = *reinterpret_cast<const bf16x8*>(&sq[(qi * 16 + l15) * AROW + s * 32 + g * 8]);
+    f32x4 st[NKT][NQT];
+#pragma unroll
+    for (int kj = 0; kj < NKT; ++kj) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&sk[(kj * 16 + l15) * AROW + g * 8]);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&sk[(kj * 16 + l15) * AROW + 32 + g * 8]);
+#pragma unroll
+        for (int qi = 0; qi < NQT; ++qi) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[qi][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[qi][1], c, 0, 0, 0);
+            st[kj][qi] = c;
+        }
+    }
+
+    // ---- softmax over keys per query column; lane holds keys kj*16 + g*4 + r
+    bf16x8 bp[NQT][NKT / 2];
+#pragma unroll
+    for (int qi = 0; qi < NQT; ++qi) {
+        const int qrow = qi * 16 + l15;
+        int kl = Lk;
+        if (p.klen && qrow < nq) {
+            const int bi = p.klen_shared_last ? (p.B - 1) : b;
+            kl = p.klen[bi * p.klen_sb + (q0 + qrow) * p.klen_sq] + p.klen_bias;
+            kl = max(0, min(kl, Lk));
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kj = 0; kj < NKT; ++kj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv_ = (kj * 16 + g * 4 + r < kl) ? st[kj][qi][r] * 0.125f : -INFINITY;
+                st[kj][qi][r] = sv_;
+                m = fmaxf(m, sv_);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kj = 0; kj < NKT; ++kj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (kj * 16 + g * 4 + r < kl) ? expf(st[kj][qi][r] - m) : 0.f;
+                st[kj][qi][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // an empty row gives 0/0 = NaN for every key, as softmax over all -inf does in the reference
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s) {
+            bf16x8 f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kj = 2 * s + (j >> 2), r = j & 3;
+                float pv = st[kj][qi][r] / sum;
+                if (kl == 0 && kj * 16 + g * 4 + r >= Lk) pv = 0.f;      // padded keys of an empty row: V is 0 there
+                f[j] = (short)f32_to_bf16(pv);
+            }
+            bp[qi][s] = f;
+        }
+    }
+
+    // ---- O^T[d][q] = V^T P^T: A = V^T via the transposing read of the row-major V tile
+    f32x4 ot[4][NQT];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qi = 0; qi < NQT; ++qi) ot[dt][qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = l15 >> 2, tp = l15 & 3;            // lane 4q'+p' of its 16-lane group addresses row q', columns 4p'..4p'+3
+#pragma unroll
+    for (int s = 0; s < NKT / 2; ++s) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16_t* a0p = &sv[(32 * s + 4 * g + tq) * AROW + dt * 16 + 4 * tp];
+            const bf16_t* a1p = a0p + 16 * AROW;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1p);
+            bf16x8 av;
+            av[0] = lo[0]; av[1] = lo[1]; av[2] = lo[2]; av[3] = lo[3];
+            av[4] = hi[0]; av[5] = hi[1]; av[6] = hi[2]; av[7] = hi[3];
+#pragma unroll
+            for (int qi = 0; qi < NQT; ++qi) ot[dt][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bp[qi][s], ot[dt][qi], 0, 0, 0);
+        }
+    }
+
+    // ---- store: lane holds O[q = qi*16 + l15][d = dt*16 + g*4 + 0..3]
+    bf16_t* og = p.out + ((size_t)b * p.Lq + q0) * p.ldo + h * 64;
+#pragma unroll
+    for (int qi = 0; qi < NQT; ++qi) {
+        const int qrow = qi * 16 + l15;
+        if (qrow >= nq) continue;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(ot[dt][qi][0]) | ((uint32_t)f32_to_bf16(ot[dt][qi][1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(ot[dt][qi][2]) | ((uint32_t)f32_to_bf16(ot[dt][qi][3]) << 16);
+            *reinterpret_cast<uint2*>(og + (size_t)qrow * p.ldo + dt * 16 + g * 4) = o;
+        }
+    }
+}
+
+template <int NQT, int NKT>
+static void launch_ab(const AttnParamsB& p, hipStream_t st) {
+    const dim3 grid(p.B * p.H, (p.Lq + NQT * 16 - 1) / (NQT * 16));
+    hipLaunchKernelGGL((attn_bf16_kernel<NQT, NKT>), grid, dim3(64), 0, st, p);
+}
+
+// returns -1 when the call is not eligible (then attn.hip handles it)
+int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
+    if (a.dtype != BOFI_DT_BF16 || a.Lk > 64 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
+    AttnParamsB p;
+    p.q = (const bf16_t*)a.q; p.ldq = a.ldq; p.k = (const bf16_t*)a.k; p.ldk = a.ldk; p.v = (const bf16_t*)a.v; p.ldv = a.ldv;
+    p.out = (bf16_t*)a.out; p.ldo = a.ldo; p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;
+    p.klen = a.klen; p.klen_sb = a.klen_sb; p.klen_sq = a.klen_sq; p.klen_bias = a.klen_bias;
+    p.klen_shared_last = a.klen_shared_last; p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
+    const int nkt = a.Lk <= 32 ? 2 : 4;
+    const int nqt = a.Lq <= 16 ? 1 : (a.Lq <= 32 ? 2 : 3);
+    switch (nqt * 10 + nkt) {
+        case 12: launch_ab<1, 2>(p, st); break;
+        case 14: launch_ab<1, 4>(p, st); break;
+        case 22: launch_ab<2, 2>(p, st); break;
+        case 24: launch_ab<2, 4>(p, st); break;
+        case 32: launch_ab<3, 2>(p, st); break;
+        default: launch_ab<3, 4>(p, st); break;
+    }
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+}  // namespace bofi

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
     float* lg = hid + nh;             // [32] logits: 0..19 length, 20..29 label
     float* red = lg + 32;             // [8]
     int* sint = reinterpret_cast<int*>(red + 8);   // [0] = last, [1] = finished, [2..2+L) = ext_syn row
+    float* w2s = red + 8 + 64;        // [30][hh] output layers of both heads, staged once (coalesced)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* ext_src = ext_syn_in ? ext_syn_in : st.ext_syn;
     const int* last_src = last_in ? last_in : st.last;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
     if (tid == 0) { sint[0] = last_src[b]; sint[1] = (flags & BOUND_UPDATE) ? st.finished[b] : 0; }
 
     if (flags & BOUND_HEADS) {
+        for (int i = tid; i < 30 * hh; i += 256) w2s[i] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
         const float* yr = y + (size_t)b * d;
         float s = 0.f;
         for (int k = tid; k < d; k += 256) s += yr[k];
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
         __syncthreads();
         if (tid < 30) {
             const bool is_len = tid < 20;
-            const float* wr = is_len ? (w.len_w2 + tid * hh) : (w.syn_w2 + (tid - 20) * hh);
+            const float* wr = w2s + tid * hh;
             const float* hv = is_len ? hid : (hid + hh);
             float acc = 0.f;
             for (int k = 0; k < hh; ++k) acc = fmaf(wr[k], hv[k], acc);
@@ -204,10 +206,18 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
         const float sum = wave_sum(e);
         const float pr = ElemOps<T>::to_f32(ElemOps<T>::from_f32(e / sum));     // P is held in compute dtype, as in attn.hip
         float o = 0.f;
-        for (int j = 0; j < n; ++j) {
-            const float pj = __shfl(pr, j, 64);
-            const int rj = __shfl(row, j, 64);
-            o = fmaf(pj, ElemOps<T>::to_f32(kvtab[(size_t)rj * 2 * d + d + h * 64 + lane]), o);
+        for (int j0 = 0; j0 < n; j0 += 8) {            // 8 independent loads in flight (n <= L <= 60)
+            T vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rj = __shfl(row, min(j0 + u, 63), 64);
+                vv[u] = kvtab[(size_t)rj * 2 * d + d + h * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float pj = __shfl(pr, min(j0 + u, 63), 64);
+                if (j0 + u < n) o = fmaf(pj, ElemOps<T>::to_f32(vv[u]), o);
+            }
         }
         ElemOps<T>::store(ctx + (size_t)b * d + h * 64 + lane, o);
     }
@@ -217,7 +227,7 @@ int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundStat
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
                       float* len_logp, float* syn_logp, hipStream_t s) {
     if ((2 * hh) % 4 || d % 4 || 2 * hh * 4 / 4 > 256 * 4 || L > 60) return BOFI_ERR_ARG;
-    const size_t shm = (size_t)(d + 4 * 2 * hh + 2 * hh + 32 + 8 + 64) * sizeof(float);
+    const size_t shm = (size_t)(d + 4 * 2 * hh + 2 * hh + 32 + 8 + 64 + 30 * hh) * sizeof(float);
     if (dtype == BOFI_DT_F32)
         hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(256), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
                            (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
