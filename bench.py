@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ids-only", action="store_true", help="do not materialise the [B,20,V] log-prob tensor")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1, help="decodes in flight on separate HIP streams (engine forks sharing the weights)")
+    ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
+                    "1 = strictly one decode at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -147,6 +148,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # for the record: the same K steps strictly one at a time (latency view of the same workload)
+    single_ms = None
+    if len(engines) > 1:
+        for i in range(args.warmup):
+            eng.decode_naic(att, graph=graph, out=outs[0])
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eng.decode_naic(att, graph=graph, out=outs[0])
+        barrier()
+        single_ms = (time.perf_counter() - t1) / args.steps * 1e3
     T = int(out["bound_iters"].item())
     ntok = float(out["phrase_length"].sum(1).float().mean().item())
     nan = bool(out["seq_logprob"].isnan().any().item()) if out["seq_logprob"] is not None else False
@@ -163,11 +175,13 @@ def main():
                        "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
                        "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
                        "decodes_in_flight": len(engines),
+                       "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                        "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
                        "att_feats_seed": ATT_SEED, "nan_in_output": nan, "sharding": "images by rank, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None,
-                         "kernel": "whole decode = one hipGraph launch of the path's kernels" if graph else "whole decode (eager launches)",
+                         "kernel": ("whole decode = one hipGraph launch of the path's kernels" if graph else "whole decode (eager launches)")
+                                   + (f", {len(engines)} decodes in flight" if len(engines) > 1 else ""),
                          "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
                          "note": "algorithmic FLOPs F_alg(T)*batch (SURVEY.md 8d) / HIP-event time per decode on the launch stream"},
         }

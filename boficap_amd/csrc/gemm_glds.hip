@@ -124,6 +124,35 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
 
+    // Epilogue operands of the vector path (bias, colsum, residual, region counts) are requested NOW, before
+    // the K loop: their L2 round trip then overlaps the loop instead of following it (they are older than
+    // every LDS-DMA, so the counted vmcnt waits of the loop cover them).  vmcnt counts stores too on gfx950,
+    // so all epilogue loads must precede the first store anyway.
+    constexpr int LPR = BN / 4;                        // lanes per output row (4 columns each)
+    constexpr int RPI = 64 / LPR;                      // rows per wave instruction
+    constexpr int NR = BM / (4 * RPI);                 // rows per lane
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    const int n = n0 + lc;
+    const bool ncol_ok = n < p.N;                      // N % 4 == 0: the four columns are in or out together
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = bv;
+    float4 rv[NR];
+    bool live[NR], zero[NR];
+    if (p.vec_ok) {
+        if (p.bias && ncol_ok) bv = *reinterpret_cast<const float4*>(p.bias + n);
+        if (p.ln_stats && ncol_ok) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
+            live[u] = m < p.M && ncol_ok;
+            rv[u] = (p.residual && live[u]) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            zero[u] = false;
+            if (p.row_len && live[u]) {
+                const int grp = m / p.rows_per_group;
+                zero[u] = (m - grp * p.rows_per_group) >= p.row_len[grp];
+            }
+        }
+    }
+
     // folded LayerNorm: row mean / 1/(std+eps) from the producer's partial sums.  Done first so that the
     // L2 round trip overlaps the K loop; the two small arrays live past the ring and the epilogue tile.
     float* s_mean = reinterpret_cast<float*>(smem + SMEM_MAIN);
@@ -188,30 +217,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
             *reinterpret_cast<float4*>(&es[(mrow + i * 16) * ES + ncol + j * 16]) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     __syncthreads();
-    // All loads (bias, residual, region counts) are issued BEFORE the first store: vmcnt counts stores
-    // too on gfx950, so a load behind a store would wait for that store's round trip.
     if (p.vec_ok) {
-        constexpr int LPR = BN / 4;                    // lanes per output row (4 columns each)
-        constexpr int RPI = 64 / LPR;                  // rows per wave instruction
-        constexpr int NR = BM / (4 * RPI);             // rows per lane
-        const int lr = lane / LPR, lc = (lane % LPR) * 4;
-        const int n = n0 + lc;
-        const bool ncol_ok = n < p.N;                  // N % 4 == 0: the four columns are in or out together
-        const float4 bv = (p.bias && ncol_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 cs = (p.ln_stats && ncol_ok) ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 rv[NR];
-        bool live[NR], zero[NR];
-#pragma unroll
-        for (int u = 0; u < NR; ++u) {
-            const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
-            live[u] = m < p.M && ncol_ok;
-            rv[u] = (p.residual && live[u]) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            zero[u] = false;
-            if (p.row_len && live[u]) {
-                const int grp = m / p.rows_per_group;
-                zero[u] = (m - grp * p.rows_per_group) >= p.row_len[grp];
-            }
-        }
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
@@ -257,28 +263,28 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     // general case (e.g. the vocabulary projection, N = 9491, rows not 16-byte aligned): one float per lane
     constexpr int NC = (BN + 63) / 64;
     constexpr int NRS = BM / 4;
-    float bv[NC], cs[NC];
+    float sbv[NC], scs[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int n = n0 + c * 64 + lane;
         const bool ok = c * 64 + lane < BN && n < p.N;
-        bv[c] = (p.bias && ok) ? p.bias[n] : 0.f;
-        cs[c] = (p.ln_stats && ok) ? p.ln_colsum[n] : 0.f;
+        sbv[c] = (p.bias && ok) ? p.bias[n] : 0.f;
+        scs[c] = (p.ln_stats && ok) ? p.ln_colsum[n] : 0.f;
     }
-    float rv[NRS][NC];
-    bool zero[NRS];
+    float srv[NRS][NC];
+    bool szero[NRS];
 #pragma unroll
     for (int u = 0; u < NRS; ++u) {
         const int m = m0 + wave + 4 * u;
-        zero[u] = false;
+        szero[u] = false;
         if (p.row_len && m < p.M) {
             const int grp = m / p.rows_per_group;
-            zero[u] = (m - grp * p.rows_per_group) >= p.row_len[grp];
+            szero[u] = (m - grp * p.rows_per_group) >= p.row_len[grp];
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int n = n0 + c * 64 + lane;
-            rv[u][c] = (p.residual && m < p.M && c * 64 + lane < BN && n < p.N) ? p.residual[(size_t)m * p.ldr + n] : 0.f;
+            srv[u][c] = (p.residual && m < p.M && c * 64 + lane < BN && n < p.N) ? p.residual[(size_t)m * p.ldr + n] : 0.f;
         }
     }
 #pragma unroll
@@ -288,11 +294,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
         for (int c = 0; c < NC; ++c) {
             const int n = n0 + c * 64 + lane;
             float v = es[r * ES + c * 64 + lane];
-            if (p.ln_stats) v = s_rstd[r] * (v - s_mean[r] * cs[c]);
-            v += bv[c];
+            if (p.ln_stats) v = s_rstd[r] * (v - s_mean[r] * scs[c]);
+            v += sbv[c];
             if (p.relu) v = fmaxf(v, 0.f);
-            if (zero[u]) v = 0.f;
-            v = rv[u][c] + v;
+            if (szero[u]) v = 0.f;
+            v = srv[u][c] + v;
             if (m >= p.M || c * 64 + lane >= BN || n >= p.N) continue;
             if (p.y_is_f32) static_cast<float*>(p.y)[(size_t)m * p.ldy + n] = v;
             else ElemOps<T>::store(static_cast<T*>(p.y) + (size_t)m * p.ldy + n, v);

@@ -64,7 +64,7 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 // One workgroup (256 threads) per image; heads in float32 (0.1 M parameters, stored transposed so
 // that consecutive lanes read consecutive outputs with 16-byte loads).
 template <typename T>
-__global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict__ y, BoundHeadWeights w, BoundState st,
+__global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict__ y, BoundHeadWeights w, BoundState st,
                                                          const int* ext_syn_in, const int* last_in, const T* __restrict__ q0,
                                                          const T* __restrict__ kvtab, T* __restrict__ ctx, int B, int L, int S,
                                                          int d, int hh, int H, int flags, float* len_logp_out, float* syn_logp_out) {
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
     if ((flags & BOUND_EARLY) && st.counters[0] >= B) return;
     const int nh = 2 * hh;
     float* xs = smem;                 // [d] normalised row
-    float* part = xs + d;             // [4][nh] partial hidden sums
-    float* hid = part + 4 * nh;       // [nh]
+    float* part = xs + d;             // [8][nh] partial hidden sums
+    float* hid = part + 8 * nh;       // [nh]
     float* lg = hid + nh;             // [32] logits: 0..19 length, 20..29 label
-    float* red = lg + 32;             // [8]
-    int* sint = reinterpret_cast<int*>(red + 8);   // [0] = last, [1] = finished, [2..2+L) = ext_syn row
-    float* w2s = red + 8 + 64;        // [30][hh] output layers of both heads, staged once (coalesced)
+    float* red = lg + 32;             // [16]
+    int* sint = reinterpret_cast<int*>(red + 16);  // [0] = last, [1] = finished, [2..2+L) = ext_syn row
+    float* w2s = red + 16 + 64;       // [30][hh] output layers of both heads, staged once (coalesced)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* ext_src = ext_syn_in ? ext_syn_in : st.ext_syn;
     const int* last_src = last_in ? last_in : st.last;
@@ -85,26 +85,26 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
     if (tid == 0) { sint[0] = last_src[b]; sint[1] = (flags & BOUND_UPDATE) ? st.finished[b] : 0; }
 
     if (flags & BOUND_HEADS) {
-        for (int i = tid; i < 30 * hh; i += 256) w2s[i] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
+        for (int i = tid; i < 30 * hh; i += 512) w2s[i] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
         const float* yr = y + (size_t)b * d;
         float s = 0.f;
-        for (int k = tid; k < d; k += 256) s += yr[k];
+        for (int k = tid; k < d; k += 512) s += yr[k];
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
         __syncthreads();
-        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)d;
+        const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / (float)d;
         float q = 0.f;
-        for (int k = tid; k < d; k += 256) { const float t = yr[k] - mean; q += t * t; }
+        for (int k = tid; k < d; k += 512) { const float t = yr[k] - mean; q += t * t; }
         q = wave_sum(q);
-        if (lane == 0) red[4 + wave] = q;
+        if (lane == 0) red[8 + wave] = q;
         __syncthreads();
-        const float den = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)(d - 1)) + 1e-6f;
-        for (int k = tid; k < d; k += 256) xs[k] = w.norm_gain[k] * (yr[k] - mean) / den + w.norm_bias[k];
+        const float den = sqrtf((((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]))) / (float)(d - 1)) + 1e-6f;
+        for (int k = tid; k < d; k += 512) xs[k] = w.norm_gain[k] * (yr[k] - mean) / den + w.norm_bias[k];
         __syncthreads();
-        // hidden layer of both heads: thread (slice, group) sums 4 outputs over a quarter of K
+        // hidden layer of both heads: thread (slice, group) sums 4 outputs over an eighth of K
         const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng;
-        if (slice < 4) {
-            const int k0 = slice * (d / 4), k1 = k0 + d / 4;
+        if (slice < 8) {
+            const int k0 = slice * (d / 8), k1 = k0 + d / 8;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             // latency-bound weight stream: keep 32 independent 16-byte loads in flight per thread
             for (int kb = k0; kb < k1; kb += 32) {
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
             *reinterpret_cast<float4*>(part + slice * nh + grp * 4) = acc;
         }
         __syncthreads();
-        if (tid < nh) hid[tid] = fmaxf(((part[tid] + part[nh + tid]) + (part[2 * nh + tid] + part[3 * nh + tid])) + w.b1[tid], 0.f);
+        if (tid < nh)
+            hid[tid] = fmaxf((((part[tid] + part[nh + tid]) + (part[2 * nh + tid] + part[3 * nh + tid])) +
+                              ((part[4 * nh + tid] + part[5 * nh + tid]) + (part[6 * nh + tid] + part[7 * nh + tid]))) + w.b1[tid], 0.f);
         __syncthreads();
         if (tid < 30) {
             const bool is_len = tid < 20;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
     // ---- row-0 self-attention over the (position, label) table, one wavefront per head
     constexpr int EPC = 16 / sizeof(T);
     const int n = min(sint[0], L);
-    for (int h = wave; h < H; h += 4) {
+    for (int h = wave; h < H; h += 8) {
         float sc = -INFINITY;
         int row = 0;
         if (lane < n) {
@@ -226,13 +228,13 @@ __global__ __launch_bounds__(256) void bound_tail_kernel(const float* __restrict
 int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
                       float* len_logp, float* syn_logp, hipStream_t s) {
-    if ((2 * hh) % 4 || d % 4 || 2 * hh * 4 / 4 > 256 * 4 || L > 60) return BOFI_ERR_ARG;
-    const size_t shm = (size_t)(d + 4 * 2 * hh + 2 * hh + 32 + 8 + 64 + 30 * hh) * sizeof(float);
+    if ((2 * hh) % 4 || d % 8 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60) return BOFI_ERR_ARG;
+    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * hh) * sizeof(float);
     if (dtype == BOFI_DT_F32)
-        hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(256), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
+        hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
                            (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
     else
-        hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(B), dim3(256), shm, s, y, w, st, ext_syn_in, last_in, (const bf16_t*)q0,
+        hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const bf16_t*)q0,
                            (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
@@ -285,46 +287,55 @@ int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* p
 //   log_softmax (in place), greedy argmax with torch.max's CPU semantics (lowest index among
 //   equal maxima; NaN beats everything and the first NaN is returned), pad after the image's
 //   token count.  HBM-bound: V*4 bytes read + V*4 written per row.
-__global__ __launch_bounds__(256) void vocab_finalize_kernel(float* __restrict__ logits, int V, int S, int log_softmax,
+template <int NPT>   // values per thread held in registers: V <= 512 * NPT (one HBM read + one write per value)
+__global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__ logits, int V, int S, int log_softmax,
                                                              const int* ntok, int ntok_bias, int pad_idx, int64_t* seq) {
-    __shared__ float red[8];
-    __shared__ int redi[8];
+    __shared__ float red[16];
+    __shared__ int redi[16];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* x = logits + (size_t)row * V;
+    float v[NPT];
     float m = -INFINITY;
     int first_nan = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-        const float v = x[i];
-        if (v != v) first_nan = min(first_nan, i);
-        m = fmaxf(m, v);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = tid + i * 512;
+        v[i] = idx < V ? x[idx] : -INFINITY;
+        if (v[i] != v[i]) first_nan = min(first_nan, idx);
+        m = fmaxf(m, v[i]);
     }
     m = wave_max(m);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) first_nan = min(first_nan, __shfl_xor(first_nan, o, 64));
     if (lane == 0) { red[wave] = m; redi[wave] = first_nan; }
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    first_nan = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+    m = red[0]; first_nan = redi[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) { m = fmaxf(m, red[w]); first_nan = min(first_nan, redi[w]); }
     __syncthreads();
     float lse = 0.f;
     if (log_softmax) {
         float s = 0.f;
-        for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) s += (tid + i * 512 < V) ? expf(v[i] - m) : 0.f;
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
         __syncthreads();
-        lse = logf((red[0] + red[1]) + (red[2] + red[3]));
+        lse = logf(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
         __syncthreads();
     }
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-        float v = x[i];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = tid + i * 512;
+        if (idx >= V) continue;
+        float t = v[i];
         if (log_softmax) {
-            v = (first_nan != 0x7fffffff) ? __builtin_nanf("") : (v - m) - lse;    // one NaN poisons the row's softmax
-            x[i] = v;
+            t = (first_nan != 0x7fffffff) ? __builtin_nanf("") : (t - m) - lse;    // one NaN poisons the row's softmax
+            x[idx] = t;
         }
-        if (v > bv) { bv = v; bi = i; }               // i ascends per thread: first max kept
+        if (t > bv) { bv = t; bi = idx; }             // idx ascends per thread: first max kept
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256) void vocab_finalize_kernel(float* __restrict__
     if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 8; ++w)
             if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
         if (first_nan != 0x7fffffff) bi = log_softmax ? 0 : first_nan;
         if (bi == 0x7fffffff) bi = 0;                 // all -inf row: torch.max returns index 0
@@ -351,8 +362,10 @@ int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax
                           int64_t* seq, hipStream_t st) {
     if (!logits || !seq || rows < 0 || V <= 0 || S <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(vocab_finalize_kernel, dim3(rows), dim3(256), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx,
-                       seq);
+    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq);
+    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq);
+    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq);
+    else return BOFI_ERR_ARG;
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
