@@ -107,7 +107,9 @@ def main():
     graph = not args.no_graph
     log("engine ready; first decode (graph capture)")
     engines = [eng] + [eng.fork() for _ in range(args.inflight - 1)]
-    streams = [torch.cuda.Stream(device=dev) for _ in engines]
+    # torch's pooled streams: measured best hardware-queue spread at 4 in flight (77k vs 53k img/s with
+    # streams created by the engine itself; BOFI_ENGINE_STREAMS=1 selects the latter)
+    streams = [e.stream() for e in engines] if os.environ.get("BOFI_ENGINE_STREAMS") else [torch.cuda.Stream(device=dev) for _ in engines]
     outs = []
     for e, st in zip(engines, streams):
         with torch.cuda.stream(st):

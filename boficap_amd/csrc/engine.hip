@@ -85,6 +85,7 @@ struct bofi_engine {
     bofi::BoundState st{};
 
     hipStream_t cap_stream = nullptr;
+    hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
 
     template <typename U> int dalloc(U** p, size_t n_elems, size_t elem = sizeof(U)) {
@@ -384,6 +385,7 @@ void bofi_engine_destroy(bofi_engine_t* e) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->run_stream) (void)hipStreamDestroy(e->run_stream);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
@@ -397,14 +399,17 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->allocs.clear();                           // owns nothing of the parent's
     e->graphs.clear();
     e->cap_stream = nullptr;
+    e->run_stream = nullptr;
     e->is_fork = true;
     e->st = bofi::BoundState{};
     int rc = e->alloc_workspace();
-    if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
+    if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->run_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
     if (rc != BOFI_OK) { bofi_engine_destroy(e); return rc; }
     *out = e;
     return BOFI_OK;
 }
+
+void* bofi_engine_stream(bofi_engine_t* e) { return e ? (void*)e->run_stream : nullptr; }
 
 int bofi_engine_set_weight(bofi_engine_t* e, const char* name, const float* data, int64_t numel) {
     if (!e || !name || !data || numel < 0) return fail(BOFI_ERR_ARG, "null argument");
@@ -532,7 +537,7 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, qself, e->b_q0, c.dtype, d, 1, o, nullptr));
         ENG_HIP(hipDeviceSynchronize());
     }
-    if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    if (!e->run_stream) ENG_HIP(hipStreamCreateWithFlags(&e->run_stream, hipStreamNonBlocking));
     e->finalized = true;
     return BOFI_OK;
 }
@@ -588,6 +593,9 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
         if (g.key == key) { ENG_HIP(hipGraphLaunch(g.exec, s)); return BOFI_OK; }
     GraphEntry g;
     g.key = key;
+    // the capture stream is created lazily so that the run streams of an engine and its forks are
+    // created back to back (they then land on different hardware queues)
+    if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     ENG_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
     const int rc = e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                      phrase_syn, memory_out, bound_iters, e->cap_stream);

@@ -50,6 +50,10 @@ class BofiEngine:
             hip.check(self._lib.bofi_engine_fork(self._h, C.byref(f._h)), "bofi_engine_fork")
         return f
 
+    def stream(self) -> "torch.cuda.Stream":
+        """The engine's own HIP stream wrapped for torch (one hardware queue per in-flight engine)."""
+        return torch.cuda.ExternalStream(self._lib.bofi_engine_stream(self._h), device=self.device)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

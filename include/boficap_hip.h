@@ -120,6 +120,10 @@ int bofi_engine_finalize(bofi_engine_t* e);
  * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
 int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
 
+/* A HIP stream owned by the engine (hipStream_t as void*), for callers that keep one decode per engine in
+ * flight and want each on its own hardware queue. */
+void* bofi_engine_stream(bofi_engine_t* e);
+
 #define BOFI_FLAG_STRICT_Q1 1      /* reproduce TransformerModel.py:1872-1873: every image's fill mask
                                       uses the LAST image's length.  Default ON in the Python wrapper. */
 #define BOFI_FLAG_RAW_LOGITS 2     /* output_logsoftmax = 0 (AttModel.py:208-209) */
