@@ -78,16 +78,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from boficap_amd import dp
+    rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
+    world = max(world, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)         # RCCL; only used for the barrier / max-over-ranks timing
 
     from boficap_amd import weights as W
     from boficap_amd.config import FULL as cfg
@@ -145,10 +145,7 @@ def main():
     # HIP events on the launch streams: with one stream this is the device time per decode; with several
     # in flight it is the longest stream's span divided by all the decodes (steady-state time per decode)
     dev_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dp.reduce_scalar(elapsed, "max", device=dev)
 
     # for the record: the same K steps strictly one at a time (latency view of the same workload)
     single_ms = None

@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two gloo processes shard a batch by rank; no collective on the data path."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import boficap_oracle as O
+    from boficap_amd import dp, weights as W
+    from boficap_amd.config import TINY
+    torch.set_num_threads(2)
+    r, lr, w = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    cfg = TINY
+    sd = O.as_torch(W.make_state_dict(cfg, 0, gen_scale=6.0))
+    att = torch.from_numpy(W.synthetic_att_feats(10, 36, cfg.att_feat_size, seed=3))
+    a, b = dp.shard_range(10, rank, world)
+    # the checker stands in for the device path here: per-shard decode with the per-row fill mask
+    seq, lp, pn, pl, ps, _ = O.sample_naic(sd, cfg, att[a:b], fix_q1=True)
+    pad = torch.zeros(5 - (b - a), seq.size(1), dtype=seq.dtype)
+    allseq = dp.gather_rows(torch.cat([seq, pad]))                       # equal shapes for all_gather
+    n_img = dp.reduce_scalar(b - a, "sum")
+    t_max = dp.reduce_scalar(1.0 + rank, "max")
+    if rank == 0:
+        full = O.sample_naic(sd, cfg, att, fix_q1=True)[0]
+        got = torch.cat([allseq[0:5], allseq[5:10]])
+        ret.put((bool(torch.equal(got, full)), n_img, t_max))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharded_decode_matches_single_process():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, n_img, t_max = ret.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and n_img == 10 and t_max == 2.0
+
+
+def test_shard_range_covers_everything_once():
+    from boficap_amd.dp import shard_range
+    for n in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
