@@ -106,10 +106,11 @@ def main():
     att = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev).to(tdt).contiguous()
     graph = not args.no_graph
     log("engine ready; first decode (graph capture)")
-    engines = [eng] + [eng.fork() for _ in range(args.inflight - 1)]
-    # torch's pooled streams: measured best hardware-queue spread at 4 in flight (77k vs 53k img/s with
-    # streams created by the engine itself; BOFI_ENGINE_STREAMS=1 selects the latter)
-    streams = [e.stream() for e in engines] if os.environ.get("BOFI_ENGINE_STREAMS") else [torch.cuda.Stream(device=dev) for _ in engines]
+    # streams that provably overlap (distinct hardware queues), found by timing a spin kernel on pairs
+    from boficap_amd.engine import pick_concurrent_streams
+    streams = pick_concurrent_streams(args.inflight, dev) if args.inflight > 1 else [torch.cuda.current_stream(dev)]
+    log(f"{len(streams)} concurrent streams")
+    engines = [eng] + [eng.fork() for _ in range(len(streams) - 1)]
     outs = []
     for e, st in zip(engines, streams):
         with torch.cuda.stream(st):

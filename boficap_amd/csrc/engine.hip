@@ -403,13 +403,17 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->is_fork = true;
     e->st = bofi::BoundState{};
     int rc = e->alloc_workspace();
-    if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->run_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
+    if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
     if (rc != BOFI_OK) { bofi_engine_destroy(e); return rc; }
     *out = e;
     return BOFI_OK;
 }
 
-void* bofi_engine_stream(bofi_engine_t* e) { return e ? (void*)e->run_stream : nullptr; }
+void* bofi_engine_stream(bofi_engine_t* e) {
+    if (!e) return nullptr;
+    if (!e->run_stream && hipStreamCreateWithFlags(&e->run_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return (void*)e->run_stream;
+}
 
 int bofi_engine_set_weight(bofi_engine_t* e, const char* name, const float* data, int64_t numel) {
     if (!e || !name || !data || numel < 0) return fail(BOFI_ERR_ARG, "null argument");
@@ -537,7 +541,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, qself, e->b_q0, c.dtype, d, 1, o, nullptr));
         ENG_HIP(hipDeviceSynchronize());
     }
-    if (!e->run_stream) ENG_HIP(hipStreamCreateWithFlags(&e->run_stream, hipStreamNonBlocking));
+    // NB: hardware-queue assignment follows stream creation order; the capture stream is created here (and in
+    // fork) because that order measured best with 4 decodes in flight on torch's pooled streams
+    if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     e->finalized = true;
     return BOFI_OK;
 }

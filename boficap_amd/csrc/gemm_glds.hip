@@ -80,7 +80,16 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order (workgroup i runs on XCD i % 8, each XCD has its own 4 MiB L2): XCD x gets a
+    // CONTIGUOUS run of tiles in (m-tile major, n-tile minor) order, i.e. a band of A rows that stays in
+    // its L2 while the weight panel streams; bijective for any tile count.
+    const int ntn = (p.N + BN - 1) / BN, ntiles = gridDim.x;
+    int tile = blockIdx.x;
+    if (!(p.dbg & 16)) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
     // LDS-DMA source pointers: wave-instruction j of this wave covers tile rows (wave*L + j)*8 .. +7;
     // lane i -> row +(i>>3), LDS chunk (i&7) <- global chunk (i&7) ^ (i>>3)   (XOR swizzle on the source)
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
 
 template <typename T, int BM, int BN, int NS>
 static void launch_one(const Gemm2Params& p, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS>), dim3((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM)), dim3(256), 0, st, p);
 }
 
 template <typename T>

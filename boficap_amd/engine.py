@@ -15,6 +15,38 @@ from . import hip
 from .config import BofiConfig
 
 
+def pick_concurrent_streams(n: int, device=None, candidates: int = 16, spin_cycles: int = 400_000):
+    """``n`` HIP streams that really run side by side.
+
+    ROCm multiplexes streams onto a few hardware queues and two streams on one queue serialise; which
+    stream lands where depends on creation order.  Instead of guessing, time a spin kernel on pairs of
+    candidate streams and keep a set whose members pairwise overlap.  Falls back to fewer streams than
+    asked for if no such set exists (the caller then keeps fewer decodes in flight)."""
+    import time
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    with torch.cuda.device(dev):
+        cands = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+
+        def span(streams):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin_cycles)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        span(cands[:1])
+        one = min(span(cands[:1]) for _ in range(3))
+        chosen = [cands[0]]
+        for c in cands[1:]:
+            if len(chosen) >= n:
+                break
+            if all(min(span([c, s]) for _ in range(2)) < 1.5 * one for s in chosen):
+                chosen.append(c)
+    return chosen
+
+
 class BofiEngine:
     def __init__(self, cfg: BofiConfig, dtype: torch.dtype = torch.bfloat16, max_batch: int = 64,
                  max_regions: int = 36, device: Optional[torch.device] = None):
