@@ -52,6 +52,6 @@ int launch_attention(const AttnArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
-                          int pad_idx, int64_t* seq, hipStream_t st);
+                          int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr);
 
 }  // namespace bofi

@@ -17,6 +17,17 @@ struct BoundState {
     int* counters;        // [4]: 0 = images finished, 1 = bound iterations executed
 };
 
+// Extra per-image state of core_SAIC (reference TransformerModel.py:1879-1896), int32 on the device.
+// BoundState.last doubles as phrase_last; BoundState.counters[2] is the halt word (all finished or NaN seen),
+// counters[3] the NaN flag.
+struct SaicState {
+    int* seq_last;        // [B]
+    int* seq;             // [B, L]  tokens, position 0 = BOS
+    int* ext_len;         // [B, L]  extend_phrase_len: [LEN] id at 0, then the tokens emitted so far
+    int* ext_phrase;      // [B, L]  decoder input tokens (position-wise copy of the previous phrase)
+    int* klen_dec;        // [B, L]  key-prefix length of row r of phrase_mask
+};
+
 struct BoundHeadWeights {   // float32
     const float* norm_gain; const float* norm_bias;      // length_predictor.norm
     const float* w1t; const float* b1;                   // TRANSPOSED [d, 2*hh]: Length_classifier1 | Syntactic_classifier1
@@ -32,9 +43,19 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 #define BOUND_UPDATE 2   /* apply the slot bookkeeping (needs BOUND_HEADS) */
 #define BOUND_ATTN 4     /* row-0 self-attention of the next iteration -> ctx */
 #define BOUND_EARLY 8    /* return at once when every image is finished */
+#define BOUND_SAIC 16    /* SAIC bookkeeping (TransformerModel.py:1910-1948) instead of NAIC's; early-out on the halt word */
 int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
-                      float* len_logp, float* syn_logp, hipStream_t s);
+                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa = nullptr, int iter = 0);
+// rows of pos_embed(tgt_embed(tok) [+ syn_embed(syn)]): row r = (b, t), ids read at [b*ld + off + t]; tok == NULL -> BOS
+int launch_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int* tok, const int* syn, int ld, int off,
+                      int B, int T, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, const int* halt, hipStream_t s);
+int launch_saic_init(const BoundState& st, const SaicState& sa, int B, int L, int pad_idx, int bos_idx, int len_idx, hipStream_t s);
+// after the decoder pass of iteration `iter`: copy the new phrase's tokens / log-probs (TransformerModel.py:1968-1977), set halt
+int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* tok, const float* logp, float* seq_logprob, int B, int L,
+                     int S, int V, int iter, hipStream_t s);
+int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, int S, int64_t* seq, int* phrase_num,
+                       int* phrase_length, int64_t* phrase_syn, int* iters, hipStream_t s);
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,
                       int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s);
 

@@ -83,6 +83,12 @@ struct bofi_engine {
     float *by1 = nullptr, *by2 = nullptr, *by3 = nullptr;
     void *bctx = nullptr, *bq2 = nullptr, *bctx2 = nullptr, *bh = nullptr;
     bofi::BoundState st{};
+    bofi::SaicState sa{};
+    float* xw = nullptr; void* xwb = nullptr; float* st_w = nullptr;   // SAIC bound input rows [B*L, d] (+copy, +stats)
+    void* kvs = nullptr;                                                // their K|V [B*L, 2d]
+    int64_t* tok64 = nullptr;                                           // greedy ids of one decoder pass [B*S]
+    Lin b_kv_self;                                                      // bound self-attention K|V with sublayer.0.norm folded in
+    void* b_q0_sa = nullptr; float* b_x0_sa = nullptr;                  // row-0 constants when position 0 holds tgt_embed([LEN])
 
     hipStream_t cap_stream = nullptr;
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
@@ -175,6 +181,7 @@ struct bofi_engine {
         int relu = 0;
         const int* row_len = nullptr; int rpg = 0;
         bool early = false;
+        bool halt = false;                   // SAIC: early-out on the halt word (counters[2] >= 1)
         const Norm* ln = nullptr;            // explicit LayerNorm kernel on x first (setup-time use only)
         const float* ln_stats = nullptr;     // LayerNorm folded into the GEMM (Lin built with fold_norm)
         float* stats_out = nullptr;          // emit row partial sums of the output
@@ -195,6 +202,7 @@ struct bofi_engine {
         a.ln_stats = o.ln_stats; a.ln_colsum = o.ln_stats ? l.cs : nullptr;
         a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N;
         if (o.early) { a.skip_if_ge = st.counters; a.skip_threshold = cur_B; }
+        if (o.halt) { a.skip_if_ge = st.counters + 2; a.skip_threshold = 1; }
         return bofi::launch_linear(a, s);
     }
     // residual stream in the compute dtype: the fp32 engine reads the stream itself
@@ -231,6 +239,10 @@ struct bofi_engine {
     ENG_OK(dalloc(&st.last, Bm)); ENG_OK(dalloc(&st.finished, Bm)); ENG_OK(dalloc(&st.phrase_num, Bm));
     ENG_OK(dalloc(&st.phrase_length, Bm * L)); ENG_OK(dalloc(&st.phrase_syn, Bm * L));
     ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 4));
+    ENG_OK(dalloc(&sa.seq_last, Bm)); ENG_OK(dalloc(&sa.seq, Bm * L)); ENG_OK(dalloc(&sa.ext_len, Bm * L));
+    ENG_OK(dalloc(&sa.ext_phrase, Bm * L)); ENG_OK(dalloc(&sa.klen_dec, Bm * L));
+    ENG_OK(dalloc(&xw, Bm * L * d)); ENG_OK(dalloc((char**)&xwb, Bm * L * d, tsz)); ENG_OK(dalloc(&st_w, Bm * L * (d / 32) * 2));
+    ENG_OK(dalloc((char**)&kvs, Bm * L * 2 * (size_t)d, tsz)); ENG_OK(dalloc(&tok64, Bm * Sq));
 
         return BOFI_OK;
     }
@@ -238,6 +250,8 @@ struct bofi_engine {
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
                            float* syn_logp, bool early, hipStream_t s);
+    int enqueue_decode_saic(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
+                            float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn, int* bound_iters, hipStream_t s);
     int enqueue_decode(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
                        float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn, float* memory_out,
                        int* bound_iters, hipStream_t s);
@@ -353,6 +367,81 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s)); }
     ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s));
     ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
+    return BOFI_OK;
+}
+
+// Semi-autoregressive decode (reference core_SAIC TransformerModel.py:1878-1986, greedy): per phrase one bounding step on
+// the WORDS emitted so far, then a full decoder pass over all S positions whose new phrase is kept.
+int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
+                                     float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn, int* bound_iters,
+                                     hipStream_t s) {
+    const int d = cfg.d_model, dt = cfg.dtype, S = cfg.seq_length, M = B * S;
+    const int* halt = st.counters + 2;
+    ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, nullptr, s));
+    ENG_OK(bofi::launch_saic_init(st, sa, B, L, cfg.pad_idx, cfg.bos_idx, cfg.len_idx, s));
+    if (seq_logprob) ENG_HIP(hipMemsetAsync(seq_logprob, 0, (size_t)M * cfg.vocab * sizeof(float), s));   // seq_logprobs = zeros (:1883)
+    const void* xwa = stream_t(xw, xwb);
+    const void* xa = stream_t(x_fill, xb_fill);
+    for (int it = 1; it <= S; ++it) {
+        // ---- bounding step on the words: K|V of all L rows, row-0 query attends keys < phrase_last
+        ENG_OK(bofi::launch_embed_rows(lut_tok, nullptr, pe, sa.ext_len, nullptr, L, 0, B, L, d, cfg.bos_idx, xw, copy_t(xwb), dt, st_w, halt, s));
+        { LinOpt o; o.halt = true; o.ln_stats = st_w; ENG_OK(linear(xwa, dt, d, b_kv_self, kvs, dt, 2 * d, B * L, o, s)); }
+        {
+            bofi::AttnArgs a{};
+            a.q = b_q0_sa; a.ldq = 0; a.k = kvs; a.v = (char*)kvs + (size_t)d * tsz; a.ldk = a.ldv = 2 * d;
+            a.out = bctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = L;
+            a.klen = st.last; a.klen_sb = 1; a.klen_sq = 0; a.skip_if_ge = halt; a.skip_threshold = 1;
+            ENG_OK(bofi::launch_attention(a, s));
+        }
+        { LinOpt o; o.residual = b_x0_sa; o.ldr = 0; o.halt = true; o.stats_out = st_b; o.y2 = copy_t(byb);
+          ENG_OK(linear(bctx, dt, d, b_o_self, by1, BOFI_DT_F32, d, B, o, s)); }
+        { LinOpt o; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
+        {
+            bofi::AttnArgs a{};
+            a.q = bq2; a.ldq = d; a.k = kv; a.v = (char*)kv + (size_t)d * tsz; a.ldk = a.ldv = kv_all.N;
+            a.out = bctx2; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = R;
+            a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0; a.skip_if_ge = halt; a.skip_threshold = 1;
+            ENG_OK(bofi::launch_attention(a, s));
+        }
+        { LinOpt o; o.residual = by1; o.ldr = d; o.halt = true; o.stats_out = st_b; o.y2 = copy_t(byb);
+          ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
+        { LinOpt o; o.relu = 1; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
+        { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
+        ENG_OK(bofi::launch_bound_tail(by3, heads, st, nullptr, nullptr, b_q0, b_kvtab, bctx, dt, B, L, S, d, cfg.head_hidden, cfg.heads,
+                                       BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, &sa, it));
+        // ---- decoder pass over all S positions (decode_SA :520-530) with the phrase-block mask as per-row key prefixes
+        ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
+                                       st_fill, halt, s));
+        for (size_t li = 0; li < dec.size(); ++li) {
+            auto& l = dec[li];
+            { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
+            bofi::AttnArgs a{};
+            a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
+            a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
+            // phrase_mask[:, 1:-1, 1:-1]: row t <- row t+1, one key column dropped
+            a.klen = sa.klen_dec + 1; a.klen_sb = L; a.klen_sq = 1; a.klen_bias = -1; a.skip_if_ge = halt; a.skip_threshold = 1;
+            ENG_OK(bofi::launch_attention(a, s));
+            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+              ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s)); }
+            { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
+            bofi::AttnArgs c{};
+            c.q = qs; c.ldq = d;
+            c.k = (char*)kv + (size_t)(1 + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(1 + li) * 2 * d + d) * tsz;
+            c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
+            c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0; c.skip_if_ge = halt; c.skip_threshold = 1;
+            ENG_OK(bofi::launch_attention(c, s));
+            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+              ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, BOFI_DT_F32, d, M, o, s)); }
+            { LinOpt o; o.halt = true; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+              ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
+        }
+        { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, logits, BOFI_DT_F32, cfg.vocab, M, o, s)); }
+        ENG_OK(bofi::launch_vocab_finalize(logits, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, nullptr, 0, cfg.pad_idx, tok64, s,
+                                           st.counters + 3, halt));
+        ENG_OK(bofi::launch_saic_copy(st, sa, tok64, logits, seq_logprob, B, L, S, cfg.vocab, it, s));
+    }
+    ENG_OK(bofi::launch_saic_export(st, sa, B, L, S, seq, phrase_num, phrase_length, phrase_syn, bound_iters, s));
     return BOFI_OK;
 }
 
@@ -539,6 +628,14 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         bofi_engine::LinOpt o; o.ln = &e->b_n0;
         ENG_OK(e->linear(d_xt, BOFI_DT_F32, d, kvself, e->b_kvtab, c.dtype, 2 * d, L * 10, o, nullptr));
         ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, qself, e->b_q0, c.dtype, d, 1, o, nullptr));
+        // SAIC: position 0 of the bound input is tgt_embed([LEN]) (TransformerModel.py:1903, 515-518)
+        const auto& lt = e->host["model.tgt_embed.lut.weight"];
+        std::vector<float> x0s(d);
+        for (int k = 0; k < d; ++k) x0s[k] = lt[(size_t)c.len_idx * d + k] * sq + pe[k];
+        ENG_OK(e->upload_f32(&e->b_x0_sa, x0s));
+        ENG_OK(e->dalloc((char**)&e->b_q0_sa, (size_t)d, e->tsz));
+        ENG_OK(e->linear(e->b_x0_sa, BOFI_DT_F32, d, qself, e->b_q0_sa, c.dtype, d, 1, o, nullptr));
+        ENG_OK(e->make_lin(&e->b_kv_self, {bl + ".self_attn.linears.1", bl + ".self_attn.linears.2"}, d, d, bl + ".sublayer.0.norm"));
         ENG_HIP(hipDeviceSynchronize());
     }
     // NB: hardware-queue assignment follows stream creation order; the capture stream is created here (and in
@@ -578,6 +675,17 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
                                    e->cfg.seq_length, e->cfg.d_model, e->cfg.head_hidden, e->cfg.heads, BOUND_ATTN, nullptr, nullptr,
                                    (hipStream_t)stream));
     return e->enqueue_bound_iter(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, false, (hipStream_t)stream);
+}
+
+int bofi_engine_decode_saic(bofi_engine_t* e, const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags,
+                            int64_t* seq, float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn,
+                            int* bound_iters, void* stream) {
+    g_err.clear();
+    ENG_OK(check_call(e, B, R));
+    ENG_OK(check_feats(e, feats, feats_dtype));
+    if (!seq) return fail(BOFI_ERR_ARG, "null seq");
+    return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
+                                  bound_iters, (hipStream_t)stream);
 }
 
 int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags,

@@ -67,9 +67,10 @@ template <typename T>
 __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict__ y, BoundHeadWeights w, BoundState st,
                                                          const int* ext_syn_in, const int* last_in, const T* __restrict__ q0,
                                                          const T* __restrict__ kvtab, T* __restrict__ ctx, int B, int L, int S,
-                                                         int d, int hh, int H, int flags, float* len_logp_out, float* syn_logp_out) {
+                                                         int d, int hh, int H, int flags, float* len_logp_out, float* syn_logp_out,
+                                                         SaicState sa, int iter) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((flags & BOUND_EARLY) && st.counters[0] >= B) return;
+    if ((flags & BOUND_EARLY) && ((flags & BOUND_SAIC) ? st.counters[2] >= 1 : st.counters[0] >= B)) return;
     const int nh = 2 * hh;
     float* xs = smem;                 // [d] normalised row
     float* part = xs + d;             // [8][nh] partial hidden sums
@@ -156,7 +157,43 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
                 }
                 pick[head] = best;
             }
-            if (flags & BOUND_UPDATE) {
+            if (flags & BOUND_SAIC) {
+                // core_SAIC bookkeeping of iteration `iter` (TransformerModel.py:1910-1948)
+                if (b == 0) st.counters[1] += 1;
+                const int pl = sint[0];
+                if (!sint[1]) {
+                    int ln = pick[0];
+                    const int sn = pick[1];
+                    bool fin = false;
+                    if (ln == 0 || sn < 4 || sn > 6) {
+                        fin = true;
+                    } else {
+                        if (ln + pl >= S + 1) { ln = S + 1 - pl; fin = true; }
+                        st.phrase_length[b * L + iter] = ln;
+                        st.phrase_syn[b * L + iter] = sn;
+                        st.phrase_num[b] += 1;
+                    }
+                    if (fin) { st.finished[b] = 1; atomicAdd(&st.counters[0], 1); }
+                }
+                const int cur = st.phrase_length[b * L + iter];
+                if (cur != 0) {
+                    const int prev = st.phrase_length[b * L + iter - 1], sl = sa.seq_last[b], sy = st.phrase_syn[b * L + iter];
+                    for (int p = pl; p < pl + cur; ++p) st.ext_syn[b * L + p] = sy;
+                    if (cur <= prev) {                        // :1934-1936
+                        const int pre_pad = prev - cur;
+                        for (int k = 0; k < cur; ++k) sa.ext_phrase[b * L + pl + k] = sa.seq[b * L + sl + pre_pad + k];
+                    } else {                                  // :1937-1947 position-wise stretch
+                        const int pre_less = prev - (cur % prev), times = cur / prev;
+                        int copied = 0;
+                        for (int k = 0; k < prev; ++k) {
+                            const int nrep = k < pre_less ? times : times + 1, tokv = sa.seq[b * L + sl + k];
+                            for (int c = 0; c < nrep; ++c) sa.ext_phrase[b * L + pl + copied + c] = tokv;
+                            copied += nrep;
+                        }
+                    }
+                    for (int r = pl; r < L; ++r) sa.klen_dec[b * L + r] = pl + cur;      // phrase_mask[j, pl:, :pl+cur] = True
+                }
+            } else if (flags & BOUND_UPDATE) {
                 if (b == 0) st.counters[1] += 1;              // iterations in which some image was active
                 if (!sint[1]) {
                     int ln = pick[0];
@@ -227,15 +264,16 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
 
 int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
-                      float* len_logp, float* syn_logp, hipStream_t s) {
+                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa, int iter) {
+    const SaicState sav = sa ? *sa : SaicState{};
     if ((2 * hh) % 4 || d % 8 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60) return BOFI_ERR_ARG;
     const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * hh) * sizeof(float);
     if (dtype == BOFI_DT_F32)
         hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
-                           (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
+                           (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter);
     else
         hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const bf16_t*)q0,
-                           (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp);
+                           (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -283,15 +321,143 @@ int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* p
 }
 
 // ------------------------------------------------------------------------------------------------
+// Generic embedding rows for the SAIC path: pos_embed(tgt_embed(tok) [+ syn_embed(syn)]) with int32 ids read from
+// the slot state (bound input TransformerModel.py:515-518, decoder input :520-530).
+template <typename T>
+__global__ __launch_bounds__(128) void embed_rows_kernel(const float* __restrict__ lut_tok, const float* __restrict__ lut_syn,
+                                                         const float* __restrict__ pe, const int* tok, const int* syn, int ld, int off,
+                                                         int Tn, int d, int bos_idx, float sqrt_d, float* __restrict__ x,
+                                                         T* __restrict__ xt, float* __restrict__ stats, const int* halt) {
+    if (halt && *halt >= 1) return;
+    const int row = blockIdx.x, b = row / Tn, t = row - b * Tn;
+    const int word = tok ? tok[b * ld + off + t] : bos_idx;
+    const float* tr = lut_tok + (size_t)word * d;
+    const float* sr = syn ? lut_syn + (size_t)syn[b * ld + off + t] * d : nullptr;
+    const float* pr = pe + (size_t)t * d;
+    for (int k = threadIdx.x; k < d; k += 128) {
+        const float v = sr ? (tr[k] * sqrt_d + sr[k] * sqrt_d) + pr[k] : tr[k] * sqrt_d + pr[k];
+        x[(size_t)row * d + k] = v;
+        if (xt) ElemOps<T>::store(xt + (size_t)row * d + k, v);
+        if (stats) {
+            float ps = v, pq = v * v;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+            if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
+        }
+    }
+}
+
+int launch_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int* tok, const int* syn, int ld, int off,
+                      int B, int Tn, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, const int* halt, hipStream_t s) {
+    if (d % 128) return BOFI_ERR_ARG;
+    const float sqrt_d = (float)sqrt((double)d);
+    if (dtype == BOFI_DT_F32)
+        hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(B * Tn), dim3(128), 0, s, lut_tok, lut_syn, pe, tok, syn, ld, off, Tn, d, bos_idx,
+                           sqrt_d, x, (float*)xt, stats, halt);
+    else
+        hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(B * Tn), dim3(128), 0, s, lut_tok, lut_syn, pe, tok, syn, ld, off, Tn, d, bos_idx,
+                           sqrt_d, x, (bf16_t*)xt, stats, halt);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+__global__ void saic_init_kernel(BoundState st, SaicState sa, int B, int L, int pad_idx, int bos_idx, int len_idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4) st.counters[i] = 0;
+    if (i < B) { st.last[i] = 1; st.finished[i] = 0; st.phrase_num[i] = 0; sa.seq_last[i] = 0; }
+    if (i < B * L) {
+        const bool first = (i % L) == 0;
+        st.phrase_length[i] = first ? 1 : 0;                   // phrase_length[:, 0] = 1 (TransformerModel.py:1902)
+        st.phrase_syn[i] = pad_idx;
+        st.ext_syn[i] = pad_idx;
+        sa.seq[i] = first ? bos_idx : pad_idx;
+        sa.ext_len[i] = first ? len_idx : pad_idx;
+        sa.ext_phrase[i] = pad_idx;
+        sa.klen_dec[i] = 0;
+    }
+}
+
+int launch_saic_init(const BoundState& st, const SaicState& sa, int B, int L, int pad_idx, int bos_idx, int len_idx, hipStream_t s) {
+    const int n = max(B * L, 4);
+    hipLaunchKernelGGL(saic_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, sa, B, L, pad_idx, bos_idx, len_idx);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// One workgroup per image.  tok/logp: greedy ids and log-probs of ALL S positions of this iteration's decoder pass.
+__global__ __launch_bounds__(256) void saic_copy_kernel(BoundState st, SaicState sa, const int64_t* __restrict__ tok,
+                                                        const float* __restrict__ logp, float* __restrict__ seq_logprob, int B,
+                                                        int L, int S, int V, int iter) {
+    if (st.counters[2] >= 1) return;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool nan_seen = st.counters[3] != 0;                  // "phrase nan!": return before the copy (TransformerModel.py:1956-1958)
+    const int cur = st.phrase_length[b * L + iter], pl = st.last[b];
+    if (!nan_seen && cur != 0) {
+        for (int k = 0; k < cur; ++k) {
+            const float* src = logp + ((size_t)b * S + pl - 1 + k) * V;
+            float* dst = seq_logprob + ((size_t)b * S + pl - 1 + k) * V;      // seq_logprobs[j, pl+k] -> returned slice [:, 1:-1]
+            if (seq_logprob) for (int i = tid; i < V; i += 256) dst[i] = src[i];
+        }
+    }
+    __syncthreads();                                            // every thread has read last/phrase_length before thread 0 updates them
+    if (tid == 0) {
+        if (!nan_seen && cur != 0) {
+            for (int k = 0; k < cur; ++k) {
+                const int t = (int)tok[(size_t)b * S + pl - 1 + k];
+                sa.seq[b * L + pl + k] = t;
+                sa.ext_len[b * L + pl + k] = t;
+            }
+            st.last[b] = pl + cur;
+            sa.seq_last[b] += st.phrase_length[b * L + iter - 1];
+        }
+    }
+}
+__global__ void saic_halt_kernel(BoundState st, int B) {       // after saic_copy of every image: loop exit conditions
+    if (st.counters[2] >= 1) return;
+    if (st.counters[3] != 0 || st.counters[0] >= B) st.counters[2] = 1;
+}
+
+int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* tok, const float* logp, float* seq_logprob, int B, int L,
+                     int S, int V, int iter, hipStream_t s) {
+    hipLaunchKernelGGL(saic_copy_kernel, dim3(B), dim3(256), 0, s, st, sa, tok, logp, seq_logprob, B, L, S, V, iter);
+    hipLaunchKernelGGL(saic_halt_kernel, dim3(1), dim3(1), 0, s, st, B);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+__global__ void saic_export_kernel(BoundState st, SaicState sa, int B, int L, int S, int64_t* seq, int* phrase_num, int* phrase_length,
+                                   int64_t* phrase_syn, int* iters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && iters) *iters = st.counters[1];
+    if (i < B && phrase_num) phrase_num[i] = st.phrase_num[i];
+    if (i < B * S) {
+        const int b = i / S, t = i - b * S;                      // reference returns [:, 1:-1]
+        seq[i] = sa.seq[b * L + t + 1];
+        if (phrase_length) phrase_length[i] = st.phrase_length[b * L + t + 1];
+        if (phrase_syn) phrase_syn[i] = st.phrase_syn[b * L + t + 1];
+    }
+}
+
+int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, int S, int64_t* seq, int* phrase_num,
+                       int* phrase_length, int64_t* phrase_syn, int* iters, hipStream_t s) {
+    hipLaunchKernelGGL(saic_export_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, st, sa, B, L, S, seq, phrase_num, phrase_length,
+                       phrase_syn, iters);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Vocabulary epilogue, one workgroup per (image, position) row of V logits:
 //   log_softmax (in place), greedy argmax with torch.max's CPU semantics (lowest index among
 //   equal maxima; NaN beats everything and the first NaN is returned), pad after the image's
 //   token count.  HBM-bound: V*4 bytes read + V*4 written per row.
 template <int NPT>   // values per thread held in registers: V <= 512 * NPT (one HBM read + one write per value)
 __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__ logits, int V, int S, int log_softmax,
-                                                             const int* ntok, int ntok_bias, int pad_idx, int64_t* seq) {
+                                                             const int* ntok, int ntok_bias, int pad_idx, int64_t* seq,
+                                                             int* nan_flag, const int* halt) {
     __shared__ float red[16];
     __shared__ int redi[16];
+    if (halt && *halt >= 1) return;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* x = logits + (size_t)row * V;
     float v[NPT];
@@ -348,7 +514,7 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
     if (tid == 0) {
         for (int w = 1; w < 8; ++w)
             if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
-        if (first_nan != 0x7fffffff) bi = log_softmax ? 0 : first_nan;
+        if (first_nan != 0x7fffffff) { bi = log_softmax ? 0 : first_nan; if (nan_flag) atomicOr(nan_flag, 1); }
         if (bi == 0x7fffffff) bi = 0;                 // all -inf row: torch.max returns index 0
         if (ntok) {
             const int b = row / S, t = row - b * S;
@@ -359,12 +525,12 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
 }
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias, int pad_idx,
-                          int64_t* seq, hipStream_t st) {
+                          int64_t* seq, hipStream_t st, int* nan_flag, const int* halt) {
     if (!logits || !seq || rows < 0 || V <= 0 || S <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq);
-    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq);
-    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq);
+    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt);
+    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt);
+    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt);
     else return BOFI_ERR_ARG;
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;

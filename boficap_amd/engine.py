@@ -140,6 +140,25 @@ class BofiEngine:
             hip.ptr(out["memory"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_naic")
         return out
 
+    def decode_saic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, raw_logits: bool = False,
+                    want_logprob: bool = True) -> dict:
+        """Greedy semi-autoregressive decode (core_SAIC).  Same result layout as ``decode_naic``."""
+        self._check_feats(att_feats, att_len)
+        B, R, _ = att_feats.shape
+        S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
+        out = dict(
+            seq=torch.empty(B, S, dtype=torch.int64, device=dev),
+            seq_logprob=torch.empty(B, S, V, dtype=torch.float32, device=dev) if want_logprob else None,
+            phrase_num=torch.empty(B, dtype=torch.int32, device=dev),
+            phrase_length=torch.empty(B, S, dtype=torch.int32, device=dev),
+            phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
+            bound_iters=torch.empty(1, dtype=torch.int32, device=dev), memory=None)
+        hip.check(self._lib.bofi_engine_decode_saic(
+            self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, hip.FLAG_RAW_LOGITS if raw_logits else 0,
+            hip.ptr(out["seq"]), hip.ptr(out["seq_logprob"]), hip.ptr(out["phrase_num"]), hip.ptr(out["phrase_length"]),
+            hip.ptr(out["phrase_syn"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_saic")
+        return out
+
     def encode(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Encoder output (float32 [B, R, d]); also leaves memory + cross K/V in the engine workspace."""
         self._check_feats(att_feats, att_len)

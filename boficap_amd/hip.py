@@ -43,6 +43,7 @@ SIGNATURES = {
     "bofi_engine_set_weight": (_I, [_P, C.c_char_p, _P, _I64]),
     "bofi_engine_finalize": (_I, [_P]),
     "bofi_engine_decode_naic": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "bofi_engine_decode_saic": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bofi_engine_encode": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "bofi_engine_bound_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
 }

@@ -130,7 +130,7 @@ class TransformerModel(nn.Module):
         return att_feats.contiguous()
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
-        """AttModel.py:307-338, 419-429 for train_mode 'NAIC' (the bound+fill decode)."""
+        """AttModel.py:307-338, 419-437 for train_mode 'NAIC' (bound+fill) and 'SAIC' (phrase by phrase)."""
         sample_method = opt.get("sample_method", "greedy")
         beam_size = opt.get("beam_size", 1)
         sample_n = int(opt.get("sample_n", 1))
@@ -139,15 +139,18 @@ class TransformerModel(nn.Module):
         train_mode = opt.get("train_mode", "AIC")
         if beam_size > 1 or group_size > 1:
             raise NotImplementedError("beam / diverse sampling are AR-only host-side paths (out of scope, SURVEY.md §2 row 10)")
-        if train_mode != "NAIC":
-            raise NotImplementedError(f"inference mode {train_mode!r}: only 'NAIC' (bound+fill) is built so far")
+        if train_mode not in ("NAIC", "SAIC"):
+            raise NotImplementedError(f"inference mode {train_mode!r}: a UIC model decodes in 'NAIC' or 'SAIC' mode")
         if sample_method != "greedy":
             raise NotImplementedError(f"sample_method {sample_method!r}: only greedy decode is built so far")
         eng = self.engine()
         torch.cuda.synchronize()                                  # the reference does (AttModel.py:337)
         start = time.time()
-        r = eng.decode_naic(self._as_input(att_feats), self._att_len(att_masks), strict_q1=self.strict_reference,
-                            raw_logits=not output_logsoftmax)
+        if train_mode == "NAIC":
+            r = eng.decode_naic(self._as_input(att_feats), self._att_len(att_masks), strict_q1=self.strict_reference,
+                                raw_logits=not output_logsoftmax)
+        else:                                                     # core_SAIC, AttModel.py:430-437
+            r = eng.decode_saic(self._as_input(att_feats), self._att_len(att_masks), raw_logits=not output_logsoftmax)
         torch.cuda.synchronize()
         end = time.time()
         outs = [r["seq"], r["seq_logprob"], r["phrase_num"], r["phrase_length"], r["phrase_syn"]]

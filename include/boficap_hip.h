@@ -143,6 +143,16 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* att_feats, int feats_d
                             int* phrase_length, int64_t* phrase_syn, float* memory_out, int* bound_iters,
                             void* stream);
 
+/* model(..., opt={'train_mode':'SAIC','sample_method':'greedy'}, mode='sample'): the semi-autoregressive decode
+ * core_SAIC TransformerModel.py:1878-1986 (AttModel.py:430-437) -- per phrase one bounding step on the words
+ * emitted so far (:1907-1926), the position-wise copy of the previous phrase (:1928-1948), a full decoder
+ * pass (decode_SA :520-530) and the copy of the new phrase's tokens and log-probs (:1968-1977); stops
+ * when every image is finished or a NaN appears (:1956-1958).  Outputs as for decode_naic
+ * (seq_logprob rows never written stay 0, as in the reference). */
+int bofi_engine_decode_saic(bofi_engine_t* e, const void* att_feats, int feats_dtype, const int* att_len,
+                            int B, int R, int flags, int64_t* seq, float* seq_logprob, int* phrase_num,
+                            int* phrase_length, int64_t* phrase_syn, int* bound_iters, void* stream);
+
 /* Stages of the call above, exposed for module-level parity tests (SURVEY.md §4 pyramid level 2). */
 int bofi_engine_encode(bofi_engine_t* e, const void* att_feats, int feats_dtype, const int* att_len,
                        int B, int R, float* memory_out, void* stream);

@@ -68,6 +68,32 @@ def test_golden_tiny_f32(name, engines):
         assert r["phrase_length"].dtype == torch.int32 and r["phrase_syn"].dtype == torch.int64
 
 
+@pytest.mark.parametrize("name", TINY_CASES + ["full_b8"])
+def test_golden_saic_f32(name, engines, manifest):
+    """Semi-autoregressive decode (core_SAIC) vs vectors recorded from the reference, including the early
+    return on NaN (an image whose first phrase is empty)."""
+    from boficap_amd import weights as W
+    cfg, sd, eng = engines(name, torch.float32)
+    g = load_golden(name)
+    if name == "full_b8":
+        m = manifest[name]
+        att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
+        att_len = None
+    else:
+        att, att_len = _inputs(g)
+    r = eng.decode_saic(att, att_len)
+    torch.cuda.synchronize()
+    assert (r["phrase_num"].cpu().numpy() == g["saic_phrase_num"]).all()
+    assert (r["phrase_length"].cpu().numpy() == g["saic_phrase_length"]).all()
+    assert (r["phrase_syn"].cpu().numpy() == g["saic_phrase_syn"]).all()
+    assert (r["seq"].cpu().numpy() == g["saic_seq"]).all()
+    lp = r["seq_logprob"].cpu()
+    if "saic_logprob" in g:
+        assert _close(lp.numpy(), g["saic_logprob"], 0) < 1e-3
+    else:
+        assert _close(torch.topk(lp, 2, dim=2)[0].numpy(), g["saic_top2_val"], 0) < 1e-3
+
+
 def test_golden_full_f32(engines, manifest):
     from boficap_amd import weights as W
     cfg, sd, eng = engines("full_b8", torch.float32)
@@ -195,5 +221,7 @@ def test_drop_in_module_sample(weight_cache, manifest):
     assert _close(lp.cpu().numpy(), g["naic_logprob"], 0) < 1e-3
     assert isinstance(secs, float) and masks.shape == (att.size(0), 1, 36)
     assert _close(memory.cpu().numpy(), g["memory"], 0) < 1e-4
+    seq, lp, pn, pl, ps, secs = model(fc, att, None, opt={"train_mode": "SAIC", "sample_method": "greedy"}, mode="sample")
+    assert (seq.cpu().numpy() == g["saic_seq"]).all() and (pl.cpu().numpy() == g["saic_phrase_length"]).all()
     with pytest.raises(NotImplementedError):
-        model(fc, att, None, opt={"train_mode": "SAIC"}, mode="sample")
+        model(fc, att, None, opt={"train_mode": "AIC"}, mode="sample")
