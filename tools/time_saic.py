@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Time the SAIC greedy decode at the benchmark shape (B=64, bf16)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from boficap_amd import weights as W
+from boficap_amd.config import FULL as cfg
+from boficap_amd.engine import BofiEngine
+sd = W.make_state_dict(cfg, 0)
+eng = BofiEngine(cfg, torch.bfloat16, max_batch=64, max_regions=36); eng.load_state_dict(sd)
+att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16)
+r = eng.decode_saic(att); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10): r = eng.decode_saic(att)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+print(f"SAIC greedy B=64 bf16: {dt*1e3:.2f} ms/batch = {64/dt:.0f} images/s, iterations {int(r['bound_iters'])}, NaN {bool(r['seq_logprob'].isnan().any())}")
