@@ -333,10 +333,14 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
                                    cfg.heads, BOUND_ATTN, nullptr, nullptr, s));
     for (int it = 0; it < S; ++it)
         ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
-    // ---- filling pass (decode_NA :570-587)
-    ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
-                                   st_fill, s));
+    // ---- filling pass (decode_NA :570-587); with refinement the pass is repeated with the previous round's ids as
+    // decoder input tokens (the glat_input hook of decode_NA :570-574 -- the reference has no refinement loop itself)
+    const int rounds = 1 + ((flags >> BOFI_FLAG_REFINE_SHIFT) & 15);
     const void* xa = stream_t(x_fill, xb_fill);
+    float* lg = seq_logprob ? seq_logprob : logits;
+    for (int round = 0; round < rounds; ++round) {
+    ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
+                                   st_fill, s));
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
         { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
@@ -363,9 +367,9 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
           ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
     }
     // ---- vocabulary projection (decoder.norm folded in), log-softmax, greedy pick, pad tail
-    float* lg = seq_logprob ? seq_logprob : logits;
     { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s)); }
     ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s));
+    }
     ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
     return BOFI_OK;
 }

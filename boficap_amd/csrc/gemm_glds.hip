@@ -324,7 +324,7 @@ template <typename T>
 static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     // developer override: BOFI_GEMM_TILE=<BM>x<BN>x<NS>
     int bm = 0, bn = 0, ns = 0;
-    if (const char* t = getenv("BOFI_GEMM_TILE")) sscanf(t, "%dx%dx%d", &bm, &bn, &ns);
+    if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%d", &bm, &bn, &ns); }
     if (!bm) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
         // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop

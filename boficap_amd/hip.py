@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "libboficap_hip.so")
 
 DT_F32, DT_BF16 = 0, 1
 FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
+FLAG_REFINE_SHIFT = 8
 ABI_VERSION = 1
 
 

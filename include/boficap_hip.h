@@ -128,6 +128,9 @@ void* bofi_engine_stream(bofi_engine_t* e);
                                       uses the LAST image's length.  Default ON in the Python wrapper. */
 #define BOFI_FLAG_RAW_LOGITS 2     /* output_logsoftmax = 0 (AttModel.py:208-209) */
 #define BOFI_FLAG_GRAPH 4          /* replay the call from a captured hipGraph when possible */
+#define BOFI_FLAG_REFINE_SHIFT 8   /* bits 8..11: extra filling rounds; round r > 0 feeds round r-1's ids back as the
+                                      decoder input tokens (decode_NA's glat_input, TransformerModel.py:570-574).  The
+                                      reference has no refinement loop: parity of rounds > 0 is pinned to the oracle only. */
 
 /* model(fc, att, att_masks, opt={'train_mode':'NAIC','sample_method':'greedy'}, mode='sample'):
  * AttModel._sample AttModel.py:307-338,419-429 -> _prepare_feature TransformerModel.py:1674-1690

@@ -240,6 +240,27 @@ def core_naic(w: Weights, cfg, memory, src_mask, *, fix_q1: bool = False, trace=
     return phrase, phrase_num, phrase_length[:, :-2], phrase_syn[:, :-2], dict(iters=iters, last=last.clone(), ext_syn=ext_syn.clone(), reason=reason)
 
 
+def sample_naic_refine(w: Weights, cfg, att_feats, att_masks=None, *, rounds: int = 2, fix_q1: bool = False):
+    """Iterative refinement of the filling pass (BASELINE config 5).  NOT in the reference: parity unpinned.
+    Defined on the reference's own hook decode_NA(..., glat_input) TM:570-574: round r > 0 decodes with the
+    greedy ids of round r-1 (after the pad-tail rule) as word_seq, same slot layout and fill mask."""
+    memory, src_mask = memory_of(w, cfg, att_feats, att_masks)
+    _, phrase_num, phrase_length, phrase_syn, dg = core_naic(w, cfg, memory, src_mask, fix_q1=fix_q1)
+    B, S = memory.size(0), cfg.seq_length
+    syn_mask = torch.zeros(B, S, S, dtype=torch.bool)
+    for i in range(B):
+        n = int(dg["last"][i] if fix_q1 else dg["last"][B - 1]) - 1
+        syn_mask[i, :, :max(n, 0)] = True
+    seq = None
+    for r in range(rounds + 1):
+        phrase = decode_na(w, cfg, memory, dg["ext_syn"][:, 1:-1], src_mask, syn_mask, glat_input=seq)
+        lp = F.log_softmax(logit(w, phrase), dim=2)
+        seq = torch.max(lp, 2)[1].long()
+        for b in range(B):
+            seq[b, int(phrase_length[b].sum()):] = cfg.pad_idx
+    return seq, lp, phrase_num, phrase_length, phrase_syn
+
+
 def sample_naic(w: Weights, cfg, att_feats, att_masks=None, *, output_logsoftmax: int = 1,
                 fix_q1: bool = False):
     """AM:307-338, 419-429 + AM:203-210 + CM:388-390, greedy, sample_n = 1.

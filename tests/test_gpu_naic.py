@@ -178,6 +178,30 @@ def test_full_batch_properties(engines, weight_cache):
         assert (a["seq_logprob"].cpu() - lp).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("name", ["tiny_mix", "full_b8"])
+def test_iterative_refine_vs_oracle(name, engines, manifest):
+    """BASELINE config 5: refinement rounds of the filling pass.  No reference implementation exists; the oracle
+    defines it on the reference's glat_input hook and the engine must match the oracle."""
+    from boficap_amd import weights as W
+    cfg, sd, eng = engines(name, torch.float32)
+    g = load_golden(name)
+    if name == "full_b8":
+        m = manifest[name]
+        att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]])
+    else:
+        att = torch.from_numpy(g["att_feats"])
+    w = O.as_torch(sd)
+    for rounds in (1, 3):
+        oseq, olp, opn, opl, ops = O.sample_naic_refine(w, cfg, att, rounds=rounds)
+        r = eng.decode_naic(att.cuda(), refine_rounds=rounds)
+        torch.cuda.synchronize()
+        assert torch.equal(r["phrase_length"].cpu(), opl)
+        assert float((r["seq_logprob"].cpu() - olp).nan_to_num().abs().max()) < 1e-3
+        top = torch.topk(olp, 2, dim=2)[0]
+        safe = (top[..., 0] - top[..., 1]) > 1e-3
+        assert torch.equal(r["seq"].cpu()[safe], oseq[safe])
+
+
 def test_forked_engines_in_flight(engines):
     """Several decodes in flight on separate streams (engine forks sharing the weights) give exactly
     the results of one-at-a-time decodes, for equal and for different inputs."""
