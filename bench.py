@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ids-only", action="store_true", help="do not materialise the [B,20,V] log-prob tensor")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--refine", type=int, default=0, help="extra filling rounds (BASELINE config 5 uses 3 rounds at batch 256)")
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,7 +115,7 @@ def main():
     outs = []
     for e, st in zip(engines, streams):
         with torch.cuda.stream(st):
-            outs.append(e.decode_naic(att, want_logprob=not args.ids_only, graph=graph))
+            outs.append(e.decode_naic(att, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine))
     torch.cuda.synchronize()
     out = outs[0]
     log("warm-up + timed steps")
@@ -122,7 +123,7 @@ def main():
     def step(i):
         k = i % len(engines)
         with torch.cuda.stream(streams[k]):
-            engines[k].decode_naic(att, graph=graph, out=outs[k])
+            engines[k].decode_naic(att, graph=graph, out=outs[k], refine_rounds=args.refine)
 
     def barrier():
         if world > 1:
@@ -152,19 +153,25 @@ def main():
     single_ms = None
     if len(engines) > 1:
         for i in range(args.warmup):
-            eng.decode_naic(att, graph=graph, out=outs[0])
+            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine)
         barrier()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            eng.decode_naic(att, graph=graph, out=outs[0])
+            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine)
         barrier()
         single_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    traffic = None                                  # HBM bytes per decode from the committed PMC run (profiles/r01_hbm_traffic.json)
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_decode")
     T = int(out["bound_iters"].item())
     ntok = float(out["phrase_length"].sum(1).float().mean().item())
     nan = bool(out["seq_logprob"].isnan().any().item()) if out["seq_logprob"] is not None else False
     if rank == 0:
         images = args.batch * world * args.steps
-        flops_launch = f_alg(T, cfg) * args.batch
+        dl = 2 * cfg.seq_length * (6 * cfg.d_model ** 2 + 2 * cfg.d_model * cfg.d_ff) + 4 * cfg.seq_length * (cfg.seq_length + 36) * cfg.d_model
+        flops_launch = (f_alg(T, cfg) + args.refine * (cfg.N_dec * dl + 2 * cfg.seq_length * cfg.d_model * cfg.tgt_vocab)) * args.batch
         achieved = flops_launch / (dev_ms * 1e-3) / 1e12
         res = {
             "metric": "images/sec NAR bound+fill greedy decode (NAIC _sample)",
@@ -174,12 +181,14 @@ def main():
             "config": {"workload": f"batch={args.batch} NAR bound+fill inference, 36x2048 regions, d_model=512 6+6 layers(+1 bound layer), {args.dtype}",
                        "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
                        "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
-                       "decodes_in_flight": len(engines),
+                       "decodes_in_flight": len(engines), "refine_rounds": args.refine,
                        "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                        "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
                        "att_feats_seed": ATT_SEED, "nan_in_output": nan, "sharding": "images by rank, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": traffic,
+                         "traffic_note": "HBM-side bytes per decode, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, "
+                                         "one-at-a-time run (profiles/r01_hbm_traffic.json); algorithmic minimum = 9.4 MB features + 125 MB weights + 48.6 MB log-probs",
                          "kernel": ("whole decode = one hipGraph launch of the path's kernels" if graph else "whole decode (eager launches)")
                                    + (f", {len(engines)} decodes in flight" if len(engines) > 1 else ""),
                          "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
