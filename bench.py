@@ -64,6 +64,45 @@ def cpu_baseline(cfg, sd, batch, seed, budget_s=20.0):
             "sample": f"{len(times)} x one batch of {batch} images, fp32 torch-CPU oracle, median, {torch.get_num_threads()} threads"}
 
 
+def gemm_rooflines(dtype, dev):
+    """MFMA roofline of the GEMM kernel on the path's largest shapes: 100 dependent launches of one shape captured in
+    a graph, HIP events around 20 replays on the launch stream (in-graph time per launch, launch boundary included)."""
+    from boficap_amd import hip as H
+    lib = H.lib()
+    out = []
+    for name, M, N, K in (("cross K|V of all layers (kv_all)", 2304, 7168, 512), ("encoder FFN w_1", 2304, 2048, 512),
+                          ("encoder FFN w_2", 2304, 512, 2048), ("generator.proj", 1280, 9491, 512)):
+        x = torch.randn(M, K, device=dev).to(dtype)
+        w = (torch.randn(N, K, device=dev) / K ** 0.5).to(dtype)
+        b = torch.zeros(N, device=dev)
+        y = torch.empty(M, N, device=dev, dtype=dtype)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            def run():
+                H.check(lib.bofi_linear(H.ptr(x), H.dtype_code(x), K, H.ptr(w), H.dtype_code(w), H.ptr(b), None, N, H.ptr(y), H.dtype_code(y), N,
+                                        M, N, K, 0, None, 0, H.stream_ptr()))
+            run(); torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(100):
+                    run()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(20):
+                g.replay()
+            e1.record(st)
+            torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / 2000
+        tf = 2.0 * M * N * K / us / 1e6
+        out.append({"kernel": "gemm_glds_kernel", "shape": f"{name}: M={M} N={N} K={K}", "us_per_launch": round(us, 2),
+                    "achieved": round(tf, 1), "peak": MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], 4)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +233,8 @@ def main():
                          "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
                          "note": "algorithmic FLOPs F_alg(T)*batch (SURVEY.md 8d) / HIP-event time per decode on the launch stream"},
         }
+        if world == 1:
+            res["roofline_gemm"] = gemm_rooflines(tdt, dev)
         log(f"gpu done: {res['value']} images/sec; timing the CPU oracle")
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, args.batch, ATT_SEED)
