@@ -62,13 +62,15 @@ struct Gemm2Params {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
+template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2>     // WM x WN wavefronts, each owns (BM/WM) x (BN/WN)
+__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) {
+    constexpr int NW = WM * WN;
     constexpr int EPC = 16 / sizeof(T);                 // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;                         // one 128-byte slab row
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int STAGE = (BM + BN) * 128;              // bytes per ring slot
-    constexpr int LA = BM / 32, LB = BN / 32;           // LDS-DMA instructions per wave per slab (A, B)
+    constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW;   // LDS-DMA instructions per wave per slab (A, B)
+    static_assert(LA >= 1 && LB >= 1 && LA * 8 * NW == BM && LB * 8 * NW == BN, "tile rows must split evenly over the waves");
     constexpr int LPS = LA + LB;
     constexpr int EPI = BM * (BN + 4) * 4;              // epilogue staging, float32, +4 columns pad
     constexpr int SMEM_MAIN = (NS * STAGE > EPI) ? NS * STAGE : EPI;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     // XCD-aware tile order (workgroup i runs on XCD i % 8, each XCD has its own 4 MiB L2): XCD x gets a
     // CONTIGUOUS run of tiles in (m-tile major, n-tile minor) order, i.e. a band of A rows that stays in
     // its L2 while the weight panel streams; bijective for any tile count.
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     // so all epilogue loads must precede the first store anyway.
     constexpr int LPR = BN / 4;                        // lanes per output row (4 columns each)
     constexpr int RPI = 64 / LPR;                      // rows per wave instruction
-    constexpr int NR = BM / (4 * RPI);                 // rows per lane
+    constexpr int NR = BM / (NW * RPI);                // rows per lane
     const int lr = lane / LPR, lc = (lane % LPR) * 4;
     const int n = n0 + lc;
     const bool ncol_ok = n < p.N;                      // N % 4 == 0: the four columns are in or out together
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
         if (p.ln_stats && ncol_ok) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
+            const int r = wave * RPI + lr + u * NW * RPI, m = m0 + r;
             live[u] = m < p.M && ncol_ok;
             rv[u] = (p.residual && live[u]) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             zero[u] = false;
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, kt + NS - 1);
         if (p.dbg & 2) continue;
-        const unsigned char* sa = smem + (kt % NS) * STAGE + (wr * (BM / 2) + frow) * 128;
-        const unsigned char* sb = smem + (kt % NS) * STAGE + BM * 128 + (wc * (BN / 2) + frow) * 128;
+        const unsigned char* sa = smem + (kt % NS) * STAGE + (wr * (BM / WM) + frow) * 128;
+        const unsigned char* sb = smem + (kt % NS) * STAGE + BM * 128 + (wc * (BN / WN) + frow) * 128;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int coff = (((g * 4 + fq) ^ fx) << 4);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     // output row m = i*16 + (lane & 15) and the FOUR CONSECUTIVE columns n = j*16 + (lane >> 4)*4 + r.
     // Stores straight from that layout would be 32..64-byte pieces (measured: ~1 TB/s); the tile is
     // staged in LDS (reusing the ring) and written back as whole row segments, 16 B per lane.
-    const int mrow = wr * (BM / 2) + (lane & 15), ncol = wc * (BN / 2) + (lane >> 4) * 4;
+    const int mrow = wr * (BM / WM) + (lane & 15), ncol = wc * (BN / WN) + (lane >> 4) * 4;
     if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = 1.f; return; }
     __syncthreads();
     float* es = reinterpret_cast<float*>(smem);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     if (p.vec_ok) {
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            const int r = wave * RPI + lr + u * 4 * RPI, m = m0 + r;
+            const int r = wave * RPI + lr + u * NW * RPI, m = m0 + r;
             float4 v = *reinterpret_cast<const float4*>(&es[r * ES + lc]);
             if (p.ln_stats) {
                 const float mu = s_mean[r], rs = s_rstd[r];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     }
     // general case (e.g. the vocabulary projection, N = 9491, rows not 16-byte aligned): one float per lane
     constexpr int NC = (BN + 63) / 64;
-    constexpr int NRS = BM / 4;
+    constexpr int NRS = BM / NW;
     float sbv[NC], scs[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     bool szero[NRS];
 #pragma unroll
     for (int u = 0; u < NRS; ++u) {
-        const int m = m0 + wave + 4 * u;
+        const int m = m0 + wave + NW * u;
         szero[u] = false;
         if (p.row_len && m < p.M) {
             const int grp = m / p.rows_per_group;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     }
 #pragma unroll
     for (int u = 0; u < NRS; ++u) {
-        const int r = wave + 4 * u, m = m0 + r;
+        const int r = wave + NW * u, m = m0 + r;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int n = n0 + c * 64 + lane;
@@ -315,27 +317,36 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(Gemm2Params p) {
     }
 }
 
-template <typename T, int BM, int BN, int NS>
+template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2>
 static void launch_one(const Gemm2Params& p, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS, WM, WN>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM)), dim3(64 * WM * WN), 0, st, p);
 }
 
 template <typename T>
 static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     // developer override: BOFI_GEMM_TILE=<BM>x<BN>x<NS>
     int bm = 0, bn = 0, ns = 0;
-    if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%d", &bm, &bn, &ns); }
+    int nw = 4;
+    if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%dx%d", &bm, &bn, &ns, &nw); }
     if (!bm) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
         // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop
         const long t = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
         if (p.M <= 64) { bm = 64; bn = 32; ns = 4; }
-        else if (t >= 400) { bm = 128; bn = 64; ns = 2; }
-        else if (p.K >= 2048) { bm = 64; bn = 64; ns = 3; }
-        else { bm = 64; bn = 64; ns = 2; }
+        else if (t >= 400) { bm = 128; bn = 64; ns = 2; nw = 8; }
+        else { bm = 64; bn = 64; ns = 2; nw = 8; }          // 8 waves of 16x32 / 32x32: more waves per CU hide the slab latency
     }
-    const int key = bm * 10000 + bn * 10 + ns;
+    const int key = bm * 10000 + bn * 10 + ns + (nw == 8 ? 100000000 : nw == 16 ? 200000000 : 0);
     switch (key) {
+        case 100640642: launch_one<T, 64, 64, 2, 4, 2>(p, st); break;
+        case 100640643: launch_one<T, 64, 64, 3, 4, 2>(p, st); break;
+        case 101280643: launch_one<T, 128, 64, 3, 4, 2>(p, st); break;
+        case 201281282: launch_one<T, 128, 128, 2, 4, 4>(p, st); break;    // 16 waves
+        case 101281282: launch_one<T, 128, 128, 2, 4, 2>(p, st); break;     // 8 waves
+        case 101281283: launch_one<T, 128, 128, 3, 4, 2>(p, st); break;
+        case 102561282: launch_one<T, 256, 128, 2, 4, 2>(p, st); break;
+        case 101282562: launch_one<T, 128, 256, 2, 2, 4>(p, st); break;
+        case 101280642: launch_one<T, 128, 64, 2, 4, 2>(p, st); break;
         case 1281282: launch_one<T, 128, 128, 2>(p, st); break;
         case 1281283: launch_one<T, 128, 128, 3>(p, st); break;
         case 1281284: launch_one<T, 128, 128, 4>(p, st); break;
