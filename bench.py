@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     args = ap.parse_args()
 
     from boficap_amd import dp
@@ -233,7 +234,7 @@ def main():
                          "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
                          "note": "algorithmic FLOPs F_alg(T)*batch (SURVEY.md 8d) / HIP-event time per decode on the launch stream"},
         }
-        if world == 1:
+        if world == 1 and not args.no_gemm_roofline:
             res["roofline_gemm"] = gemm_rooflines(tdt, dev)
         log(f"gpu done: {res['value']} images/sec; timing the CPU oracle")
         if not args.no_cpu_baseline and world == 1:

@@ -32,6 +32,7 @@ struct LinearArgs {
     const float* ln_stats; const float* ln_colsum;
     float* stats_out;         // write partial (sum, sumsq) of the OUTPUT rows: float2 [M][N/32]
     void* y2; int ldy2;       // second copy of the output in the compute dtype (feeds the next folded GEMM)
+    int splitk;               // > 1: K split over workgroups; y receives `splitk` float32 partial slabs [splitk][M][ldy]
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
 int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible

@@ -46,7 +46,7 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 #define BOUND_SAIC 16    /* SAIC bookkeeping (TransformerModel.py:1910-1948) instead of NAIC's; early-out on the halt word */
 int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
-                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa = nullptr, int iter = 0);
+                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa = nullptr, int iter = 0, int yparts = 1);
 // rows of pos_embed(tgt_embed(tok) [+ syn_embed(syn)]): row r = (b, t), ids read at [b*ld + off + t]; tok == NULL -> BOS
 int launch_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int* tok, const int* syn, int ld, int off,
                       int B, int T, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, const int* halt, hipStream_t s);

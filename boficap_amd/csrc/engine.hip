@@ -182,6 +182,7 @@ struct bofi_engine {
         const int* row_len = nullptr; int rpg = 0;
         bool early = false;
         bool halt = false;                   // SAIC: early-out on the halt word (counters[2] >= 1)
+        int splitk = 1;                      // K split over workgroups, float32 partial slabs out
         const Norm* ln = nullptr;            // explicit LayerNorm kernel on x first (setup-time use only)
         const float* ln_stats = nullptr;     // LayerNorm folded into the GEMM (Lin built with fold_norm)
         float* stats_out = nullptr;          // emit row partial sums of the output
@@ -200,7 +201,7 @@ struct bofi_engine {
         a.residual = o.residual; a.ldr = o.ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy;
         a.M = M; a.N = l.N; a.K = l.K; a.relu = o.relu; a.row_len = o.row_len; a.rows_per_group = o.rpg;
         a.ln_stats = o.ln_stats; a.ln_colsum = o.ln_stats ? l.cs : nullptr;
-        a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N;
+        a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N; a.splitk = o.splitk;
         if (o.early) { a.skip_if_ge = st.counters; a.skip_threshold = cur_B; }
         if (o.halt) { a.skip_if_ge = st.counters + 2; a.skip_threshold = 1; }
         return bofi::launch_linear(a, s);
@@ -233,7 +234,7 @@ struct bofi_engine {
     if (c.dtype == BOFI_DT_BF16) ENG_OK(dalloc((char**)&feats_t, Bm * Rm * (size_t)c.feat, 2));
     ENG_OK(dalloc(&st_enc, Bm * Rm * (d / 32) * 2)); ENG_OK(dalloc(&st_fill, Bm * Sq * (d / 32) * 2));
     ENG_OK(dalloc(&st_b, Bm * (d / 32) * 2));
-    ENG_OK(dalloc(&by1, Bm * d)); ENG_OK(dalloc(&by2, Bm * d)); ENG_OK(dalloc(&by3, Bm * d));
+    ENG_OK(dalloc(&by1, Bm * d)); ENG_OK(dalloc(&by2, Bm * d)); ENG_OK(dalloc(&by3, 4 * Bm * d));
     ENG_OK(dalloc((char**)&bctx, Bm * d, tsz)); ENG_OK(dalloc((char**)&bq2, Bm * d, tsz));
     ENG_OK(dalloc((char**)&bctx2, Bm * d, tsz)); ENG_OK(dalloc((char**)&bh, Bm * dff, tsz));
     ENG_OK(dalloc(&st.last, Bm)); ENG_OK(dalloc(&st.finished, Bm)); ENG_OK(dalloc(&st.phrase_num, Bm));
@@ -314,11 +315,12 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     { LinOpt o; o.residual = by1; o.ldr = d; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
       ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
     { LinOpt o; o.relu = 1; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
-    { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
+    const int w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;     // K = d_ff split 4 ways: 4x the workgroups, a quarter of the K loop
+    { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
     // heads + bookkeeping, fused with the next iteration's row-0 self-attention
     const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
     ENG_OK(bofi::launch_bound_tail(by3, heads, st, update ? nullptr : ext_syn, update ? nullptr : last, b_q0, b_kvtab, bctx, dt, B, L,
-                                   cfg.seq_length, d, cfg.head_hidden, cfg.heads, flags, len_logp, syn_logp, s));
+                                   cfg.seq_length, d, cfg.head_hidden, cfg.heads, flags, len_logp, syn_logp, s, nullptr, 0, w2parts));
     return BOFI_OK;
 }
 
@@ -410,9 +412,10 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
         { LinOpt o; o.residual = by1; o.ldr = d; o.halt = true; o.stats_out = st_b; o.y2 = copy_t(byb);
           ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
         { LinOpt o; o.relu = 1; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
-        { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
+        const int w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;
+        { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
         ENG_OK(bofi::launch_bound_tail(by3, heads, st, nullptr, nullptr, b_q0, b_kvtab, bctx, dt, B, L, S, d, cfg.head_hidden, cfg.heads,
-                                       BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, &sa, it));
+                                       BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, &sa, it, w2parts));
         // ---- decoder pass over all S positions (decode_SA :520-530) with the phrase-block mask as per-row key prefixes
         ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                        st_fill, halt, s));

@@ -56,6 +56,8 @@ struct Gemm2Params {
     const float* ln_stats; const float* ln_colsum;
     float* stats_out;         // this GEMM is a producer: partial (sum, sumsq) of its OUTPUT rows, [M][N/32][2]
     void* y2; int ldy2;       // optional second copy of the output in the compute dtype
+    int splitk;               // > 1: blockIdx.y walks K slices; slice s writes its partial tile to y + s*M*ldy (f32),
+                              // bias / residual are added by slice 0 only, the consumer sums the slabs
     int vec_ok;               // N, ldy, ldr multiples of 4 and y/bias/residual 16-byte aligned
     int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
 };
@@ -102,13 +104,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     for (int j = 0; j < LA; ++j) {
         int m = m0 + (wave * LA + j) * 8 + lrow;
         m = m < p.M ? m : p.M - 1;                      // clamp: rows past M are computed and dropped
-        asrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * EPC;
+        asrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * EPC + (size_t)blockIdx.y * (p.K / p.splitk);
     }
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
         int n = n0 + (wave * LB + j) * 8 + lrow;
         n = n < p.N ? n : p.N - 1;
-        bsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * EPC;
+        bsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * EPC + (size_t)blockIdx.y * (p.K / p.splitk);
     }
     auto issue = [&](int slot, int kt) {
         if (p.dbg & 1) return;
@@ -130,7 +132,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.K / p.splitk / BK;
+    if (blockIdx.y > 0) { p.bias = nullptr; p.residual = nullptr; }
+    p.y = static_cast<char*>(p.y) + (size_t)blockIdx.y * p.M * p.ldy * sizeof(float);      // split-K slabs are float32
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, s);
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
 
 template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2>
 static void launch_one(const Gemm2Params& p, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS, WM, WN>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM)), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS, WM, WN>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), p.splitk), dim3(64 * WM * WN), 0, st, p);
 }
 
 template <typename T>
@@ -377,6 +381,9 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.relu = a.relu; p.row_len = a.row_len; p.rows_per_group = a.rows_per_group;
     p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
     p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
+    p.splitk = a.splitk > 1 ? a.splitk : 1;
+    if (p.splitk > 1 && (a.y_dtype != BOFI_DT_F32 || a.relu || a.ln_stats || a.stats_out || a.y2 || a.row_len || (a.K / p.splitk) % bk || a.K % p.splitk))
+        return BOFI_ERR_ARG;
     { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }
     const int yel = p.y_is_f32 ? 4 : el;
     p.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && ((uintptr_t)a.y * 0 + (size_t)a.ldy * yel) % 8 == 0 &&

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
                                                          const int* ext_syn_in, const int* last_in, const T* __restrict__ q0,
                                                          const T* __restrict__ kvtab, T* __restrict__ ctx, int B, int L, int S,
                                                          int d, int hh, int H, int flags, float* len_logp_out, float* syn_logp_out,
-                                                         SaicState sa, int iter) {
+                                                         SaicState sa, int iter, int yparts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((flags & BOUND_EARLY) && ((flags & BOUND_SAIC) ? st.counters[2] >= 1 : st.counters[0] >= B)) return;
     const int nh = 2 * hh;
@@ -87,20 +87,37 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
 
     if (flags & BOUND_HEADS) {
         for (int i = tid; i < 30 * hh; i += 512) w2s[i] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
-        const float* yr = y + (size_t)b * d;
+        // Everything this phase needs from global memory is requested up front (one round trip): the row of y
+        // (possibly split-K partial slabs [yparts][B][d], summed in fixed order), the norm vectors, the hidden bias.
+        constexpr int KPT = 4;                        // columns per thread: d <= 512 * KPT
+        float yv[KPT], gv[KPT], bvn[KPT];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) {
+            const int k = tid + c * 512;
+            yv[c] = 0.f; gv[c] = 0.f; bvn[c] = 0.f;
+            if (k < d) {
+                float acc = y[(size_t)b * d + k];
+                for (int pz = 1; pz < yparts; ++pz) acc += y[((size_t)pz * B + b) * d + k];
+                yv[c] = acc; gv[c] = w.norm_gain[k]; bvn[c] = w.norm_bias[k];
+            }
+        }
+        const float b1v = tid < nh ? w.b1[tid] : 0.f;
         float s = 0.f;
-        for (int k = tid; k < d; k += 512) s += yr[k];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) s += yv[c];
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
         __syncthreads();
         const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / (float)d;
         float q = 0.f;
-        for (int k = tid; k < d; k += 512) { const float t = yr[k] - mean; q += t * t; }
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) if (tid + c * 512 < d) { const float t = yv[c] - mean; q += t * t; }
         q = wave_sum(q);
         if (lane == 0) red[8 + wave] = q;
         __syncthreads();
         const float den = sqrtf((((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]))) / (float)(d - 1)) + 1e-6f;
-        for (int k = tid; k < d; k += 512) xs[k] = w.norm_gain[k] * (yr[k] - mean) / den + w.norm_bias[k];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) if (tid + c * 512 < d) xs[tid + c * 512] = gv[c] * (yv[c] - mean) / den + bvn[c];
         __syncthreads();
         // hidden layer of both heads: thread (slice, group) sums 4 outputs over an eighth of K
         const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng;
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
         __syncthreads();
         if (tid < nh)
             hid[tid] = fmaxf((((part[tid] + part[nh + tid]) + (part[2 * nh + tid] + part[3 * nh + tid])) +
-                              ((part[4 * nh + tid] + part[5 * nh + tid]) + (part[6 * nh + tid] + part[7 * nh + tid]))) + w.b1[tid], 0.f);
+                              ((part[4 * nh + tid] + part[5 * nh + tid]) + (part[6 * nh + tid] + part[7 * nh + tid]))) + b1v, 0.f);
         __syncthreads();
         if (tid < 30) {
             const bool is_len = tid < 20;
@@ -264,16 +281,16 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
 
 int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
                       const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
-                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa, int iter) {
+                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa, int iter, int yparts) {
     const SaicState sav = sa ? *sa : SaicState{};
-    if ((2 * hh) % 4 || d % 8 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60) return BOFI_ERR_ARG;
+    if (d > 2048 || (2 * hh) % 4 || d % 8 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60) return BOFI_ERR_ARG;
     const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * hh) * sizeof(float);
     if (dtype == BOFI_DT_F32)
         hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
-                           (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter);
+                           (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter, yparts > 1 ? yparts : 1);
     else
         hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const bf16_t*)q0,
-                           (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter);
+                           (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter, yparts > 1 ? yparts : 1);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
