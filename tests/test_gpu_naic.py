@@ -226,6 +226,57 @@ def test_forked_engines_in_flight(engines):
     del forks, outs
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ragged_regions_full_config(dtype, weight_cache):
+    """Full-size model, 50 regions with per-image region counts (att_masks), batch sizes 1 and 5: the padded
+    rows must be exact zeros after att_embed and masked as keys everywhere (AttModel.py:46-51, 113-120)."""
+    from boficap_amd import weights as W
+    from boficap_amd.engine import BofiEngine
+    cfg, sd = weight_cache("FULL", 0, 1.0)
+    w = O.as_torch(sd)
+    eng = BofiEngine(cfg, dtype, max_batch=8, max_regions=50)
+    eng.load_state_dict(sd)
+    att_np = W.synthetic_att_feats(5, 50, cfg.att_feat_size, seed=21)
+    lens = [50, 17, 36, 1, 44]
+    masks = np.zeros((5, 50), np.float32)
+    for b, n in enumerate(lens):
+        masks[b, :n] = 1
+        att_np[b, n:] = 7.0                                  # garbage in the padding must not leak
+    for sl in (slice(0, 5), slice(1, 2)):
+        att, am = torch.from_numpy(att_np[sl]), torch.from_numpy(masks[sl])
+        oseq, olp, opn, opl, ops, _ = O.sample_naic(w, cfg, att, am, fix_q1=True)
+        r = eng.decode_naic(att.cuda(), am.sum(1).to(torch.int32).cuda(), strict_q1=False)
+        torch.cuda.synchronize()
+        if dtype == torch.float32:
+            assert torch.equal(r["phrase_length"].cpu(), opl) and torch.equal(r["phrase_syn"].cpu(), ops)
+            assert float((r["seq_logprob"].cpu() - olp).nan_to_num().abs().max()) < 1e-3
+        else:
+            same = (r["phrase_length"].cpu() == opl).all(1)
+            assert int(same.sum()) >= len(same) - 1
+            assert float((r["seq_logprob"].cpu()[same] - olp[same]).nan_to_num().abs().max()) < 2e-2
+
+
+def test_engine_rejects_bad_calls(engines):
+    from boficap_amd.hip import BofiHipError
+    cfg, sd, eng = engines("tiny_mix", torch.float32)
+    good = torch.zeros(2, 36, cfg.att_feat_size, device="cuda")
+    with pytest.raises(BofiHipError):
+        eng.decode_naic(torch.zeros(2, 36, cfg.att_feat_size + 64, device="cuda"))      # wrong feature size
+    with pytest.raises(BofiHipError):
+        eng.decode_naic(torch.zeros(65, 36, cfg.att_feat_size, device="cuda"))          # batch > max_batch
+    with pytest.raises(BofiHipError):
+        eng.decode_naic(torch.zeros(2, 40, cfg.att_feat_size, device="cuda"))           # regions > max_regions
+    with pytest.raises(BofiHipError):
+        eng.decode_naic(good.cpu())                                                      # host tensor
+    with pytest.raises(BofiHipError):
+        eng.decode_naic(good.to(torch.bfloat16))                                         # bf16 features into an f32 engine
+    with pytest.raises(BofiHipError):
+        eng.decode_naic(good, torch.ones(2, dtype=torch.int64, device="cuda"))           # att_len must be int32
+    r = eng.decode_naic(good)                                                            # and the engine still works afterwards
+    torch.cuda.synchronize()
+    assert r["seq"].shape == (2, cfg.seq_length)
+
+
 def test_drop_in_module_sample(weight_cache, manifest):
     """captioning.models.setup(opt) -> load_state_dict -> model(..., mode='sample'): the 6-tuple."""
     import captioning.models as models
