@@ -367,3 +367,88 @@ def sample_saic(w: Weights, cfg, att_feats, att_masks=None, *, output_logsoftmax
     t0 = time.time()
     seq, lp, pn, pl, ps, _ = core_saic(w, cfg, memory, src_mask, output_logsoftmax=output_logsoftmax)
     return seq, lp, pn, pl, ps, time.time() - t0
+
+
+# ----------------------------------------------------------------------------- XE training forward (a14) and criterion (a15)
+def _teacher_forced_bound(w, cfg, input_embed, memory, src_mask, phrase_num, phrase_length):
+    """get_predict_phrase_length_syn_SA / _NA, TM:476-513 / TM:532-565 (shared body): one predictor pass per
+    phrase index with the mask grown per caption; pass i lands in slot i+1; returns ([N,L-1,20], [N,L-1,10], last)."""
+    B, L = phrase_length.shape
+    tgt_mask = torch.zeros(B, L, L, dtype=torch.bool)
+    len_lp = torch.zeros(B, L, LENGTH_DIM)
+    syn_lp = torch.zeros(B, L, SYN_DIM)
+    last = torch.ones(B, dtype=torch.int)
+    tgt_mask[:, :, 0] = True
+    _, a, _, b = bound_step(w, cfg, input_embed, memory, src_mask, tgt_mask)
+    len_lp[:, 1], syn_lp[:, 1] = a, b
+    for i in range(1, int(phrase_num.max())):
+        for j in range(B):
+            if int(phrase_num[j]) <= i:
+                continue
+            la, pl = int(last[j]), int(phrase_length[j, i])
+            tgt_mask[j, la:, :la + pl] = True
+            last[j] = la + pl
+            tgt_mask[j, 0, :la + pl] = True
+        _, a, _, b = bound_step(w, cfg, input_embed, memory, src_mask, tgt_mask)
+        len_lp[:, i + 1], syn_lp[:, i + 1] = a, b
+    return len_lp[:, 1:, :], syn_lp[:, 1:, :], last
+
+
+def forward_uic(w: Weights, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn,
+                extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask):
+    """TransformerModel._forward TM:1713-1724,1759-1775 -> EncoderDecoder_UIC.forward TM:413-468 with glat_p < 0,
+    dropout off (eval mode).  Inputs may be [B, spi, ...]; returns the six log-prob tensors."""
+    if labels.dim() == 3:
+        labels = labels.reshape(-1, labels.shape[2])
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        extend_phrase_syn_seq = extend_phrase_syn_seq.reshape(-1, extend_phrase_syn_seq.shape[2])
+        extend_phrase_seq = extend_phrase_seq.reshape(-1, extend_phrase_seq.shape[2])
+        extend_phrase_seq_mask = extend_phrase_seq_mask.reshape(-1, extend_phrase_seq.shape[1], extend_phrase_seq.shape[1])
+    x, src_mask = prepare_feature(w, cfg, att_feats, att_masks)
+    spi = labels.shape[0] // x.shape[0]
+    if spi > 1:                                                         # TM:1703-1707, models/utils.py:3-14
+        x = x.repeat_interleave(spi, dim=0)
+        src_mask = src_mask.repeat_interleave(spi, dim=0)
+    memory = encode(w, cfg, x, src_mask)
+    d = cfg.d_model
+    word_seq = labels.clone().long()
+    word_seq[:, 0] = cfg.len_idx                                        # TM:478-479
+    sa_len, sa_syn, _ = _teacher_forced_bound(w, cfg, add_pe(w, embed(w, "model.tgt_embed", word_seq, d)), memory, src_mask,
+                                              phrase_num, phrase_length)
+    sa_phrase = decode_sa(w, cfg, memory, extend_phrase_seq, extend_phrase_syn_seq[:, 1:-1], src_mask, extend_phrase_seq_mask)
+    na_len, na_syn, last = _teacher_forced_bound(w, cfg, add_pe(w, embed(w, "model.syn_embed", extend_phrase_syn_seq, d)), memory,
+                                                 src_mask, phrase_num, phrase_length)
+    S = cfg.seq_length
+    syn_mask = torch.zeros(labels.shape[0], S, S, dtype=torch.bool)
+    for i in range(labels.shape[0]):
+        syn_mask[i, :, :int(last[i]) - 1] = True                        # TM:562-564 (per-row index here)
+    na_phrase = decode_na(w, cfg, memory, extend_phrase_syn_seq[:, 1:-1], src_mask, syn_mask)
+    return (sa_len, sa_syn, F.log_softmax(logit(w, sa_phrase), dim=-1),
+            na_len, na_syn, F.log_softmax(logit(w, na_phrase), dim=-1))
+
+
+def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
+    """LanguageModelCriterion_UIC.forward losses.py:319-369, reduction='mean', self_dis=False."""
+    sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok = outs
+    if phrase_length.dim() == 3:
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        phrase_syn = phrase_syn.reshape(-1, phrase_syn.shape[2])
+        labels = labels.reshape(-1, labels.shape[2])
+    B = labels.shape[0]
+    real = labels[:, 1:-1].long()
+    tok_mask = torch.zeros(real.shape, dtype=torch.bool)
+    for i in range(B):
+        tok_mask[i, 0:int(phrase_length[i].sum()) - 1] = True
+    sa_tok_loss = -sa_tok.gather(2, real.unsqueeze(2)).squeeze(2) * tok_mask
+    na_tok_loss = -na_tok.gather(2, real.unsqueeze(2)).squeeze(2) * tok_mask
+    len_lab, syn_lab = phrase_length[:, 1:].long(), phrase_syn[:, 1:].long()
+    slot_mask = torch.zeros(len_lab.shape, dtype=torch.bool)
+    for i in range(B):
+        slot_mask[i, 0:int(phrase_num[i])] = True
+    g = lambda lp, lab: -lp.gather(2, lab.unsqueeze(2)).squeeze(2) * slot_mask
+    denom = tok_mask.sum()
+    parts = [g(sa_len, len_lab).sum() / denom, sa_tok_loss.sum() / denom, g(sa_syn, syn_lab).sum() / denom,
+             g(na_len, len_lab).sum() / denom, na_tok_loss.sum() / denom, g(na_syn, syn_lab).sum() / denom]
+    return sum(parts), parts

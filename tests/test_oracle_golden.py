@@ -84,3 +84,19 @@ def test_q1_fix_changes_only_fill(manifest, weight_cache):
     b = O.sample_naic(w, cfg, att, None, fix_q1=True)
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     assert not torch.equal(a[0], b[0])
+
+
+def test_oracle_xe_forward_and_criterion(manifest, weight_cache):
+    """XE training forward (six log-prob tensors) and LanguageModelCriterion_UIC vs the reference's recorded outputs."""
+    m = manifest["tiny_train_xe"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    w = O.as_torch(sd)
+    g = load_golden("tiny_train_xe")
+    t = lambda k: torch.from_numpy(g[k])
+    outs = O.forward_uic(w, cfg, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                         t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"))
+    for i, o in enumerate(outs):
+        assert _close(o.numpy(), g[f"out{i}"], 1e-5)
+    loss, parts = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4
+    assert np.allclose([float(p) for p in parts], g["losses"][1:], atol=1e-5)
