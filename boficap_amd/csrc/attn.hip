@@ -51,6 +51,7 @@ struct AttnParams {
     int B, H, Lq, Lk;
     const int* klen; int klen_sb, klen_sq, klen_bias, klen_shared_last;
     const int* skip_if_ge; int skip_threshold;
+    int kdiv;
 };
 
 constexpr int DK = 64;
@@ -87,14 +88,15 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
         if (r < nq) val = *reinterpret_cast<const u32x4*>(qg + (size_t)r * p.ldq + ch * EPC);
         *reinterpret_cast<u32x4*>(&sq[r * QS + ch * EPC]) = val;
     }
-    const T* kg = static_cast<const T*>(p.k) + (size_t)b * Lk * p.ldk + h * DK;
+    const int bk = b / p.kdiv;                         // captions of one image share its keys (training)
+    const T* kg = static_cast<const T*>(p.k) + (size_t)bk * Lk * p.ldk + h * DK;
     for (int c = lane; c < nkt * 16 * CPR; c += 64) {
         const int r = c / CPR, ch = c - r * CPR;
         u32x4 val = u32x4{0u, 0u, 0u, 0u};
         if (r < Lk) val = *reinterpret_cast<const u32x4*>(kg + (size_t)r * p.ldk + ch * EPC);
         *reinterpret_cast<u32x4*>(&sk[r * QS + ch * EPC]) = val;
     }
-    const T* vg = static_cast<const T*>(p.v) + (size_t)b * Lk * p.ldv + h * DK;
+    const T* vg = static_cast<const T*>(p.v) + (size_t)bk * Lk * p.ldv + h * DK;
     for (int c = lane; c < lkr * CPR; c += 64) {
         const int r = c / CPR, ch = c - r * CPR;
         union { u32x4 v; T e[EPC]; } u;
@@ -208,6 +210,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     p.q = a.q; p.ldq = a.ldq; p.k = a.k; p.ldk = a.ldk; p.v = a.v; p.ldv = a.ldv; p.out = a.out; p.ldo = a.ldo;
     p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;
     p.klen = a.klen; p.klen_sb = a.klen_sb; p.klen_sq = a.klen_sq; p.klen_bias = a.klen_bias;
+    p.kdiv = a.kdiv > 0 ? a.kdiv : 1;
     p.klen_shared_last = a.klen_shared_last; p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
     return a.dtype == BOFI_DT_F32 ? launch_attn_t<float>(p, st) : launch_attn_t<bf16_t>(p, st);
 }
@@ -220,5 +223,16 @@ extern "C" int bofi_attention(const void* q, int ldq, const void* k, int ldk, co
     bofi::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.dtype = dtype;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = klen_sq;
+    return bofi::launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
+                                 int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq,
+                                 int klen_bias, void* stream) {
+    if (kdiv <= 0) return BOFI_ERR_ARG;
+    bofi::AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.dtype = dtype;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = klen_sq;
+    a.klen_bias = klen_bias; a.kdiv = kdiv;
     return bofi::launch_attention(a, (hipStream_t)stream);
 }

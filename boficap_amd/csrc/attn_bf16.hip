@@ -181,7 +181,7 @@ static void launch_ab(const AttnParamsB& p, hipStream_t st) {
 
 // returns -1 when the call is not eligible (then attn.hip handles it)
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
-    if (a.dtype != BOFI_DT_BF16 || a.Lk > 64 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
+    if (a.dtype != BOFI_DT_BF16 || a.kdiv > 1 || a.Lk > 64 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
     AttnParamsB p;
     p.q = (const bf16_t*)a.q; p.ldq = a.ldq; p.k = (const bf16_t*)a.k; p.ldk = a.ldk; p.v = (const bf16_t*)a.v; p.ldv = a.ldv;
     p.out = (bf16_t*)a.out; p.ldo = a.ldo; p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;

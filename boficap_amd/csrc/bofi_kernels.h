@@ -48,6 +48,7 @@ struct AttnArgs {
     int klen_bias;            // effective length = klen[...] + klen_bias (e.g. -1 for last-1)
     int klen_shared_last;     // quirk Q1: use entry (B-1) of klen for every batch item
     const int* skip_if_ge; int skip_threshold;
+    int kdiv;                 // key/value batch item = b / kdiv (0 or 1: one per query batch item)
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible

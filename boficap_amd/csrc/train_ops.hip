@@ -1,0 +1,279 @@
+// Backward kernels for the XE training step (reference tools/train.py:212-227 runs autograd over the torch ops of
+// TransformerModel._forward; here each forward kernel gets its hand-written backward).  All float32: the training
+// path is built for parity first.  Gradients w.r.t. parameters that are sums over rows are accumulated with float
+// atomics into zero-initialised buffers (order-dependent in the last bits, as any parallel reduction).
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (forward: y = g * t / s + b, t = x - mean, s = sqrt(sum t^2 / (d-1)) + eps; TransformerModel.py:1346-1349)
+//   dt_i = dyh_i / s - t_i * (sum_j dyh_j t_j) / (s^2 * sigma * (d-1)),  dyh = dy * g,  dx = dt - mean(dt)
+// One wavefront per row.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gain,
+                                                     const float* __restrict__ dy, float* __restrict__ dx, float* dgain,
+                                                     float* dbias, int rows, int d) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * d;
+    const float* dyr = dy + (size_t)row * d;
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) s += xr[k];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f, c = 0.f;
+    for (int k = lane; k < d; k += 64) { const float t = xr[k] - mean; q += t * t; c += dyr[k] * gain[k] * t; }
+    q = wave_sum(q); c = wave_sum(c);
+    const float sigma = sqrtf(q / (float)(d - 1)), sd = sigma + 1e-6f;
+    const float coef = sigma > 0.f ? c / (sd * sd * sigma * (float)(d - 1)) : 0.f;
+    float m = 0.f;
+    for (int k = lane; k < d; k += 64) m += dyr[k] * gain[k] / sd - (xr[k] - mean) * coef;
+    m = wave_sum(m) / (float)d;
+    for (int k = lane; k < d; k += 64) {
+        const float t = xr[k] - mean;
+        dx[(size_t)row * d + k] = dyr[k] * gain[k] / sd - t * coef - m;
+        atomicAdd(&dgain[k], dyr[k] * t / sd);
+        atomicAdd(&dbias[k], dyr[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention backward for the short sequences of this model (Lq, Lk <= 64, d_k = 64), float32, one workgroup per
+// (batch item, head): recompute P, then dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8.
+struct AttnBwdParams {
+    const float* q; int ldq; const float* k; int ldk; const float* v; int ldv;
+    const float* dout; int ldo;
+    float* dq; float* dk; float* dv;          // same layouts as q / k / v; dk, dv accumulate with atomics when kdiv > 1
+    int B, H, Lq, Lk, kdiv;
+    const int* klen; int klen_sb, klen_sq, klen_bias;
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
+    __shared__ float sq[64 * 65], sk[64 * 65], sv[64 * 65], sdo[64 * 65], sp[64 * 65], sds[64 * 65];
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, tid = threadIdx.x;
+    const int bk = b / p.kdiv;
+    const int Lq = p.Lq, Lk = p.Lk;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        sq[r * 65 + c] = r < Lq ? p.q[((size_t)b * Lq + r) * p.ldq + h * 64 + c] : 0.f;
+        sdo[r * 65 + c] = r < Lq ? p.dout[((size_t)b * Lq + r) * p.ldo + h * 64 + c] : 0.f;
+        sk[r * 65 + c] = r < Lk ? p.k[((size_t)bk * Lk + r) * p.ldk + h * 64 + c] : 0.f;
+        sv[r * 65 + c] = r < Lk ? p.v[((size_t)bk * Lk + r) * p.ldv + h * 64 + c] : 0.f;
+    }
+    __syncthreads();
+    // scores and dP, thread (i, j-range)
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        float s = 0.f, dp = 0.f;
+        if (i < Lq && j < Lk) {
+            for (int c = 0; c < 64; ++c) { s = fmaf(sq[i * 65 + c], sk[j * 65 + c], s); dp = fmaf(sdo[i * 65 + c], sv[j * 65 + c], dp); }
+        }
+        sp[i * 65 + j] = s * 0.125f;
+        sds[i * 65 + j] = dp;
+    }
+    __syncthreads();
+    // row softmax + dS, one thread per query row (rows are short)
+    if (tid < 64) {
+        const int i = tid;
+        int kl = Lk;
+        if (p.klen && i < Lq) { kl = p.klen[b * p.klen_sb + i * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
+        if (i >= Lq) kl = 0;
+        float m = -INFINITY;
+        for (int j = 0; j < kl; ++j) m = fmaxf(m, sp[i * 65 + j]);
+        float sum = 0.f;
+        for (int j = 0; j < kl; ++j) { const float e = expf(sp[i * 65 + j] - m); sp[i * 65 + j] = e; sum += e; }
+        float dot = 0.f;
+        for (int j = 0; j < 64; ++j) { const float pv = j < kl ? sp[i * 65 + j] / sum : 0.f; sp[i * 65 + j] = pv; dot += pv * sds[i * 65 + j]; }
+        for (int j = 0; j < 64; ++j) sds[i * 65 + j] = sp[i * 65 + j] * (sds[i * 65 + j] - dot) * 0.125f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (r < Lq) {                                           // dQ[r][c] = sum_j dS[r][j] K[j][c]
+            float a = 0.f;
+            for (int j = 0; j < Lk; ++j) a = fmaf(sds[r * 65 + j], sk[j * 65 + c], a);
+            p.dq[((size_t)b * Lq + r) * p.ldq + h * 64 + c] = a;
+        }
+        if (r < Lk) {                                           // dK[r][c] = sum_i dS[i][r] Q[i][c];  dV[r][c] = sum_i P[i][r] dO[i][c]
+            float a = 0.f, g = 0.f;
+            for (int i = 0; i < Lq; ++i) { a = fmaf(sds[i * 65 + r], sq[i * 65 + c], a); g = fmaf(sp[i * 65 + r], sdo[i * 65 + c], g); }
+            float* dkp = p.dk + ((size_t)bk * Lk + r) * p.ldk + h * 64 + c;
+            float* dvp = p.dv + ((size_t)bk * Lk + r) * p.ldv + h * 64 + c;
+            if (p.kdiv > 1) { atomicAdd(dkp, a); atomicAdd(dvp, g); } else { *dkp = a; *dvp = g; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log_softmax backward: dx = dy - exp(y) * rowsum(dy)   (y = log-probabilities)
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, int V) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* yr = y + (size_t)row * V;
+    const float* dyr = dy + (size_t)row * V;
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += dyr[i];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = tid; i < V; i += 256) dx[(size_t)row * V + i] = dyr[i] - expf(yr[i]) * s;
+}
+
+// column sums (bias gradients): out[n] += sum_m x[m][n]
+__global__ void colsum_kernel(const float* __restrict__ x, float* out, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * 64, m1 = min(M, m0 + 64);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += x[(size_t)m * N + n];
+    atomicAdd(&out[n], s);
+}
+
+// embedding backward: d_lut[id[r]] += scale * dx[r]
+__global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids, float* dlut, int rows, int d, float scale) {
+    const int r = blockIdx.x;
+    const int64_t id = ids[r];
+    for (int k = threadIdx.x; k < d; k += blockDim.x) atomicAdd(&dlut[(size_t)id * d + k], scale * dx[(size_t)r * d + k]);
+}
+
+// embedding forward for teacher-forced rows: x[r] = (tok ? lut_tok[tok[r]] * sqrt(d) : 0) (+ syn likewise) + pe[r % L]
+// (Embeddings TransformerModel.py:1484-1492, PositionalEncoding :1494-1511; (tok + syn) + pe keeps the reference's order)
+__global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict__ lut_tok, const float* __restrict__ lut_syn,
+                                                        const float* __restrict__ pe, const int64_t* tok, const int64_t* syn, int L,
+                                                        int d, float sqrt_d, float* __restrict__ x) {
+    const int r = blockIdx.x;
+    const float* tr = tok ? lut_tok + (size_t)tok[r] * d : nullptr;
+    const float* sr = syn ? lut_syn + (size_t)syn[r] * d : nullptr;
+    const float* pr = pe + (size_t)(r % L) * d;
+    for (int k = threadIdx.x; k < d; k += 128) {
+        float v;
+        if (tr && sr) v = (tr[k] * sqrt_d + sr[k] * sqrt_d) + pr[k];
+        else v = (tr ? tr[k] : sr[k]) * sqrt_d + pr[k];
+        x[(size_t)r * d + k] = v;
+    }
+}
+
+// xt[n][m] = x[m][n] for m < M, 0 for M <= m < Mpad   (operands of the weight-gradient GEMM, whose inner dimension is M)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int ldx, float* __restrict__ xt, int M, int N, int Mpad) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int m = m0 + i, n = n0 + tx;
+        tile[i][tx] = (m < M && n < N) ? x[(size_t)m * ldx + n] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, m = m0 + tx;
+        if (n < N && m < Mpad) xt[(size_t)n * Mpad + m] = tile[tx][i];
+    }
+}
+
+// counter-based dropout mask: keep element i of stream `seed` iff hash(seed, i) >= p * 2^32.  The backward pass
+// regenerates the mask from (seed, i), so no mask is stored.
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+// y = (residual ? residual : 0) + keep(x) / (1 - p)
+__global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y, size_t n,
+                               uint32_t thresh, float scale, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = drop_hash(seed, i) >= thresh ? x[i] * scale : 0.f;
+        y[i] = residual ? residual[i] + v : v;
+    }
+}
+
+// dx = dy where y > 0 else 0
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+}  // namespace bofi
+
+using namespace bofi;
+
+extern "C" int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok, const int64_t* syn, int rows,
+                               int L, int d, float* x, void* stream) {
+    if (!pe || !x || (!tok && !syn) || (tok && !lut_tok) || (syn && !lut_syn) || rows < 0 || L <= 0 || d <= 0) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(128), 0, (hipStream_t)stream, lut_tok, lut_syn, pe, tok, syn, L, d,
+                       (float)sqrt((double)d), x);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_transpose_pad(const float* x, int ldx, float* xt, int M, int N, int Mpad, void* stream) {
+    if (!x || !xt || M <= 0 || N <= 0 || Mpad < M || ldx < N) return BOFI_ERR_ARG;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Mpad + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, xt, M, N, Mpad);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y || n < 0 || !(p >= 0.f && p < 1.f)) return BOFI_ERR_ARG;
+    if (n == 0) return BOFI_OK;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, residual, y, (size_t)n, thresh, 1.0f / (1.0f - p), seed);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) {
+    if (!y || !dy || !dx || n < 0) return BOFI_ERR_ARG;
+    if (n == 0) return BOFI_OK;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dy, dx, (size_t)n);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, float* dx, float* dgain, float* dbias, int rows,
+                                  int d, void* stream) {
+    if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout, int ldo,
+                                  float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb,
+                                  int klen_sq, int klen_bias, void* stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0) return BOFI_ERR_ARG;
+    if (B == 0) return BOFI_OK;
+    AttnBwdParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, dk, dv, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias};
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream) {
+    if (!y || !dy || !dx || rows < 0 || V <= 0) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, V);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream) {
+    if (!x || !out || M < 0 || N <= 0) return BOFI_ERR_ARG;
+    if (M == 0) return BOFI_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, out, M, N);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream) {
+    if (!dx || !ids || !dlut || rows < 0 || d <= 0) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, (hipStream_t)stream, dx, ids, dlut, rows, d, scale);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}

@@ -37,6 +37,16 @@ SIGNATURES = {
     "bofi_linear": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "bofi_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "bofi_vocab_finalize": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "bofi_attention_ex": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "bofi_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "bofi_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "bofi_logsoftmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "bofi_colsum_add": (_I, [_P, _P, _I, _I, _P]),
+    "bofi_embed_rows": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "bofi_embed_bwd": (_I, [_P, _P, _P, _I, _I, C.c_float, _P]),
+    "bofi_transpose_pad": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "bofi_dropout": (_I, [_P, _P, _P, _I64, C.c_float, C.c_uint64, _P]),
+    "bofi_relu_bwd": (_I, [_P, _P, _P, _I64, _P]),
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),

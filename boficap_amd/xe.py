@@ -1,0 +1,528 @@
+"""XE training forward / backward of the UIC model on the HIP ops (float32).
+
+Replaces, for train_mode 'UIC', ``TransformerModel._forward`` (TransformerModel.py:1713-1724,1759-1775) ->
+``EncoderDecoder_UIC.forward`` (:413-468) and the autograd graph torch builds under it (tools/train.py:212-227).
+Every arithmetic node is a kernel of libboficap_hip.so wrapped in a ``torch.autograd.Function``; torch only owns
+the buffers, the tape and the parameter tensors.  Differences in STRUCTURE from the reference (same results):
+
+  * the image memory is encoded once per image; the seq_per_img captions of an image attend it through the
+    attention kernels' ``kdiv`` (the reference repeats the features and encodes every copy, :1703-1707);
+  * the teacher-forced bound passes (:476-513 SA, :532-565 NA: one predictor pass per phrase index, the mask
+    grown per caption) run as ONE batched pass over N x Pmax virtual [LEN] queries with per-query key counts,
+    because only row 0 of each pass is ever read (:375);
+  * every mask on this path is a key prefix per query row, so masks travel as int32 key counts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+F32 = hip.DT_F32
+
+
+def _lib():
+    return hip.lib()
+
+
+def _chk(rc, what):
+    hip.check(rc, what)
+
+
+def _empty(ref: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=ref.device)
+
+
+def _zeros(ref: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.zeros(*shape, dtype=torch.float32, device=ref.device)
+
+
+def _need(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise hip.BofiHipError(f"{what}: float32 tensor on the HIP device expected, got {t.dtype} on {t.device}")
+    return t.contiguous()
+
+
+def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0):
+    _chk(_lib().bofi_linear(hip.ptr(x), F32, ldx, hip.ptr(w), F32, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
+                            hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, hip.stream_ptr()), "bofi_linear")
+
+
+def _transpose_pad(x, M, N, Mpad):
+    xt = _empty(x, N, Mpad)
+    _chk(_lib().bofi_transpose_pad(hip.ptr(x), N, hip.ptr(xt), M, N, Mpad, hip.stream_ptr()), "bofi_transpose_pad")
+    return xt
+
+
+def _pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+class LinearFn(Function):
+    """y = act(x w^T + b) [+ residual]  (bofi_linear).  Backward: dx = dz w, dw = dz^T x, db = colsum(dz), all on
+    the same MFMA GEMM kernel; the weight-gradient GEMM contracts over rows, so both operands are transposed
+    (and zero-padded to the kernel's K granule) first."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, relu, row_len, rpg):
+        x, w = _need(x, "linear x"), _need(w, "linear w")
+        M, K = x.shape
+        N = w.shape[0]
+        if relu and residual is not None:
+            raise hip.BofiHipError("relu with a residual is not a node of this model")
+        if row_len is not None and not relu:
+            raise hip.BofiHipError("row_len is only used with relu (att_embed)")
+        y = _empty(x, M, N)
+        if M:
+            _gemm(x, K, w, b, residual, y, M, N, K, 1 if relu else 0, row_len, rpg)
+        ctx.relu = bool(relu)
+        ctx.has_b, ctx.has_r = b is not None, residual is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dy = _need(dy, "linear dy")
+        L, st = _lib(), hip.stream_ptr()
+        dz = dy
+        if ctx.relu:                                   # zeroed rows (row_len) have y == 0 and drop out here too
+            dz = torch.empty_like(dy)
+            _chk(L.bofi_relu_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dz), dy.numel(), st), "bofi_relu_bwd")
+        dx = dw = db = None
+        if M == 0:
+            return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None, torch.zeros_like(w) if ctx.needs_input_grad[1] else None,
+                    _zeros(x, N) if ctx.has_b else None, dy if ctx.has_r else None, None, None, None)
+        if ctx.needs_input_grad[0]:
+            Np = _pad32(N)
+            wt = _transpose_pad(w, N, K, Np)           # [K, Np]
+            dzp = dz
+            if Np != N:
+                dzp = _zeros(x, M, Np)
+                dzp[:, :N] = dz
+            dx = _empty(x, M, K)
+            _gemm(dzp, Np, wt, None, None, dx, M, K, Np)
+        if ctx.needs_input_grad[1]:
+            Mp = _pad32(M)
+            dzt = _transpose_pad(dz, M, N, Mp)         # [N, Mp]
+            xt = _transpose_pad(x, M, K, Mp)           # [K, Mp]
+            dw = _empty(x, N, K)
+            _gemm(dzt, Mp, xt, None, None, dw, N, K, Mp)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _zeros(x, N)
+            _chk(L.bofi_colsum_add(hip.ptr(dz), hip.ptr(db), M, N, st), "bofi_colsum_add")
+        return dx, dw, db, (dy if ctx.has_r else None), None, None, None
+
+
+def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0):
+    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg)
+
+
+class LayerNormFn(Function):
+    """a_2 (x - mean) / (std + eps) + b_2 with the unbiased std (TransformerModel.py:1346-1349)."""
+
+    @staticmethod
+    def forward(ctx, x, gain, bias):
+        x, gain, bias = _need(x, "ln x"), _need(gain, "ln gain"), _need(bias, "ln bias")
+        rows, d = x.shape
+        y = torch.empty_like(x)
+        _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(y), F32, rows, d, hip.stream_ptr()), "bofi_layernorm")
+        ctx.save_for_backward(x, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gain = ctx.saved_tensors
+        rows, d = x.shape
+        dy = _need(dy, "ln dy")
+        dx, dg, db = torch.empty_like(x), _zeros(x, d), _zeros(x, d)
+        _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
+                                       hip.stream_ptr()), "bofi_layernorm_bwd")
+        return dx, dg, db
+
+
+def layer_norm(x, gain, bias):
+    return LayerNormFn.apply(x, gain, bias)
+
+
+def _off(t: torch.Tensor, col: int) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr() + 4 * col)
+
+
+class AttentionFn(Function):
+    """softmax(q k^T / 8, keys < klen) v per head (TransformerModel.py:1421-1432) on column slices of packed
+    projection buffers: q = qbuf[:, qoff:qoff+d], k = kvbuf[:, koff:...], v = kvbuf[:, voff:...].
+    qbuf may be the same tensor as kvbuf (packed q|k|v of a self-attention)."""
+
+    @staticmethod
+    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias):
+        qbuf, kvbuf = _need(qbuf, "attention q"), _need(kvbuf, "attention kv")
+        if qbuf.shape[0] != B * Lq or kvbuf.shape[0] * kdiv != B * Lk:
+            raise hip.BofiHipError(f"attention operand rows {qbuf.shape[0]}, {kvbuf.shape[0]} do not match B={B} Lq={Lq} Lk={Lk} kdiv={kdiv}")
+        if klen is not None and (klen.dtype != torch.int32 or klen.numel() < (B - 1) * klen_sb + (Lq - 1) * klen_sq + 1):
+            raise hip.BofiHipError("klen must be int32 and cover every (b, query) it is indexed with")
+        d = H * 64
+        out = _empty(qbuf, B * Lq, d)
+        ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
+        _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
+                                      Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
+        ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
+        ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
+        ctx.klen = klen
+        ctx.save_for_backward(qbuf, kvbuf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qbuf, kvbuf = ctx.saved_tensors
+        qoff, koff, voff, B, H, Lq, Lk, kdiv, sb, sq, bias = ctx.meta
+        dout = _need(dout, "attention dout")
+        dq = torch.zeros_like(qbuf)
+        dkv = dq if ctx.same else torch.zeros_like(kvbuf)
+        ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
+        _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
+                                       _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,
+                                       hip.stream_ptr()), "bofi_attention_bwd")
+        return (dq, None if ctx.same else dkv) + (None,) * 12
+
+
+def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0):
+    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias)
+
+
+class EmbedFn(Function):
+    """pos_embed(tgt_embed(tok) [+ syn_embed(syn)]) (TransformerModel.py:1484-1511); ids int64 [rows], position = row % L."""
+
+    @staticmethod
+    def forward(ctx, lut_tok, lut_syn, pe, tok, syn, L):
+        ref = lut_tok if lut_tok is not None else lut_syn
+        d = ref.shape[1]
+        ids = tok if tok is not None else syn
+        rows = ids.numel()
+        for t, lut in ((tok, lut_tok), (syn, lut_syn)):
+            if t is not None and (t.dtype != torch.int64 or not t.is_contiguous() or lut is None):
+                raise hip.BofiHipError("embedding ids must be contiguous int64 with their table")
+        x = _empty(ref, rows, d)
+        _chk(_lib().bofi_embed_rows(hip.ptr(lut_tok if tok is not None else None), hip.ptr(lut_syn if syn is not None else None), hip.ptr(pe),
+                                    hip.ptr(tok), hip.ptr(syn), rows, L, d, hip.ptr(x), hip.stream_ptr()), "bofi_embed_rows")
+        ctx.tok, ctx.syn = tok, syn
+        ctx.shapes = (None if lut_tok is None else lut_tok.shape, None if lut_syn is None else lut_syn.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        dx = _need(dx, "embed dx")
+        rows, d = dx.shape
+        out = []
+        for ids, shape in ((ctx.tok, ctx.shapes[0]), (ctx.syn, ctx.shapes[1])):
+            if ids is None or shape is None:
+                out.append(None)
+                continue
+            g = _zeros(dx, *shape)
+            _chk(_lib().bofi_embed_bwd(hip.ptr(dx), hip.ptr(ids), hip.ptr(g), rows, d, float(d) ** 0.5, hip.stream_ptr()), "bofi_embed_bwd")
+            out.append(g)
+        return out[0], out[1], None, None, None, None
+
+
+def embed(lut_tok, lut_syn, pe, tok, syn, L):
+    return EmbedFn.apply(lut_tok, lut_syn, pe, tok, syn, L)
+
+
+class LogSoftmaxFn(Function):
+    """F.log_softmax over the last dim, in place on the logits (bofi_vocab_finalize); also leaves the greedy ids."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        logits = _need(logits, "log_softmax input")
+        rows, V = logits.shape
+        ids = torch.empty(rows, dtype=torch.int64, device=logits.device)
+        if rows:
+            _chk(_lib().bofi_vocab_finalize(hip.ptr(logits), rows, V, 1, 1, None, 0, hip.ptr(ids), hip.stream_ptr()), "bofi_vocab_finalize")
+        ctx.mark_dirty(logits)
+        ctx.save_for_backward(logits)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _need(dy, "log_softmax dy")
+        dx = torch.empty_like(y)
+        _chk(_lib().bofi_logsoftmax_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dx), y.shape[0], y.shape[1], hip.stream_ptr()), "bofi_logsoftmax_bwd")
+        return dx
+
+
+def log_softmax(logits):
+    return LogSoftmaxFn.apply(logits)
+
+
+def greedy_ids(logits):
+    """argmax over the last dim (first maximal index), no tape; the logits are consumed."""
+    rows, V = logits.shape
+    ids = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    _chk(_lib().bofi_vocab_finalize(hip.ptr(logits), rows, V, 1, 0, None, 0, hip.ptr(ids), hip.stream_ptr()), "bofi_vocab_finalize")
+    return ids
+
+
+class DropoutFn(Function):
+    """residual + dropout(x): the mask is a counter hash of (seed, element), regenerated in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        x = _need(x, "dropout x")
+        y = torch.empty_like(x)
+        _chk(_lib().bofi_dropout(hip.ptr(x), hip.ptr(residual), hip.ptr(y), x.numel(), p, seed, hip.stream_ptr()), "bofi_dropout")
+        ctx.p, ctx.seed, ctx.has_r = p, seed, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _need(dy, "dropout dy")
+        dx = torch.empty_like(dy)
+        _chk(_lib().bofi_dropout(hip.ptr(dy), None, hip.ptr(dx), dy.numel(), ctx.p, ctx.seed, hip.stream_ptr()), "bofi_dropout")
+        return dx, (dy if ctx.has_r else None), None, None
+
+
+class _Drop:
+    """Dropout sites of one forward pass: site k of step s draws from stream (base seed, s, k)."""
+
+    def __init__(self, p: float, p_att: float, seed: Optional[int]):
+        self.p, self.p_att, self.on = p, p_att, seed is not None
+        self.seed, self.k = (seed or 0), 0
+
+    def _next(self):
+        self.k += 1
+        return (self.seed * 0x100000001B3 + self.k * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+    def __call__(self, x, residual=None, p=None):
+        p = self.p if p is None else p
+        if not self.on or p <= 0.0:
+            return x if residual is None else None          # None: caller fuses the residual into the GEMM instead
+        return DropoutFn.apply(x, residual, p, self._next())
+
+
+# ------------------------------------------------------------------------------------------------ the model
+def _sublayer_linear(drop, x_in, w, b, residual):
+    """residual + dropout(x_in w^T + b): the residual rides in the GEMM epilogue when dropout is off."""
+    if not drop.on or drop.p <= 0.0:
+        return linear(x_in, w, b, residual=residual)
+    return drop(linear(x_in, w, b), residual)
+
+
+def _ffn(P, pre, drop, n, x):
+    h = linear(n, P[pre + ".w_1.weight"], P[pre + ".w_1.bias"], relu=True)
+    if drop.on and drop.p > 0.0:
+        h = drop(h)
+    return _sublayer_linear(drop, h, P[pre + ".w_2.weight"], P[pre + ".w_2.bias"], x)
+
+
+def _cat(P, pre, idx, what):
+    return torch.cat([P[f"{pre}.linears.{i}.{what}"] for i in idx], 0)
+
+
+def encode_memory(P, cfg, att_feats, att_len, drop):
+    """att_embed (TransformerModel.py:1642-1645 + pack_wrapper AttModel.py:36-44) and the encoder stack
+    (:1366-1383): returns memory [B*R, d]."""
+    B, R, Fdim = att_feats.shape
+    H = cfg.h
+    x = linear(att_feats.reshape(B * R, Fdim), P["att_embed.0.weight"], P["att_embed.0.bias"], relu=True, row_len=att_len, rpg=R)
+    if drop.on:
+        x = drop(x, None, drop.p_att)
+    sb = 1 if att_len is not None else 0
+    for l in range(cfg.N_enc):
+        p = f"model.encoder.layers.{l}"
+        n = layer_norm(x, P[p + ".sublayer.0.norm.a_2"], P[p + ".sublayer.0.norm.b_2"])
+        qkv = linear(n, _cat(P, p + ".self_attn", (0, 1, 2), "weight"), _cat(P, p + ".self_attn", (0, 1, 2), "bias"))
+        d = cfg.d_model
+        ctx = attention(qkv, qkv, 0, d, 2 * d, B, H, R, R, 1, att_len, sb, 0, 0)
+        x = _sublayer_linear(drop, ctx, P[p + ".self_attn.linears.3.weight"], P[p + ".self_attn.linears.3.bias"], x)
+        n = layer_norm(x, P[p + ".sublayer.1.norm.a_2"], P[p + ".sublayer.1.norm.b_2"])
+        x = _ffn(P, p + ".feed_forward", drop, n, x)
+    return layer_norm(x, P["model.encoder.norm.a_2"], P["model.encoder.norm.b_2"])
+
+
+def _cross(P, pre, cfg, drop, n, x, memory, B, Lq, R, spi, att_len):
+    """x + src_attn(n, memory, memory) with the image's keys shared by its captions."""
+    d = cfg.d_model
+    q = linear(n, P[pre + ".linears.0.weight"], P[pre + ".linears.0.bias"])
+    kv = linear(memory, _cat(P, pre, (1, 2), "weight"), _cat(P, pre, (1, 2), "bias"))
+    ctx = attention(q, kv, 0, 0, d, B, cfg.h, Lq, R, spi, att_len, (1 if att_len is not None else 0), 0, 0)
+    # klen is indexed by the QUERY batch item; att_len is per image -> expand for kdiv > 1 is done by the caller
+    return _sublayer_linear(drop, ctx, P[pre + ".linears.3.weight"], P[pre + ".linears.3.bias"], x)
+
+
+def decode_rows(P, cfg, drop, x, memory, N, S, R, spi, klen_self, att_len_cap):
+    """Decoder stack + final norm (TransformerModel.py:1386-1413) over N captions x S positions; self-attention
+    row (n, i) sees keys < klen_self[n, i]."""
+    d = cfg.d_model
+    for l in range(cfg.N_dec):
+        p = f"model.decoder.layers.{l}"
+        n_ = layer_norm(x, P[p + ".sublayer.0.norm.a_2"], P[p + ".sublayer.0.norm.b_2"])
+        qkv = linear(n_, _cat(P, p + ".self_attn", (0, 1, 2), "weight"), _cat(P, p + ".self_attn", (0, 1, 2), "bias"))
+        ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0)
+        x = _sublayer_linear(drop, ctx, P[p + ".self_attn.linears.3.weight"], P[p + ".self_attn.linears.3.bias"], x)
+        n_ = layer_norm(x, P[p + ".sublayer.1.norm.a_2"], P[p + ".sublayer.1.norm.b_2"])
+        x = _cross(P, p + ".src_attn", cfg, drop, n_, x, memory, N, S, R, spi, att_len_cap)
+        n_ = layer_norm(x, P[p + ".sublayer.2.norm.a_2"], P[p + ".sublayer.2.norm.b_2"])
+        x = _ffn(P, p + ".feed_forward", drop, n_, x)
+    return layer_norm(x, P["model.decoder.norm.a_2"], P["model.decoder.norm.b_2"])
+
+
+def bound_teacher_forced(P, cfg, drop, x_in, memory, N, L, R, spi, klen_pass, att_len_cap):
+    """The teacher-forced bound passes of one branch as one batch.
+
+    x_in [N*L, d] is the embedded bound input; klen_pass int32 [N, Pmax] the number of keys the [LEN] row of
+    caption n sees in pass i.  Returns (len_logp [N, Pmax, 20], syn_logp [N, Pmax, 10]).  Follows
+    LengthPredictorLayer (TransformerModel.py:1025-1029) + LengthPredictor_UIC.forward (:367-383), row 0 only."""
+    d, H = cfg.d_model, cfg.h
+    Pm = klen_pass.shape[1]
+    lp = "model.length_predictor"
+    p = lp + ".LengthPredictor.0"
+    n_all = layer_norm(x_in, P[p + ".sublayer.0.norm.a_2"], P[p + ".sublayer.0.norm.b_2"])
+    kv = linear(n_all, _cat(P, p + ".self_attn", (1, 2), "weight"), _cat(P, p + ".self_attn", (1, 2), "bias"))
+    x0 = x_in.view(N, L, d)[:, 0, :]
+    n0 = n_all.view(N, L, d)[:, 0, :].contiguous()
+    q0 = linear(n0, P[p + ".self_attn.linears.0.weight"], P[p + ".self_attn.linears.0.bias"])
+    qv = q0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
+    xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
+    ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0)
+    x = _sublayer_linear(drop, ctx, P[p + ".self_attn.linears.3.weight"], P[p + ".self_attn.linears.3.bias"], xv)
+    n_ = layer_norm(x, P[p + ".sublayer.1.norm.a_2"], P[p + ".sublayer.1.norm.b_2"])
+    x = _cross(P, p + ".src_attn", cfg, drop, n_, x, memory, N, Pm, R, spi, att_len_cap)
+    n_ = layer_norm(x, P[p + ".sublayer.2.norm.a_2"], P[p + ".sublayer.2.norm.b_2"])
+    x = _ffn(P, p + ".ff", drop, n_, x)
+    o = layer_norm(x, P[lp + ".norm.a_2"], P[lp + ".norm.b_2"])
+    # heads: hidden 100 is not a multiple of the GEMM K granule -> both first layers side by side in one padded GEMM
+    w1l, w1s = P[lp + ".Length_classifier1.weight"], P[lp + ".Syntactic_classifier1.weight"]
+    hh = w1l.shape[0]
+    Hp = _pad32(2 * hh)
+    zpad = w1l.new_zeros(Hp - 2 * hh, d)
+    w1 = torch.cat([w1l, w1s, zpad], 0)
+    b1 = torch.cat([P[lp + ".Length_classifier1.bias"], P[lp + ".Syntactic_classifier1.bias"], w1l.new_zeros(Hp - 2 * hh)], 0)
+    hid = linear(o, w1, b1, relu=True)
+    if drop.on and drop.p > 0.0:
+        hid = drop(hid)
+    w2l, w2s = P[lp + ".Length_classifier2.weight"], P[lp + ".Syntactic_classifier2.weight"]
+    w2l_p = torch.cat([w2l, w2l.new_zeros(w2l.shape[0], Hp - hh)], 1)
+    w2s_p = torch.cat([w2s.new_zeros(w2s.shape[0], hh), w2s, w2s.new_zeros(w2s.shape[0], Hp - 2 * hh)], 1)
+    len_lp = log_softmax(linear(hid, w2l_p, P[lp + ".Length_classifier2.bias"]))
+    syn_lp = log_softmax(linear(hid, w2s_p, P[lp + ".Syntactic_classifier2.bias"]))
+    return len_lp.view(N, Pm, -1), syn_lp.view(N, Pm, -1)
+
+
+def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor):
+    """Key count of the [LEN] row per (caption, pass), TransformerModel.py:493-511: pass 0 sees 1 key; pass i >= 1 sees
+    1 + sum(phrase_length[n, 1..min(i, phrase_num[n]-1)]).  Also the final ``last`` per caption (:562-564)."""
+    N, L = phrase_length.shape
+    Pm = int(phrase_num.max())
+    idx = torch.arange(L, device=phrase_length.device).unsqueeze(0)
+    pl = torch.where((idx >= 1) & (idx < phrase_num.unsqueeze(1)), phrase_length, torch.zeros_like(phrase_length))
+    cum = 1 + pl.cumsum(1)                                     # cum[n, i] = 1 + sum_{t<=i} pl[n, t]
+    return cum[:, :Pm].to(torch.int32).contiguous(), cum[:, -1].to(torch.int32).contiguous(), Pm
+
+
+def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, extend_phrase_seq,
+                extend_phrase_seq_mask, *, glat_p: float = -1.0, training: bool = False, seed: Optional[int] = None):
+    """The six log-prob tensors of EncoderDecoder_UIC.forward (TransformerModel.py:413-468, glat_p < 0):
+    (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok)."""
+    dev = att_feats.device
+    S, L, d = cfg.seq_length, cfg.seq_length + 2, cfg.d_model
+    if labels.dim() == 3:
+        labels = labels.reshape(-1, labels.shape[2])
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        extend_phrase_syn_seq = extend_phrase_syn_seq.reshape(-1, extend_phrase_syn_seq.shape[2])
+        extend_phrase_seq = extend_phrase_seq.reshape(-1, extend_phrase_seq.shape[2])
+        extend_phrase_seq_mask = extend_phrase_seq_mask.reshape(-1, extend_phrase_seq.shape[1], extend_phrase_seq.shape[1])
+    att_len = None
+    if att_masks is not None:                                  # clip_att, AttModel.py:113-120
+        max_len = int(att_masks.long().sum(1).max())
+        att_feats, att_masks = att_feats[:, :max_len].contiguous(), att_masks[:, :max_len]
+        att_len = att_masks.long().sum(1).to(torch.int32).contiguous()
+    att_feats = _need(att_feats.float() if att_feats.dtype != torch.float32 else att_feats, "att_feats")
+    B, R, _ = att_feats.shape
+    N = labels.shape[0]
+    if N % B:
+        raise hip.BofiHipError(f"{N} captions for {B} images")
+    spi = N // B
+    drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None)
+    memory = encode_memory(P, cfg, att_feats, att_len, drop)
+    att_len_cap = None if att_len is None else att_len.repeat_interleave(spi).contiguous()
+
+    labels, phrase_num, phrase_length = labels.to(dev).long(), phrase_num.to(dev).long(), phrase_length.to(dev).long()
+    ext_syn = extend_phrase_syn_seq.to(dev).long().contiguous()
+    ext_seq = extend_phrase_seq.to(dev).long().contiguous()
+    klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length)
+    lut_tok, lut_syn, pe = P["model.tgt_embed.lut.weight"], P["model.syn_embed.lut.weight"], P["model.pos_embed.pe"]
+
+    def emb(tok, syn, Lp):
+        x = embed(lut_tok if tok is not None else None, lut_syn if syn is not None else None, pe, tok, syn, Lp)
+        return drop(x) if drop.on and drop.p > 0.0 else x
+
+    def pad_slots(t):                                          # pass i lands in slot i of the returned [:, 1:] view
+        out = t.new_zeros(N, L - 1, t.shape[2])
+        out[:, :Pm] = t
+        return out
+
+    # --- semi-autoregressive branch (TransformerModel.py:476-530)
+    word_seq = labels.clone()
+    word_seq[:, 0] = cfg.len_idx
+    sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, N, L, R, spi, klen_pass, att_len_cap)
+    syn_mid = ext_syn[:, 1:-1].contiguous()
+    klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1).to(torch.int32).contiguous()          # prefix masks (dataloader.py:414)
+    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, S), memory, N, S, R, spi, klen_sa, att_len_cap)
+    gw, gb = P["model.generator.proj.weight"], P["model.generator.proj.bias"]
+    sa_tok = log_softmax(linear(x, gw, gb)).view(N, S, -1)
+
+    # --- non-autoregressive branch (:532-587)
+    na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, N, L, R, spi, klen_pass, att_len_cap)
+    klen_na = (last - 1).unsqueeze(1).expand(N, S).contiguous()
+    fill_in = torch.full((N, S), cfg.bos_idx, dtype=torch.int64, device=dev)
+    if glat_p >= 0:                                            # glancing input (:437-463): reveal a share of the true tokens
+        with torch.no_grad():
+            x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, N, S, R, spi, klen_na, att_len_cap)
+            pred = greedy_ids(linear(x, gw, gb)).view(N, S)
+            real = labels[:, 1:-1]
+            ntok = phrase_length.sum(1) - 1
+            tok_mask = torch.arange(S, device=dev).unsqueeze(0) < ntok.unsqueeze(1)
+            same = ((pred == real) & tok_mask).sum(1)
+            keep_prob = ((ntok - same) / ntok * glat_p).unsqueeze(-1) * tok_mask.float()
+            keep = torch.rand(real.shape, device=dev) < keep_prob
+            fill_in = torch.where(keep, real, fill_in).contiguous()
+    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, N, S, R, spi, klen_na, att_len_cap)
+    na_tok = log_softmax(linear(x, gw, gb)).view(N, S, -1)
+    return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+
+
+def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
+    """LanguageModelCriterion_UIC.forward (captioning/modules/losses.py:319-369), reduction 'mean', self_dis off:
+    six masked NLL sums, each divided by the number of real caption tokens.  Index bookkeeping only (gathers and
+    masks on tensors of N x S elements); returns (loss, [6 parts])."""
+    sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok = outs
+    dev = sa_tok.device
+    if phrase_length.dim() == 3:
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        phrase_syn = phrase_syn.reshape(-1, phrase_syn.shape[2])
+        labels = labels.reshape(-1, labels.shape[2])
+    phrase_num, phrase_length = phrase_num.to(dev).long(), phrase_length.to(dev).long()
+    phrase_syn, labels = phrase_syn.to(dev).long(), labels.to(dev).long()
+    real = labels[:, 1:-1]
+    pos = torch.arange(real.shape[1], device=dev).unsqueeze(0)
+    tok_mask = pos < (phrase_length.sum(1, keepdim=True) - 1)
+    slot = torch.arange(phrase_length.shape[1] - 1, device=dev).unsqueeze(0)
+    slot_mask = slot < phrase_num.unsqueeze(1)
+    len_lab, syn_lab = phrase_length[:, 1:], phrase_syn[:, 1:]
+    denom = tok_mask.sum()
+
+    def nll(lp, lab, mask):
+        return (-lp.gather(2, lab.unsqueeze(2)).squeeze(2) * mask).sum() / denom
+
+    parts = [nll(sa_len, len_lab, slot_mask), nll(sa_tok, real, tok_mask), nll(sa_syn, syn_lab, slot_mask),
+             nll(na_len, len_lab, slot_mask), nll(na_tok, real, tok_mask), nll(na_syn, syn_lab, slot_mask)]
+    return sum(parts), parts

@@ -80,6 +80,44 @@ int bofi_attention(const void* q, int ldq, const void* k, int ldk, const void* v
 int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok,
                         int pad_idx, int64_t* seq, void* stream);
 
+/* bofi_attention with the two extra knobs of the training path: effective key count =
+ * klen[...] + klen_bias, and key/value batch item = b / kdiv (the seq_per_img captions of one image
+ * attend the image's memory without repeating it; the reference repeats it, models/utils.py:3-14). */
+int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
+                      int ldo, int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen,
+                      int klen_sb, int klen_sq, int klen_bias, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training ops (float32).  The reference trains by running torch autograd over
+ * TransformerModel._forward (tools/train.py:212-227); these are the hand-written backward (and the
+ * few extra forward) kernels the XE step needs.  Parameter gradients that are sums over rows are
+ * ACCUMULATED into the given buffers (zero them first).
+ * ------------------------------------------------------------------------------------------- */
+/* backward of bofi_layernorm: dx [rows, d]; dgain, dbias [d] accumulated */
+int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, float* dx, float* dgain,
+                       float* dbias, int rows, int d, void* stream);
+/* backward of bofi_attention_ex (Lq, Lk <= 64): dq like q, dk/dv like k/v (accumulated when kdiv > 1) */
+int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                       const float* dout, int ldo, float* dq, float* dk, float* dv, int B, int H, int Lq,
+                       int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias,
+                       void* stream);
+/* backward of log_softmax given the log-probabilities y: dx = dy - exp(y) * rowsum(dy) */
+int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
+/* out[n] += sum_m x[m][n]  (bias gradients) */
+int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
+/* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[r % L]; tok or syn may be NULL
+ * (Embeddings + PositionalEncoding, TransformerModel.py:1484-1511) and its backward into one table */
+int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok,
+                    const int64_t* syn, int rows, int L, int d, float* x, void* stream);
+int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream);
+/* xt[n][m] = x[m][n], zero for M <= m < Mpad: operand layout of the weight-gradient GEMM */
+int bofi_transpose_pad(const float* x, int ldx, float* xt, int M, int N, int Mpad, void* stream);
+/* y = (residual or 0) + keep(x) / (1 - p), keep mask = hash(seed, index) (nn.Dropout of the sublayers,
+ * TransformerModel.py:1361-1363; the backward is the same call on dy with the same seed) */
+int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* dx = dy where y > 0 */
+int bofi_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Engine level: the whole NAIC bound+fill decode as one call.
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,223 @@
+"""XE training step on the MI355X: backward kernels against torch autograd of the oracle's formulas, and the
+whole forward + criterion + gradients against what the reference itself produced (tests/golden/tiny_train_xe)."""
+import numpy as np
+import pytest
+import torch
+
+import boficap_oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(*ts):
+    return [t.cuda() for t in ts]
+
+
+def _maxdiff(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ op level
+@pytest.mark.parametrize("M,N,K,relu,res", [(50, 96, 64, False, False), (37, 20, 128, False, True), (130, 256, 128, True, False),
+                                            (8, 61, 32, False, False)])
+def test_linear_backward(M, N, K, relu, res):
+    from boficap_amd import xe
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    dy = torch.randn(M, N, generator=g)
+    ref_in = [t.clone().requires_grad_() for t in (x, w, b)] + ([r.clone().requires_grad_()] if res else [])
+    y_ref = torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2])
+    y_ref = torch.relu(y_ref) if relu else y_ref
+    y_ref = y_ref + ref_in[3] if res else y_ref
+    y_ref.backward(dy)
+    dev_in = [t.clone().cuda().requires_grad_() for t in (x, w, b)] + ([r.clone().cuda().requires_grad_()] if res else [])
+    y = xe.linear(dev_in[0], dev_in[1], dev_in[2], residual=dev_in[3] if res else None, relu=relu)
+    y.backward(dy.cuda())
+    assert _maxdiff(y, y_ref) < 2e-4
+    for a, b_ in zip(dev_in, ref_in):
+        assert _maxdiff(a.grad, b_.grad) < 5e-4 * max(1.0, float(b_.grad.abs().max()))
+
+
+def test_layernorm_backward():
+    from boficap_amd import xe
+    g = torch.Generator().manual_seed(3)
+    x, gain, bias, dy = torch.randn(45, 128, generator=g) * 2, torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g), torch.randn(45, 128, generator=g)
+    xr, gr, br = [t.clone().requires_grad_() for t in (x, gain, bias)]
+    mean, std = xr.mean(-1, keepdim=True), xr.std(-1, keepdim=True)          # TransformerModel.py:1346-1349
+    (gr * (xr - mean) / (std + 1e-6) + br).backward(dy)
+    xd, gd, bd = [t.clone().cuda().requires_grad_() for t in (x, gain, bias)]
+    xe.layer_norm(xd, gd, bd).backward(dy.cuda())
+    assert _maxdiff(xd.grad, xr.grad) < 1e-4 and _maxdiff(gd.grad, gr.grad) < 1e-3 and _maxdiff(bd.grad, br.grad) < 1e-3
+
+
+@pytest.mark.parametrize("B,Lq,Lk,kdiv,same", [(4, 20, 20, 1, True), (6, 21, 36, 2, False), (3, 36, 36, 1, True), (4, 7, 22, 1, False)])
+def test_attention_backward(B, Lq, Lk, kdiv, same):
+    from boficap_amd import xe
+    H, d = 2, 128
+    g = torch.Generator().manual_seed(B * 100 + Lq)
+    klen = torch.randint(1, Lk + 1, (B, Lq), generator=g).int()
+    if same:
+        buf = torch.randn(B * Lq, 3 * d, generator=g)
+        qb, kvb, offs = buf, buf, (0, d, 2 * d)
+    else:
+        qb, kvb, offs = torch.randn(B * Lq, d, generator=g), torch.randn(B // kdiv * Lk, 2 * d, generator=g), (0, 0, d)
+    dout = torch.randn(B * Lq, d, generator=g)
+
+    def ref(qb, kvb):
+        q = qb[:, offs[0]:offs[0] + d].reshape(B, Lq, H, 64).transpose(1, 2)
+        k = kvb[:, offs[1]:offs[1] + d].reshape(B // kdiv, Lk, H, 64).transpose(1, 2).repeat_interleave(kdiv, 0)
+        v = kvb[:, offs[2]:offs[2] + d].reshape(B // kdiv, Lk, H, 64).transpose(1, 2).repeat_interleave(kdiv, 0)
+        s = q @ k.transpose(-1, -2) / 8.0
+        mask = torch.arange(Lk).view(1, 1, 1, Lk) < klen.view(B, 1, Lq, 1)
+        p = torch.softmax(s.masked_fill(~mask, float("-inf")), -1)
+        return (p @ v).transpose(1, 2).reshape(B * Lq, d)
+
+    qr = qb.clone().requires_grad_()
+    kr = qr if same else kvb.clone().requires_grad_()
+    ref(qr, kr).backward(dout)
+    qd = qb.clone().cuda().requires_grad_()
+    kd = qd if same else kvb.clone().cuda().requires_grad_()
+    out = xe.attention(qd, kd, offs[0], offs[1], offs[2], B, H, Lq, Lk, kdiv, klen.cuda().contiguous(), Lq, 1, 0)
+    assert _maxdiff(out, ref(qb, kvb)) < 1e-4
+    out.backward(dout.cuda())
+    assert _maxdiff(qd.grad, qr.grad) < 2e-4
+    if not same:
+        assert _maxdiff(kd.grad, kr.grad) < 2e-4
+
+
+def test_logsoftmax_embed_dropout_backward():
+    from boficap_amd import xe
+    g = torch.Generator().manual_seed(11)
+    x, dy = torch.randn(33, 61, generator=g) * 3, torch.randn(33, 61, generator=g)
+    xr = x.clone().requires_grad_()
+    torch.log_softmax(xr, -1).backward(dy)
+    xd = x.clone().cuda().requires_grad_()
+    y = xe.log_softmax(xd * 1.0)                               # in place on a fresh (non-leaf) tensor
+    y.backward(dy.cuda())
+    assert _maxdiff(y, torch.log_softmax(x, -1)) < 1e-5 and _maxdiff(xd.grad, xr.grad) < 1e-5
+    # embedding: tok + syn + pe, gradients scattered back into both tables
+    d, L = 128, 5
+    lut_t, lut_s, pe = torch.randn(30, d, generator=g), torch.randn(10, d, generator=g), torch.randn(50, d, generator=g)
+    tok, syn = torch.randint(0, 30, (3 * L,), generator=g), torch.randint(0, 10, (3 * L,), generator=g)
+    de = torch.randn(3 * L, d, generator=g)
+    tr, sr = lut_t.clone().requires_grad_(), lut_s.clone().requires_grad_()
+    ((tr[tok] * d ** 0.5 + sr[syn] * d ** 0.5) + pe[:L].repeat(3, 1)).backward(de)
+    td, sd_ = lut_t.clone().cuda().requires_grad_(), lut_s.clone().cuda().requires_grad_()
+    e = xe.embed(td, sd_, pe.cuda(), tok.cuda(), syn.cuda(), L)
+    e.backward(de.cuda())
+    assert _maxdiff(e, (lut_t[tok] * d ** 0.5 + lut_s[syn] * d ** 0.5) + pe[:L].repeat(3, 1)) < 1e-5
+    assert _maxdiff(td.grad, tr.grad) < 1e-3 and _maxdiff(sd_.grad, sr.grad) < 1e-3
+    # dropout: keep rate, scaling, and the backward uses the forward's mask
+    xd = torch.ones(400, 256, device="cuda", requires_grad=True)
+    y = xe.DropoutFn.apply(xd, None, 0.1, 12345)
+    keep = (y != 0).float()
+    assert abs(float(keep.mean()) - 0.9) < 0.01 and torch.allclose(y[y != 0], torch.tensor(1 / 0.9, device="cuda"))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(xd.grad != 0, y != 0)
+    y2 = xe.DropoutFn.apply(xd, None, 0.1, 12346)
+    assert not torch.equal(y2 != 0, y != 0)
+
+
+# ------------------------------------------------------------------------------------------------ whole step
+def _model(weight_cache, manifest, case):
+    import captioning.models as models
+    m = manifest[case]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return cfg, model.cuda()
+
+
+def test_xe_step_vs_reference(weight_cache, manifest):
+    """model(..., mode='forward') -> criterion -> backward against the reference's own outputs, loss and gradients."""
+    from boficap_amd import xe
+    cfg, model = _model(weight_cache, manifest, "tiny_train_xe")
+    model.eval()                                               # the fixture was recorded with dropout off
+    g = load_golden("tiny_train_xe")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    fc = torch.zeros(g["att_feats"].shape[0], 0, device="cuda")
+    outs = model(fc, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                 t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"), -1.0)
+    for i, o in enumerate(outs):
+        assert o.shape == g[f"out{i}"].shape
+        assert _maxdiff(o, torch.from_numpy(g[f"out{i}"])) < 1e-4, f"output {i}"
+    loss, parts = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-3
+    assert np.allclose([float(p) for p in parts], g["losses"][1:], atol=1e-4)
+    loss.backward()
+    names = [str(n) for n in g["grad_names"]]
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        p = params[n]
+        if ref_norm < 0:                                        # the reference leaves this parameter without a gradient
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        got = float(p.grad.double().norm())
+        worst = max(worst, abs(got - ref_norm) / max(ref_norm, 1e-6))
+        assert abs(got - ref_norm) <= 2e-3 * max(ref_norm, 1e-3), (n, got, float(ref_norm))
+        if "grad." + n in g:
+            ref_g = torch.from_numpy(g["grad." + n])
+            assert _maxdiff(p.grad, ref_g) <= 2e-3 * max(1e-3, float(ref_g.abs().max())), n
+    print("worst relative grad-norm error", worst)
+
+
+def test_xe_step_oracle_ragged_regions(weight_cache, manifest):
+    """Ragged att_masks + seq_per_img 2 against autograd over the oracle on the CPU (same weights, same batch)."""
+    from boficap_amd import xe
+    from boficap_amd.weights import synthetic_att_feats
+    from training_batch import make_training_batch
+    cfg, model = _model(weight_cache, manifest, "tiny_train_xe")
+    model.eval()
+    n_img, spi = 4, 2
+    att = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=77))
+    masks = torch.zeros(n_img, 36)
+    for i, n in enumerate((36, 20, 9, 31)):
+        masks[i, :n] = 1
+    b = {k: torch.from_numpy(v) for k, v in make_training_batch(cfg, n_img, spi, seed=5).items()}
+    w = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and k != "model.pos_embed.pe") for k, v in model.state_dict().items()}
+    outs_ref = O.forward_uic(w, cfg, att, b["labels"], masks, b["phrase_num"], b["phrase_length"], b["phrase_syn"],
+                             b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"])
+    loss_ref, _ = O.criterion_uic(outs_ref, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])
+    loss_ref.backward()
+    fc = torch.zeros(n_img, 0, device="cuda")
+    outs = model(fc, att.cuda(), b["labels"].cuda(), masks.cuda(), b["phrase_num"], b["phrase_length"], b["phrase_syn"],
+                 b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"], -1.0)
+    for i, (o, r) in enumerate(zip(outs, outs_ref)):
+        assert _maxdiff(o, r) < 1e-4, f"output {i}"
+    loss, _ = xe.criterion_uic(outs, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])
+    assert abs(float(loss) - float(loss_ref)) < 1e-3
+    loss.backward()
+    for n, p in model.named_parameters():
+        r = w[n].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert _maxdiff(p.grad, r) <= 2e-3 * max(1e-3, float(r.abs().max())), n
+
+
+def test_xe_training_mode_runs_and_glat(weight_cache, manifest):
+    """Dropout on: finite loss, gradients everywhere the reference has them; glat_p = 0 reveals nothing (same as -1)."""
+    from boficap_amd import xe
+    cfg, model = _model(weight_cache, manifest, "tiny_train_xe")
+    g = load_golden("tiny_train_xe")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    fc = torch.zeros(g["att_feats"].shape[0], 0, device="cuda")
+    args = (fc, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+            t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"))
+    model.train()
+    outs = model(*args, -1.0)
+    loss, _ = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert abs(float(loss) - float(g["losses"][0])) > 1e-4                         # dropout really changed the pass
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    with torch.no_grad():
+        a, b = model(*args, -1.0), model(*args, 0.0)
+        c = model(*args, 1.0)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert all(torch.equal(x, y) for x, y in zip(a[:5], c[:5])) and not torch.equal(a[5], c[5])
