@@ -103,8 +103,141 @@ def gemm_rooflines(dtype, dev):
     return out
 
 
+def f_alg_xe(cfg, seq_per_img: int, passes: float) -> float:
+    """Algorithmic forward FLOPs per IMAGE of the XE step as the reference computes it: the encoder on
+    every caption copy, `passes` full bound-layer passes per branch, two decoder passes and two vocabulary projections
+    per caption; the step is priced at 3x forward (forward + two backward GEMMs per forward GEMM)."""
+    d, dff, F, R, S, L, V = cfg.d_model, cfg.d_ff, cfg.att_feat_size, 36, cfg.seq_length, cfg.seq_length + 2, cfg.tgt_vocab
+    att_embed = 2 * R * F * d
+    enc_layer = 2 * R * (4 * d * d + 2 * d * dff) + 4 * R * R * d
+    dec_layer = 2 * S * (4 * d * d + 2 * d * d + 2 * d * dff) + 2 * R * 2 * d * d + 4 * S * S * d + 4 * S * R * d
+    bound_pass = 2 * L * (4 * d * d + 2 * d * d + 2 * d * dff) + 2 * R * 2 * d * d + 4 * L * L * d + 4 * L * R * d
+    vocab = 2 * S * d * V
+    per_caption = cfg.N_enc * enc_layer + 2 * passes * bound_pass + 2 * cfg.N_dec * dec_layer + 2 * vocab
+    return 3.0 * (att_embed + seq_per_img * per_caption)
+
+
+def cpu_baseline_xe(cfg, sd, spi, budget_s=25.0):
+    """The CPU oracle's XE forward + criterion + backward (torch autograd on the host cores) on a 2-image sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import boficap_oracle as O
+    from boficap_amd import weights as W
+    from boficap_amd.collate import synthetic_training_batch
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("BOFI_CPU_THREADS", "16")))
+    torch.set_num_threads(cores)
+    n_img = 2
+    att = torch.from_numpy(W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=ATT_SEED))
+    b = {k: torch.from_numpy(v) for k, v in synthetic_training_batch(cfg, n_img, spi, seed=0).items()}
+    w = {k: torch.from_numpy(v).clone().requires_grad_(k != "model.pos_embed.pe") for k, v in sd.items()}
+
+    def once():
+        for t in w.values():
+            t.grad = None
+        outs = O.forward_uic(w, cfg, att, b["labels"], None, b["phrase_num"], b["phrase_length"], b["phrase_syn"],
+                             b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"])
+        O.criterion_uic(outs, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])[0].backward()
+    once()
+    times, t_end = [], time.time() + budget_s
+    while len(times) < 5 and (time.time() < t_end or not times):
+        t0 = time.time()
+        once()
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(n_img / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} x XE forward+backward of {n_img} images x {spi} captions, fp32 torch-CPU oracle (no optimiser step), median"}
+
+
+def main_xe(args):
+    """BASELINE config 3: XE training step, batch 64 images x 5 captions per GPU, data-parallel with one flat-bucket
+    RCCL all-reduce per step (weak scaling)."""
+    from boficap_amd import dp
+    rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
+    world = max(world, 1)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    import captioning.models as models
+    from boficap_amd import weights as W
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.config import FULL as cfg
+    from boficap_amd.trainer import XETrainer
+    spi = args.seq_per_img
+    log("building model")
+    sd = W.make_state_dict(cfg, seed=0)
+    opt = cfg.to_opt()
+    opt.seed = 42
+    if args.dtype == "bf16":
+        opt.bofi_train_dtype = torch.bfloat16
+    model = models.setup(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.to(dev).train()
+    tr = XETrainer(model, opt)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_training_batch(cfg, args.batch, spi, seed=100 + rank).items()}
+    batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
+    batch["att_masks"] = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("warm-up")
+    for _ in range(args.warmup):
+        loss, _ = tr.step(batch)
+    barrier()
+    log(f"loss after warm-up {float(loss) if args.warmup else float('nan'):.4f}; timing")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss, _ = tr.step(batch)
+    e1.record()
+    barrier()
+    elapsed = dp.reduce_scalar(time.perf_counter() - t0, "max", device=dev)
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    if rank == 0:
+        images = args.batch * world * args.steps
+        passes = float(batch["phrase_num"].float().max().item())
+        flops = f_alg_xe(cfg, spi, passes) * args.batch
+        achieved = flops / (dev_ms * 1e-3) / 1e12
+        res = {
+            "metric": "images/sec XE training step (forward + criterion + backward + all-reduce + clip + Adam)",
+            "value": round(images / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"XE training (configs/uic_sd.yml model) batch={args.batch} images x {spi} captions per GPU, 36x2048 regions, "
+                                   f"d_model=512 6 enc + 6 dec + 1 bound layer, {args.dtype}, dropout on",
+                       "images_per_step_per_gpu": args.batch, "captions_per_image": spi, "vocab": cfg.tgt_vocab,
+                       "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel,
+                       "sharding": "images by rank; one RCCL all-reduce over the flat fp32 gradient bucket per step"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None, "kernel": "whole XE step (eager launches)",
+                         "flops_per_launch": flops, "launch_ms": round(dev_ms, 3),
+                         "note": "algorithmic FLOPs of the step as the reference computes it (SURVEY.md 8d: encoder per caption copy, "
+                                 "max(phrase_num) full bound passes per branch, x3 for fwd+bwd) / HIP-event time per step"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            log("timing the CPU oracle")
+            res["cpu_baseline"] = cpu_baseline_xe(cfg, sd, spi)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="naic", choices=["naic", "xe"], help="naic: bound+fill decode (headline); xe: XE training step (config 3)")
+    ap.add_argument("--seq-per-img", type=int, default=5)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -118,6 +251,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     args = ap.parse_args()
+    if args.mode == "xe":
+        return main_xe(args)
 
     from boficap_amd import dp
     rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))

@@ -194,9 +194,50 @@ __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __rest
         dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
+// Adam step over the flat parameter bucket (torch.optim.Adam semantics, misc.py:245-251: betas (0.9, 0.98), eps 1e-9)
+// with the averaging of the all-reduced gradient and clip_grad_value_ (train.py:225-226) folded in, and an optional
+// bf16 copy of the new parameters for the next step's GEMMs.  7 float streams per element: HBM-bound.
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ shadow, size_t n4, float step_size,
+                                                        float b1, float b2, float eps, float inv_sqrt_bc2, float clip, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gi = gp[k] * gscale;
+            if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+            mp[k] = mp[k] + (1.f - b1) * (gi - mp[k]);
+            vp[k] = b2 * vp[k] + (1.f - b2) * gi * gi;
+            pp[k] -= step_size * (mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps));
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (shadow) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ElemOps<bf16_t>::store(shadow + i * 4 + k, pp[k]);
+        }
+    }
+}
+
 }  // namespace bofi
 
 using namespace bofi;
+
+extern "C" int bofi_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                              float beta2, float eps, int step, float clip_value, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || n % 4 || step < 1 || ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) return BOFI_ERR_ARG;
+    if (n == 0) return BOFI_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const size_t n4 = (size_t)n / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n4,
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), clip_value, grad_scale);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
 
 extern "C" int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok, const int64_t* syn, int rows,
                                int L, int d, float* x, void* stream) {

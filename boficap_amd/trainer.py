@@ -1,0 +1,136 @@
+"""XE train step: forward -> criterion -> backward -> gradient all-reduce -> clip -> Noam/Adam step.
+
+Replaces the loop body of the reference's tools/train.py:198-229 and its ``nn.DataParallel`` wrapper (:97-101)
+with one process per GPU: all parameters live in ONE flat float32 bucket in HBM (the module's parameters are views
+into it), all gradients in a second one, so that the data-parallel exchange is a single RCCL all-reduce over the
+flat gradient bucket and the optimiser is a single HBM-bound kernel (``bofi_adam_step``) over four flat streams.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import hip
+
+ALIGN = 4            # elements: every parameter starts on a 16-byte boundary (the GEMM's operand alignment)
+
+
+class FlatBucket:
+    """Re-homes the parameters of ``module`` into one flat buffer (values preserved) and gives every parameter a
+    ``.grad`` that is a view into a second flat buffer.  Works on any device (the gloo tests use the CPU)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters()]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.offsets, n = [], 0
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("all parameters must share one device and dtype")
+            self.offsets.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        self.grad = torch.zeros(n, dtype=dt, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):             # a backward may have replaced a view; put it back
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def all_reduce(self, group=None) -> float:
+        """Sum the flat gradient bucket over the ranks (one collective); returns the scale that turns the sum into
+        the mean of the per-rank gradients (= the reference's loss.mean() over DataParallel replicas, train.py:217)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return 1.0
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / dist.get_world_size(group)
+
+
+def noam_rate(step: int, d_model: int, factor: float = 1.0, warmup: int = 2000) -> float:
+    """NoamOpt.rate, captioning/utils/misc.py:179-185."""
+    return factor * (d_model ** -0.5 * min(step ** -0.5, step * warmup ** -1.5))
+
+
+class XETrainer:
+    """One XE optimisation step of the UIC model per ``step()`` call.
+
+    opt attributes read (defaults as the reference's opts.py / uic_sd.yml): ``noamopt`` (True), ``noamopt_warmup``
+    (20000), ``noamopt_factor`` (1), ``learning_rate`` (5e-4, used when noamopt is off), ``optim_alpha/beta/epsilon``
+    (plain Adam), ``grad_clip_value`` (0.1) with ``grad_clip_mode`` 'value'."""
+
+    def __init__(self, model, opt=None, group=None):
+        if next(model.parameters()).device.type != "cuda":
+            raise hip.BofiHipError("the model must be on a HIP device; there is no CPU training path")
+        opt = opt if opt is not None else model.opt
+        g = lambda k, d: getattr(opt, k, d)
+        self.model, self.group = model, group
+        self.noam = bool(g("noamopt", True))
+        self.warmup, self.factor = int(g("noamopt_warmup", 20000)), float(g("noamopt_factor", 1.0))
+        self.lr = float(g("learning_rate", 5e-4))
+        if self.noam:
+            self.beta1, self.beta2, self.eps = 0.9, 0.98, 1e-9          # get_std_opt, misc.py:245-251
+        else:
+            self.beta1, self.beta2, self.eps = float(g("optim_alpha", 0.9)), float(g("optim_beta", 0.999)), float(g("optim_epsilon", 1e-8))
+        if g("grad_clip_mode", "value") != "value":
+            raise NotImplementedError("grad_clip_mode 'norm': the shipped configs clip by value (opts.py:98-101)")
+        self.clip = float(g("grad_clip_value", 0.1))
+        self.bucket = FlatBucket(model)
+        self.m = torch.zeros_like(self.bucket.flat)
+        self.v = torch.zeros_like(self.bucket.flat)
+        self._step = 0
+
+    # ------------------------------------------------------------------ pieces (exposed for the tests)
+    def rate(self, step: Optional[int] = None) -> float:
+        step = self._step if step is None else step
+        return noam_rate(step, self.model.d_model, self.factor, self.warmup) if self.noam else self.lr
+
+    def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
+        from . import xe
+        self.bucket.zero_grad()
+        fc = batch.get("fc_feats")
+        if fc is None:
+            fc = torch.zeros(batch["att_feats"].shape[0], 0, device=batch["att_feats"].device)
+        outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
+                          batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
+                          glat_p)
+        loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"])
+        loss.backward()
+        return loss.detach(), [p.detach() for p in parts]
+
+    def optimizer_step(self, grad_scale: float = 1.0) -> float:
+        self._step += 1
+        lr = self.rate()
+        b = self.bucket
+        hip.check(hip.lib().bofi_adam_step(hip.ptr(b.flat), hip.ptr(b.grad), hip.ptr(self.m), hip.ptr(self.v), None, b.numel, lr,
+                                           self.beta1, self.beta2, self.eps, self._step, self.clip, grad_scale, hip.stream_ptr()),
+                  "bofi_adam_step")
+        self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1     # the decode engine repacks on next use
+        return lr
+
+    # ------------------------------------------------------------------ the step
+    def step(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
+        """Returns (loss, parts) as device scalars of THIS rank's shard (no host sync inside)."""
+        loss, parts = self.forward_backward(batch, glat_p)
+        scale = self.bucket.all_reduce(self.group)
+        self.optimizer_step(scale)
+        return loss, parts
+
+    # ------------------------------------------------------------------ checkpoint (optimizer.pth of misc.py:87-102)
+    def state_dict(self):
+        return {"_step": self._step, "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu()}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd["_step"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])

@@ -86,7 +86,7 @@ class TransformerModel(nn.Module):
             self.model.pos_embed.pe.copy_(torch.from_numpy(positional_table(self.cfg.max_pe, self.cfg.d_model)))
 
     def _weights_key(self):
-        return (sum(p._version for p in self.parameters()), self.compute_dtype, self.max_batch, self.max_regions,
+        return (sum(p._version for p in self.parameters()) + getattr(self, "_weights_epoch", 0), self.compute_dtype, self.max_batch, self.max_regions,
                 next(self.parameters()).device)
 
     def engine(self):

@@ -115,6 +115,11 @@ int bofi_transpose_pad(const float* x, int ldx, float* xt, int M, int N, int Mpa
 /* y = (residual or 0) + keep(x) / (1 - p), keep mask = hash(seed, index) (nn.Dropout of the sublayers,
  * TransformerModel.py:1361-1363; the backward is the same call on dy with the same seed) */
 int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* One optimiser step over a flat float32 bucket (n % 4 == 0, 16-byte aligned): g' = clamp(g * grad_scale, +-clip_value)
+ * (clip_value <= 0: no clamp; train.py:225-226), then torch.optim.Adam's update with bias correction for `step` >= 1
+ * (misc.py:245-251).  shadow_bf16 (may be NULL) receives a bf16 copy of the new parameters. */
+int bofi_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int step, float clip_value, float grad_scale, void* stream);
 /* dx = dy where y > 0 */
 int bofi_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
 

@@ -28,6 +28,15 @@ def make_training_batch(cfg, n_img: int, seq_per_img: int, seed: int = 0):
         psyn[n, :P] = rng.integers(4, 7, P)
         ntok = int(lens.sum())
         labels[n, 1:1 + ntok] = rng.integers(7, cfg.tgt_vocab, ntok)     # ids above the special / label range
+    b = collate_loops(cfg, labels, phrase_num, plen, psyn)
+    sh = lambda a: a.reshape(n_img, seq_per_img, *a.shape[1:])
+    return {k: sh(v) for k, v in b.items()}
+
+
+def collate_loops(cfg, labels, phrase_num, plen, psyn):
+    """dataloader.py:343-428 with its loops kept as loops (the checker for boficap_amd.collate.phrase_collate)."""
+    N, L = labels.shape
+    S = L - 2
     data_phrase_num = phrase_num + 1
     ext_syn = np.zeros((N, L), np.int64)
     ext_syn[:, 0] = cfg.len_idx
@@ -64,6 +73,5 @@ def make_training_batch(cfg, n_img: int, seq_per_img: int, seed: int = 0):
             ext_mask[ix, phrase_last:, :phrase_last + cur] = True
             seq_last += prev
             phrase_last += cur
-    sh = lambda a: a.reshape(n_img, seq_per_img, *a.shape[1:])
-    return dict(labels=sh(labels), phrase_num=sh(data_phrase_num), phrase_length=sh(phrase_length), phrase_syn=sh(phrase_syn),
-                extend_phrase_syn_seq=sh(ext_syn), extend_phrase_seq=sh(ext_seq), extend_phrase_seq_mask=sh(ext_mask))
+    return dict(labels=labels, phrase_num=data_phrase_num, phrase_length=phrase_length, phrase_syn=phrase_syn,
+                extend_phrase_syn_seq=ext_syn, extend_phrase_seq=ext_seq, extend_phrase_seq_mask=ext_mask)

@@ -60,3 +60,45 @@ def test_shard_range_covers_everything_once():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _bucket_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from boficap_amd import dp
+    from boficap_amd.trainer import FlatBucket
+    torch.set_num_threads(1)
+    dp.init_from_env("gloo")
+    torch.manual_seed(0)                                                  # same initial weights on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    before = [p.detach().clone() for p in net.parameters()]
+    bucket = FlatBucket(net)
+    same_values = all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    x = torch.full((4, 7), float(rank + 1))
+    bucket.zero_grad()
+    net(x).sum().backward()                                               # autograd accumulates INTO the flat views
+    in_bucket = all(p.grad.data_ptr() == bucket.grad.data_ptr() + o * 4 for p, o in zip(bucket.params, bucket.offsets))
+    local = bucket.grad.clone()
+    scale = bucket.all_reduce()
+    mean = bucket.grad * scale
+    gathered = dp.gather_rows(local.unsqueeze(0))
+    if rank == 0:
+        ret.put((same_values, in_bucket, bool(torch.allclose(mean, gathered.mean(0))), scale, bucket.numel))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_gradient_bucket_all_reduce_two_ranks():
+    """The training exchange step: one all-reduce over the flat gradient bucket = mean of the per-rank gradients."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same_values, in_bucket, ok, scale, numel = ret.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert same_values and in_bucket and ok and scale == 0.5
+    assert numel == 36 + 8 + 16 + 4                                       # every parameter padded to a 16-byte boundary

@@ -144,8 +144,8 @@ def test_xe_step_vs_reference(weight_cache, manifest):
         assert o.shape == g[f"out{i}"].shape
         assert _maxdiff(o, torch.from_numpy(g[f"out{i}"])) < 1e-4, f"output {i}"
     loss, parts = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
-    assert abs(float(loss) - float(g["losses"][0])) < 1e-3
-    assert np.allclose([float(p) for p in parts], g["losses"][1:], atol=1e-4)
+    assert abs(float(loss.detach()) - float(g["losses"][0])) < 1e-3
+    assert np.allclose([float(p.detach()) for p in parts], g["losses"][1:], atol=1e-4)
     loss.backward()
     names = [str(n) for n in g["grad_names"]]
     params = dict(model.named_parameters())
@@ -189,7 +189,7 @@ def test_xe_step_oracle_ragged_regions(weight_cache, manifest):
     for i, (o, r) in enumerate(zip(outs, outs_ref)):
         assert _maxdiff(o, r) < 1e-4, f"output {i}"
     loss, _ = xe.criterion_uic(outs, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])
-    assert abs(float(loss) - float(loss_ref)) < 1e-3
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3
     loss.backward()
     for n, p in model.named_parameters():
         r = w[n].grad
@@ -213,7 +213,7 @@ def test_xe_training_mode_runs_and_glat(weight_cache, manifest):
     loss, _ = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
     loss.backward()
     assert torch.isfinite(loss)
-    assert abs(float(loss) - float(g["losses"][0])) > 1e-4                         # dropout really changed the pass
+    assert abs(float(loss.detach()) - float(g["losses"][0])) > 1e-4                         # dropout really changed the pass
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     model.eval()
     with torch.no_grad():
@@ -221,3 +221,66 @@ def test_xe_training_mode_runs_and_glat(weight_cache, manifest):
         c = model(*args, 1.0)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert all(torch.equal(x, y) for x, y in zip(a[:5], c[:5])) and not torch.equal(a[5], c[5])
+
+
+# ------------------------------------------------------------------------------------------------ optimiser / trainer
+def test_adam_kernel_matches_torch_adam():
+    """bofi_adam_step (clip by value + Adam, flat bucket) against clip_grad_value_ + torch.optim.Adam on the CPU."""
+    from boficap_amd import hip
+    n = 4096 + 8
+    g0 = torch.Generator().manual_seed(5)
+    p_ref = torch.randn(n, generator=g0).requires_grad_()
+    opt = torch.optim.Adam([p_ref], lr=0.0, betas=(0.9, 0.98), eps=1e-9)
+    p, m, v = p_ref.detach().clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    shadow = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g0) * (0.3 if step % 2 else 0.01)
+        lr = 1e-3 * step
+        p_ref.grad = (grad * 0.5).clone()
+        torch.nn.utils.clip_grad_value_([p_ref], 0.1)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        hip.check(hip.lib().bofi_adam_step(hip.ptr(p), hip.ptr(grad.cuda()), hip.ptr(m), hip.ptr(v), hip.ptr(shadow), n, lr, 0.9, 0.98, 1e-9,
+                                           step, 0.1, 0.5, hip.stream_ptr()))
+        assert _maxdiff(p, p_ref) < 2e-6
+    assert _maxdiff(shadow.float(), p) < 1e-2 * float(p.abs().max())
+
+
+def test_trainer_steps_reduce_loss_and_refresh_engine(weight_cache, manifest):
+    """A few XE steps on one synthetic batch: the loss falls, parameters stay views of the flat bucket, the first
+    step equals clip+Adam applied to the reference-checked gradients, and decode afterwards sees the new weights."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, model = _model(weight_cache, manifest, "tiny_train_xe")
+    model.eval()                                               # deterministic steps (dropout off)
+    opt = cfg.to_opt()
+    opt.noamopt, opt.learning_rate, opt.grad_clip_value = False, 2e-3, 0.1
+    tr = XETrainer(model, opt)
+    n_img, spi = 4, 5
+    batch = {k: torch.from_numpy(v).cuda() for k, v in synthetic_training_batch(cfg, n_img, spi, seed=2).items()}
+    batch["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=8)).cuda()
+    fc = torch.zeros(n_img, 0, device="cuda")
+    with torch.no_grad():
+        seq0 = model(fc, batch["att_feats"], None, opt={"train_mode": "NAIC"}, mode="sample")[0].clone()
+    w0 = tr.bucket.flat.clone()
+    loss0, _ = tr.forward_backward(batch)
+    g = tr.bucket.grad.clone()
+    tr.optimizer_step(1.0)
+    # first Adam step: m / bc1 = g and sqrt(v / bc2) = |g|  ->  update = lr * g / (|g| + eps)
+    gc = g.clamp(-0.1, 0.1)
+    expect = w0 - 2e-3 * gc / (gc.abs() + 1e-8)
+    assert _maxdiff(tr.bucket.flat, expect) < 1e-6
+    losses = [float(loss0)]
+    for _ in range(7):
+        losses.append(float(tr.step(batch)[0]))
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert all(p.data_ptr() == tr.bucket.flat.data_ptr() + o * 4 for p, o in zip(tr.bucket.params, tr.bucket.offsets))
+    with torch.no_grad():
+        seq1 = model(fc, batch["att_feats"], None, opt={"train_mode": "NAIC"}, mode="sample")[0]
+    ref = O.sample_naic(O.as_torch({k: v.detach().cpu() for k, v in model.state_dict().items()}), cfg, batch["att_feats"].cpu())[0]
+    assert torch.equal(seq1.cpu(), ref)                        # the engine repacked the trained weights
+    assert not torch.equal(seq1, seq0) or losses[-1] < losses[0]
+    sd = tr.state_dict()
+    assert sd["_step"] == 8 and sd["exp_avg"].shape == (tr.bucket.numel,)

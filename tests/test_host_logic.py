@@ -1,5 +1,7 @@
 """CPU-side checks: state_dict schema, opt handling, C-ABI header/library agreement (no GPU)."""
 import os
+
+import numpy as np
 import re
 
 import pytest
@@ -74,3 +76,43 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.bofi_abi_version() == hip.ABI_VERSION
+
+
+def test_vectorised_phrase_collate_equals_the_loops():
+    """boficap_amd.collate.phrase_collate against the loop restatement of dataloader.py:343-428, including phrase
+    lengths the synthetic sampler never draws (long phrases after short ones: the stretch branch)."""
+    from training_batch import collate_loops, make_training_batch
+    from boficap_amd.collate import phrase_collate, synthetic_training_batch
+    from boficap_amd.config import FULL, TINY
+    for cfg in (TINY, FULL):
+        a, b = make_training_batch(cfg, 3, 5, 9), synthetic_training_batch(cfg, 3, 5, 9)
+        assert a.keys() == b.keys() and all(a[k].shape == b[k].shape and (a[k] == b[k]).all() for k in a)
+    rng = np.random.default_rng(0)
+    S = FULL.seq_length
+    for _ in range(100):
+        N = 5
+        labels, plen, psyn, pn = np.zeros((N, S + 2), np.int64), np.zeros((N, S), np.int64), np.zeros((N, S), np.int64), np.zeros(N, np.int64)
+        for n in range(N):
+            lens = rng.integers(1, 8, int(rng.integers(1, 9)))
+            while lens.sum() > S:
+                lens = lens[:-1]
+            P = len(lens)
+            pn[n], plen[n, :P], psyn[n, :P] = P, lens, rng.integers(4, 10, P)
+            labels[n, 1:1 + lens.sum()] = rng.integers(7, 9000, lens.sum())
+        a, b = collate_loops(FULL, labels, pn, plen, psyn), phrase_collate(labels, plen, psyn, len_idx=FULL.len_idx)
+        assert all((a[k] == b[k]).all() for k in a)
+    with pytest.raises(ValueError):
+        phrase_collate(np.zeros((1, S + 2), np.int64), np.array([[0, 2] + [0] * (S - 2)]), np.zeros((1, S), np.int64))
+
+
+def test_noam_rate_and_bucket_layout():
+    from boficap_amd.trainer import FlatBucket, noam_rate
+    assert abs(noam_rate(1, 512, 1.0, 20000) - 512 ** -0.5 * 20000 ** -1.5) < 1e-15          # misc.py:179-185
+    assert abs(noam_rate(20000, 512, 1.0, 20000) - 512 ** -0.5 * 20000 ** -0.5) < 1e-12
+    assert noam_rate(40000, 512, 1.0, 20000) < noam_rate(20000, 512, 1.0, 20000)
+    net = torch.nn.Linear(3, 2)
+    w0 = net.weight.detach().clone()
+    b = FlatBucket(net)
+    assert torch.equal(net.weight, w0) and b.numel == 8 + 4 and net.weight.data_ptr() == b.flat.data_ptr()
+    b.flat.zero_()
+    assert float(net.weight.detach().abs().sum()) == 0.0                                                # the module sees the bucket
