@@ -37,6 +37,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// Fast path for d = 64 * NJ: a wavefront keeps its row in registers, accumulates the gain/bias gradients of its rows in
+// registers, the four wavefronts of the workgroup combine through LDS, and the workgroup issues ONE atomic per column.
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ gain,
+                                                          const float* __restrict__ dy, float* __restrict__ dx, float* dgain,
+                                                          float* dbias, int rows, int rows_per_block) {
+    constexpr int d = NJ * 64;
+    __shared__ float red[2][4][d];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NJ], dg[NJ], db[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { g[j] = gain[lane + 64 * j]; dg[j] = 0.f; db[j] = 0.f; }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        float xv[NJ], dv[NJ];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { xv[j] = x[(size_t)row * d + lane + 64 * j]; dv[j] = dy[(size_t)row * d + lane + 64 * j]; s += xv[j]; }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f, c = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { xv[j] -= mean; q += xv[j] * xv[j]; c += dv[j] * g[j] * xv[j]; }
+        q = wave_sum(q); c = wave_sum(c);
+        const float sigma = sqrtf(q / (float)(d - 1)), sd = sigma + 1e-6f, inv = 1.f / sd;
+        const float coef = sigma > 0.f ? c / (sd * sd * sigma * (float)(d - 1)) : 0.f;
+        float m = 0.f, t[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { t[j] = dv[j] * g[j] * inv - xv[j] * coef; m += t[j]; }
+        m = wave_sum(m) / (float)d;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            dx[(size_t)row * d + lane + 64 * j] = t[j] - m;
+            dg[j] += dv[j] * xv[j] * inv;
+            db[j] += dv[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { red[0][wave][lane + 64 * j] = dg[j]; red[1][wave][lane + 64 * j] = db[j]; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < d; k += 256) {
+        atomicAdd(&dgain[k], (red[0][0][k] + red[0][1][k]) + (red[0][2][k] + red[0][3][k]));
+        atomicAdd(&dbias[k], (red[1][0][k] + red[1][1][k]) + (red[1][2][k] + red[1][3][k]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention backward for the short sequences of this model (Lq, Lk <= 64, d_k = 64), float32, one workgroup per
 // (batch item, head): recompute P, then dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8.
@@ -48,59 +93,66 @@ struct AttnBwdParams {
     const int* klen; int klen_sb, klen_sq, klen_bias;
 };
 
+template <int LQ, int LK>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
-    __shared__ float sq[64 * 65], sk[64 * 65], sv[64 * 65], sdo[64 * 65], sp[64 * 65], sds[64 * 65];
+    constexpr int DS = 65, PS = LK + 1;                        // padded strides: conflict-free column walks
+    __shared__ float sq[LQ * DS], sdo[LQ * DS], sk[LK * DS], sv[LK * DS], sp[LQ * PS], sds[LQ * PS];
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, tid = threadIdx.x;
     const int bk = b / p.kdiv;
     const int Lq = p.Lq, Lk = p.Lk;
-    for (int i = tid; i < 64 * 64; i += 256) {
+    for (int i = tid; i < Lq * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
-        sq[r * 65 + c] = r < Lq ? p.q[((size_t)b * Lq + r) * p.ldq + h * 64 + c] : 0.f;
-        sdo[r * 65 + c] = r < Lq ? p.dout[((size_t)b * Lq + r) * p.ldo + h * 64 + c] : 0.f;
-        sk[r * 65 + c] = r < Lk ? p.k[((size_t)bk * Lk + r) * p.ldk + h * 64 + c] : 0.f;
-        sv[r * 65 + c] = r < Lk ? p.v[((size_t)bk * Lk + r) * p.ldv + h * 64 + c] : 0.f;
+        sq[r * DS + c] = p.q[((size_t)b * Lq + r) * p.ldq + h * 64 + c];
+        sdo[r * DS + c] = p.dout[((size_t)b * Lq + r) * p.ldo + h * 64 + c];
+    }
+    for (int i = tid; i < Lk * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        sk[r * DS + c] = p.k[((size_t)bk * Lk + r) * p.ldk + h * 64 + c];
+        sv[r * DS + c] = p.v[((size_t)bk * Lk + r) * p.ldv + h * 64 + c];
     }
     __syncthreads();
-    // scores and dP, thread (i, j-range)
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int i = e >> 6, j = e & 63;
+    // scores and dP = dO V^T over the real Lq x Lk rectangle
+    for (int e = tid; e < Lq * Lk; e += 256) {
+        const int i = e / Lk, j = e - i * Lk;
         float s = 0.f, dp = 0.f;
-        if (i < Lq && j < Lk) {
-            for (int c = 0; c < 64; ++c) { s = fmaf(sq[i * 65 + c], sk[j * 65 + c], s); dp = fmaf(sdo[i * 65 + c], sv[j * 65 + c], dp); }
+#pragma unroll 16
+        for (int c = 0; c < 64; ++c) { s = fmaf(sq[i * DS + c], sk[j * DS + c], s); dp = fmaf(sdo[i * DS + c], sv[j * DS + c], dp); }
+        sp[i * PS + j] = s * 0.125f;
+        sds[i * PS + j] = dp;
+    }
+    __syncthreads();
+    // row softmax + dS: 4 lanes per query row
+    {
+        const int i = tid >> 2, sub = tid & 3;
+        if (i < Lq) {
+            int kl = Lk;
+            if (p.klen) { kl = p.klen[b * p.klen_sb + i * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
+            float m = -INFINITY;
+            for (int j = sub; j < kl; j += 4) m = fmaxf(m, sp[i * PS + j]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+            float sum = 0.f;
+            for (int j = sub; j < kl; j += 4) { const float e = expf(sp[i * PS + j] - m); sp[i * PS + j] = e; sum += e; }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+            float dot = 0.f;
+            for (int j = sub; j < Lk; j += 4) { const float pv = j < kl ? sp[i * PS + j] / sum : 0.f; sp[i * PS + j] = pv; dot += pv * sds[i * PS + j]; }
+            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+            for (int j = sub; j < Lk; j += 4) sds[i * PS + j] = sp[i * PS + j] * (sds[i * PS + j] - dot) * 0.125f;
         }
-        sp[i * 65 + j] = s * 0.125f;
-        sds[i * 65 + j] = dp;
     }
     __syncthreads();
-    // row softmax + dS, one thread per query row (rows are short)
-    if (tid < 64) {
-        const int i = tid;
-        int kl = Lk;
-        if (p.klen && i < Lq) { kl = p.klen[b * p.klen_sb + i * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
-        if (i >= Lq) kl = 0;
-        float m = -INFINITY;
-        for (int j = 0; j < kl; ++j) m = fmaxf(m, sp[i * 65 + j]);
-        float sum = 0.f;
-        for (int j = 0; j < kl; ++j) { const float e = expf(sp[i * 65 + j] - m); sp[i * 65 + j] = e; sum += e; }
-        float dot = 0.f;
-        for (int j = 0; j < 64; ++j) { const float pv = j < kl ? sp[i * 65 + j] / sum : 0.f; sp[i * 65 + j] = pv; dot += pv * sds[i * 65 + j]; }
-        for (int j = 0; j < 64; ++j) sds[i * 65 + j] = sp[i * 65 + j] * (sds[i * 65 + j] - dot) * 0.125f;
-    }
-    __syncthreads();
-    for (int e = tid; e < 64 * 64; e += 256) {
+    for (int e = tid; e < Lq * 64; e += 256) {                 // dQ[r][c] = sum_j dS[r][j] K[j][c]
         const int r = e >> 6, c = e & 63;
-        if (r < Lq) {                                           // dQ[r][c] = sum_j dS[r][j] K[j][c]
-            float a = 0.f;
-            for (int j = 0; j < Lk; ++j) a = fmaf(sds[r * 65 + j], sk[j * 65 + c], a);
-            p.dq[((size_t)b * Lq + r) * p.ldq + h * 64 + c] = a;
-        }
-        if (r < Lk) {                                           // dK[r][c] = sum_i dS[i][r] Q[i][c];  dV[r][c] = sum_i P[i][r] dO[i][c]
-            float a = 0.f, g = 0.f;
-            for (int i = 0; i < Lq; ++i) { a = fmaf(sds[i * 65 + r], sq[i * 65 + c], a); g = fmaf(sp[i * 65 + r], sdo[i * 65 + c], g); }
-            float* dkp = p.dk + ((size_t)bk * Lk + r) * p.ldk + h * 64 + c;
-            float* dvp = p.dv + ((size_t)bk * Lk + r) * p.ldv + h * 64 + c;
-            if (p.kdiv > 1) { atomicAdd(dkp, a); atomicAdd(dvp, g); } else { *dkp = a; *dvp = g; }
-        }
+        float a = 0.f;
+        for (int j = 0; j < Lk; ++j) a = fmaf(sds[r * PS + j], sk[j * DS + c], a);
+        p.dq[((size_t)b * Lq + r) * p.ldq + h * 64 + c] = a;
+    }
+    for (int e = tid; e < Lk * 64; e += 256) {                 // dK[r][c] = sum_i dS[i][r] Q[i][c];  dV[r][c] = sum_i P[i][r] dO[i][c]
+        const int r = e >> 6, c = e & 63;
+        float a = 0.f, g = 0.f;
+        for (int i = 0; i < Lq; ++i) { a = fmaf(sds[i * PS + r], sq[i * DS + c], a); g = fmaf(sp[i * PS + r], sdo[i * DS + c], g); }
+        float* dkp = p.dk + ((size_t)bk * Lk + r) * p.ldk + h * 64 + c;
+        float* dvp = p.dv + ((size_t)bk * Lk + r) * p.ldv + h * 64 + c;
+        if (p.kdiv > 1) { atomicAdd(dkp, a); atomicAdd(dvp, g); } else { *dkp = a; *dvp = g; }
     }
 }
 
@@ -155,8 +207,10 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict_
     }
 }
 
-// xt[n][m] = x[m][n] for m < M, 0 for M <= m < Mpad   (operands of the weight-gradient GEMM, whose inner dimension is M)
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int ldx, float* __restrict__ xt, int M, int N, int Mpad) {
+// xt[n][m] = x[m][n] for m < M, 0 for M <= m < Mpad   (operands of the weight-gradient GEMM, whose inner dimension is M);
+// the output is written in the GEMM's compute dtype
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int ldx, T* __restrict__ xt, int M, int N, int Mpad) {
     __shared__ float tile[32][33];
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
@@ -166,7 +220,16 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int n = n0 + i, m = m0 + tx;
-        if (n < N && m < Mpad) xt[(size_t)n * Mpad + m] = tile[tx][i];
+        if (n < N && m < Mpad) ElemOps<T>::store(xt + (size_t)n * Mpad + m, tile[tx][i]);
+    }
+}
+
+// y[m][n] = bf16(x[m][n]) for n < N, 0 for N <= n < ldy
+__global__ void cast_pad_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N) {
+    const size_t total = (size_t)M * ldy;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / ldy; const int n = (int)(i - m * ldy);
+        ElemOps<bf16_t>::store(y + i, n < N ? x[m * ldx + n] : 0.f);
     }
 }
 
@@ -249,9 +312,21 @@ extern "C" int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const
     return BOFI_OK;
 }
 
-extern "C" int bofi_transpose_pad(const float* x, int ldx, float* xt, int M, int N, int Mpad, void* stream) {
-    if (!x || !xt || M <= 0 || N <= 0 || Mpad < M || ldx < N) return BOFI_ERR_ARG;
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Mpad + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, xt, M, N, Mpad);
+extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, void* stream) {
+    if (!x || !xt || M <= 0 || N <= 0 || Mpad < M || ldx < N || (out_dtype != BOFI_DT_F32 && out_dtype != BOFI_DT_BF16)) return BOFI_ERR_ARG;
+    const dim3 grid((Mpad + 31) / 32, (N + 31) / 32);
+    if (out_dtype == BOFI_DT_F32) hipLaunchKernelGGL((transpose_pad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (float*)xt, M, N, Mpad);
+    else hipLaunchKernelGGL((transpose_pad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)xt, M, N, Mpad);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, void* stream) {
+    if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N) return BOFI_ERR_ARG;
+    if (M == 0) return BOFI_OK;
+    const size_t total = (size_t)M * ldy;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -279,7 +354,10 @@ extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float
                                   int d, void* stream) {
     if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d);
+    const int rpb = rows >= 16384 ? 64 : 32;
+    if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
+    else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
+    else hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -290,7 +368,10 @@ extern "C" int bofi_attention_bwd(const float* q, int ldq, const float* k, int l
     if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0) return BOFI_ERR_ARG;
     if (B == 0) return BOFI_OK;
     AttnBwdParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, dk, dv, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias};
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid(B * H), block(256);
+    if (Lq <= 32 && Lk <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 32>), grid, block, 0, (hipStream_t)stream, p);
+    else if (Lq <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 64>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_bwd_kernel<64, 64>), grid, block, 0, (hipStream_t)stream, p);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

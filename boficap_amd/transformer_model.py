@@ -62,6 +62,7 @@ class TransformerModel(nn.Module):
         self.max_batch = max_batch or getattr(opt, "bofi_max_batch", 64)
         self.max_regions = max_regions or getattr(opt, "bofi_max_regions", getattr(opt, "max_boxes", 100))
         self.strict_reference = strict_reference       # reproduce quirk Q1 (TransformerModel.py:1872-1873)
+        self.train_dtype = getattr(opt, "bofi_train_dtype", torch.float32)   # GEMM operand dtype of the XE step
         _build_param_tree(self, cfg)
         self.reset_parameters()
         self._engine = None
@@ -178,7 +179,7 @@ class TransformerModel(nn.Module):
         seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._step if self.training else None
         return xe.forward_uic(self._params(), self.cfg, att_feats, seq, att_masks, phrase_num, phrase_length, phrase_syn,
                               extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask, glat_p=float(glat_p),
-                              training=self.training, seed=seed)
+                              training=self.training, seed=seed, compute_dtype=self.train_dtype)
 
 
 def setup(opt):

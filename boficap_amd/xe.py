@@ -47,39 +47,67 @@ def _need(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+# GEMM compute dtype of the training path: float32 (parity) or bfloat16 operands with float32 accumulation, outputs,
+# master weights and gradients (BASELINE config 3).  Set per forward pass by forward_uic.
+_COMPUTE = {"dtype": torch.float32}
+
+
 def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0):
-    _chk(_lib().bofi_linear(hip.ptr(x), F32, ldx, hip.ptr(w), F32, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
+    code = hip.dtype_code(x)
+    _chk(_lib().bofi_linear(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
                             hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, hip.stream_ptr()), "bofi_linear")
 
 
-def _transpose_pad(x, M, N, Mpad):
-    xt = _empty(x, N, Mpad)
-    _chk(_lib().bofi_transpose_pad(hip.ptr(x), N, hip.ptr(xt), M, N, Mpad, hip.stream_ptr()), "bofi_transpose_pad")
-    return xt
+def _operand(x, M, N, dt):
+    """[M, N] float32 -> GEMM operand [M, pad(N)] in the compute dtype (zero padded to the kernel's K granule)."""
+    g = 32 if dt == torch.float32 else 64
+    Np = (N + g - 1) // g * g
+    if dt == torch.float32:
+        if Np == N:
+            return x, Np
+        xp = _zeros(x, M, Np)
+        xp[:, :N] = x
+        return xp, Np
+    y = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
+    _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.stream_ptr()), "bofi_cast_bf16")
+    return y, Np
 
 
-def _pad32(n: int) -> int:
-    return (n + 31) // 32 * 32
+def _transposed(x, M, N, dt):
+    """[M, N] float32 -> [N, pad(M)] in the compute dtype."""
+    g = 32 if dt == torch.float32 else 64
+    Mp = (M + g - 1) // g * g
+    xt = torch.empty(N, Mp, dtype=dt, device=x.device)
+    _chk(_lib().bofi_transpose_pad(hip.ptr(x), N, hip.ptr(xt), F32 if dt == torch.float32 else hip.DT_BF16, M, N, Mp, hip.stream_ptr()),
+         "bofi_transpose_pad")
+    return xt, Mp
+
+
+def _pad_k(n: int) -> int:
+    return (n + 63) // 64 * 64
 
 
 class LinearFn(Function):
     """y = act(x w^T + b) [+ residual]  (bofi_linear).  Backward: dx = dz w, dw = dz^T x, db = colsum(dz), all on
     the same MFMA GEMM kernel; the weight-gradient GEMM contracts over rows, so both operands are transposed
-    (and zero-padded to the kernel's K granule) first."""
+    (and zero-padded to the kernel's K granule) first.  Operands are cast to the compute dtype on the way in."""
 
     @staticmethod
     def forward(ctx, x, w, b, residual, relu, row_len, rpg):
         x, w = _need(x, "linear x"), _need(w, "linear w")
         M, K = x.shape
         N = w.shape[0]
+        dt = _COMPUTE["dtype"]
         if relu and residual is not None:
             raise hip.BofiHipError("relu with a residual is not a node of this model")
         if row_len is not None and not relu:
             raise hip.BofiHipError("row_len is only used with relu (att_embed)")
         y = _empty(x, M, N)
         if M:
-            _gemm(x, K, w, b, residual, y, M, N, K, 1 if relu else 0, row_len, rpg)
-        ctx.relu = bool(relu)
+            xo, Kp = _operand(x, M, K, dt)
+            wo, _ = _operand(w, N, K, dt)
+            _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg)
+        ctx.relu, ctx.dt = bool(relu), dt
         ctx.has_b, ctx.has_r = b is not None, residual is not None
         ctx.save_for_backward(x, w, y if relu else None)
         return y
@@ -89,6 +117,7 @@ class LinearFn(Function):
         x, w, y = ctx.saved_tensors
         M, K = x.shape
         N = w.shape[0]
+        dt = ctx.dt
         dy = _need(dy, "linear dy")
         L, st = _lib(), hip.stream_ptr()
         dz = dy
@@ -100,18 +129,13 @@ class LinearFn(Function):
             return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None, torch.zeros_like(w) if ctx.needs_input_grad[1] else None,
                     _zeros(x, N) if ctx.has_b else None, dy if ctx.has_r else None, None, None, None)
         if ctx.needs_input_grad[0]:
-            Np = _pad32(N)
-            wt = _transpose_pad(w, N, K, Np)           # [K, Np]
-            dzp = dz
-            if Np != N:
-                dzp = _zeros(x, M, Np)
-                dzp[:, :N] = dz
+            dzo, Np = _operand(dz, M, N, dt)
+            wt, _ = _transposed(w, N, K, dt)           # [K, Np]
             dx = _empty(x, M, K)
-            _gemm(dzp, Np, wt, None, None, dx, M, K, Np)
+            _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
         if ctx.needs_input_grad[1]:
-            Mp = _pad32(M)
-            dzt = _transpose_pad(dz, M, N, Mp)         # [N, Mp]
-            xt = _transpose_pad(x, M, K, Mp)           # [K, Mp]
+            dzt, Mp = _transposed(dz, M, N, dt)        # [N, Mp]
+            xt, _ = _transposed(x, M, K, dt)           # [K, Mp]
             dw = _empty(x, N, K)
             _gemm(dzt, Mp, xt, None, None, dw, N, K, Mp)
         if ctx.has_b and ctx.needs_input_grad[2]:
@@ -400,7 +424,7 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, N, L, R, spi, klen_pass, at
     # heads: hidden 100 is not a multiple of the GEMM K granule -> both first layers side by side in one padded GEMM
     w1l, w1s = P[lp + ".Length_classifier1.weight"], P[lp + ".Syntactic_classifier1.weight"]
     hh = w1l.shape[0]
-    Hp = _pad32(2 * hh)
+    Hp = _pad_k(2 * hh)
     zpad = w1l.new_zeros(Hp - 2 * hh, d)
     w1 = torch.cat([w1l, w1s, zpad], 0)
     b1 = torch.cat([P[lp + ".Length_classifier1.bias"], P[lp + ".Syntactic_classifier1.bias"], w1l.new_zeros(Hp - 2 * hh)], 0)
@@ -427,11 +451,15 @@ def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor):
 
 
 def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, extend_phrase_seq,
-                extend_phrase_seq_mask, *, glat_p: float = -1.0, training: bool = False, seed: Optional[int] = None):
+                extend_phrase_seq_mask, *, glat_p: float = -1.0, training: bool = False, seed: Optional[int] = None,
+                compute_dtype: torch.dtype = torch.float32):
     """The six log-prob tensors of EncoderDecoder_UIC.forward (TransformerModel.py:413-468, glat_p < 0):
     (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok)."""
     dev = att_feats.device
     S, L, d = cfg.seq_length, cfg.seq_length + 2, cfg.d_model
+    if compute_dtype not in (torch.float32, torch.bfloat16):
+        raise hip.BofiHipError(f"training compute dtype {compute_dtype}: float32 or bfloat16")
+    _COMPUTE["dtype"] = compute_dtype
     if labels.dim() == 3:
         labels = labels.reshape(-1, labels.shape[2])
         phrase_num = phrase_num.reshape(-1)
