@@ -210,7 +210,8 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict_
 // xt[n][m] = x[m][n] for m < M, 0 for M <= m < Mpad   (operands of the weight-gradient GEMM, whose inner dimension is M);
 // the output is written in the GEMM's compute dtype
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int ldx, T* __restrict__ xt, int M, int N, int Mpad) {
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, int ldx, T* __restrict__ xt, int M, int N, int Mpad,
+                                                            float* colsum) {
     __shared__ float tile[32][33];
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
@@ -221,6 +222,12 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     for (int i = ty; i < 32; i += 8) {
         const int n = n0 + i, m = m0 + tx;
         if (n < N && m < Mpad) ElemOps<T>::store(xt + (size_t)n * Mpad + m, tile[tx][i]);
+    }
+    if (colsum && threadIdx.x < 32 && n0 + tx < N && m0 < M) {   // the tile is in LDS anyway: its column sums are the bias gradient
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += tile[i][tx];
+        atomicAdd(&colsum[n0 + tx], s);
     }
 }
 
@@ -312,11 +319,11 @@ extern "C" int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const
     return BOFI_OK;
 }
 
-extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, void* stream) {
+extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream) {
     if (!x || !xt || M <= 0 || N <= 0 || Mpad < M || ldx < N || (out_dtype != BOFI_DT_F32 && out_dtype != BOFI_DT_BF16)) return BOFI_ERR_ARG;
     const dim3 grid((Mpad + 31) / 32, (N + 31) / 32);
-    if (out_dtype == BOFI_DT_F32) hipLaunchKernelGGL((transpose_pad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (float*)xt, M, N, Mpad);
-    else hipLaunchKernelGGL((transpose_pad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)xt, M, N, Mpad);
+    if (out_dtype == BOFI_DT_F32) hipLaunchKernelGGL((transpose_pad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (float*)xt, M, N, Mpad, colsum);
+    else hipLaunchKernelGGL((transpose_pad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)xt, M, N, Mpad, colsum);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

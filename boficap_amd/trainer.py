@@ -7,6 +7,7 @@ flat gradient bucket and the optimiser is a single HBM-bound kernel (``bofi_adam
 """
 from __future__ import annotations
 
+import re
 from typing import Dict, Optional
 
 import torch
@@ -21,9 +22,22 @@ class FlatBucket:
     ``.grad`` that is a view into a second flat buffer.  Works on any device (the gloo tests use the CPU)."""
 
     def __init__(self, module: torch.nn.Module):
-        self.params = [p for p in module.parameters()]
-        if not self.params:
+        named = list(module.named_parameters())
+        if not named:
             raise ValueError("no parameters")
+        # q, k, v projections of one attention block next to each other (weights, then biases): the packed [3d, d]
+        # operand of the fused projection GEMM and its gradient are then plain views of the buckets (span()).
+        pat = re.compile(r"^(.*)\.linears\.([012])\.(weight|bias)$")
+        groups, order = {}, []
+        for name, p in named:
+            m = pat.match(name)
+            key = (m.group(1), m.group(3)) if m else name
+            if key not in groups:
+                groups[key] = []
+                order.append(key)
+            groups[key].append((name, p))
+        self.names = [n for key in order for n, _ in groups[key]]
+        self.params = [p for key in order for _, p in groups[key]]
         dev, dt = self.params[0].device, self.params[0].dtype
         self.offsets, n = [], 0
         for p in self.params:
@@ -40,6 +54,21 @@ class FlatBucket:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self._offset = {id(p): o for p, o in zip(self.params, self.offsets)}
+        module._bucket = self
+
+    def span(self, parts):
+        """(view, gradient view) over parameters that are adjacent in the bucket and stack on dim 0, else None."""
+        o0 = self._offset.get(id(parts[0]))
+        if o0 is None:
+            return None
+        o = o0
+        for p in parts:
+            if self._offset.get(id(p)) != o or p.numel() % ALIGN or p.shape[1:] != parts[0].shape[1:]:
+                return None
+            o += p.numel()
+        shape = (sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:])
+        return self.flat[o0:o].view(shape).requires_grad_(), self.grad[o0:o].view(shape)
 
     def zero_grad(self) -> None:
         self.grad.zero_()

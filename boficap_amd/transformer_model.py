@@ -159,11 +159,6 @@ class TransformerModel(nn.Module):
             outs = [o.repeat_interleave(sample_n, dim=0) for o in outs]
         return (*outs, end - start)
 
-    def _params(self):
-        P = dict(self.named_parameters())
-        P["model.pos_embed.pe"] = self.model.pos_embed.pe
-        return P
-
     def _forward(self, fc_feats, att_feats, seq, att_masks=None, phrase_num=None, phrase_length=None, phrase_syn=None,
                  extend_phrase_syn_seq=None, extend_phrase_seq=None, extend_phrase_seq_mask=None, glat_p=-1.0):
         """TransformerModel.py:1713-1724,1759-1775 (train_mode 'UIC', ss_prob 0): the six log-prob tensors, with the
@@ -177,7 +172,7 @@ class TransformerModel(nn.Module):
             raise hip.BofiHipError("the model must be on a HIP device (model.cuda()); there is no CPU training path")
         self._step = getattr(self, "_step", 0) + 1
         seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._step if self.training else None
-        return xe.forward_uic(self._params(), self.cfg, att_feats, seq, att_masks, phrase_num, phrase_length, phrase_syn,
+        return xe.forward_uic(xe.Params(self), self.cfg, att_feats, seq, att_masks, phrase_num, phrase_length, phrase_syn,
                               extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask, glat_p=float(glat_p),
                               training=self.training, seed=seed, compute_dtype=self.train_dtype)
 

@@ -51,6 +51,11 @@ def _need(t: torch.Tensor, what: str) -> torch.Tensor:
 # master weights and gradients (BASELINE config 3).  Set per forward pass by forward_uic.
 _COMPUTE = {"dtype": torch.float32}
 
+# GEMM operands made during the current step: (kind, data_ptr, shape, dtype) -> (source kept alive, operand).  A weight
+# that serves two passes (the decoder runs for the SA and the NA branch) and the image memory that feeds every cross
+# K/V projection are cast / transposed once per step instead of once per use.  Cleared by forward_uic.
+_STEP_CACHE: dict = {}
+
 
 def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0):
     code = hip.dtype_code(x)
@@ -58,28 +63,44 @@ def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0):
                             hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, hip.stream_ptr()), "bofi_linear")
 
 
-def _operand(x, M, N, dt):
+def _granule(dt) -> int:
+    return 32 if dt == torch.float32 else 64
+
+
+def _operand(x, M, N, dt, cache=True):
     """[M, N] float32 -> GEMM operand [M, pad(N)] in the compute dtype (zero padded to the kernel's K granule)."""
-    g = 32 if dt == torch.float32 else 64
+    g = _granule(dt)
     Np = (N + g - 1) // g * g
+    if dt == torch.float32 and Np == N:
+        return x, Np
+    key = ("op", x.data_ptr(), M, N, dt)
+    hit = _STEP_CACHE.get(key) if cache else None
+    if hit is not None:
+        return hit[1], Np
     if dt == torch.float32:
-        if Np == N:
-            return x, Np
-        xp = _zeros(x, M, Np)
-        xp[:, :N] = x
-        return xp, Np
-    y = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
-    _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.stream_ptr()), "bofi_cast_bf16")
+        y = _zeros(x, M, Np)
+        y[:, :N] = x
+    else:
+        y = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
+        _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.stream_ptr()), "bofi_cast_bf16")
+    if cache:
+        _STEP_CACHE[key] = (x, y)
     return y, Np
 
 
-def _transposed(x, M, N, dt):
-    """[M, N] float32 -> [N, pad(M)] in the compute dtype."""
-    g = 32 if dt == torch.float32 else 64
+def _transposed(x, M, N, dt, colsum=None, cache=True):
+    """[M, N] float32 -> [N, pad(M)] in the compute dtype; optionally adds the column sums of x into ``colsum``."""
+    g = _granule(dt)
     Mp = (M + g - 1) // g * g
+    key = ("tr", x.data_ptr(), M, N, dt)
+    hit = _STEP_CACHE.get(key) if (cache and colsum is None) else None
+    if hit is not None:
+        return hit[1], Mp
     xt = torch.empty(N, Mp, dtype=dt, device=x.device)
-    _chk(_lib().bofi_transpose_pad(hip.ptr(x), N, hip.ptr(xt), F32 if dt == torch.float32 else hip.DT_BF16, M, N, Mp, hip.stream_ptr()),
-         "bofi_transpose_pad")
+    _chk(_lib().bofi_transpose_pad(hip.ptr(x), N, hip.ptr(xt), F32 if dt == torch.float32 else hip.DT_BF16, M, N, Mp, hip.ptr(colsum),
+                                   hip.stream_ptr()), "bofi_transpose_pad")
+    if cache and colsum is None:
+        _STEP_CACHE[key] = (x, xt)
     return xt, Mp
 
 
@@ -88,12 +109,14 @@ def _pad_k(n: int) -> int:
 
 
 class LinearFn(Function):
-    """y = act(x w^T + b) [+ residual]  (bofi_linear).  Backward: dx = dz w, dw = dz^T x, db = colsum(dz), all on
-    the same MFMA GEMM kernel; the weight-gradient GEMM contracts over rows, so both operands are transposed
-    (and zero-padded to the kernel's K granule) first.  Operands are cast to the compute dtype on the way in."""
+    """y = act(x w^T + b) [+ residual]  (bofi_linear).  Backward: dx = dz w, dw = dz^T x, db = colsum(dz), all on the
+    same MFMA GEMM kernel; the weight-gradient GEMM contracts over rows, so both operands are transposed (and
+    zero-padded to the kernel's K granule) first, and the bias gradient falls out of the transpose of dz.
+    ``gw`` / ``gb``: gradient buffers (views of the trainer's flat bucket) to ACCUMULATE into -- the weight-gradient GEMM
+    then adds in its epilogue (residual = output = gw) and autograd sees no gradient for w / b at all."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu, row_len, rpg):
+    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb):
         x, w = _need(x, "linear x"), _need(w, "linear w")
         M, K = x.shape
         N = w.shape[0]
@@ -102,6 +125,8 @@ class LinearFn(Function):
             raise hip.BofiHipError("relu with a residual is not a node of this model")
         if row_len is not None and not relu:
             raise hip.BofiHipError("row_len is only used with relu (att_embed)")
+        if gw is not None and (gw.shape != w.shape or not gw.is_contiguous()):
+            raise hip.BofiHipError("weight gradient buffer must match the weight")
         y = _empty(x, M, N)
         if M:
             xo, Kp = _operand(x, M, K, dt)
@@ -109,6 +134,7 @@ class LinearFn(Function):
             _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg)
         ctx.relu, ctx.dt = bool(relu), dt
         ctx.has_b, ctx.has_r = b is not None, residual is not None
+        ctx.gw, ctx.gb = gw, gb
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -125,38 +151,49 @@ class LinearFn(Function):
             dz = torch.empty_like(dy)
             _chk(L.bofi_relu_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dz), dy.numel(), st), "bofi_relu_bwd")
         dx = dw = db = None
+        tail = (dy if ctx.has_r else None, None, None, None, None, None)
         if M == 0:
-            return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None, torch.zeros_like(w) if ctx.needs_input_grad[1] else None,
-                    _zeros(x, N) if ctx.has_b else None, dy if ctx.has_r else None, None, None, None)
+            return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(w) if ctx.needs_input_grad[1] and ctx.gw is None else None,
+                    _zeros(x, N) if ctx.has_b and ctx.gb is None else None) + tail
         if ctx.needs_input_grad[0]:
-            dzo, Np = _operand(dz, M, N, dt)
+            dzo, Np = _operand(dz, M, N, dt, cache=False)
             wt, _ = _transposed(w, N, K, dt)           # [K, Np]
             dx = _empty(x, M, K)
             _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
-        if ctx.needs_input_grad[1]:
-            dzt, Mp = _transposed(dz, M, N, dt)        # [N, Mp]
-            xt, _ = _transposed(x, M, K, dt)           # [K, Mp]
-            dw = _empty(x, N, K)
-            _gemm(dzt, Mp, xt, None, None, dw, N, K, Mp)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        want_w = ctx.gw is not None or ctx.needs_input_grad[1]
+        want_b = ctx.has_b and (ctx.gb is not None or ctx.needs_input_grad[2])
+        if want_b and ctx.gb is None:
             db = _zeros(x, N)
-            _chk(L.bofi_colsum_add(hip.ptr(dz), hip.ptr(db), M, N, st), "bofi_colsum_add")
-        return dx, dw, db, (dy if ctx.has_r else None), None, None, None
+        bsum = (ctx.gb if ctx.gb is not None else db) if want_b else None
+        if want_w:
+            dzt, Mp = _transposed(dz, M, N, dt, colsum=bsum, cache=False)     # [N, Mp] (+ bias gradient)
+            xt, _ = _transposed(x, M, K, dt)                                   # [K, Mp]
+            if ctx.gw is not None:
+                _gemm(dzt, Mp, xt, None, ctx.gw, ctx.gw, N, K, Mp)             # gw += dz^T x
+            else:
+                dw = _empty(x, N, K)
+                _gemm(dzt, Mp, xt, None, None, dw, N, K, Mp)
+        elif want_b:
+            _chk(L.bofi_colsum_add(hip.ptr(dz), hip.ptr(bsum), M, N, st), "bofi_colsum_add")
+        return (dx, dw, db) + tail
 
 
-def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0):
-    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg)
+def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None):
+    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb)
 
 
 class LayerNormFn(Function):
-    """a_2 (x - mean) / (std + eps) + b_2 with the unbiased std (TransformerModel.py:1346-1349)."""
+    """a_2 (x - mean) / (std + eps) + b_2 with the unbiased std (TransformerModel.py:1346-1349).
+    ``gg`` / ``gb``: gradient buffers of gain / bias to accumulate into (see LinearFn)."""
 
     @staticmethod
-    def forward(ctx, x, gain, bias):
+    def forward(ctx, x, gain, bias, gg, gb):
         x, gain, bias = _need(x, "ln x"), _need(gain, "ln gain"), _need(bias, "ln bias")
         rows, d = x.shape
         y = torch.empty_like(x)
         _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(y), F32, rows, d, hip.stream_ptr()), "bofi_layernorm")
+        ctx.gg, ctx.gb = gg, gb
         ctx.save_for_backward(x, gain)
         return y
 
@@ -165,14 +202,16 @@ class LayerNormFn(Function):
         x, gain = ctx.saved_tensors
         rows, d = x.shape
         dy = _need(dy, "ln dy")
-        dx, dg, db = torch.empty_like(x), _zeros(x, d), _zeros(x, d)
+        direct = ctx.gg is not None and ctx.gb is not None
+        dx = torch.empty_like(x)
+        dg, db = (ctx.gg, ctx.gb) if direct else (_zeros(x, d), _zeros(x, d))
         _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
                                        hip.stream_ptr()), "bofi_layernorm_bwd")
-        return dx, dg, db
+        return (dx, None, None, None, None) if direct else (dx, dg, db, None, None)
 
 
-def layer_norm(x, gain, bias):
-    return LayerNormFn.apply(x, gain, bias)
+def layer_norm(x, gain, bias, gg=None, gb=None):
+    return LayerNormFn.apply(x, gain, bias, gg, gb)
 
 
 def _off(t: torch.Tensor, col: int) -> C.c_void_p:
@@ -221,10 +260,11 @@ def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, kl
 
 
 class EmbedFn(Function):
-    """pos_embed(tgt_embed(tok) [+ syn_embed(syn)]) (TransformerModel.py:1484-1511); ids int64 [rows], position = row % L."""
+    """pos_embed(tgt_embed(tok) [+ syn_embed(syn)]) (TransformerModel.py:1484-1511); ids int64 [rows], position = row % L.
+    ``g_tok`` / ``g_syn``: gradient buffers of the tables to scatter-add into (see LinearFn)."""
 
     @staticmethod
-    def forward(ctx, lut_tok, lut_syn, pe, tok, syn, L):
+    def forward(ctx, lut_tok, lut_syn, pe, tok, syn, L, g_tok, g_syn):
         ref = lut_tok if lut_tok is not None else lut_syn
         d = ref.shape[1]
         ids = tok if tok is not None else syn
@@ -235,7 +275,7 @@ class EmbedFn(Function):
         x = _empty(ref, rows, d)
         _chk(_lib().bofi_embed_rows(hip.ptr(lut_tok if tok is not None else None), hip.ptr(lut_syn if syn is not None else None), hip.ptr(pe),
                                     hip.ptr(tok), hip.ptr(syn), rows, L, d, hip.ptr(x), hip.stream_ptr()), "bofi_embed_rows")
-        ctx.tok, ctx.syn = tok, syn
+        ctx.tok, ctx.syn, ctx.g = tok, syn, (g_tok, g_syn)
         ctx.shapes = (None if lut_tok is None else lut_tok.shape, None if lut_syn is None else lut_syn.shape)
         return x
 
@@ -244,18 +284,18 @@ class EmbedFn(Function):
         dx = _need(dx, "embed dx")
         rows, d = dx.shape
         out = []
-        for ids, shape in ((ctx.tok, ctx.shapes[0]), (ctx.syn, ctx.shapes[1])):
+        for ids, shape, direct in ((ctx.tok, ctx.shapes[0], ctx.g[0]), (ctx.syn, ctx.shapes[1], ctx.g[1])):
             if ids is None or shape is None:
                 out.append(None)
                 continue
-            g = _zeros(dx, *shape)
+            g = direct if direct is not None else _zeros(dx, *shape)
             _chk(_lib().bofi_embed_bwd(hip.ptr(dx), hip.ptr(ids), hip.ptr(g), rows, d, float(d) ** 0.5, hip.stream_ptr()), "bofi_embed_bwd")
-            out.append(g)
-        return out[0], out[1], None, None, None, None
+            out.append(None if direct is not None else g)
+        return out[0], out[1], None, None, None, None, None, None
 
 
-def embed(lut_tok, lut_syn, pe, tok, syn, L):
-    return EmbedFn.apply(lut_tok, lut_syn, pe, tok, syn, L)
+def embed(lut_tok, lut_syn, pe, tok, syn, L, g_tok=None, g_syn=None):
+    return EmbedFn.apply(lut_tok, lut_syn, pe, tok, syn, L, g_tok, g_syn)
 
 
 class LogSoftmaxFn(Function):
@@ -331,73 +371,109 @@ class _Drop:
 
 
 # ------------------------------------------------------------------------------------------------ the model
-def _sublayer_linear(drop, x_in, w, b, residual):
+class Params:
+    """Where the forward pass gets its weights -- and, when the model's parameters live in a trainer's flat bucket
+    (boficap_amd.trainer.FlatBucket), the gradient buffer each kernel accumulates into directly.
+
+    Without a bucket every entry is the module's own nn.Parameter, packed projections are ``torch.cat``s and the
+    gradients travel through autograd as usual (what the parity tests exercise).  With a bucket, q|k|v weights of an
+    attention block are adjacent in HBM, so the packed [3d, d] operand is a free view, and its gradient view is handed
+    to the weight-gradient GEMM as the accumulation target."""
+
+    def __init__(self, module):
+        self.t = dict(module.named_parameters())
+        self.t["model.pos_embed.pe"] = module.model.pos_embed.pe
+        self.bucket = getattr(module, "_bucket", None)
+        self._packed = {}
+
+    def __getitem__(self, name):
+        return self.t[name]
+
+    def g(self, name):
+        """Gradient accumulation buffer of a parameter (None: let autograd carry the gradient)."""
+        return self.t[name].grad if self.bucket is not None else None
+
+    def packed(self, prefix, idx, what):
+        """(linears[idx...].what stacked on dim 0, its gradient buffer or None)."""
+        key = (prefix, idx, what)
+        if key not in self._packed:
+            parts = [self.t[f"{prefix}.linears.{i}.{what}"] for i in idx]
+            view = self.bucket.span(parts) if self.bucket is not None else None
+            self._packed[key] = view if view is not None else (torch.cat(parts, 0), None)
+        return self._packed[key]
+
+    # ---- the model's recurring nodes
+    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0):
+        w, b = wname + ".weight", wname + ".bias"
+        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b))
+
+    def lin_packed(self, x, prefix, idx):
+        (w, gw), (b, gb) = self.packed(prefix, idx, "weight"), self.packed(prefix, idx, "bias")
+        return linear(x, w, b, gw=gw, gb=gb)
+
+    def ln(self, x, prefix):
+        a, b = prefix + ".a_2", prefix + ".b_2"
+        return layer_norm(x, self.t[a], self.t[b], self.g(a), self.g(b))
+
+
+def _sublayer_linear(P, drop, x_in, wname, residual):
     """residual + dropout(x_in w^T + b): the residual rides in the GEMM epilogue when dropout is off."""
     if not drop.on or drop.p <= 0.0:
-        return linear(x_in, w, b, residual=residual)
-    return drop(linear(x_in, w, b), residual)
+        return P.lin(x_in, wname, residual=residual)
+    return drop(P.lin(x_in, wname), residual)
 
 
 def _ffn(P, pre, drop, n, x):
-    h = linear(n, P[pre + ".w_1.weight"], P[pre + ".w_1.bias"], relu=True)
+    h = P.lin(n, pre + ".w_1", relu=True)
     if drop.on and drop.p > 0.0:
         h = drop(h)
-    return _sublayer_linear(drop, h, P[pre + ".w_2.weight"], P[pre + ".w_2.bias"], x)
-
-
-def _cat(P, pre, idx, what):
-    return torch.cat([P[f"{pre}.linears.{i}.{what}"] for i in idx], 0)
+    return _sublayer_linear(P, drop, h, pre + ".w_2", x)
 
 
 def encode_memory(P, cfg, att_feats, att_len, drop):
     """att_embed (TransformerModel.py:1642-1645 + pack_wrapper AttModel.py:36-44) and the encoder stack
     (:1366-1383): returns memory [B*R, d]."""
     B, R, Fdim = att_feats.shape
-    H = cfg.h
-    x = linear(att_feats.reshape(B * R, Fdim), P["att_embed.0.weight"], P["att_embed.0.bias"], relu=True, row_len=att_len, rpg=R)
+    d = cfg.d_model
+    x = P.lin(att_feats.reshape(B * R, Fdim), "att_embed.0", relu=True, row_len=att_len, rpg=R)
     if drop.on:
         x = drop(x, None, drop.p_att)
     sb = 1 if att_len is not None else 0
     for l in range(cfg.N_enc):
         p = f"model.encoder.layers.{l}"
-        n = layer_norm(x, P[p + ".sublayer.0.norm.a_2"], P[p + ".sublayer.0.norm.b_2"])
-        qkv = linear(n, _cat(P, p + ".self_attn", (0, 1, 2), "weight"), _cat(P, p + ".self_attn", (0, 1, 2), "bias"))
-        d = cfg.d_model
-        ctx = attention(qkv, qkv, 0, d, 2 * d, B, H, R, R, 1, att_len, sb, 0, 0)
-        x = _sublayer_linear(drop, ctx, P[p + ".self_attn.linears.3.weight"], P[p + ".self_attn.linears.3.bias"], x)
-        n = layer_norm(x, P[p + ".sublayer.1.norm.a_2"], P[p + ".sublayer.1.norm.b_2"])
-        x = _ffn(P, p + ".feed_forward", drop, n, x)
-    return layer_norm(x, P["model.encoder.norm.a_2"], P["model.encoder.norm.b_2"])
+        qkv = P.lin_packed(P.ln(x, p + ".sublayer.0.norm"), p + ".self_attn", (0, 1, 2))
+        ctx = attention(qkv, qkv, 0, d, 2 * d, B, cfg.h, R, R, 1, att_len, sb, 0, 0)
+        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", x)
+        x = _ffn(P, p + ".feed_forward", drop, P.ln(x, p + ".sublayer.1.norm"), x)
+    return P.ln(x, "model.encoder.norm")
 
 
-def _cross(P, pre, cfg, drop, n, x, memory, B, Lq, R, spi, att_len):
-    """x + src_attn(n, memory, memory) with the image's keys shared by its captions."""
+def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap):
+    """x + src_attn(n, memory, memory): the image's keys are shared by its captions (kdiv) and, because they depend
+    on the memory and the layer only, by the SA and the NA pass of the same layer (kv_cache)."""
     d = cfg.d_model
-    q = linear(n, P[pre + ".linears.0.weight"], P[pre + ".linears.0.bias"])
-    kv = linear(memory, _cat(P, pre, (1, 2), "weight"), _cat(P, pre, (1, 2), "bias"))
-    ctx = attention(q, kv, 0, 0, d, B, cfg.h, Lq, R, spi, att_len, (1 if att_len is not None else 0), 0, 0)
-    # klen is indexed by the QUERY batch item; att_len is per image -> expand for kdiv > 1 is done by the caller
-    return _sublayer_linear(drop, ctx, P[pre + ".linears.3.weight"], P[pre + ".linears.3.bias"], x)
+    q = P.lin(n, pre + ".linears.0")
+    if pre not in kv_cache:
+        kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
+    ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, (1 if att_len_cap is not None else 0), 0, 0)
+    return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
-def decode_rows(P, cfg, drop, x, memory, N, S, R, spi, klen_self, att_len_cap):
+def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap):
     """Decoder stack + final norm (TransformerModel.py:1386-1413) over N captions x S positions; self-attention
     row (n, i) sees keys < klen_self[n, i]."""
     d = cfg.d_model
     for l in range(cfg.N_dec):
         p = f"model.decoder.layers.{l}"
-        n_ = layer_norm(x, P[p + ".sublayer.0.norm.a_2"], P[p + ".sublayer.0.norm.b_2"])
-        qkv = linear(n_, _cat(P, p + ".self_attn", (0, 1, 2), "weight"), _cat(P, p + ".self_attn", (0, 1, 2), "bias"))
+        qkv = P.lin_packed(P.ln(x, p + ".sublayer.0.norm"), p + ".self_attn", (0, 1, 2))
         ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0)
-        x = _sublayer_linear(drop, ctx, P[p + ".self_attn.linears.3.weight"], P[p + ".self_attn.linears.3.bias"], x)
-        n_ = layer_norm(x, P[p + ".sublayer.1.norm.a_2"], P[p + ".sublayer.1.norm.b_2"])
-        x = _cross(P, p + ".src_attn", cfg, drop, n_, x, memory, N, S, R, spi, att_len_cap)
-        n_ = layer_norm(x, P[p + ".sublayer.2.norm.a_2"], P[p + ".sublayer.2.norm.b_2"])
-        x = _ffn(P, p + ".feed_forward", drop, n_, x)
-    return layer_norm(x, P["model.decoder.norm.a_2"], P["model.decoder.norm.b_2"])
+        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", x)
+        x = _cross(P, p + ".src_attn", cfg, drop, P.ln(x, p + ".sublayer.1.norm"), x, memory, kv_cache, N, S, R, spi, att_len_cap)
+        x = _ffn(P, p + ".feed_forward", drop, P.ln(x, p + ".sublayer.2.norm"), x)
+    return P.ln(x, "model.decoder.norm")
 
 
-def bound_teacher_forced(P, cfg, drop, x_in, memory, N, L, R, spi, klen_pass, att_len_cap):
+def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap):
     """The teacher-forced bound passes of one branch as one batch.
 
     x_in [N*L, d] is the embedded bound input; klen_pass int32 [N, Pmax] the number of keys the [LEN] row of
@@ -407,26 +483,24 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, N, L, R, spi, klen_pass, at
     Pm = klen_pass.shape[1]
     lp = "model.length_predictor"
     p = lp + ".LengthPredictor.0"
-    n_all = layer_norm(x_in, P[p + ".sublayer.0.norm.a_2"], P[p + ".sublayer.0.norm.b_2"])
-    kv = linear(n_all, _cat(P, p + ".self_attn", (1, 2), "weight"), _cat(P, p + ".self_attn", (1, 2), "bias"))
+    n_all = P.ln(x_in, p + ".sublayer.0.norm")
+    kv = P.lin_packed(n_all, p + ".self_attn", (1, 2))
     x0 = x_in.view(N, L, d)[:, 0, :]
     n0 = n_all.view(N, L, d)[:, 0, :].contiguous()
-    q0 = linear(n0, P[p + ".self_attn.linears.0.weight"], P[p + ".self_attn.linears.0.bias"])
+    q0 = P.lin(n0, p + ".self_attn.linears.0")
     qv = q0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
     xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
     ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0)
-    x = _sublayer_linear(drop, ctx, P[p + ".self_attn.linears.3.weight"], P[p + ".self_attn.linears.3.bias"], xv)
-    n_ = layer_norm(x, P[p + ".sublayer.1.norm.a_2"], P[p + ".sublayer.1.norm.b_2"])
-    x = _cross(P, p + ".src_attn", cfg, drop, n_, x, memory, N, Pm, R, spi, att_len_cap)
-    n_ = layer_norm(x, P[p + ".sublayer.2.norm.a_2"], P[p + ".sublayer.2.norm.b_2"])
-    x = _ffn(P, p + ".ff", drop, n_, x)
-    o = layer_norm(x, P[lp + ".norm.a_2"], P[lp + ".norm.b_2"])
+    x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xv)
+    x = _cross(P, p + ".src_attn", cfg, drop, P.ln(x, p + ".sublayer.1.norm"), x, memory, kv_cache, N, Pm, R, spi, att_len_cap)
+    x = _ffn(P, p + ".ff", drop, P.ln(x, p + ".sublayer.2.norm"), x)
+    o = P.ln(x, lp + ".norm")
     # heads: hidden 100 is not a multiple of the GEMM K granule -> both first layers side by side in one padded GEMM
+    # (small tensors; their gradients go through autograd's cat/slice nodes)
     w1l, w1s = P[lp + ".Length_classifier1.weight"], P[lp + ".Syntactic_classifier1.weight"]
     hh = w1l.shape[0]
     Hp = _pad_k(2 * hh)
-    zpad = w1l.new_zeros(Hp - 2 * hh, d)
-    w1 = torch.cat([w1l, w1s, zpad], 0)
+    w1 = torch.cat([w1l, w1s, w1l.new_zeros(Hp - 2 * hh, d)], 0)
     b1 = torch.cat([P[lp + ".Length_classifier1.bias"], P[lp + ".Syntactic_classifier1.bias"], w1l.new_zeros(Hp - 2 * hh)], 0)
     hid = linear(o, w1, b1, relu=True)
     if drop.on and drop.p > 0.0:
@@ -453,13 +527,14 @@ def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor):
 def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, extend_phrase_seq,
                 extend_phrase_seq_mask, *, glat_p: float = -1.0, training: bool = False, seed: Optional[int] = None,
                 compute_dtype: torch.dtype = torch.float32):
-    """The six log-prob tensors of EncoderDecoder_UIC.forward (TransformerModel.py:413-468, glat_p < 0):
-    (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok)."""
+    """The six log-prob tensors of EncoderDecoder_UIC.forward (TransformerModel.py:413-468):
+    (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok).  ``P``: a ``Params``."""
     dev = att_feats.device
     S, L, d = cfg.seq_length, cfg.seq_length + 2, cfg.d_model
     if compute_dtype not in (torch.float32, torch.bfloat16):
         raise hip.BofiHipError(f"training compute dtype {compute_dtype}: float32 or bfloat16")
     _COMPUTE["dtype"] = compute_dtype
+    _STEP_CACHE.clear()
     if labels.dim() == 3:
         labels = labels.reshape(-1, labels.shape[2])
         phrase_num = phrase_num.reshape(-1)
@@ -481,15 +556,18 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None)
     memory = encode_memory(P, cfg, att_feats, att_len, drop)
     att_len_cap = None if att_len is None else att_len.repeat_interleave(spi).contiguous()
+    kv_cache: dict = {}
 
     labels, phrase_num, phrase_length = labels.to(dev).long(), phrase_num.to(dev).long(), phrase_length.to(dev).long()
     ext_syn = extend_phrase_syn_seq.to(dev).long().contiguous()
     ext_seq = extend_phrase_seq.to(dev).long().contiguous()
     klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length)
-    lut_tok, lut_syn, pe = P["model.tgt_embed.lut.weight"], P["model.syn_embed.lut.weight"], P["model.pos_embed.pe"]
+    tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
+    pe = P["model.pos_embed.pe"]
 
     def emb(tok, syn, Lp):
-        x = embed(lut_tok if tok is not None else None, lut_syn if syn is not None else None, pe, tok, syn, Lp)
+        x = embed(P[tname] if tok is not None else None, P[sname] if syn is not None else None, pe, tok, syn, Lp,
+                  P.g(tname) if tok is not None else None, P.g(sname) if syn is not None else None)
         return drop(x) if drop.on and drop.p > 0.0 else x
 
     def pad_slots(t):                                          # pass i lands in slot i of the returned [:, 1:] view
@@ -497,24 +575,27 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
         out[:, :Pm] = t
         return out
 
+    def vocab(x):
+        return P.lin(x, "model.generator.proj")
+
     # --- semi-autoregressive branch (TransformerModel.py:476-530)
     word_seq = labels.clone()
     word_seq[:, 0] = cfg.len_idx
-    sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, N, L, R, spi, klen_pass, att_len_cap)
+    sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
+                                          att_len_cap)
     syn_mid = ext_syn[:, 1:-1].contiguous()
     klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1).to(torch.int32).contiguous()          # prefix masks (dataloader.py:414)
-    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, S), memory, N, S, R, spi, klen_sa, att_len_cap)
-    gw, gb = P["model.generator.proj.weight"], P["model.generator.proj.bias"]
-    sa_tok = log_softmax(linear(x, gw, gb)).view(N, S, -1)
+    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, S), memory, kv_cache, N, S, R, spi, klen_sa, att_len_cap)
+    sa_tok = log_softmax(vocab(x)).view(N, S, -1)
 
     # --- non-autoregressive branch (:532-587)
-    na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, N, L, R, spi, klen_pass, att_len_cap)
+    na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
     klen_na = (last - 1).unsqueeze(1).expand(N, S).contiguous()
     fill_in = torch.full((N, S), cfg.bos_idx, dtype=torch.int64, device=dev)
     if glat_p >= 0:                                            # glancing input (:437-463): reveal a share of the true tokens
         with torch.no_grad():
-            x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, N, S, R, spi, klen_na, att_len_cap)
-            pred = greedy_ids(linear(x, gw, gb)).view(N, S)
+            x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, dict(kv_cache), N, S, R, spi, klen_na, att_len_cap)
+            pred = greedy_ids(vocab(x)).view(N, S)
             real = labels[:, 1:-1]
             ntok = phrase_length.sum(1) - 1
             tok_mask = torch.arange(S, device=dev).unsqueeze(0) < ntok.unsqueeze(1)
@@ -522,8 +603,8 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
             keep_prob = ((ntok - same) / ntok * glat_p).unsqueeze(-1) * tok_mask.float()
             keep = torch.rand(real.shape, device=dev) < keep_prob
             fill_in = torch.where(keep, real, fill_in).contiguous()
-    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, N, S, R, spi, klen_na, att_len_cap)
-    na_tok = log_softmax(linear(x, gw, gb)).view(N, S, -1)
+    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, kv_cache, N, S, R, spi, klen_na, att_len_cap)
+    na_tok = log_softmax(vocab(x)).view(N, S, -1)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
 
 

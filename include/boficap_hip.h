@@ -110,8 +110,9 @@ int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
 int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok,
                     const int64_t* syn, int rows, int L, int d, float* x, void* stream);
 int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream);
-/* xt[n][m] = x[m][n], zero for M <= m < Mpad, written as out_dtype: operand layout of the weight-gradient GEMM */
-int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, void* stream);
+/* xt[n][m] = x[m][n], zero for M <= m < Mpad, written as out_dtype: operand layout of the weight-gradient GEMM.
+ * colsum (may be NULL): colsum[n] += sum_m x[m][n], the bias gradient, taken from the tiles while they are in LDS */
+int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream);
 /* y[m][n] = bf16(x[m][n]) for n < N, zero for N <= n < ldy: a GEMM operand in the bf16 compute dtype */
 int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, void* stream);
 /* y = (residual or 0) + keep(x) / (1 - p), keep mask = hash(seed, index) (nn.Dropout of the sublayers,

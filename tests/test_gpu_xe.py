@@ -316,3 +316,42 @@ def test_xe_step_bf16_operands_close_to_reference(weight_cache, manifest):
         worst = max(worst, abs(float(params[n].grad.double().norm()) - ref_norm) / ref_norm)
     print("bf16: worst log-prob error", worst_out, "worst relative grad-norm error", worst)
     assert worst_out < 6e-2 and worst < 5e-2
+
+
+@pytest.mark.parametrize("masks", [False, True])
+def test_bucket_accumulated_gradients_equal_autograd_gradients(weight_cache, manifest, masks):
+    """With a flat bucket the kernels accumulate parameter gradients straight into the bucket (packed q|k|v views, GEMM
+    epilogue accumulation, atomics); without one autograd carries them.  Both must give the same gradients."""
+    from boficap_amd import xe
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, plain = _model(weight_cache, manifest, "tiny_train_xe")
+    _, bucketed = _model(weight_cache, manifest, "tiny_train_xe")
+    plain.eval(); bucketed.eval()
+    n_img, spi = 3, 5
+    batch = {k: torch.from_numpy(v).cuda() for k, v in synthetic_training_batch(cfg, n_img, spi, seed=4).items()}
+    batch["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=6)).cuda()
+    if masks:
+        m = torch.zeros(n_img, 36, device="cuda")
+        for i, n in enumerate((30, 36, 12)):
+            m[i, :n] = 1
+        batch["att_masks"] = m
+    fc = torch.zeros(n_img, 0, device="cuda")
+    outs = plain(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
+                 batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"], -1.0)
+    loss, _ = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"])
+    loss.backward()
+    tr = XETrainer(bucketed)
+    assert tr.bucket.span([dict(bucketed.named_parameters())[f"model.encoder.layers.0.self_attn.linears.{i}.weight"] for i in range(3)]) is not None
+    loss_b, _ = tr.forward_backward(batch)
+    assert abs(float(loss_b) - float(loss.detach())) < 1e-5
+    ref = dict(plain.named_parameters())
+    for n, p in bucketed.named_parameters():
+        r = ref[n].grad
+        if r is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+        else:
+            assert _maxdiff(p.grad, r) <= 1e-4 * max(1e-3, float(r.abs().max())), n
+    tr.forward_backward(batch)                                 # a second pass starts from zeroed buckets
+    assert _maxdiff(dict(bucketed.named_parameters())["model.generator.proj.weight"].grad, ref["model.generator.proj.weight"].grad) < 1e-4
