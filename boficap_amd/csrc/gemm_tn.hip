@@ -1,0 +1,132 @@
+// Weight-gradient GEMM of the training path:  C[i][j] += sum_m A[m][i] * B[m][j]   (dW = dz^T x)
+//
+// Both operands are row-major with the CONTRACTION index as the row -- the layout the activations already have -- so
+// no transposed copies are made: tiles of 32 rows go to LDS as they lie in HBM and the MFMA operands are gathered with
+// the transposing LDS read of gfx950 (ds_read_b64_tr_b16), the same idiom attn_bf16.hip uses for P.V.  The contraction
+// runs over the rows of the batch (thousands) while the output is a weight matrix (often only 64 tiles), so the rows are
+// split across workgroups (blockIdx.z) and every workgroup adds its partial tile into C with float atomics -- C is the
+// trainer's gradient buffer, which accumulates by definition.
+//
+// bf16 operands, fp32 accumulation.  Workgroup = 4 wavefronts, tile 64 x 64, each wavefront 32 x 32 (2 x 2 MFMA
+// 16x16x32 tiles).  LDS: two stages x (A tile + B tile) x 32 rows x 128 B = 16 KB -> several workgroups per CU.
+// 16-byte chunk c of LDS row r holds source chunk c ^ ((r >> 1) & 7): the 16 rows one transposing read touches then
+// fall in 16 different bank groups.
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct GemmTnParams {
+    const bf16_t* a; int lda; int a_cols;        // a_cols: readable columns of A (multiple of 8, >= NI)
+    const bf16_t* b; int ldb; int b_cols;
+    float* c; int ldc;
+    int M, NI, NJ, m_per_block;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
+    constexpr int T = 64, TM = 32;
+    __shared__ __attribute__((aligned(16))) bf16_t sa[2][TM * T];
+    __shared__ __attribute__((aligned(16))) bf16_t sb[2][TM * T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
+    const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+    const int m_begin = blockIdx.z * p.m_per_block, m_end = min(p.M, m_begin + p.m_per_block);
+    if (m_begin >= m_end) return;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int lr = tid >> 3, lc = tid & 7;                       // loader: row lr of the 32-row tile, 16-byte chunk lc
+    const bool a_ok = i0 + lc * 8 < p.a_cols, b_ok = j0 + lc * 8 < p.b_cols;
+    const int sw = (lc ^ ((lr >> 1) & 7)) * 8;
+
+    u32x4 va, vb;
+    auto load = [&](int m0) {
+        const int m = m0 + lr;
+        va = u32x4{0u, 0u, 0u, 0u};
+        vb = va;
+        if (m < m_end) {
+            if (a_ok) va = *reinterpret_cast<const u32x4*>(p.a + (size_t)m * p.lda + i0 + lc * 8);
+            if (b_ok) vb = *reinterpret_cast<const u32x4*>(p.b + (size_t)m * p.ldb + j0 + lc * 8);
+        }
+    };
+    auto stash = [&](int buf) {
+        *reinterpret_cast<u32x4*>(&sa[buf][lr * T + sw]) = va;
+        *reinterpret_cast<u32x4*>(&sb[buf][lr * T + sw]) = vb;
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // operand gather: lane (g, tq, tp) addresses row 4g + tq (and + 16), columns 4tp .. 4tp + 3 of a 16-column block
+    const int row0 = 4 * g + tq, rsw = (row0 >> 1) & 7;           // (row0 + 16) swizzles like row0
+    auto frag = [&](const bf16_t* tile, int col) -> bf16x8 {
+        const bf16_t* p0 = tile + row0 * T + (((col >> 3) ^ rsw) << 3) + (col & 7);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * T));
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    };
+
+    load(m_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += TM) {
+        const bool more = m0 + TM < m_end;
+        if (more) load(m0 + TM);                                  // next tile in flight while this one is multiplied
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[t] = frag(sa[buf], wi + t * 16 + 4 * tp);
+            fb[t] = frag(sb[buf], wj + t * 16 + 4 * tp);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // lane holds C[i = .. + 4g + r][j = .. + l15]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 + wj + b * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi + a * 16 + 4 * g + r;
+                if (i < p.NI && j < p.NJ) atomicAdd(&p.c[(size_t)i * p.ldc + j], acc[a][b][r]);
+            }
+        }
+}
+
+int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M, int NI, int NJ,
+                   hipStream_t st) {
+    if (!a || !b || !c || M < 0 || NI <= 0 || NJ <= 0 || ldc < NJ) return BOFI_ERR_ARG;
+    if (a_cols < NI || b_cols < NJ || a_cols % 8 || b_cols % 8 || lda < a_cols || ldb < b_cols || lda % 8 || ldb % 8) return BOFI_ERR_ARG;
+    if (((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return BOFI_ERR_ARG;
+    if (M == 0) return BOFI_OK;
+    const int ti = (NI + 63) / 64, tj = (NJ + 63) / 64;
+    int splits = 1024 / (ti * tj);
+    splits = max(1, min(splits, (M + 127) / 128));                 // at least 4 tiles of rows per workgroup
+    int mpb = ((M + splits - 1) / splits + 31) / 32 * 32;
+    splits = (M + mpb - 1) / mpb;
+    GemmTnParams p{static_cast<const bf16_t*>(a), lda, a_cols, static_cast<const bf16_t*>(b), ldb, b_cols, c, ldc, M, NI, NJ, mpb};
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ti, tj, splits), dim3(256), 0, st, p);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+}  // namespace bofi
+
+extern "C" int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M, int NI,
+                                int NJ, void* stream) {
+    return bofi::launch_gemm_tn(a, lda, a_cols, b, ldb, b_cols, c, ldc, M, NI, NJ, (hipStream_t)stream);
+}

@@ -328,9 +328,30 @@ extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dty
     return BOFI_OK;
 }
 
-extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, void* stream) {
+// the same cast with the column sums of x (the bias gradient) taken on the way: one thread per column, 32 rows per block
+__global__ __launch_bounds__(256) void cast_pad_colsum_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
+                                                              float* colsum) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= ldy) return;
+    const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        const float v = n < N ? x[(size_t)m * ldx + n] : 0.f;
+        ElemOps<bf16_t>::store(y + (size_t)m * ldy + n, v);
+        s += v;
+    }
+    if (n < N) atomicAdd(&colsum[n], s);
+}
+
+extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, void* stream) {
     if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N) return BOFI_ERR_ARG;
     if (M == 0) return BOFI_OK;
+    if (colsum) {
+        hipLaunchKernelGGL(cast_pad_colsum_kernel, dim3((ldy + 255) / 256, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y,
+                           ldy, M, N, colsum);
+        BOFI_CHECK_LAUNCH();
+        return BOFI_OK;
+    }
     const size_t total = (size_t)M * ldy;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N);

@@ -67,14 +67,15 @@ def _granule(dt) -> int:
     return 32 if dt == torch.float32 else 64
 
 
-def _operand(x, M, N, dt, cache=True):
-    """[M, N] float32 -> GEMM operand [M, pad(N)] in the compute dtype (zero padded to the kernel's K granule)."""
+def _operand(x, M, N, dt, cache=True, colsum=None):
+    """[M, N] float32 -> GEMM operand [M, pad(N)] in the compute dtype (zero padded to the kernel's K granule);
+    with ``colsum`` (bf16 only) the column sums of x are added into it on the way."""
     g = _granule(dt)
     Np = (N + g - 1) // g * g
     if dt == torch.float32 and Np == N:
         return x, Np
     key = ("op", x.data_ptr(), M, N, dt)
-    hit = _STEP_CACHE.get(key) if cache else None
+    hit = _STEP_CACHE.get(key) if (cache and colsum is None) else None
     if hit is not None:
         return hit[1], Np
     if dt == torch.float32:
@@ -82,8 +83,8 @@ def _operand(x, M, N, dt, cache=True):
         y[:, :N] = x
     else:
         y = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
-        _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.stream_ptr()), "bofi_cast_bf16")
-    if cache:
+        _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.ptr(colsum), hip.stream_ptr()), "bofi_cast_bf16")
+    if cache and colsum is None:
         _STEP_CACHE[key] = (x, y)
     return y, Np
 
@@ -156,16 +157,31 @@ class LinearFn(Function):
             return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(w) if ctx.needs_input_grad[1] and ctx.gw is None else None,
                     _zeros(x, N) if ctx.has_b and ctx.gb is None else None) + tail
-        if ctx.needs_input_grad[0]:
-            dzo, Np = _operand(dz, M, N, dt, cache=False)
-            wt, _ = _transposed(w, N, K, dt)           # [K, Np]
-            dx = _empty(x, M, K)
-            _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
         want_w = ctx.gw is not None or ctx.needs_input_grad[1]
         want_b = ctx.has_b and (ctx.gb is not None or ctx.needs_input_grad[2])
         if want_b and ctx.gb is None:
             db = _zeros(x, N)
         bsum = (ctx.gb if ctx.gb is not None else db) if want_b else None
+        if dt == torch.bfloat16:
+            # one bf16 copy of dz serves both products (its column sums = the bias gradient, taken during the cast);
+            # dW = dz^T x runs on the transposing-read GEMM straight from the row-major operands
+            dzo, Np = _operand(dz, M, N, dt, cache=False, colsum=bsum)
+            if ctx.needs_input_grad[0]:
+                wt, _ = _transposed(w, N, K, dt)       # [K, Np], once per weight per step
+                dx = _empty(x, M, K)
+                _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
+            if want_w:
+                xo, Kp = _operand(x, M, K, dt)         # the forward's operand, still in the step cache
+                target = ctx.gw
+                if target is None:
+                    dw = target = _zeros(x, N, K)
+                _chk(L.bofi_gemm_tn_acc(hip.ptr(dzo), Np, Np, hip.ptr(xo), Kp, Kp, hip.ptr(target), K, M, N, K, st), "bofi_gemm_tn_acc")
+            return (dx, dw, db) + tail
+        if ctx.needs_input_grad[0]:
+            dzo, Np = _operand(dz, M, N, dt, cache=False)
+            wt, _ = _transposed(w, N, K, dt)           # [K, Np]
+            dx = _empty(x, M, K)
+            _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
         if want_w:
             dzt, Mp = _transposed(dz, M, N, dt, colsum=bsum, cache=False)     # [N, Mp] (+ bias gradient)
             xt, _ = _transposed(x, M, K, dt)                                   # [K, Mp]

@@ -110,11 +110,17 @@ int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
 int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok,
                     const int64_t* syn, int rows, int L, int d, float* x, void* stream);
 int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream);
+/* Weight-gradient GEMM: c[i][j] += sum_m a[m][i] * b[m][j], i < NI, j < NJ (dW = dz^T x without transposed copies).
+ * a, b: bf16 row-major [M, a_cols | b_cols] (cols a multiple of 8, zero beyond NI | NJ; 16-byte aligned rows);
+ * c: float32 [NI, NJ] row stride ldc, ACCUMULATED into with atomics (zero it for a plain product). */
+int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M,
+                     int NI, int NJ, void* stream);
 /* xt[n][m] = x[m][n], zero for M <= m < Mpad, written as out_dtype: operand layout of the weight-gradient GEMM.
  * colsum (may be NULL): colsum[n] += sum_m x[m][n], the bias gradient, taken from the tiles while they are in LDS */
 int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream);
-/* y[m][n] = bf16(x[m][n]) for n < N, zero for N <= n < ldy: a GEMM operand in the bf16 compute dtype */
-int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, void* stream);
+/* y[m][n] = bf16(x[m][n]) for n < N, zero for N <= n < ldy: a GEMM operand in the bf16 compute dtype.
+ * colsum (may be NULL): colsum[n] += sum_m x[m][n] on the way (the bias gradient when x is dz) */
+int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, void* stream);
 /* y = (residual or 0) + keep(x) / (1 - p), keep mask = hash(seed, index) (nn.Dropout of the sublayers,
  * TransformerModel.py:1361-1363; the backward is the same call on dy with the same seed) */
 int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, void* stream);

@@ -355,3 +355,23 @@ def test_bucket_accumulated_gradients_equal_autograd_gradients(weight_cache, man
             assert _maxdiff(p.grad, r) <= 1e-4 * max(1e-3, float(r.abs().max())), n
     tr.forward_backward(batch)                                 # a second pass starts from zeroed buckets
     assert _maxdiff(dict(bucketed.named_parameters())["model.generator.proj.weight"].grad, ref["model.generator.proj.weight"].grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,NI,NJ", [(96, 64, 64), (6400, 512, 512), (1000, 200, 72), (37, 24, 136), (2304, 2048, 512)])
+def test_gemm_tn_accumulates_a_transposed_times_b(M, NI, NJ):
+    """bofi_gemm_tn_acc (transposing LDS reads, split over rows, atomics into C) against A^T B in float64."""
+    from boficap_amd import hip
+    g = torch.Generator().manual_seed(M + NI)
+    pad8 = lambda n: (n + 63) // 64 * 64
+    a = torch.zeros(M, pad8(NI)); a[:, :NI] = torch.randn(M, NI, generator=g)
+    b = torch.zeros(M, pad8(NJ)); b[:, :NJ] = torch.randn(M, NJ, generator=g)
+    ab, bb = a.cuda().to(torch.bfloat16), b.cuda().to(torch.bfloat16)
+    base = torch.randn(NI, NJ, generator=g)
+    c = base.clone().cuda()
+    hip.check(hip.lib().bofi_gemm_tn_acc(hip.ptr(ab), ab.shape[1], ab.shape[1], hip.ptr(bb), bb.shape[1], bb.shape[1], hip.ptr(c), NJ, M, NI, NJ,
+                                         hip.stream_ptr()))
+    ref = base.double() + ab.float().cpu().double()[:, :NI].t() @ bb.float().cpu().double()[:, :NJ]
+    assert _maxdiff(c, ref) < 2e-3 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(hip.BofiHipError):
+        hip.check(hip.lib().bofi_gemm_tn_acc(hip.ptr(ab), ab.shape[1], 7, hip.ptr(bb), bb.shape[1], bb.shape[1], hip.ptr(c), NJ, M, NI, NJ,
+                                             hip.stream_ptr()))
