@@ -55,6 +55,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// counter-based dropout mask of the training path: element i of stream `seed` is kept iff drop_hash(seed, i) >= p * 2^32
+// (splitmix64 finaliser).  Forward and backward regenerate the same mask from (seed, i); nothing is stored.
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
 }  // namespace bofi
 
 // host-side launch check: kernels are enqueued on a stream, so this only catches launch errors

@@ -33,6 +33,8 @@ struct LinearArgs {
     float* stats_out;         // write partial (sum, sumsq) of the OUTPUT rows: float2 [M][N/32]
     void* y2; int ldy2;       // second copy of the output in the compute dtype (feeds the next folded GEMM)
     int splitk;               // > 1: K split over workgroups; y receives `splitk` float32 partial slabs [splitk][M][ldy]
+    // training: y = residual + keep(act(x w^T + bias)) / (1 - p), keep = drop_hash(drop_seed, m * N + n) >= drop_thresh (0: off)
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
 int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible

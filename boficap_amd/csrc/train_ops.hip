@@ -183,11 +183,22 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* out, int M, in
     atomicAdd(&out[n], s);
 }
 
-// embedding backward: d_lut[id[r]] += scale * dx[r]
-__global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids, float* dlut, int rows, int d, float scale) {
-    const int r = blockIdx.x;
-    const int64_t id = ids[r];
-    for (int k = threadIdx.x; k < d; k += blockDim.x) atomicAdd(&dlut[(size_t)id * d + k], scale * dx[(size_t)r * d + k]);
+// embedding backward: d_lut[id[r]] += scale * dx[r].  A workgroup owns 32 consecutive rows and one thread a column; runs of
+// equal ids (the NA decoder input is [BOS] everywhere, pad tails are all 0) are summed in registers and flushed with ONE
+// atomic per run, so the hot rows of the table are not hammered once per position.
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids, float* dlut, int rows,
+                                                        int d, float scale) {
+    const int r0 = blockIdx.x * 32, r1 = min(rows, r0 + 32);
+    for (int k = threadIdx.x; k < d; k += 128) {
+        int64_t cur = ids[r0];
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const int64_t id = ids[r];
+            if (id != cur) { atomicAdd(&dlut[(size_t)cur * d + k], scale * s); cur = id; s = 0.f; }
+            s += dx[(size_t)r * d + k];
+        }
+        atomicAdd(&dlut[(size_t)cur * d + k], scale * s);
+    }
 }
 
 // embedding forward for teacher-forced rows: x[r] = (tok ? lut_tok[tok[r]] * sqrt(d) : 0) (+ syn likewise) + pe[r % L]
@@ -232,21 +243,17 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 }
 
 // y[m][n] = bf16(x[m][n]) for n < N, 0 for N <= n < ldy
-__global__ void cast_pad_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N) {
+// relu_y (may be NULL): the forward output of a ReLU layer; elements where it is <= 0 pass no gradient (x is then dy)
+__global__ void cast_pad_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
+                                const float* __restrict__ relu_y, uint32_t drop_thresh, float drop_scale, uint64_t drop_seed) {
     const size_t total = (size_t)M * ldy;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i / ldy; const int n = (int)(i - m * ldy);
-        ElemOps<bf16_t>::store(y + i, n < N ? x[m * ldx + n] : 0.f);
+        float v = n < N ? x[m * ldx + n] : 0.f;
+        if (relu_y && n < N && !(relu_y[m * ldx + n] > 0.f)) v = 0.f;
+        if (drop_thresh && n < N) v = drop_hash(drop_seed, m * N + n) >= drop_thresh ? v * drop_scale : 0.f;
+        ElemOps<bf16_t>::store(y + i, v);
     }
-}
-
-// counter-based dropout mask: keep element i of stream `seed` iff hash(seed, i) >= p * 2^32.  The backward pass
-// regenerates the mask from (seed, i), so no mask is stored.
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t i) {
-    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (uint32_t)((z ^ (z >> 31)) >> 32);
 }
 
 // y = (residual ? residual : 0) + keep(x) / (1 - p)
@@ -330,31 +337,37 @@ extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dty
 
 // the same cast with the column sums of x (the bias gradient) taken on the way: one thread per column, 32 rows per block
 __global__ __launch_bounds__(256) void cast_pad_colsum_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
-                                                              float* colsum) {
+                                                              float* colsum, const float* __restrict__ relu_y, uint32_t drop_thresh,
+                                                              float drop_scale, uint64_t drop_seed) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= ldy) return;
     const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
     float s = 0.f;
     for (int m = m0; m < m1; ++m) {
-        const float v = n < N ? x[(size_t)m * ldx + n] : 0.f;
+        float v = n < N ? x[(size_t)m * ldx + n] : 0.f;
+        if (relu_y && n < N && !(relu_y[(size_t)m * ldx + n] > 0.f)) v = 0.f;
+        if (drop_thresh && n < N) v = drop_hash(drop_seed, (uint64_t)m * N + n) >= drop_thresh ? v * drop_scale : 0.f;
         ElemOps<bf16_t>::store(y + (size_t)m * ldy + n, v);
         s += v;
     }
     if (n < N) atomicAdd(&colsum[n], s);
 }
 
-extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, void* stream) {
-    if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N) return BOFI_ERR_ARG;
+extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, const float* relu_y, float drop_p,
+                              uint64_t drop_seed, void* stream) {
+    if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (M == 0) return BOFI_OK;
+    const uint32_t drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    const float drop_scale = 1.0f / (1.0f - drop_p);
     if (colsum) {
         hipLaunchKernelGGL(cast_pad_colsum_kernel, dim3((ldy + 255) / 256, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y,
-                           ldy, M, N, colsum);
+                           ldy, M, N, colsum, relu_y, drop_thresh, drop_scale, drop_seed);
         BOFI_CHECK_LAUNCH();
         return BOFI_OK;
     }
     const size_t total = (size_t)M * ldy;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N, relu_y, drop_thresh, drop_scale, drop_seed);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -423,7 +436,7 @@ extern "C" int bofi_colsum_add(const float* x, float* out, int M, int N, void* s
 extern "C" int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream) {
     if (!dx || !ids || !dlut || rows < 0 || d <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, (hipStream_t)stream, dx, ids, dlut, rows, d, scale);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 31) / 32), dim3(128), 0, (hipStream_t)stream, dx, ids, dlut, rows, d, scale);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -57,8 +57,14 @@ _COMPUTE = {"dtype": torch.float32}
 _STEP_CACHE: dict = {}
 
 
-def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0):
+def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0, drop=None):
     code = hip.dtype_code(x)
+    if drop is not None:
+        if row_len is not None:
+            raise hip.BofiHipError("dropout in the epilogue is not combined with row_len")
+        _chk(_lib().bofi_linear_dropout(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
+                                        hip.ptr(y), F32, N, M, N, K, relu, drop[0], drop[1], hip.stream_ptr()), "bofi_linear_dropout")
+        return
     _chk(_lib().bofi_linear(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
                             hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, hip.stream_ptr()), "bofi_linear")
 
@@ -67,7 +73,7 @@ def _granule(dt) -> int:
     return 32 if dt == torch.float32 else 64
 
 
-def _operand(x, M, N, dt, cache=True, colsum=None):
+def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     """[M, N] float32 -> GEMM operand [M, pad(N)] in the compute dtype (zero padded to the kernel's K granule);
     with ``colsum`` (bf16 only) the column sums of x are added into it on the way."""
     g = _granule(dt)
@@ -83,7 +89,8 @@ def _operand(x, M, N, dt, cache=True, colsum=None):
         y[:, :N] = x
     else:
         y = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
-        _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.ptr(colsum), hip.stream_ptr()), "bofi_cast_bf16")
+        _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.ptr(colsum), hip.ptr(relu_y),
+                                   drop[0] if drop else 0.0, drop[1] if drop else 0, hip.stream_ptr()), "bofi_cast_bf16")
     if cache and colsum is None:
         _STEP_CACHE[key] = (x, y)
     return y, Np
@@ -117,7 +124,7 @@ class LinearFn(Function):
     then adds in its epilogue (residual = output = gw) and autograd sees no gradient for w / b at all."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb):
+    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb, drop):
         x, w = _need(x, "linear x"), _need(w, "linear w")
         M, K = x.shape
         N = w.shape[0]
@@ -128,12 +135,14 @@ class LinearFn(Function):
             raise hip.BofiHipError("row_len is only used with relu (att_embed)")
         if gw is not None and (gw.shape != w.shape or not gw.is_contiguous()):
             raise hip.BofiHipError("weight gradient buffer must match the weight")
+        if drop is not None and dt != torch.bfloat16:
+            raise hip.BofiHipError("dropout in the GEMM epilogue is the bf16 path; float32 composes DropoutFn")
         y = _empty(x, M, N)
         if M:
             xo, Kp = _operand(x, M, K, dt)
             wo, _ = _operand(w, N, K, dt)
-            _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg)
-        ctx.relu, ctx.dt = bool(relu), dt
+            _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg, drop)
+        ctx.relu, ctx.dt, ctx.drop = bool(relu), dt, drop
         ctx.has_b, ctx.has_r = b is not None, residual is not None
         ctx.gw, ctx.gb = gw, gb
         ctx.save_for_backward(x, w, y if relu else None)
@@ -148,11 +157,11 @@ class LinearFn(Function):
         dy = _need(dy, "linear dy")
         L, st = _lib(), hip.stream_ptr()
         dz = dy
-        if ctx.relu:                                   # zeroed rows (row_len) have y == 0 and drop out here too
+        if ctx.relu and dt != torch.bfloat16:          # zeroed rows (row_len) have y == 0 and drop out here too
             dz = torch.empty_like(dy)
             _chk(L.bofi_relu_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dz), dy.numel(), st), "bofi_relu_bwd")
         dx = dw = db = None
-        tail = (dy if ctx.has_r else None, None, None, None, None, None)
+        tail = (dy if ctx.has_r else None, None, None, None, None, None, None)
         if M == 0:
             return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(w) if ctx.needs_input_grad[1] and ctx.gw is None else None,
@@ -165,7 +174,8 @@ class LinearFn(Function):
         if dt == torch.bfloat16:
             # one bf16 copy of dz serves both products (its column sums = the bias gradient, taken during the cast);
             # dW = dz^T x runs on the transposing-read GEMM straight from the row-major operands
-            dzo, Np = _operand(dz, M, N, dt, cache=False, colsum=bsum)
+            # ReLU and dropout masks are applied inside the cast (a dropped ReLU unit has y == 0: the ReLU test covers it)
+            dzo, Np = _operand(dy, M, N, dt, cache=False, colsum=bsum, relu_y=y if ctx.relu else None, drop=ctx.drop)
             if ctx.needs_input_grad[0]:
                 wt, _ = _transposed(w, N, K, dt)       # [K, Np], once per weight per step
                 dx = _empty(x, M, K)
@@ -195,8 +205,9 @@ class LinearFn(Function):
         return (dx, dw, db) + tail
 
 
-def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None):
-    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb)
+def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None, drop=None):
+    """``drop``: (p, seed) -> y = residual + dropout(act(x w^T + b)) with the mask made in the GEMM epilogue (bf16 path)."""
+    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb, drop)
 
 
 class LayerNormFn(Function):
@@ -419,9 +430,9 @@ class Params:
         return self._packed[key]
 
     # ---- the model's recurring nodes
-    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0):
+    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0, drop=None):
         w, b = wname + ".weight", wname + ".bias"
-        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b))
+        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b), drop)
 
     def lin_packed(self, x, prefix, idx):
         (w, gw), (b, gb) = self.packed(prefix, idx, "weight"), self.packed(prefix, idx, "bias")
@@ -436,12 +447,15 @@ def _sublayer_linear(P, drop, x_in, wname, residual):
     """residual + dropout(x_in w^T + b): the residual rides in the GEMM epilogue when dropout is off."""
     if not drop.on or drop.p <= 0.0:
         return P.lin(x_in, wname, residual=residual)
+    if _COMPUTE["dtype"] == torch.bfloat16:
+        return P.lin(x_in, wname, residual=residual, drop=(drop.p, drop._next()))
     return drop(P.lin(x_in, wname), residual)
 
 
 def _ffn(P, pre, drop, n, x):
-    h = P.lin(n, pre + ".w_1", relu=True)
-    if drop.on and drop.p > 0.0:
+    fused = drop.on and drop.p > 0.0 and _COMPUTE["dtype"] == torch.bfloat16
+    h = P.lin(n, pre + ".w_1", relu=True, drop=(drop.p, drop._next()) if fused else None)
+    if drop.on and drop.p > 0.0 and not fused:
         h = drop(h)
     return _sublayer_linear(P, drop, h, pre + ".w_2", x)
 

@@ -375,3 +375,35 @@ def test_gemm_tn_accumulates_a_transposed_times_b(M, NI, NJ):
     with pytest.raises(hip.BofiHipError):
         hip.check(hip.lib().bofi_gemm_tn_acc(hip.ptr(ab), ab.shape[1], 7, hip.ptr(bb), bb.shape[1], bb.shape[1], hip.ptr(c), NJ, M, NI, NJ,
                                              hip.stream_ptr()))
+
+
+@pytest.mark.parametrize("relu,res", [(False, True), (True, False)])
+def test_linear_with_epilogue_dropout_bf16(relu, res):
+    """Dropout made in the GEMM epilogue (forward) and in the dz cast (backward) = the separate dropout kernel's mask."""
+    from boficap_amd import xe
+    M, N, K, p, seed = 70, 128, 64, 0.25, 987654321
+    g = torch.Generator().manual_seed(1)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    dy = torch.randn(M, N, generator=g)
+    mask = xe.DropoutFn.apply(torch.ones(M, N, device="cuda"), None, p, seed).cpu()        # keep / (1 - p)
+    assert 0.6 < float((mask > 0).float().mean()) < 0.9
+    bf = lambda t: t.to(torch.bfloat16).float()
+    xr, wr, br = bf(x).requires_grad_(), bf(w).requires_grad_(), b.clone().requires_grad_()
+    z = torch.nn.functional.linear(xr, wr, br)
+    z = torch.relu(z) if relu else z
+    y_ref = z * mask + (r if res else 0)
+    y_ref.backward(dy)
+    xe._COMPUTE["dtype"] = torch.bfloat16
+    xe._STEP_CACHE.clear()
+    try:
+        xd, wd, bd = x.clone().cuda().requires_grad_(), w.clone().cuda().requires_grad_(), b.clone().cuda().requires_grad_()
+        y = xe.linear(xd, wd, bd, residual=r.cuda() if res else None, relu=relu, drop=(p, seed))
+        y.backward(dy.cuda())
+    finally:
+        xe._COMPUTE["dtype"] = torch.float32
+        xe._STEP_CACHE.clear()
+    assert _maxdiff(y, y_ref) < 2e-3
+    assert torch.equal((y.cpu() - (r if res else 0)) == 0, (mask == 0) | (z.detach() * mask == 0))
+    rel = lambda a, ref: _maxdiff(a, ref) / float(ref.abs().max())               # dz is rounded to bf16 for the two products
+    assert rel(xd.grad, xr.grad) < 1e-2 and rel(wd.grad, wr.grad) < 1e-2 and rel(bd.grad, br.grad) < 1e-4
