@@ -407,3 +407,27 @@ def test_linear_with_epilogue_dropout_bf16(relu, res):
     assert torch.equal((y.cpu() - (r if res else 0)) == 0, (mask == 0) | (z.detach() * mask == 0))
     rel = lambda a, ref: _maxdiff(a, ref) / float(ref.abs().max())               # dz is rounded to bf16 for the two products
     assert rel(xd.grad, xr.grad) < 1e-2 and rel(wd.grad, wr.grad) < 1e-2 and rel(bd.grad, br.grad) < 1e-4
+
+
+def test_tools_train_entry_point_writes_reference_checkpoints(tmp_path):
+    """python tools/train.py (XE phase, synthetic batches): runs, logs a finite loss, writes model.pth with the
+    reference's state_dict schema (311 entries at full size) and optimizer.pth; a second run resumes from them."""
+    from boficap_amd.config import TINY
+    from boficap_amd.weights import schema
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = str(tmp_path / "ck")
+    cmd = [sys.executable, os.path.join(root, "tools", "train.py"), "--tiny", "--max_iters", "3", "--batch_size", "2", "--seq_per_img", "3",
+           "--losses_log_every", "1", "--checkpoint_path", ck, "--glancing_token", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "iter 3" in out.stdout and "nan" not in out.stdout.lower()
+    sd = torch.load(os.path.join(ck, "model.pth"))
+    assert list(sd.keys()) == list(schema(TINY).keys())
+    osd = torch.load(os.path.join(ck, "optimizer.pth"))
+    assert osd["_step"] == 3
+    out = subprocess.run(cmd + ["--start_from", ck, "--dtype", "f32"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "iter 6" in out.stdout
