@@ -1,0 +1,224 @@
+// Attention backward on the matrix cores (bf16 operands, fp32 accumulation) for the sequence lengths of this model
+// (Lq, Lk <= 64, head dim 64).  One wavefront per (caption, head); everything it needs lives in LDS as bf16:
+//
+//   S  = Q K^T / 8, dP = dO V^T                     operands read row-wise (contraction along the head dim)
+//   P  = softmax(S | key < klen), dS = P (dP - rowsum(P dP)) / 8        in registers, rows reduced over 16-lane groups
+//   dQ = dS K                                       A = dS rows (two 8-byte reads in the transposed-read k order),
+//                                                   B = K gathered with the transposing LDS read (ds_read_b64_tr_b16)
+//   dK = dS^T Q,  dV = P^T dO                       both operands gathered with the transposing read
+//
+// so no transposed copy of anything is ever written.  q, k, v may be float32 (rounded to bf16 on the way into LDS) or
+// bf16; dO, dQ, dK, dV are float32.  Captions of one image share its keys (kdiv): dK / dV then accumulate with atomics.
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct AttnBwdMfmaParams {
+    const void* q; int ldq; const void* k; int ldk; const void* v; int ldv;
+    const float* dout; int ldo;
+    float* dq; int lddq; float* dk; float* dv; int lddk;
+    int B, H, Lq, Lk, kdiv;
+    const int* klen; int klen_sb, klen_sq, klen_bias;
+};
+
+template <typename TIN>
+__device__ __forceinline__ void stage_rows(const TIN* __restrict__ src, int ld, int rows_real, int rows_pad, bf16_t* dst, int stride, int lane) {
+    for (int i = lane; i < rows_pad * 8; i += 64) {
+        const int r = i >> 3, c = (i & 7) * 8;
+        u32x4 o = u32x4{0u, 0u, 0u, 0u};
+        if (r < rows_real) {
+            if constexpr (sizeof(TIN) == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+                const float4 b = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c + 4);
+                o[0] = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+                o[1] = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+                o[2] = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+                o[3] = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+            } else {
+                o = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c);
+            }
+        }
+        *reinterpret_cast<u32x4*>(dst + r * stride + c) = o;
+    }
+}
+
+// MFMA operand gathered from a row-major LDS tile whose ROWS are the contraction index: rows row_base .. row_base + 31,
+// operand index (A row / B column) = col_base + (lane & 15)
+__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* tile, int stride, int row_base, int col_base, int g, int tq, int tp) {
+    const bf16_t* p0 = tile + (row_base + 4 * g + tq) * stride + col_base + 4 * tp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * stride));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// the matching operand when the contraction index runs along the COLUMNS of the tile: same k order as frag_tr
+// (lane group g holds k = 4g..4g+3 and 16+4g..16+4g+3 of the 32-wide step)
+__device__ __forceinline__ bf16x8 frag_row_trorder(const bf16_t* tile, int stride, int row, int col_base, int g) {
+    const s16x4 lo = *reinterpret_cast<const s16x4*>(tile + row * stride + col_base + 4 * g);
+    const s16x4 hi = *reinterpret_cast<const s16x4*>(tile + row * stride + col_base + 16 + 4 * g);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+template <typename TIN, int QT, int KT>
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) {
+    constexpr int DS = 72, PS = KT * 16 + 8;                     // padded strides (elements)
+    constexpr int LQ = QT * 16, LK = KT * 16;
+    __shared__ __attribute__((aligned(16))) bf16_t sq[LQ * DS], sdo[LQ * DS], sk[LK * DS], sv[LK * DS], sp[LQ * PS], sds[LQ * PS];
+    const int lane = threadIdx.x, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, bk = b / p.kdiv;
+    const int Lq = p.Lq, Lk = p.Lk;
+
+    stage_rows<TIN>(static_cast<const TIN*>(p.q) + (size_t)b * Lq * p.ldq + h * 64, p.ldq, Lq, LQ, sq, DS, lane);
+    stage_rows<float>(p.dout + (size_t)b * Lq * p.ldo + h * 64, p.ldo, Lq, LQ, sdo, DS, lane);
+    stage_rows<TIN>(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, LK, sk, DS, lane);
+    stage_rows<TIN>(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, LK, sv, DS, lane);
+    __syncthreads();
+
+    // ---- S = Q K^T, dP = dO V^T  (lane holds rows q = qt*16 + 4g + r, column k = kt*16 + l15)
+    f32x4 S[QT][KT], dP[QT][KT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        bf16x8 aq[2], ao[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            aq[s] = *reinterpret_cast<const bf16x8*>(&sq[(qt * 16 + l15) * DS + s * 32 + g * 8]);
+            ao[s] = *reinterpret_cast<const bf16x8*>(&sdo[(qt * 16 + l15) * DS + s * 32 + g * 8]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 bkf = *reinterpret_cast<const bf16x8*>(&sk[(kt * 16 + l15) * DS + s * 32 + g * 8]);
+                const bf16x8 bvf = *reinterpret_cast<const bf16x8*>(&sv[(kt * 16 + l15) * DS + s * 32 + g * 8]);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[s], bkf, a, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[s], bvf, d, 0, 0, 0);
+            }
+            S[qt][kt] = a;
+            dP[qt][kt] = d;
+        }
+    }
+
+    // ---- softmax rows and dS; P and dS go to LDS as bf16 [q][k]
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = qt * 16 + 4 * g + r;
+            int kl = 0;
+            if (qrow < Lq) {
+                kl = Lk;
+                if (p.klen) { kl = p.klen[b * p.klen_sb + qrow * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                if (kt * 16 + l15 < kl) m = fmaxf(m, S[qt][kt][r] * 0.125f);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            float e[KT], sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                e[kt] = (kt * 16 + l15 < kl) ? expf(S[qt][kt][r] * 0.125f - m) : 0.f;
+                sum += e[kt];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = sum > 0.f ? 1.f / sum : 0.f;
+            float dot = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) { e[kt] *= inv; dot += e[kt] * dP[qt][kt][r]; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                sp[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt]);
+                sds[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * (dP[qt][kt][r] - dot) * 0.125f);
+            }
+        }
+    __syncthreads();
+
+    // ---- dQ = dS K
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KT / 2; ++s) {
+            const bf16x8 a = frag_row_trorder(sds, PS, qt * 16 + l15, s * 32, g);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sk, DS, s * 32, dt * 16, g, tq, tp), acc[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = qt * 16 + 4 * g + r;
+                if (qrow < Lq) p.dq[((size_t)b * Lq + qrow) * p.lddq + h * 64 + dt * 16 + l15] = acc[dt][r];
+            }
+    }
+    // ---- dK = dS^T Q, dV = P^T dO
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        f32x4 ak[4], av[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; av[dt] = ak[dt]; }
+#pragma unroll
+        for (int s = 0; s < QT / 2; ++s) {
+            const bf16x8 a_ds = frag_tr(sds, PS, s * 32, kt * 16, g, tq, tp);
+            const bf16x8 a_p = frag_tr(sp, PS, s * 32, kt * 16, g, tq, tp);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ds, frag_tr(sq, DS, s * 32, dt * 16, g, tq, tp), ak[dt], 0, 0, 0);
+                av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_p, frag_tr(sdo, DS, s * 32, dt * 16, g, tq, tp), av[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int krow = kt * 16 + 4 * g + r;
+                if (krow >= Lk) continue;
+                const size_t o = ((size_t)bk * Lk + krow) * p.lddk + h * 64 + dt * 16 + l15;
+                if (p.kdiv > 1) { atomicAdd(p.dk + o, ak[dt][r]); atomicAdd(p.dv + o, av[dt][r]); }
+                else { p.dk[o] = ak[dt][r]; p.dv[o] = av[dt][r]; }
+            }
+    }
+}
+
+template <typename TIN>
+static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
+    const dim3 grid(p.B * p.H), block(64);
+    if (p.Lq <= 32 && p.Lk <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 2>), grid, block, 0, st, p);
+    else if (p.Lq <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 4, 4>), grid, block, 0, st, p);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+}  // namespace bofi
+
+extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
+                                       const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H, int Lq,
+                                       int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, void* stream) {
+    using namespace bofi;
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0) return BOFI_ERR_ARG;
+    if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
+    const int el = in_dtype == BOFI_DT_F32 ? 4 : 2;
+    if ((ldq * el) % 16 || (ldk * el) % 16 || (ldv * el) % 16 || ldo % 4 || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16) ||
+        ((uintptr_t)dout % 16))
+        return BOFI_ERR_ARG;
+    if (B == 0) return BOFI_OK;
+    AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias};
+    return in_dtype == BOFI_DT_F32 ? launch_t<float>(p, (hipStream_t)stream) : launch_t<bf16_t>(p, (hipStream_t)stream);
+}

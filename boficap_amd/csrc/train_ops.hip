@@ -242,18 +242,60 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     }
 }
 
-// y[m][n] = bf16(x[m][n]) for n < N, 0 for N <= n < ldy
-// relu_y (may be NULL): the forward output of a ReLU layer; elements where it is <= 0 pass no gradient (x is then dy)
-__global__ void cast_pad_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
-                                const float* __restrict__ relu_y, uint32_t drop_thresh, float drop_scale, uint64_t drop_seed) {
-    const size_t total = (size_t)M * ldy;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t m = i / ldy; const int n = (int)(i - m * ldy);
-        float v = n < N ? x[m * ldx + n] : 0.f;
-        if (relu_y && n < N && !(relu_y[m * ldx + n] > 0.f)) v = 0.f;
-        if (drop_thresh && n < N) v = drop_hash(drop_seed, m * N + n) >= drop_thresh ? v * drop_scale : 0.f;
-        ElemOps<bf16_t>::store(y + i, v);
+// y[m][n] = bf16(x'[m][n]) for n < N, 0 for N <= n < ldy, where x' = x with the optional ReLU mask (relu_y: forward output of a
+// ReLU layer; x is then dy and passes only where relu_y > 0) and the optional dropout mask of bofi_linear_dropout applied;
+// colsum (may be NULL): colsum[n] += sum_m x'[m][n], the bias gradient when x is dz.
+// Workgroup = 64 column quads x 4 row lanes over a 256-column x 32-row tile: float4 loads, 8-byte bf16 stores, the four
+// row lanes combine their column sums through LDS and the workgroup issues one atomic per column.
+template <bool VEC>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
+                                                       float* colsum, const float* __restrict__ relu_y, uint32_t drop_thresh,
+                                                       float drop_scale, uint64_t drop_seed) {
+    __shared__ float red[4][256];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + cq * 4;
+    const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < ldy) {
+        for (int m = m0 + rl; m < m1; m += 4) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (VEC && n + 3 < N) {
+                const float4 t = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + n);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                if (relu_y) {
+                    const float4 r = *reinterpret_cast<const float4*>(relu_y + (size_t)m * ldx + n);
+                    if (!(r.x > 0.f)) v[0] = 0.f;
+                    if (!(r.y > 0.f)) v[1] = 0.f;
+                    if (!(r.z > 0.f)) v[2] = 0.f;
+                    if (!(r.w > 0.f)) v[3] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (n + c < N) {
+                        v[c] = x[(size_t)m * ldx + n + c];
+                        if (relu_y && !(relu_y[(size_t)m * ldx + n + c] > 0.f)) v[c] = 0.f;
+                    }
+            }
+            if (drop_thresh) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (n + c < N) v[c] = drop_hash(drop_seed, (uint64_t)m * N + n + c) >= drop_thresh ? v[c] * drop_scale : 0.f;
+            }
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = o;          // ldy % 4 == 0 and n % 4 == 0
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += v[c];
+        }
     }
+    if (!colsum) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rl][cq * 4 + c] = s[c];
+    __syncthreads();
+    const int nn = blockIdx.x * 256 + threadIdx.x;
+    if (nn < N) atomicAdd(&colsum[nn], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // y = (residual ? residual : 0) + keep(x) / (1 - p)
@@ -335,39 +377,18 @@ extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dty
     return BOFI_OK;
 }
 
-// the same cast with the column sums of x (the bias gradient) taken on the way: one thread per column, 32 rows per block
-__global__ __launch_bounds__(256) void cast_pad_colsum_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
-                                                              float* colsum, const float* __restrict__ relu_y, uint32_t drop_thresh,
-                                                              float drop_scale, uint64_t drop_seed) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= ldy) return;
-    const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
-    float s = 0.f;
-    for (int m = m0; m < m1; ++m) {
-        float v = n < N ? x[(size_t)m * ldx + n] : 0.f;
-        if (relu_y && n < N && !(relu_y[(size_t)m * ldx + n] > 0.f)) v = 0.f;
-        if (drop_thresh && n < N) v = drop_hash(drop_seed, (uint64_t)m * N + n) >= drop_thresh ? v * drop_scale : 0.f;
-        ElemOps<bf16_t>::store(y + (size_t)m * ldy + n, v);
-        s += v;
-    }
-    if (n < N) atomicAdd(&colsum[n], s);
-}
-
 extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, const float* relu_y, float drop_p,
                               uint64_t drop_seed, void* stream) {
-    if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
+    if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N || ldy % 4 || ((uintptr_t)y % 8) || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (M == 0) return BOFI_OK;
     const uint32_t drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
     const float drop_scale = 1.0f / (1.0f - drop_p);
-    if (colsum) {
-        hipLaunchKernelGGL(cast_pad_colsum_kernel, dim3((ldy + 255) / 256, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y,
-                           ldy, M, N, colsum, relu_y, drop_thresh, drop_scale, drop_seed);
-        BOFI_CHECK_LAUNCH();
-        return BOFI_OK;
-    }
-    const size_t total = (size_t)M * ldy;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(cast_pad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N, relu_y, drop_thresh, drop_scale, drop_seed);
+    const dim3 grid((ldy + 255) / 256, (M + 31) / 32);
+    const bool vec = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0) && (!relu_y || (uintptr_t)relu_y % 16 == 0);
+    if (vec) hipLaunchKernelGGL((cast_pad_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N, colsum, relu_y,
+                                drop_thresh, drop_scale, drop_seed);
+    else hipLaunchKernelGGL((cast_pad_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N, colsum, relu_y,
+                            drop_thresh, drop_scale, drop_seed);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -395,7 +416,7 @@ extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float
                                   int d, void* stream) {
     if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    const int rpb = rows >= 16384 ? 64 : 32;
+    const int rpb = rows >= 32768 ? 32 : (rows >= 8192 ? 16 : 8);        // >= 1 row per wavefront pass, >= ~800 workgroups at 6400 rows
     if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
     else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d);

@@ -263,6 +263,7 @@ class AttentionFn(Function):
         _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
                                       Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
         ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
+        ctx.mfma = _COMPUTE["dtype"] == torch.bfloat16       # bf16 mode: backward on the matrix cores
         ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
         ctx.klen = klen
         ctx.save_for_backward(qbuf, kvbuf)
@@ -276,6 +277,11 @@ class AttentionFn(Function):
         dq = torch.zeros_like(qbuf)
         dkv = dq if ctx.same else torch.zeros_like(kvbuf)
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
+        if ctx.mfma:
+            _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, F32, hip.ptr(dout), H * 64,
+                                                _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen),
+                                                sb, sq, bias, hip.stream_ptr()), "bofi_attention_bwd_mfma")
+            return (dq, None if ctx.same else dkv) + (None,) * 12
         _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
                                        _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,
                                        hip.stream_ptr()), "bofi_attention_bwd")
