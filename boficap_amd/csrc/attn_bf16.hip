@@ -26,6 +26,7 @@ struct AttnParamsB {
     int B, H, Lq, Lk;
     const int* klen; int klen_sb, klen_sq, klen_bias, klen_shared_last;
     const int* skip_if_ge; int skip_threshold;
+    int kdiv;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -48,8 +49,9 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
 
     // ---- stage Q, K, V head slices (16-byte chunks; rows past the data are zero)
     const bf16_t* qg = p.q + ((size_t)b * p.Lq + q0) * p.ldq + h * 64;
-    const bf16_t* kg = p.k + (size_t)b * Lk * p.ldk + h * 64;
-    const bf16_t* vg = p.v + (size_t)b * Lk * p.ldv + h * 64;
+    const int bk = b / p.kdiv;                      // captions of one image share its keys (training)
+    const bf16_t* kg = p.k + (size_t)bk * Lk * p.ldk + h * 64;
+    const bf16_t* vg = p.v + (size_t)bk * Lk * p.ldv + h * 64;
     const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int c = lane; c < NQT * 16 * 8; c += 64) {
@@ -181,12 +183,13 @@ static void launch_ab(const AttnParamsB& p, hipStream_t st) {
 
 // returns -1 when the call is not eligible (then attn.hip handles it)
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
-    if (a.dtype != BOFI_DT_BF16 || a.kdiv > 1 || a.Lk > 64 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
+    if (a.dtype != BOFI_DT_BF16 || a.Lk > 64 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
     AttnParamsB p;
     p.q = (const bf16_t*)a.q; p.ldq = a.ldq; p.k = (const bf16_t*)a.k; p.ldk = a.ldk; p.v = (const bf16_t*)a.v; p.ldv = a.ldv;
     p.out = (bf16_t*)a.out; p.ldo = a.ldo; p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;
     p.klen = a.klen; p.klen_sb = a.klen_sb; p.klen_sq = a.klen_sq; p.klen_bias = a.klen_bias;
     p.klen_shared_last = a.klen_shared_last; p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
+    p.kdiv = a.kdiv > 0 ? a.kdiv : 1;
     const int nkt = a.Lk <= 32 ? 2 : 4;
     const int nqt = a.Lq <= 16 ? 1 : (a.Lq <= 32 ? 2 : 3);
     switch (nqt * 10 + nkt) {

@@ -24,24 +24,47 @@ struct AttnBwdMfmaParams {
     const int* klen; int klen_sb, klen_sq, klen_bias;
 };
 
-template <typename TIN>
-__device__ __forceinline__ void stage_rows(const TIN* __restrict__ src, int ld, int rows_real, int rows_pad, bf16_t* dst, int stride, int lane) {
-    for (int i = lane; i < rows_pad * 8; i += 64) {
-        const int r = i >> 3, c = (i & 7) * 8;
-        u32x4 o = u32x4{0u, 0u, 0u, 0u};
-        if (r < rows_real) {
-            if constexpr (sizeof(TIN) == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
-                const float4 b = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c + 4);
-                o[0] = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-                o[1] = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-                o[2] = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-                o[3] = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
-            } else {
-                o = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c);
+// Head slice [rows_real, 64] -> LDS as bf16, rows past the data zero.  All global loads of the slice are issued before the
+// first conversion / LDS store (ROWS is a compile-time constant, the loops unroll): one memory round trip per operand
+// instead of one per 8 rows.
+template <typename TIN, int ROWS>
+__device__ __forceinline__ void stage_rows(const TIN* __restrict__ src, int ld, int rows_real, bf16_t* dst, int stride, int lane) {
+    constexpr int IT = ROWS * 8 / 64;
+    if constexpr (sizeof(TIN) == 4) {
+        float4 a[IT], b[IT];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
+            a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b[t] = a[t];
+            if (r < rows_real) {
+                a[t] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+                b[t] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c + 4);
             }
         }
-        *reinterpret_cast<u32x4*>(dst + r * stride + c) = o;
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
+            u32x4 o;
+            o[0] = (uint32_t)f32_to_bf16(a[t].x) | ((uint32_t)f32_to_bf16(a[t].y) << 16);
+            o[1] = (uint32_t)f32_to_bf16(a[t].z) | ((uint32_t)f32_to_bf16(a[t].w) << 16);
+            o[2] = (uint32_t)f32_to_bf16(b[t].x) | ((uint32_t)f32_to_bf16(b[t].y) << 16);
+            o[3] = (uint32_t)f32_to_bf16(b[t].z) | ((uint32_t)f32_to_bf16(b[t].w) << 16);
+            *reinterpret_cast<u32x4*>(dst + r * stride + c) = o;
+        }
+    } else {
+        u32x4 v[IT];
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
+            v[t] = u32x4{0u, 0u, 0u, 0u};
+            if (r < rows_real) v[t] = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c);
+        }
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
+            *reinterpret_cast<u32x4*>(dst + r * stride + c) = v[t];
+        }
     }
 }
 
@@ -77,10 +100,10 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, bk = b / p.kdiv;
     const int Lq = p.Lq, Lk = p.Lk;
 
-    stage_rows<TIN>(static_cast<const TIN*>(p.q) + (size_t)b * Lq * p.ldq + h * 64, p.ldq, Lq, LQ, sq, DS, lane);
-    stage_rows<float>(p.dout + (size_t)b * Lq * p.ldo + h * 64, p.ldo, Lq, LQ, sdo, DS, lane);
-    stage_rows<TIN>(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, LK, sk, DS, lane);
-    stage_rows<TIN>(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, LK, sv, DS, lane);
+    stage_rows<TIN, LQ>(static_cast<const TIN*>(p.q) + (size_t)b * Lq * p.ldq + h * 64, p.ldq, Lq, sq, DS, lane);
+    stage_rows<float, LQ>(p.dout + (size_t)b * Lq * p.ldo + h * 64, p.ldo, Lq, sdo, DS, lane);
+    stage_rows<TIN, LK>(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, sk, DS, lane);
+    stage_rows<TIN, LK>(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, sv, DS, lane);
     __syncthreads();
 
     // ---- S = Q K^T, dP = dO V^T  (lane holds rows q = qt*16 + 4g + r, column k = kt*16 + l15)

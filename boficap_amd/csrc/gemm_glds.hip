@@ -392,7 +392,7 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
     p.splitk = a.splitk > 1 ? a.splitk : 1;
     p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed;
-    if (p.drop_thresh && (a.splitk > 1 || a.stats_out || a.y2)) return BOFI_ERR_ARG;
+    if (p.drop_thresh && (a.splitk > 1 || a.stats_out)) return BOFI_ERR_ARG;
     if (p.splitk > 1 && (a.y_dtype != BOFI_DT_F32 || a.relu || a.ln_stats || a.stats_out || a.y2 || a.row_len || (a.K / p.splitk) % bk || a.K % p.splitk))
         return BOFI_ERR_ARG;
     { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }

@@ -56,14 +56,39 @@ _COMPUTE = {"dtype": torch.float32}
 # K/V projection are cast / transposed once per step instead of once per use.  Cleared by forward_uic.
 _STEP_CACHE: dict = {}
 
+# bf16 mode keeps activations that only ever feed a GEMM / attention kernel as bf16 "shadows" made by their producer
+# (GEMM second output, LayerNorm / attention writing bf16 directly).  The float32 tensor autograd sees is then either
+# written as well (GEMM outputs) or a PLACEHOLDER whose storage is never filled (LayerNorm / attention outputs); the
+# data pointers of placeholders are listed here and every kernel wrapper that reads float32 input refuses them.
+_SHADOW_ONLY: set = set()
 
-def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0, drop=None):
+
+def _register_shadow(t, shadow, only=False):
+    M, N = t.shape
+    _STEP_CACHE[("op", t.data_ptr(), M, N, torch.bfloat16)] = (t, shadow)
+    if only:
+        _SHADOW_ONLY.add(t.data_ptr())
+
+
+def _shadow(t):
+    hit = _STEP_CACHE.get(("op", t.data_ptr(), t.shape[0], t.shape[1], torch.bfloat16)) if t.dim() == 2 else None
+    return hit[1] if hit is not None and hit[0] is t else None
+
+
+def _real(t, what):
+    if t.data_ptr() in _SHADOW_ONLY and _shadow(t) is not None:
+        raise hip.BofiHipError(f"{what}: this float32 tensor is a placeholder for a bf16 activation; only GEMM operands may consume it")
+    return t
+
+
+def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0, drop=None, y2=None):
     code = hip.dtype_code(x)
-    if drop is not None:
-        if row_len is not None:
+    if drop is not None or y2 is not None:
+        if drop is not None and row_len is not None:
             raise hip.BofiHipError("dropout in the epilogue is not combined with row_len")
-        _chk(_lib().bofi_linear_dropout(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
-                                        hip.ptr(y), F32, N, M, N, K, relu, drop[0], drop[1], hip.stream_ptr()), "bofi_linear_dropout")
+        _chk(_lib().bofi_linear_ex(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
+                                   hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, drop[0] if drop else 0.0, drop[1] if drop else 0,
+                                   hip.ptr(y2), N, hip.stream_ptr()), "bofi_linear_ex")
         return
     _chk(_lib().bofi_linear(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
                             hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, hip.stream_ptr()), "bofi_linear")
@@ -84,6 +109,8 @@ def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     hit = _STEP_CACHE.get(key) if (cache and colsum is None) else None
     if hit is not None:
         return hit[1], Np
+    if x.data_ptr() in _SHADOW_ONLY:
+        raise hip.BofiHipError("placeholder activation without its bf16 shadow")
     if dt == torch.float32:
         y = _zeros(x, M, Np)
         y[:, :N] = x
@@ -124,7 +151,7 @@ class LinearFn(Function):
     then adds in its epilogue (residual = output = gw) and autograd sees no gradient for w / b at all."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb, drop):
+    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow):
         x, w = _need(x, "linear x"), _need(w, "linear w")
         M, K = x.shape
         N = w.shape[0]
@@ -141,7 +168,12 @@ class LinearFn(Function):
         if M:
             xo, Kp = _operand(x, M, K, dt)
             wo, _ = _operand(w, N, K, dt)
-            _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg, drop)
+            y2 = None
+            if shadow and dt == torch.bfloat16 and N % 64 == 0:      # the consumer is a GEMM / attention kernel: hand it bf16 directly
+                y2 = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+            _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg, drop, y2)
+            if y2 is not None:
+                _register_shadow(y, y2)
         ctx.relu, ctx.dt, ctx.drop = bool(relu), dt, drop
         ctx.has_b, ctx.has_r = b is not None, residual is not None
         ctx.gw, ctx.gb = gw, gb
@@ -161,7 +193,7 @@ class LinearFn(Function):
             dz = torch.empty_like(dy)
             _chk(L.bofi_relu_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dz), dy.numel(), st), "bofi_relu_bwd")
         dx = dw = db = None
-        tail = (dy if ctx.has_r else None, None, None, None, None, None, None)
+        tail = (dy if ctx.has_r else None, None, None, None, None, None, None, None)
         if M == 0:
             return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(w) if ctx.needs_input_grad[1] and ctx.gw is None else None,
@@ -205,9 +237,10 @@ class LinearFn(Function):
         return (dx, dw, db) + tail
 
 
-def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None, drop=None):
-    """``drop``: (p, seed) -> y = residual + dropout(act(x w^T + b)) with the mask made in the GEMM epilogue (bf16 path)."""
-    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb, drop)
+def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None, drop=None, shadow=False):
+    """``drop``: (p, seed) -> y = residual + dropout(act(x w^T + b)) with the mask made in the GEMM epilogue (bf16 path).
+    ``shadow``: the output feeds a GEMM or an attention kernel -> also emit it in bf16 from the epilogue (bf16 path)."""
+    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow)
 
 
 class LayerNormFn(Function):
@@ -215,11 +248,17 @@ class LayerNormFn(Function):
     ``gg`` / ``gb``: gradient buffers of gain / bias to accumulate into (see LinearFn)."""
 
     @staticmethod
-    def forward(ctx, x, gain, bias, gg, gb):
-        x, gain, bias = _need(x, "ln x"), _need(gain, "ln gain"), _need(bias, "ln bias")
+    def forward(ctx, x, gain, bias, gg, gb, gemm_only):
+        x, gain, bias = _real(_need(x, "ln x"), "ln x"), _need(gain, "ln gain"), _need(bias, "ln bias")
         rows, d = x.shape
         y = torch.empty_like(x)
-        _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(y), F32, rows, d, hip.stream_ptr()), "bofi_layernorm")
+        if gemm_only and _COMPUTE["dtype"] == torch.bfloat16 and d % 64 == 0:
+            # every consumer is a GEMM: write the normalised rows as bf16 only; y stays an unfilled placeholder
+            yb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device)
+            _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(yb), hip.DT_BF16, rows, d, hip.stream_ptr()), "bofi_layernorm")
+            _register_shadow(y, yb, only=True)
+        else:
+            _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(y), F32, rows, d, hip.stream_ptr()), "bofi_layernorm")
         ctx.gg, ctx.gb = gg, gb
         ctx.save_for_backward(x, gain)
         return y
@@ -234,15 +273,16 @@ class LayerNormFn(Function):
         dg, db = (ctx.gg, ctx.gb) if direct else (_zeros(x, d), _zeros(x, d))
         _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
                                        hip.stream_ptr()), "bofi_layernorm_bwd")
-        return (dx, None, None, None, None) if direct else (dx, dg, db, None, None)
+        return (dx, None, None, None, None, None) if direct else (dx, dg, db, None, None, None)
 
 
-def layer_norm(x, gain, bias, gg=None, gb=None):
-    return LayerNormFn.apply(x, gain, bias, gg, gb)
+def layer_norm(x, gain, bias, gg=None, gb=None, gemm_only=False):
+    """``gemm_only``: the output is consumed by GEMMs only (bf16 mode then skips the float32 copy)."""
+    return LayerNormFn.apply(x, gain, bias, gg, gb, gemm_only)
 
 
 def _off(t: torch.Tensor, col: int) -> C.c_void_p:
-    return C.c_void_p(t.data_ptr() + 4 * col)
+    return C.c_void_p(t.data_ptr() + t.element_size() * col)
 
 
 class AttentionFn(Function):
@@ -260,27 +300,40 @@ class AttentionFn(Function):
         d = H * 64
         out = _empty(qbuf, B * Lq, d)
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
-        _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
-                                      Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
+        bf16 = _COMPUTE["dtype"] == torch.bfloat16
+        qs, kvs = (_shadow(qbuf), _shadow(kvbuf)) if bf16 else (None, None)
+        ctx.shadows = qs is not None and kvs is not None and Lk <= 64
+        if ctx.shadows:
+            # bf16 projections from the GEMM epilogue in, bf16 context out (the operand of the output projection):
+            # ``out`` stays an unfilled placeholder
+            ob = torch.empty(B * Lq, d, dtype=torch.bfloat16, device=qbuf.device)
+            _chk(_lib().bofi_attention_ex(_off(qs, qoff), ldq, _off(kvs, koff), ldk, _off(kvs, voff), ldk, hip.ptr(ob), d, hip.DT_BF16, B, H,
+                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
+            _register_shadow(out, ob, only=True)
+            ctx.save_for_backward(qs, kvs)
+        else:
+            _real(qbuf, "attention q"), _real(kvbuf, "attention kv")
+            _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
+                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
+            ctx.save_for_backward(qbuf, kvbuf)
         ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
-        ctx.mfma = _COMPUTE["dtype"] == torch.bfloat16       # bf16 mode: backward on the matrix cores
+        ctx.mfma = bf16                                        # bf16 mode: backward on the matrix cores
         ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
         ctx.klen = klen
-        ctx.save_for_backward(qbuf, kvbuf)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qbuf, kvbuf = ctx.saved_tensors
+        qbuf, kvbuf = ctx.saved_tensors                        # float32 buffers, or their bf16 shadows
         qoff, koff, voff, B, H, Lq, Lk, kdiv, sb, sq, bias = ctx.meta
-        dout = _need(dout, "attention dout")
-        dq = torch.zeros_like(qbuf)
-        dkv = dq if ctx.same else torch.zeros_like(kvbuf)
+        dout = _real(_need(dout, "attention dout"), "attention dout")
+        dq = torch.zeros(qbuf.shape, dtype=torch.float32, device=qbuf.device)
+        dkv = dq if ctx.same else torch.zeros(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
         if ctx.mfma:
-            _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, F32, hip.ptr(dout), H * 64,
-                                                _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen),
-                                                sb, sq, bias, hip.stream_ptr()), "bofi_attention_bwd_mfma")
+            _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.dtype_code(qbuf),
+                                                hip.ptr(dout), H * 64, _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk,
+                                                kdiv, hip.ptr(ctx.klen), sb, sq, bias, hip.stream_ptr()), "bofi_attention_bwd_mfma")
             return (dq, None if ctx.same else dkv) + (None,) * 12
         _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
                                        _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,
@@ -371,7 +424,7 @@ class DropoutFn(Function):
 
     @staticmethod
     def forward(ctx, x, residual, p, seed):
-        x = _need(x, "dropout x")
+        x = _real(_need(x, "dropout x"), "dropout x")
         y = torch.empty_like(x)
         _chk(_lib().bofi_dropout(hip.ptr(x), hip.ptr(residual), hip.ptr(y), x.numel(), p, seed, hip.stream_ptr()), "bofi_dropout")
         ctx.p, ctx.seed, ctx.has_r = p, seed, residual is not None
@@ -436,17 +489,18 @@ class Params:
         return self._packed[key]
 
     # ---- the model's recurring nodes
-    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0, drop=None):
+    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0, drop=None, shadow=False):
         w, b = wname + ".weight", wname + ".bias"
-        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b), drop)
+        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b), drop, shadow)
 
     def lin_packed(self, x, prefix, idx):
+        """Fused q|k|v (or k|v) projection; its output feeds an attention kernel."""
         (w, gw), (b, gb) = self.packed(prefix, idx, "weight"), self.packed(prefix, idx, "bias")
-        return linear(x, w, b, gw=gw, gb=gb)
+        return linear(x, w, b, gw=gw, gb=gb, shadow=True)
 
-    def ln(self, x, prefix):
+    def ln(self, x, prefix, gemm_only=True):
         a, b = prefix + ".a_2", prefix + ".b_2"
-        return layer_norm(x, self.t[a], self.t[b], self.g(a), self.g(b))
+        return layer_norm(x, self.t[a], self.t[b], self.g(a), self.g(b), gemm_only)
 
 
 def _sublayer_linear(P, drop, x_in, wname, residual):
@@ -460,7 +514,7 @@ def _sublayer_linear(P, drop, x_in, wname, residual):
 
 def _ffn(P, pre, drop, n, x):
     fused = drop.on and drop.p > 0.0 and _COMPUTE["dtype"] == torch.bfloat16
-    h = P.lin(n, pre + ".w_1", relu=True, drop=(drop.p, drop._next()) if fused else None)
+    h = P.lin(n, pre + ".w_1", relu=True, drop=(drop.p, drop._next()) if fused else None, shadow=True)
     if drop.on and drop.p > 0.0 and not fused:
         h = drop(h)
     return _sublayer_linear(P, drop, h, pre + ".w_2", x)
@@ -488,7 +542,7 @@ def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap
     """x + src_attn(n, memory, memory): the image's keys are shared by its captions (kdiv) and, because they depend
     on the memory and the layer only, by the SA and the NA pass of the same layer (kv_cache)."""
     d = cfg.d_model
-    q = P.lin(n, pre + ".linears.0")
+    q = P.lin(n, pre + ".linears.0", shadow=True)
     if pre not in kv_cache:
         kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
     ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, (1 if att_len_cap is not None else 0), 0, 0)
@@ -519,7 +573,7 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     Pm = klen_pass.shape[1]
     lp = "model.length_predictor"
     p = lp + ".LengthPredictor.0"
-    n_all = P.ln(x_in, p + ".sublayer.0.norm")
+    n_all = P.ln(x_in, p + ".sublayer.0.norm", gemm_only=False)         # row 0 is also read as float32 below
     kv = P.lin_packed(n_all, p + ".self_attn", (1, 2))
     x0 = x_in.view(N, L, d)[:, 0, :]
     n0 = n_all.view(N, L, d)[:, 0, :].contiguous()
@@ -571,6 +625,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
         raise hip.BofiHipError(f"training compute dtype {compute_dtype}: float32 or bfloat16")
     _COMPUTE["dtype"] = compute_dtype
     _STEP_CACHE.clear()
+    _SHADOW_ONLY.clear()
     if labels.dim() == 3:
         labels = labels.reshape(-1, labels.shape[2])
         phrase_num = phrase_num.reshape(-1)

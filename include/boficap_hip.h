@@ -129,6 +129,12 @@ int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, 
  * colsum (may be NULL): colsum[n] += sum_m x'[m][n] on the way (the bias gradient when x is dz) */
 int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, const float* relu_y, float drop_p,
                    uint64_t drop_seed, void* stream);
+/* bofi_linear with every epilogue option of the training path: dropout as bofi_linear_dropout (drop_p 0: off) and
+ * y2 (may be NULL): a second copy of the output in the compute dtype, row stride ldy2 (N % 32 == 0) -- the operand of
+ * the next GEMM / attention kernel, so that no separate cast pass is needed. */
+int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias,
+                   const float* residual, int ldr, void* y, int y_dtype, int ldy, int M, int N, int K, int relu,
+                   const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, void* y2, int ldy2, void* stream);
 /* bofi_linear with the sublayer's dropout in the epilogue (operands in one compute dtype):
  * y = residual + keep(act(x w^T + bias)) / (1 - drop_p), keep(m, n) = hash(drop_seed, m * N + n) >= drop_p * 2^32
  * (SublayerConnection x + dropout(sublayer(norm(x))), TransformerModel.py:1361-1363; FFN inner dropout :1478). */
