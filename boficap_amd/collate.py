@@ -103,3 +103,8 @@ def synthetic_training_batch(cfg, n_img: int, seq_per_img: int, seed: int = 0) -
     labels, plen, psyn = synthetic_captions(cfg, n_img * seq_per_img, seed)
     b = phrase_collate(labels, plen, psyn, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx, len_idx=cfg.len_idx)
     return {k: v.reshape(n_img, seq_per_img, *v.shape[1:]) for k, v in b.items()}
+
+
+def max_phrase_num(batch) -> int:
+    """max over the batch of the loader's phrase_num (host value; lets the training forward skip a device->host read)."""
+    return int(np.asarray(batch["phrase_num"]).max())

@@ -416,7 +416,7 @@ extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float
                                   int d, void* stream) {
     if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    const int rpb = rows >= 32768 ? 32 : (rows >= 8192 ? 16 : 8);        // >= 1 row per wavefront pass, >= ~800 workgroups at 6400 rows
+    const int rpb = rows >= 4096 ? 32 : 8;                 // the per-column atomics of a workgroup cost more than the lost occupancy
     if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
     else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d);

@@ -130,6 +130,8 @@ class XETrainer:
         fc = batch.get("fc_feats")
         if fc is None:
             fc = torch.zeros(batch["att_feats"].shape[0], 0, device=batch["att_feats"].device)
+        if batch.get("max_phrase_num") is not None:            # known on the host since the collate: spares the forward a device read
+            xe.HINTS["max_phrase_num"] = int(batch["max_phrase_num"])
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)

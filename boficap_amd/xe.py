@@ -603,11 +603,16 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     return len_lp.view(N, Pm, -1), syn_lp.view(N, Pm, -1)
 
 
-def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor):
+# Host-side facts about the batch the caller already knows (set by the trainer from the collate's output) so that the
+# forward pass needs no device->host read: {"max_phrase_num": int}.  Consumed (cleared) by the next forward_uic.
+HINTS: dict = {}
+
+
+def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor, max_phrase_num: Optional[int] = None):
     """Key count of the [LEN] row per (caption, pass), TransformerModel.py:493-511: pass 0 sees 1 key; pass i >= 1 sees
     1 + sum(phrase_length[n, 1..min(i, phrase_num[n]-1)]).  Also the final ``last`` per caption (:562-564)."""
     N, L = phrase_length.shape
-    Pm = int(phrase_num.max())
+    Pm = int(max_phrase_num) if max_phrase_num else int(phrase_num.max())     # .max() is a device->host sync
     idx = torch.arange(L, device=phrase_length.device).unsqueeze(0)
     pl = torch.where((idx >= 1) & (idx < phrase_num.unsqueeze(1)), phrase_length, torch.zeros_like(phrase_length))
     cum = 1 + pl.cumsum(1)                                     # cum[n, i] = 1 + sum_{t<=i} pl[n, t]
@@ -652,7 +657,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     labels, phrase_num, phrase_length = labels.to(dev).long(), phrase_num.to(dev).long(), phrase_length.to(dev).long()
     ext_syn = extend_phrase_syn_seq.to(dev).long().contiguous()
     ext_seq = extend_phrase_seq.to(dev).long().contiguous()
-    klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length)
+    klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length, HINTS.pop("max_phrase_num", None))
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
