@@ -8,7 +8,8 @@
 //   dK = dS^T Q,  dV = P^T dO                       both operands gathered with the transposing read
 //
 // so no transposed copy of anything is ever written.  q, k, v may be float32 (rounded to bf16 on the way into LDS) or
-// bf16; dO, dQ, dK, dV are float32.  Captions of one image share its keys (kdiv): dK / dV then accumulate with atomics.
+// bf16; dO, dQ, dK, dV are float32.  Captions of one image share its keys (kdiv): the wavefront owning (image, head) walks
+// them and sums dK / dV in registers -- plain stores, no atomics.
 #include "bofi_common.h"
 #include "bofi_kernels.h"
 
@@ -97,115 +98,128 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
     constexpr int LQ = QT * 16, LK = KT * 16;
     __shared__ __attribute__((aligned(16))) bf16_t sq[LQ * DS], sdo[LQ * DS], sk[LK * DS], sv[LK * DS], sp[LQ * PS], sds[LQ * PS];
     const int lane = threadIdx.x, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, bk = b / p.kdiv;
+    // one wavefront per (key owner, head): with kdiv > 1 it walks the kdiv captions that share these keys and keeps
+    // dK / dV in registers across them, so the shared rows are written once, without atomics
+    const int bh = blockIdx.x, bk = bh / p.H, h = bh - bk * p.H;
     const int Lq = p.Lq, Lk = p.Lk;
 
-    stage_rows<TIN, LQ>(static_cast<const TIN*>(p.q) + (size_t)b * Lq * p.ldq + h * 64, p.ldq, Lq, sq, DS, lane);
-    stage_rows<float, LQ>(p.dout + (size_t)b * Lq * p.ldo + h * 64, p.ldo, Lq, sdo, DS, lane);
     stage_rows<TIN, LK>(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, sk, DS, lane);
     stage_rows<TIN, LK>(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, sv, DS, lane);
-    __syncthreads();
 
-    // ---- S = Q K^T, dP = dO V^T  (lane holds rows q = qt*16 + 4g + r, column k = kt*16 + l15)
-    f32x4 S[QT][KT], dP[QT][KT];
+    f32x4 ak[KT][4], av[KT][4];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        bf16x8 aq[2], ao[2];
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            aq[s] = *reinterpret_cast<const bf16x8*>(&sq[(qt * 16 + l15) * DS + s * 32 + g * 8]);
-            ao[s] = *reinterpret_cast<const bf16x8*>(&sdo[(qt * 16 + l15) * DS + s * 32 + g * 8]);
-        }
+        for (int dt = 0; dt < 4; ++dt) { ak[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; av[kt][dt] = ak[kt][dt]; }
+
+    for (int c = 0; c < p.kdiv; ++c) {
+        const int b = bk * p.kdiv + c;
+        if (c) __syncthreads();                                  // the previous caption's operands are still being read
+        stage_rows<TIN, LQ>(static_cast<const TIN*>(p.q) + (size_t)b * Lq * p.ldq + h * 64, p.ldq, Lq, sq, DS, lane);
+        stage_rows<float, LQ>(p.dout + (size_t)b * Lq * p.ldo + h * 64, p.ldo, Lq, sdo, DS, lane);
+        __syncthreads();
+
+        // ---- S = Q K^T, dP = dO V^T  (lane holds rows q = qt*16 + 4g + r, column k = kt*16 + l15)
+        f32x4 S[QT][KT], dP[QT][KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, d = a;
+        for (int qt = 0; qt < QT; ++qt) {
+            bf16x8 aq[2], ao[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 bkf = *reinterpret_cast<const bf16x8*>(&sk[(kt * 16 + l15) * DS + s * 32 + g * 8]);
-                const bf16x8 bvf = *reinterpret_cast<const bf16x8*>(&sv[(kt * 16 + l15) * DS + s * 32 + g * 8]);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[s], bkf, a, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[s], bvf, d, 0, 0, 0);
+                aq[s] = *reinterpret_cast<const bf16x8*>(&sq[(qt * 16 + l15) * DS + s * 32 + g * 8]);
+                ao[s] = *reinterpret_cast<const bf16x8*>(&sdo[(qt * 16 + l15) * DS + s * 32 + g * 8]);
             }
-            S[qt][kt] = a;
-            dP[qt][kt] = d;
-        }
-    }
-
-    // ---- softmax rows and dS; P and dS go to LDS as bf16 [q][k]
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qrow = qt * 16 + 4 * g + r;
-            int kl = 0;
-            if (qrow < Lq) {
-                kl = Lk;
-                if (p.klen) { kl = p.klen[b * p.klen_sb + qrow * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
-            }
-            float m = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-                if (kt * 16 + l15 < kl) m = fmaxf(m, S[qt][kt][r] * 0.125f);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            float e[KT], sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
-                e[kt] = (kt * 16 + l15 < kl) ? expf(S[qt][kt][r] * 0.125f - m) : 0.f;
-                sum += e[kt];
-            }
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, d = a;
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            const float inv = sum > 0.f ? 1.f / sum : 0.f;
-            float dot = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) { e[kt] *= inv; dot += e[kt] * dP[qt][kt][r]; }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                sp[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt]);
-                sds[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * (dP[qt][kt][r] - dot) * 0.125f);
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 bkf = *reinterpret_cast<const bf16x8*>(&sk[(kt * 16 + l15) * DS + s * 32 + g * 8]);
+                    const bf16x8 bvf = *reinterpret_cast<const bf16x8*>(&sv[(kt * 16 + l15) * DS + s * 32 + g * 8]);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[s], bkf, a, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[s], bvf, d, 0, 0, 0);
+                }
+                S[qt][kt] = a;
+                dP[qt][kt] = d;
             }
         }
-    __syncthreads();
 
-    // ---- dQ = dS K
+        // ---- softmax rows and dS; P and dS go to LDS as bf16 [q][k]
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        f32x4 acc[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KT / 2; ++s) {
-            const bf16x8 a = frag_row_trorder(sds, PS, qt * 16 + l15, s * 32, g);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sk, DS, s * 32, dt * 16, g, tq, tp), acc[dt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qrow = qt * 16 + 4 * g + r;
-                if (qrow < Lq) p.dq[((size_t)b * Lq + qrow) * p.lddq + h * 64 + dt * 16 + l15] = acc[dt][r];
+                int kl = 0;
+                if (qrow < Lq) {
+                    kl = Lk;
+                    if (p.klen) { kl = p.klen[b * p.klen_sb + qrow * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    if (kt * 16 + l15 < kl) m = fmaxf(m, S[qt][kt][r] * 0.125f);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                float e[KT], sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    e[kt] = (kt * 16 + l15 < kl) ? expf(S[qt][kt][r] * 0.125f - m) : 0.f;
+                    sum += e[kt];
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                const float inv = sum > 0.f ? 1.f / sum : 0.f;
+                float dot = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) { e[kt] *= inv; dot += e[kt] * dP[qt][kt][r]; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    sp[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt]);
+                    sds[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * (dP[qt][kt][r] - dot) * 0.125f);
+                }
+            }
+        __syncthreads();
+
+        // ---- dQ = dS K
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KT / 2; ++s) {
+                const bf16x8 a = frag_row_trorder(sds, PS, qt * 16 + l15, s * 32, g);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag_tr(sk, DS, s * 32, dt * 16, g, tq, tp), acc[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = qt * 16 + 4 * g + r;
+                    if (qrow < Lq) p.dq[((size_t)b * Lq + qrow) * p.lddq + h * 64 + dt * 16 + l15] = acc[dt][r];
+                }
+        }
+        // ---- dK += dS^T Q, dV += P^T dO
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < QT / 2; ++s) {
+                const bf16x8 a_ds = frag_tr(sds, PS, s * 32, kt * 16, g, tq, tp);
+                const bf16x8 a_p = frag_tr(sp, PS, s * 32, kt * 16, g, tq, tp);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    ak[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ds, frag_tr(sq, DS, s * 32, dt * 16, g, tq, tp), ak[kt][dt], 0, 0, 0);
+                    av[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_p, frag_tr(sdo, DS, s * 32, dt * 16, g, tq, tp), av[kt][dt], 0, 0, 0);
+                }
             }
     }
-    // ---- dK = dS^T Q, dV = P^T dO
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        f32x4 ak[4], av[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; av[dt] = ak[dt]; }
-#pragma unroll
-        for (int s = 0; s < QT / 2; ++s) {
-            const bf16x8 a_ds = frag_tr(sds, PS, s * 32, kt * 16, g, tq, tp);
-            const bf16x8 a_p = frag_tr(sp, PS, s * 32, kt * 16, g, tq, tp);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ds, frag_tr(sq, DS, s * 32, dt * 16, g, tq, tp), ak[dt], 0, 0, 0);
-                av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_p, frag_tr(sdo, DS, s * 32, dt * 16, g, tq, tp), av[dt], 0, 0, 0);
-            }
-        }
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -213,15 +227,14 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
                 const int krow = kt * 16 + 4 * g + r;
                 if (krow >= Lk) continue;
                 const size_t o = ((size_t)bk * Lk + krow) * p.lddk + h * 64 + dt * 16 + l15;
-                if (p.kdiv > 1) { atomicAdd(p.dk + o, ak[dt][r]); atomicAdd(p.dv + o, av[dt][r]); }
-                else { p.dk[o] = ak[dt][r]; p.dv[o] = av[dt][r]; }
+                p.dk[o] = ak[kt][dt][r];
+                p.dv[o] = av[kt][dt][r];
             }
-    }
 }
 
 template <typename TIN>
 static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
-    const dim3 grid(p.B * p.H), block(64);
+    const dim3 grid((p.B / p.kdiv) * p.H), block(64);
     if (p.Lq <= 32 && p.Lk <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 2>), grid, block, 0, st, p);
     else if (p.Lq <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 4, 4>), grid, block, 0, st, p);
@@ -235,7 +248,7 @@ extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, in
                                        const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H, int Lq,
                                        int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, void* stream) {
     using namespace bofi;
-    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0) return BOFI_ERR_ARG;
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0 || B % kdiv) return BOFI_ERR_ARG;
     if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
     const int el = in_dtype == BOFI_DT_F32 ? 4 : 2;
     if ((ldq * el) % 16 || (ldk * el) % 16 || (ldv * el) % 16 || ldo % 4 || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16) ||

@@ -256,38 +256,52 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     const int n = blockIdx.x * 256 + cq * 4;
     const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&](int m, float (&v)[4]) {
+        if (drop_thresh) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (n + c < N) v[c] = drop_hash(drop_seed, (uint64_t)m * N + n + c) >= drop_thresh ? v[c] * drop_scale : 0.f;
+        }
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = o;              // ldy % 4 == 0 and n % 4 == 0
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += v[c];
+    };
     if (n < ldy) {
-        for (int m = m0 + rl; m < m1; m += 4) {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (VEC && n + 3 < N) {
-                const float4 t = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + n);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                if (relu_y) {
-                    const float4 r = *reinterpret_cast<const float4*>(relu_y + (size_t)m * ldx + n);
-                    if (!(r.x > 0.f)) v[0] = 0.f;
-                    if (!(r.y > 0.f)) v[1] = 0.f;
-                    if (!(r.z > 0.f)) v[2] = 0.f;
-                    if (!(r.w > 0.f)) v[3] = 0.f;
+        if (VEC && n + 3 < N) {
+            // the eight rows of this thread are requested before the first one is converted
+            float4 t[8], r[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = m0 + rl + 4 * it;
+                t[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (m < m1) {
+                    t[it] = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + n);
+                    if (relu_y) r[it] = *reinterpret_cast<const float4*>(relu_y + (size_t)m * ldx + n);
                 }
-            } else {
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = m0 + rl + 4 * it;
+                if (m >= m1) break;
+                float v[4] = {r[it].x > 0.f ? t[it].x : 0.f, r[it].y > 0.f ? t[it].y : 0.f, r[it].z > 0.f ? t[it].z : 0.f,
+                              r[it].w > 0.f ? t[it].w : 0.f};
+                finish(m, v);
+            }
+        } else {
+            for (int m = m0 + rl; m < m1; m += 4) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (n + c < N) {
                         v[c] = x[(size_t)m * ldx + n + c];
                         if (relu_y && !(relu_y[(size_t)m * ldx + n + c] > 0.f)) v[c] = 0.f;
                     }
+                finish(m, v);
             }
-            if (drop_thresh) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (n + c < N) v[c] = drop_hash(drop_seed, (uint64_t)m * N + n + c) >= drop_thresh ? v[c] * drop_scale : 0.f;
-            }
-            uint2 o;
-            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = o;          // ldy % 4 == 0 and n % 4 == 0
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s[c] += v[c];
         }
     }
     if (!colsum) return;

@@ -114,6 +114,13 @@ def dtype_code(t) -> int:
     raise BofiHipError(f"unsupported dtype {t.dtype}")
 
 
+_torch = None
+
+
 def stream_ptr():
-    import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current torch HIP stream as a raw pointer (hot: called once per kernel launch)."""
+    global _torch
+    if _torch is None:
+        import torch
+        _torch = torch
+    return _torch._C._cuda_getCurrentRawStream(_torch.cuda.current_device())

@@ -25,12 +25,19 @@ from . import hip
 F32 = hip.DT_F32
 
 
+_LIB = None
+
+
 def _lib():
-    return hip.lib()
+    global _LIB
+    if _LIB is None:
+        _LIB = hip.lib()
+    return _LIB
 
 
 def _chk(rc, what):
-    hip.check(rc, what)
+    if rc:
+        hip.check(rc, what)
 
 
 def _empty(ref: torch.Tensor, *shape) -> torch.Tensor:
@@ -327,9 +334,12 @@ class AttentionFn(Function):
         qbuf, kvbuf = ctx.saved_tensors                        # float32 buffers, or their bf16 shadows
         qoff, koff, voff, B, H, Lq, Lk, kdiv, sb, sq, bias = ctx.meta
         dout = _real(_need(dout, "attention dout"), "attention dout")
-        dq = torch.zeros(qbuf.shape, dtype=torch.float32, device=qbuf.device)
-        dkv = dq if ctx.same else torch.zeros(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
+        # the MFMA kernel writes every element of the q / k / v slices (no atomics); the VALU kernel accumulates shared keys
+        covered = ctx.mfma and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64))
+        alloc = torch.empty if covered else torch.zeros
+        dq = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
+        dkv = dq if ctx.same else alloc(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         if ctx.mfma:
             _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.dtype_code(qbuf),
                                                 hip.ptr(dout), H * 64, _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk,

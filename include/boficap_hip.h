@@ -102,7 +102,8 @@ int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const f
                        int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias,
                        void* stream);
 /* the same backward on the matrix cores: q/k/v float32 or bf16 (in_dtype), products in bf16 with fp32 accumulation,
- * operands gathered with transposing LDS reads; dq row stride lddq, dk/dv row stride lddk (float32) */
+ * operands gathered with transposing LDS reads; dq row stride lddq, dk/dv row stride lddk (float32), WRITTEN (not
+ * accumulated) also when kdiv > 1: one wavefront owns an (image, head) and sums over its captions in registers */
 int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
                             const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H,
                             int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, void* stream);
