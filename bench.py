@@ -180,7 +180,7 @@ def main_xe(args):
     model = models.setup(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev).train()
-    tr = XETrainer(model, opt)
+    tr = XETrainer(model, opt, graph=not args.no_graph)
     host_batch = synthetic_training_batch(cfg, args.batch, spi, seed=100 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in host_batch.items()}
     batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
@@ -220,10 +220,11 @@ def main_xe(args):
             "config": {"workload": f"XE training (configs/uic_sd.yml model) batch={args.batch} images x {spi} captions per GPU, 36x2048 regions, "
                                    f"d_model=512 6 enc + 6 dec + 1 bound layer, {args.dtype}, dropout on",
                        "images_per_step_per_gpu": args.batch, "captions_per_image": spi, "vocab": cfg.tgt_vocab,
-                       "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
+                       "hip_graph": tr.graph, "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
                        "sharding": "images by rank; one RCCL all-reduce over the flat fp32 gradient bucket per step"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None, "kernel": "whole XE step (eager launches)",
+                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None,
+                         "kernel": "whole XE step (" + ("one hipGraph launch + all-reduce + Adam kernel" if tr.graph else "eager launches") + ")",
                          "flops_per_launch": flops, "launch_ms": round(dev_ms, 3),
                          "note": "algorithmic FLOPs of the step as the reference computes it (SURVEY.md 8d: encoder per caption copy, "
                                  "max(phrase_num) full bound passes per branch, x3 for fwd+bwd) / HIP-event time per step"},

@@ -35,6 +35,7 @@ struct LinearArgs {
     int splitk;               // > 1: K split over workgroups; y receives `splitk` float32 partial slabs [splitk][M][ldy]
     // training: y = residual + keep(act(x w^T + bias)) / (1 - p), keep = drop_hash(drop_seed, m * N + n) >= drop_thresh (0: off)
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
+    const uint64_t* drop_step;    // device word added to drop_seed when set (a captured graph replays with fresh masks)
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
 int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible

@@ -321,25 +321,15 @@ extern "C" int bofi_linear(const void* x, int x_dtype, int ldx, const void* w, i
 
 extern "C" int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias,
                               const float* residual, int ldr, void* y, int y_dtype, int ldy, int M, int N, int K, int relu,
-                              const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, void* y2, int ldy2, void* stream) {
+                              const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* y2, int ldy2,
+                              void* stream) {
     if (!(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     bofi::LinearArgs a{};
     a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = w; a.w_dtype = w_dtype; a.bias = bias;
     a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.M = M; a.N = N; a.K = K;
     a.relu = relu; a.row_len = row_len; a.rows_per_group = rows_per_group;
-    if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; }
+    if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.drop_step = drop_step; }
     a.y2 = y2; a.ldy2 = ldy2;
     return bofi::launch_linear(a, (hipStream_t)stream);
 }
 
-extern "C" int bofi_linear_dropout(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias,
-                                   const float* residual, int ldr, void* y, int y_dtype, int ldy, int M, int N, int K, int relu,
-                                   float drop_p, uint64_t drop_seed, void* stream) {
-    if (!(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
-    bofi::LinearArgs a{};
-    a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = w; a.w_dtype = w_dtype; a.bias = bias;
-    a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.M = M; a.N = N; a.K = K;
-    a.relu = relu;
-    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed;
-    return bofi::launch_linear(a, (hipStream_t)stream);
-}

@@ -60,6 +60,7 @@ struct Gemm2Params {
                               // bias / residual are added by slice 0 only, the consumer sums the slabs
     int vec_ok;               // N, ldy, ldr multiples of 4 and y/bias/residual 16-byte aligned
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;     // training dropout on act(..) before the residual (0: off)
+    const uint64_t* drop_step;
     int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
 };
 
@@ -246,11 +247,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (zero[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.drop_thresh) {
-                const uint64_t e = (uint64_t)m * p.N + n;
-                v.x = drop_hash(p.drop_seed, e) >= p.drop_thresh ? v.x * p.drop_scale : 0.f;
-                v.y = drop_hash(p.drop_seed, e + 1) >= p.drop_thresh ? v.y * p.drop_scale : 0.f;
-                v.z = drop_hash(p.drop_seed, e + 2) >= p.drop_thresh ? v.z * p.drop_scale : 0.f;
-                v.w = drop_hash(p.drop_seed, e + 3) >= p.drop_thresh ? v.w * p.drop_scale : 0.f;
+                const uint64_t e = (uint64_t)m * p.N + n, dseed = p.drop_seed + (p.drop_step ? *p.drop_step : 0ull);
+                v.x = drop_hash(dseed, e) >= p.drop_thresh ? v.x * p.drop_scale : 0.f;
+                v.y = drop_hash(dseed, e + 1) >= p.drop_thresh ? v.y * p.drop_scale : 0.f;
+                v.z = drop_hash(dseed, e + 2) >= p.drop_thresh ? v.z * p.drop_scale : 0.f;
+                v.w = drop_hash(dseed, e + 3) >= p.drop_thresh ? v.w * p.drop_scale : 0.f;
             }
             v.x = rv[u].x + v.x; v.y = rv[u].y + v.y; v.z = rv[u].z + v.z; v.w = rv[u].w + v.w;
             if (p.stats_out) {                         // partial sums over this lane's aligned 32-column group (8 lanes)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
             v += sbv[c];
             if (p.relu) v = fmaxf(v, 0.f);
             if (szero[u]) v = 0.f;
-            if (p.drop_thresh) v = drop_hash(p.drop_seed, (uint64_t)m * p.N + n) >= p.drop_thresh ? v * p.drop_scale : 0.f;
+            if (p.drop_thresh) v = drop_hash(p.drop_seed + (p.drop_step ? *p.drop_step : 0ull), (uint64_t)m * p.N + n) >= p.drop_thresh ? v * p.drop_scale : 0.f;
             v = srv[u][c] + v;
             if (m >= p.M || c * 64 + lane >= BN || n >= p.N) continue;
             if (p.y_is_f32) static_cast<float*>(p.y)[(size_t)m * p.ldy + n] = v;
@@ -391,7 +392,7 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
     p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
     p.splitk = a.splitk > 1 ? a.splitk : 1;
-    p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed;
+    p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
     if (p.drop_thresh && (a.splitk > 1 || a.stats_out)) return BOFI_ERR_ARG;
     if (p.splitk > 1 && (a.y_dtype != BOFI_DT_F32 || a.relu || a.ln_stats || a.stats_out || a.y2 || a.row_len || (a.K / p.splitk) % bk || a.K % p.splitk))
         return BOFI_ERR_ARG;

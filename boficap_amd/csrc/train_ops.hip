@@ -250,8 +250,9 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 template <bool VEC>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M, int N,
                                                        float* colsum, const float* __restrict__ relu_y, uint32_t drop_thresh,
-                                                       float drop_scale, uint64_t drop_seed) {
+                                                       float drop_scale, uint64_t drop_seed0, const uint64_t* drop_step) {
     __shared__ float red[4][256];
+    const uint64_t drop_seed = drop_seed0 + ((drop_thresh && drop_step) ? *drop_step : 0ull);
     const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 256 + cq * 4;
     const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
 
 // y = (residual ? residual : 0) + keep(x) / (1 - p)
 __global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y, size_t n,
-                               uint32_t thresh, float scale, uint64_t seed) {
+                               uint32_t thresh, float scale, uint64_t seed0, const uint64_t* drop_step) {
+    const uint64_t seed = seed0 + (drop_step ? *drop_step : 0ull);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = drop_hash(seed, i) >= thresh ? x[i] * scale : 0.f;
         y[i] = residual ? residual[i] + v : v;
@@ -392,7 +394,7 @@ extern "C" int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dty
 }
 
 extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, const float* relu_y, float drop_p,
-                              uint64_t drop_seed, void* stream) {
+                              uint64_t drop_seed, const uint64_t* drop_step, void* stream) {
     if (!x || !y || M < 0 || N <= 0 || ldx < N || ldy < N || ldy % 4 || ((uintptr_t)y % 8) || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (M == 0) return BOFI_OK;
     const uint32_t drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
@@ -400,19 +402,20 @@ extern "C" int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, 
     const dim3 grid((ldy + 255) / 256, (M + 31) / 32);
     const bool vec = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0) && (!relu_y || (uintptr_t)relu_y % 16 == 0);
     if (vec) hipLaunchKernelGGL((cast_pad_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N, colsum, relu_y,
-                                drop_thresh, drop_scale, drop_seed);
+                                drop_thresh, drop_scale, drop_seed, drop_step);
     else hipLaunchKernelGGL((cast_pad_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, N, colsum, relu_y,
-                            drop_thresh, drop_scale, drop_seed);
+                            drop_thresh, drop_scale, drop_seed, drop_step);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
 
-extern "C" int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, const uint64_t* drop_step,
+                            void* stream) {
     if (!x || !y || n < 0 || !(p >= 0.f && p < 1.f)) return BOFI_ERR_ARG;
     if (n == 0) return BOFI_OK;
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, residual, y, (size_t)n, thresh, 1.0f / (1.0f - p), seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, residual, y, (size_t)n, thresh, 1.0f / (1.0f - p), seed, drop_step);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -98,7 +98,11 @@ class XETrainer:
     (20000), ``noamopt_factor`` (1), ``learning_rate`` (5e-4, used when noamopt is off), ``optim_alpha/beta/epsilon``
     (plain Adam), ``grad_clip_value`` (0.1) with ``grad_clip_mode`` 'value'."""
 
-    def __init__(self, model, opt=None, group=None):
+    def __init__(self, model, opt=None, group=None, graph: bool = False):
+        """``graph``: capture zero-grad + forward + criterion + backward of a batch signature (shapes, max phrase count,
+        GLAT on/off) into a hipGraph on first use and replay it afterwards -- ~1 200 kernel launches and the whole Python /
+        autograd dispatch of a step become one graph launch.  Inputs are copied into static buffers, the dropout step lives
+        in a device word the kernels read.  The all-reduce and the optimiser kernel stay outside the graph."""
         if next(model.parameters()).device.type != "cuda":
             raise hip.BofiHipError("the model must be on a HIP device; there is no CPU training path")
         opt = opt if opt is not None else model.opt
@@ -118,13 +122,56 @@ class XETrainer:
         self.m = torch.zeros_like(self.bucket.flat)
         self.v = torch.zeros_like(self.bucket.flat)
         self._step = 0
+        self.graph = bool(graph)
+        self._graphs = {}
+        self._fwd_calls = 0
+        if self.graph:
+            dev = self.bucket.flat.device
+            self._step_word = torch.zeros(1, dtype=torch.int64, device=dev)      # dropout step, read by the kernels
+            model._drop_step_word = self._step_word
 
     # ------------------------------------------------------------------ pieces (exposed for the tests)
     def rate(self, step: Optional[int] = None) -> float:
         step = self._step if step is None else step
         return noam_rate(step, self.model.d_model, self.factor, self.warmup) if self.noam else self.lr
 
+    _KEYS = ("att_feats", "labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq",
+             "extend_phrase_seq_mask")
+
     def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
+        """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
+        if self.graph and not self._capturing():
+            self._fwd_calls += 1
+            self._step_word.fill_(self._fwd_calls)             # outside any graph: every step draws new dropout masks
+            if batch.get("att_masks") is None and batch.get("max_phrase_num") is not None:
+                return self._replay(batch, glat_p)
+        return self._forward_backward_eager(batch, glat_p)
+
+    @staticmethod
+    def _capturing() -> bool:
+        return torch.cuda.is_current_stream_capturing()
+
+    def _replay(self, batch, glat_p):
+        key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), int(batch["max_phrase_num"]), round(float(glat_p), 6),
+               self.model.training, self.model.train_dtype)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = {k: batch[k].clone() for k in self._KEYS}
+            static["max_phrase_num"] = int(batch["max_phrase_num"])
+            self._forward_backward_eager(static, glat_p)        # warm-up outside the capture (lazy initialisations, allocator)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, parts = self._forward_backward_eager(static, glat_p)
+            entry = self._graphs[key] = (g, static, loss, parts)
+        g, static, loss, parts = entry
+        for k in self._KEYS:
+            if static[k].data_ptr() != batch[k].data_ptr():
+                static[k].copy_(batch[k], non_blocking=True)
+        g.replay()
+        return loss, parts
+
+    def _forward_backward_eager(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         from . import xe
         self.bucket.zero_grad()
         fc = batch.get("fc_feats")

@@ -171,10 +171,12 @@ class TransformerModel(nn.Module):
         if next(self.parameters()).device.type != "cuda":
             raise hip.BofiHipError("the model must be on a HIP device (model.cuda()); there is no CPU training path")
         self._step = getattr(self, "_step", 0) + 1
-        seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._step if self.training else None
+        step_word = getattr(self, "_drop_step_word", None)     # set by a graph-capturing trainer: the step lives on the device
+        base = int(getattr(self.opt, "seed", 0)) << 32
+        seed = (base if step_word is not None else base + self._step) if self.training else None
         return xe.forward_uic(xe.Params(self), self.cfg, att_feats, seq, att_masks, phrase_num, phrase_length, phrase_syn,
                               extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask, glat_p=float(glat_p),
-                              training=self.training, seed=seed, compute_dtype=self.train_dtype)
+                              training=self.training, seed=seed, compute_dtype=self.train_dtype, step_word=step_word)
 
 
 def setup(opt):

@@ -95,7 +95,7 @@ def _gemm(x, ldx, w, bias, residual, y, M, N, K, relu=0, row_len=None, rpg=0, dr
             raise hip.BofiHipError("dropout in the epilogue is not combined with row_len")
         _chk(_lib().bofi_linear_ex(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
                                    hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, drop[0] if drop else 0.0, drop[1] if drop else 0,
-                                   hip.ptr(y2), N, hip.stream_ptr()), "bofi_linear_ex")
+                                   hip.ptr(drop[2]) if drop else None, hip.ptr(y2), N, hip.stream_ptr()), "bofi_linear_ex")
         return
     _chk(_lib().bofi_linear(hip.ptr(x), code, ldx, hip.ptr(w), code, hip.ptr(bias), hip.ptr(residual), N if residual is not None else 0,
                             hip.ptr(y), F32, N, M, N, K, relu, hip.ptr(row_len), rpg, hip.stream_ptr()), "bofi_linear")
@@ -124,7 +124,8 @@ def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     else:
         y = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
         _chk(_lib().bofi_cast_bf16(hip.ptr(x), N, hip.ptr(y), Np, M, N, hip.ptr(colsum), hip.ptr(relu_y),
-                                   drop[0] if drop else 0.0, drop[1] if drop else 0, hip.stream_ptr()), "bofi_cast_bf16")
+                                   drop[0] if drop else 0.0, drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, hip.stream_ptr()),
+             "bofi_cast_bf16")
     if cache and colsum is None:
         _STEP_CACHE[key] = (x, y)
     return y, Np
@@ -245,7 +246,7 @@ class LinearFn(Function):
 
 
 def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None, drop=None, shadow=False):
-    """``drop``: (p, seed) -> y = residual + dropout(act(x w^T + b)) with the mask made in the GEMM epilogue (bf16 path).
+    """``drop``: (p, seed, step word or None) -> y = residual + dropout(act(x w^T + b)), mask made in the GEMM epilogue (bf16 path).
     ``shadow``: the output feeds a GEMM or an attention kernel -> also emit it in bf16 from the epilogue (bf16 path)."""
     return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow)
 
@@ -433,37 +434,43 @@ class DropoutFn(Function):
     """residual + dropout(x): the mask is a counter hash of (seed, element), regenerated in the backward."""
 
     @staticmethod
-    def forward(ctx, x, residual, p, seed):
+    def forward(ctx, x, residual, p, seed, step_word=None):
         x = _real(_need(x, "dropout x"), "dropout x")
         y = torch.empty_like(x)
-        _chk(_lib().bofi_dropout(hip.ptr(x), hip.ptr(residual), hip.ptr(y), x.numel(), p, seed, hip.stream_ptr()), "bofi_dropout")
-        ctx.p, ctx.seed, ctx.has_r = p, seed, residual is not None
+        _chk(_lib().bofi_dropout(hip.ptr(x), hip.ptr(residual), hip.ptr(y), x.numel(), p, seed, hip.ptr(step_word), hip.stream_ptr()), "bofi_dropout")
+        ctx.p, ctx.seed, ctx.has_r, ctx.step_word = p, seed, residual is not None, step_word
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = _need(dy, "dropout dy")
         dx = torch.empty_like(dy)
-        _chk(_lib().bofi_dropout(hip.ptr(dy), None, hip.ptr(dx), dy.numel(), ctx.p, ctx.seed, hip.stream_ptr()), "bofi_dropout")
-        return dx, (dy if ctx.has_r else None), None, None
+        _chk(_lib().bofi_dropout(hip.ptr(dy), None, hip.ptr(dx), dy.numel(), ctx.p, ctx.seed, hip.ptr(ctx.step_word), hip.stream_ptr()), "bofi_dropout")
+        return dx, (dy if ctx.has_r else None), None, None, None
 
 
 class _Drop:
-    """Dropout sites of one forward pass: site k of step s draws from stream (base seed, s, k)."""
+    """Dropout sites of one forward pass.  Site k draws from stream ``seed_k + step``: seed_k is a per-site constant mixed
+    from the base seed, ``step`` either folded in on the host (eager) or read by the kernels from a DEVICE word
+    (``step_word``: what lets a captured graph draw fresh masks on every replay)."""
 
-    def __init__(self, p: float, p_att: float, seed: Optional[int]):
+    def __init__(self, p: float, p_att: float, seed: Optional[int], step_word: Optional[torch.Tensor] = None):
         self.p, self.p_att, self.on = p, p_att, seed is not None
-        self.seed, self.k = (seed or 0), 0
+        self.seed, self.k, self.step_word = (seed or 0), 0, step_word
 
     def _next(self):
         self.k += 1
         return (self.seed * 0x100000001B3 + self.k * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
+    def site(self, p=None):
+        """(p, seed, step word) for a kernel with built-in dropout."""
+        return (self.p if p is None else p, self._next(), self.step_word)
+
     def __call__(self, x, residual=None, p=None):
         p = self.p if p is None else p
         if not self.on or p <= 0.0:
             return x if residual is None else None          # None: caller fuses the residual into the GEMM instead
-        return DropoutFn.apply(x, residual, p, self._next())
+        return DropoutFn.apply(x, residual, p, self._next(), self.step_word)
 
 
 # ------------------------------------------------------------------------------------------------ the model
@@ -518,13 +525,13 @@ def _sublayer_linear(P, drop, x_in, wname, residual):
     if not drop.on or drop.p <= 0.0:
         return P.lin(x_in, wname, residual=residual)
     if _COMPUTE["dtype"] == torch.bfloat16:
-        return P.lin(x_in, wname, residual=residual, drop=(drop.p, drop._next()))
+        return P.lin(x_in, wname, residual=residual, drop=drop.site())
     return drop(P.lin(x_in, wname), residual)
 
 
 def _ffn(P, pre, drop, n, x):
     fused = drop.on and drop.p > 0.0 and _COMPUTE["dtype"] == torch.bfloat16
-    h = P.lin(n, pre + ".w_1", relu=True, drop=(drop.p, drop._next()) if fused else None, shadow=True)
+    h = P.lin(n, pre + ".w_1", relu=True, drop=drop.site() if fused else None, shadow=True)
     if drop.on and drop.p > 0.0 and not fused:
         h = drop(h)
     return _sublayer_linear(P, drop, h, pre + ".w_2", x)
@@ -631,7 +638,7 @@ def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor, max_p
 
 def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, extend_phrase_seq,
                 extend_phrase_seq_mask, *, glat_p: float = -1.0, training: bool = False, seed: Optional[int] = None,
-                compute_dtype: torch.dtype = torch.float32):
+                compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
     """The six log-prob tensors of EncoderDecoder_UIC.forward (TransformerModel.py:413-468):
     (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok).  ``P``: a ``Params``."""
     dev = att_feats.device
@@ -659,7 +666,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     if N % B:
         raise hip.BofiHipError(f"{N} captions for {B} images")
     spi = N // B
-    drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None)
+    drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None, step_word)
     memory = encode_memory(P, cfg, att_feats, att_len, drop)
     att_len_cap = None if att_len is None else att_len.repeat_interleave(spi).contiguous()
     kv_cache: dict = {}

@@ -126,25 +126,25 @@ int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb,
 int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream);
 /* y[m][n] = bf16(x[m][n]) for n < N, zero for N <= n < ldy: a GEMM operand in the bf16 compute dtype.
  * relu_y (may be NULL): forward output of a ReLU layer, same layout as x: x is masked where relu_y <= 0 first.
- * drop_p > 0: then the dropout mask of bofi_linear_dropout(drop_p, drop_seed) is applied (x' = keep(x) / (1 - p)).
+ * drop_p > 0: then the dropout mask of bofi_linear_ex(drop_p, drop_seed, drop_step) is applied (x' = keep(x) / (1 - p)).
  * colsum (may be NULL): colsum[n] += sum_m x'[m][n] on the way (the bias gradient when x is dz) */
 int bofi_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int N, float* colsum, const float* relu_y, float drop_p,
-                   uint64_t drop_seed, void* stream);
-/* bofi_linear with every epilogue option of the training path: dropout as bofi_linear_dropout (drop_p 0: off) and
+                   uint64_t drop_seed, const uint64_t* drop_step, void* stream);
+/* bofi_linear with every epilogue option of the training path.  Dropout (drop_p 0: off):
+ * y = residual + keep(act(x w^T + bias)) / (1 - drop_p), keep(m, n) = hash(seed, m * N + n) >= drop_p * 2^32 with
+ * seed = drop_seed + (drop_step ? *drop_step : 0) -- drop_step is a DEVICE word, so a captured hipGraph draws fresh masks
+ * on every replay (SublayerConnection x + dropout(sublayer(norm(x))), TransformerModel.py:1361-1363; FFN dropout :1478);
  * y2 (may be NULL): a second copy of the output in the compute dtype, row stride ldy2 (N % 32 == 0) -- the operand of
  * the next GEMM / attention kernel, so that no separate cast pass is needed. */
 int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias,
                    const float* residual, int ldr, void* y, int y_dtype, int ldy, int M, int N, int K, int relu,
-                   const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, void* y2, int ldy2, void* stream);
-/* bofi_linear with the sublayer's dropout in the epilogue (operands in one compute dtype):
- * y = residual + keep(act(x w^T + bias)) / (1 - drop_p), keep(m, n) = hash(drop_seed, m * N + n) >= drop_p * 2^32
- * (SublayerConnection x + dropout(sublayer(norm(x))), TransformerModel.py:1361-1363; FFN inner dropout :1478). */
-int bofi_linear_dropout(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias,
-                        const float* residual, int ldr, void* y, int y_dtype, int ldy, int M, int N, int K, int relu,
-                        float drop_p, uint64_t drop_seed, void* stream);
+                   const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* y2,
+                   int ldy2, void* stream);
+
 /* y = (residual or 0) + keep(x) / (1 - p), keep mask = hash(seed, index) (nn.Dropout of the sublayers,
  * TransformerModel.py:1361-1363; the backward is the same call on dy with the same seed) */
-int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, void* stream);
+int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, const uint64_t* drop_step,
+                 void* stream);
 /* One optimiser step over a flat float32 bucket (n % 4 == 0, 16-byte aligned): g' = clamp(g * grad_scale, +-clip_value)
  * (clip_value <= 0: no clamp; train.py:225-226), then torch.optim.Adam's update with bias correction for `step` >= 1
  * (misc.py:245-251).  shadow_bf16 (may be NULL) receives a bf16 copy of the new parameters. */

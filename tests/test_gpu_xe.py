@@ -119,12 +119,12 @@ def test_logsoftmax_embed_dropout_backward():
     assert _maxdiff(td.grad, tr.grad) < 1e-3 and _maxdiff(sd_.grad, sr.grad) < 1e-3
     # dropout: keep rate, scaling, and the backward uses the forward's mask
     xd = torch.ones(400, 256, device="cuda", requires_grad=True)
-    y = xe.DropoutFn.apply(xd, None, 0.1, 12345)
+    y = xe.DropoutFn.apply(xd, None, 0.1, 12345, None)
     keep = (y != 0).float()
     assert abs(float(keep.mean()) - 0.9) < 0.01 and torch.allclose(y[y != 0], torch.tensor(1 / 0.9, device="cuda"))
     y.backward(torch.ones_like(y))
     assert torch.equal(xd.grad != 0, y != 0)
-    y2 = xe.DropoutFn.apply(xd, None, 0.1, 12346)
+    y2 = xe.DropoutFn.apply(xd, None, 0.1, 12346, None)
     assert not torch.equal(y2 != 0, y != 0)
 
 
@@ -394,7 +394,7 @@ def test_linear_with_epilogue_dropout_bf16(relu, res):
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
     r = torch.randn(M, N, generator=g) if res else None
     dy = torch.randn(M, N, generator=g)
-    mask = xe.DropoutFn.apply(torch.ones(M, N, device="cuda"), None, p, seed).cpu()        # keep / (1 - p)
+    mask = xe.DropoutFn.apply(torch.ones(M, N, device="cuda"), None, p, seed, None).cpu()        # keep / (1 - p)
     assert 0.6 < float((mask > 0).float().mean()) < 0.9
     bf = lambda t: t.to(torch.bfloat16).float()
     xr, wr, br = bf(x).requires_grad_(), bf(w).requires_grad_(), b.clone().requires_grad_()
@@ -406,7 +406,7 @@ def test_linear_with_epilogue_dropout_bf16(relu, res):
     xe._STEP_CACHE.clear()
     try:
         xd, wd, bd = x.clone().cuda().requires_grad_(), w.clone().cuda().requires_grad_(), b.clone().cuda().requires_grad_()
-        y = xe.linear(xd, wd, bd, residual=r.cuda() if res else None, relu=relu, drop=(p, seed))
+        y = xe.linear(xd, wd, bd, residual=r.cuda() if res else None, relu=relu, drop=(p, seed, None))
         y.backward(dy.cuda())
     finally:
         xe._COMPUTE["dtype"] = torch.float32
@@ -439,3 +439,34 @@ def test_tools_train_entry_point_writes_reference_checkpoints(tmp_path):
     out = subprocess.run(cmd + ["--start_from", ck, "--dtype", "f32"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "iter 6" in out.stdout
+
+
+def test_trainer_graph_replay_matches_eager_steps(weight_cache, manifest):
+    """The captured step (hipGraph of zero-grad + forward + criterion + backward) against eager steps: same losses and
+    weights with dropout off; with dropout on, replays draw fresh masks (the step word lives on the device)."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, eager_model = _model(weight_cache, manifest, "tiny_train_xe")
+    _, graph_model = _model(weight_cache, manifest, "tiny_train_xe")
+    eager_model.eval(); graph_model.eval()
+    opt = cfg.to_opt()
+    opt.noamopt, opt.learning_rate = False, 1e-3
+    te, tg = XETrainer(eager_model, opt), XETrainer(graph_model, opt, graph=True)
+    n_img, spi = 3, 4
+    batches = []
+    for seed in (1, 2, 3, 4):
+        hb = synthetic_training_batch(cfg, n_img, spi, seed=seed)
+        b = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+        b["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=seed)).cuda()
+        b["max_phrase_num"] = int(hb["phrase_num"].max())
+        batches.append(b)
+    for b in batches + batches:
+        le, _ = te.step(b)
+        lg, _ = tg.step(b)
+        assert abs(float(le) - float(lg)) < 2e-4 * max(1.0, abs(float(le)))
+    # Adam turns gradients that differ in the last bits (atomic accumulation order) into +-lr steps where |g| ~ eps
+    assert len(tg._graphs) >= 1 and float((tg.bucket.flat - te.bucket.flat).abs().mean()) < 2e-5 and _maxdiff(tg.bucket.flat, te.bucket.flat) < 8e-3
+    graph_model.train()
+    l1 = float(tg.step(batches[0])[0]); l2 = float(tg.step(batches[0])[0]); l3 = float(tg.step(batches[0])[0])
+    assert all(map(lambda v: v == v, (l1, l2, l3))) and len({round(l1, 5), round(l2, 5), round(l3, 5)}) == 3
