@@ -1,14 +1,14 @@
 // Weight-gradient GEMM of the training path:  C[i][j] += sum_m A[m][i] * B[m][j]   (dW = dz^T x)
 //
 // Both operands are row-major with the CONTRACTION index as the row -- the layout the activations already have -- so
-// no transposed copies are made: tiles of 32 rows go to LDS as they lie in HBM and the MFMA operands are gathered with
+// no transposed copies are made: tiles of 64 rows go to LDS as they lie in HBM and the MFMA operands are gathered with
 // the transposing LDS read of gfx950 (ds_read_b64_tr_b16), the same idiom attn_bf16.hip uses for P.V.  The contraction
 // runs over the rows of the batch (thousands) while the output is a weight matrix (often only 64 tiles), so the rows are
 // split across workgroups (blockIdx.z) and every workgroup adds its partial tile into C with float atomics -- C is the
 // trainer's gradient buffer, which accumulates by definition.
 //
 // bf16 operands, fp32 accumulation.  Workgroup = 4 wavefronts, tile 64 x 64, each wavefront 32 x 32 (2 x 2 MFMA
-// 16x16x32 tiles).  LDS: two stages x (A tile + B tile) x 32 rows x 128 B = 16 KB -> several workgroups per CU.
+// 16x16x32 tiles), 64 contraction rows per barrier.  LDS: two stages x (A tile + B tile) x 64 rows x 128 B = 32 KB.
 // 16-byte chunk c of LDS row r holds source chunk c ^ ((r >> 1) & 7): the 16 rows one transposing read touches then
 // fall in 16 different bank groups.
 #include "bofi_common.h"
@@ -26,7 +26,7 @@ struct GemmTnParams {
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
-    constexpr int T = 64, TM = 32;
+    constexpr int T = 64, TM = 64;                               // 64 contraction rows per barrier (two MFMA k-steps)
     __shared__ __attribute__((aligned(16))) bf16_t sa[2][TM * T];
     __shared__ __attribute__((aligned(16))) bf16_t sb[2][TM * T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,19 +39,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     const bool a_ok = i0 + lc * 8 < p.a_cols, b_ok = j0 + lc * 8 < p.b_cols;
     const int sw = (lc ^ ((lr >> 1) & 7)) * 8;
 
-    u32x4 va, vb;
+    u32x4 va[2], vb[2];
     auto load = [&](int m0) {
-        const int m = m0 + lr;
-        va = u32x4{0u, 0u, 0u, 0u};
-        vb = va;
-        if (m < m_end) {
-            if (a_ok) va = *reinterpret_cast<const u32x4*>(p.a + (size_t)m * p.lda + i0 + lc * 8);
-            if (b_ok) vb = *reinterpret_cast<const u32x4*>(p.b + (size_t)m * p.ldb + j0 + lc * 8);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int m = m0 + lr + 32 * hh;
+            va[hh] = u32x4{0u, 0u, 0u, 0u};
+            vb[hh] = va[hh];
+            if (m < m_end) {
+                if (a_ok) va[hh] = *reinterpret_cast<const u32x4*>(p.a + (size_t)m * p.lda + i0 + lc * 8);
+                if (b_ok) vb[hh] = *reinterpret_cast<const u32x4*>(p.b + (size_t)m * p.ldb + j0 + lc * 8);
+            }
         }
     };
     auto stash = [&](int buf) {
-        *reinterpret_cast<u32x4*>(&sa[buf][lr * T + sw]) = va;
-        *reinterpret_cast<u32x4*>(&sb[buf][lr * T + sw]) = vb;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {                          // row + 32 swizzles like row
+            *reinterpret_cast<u32x4*>(&sa[buf][(lr + 32 * hh) * T + sw]) = va[hh];
+            *reinterpret_cast<u32x4*>(&sb[buf][(lr + 32 * hh) * T + sw]) = vb[hh];
+        }
     };
 
     f32x4 acc[2][2];
@@ -62,8 +68,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 
     // operand gather: lane (g, tq, tp) addresses row 4g + tq (and + 16), columns 4tp .. 4tp + 3 of a 16-column block
     const int row0 = 4 * g + tq, rsw = (row0 >> 1) & 7;           // (row0 + 16) swizzles like row0
-    auto frag = [&](const bf16_t* tile, int col) -> bf16x8 {
-        const bf16_t* p0 = tile + row0 * T + (((col >> 3) ^ rsw) << 3) + (col & 7);
+    auto frag = [&](const bf16_t* tile, int col, int sub) -> bf16x8 {
+        const bf16_t* p0 = tile + (row0 + 32 * sub) * T + (((col >> 3) ^ rsw) << 3) + (col & 7);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * T));
         bf16x8 f;
@@ -79,16 +85,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     for (int m0 = m_begin; m0 < m_end; m0 += TM) {
         const bool more = m0 + TM < m_end;
         if (more) load(m0 + TM);                                  // next tile in flight while this one is multiplied
-        bf16x8 fa[2], fb[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            fa[t] = frag(sa[buf], wi + t * 16 + 4 * tp);
-            fb[t] = frag(sb[buf], wj + t * 16 + 4 * tp);
+        for (int sub = 0; sub < 2; ++sub) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = frag(sa[buf], wi + t * 16 + 4 * tp, sub);
+                fb[t] = frag(sb[buf], wj + t * 16 + 4 * tp, sub);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -116,7 +125,7 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
     const int ti = (NI + 63) / 64, tj = (NJ + 63) / 64;
     int splits = 1024 / (ti * tj);
     splits = max(1, min(splits, (M + 127) / 128));                 // at least 4 tiles of rows per workgroup
-    int mpb = ((M + splits - 1) / splits + 31) / 32 * 32;
+    int mpb = ((M + splits - 1) / splits + 63) / 64 * 64;
     splits = (M + mpb - 1) / mpb;
     GemmTnParams p{static_cast<const bf16_t*>(a), lda, a_cols, static_cast<const bf16_t*>(b), ldb, b_cols, c, ldc, M, NI, NJ, mpb};
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(ti, tj, splits), dim3(256), 0, st, p);

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Microbenchmark of the weight-gradient GEMM (bofi_gemm_tn_acc) on the shapes of the XE step: TFLOP/s per shape."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from boficap_amd import hip
+
+lib = hip.lib()
+for M, NI, NJ in ((6400, 512, 512), (6400, 1536, 512), (6400, 2048, 512), (6400, 512, 2048), (2304, 1024, 512), (6400, 9536, 512), (2304, 512, 2048)):
+    a = torch.randn(M, NI, device="cuda").to(torch.bfloat16)
+    b = torch.randn(M, NJ, device="cuda").to(torch.bfloat16)
+    c = torch.zeros(NI, NJ, device="cuda")
+    run = lambda: hip.check(lib.bofi_gemm_tn_acc(hip.ptr(a), NI, NI, hip.ptr(b), NJ, NJ, hip.ptr(c), NJ, M, NI, NJ, hip.stream_ptr()))
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    print(f"M={M:5d} NI={NI:5d} NJ={NJ:5d}  {us:8.1f} us  {2.0 * M * NI * NJ / us / 1e6:7.1f} TFLOP/s", flush=True)
