@@ -206,6 +206,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
         const int rc = launch_attention_bf16(a, st);
         if (rc >= 0) return rc;
     }
+    if (a.drop_thresh) return BOFI_ERR_ARG;             // attention dropout lives in the bf16 kernel only
     AttnParams p;
     p.q = a.q; p.ldq = a.ldq; p.k = a.k; p.ldk = a.ldk; p.v = a.v; p.ldv = a.ldv; p.out = a.out; p.ldo = a.ldo;
     p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;
@@ -228,11 +229,12 @@ extern "C" int bofi_attention(const void* q, int ldq, const void* k, int ldk, co
 
 extern "C" int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                                  int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq,
-                                 int klen_bias, void* stream) {
-    if (kdiv <= 0) return BOFI_ERR_ARG;
+                                 int klen_bias, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* stream) {
+    if (kdiv <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     bofi::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.dtype = dtype;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = klen_sq;
     a.klen_bias = klen_bias; a.kdiv = kdiv;
+    if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.drop_step = drop_step; }
     return bofi::launch_attention(a, (hipStream_t)stream);
 }

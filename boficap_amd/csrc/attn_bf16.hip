@@ -27,6 +27,7 @@ struct AttnParamsB {
     const int* klen; int klen_sb, klen_sq, klen_bias, klen_shared_last;
     const int* skip_if_ge; int skip_threshold;
     int kdiv;
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     }
 
     // ---- softmax over keys per query column; lane holds keys kj*16 + g*4 + r
+    const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.drop_step) ? *p.drop_step : 0ull);
     bf16x8 bp[NQT][NKT / 2];
 #pragma unroll
     for (int qi = 0; qi < NQT; ++qi) {
@@ -130,6 +132,10 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
                 const int kj = 2 * s + (j >> 2), r = j & 3;
                 float pv = st[kj][qi][r] / sum;
                 if (kl == 0 && kj * 16 + g * 4 + r >= Lk) pv = 0.f;      // padded keys of an empty row: V is 0 there
+                if (p.drop_thresh) {                                     // training: dropout(p_attn)
+                    const uint64_t e = ((uint64_t)(b * p.H + h) * p.Lq + q0 + qrow) * Lk + kj * 16 + g * 4 + r;
+                    pv = drop_hash(dseed, e) >= p.drop_thresh ? pv * p.drop_scale : 0.f;
+                }
                 f[j] = (short)f32_to_bf16(pv);
             }
             bp[qi][s] = f;
@@ -190,6 +196,7 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     p.klen = a.klen; p.klen_sb = a.klen_sb; p.klen_sq = a.klen_sq; p.klen_bias = a.klen_bias;
     p.klen_shared_last = a.klen_shared_last; p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
     p.kdiv = a.kdiv > 0 ? a.kdiv : 1;
+    p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
     const int nkt = a.Lk <= 32 ? 2 : 4;
     const int nqt = a.Lq <= 16 ? 1 : (a.Lq <= 32 ? 2 : 3);
     switch (nqt * 10 + nkt) {

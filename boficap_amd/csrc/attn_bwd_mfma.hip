@@ -23,6 +23,7 @@ struct AttnBwdMfmaParams {
     float* dq; int lddq; float* dk; float* dv; int lddk;
     int B, H, Lq, Lk, kdiv;
     const int* klen; int klen_sb, klen_sq, klen_bias;
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;     // dropout(p_attn) of the forward
 };
 
 // Head slice [rows_real, 64] -> LDS as bf16, rows past the data zero.  All global loads of the slice are issued before the
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
     // dK / dV in registers across them, so the shared rows are written once, without atomics
     const int bh = blockIdx.x, bk = bh / p.H, h = bh - bk * p.H;
     const int Lq = p.Lq, Lk = p.Lk;
+    const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.drop_step) ? *p.drop_step : 0ull);
 
     stage_rows<TIN, LK>(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, sk, DS, lane);
     stage_rows<TIN, LK>(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, sv, DS, lane);
@@ -170,15 +172,24 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
                 const float inv = sum > 0.f ? 1.f / sum : 0.f;
-                float dot = 0.f;
+                // forward: O = (P o M) V with M = keep / (1 - p); so dV uses P o M, and dP = (dO V^T) o M
+                float dot = 0.f, mk[KT];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) { e[kt] *= inv; dot += e[kt] * dP[qt][kt][r]; }
+                for (int kt = 0; kt < KT; ++kt) {
+                    mk[kt] = 1.f;
+                    if (p.drop_thresh) {
+                        const uint64_t ei = ((uint64_t)(b * p.H + h) * Lq + qrow) * Lk + kt * 16 + l15;
+                        mk[kt] = drop_hash(dseed, ei) >= p.drop_thresh ? p.drop_scale : 0.f;
+                    }
+                    e[kt] *= inv;
+                    dot += e[kt] * dP[qt][kt][r] * mk[kt];
+                }
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
-                    sp[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt]);
-                    sds[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * (dP[qt][kt][r] - dot) * 0.125f);
+                    sp[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * mk[kt]);
+                    sds[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * (dP[qt][kt][r] * mk[kt] - dot) * 0.125f);
                 }
             }
         __syncthreads();
@@ -246,15 +257,18 @@ static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
 
 extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
                                        const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H, int Lq,
-                                       int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, void* stream) {
+                                       int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, float drop_p,
+                                       uint64_t drop_seed, const uint64_t* drop_step, void* stream) {
     using namespace bofi;
-    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0 || B % kdiv) return BOFI_ERR_ARG;
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0 || B % kdiv || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
     const int el = in_dtype == BOFI_DT_F32 ? 4 : 2;
     if ((ldq * el) % 16 || (ldk * el) % 16 || (ldv * el) % 16 || ldo % 4 || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16) ||
         ((uintptr_t)dout % 16))
         return BOFI_ERR_ARG;
     if (B == 0) return BOFI_OK;
-    AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias};
+    AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias,
+                        0u, 1.f, drop_seed, drop_step};
+    if (drop_p > 0.f) { p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_scale = 1.0f / (1.0f - drop_p); }
     return in_dtype == BOFI_DT_F32 ? launch_t<float>(p, (hipStream_t)stream) : launch_t<bf16_t>(p, (hipStream_t)stream);
 }

@@ -52,6 +52,9 @@ struct AttnArgs {
     int klen_shared_last;     // quirk Q1: use entry (B-1) of klen for every batch item
     const int* skip_if_ge; int skip_threshold;
     int kdiv;                 // key/value batch item = b / kdiv (0 or 1: one per query batch item)
+    // training: dropout on the attention probabilities (TransformerModel.py:1430-1431), bf16 kernel only;
+    // keep(b, h, q, k) = drop_hash(seed, ((b*H + h)*Lq + q)*Lk + k) >= drop_thresh (0: off)
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible

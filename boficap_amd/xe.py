@@ -299,7 +299,7 @@ class AttentionFn(Function):
     qbuf may be the same tensor as kvbuf (packed q|k|v of a self-attention)."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias):
+    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop):
         qbuf, kvbuf = _need(qbuf, "attention q"), _need(kvbuf, "attention kv")
         if qbuf.shape[0] != B * Lq or kvbuf.shape[0] * kdiv != B * Lk:
             raise hip.BofiHipError(f"attention operand rows {qbuf.shape[0]}, {kvbuf.shape[0]} do not match B={B} Lq={Lq} Lk={Lk} kdiv={kdiv}")
@@ -316,14 +316,18 @@ class AttentionFn(Function):
             # ``out`` stays an unfilled placeholder
             ob = torch.empty(B * Lq, d, dtype=torch.bfloat16, device=qbuf.device)
             _chk(_lib().bofi_attention_ex(_off(qs, qoff), ldq, _off(kvs, koff), ldk, _off(kvs, voff), ldk, hip.ptr(ob), d, hip.DT_BF16, B, H,
-                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
+                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, drop[0] if drop else 0.0,
+                                          drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, hip.stream_ptr()), "bofi_attention_ex")
             _register_shadow(out, ob, only=True)
             ctx.save_for_backward(qs, kvs)
         else:
             _real(qbuf, "attention q"), _real(kvbuf, "attention kv")
+            drop = None                                        # dropout(p_attn) is built into the bf16 kernels only
             _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
-                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, hip.stream_ptr()), "bofi_attention_ex")
+                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, 0.0, 0, None, hip.stream_ptr()),
+                 "bofi_attention_ex")
             ctx.save_for_backward(qbuf, kvbuf)
+        ctx.drop = drop
         ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
         ctx.mfma = bf16                                        # bf16 mode: backward on the matrix cores
         ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
@@ -344,16 +348,20 @@ class AttentionFn(Function):
         if ctx.mfma:
             _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.dtype_code(qbuf),
                                                 hip.ptr(dout), H * 64, _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk,
-                                                kdiv, hip.ptr(ctx.klen), sb, sq, bias, hip.stream_ptr()), "bofi_attention_bwd_mfma")
-            return (dq, None if ctx.same else dkv) + (None,) * 12
+                                                kdiv, hip.ptr(ctx.klen), sb, sq, bias, ctx.drop[0] if ctx.drop else 0.0,
+                                                ctx.drop[1] if ctx.drop else 0, hip.ptr(ctx.drop[2]) if ctx.drop else None, hip.stream_ptr()),
+                 "bofi_attention_bwd_mfma")
+            return (dq, None if ctx.same else dkv) + (None,) * 13
         _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
                                        _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,
                                        hip.stream_ptr()), "bofi_attention_bwd")
-        return (dq, None if ctx.same else dkv) + (None,) * 12
+        return (dq, None if ctx.same else dkv) + (None,) * 13
 
 
-def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0):
-    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias)
+def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0, drop=None):
+    """``drop``: (p, seed, step word) dropout on the attention probabilities (TransformerModel.py:1430-1431); applied by the bf16
+    kernels (bf16 training mode with bf16 projections at hand), ignored by the float32 parity kernels."""
+    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop)
 
 
 class EmbedFn(Function):
@@ -466,6 +474,10 @@ class _Drop:
         """(p, seed, step word) for a kernel with built-in dropout."""
         return (self.p if p is None else p, self._next(), self.step_word)
 
+    def attn(self):
+        """Dropout site of an attention core (None when dropout is off)."""
+        return self.site() if self.on and self.p > 0.0 else None
+
     def __call__(self, x, residual=None, p=None):
         p = self.p if p is None else p
         if not self.on or p <= 0.0:
@@ -549,7 +561,7 @@ def encode_memory(P, cfg, att_feats, att_len, drop):
     for l in range(cfg.N_enc):
         p = f"model.encoder.layers.{l}"
         qkv = P.lin_packed(P.ln(x, p + ".sublayer.0.norm"), p + ".self_attn", (0, 1, 2))
-        ctx = attention(qkv, qkv, 0, d, 2 * d, B, cfg.h, R, R, 1, att_len, sb, 0, 0)
+        ctx = attention(qkv, qkv, 0, d, 2 * d, B, cfg.h, R, R, 1, att_len, sb, 0, 0, drop.attn())
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", x)
         x = _ffn(P, p + ".feed_forward", drop, P.ln(x, p + ".sublayer.1.norm"), x)
     return P.ln(x, "model.encoder.norm")
@@ -562,7 +574,7 @@ def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap
     q = P.lin(n, pre + ".linears.0", shadow=True)
     if pre not in kv_cache:
         kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
-    ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, (1 if att_len_cap is not None else 0), 0, 0)
+    ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, (1 if att_len_cap is not None else 0), 0, 0, drop.attn())
     return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
@@ -573,7 +585,7 @@ def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_
     for l in range(cfg.N_dec):
         p = f"model.decoder.layers.{l}"
         qkv = P.lin_packed(P.ln(x, p + ".sublayer.0.norm"), p + ".self_attn", (0, 1, 2))
-        ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0)
+        ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn())
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", x)
         x = _cross(P, p + ".src_attn", cfg, drop, P.ln(x, p + ".sublayer.1.norm"), x, memory, kv_cache, N, S, R, spi, att_len_cap)
         x = _ffn(P, p + ".feed_forward", drop, P.ln(x, p + ".sublayer.2.norm"), x)
@@ -597,7 +609,7 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     q0 = P.lin(n0, p + ".self_attn.linears.0")
     qv = q0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
     xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
-    ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0)
+    ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0, drop.attn())
     x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xv)
     x = _cross(P, p + ".src_attn", cfg, drop, P.ln(x, p + ".sublayer.1.norm"), x, memory, kv_cache, N, Pm, R, spi, att_len_cap)
     x = _ffn(P, p + ".ff", drop, P.ln(x, p + ".sublayer.2.norm"), x)

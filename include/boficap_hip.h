@@ -82,10 +82,13 @@ int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, 
 
 /* bofi_attention with the two extra knobs of the training path: effective key count =
  * klen[...] + klen_bias, and key/value batch item = b / kdiv (the seq_per_img captions of one image
- * attend the image's memory without repeating it; the reference repeats it, models/utils.py:3-14). */
+ * attend the image's memory without repeating it; the reference repeats it, models/utils.py:3-14).
+ * drop_p > 0 (bf16, Lk <= 64 only): dropout on the attention probabilities (TransformerModel.py:1430-1431),
+ * keep(b, h, q, k) = hash(drop_seed + *drop_step, ((b*H + h)*Lq + q)*Lk + k) >= drop_p * 2^32, kept ones / (1 - drop_p). */
 int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                       int ldo, int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen,
-                      int klen_sb, int klen_sq, int klen_bias, void* stream);
+                      int klen_sb, int klen_sq, int klen_bias, float drop_p, uint64_t drop_seed,
+                      const uint64_t* drop_step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training ops (float32).  The reference trains by running torch autograd over
@@ -103,10 +106,12 @@ int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const f
                        void* stream);
 /* the same backward on the matrix cores: q/k/v float32 or bf16 (in_dtype), products in bf16 with fp32 accumulation,
  * operands gathered with transposing LDS reads; dq row stride lddq, dk/dv row stride lddk (float32), WRITTEN (not
- * accumulated) also when kdiv > 1: one wavefront owns an (image, head) and sums over its captions in registers */
+ * accumulated) also when kdiv > 1: one wavefront owns an (image, head) and sums over its captions in registers;
+ * drop_*: the dropout of the forward's attention probabilities, regenerated from the same (seed, index) */
 int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
                             const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H,
-                            int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, void* stream);
+                            int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, float drop_p,
+                            uint64_t drop_seed, const uint64_t* drop_step, void* stream);
 /* backward of log_softmax given the log-probabilities y: dx = dy - exp(y) * rowsum(dy) */
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */

@@ -95,6 +95,60 @@ def test_attention_backward(B, Lq, Lk, kdiv, same, mfma):
         assert _maxdiff(kd.grad, kr.grad) < tol * max(1.0, float(kr.grad.abs().max()))
 
 
+def test_attention_probability_dropout_bf16():
+    """dropout(p_attn) inside the bf16 attention forward and the MFMA backward: against a float64 reference that
+    applies the SAME keep mask (recovered from a run with V = identity-like probes), and rate / scaling checks."""
+    from boficap_amd import xe
+    B, H, L, d, p, seed = 3, 2, 20, 128, 0.3, 4242
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * L, 3 * d, generator=g)
+    klen = torch.randint(4, L + 1, (B, L), generator=g).int()
+    dout = torch.randn(B * L, d, generator=g)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    xe._COMPUTE["dtype"] = torch.bfloat16
+    xe._STEP_CACHE.clear(); xe._SHADOW_ONLY.clear()
+    try:
+        def run(qkv_t, drop):
+            x = qkv_t.clone().cuda().requires_grad_()
+            xe._register_shadow(x, x.detach().to(torch.bfloat16))
+            out = xe.attention(x, x, 0, d, 2 * d, B, H, L, L, 1, klen.cuda().contiguous(), L, 1, 0, drop)
+            return x, out, xe._shadow(out).float().cpu()
+        # recover the mask: with v = one-hot(key) per head dim the context row IS the dropped probability row
+        probe = qkv.clone()
+        probe[:, 2 * d:] = 0
+        for b in range(B):
+            for k in range(L):
+                for h in range(H):
+                    probe[b * L + k, 2 * d + h * 64 + k] = 1.0
+        _, _, ctx_nodrop = run(probe, None)
+        _, _, ctx_drop = run(probe, (p, seed, None))
+        P0 = ctx_nodrop.view(B, L, H, 64)[..., :L]             # [b, q, h, k]
+        Pd = ctx_drop.view(B, L, H, 64)[..., :L]
+        valid = (torch.arange(L).view(1, 1, 1, L) < klen.view(B, L, 1, 1)) & (P0 > 1e-3)
+        keep = Pd > 0
+        rate = float(keep[valid].float().mean())
+        assert abs(rate - (1 - p)) < 0.05, rate
+        assert torch.allclose(Pd[valid & keep], P0[valid & keep] / (1 - p), rtol=3e-2, atol=2e-3)
+        mask = torch.where(keep, torch.tensor(1 / (1 - p)), torch.tensor(0.0)).permute(0, 2, 1, 3)      # [b, h, q, k]
+        # full forward / backward with that mask in float64-ish torch
+        xr = bf(qkv).clone().requires_grad_()
+        q = xr[:, :d].reshape(B, L, H, 64).transpose(1, 2)
+        k = xr[:, d:2 * d].reshape(B, L, H, 64).transpose(1, 2)
+        v = xr[:, 2 * d:].reshape(B, L, H, 64).transpose(1, 2)
+        s_ = q @ k.transpose(-1, -2) / 8.0
+        km = torch.arange(L).view(1, 1, 1, L) < klen.view(B, 1, L, 1)
+        pr = torch.softmax(s_.masked_fill(~km, float("-inf")), -1) * mask
+        ref = (pr @ v).transpose(1, 2).reshape(B * L, d)
+        ref.backward(dout)
+        x, out, ctx = run(qkv, (p, seed, None))
+        assert _maxdiff(ctx, ref) < 3e-2
+        out.backward(dout.cuda())
+        assert _maxdiff(x.grad, xr.grad) < 3e-2 * max(1.0, float(xr.grad.abs().max()))
+    finally:
+        xe._COMPUTE["dtype"] = torch.float32
+        xe._STEP_CACHE.clear(); xe._SHADOW_ONLY.clear()
+
+
 def test_logsoftmax_embed_dropout_backward():
     from boficap_amd import xe
     g = torch.Generator().manual_seed(11)
