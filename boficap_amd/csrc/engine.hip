@@ -505,6 +505,10 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     return BOFI_OK;
 }
 
+const float* bofi_engine_logprob(bofi_engine_t* e) {
+    return e ? e->logits : nullptr;
+}
+
 void* bofi_engine_stream(bofi_engine_t* e) {
     if (!e) return nullptr;
     if (!e->run_stream && hipStreamCreateWithFlags(&e->run_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;

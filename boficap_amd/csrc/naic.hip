@@ -553,7 +553,86 @@ int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax
     return BOFI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Consumers of the finished [rows, V] log-prob tensor that do not need it in user memory.
+//
+// vocab_stats: per row, sum_v p_v * logp_v and the log-prob of the emitted id -- the two reductions eval needs for its
+// per-image entropy / perplexity (captioning/utils/eval_utils.py:463-464), so a caller can skip materialising the
+// 48.6 MB tensor.
+__global__ __launch_bounds__(256) void vocab_stats_kernel(const float* __restrict__ logp, const int64_t* __restrict__ seq, int V,
+                                                          float* __restrict__ row_plogp, float* __restrict__ row_chosen) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* x = logp + (size_t)row * V;
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) { const float t = x[i]; s += expf(t) * t; }       // softmax(logp) == exp(logp)
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        row_plogp[row] = (red[0] + red[1]) + (red[2] + red[3]);
+        row_chosen[row] = x[seq[row]];
+    }
+}
+
+// vocab_sample: `n` independent draws per row from Categorical(logits = logp / temperature) (CaptionModel.py:419-425; a
+// NaN log-prob counts as -10 as there) by the Gumbel-max rule with a counter-hash uniform; draw c of image b goes to
+// row b * n + c of the output (models/utils.py:3-14 repeats each image n times), ids past the image's token count are pad.
+__global__ __launch_bounds__(256) void vocab_sample_kernel(const float* __restrict__ logp, int V, int S, int n, float inv_temp, uint64_t seed,
+                                                           const int* __restrict__ ntok, int pad_idx, int64_t* __restrict__ out) {
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = row / S, t = row - b * S;
+    const float* x = logp + (size_t)row * V;
+    for (int c = 0; c < n; ++c) {
+        float bv = -INFINITY;
+        int bi = 0;
+        const uint64_t base = ((uint64_t)row * n + c) * (uint64_t)V;
+        for (int i = tid; i < V; i += 256) {
+            float lp = x[i];
+            if (lp != lp) lp = -10.f;
+            const float u = ((float)drop_hash(seed, base + i) + 0.5f) * (1.0f / 4294967296.0f);
+            const float gv = lp * inv_temp - logf(-logf(u));
+            if (gv > bv) { bv = gv; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+            if (ntok && t >= ntok[b]) bi = pad_idx;
+            out[((size_t)b * n + c) * S + t] = bi;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace bofi
+
+extern "C" int bofi_vocab_stats(const float* logp, const int64_t* seq, int rows, int V, float* row_plogp, float* row_chosen, void* stream) {
+    if (!logp || !seq || !row_plogp || !row_chosen || rows < 0 || V <= 0) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(bofi::vocab_stats_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logp, seq, V, row_plogp, row_chosen);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok,
+                                 int pad_idx, int64_t* out, void* stream) {
+    if (!logp || !out || rows < 0 || V <= 0 || S <= 0 || rows % S || n <= 0 || !(temperature > 0.f)) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(bofi::vocab_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logp, V, S, n, 1.0f / temperature, seed, ntok,
+                       pad_idx, out);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
 
 extern "C" int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int pad_idx,
                                    int64_t* seq, void* stream) {

@@ -144,6 +144,38 @@ class BofiEngine:
             hip.ptr(out["memory"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_naic")
         return out
 
+    def row_stats(self, out: dict):
+        """(sum_v p log p, log-prob of the emitted id) per position, float32 [B, S] each, of the decode that produced ``out`` --
+        from its seq_logprob tensor, or from the engine's own workspace when that was not materialised."""
+        seq = out["seq"]
+        B, S = seq.shape
+        lp = out.get("seq_logprob")
+        src = hip.ptr(lp) if lp is not None else self._lib.bofi_engine_logprob(self._h)
+        plogp = torch.empty(B, S, dtype=torch.float32, device=seq.device)
+        chosen = torch.empty(B, S, dtype=torch.float32, device=seq.device)
+        hip.check(self._lib.bofi_vocab_stats(src, hip.ptr(seq), B * S, self.cfg.tgt_vocab, hip.ptr(plogp), hip.ptr(chosen), hip.stream_ptr()),
+                  "bofi_vocab_stats")
+        return plogp, chosen
+
+    def entropy_perplexity(self, out: dict, vocab_lower: int = 0):
+        """Per-image entropy and perplexity exactly as eval computes them (captioning/utils/eval_utils.py:463-464)."""
+        plogp, chosen = self.row_stats(out)
+        denom = (out["seq"] > vocab_lower).to(torch.float32).sum(1) + 1
+        return -plogp.sum(1) / denom, -chosen.sum(1) / denom
+
+    def sample_tokens(self, out: dict, n: int = 1, temperature: float = 1.0, seed: int = 0) -> torch.Tensor:
+        """``n`` sampled captions per image on the slot layout of ``out`` (sample_method 'sample', CaptionModel.py:405-425):
+        int64 [B * n, S], image b's draws in rows b*n .. b*n+n-1."""
+        seq = out["seq"]
+        B, S = seq.shape
+        lp = out.get("seq_logprob")
+        src = hip.ptr(lp) if lp is not None else self._lib.bofi_engine_logprob(self._h)
+        ntok = out["phrase_length"].sum(1).to(torch.int32).contiguous()
+        res = torch.empty(B * n, S, dtype=torch.int64, device=seq.device)
+        hip.check(self._lib.bofi_vocab_sample(src, B * S, self.cfg.tgt_vocab, S, n, float(temperature), seed & 0xFFFFFFFFFFFFFFFF, hip.ptr(ntok),
+                                              self.cfg.pad_idx, hip.ptr(res), hip.stream_ptr()), "bofi_vocab_sample")
+        return res
+
     def decode_saic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, raw_logits: bool = False,
                     want_logprob: bool = True) -> dict:
         """Greedy semi-autoregressive decode (core_SAIC).  Same result layout as ``decode_naic``."""

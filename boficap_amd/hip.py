@@ -53,6 +53,9 @@ SIGNATURES = {
     "bofi_dropout": (_I, [_P, _P, _P, _I64, C.c_float, C.c_uint64, _P, _P]),
     "bofi_adam_step": (_I, [_P, _P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, _I, C.c_float, C.c_float, _P]),
     "bofi_relu_bwd": (_I, [_P, _P, _P, _I64, _P]),
+    "bofi_vocab_stats": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "bofi_vocab_sample": (_I, [_P, _I, _I, _I, _I, C.c_float, C.c_uint64, _P, _I, _P, _P]),
+    "bofi_engine_logprob": (_P, [_P]),
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),

@@ -142,8 +142,12 @@ class TransformerModel(nn.Module):
             raise NotImplementedError("beam / diverse sampling are AR-only host-side paths (out of scope, SURVEY.md §2 row 10)")
         if train_mode not in ("NAIC", "SAIC"):
             raise NotImplementedError(f"inference mode {train_mode!r}: a UIC model decodes in 'NAIC' or 'SAIC' mode")
-        if sample_method != "greedy":
-            raise NotImplementedError(f"sample_method {sample_method!r}: only greedy decode is built so far")
+        temperature = float(opt.get("temperature", 1.0))
+        if sample_method not in ("greedy", "sample"):
+            raise NotImplementedError(f"sample_method {sample_method!r}: greedy and 'sample' (Categorical) are built; "
+                                      "gumbel / top-k / top-p are autoregressive-path options")
+        if sample_method == "sample" and train_mode == "SAIC":
+            raise NotImplementedError("sampling inside the semi-autoregressive loop (core_SAIC with sample_method='sample') is not built")
         eng = self.engine()
         torch.cuda.synchronize()                                  # the reference does (AttModel.py:337)
         start = time.time()
@@ -155,8 +159,12 @@ class TransformerModel(nn.Module):
         torch.cuda.synchronize()
         end = time.time()
         outs = [r["seq"], r["seq_logprob"], r["phrase_num"], r["phrase_length"], r["phrase_syn"]]
-        if sample_n > 1:                                          # greedy: n identical copies (models/utils.py:3-14)
+        if sample_n > 1:                                          # the bound is deterministic: n identical layouts (models/utils.py:3-14)
             outs = [o.repeat_interleave(sample_n, dim=0) for o in outs]
+        if sample_method == "sample":                             # tokens drawn per copy from the fill distribution (CaptionModel.py:405-425)
+            self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+            seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._sample_calls
+            outs[0] = eng.sample_tokens(r, sample_n, temperature, seed)
         return (*outs, end - start)
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None, phrase_num=None, phrase_length=None, phrase_syn=None,

@@ -158,6 +158,15 @@ int bofi_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf
 /* dx = dy where y > 0 */
 int bofi_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
 
+/* Per row sum_v exp(logp_v) * logp_v and logp[row, seq[row]]: the reductions behind eval's per-image entropy and
+ * perplexity (captioning/utils/eval_utils.py:463-464) without reading the distribution back in user code. */
+int bofi_vocab_stats(const float* logp, const int64_t* seq, int rows, int V, float* row_plogp, float* row_chosen, void* stream);
+/* n draws per row from Categorical(logits = logp / temperature) (sample_next_word, CaptionModel.py:405-425; NaN counts as
+ * -10): Gumbel-max with a counter-hash uniform.  out int64 [(rows / S) * n, S], draw c of image b in row b * n + c
+ * (the reference repeats each image n times, models/utils.py:3-14); positions >= ntok[b] get pad_idx (AttModel.py:422-423). */
+int bofi_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok,
+                      int pad_idx, int64_t* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Engine level: the whole NAIC bound+fill decode as one call.
  * ------------------------------------------------------------------------------------------- */
@@ -197,6 +206,11 @@ int bofi_engine_finalize(bofi_engine_t* e);
  * CUs idle; a batch in another stream fills them).  The parent must outlive its forks and must not be
  * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
 int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
+
+/* Device pointer of the engine's own [max_batch * S, V] float32 log-prob workspace: where a decode called WITHOUT a
+ * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of
+ * bofi_vocab_stats / bofi_vocab_sample when the 48.6 MB tensor is not wanted in user memory. */
+const float* bofi_engine_logprob(bofi_engine_t* e);
 
 /* A HIP stream owned by the engine (hipStream_t as void*), for callers that keep one decode per engine in
  * flight and want each on its own hardware queue. */

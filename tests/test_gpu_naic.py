@@ -300,3 +300,58 @@ def test_drop_in_module_sample(weight_cache, manifest):
     assert (seq.cpu().numpy() == g["saic_seq"]).all() and (pl.cpu().numpy() == g["saic_phrase_length"]).all()
     with pytest.raises(NotImplementedError):
         model(fc, att, None, opt={"train_mode": "AIC"}, mode="sample")
+
+
+def test_entropy_perplexity_without_materialising_logprobs(engines):
+    """eval's per-image entropy / perplexity (eval_utils.py:463-464) from the fused row reductions, with the log-prob
+    tensor in user memory and with it left in the engine's workspace."""
+    import torch.nn.functional as F
+    cfg, sd, eng = engines("tiny_mix", torch.float32)
+    att, att_len = _inputs(load_golden("tiny_mix"))
+    r = eng.decode_naic(att, att_len)
+    lp, seq = r["seq_logprob"], r["seq"]
+    denom = (seq > 0).to(lp).sum(1) + 1
+    ent_ref = -(F.softmax(lp, dim=2) * lp).sum(2).sum(1) / denom
+    ppl_ref = -lp.gather(2, seq.unsqueeze(2)).squeeze(2).sum(1) / denom
+    ent, ppl = eng.entropy_perplexity(r)
+    assert _close(ent.cpu().numpy(), ent_ref.cpu().numpy(), 0) < 1e-4 and _close(ppl.cpu().numpy(), ppl_ref.cpu().numpy(), 0) < 1e-4
+    r2 = eng.decode_naic(att, att_len, want_logprob=False)
+    assert r2["seq_logprob"] is None and torch.equal(r2["seq"], seq)
+    ent2, ppl2 = eng.entropy_perplexity(r2)
+    assert _close(ent2.cpu().numpy(), ent_ref.cpu().numpy(), 0) < 1e-4 and _close(ppl2.cpu().numpy(), ppl_ref.cpu().numpy(), 0) < 1e-4
+
+
+def test_sampled_tokens_follow_the_fill_distribution(weight_cache, manifest):
+    """sample_method='sample' (Categorical(logits = logp / T), CaptionModel.py:405-425): empirical frequencies of many
+    draws against softmax(logp / T), pad after the caption length, the reference's row layout for sample_n."""
+    import captioning.models as models
+    m = manifest["tiny_mix"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    g = load_golden("tiny_mix")
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    att = torch.from_numpy(g["att_feats"]).cuda()
+    fc = torch.zeros(att.size(0), 0, device="cuda")
+    B, n, T = att.size(0), 3000, 0.7
+    with torch.no_grad():
+        seq, lp, pn, pl, ps, _ = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "sample", "sample_n": n, "temperature": T},
+                                       mode="sample")
+        greedy = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "greedy"}, mode="sample")
+    assert seq.shape == (B * n, cfg.seq_length) and lp.shape[0] == B * n and pl.shape[0] == B * n
+    assert torch.equal(pl[::n], greedy[3]) and torch.equal(lp[::n], greedy[1])              # layouts / distributions are per image
+    ntok = greedy[3].sum(1)
+    seq = seq.view(B, n, -1)
+    for b in range(B):
+        k = int(ntok[b])
+        assert (seq[b, :, k:] == 0).all()
+        if k == 0 or greedy[1][b].isnan().any():
+            continue
+        probs = torch.softmax(greedy[1][b, 0] / T, -1)                                      # position 0 of image b
+        freq = torch.bincount(seq[b, :, 0], minlength=probs.numel()).float() / n
+        assert float((freq - probs).abs().max()) < 0.035, float((freq - probs).abs().max())
+    again = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "sample", "sample_n": 2}, mode="sample")[0]
+    again2 = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "sample", "sample_n": 2}, mode="sample")[0]
+    assert not torch.equal(again, again2)                                                  # a new seed per call
+    with pytest.raises(NotImplementedError):
+        model(fc, att, None, opt={"train_mode": "SAIC", "sample_method": "sample"}, mode="sample")

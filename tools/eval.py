@@ -61,11 +61,14 @@ def main():
         for i in range(0, len(feats), args.batch_size):
             att = torch.from_numpy(np.ascontiguousarray(feats[i:i + args.batch_size])).cuda()
             fc = torch.zeros(att.size(0), 0, device="cuda")
-            seq, _, pn, pl, ps, t = model(fc, att, None, opt={"train_mode": args.inference_mode, "sample_method": "greedy", "sample_n": 1}, mode="sample")
+            seq, lp, pn, pl, ps, t = model(fc, att, None, opt={"train_mode": args.inference_mode, "sample_method": "greedy", "sample_n": 1}, mode="sample")
             seconds += t
+            # per-image entropy / perplexity as eval_utils.py:463-464, from the fused row reductions (bofi_vocab_stats)
+            ent, ppl = model.engine().entropy_perplexity({"seq": seq, "seq_logprob": lp})
             for k in range(att.size(0)):
                 ids = [int(v) for v in seq[k].tolist() if v > 0]
-                entry = {"image_id": i + k, "seq": ids, "phrase_num": int(pn[k]), "phrase_length": [int(v) for v in pl[k].tolist() if v > 0]}
+                entry = {"image_id": i + k, "seq": ids, "phrase_num": int(pn[k]), "phrase_length": [int(v) for v in pl[k].tolist() if v > 0],
+                         "entropy": float(ent[k]), "perplexity": float(ppl[k])}
                 if vocab:
                     entry["caption"] = " ".join(vocab.get(str(v), "UNK") for v in ids if v > 6)
                 results.append(entry)
