@@ -62,4 +62,7 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.h
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
                           int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr);
 
+int launch_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok, int pad_idx,
+                        int64_t* out, hipStream_t st, const int* halt = nullptr);
+
 }  // namespace bofi

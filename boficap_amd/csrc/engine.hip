@@ -91,6 +91,8 @@ struct bofi_engine {
     void* b_q0_sa = nullptr; float* b_x0_sa = nullptr;                  // row-0 constants when position 0 holds tgt_embed([LEN])
 
     hipStream_t cap_stream = nullptr;
+    float sample_temperature = 1.0f;      // BOFI_FLAG_SAMPLE: token draws inside the semi-autoregressive loop
+    uint64_t sample_seed = 0;
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
 
@@ -446,6 +448,9 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
         { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, logits, BOFI_DT_F32, cfg.vocab, M, o, s)); }
         ENG_OK(bofi::launch_vocab_finalize(logits, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, nullptr, 0, cfg.pad_idx, tok64, s,
                                            st.counters + 3, halt));
+        if (flags & BOFI_FLAG_SAMPLE)          // sample_next_word 'sample' (CaptionModel.py:405-425): the drawn ids feed the next bound step
+            ENG_OK(bofi::launch_vocab_sample(logits, M, cfg.vocab, S, 1, sample_temperature, sample_seed + (uint64_t)it * 0x9E3779B97F4A7C15ull, nullptr,
+                                             cfg.pad_idx, tok64, s, halt));
         ENG_OK(bofi::launch_saic_copy(st, sa, tok64, logits, seq_logprob, B, L, S, cfg.vocab, it, s));
     }
     ENG_OK(bofi::launch_saic_export(st, sa, B, L, S, seq, phrase_num, phrase_length, phrase_syn, bound_iters, s));
@@ -502,6 +507,13 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
     if (rc != BOFI_OK) { bofi_engine_destroy(e); return rc; }
     *out = e;
+    return BOFI_OK;
+}
+
+int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed) {
+    if (!e || !(temperature > 0.f)) return fail(BOFI_ERR_ARG, "temperature must be positive");
+    e->sample_temperature = temperature;
+    e->sample_seed = seed;
     return BOFI_OK;
 }
 

@@ -579,9 +579,11 @@ __global__ __launch_bounds__(256) void vocab_stats_kernel(const float* __restric
 // NaN log-prob counts as -10 as there) by the Gumbel-max rule with a counter-hash uniform; draw c of image b goes to
 // row b * n + c of the output (models/utils.py:3-14 repeats each image n times), ids past the image's token count are pad.
 __global__ __launch_bounds__(256) void vocab_sample_kernel(const float* __restrict__ logp, int V, int S, int n, float inv_temp, uint64_t seed,
-                                                           const int* __restrict__ ntok, int pad_idx, int64_t* __restrict__ out) {
+                                                           const int* __restrict__ ntok, int pad_idx, int64_t* __restrict__ out,
+                                                           const int* halt) {
     __shared__ float redv[4];
     __shared__ int redi[4];
+    if (halt && *halt >= 1) return;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = row / S, t = row - b * S;
     const float* x = logp + (size_t)row * V;
@@ -614,6 +616,15 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const float* __restri
     }
 }
 
+int launch_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok, int pad_idx,
+                        int64_t* out, hipStream_t st, const int* halt) {
+    if (!logp || !out || rows < 0 || V <= 0 || S <= 0 || rows % S || n <= 0 || !(temperature > 0.f)) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(vocab_sample_kernel, dim3(rows), dim3(256), 0, st, logp, V, S, n, 1.0f / temperature, seed, ntok, pad_idx, out, halt);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 }  // namespace bofi
 
 extern "C" int bofi_vocab_stats(const float* logp, const int64_t* seq, int rows, int V, float* row_plogp, float* row_chosen, void* stream) {
@@ -626,12 +637,7 @@ extern "C" int bofi_vocab_stats(const float* logp, const int64_t* seq, int rows,
 
 extern "C" int bofi_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok,
                                  int pad_idx, int64_t* out, void* stream) {
-    if (!logp || !out || rows < 0 || V <= 0 || S <= 0 || rows % S || n <= 0 || !(temperature > 0.f)) return BOFI_ERR_ARG;
-    if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(bofi::vocab_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logp, V, S, n, 1.0f / temperature, seed, ntok,
-                       pad_idx, out);
-    BOFI_CHECK_LAUNCH();
-    return BOFI_OK;
+    return bofi::launch_vocab_sample(logp, rows, V, S, n, temperature, seed, ntok, pad_idx, out, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int pad_idx,

@@ -177,8 +177,10 @@ class BofiEngine:
         return res
 
     def decode_saic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, raw_logits: bool = False,
-                    want_logprob: bool = True) -> dict:
-        """Greedy semi-autoregressive decode (core_SAIC).  Same result layout as ``decode_naic``."""
+                    want_logprob: bool = True, sample: Optional[tuple] = None) -> dict:
+        """Semi-autoregressive decode (core_SAIC), greedy or -- ``sample=(temperature, seed)`` -- with every phrase's tokens
+        drawn from Categorical(logits / temperature) (the bound heads stay greedy, as in the reference).  Same result
+        layout as ``decode_naic``."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
@@ -189,8 +191,12 @@ class BofiEngine:
             phrase_length=torch.empty(B, S, dtype=torch.int32, device=dev),
             phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
             bound_iters=torch.empty(1, dtype=torch.int32, device=dev), memory=None)
+        flags = hip.FLAG_RAW_LOGITS if raw_logits else 0
+        if sample is not None:
+            hip.check(self._lib.bofi_engine_set_sampling(self._h, float(sample[0]), int(sample[1]) & 0xFFFFFFFFFFFFFFFF), "bofi_engine_set_sampling")
+            flags |= hip.FLAG_SAMPLE
         hip.check(self._lib.bofi_engine_decode_saic(
-            self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, hip.FLAG_RAW_LOGITS if raw_logits else 0,
+            self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, flags,
             hip.ptr(out["seq"]), hip.ptr(out["seq_logprob"]), hip.ptr(out["phrase_num"]), hip.ptr(out["phrase_length"]),
             hip.ptr(out["phrase_syn"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_saic")
         return out

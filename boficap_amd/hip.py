@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libboficap_hip.so")
 DT_F32, DT_BF16 = 0, 1
 FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
 FLAG_REFINE_SHIFT = 8
+FLAG_SAMPLE = 16
 ABI_VERSION = 1
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "bofi_vocab_stats": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "bofi_vocab_sample": (_I, [_P, _I, _I, _I, _I, C.c_float, C.c_uint64, _P, _I, _P, _P]),
     "bofi_engine_logprob": (_P, [_P]),
+    "bofi_engine_set_sampling": (_I, [_P, C.c_float, C.c_uint64]),
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),

@@ -204,6 +204,43 @@ class XETrainer:
         self.optimizer_step(scale)
         return loss, parts
 
+    # ------------------------------------------------------------------ self-critical step (loss_wrapper.py:181-230, structure_loss_weight 1)
+    def rl_step(self, att_feats, att_masks, score_fn, *, sample_n: int = 5, temperature: float = 1.0):
+        """One self-critical step of a UIC model: sample ``sample_n`` captions per image in SAIC and in NAIC mode on the decode
+        engine (no tape), score them with ``score_fn(seq int64 [N, S] on the host) -> [N] floats`` (the external CIDEr-D scorer of
+        captioning/utils/rewards.py in the reference), recompute the samples' log-probs with the tape
+        (``xe.sampled_logprobs``), loss = new_self_critical(SAIC) + new_self_critical(NAIC), backward, all-reduce, Adam.
+        Returns (loss, mean SAIC score, mean NAIC score)."""
+        from . import xe
+        model = self.model
+        fc = torch.zeros(att_feats.shape[0], 0, device=att_feats.device)
+        was_training = model.training
+        model.eval()                                           # sampling runs on the inference engine (no dropout)
+        with torch.no_grad():
+            opt = {"sample_method": "sample", "sample_n": sample_n, "temperature": temperature, "output_logsoftmax": 1}
+            ks = ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")
+            saic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="SAIC"), mode="sample")[:5]))
+            naic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
+        model.train(was_training)
+        s_saic, s_naic = score_fn(saic["seq"].cpu()), score_fn(naic["seq"].cpu())
+        self.bucket.zero_grad()
+        self._fwd_calls += 1
+        step_word = getattr(self, "_step_word", None)
+        if step_word is not None:
+            step_word.fill_(self._fwd_calls)
+        base = int(getattr(model.opt, "seed", 0)) << 32
+        lp_saic, lp_naic = xe.sampled_logprobs(xe.Params(model), model.cfg, att_feats, att_masks, saic, naic, sample_n=sample_n,
+                                               strict_q1=model.strict_reference, training=model.training,
+                                               seed=base if step_word is not None else base + self._fwd_calls,
+                                               compute_dtype=model.train_dtype, step_word=step_word)
+        l1, r1 = xe.new_self_critical(lp_saic, saic["seq"], s_saic, sample_n)
+        l2, r2 = xe.new_self_critical(lp_naic, naic["seq"], s_naic, sample_n)
+        loss = l1 + l2
+        loss.backward()
+        scale = self.bucket.all_reduce(self.group)
+        self.optimizer_step(scale)
+        return loss.detach(), r1.mean(), r2.mean()
+
     # ------------------------------------------------------------------ checkpoint (optimizer.pth of misc.py:87-102)
     def state_dict(self):
         return {"_step": self._step, "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu()}

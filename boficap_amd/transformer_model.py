@@ -146,18 +146,30 @@ class TransformerModel(nn.Module):
         if sample_method not in ("greedy", "sample"):
             raise NotImplementedError(f"sample_method {sample_method!r}: greedy and 'sample' (Categorical) are built; "
                                       "gumbel / top-k / top-p are autoregressive-path options")
-        if sample_method == "sample" and train_mode == "SAIC":
-            raise NotImplementedError("sampling inside the semi-autoregressive loop (core_SAIC with sample_method='sample') is not built")
         eng = self.engine()
         torch.cuda.synchronize()                                  # the reference does (AttModel.py:337)
         start = time.time()
         if train_mode == "NAIC":
             r = eng.decode_naic(self._as_input(att_feats), self._att_len(att_masks), strict_q1=self.strict_reference,
                                 raw_logits=not output_logsoftmax)
-        else:                                                     # core_SAIC, AttModel.py:430-437
+        elif sample_method == "greedy":                           # core_SAIC, AttModel.py:430-437
             r = eng.decode_saic(self._as_input(att_feats), self._att_len(att_masks), raw_logits=not output_logsoftmax)
+        else:
+            # sampled tokens feed the next bound step, so the sample_n copies of an image diverge: decode B * n rows
+            # (the reference repeats features and masks the same way, AttModel.py:331-334)
+            feats, lens = self._as_input(att_feats), self._att_len(att_masks)
+            if sample_n > 1:
+                feats = feats.repeat_interleave(sample_n, dim=0).contiguous()
+                lens = None if lens is None else lens.repeat_interleave(sample_n).contiguous()
+            if feats.size(0) > self.max_batch:
+                raise hip.BofiHipError(f"{feats.size(0)} sampled rows exceed bofi_max_batch={self.max_batch}")
+            self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+            seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._sample_calls
+            r = eng.decode_saic(feats, lens, raw_logits=not output_logsoftmax, sample=(temperature, seed))
         torch.cuda.synchronize()
         end = time.time()
+        if train_mode == "SAIC" and sample_method == "sample":
+            return r["seq"], r["seq_logprob"], r["phrase_num"], r["phrase_length"], r["phrase_syn"], end - start
         outs = [r["seq"], r["seq_logprob"], r["phrase_num"], r["phrase_length"], r["phrase_syn"]]
         if sample_n > 1:                                          # the bound is deterministic: n identical layouts (models/utils.py:3-14)
             outs = [o.repeat_interleave(sample_n, dim=0) for o in outs]

@@ -733,6 +733,97 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
 
 
+def sampled_logprobs(P, cfg, att_feats, att_masks, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool = True, training: bool = False,
+                     seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
+    """Token log-probs of SAMPLED captions with the autograd tape: the differentiable half of the self-critical step.
+
+    The reference samples with gradients enabled (loss_wrapper.py:193-209: ``model(..., mode='sample')`` in SAIC and in NAIC
+    mode, then ``struc_crit(seq_logprobs, seq, gts)``).  Here the engine samples without a tape and this function recomputes
+    the log-probs of what was sampled: given a sampled slot layout the distribution of every position is exactly the
+    teacher-forced one -- ``decode_SA`` on the sampled caption (inputs of a phrase = the previous phrase squeezed / stretched,
+    block mask; TransformerModel.py:1933-1952 does this per iteration) resp. ``decode_NA`` on the layout's syntactic labels
+    (:1870-1875, with quirk Q1's fill mask when ``strict_q1``).  Slot layouts are discrete: no gradient reaches the bound layer,
+    as in the reference.
+
+    ``saic`` / ``naic``: dicts with ``seq`` [N, S] int64, ``phrase_length`` [N, S] and ``phrase_syn`` [N, S] as returned by
+    ``_sample`` (N = images x sample_n, image b's copies in rows b*n..b*n+n-1).  Returns (saic_logprobs, naic_logprobs), each
+    [N, S, V] float32 or None.  One encoder pass serves both."""
+    import numpy as np
+    from .collate import phrase_collate
+    dev = att_feats.device
+    S, d = cfg.seq_length, cfg.d_model
+    if compute_dtype not in (torch.float32, torch.bfloat16):
+        raise hip.BofiHipError(f"training compute dtype {compute_dtype}: float32 or bfloat16")
+    _COMPUTE["dtype"] = compute_dtype
+    _STEP_CACHE.clear()
+    _SHADOW_ONLY.clear()
+    att_len = None
+    if att_masks is not None:
+        max_len = int(att_masks.long().sum(1).max())
+        att_feats, att_masks = att_feats[:, :max_len].contiguous(), att_masks[:, :max_len]
+        att_len = att_masks.long().sum(1).to(torch.int32).contiguous()
+    att_feats = _need(att_feats.float() if att_feats.dtype != torch.float32 else att_feats, "att_feats")
+    B, R, _ = att_feats.shape
+    N = B * sample_n
+    drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None, step_word)
+    memory = encode_memory(P, cfg, att_feats, att_len, drop)
+    att_len_cap = None if att_len is None else att_len.repeat_interleave(sample_n).contiguous()
+    kv_cache: dict = {}
+    tname, sname, pe = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight", P["model.pos_embed.pe"]
+
+    def emb(tok, syn):
+        x = embed(P[tname], P[sname], pe, tok, syn, S, P.g(tname), P.g(sname))
+        return drop(x) if drop.on and drop.p > 0.0 else x
+
+    def layout(r):
+        seq = r["seq"].detach().cpu().numpy().astype(np.int64)
+        if seq.shape != (N, S):
+            raise hip.BofiHipError(f"sampled captions {seq.shape} for {B} images x {sample_n} samples")
+        labels = np.zeros((N, S + 2), np.int64)
+        labels[:, 0] = cfg.bos_idx            # core_SAIC starts from seq[:, 0] = BOS (TransformerModel.py:1900); the loader's labels have 0 there
+        labels[:, 1:S + 1] = seq
+        plen = r["phrase_length"].detach().cpu().numpy().astype(np.int64)
+        psyn = np.where(plen > 0, r["phrase_syn"].detach().cpu().numpy().astype(np.int64), 0)
+        return phrase_collate(labels, plen, psyn, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx, len_idx=cfg.len_idx)
+
+    def tokens(x):
+        return log_softmax(P.lin(x, "model.generator.proj")).view(N, S, -1)
+
+    out = [None, None]
+    if saic is not None:
+        c = layout(saic)
+        syn_mid = torch.from_numpy(np.ascontiguousarray(c["extend_phrase_syn_seq"][:, 1:-1])).to(dev)
+        ext_seq = torch.from_numpy(c["extend_phrase_seq"]).to(dev)
+        klen = torch.from_numpy(c["extend_phrase_seq_mask"].sum(-1).astype(np.int32)).to(dev)
+        out[0] = tokens(decode_rows(P, cfg, drop, emb(ext_seq, syn_mid), memory, kv_cache, N, S, R, sample_n, klen, att_len_cap))
+    if naic is not None:
+        c = layout(naic)
+        syn_mid = torch.from_numpy(np.ascontiguousarray(c["extend_phrase_syn_seq"][:, 1:-1])).to(dev)
+        last = c["phrase_length"][:, 1:].sum(1) + 1                       # 1 + tokens laid out (TransformerModel.py:1859-1866)
+        fill = np.full(N, last[-1] - 1) if strict_q1 else last - 1       # Q1: every row's fill mask uses the LAST row's length (:1872-1873)
+        klen = torch.from_numpy(np.repeat(fill[:, None], S, 1).astype(np.int32)).to(dev).contiguous()
+        bos = torch.full((N, S), cfg.bos_idx, dtype=torch.int64, device=dev)
+        out[1] = tokens(decode_rows(P, cfg, drop, emb(bos, syn_mid), memory, kv_cache, N, S, R, sample_n, klen, att_len_cap))
+    return out[0], out[1]
+
+
+def new_self_critical(logprobs, seq, scores, sample_n: int):
+    """StructureLosses 'new_self_critical' (captioning/modules/losses.py:37-51, 157-176), reduction 'mean': the reward of a
+    sample is its score minus the mean score of the image's OTHER samples; loss = -sum(logp(token) * mask * reward) / sum(mask),
+    mask = (seq > 0) shifted right by one with a leading 1.  ``scores``: [N] (any float tensor / array) from the external
+    caption scorer.  Returns (loss, rewards [B, n])."""
+    seq = seq.to(logprobs.device).long()
+    mask = (seq > 0).to(logprobs.dtype)
+    mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1)
+    sc = torch.as_tensor(scores, dtype=logprobs.dtype, device=logprobs.device).view(-1, sample_n)
+    if sample_n < 2:
+        raise ValueError("new_self_critical needs at least two samples per image")
+    reward = sc - (sc.sum(1, keepdim=True) - sc) / (sample_n - 1)
+    picked = logprobs.gather(2, seq.unsqueeze(2)).squeeze(2)
+    loss = (-picked * mask * reward.view(-1, 1)).sum() / mask.sum()
+    return loss, sc
+
+
 def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
     """LanguageModelCriterion_UIC.forward (captioning/modules/losses.py:319-369), reduction 'mean', self_dis off:
     six masked NLL sums, each divided by the number of real caption tokens.  Index bookkeeping only (gathers and

@@ -207,6 +207,9 @@ int bofi_engine_finalize(bofi_engine_t* e);
  * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
 int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
 
+/* Temperature (> 0) and seed of the token draws of a decode called with BOFI_FLAG_SAMPLE. */
+int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed);
+
 /* Device pointer of the engine's own [max_batch * S, V] float32 log-prob workspace: where a decode called WITHOUT a
  * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of
  * bofi_vocab_stats / bofi_vocab_sample when the 48.6 MB tensor is not wanted in user memory. */
@@ -220,6 +223,8 @@ void* bofi_engine_stream(bofi_engine_t* e);
                                       uses the LAST image's length.  Default ON in the Python wrapper. */
 #define BOFI_FLAG_RAW_LOGITS 2     /* output_logsoftmax = 0 (AttModel.py:208-209) */
 #define BOFI_FLAG_GRAPH 4          /* replay the call from a captured hipGraph when possible */
+#define BOFI_FLAG_SAMPLE 16         /* decode_saic: draw each phrase's tokens from Categorical(logits / temperature) instead of
+                                      the argmax (sample_method 'sample'); parameters from bofi_engine_set_sampling */
 #define BOFI_FLAG_REFINE_SHIFT 8   /* bits 8..11: extra filling rounds; round r > 0 feeds round r-1's ids back as the
                                       decoder input tokens (decode_NA's glat_input, TransformerModel.py:570-574).  The
                                       reference has no refinement loop: parity of rounds > 0 is pinned to the oracle only. */
