@@ -158,3 +158,15 @@ def synthetic_att_feats(B: int, R: int, F: int, seed: int = 1234) -> np.ndarray:
     """|N(0,1)| region features, float32 [B, R, F]."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return np.abs(rng.standard_normal((B, R, F), dtype=np.float32))
+
+
+def with_len_row_shared(sd, cfg):
+    """A copy of ``sd`` whose word table's [LEN] row equals the syntactic table's.  The synthetic bound-head preset is
+    calibrated on the NA bound input (syn_embed); with this one row shared, iteration 1 of the semi-autoregressive bound step
+    (tgt_embed input, TransformerModel.py:515-518) equals the NA one, so SAIC decodes emit multi-phrase captions instead of
+    stopping (or NaN-ing, :1956-1958) at once.  Used by the SAIC / self-critical fixtures and tests."""
+    out = dict(sd)
+    lut = np.array(sd["model.tgt_embed.lut.weight"], copy=True)
+    lut[cfg.len_idx] = sd["model.syn_embed.lut.weight"][cfg.len_idx]
+    out["model.tgt_embed.lut.weight"] = lut
+    return out

@@ -235,6 +235,18 @@ def main():
     for name in cases:
         if "nan" not in name:
             assert manifest[name]["gap"] >= 1e-3, (name, manifest[name]["gap"])
+    # a non-degenerate semi-autoregressive case: with the seeded weights SAIC stops (or hits the "phrase nan!" return) at
+    # iteration 1; sharing the [LEN] embedding row between the two tables makes it lay out and fill several phrases
+    # (natural generator scale: the decoder's token distributions are then flat enough for long captions)
+    sd_s = W.with_len_row_shared(W.make_state_dict(cfg, seed=0, gen_scale=1.0), cfg)
+    model_s, w_s = build_reference(cfg, sd_s), O.as_torch(sd_s)
+    att_s = pool[mix][np.load(os.path.join(OUT, "tiny_mix.npz"))["naic_phrase_num"] > 0]       # tiny_mix's images that open a phrase
+    res = run_case("tiny_saic_multi", cfg, model_s, w_s, att_s, None)
+    assert int((res["saic_seq"] > 0).sum()) > 20 and int(res["saic_phrase_num"].max()) >= 4, (res["saic_phrase_num"], res["saic_seq"])
+    np.savez_compressed(os.path.join(OUT, "tiny_saic_multi.npz"), **res)
+    manifest["tiny_saic_multi"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_s), patch="len_row_shared",
+                                       B=int(att_s.shape[0]), saic_phrase_num=res["saic_phrase_num"].tolist())
+    print("tiny_saic_multi", manifest["tiny_saic_multi"])
     # XE training step (forward, criterion, gradients) on the tiny config, natural generator scale
     sd_t = W.make_state_dict(TINY, seed=0, gen_scale=1.0)
     manifest["tiny_train_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t), **run_train_case("tiny_train_xe", TINY, sd_t, 3, 2, 5))

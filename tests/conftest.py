@@ -29,7 +29,7 @@ def load_golden(name):
 
 
 TINY_CASES = ["tiny_mix", "tiny_q1_last_shortest", "tiny_q1_last_empty_nan", "tiny_single",
-              "tiny_ragged", "tiny_ragged_short"]
+              "tiny_ragged", "tiny_ragged_short", "tiny_saic_multi"]       # the last one: multi-phrase SAIC decodes (patched [LEN] row)
 
 
 @pytest.fixture(scope="session")
@@ -39,11 +39,15 @@ def weight_cache():
     from boficap_amd.config import FULL, TINY
     cache = {}
 
-    def get(config_name, seed, gen_scale, digest=None):
-        key = (config_name, seed, gen_scale)
+    def get(config_name, seed, gen_scale, digest=None, patch=None):
+        key = (config_name, seed, gen_scale, patch)
         if key not in cache:
             cfg = {"TINY": TINY, "FULL": FULL}[config_name]
             sd = W.make_state_dict(cfg, seed=seed, gen_scale=gen_scale)
+            if patch == "len_row_shared":
+                sd = W.with_len_row_shared(sd, cfg)
+            elif patch is not None:
+                raise KeyError(patch)
             if digest is not None:
                 assert W.digest(sd) == digest, "regenerated weights differ from the ones the fixture was made with"
             cache[key] = (cfg, sd)

@@ -16,9 +16,9 @@ def engines(weight_cache, manifest):
 
     def get(case, dtype, max_batch=64):
         m = manifest[case]
-        key = (m["config"], m["seed"], m["gen_scale"], dtype, max_batch)
+        key = (m["config"], m["seed"], m["gen_scale"], m.get("patch"), dtype, max_batch)
         if key not in cache:
-            cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+            cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
             e = BofiEngine(cfg, dtype, max_batch=max_batch, max_regions=36)
             e.load_state_dict(sd)
             cache[key] = (cfg, sd, e)
@@ -281,7 +281,7 @@ def test_drop_in_module_sample(weight_cache, manifest):
     """captioning.models.setup(opt) -> load_state_dict -> model(..., mode='sample'): the 6-tuple."""
     import captioning.models as models
     m = manifest["tiny_mix"]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     g = load_golden("tiny_mix")
     model = models.setup(cfg.to_opt())
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -326,7 +326,7 @@ def test_sampled_tokens_follow_the_fill_distribution(weight_cache, manifest):
     draws against softmax(logp / T), pad after the caption length, the reference's row layout for sample_n."""
     import captioning.models as models
     m = manifest["tiny_mix"]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     g = load_golden("tiny_mix")
     model = models.setup(cfg.to_opt())
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -354,4 +354,4 @@ def test_sampled_tokens_follow_the_fill_distribution(weight_cache, manifest):
     again2 = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "sample", "sample_n": 2}, mode="sample")[0]
     assert not torch.equal(again, again2)                                                  # a new seed per call
     with pytest.raises(NotImplementedError):
-        model(fc, att, None, opt={"train_mode": "SAIC", "sample_method": "sample"}, mode="sample")
+        model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "top5"}, mode="sample")

@@ -12,27 +12,19 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _model(weight_cache, manifest, case="tiny_mix"):
-    """The seeded test weights, with ONE change so that the semi-autoregressive mode emits phrases: the bound heads are
-    calibrated for the NA input (syn_embed), so the word table's [LEN] row is made equal to the syn table's -- iteration 1 of
-    the SA bound then equals iteration 1 of the NA bound (later iterations see sampled words and do whatever they do)."""
+def _model(weight_cache, manifest, case="tiny_saic_multi"):
+    """Weights of the tiny_saic_multi fixture (boficap_amd.weights.with_len_row_shared): the semi-autoregressive mode lays
+    out and fills several phrases with them -- pinned to the real reference by tests/golden/tiny_saic_multi.npz."""
     import captioning.models as models
     m = manifest[case]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
-    sd = dict(sd)
-    lut = sd["model.tgt_embed.lut.weight"].copy()
-    lut[cfg.len_idx] = sd["model.syn_embed.lut.weight"][cfg.len_idx]
-    sd["model.tgt_embed.lut.weight"] = lut
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     model = models.setup(cfg.to_opt())
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     return cfg, sd, model.cuda().eval()
 
 
 def _images():
-    """tiny_mix images whose first bound step opens a phrase (an image without any phrase NaNs the whole SAIC batch,
-    TransformerModel.py:1956-1958)."""
-    g = load_golden("tiny_mix")
-    return torch.from_numpy(g["att_feats"][g["naic_phrase_num"] > 0])
+    return torch.from_numpy(load_golden("tiny_saic_multi")["att_feats"])
 
 
 def _sample(model, att, mode, n, T=1.0):

@@ -186,7 +186,7 @@ def test_logsoftmax_embed_dropout_backward():
 def _model(weight_cache, manifest, case):
     import captioning.models as models
     m = manifest[case]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     model = models.setup(cfg.to_opt())
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     return cfg, model.cuda()

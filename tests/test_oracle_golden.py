@@ -18,7 +18,7 @@ def _close(a, b, tol):
 @pytest.mark.parametrize("name", TINY_CASES)
 def test_oracle_matches_reference_tiny(name, manifest, weight_cache):
     m = manifest[name]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     w = O.as_torch(sd)
     g = load_golden(name)
     att = torch.from_numpy(g["att_feats"])
@@ -49,18 +49,20 @@ def test_case_mix_covers_reference_branches(manifest):
     """EOS by length 0, EOS by label out of range, truncation at 21, Q1 NaN batch."""
     reasons = set()
     for name in TINY_CASES:
-        reasons.update(manifest[name]["reasons"])
+        reasons.update(manifest[name].get("reasons", []))
     assert {"len0", "syn", "trunc"} <= reasons
     g = load_golden("tiny_q1_last_empty_nan")
     assert np.isnan(g["naic_logprob"]).all() and (g["naic_seq"] == 0).all()
     g = load_golden("tiny_q1_last_shortest")
     assert g["naic_last"][-1] < g["naic_last"][:-1].min()
+    g = load_golden("tiny_saic_multi")                        # the semi-autoregressive mode beyond its first iteration
+    assert g["saic_phrase_num"].max() >= 4 and (g["saic_seq"] > 0).sum() > 20 and not np.isnan(g["saic_logprob"]).any()
 
 
 def test_oracle_matches_reference_full(manifest, weight_cache):
     from boficap_amd import weights as W
     m = manifest["full_b8"]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     w = O.as_torch(sd)
     g = load_golden("full_b8")
     att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]])
@@ -76,7 +78,7 @@ def test_oracle_matches_reference_full(manifest, weight_cache):
 def test_q1_fix_changes_only_fill(manifest, weight_cache):
     """The strict_reference=False escape hatch (per-row fill mask) leaves the slot layout alone."""
     m = manifest["tiny_q1_last_shortest"]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     w = O.as_torch(sd)
     g = load_golden("tiny_q1_last_shortest")
     att = torch.from_numpy(g["att_feats"])
@@ -89,7 +91,7 @@ def test_q1_fix_changes_only_fill(manifest, weight_cache):
 def test_oracle_xe_forward_and_criterion(manifest, weight_cache):
     """XE training forward (six log-prob tensors) and LanguageModelCriterion_UIC vs the reference's recorded outputs."""
     m = manifest["tiny_train_xe"]
-    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     w = O.as_torch(sd)
     g = load_golden("tiny_train_xe")
     t = lambda k: torch.from_numpy(g[k])
