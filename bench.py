@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--refine", type=int, default=0, help="extra filling rounds (BASELINE config 5 uses 3 rounds at batch 256)")
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")
+    ap.add_argument("--coalesce", type=int, default=1, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
+                    "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     args = ap.parse_args()
@@ -280,10 +282,15 @@ def main():
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     log("building weights")
     sd = W.make_state_dict(cfg, seed=0)
-    eng = BofiEngine(cfg, tdt, max_batch=args.batch, max_regions=36, device=dev)
+    C = max(1, args.coalesce)
+    if args.steps % C or args.warmup % C:
+        raise SystemExit("--steps and --warmup must be multiples of --coalesce")
+    eng = BofiEngine(cfg, tdt, max_batch=args.batch * C, max_regions=36, device=dev)
     eng.load_state_dict(sd)
-    # every rank decodes its own shard of images (different seed per rank), already resident in HBM
-    att = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev).to(tdt).contiguous()
+    # every rank decodes its own shard of images (different seed per rank), already resident in HBM; with --coalesce the
+    # C batches of a launch are C different batches (same generator, more images)
+    att = torch.from_numpy(W.synthetic_att_feats(args.batch * C, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev).to(tdt).contiguous()
+    qg = args.batch if C > 1 else 0
     graph = not args.no_graph
     log("engine ready; first decode (graph capture)")
     # streams that provably overlap (distinct hardware queues), found by timing a spin kernel on pairs
@@ -294,7 +301,7 @@ def main():
     outs = []
     for e, st in zip(engines, streams):
         with torch.cuda.stream(st):
-            outs.append(e.decode_naic(att, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine))
+            outs.append(e.decode_naic(att, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine, q1_group=qg))
     torch.cuda.synchronize()
     out = outs[0]
     log("warm-up + timed steps")
@@ -302,14 +309,15 @@ def main():
     def step(i):
         k = i % len(engines)
         with torch.cuda.stream(streams[k]):
-            engines[k].decode_naic(att, graph=graph, out=outs[k], refine_rounds=args.refine)
+            engines[k].decode_naic(att, graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    launches = args.steps // C
+    for i in range(args.warmup // C):
         step(i)
     barrier()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
@@ -317,7 +325,7 @@ def main():
     t0 = time.perf_counter()
     for st, e in zip(streams, ev0):
         e.record(st)
-    for i in range(args.steps):
+    for i in range(launches):
         step(i)
     for st, e in zip(streams, ev1):
         e.record(st)
@@ -325,23 +333,23 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP events on the launch streams: with one stream this is the device time per decode; with several
     # in flight it is the longest stream's span divided by all the decodes (steady-state time per decode)
-    dev_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    dev_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / launches
     elapsed = dp.reduce_scalar(elapsed, "max", device=dev)
 
     # for the record: the same K steps strictly one at a time (latency view of the same workload)
     single_ms = None
     if len(engines) > 1:
-        for i in range(args.warmup):
-            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine)
+        for i in range(args.warmup // C):
+            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg)
         barrier()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine)
+        for i in range(launches):
+            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg)
         barrier()
         single_ms = (time.perf_counter() - t1) / args.steps * 1e3
     traffic = None                                  # HBM bytes per decode from the committed PMC run (profiles/r01_hbm_traffic.json)
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
+    if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine and C == 1:
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_decode")
     T = int(out["bound_iters"].item())
@@ -350,7 +358,7 @@ def main():
     if rank == 0:
         images = args.batch * world * args.steps
         dl = 2 * cfg.seq_length * (6 * cfg.d_model ** 2 + 2 * cfg.d_model * cfg.d_ff) + 4 * cfg.seq_length * (cfg.seq_length + 36) * cfg.d_model
-        flops_launch = (f_alg(T, cfg) + args.refine * (cfg.N_dec * dl + 2 * cfg.seq_length * cfg.d_model * cfg.tgt_vocab)) * args.batch
+        flops_launch = (f_alg(T, cfg) + args.refine * (cfg.N_dec * dl + 2 * cfg.seq_length * cfg.d_model * cfg.tgt_vocab)) * args.batch * C
         achieved = flops_launch / (dev_ms * 1e-3) / 1e12
         res = {
             "metric": "images/sec NAR bound+fill greedy decode (NAIC _sample)",
@@ -360,7 +368,7 @@ def main():
             "config": {"workload": f"batch={args.batch} NAR bound+fill inference, 36x2048 regions, d_model=512 6+6 layers(+1 bound layer), {args.dtype}",
                        "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
                        "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
-                       "decodes_in_flight": len(engines), "refine_rounds": args.refine,
+                       "decodes_in_flight": len(engines), "batches_per_launch": C, "refine_rounds": args.refine,
                        "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                        "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
                        "att_feats_seed": ATT_SEED, "nan_in_output": nan, "sharding": "images by rank, no collective"},

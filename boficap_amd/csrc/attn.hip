@@ -132,7 +132,8 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
         const int r = r0 + (lane >> 2), sub = lane & 3;
         int kl = Lk;
         if (p.klen && r < nq) {
-            const int bi = p.klen_shared_last ? (p.B - 1) : b;
+            // quirk Q1 per group of klen_shared_last images: every image uses the key count of its group's LAST image
+            const int bi = p.klen_shared_last ? min(p.B, (b / p.klen_shared_last + 1) * p.klen_shared_last) - 1 : b;
             kl = p.klen[bi * p.klen_sb + (q0 + r) * p.klen_sq] + p.klen_bias;
             kl = max(0, min(kl, Lk));
         }

@@ -49,7 +49,7 @@ struct AttnArgs {
     int B, H, Lq, Lk;
     const int* klen; int klen_sb, klen_sq;
     int klen_bias;            // effective length = klen[...] + klen_bias (e.g. -1 for last-1)
-    int klen_shared_last;     // quirk Q1: use entry (B-1) of klen for every batch item
+    int klen_shared_last;     // quirk Q1, group size G (0: off): item b uses entry min(B, (b/G + 1)*G) - 1 of klen; G >= B: entry B-1 for all
     const int* skip_if_ge; int skip_threshold;
     int kdiv;                 // key/value batch item = b / kdiv (0 or 1: one per query batch item)
     // training: dropout on the attention probabilities (TransformerModel.py:1430-1431), bf16 kernel only;

@@ -91,6 +91,7 @@ struct bofi_engine {
     void* b_q0_sa = nullptr; float* b_x0_sa = nullptr;                  // row-0 constants when position 0 holds tgt_embed([LEN])
 
     hipStream_t cap_stream = nullptr;
+    int q1_group = 0;                     // > 0: the call carries several independent batches of this many images (quirk Q1 per batch)
     float sample_temperature = 1.0f;      // BOFI_FLAG_SAMPLE: token draws inside the semi-autoregressive loop
     uint64_t sample_seed = 0;
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
@@ -353,7 +354,7 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
         // syn_mask[i, :, :last-1] = True; strict mode reproduces the stale index of :1872-1873 (quirk Q1)
         a.klen = st.last; a.klen_sb = 1; a.klen_sq = 0; a.klen_bias = -1;
-        a.klen_shared_last = (flags & BOFI_FLAG_STRICT_Q1) ? 1 : 0;
+        a.klen_shared_last = (flags & BOFI_FLAG_STRICT_Q1) ? (q1_group > 0 ? q1_group : B) : 0;
         ENG_OK(bofi::launch_attention(a, s));
         { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
           ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s)); }
@@ -507,6 +508,12 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
     if (rc != BOFI_OK) { bofi_engine_destroy(e); return rc; }
     *out = e;
+    return BOFI_OK;
+}
+
+int bofi_engine_set_q1_group(bofi_engine_t* e, int group) {
+    if (!e || group < 0) return fail(BOFI_ERR_ARG, "group must be >= 0");
+    e->q1_group = group;
     return BOFI_OK;
 }
 
@@ -725,7 +732,8 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
     // graph path: the captured launch sequence is keyed by every argument that is baked into it
     std::vector<uintptr_t> key = {(uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
-                                  (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters};
+                                  (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
+                                  (uintptr_t)e->q1_group};
     for (auto& g : e->graphs)
         if (g.key == key) { ENG_HIP(hipGraphLaunch(g.exec, s)); return BOFI_OK; }
     GraphEntry g;

@@ -116,12 +116,14 @@ class BofiEngine:
 
     def decode_naic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, strict_q1: bool = True,
                     want_logprob: bool = True, want_memory: bool = False, raw_logits: bool = False, graph: bool = False,
-                    refine_rounds: int = 0, out: Optional[dict] = None) -> dict:
+                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0) -> dict:
         """Greedy NAIC bound+fill decode.  Returns a dict of device tensors: seq [B,S] int64,
         seq_logprob [B,S,V] float32 (or None), phrase_num [B] int32, phrase_length [B,S] int32,
         phrase_syn [B,S] int64, bound_iters [1] int32, memory [B,R,d] float32 (or None).
         Pass the previous result as ``out`` to reuse its buffers (required for graph replay).
-        ``refine_rounds`` extra filling passes feed the previous ids back as decoder input (BASELINE config 5)."""
+        ``refine_rounds`` extra filling passes feed the previous ids back as decoder input (BASELINE config 5).
+        ``q1_group`` > 0: the call carries B / q1_group independent batches (dynamic batching); quirk Q1 applies per batch,
+        so each batch's outputs equal its own separate decode."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
@@ -136,6 +138,9 @@ class BofiEngine:
                 memory=torch.empty(B, R, self.cfg.d_model, dtype=torch.float32, device=dev) if want_memory else None)
         if not 0 <= refine_rounds <= 15:
             raise hip.BofiHipError("refine_rounds must be in 0..15")
+        if q1_group != getattr(self, "_q1_group", 0):
+            hip.check(self._lib.bofi_engine_set_q1_group(self._h, int(q1_group)), "bofi_engine_set_q1_group")
+            self._q1_group = q1_group
         flags = ((hip.FLAG_STRICT_Q1 if strict_q1 else 0) | (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0)
                  | (refine_rounds << hip.FLAG_REFINE_SHIFT))
         hip.check(self._lib.bofi_engine_decode_naic(

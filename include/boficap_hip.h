@@ -207,6 +207,11 @@ int bofi_engine_finalize(bofi_engine_t* e);
  * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
 int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
 
+/* Several independent batches in ONE decode call (dynamic batching for serving): with group > 0 the B images of a call are
+ * consecutive batches of `group` images and quirk Q1 (BOFI_FLAG_STRICT_Q1) applies inside each batch, so every batch's result
+ * equals its own separate decode.  0 (default): the whole call is one batch. */
+int bofi_engine_set_q1_group(bofi_engine_t* e, int group);
+
 /* Temperature (> 0) and seed of the token draws of a decode called with BOFI_FLAG_SAMPLE. */
 int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed);
 

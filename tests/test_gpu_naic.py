@@ -355,3 +355,29 @@ def test_sampled_tokens_follow_the_fill_distribution(weight_cache, manifest):
     assert not torch.equal(again, again2)                                                  # a new seed per call
     with pytest.raises(NotImplementedError):
         model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "top5"}, mode="sample")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dynamic_batching_keeps_per_batch_results(dtype, weight_cache, manifest):
+    """Three batches of different images in ONE decode call with q1_group = batch size: every batch's ids, slot layout and
+    log-probs equal its own separate decode (quirk Q1 couples rows inside a batch only; the loop count is a max)."""
+    from boficap_amd import weights as W
+    from boficap_amd.engine import BofiEngine
+    m = manifest["tiny_q1_last_shortest"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    G = 4
+    batches = [torch.from_numpy(load_golden("tiny_q1_last_shortest")["att_feats"]),
+               torch.from_numpy(load_golden("tiny_mix")["att_feats"][:G]), torch.from_numpy(load_golden("tiny_mix")["att_feats"][G:2 * G])]
+    eng = BofiEngine(cfg, dtype, max_batch=3 * G, max_regions=36)
+    eng.load_state_dict(sd)
+    cast = (lambda t: t.cuda().to(dtype).contiguous())
+    sep = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_naic(cast(b)).items()} for b in batches]
+    allb = eng.decode_naic(cast(torch.cat(batches)), q1_group=G)
+    whole = eng.decode_naic(cast(torch.cat(batches)))                    # one big batch: Q1 then uses the very last image
+    for i, r in enumerate(sep):
+        sl = slice(i * G, (i + 1) * G)
+        assert torch.equal(allb["seq"][sl], r["seq"]) and torch.equal(allb["phrase_length"][sl], r["phrase_length"])
+        assert torch.equal(allb["phrase_syn"][sl], r["phrase_syn"]) and torch.equal(allb["phrase_num"][sl], r["phrase_num"])
+        a, b = allb["seq_logprob"][sl], r["seq_logprob"]
+        assert torch.equal(a.isnan(), b.isnan()) and float((a - b).nan_to_num().abs().max()) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert not torch.equal(whole["seq"], allb["seq"])                   # the grouping matters
