@@ -238,9 +238,78 @@ def main_xe(args):
         dist.destroy_process_group()
 
 
+def main_rl(args):
+    """BASELINE config 4: self-critical step, 10 images x 5 sampled captions per GPU in SAIC and in NAIC mode, re-forward with the
+    tape, new_self_critical, backward, all-reduce, Adam.  The caption scorer (CIDEr-D in the reference) is an external CPU
+    package: a stand-in that scores token overlap with a fixed pseudo-reference runs on the host in its place, so the measured
+    step contains the same device->host->device round trip."""
+    from boficap_amd import dp
+    rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
+    world = max(world, 1)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import captioning.models as models
+    from boficap_amd import weights as W
+    from boficap_amd.config import FULL as cfg
+    from boficap_amd.trainer import XETrainer
+    n_img, n = args.batch, args.seq_per_img
+    sd = W.with_len_row_shared(W.make_state_dict(cfg, seed=0), cfg)      # weights with which the semi-autoregressive mode emits captions
+    opt = cfg.to_opt()
+    opt.seed = 42
+    opt.bofi_max_batch = max(64, n_img * n)
+    if args.dtype == "bf16":
+        opt.bofi_train_dtype = torch.bfloat16
+        opt.bofi_compute_dtype = torch.bfloat16
+    model = models.setup(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.to(dev).train()
+    tr = XETrainer(model, opt)
+    att = torch.from_numpy(W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
+    ref = torch.randint(7, cfg.tgt_vocab, (n_img, cfg.seq_length), generator=torch.Generator().manual_seed(rank))
+
+    def score(seq):                                                        # host-side stand-in for the external scorer
+        r = ref.repeat_interleave(n, 0)
+        return ((seq == r) & (seq > 0)).float().sum(1) / (seq > 0).float().sum(1).clamp(min=1) + 0.01 * (seq > 0).float().sum(1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, rs, rn = tr.rl_step(att, None, score, sample_n=n)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, rs, rn = tr.rl_step(att, None, score, sample_n=n)
+    barrier()
+    elapsed = dp.reduce_scalar(time.perf_counter() - t0, "max", device=dev)
+    if rank == 0:
+        res = {"metric": "images/sec self-critical step (SAIC + NAIC sampling, re-forward, new_self_critical, backward, all-reduce, Adam)",
+               "value": round(n_img * world * args.steps / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"self-critical RL step, {n_img} images x {n} sampled captions per GPU in each of the two modes, "
+                                      f"36x2048 regions, d_model=512 6+6(+1) layers, {args.dtype}",
+                          "images_per_step_per_gpu": n_img, "samples_per_image": n, "final_loss": round(float(loss), 5),
+                          "scorer": "host-side stand-in (the reference's CIDEr-D scorer is external)", "hip_graph": False},
+               "roofline": {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s", "frac": None, "traffic": None,
+                            "note": "latency-bound at 50 captions: two 20-iteration sampling decodes with a host round trip between them and the gradient pass"}}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="naic", choices=["naic", "xe"], help="naic: bound+fill decode (headline); xe: XE training step (config 3)")
+    ap.add_argument("--mode", default="naic", choices=["naic", "xe", "rl"],
+                    help="naic: bound+fill decode (headline); xe: XE training step (config 3); rl: self-critical step (config 4)")
     ap.add_argument("--seq-per-img", type=int, default=5)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -259,6 +328,8 @@ def main():
     args = ap.parse_args()
     if args.mode == "xe":
         return main_xe(args)
+    if args.mode == "rl":
+        return main_rl(args)
 
     from boficap_amd import dp
     rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libboficap_hip.so")
-SOURCES = ["ln.hip", "gemm.hip", "gemm_glds.hip", "attn.hip", "attn_bf16.hip", "naic.hip", "train_ops.hip", "gemm_tn.hip", "attn_bwd_mfma.hip", "engine.hip"]
+SOURCES = ["ln.hip", "gemm.hip", "gemm_glds.hip", "attn.hip", "attn_bf16.hip", "naic.hip", "train_ops.hip", "gemm_tn.hip", "attn_bwd_mfma.hip", "repack.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]

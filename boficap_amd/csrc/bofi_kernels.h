@@ -62,6 +62,17 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.h
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
                           int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr);
 
+// ---- device-side weight repack (repack.hip)
+struct PackLinArgs {
+    const float* w[16]; const float* b[16]; int nsrc, n_each, K;
+    const float* gain; const float* bln;            // pre-norm LayerNorm to fold in (or null)
+    float* bout; float* cs;
+};
+int launch_pack_lin(const PackLinArgs& a, void* wout, int dtype, hipStream_t st);
+int launch_pack_heads(const float* lw1, const float* sw1, const float* lb1, const float* sb1, float* w1t, float* b1, int d, int hh, hipStream_t st);
+int launch_bound_table(const float* lut_syn, const float* lut_tok, const float* pe, float* xt, float* x0, float* x0_sa, int L, int d, int len_idx,
+                       hipStream_t st);
+
 int launch_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok, int pad_idx,
                         int64_t* out, hipStream_t st, const int* halt = nullptr);
 

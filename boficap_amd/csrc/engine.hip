@@ -44,6 +44,10 @@ struct Norm { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, w1, w2; Norm n0, n1; };
 struct DecLayer { Lin qkv, o, q_src, o_src, w1, w2; Norm n0, n1, n2; };
 
+// how a packed weight was made from the named parameters: replayed on the device by bofi_engine_refresh_device
+struct LinRecipe { Lin* out; std::vector<std::string> prefixes; int n_each, K; std::string fold; };
+struct NormRecipe { Norm* out; std::string prefix; int d; };
+
 struct GraphEntry {
     std::vector<uintptr_t> key;
     hipGraph_t graph = nullptr;
@@ -88,6 +92,8 @@ struct bofi_engine {
     void* kvs = nullptr;                                                // their K|V [B*L, 2d]
     int64_t* tok64 = nullptr;                                           // greedy ids of one decoder pass [B*S]
     Lin b_kv_self;                                                      // bound self-attention K|V with sublayer.0.norm folded in
+    Lin t_kvself, t_qself; float* d_xt = nullptr; Norm head_norm;       // setup-time operands of the bound tables, kept for refreshes
+    std::vector<LinRecipe> lin_recipes; std::vector<NormRecipe> norm_recipes;
     void* b_q0_sa = nullptr; float* b_x0_sa = nullptr;                  // row-0 constants when position 0 holds tgt_embed([LEN])
 
     hipStream_t cap_stream = nullptr;
@@ -167,6 +173,7 @@ struct bofi_engine {
         }
         ENG_OK(upload_t(&out->w, w));
         ENG_OK(upload_f32(&out->b, b));
+        lin_recipes.push_back(LinRecipe{out, prefixes, n_each, K, fold_norm});
         return BOFI_OK;
     }
     int make_norm(Norm* out, const std::string& prefix, int d) {
@@ -175,6 +182,7 @@ struct bofi_engine {
         if (!g || !b) return BOFI_ERR_STATE;
         ENG_OK(upload_f32(&out->g, *g));
         ENG_OK(upload_f32(&out->b, *b));
+        norm_recipes.push_back(NormRecipe{out, prefix, d});
         return BOFI_OK;
     }
 
@@ -511,6 +519,73 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     return BOFI_OK;
 }
 
+int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names, const float* const* ptrs, const int64_t* numels, void* stream) {
+    if (!e || !names || !ptrs || !numels || n <= 0) return fail(BOFI_ERR_ARG, "null argument");
+    g_err.clear();
+    if (e->is_fork) return fail(BOFI_ERR_STATE, "refresh the parent engine (forks share its weights)");
+    if (!e->finalized) return fail(BOFI_ERR_STATE, "engine not finalized: the first load goes through set_weight + finalize");
+    hipStream_t s = (hipStream_t)stream;
+    const bofi_config_t& c = e->cfg;
+    const int d = c.d_model, L = e->L, hh = c.head_hidden;
+    std::map<std::string, std::pair<const float*, int64_t>> src;
+    for (int i = 0; i < n; ++i) src[names[i]] = {ptrs[i], numels[i]};
+    auto get = [&](const std::string& name, int64_t numel) -> const float* {
+        auto it = src.find(name);
+        if (it == src.end() || !it->second.first) { g_err = "missing weight " + name; return nullptr; }
+        if (it->second.second != numel) { g_err = "weight " + name + " has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel); return nullptr; }
+        return it->second.first;
+    };
+    for (const auto& r : e->lin_recipes) {
+        bofi::PackLinArgs a{};
+        a.nsrc = (int)r.prefixes.size(); a.n_each = r.n_each; a.K = r.K;
+        if (a.nsrc > 16) return fail(BOFI_ERR_STATE, "too many stacked matrices");
+        for (int i = 0; i < a.nsrc; ++i) {
+            a.w[i] = get(r.prefixes[i] + ".weight", (int64_t)r.n_each * r.K);
+            a.b[i] = get(r.prefixes[i] + ".bias", r.n_each);
+            if (!a.w[i] || !a.b[i]) return BOFI_ERR_STATE;
+        }
+        if (!r.fold.empty()) {
+            a.gain = get(r.fold + ".a_2", r.K);
+            a.bln = get(r.fold + ".b_2", r.K);
+            if (!a.gain || !a.bln) return BOFI_ERR_STATE;
+        }
+        a.bout = r.out->b; a.cs = r.out->cs;
+        ENG_OK(bofi::launch_pack_lin(a, r.out->w, c.dtype, s));
+    }
+    for (const auto& r : e->norm_recipes) {
+        const float *g = get(r.prefix + ".a_2", r.d), *b = get(r.prefix + ".b_2", r.d);
+        if (!g || !b) return BOFI_ERR_STATE;
+        ENG_HIP(hipMemcpyAsync(r.out->g, g, (size_t)r.d * 4, hipMemcpyDeviceToDevice, s));
+        ENG_HIP(hipMemcpyAsync(r.out->b, b, (size_t)r.d * 4, hipMemcpyDeviceToDevice, s));
+    }
+    const float *ls = get("model.syn_embed.lut.weight", (int64_t)10 * d), *lt = get("model.tgt_embed.lut.weight", (int64_t)c.vocab * d);
+    if (!ls || !lt) return BOFI_ERR_STATE;
+    ENG_HIP(hipMemcpyAsync(e->lut_syn, ls, (size_t)10 * d * 4, hipMemcpyDeviceToDevice, s));
+    ENG_HIP(hipMemcpyAsync(e->lut_tok, lt, (size_t)c.vocab * d * 4, hipMemcpyDeviceToDevice, s));
+    {
+        const std::string lp = "model.length_predictor";
+        const float *lw1 = get(lp + ".Length_classifier1.weight", (int64_t)hh * d), *lb1 = get(lp + ".Length_classifier1.bias", hh);
+        const float *sw1 = get(lp + ".Syntactic_classifier1.weight", (int64_t)hh * d), *sb1 = get(lp + ".Syntactic_classifier1.bias", hh);
+        const float *lw2 = get(lp + ".Length_classifier2.weight", (int64_t)20 * hh), *lb2 = get(lp + ".Length_classifier2.bias", 20);
+        const float *sw2 = get(lp + ".Syntactic_classifier2.weight", (int64_t)10 * hh), *sb2 = get(lp + ".Syntactic_classifier2.bias", 10);
+        if (!lw1 || !lb1 || !sw1 || !sb1 || !lw2 || !lb2 || !sw2 || !sb2) return BOFI_ERR_STATE;
+        auto& h = e->heads;
+        ENG_OK(bofi::launch_pack_heads(lw1, sw1, lb1, sb1, const_cast<float*>(h.w1t), const_cast<float*>(h.b1), d, hh, s));
+        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.len_w2), lw2, (size_t)20 * hh * 4, hipMemcpyDeviceToDevice, s));
+        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.len_b2), lb2, 20 * 4, hipMemcpyDeviceToDevice, s));
+        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.syn_w2), sw2, (size_t)10 * hh * 4, hipMemcpyDeviceToDevice, s));
+        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.syn_b2), sb2, 10 * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // the bound layer's input-independent tables (as at the end of finalize)
+    ENG_OK(bofi::launch_bound_table(e->lut_syn, e->lut_tok, e->pe, e->d_xt, e->b_x0, e->b_x0_sa, L, d, c.len_idx, s));
+    bofi_engine::LinOpt o; o.ln = &e->b_n0;
+    ENG_OK(e->linear(e->d_xt, BOFI_DT_F32, d, e->t_kvself, e->b_kvtab, c.dtype, 2 * d, L * 10, o, s));
+    ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, e->t_qself, e->b_q0, c.dtype, d, 1, o, s));
+    ENG_OK(e->linear(e->b_x0_sa, BOFI_DT_F32, d, e->t_qself, e->b_q0_sa, c.dtype, d, 1, o, s));
+    e->host.clear();                          // the host copies are stale now; a later finalize needs set_weight again
+    return BOFI_OK;
+}
+
 int bofi_engine_set_q1_group(bofi_engine_t* e, int group) {
     if (!e || group < 0) return fail(BOFI_ERR_ARG, "group must be >= 0");
     e->q1_group = group;
@@ -556,6 +631,8 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     e->allocs.clear();
     e->enc.assign(c.n_enc, EncLayer());
     e->dec.assign(c.n_dec, DecLayer());
+    e->lin_recipes.clear();
+    e->norm_recipes.clear();
 
     auto S = [](const char* fmt, int a, int b = 0) { char buf[256]; std::snprintf(buf, sizeof buf, fmt, a, b); return std::string(buf); };
     ENG_OK(e->make_lin(&e->att_embed, {"att_embed.0"}, d, c.feat));
@@ -612,7 +689,7 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     ENG_OK(e->make_norm(&e->b_n2, bl + ".sublayer.2.norm", d));
     {
         const std::string lp = "model.length_predictor";
-        Norm nf;
+        Norm& nf = e->head_norm;
         ENG_OK(e->make_norm(&nf, lp + ".norm", d));
         const auto *lw1 = e->get(lp + ".Length_classifier1.weight", (size_t)hh * d), *lb1 = e->get(lp + ".Length_classifier1.bias", hh);
         const auto *sw1 = e->get(lp + ".Syntactic_classifier1.weight", (size_t)hh * d), *sb1 = e->get(lp + ".Syntactic_classifier1.bias", hh);
@@ -647,10 +724,10 @@ int bofi_engine_finalize(bofi_engine_t* e) {
             for (int s = 0; s < 10; ++s)
                 for (int k = 0; k < d; ++k) xt[((size_t)p * 10 + s) * d + k] = ls[(size_t)s * d + k] * sq + pe[(size_t)p * d + k];
         std::vector<float> x0(xt.begin() + (size_t)c.len_idx * d, xt.begin() + (size_t)(c.len_idx + 1) * d);
-        float* d_xt;
+        float*& d_xt = e->d_xt;
+        Lin &kvself = e->t_kvself, &qself = e->t_qself;
         ENG_OK(e->upload_f32(&d_xt, xt));
         ENG_OK(e->upload_f32(&e->b_x0, x0));
-        Lin kvself, qself;
         ENG_OK(e->make_lin(&kvself, {bl + ".self_attn.linears.1", bl + ".self_attn.linears.2"}, d, d));
         ENG_OK(e->make_lin(&qself, {bl + ".self_attn.linears.0"}, d, d));
         ENG_OK(e->dalloc((char**)&e->b_kvtab, (size_t)L * 10 * 2 * d, e->tsz));

@@ -1,0 +1,91 @@
+// Device-side refresh of the decode engine's packed weights from float32 parameters that already live in HBM (the
+// trainer's flat bucket): what bofi_engine_finalize does on the host -- stack q|k|v, fold the pre-norm LayerNorm into the
+// consumer GEMM (w' = w * gain, c[n] = bias[n] + sum_k b_ln[k] w[n][k], colsum[n] = sum_k round(w'[n][k])), cast to the
+// compute dtype, transpose the bound heads' first layers, rebuild the bound layer's input table -- as a handful of
+// kernels, so that a training loop can decode with its current weights without a host round trip.
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_lin_kernel(PackLinArgs a, T* __restrict__ wout) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.n_each * a.nsrc) return;
+    const int src = n / a.n_each, r = n - src * a.n_each;
+    const float* row = a.w[src] + (size_t)r * a.K;
+    T* out = wout + (size_t)n * a.K;
+    double c = 0.0, s = 0.0;
+    for (int k = lane; k < a.K; k += 64) {
+        float wv = row[k];
+        if (a.gain) {
+            c += (double)a.bln[k] * (double)wv;
+            wv = wv * a.gain[k];
+        }
+        ElemOps<T>::store(out + k, wv);
+        float rv = wv;
+        if constexpr (sizeof(T) == 2) rv = bf16_to_f32(f32_to_bf16(wv));
+        s += (double)rv;
+    }
+    if (a.gain) { c = wave_sum_f64(c); s = wave_sum_f64(s); }
+    if (lane == 0) {
+        a.bout[n] = (float)((double)a.b[src][r] + c);
+        if (a.gain) a.cs[n] = (float)s;
+    }
+}
+
+int launch_pack_lin(const PackLinArgs& a, void* wout, int dtype, hipStream_t st) {
+    const int N = a.n_each * a.nsrc;
+    if (N <= 0 || a.K <= 0 || a.nsrc > 16 || !wout || !a.bout || (a.gain && (!a.bln || !a.cs))) return BOFI_ERR_ARG;
+    if (dtype == BOFI_DT_F32) hipLaunchKernelGGL((pack_lin_kernel<float>), dim3((N + 3) / 4), dim3(256), 0, st, a, (float*)wout);
+    else hipLaunchKernelGGL((pack_lin_kernel<bf16_t>), dim3((N + 3) / 4), dim3(256), 0, st, a, (bf16_t*)wout);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// bound heads: first layers of both heads transposed side by side [d][2*hh], biases concatenated
+__global__ void pack_heads_kernel(const float* __restrict__ lw1, const float* __restrict__ sw1, const float* __restrict__ lb1,
+                                  const float* __restrict__ sb1, float* __restrict__ w1t, float* __restrict__ b1, int d, int hh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hh * d) {
+        const int j = i / d, k = i - j * d;
+        w1t[(size_t)k * 2 * hh + j] = lw1[i];
+        w1t[(size_t)k * 2 * hh + hh + j] = sw1[i];
+    }
+    if (i < hh) { b1[i] = lb1[i]; b1[hh + i] = sb1[i]; }
+}
+
+int launch_pack_heads(const float* lw1, const float* sw1, const float* lb1, const float* sb1, float* w1t, float* b1, int d, int hh, hipStream_t st) {
+    hipLaunchKernelGGL(pack_heads_kernel, dim3((hh * d + 255) / 256), dim3(256), 0, st, lw1, sw1, lb1, sb1, w1t, b1, d, hh);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// bound-layer input table: xt[(p*10 + s)*d + k] = lut_syn[s][k]*sqrt(d) + pe[p][k]; x0 = row (0, len_idx); x0_sa from the word table
+__global__ void bound_table_kernel(const float* __restrict__ lut_syn, const float* __restrict__ lut_tok, const float* __restrict__ pe,
+                                   float* __restrict__ xt, float* __restrict__ x0, float* __restrict__ x0_sa, int L, int d, int len_idx, float sq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L * 10 * d) {
+        const int k = i % d, ps = i / d, s = ps % 10, p = ps / 10;
+        const float v = lut_syn[(size_t)s * d + k] * sq + pe[(size_t)p * d + k];
+        xt[i] = v;
+        if (p == 0 && s == len_idx) x0[k] = v;
+    }
+    if (i < d) x0_sa[i] = lut_tok[(size_t)len_idx * d + i] * sq + pe[i];
+}
+
+int launch_bound_table(const float* lut_syn, const float* lut_tok, const float* pe, float* xt, float* x0, float* x0_sa, int L, int d, int len_idx,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(bound_table_kernel, dim3((L * 10 * d + 255) / 256), dim3(256), 0, st, lut_syn, lut_tok, pe, xt, x0, x0_sa, L, d, len_idx,
+                       (float)sqrt((double)d));
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+}  // namespace bofi

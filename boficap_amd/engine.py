@@ -105,6 +105,22 @@ class BofiEngine:
             hip.check(self._lib.bofi_engine_finalize(self._h), "bofi_engine_finalize")
         self._finalized = True
 
+    def refresh_from_device(self, named: Dict[str, torch.Tensor]) -> None:
+        """Re-pack the weights from float32 tensors on the device (e.g. ``dict(model.named_parameters())``): kernels only,
+        existing allocations, captured graphs and forks stay valid (``bofi_engine_refresh_device``)."""
+        if not self._finalized:
+            raise hip.BofiHipError("the first load goes through load_state_dict")
+        items = [(k, v) for k, v in named.items() if k != "model.pos_embed.pe"]
+        for k, v in items:
+            if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous():
+                raise hip.BofiHipError(f"{k}: contiguous float32 tensor on the HIP device expected")
+        n = len(items)
+        names = (C.c_char_p * n)(*[k.encode() for k, _ in items])
+        ptrs = (C.c_void_p * n)(*[v.data_ptr() for _, v in items])
+        numels = (C.c_int64 * n)(*[v.numel() for _, v in items])
+        with torch.cuda.device(self.device):
+            hip.check(self._lib.bofi_engine_refresh_device(self._h, n, names, ptrs, numels, hip.stream_ptr()), "bofi_engine_refresh_device")
+
     # ---------------------------------------------------------------- calls
     def _check_feats(self, att_feats, att_len):
         if att_feats.dim() != 3 or att_feats.size(2) != self.cfg.att_feat_size:

@@ -100,7 +100,9 @@ class TransformerModel(nn.Module):
         if self._engine is None or self._engine_key != key:
             if self._engine is None or self._engine_key[1:] != key[1:]:
                 self._engine = BofiEngine(self.cfg, self.compute_dtype, self.max_batch, self.max_regions, device=dev)
-            self._engine.load_state_dict(self.state_dict())
+                self._engine.load_state_dict(self.state_dict())
+            else:                                              # same engine, new values: re-pack on the device (no host round trip)
+                self._engine.refresh_from_device({k: v.detach() for k, v in self.named_parameters()})
             self._engine_key = key
         return self._engine
 

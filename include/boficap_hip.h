@@ -207,6 +207,13 @@ int bofi_engine_finalize(bofi_engine_t* e);
  * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
 int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
 
+/* Re-pack the engine's weights from float32 parameters that live on the DEVICE (reference names, as set_weight): the
+ * packing of bofi_engine_finalize (q|k|v stacking, LayerNorm folding, compute-dtype cast, bound tables) as kernels on
+ * `stream`, into the existing allocations -- captured graphs and forks stay valid.  For a training loop that decodes
+ * with its current weights every step (the self-critical phase, periodic evaluation).  Requires a finalized engine. */
+int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names, const float* const* ptrs, const int64_t* numels,
+                               void* stream);
+
 /* Several independent batches in ONE decode call (dynamic batching for serving): with group > 0 the B images of a call are
  * consecutive batches of `group` images and quirk Q1 (BOFI_FLAG_STRICT_Q1) applies inside each batch, so every batch's result
  * equals its own separate decode.  0 (default): the whole call is one batch. */

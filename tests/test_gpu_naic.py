@@ -381,3 +381,37 @@ def test_dynamic_batching_keeps_per_batch_results(dtype, weight_cache, manifest)
         a, b = allb["seq_logprob"][sl], r["seq_logprob"]
         assert torch.equal(a.isnan(), b.isnan()) and float((a - b).nan_to_num().abs().max()) < (1e-5 if dtype == torch.float32 else 2e-2)
     assert not torch.equal(whole["seq"], allb["seq"])                   # the grouping matters
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_device_side_weight_refresh_equals_a_fresh_load(dtype, weight_cache, manifest):
+    """bofi_engine_refresh_device (re-pack from float32 parameters in HBM: stacking, LayerNorm folding, cast, bound tables,
+    all as kernels) against an engine loaded through the host path with the same weights; captured graphs stay valid."""
+    from boficap_amd.engine import BofiEngine
+    m = manifest["tiny_mix"]
+    cfg, sd_a = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    _, sd_b = weight_cache("TINY", 0, 1.0)                     # another set of values, same schema
+    att = torch.from_numpy(load_golden("tiny_mix")["att_feats"]).cuda()
+    att = att.to(dtype).contiguous()
+    eng = BofiEngine(cfg, dtype, max_batch=16, max_regions=36)
+    eng.load_state_dict(sd_a)
+    out = eng.decode_naic(att, graph=True)
+    first = {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}
+    dev_b = {k: torch.from_numpy(v).cuda().contiguous() for k, v in sd_b.items()}
+    eng.refresh_from_device(dev_b)
+    out = eng.decode_naic(att, graph=True, out=out)            # replay of the graph captured before the refresh
+    ref = BofiEngine(cfg, dtype, max_batch=16, max_regions=36)
+    ref.load_state_dict(sd_b)
+    want = ref.decode_naic(att)
+    assert not torch.equal(first["seq"], want["seq"])
+    assert torch.equal(out["seq"], want["seq"]) and torch.equal(out["phrase_length"], want["phrase_length"])
+    assert torch.equal(out["phrase_syn"], want["phrase_syn"])
+    a, b = out["seq_logprob"], want["seq_logprob"]
+    assert torch.equal(a.isnan(), b.isnan()) and float((a - b).nan_to_num().abs().max()) < (2e-5 if dtype == torch.float32 else 2e-2)
+    s1, s2 = eng.decode_saic(att), ref.decode_saic(att)
+    assert torch.equal(s1["seq"], s2["seq"]) and torch.equal(s1["phrase_length"], s2["phrase_length"])
+    eng.refresh_from_device({k: torch.from_numpy(v).cuda().contiguous() for k, v in sd_a.items()})
+    back = eng.decode_naic(att, graph=True, out=out)
+    assert torch.equal(back["seq"], first["seq"])
+    with pytest.raises(Exception):
+        eng.refresh_from_device({k: v for k, v in dev_b.items() if "generator" not in k})
