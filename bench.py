@@ -269,7 +269,17 @@ def main_rl(args):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev).train()
     tr = XETrainer(model, opt)
-    att = torch.from_numpy(W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
+    # images whose first bound step opens a phrase: one image without any phrase NaNs the whole semi-autoregressive batch
+    # (TransformerModel.py:1956-1958, reproduced), which would turn the SAIC half of the step into a no-op
+    pool = torch.from_numpy(W.synthetic_att_feats(6 * n_img, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
+    model.eval()
+    with torch.no_grad():
+        pn = torch.cat([model(torch.zeros(len(c), 0, device=dev), c, None, opt={"train_mode": "NAIC", "sample_method": "greedy"}, mode="sample")[2]
+                        for c in pool.split(opt.bofi_max_batch)])
+    model.train()
+    att = pool[pn > 0][:n_img].contiguous()
+    if att.size(0) < n_img:
+        raise SystemExit("not enough images with a first phrase in the synthetic pool")
     ref = torch.randint(7, cfg.tgt_vocab, (n_img, cfg.seq_length), generator=torch.Generator().manual_seed(rank))
 
     def score(seq):                                                        # host-side stand-in for the external scorer
@@ -297,6 +307,7 @@ def main_rl(args):
                "config": {"workload": f"self-critical RL step, {n_img} images x {n} sampled captions per GPU in each of the two modes, "
                                       f"36x2048 regions, d_model=512 6+6(+1) layers, {args.dtype}",
                           "images_per_step_per_gpu": n_img, "samples_per_image": n, "final_loss": round(float(loss), 5),
+                          "saic_tokens_per_sample": round(float(tr._last_rl["saic_tokens"]), 2), "naic_tokens_per_sample": round(float(tr._last_rl["naic_tokens"]), 2),
                           "scorer": "host-side stand-in (the reference's CIDEr-D scorer is external)", "hip_graph": False},
                "roofline": {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s", "frac": None, "traffic": None,
                             "note": "latency-bound at 50 captions: two 20-iteration sampling decodes with a host round trip between them and the gradient pass"}}

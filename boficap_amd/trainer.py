@@ -222,7 +222,9 @@ class XETrainer:
             saic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="SAIC"), mode="sample")[:5]))
             naic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
         model.train(was_training)
-        s_saic, s_naic = score_fn(saic["seq"].cpu()), score_fn(naic["seq"].cpu())
+        seq_s, seq_n = saic["seq"].cpu(), naic["seq"].cpu()    # the scorer runs on the host
+        self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean()}
+        s_saic, s_naic = score_fn(seq_s), score_fn(seq_n)
         self.bucket.zero_grad()
         self._fwd_calls += 1
         step_word = getattr(self, "_step_word", None)

@@ -7,6 +7,8 @@ from boficap_amd import weights as W
 from boficap_amd.config import FULL as cfg
 from boficap_amd.engine import BofiEngine
 sd = W.make_state_dict(cfg, 0)
+if "--multi" in sys.argv:                   # weights with which the mode lays out several phrases (tests/golden/tiny_saic_multi)
+    sd = W.with_len_row_shared(sd, cfg)
 eng = BofiEngine(cfg, torch.bfloat16, max_batch=64, max_regions=36); eng.load_state_dict(sd)
 att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16)
 r = eng.decode_saic(att); torch.cuda.synchronize()
@@ -14,4 +16,5 @@ t0 = time.perf_counter()
 for _ in range(10): r = eng.decode_saic(att)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
-print(f"SAIC greedy B=64 bf16: {dt*1e3:.2f} ms/batch = {64/dt:.0f} images/s, iterations {int(r['bound_iters'])}, NaN {bool(r['seq_logprob'].isnan().any())}")
+print(f"SAIC greedy B=64 bf16: {dt*1e3:.2f} ms/batch = {64/dt:.0f} images/s, iterations {int(r['bound_iters'])}, NaN {bool(r['seq_logprob'].isnan().any())}, "
+      f"tokens/image {float((r['seq'] > 0).sum(1).float().mean()):.1f}, phrases/image {float(r['phrase_num'].float().mean()):.1f}")
