@@ -11,6 +11,10 @@ if "--multi" in sys.argv:                   # weights with which the mode lays o
     sd = W.with_len_row_shared(sd, cfg)
 eng = BofiEngine(cfg, torch.bfloat16, max_batch=64, max_regions=36); eng.load_state_dict(sd)
 att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16)
+if "--multi" in sys.argv:                   # keep images that open a phrase (one without NaN-halts the batch, as in the reference)
+    pool = torch.from_numpy(W.synthetic_att_feats(256, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16)
+    pn = torch.cat([eng.decode_naic(c)["phrase_num"].clone() for c in pool.split(64)])
+    att = pool[pn > 0][:64].contiguous()
 r = eng.decode_saic(att); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(10): r = eng.decode_saic(att)
