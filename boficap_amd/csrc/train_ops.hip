@@ -13,7 +13,7 @@ namespace bofi {
 // One wavefront per row.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                      const float* __restrict__ dy, float* __restrict__ dx, float* dgain,
-                                                     float* dbias, int rows, int d) {
+                                                     float* dbias, int rows, int d, const float* __restrict__ add) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * d;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     m = wave_sum(m) / (float)d;
     for (int k = lane; k < d; k += 64) {
         const float t = xr[k] - mean;
-        dx[(size_t)row * d + k] = dyr[k] * gain[k] / sd - t * coef - m;
+        dx[(size_t)row * d + k] = dyr[k] * gain[k] / sd - t * coef - m + (add ? add[(size_t)row * d + k] : 0.f);
         atomicAdd(&dgain[k], dyr[k] * t / sd);
         atomicAdd(&dbias[k], dyr[k]);
     }
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 template <int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                           const float* __restrict__ dy, float* __restrict__ dx, float* dgain,
-                                                          float* dbias, int rows, int rows_per_block) {
+                                                          float* dbias, int rows, int rows_per_block, const float* __restrict__ add) {
     constexpr int d = NJ * 64;
     __shared__ float red[2][4][d];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
         m = wave_sum(m) / (float)d;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            dx[(size_t)row * d + lane + 64 * j] = t[j] - m;
+            dx[(size_t)row * d + lane + 64 * j] = t[j] - m + (add ? add[(size_t)row * d + lane + 64 * j] : 0.f);
             dg[j] += dv[j] * xv[j] * inv;
             db[j] += dv[j];
         }
@@ -429,14 +429,14 @@ extern "C" int bofi_relu_bwd(const float* y, const float* dy, float* dx, int64_t
     return BOFI_OK;
 }
 
-extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, float* dx, float* dgain, float* dbias, int rows,
-                                  int d, void* stream) {
+extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain, float* dbias,
+                                  int rows, int d, void* stream) {
     if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
     const int rpb = rows >= 4096 ? 32 : 8;                 // the per-column atomics of a workgroup cost more than the lost occupancy
-    if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
-    else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb);
-    else hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d);
+    if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb, add);
+    else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb, add);
+    else hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d, add);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -253,7 +253,10 @@ def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None
 
 class LayerNormFn(Function):
     """a_2 (x - mean) / (std + eps) + b_2 with the unbiased std (TransformerModel.py:1346-1349).
-    ``gg`` / ``gb``: gradient buffers of gain / bias to accumulate into (see LinearFn)."""
+    ``gg`` / ``gb``: gradient buffers of gain / bias to accumulate into (see LinearFn).
+    Returns (x, y): the pre-norm sublayers use x twice -- normalised, and as the residual (SublayerConnection, :1361-1363).
+    Taking the residual from the FIRST output routes both gradients of x through this node, and the backward kernel adds them
+    on the fly instead of autograd launching an add."""
 
     @staticmethod
     def forward(ctx, x, gain, bias, gg, gb, gemm_only):
@@ -268,24 +271,33 @@ class LayerNormFn(Function):
         else:
             _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(y), F32, rows, d, hip.stream_ptr()), "bofi_layernorm")
         ctx.gg, ctx.gb = gg, gb
+        ctx.set_materialize_grads(False)                       # an unused output gets None, not a zero tensor
         ctx.save_for_backward(x, gain)
-        return y
+        return x.view_as(x), y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, g_pass, dy):
         x, gain = ctx.saved_tensors
         rows, d = x.shape
+        if dy is None:                                         # only the pass-through was used
+            return g_pass, None, None, None, None, None
         dy = _need(dy, "ln dy")
+        add = None if g_pass is None else _need(g_pass, "ln residual gradient")
         direct = ctx.gg is not None and ctx.gb is not None
         dx = torch.empty_like(x)
         dg, db = (ctx.gg, ctx.gb) if direct else (_zeros(x, d), _zeros(x, d))
-        _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
+        _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(add), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
                                        hip.stream_ptr()), "bofi_layernorm_bwd")
         return (dx, None, None, None, None, None) if direct else (dx, dg, db, None, None, None)
 
 
 def layer_norm(x, gain, bias, gg=None, gb=None, gemm_only=False):
     """``gemm_only``: the output is consumed by GEMMs only (bf16 mode then skips the float32 copy)."""
+    return LayerNormFn.apply(x, gain, bias, gg, gb, gemm_only)[1]
+
+
+def layer_norm_res(x, gain, bias, gg=None, gb=None, gemm_only=False):
+    """(x for the residual connection, LayerNorm(x)): see LayerNormFn."""
     return LayerNormFn.apply(x, gain, bias, gg, gb, gemm_only)
 
 
@@ -531,6 +543,11 @@ class Params:
         a, b = prefix + ".a_2", prefix + ".b_2"
         return layer_norm(x, self.t[a], self.t[b], self.g(a), self.g(b), gemm_only)
 
+    def ln_res(self, x, prefix, gemm_only=True):
+        """(x to use as the sublayer's residual, LayerNorm(x))."""
+        a, b = prefix + ".a_2", prefix + ".b_2"
+        return layer_norm_res(x, self.t[a], self.t[b], self.g(a), self.g(b), gemm_only)
+
 
 def _sublayer_linear(P, drop, x_in, wname, residual):
     """residual + dropout(x_in w^T + b): the residual rides in the GEMM epilogue when dropout is off."""
@@ -560,10 +577,12 @@ def encode_memory(P, cfg, att_feats, att_len, drop):
     sb = 1 if att_len is not None else 0
     for l in range(cfg.N_enc):
         p = f"model.encoder.layers.{l}"
-        qkv = P.lin_packed(P.ln(x, p + ".sublayer.0.norm"), p + ".self_attn", (0, 1, 2))
+        xr, n = P.ln_res(x, p + ".sublayer.0.norm")
+        qkv = P.lin_packed(n, p + ".self_attn", (0, 1, 2))
         ctx = attention(qkv, qkv, 0, d, 2 * d, B, cfg.h, R, R, 1, att_len, sb, 0, 0, drop.attn())
-        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", x)
-        x = _ffn(P, p + ".feed_forward", drop, P.ln(x, p + ".sublayer.1.norm"), x)
+        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
+        xr, n = P.ln_res(x, p + ".sublayer.1.norm")
+        x = _ffn(P, p + ".feed_forward", drop, n, xr)
     return P.ln(x, "model.encoder.norm")
 
 
@@ -584,11 +603,14 @@ def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_
     d = cfg.d_model
     for l in range(cfg.N_dec):
         p = f"model.decoder.layers.{l}"
-        qkv = P.lin_packed(P.ln(x, p + ".sublayer.0.norm"), p + ".self_attn", (0, 1, 2))
+        xr, n_ = P.ln_res(x, p + ".sublayer.0.norm")
+        qkv = P.lin_packed(n_, p + ".self_attn", (0, 1, 2))
         ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn())
-        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", x)
-        x = _cross(P, p + ".src_attn", cfg, drop, P.ln(x, p + ".sublayer.1.norm"), x, memory, kv_cache, N, S, R, spi, att_len_cap)
-        x = _ffn(P, p + ".feed_forward", drop, P.ln(x, p + ".sublayer.2.norm"), x)
+        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
+        xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
+        x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap)
+        xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
+        x = _ffn(P, p + ".feed_forward", drop, n_, xr)
     return P.ln(x, "model.decoder.norm")
 
 
@@ -611,8 +633,10 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
     ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0, drop.attn())
     x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xv)
-    x = _cross(P, p + ".src_attn", cfg, drop, P.ln(x, p + ".sublayer.1.norm"), x, memory, kv_cache, N, Pm, R, spi, att_len_cap)
-    x = _ffn(P, p + ".ff", drop, P.ln(x, p + ".sublayer.2.norm"), x)
+    xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
+    x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, Pm, R, spi, att_len_cap)
+    xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
+    x = _ffn(P, p + ".ff", drop, n_, xr)
     o = P.ln(x, lp + ".norm")
     # heads: hidden 100 is not a multiple of the GEMM K granule -> both first layers side by side in one padded GEMM
     # (small tensors; their gradients go through autograd's cat/slice nodes)

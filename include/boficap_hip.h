@@ -96,8 +96,9 @@ int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void
  * few extra forward) kernels the XE step needs.  Parameter gradients that are sums over rows are
  * ACCUMULATED into the given buffers (zero them first).
  * ------------------------------------------------------------------------------------------- */
-/* backward of bofi_layernorm: dx [rows, d]; dgain, dbias [d] accumulated */
-int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, float* dx, float* dgain,
+/* backward of bofi_layernorm: dx [rows, d] (+ add [rows, d] when given: the gradient that reaches x along the residual
+ * connection, so that the sum of the two branches costs no extra pass); dgain, dbias [d] accumulated */
+int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain,
                        float* dbias, int rows, int d, void* stream);
 /* backward of bofi_attention_ex (Lq, Lk <= 64): dq like q, dk/dv like k/v (accumulated when kdiv > 1) */
 int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
