@@ -51,10 +51,16 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
     for (int j = 0; j < NJ; ++j) { g[j] = gain[lane + 64 * j]; dg[j] = 0.f; db[j] = 0.f; }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int row = r0 + wave; row < r1; row += 4) {
-        float xv[NJ], dv[NJ];
+        float xv[NJ], dv[NJ], av[NJ];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { xv[j] = x[(size_t)row * d + lane + 64 * j]; dv[j] = dy[(size_t)row * d + lane + 64 * j]; s += xv[j]; }
+        for (int j = 0; j < NJ; ++j) {                        // all three streams of the row are requested up front
+            xv[j] = x[(size_t)row * d + lane + 64 * j];
+            dv[j] = dy[(size_t)row * d + lane + 64 * j];
+            av[j] = add ? add[(size_t)row * d + lane + 64 * j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s += xv[j];
         const float mean = wave_sum(s) / (float)d;
         float q = 0.f, c = 0.f;
 #pragma unroll
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
         m = wave_sum(m) / (float)d;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            dx[(size_t)row * d + lane + 64 * j] = t[j] - m + (add ? add[(size_t)row * d + lane + 64 * j] : 0.f);
+            dx[(size_t)row * d + lane + 64 * j] = t[j] - m + av[j];
             dg[j] += dv[j] * xv[j] * inv;
             db[j] += dv[j];
         }
