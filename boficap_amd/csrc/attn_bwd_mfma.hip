@@ -26,49 +26,50 @@ struct AttnBwdMfmaParams {
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;     // dropout(p_attn) of the forward
 };
 
-// Head slice [rows_real, 64] -> LDS as bf16, rows past the data zero.  All global loads of the slice are issued before the
-// first conversion / LDS store (ROWS is a compile-time constant, the loops unroll): one memory round trip per operand
-// instead of one per 8 rows.
+// Head slice [rows_real, 64] -> LDS as bf16, rows past the data zero, in two phases: load() requests every 16-byte piece of
+// the slice into registers (ROWS is a compile-time constant, the loops unroll: one memory round trip per operand), store()
+// converts and writes them to LDS.  Keeping the phases apart lets the next caption's slices travel while the current one is
+// being multiplied.
 template <typename TIN, int ROWS>
-__device__ __forceinline__ void stage_rows(const TIN* __restrict__ src, int ld, int rows_real, bf16_t* dst, int stride, int lane) {
-    constexpr int IT = ROWS * 8 / 64;
-    if constexpr (sizeof(TIN) == 4) {
-        float4 a[IT], b[IT];
+struct RowStage {
+    static constexpr int IT = ROWS * 8 / 64;
+    static constexpr int NV = sizeof(TIN) == 4 ? 2 * IT : IT;
+    u32x4 v[NV];
+    __device__ __forceinline__ void load(const TIN* __restrict__ src, int ld, int rows_real, int lane) {
 #pragma unroll
         for (int t = 0; t < IT; ++t) {
             const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
-            a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b[t] = a[t];
-            if (r < rows_real) {
-                a[t] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
-                b[t] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c + 4);
+            if constexpr (sizeof(TIN) == 4) {
+                v[2 * t] = u32x4{0u, 0u, 0u, 0u};
+                v[2 * t + 1] = v[2 * t];
+                if (r < rows_real) {
+                    v[2 * t] = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c);
+                    v[2 * t + 1] = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c + 4);
+                }
+            } else {
+                v[t] = u32x4{0u, 0u, 0u, 0u};
+                if (r < rows_real) v[t] = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c);
             }
         }
+    }
+    __device__ __forceinline__ void store(bf16_t* dst, int stride, int lane) const {
 #pragma unroll
         for (int t = 0; t < IT; ++t) {
             const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
-            u32x4 o;
-            o[0] = (uint32_t)f32_to_bf16(a[t].x) | ((uint32_t)f32_to_bf16(a[t].y) << 16);
-            o[1] = (uint32_t)f32_to_bf16(a[t].z) | ((uint32_t)f32_to_bf16(a[t].w) << 16);
-            o[2] = (uint32_t)f32_to_bf16(b[t].x) | ((uint32_t)f32_to_bf16(b[t].y) << 16);
-            o[3] = (uint32_t)f32_to_bf16(b[t].z) | ((uint32_t)f32_to_bf16(b[t].w) << 16);
-            *reinterpret_cast<u32x4*>(dst + r * stride + c) = o;
-        }
-    } else {
-        u32x4 v[IT];
-#pragma unroll
-        for (int t = 0; t < IT; ++t) {
-            const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
-            v[t] = u32x4{0u, 0u, 0u, 0u};
-            if (r < rows_real) v[t] = *reinterpret_cast<const u32x4*>(src + (size_t)r * ld + c);
-        }
-#pragma unroll
-        for (int t = 0; t < IT; ++t) {
-            const int i = lane + 64 * t, r = i >> 3, c = (i & 7) * 8;
-            *reinterpret_cast<u32x4*>(dst + r * stride + c) = v[t];
+            if constexpr (sizeof(TIN) == 4) {
+                const u32x4 a = v[2 * t], b = v[2 * t + 1];
+                u32x4 o;
+                o[0] = (uint32_t)f32_to_bf16(__uint_as_float(a[0])) | ((uint32_t)f32_to_bf16(__uint_as_float(a[1])) << 16);
+                o[1] = (uint32_t)f32_to_bf16(__uint_as_float(a[2])) | ((uint32_t)f32_to_bf16(__uint_as_float(a[3])) << 16);
+                o[2] = (uint32_t)f32_to_bf16(__uint_as_float(b[0])) | ((uint32_t)f32_to_bf16(__uint_as_float(b[1])) << 16);
+                o[3] = (uint32_t)f32_to_bf16(__uint_as_float(b[2])) | ((uint32_t)f32_to_bf16(__uint_as_float(b[3])) << 16);
+                *reinterpret_cast<u32x4*>(dst + r * stride + c) = o;
+            } else {
+                *reinterpret_cast<u32x4*>(dst + r * stride + c) = v[t];
+            }
         }
     }
-}
+};
 
 // MFMA operand gathered from a row-major LDS tile whose ROWS are the contraction index: rows row_base .. row_base + 31,
 // operand index (A row / B column) = col_base + (lane & 15)
@@ -105,8 +106,17 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
     const int Lq = p.Lq, Lk = p.Lk;
     const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.drop_step) ? *p.drop_step : 0ull);
 
-    stage_rows<TIN, LK>(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, sk, DS, lane);
-    stage_rows<TIN, LK>(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, sv, DS, lane);
+    RowStage<TIN, LQ> rq;
+    RowStage<float, LQ> rdo;
+    {   // keys, values and the first caption's queries / output gradients: all requested before anything is converted
+        RowStage<TIN, LK> rk, rv;
+        rk.load(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, lane);
+        rv.load(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, lane);
+        rq.load(static_cast<const TIN*>(p.q) + (size_t)bk * p.kdiv * Lq * p.ldq + h * 64, p.ldq, Lq, lane);
+        rdo.load(p.dout + (size_t)bk * p.kdiv * Lq * p.ldo + h * 64, p.ldo, Lq, lane);
+        rk.store(sk, DS, lane);
+        rv.store(sv, DS, lane);
+    }
 
     f32x4 ak[KT][4], av[KT][4];
 #pragma unroll
@@ -117,8 +127,12 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
     for (int c = 0; c < p.kdiv; ++c) {
         const int b = bk * p.kdiv + c;
         if (c) __syncthreads();                                  // the previous caption's operands are still being read
-        stage_rows<TIN, LQ>(static_cast<const TIN*>(p.q) + (size_t)b * Lq * p.ldq + h * 64, p.ldq, Lq, sq, DS, lane);
-        stage_rows<float, LQ>(p.dout + (size_t)b * Lq * p.ldo + h * 64, p.ldo, Lq, sdo, DS, lane);
+        rq.store(sq, DS, lane);
+        rdo.store(sdo, DS, lane);
+        if (c + 1 < p.kdiv) {                                    // the next caption's slices travel while this one is multiplied
+            rq.load(static_cast<const TIN*>(p.q) + (size_t)(b + 1) * Lq * p.ldq + h * 64, p.ldq, Lq, lane);
+            rdo.load(p.dout + (size_t)(b + 1) * Lq * p.ldo + h * 64, p.ldo, Lq, lane);
+        }
         __syncthreads();
 
         // ---- S = Q K^T, dP = dO V^T  (lane holds rows q = qt*16 + 4g + r, column k = kt*16 + l15)
