@@ -415,3 +415,19 @@ def test_device_side_weight_refresh_equals_a_fresh_load(dtype, weight_cache, man
     assert torch.equal(back["seq"], first["seq"])
     with pytest.raises(Exception):
         eng.refresh_from_device({k: v for k, v in dev_b.items() if "generator" not in k})
+
+
+def test_dynamic_batching_with_refinement_rounds(weight_cache, manifest):
+    """q1_group together with iterative refinement: each batch equals its own refined decode."""
+    from boficap_amd.engine import BofiEngine
+    m = manifest["tiny_mix"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"])
+    g = load_golden("tiny_mix")
+    a, b = torch.from_numpy(g["att_feats"][:4]).cuda(), torch.from_numpy(g["att_feats"][4:8]).cuda()
+    eng = BofiEngine(cfg, torch.float32, max_batch=8, max_regions=36)
+    eng.load_state_dict(sd)
+    ra = {k: v.clone() for k, v in eng.decode_naic(a, refine_rounds=2).items() if torch.is_tensor(v)}
+    rb = {k: v.clone() for k, v in eng.decode_naic(b, refine_rounds=2).items() if torch.is_tensor(v)}
+    both = eng.decode_naic(torch.cat([a, b]), refine_rounds=2, q1_group=4)
+    assert torch.equal(both["seq"][:4], ra["seq"]) and torch.equal(both["seq"][4:], rb["seq"])
+    assert torch.equal(both["phrase_length"][:4], ra["phrase_length"]) and torch.equal(both["phrase_length"][4:], rb["phrase_length"])

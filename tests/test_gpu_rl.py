@@ -154,3 +154,37 @@ def test_rl_step_runs_and_moves_the_weights(weight_cache, manifest):
     assert model.training and float((tr.bucket.flat - w0).abs().max()) > 0
     length_w = dict(model.named_parameters())["model.length_predictor.Length_classifier2.weight"]
     assert torch.equal(length_w.detach().cpu(), torch.from_numpy(sd["model.length_predictor.Length_classifier2.weight"]))   # no RL gradient reaches the bound heads
+
+
+def test_rl_step_with_ragged_regions_and_bf16(weight_cache, manifest):
+    """att_masks (ragged region counts) through both samplers and the re-forward, bf16 operands, graph-mode trainer falling
+    back to eager for the self-critical step."""
+    from boficap_amd import xe
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, model = _model(weight_cache, manifest)
+    model.train_dtype = torch.bfloat16
+    att = _images().cuda()
+    B = att.size(0)
+    masks = torch.ones(B, 36, device="cuda")
+    for i, n in enumerate((36, 30, 25, 36, 19, 33)[:B]):
+        masks[i, n:] = 0
+        att[i, n:] = 0
+    # the re-forward still returns the sampled distributions with masks in play (float32 check first)
+    model.train_dtype = torch.float32
+    fc = torch.zeros(B, 0, device="cuda")
+    with torch.no_grad():
+        r = model(fc, att, masks, opt={"train_mode": "SAIC", "sample_method": "sample", "sample_n": 2}, mode="sample")
+    rs = dict(zip(("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn"), r[:5]))
+    lp, _ = xe.sampled_logprobs(xe.Params(model), cfg, att, masks, rs, None, sample_n=2)
+    ntok = rs["phrase_length"].sum(1)
+    for i in range(lp.shape[0]):
+        k = int(ntok[i])
+        if k and not rs["seq_logprob"][i, :k].isnan().any():
+            assert float((lp[i, :k].detach() - rs["seq_logprob"][i, :k]).abs().max()) < 2e-3
+    model.train_dtype = torch.bfloat16
+    opt = cfg.to_opt()
+    opt.noamopt, opt.learning_rate = False, 1e-4
+    tr = XETrainer(model, opt, graph=True)
+    model.train()
+    loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
+    assert torch.isfinite(loss)
