@@ -123,7 +123,11 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
     if (((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return BOFI_ERR_ARG;
     if (M == 0) return BOFI_OK;
     const int ti = (NI + 63) / 64, tj = (NJ + 63) / 64;
-    int splits = 1024 / (ti * tj);
+    // workgroups to aim for: every extra row split adds a tile of atomics, so small outputs (<= 128 tiles) take half as many
+    // (measured, tools/mb_tn.py: 512x512 20.0 -> 17.1 us, 1024x512 over 2304 rows 17.1 -> 12.8 us; larger outputs prefer 1024)
+    static const int forced_wgs = [] { const char* v = getenv("BOFI_TN_WGS"); return v ? atoi(v) : 0; }();   // developer knob
+    const int target_wgs = forced_wgs ? forced_wgs : (ti * tj <= 128 ? 512 : 1024);
+    int splits = target_wgs / (ti * tj);
     splits = max(1, min(splits, (M + 127) / 128));                 // at least 4 tiles of rows per workgroup
     int mpb = ((M + splits - 1) / splits + 63) / 64 * 64;
     splits = (M + mpb - 1) / mpb;
