@@ -123,6 +123,7 @@ class XETrainer:
         self.v = torch.zeros_like(self.bucket.flat)
         self._step = 0
         self.graph = bool(graph)
+        self.max_graphs = 8                                    # batch signatures (shapes x max phrase count x GLAT rate) kept as graphs
         self._graphs = {}
         self._fwd_calls = 0
         if self.graph:
@@ -155,6 +156,8 @@ class XETrainer:
         key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), int(batch["max_phrase_num"]), round(float(glat_p), 6),
                self.model.training, self.model.train_dtype)
         entry = self._graphs.get(key)
+        if entry is None and len(self._graphs) >= self.max_graphs:
+            return self._forward_backward_eager(batch, glat_p)     # every capture pins its activations' pool: bound their number
         if entry is None:
             static = {k: batch[k].clone() for k in self._KEYS}
             static["max_phrase_num"] = int(batch["max_phrase_num"])
