@@ -23,6 +23,7 @@ struct GemmTnParams {
     const bf16_t* b; int ldb; int b_cols;
     float* c; int ldc;
     int M, NI, NJ, m_per_block;
+    float* colsum;                               // optional: colsum[i] += sum_m A[m][i] (the bias gradient when A is dz)
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
@@ -78,6 +79,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
         return f;
     };
 
+    // column sums of the A tiles (workgroups of the first tile column only): thread -> column tid & 63, rows (tid >> 6) * 16 .. + 15
+    const bool do_colsum = p.colsum != nullptr && blockIdx.y == 0;
+    float csum = 0.f;
+    const int cc = tid & 63, crg = tid >> 6;
+
     load(m_begin);
     stash(0);
     __syncthreads();
@@ -98,9 +104,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+        if (do_colsum) {
+#pragma unroll
+            for (int hh = 0; hh < 16; ++hh) {
+                const int r = crg * 16 + hh;
+                csum += bf16_to_f32(sa[buf][r * T + ((((cc >> 3) ^ ((r >> 1) & 7))) << 3) + (cc & 7)]);
+            }
+        }
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
+    if (do_colsum) {                                              // combine the four row groups, one atomic per column
+        float* red = reinterpret_cast<float*>(&sa[0][0]);
+        red[crg * 64 + cc] = csum;
+        __syncthreads();
+        if (tid < 64 && i0 + tid < p.NI) atomicAdd(&p.colsum[i0 + tid], (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
     }
     // lane holds C[i = .. + 4g + r][j = .. + l15]
 #pragma unroll
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 }
 
 int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M, int NI, int NJ,
-                   hipStream_t st) {
+                   float* colsum, hipStream_t st) {
     if (!a || !b || !c || M < 0 || NI <= 0 || NJ <= 0 || ldc < NJ) return BOFI_ERR_ARG;
     if (a_cols < NI || b_cols < NJ || a_cols % 8 || b_cols % 8 || lda < a_cols || ldb < b_cols || lda % 8 || ldb % 8) return BOFI_ERR_ARG;
     if (((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return BOFI_ERR_ARG;
@@ -131,7 +150,7 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
     splits = max(1, min(splits, (M + 127) / 128));                 // at least 4 tiles of rows per workgroup
     int mpb = ((M + splits - 1) / splits + 63) / 64 * 64;
     splits = (M + mpb - 1) / mpb;
-    GemmTnParams p{static_cast<const bf16_t*>(a), lda, a_cols, static_cast<const bf16_t*>(b), ldb, b_cols, c, ldc, M, NI, NJ, mpb};
+    GemmTnParams p{static_cast<const bf16_t*>(a), lda, a_cols, static_cast<const bf16_t*>(b), ldb, b_cols, c, ldc, M, NI, NJ, mpb, colsum};
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(ti, tj, splits), dim3(256), 0, st, p);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
@@ -140,6 +159,6 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
 }  // namespace bofi
 
 extern "C" int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M, int NI,
-                                int NJ, void* stream) {
-    return bofi::launch_gemm_tn(a, lda, a_cols, b, ldb, b_cols, c, ldc, M, NI, NJ, (hipStream_t)stream);
+                                int NJ, float* colsum, void* stream) {
+    return bofi::launch_gemm_tn(a, lda, a_cols, b, ldb, b_cols, c, ldc, M, NI, NJ, colsum, (hipStream_t)stream);
 }

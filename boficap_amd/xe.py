@@ -215,7 +215,8 @@ class LinearFn(Function):
             # one bf16 copy of dz serves both products (its column sums = the bias gradient, taken during the cast);
             # dW = dz^T x runs on the transposing-read GEMM straight from the row-major operands
             # ReLU and dropout masks are applied inside the cast (a dropped ReLU unit has y == 0: the ReLU test covers it)
-            dzo, Np = _operand(dy, M, N, dt, cache=False, colsum=bsum, relu_y=y if ctx.relu else None, drop=ctx.drop)
+            # the bias gradient (column sums of dz) is taken by the weight-gradient GEMM from its A tiles
+            dzo, Np = _operand(dy, M, N, dt, cache=False, colsum=None if want_w else bsum, relu_y=y if ctx.relu else None, drop=ctx.drop)
             if ctx.needs_input_grad[0]:
                 wt, _ = _transposed(w, N, K, dt)       # [K, Np], once per weight per step
                 dx = _empty(x, M, K)
@@ -225,7 +226,7 @@ class LinearFn(Function):
                 target = ctx.gw
                 if target is None:
                     dw = target = _zeros(x, N, K)
-                _chk(L.bofi_gemm_tn_acc(hip.ptr(dzo), Np, Np, hip.ptr(xo), Kp, Kp, hip.ptr(target), K, M, N, K, st), "bofi_gemm_tn_acc")
+                _chk(L.bofi_gemm_tn_acc(hip.ptr(dzo), Np, Np, hip.ptr(xo), Kp, Kp, hip.ptr(target), K, M, N, K, hip.ptr(bsum), st), "bofi_gemm_tn_acc")
             return (dx, dw, db) + tail
         if ctx.needs_input_grad[0]:
             dzo, Np = _operand(dz, M, N, dt, cache=False)

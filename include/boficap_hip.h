@@ -124,9 +124,11 @@ int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe,
 int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream);
 /* Weight-gradient GEMM: c[i][j] += sum_m a[m][i] * b[m][j], i < NI, j < NJ (dW = dz^T x without transposed copies).
  * a, b: bf16 row-major [M, a_cols | b_cols] (cols a multiple of 8, zero beyond NI | NJ; 16-byte aligned rows);
- * c: float32 [NI, NJ] row stride ldc, ACCUMULATED into with atomics (zero it for a plain product). */
+ * c: float32 [NI, NJ] row stride ldc, ACCUMULATED into with atomics (zero it for a plain product).
+ * colsum (may be NULL): colsum[i] += sum_m a[m][i], taken from the A tiles while they sit in LDS (dz's column sums = the
+ * bias gradient; a few atomics per workgroup instead of a reduction pass of its own). */
 int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M,
-                     int NI, int NJ, void* stream);
+                     int NI, int NJ, float* colsum, void* stream);
 /* xt[n][m] = x[m][n], zero for M <= m < Mpad, written as out_dtype: operand layout of the weight-gradient GEMM.
  * colsum (may be NULL): colsum[n] += sum_m x[m][n], the bias gradient, taken from the tiles while they are in LDS */
 int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream);

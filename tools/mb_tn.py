@@ -10,7 +10,7 @@ for M, NI, NJ in ((6400, 512, 512), (6400, 1536, 512), (6400, 2048, 512), (6400,
     a = torch.randn(M, NI, device="cuda").to(torch.bfloat16)
     b = torch.randn(M, NJ, device="cuda").to(torch.bfloat16)
     c = torch.zeros(NI, NJ, device="cuda")
-    run = lambda: hip.check(lib.bofi_gemm_tn_acc(hip.ptr(a), NI, NI, hip.ptr(b), NJ, NJ, hip.ptr(c), NJ, M, NI, NJ, hip.stream_ptr()))
+    run = lambda: hip.check(lib.bofi_gemm_tn_acc(hip.ptr(a), NI, NI, hip.ptr(b), NJ, NJ, hip.ptr(c), NJ, M, NI, NJ, None, hip.stream_ptr()))
     for _ in range(5):
         run()
     torch.cuda.synchronize()
