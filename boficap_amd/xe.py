@@ -662,6 +662,21 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
 HINTS: dict = {}
 
 
+def _scoped_compute_dtype(fn):
+    """The GEMM compute dtype is a module global while a forward pass builds its graph (the Functions record what they need
+    for their backward); restore the previous value on the way out so that nothing leaks into later op-level calls."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        prev = _COMPUTE["dtype"]
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            _COMPUTE["dtype"] = prev
+    return wrapper
+
+
 def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor, max_phrase_num: Optional[int] = None):
     """Key count of the [LEN] row per (caption, pass), TransformerModel.py:493-511: pass 0 sees 1 key; pass i >= 1 sees
     1 + sum(phrase_length[n, 1..min(i, phrase_num[n]-1)]).  Also the final ``last`` per caption (:562-564)."""
@@ -673,6 +688,7 @@ def bound_pass_klen(phrase_num: torch.Tensor, phrase_length: torch.Tensor, max_p
     return cum[:, :Pm].to(torch.int32).contiguous(), cum[:, -1].to(torch.int32).contiguous(), Pm
 
 
+@_scoped_compute_dtype
 def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, extend_phrase_seq,
                 extend_phrase_seq_mask, *, glat_p: float = -1.0, training: bool = False, seed: Optional[int] = None,
                 compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
@@ -758,6 +774,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
 
 
+@_scoped_compute_dtype
 def sampled_logprobs(P, cfg, att_feats, att_masks, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool = True, training: bool = False,
                      seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
     """Token log-probs of SAMPLED captions with the autograd tape: the differentiable half of the self-critical step.
