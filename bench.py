@@ -184,6 +184,7 @@ def main_xe(args):
     host_batch = synthetic_training_batch(cfg, args.batch, spi, seed=100 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in host_batch.items()}
     batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
+    batch["max_tokens"] = int((host_batch["phrase_length"].sum(-1) - 1).max())
     batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
     batch["att_masks"] = None
 
@@ -220,7 +221,8 @@ def main_xe(args):
             "config": {"workload": f"XE training (configs/uic_sd.yml model) batch={args.batch} images x {spi} captions per GPU, 36x2048 regions, "
                                    f"d_model=512 6 enc + 6 dec + 1 bound layer, {args.dtype}, dropout on",
                        "images_per_step_per_gpu": args.batch, "captions_per_image": spi, "vocab": cfg.tgt_vocab,
-                       "hip_graph": tr.graph, "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
+                       "hip_graph": tr.graph, "decoder_positions_computed": batch["max_tokens"],
+                       "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
                        "sharding": "images by rank; one RCCL all-reduce over the flat fp32 gradient bucket per step"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None,

@@ -105,6 +105,11 @@ def synthetic_training_batch(cfg, n_img: int, seq_per_img: int, seed: int = 0) -
     return {k: v.reshape(n_img, seq_per_img, *v.shape[1:]) for k, v in b.items()}
 
 
+def max_tokens(batch) -> int:
+    """Length of the longest caption of the batch (host value): the training forward computes that many decoder positions."""
+    return int((np.asarray(batch["phrase_length"]).sum(-1) - 1).max())
+
+
 def max_phrase_num(batch) -> int:
     """max over the batch of the loader's phrase_num (host value; lets the training forward skip a device->host read)."""
     return int(np.asarray(batch["phrase_num"]).max())

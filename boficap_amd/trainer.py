@@ -153,7 +153,8 @@ class XETrainer:
         return torch.cuda.is_current_stream_capturing()
 
     def _replay(self, batch, glat_p):
-        key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), int(batch["max_phrase_num"]), round(float(glat_p), 6),
+        key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), int(batch["max_phrase_num"]),
+               int(batch.get("max_tokens") or 0), round(float(glat_p), 6),
                self.model.training, self.model.train_dtype)
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
@@ -161,6 +162,7 @@ class XETrainer:
         if entry is None:
             static = {k: batch[k].clone() for k in self._KEYS}
             static["max_phrase_num"] = int(batch["max_phrase_num"])
+            static["max_tokens"] = batch.get("max_tokens")
             self._forward_backward_eager(static, glat_p)        # warm-up outside the capture (lazy initialisations, allocator)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -182,6 +184,8 @@ class XETrainer:
             fc = torch.zeros(batch["att_feats"].shape[0], 0, device=batch["att_feats"].device)
         if batch.get("max_phrase_num") is not None:            # known on the host since the collate: spares the forward a device read
             xe.HINTS["max_phrase_num"] = int(batch["max_phrase_num"])
+        if batch.get("max_tokens") is not None:                # dynamic padding: decoder positions past the longest caption are skipped
+            xe.HINTS["max_tokens"] = int(batch["max_tokens"])
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)

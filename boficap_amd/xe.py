@@ -658,7 +658,11 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
 
 
 # Host-side facts about the batch the caller already knows (set by the trainer from the collate's output) so that the
-# forward pass needs no device->host read: {"max_phrase_num": int}.  Consumed (cleared) by the next forward_uic.
+# forward pass needs no device->host read: {"max_phrase_num": int, "max_tokens": int}.  Consumed (cleared) by the next
+# forward_uic.  "max_tokens" (the longest caption of the batch) additionally lets the two decoder passes and the vocabulary
+# projection run over that many positions instead of seq_length: positions past a caption's last token are neither attended
+# by earlier ones nor counted by the criterion, so the loss and every gradient are unchanged (dynamic padding); the two token
+# tensors then come back as [N, max_tokens, V].
 HINTS: dict = {}
 
 
@@ -728,6 +732,8 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     ext_syn = extend_phrase_syn_seq.to(dev).long().contiguous()
     ext_seq = extend_phrase_seq.to(dev).long().contiguous()
     klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length, HINTS.pop("max_phrase_num", None))
+    Sd = HINTS.pop("max_tokens", None)
+    Sd = S if not Sd else max(1, min(S, int(Sd)))               # decoder positions actually computed
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
@@ -749,28 +755,29 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     word_seq[:, 0] = cfg.len_idx
     sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
                                           att_len_cap)
-    syn_mid = ext_syn[:, 1:-1].contiguous()
-    klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1).to(torch.int32).contiguous()          # prefix masks (dataloader.py:414)
-    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, S), memory, kv_cache, N, S, R, spi, klen_sa, att_len_cap)
-    sa_tok = log_softmax(vocab(x)).view(N, S, -1)
+    syn_mid = ext_syn[:, 1:1 + Sd].contiguous()
+    ext_seq = ext_seq[:, :Sd].contiguous()
+    klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1)[:, :Sd].to(torch.int32).contiguous()  # prefix masks (dataloader.py:414)
+    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_sa, att_len_cap)
+    sa_tok = log_softmax(vocab(x)).view(N, Sd, -1)
 
     # --- non-autoregressive branch (:532-587)
     na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
-    klen_na = (last - 1).unsqueeze(1).expand(N, S).contiguous()
-    fill_in = torch.full((N, S), cfg.bos_idx, dtype=torch.int64, device=dev)
+    klen_na = (last - 1).unsqueeze(1).expand(N, Sd).contiguous()
+    fill_in = torch.full((N, Sd), cfg.bos_idx, dtype=torch.int64, device=dev)
     if glat_p >= 0:                                            # glancing input (:437-463): reveal a share of the true tokens
         with torch.no_grad():
-            x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, dict(kv_cache), N, S, R, spi, klen_na, att_len_cap)
-            pred = greedy_ids(vocab(x)).view(N, S)
-            real = labels[:, 1:-1]
+            x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, dict(kv_cache), N, Sd, R, spi, klen_na, att_len_cap)
+            pred = greedy_ids(vocab(x)).view(N, Sd)
+            real = labels[:, 1:1 + Sd]
             ntok = phrase_length.sum(1) - 1
-            tok_mask = torch.arange(S, device=dev).unsqueeze(0) < ntok.unsqueeze(1)
+            tok_mask = torch.arange(Sd, device=dev).unsqueeze(0) < ntok.unsqueeze(1)
             same = ((pred == real) & tok_mask).sum(1)
             keep_prob = ((ntok - same) / ntok * glat_p).unsqueeze(-1) * tok_mask.float()
             keep = torch.rand(real.shape, device=dev) < keep_prob
             fill_in = torch.where(keep, real, fill_in).contiguous()
-    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, S), memory, kv_cache, N, S, R, spi, klen_na, att_len_cap)
-    na_tok = log_softmax(vocab(x)).view(N, S, -1)
+    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap)
+    na_tok = log_softmax(vocab(x)).view(N, Sd, -1)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
 
 
@@ -879,7 +886,7 @@ def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
         labels = labels.reshape(-1, labels.shape[2])
     phrase_num, phrase_length = phrase_num.to(dev).long(), phrase_length.to(dev).long()
     phrase_syn, labels = phrase_syn.to(dev).long(), labels.to(dev).long()
-    real = labels[:, 1:-1]
+    real = labels[:, 1:-1][:, :sa_tok.shape[1]]                # the token tensors may cover max_tokens positions only (HINTS)
     pos = torch.arange(real.shape[1], device=dev).unsqueeze(0)
     tok_mask = pos < (phrase_length.sum(1, keepdim=True) - 1)
     slot = torch.arange(phrase_length.shape[1] - 1, device=dev).unsqueeze(0)

@@ -527,3 +527,32 @@ def test_trainer_graph_replay_matches_eager_steps(weight_cache, manifest):
     graph_model.train()
     l1 = float(tg.step(batches[0])[0]); l2 = float(tg.step(batches[0])[0]); l3 = float(tg.step(batches[0])[0])
     assert all(map(lambda v: v == v, (l1, l2, l3))) and len({round(l1, 5), round(l2, 5), round(l3, 5)}) == 3
+
+
+def test_dynamic_padding_leaves_loss_and_gradients_unchanged(weight_cache, manifest):
+    """With the longest caption's length as a host hint the decoder passes and the vocabulary projection skip the positions
+    past it: same loss, same gradients (those positions are neither attended nor counted by the criterion)."""
+    from boficap_amd.collate import max_tokens, synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, full = _model(weight_cache, manifest, "tiny_train_xe")
+    _, short = _model(weight_cache, manifest, "tiny_train_xe")
+    full.eval(); short.eval()
+    n_img, spi = 3, 3
+    hb = synthetic_training_batch(cfg, n_img, spi, seed=12)
+    mt = max_tokens(hb)
+    assert mt < cfg.seq_length
+    batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+    batch["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=3)).cuda()
+    batch["max_phrase_num"] = int(hb["phrase_num"].max())
+    ta, tb = XETrainer(full), XETrainer(short)
+    la, _ = ta.forward_backward(batch)
+    lb, _ = tb.forward_backward(dict(batch, max_tokens=mt))
+    assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
+    assert _maxdiff(tb.bucket.grad, ta.bucket.grad) <= 1e-4 * max(1e-3, float(ta.bucket.grad.abs().max()))
+    fc = torch.zeros(n_img, 0, device="cuda")
+    from boficap_amd import xe
+    xe.HINTS["max_tokens"] = mt
+    outs = short(fc, batch["att_feats"], batch["labels"], None, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
+                 batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"], -1.0)
+    assert outs[2].shape[1] == mt and outs[5].shape[1] == mt and outs[0].shape[1] == cfg.seq_length + 1

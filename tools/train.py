@@ -85,6 +85,7 @@ def main():
         host_batch = synthetic_training_batch(cfg, opt.batch_size, opt.seq_per_img, seed=seed)
         batch = {k: torch.from_numpy(v).to(dev) for k, v in host_batch.items()}
         batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
+        batch["max_tokens"] = int((host_batch["phrase_length"].sum(-1) - 1).max())
         batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(opt.batch_size, 36, cfg.att_feat_size, seed=seed)).to(dev)
         glat_p = args.unmasked_rate_start if args.glancing_token else -1.0          # train.py:165-170
         loss, parts = trainer.step(batch, glat_p)
