@@ -149,12 +149,19 @@ class XETrainer:
         return self._forward_backward_eager(batch, glat_p)
 
     @staticmethod
+    def _bucket(v, cap: int, step: int = 4) -> int:
+        """Round a batch-dependent upper bound up to a multiple of ``step``: the bounds only have to be upper bounds (what lies
+        past the true value is masked), and a handful of distinct values keeps the number of captured step graphs small."""
+        return min(cap, (int(v) + step - 1) // step * step)
+
+    @staticmethod
     def _capturing() -> bool:
         return torch.cuda.is_current_stream_capturing()
 
     def _replay(self, batch, glat_p):
-        key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), int(batch["max_phrase_num"]),
-               int(batch.get("max_tokens") or 0), round(float(glat_p), 6),
+        S = self.model.cfg.seq_length
+        key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), self._bucket(batch["max_phrase_num"], S + 1),
+               self._bucket(batch["max_tokens"], S) if batch.get("max_tokens") else 0, round(float(glat_p), 6),
                self.model.training, self.model.train_dtype)
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
@@ -183,9 +190,9 @@ class XETrainer:
         if fc is None:
             fc = torch.zeros(batch["att_feats"].shape[0], 0, device=batch["att_feats"].device)
         if batch.get("max_phrase_num") is not None:            # known on the host since the collate: spares the forward a device read
-            xe.HINTS["max_phrase_num"] = int(batch["max_phrase_num"])
+            xe.HINTS["max_phrase_num"] = self._bucket(batch["max_phrase_num"], self.model.cfg.seq_length + 1)
         if batch.get("max_tokens") is not None:                # dynamic padding: decoder positions past the longest caption are skipped
-            xe.HINTS["max_tokens"] = int(batch["max_tokens"])
+            xe.HINTS["max_tokens"] = self._bucket(batch["max_tokens"], self.model.cfg.seq_length)
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)
