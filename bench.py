@@ -380,7 +380,7 @@ def main():
     # streams that provably overlap (distinct hardware queues), found by timing a spin kernel on pairs
     from boficap_amd.engine import pick_concurrent_streams
     streams = pick_concurrent_streams(args.inflight, dev) if args.inflight > 1 else [torch.cuda.current_stream(dev)]
-    if 1 < len(streams) < args.inflight:                       # an unlucky draw of hardware queues: look among more candidates once
+    if args.inflight > 1 and len(streams) < args.inflight:                       # an unlucky draw of hardware queues: look among more candidates once
         more = pick_concurrent_streams(args.inflight, dev, candidates=48)
         streams = more if len(more) > len(streams) else streams
     log(f"{len(streams)} concurrent streams")
