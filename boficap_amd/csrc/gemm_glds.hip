@@ -66,8 +66,17 @@ struct Gemm2Params {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2>     // WM x WN wavefronts, each owns (BM/WM) x (BN/WN)
+// FEAT: the optional parts of the epilogue / control this instantiation carries (bit 0: folded LayerNorm in, 1: row statistics
+// and compute-dtype copy out, 2: padded-row zeroing, 3: dropout, 4: early-out word and developer ablations).  A specialisation
+// drops the kernel arguments of the parts it does not carry, which is what matters: the full kernel spills scalar registers.
+constexpr int FEAT_ALL = 31;
+template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2, int FEAT = FEAT_ALL>     // WM x WN wavefronts, each owns (BM/WM) x (BN/WN)
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) {
+    if constexpr (!(FEAT & 1)) { p.ln_stats = nullptr; p.ln_colsum = nullptr; }
+    if constexpr (!(FEAT & 2)) { p.stats_out = nullptr; p.y2 = nullptr; }
+    if constexpr (!(FEAT & 4)) { p.row_len = nullptr; }
+    if constexpr (!(FEAT & 8)) { p.drop_thresh = 0; p.drop_step = nullptr; }
+    if constexpr (!(FEAT & 16)) { p.skip_if_ge = nullptr; p.dbg = 0; }
     constexpr int NW = WM * WN;
     constexpr int EPC = 16 / sizeof(T);                 // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;                         // one 128-byte slab row
@@ -331,9 +340,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     }
 }
 
-template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2>
+template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2, int FEAT = FEAT_ALL>
 static void launch_one(const Gemm2Params& p, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS, WM, WN>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), p.splitk), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, NS, WM, WN, FEAT>), dim3(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), p.splitk), dim3(64 * WM * WN), 0, st, p);
+}
+
+// the three tile shapes the heuristic picks, specialised for the feature sets the decode and training paths actually use
+template <typename T, int FEAT>
+static bool launch_specialised(const Gemm2Params& p, int bm, int bn, int ns, int nw, hipStream_t st) {
+    if (bm == 128 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 128, 64, 2, 4, 2, FEAT>(p, st); return true; }
+    if (bm == 64 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 64, 64, 2, 4, 2, FEAT>(p, st); return true; }
+    if (bm == 64 && bn == 32 && ns == 4 && nw == 4) { launch_one<T, 64, 32, 4, 2, 2, FEAT>(p, st); return true; }
+    return false;
 }
 
 template <typename T>
@@ -349,6 +367,23 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
         if (p.M <= 64) { bm = 64; bn = 32; ns = 4; }
         else if (t >= 400) { bm = 128; bn = 64; ns = 2; nw = 8; }
         else { bm = 64; bn = 64; ns = 2; nw = 8; }          // 8 waves of 16x32 / 32x32: more waves per CU hide the slab latency
+    }
+    {
+        const int feat = (p.ln_stats ? 1 : 0) | ((p.stats_out || p.y2) ? 2 : 0) | (p.row_len ? 4 : 0) | (p.drop_thresh ? 8 : 0) |
+                         ((p.skip_if_ge || p.dbg) ? 16 : 0);
+        bool done = false;
+        switch (feat) {
+            case 0: done = launch_specialised<T, 0>(p, bm, bn, ns, nw, st); break;          // plain: bias / ReLU / residual
+            case 1: done = launch_specialised<T, 1>(p, bm, bn, ns, nw, st); break;          // consumer of a folded LayerNorm
+            case 2: done = launch_specialised<T, 2>(p, bm, bn, ns, nw, st); break;          // producer of a residual stream
+            case 16: done = launch_specialised<T, 16>(p, bm, bn, ns, nw, st); break;        // the same three inside the bound loop
+            case 17: done = launch_specialised<T, 17>(p, bm, bn, ns, nw, st); break;
+            case 18: done = launch_specialised<T, 18>(p, bm, bn, ns, nw, st); break;
+            case 8: done = launch_specialised<T, 8>(p, bm, bn, ns, nw, st); break;          // training: dropout (+ compute-dtype copy)
+            case 10: done = launch_specialised<T, 10>(p, bm, bn, ns, nw, st); break;
+            default: break;
+        }
+        if (done) { BOFI_CHECK_LAUNCH(); return BOFI_OK; }
     }
     const int key = bm * 10000 + bn * 10 + ns + (nw == 8 ? 100000000 : nw == 16 ? 200000000 : 0);
     switch (key) {
