@@ -187,6 +187,7 @@ def main_xe(args):
     batch["max_tokens"] = int((host_batch["phrase_length"].sum(-1) - 1).max())
     batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
     batch["att_masks"] = None
+    batch = tr.add_token_rows(batch, host_batch)               # the vocabulary projection runs over the real tokens' rows only
 
     def barrier():
         if world > 1:
@@ -222,6 +223,7 @@ def main_xe(args):
                                    f"d_model=512 6 enc + 6 dec + 1 bound layer, {args.dtype}, dropout on",
                        "images_per_step_per_gpu": args.batch, "captions_per_image": spi, "vocab": cfg.tgt_vocab,
                        "hip_graph": tr.graph, "decoder_positions_computed": batch["max_tokens"],
+                       "vocabulary_rows_computed": int(batch["token_rows"].numel()), "vocabulary_rows_dense": args.batch * spi * cfg.seq_length,
                        "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
                        "sharding": "images by rank; one RCCL all-reduce over the flat fp32 gradient bucket per step"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",

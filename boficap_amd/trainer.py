@@ -138,6 +138,7 @@ class XETrainer:
 
     _KEYS = ("att_feats", "labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq",
              "extend_phrase_seq_mask")
+    _OPT_KEYS = ("token_rows", "token_labels", "token_weight")
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
@@ -163,11 +164,13 @@ class XETrainer:
         key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), self._bucket(batch["max_phrase_num"], S + 1),
                self._bucket(batch["max_tokens"], S) if batch.get("max_tokens") else 0, round(float(glat_p), 6),
                self.model.training, self.model.train_dtype)
+        opt_keys = [k for k in self._OPT_KEYS if batch.get(k) is not None]
+        key = key + tuple((k, tuple(batch[k].shape)) for k in opt_keys)
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
             return self._forward_backward_eager(batch, glat_p)     # every capture pins its activations' pool: bound their number
         if entry is None:
-            static = {k: batch[k].clone() for k in self._KEYS}
+            static = {k: batch[k].clone() for k in list(self._KEYS) + opt_keys}
             static["max_phrase_num"] = int(batch["max_phrase_num"])
             static["max_tokens"] = batch.get("max_tokens")
             self._forward_backward_eager(static, glat_p)        # warm-up outside the capture (lazy initialisations, allocator)
@@ -177,7 +180,7 @@ class XETrainer:
                 loss, parts = self._forward_backward_eager(static, glat_p)
             entry = self._graphs[key] = (g, static, loss, parts)
         g, static, loss, parts = entry
-        for k in self._KEYS:
+        for k in list(self._KEYS) + opt_keys:
             if static[k].data_ptr() != batch[k].data_ptr():
                 static[k].copy_(batch[k], non_blocking=True)
         g.replay()
@@ -193,12 +196,41 @@ class XETrainer:
             xe.HINTS["max_phrase_num"] = self._bucket(batch["max_phrase_num"], self.model.cfg.seq_length + 1)
         if batch.get("max_tokens") is not None:                # dynamic padding: decoder positions past the longest caption are skipped
             xe.HINTS["max_tokens"] = self._bucket(batch["max_tokens"], self.model.cfg.seq_length)
+        compact = batch.get("token_rows") is not None and batch.get("max_tokens") is not None
+        if compact:                                            # project only the real tokens' rows onto the vocabulary
+            xe.HINTS["token_rows"] = batch["token_rows"]
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)
-        loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"])
+        if compact:
+            loss, parts = xe.criterion_uic_compact(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
+                                                   batch["token_labels"], batch["token_weight"])
+        else:
+            loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"])
         loss.backward()
         return loss.detach(), [p.detach() for p in parts]
+
+    def add_token_rows(self, batch: Dict[str, torch.Tensor], host_batch) -> Dict[str, torch.Tensor]:
+        """Adds ``token_rows`` / ``token_labels`` / ``token_weight`` (see xe.HINTS) to a device batch from the host copy the
+        collate produced: the flat (caption, position) indices of the real tokens under THIS trainer's bucketing of
+        ``max_tokens``, zero-padded to a multiple of 256 so that a handful of lengths covers a data stream."""
+        import numpy as np
+        S = self.model.cfg.seq_length
+        pl = np.asarray(host_batch["phrase_length"]).reshape(-1, S + 2)
+        labels = np.asarray(host_batch["labels"]).reshape(-1, S + 2)
+        ntok = pl.sum(1) - 1
+        Sd = self._bucket(int(ntok.max()), S)
+        n_idx = np.repeat(np.arange(len(ntok)), ntok)
+        t_idx = np.concatenate([np.arange(k) for k in ntok]) if len(ntok) else np.zeros(0, np.int64)
+        T = len(n_idx)
+        Tp = max(256, (T + 255) // 256 * 256)
+        rows, lab, w = np.zeros(Tp, np.int64), np.zeros(Tp, np.int64), np.zeros(Tp, np.float32)
+        rows[:T], lab[:T], w[:T] = n_idx * Sd + t_idx, labels[n_idx, 1 + t_idx], 1.0
+        dev = batch["att_feats"].device
+        out = dict(batch)
+        out.update(max_tokens=int(ntok.max()), token_rows=torch.from_numpy(rows).to(dev), token_labels=torch.from_numpy(lab).to(dev),
+                   token_weight=torch.from_numpy(w).to(dev))
+        return out
 
     def optimizer_step(self, grad_scale: float = 1.0) -> float:
         self._step += 1

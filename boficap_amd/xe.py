@@ -598,9 +598,9 @@ def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap
     return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
-def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap):
+def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap, out_gemm_only=True):
     """Decoder stack + final norm (TransformerModel.py:1386-1413) over N captions x S positions; self-attention
-    row (n, i) sees keys < klen_self[n, i]."""
+    row (n, i) sees keys < klen_self[n, i].  ``out_gemm_only`` False: the output is also read outside a GEMM (row gather)."""
     d = cfg.d_model
     for l in range(cfg.N_dec):
         p = f"model.decoder.layers.{l}"
@@ -612,7 +612,7 @@ def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_
         x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap)
         xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
         x = _ffn(P, p + ".feed_forward", drop, n_, xr)
-    return P.ln(x, "model.decoder.norm")
+    return P.ln(x, "model.decoder.norm", gemm_only=out_gemm_only)
 
 
 def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap):
@@ -662,7 +662,9 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
 # forward_uic.  "max_tokens" (the longest caption of the batch) additionally lets the two decoder passes and the vocabulary
 # projection run over that many positions instead of seq_length: positions past a caption's last token are neither attended
 # by earlier ones nor counted by the criterion, so the loss and every gradient are unchanged (dynamic padding); the two token
-# tensors then come back as [N, max_tokens, V].
+# tensors then come back as [N, max_tokens, V].  "token_rows" (int64 device tensor of flat indices n * max_tokens + t of the
+# real caption tokens, zero-padded to a fixed length) goes one step further for the vocabulary projection: only those rows are
+# projected, the two token tensors come back as [len(token_rows), V] (criterion_uic_compact is their criterion).
 HINTS: dict = {}
 
 
@@ -734,6 +736,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length, HINTS.pop("max_phrase_num", None))
     Sd = HINTS.pop("max_tokens", None)
     Sd = S if not Sd else max(1, min(S, int(Sd)))               # decoder positions actually computed
+    token_rows = HINTS.pop("token_rows", None)
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
@@ -750,6 +753,11 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     def vocab(x):
         return P.lin(x, "model.generator.proj")
 
+    def token_logprobs(x):
+        if token_rows is None:
+            return log_softmax(vocab(x)).view(N, Sd, -1)
+        return log_softmax(vocab(x.index_select(0, token_rows)))          # [len(token_rows), V]: the real tokens' rows only
+
     # --- semi-autoregressive branch (TransformerModel.py:476-530)
     word_seq = labels.clone()
     word_seq[:, 0] = cfg.len_idx
@@ -758,8 +766,8 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     syn_mid = ext_syn[:, 1:1 + Sd].contiguous()
     ext_seq = ext_seq[:, :Sd].contiguous()
     klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1)[:, :Sd].to(torch.int32).contiguous()  # prefix masks (dataloader.py:414)
-    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_sa, att_len_cap)
-    sa_tok = log_softmax(vocab(x)).view(N, Sd, -1)
+    x = decode_rows(P, cfg, drop, emb(ext_seq, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_sa, att_len_cap, token_rows is None)
+    sa_tok = token_logprobs(x)
 
     # --- non-autoregressive branch (:532-587)
     na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
@@ -776,9 +784,37 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
             keep_prob = ((ntok - same) / ntok * glat_p).unsqueeze(-1) * tok_mask.float()
             keep = torch.rand(real.shape, device=dev) < keep_prob
             fill_in = torch.where(keep, real, fill_in).contiguous()
-    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap)
-    na_tok = log_softmax(vocab(x)).view(N, Sd, -1)
+    x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap, token_rows is None)
+    na_tok = token_logprobs(x)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+
+
+@_scoped_compute_dtype
+def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_labels, token_weight):
+    """criterion_uic for token tensors that hold the real tokens' rows only (HINTS["token_rows"]): ``token_labels`` int64 and
+    ``token_weight`` float32 [len(token_rows)] are the labels of those rows and 1 / 0 for real / padding entries.  Same value and
+    gradients as criterion_uic on the full tensors (the rows left out carry zero weight there)."""
+    sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok = outs
+    dev = sa_tok.device
+    if phrase_length.dim() == 3:
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        phrase_syn = phrase_syn.reshape(-1, phrase_syn.shape[2])
+    phrase_num, phrase_length, phrase_syn = phrase_num.to(dev).long(), phrase_length.to(dev).long(), phrase_syn.to(dev).long()
+    slot = torch.arange(phrase_length.shape[1] - 1, device=dev).unsqueeze(0)
+    slot_mask = slot < phrase_num.unsqueeze(1)
+    len_lab, syn_lab = phrase_length[:, 1:], phrase_syn[:, 1:]
+    denom = token_weight.sum()
+
+    def nll(lp, lab, mask):
+        return (-lp.gather(2, lab.unsqueeze(2)).squeeze(2) * mask).sum() / denom
+
+    def tok(lp):
+        return (-lp.gather(1, token_labels.unsqueeze(1)).squeeze(1) * token_weight).sum() / denom
+
+    parts = [nll(sa_len, len_lab, slot_mask), tok(sa_tok), nll(sa_syn, syn_lab, slot_mask),
+             nll(na_len, len_lab, slot_mask), tok(na_tok), nll(na_syn, syn_lab, slot_mask)]
+    return sum(parts), parts
 
 
 @_scoped_compute_dtype

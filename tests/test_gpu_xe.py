@@ -556,3 +556,33 @@ def test_dynamic_padding_leaves_loss_and_gradients_unchanged(weight_cache, manif
     outs = short(fc, batch["att_feats"], batch["labels"], None, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
                  batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"], -1.0)
     assert outs[2].shape[1] == mt and outs[5].shape[1] == mt and outs[0].shape[1] == cfg.seq_length + 1
+
+
+def test_compact_vocabulary_rows_leave_loss_and_gradients_unchanged(weight_cache, manifest):
+    """Projecting only the real tokens' rows onto the vocabulary (token_rows hint + criterion_uic_compact) gives the same
+    loss and gradients as the dense [N, S, V] tensors with the criterion's mask; also through the captured graph."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, dense = _model(weight_cache, manifest, "tiny_train_xe")
+    _, compact = _model(weight_cache, manifest, "tiny_train_xe")
+    _, graphed = _model(weight_cache, manifest, "tiny_train_xe")
+    for m in (dense, compact, graphed):
+        m.eval()
+    n_img, spi = 4, 3
+    hb = synthetic_training_batch(cfg, n_img, spi, seed=21)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+    batch["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=4)).cuda()
+    batch["max_phrase_num"] = int(hb["phrase_num"].max())
+    ta, tb, tc = XETrainer(dense), XETrainer(compact), XETrainer(graphed, graph=True)
+    la, pa = ta.forward_backward(batch)
+    bb = tb.add_token_rows(batch, hb)
+    assert bb["token_rows"].numel() % 256 == 0 and float(bb["token_weight"].sum()) == float((hb["phrase_length"].sum(-1) - 1).sum())
+    lb, pb = tb.forward_backward(bb)
+    assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
+    assert all(abs(float(x) - float(y)) < 1e-5 * max(1.0, abs(float(x))) for x, y in zip(pa, pb))
+    assert _maxdiff(tb.bucket.grad, ta.bucket.grad) <= 1e-4 * max(1e-3, float(ta.bucket.grad.abs().max()))
+    lc, _ = tc.forward_backward(tc.add_token_rows(batch, hb))
+    lc2, _ = tc.forward_backward(tc.add_token_rows(batch, hb))      # replay
+    assert abs(float(lc2) - float(la)) < 1e-5 * max(1.0, abs(float(la)))
+    assert _maxdiff(tc.bucket.grad, ta.bucket.grad) <= 1e-4 * max(1e-3, float(ta.bucket.grad.abs().max()))

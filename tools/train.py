@@ -87,6 +87,7 @@ def main():
         batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
         batch["max_tokens"] = int((host_batch["phrase_length"].sum(-1) - 1).max())
         batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(opt.batch_size, 36, cfg.att_feat_size, seed=seed)).to(dev)
+        batch = trainer.add_token_rows(batch, host_batch)
         glat_p = args.unmasked_rate_start if args.glancing_token else -1.0          # train.py:165-170
         loss, parts = trainer.step(batch, glat_p)
         if (it + 1) % args.losses_log_every == 0 or it == 0:
