@@ -52,6 +52,7 @@ struct AttnParams {
     const int* klen; int klen_sb, klen_sq, klen_bias, klen_shared_last;
     const int* skip_if_ge; int skip_threshold;
     int kdiv;
+    const int* q_start; const int* q_count; int k_ragged;     // unpadded layout (bofi_kernels.h)
 };
 
 constexpr int DK = 64;
@@ -74,14 +75,16 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
     const int lane = threadIdx.x;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int q0 = blockIdx.y * LQ;
-    const int nq = min(LQ, p.Lq - q0);
-    const int Lk = p.Lk;
+    const int qrow0 = p.q_start ? p.q_start[b] : b * p.Lq, lq = p.q_start ? p.q_count[b] : p.Lq;
+    const int nq = min(LQ, lq - q0);
+    if (nq <= 0) return;
+    const int Lk = (p.q_start && p.k_ragged) ? lq : p.Lk;
     const int nkt = (Lk + 15) >> 4;                    // 16-key tiles that hold real keys
     const int lkr = ((Lk + 31) >> 5) << 5;             // keys rounded up for the PV k-steps
 
     // ---- stage Q (rows >= nq zero), K (rows >= Lk zero), V^T (keys >= Lk zero)
     constexpr int CPR = DK / EPC;                      // 16-byte chunks per row
-    const T* qg = static_cast<const T*>(p.q) + ((size_t)b * p.Lq + q0) * p.ldq + h * DK;
+    const T* qg = static_cast<const T*>(p.q) + ((size_t)qrow0 + q0) * p.ldq + h * DK;
     for (int c = lane; c < LQ * CPR; c += 64) {
         const int r = c / CPR, ch = c - r * CPR;
         u32x4 val = u32x4{0u, 0u, 0u, 0u};
@@ -89,14 +92,15 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
         *reinterpret_cast<u32x4*>(&sq[r * QS + ch * EPC]) = val;
     }
     const int bk = b / p.kdiv;                         // captions of one image share its keys (training)
-    const T* kg = static_cast<const T*>(p.k) + (size_t)bk * Lk * p.ldk + h * DK;
+    const size_t krow0 = (p.q_start && p.k_ragged) ? (size_t)qrow0 : (size_t)bk * p.Lk;
+    const T* kg = static_cast<const T*>(p.k) + krow0 * p.ldk + h * DK;
     for (int c = lane; c < nkt * 16 * CPR; c += 64) {
         const int r = c / CPR, ch = c - r * CPR;
         u32x4 val = u32x4{0u, 0u, 0u, 0u};
         if (r < Lk) val = *reinterpret_cast<const u32x4*>(kg + (size_t)r * p.ldk + ch * EPC);
         *reinterpret_cast<u32x4*>(&sk[r * QS + ch * EPC]) = val;
     }
-    const T* vg = static_cast<const T*>(p.v) + (size_t)bk * Lk * p.ldv + h * DK;
+    const T* vg = static_cast<const T*>(p.v) + krow0 * p.ldv + h * DK;
     for (int c = lane; c < lkr * CPR; c += 64) {
         const int r = c / CPR, ch = c - r * CPR;
         union { u32x4 v; T e[EPC]; } u;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
         if (p.klen && r < nq) {
             // quirk Q1 per group of klen_shared_last images: every image uses the key count of its group's LAST image
             const int bi = p.klen_shared_last ? min(p.B, (b / p.klen_shared_last + 1) * p.klen_shared_last) - 1 : b;
-            kl = p.klen[bi * p.klen_sb + (q0 + r) * p.klen_sq] + p.klen_bias;
+            kl = (p.q_start ? p.klen[qrow0 + q0 + r] : p.klen[bi * p.klen_sb + (q0 + r) * p.klen_sq]) + p.klen_bias;
             kl = max(0, min(kl, Lk));
         }
         float m = -INFINITY;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
     __syncthreads();
 
     // ---- O = P V
-    T* og = static_cast<T*>(p.out) + ((size_t)b * p.Lq + q0) * p.ldo + h * DK;
+    T* og = static_cast<T*>(p.out) + ((size_t)qrow0 + q0) * p.ldo + h * DK;
     for (int qi = 0; qi < LQ / 16; ++qi) {
         if (qi * 16 >= nq) break;
         f32x4 acc[DK / 16];
@@ -213,6 +217,8 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;
     p.klen = a.klen; p.klen_sb = a.klen_sb; p.klen_sq = a.klen_sq; p.klen_bias = a.klen_bias;
     p.kdiv = a.kdiv > 0 ? a.kdiv : 1;
+    if ((a.q_start != nullptr) != (a.q_count != nullptr)) return BOFI_ERR_ARG;
+    p.q_start = a.q_start; p.q_count = a.q_count; p.k_ragged = a.k_ragged;
     p.klen_shared_last = a.klen_shared_last; p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
     return a.dtype == BOFI_DT_F32 ? launch_attn_t<float>(p, st) : launch_attn_t<bf16_t>(p, st);
 }
@@ -230,12 +236,13 @@ extern "C" int bofi_attention(const void* q, int ldq, const void* k, int ldk, co
 
 extern "C" int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                                  int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq,
-                                 int klen_bias, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* stream) {
+                                 int klen_bias, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, const int* q_start,
+                                 const int* q_count, int k_ragged, void* stream) {
     if (kdiv <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     bofi::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.dtype = dtype;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = klen_sq;
-    a.klen_bias = klen_bias; a.kdiv = kdiv;
+    a.klen_bias = klen_bias; a.kdiv = kdiv; a.q_start = q_start; a.q_count = q_count; a.k_ragged = k_ragged;
     if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.drop_step = drop_step; }
     return bofi::launch_attention(a, (hipStream_t)stream);
 }

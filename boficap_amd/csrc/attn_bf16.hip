@@ -28,13 +28,14 @@ struct AttnParamsB {
     const int* skip_if_ge; int skip_threshold;
     int kdiv;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;
+    const int* q_start; const int* q_count; int k_ragged;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int AROW = 72;          // LDS row stride in elements: 64 + 8 pad (144 B: conflict-free b128 fragment reads)
 
-template <int NQT, int NKT>       // 16-row query tiles per block, 16-key tiles (even)
+template <int NQT, int NKT, bool RAGGED = false>       // 16-row query tiles per block, 16-key tiles (even); RAGGED: per-item row ranges
 __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     static_assert(NKT % 2 == 0, "keys are consumed 32 at a time");
     __shared__ __attribute__((aligned(16))) bf16_t sq[NQT * 16 * AROW];
@@ -45,14 +46,18 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     const int lane = threadIdx.x;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int q0 = blockIdx.y * (NQT * 16);
-    const int nq = min(NQT * 16, p.Lq - q0);
-    const int Lk = p.Lk;
+    int qrow0 = b * p.Lq, lq = p.Lq;                // first query row of this item and how many it has
+    if constexpr (RAGGED) { qrow0 = p.q_start[b]; lq = p.q_count[b]; }
+    const int nq = min(NQT * 16, lq - q0);
+    if constexpr (RAGGED) { if (nq <= 0) return; }
+    const int bk = b / p.kdiv;                      // captions of one image share its keys (training)
+    int krow0 = bk * p.Lk, Lk = p.Lk;
+    if constexpr (RAGGED) { if (p.k_ragged) { krow0 = qrow0; Lk = lq; } }
 
     // ---- stage Q, K, V head slices (16-byte chunks; rows past the data are zero)
-    const bf16_t* qg = p.q + ((size_t)b * p.Lq + q0) * p.ldq + h * 64;
-    const int bk = b / p.kdiv;                      // captions of one image share its keys (training)
-    const bf16_t* kg = p.k + (size_t)bk * Lk * p.ldk + h * 64;
-    const bf16_t* vg = p.v + (size_t)bk * Lk * p.ldv + h * 64;
+    const bf16_t* qg = p.q + ((size_t)qrow0 + q0) * p.ldq + h * 64;
+    const bf16_t* kg = p.k + (size_t)krow0 * p.ldk + h * 64;
+    const bf16_t* vg = p.v + (size_t)krow0 * p.ldv + h * 64;
     const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int c = lane; c < NQT * 16 * 8; c += 64) {
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
         if (p.klen && qrow < nq) {
             // quirk Q1 per group of klen_shared_last images: every image uses the key count of its group's LAST image
             const int bi = p.klen_shared_last ? min(p.B, (b / p.klen_shared_last + 1) * p.klen_shared_last) - 1 : b;
-            kl = p.klen[bi * p.klen_sb + (q0 + qrow) * p.klen_sq] + p.klen_bias;
+            if constexpr (RAGGED) kl = p.klen[qrow0 + q0 + qrow] + p.klen_bias;
+            else kl = p.klen[bi * p.klen_sb + (q0 + qrow) * p.klen_sq] + p.klen_bias;
             kl = max(0, min(kl, Lk));
         }
         float m = -INFINITY;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     }
 
     // ---- store: lane holds O[q = qi*16 + l15][d = dt*16 + g*4 + 0..3]
-    bf16_t* og = p.out + ((size_t)b * p.Lq + q0) * p.ldo + h * 64;
+    bf16_t* og = p.out + ((size_t)qrow0 + q0) * p.ldo + h * 64;
 #pragma unroll
     for (int qi = 0; qi < NQT; ++qi) {
         const int qrow = qi * 16 + l15;
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
 template <int NQT, int NKT>
 static void launch_ab(const AttnParamsB& p, hipStream_t st) {
     const dim3 grid(p.B * p.H, (p.Lq + NQT * 16 - 1) / (NQT * 16));
-    hipLaunchKernelGGL((attn_bf16_kernel<NQT, NKT>), grid, dim3(64), 0, st, p);
+    if (p.q_start) hipLaunchKernelGGL((attn_bf16_kernel<NQT, NKT, true>), grid, dim3(64), 0, st, p);
+    else hipLaunchKernelGGL((attn_bf16_kernel<NQT, NKT, false>), grid, dim3(64), 0, st, p);
 }
 
 // returns -1 when the call is not eligible (then attn.hip handles it)
@@ -198,6 +205,8 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     p.klen_shared_last = a.klen_shared_last; p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
     p.kdiv = a.kdiv > 0 ? a.kdiv : 1;
     p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
+    if ((a.q_start != nullptr) != (a.q_count != nullptr)) return BOFI_ERR_ARG;
+    p.q_start = a.q_start; p.q_count = a.q_count; p.k_ragged = a.k_ragged;
     const int nkt = a.Lk <= 32 ? 2 : 4;
     const int nqt = a.Lq <= 16 ? 1 : (a.Lq <= 32 ? 2 : 3);
     switch (nqt * 10 + nkt) {

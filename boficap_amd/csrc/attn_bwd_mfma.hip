@@ -24,6 +24,7 @@ struct AttnBwdMfmaParams {
     int B, H, Lq, Lk, kdiv;
     const int* klen; int klen_sb, klen_sq, klen_bias;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;     // dropout(p_attn) of the forward
+    const int* q_start; const int* q_count; int k_ragged;     // unpadded layout (bofi_kernels.h: AttnArgs)
 };
 
 // Head slice [rows_real, 64] -> LDS as bf16, rows past the data zero, in two phases: load() requests every 16-byte piece of
@@ -103,17 +104,22 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
     // one wavefront per (key owner, head): with kdiv > 1 it walks the kdiv captions that share these keys and keeps
     // dK / dV in registers across them, so the shared rows are written once, without atomics
     const int bh = blockIdx.x, bk = bh / p.H, h = bh - bk * p.H;
-    const int Lq = p.Lq, Lk = p.Lk;
+    const int Lqmax = p.Lq;
+    const bool kr = p.q_start && p.k_ragged;                   // self-attention over unpadded rows (kdiv == 1 then)
+    int Lq = p.q_start ? p.q_count[bk * p.kdiv] : p.Lq;
+    size_t qrow0 = p.q_start ? (size_t)p.q_start[bk * p.kdiv] : (size_t)bk * p.kdiv * p.Lq;
+    const int Lk = kr ? Lq : p.Lk;
+    const size_t krow0 = kr ? qrow0 : (size_t)bk * p.Lk;
     const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.drop_step) ? *p.drop_step : 0ull);
 
     RowStage<TIN, LQ> rq;
     RowStage<float, LQ> rdo;
     {   // keys, values and the first caption's queries / output gradients: all requested before anything is converted
         RowStage<TIN, LK> rk, rv;
-        rk.load(static_cast<const TIN*>(p.k) + (size_t)bk * Lk * p.ldk + h * 64, p.ldk, Lk, lane);
-        rv.load(static_cast<const TIN*>(p.v) + (size_t)bk * Lk * p.ldv + h * 64, p.ldv, Lk, lane);
-        rq.load(static_cast<const TIN*>(p.q) + (size_t)bk * p.kdiv * Lq * p.ldq + h * 64, p.ldq, Lq, lane);
-        rdo.load(p.dout + (size_t)bk * p.kdiv * Lq * p.ldo + h * 64, p.ldo, Lq, lane);
+        rk.load(static_cast<const TIN*>(p.k) + krow0 * p.ldk + h * 64, p.ldk, Lk, lane);
+        rv.load(static_cast<const TIN*>(p.v) + krow0 * p.ldv + h * 64, p.ldv, Lk, lane);
+        rq.load(static_cast<const TIN*>(p.q) + qrow0 * p.ldq + h * 64, p.ldq, Lq, lane);
+        rdo.load(p.dout + qrow0 * p.ldo + h * 64, p.ldo, Lq, lane);
         rk.store(sk, DS, lane);
         rv.store(sv, DS, lane);
     }
@@ -129,9 +135,13 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
         if (c) __syncthreads();                                  // the previous caption's operands are still being read
         rq.store(sq, DS, lane);
         rdo.store(sdo, DS, lane);
+        const int Lq_c = Lq;                                     // this caption's rows (the prefetch below moves Lq / qrow0 on)
+        const size_t qrow_c = qrow0;
         if (c + 1 < p.kdiv) {                                    // the next caption's slices travel while this one is multiplied
-            rq.load(static_cast<const TIN*>(p.q) + (size_t)(b + 1) * Lq * p.ldq + h * 64, p.ldq, Lq, lane);
-            rdo.load(p.dout + (size_t)(b + 1) * Lq * p.ldo + h * 64, p.ldo, Lq, lane);
+            Lq = p.q_start ? p.q_count[b + 1] : p.Lq;
+            qrow0 = p.q_start ? (size_t)p.q_start[b + 1] : (size_t)(b + 1) * p.Lq;
+            rq.load(static_cast<const TIN*>(p.q) + qrow0 * p.ldq + h * 64, p.ldq, Lq, lane);
+            rdo.load(p.dout + qrow0 * p.ldo + h * 64, p.ldo, Lq, lane);
         }
         __syncthreads();
 
@@ -167,9 +177,9 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
             for (int r = 0; r < 4; ++r) {
                 const int qrow = qt * 16 + 4 * g + r;
                 int kl = 0;
-                if (qrow < Lq) {
+                if (qrow < Lq_c) {
                     kl = Lk;
-                    if (p.klen) { kl = p.klen[b * p.klen_sb + qrow * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
+                    if (p.klen) { kl = (p.q_start ? p.klen[qrow_c + qrow] : p.klen[b * p.klen_sb + qrow * p.klen_sq]) + p.klen_bias; kl = max(0, min(kl, Lk)); }
                 }
                 float m = -INFINITY;
 #pragma unroll
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
                 for (int kt = 0; kt < KT; ++kt) {
                     mk[kt] = 1.f;
                     if (p.drop_thresh) {
-                        const uint64_t ei = ((uint64_t)(b * p.H + h) * Lq + qrow) * Lk + kt * 16 + l15;
+                        const uint64_t ei = ((uint64_t)(b * p.H + h) * Lqmax + qrow) * Lk + kt * 16 + l15;
                         mk[kt] = drop_hash(dseed, ei) >= p.drop_thresh ? p.drop_scale : 0.f;
                     }
                     e[kt] *= inv;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qrow = qt * 16 + 4 * g + r;
-                    if (qrow < Lq) p.dq[((size_t)b * Lq + qrow) * p.lddq + h * 64 + dt * 16 + l15] = acc[dt][r];
+                    if (qrow < Lq_c) p.dq[(qrow_c + qrow) * p.lddq + h * 64 + dt * 16 + l15] = acc[dt][r];
                 }
         }
         // ---- dK += dS^T Q, dV += P^T dO
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
             for (int r = 0; r < 4; ++r) {
                 const int krow = kt * 16 + 4 * g + r;
                 if (krow >= Lk) continue;
-                const size_t o = ((size_t)bk * Lk + krow) * p.lddk + h * 64 + dt * 16 + l15;
+                const size_t o = (krow0 + krow) * p.lddk + h * 64 + dt * 16 + l15;
                 p.dk[o] = ak[kt][dt][r];
                 p.dv[o] = av[kt][dt][r];
             }
@@ -272,7 +282,8 @@ static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
 extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
                                        const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H, int Lq,
                                        int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, float drop_p,
-                                       uint64_t drop_seed, const uint64_t* drop_step, void* stream) {
+                                       uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged,
+                                       void* stream) {
     using namespace bofi;
     if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0 || B % kdiv || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
@@ -282,7 +293,8 @@ extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, in
         return BOFI_ERR_ARG;
     if (B == 0) return BOFI_OK;
     AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias,
-                        0u, 1.f, drop_seed, drop_step};
+                        0u, 1.f, drop_seed, drop_step, q_start, q_count, k_ragged};
+    if ((q_start != nullptr) != (q_count != nullptr) || (k_ragged && kdiv != 1)) return BOFI_ERR_ARG;
     if (drop_p > 0.f) { p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_scale = 1.0f / (1.0f - drop_p); }
     return in_dtype == BOFI_DT_F32 ? launch_t<float>(p, (hipStream_t)stream) : launch_t<bf16_t>(p, (hipStream_t)stream);
 }

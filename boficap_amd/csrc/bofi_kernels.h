@@ -55,6 +55,10 @@ struct AttnArgs {
     // training: dropout on the attention probabilities (TransformerModel.py:1430-1431), bf16 kernel only;
     // keep(b, h, q, k) = drop_hash(seed, ((b*H + h)*Lq + q)*Lk + k) >= drop_thresh (0: off)
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;
+    // training with unpadded captions: batch item b owns the q_count[b] query rows that start at row q_start[b] (B entries each;
+    // NULL: the dense layout b * Lq, Lq rows); k_ragged: its keys / values are laid out the same way (self-attention) instead of
+    // (b / kdiv) * Lk.  klen is then indexed by the global query row.  Lq / Lk stay the maxima (they size the kernel).
+    const int* q_start; const int* q_count; int k_ragged;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible

@@ -97,6 +97,7 @@ struct AttnBwdParams {
     float* dq; float* dk; float* dv;          // same layouts as q / k / v; dk, dv accumulate with atomics when kdiv > 1
     int B, H, Lq, Lk, kdiv;
     const int* klen; int klen_sb, klen_sq, klen_bias;
+    const int* q_start; const int* q_count; int k_ragged;     // unpadded layout (bofi_kernels.h: AttnArgs)
 };
 
 template <int LQ, int LK>
@@ -105,16 +106,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
     __shared__ float sq[LQ * DS], sdo[LQ * DS], sk[LK * DS], sv[LK * DS], sp[LQ * PS], sds[LQ * PS];
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, tid = threadIdx.x;
     const int bk = b / p.kdiv;
-    const int Lq = p.Lq, Lk = p.Lk;
+    const int Lq = p.q_start ? p.q_count[b] : p.Lq;
+    const size_t qrow0 = p.q_start ? (size_t)p.q_start[b] : (size_t)b * p.Lq;
+    const bool kr = p.q_start && p.k_ragged;
+    const int Lk = kr ? Lq : p.Lk;
+    const size_t krow0 = kr ? qrow0 : (size_t)bk * p.Lk;
+    if (Lq <= 0) return;
     for (int i = tid; i < Lq * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
-        sq[r * DS + c] = p.q[((size_t)b * Lq + r) * p.ldq + h * 64 + c];
-        sdo[r * DS + c] = p.dout[((size_t)b * Lq + r) * p.ldo + h * 64 + c];
+        sq[r * DS + c] = p.q[(qrow0 + r) * p.ldq + h * 64 + c];
+        sdo[r * DS + c] = p.dout[(qrow0 + r) * p.ldo + h * 64 + c];
     }
     for (int i = tid; i < Lk * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
-        sk[r * DS + c] = p.k[((size_t)bk * Lk + r) * p.ldk + h * 64 + c];
-        sv[r * DS + c] = p.v[((size_t)bk * Lk + r) * p.ldv + h * 64 + c];
+        sk[r * DS + c] = p.k[(krow0 + r) * p.ldk + h * 64 + c];
+        sv[r * DS + c] = p.v[(krow0 + r) * p.ldv + h * 64 + c];
     }
     __syncthreads();
     // scores and dP = dO V^T over the real Lq x Lk rectangle
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
         const int i = tid >> 2, sub = tid & 3;
         if (i < Lq) {
             int kl = Lk;
-            if (p.klen) { kl = p.klen[b * p.klen_sb + i * p.klen_sq] + p.klen_bias; kl = max(0, min(kl, Lk)); }
+            if (p.klen) { kl = (p.q_start ? p.klen[qrow0 + i] : p.klen[b * p.klen_sb + i * p.klen_sq]) + p.klen_bias; kl = max(0, min(kl, Lk)); }
             float m = -INFINITY;
             for (int j = sub; j < kl; j += 4) m = fmaxf(m, sp[i * PS + j]);
             m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
@@ -150,14 +156,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
         const int r = e >> 6, c = e & 63;
         float a = 0.f;
         for (int j = 0; j < Lk; ++j) a = fmaf(sds[r * PS + j], sk[j * DS + c], a);
-        p.dq[((size_t)b * Lq + r) * p.ldq + h * 64 + c] = a;
+        p.dq[(qrow0 + r) * p.ldq + h * 64 + c] = a;
     }
     for (int e = tid; e < Lk * 64; e += 256) {                 // dK[r][c] = sum_i dS[i][r] Q[i][c];  dV[r][c] = sum_i P[i][r] dO[i][c]
         const int r = e >> 6, c = e & 63;
         float a = 0.f, g = 0.f;
         for (int i = 0; i < Lq; ++i) { a = fmaf(sds[i * PS + r], sq[i * DS + c], a); g = fmaf(sp[i * PS + r], sdo[i * DS + c], g); }
-        float* dkp = p.dk + ((size_t)bk * Lk + r) * p.ldk + h * 64 + c;
-        float* dvp = p.dv + ((size_t)bk * Lk + r) * p.ldv + h * 64 + c;
+        float* dkp = p.dk + (krow0 + r) * p.ldk + h * 64 + c;
+        float* dvp = p.dv + (krow0 + r) * p.ldv + h * 64 + c;
         if (p.kdiv > 1) { atomicAdd(dkp, a); atomicAdd(dvp, g); } else { *dkp = a; *dvp = g; }
     }
 }
@@ -211,11 +217,11 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict_
 // (Embeddings TransformerModel.py:1484-1492, PositionalEncoding :1494-1511; (tok + syn) + pe keeps the reference's order)
 __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict__ lut_tok, const float* __restrict__ lut_syn,
                                                         const float* __restrict__ pe, const int64_t* tok, const int64_t* syn, int L,
-                                                        int d, float sqrt_d, float* __restrict__ x) {
+                                                        int d, float sqrt_d, float* __restrict__ x, const int64_t* __restrict__ pos) {
     const int r = blockIdx.x;
     const float* tr = tok ? lut_tok + (size_t)tok[r] * d : nullptr;
     const float* sr = syn ? lut_syn + (size_t)syn[r] * d : nullptr;
-    const float* pr = pe + (size_t)(r % L) * d;
+    const float* pr = pe + (size_t)(pos ? pos[r] : r % L) * d;
     for (int k = threadIdx.x; k < d; k += 128) {
         float v;
         if (tr && sr) v = (tr[k] * sqrt_d + sr[k] * sqrt_d) + pr[k];
@@ -380,12 +386,12 @@ extern "C" int bofi_adam_step(float* p, const float* g, float* m, float* v, void
     return BOFI_OK;
 }
 
-extern "C" int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok, const int64_t* syn, int rows,
-                               int L, int d, float* x, void* stream) {
+extern "C" int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok, const int64_t* syn,
+                               const int64_t* pos, int rows, int L, int d, float* x, void* stream) {
     if (!pe || !x || (!tok && !syn) || (tok && !lut_tok) || (syn && !lut_syn) || rows < 0 || L <= 0 || d <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(128), 0, (hipStream_t)stream, lut_tok, lut_syn, pe, tok, syn, L, d,
-                       (float)sqrt((double)d), x);
+                       (float)sqrt((double)d), x, pos);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -449,10 +455,11 @@ extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float
 
 extern "C" int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout, int ldo,
                                   float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb,
-                                  int klen_sq, int klen_bias, void* stream) {
+                                  int klen_sq, int klen_bias, const int* q_start, const int* q_count, int k_ragged, void* stream) {
     if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0) return BOFI_ERR_ARG;
     if (B == 0) return BOFI_OK;
-    AttnBwdParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, dk, dv, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias};
+    if ((q_start != nullptr) != (q_count != nullptr)) return BOFI_ERR_ARG;
+    AttnBwdParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, dk, dv, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, q_start, q_count, k_ragged};
     const dim3 grid(B * H), block(256);
     if (Lq <= 32 && Lk <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 32>), grid, block, 0, (hipStream_t)stream, p);
     else if (Lq <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 64>), grid, block, 0, (hipStream_t)stream, p);

@@ -98,7 +98,7 @@ class XETrainer:
     (20000), ``noamopt_factor`` (1), ``learning_rate`` (5e-4, used when noamopt is off), ``optim_alpha/beta/epsilon``
     (plain Adam), ``grad_clip_value`` (0.1) with ``grad_clip_mode`` 'value'."""
 
-    def __init__(self, model, opt=None, group=None, graph: bool = False):
+    def __init__(self, model, opt=None, group=None, graph: bool = False, unpadded: bool = True):
         """``graph``: capture zero-grad + forward + criterion + backward of a batch signature (shapes, max phrase count,
         GLAT on/off) into a hipGraph on first use and replay it afterwards -- ~1 200 kernel launches and the whole Python /
         autograd dispatch of a step become one graph launch.  Inputs are copied into static buffers, the dropout step lives
@@ -123,6 +123,7 @@ class XETrainer:
         self.v = torch.zeros_like(self.bucket.flat)
         self._step = 0
         self.graph = bool(graph)
+        self.unpadded = bool(unpadded)                         # add_token_rows: run the decoder over the captions' real positions only
         self.max_graphs = 8                                    # batch signatures (shapes x max phrase count x GLAT rate) kept as graphs
         self._graphs = {}
         self._fwd_calls = 0
@@ -138,7 +139,7 @@ class XETrainer:
 
     _KEYS = ("att_feats", "labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq",
              "extend_phrase_seq_mask")
-    _OPT_KEYS = ("token_rows", "token_labels", "token_weight")
+    _OPT_KEYS = ("token_rows", "token_labels", "token_weight", "row_start", "row_count", "row_cap", "row_pos")
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
@@ -199,6 +200,8 @@ class XETrainer:
         compact = batch.get("token_rows") is not None and batch.get("max_tokens") is not None
         if compact:                                            # project only the real tokens' rows onto the vocabulary
             xe.HINTS["token_rows"] = batch["token_rows"]
+            if batch.get("row_cap") is not None:               # ... and run the decoder on those rows only
+                xe.HINTS["unpadded"] = (batch["row_start"], batch["row_count"], batch["row_cap"], batch["row_pos"])
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)
@@ -230,6 +233,12 @@ class XETrainer:
         out = dict(batch)
         out.update(max_tokens=int(ntok.max()), token_rows=torch.from_numpy(rows).to(dev), token_labels=torch.from_numpy(lab).to(dev),
                    token_weight=torch.from_numpy(w).to(dev))
+        if self.unpadded:                                          # the decoder itself runs over these rows only (xe._fill_unpadded)
+            cap, pos = np.zeros(Tp, np.int64), np.zeros(Tp, np.int64)
+            cap[:T], pos[:T] = n_idx, t_idx
+            start = np.concatenate([[0], np.cumsum(ntok)[:-1]]).astype(np.int32)
+            out.update(row_start=torch.from_numpy(start).to(dev), row_count=torch.from_numpy(ntok.astype(np.int32)).to(dev),
+                       row_cap=torch.from_numpy(cap).to(dev), row_pos=torch.from_numpy(pos).to(dev))
         return out
 
     def optimizer_step(self, grad_scale: float = 1.0) -> float:

@@ -312,14 +312,20 @@ class AttentionFn(Function):
     qbuf may be the same tensor as kvbuf (packed q|k|v of a self-attention)."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop):
+    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop, seg):
         qbuf, kvbuf = _need(qbuf, "attention q"), _need(kvbuf, "attention kv")
-        if qbuf.shape[0] != B * Lq or kvbuf.shape[0] * kdiv != B * Lk:
+        # seg = (q_start int32 [B], q_count int32 [B], k_ragged): unpadded rows (see bofi_attention_ex); sizes are then the caller's business
+        if seg is None and (qbuf.shape[0] != B * Lq or kvbuf.shape[0] * kdiv != B * Lk):
             raise hip.BofiHipError(f"attention operand rows {qbuf.shape[0]}, {kvbuf.shape[0]} do not match B={B} Lq={Lq} Lk={Lk} kdiv={kdiv}")
-        if klen is not None and (klen.dtype != torch.int32 or klen.numel() < (B - 1) * klen_sb + (Lq - 1) * klen_sq + 1):
+        if seg is None and klen is not None and (klen.dtype != torch.int32 or klen.numel() < (B - 1) * klen_sb + (Lq - 1) * klen_sq + 1):
             raise hip.BofiHipError("klen must be int32 and cover every (b, query) it is indexed with")
+        if seg is not None and ((klen is not None and (klen.dtype != torch.int32 or klen.numel() < qbuf.shape[0])) or seg[0].dtype != torch.int32
+                                or seg[1].dtype != torch.int32 or seg[0].numel() != B or seg[1].numel() != B):
+            raise hip.BofiHipError("unpadded attention needs int32 q_start / q_count of B entries and, if any, one klen per query row")
         d = H * 64
-        out = _empty(qbuf, B * Lq, d)
+        # rows outside every segment (padding of the row list) are never written by the kernels: keep them finite
+        out = _zeros(qbuf, qbuf.shape[0], d) if seg is not None else _empty(qbuf, B * Lq, d)
+        sp = (hip.ptr(seg[0]), hip.ptr(seg[1]), int(bool(seg[2]))) if seg is not None else (None, None, 0)
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
         bf16 = _COMPUTE["dtype"] == torch.bfloat16
         qs, kvs = (_shadow(qbuf), _shadow(kvbuf)) if bf16 else (None, None)
@@ -327,22 +333,24 @@ class AttentionFn(Function):
         if ctx.shadows:
             # bf16 projections from the GEMM epilogue in, bf16 context out (the operand of the output projection):
             # ``out`` stays an unfilled placeholder
-            ob = torch.empty(B * Lq, d, dtype=torch.bfloat16, device=qbuf.device)
+            ob = (torch.zeros if seg is not None else torch.empty)(qbuf.shape[0], d, dtype=torch.bfloat16, device=qbuf.device)
             _chk(_lib().bofi_attention_ex(_off(qs, qoff), ldq, _off(kvs, koff), ldk, _off(kvs, voff), ldk, hip.ptr(ob), d, hip.DT_BF16, B, H,
                                           Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, drop[0] if drop else 0.0,
-                                          drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, hip.stream_ptr()), "bofi_attention_ex")
+                                          drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, sp[0], sp[1], sp[2], hip.stream_ptr()),
+                 "bofi_attention_ex")
             _register_shadow(out, ob, only=True)
             ctx.save_for_backward(qs, kvs)
         else:
             _real(qbuf, "attention q"), _real(kvbuf, "attention kv")
             drop = None                                        # dropout(p_attn) is built into the bf16 kernels only
             _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
-                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, 0.0, 0, None, hip.stream_ptr()),
-                 "bofi_attention_ex")
+                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, 0.0, 0, None, sp[0], sp[1], sp[2],
+                                          hip.stream_ptr()), "bofi_attention_ex")
             ctx.save_for_backward(qbuf, kvbuf)
         ctx.drop = drop
         ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
         ctx.mfma = bf16                                        # bf16 mode: backward on the matrix cores
+        ctx.seg = seg
         ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
         ctx.klen = klen
         return out
@@ -354,7 +362,8 @@ class AttentionFn(Function):
         dout = _real(_need(dout, "attention dout"), "attention dout")
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
         # the MFMA kernel writes every element of the q / k / v slices (no atomics); the VALU kernel accumulates shared keys
-        covered = ctx.mfma and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64))
+        covered = ctx.seg is None and ctx.mfma and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64))
+        sp = (hip.ptr(ctx.seg[0]), hip.ptr(ctx.seg[1]), int(bool(ctx.seg[2]))) if ctx.seg is not None else (None, None, 0)
         alloc = torch.empty if covered else torch.zeros
         dq = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
         dkv = dq if ctx.same else alloc(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
@@ -362,19 +371,19 @@ class AttentionFn(Function):
             _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.dtype_code(qbuf),
                                                 hip.ptr(dout), H * 64, _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk,
                                                 kdiv, hip.ptr(ctx.klen), sb, sq, bias, ctx.drop[0] if ctx.drop else 0.0,
-                                                ctx.drop[1] if ctx.drop else 0, hip.ptr(ctx.drop[2]) if ctx.drop else None, hip.stream_ptr()),
-                 "bofi_attention_bwd_mfma")
-            return (dq, None if ctx.same else dkv) + (None,) * 13
+                                                ctx.drop[1] if ctx.drop else 0, hip.ptr(ctx.drop[2]) if ctx.drop else None, sp[0], sp[1], sp[2],
+                                                hip.stream_ptr()), "bofi_attention_bwd_mfma")
+            return (dq, None if ctx.same else dkv) + (None,) * 14
         _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
                                        _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,
-                                       hip.stream_ptr()), "bofi_attention_bwd")
-        return (dq, None if ctx.same else dkv) + (None,) * 13
+                                       sp[0], sp[1], sp[2], hip.stream_ptr()), "bofi_attention_bwd")
+        return (dq, None if ctx.same else dkv) + (None,) * 14
 
 
-def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0, drop=None):
+def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0, drop=None, seg=None):
     """``drop``: (p, seed, step word) dropout on the attention probabilities (TransformerModel.py:1430-1431); applied by the bf16
     kernels (bf16 training mode with bf16 projections at hand), ignored by the float32 parity kernels."""
-    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop)
+    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop, seg)
 
 
 class EmbedFn(Function):
@@ -382,7 +391,7 @@ class EmbedFn(Function):
     ``g_tok`` / ``g_syn``: gradient buffers of the tables to scatter-add into (see LinearFn)."""
 
     @staticmethod
-    def forward(ctx, lut_tok, lut_syn, pe, tok, syn, L, g_tok, g_syn):
+    def forward(ctx, lut_tok, lut_syn, pe, tok, syn, L, g_tok, g_syn, pos=None):
         ref = lut_tok if lut_tok is not None else lut_syn
         d = ref.shape[1]
         ids = tok if tok is not None else syn
@@ -392,7 +401,7 @@ class EmbedFn(Function):
                 raise hip.BofiHipError("embedding ids must be contiguous int64 with their table")
         x = _empty(ref, rows, d)
         _chk(_lib().bofi_embed_rows(hip.ptr(lut_tok if tok is not None else None), hip.ptr(lut_syn if syn is not None else None), hip.ptr(pe),
-                                    hip.ptr(tok), hip.ptr(syn), rows, L, d, hip.ptr(x), hip.stream_ptr()), "bofi_embed_rows")
+                                    hip.ptr(tok), hip.ptr(syn), hip.ptr(pos), rows, L, d, hip.ptr(x), hip.stream_ptr()), "bofi_embed_rows")
         ctx.tok, ctx.syn, ctx.g = tok, syn, (g_tok, g_syn)
         ctx.shapes = (None if lut_tok is None else lut_tok.shape, None if lut_syn is None else lut_syn.shape)
         return x
@@ -409,11 +418,12 @@ class EmbedFn(Function):
             g = direct if direct is not None else _zeros(dx, *shape)
             _chk(_lib().bofi_embed_bwd(hip.ptr(dx), hip.ptr(ids), hip.ptr(g), rows, d, float(d) ** 0.5, hip.stream_ptr()), "bofi_embed_bwd")
             out.append(None if direct is not None else g)
-        return out[0], out[1], None, None, None, None, None, None
+        return out[0], out[1], None, None, None, None, None, None, None
 
 
-def embed(lut_tok, lut_syn, pe, tok, syn, L, g_tok=None, g_syn=None):
-    return EmbedFn.apply(lut_tok, lut_syn, pe, tok, syn, L, g_tok, g_syn)
+def embed(lut_tok, lut_syn, pe, tok, syn, L, g_tok=None, g_syn=None, pos=None):
+    """``pos``: explicit position per row (int64) instead of row % L (unpadded row lists)."""
+    return EmbedFn.apply(lut_tok, lut_syn, pe, tok, syn, L, g_tok, g_syn, pos)
 
 
 class LogSoftmaxFn(Function):
@@ -587,29 +597,39 @@ def encode_memory(P, cfg, att_feats, att_len, drop):
     return P.ln(x, "model.encoder.norm")
 
 
-def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap):
+def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap, seg=None):
     """x + src_attn(n, memory, memory): the image's keys are shared by its captions (kdiv) and, because they depend
-    on the memory and the layer only, by the SA and the NA pass of the same layer (kv_cache)."""
+    on the memory and the layer only, by the SA and the NA pass of the same layer (kv_cache).  ``seg``: unpadded query rows
+    (then ``att_len_cap`` holds one key count per ROW)."""
     d = cfg.d_model
     q = P.lin(n, pre + ".linears.0", shadow=True)
     if pre not in kv_cache:
         kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
-    ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, (1 if att_len_cap is not None else 0), 0, 0, drop.attn())
+    sb = 0 if seg is not None else (1 if att_len_cap is not None else 0)
+    ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, sb, (1 if seg is not None else 0), 0, drop.attn(),
+                    None if seg is None else (seg[0], seg[1], False))
     return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
-def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap, out_gemm_only=True):
+def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap, out_gemm_only=True, seg=None):
     """Decoder stack + final norm (TransformerModel.py:1386-1413) over N captions x S positions; self-attention
-    row (n, i) sees keys < klen_self[n, i].  ``out_gemm_only`` False: the output is also read outside a GEMM (row gather)."""
+    row (n, i) sees keys < klen_self[n, i].  ``out_gemm_only`` False: the output is also read outside a GEMM (row gather).
+
+    ``seg`` = (row_start int32 [N], row_count int32 [N]): ``x`` holds the captions' REAL positions only, caption n in rows
+    row_start[n] .. +row_count[n] (rows past the last caption are padding nobody attends to); klen_self / att_len_cap are then
+    per row.  Every other op of the stack is row-wise, so only the two attentions know about the layout."""
     d = cfg.d_model
     for l in range(cfg.N_dec):
         p = f"model.decoder.layers.{l}"
         xr, n_ = P.ln_res(x, p + ".sublayer.0.norm")
         qkv = P.lin_packed(n_, p + ".self_attn", (0, 1, 2))
-        ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn())
+        if seg is None:
+            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn())
+        else:
+            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, 0, 1, 0, drop.attn(), (seg[0], seg[1], True))
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
         xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
-        x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap)
+        x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap, seg)
         xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
         x = _ffn(P, p + ".feed_forward", drop, n_, xr)
     return P.ln(x, "model.decoder.norm", gemm_only=out_gemm_only)
@@ -737,12 +757,13 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     Sd = HINTS.pop("max_tokens", None)
     Sd = S if not Sd else max(1, min(S, int(Sd)))               # decoder positions actually computed
     token_rows = HINTS.pop("token_rows", None)
+    unpadded = HINTS.pop("unpadded", None)
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
-    def emb(tok, syn, Lp):
+    def emb(tok, syn, Lp, pos=None):
         x = embed(P[tname] if tok is not None else None, P[sname] if syn is not None else None, pe, tok, syn, Lp,
-                  P.g(tname) if tok is not None else None, P.g(sname) if syn is not None else None)
+                  P.g(tname) if tok is not None else None, P.g(sname) if syn is not None else None, pos)
         return drop(x) if drop.on and drop.p > 0.0 else x
 
     def pad_slots(t):                                          # pass i lands in slot i of the returned [:, 1:] view
@@ -763,6 +784,13 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     word_seq[:, 0] = cfg.len_idx
     sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
                                           att_len_cap)
+    if unpadded is not None:
+        sa_tok, na_tok = _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ext_syn, ext_seq,
+                                        extend_phrase_seq_mask.to(dev), last, memory, kv_cache, N, Sd, R, spi, att_len_cap, glat_p,
+                                        lambda: bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi,
+                                                                     klen_pass, att_len_cap))
+        na_len, na_syn = sa_tok[1]
+        return pad_slots(sa_len), pad_slots(sa_syn), sa_tok[0], pad_slots(na_len), pad_slots(na_syn), na_tok
     syn_mid = ext_syn[:, 1:1 + Sd].contiguous()
     ext_seq = ext_seq[:, :Sd].contiguous()
     klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1)[:, :Sd].to(torch.int32).contiguous()  # prefix masks (dataloader.py:414)
@@ -787,6 +815,48 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap, token_rows is None)
     na_tok = token_logprobs(x)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+
+
+def _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ext_syn, ext_seq, ext_mask, last, memory, kv_cache, N, Sd, R,
+                   spi, att_len_cap, glat_p, na_bound):
+    """decode_SA / decode_NA (+ the glancing pass) of forward_uic over the captions' real positions only.
+
+    ``unpadded`` = (row_start int32 [N], row_count int32 [N], row_cap int64 [T], row_pos int64 [T]): row r of the decoder
+    batch is position row_pos[r] of caption row_cap[r]; T is padded (to a multiple the caller chooses) with rows that belong
+    to no caption.  A padded [N, Sd] batch spends most of its rows on positions past the captions' ends (synthetic
+    COCO-like captions: ~45% real); their outputs carry zero loss weight and nothing attends to them, so leaving them out
+    changes neither the loss nor any gradient.  Returns ((sa_tok [T, V], na_bound()), na_tok [T, V]); the op order (SA fill,
+    NA bound, glancing, NA fill) is the padded path's, so the dropout streams agree with it site by site."""
+    dev = labels.device
+    row_start, row_count, row_cap, row_pos = unpadded
+    seg = (row_start, row_count)
+    L = labels.shape[1]
+    with torch.no_grad():
+        at = row_cap * L + row_pos                                # (caption, position) in the [N, L] loader arrays
+        syn_c = ext_syn.reshape(-1)[at + 1].contiguous()
+        seq_c = ext_seq.reshape(-1)[row_cap * ext_seq.shape[1] + row_pos].contiguous()
+        klen_full = ext_mask.long().sum(-1)                       # [N, S'] prefix masks (dataloader.py:414)
+        klen_sa = klen_full.reshape(-1)[row_cap * klen_full.shape[1] + row_pos].to(torch.int32).contiguous()
+        klen_na = (last - 1)[row_cap].to(torch.int32).contiguous()
+        cross_len = None if att_len_cap is None else att_len_cap[row_cap].contiguous()
+        real = labels.reshape(-1)[at + 1]
+        T = row_cap.numel()
+    x = decode_rows(P, cfg, drop, emb(seq_c, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_sa, cross_len, True, seg)
+    sa_tok = log_softmax(vocab(x))
+    bound = na_bound()
+    fill_in = torch.full((T,), cfg.bos_idx, dtype=torch.int64, device=dev)
+    if glat_p >= 0:                                               # glancing input (TransformerModel.py:437-463)
+        with torch.no_grad():
+            x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, dict(kv_cache), N, Sd, R, spi, klen_na, cross_len, True, seg)
+            pred = greedy_ids(vocab(x)).view(T)
+            ntok = phrase_length.sum(1) - 1
+            in_cap = torch.arange(T, device=dev) < (row_start[-1] + row_count[-1])
+            same = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, row_cap, ((pred == real) & in_cap).long())
+            keep_prob = ((ntok - same) / ntok * glat_p)[row_cap] * in_cap.float()
+            keep = torch.rand(T, device=dev) < keep_prob
+            fill_in = torch.where(keep, real, fill_in).contiguous()
+    x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_na, cross_len, True, seg)
+    return (sa_tok, bound), log_softmax(vocab(x))
 
 
 @_scoped_compute_dtype

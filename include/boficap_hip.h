@@ -84,11 +84,14 @@ int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, 
  * klen[...] + klen_bias, and key/value batch item = b / kdiv (the seq_per_img captions of one image
  * attend the image's memory without repeating it; the reference repeats it, models/utils.py:3-14).
  * drop_p > 0 (bf16, Lk <= 64 only): dropout on the attention probabilities (TransformerModel.py:1430-1431),
- * keep(b, h, q, k) = hash(drop_seed + *drop_step, ((b*H + h)*Lq + q)*Lk + k) >= drop_p * 2^32, kept ones / (1 - drop_p). */
+ * keep(b, h, q, k) = hash(drop_seed + *drop_step, ((b*H + h)*Lq + q)*Lk + k) >= drop_p * 2^32, kept ones / (1 - drop_p).
+ * q_start / q_count (int32 [B] each, or both NULL): unpadded rows -- batch item b owns the q_count[b] query rows starting at
+ * row q_start[b]; with k_ragged its keys / values are laid out the same way (self-attention), else (b / kdiv) * Lk as usual;
+ * klen is then indexed by the global query row; Lq / Lk are the maxima.  Same three arguments on the two backward entry points. */
 int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                       int ldo, int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen,
                       int klen_sb, int klen_sq, int klen_bias, float drop_p, uint64_t drop_seed,
-                      const uint64_t* drop_step, void* stream);
+                      const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training ops (float32).  The reference trains by running torch autograd over
@@ -112,15 +115,16 @@ int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const f
 int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
                             const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H,
                             int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, float drop_p,
-                            uint64_t drop_seed, const uint64_t* drop_step, void* stream);
+                            uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged,
+                            void* stream);
 /* backward of log_softmax given the log-probabilities y: dx = dy - exp(y) * rowsum(dy) */
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
-/* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[r % L]; tok or syn may be NULL
+/* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[pos ? pos[r] : r % L]; tok or syn may be NULL
  * (Embeddings + PositionalEncoding, TransformerModel.py:1484-1511) and its backward into one table */
 int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok,
-                    const int64_t* syn, int rows, int L, int d, float* x, void* stream);
+                    const int64_t* syn, const int64_t* pos, int rows, int L, int d, float* x, void* stream);
 int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream);
 /* Weight-gradient GEMM: c[i][j] += sum_m a[m][i] * b[m][j], i < NI, j < NJ (dW = dz^T x without transposed copies).
  * a, b: bf16 row-major [M, a_cols | b_cols] (cols a multiple of 8, zero beyond NI | NJ; 16-byte aligned rows);

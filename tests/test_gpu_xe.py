@@ -586,3 +586,94 @@ def test_compact_vocabulary_rows_leave_loss_and_gradients_unchanged(weight_cache
     lc2, _ = tc.forward_backward(tc.add_token_rows(batch, hb))      # replay
     assert abs(float(lc2) - float(la)) < 1e-5 * max(1.0, abs(float(la)))
     assert _maxdiff(tc.bucket.grad, ta.bucket.grad) <= 1e-4 * max(1e-3, float(ta.bucket.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_over_unpadded_rows_matches_padded(weight_cache, manifest, dtype):
+    """The decoder over the captions' real positions only (row lists from add_token_rows) against the padded [N, Sd] batch:
+    same loss and gradients, with ragged region masks, in both GEMM dtypes; the glancing pass runs on the same rows."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, padded = _model(weight_cache, manifest, "tiny_train_xe")
+    _, ragged = _model(weight_cache, manifest, "tiny_train_xe")
+    for m in (padded, ragged):
+        m.eval()
+        m.train_dtype = dtype
+    n_img, spi = 5, 3
+    hb = synthetic_training_batch(cfg, n_img, spi, seed=33)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+    batch["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=6)).cuda()
+    masks = torch.ones(n_img, 36)
+    for b, n in enumerate((36, 20, 31, 7, 36)):
+        masks[b, n:] = 0
+    batch["att_masks"] = masks.cuda()
+    batch["max_phrase_num"] = int(hb["phrase_num"].max())
+    ta, tb = XETrainer(padded, unpadded=False), XETrainer(ragged)
+    ba, bb = ta.add_token_rows(batch, hb), tb.add_token_rows(batch, hb)
+    assert "row_cap" not in ba and bb["row_cap"].numel() == bb["token_rows"].numel()
+    la, pa = ta.forward_backward(ba)
+    lb, pb = tb.forward_backward(bb)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert abs(float(la) - float(lb)) < tol * max(1.0, abs(float(la)))
+    assert all(abs(float(x) - float(y)) < tol * max(1.0, abs(float(x))) for x, y in zip(pa, pb))
+    gtol = 1e-4 if dtype == torch.float32 else 6e-2
+    assert _maxdiff(tb.bucket.grad, ta.bucket.grad) <= gtol * max(1e-3, float(ta.bucket.grad.abs().max()))
+    lg, _ = tb.forward_backward(bb, glat_p=0.5)                   # glancing pass over the same rows
+    assert torch.isfinite(lg) and torch.isfinite(tb.bucket.grad).all()
+
+
+@pytest.mark.parametrize("mfma", [False, True])
+@pytest.mark.parametrize("kdiv,self_attn", [(1, True), (2, False)])
+def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):
+    """q_start / q_count (variable rows per caption, padding rows at the end of the list) through the forward and both
+    backward kernels: self-attention over each caption's own rows, cross-attention to the image's dense keys."""
+    from boficap_amd import xe
+    H, d, B, Lmax, R = 2, 128, 6, 20, 36
+    g = torch.Generator().manual_seed(31 + kdiv)
+    counts = torch.tensor([5, 20, 1, 0, 13, 8], dtype=torch.int32)
+    starts = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int32), counts[:-1]]), 0).to(torch.int32)
+    T = int(counts.sum())
+    Tp = T + 9                                                  # rows outside every segment
+    klen = torch.zeros(Tp, dtype=torch.int32)
+    for b in range(B):
+        n, s0 = int(counts[b]), int(starts[b])
+        lim = n if self_attn else R
+        klen[s0:s0 + n] = torch.randint(1, lim + 1, (n,), generator=g).int() if n else klen[s0:s0 + n]
+    if self_attn:
+        buf = torch.randn(Tp, 3 * d, generator=g)
+        qb, kvb, offs = buf, buf, (0, d, 2 * d)
+    else:
+        qb, kvb, offs = torch.randn(Tp, d, generator=g), torch.randn(B // kdiv * R, 2 * d, generator=g), (0, 0, d)
+    dout = torch.randn(Tp, d, generator=g)
+    dout[T:] = 0
+
+    def ref(qb, kvb):
+        out = torch.zeros(Tp, d)
+        for b in range(B):
+            n, s0 = int(counts[b]), int(starts[b])
+            if n == 0:
+                continue
+            q = qb[s0:s0 + n, offs[0]:offs[0] + d].reshape(n, H, 64).transpose(0, 1)
+            src = kvb[s0:s0 + n] if self_attn else kvb[(b // kdiv) * R:(b // kdiv + 1) * R]
+            k = src[:, offs[1]:offs[1] + d].reshape(-1, H, 64).transpose(0, 1)
+            v = src[:, offs[2]:offs[2] + d].reshape(-1, H, 64).transpose(0, 1)
+            s = q @ k.transpose(-1, -2) / 8.0
+            mask = torch.arange(k.shape[1]).view(1, 1, -1) < klen[s0:s0 + n].view(1, n, 1)
+            out[s0:s0 + n] = (torch.softmax(s.masked_fill(~mask, float("-inf")), -1) @ v).transpose(0, 1).reshape(n, d)
+        return out
+
+    qr = qb.clone().requires_grad_()
+    kr = qr if self_attn else kvb.clone().requires_grad_()
+    ref(qr, kr).backward(dout)
+    xe._COMPUTE["dtype"] = torch.bfloat16 if mfma else torch.float32
+    tol = 3e-2 if mfma else 2e-4
+    qd = qb.clone().cuda().requires_grad_()
+    kd = qd if self_attn else kvb.clone().cuda().requires_grad_()
+    seg = (starts.cuda(), counts.cuda(), self_attn)
+    out = xe.attention(qd, kd, offs[0], offs[1], offs[2], B, H, Lmax, Lmax if self_attn else R, kdiv, klen.cuda(), 0, 1, 0, None, seg)
+    assert _maxdiff(out, ref(qb, kvb)) < 1e-4 and float(out[T:].abs().max()) == 0.0
+    out.backward(dout.cuda())
+    assert _maxdiff(qd.grad, qr.grad) < tol * max(1.0, float(qr.grad.abs().max()))
+    if not self_attn:
+        assert _maxdiff(kd.grad, kr.grad) < tol * max(1.0, float(kr.grad.abs().max()))
