@@ -143,16 +143,14 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnParams p) {
         }
         float m = -INFINITY;
         for (int c = sub; c < kl; c += 4) m = fmaxf(m, ss[r * SS + c]);
-        m = fmaxf(m, __shfl_xor(m, 1, 64));
-        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = quad_max(m);
         float sum = 0.f;
         for (int c = sub; c < kl; c += 4) {
             const float e = expf(ss[r * SS + c] - m);
             ss[r * SS + c] = e;
             sum += e;
         }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
+        sum = quad_sum(sum);
         const bool empty = (kl == 0) && (r < nq);      // softmax over all -inf -> NaN in the reference
         for (int c = sub; c < lkr; c += 4) {
             float pv = 0.f;

@@ -185,16 +185,14 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
                     if (kt * 16 + l15 < kl) m = fmaxf(m, S[qt][kt][r] * 0.125f);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                m = row16_max(m);
                 float e[KT], sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     e[kt] = (kt * 16 + l15 < kl) ? expf(S[qt][kt][r] * 0.125f - m) : 0.f;
                     sum += e[kt];
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                sum = row16_sum(sum);
                 const float inv = sum > 0.f ? 1.f / sum : 0.f;
                 // forward: O = (P o M) V with M = keep / (1 - p); so dV uses P o M, and dP = (dO V^T) o M
                 float dot = 0.f, mk[KT];
@@ -208,8 +206,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
                     e[kt] *= inv;
                     dot += e[kt] * dP[qt][kt][r] * mk[kt];
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+                dot = row16_sum(dot);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     sp[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * mk[kt]);

@@ -44,24 +44,62 @@ template <> struct ElemOps<bf16_t> {
     static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
 };
 
+// Cross-lane moves inside a row of 16 lanes as DPP modifiers (folded into the VALU op that consumes them) instead of
+// ds_bpermute round trips through the LDS pipeline (which is what __shfl_xor compiles to): quad_perm [1,0,3,2] and
+// [2,3,0,1] are lane ^ 1 and lane ^ 2, row_half_mirror pairs the two quads of a half row, row_mirror the two halves.
+// All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+// sums / maxima over groups of 4, 8 or 16 consecutive lanes; every lane of the group ends with the result
+__device__ __forceinline__ float quad_sum(float v) { v += dpp_f32<DPP_XOR1>(v); v += dpp_f32<DPP_XOR2>(v); return v; }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, dpp_f32<DPP_XOR1>(v)); return fmaxf(v, dpp_f32<DPP_XOR2>(v)); }
+__device__ __forceinline__ float oct_sum(float v) { v = quad_sum(v); return v + dpp_f32<DPP_HALF_MIRROR>(v); }
+__device__ __forceinline__ float row16_sum(float v) { v = oct_sum(v); return v + dpp_f32<DPP_MIRROR>(v); }
+__device__ __forceinline__ float row16_max(float v) {
+    v = quad_max(v);
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    return fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = row16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 
-// counter-based dropout mask of the training path: element i of stream `seed` is kept iff drop_hash(seed, i) >= p * 2^32
-// (splitmix64 finaliser).  Forward and backward regenerate the same mask from (seed, i); nothing is stored.
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t i) {
+// 64-bit counter hash (splitmix64 finaliser), upper half: the uniform numbers of the sampling kernels
+__device__ __forceinline__ uint32_t hash64_hi(uint64_t seed, uint64_t i) {
     uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+// counter-based dropout mask of the training path: element i of stream `seed` is kept iff drop_hash(seed, i) >= p * 2^32.
+// Forward and backward regenerate the same mask from (seed, i); nothing is stored.  The stream key is a full 64-bit mix of
+// the seed -- wave-uniform, so it is scalar-ALU work done once per kernel -- and the per-element part is a 32-bit
+// multiply-xorshift hash (two v_mul_lo_u32): 64-bit multiplies are 4 quarter-rate VALU multiplies each on CDNA and a
+// splitmix64 per element was a third of the attention-backward time.
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t i) {
+    uint64_t k = (seed + 0x632BE59BD9B4E019ull) * 0x9E3779B97F4A7C15ull;
+    k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+    k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+    k ^= k >> 31;
+    uint32_t x = (uint32_t)i + __builtin_rotateleft32((uint32_t)(i >> 32), 19);
+    x ^= (uint32_t)k;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x += (uint32_t)(k >> 32); x *= 0x846CA68Bu;
+    return x ^ (x >> 16);
 }
 
 }  // namespace bofi

@@ -266,8 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
             if (p.stats_out) {                         // partial sums over this lane's aligned 32-column group (8 lanes)
                 float ps = live[u] ? (v.x + v.y) + (v.z + v.w) : 0.f;
                 float pq = live[u] ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+                ps = oct_sum(ps); pq = oct_sum(pq);
                 if (live[u] && (lane & 7) == 0)
                     reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 5) + (n >> 5)] = make_float2(ps, pq);
             }

@@ -316,8 +316,8 @@ __global__ __launch_bounds__(128) void embed_fill_kernel(const float* __restrict
         if (xt) ElemOps<T>::store(xt + (size_t)row * d + k, v);
         if (stats) {                                  // partial (sum, sumsq) per 32 columns, as the GEMM epilogues write them
             float ps = v, pq = v * v;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+            ps = row16_sum(ps); pq = row16_sum(pq);
+            ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
             if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
         }
     }
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(128) void embed_rows_kernel(const float* __restrict
         if (xt) ElemOps<T>::store(xt + (size_t)row * d + k, v);
         if (stats) {
             float ps = v, pq = v * v;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) { ps += __shfl_xor(ps, o, 64); pq += __shfl_xor(pq, o, 64); }
+            ps = row16_sum(ps); pq = row16_sum(pq);
+            ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
             if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
         }
     }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const float* __restri
         for (int i = tid; i < V; i += 256) {
             float lp = x[i];
             if (lp != lp) lp = -10.f;
-            const float u = ((float)drop_hash(seed, base + i) + 0.5f) * (1.0f / 4294967296.0f);
+            const float u = ((float)hash64_hi(seed, base + i) + 0.5f) * (1.0f / 4294967296.0f);
             const float gv = lp * inv_temp - logf(-logf(u));
             if (gv > bv) { bv = gv; bi = i; }
         }

@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
             if (p.klen) { kl = (p.q_start ? p.klen[qrow0 + i] : p.klen[b * p.klen_sb + i * p.klen_sq]) + p.klen_bias; kl = max(0, min(kl, Lk)); }
             float m = -INFINITY;
             for (int j = sub; j < kl; j += 4) m = fmaxf(m, sp[i * PS + j]);
-            m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+            m = quad_max(m);
             float sum = 0.f;
             for (int j = sub; j < kl; j += 4) { const float e = expf(sp[i * PS + j] - m); sp[i * PS + j] = e; sum += e; }
-            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+            sum = quad_sum(sum);
             float dot = 0.f;
             for (int j = sub; j < Lk; j += 4) { const float pv = j < kl ? sp[i * PS + j] / sum : 0.f; sp[i * PS + j] = pv; dot += pv * sds[i * PS + j]; }
-            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+            dot = quad_sum(dot);
             for (int j = sub; j < Lk; j += 4) sds[i * PS + j] = sp[i * PS + j] * (sds[i * PS + j] - dot) * 0.125f;
         }
     }

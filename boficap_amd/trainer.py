@@ -201,7 +201,8 @@ class XETrainer:
         if compact:                                            # project only the real tokens' rows onto the vocabulary
             xe.HINTS["token_rows"] = batch["token_rows"]
             if batch.get("row_cap") is not None:               # ... and run the decoder on those rows only
-                xe.HINTS["unpadded"] = (batch["row_start"], batch["row_count"], batch["row_cap"], batch["row_pos"])
+                # add_token_rows pads the list to a multiple of 256: fewer than 256 rows at its end belong to no caption
+                xe.HINTS["unpadded"] = (batch["row_start"], batch["row_count"], batch["row_cap"], batch["row_pos"], 256)
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)

@@ -306,6 +306,19 @@ def _off(t: torch.Tensor, col: int) -> C.c_void_p:
     return C.c_void_p(t.data_ptr() + t.element_size() * col)
 
 
+def _rows_alloc(shape, dtype, device, ragged: bool, tail):
+    """Output buffer of an attention over unpadded rows: the kernels write the captions' rows only, the rows behind the last
+    caption must still be finite (row-wise ops and weight-gradient GEMMs read them).  ``tail``: an upper bound, known on the
+    host, of how many such rows there are at the end of the list (None: unknown, clear everything)."""
+    if not ragged:
+        return torch.empty(shape, dtype=dtype, device=device)
+    if tail is None or tail >= shape[0]:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    t = torch.empty(shape, dtype=dtype, device=device)
+    t[shape[0] - tail:].zero_()
+    return t
+
+
 class AttentionFn(Function):
     """softmax(q k^T / 8, keys < klen) v per head (TransformerModel.py:1421-1432) on column slices of packed
     projection buffers: q = qbuf[:, qoff:qoff+d], k = kvbuf[:, koff:...], v = kvbuf[:, voff:...].
@@ -324,8 +337,8 @@ class AttentionFn(Function):
             raise hip.BofiHipError("unpadded attention needs int32 q_start / q_count of B entries and, if any, one klen per query row")
         d = H * 64
         # rows outside every segment (padding of the row list) are never written by the kernels: keep them finite
-        out = _zeros(qbuf, qbuf.shape[0], d) if seg is not None else _empty(qbuf, B * Lq, d)
         sp = (hip.ptr(seg[0]), hip.ptr(seg[1]), int(bool(seg[2]))) if seg is not None else (None, None, 0)
+        tail = seg[3] if seg is not None and len(seg) > 3 else None
         ldq, ldk = qbuf.shape[1], kvbuf.shape[1]
         bf16 = _COMPUTE["dtype"] == torch.bfloat16
         qs, kvs = (_shadow(qbuf), _shadow(kvbuf)) if bf16 else (None, None)
@@ -333,7 +346,8 @@ class AttentionFn(Function):
         if ctx.shadows:
             # bf16 projections from the GEMM epilogue in, bf16 context out (the operand of the output projection):
             # ``out`` stays an unfilled placeholder
-            ob = (torch.zeros if seg is not None else torch.empty)(qbuf.shape[0], d, dtype=torch.bfloat16, device=qbuf.device)
+            out = _empty(qbuf, qbuf.shape[0], d)              # placeholder: consumers read the bf16 copy
+            ob = _rows_alloc((qbuf.shape[0], d), torch.bfloat16, qbuf.device, seg is not None, tail)
             _chk(_lib().bofi_attention_ex(_off(qs, qoff), ldq, _off(kvs, koff), ldk, _off(kvs, voff), ldk, hip.ptr(ob), d, hip.DT_BF16, B, H,
                                           Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, drop[0] if drop else 0.0,
                                           drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, sp[0], sp[1], sp[2], hip.stream_ptr()),
@@ -342,6 +356,7 @@ class AttentionFn(Function):
             ctx.save_for_backward(qs, kvs)
         else:
             _real(qbuf, "attention q"), _real(kvbuf, "attention kv")
+            out = _rows_alloc((qbuf.shape[0], d), torch.float32, qbuf.device, seg is not None, tail)
             drop = None                                        # dropout(p_attn) is built into the bf16 kernels only
             _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
                                           Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, 0.0, 0, None, sp[0], sp[1], sp[2],
@@ -365,8 +380,14 @@ class AttentionFn(Function):
         covered = ctx.seg is None and ctx.mfma and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64))
         sp = (hip.ptr(ctx.seg[0]), hip.ptr(ctx.seg[1]), int(bool(ctx.seg[2]))) if ctx.seg is not None else (None, None, 0)
         alloc = torch.empty if covered else torch.zeros
-        dq = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
-        dkv = dq if ctx.same else alloc(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
+        tail = ctx.seg[3] if ctx.seg is not None and len(ctx.seg) > 3 else None
+        if ctx.seg is not None and ctx.mfma and tail is not None and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64)):
+            # unpadded rows: the kernel writes every caption's rows; only the rows behind the last caption need zeros
+            dq = _rows_alloc(qbuf.shape, torch.float32, qbuf.device, True, tail)
+            dkv = dq if ctx.same else torch.empty(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
+        else:
+            dq = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
+            dkv = dq if ctx.same else alloc(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         if ctx.mfma:
             _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.dtype_code(qbuf),
                                                 hip.ptr(dout), H * 64, _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk,
@@ -607,7 +628,7 @@ def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap
         kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
     sb = 0 if seg is not None else (1 if att_len_cap is not None else 0)
     ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, sb, (1 if seg is not None else 0), 0, drop.attn(),
-                    None if seg is None else (seg[0], seg[1], False))
+                    None if seg is None else (seg[0], seg[1], False) + tuple(seg[2:3]))
     return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
@@ -626,7 +647,7 @@ def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_
         if seg is None:
             ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn())
         else:
-            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, 0, 1, 0, drop.attn(), (seg[0], seg[1], True))
+            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, 0, 1, 0, drop.attn(), (seg[0], seg[1], True) + tuple(seg[2:3]))
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
         xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
         x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap, seg)
@@ -821,15 +842,15 @@ def _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ex
                    spi, att_len_cap, glat_p, na_bound):
     """decode_SA / decode_NA (+ the glancing pass) of forward_uic over the captions' real positions only.
 
-    ``unpadded`` = (row_start int32 [N], row_count int32 [N], row_cap int64 [T], row_pos int64 [T]): row r of the decoder
+    ``unpadded`` = (row_start int32 [N], row_count int32 [N], row_cap int64 [T], row_pos int64 [T] [, tail]): row r of the decoder
     batch is position row_pos[r] of caption row_cap[r]; T is padded (to a multiple the caller chooses) with rows that belong
     to no caption.  A padded [N, Sd] batch spends most of its rows on positions past the captions' ends (synthetic
     COCO-like captions: ~45% real); their outputs carry zero loss weight and nothing attends to them, so leaving them out
     changes neither the loss nor any gradient.  Returns ((sa_tok [T, V], na_bound()), na_tok [T, V]); the op order (SA fill,
     NA bound, glancing, NA fill) is the padded path's, so the dropout streams agree with it site by site."""
     dev = labels.device
-    row_start, row_count, row_cap, row_pos = unpadded
-    seg = (row_start, row_count)
+    row_start, row_count, row_cap, row_pos = unpadded[:4]
+    seg = (row_start, row_count) + tuple(unpadded[4:5])        # (+ the host's bound on the number of padding rows, if given)
     L = labels.shape[1]
     with torch.no_grad():
         at = row_cap * L + row_pos                                # (caption, position) in the [N, L] loader arrays
