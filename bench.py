@@ -180,7 +180,7 @@ def main_xe(args):
     model = models.setup(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev).train()
-    tr = XETrainer(model, opt, graph=not args.no_graph)
+    tr = XETrainer(model, opt, graph=not args.no_graph, streams=bool(args.streams))
     host_batch = synthetic_training_batch(cfg, args.batch, spi, seed=100 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in host_batch.items()}
     batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
@@ -333,6 +333,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ids-only", action="store_true", help="do not materialise the [B,20,V] log-prob tensor")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--streams", type=int, default=0, help="xe mode: 1 = the forward's four branches on HIP streams of their own")
     ap.add_argument("--refine", type=int, default=0, help="extra filling rounds (BASELINE config 5 uses 3 rounds at batch 256)")
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")

@@ -369,9 +369,50 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
     }
 }
 
+
+// Every GEMM weight of the model transposed in ONE launch: entry e of ``table`` = (src offset, dst offset, N, K, Np) says that
+// the bf16 matrix [N, K] at src + src_off goes to [K, Np] at dst + dst_off (columns N..Np-1 are never written: the caller
+// cleared them once).  tile_first[e] is the index of e's first 64 x 64 tile in the grid.  The backward's dX = dZ W GEMMs take
+// their weight operand contraction-major; per-weight transposes were 81 launches a step.
+__global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const int64_t* __restrict__ table, const int* __restrict__ tile_first, int n) {
+    __shared__ bf16_t tile[64][66];
+    int lo = 0, hi = n - 1;                                     // last entry whose first tile is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = table + (size_t)lo * 5;
+    const int N = (int)e[2], K = (int)e[3], Np = (int)e[4];
+    const bf16_t* s = src + e[0];
+    bf16_t* d = dst + e[1];
+    const int t = (int)blockIdx.x - tile_first[lo], tk = (K + 63) >> 6;
+    const int n0 = (t / tk) * 64, k0 = (t % tk) * 64;
+    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+    for (int r = r4; r < 64; r += 4) {
+        const int nn = n0 + r, kk = k0 + c;
+        tile[r][c] = (nn < N && kk < K) ? s[(size_t)nn * K + kk] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int r = r4; r < 64; r += 4) {
+        const int kk = k0 + r, nn = n0 + c;
+        if (kk < K && nn < N) d[(size_t)kk * Np + nn] = tile[c][r];
+    }
+}
+
 }  // namespace bofi
 
 using namespace bofi;
+
+extern "C" int bofi_transpose_many(const void* src_bf16, void* dst_bf16, const int64_t* table, const int* tile_first, int n, int total_tiles,
+                                   void* stream) {
+    if (!src_bf16 || !dst_bf16 || !table || !tile_first || n < 0 || total_tiles < 0) return BOFI_ERR_ARG;
+    if (n == 0 || total_tiles == 0) return BOFI_OK;
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src_bf16, (bf16_t*)dst_bf16,
+                       table, tile_first, n);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
 
 extern "C" int bofi_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
                               float beta2, float eps, int step, float clip_value, float grad_scale, void* stream) {

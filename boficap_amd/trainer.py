@@ -14,7 +14,7 @@ import torch
 
 from . import hip
 
-ALIGN = 4            # elements: every parameter starts on a 16-byte boundary (the GEMM's operand alignment)
+ALIGN = 64           # elements: every parameter -- and its bf16 copy (WeightOperands) -- starts on a 128-byte boundary: the GEMM's LDS-DMA reads weights in 128-byte row slabs, a straddling base costs two cache lines per slab (measured: +18% GEMM time)
 
 
 class FlatBucket:
@@ -86,6 +86,84 @@ class FlatBucket:
         return 1.0 / dist.get_world_size(group)
 
 
+class WeightOperands:
+    """bf16 GEMM operands of the weights in a FlatBucket, kept current per STEP instead of per use.
+
+    The bf16 training path used to cast every weight once a step (one launch each) and transpose every weight once a step for
+    the input-gradient GEMMs (one launch each): ~180 small launches.  Here the optimiser kernel writes a bf16 copy of the whole
+    bucket while it updates it (``shadow``; one cast of the bucket whenever somebody else changed the weights, detected through
+    the tensors' version counters), forward operands are views of that copy, and the transposed operands of all weights come from
+    ONE launch (bofi_transpose_many) at the start of the step.  Which (offset, N, K) matrices the backward asks for is learnt
+    from the first step that asks; tables are append-only so that captured step graphs keep valid pointers."""
+
+    def __init__(self, bucket: "FlatBucket"):
+        self.bucket = bucket
+        self.shadow = torch.empty(bucket.numel, dtype=torch.bfloat16, device=bucket.flat.device)
+        self._version = None
+        self._tables = []                                       # (buffer, table int64 [n,5], tile_first int32 [n+1], n, tiles)
+        self._views = {}                                        # (offset, N, K) -> [K, Np] view of a buffer
+        self._pending = []
+        self._base = bucket.flat.data_ptr()
+        self._bytes = bucket.numel * 4
+
+    def _offset_of(self, t: torch.Tensor, numel: int):
+        o = t.data_ptr() - self._base
+        if o < 0 or o + numel * 4 > self._bytes or o % 4 or not t.is_contiguous() or t.numel() != numel:
+            return None
+        return o // 4
+
+    def refresh_if_stale(self) -> None:
+        """Outside any graph: re-cast the bucket if anything but the optimiser kernel touched it since the last look."""
+        flat = self.bucket.flat
+        # in-place edits bump the version counter of the tensor they go through: the parameters' own (load_state_dict, p.mul_())
+        # or the flat buffer's; the optimiser kernel works on raw pointers and bumps neither
+        stamp = (flat._version, sum(p._version for p in self.bucket.params))
+        if self._version != stamp:
+            hip.check(hip.lib().bofi_cast_bf16(hip.ptr(flat), self.bucket.numel, hip.ptr(self.shadow), self.bucket.numel, 1, self.bucket.numel,
+                                               None, None, 0.0, 0, None, hip.stream_ptr()), "bofi_cast_bf16")
+            self._version = stamp
+
+    def launch_transposes(self) -> None:
+        for buf, table, first, n, tiles in self._tables:
+            hip.check(hip.lib().bofi_transpose_many(hip.ptr(self.shadow), hip.ptr(buf), hip.ptr(table), hip.ptr(first), n, tiles,
+                                                    hip.stream_ptr()), "bofi_transpose_many")
+
+    # ---- what xe._operand / xe._transposed ask (None: not a bucket weight, or not known yet -> the per-use path)
+    def operand(self, w: torch.Tensor, N: int, K: int):
+        if K % 64:
+            return None
+        o = self._offset_of(w, N * K)
+        return None if o is None else self.shadow[o:o + N * K].view(N, K)
+
+    def transposed(self, w: torch.Tensor, N: int, K: int):
+        o = self._offset_of(w, N * K)
+        if o is None:
+            return None
+        hit = self._views.get((o, N, K))
+        if hit is None and (o, N, K) not in self._pending:
+            self._pending.append((o, N, K))
+        return hit
+
+    def end_step(self) -> None:
+        """Matrices asked for the first time during this step join the batched launch from the next step on."""
+        if not self._pending or torch.cuda.is_current_stream_capturing():
+            return
+        dev = self.shadow.device
+        rows, first, dst, tiles = [], [0], 0, 0
+        for o, N, K in self._pending:
+            Np = (N + 63) // 64 * 64
+            rows.append((o, dst, N, K, Np))
+            dst += K * Np
+            tiles += ((N + 63) // 64) * ((K + 63) // 64)
+            first.append(tiles)
+        buf = torch.zeros(dst, dtype=torch.bfloat16, device=dev)
+        for (o, d0, N, K, Np) in rows:
+            self._views[(o, N, K)] = buf[d0:d0 + K * Np].view(K, Np)
+        self._tables.append((buf, torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(first, dtype=torch.int32, device=dev),
+                             len(rows), tiles))
+        self._pending = []
+
+
 def noam_rate(step: int, d_model: int, factor: float = 1.0, warmup: int = 2000) -> float:
     """NoamOpt.rate, captioning/utils/misc.py:179-185."""
     return factor * (d_model ** -0.5 * min(step ** -0.5, step * warmup ** -1.5))
@@ -98,7 +176,8 @@ class XETrainer:
     (20000), ``noamopt_factor`` (1), ``learning_rate`` (5e-4, used when noamopt is off), ``optim_alpha/beta/epsilon``
     (plain Adam), ``grad_clip_value`` (0.1) with ``grad_clip_mode`` 'value'."""
 
-    def __init__(self, model, opt=None, group=None, graph: bool = False, unpadded: bool = True):
+    def __init__(self, model, opt=None, group=None, graph: bool = False, unpadded: bool = True, prepared_weights: bool = True,
+                 streams: bool = False):
         """``graph``: capture zero-grad + forward + criterion + backward of a batch signature (shapes, max phrase count,
         GLAT on/off) into a hipGraph on first use and replay it afterwards -- ~1 200 kernel launches and the whole Python /
         autograd dispatch of a step become one graph launch.  Inputs are copied into static buffers, the dropout step lives
@@ -124,6 +203,11 @@ class XETrainer:
         self._step = 0
         self.graph = bool(graph)
         self.unpadded = bool(unpadded)                         # add_token_rows: run the decoder over the captions' real positions only
+        # bf16 mode: weight operands of the GEMMs come from a bf16 copy of the bucket the optimiser kernel maintains
+        self.ops = WeightOperands(self.bucket) if prepared_weights else None
+        # the forward's four branches (and with them the backward's) on HIP streams of their own (xe._Fork); needs the bucket-level
+        # weight operands: per-use casts / transposes of a weight two branches share would race
+        self._side = [torch.cuda.Stream() for _ in range(3)] if streams and self.ops is not None else None
         self.max_graphs = 8                                    # batch signatures (shapes x max phrase count x GLAT rate) kept as graphs
         self._graphs = {}
         self._fwd_calls = 0
@@ -143,6 +227,8 @@ class XETrainer:
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
+        if self.ops is not None and not self._capturing() and self.model.train_dtype == torch.bfloat16:
+            self.ops.refresh_if_stale()
         if self.graph and not self._capturing():
             self._fwd_calls += 1
             self._step_word.fill_(self._fwd_calls)             # outside any graph: every step draws new dropout masks
@@ -190,6 +276,19 @@ class XETrainer:
     def _forward_backward_eager(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         from . import xe
         self.bucket.zero_grad()
+        armed = self.ops is not None and self.model.train_dtype == torch.bfloat16
+        if armed:
+            self.ops.launch_transposes()
+            xe._WEIGHTS["provider"] = self.ops
+        try:
+            return self._forward_backward_armed(batch, glat_p)
+        finally:
+            if armed:
+                xe._WEIGHTS["provider"] = None
+                self.ops.end_step()
+
+    def _forward_backward_armed(self, batch, glat_p):
+        from . import xe
         fc = batch.get("fc_feats")
         if fc is None:
             fc = torch.zeros(batch["att_feats"].shape[0], 0, device=batch["att_feats"].device)
@@ -203,6 +302,8 @@ class XETrainer:
             if batch.get("row_cap") is not None:               # ... and run the decoder on those rows only
                 # add_token_rows pads the list to a multiple of 256: fewer than 256 rows at its end belong to no caption
                 xe.HINTS["unpadded"] = (batch["row_start"], batch["row_count"], batch["row_cap"], batch["row_pos"], 256)
+                if self._side is not None and xe._WEIGHTS["provider"] is not None and self.ops._tables and not self.ops._pending:
+                    xe.HINTS["streams"] = self._side
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)
@@ -212,6 +313,12 @@ class XETrainer:
         else:
             loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"])
         loss.backward()
+        if self._side is not None:
+            # the kernels accumulate parameter gradients themselves, so autograd sees no leaf on the side streams and does not
+            # join them at the end of backward(): do it here (the optimiser, or the end of a graph capture, comes next)
+            main = torch.cuda.current_stream()
+            for s_ in self._side:
+                main.wait_stream(s_)
         return loss.detach(), [p.detach() for p in parts]
 
     def add_token_rows(self, batch: Dict[str, torch.Tensor], host_batch) -> Dict[str, torch.Tensor]:
@@ -246,7 +353,8 @@ class XETrainer:
         self._step += 1
         lr = self.rate()
         b = self.bucket
-        hip.check(hip.lib().bofi_adam_step(hip.ptr(b.flat), hip.ptr(b.grad), hip.ptr(self.m), hip.ptr(self.v), None, b.numel, lr,
+        shadow = self.ops.shadow if self.ops is not None and self.ops._version is not None else None
+        hip.check(hip.lib().bofi_adam_step(hip.ptr(b.flat), hip.ptr(b.grad), hip.ptr(self.m), hip.ptr(self.v), hip.ptr(shadow), b.numel, lr,
                                            self.beta1, self.beta2, self.eps, self._step, self.clip, grad_scale, hip.stream_ptr()),
                   "bofi_adam_step")
         self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1     # the decode engine repacks on next use
@@ -287,14 +395,24 @@ class XETrainer:
         if step_word is not None:
             step_word.fill_(self._fwd_calls)
         base = int(getattr(model.opt, "seed", 0)) << 32
-        lp_saic, lp_naic = xe.sampled_logprobs(xe.Params(model), model.cfg, att_feats, att_masks, saic, naic, sample_n=sample_n,
-                                               strict_q1=model.strict_reference, training=model.training,
-                                               seed=base if step_word is not None else base + self._fwd_calls,
-                                               compute_dtype=model.train_dtype, step_word=step_word)
-        l1, r1 = xe.new_self_critical(lp_saic, saic["seq"], s_saic, sample_n)
-        l2, r2 = xe.new_self_critical(lp_naic, naic["seq"], s_naic, sample_n)
-        loss = l1 + l2
-        loss.backward()
+        armed = self.ops is not None and model.train_dtype == torch.bfloat16
+        if armed:
+            self.ops.refresh_if_stale()
+            self.ops.launch_transposes()
+            xe._WEIGHTS["provider"] = self.ops
+        try:
+            lp_saic, lp_naic = xe.sampled_logprobs(xe.Params(model), model.cfg, att_feats, att_masks, saic, naic, sample_n=sample_n,
+                                                   strict_q1=model.strict_reference, training=model.training,
+                                                   seed=base if step_word is not None else base + self._fwd_calls,
+                                                   compute_dtype=model.train_dtype, step_word=step_word)
+            l1, r1 = xe.new_self_critical(lp_saic, saic["seq"], s_saic, sample_n)
+            l2, r2 = xe.new_self_critical(lp_naic, naic["seq"], s_naic, sample_n)
+            loss = l1 + l2
+            loss.backward()
+        finally:
+            if armed:
+                xe._WEIGHTS["provider"] = None
+                self.ops.end_step()
         scale = self.bucket.all_reduce(self.group)
         self.optimizer_step(scale)
         return loss.detach(), r1.mean(), r2.mean()

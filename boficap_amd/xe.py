@@ -15,6 +15,7 @@ the buffers, the tape and the parameter tensors.  Differences in STRUCTURE from 
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 from typing import Optional
 
 import torch
@@ -69,6 +70,10 @@ _STEP_CACHE: dict = {}
 # data pointers of placeholders are listed here and every kernel wrapper that reads float32 input refuses them.
 _SHADOW_ONLY: set = set()
 
+# bf16 operands of the WEIGHTS kept per step by a trainer (boficap_amd.trainer.WeightOperands); set for the duration of one
+# forward + backward.  None: every weight is cast / transposed on first use in the step (the _STEP_CACHE path).
+_WEIGHTS = {"provider": None}
+
 
 def _register_shadow(t, shadow, only=False):
     M, N = t.shape
@@ -116,6 +121,10 @@ def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     hit = _STEP_CACHE.get(key) if (cache and colsum is None) else None
     if hit is not None:
         return hit[1], Np
+    if _WEIGHTS["provider"] is not None and dt == torch.bfloat16 and cache and colsum is None and relu_y is None and drop is None:
+        y = _WEIGHTS["provider"].operand(x, M, N)
+        if y is not None:
+            return y, Np
     if x.data_ptr() in _SHADOW_ONLY:
         raise hip.BofiHipError("placeholder activation without its bf16 shadow")
     if dt == torch.float32:
@@ -139,6 +148,10 @@ def _transposed(x, M, N, dt, colsum=None, cache=True):
     hit = _STEP_CACHE.get(key) if (cache and colsum is None) else None
     if hit is not None:
         return hit[1], Mp
+    if _WEIGHTS["provider"] is not None and dt == torch.bfloat16 and cache and colsum is None:
+        xt = _WEIGHTS["provider"].transposed(x, M, N)
+        if xt is not None:
+            return xt, Mp
     xt = torch.empty(N, Mp, dtype=dt, device=x.device)
     _chk(_lib().bofi_transpose_pad(hip.ptr(x), N, hip.ptr(xt), F32 if dt == torch.float32 else hip.DT_BF16, M, N, Mp, hip.ptr(colsum),
                                    hip.stream_ptr()), "bofi_transpose_pad")
@@ -779,6 +792,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     Sd = S if not Sd else max(1, min(S, int(Sd)))               # decoder positions actually computed
     token_rows = HINTS.pop("token_rows", None)
     unpadded = HINTS.pop("unpadded", None)
+    streams = HINTS.pop("streams", None)
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
@@ -803,15 +817,15 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     # --- semi-autoregressive branch (TransformerModel.py:476-530)
     word_seq = labels.clone()
     word_seq[:, 0] = cfg.len_idx
-    sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
-                                          att_len_cap)
+    sa_bound = lambda: bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
+                                            att_len_cap)
     if unpadded is not None:
-        sa_tok, na_tok = _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ext_syn, ext_seq,
-                                        extend_phrase_seq_mask.to(dev), last, memory, kv_cache, N, Sd, R, spi, att_len_cap, glat_p,
-                                        lambda: bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi,
-                                                                     klen_pass, att_len_cap))
-        na_len, na_syn = sa_tok[1]
-        return pad_slots(sa_len), pad_slots(sa_syn), sa_tok[0], pad_slots(na_len), pad_slots(na_syn), na_tok
+        na_bound = lambda: bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
+        (sa_len, sa_syn), sa_tok, (na_len, na_syn), na_tok = _fill_unpadded(
+            P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ext_syn, ext_seq, extend_phrase_seq_mask.to(dev), last, memory,
+            kv_cache, N, Sd, R, spi, att_len_cap, glat_p, sa_bound, na_bound, streams)
+        return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+    sa_len, sa_syn = sa_bound()
     syn_mid = ext_syn[:, 1:1 + Sd].contiguous()
     ext_seq = ext_seq[:, :Sd].contiguous()
     klen_sa = extend_phrase_seq_mask.to(dev).long().sum(-1)[:, :Sd].to(torch.int32).contiguous()  # prefix masks (dataloader.py:414)
@@ -838,16 +852,66 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
 
 
+class _Fork:
+    """The four branches of the training forward (SA bound, SA fill, NA bound, glancing + NA fill) on HIP streams of their own.
+
+    They only share the image memory and its cross-attention K/V; most of their kernels are far too small to fill 256 CUs, so
+    running them side by side is what keeps the chip busy.  Autograd runs each node's backward on the stream of its forward and
+    orders the streams where gradients meet, so the backward forks the same way; inside a captured step the streams become
+    parallel branches of the hipGraph.  Parameter gradients are accumulated with float atomics into the flat bucket, which is
+    what makes concurrent branches over the SAME weights (the decoder serves both fills) legal."""
+
+    def __init__(self, streams):
+        self.main = torch.cuda.current_stream()
+        self.side = list(streams)
+
+    def share(self, tensors):
+        """Tensors made on the main stream that the side streams read (and their bf16 shadows): tell the allocator."""
+        for t in tensors:
+            if t is None:
+                continue
+            sh = _shadow(t)
+            for s in self.side:
+                t.record_stream(s)
+                if sh is not None:
+                    sh.record_stream(s)
+
+    def begin(self):
+        for s in self.side:
+            s.wait_stream(self.main)
+
+    def on(self, i):
+        return torch.cuda.stream(self.side[i])
+
+    def join(self, outs):
+        for s in self.side:
+            self.main.wait_stream(s)
+        for t in outs:
+            t.record_stream(self.main)
+            sh = _shadow(t)
+            if sh is not None:
+                sh.record_stream(self.main)
+
+
+class _NoFork:
+    def share(self, tensors): pass
+    def begin(self): pass
+    def on(self, i): return contextlib.nullcontext()
+    def join(self, outs): pass
+
+
 def _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ext_syn, ext_seq, ext_mask, last, memory, kv_cache, N, Sd, R,
-                   spi, att_len_cap, glat_p, na_bound):
-    """decode_SA / decode_NA (+ the glancing pass) of forward_uic over the captions' real positions only.
+                   spi, att_len_cap, glat_p, sa_bound, na_bound, streams=None):
+    """The two bound passes and decode_SA / decode_NA (+ the glancing pass) of forward_uic, the decoder over the captions' real
+    positions only.
 
     ``unpadded`` = (row_start int32 [N], row_count int32 [N], row_cap int64 [T], row_pos int64 [T] [, tail]): row r of the decoder
     batch is position row_pos[r] of caption row_cap[r]; T is padded (to a multiple the caller chooses) with rows that belong
     to no caption.  A padded [N, Sd] batch spends most of its rows on positions past the captions' ends (synthetic
     COCO-like captions: ~45% real); their outputs carry zero loss weight and nothing attends to them, so leaving them out
-    changes neither the loss nor any gradient.  Returns ((sa_tok [T, V], na_bound()), na_tok [T, V]); the op order (SA fill,
-    NA bound, glancing, NA fill) is the padded path's, so the dropout streams agree with it site by site."""
+    changes neither the loss nor any gradient.  Returns (sa_bound(), sa_tok [T, V], na_bound(), na_tok [T, V]); the op order
+    (SA bound, SA fill, NA bound, glancing, NA fill) is the padded path's, so the dropout streams agree with it site by site.
+    ``streams``: three side streams -> the branches run concurrently (see _Fork)."""
     dev = labels.device
     row_start, row_count, row_cap, row_pos = unpadded[:4]
     seg = (row_start, row_count) + tuple(unpadded[4:5])        # (+ the host's bound on the number of padding rows, if given)
@@ -861,23 +925,41 @@ def _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ex
         klen_na = (last - 1)[row_cap].to(torch.int32).contiguous()
         cross_len = None if att_len_cap is None else att_len_cap[row_cap].contiguous()
         real = labels.reshape(-1)[at + 1]
+        ntok = phrase_length.sum(1) - 1
         T = row_cap.numel()
-    x = decode_rows(P, cfg, drop, emb(seq_c, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_sa, cross_len, True, seg)
-    sa_tok = log_softmax(vocab(x))
-    bound = na_bound()
-    fill_in = torch.full((T,), cfg.bos_idx, dtype=torch.int64, device=dev)
-    if glat_p >= 0:                                               # glancing input (TransformerModel.py:437-463)
-        with torch.no_grad():
-            x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, dict(kv_cache), N, Sd, R, spi, klen_na, cross_len, True, seg)
-            pred = greedy_ids(vocab(x)).view(T)
-            ntok = phrase_length.sum(1) - 1
-            in_cap = torch.arange(T, device=dev) < (row_start[-1] + row_count[-1])
-            same = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, row_cap, ((pred == real) & in_cap).long())
-            keep_prob = ((ntok - same) / ntok * glat_p)[row_cap] * in_cap.float()
-            keep = torch.rand(T, device=dev) < keep_prob
-            fill_in = torch.where(keep, real, fill_in).contiguous()
-    x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_na, cross_len, True, seg)
-    return (sa_tok, bound), log_softmax(vocab(x))
+        in_cap = torch.arange(T, device=dev) < (row_start[-1] + row_count[-1])
+    fork = _NoFork()
+    if streams:
+        if len(streams) < 3:
+            raise hip.BofiHipError("three side streams expected")
+        fork = _Fork(streams)
+        # what every branch reads is made here, on the main stream, before the streams part: the image's cross-attention K/V of
+        # the decoder layers and of the bound layer
+        for pre in [f"model.decoder.layers.{l}.src_attn" for l in range(cfg.N_dec)] + ["model.length_predictor.LengthPredictor.0.src_attn"]:
+            if pre not in kv_cache:
+                kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
+        fork.share([memory, syn_c, seq_c, klen_sa, klen_na, cross_len, real, ntok, in_cap] + list(kv_cache.values()))
+        fork.begin()
+    bound_sa = sa_bound()
+    with fork.on(0):
+        x = decode_rows(P, cfg, drop, emb(seq_c, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_sa, cross_len, True, seg)
+        sa_tok = log_softmax(vocab(x))
+    with fork.on(1):
+        bound_na = na_bound()
+    with fork.on(2):
+        fill_in = torch.full((T,), cfg.bos_idx, dtype=torch.int64, device=dev)
+        if glat_p >= 0:                                           # glancing input (TransformerModel.py:437-463)
+            with torch.no_grad():
+                x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, dict(kv_cache), N, Sd, R, spi, klen_na, cross_len, True, seg)
+                pred = greedy_ids(vocab(x)).view(T)
+                same = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, row_cap, ((pred == real) & in_cap).long())
+                keep_prob = ((ntok - same) / ntok * glat_p)[row_cap] * in_cap.float()
+                keep = torch.rand(T, device=dev) < keep_prob
+                fill_in = torch.where(keep, real, fill_in).contiguous()
+        x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_na, cross_len, True, seg)
+        na_tok = log_softmax(vocab(x))
+    fork.join([sa_tok, na_tok, bound_na[0], bound_na[1]])
+    return bound_sa, sa_tok, bound_na, na_tok
 
 
 @_scoped_compute_dtype

@@ -136,6 +136,13 @@ int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb,
 /* xt[n][m] = x[m][n], zero for M <= m < Mpad, written as out_dtype: operand layout of the weight-gradient GEMM.
  * colsum (may be NULL): colsum[n] += sum_m x[m][n], the bias gradient, taken from the tiles while they are in LDS */
 int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream);
+
+/* All weight operands of the backward's input-gradient GEMMs in one launch.  table[e] = {src_off, dst_off, N, K, Np} (int64,
+ * element offsets): the bf16 matrix [N, K] at src + src_off is written transposed as [K, Np] at dst + dst_off (pad columns
+ * N..Np-1 untouched).  tile_first[e] = number of 64 x 64 tiles of the entries before e (tile_first[n] = total_tiles).
+ * Replaces one bofi_transpose_pad per weight and step; same role as the .t() views autograd takes of nn.Linear weights. */
+int bofi_transpose_many(const void* src_bf16, void* dst_bf16, const int64_t* table, const int* tile_first, int n,
+                        int total_tiles, void* stream);
 /* y[m][n] = bf16(x[m][n]) for n < N, zero for N <= n < ldy: a GEMM operand in the bf16 compute dtype.
  * relu_y (may be NULL): forward output of a ReLU layer, same layout as x: x is masked where relu_y <= 0 first.
  * drop_p > 0: then the dropout mask of bofi_linear_ex(drop_p, drop_seed, drop_step) is applied (x' = keep(x) / (1 - p)).

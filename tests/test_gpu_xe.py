@@ -623,6 +623,77 @@ def test_decoder_over_unpadded_rows_matches_padded(weight_cache, manifest, dtype
     assert torch.isfinite(lg) and torch.isfinite(tb.bucket.grad).all()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_forward_branches_on_streams_leave_the_step_unchanged(weight_cache, manifest, graph):
+    """SA bound / SA fill / NA bound / NA fill on four HIP streams (forward and, through autograd, backward), eager and as
+    parallel branches of the captured step graph: same loss and gradients as the one-stream step, dropout on."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, a = _model(weight_cache, manifest, "tiny_train_xe")
+    _, b = _model(weight_cache, manifest, "tiny_train_xe")
+    for m in (a, b):
+        m.train()
+        m.train_dtype = torch.bfloat16
+        m.opt.seed = 5
+    ta, tb = XETrainer(a, graph=graph), XETrainer(b, graph=graph, streams=True)
+    assert tb._side is not None and ta._side is None
+    for step in range(4):
+        hb = synthetic_training_batch(cfg, 4, 3, seed=70 + step // 2)      # two signatures' worth of replays in graph mode
+        batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+        batch["att_feats"] = torch.from_numpy(synthetic_att_feats(4, 36, cfg.att_feat_size, seed=19 + step)).cuda()
+        batch["max_phrase_num"] = int(hb["phrase_num"].max())
+        la, pa = ta.forward_backward(ta.add_token_rows(batch, hb))
+        lb, pb = tb.forward_backward(tb.add_token_rows(batch, hb))
+        torch.cuda.synchronize()
+        assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la))), step
+        assert all(abs(float(x) - float(y)) < 1e-5 * max(1.0, abs(float(x))) for x, y in zip(pa, pb))
+        # bf16 operands: a last-bit difference from the order of the float atomics can flip a rounding of dz
+        assert _maxdiff(tb.bucket.grad, ta.bucket.grad) <= 4e-4 * max(1e-3, float(ta.bucket.grad.abs().max())), step
+        assert float((tb.bucket.grad - ta.bucket.grad).abs().mean()) <= 2e-6 * max(1e-3, float(ta.bucket.grad.abs().max())), step
+    lg, _ = tb.forward_backward(tb.add_token_rows(batch, hb), glat_p=0.5)
+    assert torch.isfinite(lg) and torch.isfinite(tb.bucket.grad).all()
+
+
+def test_bucket_weight_operands_match_per_use_casts(weight_cache, manifest):
+    """WeightOperands (bf16 copy of the bucket kept by the optimiser kernel, all transposed weights from one launch) against
+    the per-use casts / transposes: same loss and gradients step after step, the copy follows the optimiser and notices
+    weights changed behind its back."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, a = _model(weight_cache, manifest, "tiny_train_xe")
+    _, b = _model(weight_cache, manifest, "tiny_train_xe")
+    for m in (a, b):
+        m.eval()
+        m.train_dtype = torch.bfloat16
+    ta, tb = XETrainer(a, prepared_weights=False), XETrainer(b)
+    assert ta.ops is None and tb.ops is not None
+    for step in range(3):
+        hb = synthetic_training_batch(cfg, 4, 3, seed=50 + step)
+        batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+        batch["att_feats"] = torch.from_numpy(synthetic_att_feats(4, 36, cfg.att_feat_size, seed=9 + step)).cuda()
+        batch["max_phrase_num"] = int(hb["phrase_num"].max())
+        la, _ = ta.forward_backward(ta.add_token_rows(batch, hb))
+        lb, _ = tb.forward_backward(tb.add_token_rows(batch, hb))
+        assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
+        assert _maxdiff(tb.bucket.grad, ta.bucket.grad) <= 1e-4 * max(1e-3, float(ta.bucket.grad.abs().max()))
+        if step == 1:
+            assert len(tb.ops._tables) == 1 and len(tb.ops._views) > 10        # learnt in step 0, batched from step 1 on
+            for (o, N, K), view in list(tb.ops._views.items())[:8]:
+                w = tb.bucket.flat[o:o + N * K].view(N, K)
+                assert torch.equal(view[:, :N], w.bfloat16().t()) and float(view[:, N:].abs().sum()) == 0.0
+        ta.optimizer_step()
+        tb.optimizer_step()
+        # (the two trainers' gradients differ by float-atomics ordering; Adam's g / sqrt(v) turns that into visible weight noise)
+        assert float((tb.bucket.flat - ta.bucket.flat).abs().mean()) < 2e-5
+        assert torch.equal(tb.ops.shadow, tb.bucket.flat.bfloat16())
+    with torch.no_grad():
+        b.model.generator.proj.weight.mul_(0.5)                   # somebody else edits a weight
+    tb.ops.refresh_if_stale()
+    assert torch.equal(tb.ops.shadow, tb.bucket.flat.bfloat16())
+
+
 @pytest.mark.parametrize("mfma", [False, True])
 @pytest.mark.parametrize("kdiv,self_attn", [(1, True), (2, False)])
 def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):

@@ -113,6 +113,6 @@ def test_noam_rate_and_bucket_layout():
     net = torch.nn.Linear(3, 2)
     w0 = net.weight.detach().clone()
     b = FlatBucket(net)
-    assert torch.equal(net.weight, w0) and b.numel == 8 + 4 and net.weight.data_ptr() == b.flat.data_ptr()
+    assert torch.equal(net.weight, w0) and b.numel == 64 + 64 and net.weight.data_ptr() == b.flat.data_ptr()
     b.flat.zero_()
     assert float(net.weight.detach().abs().sum()) == 0.0                                                # the module sees the bucket
