@@ -26,14 +26,14 @@ struct GemmTnParams {
     float* colsum;                               // optional: colsum[i] += sum_m A[m][i] (the bias gradient when A is dz)
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
+// one 64 x 64 output tile at (i0, j0), contraction rows m_begin .. m_end - 1, added into C (and, when ``first_col``, the column
+// sums of the A tiles into colsum)
+__device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int j0, int m_begin, int m_end, bool first_col) {
     constexpr int T = 64, TM = 64;                               // 64 contraction rows per barrier (two MFMA k-steps)
     __shared__ __attribute__((aligned(16))) bf16_t sa[2][TM * T];
     __shared__ __attribute__((aligned(16))) bf16_t sb[2][TM * T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
-    const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
-    const int m_begin = blockIdx.z * p.m_per_block, m_end = min(p.M, m_begin + p.m_per_block);
     if (m_begin >= m_end) return;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
     const int lr = tid >> 3, lc = tid & 7;                       // loader: row lr of the 32-row tile, 16-byte chunk lc
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     };
 
     // column sums of the A tiles (workgroups of the first tile column only): thread -> column tid & 63, rows (tid >> 6) * 16 .. + 15
-    const bool do_colsum = p.colsum != nullptr && blockIdx.y == 0;
+    const bool do_colsum = p.colsum != nullptr && first_col;
     float csum = 0.f;
     const int cc = tid & 63, crg = tid >> 6;
 
@@ -135,6 +135,74 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
         }
 }
 
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
+    const int m_begin = blockIdx.z * p.m_per_block;
+    gemm_tn_tile(p, blockIdx.x * 64, blockIdx.y * 64, m_begin, min(p.M, m_begin + p.m_per_block), blockIdx.y == 0);
+}
+
+// Many independent weight-gradient GEMMs in one launch.  A training step has ~126 of them (one per Linear use), each a
+// small output with a long contraction; launched one by one every GEMM is a latency chain of its own with two workgroups
+// per CU at best.  Grouped, the step's weight gradients are ~15 000 tiles in a few launches: no row split (no extra atomics),
+// five workgroups per CU hiding each other's loads.  The problems travel BY VALUE in the kernel arguments, so a captured step
+// graph holds them without a device-side table.
+constexpr int TN_GROUP_MAX = 40;
+struct GemmTnGroup {
+    GemmTnParams prob[TN_GROUP_MAX];
+    int tile_first[TN_GROUP_MAX + 1];                            // tiles of the problems before e
+    int n, splits;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const GemmTnGroup grp) {
+    const int t = blockIdx.x;
+    int lo = 0, hi = grp.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (grp.tile_first[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const GemmTnParams& q = grp.prob[lo];
+    const int local = t - grp.tile_first[lo], tj = (q.NJ + 63) >> 6;
+    const int m_begin = blockIdx.y * q.m_per_block;
+    gemm_tn_tile(q, (local / tj) * 64, (local % tj) * 64, m_begin, min(q.M, m_begin + q.m_per_block), local % tj == 0);
+}
+
+static int check_tn(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, const float* c, int ldc, int M, int NI, int NJ) {
+    if (!a || !b || !c || M < 0 || NI <= 0 || NJ <= 0 || ldc < NJ) return BOFI_ERR_ARG;
+    if (a_cols < NI || b_cols < NJ || a_cols % 8 || b_cols % 8 || lda < a_cols || ldb < b_cols || lda % 8 || ldb % 8) return BOFI_ERR_ARG;
+    if (((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return BOFI_ERR_ARG;
+    return BOFI_OK;
+}
+
+int launch_gemm_tn_grouped(int n, const void* const* a, const int* lda, const int* a_cols, const void* const* b, const int* ldb,
+                           const int* b_cols, float* const* c, const int* ldc, const int* M, const int* NI, const int* NJ,
+                           float* const* colsum, hipStream_t st) {
+    if (n < 0 || (n && (!a || !lda || !a_cols || !b || !ldb || !b_cols || !c || !ldc || !M || !NI || !NJ))) return BOFI_ERR_ARG;
+    for (int e = 0; e < n; ++e)
+        if (int rc = check_tn(a[e], lda[e], a_cols[e], b[e], ldb[e], b_cols[e], c[e], ldc[e], M[e], NI[e], NJ[e])) return rc;
+    int e = 0;
+    while (e < n) {
+        GemmTnGroup g;
+        g.n = 0;
+        int tiles = 0, max_m = 0;
+        for (; e < n && g.n < TN_GROUP_MAX; ++e) {
+            if (M[e] == 0) continue;
+            g.prob[g.n] = GemmTnParams{static_cast<const bf16_t*>(a[e]), lda[e], a_cols[e], static_cast<const bf16_t*>(b[e]), ldb[e], b_cols[e],
+                                       c[e], ldc[e], M[e], NI[e], NJ[e], 0, colsum ? colsum[e] : nullptr};
+            g.tile_first[g.n] = tiles;
+            tiles += ((NI[e] + 63) / 64) * ((NJ[e] + 63) / 64);
+            max_m = max(max_m, M[e]);
+            ++g.n;
+        }
+        if (!g.n) break;
+        g.tile_first[g.n] = tiles;
+        // enough workgroups for ~5 per CU; a split costs one more tile of atomics per output tile
+        g.splits = max(1, min(min(8, (max_m + 255) / 256), (1280 + tiles - 1) / tiles));
+        for (int k = 0; k < g.n; ++k) g.prob[k].m_per_block = ((g.prob[k].M + g.splits - 1) / g.splits + 63) / 64 * 64;
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles, g.splits), dim3(256), 0, st, g);
+        BOFI_CHECK_LAUNCH();
+    }
+    return BOFI_OK;
+}
+
 int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M, int NI, int NJ,
                    float* colsum, hipStream_t st) {
     if (!a || !b || !c || M < 0 || NI <= 0 || NJ <= 0 || ldc < NJ) return BOFI_ERR_ARG;
@@ -157,6 +225,12 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
 }
 
 }  // namespace bofi
+
+extern "C" int bofi_gemm_tn_grouped(int n, const void* const* a, const int* lda, const int* a_cols, const void* const* b, const int* ldb,
+                                    const int* b_cols, float* const* c, const int* ldc, const int* M, const int* NI, const int* NJ,
+                                    float* const* colsum, void* stream) {
+    return bofi::launch_gemm_tn_grouped(n, a, lda, a_cols, b, ldb, b_cols, c, ldc, M, NI, NJ, colsum, (hipStream_t)stream);
+}
 
 extern "C" int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M, int NI,
                                 int NJ, float* colsum, void* stream) {

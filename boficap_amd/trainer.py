@@ -177,7 +177,7 @@ class XETrainer:
     (plain Adam), ``grad_clip_value`` (0.1) with ``grad_clip_mode`` 'value'."""
 
     def __init__(self, model, opt=None, group=None, graph: bool = False, unpadded: bool = True, prepared_weights: bool = True,
-                 streams: bool = False):
+                 streams: bool = False, grouped_dw: bool = True):
         """``graph``: capture zero-grad + forward + criterion + backward of a batch signature (shapes, max phrase count,
         GLAT on/off) into a hipGraph on first use and replay it afterwards -- ~1 200 kernel launches and the whole Python /
         autograd dispatch of a step become one graph launch.  Inputs are copied into static buffers, the dropout step lives
@@ -205,6 +205,7 @@ class XETrainer:
         self.unpadded = bool(unpadded)                         # add_token_rows: run the decoder over the captions' real positions only
         # bf16 mode: weight operands of the GEMMs come from a bf16 copy of the bucket the optimiser kernel maintains
         self.ops = WeightOperands(self.bucket) if prepared_weights else None
+        self.grouped_dw = bool(grouped_dw)                     # bf16 mode: all weight-gradient GEMMs of a step in a few grouped launches
         # the forward's four branches (and with them the backward's) on HIP streams of their own (xe._Fork); needs the bucket-level
         # weight operands: per-use casts / transposes of a weight two branches share would race
         self._side = [torch.cuda.Stream() for _ in range(3)] if streams and self.ops is not None else None
@@ -280,9 +281,14 @@ class XETrainer:
         if armed:
             self.ops.launch_transposes()
             xe._WEIGHTS["provider"] = self.ops
+        if self.grouped_dw:
+            xe._DEFER["list"] = []                             # weight gradients: one grouped launch after backward
         try:
-            return self._forward_backward_armed(batch, glat_p)
+            out = self._forward_backward_armed(batch, glat_p)
+            xe.flush_weight_grads()
+            return out
         finally:
+            xe._DEFER["list"] = None
             if armed:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()

@@ -74,6 +74,27 @@ _SHADOW_ONLY: set = set()
 # forward + backward.  None: every weight is cast / transposed on first use in the step (the _STEP_CACHE path).
 _WEIGHTS = {"provider": None}
 
+# Weight-gradient GEMMs put off to one grouped launch after backward (flush_weight_grads): a list of
+# (dz operand, ld, x operand, ld, target, ldc, M, N, K, bias target) while a trainer collects them, else None.
+_DEFER = {"list": None}
+
+
+def flush_weight_grads():
+    """Run the deferred weight-gradient GEMMs (bofi_gemm_tn_grouped) on the current stream and forget them."""
+    todo = _DEFER["list"]
+    if not todo:
+        return 0
+    n = len(todo)
+    vp, ci = C.c_void_p * n, C.c_int * n
+    col = lambda k: [t[k] for t in todo]
+    rc = _lib().bofi_gemm_tn_grouped(
+        n, vp(*[hip.ptr(t) for t in col(0)]), ci(*col(1)), ci(*col(1)), vp(*[hip.ptr(t) for t in col(2)]), ci(*col(3)), ci(*col(3)),
+        vp(*[hip.ptr(t) for t in col(4)]), ci(*col(5)), ci(*col(6)), ci(*col(7)), ci(*col(8)),
+        vp(*[hip.ptr(t) for t in col(9)]), hip.stream_ptr())
+    _DEFER["list"] = []
+    _chk(rc, "bofi_gemm_tn_grouped")
+    return n
+
 
 def _register_shadow(t, shadow, only=False):
     M, N = t.shape
@@ -239,7 +260,10 @@ class LinearFn(Function):
                 target = ctx.gw
                 if target is None:
                     dw = target = _zeros(x, N, K)
-                _chk(L.bofi_gemm_tn_acc(hip.ptr(dzo), Np, Np, hip.ptr(xo), Kp, Kp, hip.ptr(target), K, M, N, K, hip.ptr(bsum), st), "bofi_gemm_tn_acc")
+                if _DEFER["list"] is not None and ctx.gw is not None:
+                    _DEFER["list"].append((dzo, Np, xo, Kp, target, K, M, N, K, bsum))      # with the step's other weight gradients
+                else:
+                    _chk(L.bofi_gemm_tn_acc(hip.ptr(dzo), Np, Np, hip.ptr(xo), Kp, Kp, hip.ptr(target), K, M, N, K, hip.ptr(bsum), st), "bofi_gemm_tn_acc")
             return (dx, dw, db) + tail
         if ctx.needs_input_grad[0]:
             dzo, Np = _operand(dz, M, N, dt, cache=False)

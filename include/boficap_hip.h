@@ -133,6 +133,14 @@ int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, i
  * bias gradient; a few atomics per workgroup instead of a reduction pass of its own). */
 int bofi_gemm_tn_acc(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, float* c, int ldc, int M,
                      int NI, int NJ, float* colsum, void* stream);
+
+/* n weight-gradient GEMMs (each as bofi_gemm_tn_acc: c[e] += a[e]^T b[e], colsum[e] += column sums of a[e]; colsum or its
+ * entries may be NULL) in as few launches as the kernel-argument space allows (40 problems each).  All arrays are HOST arrays
+ * of n entries; the problems are passed to the kernel by value.  The training step defers the weight gradients of all its
+ * Linear layers (nn.Linear's grad_weight, one addmm each in the reference) to one such call after backward. */
+int bofi_gemm_tn_grouped(int n, const void* const* a, const int* lda, const int* a_cols, const void* const* b, const int* ldb,
+                         const int* b_cols, float* const* c, const int* ldc, const int* M, const int* NI, const int* NJ,
+                         float* const* colsum, void* stream);
 /* xt[n][m] = x[m][n], zero for M <= m < Mpad, written as out_dtype: operand layout of the weight-gradient GEMM.
  * colsum (may be NULL): colsum[n] += sum_m x[m][n], the bias gradient, taken from the tiles while they are in LDS */
 int bofi_transpose_pad(const float* x, int ldx, void* xt, int out_dtype, int M, int N, int Mpad, float* colsum, void* stream);

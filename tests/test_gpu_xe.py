@@ -442,6 +442,40 @@ def test_gemm_tn_accumulates_a_transposed_times_b(M, NI, NJ):
                                              None, hip.stream_ptr()))
 
 
+@pytest.mark.parametrize("n", [3, 45])
+def test_grouped_weight_gradient_gemms(n):
+    """bofi_gemm_tn_grouped: n problems of mixed sizes (ragged tiles, empty row sets, two problems adding into the same
+    target, with and without column sums) = the problems run one by one; 45 spans two launches."""
+    from boficap_amd import hip, xe
+    g = torch.Generator().manual_seed(n)
+    pad = lambda v: (v + 63) // 64 * 64
+    shapes = [(300, 70, 130), (0, 64, 64), (129, 20, 64), (1000, 128, 65), (64, 64, 192)]
+    todo, refs, targets = [], [], {}
+    for e in range(n):
+        M, NI, NJ = shapes[e % len(shapes)]
+        a = torch.zeros(max(M, 1), pad(NI)); a[:M, :NI] = torch.randn(M, NI, generator=g)
+        b = torch.zeros(max(M, 1), pad(NJ)); b[:M, :NJ] = torch.randn(M, NJ, generator=g)
+        ab, bb = a.cuda().bfloat16(), b.cuda().bfloat16()
+        key = (NI, NJ, e % 2 if e >= len(shapes) else e + 100)               # later problems share targets pairwise
+        if key not in targets:
+            targets[key] = (torch.zeros(NI, NJ, device="cuda"), torch.zeros(NI, device="cuda"), torch.zeros(NI, NJ, dtype=torch.float64),
+                            torch.zeros(NI, dtype=torch.float64))
+        c, cs, rc, rcs = targets[key]
+        with_cs = e % 3 != 1
+        todo.append((ab, ab.shape[1], bb, bb.shape[1], c, NJ, M, NI, NJ, cs if with_cs else None))
+        rc += ab[:M, :NI].float().cpu().double().t() @ bb[:M, :NJ].float().cpu().double()
+        if with_cs:
+            rcs += ab[:M, :NI].float().cpu().double().sum(0)
+    xe._DEFER["list"] = todo
+    try:
+        assert xe.flush_weight_grads() == n and xe._DEFER["list"] == []
+    finally:
+        xe._DEFER["list"] = None
+    for c, cs, rc, rcs in targets.values():
+        assert _maxdiff(c, rc) < 2e-3 * max(1.0, float(rc.abs().max()))
+        assert _maxdiff(cs, rcs) < 2e-3 * max(1.0, float(rcs.abs().max()))
+
+
 @pytest.mark.parametrize("relu,res", [(False, True), (True, False)])
 def test_linear_with_epilogue_dropout_bf16(relu, res):
     """Dropout made in the GEMM epilogue (forward) and in the dz cast (backward) = the separate dropout kernel's mask."""
