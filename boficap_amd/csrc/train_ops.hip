@@ -206,10 +206,10 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict_
         float s = 0.f;
         for (int r = r0; r < r1; ++r) {
             const int64_t id = ids[r];
-            if (id != cur) { atomicAdd(&dlut[(size_t)cur * d + k], scale * s); cur = id; s = 0.f; }
+            if (id != cur) { if (cur >= 0) atomicAdd(&dlut[(size_t)cur * d + k], scale * s); cur = id; s = 0.f; }
             s += dx[(size_t)r * d + k];
         }
-        atomicAdd(&dlut[(size_t)cur * d + k], scale * s);
+        if (cur >= 0) atomicAdd(&dlut[(size_t)cur * d + k], scale * s);                 // negative id: the row has no such term
     }
 }
 
@@ -219,13 +219,14 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ pe, const int64_t* tok, const int64_t* syn, int L,
                                                         int d, float sqrt_d, float* __restrict__ x, const int64_t* __restrict__ pos) {
     const int r = blockIdx.x;
-    const float* tr = tok ? lut_tok + (size_t)tok[r] * d : nullptr;
-    const float* sr = syn ? lut_syn + (size_t)syn[r] * d : nullptr;
+    const float* tr = (tok && tok[r] >= 0) ? lut_tok + (size_t)tok[r] * d : nullptr;      // negative id: the row has no such term
+    const float* sr = (syn && syn[r] >= 0) ? lut_syn + (size_t)syn[r] * d : nullptr;
     const float* pr = pe + (size_t)(pos ? pos[r] : r % L) * d;
     for (int k = threadIdx.x; k < d; k += 128) {
         float v;
         if (tr && sr) v = (tr[k] * sqrt_d + sr[k] * sqrt_d) + pr[k];
-        else v = (tr ? tr[k] : sr[k]) * sqrt_d + pr[k];
+        else if (tr || sr) v = (tr ? tr[k] : sr[k]) * sqrt_d + pr[k];
+        else v = pr[k];
         x[(size_t)r * d + k] = v;
     }
 }

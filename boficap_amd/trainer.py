@@ -177,7 +177,7 @@ class XETrainer:
     (plain Adam), ``grad_clip_value`` (0.1) with ``grad_clip_mode`` 'value'."""
 
     def __init__(self, model, opt=None, group=None, graph: bool = False, unpadded: bool = True, prepared_weights: bool = True,
-                 streams: bool = False, grouped_dw: bool = True):
+                 streams: bool = False, grouped_dw: bool = True, paired: bool = True):
         """``graph``: capture zero-grad + forward + criterion + backward of a batch signature (shapes, max phrase count,
         GLAT on/off) into a hipGraph on first use and replay it afterwards -- ~1 200 kernel launches and the whole Python /
         autograd dispatch of a step become one graph launch.  Inputs are copied into static buffers, the dropout step lives
@@ -205,6 +205,7 @@ class XETrainer:
         self.unpadded = bool(unpadded)                         # add_token_rows: run the decoder over the captions' real positions only
         # bf16 mode: weight operands of the GEMMs come from a bf16 copy of the bucket the optimiser kernel maintains
         self.ops = WeightOperands(self.bucket) if prepared_weights else None
+        self.paired = bool(paired) and self.unpadded            # add_token_rows: SA and NA branch as one batch (xe._forward_paired)
         self.grouped_dw = bool(grouped_dw)                     # bf16 mode: all weight-gradient GEMMs of a step in a few grouped launches
         # the forward's four branches (and with them the backward's) on HIP streams of their own (xe._Fork); needs the bucket-level
         # weight operands: per-use casts / transposes of a weight two branches share would race
@@ -224,7 +225,8 @@ class XETrainer:
 
     _KEYS = ("att_feats", "labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq",
              "extend_phrase_seq_mask")
-    _OPT_KEYS = ("token_rows", "token_labels", "token_weight", "row_start", "row_count", "row_cap", "row_pos")
+    _OPT_KEYS = ("token_rows", "token_labels", "token_weight", "row_start", "row_count", "row_cap", "row_pos",
+                 "pair_start", "pair_count", "pair_src", "pair_na", "pair_labels", "pair_w_sa", "pair_w_na")
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
@@ -310,10 +312,17 @@ class XETrainer:
                 xe.HINTS["unpadded"] = (batch["row_start"], batch["row_count"], batch["row_cap"], batch["row_pos"], 256)
                 if self._side is not None and xe._WEIGHTS["provider"] is not None and self.ops._tables and not self.ops._pending:
                     xe.HINTS["streams"] = self._side
+        paired = compact and batch.get("row_cap") is not None and batch.get("pair_src") is not None
+        if paired:
+            xe.HINTS["paired"] = (batch["pair_start"], batch["pair_count"], batch["pair_src"], batch["pair_na"], 256)
+            xe.HINTS.pop("streams", None)
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
                           glat_p)
-        if compact:
+        if paired:
+            loss, parts = xe.criterion_uic_compact(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
+                                                   batch["pair_labels"], (batch["pair_w_sa"], batch["pair_w_na"]))
+        elif compact:
             loss, parts = xe.criterion_uic_compact(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
                                                    batch["token_labels"], batch["token_weight"])
         else:
@@ -353,6 +362,25 @@ class XETrainer:
             start = np.concatenate([[0], np.cumsum(ntok)[:-1]]).astype(np.int32)
             out.update(row_start=torch.from_numpy(start).to(dev), row_count=torch.from_numpy(ntok.astype(np.int32)).to(dev),
                        row_cap=torch.from_numpy(cap).to(dev), row_pos=torch.from_numpy(pos).to(dev))
+        n_img = int(batch["att_feats"].shape[0])
+        if self.paired and len(ntok) % n_img == 0:
+            # both branches' rows as one list, captions image-major: image i's SA copies, then its NA copies
+            N, spi = len(ntok), len(ntok) // n_img
+            pn = np.arange(2 * N)
+            j = pn % (2 * spi)
+            cap_n, cap_na = (pn // (2 * spi)) * spi + j % spi, j >= spi
+            cnt = ntok[cap_n]
+            T2 = int(cnt.sum())
+            T2p = max(256, (T2 + 255) // 256 * 256)
+            src, na = np.zeros(T2p, np.int64), np.zeros(T2p, bool)
+            src[:T2] = np.concatenate([start[n] + np.arange(ntok[n]) for n in cap_n]) if T2 else 0
+            na[:T2] = np.repeat(cap_na, cnt)
+            lab2, w2 = lab[src], w[src]
+            w2[T2:] = 0.0
+            pstart = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            out.update(pair_start=t(pstart), pair_count=t(cnt.astype(np.int32)), pair_src=t(src), pair_na=t(na), pair_labels=t(lab2),
+                       pair_w_sa=t(w2 * ~na), pair_w_na=t(w2 * na))
         return out
 
     def optimizer_step(self, grad_scale: float = 1.0) -> float:

@@ -817,6 +817,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     token_rows = HINTS.pop("token_rows", None)
     unpadded = HINTS.pop("unpadded", None)
     streams = HINTS.pop("streams", None)
+    paired = HINTS.pop("paired", None)
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
@@ -843,6 +844,9 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     word_seq[:, 0] = cfg.len_idx
     sa_bound = lambda: bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
                                             att_len_cap)
+    if unpadded is not None and paired is not None:
+        return _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq,
+                               extend_phrase_seq_mask.to(dev), last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p)
     if unpadded is not None:
         na_bound = lambda: bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
         (sa_len, sa_syn), sa_tok, (na_len, na_syn), na_tok = _fill_unpadded(
@@ -874,6 +878,81 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap, token_rows is None)
     na_tok = token_logprobs(x)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+
+
+def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq, ext_mask,
+                    last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p):
+    """forward_uic with the SA and the NA branch as ONE batch: one bound pass over 2N captions and one decoder pass over both
+    branches' rows, instead of two of each.
+
+    At these sizes (a few thousand rows, d_model 512) every GEMM / LayerNorm / attention launch is bound by its own latency
+    chain, not by its rows: a 2 560-row projection takes as long as a 5 120-row one (measured, 15.4 us both).  The two branches
+    run the same layers with the same weights on different inputs, so their rows share every launch: half the launches of the
+    decoder and bound stacks, forward and backward.  Captions are ordered image-major -- image i's ``spi`` SA copies, then its
+    ``spi`` NA copies -- so that the 2*spi captions sharing an image's cross-attention keys stay adjacent (kdiv = 2 spi).
+
+    ``unpadded`` as in _fill_unpadded (the single-branch row list: the glancing pass runs on it); ``paired`` =
+    (pair_start int32 [2N], pair_count int32 [2N], pair_src int64 [T2], pair_na bool [T2] [, tail]): row r of the paired list is
+    row pair_src[r] of the single list, in the NA branch iff pair_na[r]; T2 padded like T.  Returns the six tensors of
+    forward_uic with BOTH token entries being the paired log-probs [T2, V] (criterion_uic_compact with a pair of weights)."""
+    dev = labels.device
+    row_start, row_count, row_cap, row_pos = unpadded[:4]
+    pair_start, pair_count, pair_src, pair_na = paired[:4]
+    with torch.no_grad():
+        at = row_cap * L + row_pos
+        syn_c = ext_syn.reshape(-1)[at + 1]
+        seq_c = ext_seq.reshape(-1)[row_cap * ext_seq.shape[1] + row_pos]
+        klen_full = ext_mask.long().sum(-1)
+        klen_sa = klen_full.reshape(-1)[row_cap * klen_full.shape[1] + row_pos].to(torch.int32)
+        klen_na = (last - 1)[row_cap].to(torch.int32)
+        cross_len = None if att_len_cap is None else att_len_cap[row_cap]
+        T = row_cap.numel()
+        # captions in paired order
+        pn = torch.arange(2 * N, device=dev)
+        j = pn % (2 * spi)
+        cap_n = (pn // (2 * spi)) * spi + j % spi
+        cap_na = (j >= spi).unsqueeze(1)
+        n_all = torch.arange(N, device=dev)
+        at_sa = (n_all // spi) * (2 * spi) + n_all % spi          # where caption n's SA / NA copy sits
+        at_na = at_sa + spi
+        tok_b, syn_b = word_seq[cap_n], ext_syn[cap_n]
+        none = torch.full_like(tok_b, -1)                         # the SA bound input has no syntactic term, the NA one no token term
+        tok_b = torch.where(cap_na, none, tok_b).contiguous()
+        syn_b = torch.where(cap_na, syn_b, none).contiguous()
+        klen_b = klen_pass[cap_n].contiguous()
+        att_b = None if att_len_cap is None else att_len_cap[cap_n].contiguous()
+    # the image's cross-attention K/V of every layer that reads it, once, with the tape (the glancing pass below has none)
+    for pre in [f"model.decoder.layers.{l}.src_attn" for l in range(cfg.N_dec)]:
+        if pre not in kv_cache:
+            kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
+    len_lp, syn_lp = bound_teacher_forced(P, cfg, drop, emb(tok_b, syn_b, L), memory, kv_cache, 2 * N, L, R, 2 * spi, klen_b, att_b)
+    sa_len, sa_syn = len_lp.index_select(0, at_sa), syn_lp.index_select(0, at_sa)
+    na_len, na_syn = len_lp.index_select(0, at_na), syn_lp.index_select(0, at_na)
+
+    fill_in = torch.full((T,), cfg.bos_idx, dtype=torch.int64, device=dev)
+    if glat_p >= 0:                                               # glancing input (TransformerModel.py:437-463), NA rows only
+        with torch.no_grad():
+            seg1 = (row_start, row_count) + tuple(unpadded[4:5])
+            x = decode_rows(P, cfg, drop, emb(fill_in, syn_c.contiguous(), Sd, row_pos), memory, dict(kv_cache), N, Sd, R, spi,
+                            klen_na.contiguous(), None if cross_len is None else cross_len.contiguous(), True, seg1)
+            pred = greedy_ids(vocab(x)).view(T)
+            real = labels.reshape(-1)[at + 1]
+            ntok = phrase_length.sum(1) - 1
+            in_cap = torch.arange(T, device=dev) < (row_start[-1] + row_count[-1])
+            same = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, row_cap, ((pred == real) & in_cap).long())
+            keep_prob = ((ntok - same) / ntok * glat_p)[row_cap] * in_cap.float()
+            keep = torch.rand(T, device=dev) < keep_prob
+            fill_in = torch.where(keep, real, fill_in)
+    with torch.no_grad():
+        tok2 = torch.where(pair_na, fill_in[pair_src], seq_c[pair_src]).contiguous()
+        syn2 = syn_c[pair_src].contiguous()
+        pos2 = row_pos[pair_src].contiguous()
+        klen2 = torch.where(pair_na, klen_na[pair_src], klen_sa[pair_src]).contiguous()
+        cross2 = None if cross_len is None else cross_len[pair_src].contiguous()
+    seg2 = (pair_start, pair_count) + tuple(paired[4:5])
+    x = decode_rows(P, cfg, drop, emb(tok2, syn2, Sd, pos2), memory, kv_cache, 2 * N, Sd, R, 2 * spi, klen2, cross2, True, seg2)
+    tok_all = log_softmax(vocab(x))
+    return pad_slots(sa_len), pad_slots(sa_syn), tok_all, pad_slots(na_len), pad_slots(na_syn), tok_all
 
 
 class _Fork:
@@ -1001,7 +1080,8 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
     slot = torch.arange(phrase_length.shape[1] - 1, device=dev).unsqueeze(0)
     slot_mask = slot < phrase_num.unsqueeze(1)
     len_lab, syn_lab = phrase_length[:, 1:], phrase_syn[:, 1:]
-    denom = token_weight.sum()
+    pair = isinstance(token_weight, (tuple, list))             # both branches in one tensor (_forward_paired): (SA weights, NA weights)
+    denom = token_weight[0].sum() if pair else token_weight.sum()
 
     def nll(lp, lab, mask):
         return (-lp.gather(2, lab.unsqueeze(2)).squeeze(2) * mask).sum() / denom
@@ -1009,8 +1089,15 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
     def tok(lp):
         return (-lp.gather(1, token_labels.unsqueeze(1)).squeeze(1) * token_weight).sum() / denom
 
-    parts = [nll(sa_len, len_lab, slot_mask), tok(sa_tok), nll(sa_syn, syn_lab, slot_mask),
-             nll(na_len, len_lab, slot_mask), tok(na_tok), nll(na_syn, syn_lab, slot_mask)]
+    if pair:
+        if sa_tok is not na_tok:
+            raise hip.BofiHipError("a pair of token weights goes with the paired log-probs of _forward_paired")
+        picked = -sa_tok.gather(1, token_labels.unsqueeze(1)).squeeze(1)          # one gather (one scatter in backward) for both branches
+        tok_sa, tok_na = (picked * token_weight[0]).sum() / denom, (picked * token_weight[1]).sum() / denom
+    else:
+        tok_sa, tok_na = tok(sa_tok), tok(na_tok)
+    parts = [nll(sa_len, len_lab, slot_mask), tok_sa, nll(sa_syn, syn_lab, slot_mask),
+             nll(na_len, len_lab, slot_mask), tok_na, nll(na_syn, syn_lab, slot_mask)]
     return sum(parts), parts
 
 

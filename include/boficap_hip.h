@@ -121,7 +121,8 @@ int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, cons
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
-/* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[pos ? pos[r] : r % L]; tok or syn may be NULL
+/* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[pos ? pos[r] : r % L]; tok or syn may be NULL, a negative id
+ * leaves that term out for the row (also in bofi_embed_bwd)
  * (Embeddings + PositionalEncoding, TransformerModel.py:1484-1511) and its backward into one table */
 int bofi_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int64_t* tok,
                     const int64_t* syn, const int64_t* pos, int rows, int L, int d, float* x, void* stream);

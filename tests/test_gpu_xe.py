@@ -622,10 +622,12 @@ def test_compact_vocabulary_rows_leave_loss_and_gradients_unchanged(weight_cache
     assert _maxdiff(tc.bucket.grad, ta.bucket.grad) <= 1e-4 * max(1e-3, float(ta.bucket.grad.abs().max()))
 
 
+@pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_decoder_over_unpadded_rows_matches_padded(weight_cache, manifest, dtype):
+def test_decoder_over_unpadded_rows_matches_padded(weight_cache, manifest, dtype, paired):
     """The decoder over the captions' real positions only (row lists from add_token_rows) against the padded [N, Sd] batch:
-    same loss and gradients, with ragged region masks, in both GEMM dtypes; the glancing pass runs on the same rows."""
+    same loss and gradients, with ragged region masks, in both GEMM dtypes; the glancing pass runs on the same rows.
+    ``paired``: additionally the SA and the NA branch share one bound pass and one decoder pass (xe._forward_paired)."""
     from boficap_amd.collate import synthetic_training_batch
     from boficap_amd.trainer import XETrainer
     from boficap_amd.weights import synthetic_att_feats
@@ -643,9 +645,12 @@ def test_decoder_over_unpadded_rows_matches_padded(weight_cache, manifest, dtype
         masks[b, n:] = 0
     batch["att_masks"] = masks.cuda()
     batch["max_phrase_num"] = int(hb["phrase_num"].max())
-    ta, tb = XETrainer(padded, unpadded=False), XETrainer(ragged)
+    ta, tb = XETrainer(padded, unpadded=False), XETrainer(ragged, paired=paired)
     ba, bb = ta.add_token_rows(batch, hb), tb.add_token_rows(batch, hb)
-    assert "row_cap" not in ba and bb["row_cap"].numel() == bb["token_rows"].numel()
+    assert "row_cap" not in ba and bb["row_cap"].numel() == bb["token_rows"].numel() and ("pair_src" in bb) == paired
+    if paired:
+        T = int(bb["token_weight"].sum())
+        assert float(bb["pair_w_sa"].sum()) == T == float(bb["pair_w_na"].sum()) and int(bb["pair_count"].sum()) == 2 * T
     la, pa = ta.forward_backward(ba)
     lb, pb = tb.forward_backward(bb)
     tol = 1e-5 if dtype == torch.float32 else 2e-2
@@ -670,7 +675,7 @@ def test_forward_branches_on_streams_leave_the_step_unchanged(weight_cache, mani
         m.train()
         m.train_dtype = torch.bfloat16
         m.opt.seed = 5
-    ta, tb = XETrainer(a, graph=graph), XETrainer(b, graph=graph, streams=True)
+    ta, tb = XETrainer(a, graph=graph, paired=False), XETrainer(b, graph=graph, streams=True, paired=False)
     assert tb._side is not None and ta._side is None
     for step in range(4):
         hb = synthetic_training_batch(cfg, 4, 3, seed=70 + step // 2)      # two signatures' worth of replays in graph mode
