@@ -140,7 +140,10 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
                 float pv = st[kj][qi][r] / sum;
                 if (kl == 0 && kj * 16 + g * 4 + r >= Lk) pv = 0.f;      // padded keys of an empty row: V is 0 there
                 if (p.drop_thresh) {                                     // training: dropout(p_attn)
-                    const uint64_t e = ((uint64_t)(b * p.H + h) * p.Lq + q0 + qrow) * Lk + kj * 16 + g * 4 + r;
+                    // element id of the mask: (item, head, query, key), or (global query row, head, key) for unpadded rows --
+                    // the backward walks those in chunks that ignore item boundaries
+                    const uint64_t e = (RAGGED ? (uint64_t)(qrow0 + q0 + qrow) * p.H + h : (uint64_t)(b * p.H + h) * p.Lq + q0 + qrow) * Lk +
+                                       kj * 16 + g * 4 + r;
                     pv = drop_hash(dseed, e) >= p.drop_thresh ? pv * p.drop_scale : 0.f;
                 }
                 f[j] = (short)f32_to_bf16(pv);

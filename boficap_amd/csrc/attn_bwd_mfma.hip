@@ -9,7 +9,9 @@
 //
 // so no transposed copy of anything is ever written.  q, k, v may be float32 (rounded to bf16 on the way into LDS) or
 // bf16; dO, dQ, dK, dV are float32.  Captions of one image share its keys (kdiv): the wavefront owning (image, head) walks
-// them and sums dK / dV in registers -- plain stores, no atomics.
+// them and sums dK / dV in registers -- plain stores, no atomics.  With NW > 1 the workgroup has NW wavefronts that take the
+// captions (or, for unpadded rows, 16*QT-row chunks of the image's contiguous query rows) round robin and add their dK / dV
+// through LDS at the end: a wavefront per image and head alone leaves half the SIMDs idle and serialises ten captions.
 #include "bofi_common.h"
 #include "bofi_kernels.h"
 
@@ -95,34 +97,67 @@ __device__ __forceinline__ bf16x8 frag_row_trorder(const bf16_t* tile, int strid
     return f;
 }
 
-template <typename TIN, int QT, int KT>
-__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) {
+// LDS traffic of one wavefront is in order, so between its own writes and reads of its private staging tiles a wavefront
+// only needs the compiler not to reorder them (the waits on lgkmcnt are inserted per access)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename TIN, int QT, int KT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) {
     constexpr int DS = 72, PS = KT * 16 + 8;                     // padded strides (elements)
     constexpr int LQ = QT * 16, LK = KT * 16;
-    __shared__ __attribute__((aligned(16))) bf16_t sq[LQ * DS], sdo[LQ * DS], sk[LK * DS], sv[LK * DS], sp[LQ * PS], sds[LQ * PS];
-    const int lane = threadIdx.x, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
-    // one wavefront per (key owner, head): with kdiv > 1 it walks the kdiv captions that share these keys and keeps
-    // dK / dV in registers across them, so the shared rows are written once, without atomics
+    constexpr int STAGE = 2 * LQ * DS + 2 * LQ * PS;             // one wavefront's private tiles: Q, dO, P, dS (elements)
+    __shared__ __attribute__((aligned(16))) bf16_t sk[LK * DS], sv[LK * DS];
+    __shared__ __attribute__((aligned(16))) bf16_t stage[NW * STAGE];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bf16_t* const sq = stage + wave * STAGE;
+    bf16_t* const sdo = sq + LQ * DS;
+    bf16_t* const sp = sdo + LQ * DS;
+    bf16_t* const sds = sp + LQ * PS;
+    const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
+    // one workgroup per (key owner, head).  Its work items are the kdiv captions that share these keys -- or, when those
+    // captions' query rows are unpadded (and therefore one contiguous run of rows), 16*QT-row chunks of that run: chunks are
+    // fuller than captions.  Wavefront w takes items w, w + NW, ...; dK / dV stay in registers across them.
     const int bh = blockIdx.x, bk = bh / p.H, h = bh - bk * p.H;
-    const int Lqmax = p.Lq;
     const bool kr = p.q_start && p.k_ragged;                   // self-attention over unpadded rows (kdiv == 1 then)
-    int Lq = p.q_start ? p.q_count[bk * p.kdiv] : p.Lq;
-    size_t qrow0 = p.q_start ? (size_t)p.q_start[bk * p.kdiv] : (size_t)bk * p.kdiv * p.Lq;
+    const bool run = p.q_start && !p.k_ragged && p.kdiv > 1;   // cross-attention over unpadded rows: walk the image's run in chunks
+    const int b_first = bk * p.kdiv;
+    int run0 = 0, run_rows = 0, n_items = p.kdiv;
+    if (run) {
+        run0 = p.q_start[b_first];
+        run_rows = p.q_start[b_first + p.kdiv - 1] + p.q_count[b_first + p.kdiv - 1] - run0;
+        n_items = (run_rows + LQ - 1) / LQ;
+    }
+    auto item_rows = [&](int c, size_t& row0) -> int {         // first query row and row count of item c
+        if (run) { row0 = (size_t)run0 + (size_t)c * LQ; return min(LQ, run_rows - c * LQ); }
+        if (p.q_start) { row0 = (size_t)p.q_start[b_first + c]; return p.q_count[b_first + c]; }
+        row0 = (size_t)(b_first + c) * p.Lq;
+        return p.Lq;
+    };
+    size_t qrow0 = 0;
+    int Lq = wave < n_items ? item_rows(wave, qrow0) : 0;
     const int Lk = kr ? Lq : p.Lk;
     const size_t krow0 = kr ? qrow0 : (size_t)bk * p.Lk;
     const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.drop_step) ? *p.drop_step : 0ull);
 
     RowStage<TIN, LQ> rq;
     RowStage<float, LQ> rdo;
-    {   // keys, values and the first caption's queries / output gradients: all requested before anything is converted
+    {   // keys, values and this wavefront's first queries / output gradients: all requested before anything is converted
+        // (every wavefront of the workgroup stages the same K / V tile: identical bytes, L2 hits, no hand-off to wait for)
         RowStage<TIN, LK> rk, rv;
         rk.load(static_cast<const TIN*>(p.k) + krow0 * p.ldk + h * 64, p.ldk, Lk, lane);
         rv.load(static_cast<const TIN*>(p.v) + krow0 * p.ldv + h * 64, p.ldv, Lk, lane);
-        rq.load(static_cast<const TIN*>(p.q) + qrow0 * p.ldq + h * 64, p.ldq, Lq, lane);
-        rdo.load(p.dout + qrow0 * p.ldo + h * 64, p.ldo, Lq, lane);
+        if (wave < n_items) {
+            rq.load(static_cast<const TIN*>(p.q) + qrow0 * p.ldq + h * 64, p.ldq, Lq, lane);
+            rdo.load(p.dout + qrow0 * p.ldo + h * 64, p.ldo, Lq, lane);
+        }
         rk.store(sk, DS, lane);
         rv.store(sv, DS, lane);
     }
+    __syncthreads();
 
     f32x4 ak[KT][4], av[KT][4];
 #pragma unroll
@@ -130,20 +165,19 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { ak[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; av[kt][dt] = ak[kt][dt]; }
 
-    for (int c = 0; c < p.kdiv; ++c) {
-        const int b = bk * p.kdiv + c;
-        if (c) __syncthreads();                                  // the previous caption's operands are still being read
+    for (int c = wave; c < n_items; c += NW) {
+        const int b = b_first + c;                               // (caption index; unused for unpadded rows)
+        wave_lds_sync();                                         // the previous item's operands are still being read
         rq.store(sq, DS, lane);
         rdo.store(sdo, DS, lane);
-        const int Lq_c = Lq;                                     // this caption's rows (the prefetch below moves Lq / qrow0 on)
+        const int Lq_c = Lq;                                     // this item's rows (the prefetch below moves Lq / qrow0 on)
         const size_t qrow_c = qrow0;
-        if (c + 1 < p.kdiv) {                                    // the next caption's slices travel while this one is multiplied
-            Lq = p.q_start ? p.q_count[b + 1] : p.Lq;
-            qrow0 = p.q_start ? (size_t)p.q_start[b + 1] : (size_t)(b + 1) * p.Lq;
+        if (c + NW < n_items) {                                  // the next item's slices travel while this one is multiplied
+            Lq = item_rows(c + NW, qrow0);
             rq.load(static_cast<const TIN*>(p.q) + qrow0 * p.ldq + h * 64, p.ldq, Lq, lane);
             rdo.load(p.dout + qrow0 * p.ldo + h * 64, p.ldo, Lq, lane);
         }
-        __syncthreads();
+        wave_lds_sync();
 
         // ---- S = Q K^T, dP = dO V^T  (lane holds rows q = qt*16 + 4g + r, column k = kt*16 + l15)
         f32x4 S[QT][KT], dP[QT][KT];
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
                 for (int kt = 0; kt < KT; ++kt) {
                     mk[kt] = 1.f;
                     if (p.drop_thresh) {
-                        const uint64_t ei = ((uint64_t)(b * p.H + h) * Lqmax + qrow) * Lk + kt * 16 + l15;
+                        const uint64_t ei = (p.q_start ? (uint64_t)(qrow_c + qrow) * p.H + h : (uint64_t)(b * p.H + h) * p.Lq + qrow) * Lk + kt * 16 + l15;
                         mk[kt] = drop_hash(dseed, ei) >= p.drop_thresh ? p.drop_scale : 0.f;
                     }
                     e[kt] *= inv;
@@ -213,7 +247,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
                     sds[qrow * PS + kt * 16 + l15] = f32_to_bf16(e[kt] * (dP[qt][kt][r] * mk[kt] - dot) * 0.125f);
                 }
             }
-        __syncthreads();
+        wave_lds_sync();
 
         // ---- dQ = dS K
 #pragma unroll
@@ -250,6 +284,35 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
                 }
             }
     }
+    if constexpr (NW > 1) {                                      // dK / dV of the other wavefronts join wavefront 0's through LDS
+        static_assert(NW * STAGE * 2 >= KT * 4 * 2 * 256 * 4, "staging tiles too small for the reduction");
+        float* red = reinterpret_cast<float*>(stage);            // the staging tiles are no longer needed
+        for (int w = 1; w < NW; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        *reinterpret_cast<f32x4*>(&red[((kt * 4 + dt) * 2 + 0) * 256 + lane * 4]) = ak[kt][dt];
+                        *reinterpret_cast<f32x4*>(&red[((kt * 4 + dt) * 2 + 1) * 256 + lane * 4]) = av[kt][dt];
+                    }
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(&red[((kt * 4 + dt) * 2 + 0) * 256 + lane * 4]);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&red[((kt * 4 + dt) * 2 + 1) * 256 + lane * 4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ak[kt][dt][r] += a[r]; av[kt][dt][r] += v[r]; }
+                    }
+            }
+        }
+        if (wave != 0) return;
+    }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -266,10 +329,12 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) 
 
 template <typename TIN>
 static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
-    const dim3 grid((p.B / p.kdiv) * p.H), block(64);
-    if (p.Lq <= 32 && p.Lk <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 2>), grid, block, 0, st, p);
-    else if (p.Lq <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 4, 4>), grid, block, 0, st, p);
+    const dim3 grid((p.B / p.kdiv) * p.H);
+    // several captions per key owner: two wavefronts share them
+    if (p.Lq <= 32 && p.Lk <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 2, 1>), grid, dim3(64), 0, st, p);
+    else if (p.Lq <= 32 && p.kdiv > 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4, 2>), grid, dim3(128), 0, st, p);
+    else if (p.Lq <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4, 1>), grid, dim3(64), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 4, 4, 1>), grid, dim3(64), 0, st, p);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -734,14 +734,15 @@ def test_bucket_weight_operands_match_per_use_casts(weight_cache, manifest):
 
 
 @pytest.mark.parametrize("mfma", [False, True])
-@pytest.mark.parametrize("kdiv,self_attn", [(1, True), (2, False)])
+@pytest.mark.parametrize("kdiv,self_attn", [(1, True), (2, False), (3, False), (6, False)])
 def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):
     """q_start / q_count (variable rows per caption, padding rows at the end of the list) through the forward and both
-    backward kernels: self-attention over each caption's own rows, cross-attention to the image's dense keys."""
+    backward kernels: self-attention over each caption's own rows, cross-attention to the image's dense keys.  kdiv 3 and 6:
+    an image's captions have 55 / 82 rows, which the MFMA backward walks in 32-row chunks shared by two wavefronts."""
     from boficap_amd import xe
     H, d, B, Lmax, R = 2, 128, 6, 20, 36
     g = torch.Generator().manual_seed(31 + kdiv)
-    counts = torch.tensor([5, 20, 1, 0, 13, 8], dtype=torch.int32)
+    counts = torch.tensor([5, 20, 1, 0, 13, 8] if kdiv < 3 else [16, 20, 19, 7, 0, 20], dtype=torch.int32)
     starts = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int32), counts[:-1]]), 0).to(torch.int32)
     T = int(counts.sum())
     Tp = T + 9                                                  # rows outside every segment
@@ -782,8 +783,26 @@ def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):
     kd = qd if self_attn else kvb.clone().cuda().requires_grad_()
     seg = (starts.cuda(), counts.cuda(), self_attn)
     out = xe.attention(qd, kd, offs[0], offs[1], offs[2], B, H, Lmax, Lmax if self_attn else R, kdiv, klen.cuda(), 0, 1, 0, None, seg)
-    assert _maxdiff(out, ref(qb, kvb)) < 1e-4 and float(out[T:].abs().max()) == 0.0
+    assert _maxdiff(out.detach(), ref(qb, kvb)) < 1e-4 and float(out.detach()[T:].abs().max()) == 0.0
     out.backward(dout.cuda())
     assert _maxdiff(qd.grad, qr.grad) < tol * max(1.0, float(qr.grad.abs().max()))
     if not self_attn:
         assert _maxdiff(kd.grad, kr.grad) < tol * max(1.0, float(kr.grad.abs().max()))
+    if mfma:
+        # dropout(p_attn) on unpadded rows: the context is linear in V, so <dO, out> == <dV, V> exactly when the backward
+        # regenerates the forward's keep mask (chunks of the backward cut across the captions the forward walks)
+        qd = qb.clone().cuda().requires_grad_()
+        kd = qd if self_attn else kvb.clone().cuda().requires_grad_()
+        xe._register_shadow(qd, qd.detach().to(torch.bfloat16))
+        if not self_attn:
+            xe._register_shadow(kd, kd.detach().to(torch.bfloat16))
+        out = xe.attention(qd, kd, offs[0], offs[1], offs[2], B, H, Lmax, Lmax if self_attn else R, kdiv, klen.cuda(), 0, 1, 0,
+                           (0.3, 777, None), seg)
+        ob = xe._shadow(out).float()
+        nodrop = ref(qb.bfloat16().float(), kvb.bfloat16().float()).cuda()
+        assert float((ob - nodrop).abs().max()) > 0.05                      # the mask did something
+        out.backward(dout.cuda())
+        vgrad = kd.grad[:, offs[2]:offs[2] + d]
+        vval = kd.detach().bfloat16().float()[:, offs[2]:offs[2] + d]
+        lhs, rhs = float((dout.cuda() * ob).sum()), float((vgrad * vval).sum())
+        assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(lhs)), (lhs, rhs)
