@@ -222,8 +222,11 @@ def main_xe(args):
             "config": {"workload": f"XE training (configs/uic_sd.yml model) batch={args.batch} images x {spi} captions per GPU, 36x2048 regions, "
                                    f"d_model=512 6 enc + 6 dec + 1 bound layer, {args.dtype}, dropout on",
                        "images_per_step_per_gpu": args.batch, "captions_per_image": spi, "vocab": cfg.tgt_vocab,
-                       "hip_graph": tr.graph, "decoder_positions_computed": batch["max_tokens"],
-                       "vocabulary_rows_computed": int(batch["token_rows"].numel()), "vocabulary_rows_dense": args.batch * spi * cfg.seq_length,
+                       "hip_graph": tr.graph, "longest_caption": batch["max_tokens"],
+                       # rows the decoder stack and the vocabulary projection run over, both branches together (list padded to a
+                       # multiple of 256), against the reference's 2 x N x seq_length
+                       "decoder_rows_computed": int(batch["pair_src"].numel()) if "pair_src" in batch else 2 * int(batch["token_rows"].numel()),
+                       "decoder_rows_dense": 2 * args.batch * spi * cfg.seq_length, "branches_share_launches": "pair_src" in batch,
                        "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
                        "sharding": "images by rank; one RCCL all-reduce over the flat fp32 gradient bucket per step"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
