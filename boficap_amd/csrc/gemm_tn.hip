@@ -28,23 +28,28 @@ struct GemmTnParams {
 
 // one 64 x 64 output tile at (i0, j0), contraction rows m_begin .. m_end - 1, added into C (and, when ``first_col``, the column
 // sums of the A tiles into colsum)
+// WT: 16-column MFMA tiles per wavefront side.  2 -> workgroup tile 64 x 64; 4 -> 128 x 128, which halves the LDS bytes read per
+// MFMA (WT + WT operand fragments feed WT * WT MFMAs): the 64 x 64 tile asks the LDS for 256 B/clk per CU, twice what it delivers.
+template <int WT>
 __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int j0, int m_begin, int m_end, bool first_col) {
-    constexpr int T = 64, TM = 64;                               // 64 contraction rows per barrier (two MFMA k-steps)
+    constexpr int T = 32 * WT, TM = 64;                          // 64 contraction rows per barrier (two MFMA k-steps)
+    constexpr int CPR = T / 8, NL = TM * CPR / 256;              // 16-byte chunks per tile row; chunks per thread and operand
     __shared__ __attribute__((aligned(16))) bf16_t sa[2][TM * T];
     __shared__ __attribute__((aligned(16))) bf16_t sb[2][TM * T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
     if (m_begin >= m_end) return;
-    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-    const int lr = tid >> 3, lc = tid & 7;                       // loader: row lr of the 32-row tile, 16-byte chunk lc
+    const int wi = (wave >> 1) * 16 * WT, wj = (wave & 1) * 16 * WT;
+    const int lr = tid / CPR, lc = tid % CPR;                    // loader: rows lr, lr + 256/CPR, ...; 16-byte chunk lc
+    constexpr int RSTEP = 256 / CPR;                             // 32 (WT 2) or 16 (WT 4): a multiple of 16, so row + RSTEP swizzles like row
     const bool a_ok = i0 + lc * 8 < p.a_cols, b_ok = j0 + lc * 8 < p.b_cols;
     const int sw = (lc ^ ((lr >> 1) & 7)) * 8;
 
-    u32x4 va[2], vb[2];
+    u32x4 va[NL], vb[NL];
     auto load = [&](int m0) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int m = m0 + lr + 32 * hh;
+        for (int hh = 0; hh < NL; ++hh) {
+            const int m = m0 + lr + RSTEP * hh;
             va[hh] = u32x4{0u, 0u, 0u, 0u};
             vb[hh] = va[hh];
             if (m < m_end) {
@@ -55,17 +60,17 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {                          // row + 32 swizzles like row
-            *reinterpret_cast<u32x4*>(&sa[buf][(lr + 32 * hh) * T + sw]) = va[hh];
-            *reinterpret_cast<u32x4*>(&sb[buf][(lr + 32 * hh) * T + sw]) = vb[hh];
+        for (int hh = 0; hh < NL; ++hh) {
+            *reinterpret_cast<u32x4*>(&sa[buf][(lr + RSTEP * hh) * T + sw]) = va[hh];
+            *reinterpret_cast<u32x4*>(&sb[buf][(lr + RSTEP * hh) * T + sw]) = vb[hh];
         }
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[WT][WT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < WT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // operand gather: lane (g, tq, tp) addresses row 4g + tq (and + 16), columns 4tp .. 4tp + 3 of a 16-column block
     const int row0 = 4 * g + tq, rsw = (row0 >> 1) & 7;           // (row0 + 16) swizzles like row0
@@ -81,7 +86,9 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
 
     // column sums of the A tiles (workgroups of the first tile column only): thread -> column tid & 63, rows (tid >> 6) * 16 .. + 15
     const bool do_colsum = p.colsum != nullptr && first_col;
-    float csum = 0.f;
+    float csum[WT / 2];
+#pragma unroll
+    for (int q = 0; q < WT / 2; ++q) csum[q] = 0.f;
     const int cc = tid & 63, crg = tid >> 6;
 
     load(m_begin);
@@ -93,23 +100,25 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
         if (more) load(m0 + TM);                                  // next tile in flight while this one is multiplied
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[WT], fb[WT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < WT; ++t) {
                 fa[t] = frag(sa[buf], wi + t * 16 + 4 * tp, sub);
                 fb[t] = frag(sb[buf], wj + t * 16 + 4 * tp, sub);
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < WT; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < WT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
         if (do_colsum) {
 #pragma unroll
-            for (int hh = 0; hh < 16; ++hh) {
-                const int r = crg * 16 + hh;
-                csum += bf16_to_f32(sa[buf][r * T + ((((cc >> 3) ^ ((r >> 1) & 7))) << 3) + (cc & 7)]);
-            }
+            for (int q = 0; q < WT / 2; ++q)
+#pragma unroll
+                for (int hh = 0; hh < 16; ++hh) {
+                    const int r = crg * 16 + hh, c = cc + 64 * q;
+                    csum[q] += bf16_to_f32(sa[buf][r * T + ((((c >> 3) ^ ((r >> 1) & 7))) << 3) + (c & 7)]);
+                }
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -117,15 +126,16 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
     }
     if (do_colsum) {                                              // combine the four row groups, one atomic per column
         float* red = reinterpret_cast<float*>(&sa[0][0]);
-        red[crg * 64 + cc] = csum;
+#pragma unroll
+        for (int q = 0; q < WT / 2; ++q) red[crg * T + cc + 64 * q] = csum[q];
         __syncthreads();
-        if (tid < 64 && i0 + tid < p.NI) atomicAdd(&p.colsum[i0 + tid], (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+        if (tid < T && i0 + tid < p.NI) atomicAdd(&p.colsum[i0 + tid], (red[tid] + red[T + tid]) + (red[2 * T + tid] + red[3 * T + tid]));
     }
     // lane holds C[i = .. + 4g + r][j = .. + l15]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < WT; ++b) {
             const int j = j0 + wj + b * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -137,7 +147,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     const int m_begin = blockIdx.z * p.m_per_block;
-    gemm_tn_tile(p, blockIdx.x * 64, blockIdx.y * 64, m_begin, min(p.M, m_begin + p.m_per_block), blockIdx.y == 0);
+    gemm_tn_tile<2>(p, blockIdx.x * 64, blockIdx.y * 64, m_begin, min(p.M, m_begin + p.m_per_block), blockIdx.y == 0);
 }
 
 // Many independent weight-gradient GEMMs in one launch.  A training step has ~126 of them (one per Linear use), each a
@@ -152,7 +162,9 @@ struct GemmTnGroup {
     int n, splits;
 };
 
+template <int WT>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const GemmTnGroup grp) {
+    constexpr int T = 32 * WT;
     const int t = blockIdx.x;
     int lo = 0, hi = grp.n - 1;
     while (lo < hi) {
@@ -160,9 +172,9 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const GemmTnGroup 
         if (grp.tile_first[mid] <= t) lo = mid; else hi = mid - 1;
     }
     const GemmTnParams& q = grp.prob[lo];
-    const int local = t - grp.tile_first[lo], tj = (q.NJ + 63) >> 6;
+    const int local = t - grp.tile_first[lo], tj = (q.NJ + T - 1) / T;
     const int m_begin = blockIdx.y * q.m_per_block;
-    gemm_tn_tile(q, (local / tj) * 64, (local % tj) * 64, m_begin, min(q.M, m_begin + q.m_per_block), local % tj == 0);
+    gemm_tn_tile<WT>(q, (local / tj) * T, (local % tj) * T, m_begin, min(q.M, m_begin + q.m_per_block), local % tj == 0);
 }
 
 static int check_tn(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, const float* c, int ldc, int M, int NI, int NJ) {
@@ -178,27 +190,35 @@ int launch_gemm_tn_grouped(int n, const void* const* a, const int* lda, const in
     if (n < 0 || (n && (!a || !lda || !a_cols || !b || !ldb || !b_cols || !c || !ldc || !M || !NI || !NJ))) return BOFI_ERR_ARG;
     for (int e = 0; e < n; ++e)
         if (int rc = check_tn(a[e], lda[e], a_cols[e], b[e], ldb[e], b_cols[e], c[e], ldc[e], M[e], NI[e], NJ[e])) return rc;
-    int e = 0;
-    while (e < n) {
-        GemmTnGroup g;
-        g.n = 0;
-        int tiles = 0, max_m = 0;
-        for (; e < n && g.n < TN_GROUP_MAX; ++e) {
-            if (M[e] == 0) continue;
-            g.prob[g.n] = GemmTnParams{static_cast<const bf16_t*>(a[e]), lda[e], a_cols[e], static_cast<const bf16_t*>(b[e]), ldb[e], b_cols[e],
-                                       c[e], ldc[e], M[e], NI[e], NJ[e], 0, colsum ? colsum[e] : nullptr};
+    static const int forced_wt = [] { const char* v = getenv("BOFI_TN_WT"); return v ? atoi(v) : 0; }();   // developer knob: 2 or 4
+    // two classes of problems: outputs of at least 128 x 128 take the 128 x 128 tile, the small ones (classifier heads) 64 x 64
+    for (int big = 1; big >= 0; --big) {
+        const int T = big ? 128 : 64;
+        int e = 0;
+        while (e < n) {
+            GemmTnGroup g;
+            g.n = 0;
+            int tiles = 0, max_m = 0;
+            for (; e < n && g.n < TN_GROUP_MAX; ++e) {
+                const bool is_big = forced_wt ? forced_wt == 4 : (NI[e] >= 128 && NJ[e] >= 128);
+                if (M[e] == 0 || is_big != (big == 1)) continue;
+                g.prob[g.n] = GemmTnParams{static_cast<const bf16_t*>(a[e]), lda[e], a_cols[e], static_cast<const bf16_t*>(b[e]), ldb[e], b_cols[e],
+                                           c[e], ldc[e], M[e], NI[e], NJ[e], 0, colsum ? colsum[e] : nullptr};
+                g.tile_first[g.n] = tiles;
+                tiles += ((NI[e] + T - 1) / T) * ((NJ[e] + T - 1) / T);
+                max_m = max(max_m, M[e]);
+                ++g.n;
+            }
+            if (!g.n) break;
             g.tile_first[g.n] = tiles;
-            tiles += ((NI[e] + 63) / 64) * ((NJ[e] + 63) / 64);
-            max_m = max(max_m, M[e]);
-            ++g.n;
+            // enough workgroups to fill the CUs (LDS: 5 / 2 workgroups per CU); a split costs one more tile of atomics per output tile
+            const int want = big ? 512 : 1280;
+            g.splits = max(1, min(min(8, (max_m + 255) / 256), (want + tiles - 1) / tiles));
+            for (int k = 0; k < g.n; ++k) g.prob[k].m_per_block = ((g.prob[k].M + g.splits - 1) / g.splits + 63) / 64 * 64;
+            if (big) hipLaunchKernelGGL(gemm_tn_grouped_kernel<4>, dim3(tiles, g.splits), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL(gemm_tn_grouped_kernel<2>, dim3(tiles, g.splits), dim3(256), 0, st, g);
+            BOFI_CHECK_LAUNCH();
         }
-        if (!g.n) break;
-        g.tile_first[g.n] = tiles;
-        // enough workgroups for ~5 per CU; a split costs one more tile of atomics per output tile
-        g.splits = max(1, min(min(8, (max_m + 255) / 256), (1280 + tiles - 1) / tiles));
-        for (int k = 0; k < g.n; ++k) g.prob[k].m_per_block = ((g.prob[k].M + g.splits - 1) / g.splits + 63) / 64 * 64;
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles, g.splits), dim3(256), 0, st, g);
-        BOFI_CHECK_LAUNCH();
     }
     return BOFI_OK;
 }

@@ -434,6 +434,8 @@ class XETrainer:
             self.ops.refresh_if_stale()
             self.ops.launch_transposes()
             xe._WEIGHTS["provider"] = self.ops
+        if self.grouped_dw:
+            xe._DEFER["list"] = []
         try:
             lp_saic, lp_naic = xe.sampled_logprobs(xe.Params(model), model.cfg, att_feats, att_masks, saic, naic, sample_n=sample_n,
                                                    strict_q1=model.strict_reference, training=model.training,
@@ -443,7 +445,9 @@ class XETrainer:
             l2, r2 = xe.new_self_critical(lp_naic, naic["seq"], s_naic, sample_n)
             loss = l1 + l2
             loss.backward()
+            xe.flush_weight_grads()
         finally:
+            xe._DEFER["list"] = None
             if armed:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()

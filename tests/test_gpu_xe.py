@@ -449,7 +449,7 @@ def test_grouped_weight_gradient_gemms(n):
     from boficap_amd import hip, xe
     g = torch.Generator().manual_seed(n)
     pad = lambda v: (v + 63) // 64 * 64
-    shapes = [(300, 70, 130), (0, 64, 64), (129, 20, 64), (1000, 128, 65), (64, 64, 192)]
+    shapes = [(300, 70, 130), (0, 64, 64), (129, 20, 64), (1000, 128, 65), (64, 64, 192), (500, 200, 130), (257, 128, 256)]   # the last two: 128 x 128 tiles
     todo, refs, targets = [], [], {}
     for e in range(n):
         M, NI, NJ = shapes[e % len(shapes)]
