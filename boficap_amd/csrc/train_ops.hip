@@ -201,7 +201,8 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* out, int M, in
 __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids, float* dlut, int rows,
                                                         int d, float scale) {
     const int r0 = blockIdx.x * 32, r1 = min(rows, r0 + 32);
-    for (int k = threadIdx.x; k < d; k += 128) {
+    // blockIdx.y: 128-column slice (a few thousand rows x d = 512 is 160 row blocks only: the column slices fill the CUs)
+    for (int k = blockIdx.y * 128 + threadIdx.x; k < d; k += 128 * gridDim.y) {
         int64_t cur = ids[r0];
         float s = 0.f;
         for (int r = r0; r < r1; ++r) {
@@ -529,7 +530,7 @@ extern "C" int bofi_colsum_add(const float* x, float* out, int M, int N, void* s
 extern "C" int bofi_embed_bwd(const float* dx, const int64_t* ids, float* dlut, int rows, int d, float scale, void* stream) {
     if (!dx || !ids || !dlut || rows < 0 || d <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 31) / 32), dim3(128), 0, (hipStream_t)stream, dx, ids, dlut, rows, d, scale);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 31) / 32, (d + 127) / 128), dim3(128), 0, (hipStream_t)stream, dx, ids, dlut, rows, d, scale);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
