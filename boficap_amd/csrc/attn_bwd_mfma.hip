@@ -105,8 +105,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (the 32 x 32 instantiation is asked to fit two wavefronts per SIMD: self-attention launches one single-wavefront workgroup per
+// caption and head, thousands of them, and at one wavefront per SIMD they run in five rounds)
 template <typename TIN, int QT, int KT, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) {
+__global__ __launch_bounds__(64 * NW, (QT == 2 && KT == 2) ? 2 : 1) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) {
     constexpr int DS = 72, PS = KT * 16 + 8;                     // padded strides (elements)
     constexpr int LQ = QT * 16, LK = KT * 16;
     constexpr int STAGE = 2 * LQ * DS + 2 * LQ * PS;             // one wavefront's private tiles: Q, dO, P, dS (elements)
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(AttnBwdMfmaParam
     // fuller than captions.  Wavefront w takes items w, w + NW, ...; dK / dV stay in registers across them.
     const int bh = blockIdx.x, bk = bh / p.H, h = bh - bk * p.H;
     const bool kr = p.q_start && p.k_ragged;                   // self-attention over unpadded rows (kdiv == 1 then)
-    const bool run = p.q_start && !p.k_ragged && p.kdiv > 1;   // cross-attention over unpadded rows: walk the image's run in chunks
+    const bool run = p.q_start && !p.k_ragged;                 // cross-attention over unpadded rows: walk the key owner's run in chunks
     const int b_first = bk * p.kdiv;
     int run0 = 0, run_rows = 0, n_items = p.kdiv;
     if (run) {
@@ -332,7 +334,7 @@ static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
     const dim3 grid((p.B / p.kdiv) * p.H);
     // several captions per key owner: two wavefronts share them
     if (p.Lq <= 32 && p.Lk <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 2, 1>), grid, dim3(64), 0, st, p);
-    else if (p.Lq <= 32 && p.kdiv > 1) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4, 2>), grid, dim3(128), 0, st, p);
+    else if ((p.Lq <= 32 && p.kdiv > 1) || (p.q_start && !p.k_ragged)) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4, 2>), grid, dim3(128), 0, st, p);
     else if (p.Lq <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4, 1>), grid, dim3(64), 0, st, p);
     else hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 4, 4, 1>), grid, dim3(64), 0, st, p);
     BOFI_CHECK_LAUNCH();
@@ -347,7 +349,7 @@ extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, in
                                        uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged,
                                        void* stream) {
     using namespace bofi;
-    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0 || B % kdiv || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || (Lq > 64 && !(q_start && !k_ragged)) || Lk > 64 || kdiv <= 0 || B % kdiv || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
     const int el = in_dtype == BOFI_DT_F32 ? 4 : 2;
     if ((ldq * el) % 16 || (ldk * el) % 16 || (ldv * el) % 16 || ldo % 4 || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16) ||

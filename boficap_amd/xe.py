@@ -655,7 +655,7 @@ def encode_memory(P, cfg, att_feats, att_len, drop):
     return P.ln(x, "model.encoder.norm")
 
 
-def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap, seg=None):
+def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap, seg=None, seg_img=None):
     """x + src_attn(n, memory, memory): the image's keys are shared by its captions (kdiv) and, because they depend
     on the memory and the layer only, by the SA and the NA pass of the same layer (kv_cache).  ``seg``: unpadded query rows
     (then ``att_len_cap`` holds one key count per ROW)."""
@@ -663,19 +663,27 @@ def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap
     q = P.lin(n, pre + ".linears.0", shadow=True)
     if pre not in kv_cache:
         kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
+    if seg is not None and seg_img is not None and _COMPUTE["dtype"] == torch.bfloat16:
+        # unpadded rows, bf16 kernels: one item per IMAGE (its captions' rows are one contiguous run) instead of one per caption --
+        # fuller 16-row tiles in the forward, and the MFMA backward walks runs in chunks anyway
+        ctx = attention(q, kv_cache[pre], 0, 0, d, B // spi, cfg.h, seg_img[2], R, 1, att_len_cap, 0, 1, 0, drop.attn(),
+                        (seg_img[0], seg_img[1], False) + tuple(seg[2:3]))
+        return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
     sb = 0 if seg is not None else (1 if att_len_cap is not None else 0)
     ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, sb, (1 if seg is not None else 0), 0, drop.attn(),
                     None if seg is None else (seg[0], seg[1], False) + tuple(seg[2:3]))
     return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
-def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap, out_gemm_only=True, seg=None):
+def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_len_cap, out_gemm_only=True, seg=None, seg_img=None):
     """Decoder stack + final norm (TransformerModel.py:1386-1413) over N captions x S positions; self-attention
     row (n, i) sees keys < klen_self[n, i].  ``out_gemm_only`` False: the output is also read outside a GEMM (row gather).
 
     ``seg`` = (row_start int32 [N], row_count int32 [N]): ``x`` holds the captions' REAL positions only, caption n in rows
     row_start[n] .. +row_count[n] (rows past the last caption are padding nobody attends to); klen_self / att_len_cap are then
-    per row.  Every other op of the stack is row-wise, so only the two attentions know about the layout."""
+    per row.  Every other op of the stack is row-wise, so only the two attentions know about the layout.
+    ``seg_img`` = (row_start int32 [images], row_count int32 [images], max rows of an image): the same rows grouped per image,
+    for the cross-attention (see _cross)."""
     d = cfg.d_model
     for l in range(cfg.N_dec):
         p = f"model.decoder.layers.{l}"
@@ -687,7 +695,7 @@ def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_
             ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, 0, 1, 0, drop.attn(), (seg[0], seg[1], True) + tuple(seg[2:3]))
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
         xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
-        x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap, seg)
+        x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap, seg, seg_img)
         xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
         x = _ffn(P, p + ".feed_forward", drop, n_, xr)
     return P.ln(x, "model.decoder.norm", gemm_only=out_gemm_only)
@@ -950,7 +958,9 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
         klen2 = torch.where(pair_na, klen_na[pair_src], klen_sa[pair_src]).contiguous()
         cross2 = None if cross_len is None else cross_len[pair_src].contiguous()
     seg2 = (pair_start, pair_count) + tuple(paired[4:5])
-    x = decode_rows(P, cfg, drop, emb(tok2, syn2, Sd, pos2), memory, kv_cache, 2 * N, Sd, R, 2 * spi, klen2, cross2, True, seg2)
+    with torch.no_grad():                                         # the same rows per image: its 2 spi captions are adjacent
+        img = (pair_start.view(-1, 2 * spi)[:, 0].contiguous(), pair_count.view(-1, 2 * spi).sum(1).to(torch.int32).contiguous(), 2 * spi * Sd)
+    x = decode_rows(P, cfg, drop, emb(tok2, syn2, Sd, pos2), memory, kv_cache, 2 * N, Sd, R, 2 * spi, klen2, cross2, True, seg2, img)
     tok_all = log_softmax(vocab(x))
     return pad_slots(sa_len), pad_slots(sa_syn), tok_all, pad_slots(na_len), pad_slots(na_syn), tok_all
 

@@ -734,7 +734,7 @@ def test_bucket_weight_operands_match_per_use_casts(weight_cache, manifest):
 
 
 @pytest.mark.parametrize("mfma", [False, True])
-@pytest.mark.parametrize("kdiv,self_attn", [(1, True), (2, False), (3, False), (6, False)])
+@pytest.mark.parametrize("kdiv,self_attn", [(1, True), (2, False), (3, False), (6, False), (1, False)])
 def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):
     """q_start / q_count (variable rows per caption, padding rows at the end of the list) through the forward and both
     backward kernels: self-attention over each caption's own rows, cross-attention to the image's dense keys.  kdiv 3 and 6:
@@ -743,6 +743,10 @@ def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):
     H, d, B, Lmax, R = 2, 128, 6, 20, 36
     g = torch.Generator().manual_seed(31 + kdiv)
     counts = torch.tensor([5, 20, 1, 0, 13, 8] if kdiv < 3 else [16, 20, 19, 7, 0, 20], dtype=torch.int32)
+    if kdiv == 1 and not self_attn:                             # one item per key owner with more rows than a chunk (image-level lists)
+        if not mfma:
+            pytest.skip("the float32 VALU backward takes caption-sized items")
+        counts, Lmax = torch.tensor([40, 20, 1, 0, 50, 8], dtype=torch.int32), 64
     starts = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int32), counts[:-1]]), 0).to(torch.int32)
     T = int(counts.sum())
     Tp = T + 9                                                  # rows outside every segment
