@@ -8,6 +8,7 @@ import torch
 from boficap_amd import hip as H
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+BIG = len(sys.argv) > 2 and sys.argv[2] == "big"      # compute-bound shapes: what the inner loop sustains without the latency of short K
 SHAPES = [("cross K|V of all layers", 2304, 7168, 512), ("encoder FFN w_1", 2304, 2048, 512), ("encoder FFN w_2", 2304, 512, 2048),
           ("generator.proj", 1280, 9491, 512), ("att_embed", 2304, 512, 2048), ("q|k|v self", 2304, 1536, 512),
           ("XE decoder rows w_1", 2560, 2048, 512), ("XE vocabulary rows", 2560, 9491, 512)]
@@ -26,6 +27,8 @@ def timed(fn):
     return a.elapsed_time(b) * 1e3 / iters
 
 
+if BIG:
+    SHAPES = [("square", 4096, 4096, 4096), ("wide, short K", 8192, 8192, 512), ("path rows, long K", 2304, 7168, 4096), ("square 8k", 8192, 8192, 8192)]
 out = []
 for name, M, N, K in SHAPES:
     x = torch.randn(M, K, device="cuda").bfloat16()
