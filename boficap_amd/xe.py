@@ -715,8 +715,10 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     kv = P.lin_packed(n_all, p + ".self_attn", (1, 2))
     x0 = x_in.view(N, L, d)[:, 0, :]
     n0 = n_all.view(N, L, d)[:, 0, :].contiguous()
-    q0 = P.lin(n0, p + ".self_attn.linears.0")
+    q0 = P.lin(n0, p + ".self_attn.linears.0", shadow=True)
     qv = q0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
+    if _shadow(q0) is not None:                                 # bf16 mode: the virtual queries' bf16 copy, so that the bf16 / MFMA attention kernels run
+        _register_shadow(qv, _shadow(q0).unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d))
     xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
     ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0, drop.attn())
     x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xv)
