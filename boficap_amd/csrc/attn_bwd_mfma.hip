@@ -22,7 +22,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct AttnBwdMfmaParams {
     const void* q; int ldq; const void* k; int ldk; const void* v; int ldv;
     const float* dout; int ldo;
-    float* dq; int lddq; float* dk; float* dv; int lddk;
+    void* dq; int lddq; void* dk; void* dv; int lddk;          // float32, or bf16 where dq_bf16 / dkv_bf16 (then they feed a GEMM directly)
+    int dq_bf16, dkv_bf16;
     int B, H, Lq, Lk, kdiv;
     const int* klen; int klen_sb, klen_sq, klen_bias;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;     // dropout(p_attn) of the forward
@@ -269,7 +270,11 @@ __global__ __launch_bounds__(64 * NW, (QT == 2 && KT == 2) ? 2 : 1) void attn_bw
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qrow = qt * 16 + 4 * g + r;
-                    if (qrow < Lq_c) p.dq[(qrow_c + qrow) * p.lddq + h * 64 + dt * 16 + l15] = acc[dt][r];
+                    if (qrow < Lq_c) {
+                        const size_t o = (qrow_c + qrow) * p.lddq + h * 64 + dt * 16 + l15;
+                        if (p.dq_bf16) static_cast<bf16_t*>(p.dq)[o] = f32_to_bf16(acc[dt][r]);
+                        else static_cast<float*>(p.dq)[o] = acc[dt][r];
+                    }
                 }
         }
         // ---- dK += dS^T Q, dV += P^T dO
@@ -324,8 +329,13 @@ __global__ __launch_bounds__(64 * NW, (QT == 2 && KT == 2) ? 2 : 1) void attn_bw
                 const int krow = kt * 16 + 4 * g + r;
                 if (krow >= Lk) continue;
                 const size_t o = (krow0 + krow) * p.lddk + h * 64 + dt * 16 + l15;
-                p.dk[o] = ak[kt][dt][r];
-                p.dv[o] = av[kt][dt][r];
+                if (p.dkv_bf16) {
+                    static_cast<bf16_t*>(p.dk)[o] = f32_to_bf16(ak[kt][dt][r]);
+                    static_cast<bf16_t*>(p.dv)[o] = f32_to_bf16(av[kt][dt][r]);
+                } else {
+                    static_cast<float*>(p.dk)[o] = ak[kt][dt][r];
+                    static_cast<float*>(p.dv)[o] = av[kt][dt][r];
+                }
             }
 }
 
@@ -344,19 +354,21 @@ static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
 }  // namespace bofi
 
 extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
-                                       const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H, int Lq,
-                                       int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, float drop_p,
-                                       uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged,
-                                       void* stream) {
+                                       const float* dout, int ldo, void* dq, int lddq, void* dk, void* dv, int lddk, int dq_dtype, int dkv_dtype,
+                                       int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias,
+                                       float drop_p, uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count,
+                                       int k_ragged, void* stream) {
     using namespace bofi;
     if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || (Lq > 64 && !(q_start && !k_ragged)) || Lk > 64 || kdiv <= 0 || B % kdiv || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
+    if ((dq_dtype != BOFI_DT_F32 && dq_dtype != BOFI_DT_BF16) || (dkv_dtype != BOFI_DT_F32 && dkv_dtype != BOFI_DT_BF16)) return BOFI_ERR_ARG;
     const int el = in_dtype == BOFI_DT_F32 ? 4 : 2;
     if ((ldq * el) % 16 || (ldk * el) % 16 || (ldv * el) % 16 || ldo % 4 || ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16) ||
         ((uintptr_t)dout % 16))
         return BOFI_ERR_ARG;
     if (B == 0) return BOFI_OK;
-    AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias,
+    AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, dq_dtype == BOFI_DT_BF16, dkv_dtype == BOFI_DT_BF16,
+                        B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias,
                         0u, 1.f, drop_seed, drop_step, q_start, q_count, k_ragged};
     if ((q_start != nullptr) != (q_count != nullptr) || (k_ragged && kdiv != 1)) return BOFI_ERR_ARG;
     if (drop_p > 0.f) { p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_scale = 1.0f / (1.0f - drop_p); }

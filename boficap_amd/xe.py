@@ -139,8 +139,8 @@ def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     if dt == torch.float32 and Np == N:
         return x, Np
     key = ("op", x.data_ptr(), M, N, dt)
-    hit = _STEP_CACHE.get(key) if (cache and colsum is None) else None
-    if hit is not None:
+    hit = _STEP_CACHE.get(key) if (colsum is None and (cache or (relu_y is None and drop is None))) else None
+    if hit is not None and (cache or hit[0] is x):             # (a gradient's bf16 copy made by its producer: same tensor object only)
         return hit[1], Np
     if _WEIGHTS["provider"] is not None and dt == torch.bfloat16 and cache and colsum is None and relu_y is None and drop is None:
         y = _WEIGHTS["provider"].operand(x, M, N)
@@ -250,7 +250,11 @@ class LinearFn(Function):
             # dW = dz^T x runs on the transposing-read GEMM straight from the row-major operands
             # ReLU and dropout masks are applied inside the cast (a dropped ReLU unit has y == 0: the ReLU test covers it)
             # the bias gradient (column sums of dz) is taken by the weight-gradient GEMM from its A tiles
-            dzo, Np = _operand(dy, M, N, dt, cache=False, colsum=None if want_w else bsum, relu_y=y if ctx.relu else None, drop=ctx.drop)
+            cast_sum = None if want_w else bsum
+            if cast_sum is not None and _shadow(dy) is not None:   # dy is a placeholder for a bf16 gradient (attention backward): its
+                cast_sum.add_(_shadow(dy).float().sum(0)[:N])      # column sums come from that copy (frozen weight, trainable bias: rare)
+                cast_sum = None
+            dzo, Np = _operand(dy, M, N, dt, cache=False, colsum=cast_sum, relu_y=y if ctx.relu else None, drop=ctx.drop)
             if ctx.needs_input_grad[0]:
                 wt, _ = _transposed(w, N, K, dt)       # [K, Np], once per weight per step
                 dx = _empty(x, M, K)
@@ -362,7 +366,7 @@ class AttentionFn(Function):
     qbuf may be the same tensor as kvbuf (packed q|k|v of a self-attention)."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop, seg):
+    def forward(ctx, qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop, seg, grad_bf16=False):
         qbuf, kvbuf = _need(qbuf, "attention q"), _need(kvbuf, "attention kv")
         # seg = (q_start int32 [B], q_count int32 [B], k_ragged): unpadded rows (see bofi_attention_ex); sizes are then the caller's business
         if seg is None and (qbuf.shape[0] != B * Lq or kvbuf.shape[0] * kdiv != B * Lk):
@@ -403,6 +407,7 @@ class AttentionFn(Function):
         ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
         ctx.mfma = bf16                                        # bf16 mode: backward on the matrix cores
         ctx.seg = seg
+        ctx.grad_bf16 = bool(grad_bf16)
         ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
         ctx.klen = klen
         return out
@@ -418,30 +423,43 @@ class AttentionFn(Function):
         sp = (hip.ptr(ctx.seg[0]), hip.ptr(ctx.seg[1]), int(bool(ctx.seg[2]))) if ctx.seg is not None else (None, None, 0)
         alloc = torch.empty if covered else torch.zeros
         tail = ctx.seg[3] if ctx.seg is not None and len(ctx.seg) > 3 else None
-        if ctx.seg is not None and ctx.mfma and tail is not None and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64)):
+        fits = (ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64)
+        # grad_bf16: q (and, for a packed self-attention, k and v) come straight from a projection GEMM whose backward wants
+        # its dz in bf16 anyway -- the MFMA kernel writes that, and autograd gets an unfilled float32 placeholder carrying it
+        qb16 = ctx.mfma and ctx.grad_bf16 and fits and (ctx.seg is None or tail is not None)
+        if qb16:
+            dq = torch.empty(qbuf.shape, dtype=torch.float32, device=qbuf.device)
+            dq_out = _rows_alloc(qbuf.shape, torch.bfloat16, qbuf.device, ctx.seg is not None, tail)
+            _register_shadow(dq, dq_out)
+            dkv = dq if ctx.same else torch.empty(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
+        elif ctx.seg is not None and ctx.mfma and tail is not None and fits:
             # unpadded rows: the kernel writes every caption's rows; only the rows behind the last caption need zeros
-            dq = _rows_alloc(qbuf.shape, torch.float32, qbuf.device, True, tail)
+            dq = dq_out = _rows_alloc(qbuf.shape, torch.float32, qbuf.device, True, tail)
             dkv = dq if ctx.same else torch.empty(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         else:
-            dq = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
+            dq = dq_out = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
             dkv = dq if ctx.same else alloc(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         if ctx.mfma:
+            F32c, B16c = F32, hip.DT_BF16
+            kv_out = dq_out if ctx.same else dkv
             _chk(_lib().bofi_attention_bwd_mfma(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.dtype_code(qbuf),
-                                                hip.ptr(dout), H * 64, _off(dq, qoff), ldq, _off(dkv, koff), _off(dkv, voff), ldk, B, H, Lq, Lk,
+                                                hip.ptr(dout), H * 64, _off(dq_out, qoff), ldq, _off(kv_out, koff), _off(kv_out, voff), ldk,
+                                                B16c if qb16 else F32c, B16c if (qb16 and ctx.same) else F32c, B, H, Lq, Lk,
                                                 kdiv, hip.ptr(ctx.klen), sb, sq, bias, ctx.drop[0] if ctx.drop else 0.0,
                                                 ctx.drop[1] if ctx.drop else 0, hip.ptr(ctx.drop[2]) if ctx.drop else None, sp[0], sp[1], sp[2],
                                                 hip.stream_ptr()), "bofi_attention_bwd_mfma")
-            return (dq, None if ctx.same else dkv) + (None,) * 14
+            return (dq, None if ctx.same else dkv) + (None,) * 15
         _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
                                        _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,
                                        sp[0], sp[1], sp[2], hip.stream_ptr()), "bofi_attention_bwd")
-        return (dq, None if ctx.same else dkv) + (None,) * 14
+        return (dq, None if ctx.same else dkv) + (None,) * 15
 
 
-def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0, drop=None, seg=None):
+def attention(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv=1, klen=None, klen_sb=0, klen_sq=0, klen_bias=0, drop=None, seg=None,
+              grad_bf16=False):
     """``drop``: (p, seed, step word) dropout on the attention probabilities (TransformerModel.py:1430-1431); applied by the bf16
     kernels (bf16 training mode with bf16 projections at hand), ignored by the float32 parity kernels."""
-    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop, seg)
+    return AttentionFn.apply(qbuf, kvbuf, qoff, koff, voff, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, drop, seg, grad_bf16)
 
 
 class EmbedFn(Function):
@@ -648,14 +666,14 @@ def encode_memory(P, cfg, att_feats, att_len, drop):
         p = f"model.encoder.layers.{l}"
         xr, n = P.ln_res(x, p + ".sublayer.0.norm")
         qkv = P.lin_packed(n, p + ".self_attn", (0, 1, 2))
-        ctx = attention(qkv, qkv, 0, d, 2 * d, B, cfg.h, R, R, 1, att_len, sb, 0, 0, drop.attn())
+        ctx = attention(qkv, qkv, 0, d, 2 * d, B, cfg.h, R, R, 1, att_len, sb, 0, 0, drop.attn(), None, True)
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
         xr, n = P.ln_res(x, p + ".sublayer.1.norm")
         x = _ffn(P, p + ".feed_forward", drop, n, xr)
     return P.ln(x, "model.encoder.norm")
 
 
-def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap, seg=None, seg_img=None):
+def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap, seg=None, seg_img=None, grad_bf16=True):
     """x + src_attn(n, memory, memory): the image's keys are shared by its captions (kdiv) and, because they depend
     on the memory and the layer only, by the SA and the NA pass of the same layer (kv_cache).  ``seg``: unpadded query rows
     (then ``att_len_cap`` holds one key count per ROW)."""
@@ -667,11 +685,11 @@ def _cross(P, pre, cfg, drop, n, x, memory, kv_cache, B, Lq, R, spi, att_len_cap
         # unpadded rows, bf16 kernels: one item per IMAGE (its captions' rows are one contiguous run) instead of one per caption --
         # fuller 16-row tiles in the forward, and the MFMA backward walks runs in chunks anyway
         ctx = attention(q, kv_cache[pre], 0, 0, d, B // spi, cfg.h, seg_img[2], R, 1, att_len_cap, 0, 1, 0, drop.attn(),
-                        (seg_img[0], seg_img[1], False) + tuple(seg[2:3]))
+                        (seg_img[0], seg_img[1], False) + tuple(seg[2:3]), True)
         return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
     sb = 0 if seg is not None else (1 if att_len_cap is not None else 0)
     ctx = attention(q, kv_cache[pre], 0, 0, d, B, cfg.h, Lq, R, spi, att_len_cap, sb, (1 if seg is not None else 0), 0, drop.attn(),
-                    None if seg is None else (seg[0], seg[1], False) + tuple(seg[2:3]))
+                    None if seg is None else (seg[0], seg[1], False) + tuple(seg[2:3]), grad_bf16)
     return _sublayer_linear(P, drop, ctx, pre + ".linears.3", x)
 
 
@@ -690,9 +708,9 @@ def decode_rows(P, cfg, drop, x, memory, kv_cache, N, S, R, spi, klen_self, att_
         xr, n_ = P.ln_res(x, p + ".sublayer.0.norm")
         qkv = P.lin_packed(n_, p + ".self_attn", (0, 1, 2))
         if seg is None:
-            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn())
+            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, S, 1, 0, drop.attn(), None, True)
         else:
-            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, 0, 1, 0, drop.attn(), (seg[0], seg[1], True) + tuple(seg[2:3]))
+            ctx = attention(qkv, qkv, 0, d, 2 * d, N, cfg.h, S, S, 1, klen_self, 0, 1, 0, drop.attn(), (seg[0], seg[1], True) + tuple(seg[2:3]), True)
         x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
         xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
         x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, N, S, R, spi, att_len_cap, seg, seg_img)

@@ -103,20 +103,23 @@ int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void
  * connection, so that the sum of the two branches costs no extra pass); dgain, dbias [d] accumulated */
 int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain,
                        float* dbias, int rows, int d, void* stream);
-/* backward of bofi_attention_ex (Lq, Lk <= 64): dq like q, dk/dv like k/v (accumulated when kdiv > 1) */
+/* backward of bofi_attention_ex (Lq, Lk <= 64): dq like q, dk/dv like k/v (accumulated when kdiv > 1); q_start / q_count /
+ * k_ragged as in bofi_attention_ex */
 int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                        const float* dout, int ldo, float* dq, float* dk, float* dv, int B, int H, int Lq,
                        int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias,
-                       void* stream);
+                       const int* q_start, const int* q_count, int k_ragged, void* stream);
 /* the same backward on the matrix cores: q/k/v float32 or bf16 (in_dtype), products in bf16 with fp32 accumulation,
- * operands gathered with transposing LDS reads; dq row stride lddq, dk/dv row stride lddk (float32), WRITTEN (not
- * accumulated) also when kdiv > 1: one wavefront owns an (image, head) and sums over its captions in registers;
+ * operands gathered with transposing LDS reads; dq row stride lddq, dk/dv row stride lddk, float32 or bf16 (dq_dtype /
+ * dkv_dtype: bf16 when the gradient feeds a GEMM directly), WRITTEN (not accumulated) also when kdiv > 1: one workgroup owns
+ * an (image, head) and sums over its captions in registers / LDS; Lq <= 64 unless q_start is given with k_ragged == 0 (then
+ * the key owner's rows are one contiguous run walked in chunks and Lq is only an upper bound);
  * drop_*: the dropout of the forward's attention probabilities, regenerated from the same (seed, index) */
 int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int in_dtype,
-                            const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddk, int B, int H,
-                            int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias, float drop_p,
-                            uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged,
-                            void* stream);
+                            const float* dout, int ldo, void* dq, int lddq, void* dk, void* dv, int lddk, int dq_dtype,
+                            int dkv_dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq,
+                            int klen_bias, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, const int* q_start,
+                            const int* q_count, int k_ragged, void* stream);
 /* backward of log_softmax given the log-probabilities y: dx = dy - exp(y) * rowsum(dy) */
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */

@@ -69,6 +69,12 @@ def test_cabi_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(bofi_[a-z0-9_]+)\s*\(", header))
     declared -= {"bofi_engine", "bofi_config"}
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    # ... and on the number of parameters of every entry point (the header is what a maintainer binds against)
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, params in re.findall(r"\b(bofi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", code, flags=re.S):
+        if name in hip.SIGNATURES:
+            n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+            assert n == len(hip.SIGNATURES[name][1]), (name, n, len(hip.SIGNATURES[name][1]))
     if not os.path.exists(hip.LIB_PATH):
         from boficap_amd.build import build
         build(verbose=False)
