@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 template <int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                           const float* __restrict__ dy, float* __restrict__ dx, float* dgain,
-                                                          float* dbias, int rows, int rows_per_block, const float* __restrict__ add) {
+                                                          float* dbias, int rows, int rows_per_block, const float* __restrict__ add,
+                                                          bf16_t* __restrict__ dz, uint32_t drop_thresh, float drop_scale, uint64_t drop_seed0,
+                                                          const uint64_t* drop_step) {
     constexpr int d = NJ * 64;
     __shared__ float red[2][4][d];
+    const uint64_t drop_seed = drop_seed0 + ((dz && drop_thresh && drop_step) ? *drop_step : 0ull);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[NJ], dg[NJ], db[NJ];
 #pragma unroll
@@ -74,7 +77,12 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
         m = wave_sum(m) / (float)d;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            dx[(size_t)row * d + lane + 64 * j] = t[j] - m + av[j];
+            const size_t o = (size_t)row * d + lane + 64 * j;
+            const float v = t[j] - m + av[j];
+            dx[o] = v;
+            // dz: the same gradient with the dropout mask of the linear that PRODUCED x applied, in bf16 -- what that linear's
+            // backward GEMMs read (x = residual + dropout(h W^T + b): d/dh = mask o d/dx)
+            if (dz) dz[o] = f32_to_bf16((!drop_thresh || drop_hash(drop_seed, o) >= drop_thresh) ? v * drop_scale : 0.f);
             dg[j] += dv[j] * xv[j] * inv;
             db[j] += dv[j];
         }
@@ -484,13 +492,26 @@ extern "C" int bofi_relu_bwd(const float* y, const float* dy, float* dx, int64_t
     return BOFI_OK;
 }
 
+extern "C" int bofi_layernorm_bwd_ex(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain, float* dbias,
+                                     int rows, int d, void* dz_bf16, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* stream);
+
 extern "C" int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain, float* dbias,
                                   int rows, int d, void* stream) {
     if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
+    return bofi_layernorm_bwd_ex(x, gain, dy, add, dx, dgain, dbias, rows, d, nullptr, 0.f, 0, nullptr, stream);
+}
+
+extern "C" int bofi_layernorm_bwd_ex(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain, float* dbias,
+                                     int rows, int d, void* dz_bf16, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* stream) {
+    if (!x || !gain || !dy || !dx || !dgain || !dbias || rows < 0 || d <= 1 || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
+    if (dz_bf16 && d != 512 && d != 128) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    const float scale = 1.0f / (1.0f - drop_p);
     const int rpb = rows >= 4096 ? 32 : 8;                 // the per-column atomics of a workgroup cost more than the lost occupancy
-    if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb, add);
-    else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb, add);
+    if (d == 512) hipLaunchKernelGGL((ln_bwd_rows_kernel<8>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb, add, (bf16_t*)dz_bf16, thresh, scale, drop_seed, drop_step);
+    else if (d == 128) hipLaunchKernelGGL((ln_bwd_rows_kernel<2>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, rpb, add, (bf16_t*)dz_bf16, thresh, scale, drop_seed, drop_step);
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gain, dy, dx, dgain, dbias, rows, d, add);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;

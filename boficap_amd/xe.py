@@ -142,6 +142,10 @@ def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     hit = _STEP_CACHE.get(key) if (colsum is None and (cache or (relu_y is None and drop is None))) else None
     if hit is not None and (cache or hit[0] is x):             # (a gradient's bf16 copy made by its producer: same tensor object only)
         return hit[1], Np
+    if drop is not None and relu_y is None and colsum is None and not cache and dt == torch.bfloat16 and Np == N:
+        g = _STEP_CACHE.get(("gop", x.data_ptr()))              # dz made by the producer of this gradient, mask already applied
+        if g is not None and g[0] is x and g[2][0] == drop[0] and g[2][1] == drop[1] and g[2][2] is drop[2]:
+            return g[1], Np
     if _WEIGHTS["provider"] is not None and dt == torch.bfloat16 and cache and colsum is None and relu_y is None and drop is None:
         y = _WEIGHTS["provider"].operand(x, M, N)
         if y is not None:
@@ -216,6 +220,10 @@ class LinearFn(Function):
             _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg, drop, y2)
             if y2 is not None:
                 _register_shadow(y, y2)
+            if drop is not None and residual is not None and not relu:
+                # y = residual + dropout(x w^T + b): whoever computes dL/dy next (the LayerNorm that reads y) can hand this node
+                # its dz = mask o dL/dy in bf16 right away (LayerNormFn.backward)
+                _STEP_CACHE[("prod", y.data_ptr())] = (y, drop)
         ctx.relu, ctx.dt, ctx.drop = bool(relu), dt, drop
         ctx.has_b, ctx.has_r = b is not None, residual is not None
         ctx.gw, ctx.gb = gw, gb
@@ -313,6 +321,8 @@ class LayerNormFn(Function):
         else:
             _chk(_lib().bofi_layernorm(hip.ptr(x), hip.ptr(gain), hip.ptr(bias), hip.ptr(y), F32, rows, d, hip.stream_ptr()), "bofi_layernorm")
         ctx.gg, ctx.gb = gg, gb
+        prod = _STEP_CACHE.get(("prod", x.data_ptr()))
+        ctx.prod_drop = prod[1] if (prod is not None and prod[0] is x and _COMPUTE["dtype"] == torch.bfloat16 and d in (512, 128)) else None
         ctx.set_materialize_grads(False)                       # an unused output gets None, not a zero tensor
         ctx.save_for_backward(x, gain)
         return x.view_as(x), y
@@ -328,8 +338,16 @@ class LayerNormFn(Function):
         direct = ctx.gg is not None and ctx.gb is not None
         dx = torch.empty_like(x)
         dg, db = (ctx.gg, ctx.gb) if direct else (_zeros(x, d), _zeros(x, d))
-        _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(add), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
-                                       hip.stream_ptr()), "bofi_layernorm_bwd")
+        pd = ctx.prod_drop
+        if pd is not None:
+            # x came out of a linear with epilogue dropout: also write that linear's dz (mask applied, bf16)
+            dz = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device)
+            _chk(_lib().bofi_layernorm_bwd_ex(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(add), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
+                                              hip.ptr(dz), pd[0], pd[1], hip.ptr(pd[2]), hip.stream_ptr()), "bofi_layernorm_bwd_ex")
+            _STEP_CACHE[("gop", dx.data_ptr())] = (dx, dz, pd)
+        else:
+            _chk(_lib().bofi_layernorm_bwd(hip.ptr(x), hip.ptr(gain), hip.ptr(dy), hip.ptr(add), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), rows, d,
+                                           hip.stream_ptr()), "bofi_layernorm_bwd")
         return (dx, None, None, None, None, None) if direct else (dx, dg, db, None, None, None)
 
 

@@ -103,6 +103,12 @@ int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void
  * connection, so that the sum of the two branches costs no extra pass); dgain, dbias [d] accumulated */
 int bofi_layernorm_bwd(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain,
                        float* dbias, int rows, int d, void* stream);
+/* the same, additionally writing dz_bf16 [rows, d] (d = 512 or 128; may be NULL) = bf16(keep(dx) / (1 - drop_p)) with the
+ * dropout mask of bofi_linear_ex(drop_p, drop_seed, drop_step) over [rows, d]: when x = residual + dropout(h W^T + b) came out of
+ * that linear's epilogue, dz is the gradient its backward GEMMs read, and the separate mask-and-cast pass is not needed */
+int bofi_layernorm_bwd_ex(const float* x, const float* gain, const float* dy, const float* add, float* dx, float* dgain,
+                          float* dbias, int rows, int d, void* dz_bf16, float drop_p, uint64_t drop_seed,
+                          const uint64_t* drop_step, void* stream);
 /* backward of bofi_attention_ex (Lq, Lk <= 64): dq like q, dk/dv like k/v (accumulated when kdiv > 1); q_start / q_count /
  * k_ragged as in bofi_attention_ex */
 int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,

@@ -442,6 +442,32 @@ def test_gemm_tn_accumulates_a_transposed_times_b(M, NI, NJ):
                                              None, hip.stream_ptr()))
 
 
+def test_layernorm_backward_hands_the_masked_gradient_to_its_producer():
+    """x = r + dropout(x0 W^T + b) in the GEMM epilogue, n = LayerNorm(x): the LayerNorm backward also writes the linear's
+    dz = mask o dL/dx in bf16 (bofi_layernorm_bwd_ex), which must be the dz the mask-and-cast pass would have made --
+    same weight, bias and input gradients with and without the hand-over."""
+    from boficap_amd import xe
+    M, d, K = 200, 512, 128
+    g = torch.Generator().manual_seed(12)
+    x0, w, b = torch.randn(M, K, generator=g), torch.randn(d, K, generator=g) * 0.1, torch.randn(d, generator=g)
+    r, gain, beta, gout = torch.randn(M, d, generator=g), torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g), torch.randn(M, d, generator=g)
+    grads = []
+    for hand_over in (True, False):
+        xe._COMPUTE["dtype"] = torch.bfloat16
+        xe._STEP_CACHE.clear(); xe._SHADOW_ONLY.clear()
+        t = [v.clone().cuda().requires_grad_() for v in (x0, w, b, r, gain, beta)]
+        x = xe.linear(t[0], t[1], t[2], residual=t[3], drop=(0.3, 4711, None))
+        if not hand_over:
+            for k in [k for k in xe._STEP_CACHE if k[0] == "prod"]:
+                del xe._STEP_CACHE[k]
+        xr, n = xe.layer_norm_res(x, t[4], t[5])
+        ((n * gout.cuda()).sum() + (xr * 0.5).sum()).backward()
+        assert any(k[0] == "gop" for k in xe._STEP_CACHE) == hand_over
+        grads.append([v.grad.clone() for v in t])
+    for a, c in zip(*grads):
+        assert _maxdiff(a, c) <= 1e-5 * max(1.0, float(c.abs().max()))
+
+
 @pytest.mark.parametrize("n", [3, 45])
 def test_grouped_weight_gradient_gemms(n):
     """bofi_gemm_tn_grouped: n problems of mixed sizes (ragged tiles, empty row sets, two problems adding into the same
