@@ -36,6 +36,9 @@ struct LinearArgs {
     // training: y = residual + keep(act(x w^T + bias)) / (1 - p), keep = drop_hash(drop_seed, m * N + n) >= drop_thresh (0: off)
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
     const uint64_t* drop_step;    // device word added to drop_seed when set (a captured graph replays with fresh masks)
+    // training backward through relu (+ dropout): != 0 turns `residual` into a MASK -- y = residual > 0 ? (x w^T) * mask_scale : 0
+    // (residual = the forward activation: a dropped or clipped unit is 0 there; mask_scale = 1 / (1 - p))
+    float mask_scale;
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
 int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible

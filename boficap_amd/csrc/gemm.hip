@@ -292,7 +292,7 @@ int launch_linear(const LinearArgs& a, hipStream_t st) {
         const int rc = launch_linear_glds(a, st);          // operands already in the compute dtype: LDS-DMA kernel
         if (rc >= 0) return rc;
     }
-    if (a.ln_stats || a.stats_out || a.y2 || a.splitk > 1 || a.drop_thresh) return BOFI_ERR_ARG;     // only the LDS-DMA kernel implements these
+    if (a.ln_stats || a.stats_out || a.y2 || a.splitk > 1 || a.drop_thresh || a.mask_scale != 0.f) return BOFI_ERR_ARG;     // only the LDS-DMA kernel implements these
     const bool ln = a.ln_gain != nullptr;
     if (ln && (a.x_dtype != BOFI_DT_F32 || !a.ln_bias || a.K % 8)) return BOFI_ERR_ARG;
     GemmParams p;
@@ -316,6 +316,15 @@ extern "C" int bofi_linear(const void* x, int x_dtype, int ldx, const void* w, i
     a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = w; a.w_dtype = w_dtype; a.bias = bias;
     a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.M = M; a.N = N; a.K = K;
     a.relu = relu; a.row_len = row_len; a.rows_per_group = rows_per_group;
+    return bofi::launch_linear(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_linear_masked(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* mask, int ldm, float scale, void* y,
+                                  int y_dtype, int ldy, int M, int N, int K, void* stream) {
+    if (!mask || !(scale > 0.f)) return BOFI_ERR_ARG;
+    bofi::LinearArgs a{};
+    a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = w; a.w_dtype = w_dtype;
+    a.residual = mask; a.ldr = ldm; a.mask_scale = scale; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.M = M; a.N = N; a.K = K;
     return bofi::launch_linear(a, (hipStream_t)stream);
 }
 

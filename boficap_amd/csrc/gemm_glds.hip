@@ -61,15 +61,16 @@ struct Gemm2Params {
     int vec_ok;               // N, ldy, ldr multiples of 4 and y/bias/residual 16-byte aligned
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;     // training dropout on act(..) before the residual (0: off)
     const uint64_t* drop_step;
+    float mask_scale;         // != 0: residual is a mask (see LinearArgs)
     int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // FEAT: the optional parts of the epilogue / control this instantiation carries (bit 0: folded LayerNorm in, 1: row statistics
-// and compute-dtype copy out, 2: padded-row zeroing, 3: dropout, 4: early-out word and developer ablations).  A specialisation
+// and compute-dtype copy out, 2: padded-row zeroing, 3: dropout, 4: early-out word and developer ablations, 5: residual-as-mask).  A specialisation
 // drops the kernel arguments of the parts it does not carry, which is what matters: the full kernel spills scalar registers.
-constexpr int FEAT_ALL = 31;
+constexpr int FEAT_ALL = 63;
 template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2, int FEAT = FEAT_ALL>     // WM x WN wavefronts, each owns (BM/WM) x (BN/WN)
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) {
     if constexpr (!(FEAT & 1)) { p.ln_stats = nullptr; p.ln_colsum = nullptr; }
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     if constexpr (!(FEAT & 4)) { p.row_len = nullptr; }
     if constexpr (!(FEAT & 8)) { p.drop_thresh = 0; p.drop_step = nullptr; }
     if constexpr (!(FEAT & 16)) { p.skip_if_ge = nullptr; p.dbg = 0; }
+    if constexpr (!(FEAT & 32)) { p.mask_scale = 0.f; }
     constexpr int NW = WM * WN;
     constexpr int EPC = 16 / sizeof(T);                 // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;                         // one 128-byte slab row
@@ -262,7 +264,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
                 v.z = drop_hash(dseed, e + 2) >= p.drop_thresh ? v.z * p.drop_scale : 0.f;
                 v.w = drop_hash(dseed, e + 3) >= p.drop_thresh ? v.w * p.drop_scale : 0.f;
             }
-            v.x = rv[u].x + v.x; v.y = rv[u].y + v.y; v.z = rv[u].z + v.z; v.w = rv[u].w + v.w;
+            if (p.mask_scale != 0.f) {
+                v.x = rv[u].x > 0.f ? v.x * p.mask_scale : 0.f; v.y = rv[u].y > 0.f ? v.y * p.mask_scale : 0.f;
+                v.z = rv[u].z > 0.f ? v.z * p.mask_scale : 0.f; v.w = rv[u].w > 0.f ? v.w * p.mask_scale : 0.f;
+            } else {
+                v.x = rv[u].x + v.x; v.y = rv[u].y + v.y; v.z = rv[u].z + v.z; v.w = rv[u].w + v.w;
+            }
             if (p.stats_out) {                         // partial sums over this lane's aligned 32-column group (8 lanes)
                 float ps = live[u] ? (v.x + v.y) + (v.z + v.w) : 0.f;
                 float pq = live[u] ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
@@ -369,7 +376,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     }
     {
         const int feat = (p.ln_stats ? 1 : 0) | ((p.stats_out || p.y2) ? 2 : 0) | (p.row_len ? 4 : 0) | (p.drop_thresh ? 8 : 0) |
-                         ((p.skip_if_ge || p.dbg) ? 16 : 0);
+                         ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0);
         bool done = false;
         switch (feat) {
             case 0: done = launch_specialised<T, 0>(p, bm, bn, ns, nw, st); break;          // plain: bias / ReLU / residual
@@ -380,6 +387,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
             case 18: done = launch_specialised<T, 18>(p, bm, bn, ns, nw, st); break;
             case 8: done = launch_specialised<T, 8>(p, bm, bn, ns, nw, st); break;          // training: dropout (+ compute-dtype copy)
             case 10: done = launch_specialised<T, 10>(p, bm, bn, ns, nw, st); break;
+            case 32: done = launch_specialised<T, 32>(p, bm, bn, ns, nw, st); break;        // training: dX through relu (+ dropout)
             default: break;
         }
         if (done) { BOFI_CHECK_LAUNCH(); return BOFI_OK; }
@@ -427,7 +435,9 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
     p.splitk = a.splitk > 1 ? a.splitk : 1;
     p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
+    p.mask_scale = a.mask_scale;
     if (p.drop_thresh && (a.splitk > 1 || a.stats_out)) return BOFI_ERR_ARG;
+    if (p.mask_scale != 0.f && (!a.residual || a.splitk > 1 || a.stats_out || a.ln_stats)) return BOFI_ERR_ARG;
     if (p.splitk > 1 && (a.y_dtype != BOFI_DT_F32 || a.relu || a.ln_stats || a.stats_out || a.y2 || a.row_len || (a.K / p.splitk) % bk || a.K % p.splitk))
         return BOFI_ERR_ARG;
     { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }
@@ -437,6 +447,7 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
                (!a.residual || (((uintptr_t)a.residual % 16 == 0) && (a.ldr % 4 == 0))) &&
                (!a.ln_colsum || (uintptr_t)a.ln_colsum % 16 == 0) && (!a.y2 || (((uintptr_t)a.y2 % 16 == 0) && a.ldy2 % 4 == 0));
     if ((a.stats_out || a.y2) && (!p.vec_ok || a.N % 32)) return BOFI_ERR_ARG;
+    if (p.mask_scale != 0.f && !p.vec_ok) return BOFI_ERR_ARG;
     return el == 4 ? launch_glds_t<float>(p, st) : launch_glds_t<bf16_t>(p, st);
 }
 

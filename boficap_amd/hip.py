@@ -54,6 +54,7 @@ SIGNATURES = {
     "bofi_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bofi_cast_bf16": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, C.c_float, C.c_uint64, _P, _P]),
     "bofi_linear_ex": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, C.c_float, C.c_uint64, _P, _P, _I, _P]),
+    "bofi_linear_masked": (_I, [_P, _I, _I, _P, _I, _P, _I, C.c_float, _P, _I, _I, _I, _I, _I, _P]),
     "bofi_dropout": (_I, [_P, _P, _P, _I64, C.c_float, C.c_uint64, _P, _P]),
     "bofi_adam_step": (_I, [_P, _P, _P, _P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, _I, C.c_float, C.c_float, _P]),
     "bofi_relu_bwd": (_I, [_P, _P, _P, _I64, _P]),

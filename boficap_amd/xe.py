@@ -142,6 +142,12 @@ def _operand(x, M, N, dt, cache=True, colsum=None, relu_y=None, drop=None):
     hit = _STEP_CACHE.get(key) if (colsum is None and (cache or (relu_y is None and drop is None))) else None
     if hit is not None and (cache or hit[0] is x):             # (a gradient's bf16 copy made by its producer: same tensor object only)
         return hit[1], Np
+    if relu_y is not None and colsum is None and not cache and dt == torch.bfloat16 and Np == N:
+        g = _STEP_CACHE.get(("gopr", x.data_ptr()))             # dz made by the consumer's input-gradient GEMM (bofi_linear_masked)
+        if g is not None and g[0] is x and g[2].data_ptr() == relu_y.data_ptr():     # (a saved OUTPUT comes back as a new tensor object)
+            return g[1], Np
+        if g is not None and g[0] is x:
+            raise hip.BofiHipError("masked gradient hand-over: the placeholder reached a different node than the one it was made for")
     if drop is not None and relu_y is None and colsum is None and not cache and dt == torch.bfloat16 and Np == N:
         g = _STEP_CACHE.get(("gop", x.data_ptr()))              # dz made by the producer of this gradient, mask already applied
         if g is not None and g[0] is x and g[2][0] == drop[0] and g[2][1] == drop[1] and g[2][2] is drop[2]:
@@ -197,7 +203,7 @@ class LinearFn(Function):
     then adds in its epilogue (residual = output = gw) and autograd sees no gradient for w / b at all."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow):
+    def forward(ctx, x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow, masked_grad=False):
         x, w = _need(x, "linear x"), _need(w, "linear w")
         M, K = x.shape
         N = w.shape[0]
@@ -220,6 +226,10 @@ class LinearFn(Function):
             _gemm(xo, Kp, wo, b, residual, y, M, N, Kp, 1 if relu else 0, row_len, rpg, drop, y2)
             if y2 is not None:
                 _register_shadow(y, y2)
+            if relu and masked_grad and dt == torch.bfloat16:
+                # this activation has ONE consumer, a linear: its input-gradient GEMM can mask by (y > 0) and scale by 1 / (1 - p)
+                # in its epilogue and hand this node its dz in bf16 (bofi_linear_masked) instead of a float32 dL/dy to mask and cast
+                _STEP_CACHE[("act", y.data_ptr())] = (y, 1.0 / (1.0 - drop[0]) if drop is not None else 1.0)
             if drop is not None and residual is not None and not relu:
                 # y = residual + dropout(x w^T + b): whoever computes dL/dy next (the LayerNorm that reads y) can hand this node
                 # its dz = mask o dL/dy in bf16 right away (LayerNormFn.backward)
@@ -243,7 +253,7 @@ class LinearFn(Function):
             dz = torch.empty_like(dy)
             _chk(L.bofi_relu_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dz), dy.numel(), st), "bofi_relu_bwd")
         dx = dw = db = None
-        tail = (dy if ctx.has_r else None, None, None, None, None, None, None, None)
+        tail = (dy if ctx.has_r else None, None, None, None, None, None, None, None, None)
         if M == 0:
             return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(w) if ctx.needs_input_grad[1] and ctx.gw is None else None,
@@ -259,14 +269,29 @@ class LinearFn(Function):
             # ReLU and dropout masks are applied inside the cast (a dropped ReLU unit has y == 0: the ReLU test covers it)
             # the bias gradient (column sums of dz) is taken by the weight-gradient GEMM from its A tiles
             cast_sum = None if want_w else bsum
-            if cast_sum is not None and _shadow(dy) is not None:   # dy is a placeholder for a bf16 gradient (attention backward): its
-                cast_sum.add_(_shadow(dy).float().sum(0)[:N])      # column sums come from that copy (frozen weight, trainable bias: rare)
-                cast_sum = None
+            if cast_sum is not None:                               # (frozen weight, trainable bias: rare)
+                made = _shadow(dy)                                 # dy may be a placeholder for a bf16 gradient its producer wrote
+                if made is None:                                   # (attention backward, bofi_linear_masked): column sums from that copy
+                    g_ = _STEP_CACHE.get(("gopr", dy.data_ptr()))
+                    made = g_[1] if (g_ is not None and g_[0] is dy) else None
+                if made is not None:
+                    cast_sum.add_(made.float().sum(0)[:N])
+                    cast_sum = None
             dzo, Np = _operand(dy, M, N, dt, cache=False, colsum=cast_sum, relu_y=y if ctx.relu else None, drop=ctx.drop)
             if ctx.needs_input_grad[0]:
                 wt, _ = _transposed(w, N, K, dt)       # [K, Np], once per weight per step
                 dx = _empty(x, M, K)
-                _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
+                act = _STEP_CACHE.get(("act", x.data_ptr()))
+                if act is not None and act[0] is x and K % 64 == 0:
+                    # x = relu(..) (+ dropout) of the previous linear, which is its only producer-consumer pair: dx stays an unfilled
+                    # placeholder, the masked gradient goes out in bf16
+                    dzb = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+                    _chk(L.bofi_linear_masked(hip.ptr(dzo), hip.DT_BF16, Np, hip.ptr(wt), hip.DT_BF16, hip.ptr(x), K, act[1], hip.ptr(dzb),
+                                              hip.DT_BF16, K, M, K, Np, st), "bofi_linear_masked")
+                    _STEP_CACHE[("gopr", dx.data_ptr())] = (dx, dzb, x)
+                    _SHADOW_ONLY.add(dx.data_ptr())                # a placeholder: a cast of it must never happen silently
+                else:
+                    _gemm(dzo, Np, wt, None, None, dx, M, K, Np)
             if want_w:
                 xo, Kp = _operand(x, M, K, dt)         # the forward's operand, still in the step cache
                 target = ctx.gw
@@ -295,10 +320,10 @@ class LinearFn(Function):
         return (dx, dw, db) + tail
 
 
-def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None, drop=None, shadow=False):
+def linear(x, w, b=None, residual=None, relu=False, row_len=None, rpg=0, gw=None, gb=None, drop=None, shadow=False, masked_grad=False):
     """``drop``: (p, seed, step word or None) -> y = residual + dropout(act(x w^T + b)), mask made in the GEMM epilogue (bf16 path).
     ``shadow``: the output feeds a GEMM or an attention kernel -> also emit it in bf16 from the epilogue (bf16 path)."""
-    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow)
+    return LinearFn.apply(x, w, b, residual, relu, row_len, rpg, gw, gb, drop, shadow, masked_grad)
 
 
 class LayerNormFn(Function):
@@ -448,7 +473,7 @@ class AttentionFn(Function):
         if qb16:
             dq = torch.empty(qbuf.shape, dtype=torch.float32, device=qbuf.device)
             dq_out = _rows_alloc(qbuf.shape, torch.bfloat16, qbuf.device, ctx.seg is not None, tail)
-            _register_shadow(dq, dq_out)
+            _register_shadow(dq, dq_out, only=True)            # (listed as a placeholder: any float32 reader of it raises)
             dkv = dq if ctx.same else torch.empty(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         elif ctx.seg is not None and ctx.mfma and tail is not None and fits:
             # unpadded rows: the kernel writes every caption's rows; only the rows behind the last caption need zeros
@@ -635,9 +660,9 @@ class Params:
         return self._packed[key]
 
     # ---- the model's recurring nodes
-    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0, drop=None, shadow=False):
+    def lin(self, x, wname, residual=None, relu=False, row_len=None, rpg=0, drop=None, shadow=False, masked_grad=False):
         w, b = wname + ".weight", wname + ".bias"
-        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b), drop, shadow)
+        return linear(x, self.t[w], self.t[b], residual, relu, row_len, rpg, self.g(w), self.g(b), drop, shadow, masked_grad)
 
     def lin_packed(self, x, prefix, idx):
         """Fused q|k|v (or k|v) projection; its output feeds an attention kernel."""
@@ -665,8 +690,9 @@ def _sublayer_linear(P, drop, x_in, wname, residual):
 
 def _ffn(P, pre, drop, n, x):
     fused = drop.on and drop.p > 0.0 and _COMPUTE["dtype"] == torch.bfloat16
-    h = P.lin(n, pre + ".w_1", relu=True, drop=drop.site() if fused else None, shadow=True)
-    if drop.on and drop.p > 0.0 and not fused:
+    separate = drop.on and drop.p > 0.0 and not fused
+    h = P.lin(n, pre + ".w_1", relu=True, drop=drop.site() if fused else None, shadow=True, masked_grad=not separate)   # h feeds w_2 only
+    if separate:
         h = drop(h)
     return _sublayer_linear(P, drop, h, pre + ".w_2", x)
 

@@ -178,6 +178,13 @@ int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w, int w_dty
                    const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* y2,
                    int ldy2, void* stream);
 
+/* y = mask > 0 ? (x w^T) * scale : 0 (no bias): the input gradient of a linear whose INPUT came out of relu (+ dropout with
+ * scale = 1 / (1 - p)) -- mask [M, N] float32 is that forward activation (a clipped or dropped unit is 0 there), so the
+ * gradient arrives already masked, e.g. in bf16 for the previous layer's backward GEMMs (nn.Linear backward followed by the
+ * relu / dropout backward in the reference).  Operands in the compute dtype, N % 4 == 0. */
+int bofi_linear_masked(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* mask, int ldm,
+                       float scale, void* y, int y_dtype, int ldy, int M, int N, int K, void* stream);
+
 /* y = (residual or 0) + keep(x) / (1 - p), keep mask = hash(seed, index) (nn.Dropout of the sublayers,
  * TransformerModel.py:1361-1363; the backward is the same call on dy with the same seed) */
 int bofi_dropout(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed, const uint64_t* drop_step,

@@ -468,6 +468,31 @@ def test_layernorm_backward_hands_the_masked_gradient_to_its_producer():
         assert _maxdiff(a, c) <= 1e-5 * max(1.0, float(c.abs().max()))
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_ffn_input_gradient_arrives_masked_from_the_second_linear(p_drop):
+    """h = dropout(relu(x W1^T + b1)) in the GEMM epilogue, y = h W2^T + b2: the input-gradient GEMM of the second linear masks by
+    h > 0 and scales by 1 / (1 - p) in its epilogue and hands the first linear its dz in bf16 (bofi_linear_masked) -- same
+    gradients as the float32 dL/dh + mask-and-cast pass."""
+    from boficap_amd import xe
+    M, d, dff = 300, 128, 256
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(M, d, generator=g)
+    w1, b1 = torch.randn(dff, d, generator=g) * 0.1, torch.randn(dff, generator=g) * 0.1
+    w2, b2, gout = torch.randn(d, dff, generator=g) * 0.1, torch.randn(d, generator=g), torch.randn(M, d, generator=g)
+    grads = []
+    for hand_over in (True, False):
+        xe._COMPUTE["dtype"] = torch.bfloat16
+        xe._STEP_CACHE.clear(); xe._SHADOW_ONLY.clear()
+        t = [v.clone().cuda().requires_grad_() for v in (x0, w1, b1, w2, b2)]
+        h = xe.linear(t[0], t[1], t[2], relu=True, drop=(p_drop, 99, None) if p_drop else None, shadow=True, masked_grad=hand_over)
+        y = xe.linear(h, t[3], t[4])
+        (y * gout.cuda()).sum().backward()
+        assert any(k[0] == "gopr" for k in xe._STEP_CACHE) == hand_over
+        grads.append([v.grad.clone() for v in t])
+    for a, c in zip(*grads):
+        assert _maxdiff(a, c) <= 1e-5 * max(1.0, float(c.abs().max()))
+
+
 @pytest.mark.parametrize("n", [3, 45])
 def test_grouped_weight_gradient_gemms(n):
     """bofi_gemm_tn_grouped: n problems of mixed sizes (ragged tiles, empty row sets, two problems adding into the same
