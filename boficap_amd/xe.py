@@ -1,4 +1,4 @@
-"""XE training forward / backward of the UIC model on the HIP ops (float32).
+"""XE training forward / backward of the UIC model on the HIP ops.
 
 Replaces, for train_mode 'UIC', ``TransformerModel._forward`` (TransformerModel.py:1713-1724,1759-1775) ->
 ``EncoderDecoder_UIC.forward`` (:413-468) and the autograd graph torch builds under it (tools/train.py:212-227).
@@ -10,7 +10,24 @@ the buffers, the tape and the parameter tensors.  Differences in STRUCTURE from 
   * the teacher-forced bound passes (:476-513 SA, :532-565 NA: one predictor pass per phrase index, the mask
     grown per caption) run as ONE batched pass over N x Pmax virtual [LEN] queries with per-query key counts,
     because only row 0 of each pass is ever read (:375);
-  * every mask on this path is a key prefix per query row, so masks travel as int32 key counts.
+  * every mask on this path is a key prefix per query row, so masks travel as int32 key counts;
+  * with the collate's row lists (HINTS) the decoder runs over the captions' real positions only and the SA and NA branch
+    share one bound pass and one decoder pass (_fill_unpadded, _forward_paired).
+
+float32 is the parity mode.  In bf16 mode (GEMM operands bf16, everything else float32) the module keeps a few per-step
+side tables, all cleared by the next forward:
+
+  _STEP_CACHE    ("op"/"tr", ptr, M, N, dtype) -> GEMM operand made from a float32 tensor (cast / transposed once per step);
+                 also the bf16 "shadow" a producer wrote next to (or instead of) its float32 output;
+                 ("prod", ptr) / ("act", ptr)  -> what a linear's output went through (epilogue dropout / relu), for the
+                 node that will compute the gradient w.r.t. it;  ("gop"/"gopr", ptr) -> that gradient, already masked and
+                 in bf16, made by its producer (LayerNorm backward, bofi_linear_masked);
+  _SHADOW_ONLY   data pointers of float32 PLACEHOLDERS: tensors autograd passes around whose storage is never filled because
+                 every consumer reads the bf16 copy (LayerNorm / attention outputs, handed-over gradients).  Any float32
+                 reader of a placeholder raises (_real, _operand); placeholders are only created where the tensor has one
+                 consumer, and the entries keep them alive so that a pointer names one tensor for the whole step;
+  _WEIGHTS       the trainer's per-step bf16 weight operands (trainer.WeightOperands);
+  _DEFER         weight-gradient GEMMs put off to one grouped launch after backward (flush_weight_grads).
 """
 from __future__ import annotations
 
