@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--save_checkpoint_every", type=int, default=0)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--tiny", action="store_true", help="the small test configuration instead of the 512-d model")
+    ap.add_argument("--no_graph", action="store_true", help="run the step eagerly instead of replaying one hipGraph per batch signature")
     args = ap.parse_args()
 
     import captioning.models as models
@@ -70,7 +71,7 @@ def main():
     if args.start_from:
         model.load_state_dict(torch.load(os.path.join(args.start_from, "model.pth"), map_location="cpu"), strict=True)
     model.to(dev).train()
-    trainer = XETrainer(model, opt)
+    trainer = XETrainer(model, opt, graph=not args.no_graph)
     if args.start_from and os.path.exists(os.path.join(args.start_from, "optimizer.pth")):
         trainer.load_state_dict(torch.load(os.path.join(args.start_from, "optimizer.pth"), map_location="cpu"))
     cfg = model.cfg
