@@ -117,8 +117,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
                 st[kj][qi][r] = sv_;
                 m = fmaxf(m, sv_);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = xor32_max(xor16_max(m));
         float sum = 0.f;
 #pragma unroll
         for (int kj = 0; kj < NKT; ++kj)
@@ -128,8 +127,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
                 st[kj][qi][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor32_sum(xor16_sum(sum));
         // an empty row gives 0/0 = NaN for every key, as softmax over all -inf does in the reference
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {

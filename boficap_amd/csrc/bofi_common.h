@@ -66,16 +66,28 @@ __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
     return fmaxf(v, dpp_f32<DPP_MIRROR>(v));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-    v = row16_sum(v);
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+// Across rows: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16- (32-) lane rows of one register with the even
+// rows of another.  With both operands = v the two results hold, in every lane, the lane's own row pair: (r0,r0,r2,r2) and
+// (r1,r1,r3,r3) for the 16-lane form, (lo,lo) and (hi,hi) for the 32-lane form -- so a commutative combine of the two results is
+// the lane ^ 16 (lane ^ 32) step of a butterfly, in one VALU instruction instead of a ds_bpermute (probe: tools/exp/permlane_probe.hip).
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float wave_max(float v) {
-    v = row16_max(v);
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // 64-bit counter hash (splitmix64 finaliser), upper half: the uniform numbers of the sampling kernels
 __device__ __forceinline__ uint32_t hash64_hi(uint64_t seed, uint64_t i) {

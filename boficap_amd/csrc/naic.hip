@@ -317,7 +317,7 @@ __global__ __launch_bounds__(128) void embed_fill_kernel(const float* __restrict
         if (stats) {                                  // partial (sum, sumsq) per 32 columns, as the GEMM epilogues write them
             float ps = v, pq = v * v;
             ps = row16_sum(ps); pq = row16_sum(pq);
-            ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+            ps = xor16_sum(ps); pq = xor16_sum(pq);
             if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
         }
     }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(128) void embed_rows_kernel(const float* __restrict
         if (stats) {
             float ps = v, pq = v * v;
             ps = row16_sum(ps); pq = row16_sum(pq);
-            ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+            ps = xor16_sum(ps); pq = xor16_sum(pq);
             if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
         }
     }
