@@ -53,15 +53,25 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { g[j] = gain[lane + 64 * j]; dg[j] = 0.f; db[j] = 0.f; }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    // a wavefront walks its rows one after the other and every row is three dependent wave reductions behind its loads: the NEXT
+    // row's three streams are requested before the current row is reduced (second register set), or each row pays a full
+    // memory latency of its own
+    float xn[NJ], dn[NJ], an[NJ];
+    auto request = [&](int row) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xn[j] = x[(size_t)row * d + lane + 64 * j];
+            dn[j] = dy[(size_t)row * d + lane + 64 * j];
+            an[j] = add ? add[(size_t)row * d + lane + 64 * j] : 0.f;
+        }
+    };
+    if (r0 + wave < r1) request(r0 + wave);
     for (int row = r0 + wave; row < r1; row += 4) {
         float xv[NJ], dv[NJ], av[NJ];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {                        // all three streams of the row are requested up front
-            xv[j] = x[(size_t)row * d + lane + 64 * j];
-            dv[j] = dy[(size_t)row * d + lane + 64 * j];
-            av[j] = add ? add[(size_t)row * d + lane + 64 * j] : 0.f;
-        }
+        for (int j = 0; j < NJ; ++j) { xv[j] = xn[j]; dv[j] = dn[j]; av[j] = an[j]; }
+        if (row + 4 < r1) request(row + 4);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) s += xv[j];
         const float mean = wave_sum(s) / (float)d;
