@@ -43,7 +43,11 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
     const int lr = tid / CPR, lc = tid % CPR;                    // loader: rows lr, lr + 256/CPR, ...; 16-byte chunk lc
     constexpr int RSTEP = 256 / CPR;                             // 32 (WT 2) or 16 (WT 4): a multiple of 16, so row + RSTEP swizzles like row
     const bool a_ok = i0 + lc * 8 < p.a_cols, b_ok = j0 + lc * 8 < p.b_cols;
-    const int sw = (lc ^ ((lr >> 1) & 7)) * 8;
+    // swizzle key of a row: with 128-byte rows (T = 64) rows r, r + 1 start 32 banks apart, so (r >> 1) & 7 spreads the 16 rows of
+    // a transposing read over all bank groups; with 256-byte rows (T = 128) EVERY row starts at bank 0 and it takes r & 15
+    // (the 16 chunks of a row) -- (r >> 1) & 7 there leaves two-way conflicts on every read
+    auto key = [](int r) { return T == 128 ? (r & 15) : ((r >> 1) & 7); };
+    const int sw = (lc ^ key(lr)) * 8;
 
     u32x4 va[NL], vb[NL];
     auto load = [&](int m0) {
@@ -73,7 +77,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
         for (int b = 0; b < WT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // operand gather: lane (g, tq, tp) addresses row 4g + tq (and + 16), columns 4tp .. 4tp + 3 of a 16-column block
-    const int row0 = 4 * g + tq, rsw = (row0 >> 1) & 7;           // (row0 + 16) swizzles like row0
+    const int row0 = 4 * g + tq, rsw = key(row0);                 // (row0 + 16) swizzles like row0
     auto frag = [&](const bf16_t* tile, int col, int sub) -> bf16x8 {
         const bf16_t* p0 = tile + (row0 + 32 * sub) * T + (((col >> 3) ^ rsw) << 3) + (col & 7);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -117,7 +121,7 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
 #pragma unroll
                 for (int hh = 0; hh < 16; ++hh) {
                     const int r = crg * 16 + hh, c = cc + 64 * q;
-                    csum[q] += bf16_to_f32(sa[buf][r * T + ((((c >> 3) ^ ((r >> 1) & 7))) << 3) + (c & 7)]);
+                    csum[q] += bf16_to_f32(sa[buf][r * T + ((((c >> 3) ^ key(r))) << 3) + (c & 7)]);
                 }
         }
         if (more) stash(buf ^ 1);
