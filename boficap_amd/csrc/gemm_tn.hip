@@ -9,8 +9,7 @@
 //
 // bf16 operands, fp32 accumulation.  Workgroup = 4 wavefronts, tile 64 x 64, each wavefront 32 x 32 (2 x 2 MFMA
 // 16x16x32 tiles), 64 contraction rows per barrier.  LDS: two stages x (A tile + B tile) x 64 rows x 128 B = 32 KB.
-// 16-byte chunk c of LDS row r holds source chunk c ^ ((r >> 1) & 7): the 16 rows one transposing read touches then
-// fall in 16 different bank groups.
+// LDS rows are swizzled per 16-byte chunk so that the transposing reads are bank-conflict free (see key() below).
 #include "bofi_common.h"
 #include "bofi_kernels.h"
 
@@ -43,10 +42,12 @@ __device__ __forceinline__ void gemm_tn_tile(const GemmTnParams& p, int i0, int 
     const int lr = tid / CPR, lc = tid % CPR;                    // loader: rows lr, lr + 256/CPR, ...; 16-byte chunk lc
     constexpr int RSTEP = 256 / CPR;                             // 32 (WT 2) or 16 (WT 4): a multiple of 16, so row + RSTEP swizzles like row
     const bool a_ok = i0 + lc * 8 < p.a_cols, b_ok = j0 + lc * 8 < p.b_cols;
-    // swizzle key of a row: with 128-byte rows (T = 64) rows r, r + 1 start 32 banks apart, so (r >> 1) & 7 spreads the 16 rows of
-    // a transposing read over all bank groups; with 256-byte rows (T = 128) EVERY row starts at bank 0 and it takes r & 15
-    // (the 16 chunks of a row) -- (r >> 1) & 7 there leaves two-way conflicts on every read
-    auto key = [](int r) { return T == 128 ? (r & 15) : ((r >> 1) & 7); };
+    // Swizzle: 16-byte chunk c of LDS row r holds source chunk c ^ key(r).  A transposing read is banked per 32-lane half
+    // (MI355X_MICROARCH.md, LDS): 8 rows x 32 bytes, each row's 32 bytes being one EVEN-ALIGNED PAIR of chunks -- so the key must
+    // move whole pairs (bit 0 clear) and give the 8 rows 8 different bank ranges: with 256-byte rows (T = 128) every row starts at
+    // bank 0 and the 8 rows take 8 different pairs, (r & 7) << 1; with 128-byte rows (T = 64) rows r, r + 1 sit in opposite halves
+    // of the bank row and the 4 row pairs take 4 different chunk pairs, ((r >> 1) & 3) << 1.
+    auto key = [](int r) { return T == 128 ? ((r & 7) << 1) : (((r >> 1) & 3) << 1); };
     const int sw = (lc ^ key(lr)) * 8;
 
     u32x4 va[NL], vb[NL];
@@ -169,7 +170,15 @@ struct GemmTnGroup {
 template <int WT>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const GemmTnGroup grp) {
     constexpr int T = 32 * WT;
-    const int t = blockIdx.x;
+    // XCD-aware order (workgroup i runs on XCD i % 8, each with its own 4 MiB L2): XCD x walks a CONTIGUOUS run of tiles, so the
+    // tiles that share an operand column block -- neighbours in the list -- meet in one L2 instead of being dealt round the chip.
+    // The kernel is bound by operand re-fetch from L2 / Infinity Cache (64 FLOP per byte loaded at 128 x 128 x 64-row steps:
+    // ~9 TB/s at the measured 530 TFLOP/s), not by LDS or MFMA issue: an LDS-DMA loader (no ds_write_b128) measured no faster.
+    int t = blockIdx.x;
+    {
+        const int nt = gridDim.x, q8 = nt >> 3, r8 = nt & 7, xcd = t & 7, idx = t >> 3;
+        t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
     int lo = 0, hi = grp.n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
