@@ -33,7 +33,11 @@ struct AttnParamsB {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-constexpr int AROW = 72;          // LDS row stride in elements: 64 + 8 pad (144 B: conflict-free b128 fragment reads)
+// LDS row stride in elements: 64 + 16 pad = 160 B.  Banking (MI355X_MICROARCH.md, LDS): the transposing reads of V are banked per
+// 32-lane half = 8 rows x 32 B, which tile the 256-byte bank row only if the stride is an odd multiple of 32 B; the b128 row
+// reads of Q / K (16-lane groups: 8 rows at one chunk, 8 at the next) are conflict-free at 160 B as well.  The former 144 B
+// (64 + 8) left the 32-byte segments straddling each other: SQ_LDS_BANK_CONFLICT was 25 % of the LDS cycles of this kernel.
+constexpr int AROW = 80;
 
 template <int NQT, int NKT, bool RAGGED = false>       // 16-row query tiles per block, 16-key tiles (even); RAGGED: per-item row ranges
 __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {

@@ -110,7 +110,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // caption and head, thousands of them, and at one wavefront per SIMD they run in five rounds)
 template <typename TIN, int QT, int KT, int NW>
 __global__ __launch_bounds__(64 * NW, (QT == 2 && KT == 2) ? 2 : 1) void attn_bwd_mfma_kernel(AttnBwdMfmaParams p) {
-    constexpr int DS = 72, PS = KT * 16 + 8;                     // padded strides (elements)
+    // padded strides (elements): 160 B for the head-dim tiles, 96 / 160 B for the [q][k] tiles -- odd multiples of 32 B, so that the
+    // 8 rows x 32 B a transposing read touches per 32-lane half tile the 256-byte bank row (144 B / 80 B strides cost 30 % of the
+    // LDS cycles in bank conflicts, SQ_LDS_BANK_CONFLICT); the b128 row reads are conflict-free at 160 B too
+    constexpr int DS = 80, PS = KT == 2 ? 48 : 80;
     constexpr int LQ = QT * 16, LK = KT * 16;
     constexpr int STAGE = 2 * LQ * DS + 2 * LQ * PS;             // one wavefront's private tiles: Q, dO, P, dS (elements)
     __shared__ __attribute__((aligned(16))) bf16_t sk[LK * DS], sv[LK * DS];
