@@ -235,12 +235,13 @@ extern "C" int bofi_attention(const void* q, int ldq, const void* k, int ldk, co
 extern "C" int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                                  int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq,
                                  int klen_bias, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, const int* q_start,
-                                 const int* q_count, int k_ragged, void* stream) {
+                                 const int* q_count, int k_ragged, int q_rows, void* stream) {
     if (kdiv <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     bofi::AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.dtype = dtype;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = klen_sq;
     a.klen_bias = klen_bias; a.kdiv = kdiv; a.q_start = q_start; a.q_count = q_count; a.k_ragged = k_ragged;
+    a.q_rows = (q_start && dtype == BOFI_DT_BF16) ? q_rows : 0;       // (only the bf16 kernel clears the trailing rows)
     if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.drop_step = drop_step; }
     return bofi::launch_attention(a, (hipStream_t)stream);
 }

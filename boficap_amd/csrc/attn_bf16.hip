@@ -28,7 +28,7 @@ struct AttnParamsB {
     const int* skip_if_ge; int skip_threshold;
     int kdiv;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;
-    const int* q_start; const int* q_count; int k_ragged;
+    const int* q_start; const int* q_count; int k_ragged; int q_rows;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -50,6 +50,14 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     const int lane = threadIdx.x;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int q0 = blockIdx.y * (NQT * 16);
+    if constexpr (RAGGED) {
+        if (b == p.B) {                             // the extra "item": rows behind the last one.  Nobody attends them, but the
+            if (blockIdx.y != 0) return;            // row-wise consumers of the output read them: they get zeros
+            for (int r = p.q_start[p.B - 1] + p.q_count[p.B - 1] + (lane >> 3); r < p.q_rows; r += 8)
+                *reinterpret_cast<u32x4*>(p.out + (size_t)r * p.ldo + h * 64 + (lane & 7) * 8) = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
+    }
     int qrow0 = b * p.Lq, lq = p.Lq;                // first query row of this item and how many it has
     if constexpr (RAGGED) { qrow0 = p.q_start[b]; lq = p.q_count[b]; }
     const int nq = min(NQT * 16, lq - q0);
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
 
 template <int NQT, int NKT>
 static void launch_ab(const AttnParamsB& p, hipStream_t st) {
-    const dim3 grid(p.B * p.H, (p.Lq + NQT * 16 - 1) / (NQT * 16));
+    const dim3 grid((p.B + ((p.q_start && p.q_rows > 0) ? 1 : 0)) * p.H, (p.Lq + NQT * 16 - 1) / (NQT * 16));
     if (p.q_start) hipLaunchKernelGGL((attn_bf16_kernel<NQT, NKT, true>), grid, dim3(64), 0, st, p);
     else hipLaunchKernelGGL((attn_bf16_kernel<NQT, NKT, false>), grid, dim3(64), 0, st, p);
 }
@@ -211,7 +219,8 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     p.kdiv = a.kdiv > 0 ? a.kdiv : 1;
     p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
     if ((a.q_start != nullptr) != (a.q_count != nullptr)) return BOFI_ERR_ARG;
-    p.q_start = a.q_start; p.q_count = a.q_count; p.k_ragged = a.k_ragged;
+    p.q_start = a.q_start; p.q_count = a.q_count; p.k_ragged = a.k_ragged; p.q_rows = a.q_rows;
+    if (a.q_rows > 0 && (a.ldo % 8 || ((uintptr_t)a.out % 16))) return BOFI_ERR_ARG;
     const int nkt = a.Lk <= 32 ? 2 : 4;
     const int nqt = a.Lq <= 16 ? 1 : (a.Lq <= 32 ? 2 : 3);
     switch (nqt * 10 + nkt) {

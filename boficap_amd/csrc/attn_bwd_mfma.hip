@@ -28,6 +28,7 @@ struct AttnBwdMfmaParams {
     const int* klen; int klen_sb, klen_sq, klen_bias;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; const uint64_t* drop_step;     // dropout(p_attn) of the forward
     const int* q_start; const int* q_count; int k_ragged;     // unpadded layout (bofi_kernels.h: AttnArgs)
+    int q_rows;                                               // > 0: rows of the dq buffer; rows behind the last item are cleared
 };
 
 // Head slice [rows_real, 64] -> LDS as bf16, rows past the data zero, in two phases: load() requests every 16-byte piece of
@@ -128,6 +129,21 @@ __global__ __launch_bounds__(64 * NW, (QT == 2 && KT == 2) ? 2 : 1) void attn_bw
     // captions' query rows are unpadded (and therefore one contiguous run of rows), 16*QT-row chunks of that run: chunks are
     // fuller than captions.  Wavefront w takes items w, w + NW, ...; dK / dV stay in registers across them.
     const int bh = blockIdx.x, bk = bh / p.H, h = bh - bk * p.H;
+    if (p.q_rows > 0 && bk == p.B / p.kdiv) {                   // the extra workgroups: gradient rows behind the last item are zero
+        const int c = (threadIdx.x & 15) * 4;                   // 16 threads x 4 columns per row
+        for (int r = p.q_start[p.B - 1] + p.q_count[p.B - 1] + (int)(threadIdx.x >> 4); r < p.q_rows; r += 4 * NW) {
+            const size_t oq = (size_t)r * p.lddq + h * 64 + c, ok = (size_t)r * p.lddk + h * 64 + c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p.dq_bf16) static_cast<bf16_t*>(p.dq)[oq + u] = 0; else static_cast<float*>(p.dq)[oq + u] = 0.f;
+                if (p.k_ragged) {
+                    if (p.dkv_bf16) { static_cast<bf16_t*>(p.dk)[ok + u] = 0; static_cast<bf16_t*>(p.dv)[ok + u] = 0; }
+                    else { static_cast<float*>(p.dk)[ok + u] = 0.f; static_cast<float*>(p.dv)[ok + u] = 0.f; }
+                }
+            }
+        }
+        return;
+    }
     const bool kr = p.q_start && p.k_ragged;                   // self-attention over unpadded rows (kdiv == 1 then)
     const bool run = p.q_start && !p.k_ragged;                 // cross-attention over unpadded rows: walk the key owner's run in chunks
     const int b_first = bk * p.kdiv;
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 2 && KT == 2) ? 2 : 1) void attn_bw
 
 template <typename TIN>
 static int launch_t(const AttnBwdMfmaParams& p, hipStream_t st) {
-    const dim3 grid((p.B / p.kdiv) * p.H);
+    const dim3 grid((p.B / p.kdiv + ((p.q_start && p.q_rows > 0) ? 1 : 0)) * p.H);
     // several captions per key owner: two wavefronts share them
     if (p.Lq <= 32 && p.Lk <= 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 2, 1>), grid, dim3(64), 0, st, p);
     else if ((p.Lq <= 32 && p.kdiv > 1) || (p.q_start && !p.k_ragged)) hipLaunchKernelGGL((attn_bwd_mfma_kernel<TIN, 2, 4, 2>), grid, dim3(128), 0, st, p);
@@ -360,7 +376,7 @@ extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, in
                                        const float* dout, int ldo, void* dq, int lddq, void* dk, void* dv, int lddk, int dq_dtype, int dkv_dtype,
                                        int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq, int klen_bias,
                                        float drop_p, uint64_t drop_seed, const uint64_t* drop_step, const int* q_start, const int* q_count,
-                                       int k_ragged, void* stream) {
+                                       int k_ragged, int q_rows, void* stream) {
     using namespace bofi;
     if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || (Lq > 64 && !(q_start && !k_ragged)) || Lk > 64 || kdiv <= 0 || B % kdiv || !(drop_p >= 0.f && drop_p < 1.f)) return BOFI_ERR_ARG;
     if (in_dtype != BOFI_DT_F32 && in_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
@@ -372,7 +388,7 @@ extern "C" int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, in
     if (B == 0) return BOFI_OK;
     AttnBwdMfmaParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, lddq, dk, dv, lddk, dq_dtype == BOFI_DT_BF16, dkv_dtype == BOFI_DT_BF16,
                         B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias,
-                        0u, 1.f, drop_seed, drop_step, q_start, q_count, k_ragged};
+                        0u, 1.f, drop_seed, drop_step, q_start, q_count, k_ragged, q_start ? q_rows : 0};
     if ((q_start != nullptr) != (q_count != nullptr) || (k_ragged && kdiv != 1)) return BOFI_ERR_ARG;
     if (drop_p > 0.f) { p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); p.drop_scale = 1.0f / (1.0f - drop_p); }
     return in_dtype == BOFI_DT_F32 ? launch_t<float>(p, (hipStream_t)stream) : launch_t<bf16_t>(p, (hipStream_t)stream);

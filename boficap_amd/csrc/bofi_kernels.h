@@ -62,6 +62,7 @@ struct AttnArgs {
     // NULL: the dense layout b * Lq, Lq rows); k_ragged: its keys / values are laid out the same way (self-attention) instead of
     // (b / kdiv) * Lk.  klen is then indexed by the global query row.  Lq / Lk stay the maxima (they size the kernel).
     const int* q_start; const int* q_count; int k_ragged;
+    int q_rows;                   // > 0 with q_start: rows of the q / out buffers; the bf16 kernels clear the rows behind the last item
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible

@@ -448,10 +448,11 @@ class AttentionFn(Function):
             # bf16 projections from the GEMM epilogue in, bf16 context out (the operand of the output projection):
             # ``out`` stays an unfilled placeholder
             out = _empty(qbuf, qbuf.shape[0], d)              # placeholder: consumers read the bf16 copy
-            ob = _rows_alloc((qbuf.shape[0], d), torch.bfloat16, qbuf.device, seg is not None, tail)
+            ob = torch.empty(qbuf.shape[0], d, dtype=torch.bfloat16, device=qbuf.device)      # (unpadded rows: the kernel clears the trailing rows)
             _chk(_lib().bofi_attention_ex(_off(qs, qoff), ldq, _off(kvs, koff), ldk, _off(kvs, voff), ldk, hip.ptr(ob), d, hip.DT_BF16, B, H,
                                           Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, drop[0] if drop else 0.0,
-                                          drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, sp[0], sp[1], sp[2], hip.stream_ptr()),
+                                          drop[1] if drop else 0, hip.ptr(drop[2]) if drop else None, sp[0], sp[1], sp[2],
+                                          qbuf.shape[0] if seg is not None else 0, hip.stream_ptr()),
                  "bofi_attention_ex")
             _register_shadow(out, ob, only=True)
             ctx.save_for_backward(qs, kvs)
@@ -460,7 +461,7 @@ class AttentionFn(Function):
             out = _rows_alloc((qbuf.shape[0], d), torch.float32, qbuf.device, seg is not None, tail)
             drop = None                                        # dropout(p_attn) is built into the bf16 kernels only
             _chk(_lib().bofi_attention_ex(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(out), d, F32, B, H,
-                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, 0.0, 0, None, sp[0], sp[1], sp[2],
+                                          Lq, Lk, kdiv, hip.ptr(klen), klen_sb, klen_sq, klen_bias, 0.0, 0, None, sp[0], sp[1], sp[2], 0,
                                           hip.stream_ptr()), "bofi_attention_ex")
             ctx.save_for_backward(qbuf, kvbuf)
         ctx.drop = drop
@@ -486,15 +487,15 @@ class AttentionFn(Function):
         fits = (ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64)
         # grad_bf16: q (and, for a packed self-attention, k and v) come straight from a projection GEMM whose backward wants
         # its dz in bf16 anyway -- the MFMA kernel writes that, and autograd gets an unfilled float32 placeholder carrying it
-        qb16 = ctx.mfma and ctx.grad_bf16 and fits and (ctx.seg is None or tail is not None)
+        qb16 = ctx.mfma and ctx.grad_bf16 and fits
         if qb16:
             dq = torch.empty(qbuf.shape, dtype=torch.float32, device=qbuf.device)
-            dq_out = _rows_alloc(qbuf.shape, torch.bfloat16, qbuf.device, ctx.seg is not None, tail)
+            dq_out = torch.empty(qbuf.shape, dtype=torch.bfloat16, device=qbuf.device)
             _register_shadow(dq, dq_out, only=True)            # (listed as a placeholder: any float32 reader of it raises)
             dkv = dq if ctx.same else torch.empty(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
-        elif ctx.seg is not None and ctx.mfma and tail is not None and fits:
-            # unpadded rows: the kernel writes every caption's rows; only the rows behind the last caption need zeros
-            dq = dq_out = _rows_alloc(qbuf.shape, torch.float32, qbuf.device, True, tail)
+        elif ctx.seg is not None and ctx.mfma and fits:
+            # unpadded rows: the kernel writes every caption's rows and clears the rows behind the last caption (q_rows)
+            dq = dq_out = torch.empty(qbuf.shape, dtype=torch.float32, device=qbuf.device)
             dkv = dq if ctx.same else torch.empty(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
         else:
             dq = dq_out = alloc(qbuf.shape, dtype=torch.float32, device=qbuf.device)
@@ -507,7 +508,7 @@ class AttentionFn(Function):
                                                 B16c if qb16 else F32c, B16c if (qb16 and ctx.same) else F32c, B, H, Lq, Lk,
                                                 kdiv, hip.ptr(ctx.klen), sb, sq, bias, ctx.drop[0] if ctx.drop else 0.0,
                                                 ctx.drop[1] if ctx.drop else 0, hip.ptr(ctx.drop[2]) if ctx.drop else None, sp[0], sp[1], sp[2],
-                                                hip.stream_ptr()), "bofi_attention_bwd_mfma")
+                                                qbuf.shape[0] if (ctx.seg is not None and fits) else 0, hip.stream_ptr()), "bofi_attention_bwd_mfma")
             return (dq, None if ctx.same else dkv) + (None,) * 15
         _chk(_lib().bofi_attention_bwd(_off(qbuf, qoff), ldq, _off(kvbuf, koff), ldk, _off(kvbuf, voff), ldk, hip.ptr(dout), H * 64,
                                        _off(dq, qoff), _off(dkv, koff), _off(dkv, voff), B, H, Lq, Lk, kdiv, hip.ptr(ctx.klen), sb, sq, bias,

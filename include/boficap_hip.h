@@ -87,11 +87,13 @@ int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, 
  * keep(b, h, q, k) = hash(drop_seed + *drop_step, ((b*H + h)*Lq + q)*Lk + k) >= drop_p * 2^32, kept ones / (1 - drop_p).
  * q_start / q_count (int32 [B] each, or both NULL): unpadded rows -- batch item b owns the q_count[b] query rows starting at
  * row q_start[b]; with k_ragged its keys / values are laid out the same way (self-attention), else (b / kdiv) * Lk as usual;
+ * q_rows > 0 (bf16 kernels, the MFMA backward): total rows of the q / out buffers -- the rows behind the last item, which no item
+ * owns, are written as zeros (0: left untouched);
  * klen is then indexed by the global query row; Lq / Lk are the maxima.  Same three arguments on the two backward entry points. */
 int bofi_attention_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                       int ldo, int dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen,
                       int klen_sb, int klen_sq, int klen_bias, float drop_p, uint64_t drop_seed,
-                      const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged, void* stream);
+                      const uint64_t* drop_step, const int* q_start, const int* q_count, int k_ragged, int q_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training ops (float32).  The reference trains by running torch autograd over
@@ -125,7 +127,7 @@ int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, cons
                             const float* dout, int ldo, void* dq, int lddq, void* dk, void* dv, int lddk, int dq_dtype,
                             int dkv_dtype, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb, int klen_sq,
                             int klen_bias, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, const int* q_start,
-                            const int* q_count, int k_ragged, void* stream);
+                            const int* q_count, int k_ragged, int q_rows, void* stream);
 /* backward of log_softmax given the log-probabilities y: dx = dy - exp(y) * rowsum(dy) */
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
