@@ -275,7 +275,7 @@ def main_rl(args):
     model = models.setup(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev).train()
-    tr = XETrainer(model, opt)
+    tr = XETrainer(model, opt, graph=not args.no_graph)
     # images whose first bound step opens a phrase: one image without any phrase NaNs the whole semi-autoregressive batch
     # (TransformerModel.py:1956-1958, reproduced), which would turn the SAIC half of the step into a no-op
     pool = torch.from_numpy(W.synthetic_att_feats(6 * n_img, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)

@@ -130,14 +130,14 @@ class WeightOperands:
 
     # ---- what xe._operand / xe._transposed ask (None: not a bucket weight, or not known yet -> the per-use path)
     def operand(self, w: torch.Tensor, N: int, K: int):
-        if K % 64:
+        if K % 64 or self._version is None:                     # (no copy of the bucket has been made yet)
             return None
         o = self._offset_of(w, N * K)
         return None if o is None else self.shadow[o:o + N * K].view(N, K)
 
     def transposed(self, w: torch.Tensor, N: int, K: int):
         o = self._offset_of(w, N * K)
-        if o is None:
+        if o is None or self._version is None:
             return None
         hit = self._views.get((o, N, K))
         if hit is None and (o, N, K) not in self._pending:
@@ -281,6 +281,8 @@ class XETrainer:
         self.bucket.zero_grad()
         armed = self.ops is not None and self.model.train_dtype == torch.bfloat16
         if armed:
+            if not self._capturing():
+                self.ops.refresh_if_stale()
             self.ops.launch_transposes()
             xe._WEIGHTS["provider"] = self.ops
         if self.grouped_dw:
@@ -423,26 +425,48 @@ class XETrainer:
         seq_s, seq_n = saic["seq"].cpu(), naic["seq"].cpu()    # the scorer runs on the host
         self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean()}
         s_saic, s_naic = score_fn(seq_s), score_fn(seq_n)
-        self.bucket.zero_grad()
+        dev = att_feats.device
+        # the gradient pass reads tensors only: the samples' index tensors (host collate of the sampled layouts) and the scores
+        b = {"att_feats": att_feats, "seq_saic": saic["seq"].to(dev).long(), "seq_naic": naic["seq"].to(dev).long(),
+             "sc_saic": torch.as_tensor(s_saic, dtype=torch.float32).to(dev), "sc_naic": torch.as_tensor(s_naic, dtype=torch.float32).to(dev)}
+        b.update(xe.rl_prepare(model.cfg, saic, naic, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
         self._fwd_calls += 1
         step_word = getattr(self, "_step_word", None)
         if step_word is not None:
             step_word.fill_(self._fwd_calls)
+        if self.ops is not None and model.train_dtype == torch.bfloat16:
+            self.ops.refresh_if_stale()
+        if self.graph and att_masks is None and not self._capturing():
+            loss, m1, m2 = self._rl_replay(b, sample_n)
+        else:
+            loss, m1, m2 = self._rl_forward_backward(b, att_masks, sample_n)
+        scale = self.bucket.all_reduce(self.group)
+        self.optimizer_step(scale)
+        return loss, m1, m2
+
+    def _rl_forward_backward(self, b, att_masks, sample_n):
+        """zero-grad, differentiable re-forward of the sampled captions, new_self_critical for both modes, backward (tensors in,
+        device scalars out: what a captured self-critical step replays)."""
+        from . import xe
+        model = self.model
+        self.bucket.zero_grad()
+        step_word = getattr(self, "_step_word", None)
         base = int(getattr(model.opt, "seed", 0)) << 32
         armed = self.ops is not None and model.train_dtype == torch.bfloat16
         if armed:
-            self.ops.refresh_if_stale()
+            if not self._capturing():
+                self.ops.refresh_if_stale()
             self.ops.launch_transposes()
             xe._WEIGHTS["provider"] = self.ops
         if self.grouped_dw:
             xe._DEFER["list"] = []
         try:
-            lp_saic, lp_naic = xe.sampled_logprobs(xe.Params(model), model.cfg, att_feats, att_masks, saic, naic, sample_n=sample_n,
-                                                   strict_q1=model.strict_reference, training=model.training,
-                                                   seed=base if step_word is not None else base + self._fwd_calls,
-                                                   compute_dtype=model.train_dtype, step_word=step_word)
-            l1, r1 = xe.new_self_critical(lp_saic, saic["seq"], s_saic, sample_n)
-            l2, r2 = xe.new_self_critical(lp_naic, naic["seq"], s_naic, sample_n)
+            lp_saic, lp_naic = xe.sampled_logprobs_prepared(xe.Params(model), model.cfg, b["att_feats"], att_masks, b, sample_n=sample_n,
+                                                            training=model.training,
+                                                            seed=base if step_word is not None else base + self._fwd_calls,
+                                                            compute_dtype=model.train_dtype, step_word=step_word)
+            l1, r1 = xe.new_self_critical(lp_saic, b["seq_saic"], b["sc_saic"], sample_n)
+            l2, r2 = xe.new_self_critical(lp_naic, b["seq_naic"], b["sc_naic"], sample_n)
             loss = l1 + l2
             loss.backward()
             xe.flush_weight_grads()
@@ -451,9 +475,29 @@ class XETrainer:
             if armed:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()
-        scale = self.bucket.all_reduce(self.group)
-        self.optimizer_step(scale)
         return loss.detach(), r1.mean(), r2.mean()
+
+    def _rl_replay(self, b, sample_n):
+        """The gradient pass of the self-critical step as one hipGraph per input signature (shapes are fixed by images x samples)."""
+        keys = sorted(b)
+        key = ("rl", tuple((k, tuple(b[k].shape), b[k].dtype) for k in keys), sample_n, self.model.training, self.model.train_dtype)
+        entry = self._graphs.get(key)
+        if entry is None and len(self._graphs) >= self.max_graphs:
+            return self._rl_forward_backward(b, None, sample_n)
+        if entry is None:
+            static = {k: b[k].clone() for k in keys}
+            self._rl_forward_backward(static, None, sample_n)      # warm-up outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._rl_forward_backward(static, None, sample_n)
+            entry = self._graphs[key] = (g, static, out)
+        g, static, out = entry
+        pairs = [(static[k], b[k]) for k in keys if static[k].data_ptr() != b[k].data_ptr()]
+        if pairs:
+            torch._foreach_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs], non_blocking=True)
+        g.replay()
+        return out
 
     # ------------------------------------------------------------------ checkpoint (optimizer.pth of misc.py:87-102)
     def state_dict(self):

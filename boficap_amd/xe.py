@@ -1193,24 +1193,49 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
     return sum(parts), parts
 
 
-@_scoped_compute_dtype
-def sampled_logprobs(P, cfg, att_feats, att_masks, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool = True, training: bool = False,
-                     seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
-    """Token log-probs of SAMPLED captions with the autograd tape: the differentiable half of the self-critical step.
-
-    The reference samples with gradients enabled (loss_wrapper.py:193-209: ``model(..., mode='sample')`` in SAIC and in NAIC
-    mode, then ``struc_crit(seq_logprobs, seq, gts)``).  Here the engine samples without a tape and this function recomputes
-    the log-probs of what was sampled: given a sampled slot layout the distribution of every position is exactly the
-    teacher-forced one -- ``decode_SA`` on the sampled caption (inputs of a phrase = the previous phrase squeezed / stretched,
-    block mask; TransformerModel.py:1933-1952 does this per iteration) resp. ``decode_NA`` on the layout's syntactic labels
-    (:1870-1875, with quirk Q1's fill mask when ``strict_q1``).  Slot layouts are discrete: no gradient reaches the bound layer,
-    as in the reference.
-
-    ``saic`` / ``naic``: dicts with ``seq`` [N, S] int64, ``phrase_length`` [N, S] and ``phrase_syn`` [N, S] as returned by
-    ``_sample`` (N = images x sample_n, image b's copies in rows b*n..b*n+n-1).  Returns (saic_logprobs, naic_logprobs), each
-    [N, S, V] float32 or None.  One encoder pass serves both."""
+def rl_prepare(cfg, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool = True, device=None):
+    """Host half of ``sampled_logprobs``: the sampled captions' slot layouts -> the index tensors the decoder passes read
+    (the loader's collate on the samples, boficap_amd.collate.phrase_collate).  Returns a dict of device tensors:
+    ``sa_seq`` / ``sa_syn`` int64 [N, S], ``sa_klen`` int32 [N, S] (decode_SA inputs and key counts), ``na_syn`` int64 [N, S],
+    ``na_klen`` int32 [N, S] (decode_NA; quirk Q1's fill mask when ``strict_q1``) -- for the modes given."""
     import numpy as np
     from .collate import phrase_collate
+    S = cfg.seq_length
+    out = {}
+
+    def layout(r):
+        seq = r["seq"].detach().cpu().numpy().astype(np.int64)
+        N = seq.shape[0]
+        if seq.shape[1] != S or N % sample_n:
+            raise hip.BofiHipError(f"sampled captions {seq.shape} for {sample_n} samples per image")
+        labels = np.zeros((N, S + 2), np.int64)
+        labels[:, 0] = cfg.bos_idx            # core_SAIC starts from seq[:, 0] = BOS (TransformerModel.py:1900); the loader's labels have 0 there
+        labels[:, 1:S + 1] = seq
+        plen = r["phrase_length"].detach().cpu().numpy().astype(np.int64)
+        psyn = np.where(plen > 0, r["phrase_syn"].detach().cpu().numpy().astype(np.int64), 0)
+        return phrase_collate(labels, plen, psyn, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx, len_idx=cfg.len_idx)
+
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    if saic is not None:
+        c = layout(saic)
+        out["sa_syn"] = to(c["extend_phrase_syn_seq"][:, 1:-1])
+        out["sa_seq"] = to(c["extend_phrase_seq"])
+        out["sa_klen"] = to(c["extend_phrase_seq_mask"].sum(-1).astype(np.int32))
+    if naic is not None:
+        c = layout(naic)
+        N = c["phrase_length"].shape[0]
+        out["na_syn"] = to(c["extend_phrase_syn_seq"][:, 1:-1])
+        last = c["phrase_length"][:, 1:].sum(1) + 1                       # 1 + tokens laid out (TransformerModel.py:1859-1866)
+        fill = np.full(N, last[-1] - 1) if strict_q1 else last - 1       # Q1: every row's fill mask uses the LAST row's length (:1872-1873)
+        out["na_klen"] = to(np.repeat(fill[:, None], S, 1).astype(np.int32))
+    return out
+
+
+@_scoped_compute_dtype
+def sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, *, sample_n: int = 1, training: bool = False, seed: Optional[int] = None,
+                              compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
+    """Device half of ``sampled_logprobs``: tensors in, log-probs out, no host work (``att_masks`` None) -- what a captured
+    self-critical step replays.  ``prep``: rl_prepare's dict."""
     dev = att_feats.device
     S, d = cfg.seq_length, cfg.d_model
     if compute_dtype not in (torch.float32, torch.bfloat16):
@@ -1236,36 +1261,43 @@ def sampled_logprobs(P, cfg, att_feats, att_masks, saic=None, naic=None, *, samp
         x = embed(P[tname], P[sname], pe, tok, syn, S, P.g(tname), P.g(sname))
         return drop(x) if drop.on and drop.p > 0.0 else x
 
-    def layout(r):
-        seq = r["seq"].detach().cpu().numpy().astype(np.int64)
-        if seq.shape != (N, S):
-            raise hip.BofiHipError(f"sampled captions {seq.shape} for {B} images x {sample_n} samples")
-        labels = np.zeros((N, S + 2), np.int64)
-        labels[:, 0] = cfg.bos_idx            # core_SAIC starts from seq[:, 0] = BOS (TransformerModel.py:1900); the loader's labels have 0 there
-        labels[:, 1:S + 1] = seq
-        plen = r["phrase_length"].detach().cpu().numpy().astype(np.int64)
-        psyn = np.where(plen > 0, r["phrase_syn"].detach().cpu().numpy().astype(np.int64), 0)
-        return phrase_collate(labels, plen, psyn, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx, len_idx=cfg.len_idx)
-
     def tokens(x):
         return log_softmax(P.lin(x, "model.generator.proj")).view(N, S, -1)
 
+    def check(t, dtype):
+        if t.shape != (N, S) or t.dtype != dtype:
+            raise hip.BofiHipError(f"prepared tensor {tuple(t.shape)} {t.dtype}: {(N, S)} {dtype} expected ({B} images x {sample_n} samples)")
+        return t.contiguous()
+
     out = [None, None]
-    if saic is not None:
-        c = layout(saic)
-        syn_mid = torch.from_numpy(np.ascontiguousarray(c["extend_phrase_syn_seq"][:, 1:-1])).to(dev)
-        ext_seq = torch.from_numpy(c["extend_phrase_seq"]).to(dev)
-        klen = torch.from_numpy(c["extend_phrase_seq_mask"].sum(-1).astype(np.int32)).to(dev)
-        out[0] = tokens(decode_rows(P, cfg, drop, emb(ext_seq, syn_mid), memory, kv_cache, N, S, R, sample_n, klen, att_len_cap))
-    if naic is not None:
-        c = layout(naic)
-        syn_mid = torch.from_numpy(np.ascontiguousarray(c["extend_phrase_syn_seq"][:, 1:-1])).to(dev)
-        last = c["phrase_length"][:, 1:].sum(1) + 1                       # 1 + tokens laid out (TransformerModel.py:1859-1866)
-        fill = np.full(N, last[-1] - 1) if strict_q1 else last - 1       # Q1: every row's fill mask uses the LAST row's length (:1872-1873)
-        klen = torch.from_numpy(np.repeat(fill[:, None], S, 1).astype(np.int32)).to(dev).contiguous()
+    if "sa_seq" in prep:
+        out[0] = tokens(decode_rows(P, cfg, drop, emb(check(prep["sa_seq"], torch.int64), check(prep["sa_syn"], torch.int64)), memory, kv_cache,
+                                    N, S, R, sample_n, check(prep["sa_klen"], torch.int32), att_len_cap))
+    if "na_syn" in prep:
         bos = torch.full((N, S), cfg.bos_idx, dtype=torch.int64, device=dev)
-        out[1] = tokens(decode_rows(P, cfg, drop, emb(bos, syn_mid), memory, kv_cache, N, S, R, sample_n, klen, att_len_cap))
+        out[1] = tokens(decode_rows(P, cfg, drop, emb(bos, check(prep["na_syn"], torch.int64)), memory, kv_cache, N, S, R, sample_n,
+                                    check(prep["na_klen"], torch.int32), att_len_cap))
     return out[0], out[1]
+
+
+def sampled_logprobs(P, cfg, att_feats, att_masks, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool = True, training: bool = False,
+                     seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
+    """Token log-probs of SAMPLED captions with the autograd tape: the differentiable half of the self-critical step.
+
+    The reference samples with gradients enabled (loss_wrapper.py:193-209: ``model(..., mode='sample')`` in SAIC and in NAIC
+    mode, then ``struc_crit(seq_logprobs, seq, gts)``).  Here the engine samples without a tape and this function recomputes
+    the log-probs of what was sampled: given a sampled slot layout the distribution of every position is exactly the
+    teacher-forced one -- ``decode_SA`` on the sampled caption (inputs of a phrase = the previous phrase squeezed / stretched,
+    block mask; TransformerModel.py:1933-1952 does this per iteration) resp. ``decode_NA`` on the layout's syntactic labels
+    (:1870-1875, with quirk Q1's fill mask when ``strict_q1``).  Slot layouts are discrete: no gradient reaches the bound layer,
+    as in the reference.
+
+    ``saic`` / ``naic``: dicts with ``seq`` [N, S] int64, ``phrase_length`` [N, S] and ``phrase_syn`` [N, S] as returned by
+    ``_sample`` (N = images x sample_n, image b's copies in rows b*n..b*n+n-1).  Returns (saic_logprobs, naic_logprobs), each
+    [N, S, V] float32 or None.  One encoder pass serves both.  = rl_prepare (host) + sampled_logprobs_prepared (device)."""
+    prep = rl_prepare(cfg, saic, naic, sample_n=sample_n, strict_q1=strict_q1, device=att_feats.device)
+    return sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, sample_n=sample_n, training=training, seed=seed,
+                                     compute_dtype=compute_dtype, step_word=step_word)
 
 
 def new_self_critical(logprobs, seq, scores, sample_n: int):

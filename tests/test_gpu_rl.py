@@ -188,3 +188,36 @@ def test_rl_step_with_ragged_regions_and_bf16(weight_cache, manifest):
     model.train()
     loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rl_gradient_pass_replayed_as_a_graph(weight_cache, manifest, dtype):
+    """The gradient pass of the self-critical step (re-forward of the samples, new_self_critical for both modes, backward)
+    captured as a hipGraph and replayed: same loss and gradients as the eager pass on the same samples and scores."""
+    from boficap_amd import xe
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, eager = _model(weight_cache, manifest)
+    _, _, graphed = _model(weight_cache, manifest)
+    n = 3
+    att = _images().cuda()
+    fc = torch.zeros(att.size(0), 0, device="cuda")
+    ks = ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")
+    eager.eval(); graphed.eval()
+    with torch.no_grad():
+        opt = {"sample_method": "sample", "sample_n": n, "temperature": 1.0}
+        saic = dict(zip(ks, eager(fc, att, None, opt=dict(opt, train_mode="SAIC"), mode="sample")[:5]))
+        naic = dict(zip(ks, eager(fc, att, None, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
+    score = lambda seq: (seq % 5 == 0).float().sum(1) / (seq > 0).float().sum(1).clamp(min=1)
+    b = {"att_feats": att, "seq_saic": saic["seq"].long(), "seq_naic": naic["seq"].long(),
+         "sc_saic": score(saic["seq"].cpu()).cuda(), "sc_naic": score(naic["seq"].cpu()).cuda()}
+    b.update(xe.rl_prepare(cfg, saic, naic, sample_n=n, device="cuda"))
+    for m in (eager, graphed):
+        m.train_dtype = dtype
+    te, tg = XETrainer(eager), XETrainer(graphed, graph=True)
+    le, _, _ = te._rl_forward_backward(b, None, n)
+    for _ in range(2):                                                     # capture, then replay
+        lg, _, _ = tg._rl_replay(b, n)
+    assert torch.isfinite(le) and abs(float(le) - float(lg)) < 1e-5 * max(1.0, abs(float(le)))
+    tol = 1e-4 if dtype == torch.float32 else 4e-4
+    assert float((tg.bucket.grad - te.bucket.grad).abs().max()) <= tol * max(1e-3, float(te.bucket.grad.abs().max()))
+    assert float(te.bucket.grad.abs().max()) > 0
