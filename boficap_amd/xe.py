@@ -1270,6 +1270,26 @@ def sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, *, sample_n: i
         return t.contiguous()
 
     out = [None, None]
+    if "sa_seq" in prep and "na_syn" in prep:
+        # both modes: one decoder pass over 2N captions (same layers, same weights; every launch is latency-bound at these sizes,
+        # see _forward_paired).  Image-major order -- image i's SAIC samples, then its NAIC samples -- keeps the 2n captions that
+        # share an image's keys adjacent (kdiv = 2n).
+        with torch.no_grad():
+            pn = torch.arange(2 * N, device=dev)
+            j = pn % (2 * sample_n)
+            cap = (pn // (2 * sample_n)) * sample_n + j % sample_n
+            is_na = (j >= sample_n).unsqueeze(1)
+            n_all = torch.arange(N, device=dev)
+            at_sa = (n_all // sample_n) * (2 * sample_n) + n_all % sample_n
+            tok2 = torch.where(is_na, torch.full_like(prep["sa_seq"][cap], cfg.bos_idx), check(prep["sa_seq"], torch.int64)[cap]).contiguous()
+            syn2 = torch.where(is_na, check(prep["na_syn"], torch.int64)[cap], check(prep["sa_syn"], torch.int64)[cap]).contiguous()
+            klen2 = torch.where(is_na, check(prep["na_klen"], torch.int32)[cap], check(prep["sa_klen"], torch.int32)[cap]).contiguous()
+            len2 = None if att_len_cap is None else att_len_cap[cap].contiguous()
+        x = embed(P[tname], P[sname], pe, tok2, syn2, S, P.g(tname), P.g(sname))
+        x = drop(x) if drop.on and drop.p > 0.0 else x
+        x = decode_rows(P, cfg, drop, x, memory, kv_cache, 2 * N, S, R, 2 * sample_n, klen2, len2)
+        lp = log_softmax(P.lin(x, "model.generator.proj")).view(2 * N, S, -1)
+        return lp.index_select(0, at_sa), lp.index_select(0, at_sa + sample_n)
     if "sa_seq" in prep:
         out[0] = tokens(decode_rows(P, cfg, drop, emb(check(prep["sa_seq"], torch.int64), check(prep["sa_syn"], torch.int64)), memory, kv_cache,
                                     N, S, R, sample_n, check(prep["sa_klen"], torch.int32), att_len_cap))
