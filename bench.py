@@ -103,6 +103,15 @@ def gemm_rooflines(dtype, dev):
     return out
 
 
+def xe_traffic(args):
+    """HBM bytes per XE step from the committed PMC passes -- for the configuration they were taken on only."""
+    path = os.path.join(ROOT, "profiles", "r01_xe_hbm_traffic.json")
+    if args.batch != 64 or args.seq_per_img != 5 or args.dtype != "bf16" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_step")
+
+
 def f_alg_xe(cfg, seq_per_img: int, passes: float) -> float:
     """Algorithmic forward FLOPs per IMAGE of the XE step as the reference computes it: the encoder on
     every caption copy, `passes` full bound-layer passes per branch, two decoder passes and two vocabulary projections
@@ -230,7 +239,9 @@ def main_xe(args):
                        "final_loss": round(float(loss), 4), "parameters": tr.bucket.numel, "host_enqueue_ms_per_step": round(host_ms, 3),
                        "sharding": "images by rank; one RCCL all-reduce over the flat fp32 gradient bucket per step"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": xe_traffic(args),
+                         "traffic_note": "HBM-side bytes per step, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate "
+                                         "passes (profiles/r01_xe_hbm_traffic.json, batch 64 x 5 bf16); null for other configurations",
                          "kernel": "whole XE step (" + ("one hipGraph launch + all-reduce + Adam kernel" if tr.graph else "eager launches") + ")",
                          "flops_per_launch": flops, "launch_ms": round(dev_ms, 3),
                          "note": "algorithmic FLOPs of the step as the reference computes it (SURVEY.md 8d: encoder per caption copy, "
