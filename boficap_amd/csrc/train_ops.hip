@@ -203,6 +203,18 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
     for (int i = tid; i < V; i += 256) dx[(size_t)row * V + i] = dyr[i] - expf(yr[i]) * s;
 }
 
+// backward of picked[r] = y[r][label[r]] through log_softmax, y = log-probabilities: dx[r][c] = dpicked[r] * ((c == label[r]) - exp(y[r][c]))
+// (the token NLL of the criterion: no dense dL/dy tensor is built, zero-filled and scattered into)
+__global__ __launch_bounds__(256) void nll_bwd_kernel(const float* __restrict__ y, const int64_t* __restrict__ label, const float* __restrict__ dpicked,
+                                                      float* __restrict__ dx, int V) {
+    const int row = blockIdx.x;
+    const float g = dpicked[row];
+    const int lab = (int)label[row];
+    const float* yr = y + (size_t)row * V;
+    float* dr = dx + (size_t)row * V;
+    for (int i = threadIdx.x; i < V; i += 256) dr[i] = g == 0.f ? 0.f : g * ((i == lab ? 1.f : 0.f) - expf(yr[i]));
+}
+
 // column sums (bias gradients): out[n] += sum_m x[m][n]
 __global__ void colsum_kernel(const float* __restrict__ x, float* out, int M, int N) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,6 +558,14 @@ extern "C" int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, i
     if (!y || !dy || !dx || rows < 0 || V <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
     hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, V);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_nll_bwd(const float* y, const int64_t* labels, const float* dpicked, float* dx, int rows, int V, void* stream) {
+    if (!y || !labels || !dpicked || !dx || rows < 0 || V <= 0) return BOFI_ERR_ARG;
+    if (rows == 0) return BOFI_OK;
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, labels, dpicked, dx, V);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -317,6 +317,7 @@ class XETrainer:
         paired = compact and batch.get("row_cap") is not None and batch.get("pair_src") is not None
         if paired:
             xe.HINTS["paired"] = (batch["pair_start"], batch["pair_count"], batch["pair_src"], batch["pair_na"], 256)
+            xe.HINTS["pick_labels"] = batch["pair_labels"]      # the criterion's token labels: picked inside the forward
             xe.HINTS.pop("streams", None)
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],

@@ -590,6 +590,48 @@ def log_softmax(logits):
     return LogSoftmaxFn.apply(logits)
 
 
+class PickLogSoftmaxFn(Function):
+    """(log_softmax(logits) in place, its entry at labels[r] per row): the token NLL's gather fused with the log-softmax.  When only
+    the picked values carry a gradient -- the training step -- the backward is ONE pass over the log-probs (bofi_nll_bwd) instead
+    of a zero-filled dense dL/dy, a scatter into it and the log-softmax backward reading it back."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = _need(logits, "log_softmax input")
+        rows, V = logits.shape
+        labels = labels.to(torch.int64).contiguous()
+        ids = torch.empty(rows, dtype=torch.int64, device=logits.device)
+        if rows:
+            _chk(_lib().bofi_vocab_finalize(hip.ptr(logits), rows, V, 1, 1, None, 0, hip.ptr(ids), hip.stream_ptr()), "bofi_vocab_finalize")
+        picked = logits.gather(1, labels.unsqueeze(1)).squeeze(1)
+        ctx.mark_dirty(logits)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(logits, labels)
+        return logits, picked
+
+    @staticmethod
+    def backward(ctx, g_logp, g_picked):
+        y, labels = ctx.saved_tensors
+        if g_logp is None and g_picked is None:
+            return None, None
+        dx = torch.empty_like(y)
+        if g_logp is None:
+            _chk(_lib().bofi_nll_bwd(hip.ptr(y), hip.ptr(labels), hip.ptr(_need(g_picked, "picked gradient")), hip.ptr(dx), y.shape[0], y.shape[1],
+                                     hip.stream_ptr()), "bofi_nll_bwd")
+            return dx, None
+        dy = _need(g_logp, "log_softmax dy")
+        if g_picked is not None:                               # both outputs used: fold the picked gradient into the dense one
+            dy = dy.clone()
+            dy.scatter_add_(1, labels.unsqueeze(1), g_picked.unsqueeze(1))
+        _chk(_lib().bofi_logsoftmax_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dx), y.shape[0], y.shape[1], hip.stream_ptr()), "bofi_logsoftmax_bwd")
+        return dx, None
+
+
+def log_softmax_pick(logits, labels):
+    """(log-probs [T, V], log-probs at labels [T]); see PickLogSoftmaxFn."""
+    return PickLogSoftmaxFn.apply(logits, labels)
+
+
 def greedy_ids(logits):
     """argmax over the last dim (first maximal index), no tape; the logits are consumed."""
     rows, V = logits.shape
@@ -908,6 +950,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     unpadded = HINTS.pop("unpadded", None)
     streams = HINTS.pop("streams", None)
     paired = HINTS.pop("paired", None)
+    pick_labels = HINTS.pop("pick_labels", None)
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
@@ -936,7 +979,8 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
                                             att_len_cap)
     if unpadded is not None and paired is not None:
         return _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq,
-                               extend_phrase_seq_mask.to(dev), last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p)
+                               extend_phrase_seq_mask.to(dev), last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p,
+                               pick_labels)
     if unpadded is not None:
         na_bound = lambda: bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
         (sa_len, sa_syn), sa_tok, (na_len, na_syn), na_tok = _fill_unpadded(
@@ -971,7 +1015,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
 
 
 def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq, ext_mask,
-                    last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p):
+                    last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p, pick_labels=None):
     """forward_uic with the SA and the NA branch as ONE batch: one bound pass over 2N captions and one decoder pass over both
     branches' rows, instead of two of each.
 
@@ -1043,7 +1087,11 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
     with torch.no_grad():                                         # the same rows per image: its 2 spi captions are adjacent
         img = (pair_start.view(-1, 2 * spi)[:, 0].contiguous(), pair_count.view(-1, 2 * spi).sum(1).to(torch.int32).contiguous(), 2 * spi * Sd)
     x = decode_rows(P, cfg, drop, emb(tok2, syn2, Sd, pos2), memory, kv_cache, 2 * N, Sd, R, 2 * spi, klen2, cross2, True, seg2, img)
-    tok_all = log_softmax(vocab(x))
+    if pick_labels is not None:                                   # the criterion's token labels are known: pick while the row is at hand
+        tok_all, picked = log_softmax_pick(vocab(x), pick_labels)
+        tok_all._bofi_picked = (picked, pick_labels)
+    else:
+        tok_all = log_softmax(vocab(x))
     return pad_slots(sa_len), pad_slots(sa_syn), tok_all, pad_slots(na_len), pad_slots(na_syn), tok_all
 
 
@@ -1184,7 +1232,11 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
     if pair:
         if sa_tok is not na_tok:
             raise hip.BofiHipError("a pair of token weights goes with the paired log-probs of _forward_paired")
-        picked = -sa_tok.gather(1, token_labels.unsqueeze(1)).squeeze(1)          # one gather (one scatter in backward) for both branches
+        made = getattr(sa_tok, "_bofi_picked", None)              # picked inside the forward (HINTS["pick_labels"]): fused backward
+        if made is not None and made[1] is token_labels:
+            picked = -made[0]
+        else:
+            picked = -sa_tok.gather(1, token_labels.unsqueeze(1)).squeeze(1)      # one gather (one scatter in backward) for both branches
         tok_sa, tok_na = (picked * token_weight[0]).sum() / denom, (picked * token_weight[1]).sum() / denom
     else:
         tok_sa, tok_na = tok(sa_tok), tok(na_tok)

@@ -442,6 +442,26 @@ def test_gemm_tn_accumulates_a_transposed_times_b(M, NI, NJ):
                                              None, hip.stream_ptr()))
 
 
+@pytest.mark.parametrize("dense_too", [False, True])
+def test_log_softmax_pick_against_torch(dense_too):
+    """log_softmax + gather fused (bofi_nll_bwd when only the picked values carry a gradient; dense fallback otherwise)."""
+    from boficap_amd import xe
+    T, V = 70, 1234
+    g = torch.Generator().manual_seed(8)
+    logits, labels, gp = torch.randn(T, V, generator=g) * 3, torch.randint(0, V, (T,), generator=g), torch.randn(T, generator=g)
+    gp[::7] = 0.0                                                       # zero-weight rows (padding rows of the row list)
+    gd = torch.randn(T, V, generator=g) * 0.1
+    ref_in = logits.clone().requires_grad_()
+    lp = torch.log_softmax(ref_in, 1)
+    loss = (lp.gather(1, labels[:, None]).squeeze(1) * gp).sum() + ((lp * gd).sum() if dense_too else 0.0)
+    loss.backward()
+    x = logits.clone().cuda().requires_grad_()
+    y, picked = xe.log_softmax_pick(x * 1.0, labels.cuda())
+    assert _maxdiff(y.detach(), lp.detach()) < 1e-5 and _maxdiff(picked.detach(), lp.detach().gather(1, labels[:, None]).squeeze(1)) < 1e-5
+    ((picked * gp.cuda()).sum() + ((y * gd.cuda()).sum() if dense_too else 0.0)).backward()
+    assert _maxdiff(x.grad, ref_in.grad) < 1e-5 * max(1.0, float(ref_in.grad.abs().max()))
+
+
 def test_layernorm_backward_hands_the_masked_gradient_to_its_producer():
     """x = r + dropout(x0 W^T + b) in the GEMM epilogue, n = LayerNorm(x): the LayerNorm backward also writes the linear's
     dz = mask o dL/dx in bf16 (bofi_layernorm_bwd_ex), which must be the dz the mask-and-cast pass would have made --
