@@ -205,12 +205,19 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
 
 // backward of picked[r] = y[r][label[r]] through log_softmax, y = log-probabilities: dx[r][c] = dpicked[r] * ((c == label[r]) - exp(y[r][c]))
 // (the token NLL of the criterion: no dense dL/dy tensor is built, zero-filled and scattered into)
+// (dx float32 [rows, V], or -- dx_bf16 -- bf16 [rows, ldb] with the columns V..ldb-1 written as zeros: the operand the
+// vocabulary projection's backward GEMMs read)
 __global__ __launch_bounds__(256) void nll_bwd_kernel(const float* __restrict__ y, const int64_t* __restrict__ label, const float* __restrict__ dpicked,
-                                                      float* __restrict__ dx, int V) {
+                                                      float* __restrict__ dx, bf16_t* __restrict__ dx_bf16, int ldb, int V) {
     const int row = blockIdx.x;
     const float g = dpicked[row];
     const int lab = (int)label[row];
     const float* yr = y + (size_t)row * V;
+    if (dx_bf16) {
+        bf16_t* dr = dx_bf16 + (size_t)row * ldb;
+        for (int i = threadIdx.x; i < ldb; i += 256) dr[i] = (g == 0.f || i >= V) ? (bf16_t)0 : f32_to_bf16(g * ((i == lab ? 1.f : 0.f) - expf(yr[i])));
+        return;
+    }
     float* dr = dx + (size_t)row * V;
     for (int i = threadIdx.x; i < V; i += 256) dr[i] = g == 0.f ? 0.f : g * ((i == lab ? 1.f : 0.f) - expf(yr[i]));
 }
@@ -562,10 +569,15 @@ extern "C" int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, i
     return BOFI_OK;
 }
 
-extern "C" int bofi_nll_bwd(const float* y, const int64_t* labels, const float* dpicked, float* dx, int rows, int V, void* stream) {
-    if (!y || !labels || !dpicked || !dx || rows < 0 || V <= 0) return BOFI_ERR_ARG;
+extern "C" int bofi_nll_bwd(const float* y, const int64_t* labels, const float* dpicked, void* dx, int dx_dtype, int lddx, int rows, int V,
+                            void* stream) {
+    if (!y || !labels || !dpicked || !dx || rows < 0 || V <= 0 || lddx < V) return BOFI_ERR_ARG;
+    if (dx_dtype != BOFI_DT_F32 && dx_dtype != BOFI_DT_BF16) return BOFI_ERR_ARG;
+    if (dx_dtype == BOFI_DT_F32 && lddx != V) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(nll_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, labels, dpicked, dx, V);
+    const bool b16 = dx_dtype == BOFI_DT_BF16;
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, labels, dpicked, b16 ? nullptr : (float*)dx,
+                       b16 ? (bf16_t*)dx : nullptr, lddx, V);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

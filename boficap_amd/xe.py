@@ -596,8 +596,9 @@ class PickLogSoftmaxFn(Function):
     of a zero-filled dense dL/dy, a scatter into it and the log-softmax backward reading it back."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, grad_bf16=False):
         logits = _need(logits, "log_softmax input")
+        ctx.grad_bf16 = bool(grad_bf16)
         rows, V = logits.shape
         labels = labels.to(torch.int64).contiguous()
         ids = torch.empty(rows, dtype=torch.int64, device=logits.device)
@@ -613,23 +614,34 @@ class PickLogSoftmaxFn(Function):
     def backward(ctx, g_logp, g_picked):
         y, labels = ctx.saved_tensors
         if g_logp is None and g_picked is None:
-            return None, None
+            return None, None, None
         dx = torch.empty_like(y)
         if g_logp is None:
-            _chk(_lib().bofi_nll_bwd(hip.ptr(y), hip.ptr(labels), hip.ptr(_need(g_picked, "picked gradient")), hip.ptr(dx), y.shape[0], y.shape[1],
+            gp = _need(g_picked, "picked gradient")
+            if ctx.grad_bf16 and _COMPUTE["dtype"] == torch.bfloat16:
+                # the logits have one consumer-producer pair, the vocabulary projection: hand it its dz in bf16 (K-granule padded);
+                # dx stays an unfilled placeholder
+                Vp = (y.shape[1] + 63) // 64 * 64
+                dzb = torch.empty(y.shape[0], Vp, dtype=torch.bfloat16, device=y.device)
+                _chk(_lib().bofi_nll_bwd(hip.ptr(y), hip.ptr(labels), hip.ptr(gp), hip.ptr(dzb), hip.DT_BF16, Vp, y.shape[0], y.shape[1],
+                                         hip.stream_ptr()), "bofi_nll_bwd")
+                _register_shadow(dx, dzb, only=True)
+                return dx, None, None
+            _chk(_lib().bofi_nll_bwd(hip.ptr(y), hip.ptr(labels), hip.ptr(gp), hip.ptr(dx), F32, y.shape[1], y.shape[0], y.shape[1],
                                      hip.stream_ptr()), "bofi_nll_bwd")
-            return dx, None
+            return dx, None, None
         dy = _need(g_logp, "log_softmax dy")
         if g_picked is not None:                               # both outputs used: fold the picked gradient into the dense one
             dy = dy.clone()
             dy.scatter_add_(1, labels.unsqueeze(1), g_picked.unsqueeze(1))
         _chk(_lib().bofi_logsoftmax_bwd(hip.ptr(y), hip.ptr(dy), hip.ptr(dx), y.shape[0], y.shape[1], hip.stream_ptr()), "bofi_logsoftmax_bwd")
-        return dx, None
+        return dx, None, None
 
 
-def log_softmax_pick(logits, labels):
-    """(log-probs [T, V], log-probs at labels [T]); see PickLogSoftmaxFn."""
-    return PickLogSoftmaxFn.apply(logits, labels)
+def log_softmax_pick(logits, labels, grad_bf16=False):
+    """(log-probs [T, V], log-probs at labels [T]); see PickLogSoftmaxFn.  ``grad_bf16``: the logits come straight out of a
+    linear (their only other use) -- its backward gets the gradient in bf16."""
+    return PickLogSoftmaxFn.apply(logits, labels, grad_bf16)
 
 
 def greedy_ids(logits):
@@ -1088,7 +1100,7 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
         img = (pair_start.view(-1, 2 * spi)[:, 0].contiguous(), pair_count.view(-1, 2 * spi).sum(1).to(torch.int32).contiguous(), 2 * spi * Sd)
     x = decode_rows(P, cfg, drop, emb(tok2, syn2, Sd, pos2), memory, kv_cache, 2 * N, Sd, R, 2 * spi, klen2, cross2, True, seg2, img)
     if pick_labels is not None:                                   # the criterion's token labels are known: pick while the row is at hand
-        tok_all, picked = log_softmax_pick(vocab(x), pick_labels)
+        tok_all, picked = log_softmax_pick(vocab(x), pick_labels, True)
         tok_all._bofi_picked = (picked, pick_labels)
     else:
         tok_all = log_softmax(vocab(x))

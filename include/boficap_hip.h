@@ -132,8 +132,10 @@ int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, cons
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
 /* backward of picked[r] = y[r][labels[r]] straight through the log_softmax that made y (the token terms of
  * LanguageModelCriterion_UIC, losses.py:341-347: gather on the log-probs): dx[r][c] = dpicked[r] * ((c == labels[r]) - exp(y[r][c])).
- * labels must lie in [0, V). */
-int bofi_nll_bwd(const float* y, const int64_t* labels, const float* dpicked, float* dx, int rows, int V, void* stream);
+ * labels must lie in [0, V).  dx: float32 [rows, V] (lddx == V), or bf16 [rows, lddx] with lddx >= V and the columns V..lddx-1
+ * written as zeros (the operand the vocabulary projection's backward GEMMs read, K granule 64). */
+int bofi_nll_bwd(const float* y, const int64_t* labels, const float* dpicked, void* dx, int dx_dtype, int lddx, int rows, int V,
+                 void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
 /* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[pos ? pos[r] : r % L]; tok or syn may be NULL, a negative id
