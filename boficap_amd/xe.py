@@ -1026,6 +1026,28 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
 
 
+_ORDER_CACHE: dict = {}
+
+
+def _paired_order(N, spi, dev):
+    """Index tensors of the image-major paired caption order for N captions, spi per image: (caption of paired slot p [2N],
+    is-NA flag [2N, 1], slot of caption n's SA copy [N], of its NA copy [N]).  Functions of the batch SHAPE only: made once and
+    kept (inside a captured step they would be a dozen tiny launches per replay)."""
+    key = (N, spi, str(dev))
+    hit = _ORDER_CACHE.get(key)
+    if hit is None:
+        pn = torch.arange(2 * N, device=dev)
+        j = pn % (2 * spi)
+        cap_n = (pn // (2 * spi)) * spi + j % spi
+        cap_na = (j >= spi).unsqueeze(1)
+        n_all = torch.arange(N, device=dev)
+        at_sa = (n_all // spi) * (2 * spi) + n_all % spi
+        hit = _ORDER_CACHE[key] = (cap_n, cap_na, at_sa, at_sa + spi)
+        if len(_ORDER_CACHE) > 64:
+            _ORDER_CACHE.pop(next(iter(_ORDER_CACHE)))
+    return hit
+
+
 def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq, ext_mask,
                     last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p, pick_labels=None):
     """forward_uic with the SA and the NA branch as ONE batch: one bound pass over 2N captions and one decoder pass over both
@@ -1040,7 +1062,8 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
     ``unpadded`` as in _fill_unpadded (the single-branch row list: the glancing pass runs on it); ``paired`` =
     (pair_start int32 [2N], pair_count int32 [2N], pair_src int64 [T2], pair_na bool [T2] [, tail]): row r of the paired list is
     row pair_src[r] of the single list, in the NA branch iff pair_na[r]; T2 padded like T.  Returns the six tensors of
-    forward_uic with BOTH token entries being the paired log-probs [T2, V] (criterion_uic_compact with a pair of weights)."""
+    forward_uic with BOTH token entries being the paired log-probs [T2, V] (criterion_uic_compact with a pair of weights) and the
+    four bound outputs as [N, Pm, .] -- Pm passes, not padded out to seq_length + 1 slots."""
     dev = labels.device
     row_start, row_count, row_cap, row_pos = unpadded[:4]
     pair_start, pair_count, pair_src, pair_na = paired[:4]
@@ -1053,14 +1076,7 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
         klen_na = (last - 1)[row_cap].to(torch.int32)
         cross_len = None if att_len_cap is None else att_len_cap[row_cap]
         T = row_cap.numel()
-        # captions in paired order
-        pn = torch.arange(2 * N, device=dev)
-        j = pn % (2 * spi)
-        cap_n = (pn // (2 * spi)) * spi + j % spi
-        cap_na = (j >= spi).unsqueeze(1)
-        n_all = torch.arange(N, device=dev)
-        at_sa = (n_all // spi) * (2 * spi) + n_all % spi          # where caption n's SA / NA copy sits
-        at_na = at_sa + spi
+        cap_n, cap_na, at_sa, at_na = _paired_order(N, spi, dev)  # captions in paired order (constants of the batch shape)
         tok_b, syn_b = word_seq[cap_n], ext_syn[cap_n]
         none = torch.full_like(tok_b, -1)                         # the SA bound input has no syntactic term, the NA one no token term
         tok_b = torch.where(cap_na, none, tok_b).contiguous()
@@ -1104,7 +1120,9 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
         tok_all._bofi_picked = (picked, pick_labels)
     else:
         tok_all = log_softmax(vocab(x))
-    return pad_slots(sa_len), pad_slots(sa_syn), tok_all, pad_slots(na_len), pad_slots(na_syn), tok_all
+    # the four bound outputs stay [N, Pm, .] (Pm >= the batch's largest phrase count: the slots past it carry no loss weight;
+    # criterion_uic_compact reads as many label slots as there are outputs)
+    return sa_len, sa_syn, tok_all, na_len, na_syn, tok_all
 
 
 class _Fork:
@@ -1236,7 +1254,8 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
     denom = token_weight[0].sum() if pair else token_weight.sum()
 
     def nll(lp, lab, mask):
-        return (-lp.gather(2, lab.unsqueeze(2)).squeeze(2) * mask).sum() / denom
+        P_ = lp.shape[1]                                        # [N, Pm, .] from the paired forward, [N, L - 1, .] otherwise
+        return (-lp.gather(2, lab[:, :P_].unsqueeze(2)).squeeze(2) * mask[:, :P_]).sum() / denom
 
     def tok(lp):
         return (-lp.gather(1, token_labels.unsqueeze(1)).squeeze(1) * token_weight).sum() / denom
