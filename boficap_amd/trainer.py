@@ -226,7 +226,8 @@ class XETrainer:
     _KEYS = ("att_feats", "labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq",
              "extend_phrase_seq_mask")
     _OPT_KEYS = ("token_rows", "token_labels", "token_weight", "row_start", "row_count", "row_cap", "row_pos",
-                 "pair_start", "pair_count", "pair_src", "pair_na", "pair_labels", "pair_w_sa", "pair_w_na")
+                 "pair_start", "pair_count", "pair_src", "pair_na", "pair_labels", "pair_w_sa", "pair_w_na",
+                 "prep_tok_b", "prep_syn_b", "prep_klen_b", "prep_tok2", "prep_syn2", "prep_pos2", "prep_klen2", "prep_img_start", "prep_img_count")
 
     def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
@@ -318,6 +319,8 @@ class XETrainer:
         if paired:
             xe.HINTS["paired"] = (batch["pair_start"], batch["pair_count"], batch["pair_src"], batch["pair_na"], 256)
             xe.HINTS["pick_labels"] = batch["pair_labels"]      # the criterion's token labels: picked inside the forward
+            if batch.get("prep_tok2") is not None and batch.get("att_masks") is None and glat_p < 0:
+                xe.HINTS["paired_inputs"] = {k[5:]: batch[k] for k in self._OPT_KEYS if k.startswith("prep_")}
             xe.HINTS.pop("streams", None)
         outs = self.model(fc, batch["att_feats"], batch["labels"], batch.get("att_masks"), batch["phrase_num"], batch["phrase_length"],
                           batch["phrase_syn"], batch["extend_phrase_syn_seq"], batch["extend_phrase_seq"], batch["extend_phrase_seq_mask"],
@@ -384,6 +387,35 @@ class XETrainer:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
             out.update(pair_start=t(pstart), pair_count=t(cnt.astype(np.int32)), pair_src=t(src), pair_na=t(na), pair_labels=t(lab2),
                        pair_w_sa=t(w2 * ~na), pair_w_na=t(w2 * na))
+            if all(k in host_batch for k in ("phrase_num", "extend_phrase_syn_seq", "extend_phrase_seq", "extend_phrase_seq_mask")) \
+                    and batch.get("max_phrase_num") is not None:
+                # ... and every index tensor the paired forward would otherwise derive on the device (xe._forward_paired): the bound
+                # passes' inputs and key counts, the decoder rows' token / label ids, positions and key counts
+                cfg = self.model.cfg
+                L = S + 2
+                pnum = np.asarray(host_batch["phrase_num"]).reshape(-1)
+                esyn = np.asarray(host_batch["extend_phrase_syn_seq"]).reshape(N, L)
+                eseq = np.asarray(host_batch["extend_phrase_seq"]).reshape(N, -1)
+                emask = np.asarray(host_batch["extend_phrase_seq_mask"]).reshape(N, eseq.shape[1], -1)
+                Pm = self._bucket(int(batch["max_phrase_num"]), S + 1)
+                idx = np.arange(L)[None]
+                cum = 1 + np.where((idx >= 1) & (idx < pnum[:, None]), pl, 0).cumsum(1)       # xe.bound_pass_klen
+                klen_pass, last = cum[:, :Pm], cum[:, -1]
+                word = labels.copy()
+                word[:, 0] = cfg.len_idx
+                none = np.full((2 * N, L), -1, np.int64)
+                rc, rp = cap[:T], pos[:T]                                                # the single list: caption and position per row
+                syn_c = np.zeros(Tp, np.int64); seq_c = np.zeros(Tp, np.int64); k_sa = np.zeros(Tp, np.int32); k_na = np.zeros(Tp, np.int32)
+                syn_c[:T], seq_c[:T] = esyn[rc, rp + 1], eseq[rc, rp]
+                k_sa[:T], k_na[:T] = emask.sum(-1)[rc, rp], (last - 1)[rc]
+                syn_c[T:], seq_c[T:], k_sa[T:], k_na[T:] = esyn[0, 1], eseq[0, 0], emask.sum(-1)[0, 0], (last - 1)[0]   # (padding rows read row 0, as on the device)
+                pos_all = np.zeros(Tp, np.int64); pos_all[:T] = rp
+                out.update(prep_tok_b=t(np.where(cap_na[:, None], none, word[cap_n])), prep_syn_b=t(np.where(cap_na[:, None], esyn[cap_n], none)),
+                           prep_klen_b=t(klen_pass[cap_n].astype(np.int32)),
+                           prep_tok2=t(np.where(na, cfg.bos_idx, seq_c[src])), prep_syn2=t(syn_c[src]), prep_pos2=t(pos_all[src]),
+                           prep_klen2=t(np.where(na, k_na[src], k_sa[src]).astype(np.int32)),
+                           prep_img_start=t(pstart.reshape(-1, 2 * spi)[:, 0].astype(np.int32)),
+                           prep_img_count=t(cnt.reshape(-1, 2 * spi).sum(1).astype(np.int32)))
         return out
 
     def optimizer_step(self, grad_scale: float = 1.0) -> float:

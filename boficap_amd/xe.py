@@ -955,7 +955,14 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     labels, phrase_num, phrase_length = labels.to(dev).long(), phrase_num.to(dev).long(), phrase_length.to(dev).long()
     ext_syn = extend_phrase_syn_seq.to(dev).long().contiguous()
     ext_seq = extend_phrase_seq.to(dev).long().contiguous()
-    klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length, HINTS.pop("max_phrase_num", None))
+    prepared = HINTS.pop("paired_inputs", None)                # the paired step's index tensors, made by the collate on the host
+    if prepared is not None and (glat_p >= 0 or att_len is not None or HINTS.get("paired") is None):
+        prepared = None                                        # (the glancing pass and ragged region masks take the device-side prep)
+    if prepared is None:
+        klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length, HINTS.pop("max_phrase_num", None))
+    else:
+        HINTS.pop("max_phrase_num", None)
+        klen_pass, last, Pm = None, None, int(prepared["klen_b"].shape[1])
     Sd = HINTS.pop("max_tokens", None)
     Sd = S if not Sd else max(1, min(S, int(Sd)))               # decoder positions actually computed
     token_rows = HINTS.pop("token_rows", None)
@@ -984,6 +991,9 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
             return log_softmax(vocab(x)).view(N, Sd, -1)
         return log_softmax(vocab(x.index_select(0, token_rows)))          # [len(token_rows), V]: the real tokens' rows only
 
+    if prepared is not None:
+        return _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, None, phrase_length,
+                               ext_syn, ext_seq, None, None, memory, kv_cache, N, L, Sd, R, spi, None, None, glat_p, pick_labels, prepared)
     # --- semi-autoregressive branch (TransformerModel.py:476-530)
     word_seq = labels.clone()
     word_seq[:, 0] = cfg.len_idx
@@ -1049,7 +1059,7 @@ def _paired_order(N, spi, dev):
 
 
 def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq, ext_mask,
-                    last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p, pick_labels=None):
+                    last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p, pick_labels=None, prepared=None):
     """forward_uic with the SA and the NA branch as ONE batch: one bound pass over 2N captions and one decoder pass over both
     branches' rows, instead of two of each.
 
@@ -1067,6 +1077,26 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
     dev = labels.device
     row_start, row_count, row_cap, row_pos = unpadded[:4]
     pair_start, pair_count, pair_src, pair_na = paired[:4]
+    if prepared is not None:
+        # every index tensor comes from the collate (XETrainer.add_token_rows, numpy): nothing to derive on the device
+        cap_n, cap_na, at_sa, at_na = _paired_order(N, spi, dev)
+        for pre in [f"model.decoder.layers.{l}.src_attn" for l in range(cfg.N_dec)]:
+            if pre not in kv_cache:
+                kv_cache[pre] = P.lin_packed(memory, pre, (1, 2))
+        len_lp, syn_lp = bound_teacher_forced(P, cfg, drop, emb(prepared["tok_b"], prepared["syn_b"], L), memory, kv_cache, 2 * N, L, R, 2 * spi,
+                                              prepared["klen_b"], None)
+        sa_len, sa_syn = len_lp.index_select(0, at_sa), syn_lp.index_select(0, at_sa)
+        na_len, na_syn = len_lp.index_select(0, at_na), syn_lp.index_select(0, at_na)
+        seg2 = (pair_start, pair_count) + tuple(paired[4:5])
+        img = (prepared["img_start"], prepared["img_count"], 2 * spi * Sd)
+        x = decode_rows(P, cfg, drop, emb(prepared["tok2"], prepared["syn2"], Sd, prepared["pos2"]), memory, kv_cache, 2 * N, Sd, R, 2 * spi,
+                        prepared["klen2"], None, True, seg2, img)
+        if pick_labels is not None:
+            tok_all, picked = log_softmax_pick(vocab(x), pick_labels, True)
+            tok_all._bofi_picked = (picked, pick_labels)
+        else:
+            tok_all = log_softmax(vocab(x))
+        return sa_len, sa_syn, tok_all, na_len, na_syn, tok_all
     with torch.no_grad():
         at = row_cap * L + row_pos
         syn_c = ext_syn.reshape(-1)[at + 1]
