@@ -222,6 +222,78 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < V; i += 256) dr[i] = g == 0.f ? 0.f : g * ((i == lab ? 1.f : 0.f) - expf(yr[i]));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LanguageModelCriterion_UIC (captioning/modules/losses.py:319-369, reduction 'mean') for the paired training forward, in one
+// launch: the four slot terms read their labels / mask straight from the loader's phrase tensors
+//   part[0] = -sum_{n, p < phrase_num[n]} sa_len[n][p][phrase_length[n][p+1]] / denom      (2: sa_syn / phrase_syn, 3: na_len, 5: na_syn)
+//   part[1] = -sum_r picked[r] w_sa[r] / denom,  part[4] likewise with w_na,  denom = sum_r w_sa[r],  out[6] = sum of the six.
+// One workgroup: a few thousand elements.  The reference does this with ~40 elementwise launches and as many in the backward.
+struct UicCritArgs {
+    const float* lp[4]; int C[4];                 // sa_len, sa_syn, na_len, na_syn: [N, Pm, C]
+    const int64_t* phrase_num; const int64_t* phrase_length; const int64_t* phrase_syn; int N, Pm, L;
+    const float* picked; const float* w_sa; const float* w_na; int T;
+};
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void uic_criterion_kernel(UicCritArgs a, float* __restrict__ out) {
+    __shared__ float red[16];
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 0..5 parts (unnormalised, negated later), 6 denom
+    for (int i = threadIdx.x; i < a.N * a.Pm; i += 1024) {
+        const int n = i / a.Pm, p = i - n * a.Pm;
+        if (p >= a.phrase_num[n]) continue;
+        const int ll = (int)a.phrase_length[(size_t)n * a.L + p + 1], sl = (int)a.phrase_syn[(size_t)n * a.L + p + 1];
+        acc[0] += a.lp[0][(size_t)i * a.C[0] + ll];
+        acc[2] += a.lp[1][(size_t)i * a.C[1] + sl];
+        acc[3] += a.lp[2][(size_t)i * a.C[2] + ll];
+        acc[5] += a.lp[3][(size_t)i * a.C[3] + sl];
+    }
+    for (int r = threadIdx.x; r < a.T; r += 1024) {
+        const float pk = a.picked[r], ws = a.w_sa[r], wn = a.w_na[r];
+        if (ws != 0.f) acc[1] += pk * ws;
+        if (wn != 0.f) acc[4] += pk * wn;
+        acc[6] += ws;
+    }
+    float tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tot[k] = block_sum_1024(acc[k], red);
+    if (threadIdx.x == 0) {
+        float loss = 0.f;
+        for (int k = 0; k < 6; ++k) { out[k] = -tot[k] / tot[6]; loss += out[k]; }
+        out[6] = loss;
+        out[7] = tot[6];
+    }
+}
+
+// gradients for upstream g = dL/d(out[6]) (the six parts are reported, not differentiated): dense [N, Pm, C] tensors for the four
+// slot outputs (zero except at the label of a counted slot) and dpicked [T]
+__global__ __launch_bounds__(256) void uic_criterion_bwd_kernel(UicCritArgs a, const float* __restrict__ g, const float* __restrict__ fwd,
+                                                                float* d0, float* d1, float* d2, float* d3, float* __restrict__ dpicked) {
+    const float scale = -g[0] / fwd[7];
+    float* d[4] = {d0, d1, d2, d3};
+    const int slots = a.N * a.Pm;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < slots; i += gridDim.x * 256) {
+        const int n = i / a.Pm, p = i - n * a.Pm;
+        const bool on = p < a.phrase_num[n];
+        const int ll = (int)a.phrase_length[(size_t)n * a.L + p + 1], sl = (int)a.phrase_syn[(size_t)n * a.L + p + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lab = (k & 1) ? sl : ll;
+            for (int c = 0; c < a.C[k]; ++c) d[k][(size_t)i * a.C[k] + c] = (on && c == lab) ? scale : 0.f;
+        }
+    }
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < a.T; r += gridDim.x * 256) dpicked[r] = scale * (a.w_sa[r] + a.w_na[r]);
+}
+
 // column sums (bias gradients): out[n] += sum_m x[m][n]
 __global__ void colsum_kernel(const float* __restrict__ x, float* out, int M, int N) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -565,6 +637,43 @@ extern "C" int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, i
     if (!y || !dy || !dx || rows < 0 || V <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
     hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, V);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+static int fill_crit(UicCritArgs& a, const float* sa_len, const float* sa_syn, const float* na_len, const float* na_syn, int N, int Pm, int c_len,
+                     int c_syn, const int64_t* phrase_num, const int64_t* phrase_length, const int64_t* phrase_syn, int L, const float* picked,
+                     const float* w_sa, const float* w_na, int T) {
+    if (!sa_len || !sa_syn || !na_len || !na_syn || !phrase_num || !phrase_length || !phrase_syn || !picked || !w_sa || !w_na) return BOFI_ERR_ARG;
+    if (N <= 0 || Pm <= 0 || Pm + 1 > L || c_len <= 0 || c_syn <= 0 || T < 0) return BOFI_ERR_ARG;
+    a.lp[0] = sa_len; a.lp[1] = sa_syn; a.lp[2] = na_len; a.lp[3] = na_syn;
+    a.C[0] = c_len; a.C[1] = c_syn; a.C[2] = c_len; a.C[3] = c_syn;
+    a.phrase_num = phrase_num; a.phrase_length = phrase_length; a.phrase_syn = phrase_syn; a.N = N; a.Pm = Pm; a.L = L;
+    a.picked = picked; a.w_sa = w_sa; a.w_na = w_na; a.T = T;
+    return BOFI_OK;
+}
+
+extern "C" int bofi_uic_criterion(const float* sa_len, const float* sa_syn, const float* na_len, const float* na_syn, int N, int Pm, int c_len,
+                                  int c_syn, const int64_t* phrase_num, const int64_t* phrase_length, const int64_t* phrase_syn, int L,
+                                  const float* picked, const float* w_sa, const float* w_na, int T, float* out8, void* stream) {
+    UicCritArgs a;
+    if (int rc = fill_crit(a, sa_len, sa_syn, na_len, na_syn, N, Pm, c_len, c_syn, phrase_num, phrase_length, phrase_syn, L, picked, w_sa, w_na, T)) return rc;
+    if (!out8) return BOFI_ERR_ARG;
+    hipLaunchKernelGGL(uic_criterion_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, out8);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+extern "C" int bofi_uic_criterion_bwd(const float* sa_len, const float* sa_syn, const float* na_len, const float* na_syn, int N, int Pm, int c_len,
+                                      int c_syn, const int64_t* phrase_num, const int64_t* phrase_length, const int64_t* phrase_syn, int L,
+                                      const float* picked, const float* w_sa, const float* w_na, int T, const float* g_loss, const float* out8,
+                                      float* d_sa_len, float* d_sa_syn, float* d_na_len, float* d_na_syn, float* d_picked, void* stream) {
+    UicCritArgs a;
+    if (int rc = fill_crit(a, sa_len, sa_syn, na_len, na_syn, N, Pm, c_len, c_syn, phrase_num, phrase_length, phrase_syn, L, picked, w_sa, w_na, T)) return rc;
+    if (!g_loss || !out8 || !d_sa_len || !d_sa_syn || !d_na_len || !d_na_syn || !d_picked) return BOFI_ERR_ARG;
+    const int work = N * Pm > T ? N * Pm : T;
+    hipLaunchKernelGGL(uic_criterion_bwd_kernel, dim3((work + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, g_loss, out8, d_sa_len, d_sa_syn,
+                       d_na_len, d_na_syn, d_picked);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

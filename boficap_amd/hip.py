@@ -46,6 +46,8 @@ SIGNATURES = {
                                      _P, _P, _P, _I, _I, _P]),
     "bofi_logsoftmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "bofi_nll_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "bofi_uic_criterion": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
+    "bofi_uic_criterion_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bofi_colsum_add": (_I, [_P, _P, _I, _I, _P]),
     "bofi_embed_rows": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "bofi_embed_bwd": (_I, [_P, _P, _P, _I, _I, C.c_float, _P]),

@@ -638,6 +638,43 @@ class PickLogSoftmaxFn(Function):
         return dx, None, None
 
 
+class UicCriterionFn(Function):
+    """LanguageModelCriterion_UIC (captioning/modules/losses.py:319-369) of the paired training forward in one launch each way
+    (bofi_uic_criterion): the four slot outputs [N, Pm, .], the loader's phrase tensors as labels / mask, the picked token
+    log-probs with the SA / NA row weights -> (loss [1], the six parts [6], reported only)."""
+
+    @staticmethod
+    def forward(ctx, sa_len, sa_syn, na_len, na_syn, picked, phrase_num, phrase_length, phrase_syn, w_sa, w_na):
+        ts = [_need(t, "criterion input") for t in (sa_len, sa_syn, na_len, na_syn, picked, w_sa, w_na)]
+        N, Pm, c_len = ts[0].shape
+        c_syn, L, T = ts[1].shape[2], phrase_length.shape[1], ts[4].numel()
+        if ts[1].shape[:2] != (N, Pm) or ts[2].shape != ts[0].shape or ts[3].shape != ts[1].shape or ts[5].numel() != T or ts[6].numel() != T \
+                or phrase_num.numel() != N or phrase_length.shape != (N, L) or phrase_syn.shape != (N, L) or Pm + 1 > L:
+            raise hip.BofiHipError("criterion: inconsistent shapes")
+        ints = [t.to(torch.int64).contiguous() for t in (phrase_num, phrase_length, phrase_syn)]
+        out = torch.empty(8, dtype=torch.float32, device=ts[0].device)
+        _chk(_lib().bofi_uic_criterion(hip.ptr(ts[0]), hip.ptr(ts[1]), hip.ptr(ts[2]), hip.ptr(ts[3]), N, Pm, c_len, c_syn, hip.ptr(ints[0]),
+                                       hip.ptr(ints[1]), hip.ptr(ints[2]), L, hip.ptr(ts[4]), hip.ptr(ts[5]), hip.ptr(ts[6]), T, hip.ptr(out),
+                                       hip.stream_ptr()), "bofi_uic_criterion")
+        ctx.save_for_backward(*ts, *ints, out)
+        ctx.dims = (N, Pm, c_len, c_syn, L, T)
+        parts = out[:6]
+        ctx.mark_non_differentiable(parts)
+        return out[6:7].clone(), parts
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        sa_len, sa_syn, na_len, na_syn, picked, w_sa, w_na, pnum, plen, psyn, out = ctx.saved_tensors
+        N, Pm, c_len, c_syn, L, T = ctx.dims
+        g = _need(g_loss, "criterion gradient")
+        d = [torch.empty_like(t) for t in (sa_len, sa_syn, na_len, na_syn, picked)]
+        _chk(_lib().bofi_uic_criterion_bwd(hip.ptr(sa_len), hip.ptr(sa_syn), hip.ptr(na_len), hip.ptr(na_syn), N, Pm, c_len, c_syn, hip.ptr(pnum),
+                                           hip.ptr(plen), hip.ptr(psyn), L, hip.ptr(picked), hip.ptr(w_sa), hip.ptr(w_na), T, hip.ptr(g), hip.ptr(out),
+                                           hip.ptr(d[0]), hip.ptr(d[1]), hip.ptr(d[2]), hip.ptr(d[3]), hip.ptr(d[4]), hip.stream_ptr()),
+             "bofi_uic_criterion_bwd")
+        return (*d, None, None, None, None, None)
+
+
 def log_softmax_pick(logits, labels, grad_bf16=False):
     """(log-probs [T, V], log-probs at labels [T]); see PickLogSoftmaxFn.  ``grad_bf16``: the logits come straight out of a
     linear (their only other use) -- its backward gets the gradient in bf16."""
@@ -1294,6 +1331,11 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
         if sa_tok is not na_tok:
             raise hip.BofiHipError("a pair of token weights goes with the paired log-probs of _forward_paired")
         made = getattr(sa_tok, "_bofi_picked", None)              # picked inside the forward (HINTS["pick_labels"]): fused backward
+        if made is not None and made[1] is token_labels and sa_len.dim() == 3 and sa_len.shape[1] + 1 <= phrase_length.shape[1]:
+            # everything the criterion needs is at hand as small tensors: one launch (and one in the backward)
+            loss, parts = UicCriterionFn.apply(sa_len, sa_syn, na_len, na_syn, made[0], phrase_num, phrase_length, phrase_syn,
+                                               token_weight[0], token_weight[1])
+            return loss.squeeze(0), list(parts.unbind(0))
         if made is not None and made[1] is token_labels:
             picked = -made[0]
         else:

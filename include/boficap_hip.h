@@ -136,6 +136,20 @@ int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, in
  * written as zeros (the operand the vocabulary projection's backward GEMMs read, K granule 64). */
 int bofi_nll_bwd(const float* y, const int64_t* labels, const float* dpicked, void* dx, int dx_dtype, int lddx, int rows, int V,
                  void* stream);
+
+/* LanguageModelCriterion_UIC (captioning/modules/losses.py:319-369, reduction 'mean') in one launch, for the paired training
+ * forward: the four slot outputs [N, Pm, c_len | c_syn] (log-probs), the loader's phrase_num [N], phrase_length / phrase_syn
+ * [N, L] (int64; slot p is counted iff p < phrase_num[n], its labels sit at column p + 1), the picked token log-probs [T] with
+ * the SA / NA row weights.  out8 = {sa_len, sa_tok, sa_syn, na_len, na_tok, na_syn parts, their sum (the loss), sum(w_sa)}.
+ * The backward takes dL/d(loss) (device scalar) and writes dense gradients of the four slot outputs and d_picked [T]. */
+int bofi_uic_criterion(const float* sa_len, const float* sa_syn, const float* na_len, const float* na_syn, int N, int Pm, int c_len,
+                       int c_syn, const int64_t* phrase_num, const int64_t* phrase_length, const int64_t* phrase_syn, int L,
+                       const float* picked, const float* w_sa, const float* w_na, int T, float* out8, void* stream);
+int bofi_uic_criterion_bwd(const float* sa_len, const float* sa_syn, const float* na_len, const float* na_syn, int N, int Pm,
+                           int c_len, int c_syn, const int64_t* phrase_num, const int64_t* phrase_length,
+                           const int64_t* phrase_syn, int L, const float* picked, const float* w_sa, const float* w_na, int T,
+                           const float* g_loss, const float* out8, float* d_sa_len, float* d_sa_syn, float* d_na_len,
+                           float* d_na_syn, float* d_picked, void* stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int bofi_colsum_add(const float* x, float* out, int M, int N, void* stream);
 /* x[r] = sqrt(d) * (lut_tok[tok[r]] + lut_syn[syn[r]]) + pe[pos ? pos[r] : r % L]; tok or syn may be NULL, a negative id
