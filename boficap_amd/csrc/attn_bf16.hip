@@ -33,18 +33,19 @@ struct AttnParamsB {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// LDS row stride in elements: 64 + 16 pad = 160 B.  Banking (MI355X_MICROARCH.md, LDS): the transposing reads of V are banked per
-// 32-lane half = 8 rows x 32 B, which tile the 256-byte bank row only if the stride is an odd multiple of 32 B; the b128 row
-// reads of Q / K (16-lane groups: 8 rows at one chunk, 8 at the next) are conflict-free at 160 B as well.  The former 144 B
-// (64 + 8) left the 32-byte segments straddling each other: SQ_LDS_BANK_CONFLICT was 25 % of the LDS cycles of this kernel.
-constexpr int AROW = 80;
+// LDS row strides in elements.  Q and K are read row-wise (ds_read_b128): 64 + 8 pad = 144 B is conflict-free for those.  V is read
+// with the transposing read, which is banked per 32-lane half = 8 rows x 32 B (MI355X_MICROARCH.md, LDS): the 8 segments tile the
+// 256-byte bank row only if the stride is an odd multiple of 32 B -> 64 + 16 pad = 160 B.  With V at 144 B too,
+// SQ_LDS_BANK_CONFLICT was 25 % of this kernel's LDS cycles; with all three tiles at 160 B the extra LDS cost the decode a
+// workgroup per CU.
+constexpr int AROW = 72, VROW = 80;
 
 template <int NQT, int NKT, bool RAGGED = false>       // 16-row query tiles per block, 16-key tiles (even); RAGGED: per-item row ranges
 __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     static_assert(NKT % 2 == 0, "keys are consumed 32 at a time");
     __shared__ __attribute__((aligned(16))) bf16_t sq[NQT * 16 * AROW];
     __shared__ __attribute__((aligned(16))) bf16_t sk[NKT * 16 * AROW];
-    __shared__ __attribute__((aligned(16))) bf16_t sv[NKT * 16 * AROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sv[NKT * 16 * VROW];
 
     if (p.skip_if_ge && *p.skip_if_ge >= p.skip_threshold) return;
     const int lane = threadIdx.x;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
         const int r = c >> 3, ch = c & 7;
         const bool ok = r < Lk;
         *reinterpret_cast<u32x4*>(&sk[r * AROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(kg + (size_t)r * p.ldk + ch * 8) : zero4;
-        *reinterpret_cast<u32x4*>(&sv[r * AROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * p.ldv + ch * 8) : zero4;
+        *reinterpret_cast<u32x4*>(&sv[r * VROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * p.ldv + ch * 8) : zero4;
     }
     __syncthreads();
 
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     for (int s = 0; s < NKT / 2; ++s) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16_t* a0p = &sv[(32 * s + 4 * g + tq) * AROW + dt * 16 + 4 * tp];
-            const bf16_t* a1p = a0p + 16 * AROW;
+            const bf16_t* a0p = &sv[(32 * s + 4 * g + tq) * VROW + dt * 16 + 4 * tp];
+            const bf16_t* a1p = a0p + 16 * VROW;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1p);
             bf16x8 av;
