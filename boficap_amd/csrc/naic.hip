@@ -86,7 +86,8 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
     if (tid == 0) { sint[0] = last_src[b]; sint[1] = (flags & BOUND_UPDATE) ? st.finished[b] : 0; }
 
     if (flags & BOUND_HEADS) {
-        for (int i = tid; i < 30 * hh; i += 512) w2s[i] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
+        // (rows padded by one float: 30 threads each walk one row below, and a 100-float stride puts them on 8 of the 32 banks)
+        for (int i = tid; i < 30 * hh; i += 512) w2s[(i / hh) * (hh + 1) + i % hh] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
         // Everything this phase needs from global memory is requested up front (one round trip): the row of y
         // (possibly split-K partial slabs [yparts][B][d], summed in fixed order), the norm vectors, the hidden bias.
         constexpr int KPT = 4;                        // columns per thread: d <= 512 * KPT
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
         __syncthreads();
         if (tid < 30) {
             const bool is_len = tid < 20;
-            const float* wr = w2s + tid * hh;
+            const float* wr = w2s + tid * (hh + 1);
             const float* hv = is_len ? hid : (hid + hh);
             float acc = 0.f;
             for (int k = 0; k < hh; ++k) acc = fmaf(wr[k], hv[k], acc);
@@ -266,12 +267,12 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
             T vv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int rj = __shfl(row, min(j0 + u, 63), 64);
+                const int rj = __builtin_amdgcn_readlane(row, min(j0 + u, 63));       // (wave-uniform lane: a scalar read, no LDS permute)
                 vv[u] = kvtab[(size_t)rj * 2 * d + d + h * 64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float pj = __shfl(pr, min(j0 + u, 63), 64);
+                const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), min(j0 + u, 63)));
                 if (j0 + u < n) o = fmaf(pj, ElemOps<T>::to_f32(vv[u]), o);
             }
         }
@@ -284,7 +285,7 @@ int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundStat
                       float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa, int iter, int yparts) {
     const SaicState sav = sa ? *sa : SaicState{};
     if (d > 2048 || (2 * hh) % 4 || d % 8 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60) return BOFI_ERR_ARG;
-    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * hh) * sizeof(float);
+    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1)) * sizeof(float);
     if (dtype == BOFI_DT_F32)
         hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
                            (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter, yparts > 1 ? yparts : 1);
