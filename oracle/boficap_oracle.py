@@ -394,10 +394,29 @@ def _teacher_forced_bound(w, cfg, input_embed, memory, src_mask, phrase_num, phr
     return len_lp[:, 1:, :], syn_lp[:, 1:, :], last
 
 
+def glance_input(cfg, na_pred_tokens, labels, phrase_length, glat_p: float, uniform):
+    """The glancing decoder input of EncoderDecoder_UIC.forward, TM:441-460: reveal the true token at a position with
+    probability (share of mispredicted tokens of that caption) * glat_p, [BOS] elsewhere.  ``uniform``: the [N, S] draws
+    the reference takes from torch.rand (TM:455) -- injected, so that both sides see the same numbers."""
+    real = labels[:, 1:-1]
+    N, S = real.shape
+    tokens_length = phrase_length.sum(1) - 1
+    phrase_mask = torch.zeros(N, S, dtype=torch.bool)
+    for i in range(N):
+        phrase_mask[i, 0:int(tokens_length[i])] = True
+    same_num = ((na_pred_tokens == real) & phrase_mask).sum(1)
+    mismatch_prob = (tokens_length - same_num) / tokens_length
+    keep_prob = (mismatch_prob * glat_p).unsqueeze(-1) * phrase_mask.float()
+    keep = uniform < keep_prob
+    bos = torch.full(real.shape, cfg.bos_idx, dtype=torch.long)
+    return bos.masked_fill(keep, 0) + real.masked_fill(~keep, 0)
+
+
 def forward_uic(w: Weights, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn,
-                extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask):
-    """TransformerModel._forward TM:1713-1724,1759-1775 -> EncoderDecoder_UIC.forward TM:413-468 with glat_p < 0,
-    dropout off (eval mode).  Inputs may be [B, spi, ...]; returns the six log-prob tensors."""
+                extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask, glat_p: float = -1.0, glat_uniform=None):
+    """TransformerModel._forward TM:1713-1724,1759-1775 -> EncoderDecoder_UIC.forward TM:413-468, dropout off (eval mode);
+    glat_p >= 0 takes the glancing pass TM:437-463 with the injected draws ``glat_uniform``.  Inputs may be [B, spi, ...];
+    returns the six log-prob tensors."""
     if labels.dim() == 3:
         labels = labels.reshape(-1, labels.shape[2])
         phrase_num = phrase_num.reshape(-1)
@@ -423,7 +442,12 @@ def forward_uic(w: Weights, cfg, att_feats, labels, att_masks, phrase_num, phras
     syn_mask = torch.zeros(labels.shape[0], S, S, dtype=torch.bool)
     for i in range(labels.shape[0]):
         syn_mask[i, :, :int(last[i]) - 1] = True                        # TM:562-564 (per-row index here)
-    na_phrase = decode_na(w, cfg, memory, extend_phrase_syn_seq[:, 1:-1], src_mask, syn_mask)
+    glanced = None
+    if glat_p >= 0:                                                     # TM:437-460
+        with torch.no_grad():
+            pred = logit(w, decode_na(w, cfg, memory, extend_phrase_syn_seq[:, 1:-1], src_mask, syn_mask)).argmax(-1)
+            glanced = glance_input(cfg, pred, labels.long(), phrase_length, glat_p, glat_uniform)
+    na_phrase = decode_na(w, cfg, memory, extend_phrase_syn_seq[:, 1:-1], src_mask, syn_mask, glat_input=glanced)
     return (sa_len, sa_syn, F.log_softmax(logit(w, sa_phrase), dim=-1),
             na_len, na_syn, F.log_softmax(logit(w, na_phrase), dim=-1))
 
@@ -452,3 +476,40 @@ def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
     parts = [g(sa_len, len_lab).sum() / denom, sa_tok_loss.sum() / denom, g(sa_syn, syn_lab).sum() / denom,
              g(na_len, len_lab).sum() / denom, na_tok_loss.sum() / denom, g(na_syn, syn_lab).sum() / denom]
     return sum(parts), parts
+
+
+# ----------------------------------------------------------------------------- self-critical losses (a16)
+def new_self_critical(logprobs, seq, scores, sample_n: int):
+    """StructureLosses.forward with structure_loss_type 'new_self_critical', reduction 'mean'
+    (captioning/modules/losses.py:37-51, 70, 157-176; entropy_reward_weight 0, self_cider_reward_weight 0).
+    ``scores``: [N] from the caption scorer (get_scores, external).  Returns (loss, reward [B, n] = the raw scores,
+    as the reference stores them in out['reward'] before the baseline is subtracted)."""
+    mask = (seq > 0).to(logprobs)
+    mask = torch.cat([mask.new_full((mask.size(0), 1), 1), mask[:, :-1]], 1)        # losses.py:47-48
+    sc = torch.as_tensor(scores).type_as(logprobs).view(-1, sample_n)                 # :50-51
+    picked = logprobs.gather(2, seq.unsqueeze(2)).squeeze(2)                          # :70
+    baseline = (sc.sum(1, keepdim=True) - sc) / (sc.shape[1] - 1)                     # :164
+    adv = sc - baseline
+    output = -picked * mask * adv.view(-1, 1)                                         # :172
+    return torch.sum(output) / torch.sum(mask), sc                                    # :176
+
+
+def rl_kl_term(naic_logprobs, saic_logprobs, saic_seq):
+    """LossWrapper UIC branch with rl_kl (captioning/modules/loss_wrapper.py:216-222): KL(SAIC || NAIC) per vocabulary
+    entry, nn.KLDivLoss(reduction='none') = target * (log target - input), masked by the SAIC caption's tokens."""
+    mask = saic_seq > 0
+    target = torch.exp(saic_logprobs).detach()
+    kl = torch.where(target > 0, target * (target.log() - naic_logprobs), torch.zeros_like(target))    # xlogy convention of KLDivLoss
+    return torch.sum(kl * mask.unsqueeze(2)) / (torch.sum(mask) + 1e-6)
+
+
+def loss_wrapper_uic_rl(saic_logprobs, saic_seq, naic_logprobs, naic_seq, saic_scores, naic_scores, sample_n: int,
+                        structure_loss_weight: float = 1.0, lm_loss=0.0, rl_kl: bool = False):
+    """LossWrapper.forward, train_mode 'UIC', struc_flag (captioning/modules/loss_wrapper.py:181-230): the sum of the two
+    modes' mixed losses (+ the KL term).  Returns the dict entries 'loss', 'struc_loss', 'reward'."""
+    ls, rs = new_self_critical(saic_logprobs, saic_seq, saic_scores, sample_n)
+    ln, rn = new_self_critical(naic_logprobs, naic_seq, naic_scores, sample_n)
+    loss = ((1 - structure_loss_weight) * lm_loss + structure_loss_weight * ls) + ((1 - structure_loss_weight) * lm_loss + structure_loss_weight * ln)
+    if rl_kl:
+        loss = loss + rl_kl_term(naic_logprobs, saic_logprobs, saic_seq)
+    return dict(loss=loss, struc_loss=ls + ln, reward=rs + rn)

@@ -44,6 +44,8 @@ _new_zeros = torch.Tensor.new_zeros
 torch.Tensor.new_zeros = lambda self, *a, **k: _new_zeros(self, *a, **{kk: vv for kk, vv in k.items() if kk != "requires_grad"})
 import captioning.models as ref_models                         # noqa: E402
 from captioning.modules.losses import LanguageModelCriterion_UIC    # noqa: E402
+import captioning.modules.losses as ref_losses                  # noqa: E402
+from captioning.modules.loss_wrapper import LossWrapper         # noqa: E402
 
 assert os.path.abspath(ref_models.__file__).startswith(REF), ref_models.__file__
 
@@ -144,7 +146,7 @@ def run_case(name, cfg, model, w, att_feats, att_masks, *, want_saic=True, store
     return out
 
 
-def run_train_case(name, cfg, sd, n_img, spi, seed):
+def run_train_case(name, cfg, sd, n_img, spi, seed, keep_numel=4096, full_outputs=True):
     """XE training forward + criterion + backward of the reference (eval mode: dropout off), oracle-checked."""
     import contextlib
     import io
@@ -168,13 +170,19 @@ def run_train_case(name, cfg, sd, n_img, spi, seed):
     res = {k: v for k, v in batch.items()}
     res["att_feats"] = att_np
     for i, o in enumerate(outs):
-        res[f"out{i}"] = o.detach().numpy()
+        if full_outputs or o.shape[-1] <= 32:
+            res[f"out{i}"] = o.detach().numpy()
+        else:                                                    # full config: best two log-probs per position + the true tokens' log-probs
+            top = torch.topk(o.detach(), 2, dim=2)
+            res[f"out{i}_top2_val"], res[f"out{i}_top2_idx"] = top[0].numpy(), top[1].numpy()
+            real = tb["labels"].reshape(-1, tb["labels"].shape[-1])[:, 1:-1].long()
+            res[f"out{i}_picked"] = o.detach().gather(2, real.unsqueeze(2)).squeeze(2).numpy()
     res["losses"] = np.array([float(x) for x in losses], np.float32)
     names, norms, keep = [], [], {}
     for k, p in model.named_parameters():
         names.append(k)
         norms.append(-1.0 if p.grad is None else float(p.grad.norm()))
-        if p.grad is not None and p.grad.numel() <= 4096:        # full gradients of the small tensors
+        if p.grad is not None and p.grad.numel() <= keep_numel:  # full gradients of the small tensors
             keep["grad." + k] = p.grad.numpy().copy()
     res["grad_names"] = np.array(names)
     res["grad_norms"] = np.array(norms, np.float32)
@@ -183,7 +191,163 @@ def run_train_case(name, cfg, sd, n_img, spi, seed):
     return dict(n_img=n_img, spi=spi, loss=float(losses[0]), no_grad=int(sum(n < 0 for n in norms)))
 
 
+def run_glat_case(name, cfg, sd, n_img, spi, seed, glat_p):
+    """XE forward with the glancing pass (TM:437-463) of the REAL reference, its torch.rand draw (TM:455) replaced by an
+    injected tensor for the duration of the call; the oracle must reproduce the six outputs from the same draws."""
+    import contextlib
+    import io
+    from training_batch import make_training_batch
+    model = build_reference(cfg, sd)
+    w = O.as_torch(sd)
+    batch = make_training_batch(cfg, n_img, spi, seed=seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    att_np = W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=seed + 100)
+    att, fc = torch.from_numpy(att_np), torch.zeros(n_img, 0)
+    N, S = n_img * spi, cfg.seq_length
+    uniform = torch.rand(N, S, generator=torch.Generator().manual_seed(seed))
+    args = (tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["extend_phrase_syn_seq"], tb["extend_phrase_seq"], tb["extend_phrase_seq_mask"])
+    real_rand, calls = torch.rand, []
+
+    def injected(*shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        assert shape == (N, S), shape
+        calls.append(shape)
+        return uniform.clone()
+    torch.rand = injected
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            outs = model(fc, att, tb["labels"], None, *args, glat_p)
+    finally:
+        torch.rand = real_rand
+    assert len(calls) == 1, calls
+    with torch.no_grad():
+        oouts = O.forward_uic(w, cfg, att, tb["labels"], None, *args, glat_p=glat_p, glat_uniform=uniform)
+        plain = O.forward_uic(w, cfg, att, tb["labels"], None, *args)
+    for i, (a, b) in enumerate(zip(outs, oouts)):
+        close(a, b, tol=1e-5, what=f"{name}: forward output {i}")
+    changed = float((outs[5] - plain[5]).abs().max())
+    assert changed > 1e-2, "the glancing pass must change the NA token distributions"
+    losses = LanguageModelCriterion_UIC()(*outs, tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["labels"])
+    res = {k: v for k, v in batch.items()}
+    res["att_feats"] = att_np
+    res["glat_uniform"] = uniform.numpy()
+    res["glat_p"] = np.float32(glat_p)
+    for i, o in enumerate(outs):
+        res[f"out{i}"] = o.numpy()
+    res["losses"] = np.array([float(x) for x in losses], np.float32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return dict(n_img=n_img, spi=spi, glat_p=glat_p, loss=float(losses[0]), na_tok_change=changed)
+
+
+def run_rl_loss_case(name, cfg, seed, n_img=3, sample_n=4):
+    """The self-critical losses of the REAL reference on injected samples and scores:
+      * StructureLosses('new_self_critical') (losses.py:37-51,157-176) with get_scores (the external CIDEr-D scorer,
+        utils/rewards.py:86) replaced by a function that returns injected scores;
+      * LossWrapper.forward, train_mode 'UIC', struc_flag=True, structure_loss_weight 1, with and without rl_kl
+        (loss_wrapper.py:181-230), the model call replaced by a stub that returns recorded samples.
+    Stored: inputs, losses, rewards and d loss / d logprobs of both modes."""
+    from argparse import Namespace
+    g = torch.Generator().manual_seed(seed)
+    N, S, V = n_img * sample_n, cfg.seq_length, cfg.tgt_vocab
+
+    def samples():
+        lp = F.log_softmax(torch.randn(N, S, V, generator=g), dim=2)
+        seq = torch.randint(1, V, (N, S), generator=g)
+        ntok = torch.randint(1, S + 1, (N,), generator=g)
+        for i in range(N):
+            seq[i, int(ntok[i]):] = 0
+        return lp, seq
+    import torch.nn.functional as F
+    lp_s, seq_s = samples()
+    lp_n, seq_n = samples()
+    lp_s[seq_s == 0] = 0.0                                          # core_SAIC leaves zero rows where nothing was emitted (TM:1883)
+    sc_s, sc_n = torch.rand(N, generator=g).numpy().astype(np.float64), torch.rand(N, generator=g).numpy().astype(np.float64)
+    opt = cfg.to_opt(structure_loss_type="new_self_critical", train_sample_n=sample_n, entropy_reward_weight=0, structure_loss_weight=1,
+                     train_sample_method="sample", train_beam_size=1, struc_use_logsoftmax=True, label_smoothing=0, self_cider_reward_weight=0)
+    queue = []
+    real_get_scores = ref_losses.get_scores
+    ref_losses.get_scores = lambda data_gts, gen_result, opt_: queue.pop(0)
+    try:
+        res = dict(saic_logprob=lp_s.numpy(), saic_seq=seq_s.numpy(), naic_logprob=lp_n.numpy(), naic_seq=seq_n.numpy(),
+                   saic_scores=sc_s.astype(np.float32), naic_scores=sc_n.astype(np.float32), sample_n=np.int32(sample_n))
+        gts = [[np.zeros(3, np.int64)] for _ in range(n_img)]
+        # StructureLosses alone
+        crit = ref_losses.StructureLosses(opt)
+        a = lp_s.clone().requires_grad_(True)
+        queue.append(sc_s.copy())
+        out = crit(a, seq_s, gts)
+        out["loss"].backward()
+        ol, orw = O.new_self_critical(lp_s, seq_s, sc_s, sample_n)
+        assert abs(float(out["loss"]) - float(ol)) < 1e-6 and torch.equal(out["reward"], orw.type_as(out["reward"]))
+        res.update(nsc_loss=np.float32(out["loss"].item()), nsc_reward=out["reward"].numpy(), nsc_grad_picked=a.grad.gather(2, seq_s.unsqueeze(2)).squeeze(2).numpy())
+        assert int((a.grad != 0).sum()) <= N * S
+        # LossWrapper, RL branch
+        for rl_kl in (False, True):
+            class Stub(torch.nn.Module):
+                def forward(self, fc, att, masks, opt=None, mode=None):
+                    assert mode == "sample" and opt["sample_method"] == "sample" and opt["sample_n"] == sample_n and opt["output_logsoftmax"]
+                    lp, seq = (self.lp_s, seq_s) if opt["train_mode"] == "SAIC" else (self.lp_n, seq_n)
+                    z = torch.zeros(N, dtype=torch.int32)
+                    return seq, lp, z, torch.zeros(N, S, dtype=torch.int32), torch.zeros(N, S, dtype=torch.long), 0.0
+            stub = Stub()
+            stub.lp_s, stub.lp_n = lp_s.clone().requires_grad_(True), lp_n.clone().requires_grad_(True)
+            opt.rl_kl = rl_kl
+            lw = LossWrapper(stub, opt)
+            queue.extend([sc_s.copy(), sc_n.copy()])
+            fc = torch.zeros(n_img, 0)
+            o = lw(fc, torch.zeros(n_img, 1, 1), None, None, None, gts, torch.arange(n_img), False, True, False)
+            o["loss"].backward()
+            oo = O.loss_wrapper_uic_rl(lp_s, seq_s, lp_n, seq_n, sc_s, sc_n, sample_n, rl_kl=rl_kl)
+            assert abs(float(o["loss"]) - float(oo["loss"])) < 1e-5, (float(o["loss"]), float(oo["loss"]))
+            assert abs(float(o["struc_loss"]) - float(oo["struc_loss"])) < 1e-5 and torch.allclose(o["reward"], oo["reward"].type_as(o["reward"]))
+            tag = "lw_kl" if rl_kl else "lw"
+            res[tag + "_loss"], res[tag + "_struc_loss"], res[tag + "_reward"] = np.float32(o["loss"].item()), np.float32(o["struc_loss"].item()), o["reward"].numpy()
+            if rl_kl:                                               # the KL term's gradient lands on every vocabulary entry of the NAIC rows
+                res["lw_kl_grad_naic"] = stub.lp_n.grad.numpy()
+                assert stub.lp_s.grad is not None
+                res["lw_kl_grad_saic_picked"] = stub.lp_s.grad.gather(2, seq_s.unsqueeze(2)).squeeze(2).numpy()
+    finally:
+        ref_losses.get_scores = real_get_scores
+    assert not queue
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return dict(n_img=n_img, sample_n=sample_n, nsc_loss=float(res["nsc_loss"]), lw_loss=float(res["lw_loss"]), lw_kl_loss=float(res["lw_kl_loss"]))
+
+
+def run_loss_wrapper_xe_case(name, cfg, sd, n_img, spi, seed):
+    """LossWrapper.forward, train_mode 'UIC', struc_flag=False (loss_wrapper.py:231-244) around the REAL reference model:
+    the out dict of one XE batch (eval mode, glat_p < 0)."""
+    import contextlib
+    import io
+    from training_batch import make_training_batch
+    model = build_reference(cfg, sd)
+    opt = cfg.to_opt(structure_loss_type="new_self_critical", train_sample_n=5, entropy_reward_weight=0, structure_loss_weight=1, label_smoothing=0)
+    lw = LossWrapper(model, opt)
+    batch = make_training_batch(cfg, n_img, spi, seed=seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    att_np = W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=seed + 100)
+    att, fc = torch.from_numpy(att_np), torch.zeros(n_img, 0)
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        o = lw(fc, att, tb["labels"], None, None, None, torch.arange(n_img), False, False, False, None, tb["phrase_num"], tb["phrase_length"],
+               tb["phrase_syn"], tb["extend_phrase_syn_seq"], tb["extend_phrase_seq"], tb["extend_phrase_seq_mask"], -1.0)
+    w = O.as_torch(sd)
+    with torch.no_grad():
+        oouts = O.forward_uic(w, cfg, att, tb["labels"], None, tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["extend_phrase_syn_seq"],
+                              tb["extend_phrase_seq"], tb["extend_phrase_seq_mask"])
+        ol, parts = O.criterion_uic(oouts, tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["labels"])
+    keys = ["loss", "SA_length_loss", "SA_phrase_loss", "SA_syn_loss", "NA_length_loss", "NA_phrase_loss", "NA_syn_loss"]
+    assert sorted(o.keys()) == sorted(keys), sorted(o.keys())
+    for k, v in zip(keys, [ol] + list(parts)):
+        assert abs(float(o[k]) - float(v)) < 1e-5, (k, float(o[k]), float(v))
+    res = {k: v for k, v in batch.items()}
+    res["att_feats"] = att_np
+    res["out_keys"] = np.array(keys)
+    res["out_values"] = np.array([float(o[k]) for k in keys], np.float32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return dict(n_img=n_img, spi=spi, loss=float(o["loss"]))
+
+
 def main():
+    only = set(a for a in sys.argv[1:] if not a.startswith("-"))          # developer convenience: regenerate the named cases only
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     manifest = {}
@@ -251,6 +415,14 @@ def main():
     sd_t = W.make_state_dict(TINY, seed=0, gen_scale=1.0)
     manifest["tiny_train_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t), **run_train_case("tiny_train_xe", TINY, sd_t, 3, 2, 5))
     print("tiny_train_xe", manifest["tiny_train_xe"])
+    # the glancing pass of the XE forward with injected draws, the self-critical losses with injected scores, LossWrapper's XE branch
+    manifest["tiny_glat"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t), **run_glat_case("tiny_glat", TINY, sd_t, 3, 2, 7, 0.5))
+    print("tiny_glat", manifest["tiny_glat"])
+    manifest["tiny_rl_loss"] = dict(config="TINY", **run_rl_loss_case("tiny_rl_loss", TINY, 11))
+    print("tiny_rl_loss", manifest["tiny_rl_loss"])
+    manifest["tiny_loss_wrapper_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
+                                            **run_loss_wrapper_xe_case("tiny_loss_wrapper_xe", TINY, sd_t, 2, 3, 9))
+    print("tiny_loss_wrapper_xe", manifest["tiny_loss_wrapper_xe"])
     # schema as data (name, shape) for the CPU-side state_dict test
     manifest["schema_TINY"] = [[k, list(s)] for k, s in W.schema(TINY).items()]
     manifest["schema_FULL"] = [[k, list(s)] for k, s in W.schema(FULL).items()]
@@ -265,10 +437,14 @@ def main():
     _, _, _, _, dg = O.core_naic(w, cfg, mem, sm)
     last = dg["last"].numpy()
     order = np.argsort(last, kind="stable")
-    # 8 images spanning the range of layouts; the LAST row is a mid-length one so that quirk Q1
-    # shortens the fill mask of the longer rows without emptying it
-    pick = [int(order[i]) for i in (0, 3, 6, 9, 14, 18, 23)] + [int(order[12])]
-    assert last[pick[-1]] > 3, last[pick]
+    # 8 images spanning the range of layouts.  With the synthetic bound-head preset an image either stops within its first
+    # two steps or runs into the truncation at 21 (no layout in between occurs in pools of 96 images, nor under rescaled
+    # features or region counts), so the LAST row is a one-token image (last == 2): quirk Q1 then cuts the fill mask of
+    # EVERY row -- the 20-token ones included -- down to key 0 without emptying it.  (A mid-length last row is pinned at
+    # the small size: tiny_q1_last_shortest.)
+    two = [int(i) for i in order if last[i] == 2]
+    pick = [int(order[i]) for i in (0, 3, 9, 12, 14, 18, 23)] + [two[0]]
+    assert 1 < last[pick[-1]] < max(last[pick]) and len(set(pick)) == 8, last[pick]
     att = pool[pick]
     res = run_case("full_b8", cfg, model, w, att, None, store_logprob=False)
     del res["att_feats"]                                          # regenerated: pool seed + indices
@@ -280,6 +456,26 @@ def main():
                                iters=int(res["naic_iters"]), gap=float(res["naic_gap"]), reasons=res["naic_reason"].tolist(),
                                last=res["naic_last"].tolist())
     print("full_b8", manifest["full_b8"])
+    assert res["naic_last"][-1] == 2 and not np.isnan(res["naic_top2_val"]).any()
+    # full-size multi-phrase semi-autoregressive decode ([LEN] row shared, natural generator scale, as tiny_saic_multi)
+    sd_s = W.with_len_row_shared(W.make_state_dict(cfg, seed=0, gen_scale=1.0), cfg)
+    model_s, w_s = build_reference(cfg, sd_s), O.as_torch(sd_s)
+    opens = [int(i) for i in range(24) if last[i] > 2][:6]                 # images whose first bound step opens a phrase
+    res = run_case("full_saic_multi", cfg, model_s, w_s, pool[opens], None, store_logprob=False)
+    assert int(res["saic_phrase_num"].max()) >= 4 and int((res["saic_seq"] > 0).sum()) > 40, (res["saic_phrase_num"], res["saic_seq"])
+    del res["att_feats"]
+    res["pool_index"] = np.array(opens, np.int64)
+    res["memory"] = res["memory"][:1]
+    np.savez_compressed(os.path.join(OUT, "full_saic_multi.npz"), **res)
+    manifest["full_saic_multi"] = dict(config="FULL", seed=0, gen_scale=1.0, digest=W.digest(sd_s), patch="len_row_shared", B=len(opens), pool_seed=1234,
+                                       pool_size=24, saic_phrase_num=res["saic_phrase_num"].tolist(), iters=int(res["naic_iters"]))
+    print("full_saic_multi", manifest["full_saic_multi"])
+    del model_s, w_s, model, w
+    # full-size XE step of the reference: 2 images x 5 captions (forward, criterion, backward), natural generator scale
+    sd_t = W.make_state_dict(FULL, seed=0, gen_scale=1.0)
+    manifest["full_train_xe"] = dict(config="FULL", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
+                                     **run_train_case("full_train_xe", FULL, sd_t, 2, 5, 13, keep_numel=512, full_outputs=False))
+    print("full_train_xe", manifest["full_train_xe"])
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 

@@ -102,3 +102,101 @@ def test_oracle_xe_forward_and_criterion(manifest, weight_cache):
     loss, parts = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
     assert abs(float(loss) - float(g["losses"][0])) < 1e-4
     assert np.allclose([float(p) for p in parts], g["losses"][1:], atol=1e-5)
+
+
+def test_full_fixture_exercises_q1_shortening(manifest):
+    """full_b8: the LAST image has one token, so quirk Q1 cuts every image's fill mask (the 20-token ones included) to key 0."""
+    last = manifest["full_b8"]["last"]
+    assert 1 < last[-1] < max(last)
+    g = load_golden("full_b8")
+    assert not np.isnan(g["naic_top2_val"]).any() and (g["naic_phrase_length"].sum(1).max() == 20)
+
+
+def test_oracle_saic_multi_phrase_full(manifest, weight_cache):
+    """core_SAIC beyond its first iteration at the full size (up to 10 phrases per image)."""
+    from boficap_amd import weights as W
+    m = manifest["full_saic_multi"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    w = O.as_torch(sd)
+    g = load_golden("full_saic_multi")
+    assert max(m["saic_phrase_num"]) >= 4
+    att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]])
+    seq, lp, pn, pl, ps, _ = O.sample_saic(w, cfg, att, None)
+    assert (seq.numpy() == g["saic_seq"]).all() and (pn.numpy() == g["saic_phrase_num"]).all()
+    assert (pl.numpy() == g["saic_phrase_length"]).all() and (ps.numpy() == g["saic_phrase_syn"]).all()
+    assert _close(torch.topk(lp, 2, dim=2)[0].numpy(), g["saic_top2_val"], 2e-5)
+
+
+def test_oracle_glancing_pass(manifest, weight_cache):
+    """EncoderDecoder_UIC.forward with glat_p >= 0 (TM:437-463), the reference's torch.rand draw injected."""
+    m = manifest["tiny_glat"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    w = O.as_torch(sd)
+    g = load_golden("tiny_glat")
+    t = lambda k: torch.from_numpy(g[k])
+    args = (t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("extend_phrase_syn_seq"),
+            t("extend_phrase_seq"), t("extend_phrase_seq_mask"))
+    outs = O.forward_uic(w, cfg, *args, glat_p=float(g["glat_p"]), glat_uniform=t("glat_uniform"))
+    for i, o in enumerate(outs):
+        assert _close(o.numpy(), g[f"out{i}"], 1e-5), i
+    plain = O.forward_uic(w, cfg, *args)
+    assert float((plain[5] - outs[5]).abs().max()) > 1e-2 and _close(plain[2].numpy(), g["out2"], 1e-5)     # only the NA tokens change
+    loss, _ = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4
+
+
+def test_oracle_self_critical_losses(manifest):
+    """StructureLosses('new_self_critical') and LossWrapper's UIC struc_flag branch (with and without rl_kl) vs the values and
+    gradients recorded from the reference with injected samples and scores."""
+    g = load_golden("tiny_rl_loss")
+    n = int(g["sample_n"])
+    t = lambda k: torch.from_numpy(g[k])
+    a = t("saic_logprob").clone().requires_grad_(True)
+    loss, reward = O.new_self_critical(a, t("saic_seq"), g["saic_scores"], n)
+    loss.backward()
+    assert abs(float(loss) - float(g["nsc_loss"])) < 1e-6 and np.allclose(reward.numpy(), g["nsc_reward"])
+    assert _close(a.grad.gather(2, t("saic_seq").unsqueeze(2)).squeeze(2).numpy(), g["nsc_grad_picked"], 1e-7)
+    for rl_kl, tag in ((False, "lw"), (True, "lw_kl")):
+        ls, ln = t("saic_logprob").clone().requires_grad_(True), t("naic_logprob").clone().requires_grad_(True)
+        o = O.loss_wrapper_uic_rl(ls, t("saic_seq"), ln, t("naic_seq"), g["saic_scores"], g["naic_scores"], n, rl_kl=rl_kl)
+        assert abs(float(o["loss"]) - float(g[tag + "_loss"])) < 1e-5 and abs(float(o["struc_loss"]) - float(g[tag + "_struc_loss"])) < 1e-5
+        assert np.allclose(o["reward"].numpy(), g[tag + "_reward"])
+        if rl_kl:
+            o["loss"].backward()
+            assert _close(ln.grad.numpy(), g["lw_kl_grad_naic"], 1e-6)
+            assert _close(ls.grad.gather(2, t("saic_seq").unsqueeze(2)).squeeze(2).numpy(), g["lw_kl_grad_saic_picked"], 1e-7)
+
+
+def test_oracle_loss_wrapper_xe_branch(manifest, weight_cache):
+    """LossWrapper.forward (train_mode UIC, struc_flag False): the seven entries of its out dict."""
+    m = manifest["tiny_loss_wrapper_xe"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    w = O.as_torch(sd)
+    g = load_golden("tiny_loss_wrapper_xe")
+    t = lambda k: torch.from_numpy(g[k])
+    outs = O.forward_uic(w, cfg, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                         t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"))
+    loss, parts = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert list(g["out_keys"]) == ["loss", "SA_length_loss", "SA_phrase_loss", "SA_syn_loss", "NA_length_loss", "NA_phrase_loss", "NA_syn_loss"]
+    assert np.allclose([float(loss)] + [float(p) for p in parts], g["out_values"], atol=1e-5)
+
+
+def test_oracle_xe_full_size(manifest, weight_cache):
+    """The reference's XE forward at the full size (2 images x 5 captions): best-two log-probs, the labels' log-probs, losses."""
+    m = manifest["full_train_xe"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    w = O.as_torch(sd)
+    g = load_golden("full_train_xe")
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        outs = O.forward_uic(w, cfg, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                             t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"))
+    real = t("labels").reshape(-1, cfg.seq_length + 2)[:, 1:-1].long()
+    for i, o in enumerate(outs):
+        if f"out{i}" in g:
+            assert _close(o.numpy(), g[f"out{i}"], 1e-5), i
+        else:
+            assert _close(torch.topk(o, 2, dim=2)[0].numpy(), g[f"out{i}_top2_val"], 2e-5), i
+            assert _close(o.gather(2, real.unsqueeze(2)).squeeze(2).numpy(), g[f"out{i}_picked"], 2e-5), i
+    loss, parts = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4 * float(g["losses"][0])
