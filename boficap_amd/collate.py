@@ -23,7 +23,8 @@ import numpy as np
 
 def phrase_collate(labels: np.ndarray, phrase_len: np.ndarray, phrase_syn_real: np.ndarray, *, pad_idx=0, bos_idx=1, eos_idx=2,
                    len_idx=3) -> Dict[str, np.ndarray]:
-    """labels int64 [N, S+2] (position 0 = 0, tokens from position 1); phrase_len / phrase_syn_real int64 [N, S]
+    """labels int64 [N, S+2] ([BOS] at position 0, tokens from position 1, [EOS] at S+1 as the loader frames them,
+    dataloader.py:295-300); phrase_len / phrase_syn_real int64 [N, S]
     (real phrases first, zeros after).  Returns the loader's phrase tensors, un-grouped ([N, ...])."""
     labels = np.asarray(labels, np.int64)
     plen = np.asarray(phrase_len, np.int64)
@@ -80,10 +81,11 @@ def phrase_collate(labels: np.ndarray, phrase_len: np.ndarray, phrase_syn_real: 
 
 def synthetic_captions(cfg, n_captions: int, seed: int = 0):
     """Random captions for benchmarks and tests: 2..6 phrases of 1..3 tokens, syntactic labels in 4..6, token ids
-    above the special/label range.  Returns (labels [N, S+2], phrase_len [N, S], phrase_syn_real [N, S])."""
+    above the special/label range, framed by [BOS] / [EOS].  Returns (labels [N, S+2], phrase_len [N, S], phrase_syn_real [N, S])."""
     rng = np.random.Generator(np.random.PCG64(seed))
     S, L = cfg.seq_length, cfg.seq_length + 2
     labels = np.zeros((n_captions, L), np.int64)
+    labels[:, 0], labels[:, L - 1] = cfg.bos_idx, cfg.eos_idx             # as the loader frames a caption (dataloader.py:295-300)
     plen = np.zeros((n_captions, S), np.int64)
     psyn = np.zeros((n_captions, S), np.int64)
     for n in range(n_captions):

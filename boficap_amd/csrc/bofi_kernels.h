@@ -41,6 +41,7 @@ struct LinearArgs {
     float mask_scale;
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
+extern double g_gemm_flops, g_gemm_flops_skippable;   // GEMM FLOPs enqueued since the last reset (host-side tally; gemm.hip)
 int launch_linear_glds(const LinearArgs& a, hipStream_t st);      // gemm_glds.hip; -1 = not eligible
 
 struct AttnArgs {

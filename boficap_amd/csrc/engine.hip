@@ -262,6 +262,7 @@ struct bofi_engine {
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
                            float* syn_logp, bool early, hipStream_t s);
+    int enqueue_fill(const int* att_len, int B, int R, int flags, int64_t* seq, float* seq_logprob, hipStream_t s);
     int enqueue_decode_saic(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
                             float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn, int* bound_iters, hipStream_t s);
     int enqueue_decode(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
@@ -346,8 +347,16 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
                                    cfg.heads, BOUND_ATTN, nullptr, nullptr, s));
     for (int it = 0; it < S; ++it)
         ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
-    // ---- filling pass (decode_NA :570-587); with refinement the pass is repeated with the previous round's ids as
-    // decoder input tokens (the glat_input hook of decode_NA :570-574 -- the reference has no refinement loop itself)
+    ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
+    ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
+    return BOFI_OK;
+}
+
+// ---- filling pass (decode_NA :570-587) on the slot layout in st.ext_syn / st.last and the cross K|V of the preceding
+// encode; with refinement the pass is repeated with the previous round's ids as decoder input tokens (the glat_input hook
+// of decode_NA :570-574 -- the reference has no refinement loop itself)
+int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64_t* seq, float* seq_logprob, hipStream_t s) {
+    const int d = cfg.d_model, dt = cfg.dtype, S = cfg.seq_length, M = B * S;
     const int rounds = 1 + ((flags >> BOFI_FLAG_REFINE_SHIFT) & 15);
     const void* xa = stream_t(x_fill, xb_fill);
     float* lg = seq_logprob ? seq_logprob : logits;
@@ -383,7 +392,6 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s)); }
     ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s));
     }
-    ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
     return BOFI_OK;
 }
 
@@ -511,6 +519,9 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->cap_stream = nullptr;
     e->run_stream = nullptr;
     e->is_fork = true;
+    e->q1_group = 0;                             // per-call knobs are not inherited (the Python handle starts from the defaults)
+    e->sample_temperature = 1.0f;
+    e->sample_seed = 0;
     e->st = bofi::BoundState{};
     int rc = e->alloc_workspace();
     if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
@@ -782,6 +793,18 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
                                    e->cfg.seq_length, e->cfg.d_model, e->cfg.head_hidden, e->cfg.heads, BOUND_ATTN, nullptr, nullptr,
                                    (hipStream_t)stream));
     return e->enqueue_bound_iter(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, false, (hipStream_t)stream);
+}
+
+int bofi_engine_fill_naic(bofi_engine_t* e, const int* ext_syn, const int* last, int B, int R, const int* att_len, int flags,
+                          int64_t* seq, float* seq_logprob, void* stream) {
+    g_err.clear();
+    ENG_OK(check_call(e, B, R));
+    if (!ext_syn || !last || !seq) return fail(BOFI_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    ENG_HIP(hipMemcpyAsync(e->st.ext_syn, ext_syn, (size_t)B * e->L * sizeof(int), hipMemcpyDeviceToDevice, s));
+    ENG_HIP(hipMemcpyAsync(e->st.last, last, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    e->cur_B = B;
+    return e->enqueue_fill(att_len, B, R, flags & ~BOFI_FLAG_GRAPH, seq, seq_logprob, s);
 }
 
 int bofi_engine_decode_saic(bofi_engine_t* e, const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags,

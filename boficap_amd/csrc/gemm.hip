@@ -275,9 +275,14 @@ static int launch_tiles(const GemmParams& p, hipStream_t st) {
     return BOFI_OK;
 }
 
+// host-side tally of the GEMM work handed to the device (bofi_gemm_flops): 2 M N K per launch; launches that carry an early-out
+// word (iterations of the bounding / semi-autoregressive loops that return at once when every image is finished) separately
+double g_gemm_flops = 0.0, g_gemm_flops_skippable = 0.0;
+
 int launch_linear(const LinearArgs& a, hipStream_t st) {
     if (!a.x || !a.w || !a.y || a.M < 0 || a.N <= 0 || a.K <= 0) return BOFI_ERR_ARG;
     if (a.M == 0) return BOFI_OK;
+    (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
     const bool bf = a.w_dtype == BOFI_DT_BF16;
     if (!bf && a.w_dtype != BOFI_DT_F32) return BOFI_ERR_ARG;
     if (a.x_dtype != a.w_dtype && a.x_dtype != BOFI_DT_F32) return BOFI_ERR_ARG;
@@ -342,3 +347,9 @@ extern "C" int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w
     return bofi::launch_linear(a, (hipStream_t)stream);
 }
 
+extern "C" double bofi_gemm_flops(int reset, double* skippable) {
+    const double v = bofi::g_gemm_flops;
+    if (skippable) *skippable = bofi::g_gemm_flops_skippable;
+    if (reset) bofi::g_gemm_flops = bofi::g_gemm_flops_skippable = 0.0;
+    return v;
+}

@@ -203,6 +203,7 @@ int launch_gemm_tn_grouped(int n, const void* const* a, const int* lda, const in
     if (n < 0 || (n && (!a || !lda || !a_cols || !b || !ldb || !b_cols || !c || !ldc || !M || !NI || !NJ))) return BOFI_ERR_ARG;
     for (int e = 0; e < n; ++e)
         if (int rc = check_tn(a[e], lda[e], a_cols[e], b[e], ldb[e], b_cols[e], c[e], ldc[e], M[e], NI[e], NJ[e])) return rc;
+    for (int e = 0; e < n; ++e) g_gemm_flops += 2.0 * M[e] * NI[e] * NJ[e];
     static const int forced_wt = [] { const char* v = getenv("BOFI_TN_WT"); return v ? atoi(v) : 0; }();   // developer knob: 2 or 4
     // two classes of problems: outputs of at least 128 x 128 take the 128 x 128 tile, the small ones (classifier heads) 64 x 64
     for (int big = 1; big >= 0; --big) {
@@ -242,6 +243,7 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
     if (a_cols < NI || b_cols < NJ || a_cols % 8 || b_cols % 8 || lda < a_cols || ldb < b_cols || lda % 8 || ldb % 8) return BOFI_ERR_ARG;
     if (((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return BOFI_ERR_ARG;
     if (M == 0) return BOFI_OK;
+    g_gemm_flops += 2.0 * M * NI * NJ;
     const int ti = (NI + 63) / 64, tj = (NJ + 63) / 64;
     // workgroups to aim for: every extra row split adds a tile of atomics, so small outputs (<= 128 tiles) take half as many
     // (measured, tools/mb_tn.py: 512x512 20.0 -> 17.1 us, 1024x512 over 2304 rows 17.1 -> 12.8 us; larger outputs prefer 1024)

@@ -241,3 +241,18 @@ class BofiEngine:
         hip.check(self._lib.bofi_engine_bound_step(self._h, hip.ptr(ext_syn.contiguous()), hip.ptr(last.contiguous()), B, R,
                                                    hip.ptr(att_len), hip.ptr(llp), hip.ptr(slp), hip.stream_ptr()), "bofi_engine_bound_step")
         return llp, slp
+
+    def fill_naic(self, ext_syn: torch.Tensor, last: torch.Tensor, R: int, att_len: Optional[torch.Tensor] = None, *, strict_q1: bool = True,
+                  raw_logits: bool = False, refine_rounds: int = 0):
+        """The filling pass alone on a given slot layout (``ext_syn`` int32 [B, S+2], ``last`` int32 [B]) and the memory of the
+        preceding ``encode``: (seq int64 [B, S], seq_logprob float32 [B, S, V])."""
+        B = ext_syn.size(0)
+        if ext_syn.dtype != torch.int32 or last.dtype != torch.int32 or ext_syn.size(1) != self.cfg.bound_len or last.numel() != B:
+            raise hip.BofiHipError("ext_syn must be int32 [B, S+2] and last int32 [B]")
+        S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, ext_syn.device
+        seq = torch.empty(B, S, dtype=torch.int64, device=dev)
+        lp = torch.empty(B, S, V, dtype=torch.float32, device=dev)
+        flags = (hip.FLAG_STRICT_Q1 if strict_q1 else 0) | (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (refine_rounds << hip.FLAG_REFINE_SHIFT)
+        hip.check(self._lib.bofi_engine_fill_naic(self._h, hip.ptr(ext_syn.contiguous()), hip.ptr(last.contiguous()), B, R, hip.ptr(att_len), flags,
+                                                  hip.ptr(seq), hip.ptr(lp), hip.stream_ptr()), "bofi_engine_fill_naic")
+        return seq, lp

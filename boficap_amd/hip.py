@@ -77,6 +77,8 @@ SIGNATURES = {
     "bofi_engine_decode_saic": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bofi_engine_encode": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "bofi_engine_bound_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bofi_gemm_flops": (C.c_double, [_I, _P]),
+    "bofi_engine_fill_naic": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
 }
 
 _lib = None
@@ -138,3 +140,10 @@ def stream_ptr():
         import torch
         _torch = torch
     return _torch._C._cuda_getCurrentRawStream(_torch.cuda.current_device())
+
+
+def gemm_flops(reset: bool = False):
+    """(GEMM FLOPs enqueued since the last reset, the part of them in early-out launches) -- host-side tally of the library."""
+    sk = C.c_double(0.0)
+    v = lib().bofi_gemm_flops(1 if reset else 0, C.cast(C.byref(sk), C.c_void_p))
+    return float(v), float(sk.value)

@@ -21,6 +21,8 @@ class FlatBucket:
     """Re-homes the parameters of ``module`` into one flat buffer (values preserved) and gives every parameter a
     ``.grad`` that is a view into a second flat buffer.  Works on any device (the gloo tests use the CPU)."""
 
+    DEAD_PREFIXES = ("model.length_predictor.length_attn.", "model.length_predictor.ff.")
+
     def __init__(self, module: torch.nn.Module):
         named = list(module.named_parameters())
         if not named:
@@ -36,6 +38,11 @@ class FlatBucket:
                 groups[key] = []
                 order.append(key)
             groups[key].append((name, p))
+        # parameters the UIC model never reads (the unused length_attn / ff copies inside LengthPredictor_UIC,
+        # TransformerModel.py:350-355; 3.15 M elements at the full size) go LAST: the gradients of everything in front of them
+        # -- the live prefix -- are what the data-parallel exchange moves
+        dead = lambda key: ((key[0] if isinstance(key, tuple) else key) + ".").startswith(self.DEAD_PREFIXES)
+        order = [k for k in order if not dead(k)] + [k for k in order if dead(k)]
         self.names = [n for key in order for n, _ in groups[key]]
         self.params = [p for key in order for _, p in groups[key]]
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -46,6 +53,8 @@ class FlatBucket:
             self.offsets.append(n)
             n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = n
+        first_dead = next((i for i, nm in enumerate(self.names) if nm.startswith(self.DEAD_PREFIXES)), None)
+        self.live_numel = n if first_dead is None else self.offsets[first_dead]
         self.flat = torch.zeros(n, dtype=dt, device=dev)
         self.grad = torch.zeros(n, dtype=dt, device=dev)
         with torch.no_grad():
@@ -77,13 +86,65 @@ class FlatBucket:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
     def all_reduce(self, group=None) -> float:
-        """Sum the flat gradient bucket over the ranks (one collective); returns the scale that turns the sum into
-        the mean of the per-rank gradients (= the reference's loss.mean() over DataParallel replicas, train.py:217)."""
+        """Sum the WHOLE flat gradient bucket over the ranks in one blocking collective; returns the scale that turns the sum
+        into the mean of the per-rank gradients (= the reference's loss.mean() over DataParallel replicas, train.py:217).
+        The simplest form of the exchange: kept as the reference the chunked / bf16 forms are tested against."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return 1.0
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / dist.get_world_size(group)
+
+    def chunk_bounds(self, chunks: int):
+        """The live prefix cut into ``chunks`` near-equal pieces on 16 KiB boundaries: [(start, end)], in bucket order."""
+        chunks = max(1, int(chunks))
+        gran = 4096
+        per = (self.live_numel + chunks - 1) // chunks
+        per = (per + gran - 1) // gran * gran
+        out, o = [], 0
+        while o < self.live_numel:
+            out.append((o, min(o + per, self.live_numel)))
+            o += per
+        return out
+
+    def exchange(self, group=None, chunks: int = 4, wire: Optional[str] = None):
+        """The data-parallel exchange of one step over the LIVE prefix of the gradient bucket only, as ``chunks`` collectives.
+
+        Yields (start, end, scale) per chunk as soon as that chunk's reduced gradients are usable, so that the caller can run the
+        optimiser on chunk i while chunks i+1.. are still on the wire.  The chunks are started back to back, last part of the
+        bucket first (the decoder's and generator's parameters sit at the end of the live prefix and the backward finishes
+        them first).  ``wire='bf16'``: the reduction is done by hand as the mesh-direct exchange that matches xGMI's
+        point-to-point links -- every rank sends piece r of its bf16-rounded chunk to rank r (all_to_all), sums the pieces it
+        received in float32, rounds once and all-gathers the result: half the bytes per link, one bf16 rounding of each
+        addend and one of the sum (float32 accumulation in between), and every rank ends with bit-identical gradients.
+        World size 1: one (0, live_numel, 1.0)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            yield 0, self.live_numel, 1.0
+            return
+        world = dist.get_world_size(group)
+        scale = 1.0 / world
+        bounds = self.chunk_bounds(chunks)[::-1]
+        if wire is None:
+            works = [dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True) for a, b in bounds]
+            for (a, b), w in zip(bounds, works):
+                w.wait()
+                yield a, b, scale
+            return
+        if wire != "bf16":
+            raise ValueError("wire must be None or 'bf16'")
+        for a, b in bounds:
+            n = b - a
+            piece = (n + world - 1) // world
+            send = torch.zeros(piece * world, dtype=torch.bfloat16, device=self.grad.device)
+            send[:n].copy_(self.grad[a:b])
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)                  # reduce-scatter, by hand: piece r of every rank -> rank r
+            mine = recv.view(world, piece).float().sum(0).to(torch.bfloat16)   # float32 accumulation on receipt
+            full = torch.empty(piece * world, dtype=torch.bfloat16, device=self.grad.device)
+            dist.all_gather_into_tensor(full, mine, group=group)
+            self.grad[a:b].copy_(full[:n])
+            yield a, b, scale
 
 
 class WeightOperands:
@@ -201,6 +262,8 @@ class XETrainer:
         self.m = torch.zeros_like(self.bucket.flat)
         self.v = torch.zeros_like(self.bucket.flat)
         self._step = 0
+        self.dp_chunks = int(g("bofi_dp_chunks", 4))           # collectives per step over the live gradient prefix
+        self.dp_wire = g("bofi_dp_wire", None)                 # None: float32 all-reduce; 'bf16': mesh-direct bf16 exchange, fp32 accumulation
         self.graph = bool(graph)
         self.unpadded = bool(unpadded)                         # add_token_rows: run the decoder over the captions' real positions only
         # bf16 mode: weight operands of the GEMMs come from a bf16 copy of the bucket the optimiser kernel maintains
@@ -421,20 +484,36 @@ class XETrainer:
     def optimizer_step(self, grad_scale: float = 1.0) -> float:
         self._step += 1
         lr = self.rate()
+        self._adam_range(0, self.bucket.numel, lr, grad_scale)
+        self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1     # the decode engine repacks on next use
+        return lr
+
+    def _adam_range(self, a: int, b_: int, lr: float, grad_scale: float) -> None:
+        """Averaging + clip by value + Adam (+ the bf16 copy of the weights) on elements [a, b) of the four flat streams."""
+        import ctypes as C
         b = self.bucket
         shadow = self.ops.shadow if self.ops is not None and self.ops._version is not None else None
-        hip.check(hip.lib().bofi_adam_step(hip.ptr(b.flat), hip.ptr(b.grad), hip.ptr(self.m), hip.ptr(self.v), hip.ptr(shadow), b.numel, lr,
+        at = lambda t, es: None if t is None else C.c_void_p(t.data_ptr() + a * es)
+        hip.check(hip.lib().bofi_adam_step(at(b.flat, 4), at(b.grad, 4), at(self.m, 4), at(self.v, 4), at(shadow, 2), b_ - a, lr,
                                            self.beta1, self.beta2, self.eps, self._step, self.clip, grad_scale, hip.stream_ptr()),
                   "bofi_adam_step")
-        self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1     # the decode engine repacks on next use
+
+    def reduce_and_step(self) -> float:
+        """The tail of a data-parallel step: the gradient exchange over the live prefix in chunks, the optimiser kernel on each
+        chunk as it arrives (the later chunks are still on the wire meanwhile), then the parameters no rank has a gradient for
+        (they see a zero gradient: Adam leaves them where they are, as in the reference where their .grad stays None)."""
+        self._step += 1
+        lr = self.rate()
+        for a, b_, scale in self.bucket.exchange(self.group, self.dp_chunks, self.dp_wire):
+            self._adam_range(a, b_, lr, scale)
+        self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1
         return lr
 
     # ------------------------------------------------------------------ the step
     def step(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
         """Returns (loss, parts) as device scalars of THIS rank's shard (no host sync inside)."""
         loss, parts = self.forward_backward(batch, glat_p)
-        scale = self.bucket.all_reduce(self.group)
-        self.optimizer_step(scale)
+        self.reduce_and_step()
         return loss, parts
 
     # ------------------------------------------------------------------ self-critical step (loss_wrapper.py:181-230, structure_loss_weight 1)
@@ -456,7 +535,10 @@ class XETrainer:
             naic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
         model.train(was_training)
         seq_s, seq_n = saic["seq"].cpu(), naic["seq"].cpu()    # the scorer runs on the host
-        self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean()}
+        S = model.cfg.seq_length
+        self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean(),
+                         # share of the semi-autoregressive loop's S enqueued iterations in which some caption was still open
+                         "active_share": min(S, int(saic["phrase_num"].max()) + 1) / S}
         s_saic, s_naic = score_fn(seq_s), score_fn(seq_n)
         dev = att_feats.device
         # the gradient pass reads tensors only: the samples' index tensors (host collate of the sampled layouts) and the scores
@@ -473,8 +555,7 @@ class XETrainer:
             loss, m1, m2 = self._rl_replay(b, sample_n)
         else:
             loss, m1, m2 = self._rl_forward_backward(b, att_masks, sample_n)
-        scale = self.bucket.all_reduce(self.group)
-        self.optimizer_step(scale)
+        self.reduce_and_step()
         return loss, m1, m2
 
     def _rl_forward_backward(self, b, att_masks, sample_n):
@@ -534,9 +615,60 @@ class XETrainer:
 
     # ------------------------------------------------------------------ checkpoint (optimizer.pth of misc.py:87-102)
     def state_dict(self):
-        return {"_step": self._step, "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu()}
+        """The optimiser state in the REFERENCE's layout: what ``NoamOpt.state_dict()`` returns (captioning/utils/misc.py:195-198),
+        i.e. ``torch.optim.Adam(model.parameters()).state_dict()`` plus ``_step``:
+        ``{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [0..P-1]}], '_step': n}`` with i the
+        index of the parameter in ``model.parameters()`` order and tensors in the parameter's own shape.  Parameters that never
+        received a gradient (the unused length_attn / ff copies) have no entry, as in torch (their ``.grad`` stays None).
+        ``_bofi`` (ignored by torch's loader) carries the dropout counters so that a resumed run does not replay the masks of
+        step 1."""
+        b = self.bucket
+        off = {id(p): o for p, o in zip(b.params, b.offsets)}
+        params = list(self.model.parameters())
+        m, v = self.m.detach().cpu(), self.v.detach().cpu()
+        state = {}
+        for i, (name, p) in enumerate(self.model.named_parameters()):
+            if name.startswith(b.DEAD_PREFIXES) or self._step == 0:
+                continue
+            o, n = off[id(p)], p.numel()
+            state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": m[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": v[o:o + n].view(p.shape).clone()}
+        template = torch.optim.Adam([torch.nn.Parameter(torch.empty(0)) for _ in params], lr=0.0, betas=(self.beta1, self.beta2),
+                                    eps=self.eps).state_dict()["param_groups"][0]
+        group = dict(template, lr=self.rate() if self._step else 0.0, params=list(range(len(params))))
+        return {"state": state, "param_groups": [group], "_step": self._step,
+                "_bofi": {"fwd_calls": self._fwd_calls, "model_step": getattr(self.model, "_step", 0),
+                          "sample_calls": getattr(self.model, "_sample_calls", 0)}}
 
     def load_state_dict(self, sd):
-        self._step = int(sd["_step"])
-        self.m.copy_(sd["exp_avg"])
-        self.v.copy_(sd["exp_avg_sq"])
+        """Accepts the reference's ``optimizer.pth`` (and this class's own): per-parameter Adam moments scattered into the flat
+        m / v streams through the bucket's offsets.  ``step`` may be a tensor (torch >= 1.12) or an int (the reference's torch 1.7)."""
+        if "state" not in sd or "param_groups" not in sd:
+            raise hip.BofiHipError("optimizer.pth: expected torch.optim.Adam's state_dict layout ({'state', 'param_groups'[, '_step']})")
+        b = self.bucket
+        off = {id(p): o for p, o in zip(b.params, b.offsets)}
+        params = list(self.model.parameters())
+        order = sd["param_groups"][0]["params"]
+        if len(order) != len(params):
+            raise hip.BofiHipError(f"optimizer.pth holds {len(order)} parameters, the model has {len(params)}")
+        self.m.zero_(); self.v.zero_()
+        steps = set()
+        for pos, key in enumerate(order):
+            st = sd["state"].get(key)
+            if st is None:
+                continue
+            p = params[pos]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise hip.BofiHipError(f"optimizer.pth: parameter {pos} has moments of shape {tuple(st['exp_avg'].shape)}, the model wants {tuple(p.shape)}")
+            o, n = off[id(p)], p.numel()
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise hip.BofiHipError(f"optimizer.pth: parameters at different Adam steps {sorted(steps)} (the fused kernel keeps one step count)")
+        adam_step = steps.pop() if steps else 0
+        self._step = int(sd.get("_step", adam_step))             # NoamOpt's own counter (misc.py:195-204); plain Adam: its step
+        extra = sd.get("_bofi", {})
+        self._fwd_calls = int(extra.get("fwd_calls", self._step))
+        self.model._step = int(extra.get("model_step", self._step))
+        self.model._sample_calls = int(extra.get("sample_calls", 0))

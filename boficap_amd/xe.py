@@ -1066,11 +1066,21 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
             tok_mask = torch.arange(Sd, device=dev).unsqueeze(0) < ntok.unsqueeze(1)
             same = ((pred == real) & tok_mask).sum(1)
             keep_prob = ((ntok - same) / ntok * glat_p).unsqueeze(-1) * tok_mask.float()
-            keep = torch.rand(real.shape, device=dev) < keep_prob
+            keep = _glance_draws(N, cfg.seq_length, dev)[:, :Sd] < keep_prob
             fill_in = torch.where(keep, real, fill_in).contiguous()
     x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap, token_rows is None)
     na_tok = token_logprobs(x)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+
+
+def _glance_draws(N: int, S: int, dev) -> torch.Tensor:
+    """The uniform draws of the glancing pass, one per (caption, position) as the reference takes them (torch.rand over
+    [N, S], TransformerModel.py:455).  HINTS["glat_uniform"] injects them (parity tests feed both sides the same numbers)."""
+    u = HINTS.pop("glat_uniform", None)
+    if u is None:
+        return torch.rand(N, S, device=dev)
+    u = u.to(dev).float().reshape(N, S)
+    return u
 
 
 _ORDER_CACHE: dict = {}
@@ -1170,7 +1180,7 @@ def _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, label
             in_cap = torch.arange(T, device=dev) < (row_start[-1] + row_count[-1])
             same = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, row_cap, ((pred == real) & in_cap).long())
             keep_prob = ((ntok - same) / ntok * glat_p)[row_cap] * in_cap.float()
-            keep = torch.rand(T, device=dev) < keep_prob
+            keep = _glance_draws(N, cfg.seq_length, dev)[row_cap, row_pos] < keep_prob
             fill_in = torch.where(keep, real, fill_in)
     with torch.no_grad():
         tok2 = torch.where(pair_na, fill_in[pair_src], seq_c[pair_src]).contiguous()
@@ -1294,7 +1304,7 @@ def _fill_unpadded(P, cfg, drop, emb, vocab, unpadded, labels, phrase_length, ex
                 pred = greedy_ids(vocab(x)).view(T)
                 same = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, row_cap, ((pred == real) & in_cap).long())
                 keep_prob = ((ntok - same) / ntok * glat_p)[row_cap] * in_cap.float()
-                keep = torch.rand(T, device=dev) < keep_prob
+                keep = _glance_draws(N, cfg.seq_length, dev)[row_cap, row_pos] < keep_prob
                 fill_in = torch.where(keep, real, fill_in).contiguous()
         x = decode_rows(P, cfg, drop, emb(fill_in, syn_c, Sd, row_pos), memory, kv_cache, N, Sd, R, spi, klen_na, cross_len, True, seg)
         na_tok = log_softmax(vocab(x))
@@ -1364,7 +1374,7 @@ def rl_prepare(cfg, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool 
         if seq.shape[1] != S or N % sample_n:
             raise hip.BofiHipError(f"sampled captions {seq.shape} for {sample_n} samples per image")
         labels = np.zeros((N, S + 2), np.int64)
-        labels[:, 0] = cfg.bos_idx            # core_SAIC starts from seq[:, 0] = BOS (TransformerModel.py:1900); the loader's labels have 0 there
+        labels[:, 0] = cfg.bos_idx            # core_SAIC starts from seq[:, 0] = BOS (TransformerModel.py:1900), as the loader's labels do (dataloader.py:298)
         labels[:, 1:S + 1] = seq
         plen = r["phrase_length"].detach().cpu().numpy().astype(np.int64)
         psyn = np.where(plen > 0, r["phrase_syn"].detach().cpu().numpy().astype(np.int64), 0)
@@ -1490,6 +1500,16 @@ def new_self_critical(logprobs, seq, scores, sample_n: int):
     picked = logprobs.gather(2, seq.unsqueeze(2)).squeeze(2)
     loss = (-picked * mask * reward.view(-1, 1)).sum() / mask.sum()
     return loss, sc
+
+
+def rl_kl_term(naic_logprobs, saic_logprobs, saic_seq):
+    """The KL term of LossWrapper's UIC struc_flag branch under ``rl_kl`` (captioning/modules/loss_wrapper.py:216-222):
+    sum over the SAIC caption's tokens (seq > 0) of KL(exp(SAIC log-probs), detached || NAIC) / (count + 1e-6), with
+    nn.KLDivLoss(reduction='none') = target * (log target - input) and 0 where target == 0."""
+    mask = (saic_seq.to(naic_logprobs.device) > 0).unsqueeze(2)
+    target = torch.exp(saic_logprobs).detach()
+    kl = torch.where(target > 0, target * (torch.log(target) - naic_logprobs), torch.zeros_like(target))
+    return torch.sum(kl * mask) / (torch.sum(mask) + 1e-6)
 
 
 def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):

@@ -335,6 +335,21 @@ int bofi_engine_encode(bofi_engine_t* e, const void* att_feats, int feats_dtype,
 int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last, int B, int R,
                            const int* att_len, float* len_logp, float* syn_logp, void* stream);
 
+/* Measurement aid: GEMM FLOPs (2 M N K per launch of bofi_linear* / the weight-gradient GEMMs, engine calls included) enqueued
+ * by this process since the last reset; host-side tally, not thread-safe.  Launches that carry an early-out word (loop
+ * iterations that return at once when every image is finished) are tallied apart, into *skippable (may be NULL).
+ * bench.py prices the EXECUTED work of a step with it. */
+double bofi_gemm_flops(int reset, double* skippable);
+
+/* The filling pass alone on a GIVEN slot layout (teacher-forced): decode_NA TransformerModel.py:570-587 -> logit /
+ * log_softmax AttModel.py:203-210 -> greedy pick CaptionModel.py:388-390 -> pad tail AttModel.py:422-423, on the memory of
+ * the preceding bofi_engine_encode.  ext_syn int32 [B, S+2] (extend_phrase_syn of core_NAIC :1829: position 0 = [LEN],
+ * placed slots = their label), last int32 [B] (1 + tokens laid out).  flags: BOFI_FLAG_STRICT_Q1 / RAW_LOGITS / refinement
+ * rounds as for decode_naic.  Lets a reduced-precision engine be compared with the oracle position by position on the
+ * oracle's own layout, whatever its own bounding pass would have picked. */
+int bofi_engine_fill_naic(bofi_engine_t* e, const int* ext_syn, const int* last, int B, int R, const int* att_len, int flags,
+                          int64_t* seq, float* seq_logprob, void* stream);
+
 /* Last HIP error string seen by this library on the calling thread (for exceptions in the host). */
 const char* bofi_last_error(void);
 

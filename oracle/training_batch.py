@@ -2,7 +2,7 @@
 
 Restates captioning/data/dataloader.py:343-428 (the phrase-aware part of collate_func) for captions
 drawn at random: per caption 2..6 phrases of 1..3 tokens, labels [N, S+2] with
-position 0 = 0 and the tokens from position 1 (dataloader.py:296-300).
+[BOS] at position 0, the tokens from position 1 and [EOS] at position S+1 (dataloader.py:295-300).
 """
 from __future__ import annotations
 
@@ -14,6 +14,7 @@ def make_training_batch(cfg, n_img: int, seq_per_img: int, seed: int = 0):
     S, L = cfg.seq_length, cfg.seq_length + 2
     N = n_img * seq_per_img
     labels = np.zeros((N, L), np.int64)
+    labels[:, 0], labels[:, L - 1] = cfg.bos_idx, cfg.eos_idx     # tmp_label[:, 0] = bos_idx; tmp_label[:, seq_length + 1] = eos_idx
     phrase_num = np.zeros(N, np.int64)                    # real phrases; data['phrase_num'] = this + 1
     plen = np.zeros((N, S), np.int64)
     psyn = np.zeros((N, S), np.int64)

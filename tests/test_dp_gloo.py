@@ -102,3 +102,73 @@ def test_flat_gradient_bucket_all_reduce_two_ranks():
         assert p.exitcode == 0
     assert same_values and in_bucket and ok and scale == 0.5
     assert numel == 4 * 64                                                # every parameter padded to 64 elements (35, 5, 15, 3)
+
+
+def _exchange_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from boficap_amd import dp
+    from boficap_amd.trainer import FlatBucket
+    torch.set_num_threads(1)
+    dp.init_from_env("gloo")
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):                                         # parameter names of the UIC model, dead copies included
+        def __init__(self):
+            super().__init__()
+            mk = lambda *shape: torch.nn.Parameter(torch.randn(*shape))
+            self.model = torch.nn.Module()
+            self.model.length_predictor = torch.nn.Module()
+            lp = self.model.length_predictor
+            lp.length_attn = torch.nn.Module(); lp.length_attn.w = mk(300, 40)          # never read: no gradient on any rank
+            lp.ff = torch.nn.Module(); lp.ff.w = mk(50, 7)
+            lp.live = mk(129, 65)
+            self.model.decoder = mk(9000, 3)
+            self.att_embed = mk(70, 130)
+    net = Net()
+    bucket = FlatBucket(net)
+    dead_last = bucket.names[-2:] == ["model.length_predictor.length_attn.w", "model.length_predictor.ff.w"]
+    live = bucket.live_numel
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.zeros(bucket.numel)
+    local[:live] = torch.randn(live, generator=g)
+    bucket.grad.copy_(local)
+    scale = bucket.all_reduce()                                          # the reference form: one collective over everything
+    want = bucket.grad.clone() * scale
+    out = {}
+    for chunks, wire in ((1, None), (4, None), (7, None), (3, "bf16")):
+        bucket.grad.copy_(local)
+        seen = []
+        for a, b, sc in bucket.exchange(None, chunks, wire):
+            seen.append((a, b))
+            bucket.grad[a:b] *= sc
+        covered = sorted(seen)
+        tiled = covered[0][0] == 0 and covered[-1][1] == live and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        err = float((bucket.grad[:live] - want[:live]).abs().max())
+        untouched = bool(torch.equal(bucket.grad[live:], local[live:]))
+        ranks_agree = bool(torch.equal(dp.gather_rows(bucket.grad.unsqueeze(0))[0], dp.gather_rows(bucket.grad.unsqueeze(0))[1]))
+        out[(chunks, wire)] = (len(seen), tiled, err, untouched, ranks_agree, seen[0][0] > seen[-1][0] if len(seen) > 1 else True)
+    if rank == 0:
+        ret.put((dead_last, live, bucket.numel, out, float(want.abs().max())))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_chunked_and_bf16_exchange_equal_the_flat_all_reduce():
+    """The step's exchange -- live prefix only, several collectives started last-chunk-first, optionally the bf16 mesh-direct
+    form with float32 accumulation -- against the single flat all-reduce (2 gloo ranks)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    dead_last, live, numel, out, scale = ret.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert dead_last and live < numel and numel - live >= 300 * 40 + 50 * 7
+    for (chunks, wire), (n, tiled, err, untouched, agree, reversed_order) in out.items():
+        assert tiled and untouched and agree and reversed_order, (chunks, wire)
+        assert n <= chunks
+        assert err == 0.0 if wire is None else err < 2e-2 * scale, (chunks, wire, err)

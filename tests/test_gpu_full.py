@@ -1,0 +1,503 @@
+"""The configurations BASELINE.json quotes its metric on, at their FULL size (d_model 512, V 9 491, 6 + 6 (+1) layers) on the
+MI355X: XE step 64 x 5 bf16 (config 3), self-critical step 10 x 5 (config 4), refinement at batch 256 (config 5), the
+full-size reference fixtures (XE step of the reference itself, multi-phrase SAIC, quirk Q1 shortening), and the bf16
+tolerance of north_star shown on EVERY image with the oracle's layout teacher-forced."""
+import numpy as np
+import pytest
+import torch
+
+import boficap_oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _maxdiff(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def _model(weight_cache, manifest, case=None, *, gen_scale=1.0, patch=None, **opt_extra):
+    import captioning.models as models
+    if case is not None:
+        m = manifest[case]
+        cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    else:
+        cfg, sd = weight_cache("FULL", 0, gen_scale, None, patch)
+    opt = cfg.to_opt(**opt_extra)
+    model = models.setup(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return cfg, sd, model.cuda()
+
+
+# ------------------------------------------------------------------------------------------------ config 3: XE step
+def test_xe_full_size_vs_reference(weight_cache, manifest):
+    """float32 XE step of 2 images x 5 captions at the full size against what the REFERENCE produced for the same batch
+    (tests/golden/full_train_xe: best-two log-probs and the labels' log-probs of the token outputs, the bound outputs in full,
+    seven losses, gradient norm of all 311 - 12 parameters, every gradient of <= 512 elements)."""
+    from boficap_amd import xe
+    cfg, sd, model = _model(weight_cache, manifest, "full_train_xe")
+    model.eval()                                                # recorded with dropout off
+    g = load_golden("full_train_xe")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    fc = torch.zeros(g["att_feats"].shape[0], 0, device="cuda")
+    outs = model(fc, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                 t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"), -1.0)
+    real = t("labels").reshape(-1, cfg.seq_length + 2)[:, 1:-1].long()
+    for i, o in enumerate(outs):
+        if f"out{i}" in g:
+            assert _maxdiff(o, torch.from_numpy(g[f"out{i}"])) < 1e-4, f"output {i}"
+        else:
+            assert _maxdiff(torch.topk(o.detach(), 2, dim=2)[0], torch.from_numpy(g[f"out{i}_top2_val"])) < 1e-3, f"output {i} (best two)"
+            assert _maxdiff(o.detach().gather(2, real.unsqueeze(2)).squeeze(2), torch.from_numpy(g[f"out{i}_picked"])) < 1e-3, f"output {i} (labels)"
+    loss, parts = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss.detach()) - float(g["losses"][0])) < 1e-3 * float(g["losses"][0])
+    assert np.allclose([float(p.detach()) for p in parts], g["losses"][1:], rtol=1e-3, atol=1e-4)
+    loss.backward()
+    params = dict(model.named_parameters())
+    worst, n_checked = 0.0, 0
+    for n, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        p = params[n]
+        if ref_norm < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        got = float(p.grad.double().norm())
+        worst = max(worst, abs(got - ref_norm) / max(ref_norm, 1e-6))
+        assert abs(got - ref_norm) <= 2e-3 * max(ref_norm, 1e-3), (n, got, float(ref_norm))
+        if "grad." + n in g:
+            ref_g = torch.from_numpy(g["grad." + n])
+            assert _maxdiff(p.grad, ref_g) <= 2e-3 * max(1e-3, float(ref_g.abs().max())), n
+            n_checked += 1
+    assert n_checked > 100
+    print("full-size XE: worst relative grad-norm error vs the reference", worst)
+
+
+def _xe_batch(cfg, n_img, spi, seed):
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.weights import synthetic_att_feats
+    hb = synthetic_training_batch(cfg, n_img, spi, seed=seed)
+    b = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+    b["att_feats"] = torch.from_numpy(synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=seed + 1)).cuda()
+    b["max_phrase_num"] = int(hb["phrase_num"].max())
+    b["max_tokens"] = int((hb["phrase_length"].sum(-1) - 1).max())
+    b["att_masks"] = None
+    return hb, b
+
+
+def test_xe_full_config3_graph_paired_unpadded_equals_plain_padded(weight_cache, manifest):
+    """BASELINE config 3 as bench.py --mode xe runs it -- 64 images x 5 captions, bf16 operands, one hipGraph of the step, SA and
+    NA branch sharing every launch, decoder over the captions' real rows, grouped weight gradients -- against the plain path
+    (eager, padded [N, 20] decoder batch, one branch after the other, per-weight gradient GEMMs): same loss, same parts, same
+    gradient for every parameter.  Dropout off (the two row layouts draw different masks by construction)."""
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, fast = _model(weight_cache, manifest, bofi_train_dtype=torch.bfloat16)
+    _, _, plain = _model(weight_cache, manifest, bofi_train_dtype=torch.bfloat16)
+    fast.eval(); plain.eval()
+    hb, b = _xe_batch(cfg, 64, 5, seed=100)
+    tf = XETrainer(fast, graph=True)
+    tp = XETrainer(plain, graph=False, unpadded=False, paired=False, grouped_dw=False)
+    bf = tf.add_token_rows(dict(b), hb)
+    assert "pair_src" in bf and bf["pair_src"].numel() % 256 == 0
+    lp, pp = tp.forward_backward({k: v for k, v in b.items() if k != "max_tokens"})
+    for rep in range(3):                                        # eager warm-up inside, capture, replay
+        lf, pf = tf.forward_backward(bf)
+    assert len(tf._graphs) == 1
+    assert abs(float(lf) - float(lp)) < 2e-2 * abs(float(lp)), (float(lf), float(lp))
+    assert all(abs(float(x) - float(y)) < 2e-2 * max(1.0, abs(float(y))) for x, y in zip(pf, pp))
+    gf, gp = tf.bucket.grad, tp.bucket.grad
+    assert torch.isfinite(gf).all() and float(gp.abs().max()) > 0
+    rel = float((gf - gp).double().norm() / gp.double().norm())
+    assert rel < 3e-2, rel                                      # bf16 operands on both sides, different summation orders
+    # per parameter: the gradient norms agree and nothing is missing
+    for (n, pf_), (_, pp_) in zip(fast.named_parameters(), plain.named_parameters()):
+        a, c = float(pf_.grad.double().norm()), float(pp_.grad.double().norm())
+        assert abs(a - c) <= 6e-2 * max(c, 1e-4 * float(gp.double().norm())), (n, a, c)
+    print(f"config 3: loss {float(lf):.4f} vs {float(lp):.4f}, relative gradient distance {rel:.2e}")
+
+
+def test_xe_full_float32_fast_path_equals_plain(weight_cache, manifest):
+    """The same equality in the float32 parity mode on 8 images x 5 captions (tight tolerances)."""
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, fast = _model(weight_cache, manifest)
+    _, _, plain = _model(weight_cache, manifest)
+    fast.eval(); plain.eval()
+    hb, b = _xe_batch(cfg, 8, 5, seed=7)
+    tf, tp = XETrainer(fast, graph=True), XETrainer(plain, graph=False, unpadded=False, paired=False, grouped_dw=False)
+    lp, _ = tp.forward_backward({k: v for k, v in b.items() if k != "max_tokens"})
+    bf = tf.add_token_rows(dict(b), hb)
+    for rep in range(2):
+        lf, _ = tf.forward_backward(bf)
+    assert abs(float(lf) - float(lp)) < 1e-5 * abs(float(lp))
+    assert _maxdiff(tf.bucket.grad, tp.bucket.grad) <= 2e-4 * float(tp.bucket.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ config 4: self-critical step
+def test_rl_full_config4(weight_cache, manifest):
+    """BASELINE config 4: 10 images x 5 sampled captions per mode at the full size, bf16.  The differentiable re-forward returns
+    the log-prob rows the engine sampled from (both modes); the captured gradient pass equals the eager one; a step moves the
+    weights and leaves the bound heads alone."""
+    from boficap_amd import xe
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    n_img, n = 10, 5
+    cfg, sd, model = _model(weight_cache, manifest, patch="len_row_shared", bofi_compute_dtype=torch.bfloat16, bofi_train_dtype=torch.bfloat16,
+                            bofi_max_batch=64, seed=42)
+    pool = torch.from_numpy(synthetic_att_feats(60, 36, cfg.att_feat_size, seed=1235)).cuda()
+    fc0 = torch.zeros(60, 0, device="cuda")
+    model.eval()
+    with torch.no_grad():
+        pn = model(fc0, pool, None, opt={"train_mode": "NAIC", "sample_method": "greedy"}, mode="sample")[2]
+    att = pool[pn > 0][:n_img].contiguous()                    # an image without a phrase NaN-halts the whole SAIC batch (as in the reference)
+    assert att.size(0) == n_img
+    fc = torch.zeros(n_img, 0, device="cuda")
+    ks = ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")
+    with torch.no_grad():
+        o = {"sample_method": "sample", "sample_n": n, "temperature": 1.0}
+        saic = dict(zip(ks, model(fc, att, None, opt=dict(o, train_mode="SAIC"), mode="sample")[:5]))
+        naic = dict(zip(ks, model(fc, att, None, opt=dict(o, train_mode="NAIC"), mode="sample")[:5]))
+    assert saic["seq"].shape == (n_img * n, cfg.seq_length) and float((saic["seq"] > 0).float().sum(1).mean()) > 5
+    # re-forward == the sampler's distributions (float32 re-forward against the bf16 engine: bf16 tolerance)
+    model.train_dtype = torch.float32
+    lp_s, lp_n = xe.sampled_logprobs(xe.Params(model), cfg, att, None, saic, naic, sample_n=n, strict_q1=True)
+    for lp, r, mode in ((lp_s, saic, "SAIC"), (lp_n, naic, "NAIC")):
+        ntok, worst, rows = r["phrase_length"].sum(1), 0.0, 0
+        for i in range(lp.shape[0]):
+            k = int(ntok[i]) if mode == "SAIC" else cfg.seq_length
+            if k == 0 or r["seq_logprob"][i, :k].isnan().any():
+                continue
+            worst = max(worst, float((lp[i, :k].detach() - r["seq_logprob"][i, :k]).abs().max()))
+            rows += 1
+        assert rows >= lp.shape[0] // 2 and worst < 3e-2, (mode, rows, worst)
+    # captured gradient pass == eager pass on the same samples and scores
+    model.train_dtype = torch.bfloat16
+    _, _, other = _model(weight_cache, manifest, patch="len_row_shared", bofi_compute_dtype=torch.bfloat16, bofi_train_dtype=torch.bfloat16,
+                         bofi_max_batch=64, seed=42)
+    other.eval()
+    score = lambda seq: (seq % 5 == 0).float().sum(1) / (seq > 0).float().sum(1).clamp(min=1)
+    b = {"att_feats": att, "seq_saic": saic["seq"].long(), "seq_naic": naic["seq"].long(),
+         "sc_saic": score(saic["seq"].cpu()).cuda(), "sc_naic": score(naic["seq"].cpu()).cuda()}
+    b.update(xe.rl_prepare(cfg, saic, naic, sample_n=n, device="cuda"))
+    te, tg = XETrainer(model), XETrainer(other, graph=True)
+    le, _, _ = te._rl_forward_backward(b, None, n)
+    for _ in range(2):
+        lg, _, _ = tg._rl_replay(b, n)
+    assert torch.isfinite(le) and abs(float(le) - float(lg)) < 1e-4 * max(1.0, abs(float(le)))
+    assert float((tg.bucket.grad - te.bucket.grad).abs().max()) <= 1e-3 * float(te.bucket.grad.abs().max())
+    # one whole step
+    model.train()
+    w0 = te.bucket.flat.clone()
+    loss, rs, rn = te.rl_step(att, None, score, sample_n=n)
+    assert torch.isfinite(loss) and float((te.bucket.flat - w0).abs().max()) > 0
+    k = "model.length_predictor.Length_classifier2.weight"
+    assert torch.equal(dict(model.named_parameters())[k].detach().cpu(), torch.from_numpy(sd[k]))
+
+
+# ------------------------------------------------------------------------------------------------ config 5: refinement at batch 256
+@pytest.fixture(scope="module")
+def config5(weight_cache):
+    from boficap_amd import weights as W
+    cfg, sd = weight_cache("FULL", 0, 4.0)                     # the widened generator of full_b8: greedy ids are then comparable
+    att_np = W.synthetic_att_feats(256, 36, cfg.att_feat_size, seed=1235)
+    w = O.as_torch(sd)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    with torch.no_grad():
+        ref = O.sample_naic_refine(w, cfg, torch.from_numpy(att_np), rounds=3)
+        memory, src_mask = O.memory_of(w, cfg, torch.from_numpy(att_np))
+        _, _, _, _, dg = O.core_naic(w, cfg, memory, src_mask)
+    return cfg, sd, att_np, ref, dg
+
+
+def test_config5_batch256_refine3_f32_vs_oracle(config5):
+    """BASELINE config 5 at its full size in the parity dtype: 256 images, three refinement rounds, against the CPU oracle
+    (the reference has no refinement loop; the oracle defines it on decode_NA's glat_input hook)."""
+    from boficap_amd.engine import BofiEngine
+    cfg, sd, att_np, (oseq, olp, opn, opl, ops), dg = config5
+    eng = BofiEngine(cfg, torch.float32, max_batch=256, max_regions=36)
+    eng.load_state_dict(sd)
+    att = torch.from_numpy(att_np).cuda()
+    for graph in (False, True):
+        r = eng.decode_naic(att, refine_rounds=3, graph=graph)
+        torch.cuda.synchronize()
+        assert torch.equal(r["phrase_num"].cpu(), opn) and torch.equal(r["phrase_length"].cpu(), opl) and torch.equal(r["phrase_syn"].cpu(), ops)
+        assert int(r["bound_iters"]) == dg["iters"]
+        lp = r["seq_logprob"].cpu()
+        assert torch.equal(lp.isnan(), olp.isnan()) and not olp.isnan().any()
+        assert float((lp - olp).abs().max()) < 1e-3
+        top = torch.topk(olp, 2, dim=2)[0]
+        safe = (top[..., 0] - top[..., 1]) > 1e-3
+        assert float(safe.float().mean()) > 0.9 and torch.equal(r["seq"].cpu()[safe], oseq[safe])
+
+
+def test_config5_batch256_refine3_bf16(config5):
+    """The same workload in bf16 (the dtype the benchmark line is quoted in): a property every round must keep -- the slot layout
+    is that of the unrefined decode, refinement only rewrites tokens inside the laid-out slots -- and, on the oracle's layout
+    teacher-forced, log-probs within north_star's 2e-2... the refinement feeds ids back, so one flipped near-tie changes the
+    later rounds' inputs: compared on the images whose round-0..2 ids agree with the oracle's, which must be most."""
+    from boficap_amd.engine import BofiEngine
+    cfg, sd, att_np, (oseq, olp, opn, opl, ops), dg = config5
+    eng = BofiEngine(cfg, torch.bfloat16, max_batch=256, max_regions=36)
+    eng.load_state_dict(sd)
+    att = torch.from_numpy(att_np).cuda().to(torch.bfloat16)
+    r0 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_naic(att).items()}
+    r3 = eng.decode_naic(att, refine_rounds=3, graph=True)
+    r3b = eng.decode_naic(att, refine_rounds=3, graph=True, out=r3)
+    torch.cuda.synchronize()
+    for k in ("phrase_num", "phrase_length", "phrase_syn"):
+        assert torch.equal(r0[k], r3[k])
+    ntok = r3["phrase_length"].sum(1)
+    pos = torch.arange(cfg.seq_length, device="cuda").unsqueeze(0)
+    assert bool((r3["seq"][pos >= ntok.unsqueeze(1)] == cfg.pad_idx).all())
+    assert not r3["seq_logprob"].isnan().any()
+    same_layout = (r3["phrase_length"].cpu() == opl).all(1)
+    print(f"config 5 bf16: {int(same_layout.sum())}/256 slot layouts equal the float32 oracle's")
+    assert int(same_layout.sum()) >= 0.85 * 256
+    # teacher-forced: the oracle's layout and the oracle's ids of the previous round -> this round's log-probs, every image
+    w = O.as_torch(sd)
+    ext = dg["ext_syn"].to(torch.int32).cuda()
+    last = dg["last"].to(torch.int32).cuda()
+    eng.encode(att)
+    seq_tf, lp_tf = eng.fill_naic(ext, last, 36, refine_rounds=0)
+    with torch.no_grad():
+        o0 = O.sample_naic(w, cfg, torch.from_numpy(att_np))
+    err = float((lp_tf.cpu() - o0[1]).abs().max())
+    print(f"config 5 bf16: teacher-forced fill, max |dlogp| over all 256 images = {err:.3e}")
+    assert err < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ fixtures at the full size
+def test_full_q1_shortening_and_saic_multi_fixture(weight_cache, manifest):
+    """full_b8 (its last image has ONE token: quirk Q1 cuts every image's fill mask to key 0) in float32, eager and graph, and
+    the multi-phrase semi-autoregressive fixture at the full size (up to 10 phrases per image)."""
+    from boficap_amd import weights as W
+    from boficap_amd.engine import BofiEngine
+    m, g = manifest["full_b8"], load_golden("full_b8")
+    assert m["last"][-1] == 2 and max(m["last"]) == 21
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    eng = BofiEngine(cfg, torch.float32, max_batch=8, max_regions=36)
+    eng.load_state_dict(sd)
+    att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
+    for graph in (False, True):
+        r = eng.decode_naic(att, graph=graph)
+        torch.cuda.synchronize()
+        assert (r["seq"].cpu().numpy() == g["naic_seq"]).all() and (r["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all()
+        assert _maxdiff(torch.topk(r["seq_logprob"], 2, dim=2)[0], torch.from_numpy(g["naic_top2_val"])) < 1e-3
+    free = eng.decode_naic(att, strict_q1=False)               # the per-image mask gives other tokens: the quirk is really in play
+    assert not torch.equal(free["seq"], r["seq"])
+    m, g = manifest["full_saic_multi"], load_golden("full_saic_multi")
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    eng = BofiEngine(cfg, torch.float32, max_batch=8, max_regions=36)
+    eng.load_state_dict(sd)
+    att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
+    r = eng.decode_saic(att)
+    torch.cuda.synchronize()
+    assert max(m["saic_phrase_num"]) >= 4
+    assert (r["phrase_num"].cpu().numpy() == g["saic_phrase_num"]).all() and (r["phrase_length"].cpu().numpy() == g["saic_phrase_length"]).all()
+    assert (r["phrase_syn"].cpu().numpy() == g["saic_phrase_syn"]).all() and (r["seq"].cpu().numpy() == g["saic_seq"]).all()
+    assert _maxdiff(torch.topk(r["seq_logprob"], 2, dim=2)[0], torch.from_numpy(g["saic_top2_val"])) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ bf16 tolerance on every image
+@pytest.mark.parametrize("config_name,tol", [("FULL", 2e-2), ("TINY", 6e-2)])
+def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, weight_cache):
+    """north_star: logits within 2e-2 for bf16 -- shown on ALL images, nothing filtered: (1) the bound heads' log-probs of the
+    first bounding step, (2) the fill pass with the float32 oracle's slot layout teacher-forced (bofi_engine_fill_naic), so
+    that a near-tie flipped by bf16 rounding in the bounding pass cannot hide or excuse anything.  The flip rate of the free
+    decode is reported separately.  (The TINY model's logits have 4.1x the spread of the full model's: 6e-2 there.)"""
+    from boficap_amd import weights as W
+    from boficap_amd.engine import BofiEngine
+    cfg, sd = weight_cache(config_name, 0, 1.0)
+    w = O.as_torch(sd)
+    B = 64
+    att_np = W.synthetic_att_feats(B, 36, cfg.att_feat_size, seed=99)
+    with torch.no_grad():
+        memory, src_mask = O.memory_of(w, cfg, torch.from_numpy(att_np))
+        L = cfg.seq_length + 2
+        ext0 = torch.zeros(B, L, dtype=torch.long); ext0[:, 0] = cfg.len_idx
+        tm = torch.zeros(B, L, L, dtype=torch.bool); tm[:, :, 0] = True
+        _, o_llp, _, o_slp = O.bound_step_na(w, cfg, ext0, memory, src_mask, tm)
+        oseq, olp, opn, opl, ops, _ = O.sample_naic(w, cfg, torch.from_numpy(att_np), fix_q1=True)
+        _, _, _, _, dg = O.core_naic(w, cfg, memory, src_mask, fix_q1=True)
+    eng = BofiEngine(cfg, torch.bfloat16, max_batch=B, max_regions=36)
+    eng.load_state_dict(sd)
+    att = torch.from_numpy(att_np).cuda().to(torch.bfloat16)
+    eng.encode(att)
+    llp, slp = eng.bound_step(ext0.to(torch.int32).cuda(), torch.ones(B, dtype=torch.int32, device="cuda"), 36)
+    e_len, e_syn = float((llp.cpu() - o_llp).abs().max()), float((slp.cpu() - o_slp).abs().max())
+    seq, lp = eng.fill_naic(dg["ext_syn"].to(torch.int32).cuda(), dg["last"].to(torch.int32).cuda(), 36, strict_q1=False)
+    lp = lp.cpu()
+    assert torch.equal(lp.isnan(), olp.isnan())
+    e_fill = float((lp - olp).nan_to_num().abs().max())
+    free = eng.decode_naic(att, strict_q1=False)
+    flips = int(((free["phrase_length"].cpu() != opl).any(1) | (free["phrase_syn"].cpu() != ops).any(1)).sum())
+    print(f"{config_name} bf16, all {B} images: first bound step |dlogp| len {e_len:.2e} syn {e_syn:.2e}; teacher-forced fill |dlogp| {e_fill:.2e}; "
+          f"free decode: {flips}/{B} slot layouts differ from the float32 oracle's")
+    # the bound heads end in a 20-way / 10-way softmax over calibrated (large-margin) logits: scale the bar by their spread
+    assert e_fill < tol, e_fill
+    spread = float(o_llp.max() - o_llp.min())
+    assert e_len < max(tol, 2e-3 * spread) and e_syn < max(tol, 2e-3 * spread), (e_len, e_syn, spread)
+    top = torch.topk(olp.nan_to_num(-1e30), 2, dim=2)[0]
+    safe = (top[..., 0] - top[..., 1]) > 2 * tol
+    assert torch.equal(seq.cpu()[safe], oseq[safe])
+    assert flips <= 0.3 * B
+
+
+# ------------------------------------------------------------------------------------------------ pinned losses on the device
+def test_glancing_pass_vs_reference(weight_cache, manifest):
+    """The XE forward with the glancing pass (TM:437-463) against the reference's outputs for the same injected draws, through
+    the plain path, the unpadded-row path and the paired path."""
+    from boficap_amd import xe
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, model = _model(weight_cache, manifest, "tiny_glat")
+    model.eval()
+    g = load_golden("tiny_glat")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    fc = torch.zeros(g["att_feats"].shape[0], 0, device="cuda")
+    args = (fc, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("extend_phrase_syn_seq"),
+            t("extend_phrase_seq"), t("extend_phrase_seq_mask"))
+    xe.HINTS["glat_uniform"] = t("glat_uniform")
+    outs = model(*args, float(g["glat_p"]))
+    assert "glat_uniform" not in xe.HINTS
+    for i, o in enumerate(outs):
+        assert _maxdiff(o, torch.from_numpy(g[f"out{i}"])) < 1e-4, f"output {i}"
+    loss, parts = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-3 and np.allclose([float(p) for p in parts], g["losses"][1:], atol=1e-4)
+    # the trainer's fast paths take the same draws per (caption, position)
+    hb = {k: g[k] for k in ("labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq", "extend_phrase_seq_mask")}
+    for paired in (False, True):
+        tr = XETrainer(model, paired=paired)
+        b = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+        b["att_feats"], b["att_masks"], b["max_phrase_num"] = t("att_feats"), None, int(hb["phrase_num"].max())
+        b["max_tokens"] = int((hb["phrase_length"].sum(-1) - 1).max())
+        b = tr.add_token_rows(b, hb)
+        xe.HINTS["glat_uniform"] = t("glat_uniform")
+        l2, p2 = tr.forward_backward(b, glat_p=float(g["glat_p"]))
+        assert abs(float(l2) - float(g["losses"][0])) < 1e-3, (paired, float(l2))
+        assert np.allclose([float(p) for p in p2], g["losses"][1:], atol=1e-4)
+
+
+def test_self_critical_losses_vs_reference(manifest):
+    """xe.new_self_critical / xe.rl_kl_term and the LossWrapper mirror on the device against the values and gradients recorded
+    from the reference's StructureLosses / LossWrapper with injected samples and scores (tests/golden/tiny_rl_loss)."""
+    from boficap_amd import xe
+    g = load_golden("tiny_rl_loss")
+    n = int(g["sample_n"])
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    a = t("saic_logprob").requires_grad_(True)
+    loss, reward = xe.new_self_critical(a, t("saic_seq"), g["saic_scores"], n)
+    loss.backward()
+    assert abs(float(loss) - float(g["nsc_loss"])) < 1e-6 and np.allclose(reward.cpu().numpy(), g["nsc_reward"])
+    assert _maxdiff(a.grad.gather(2, t("saic_seq").unsqueeze(2)).squeeze(2), torch.from_numpy(g["nsc_grad_picked"])) < 1e-7
+    for rl_kl, tag in ((False, "lw"), (True, "lw_kl")):
+        ls, ln = t("saic_logprob").requires_grad_(True), t("naic_logprob").requires_grad_(True)
+        l1, r1 = xe.new_self_critical(ls, t("saic_seq"), g["saic_scores"], n)
+        l2, r2 = xe.new_self_critical(ln, t("naic_seq"), g["naic_scores"], n)
+        total = l1 + l2 + (xe.rl_kl_term(ln, ls, t("saic_seq")) if rl_kl else 0.0)
+        assert abs(float(total) - float(g[tag + "_loss"])) < 1e-5 and abs(float(l1 + l2) - float(g[tag + "_struc_loss"])) < 1e-5
+        assert np.allclose((r1 + r2).cpu().numpy(), g[tag + "_reward"])
+        if rl_kl:
+            total.backward()
+            assert _maxdiff(ln.grad, torch.from_numpy(g["lw_kl_grad_naic"])) < 1e-6
+            assert _maxdiff(ls.grad.gather(2, t("saic_seq").unsqueeze(2)).squeeze(2), torch.from_numpy(g["lw_kl_grad_saic_picked"])) < 1e-7
+
+
+def test_loss_wrapper_xe_branch_vs_reference(weight_cache, manifest):
+    """captioning.modules.loss_wrapper.LossWrapper (the drop-in mirror) around the drop-in model, train_mode UIC, struc_flag
+    False: the seven entries of the out dict the REFERENCE's LossWrapper produced for the same batch."""
+    from captioning.modules.loss_wrapper import LossWrapper
+    cfg, sd, model = _model(weight_cache, manifest, "tiny_loss_wrapper_xe")
+    model.eval()
+    g = load_golden("tiny_loss_wrapper_xe")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    lw = LossWrapper(model, model.opt)
+    n_img = g["att_feats"].shape[0]
+    fc = torch.zeros(n_img, 0, device="cuda")
+    out = lw(fc, t("att_feats"), t("labels"), None, None, None, torch.arange(n_img), False, False, False, None, t("phrase_num"),
+             t("phrase_length"), t("phrase_syn"), t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"), -1.0)
+    keys = [str(k) for k in g["out_keys"]]
+    assert sorted(out.keys()) == sorted(keys)
+    assert np.allclose([float(out[k]) for k in keys], g["out_values"], rtol=1e-4, atol=1e-4)
+    out["loss"].backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_loss_wrapper_rl_branch(weight_cache, manifest):
+    """LossWrapper mirror, struc_flag True (loss_wrapper.py:181-230): dict keys, loss = SAIC + NAIC new_self_critical (+ the KL
+    term under rl_kl), gradients flow to the decoder and none to the bound layer."""
+    from captioning.modules.loss_wrapper import LossWrapper
+    cfg, sd, model = _model(weight_cache, manifest, "tiny_saic_multi", structure_loss_type="new_self_critical", train_sample_n=3,
+                            structure_loss_weight=1, train_sample_method="sample", train_beam_size=1, seed=5)
+    att = torch.from_numpy(load_golden("tiny_saic_multi")["att_feats"]).cuda()
+    B = att.size(0)
+    seen = []
+
+    def scorer(gts, seq):
+        seen.append(tuple(seq.shape))
+        return ((seq % 3 == 0) & (seq > 0)).float().sum(1) / (seq > 0).float().sum(1).clamp(min=1)
+    model.opt.bofi_score_fn = scorer
+    model.eval()
+    fc = torch.zeros(B, 0, device="cuda")
+    gts = [[np.zeros(3, np.int64)] for _ in range(B)]
+    for rl_kl in (False, True):
+        model.opt.rl_kl = rl_kl
+        lw = LossWrapper(model, model.opt)
+        model.zero_grad()
+        out = lw(fc, att, None, None, None, gts, torch.arange(B), False, True, False)
+        assert sorted(out.keys()) == ["lm_loss", "loss", "reward", "struc_loss"] and float(out["lm_loss"]) == 0.0
+        assert out["reward"].shape == (B, 3) and torch.isfinite(out["loss"])
+        if rl_kl:
+            assert float(out["loss"]) > float(out["struc_loss"])          # a KL divergence between different distributions is positive
+        else:
+            assert abs(float(out["loss"]) - float(out["struc_loss"])) < 1e-6
+        out["loss"].backward()
+        p = dict(model.named_parameters())
+        assert float(p["model.decoder.layers.0.feed_forward.w_1.weight"].grad.abs().max()) > 0
+        g = p["model.length_predictor.Length_classifier2.weight"].grad
+        assert g is None or float(g.abs().max()) == 0.0
+    assert seen == [(B * 3, cfg.seq_length)] * 4
+
+
+def test_optimizer_checkpoint_round_trips_with_torch_adam(weight_cache, manifest):
+    """optimizer.pth in the reference's layout (NoamOpt.state_dict(), misc.py:195-204): (1) XETrainer -> torch.optim.Adam: torch
+    loads our file and its next step equals ours; (2) torch.optim.Adam -> XETrainer: we load torch's file and continue equally."""
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, model = _model(weight_cache, manifest, "tiny_train_xe", noamopt=False, learning_rate=1e-3, optim_alpha=0.9, optim_beta=0.999,
+                            optim_epsilon=1e-8)
+    model.eval()
+    hb, b = _xe_batch(cfg, 3, 2, seed=5)
+    tr = XETrainer(model)
+    for _ in range(3):
+        tr.step(b)
+    state = tr.state_dict()
+    assert state["_step"] == 3 and sorted(state.keys()) == ["_bofi", "_step", "param_groups", "state"]
+    names = [n for n, _ in model.named_parameters()]
+    assert all(tuple(state["state"][i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(model.parameters()) if i in state["state"])
+    assert [names[i] for i in range(len(names)) if i not in state["state"]] == [n for n in names if n.startswith(tr.bucket.DEAD_PREFIXES)]
+    # (1) torch's Adam continues from our file
+    twin = torch.nn.ParameterList([torch.nn.Parameter(p.detach().cpu().clone()) for p in model.parameters()])
+    adam = torch.optim.Adam(twin.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    adam.load_state_dict({k: v for k, v in state.items() if k not in ("_step", "_bofi")})
+    tr.forward_backward(b)
+    for q, p in zip(twin.parameters(), model.parameters()):
+        dead = float(p.grad.abs().max()) == 0.0 and id(p) in {id(x) for n_, x in model.named_parameters() if n_.startswith(tr.bucket.DEAD_PREFIXES)}
+        q.grad = None if dead else p.grad.detach().cpu().clone().clamp_(-tr.clip, tr.clip)      # clip_grad_value_ (train.py:225-226)
+    adam.step()
+    tr.reduce_and_step()
+    for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+        assert _maxdiff(p, q) < 2e-6, n
+    # (2) and back: torch's state into a fresh trainer
+    _, _, model2 = _model(weight_cache, manifest, "tiny_train_xe", noamopt=False, learning_rate=1e-3, optim_alpha=0.9, optim_beta=0.999,
+                          optim_epsilon=1e-8)
+    model2.eval()
+    with torch.no_grad():
+        for p2, q in zip(model2.parameters(), twin.parameters()):
+            p2.copy_(q)
+    tr2 = XETrainer(model2)
+    tstate = adam.state_dict()
+    tr2.load_state_dict(tstate)
+    assert tr2._step == 4
+    la, _ = tr.step(b)
+    lb, _ = tr2.step(b)
+    assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
+    assert _maxdiff(tr.bucket.flat[:tr.bucket.live_numel], torch.cat([x for x in [tr2.bucket.flat[:tr2.bucket.live_numel]]])) < 5e-6
+    from boficap_amd.hip import BofiHipError
+    with pytest.raises(BofiHipError):
+        tr2.load_state_dict({"_step": 1, "exp_avg": tr.m, "exp_avg_sq": tr.v})       # round 1's private layout is refused loudly

@@ -580,8 +580,9 @@ def test_linear_with_epilogue_dropout_bf16(relu, res):
 
 
 def test_tools_train_entry_point_writes_reference_checkpoints(tmp_path):
-    """python tools/train.py (XE phase, synthetic batches): runs, logs a finite loss, writes model.pth with the
-    reference's state_dict schema (311 entries at full size) and optimizer.pth; a second run resumes from them."""
+    """python tools/train.py (XE phase, synthetic batches): runs, logs a finite loss, writes the reference's checkpoint files --
+    model.pth (state_dict schema), optimizer.pth (torch Adam layout + _step), infos / histories pickles; a second run resumes
+    from them and switches to the self-critical step."""
     from boficap_amd.config import TINY
     from boficap_amd.weights import schema
     import os
@@ -596,11 +597,22 @@ def test_tools_train_entry_point_writes_reference_checkpoints(tmp_path):
     assert "iter 3" in out.stdout and "nan" not in out.stdout.lower()
     sd = torch.load(os.path.join(ck, "model.pth"))
     assert list(sd.keys()) == list(schema(TINY).keys())
-    osd = torch.load(os.path.join(ck, "optimizer.pth"))
+    osd = torch.load(os.path.join(ck, "optimizer.pth"), weights_only=False)
     assert osd["_step"] == 3
-    out = subprocess.run(cmd + ["--start_from", ck, "--dtype", "f32"], capture_output=True, text=True, timeout=300)
+    # the reference's optimizer.pth layout: torch's own Adam loads it (captioning/utils/misc.py:199-204 hands it the dict minus '_step')
+    import captioning.models as models
+    ref_model = models.setup(TINY.to_opt())
+    adam = torch.optim.Adam(ref_model.parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9)
+    adam.load_state_dict({k: v for k, v in osd.items() if k != "_step"})
+    assert len(adam.state) == len(list(ref_model.parameters())) - 12      # the 12 parameters the model never reads carry no state
+    from boficap_amd.checkpoint import load_infos
+    infos, hist = load_infos(ck, "bofi")
+    assert infos["iter"] == 3 and infos["opt"].caption_model == "transformer" and sorted(hist["loss_history"]) == [1, 2, 3]
+    out = subprocess.run(cmd + ["--start_from", ck, "--dtype", "f32", "--self_critical_after", "5", "--train_sample_n", "2"],
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "iter 6" in out.stdout
+    assert "iter 5" in out.stdout and "iter 6" in out.stdout and "struc_loss" in out.stdout
+    assert load_infos(ck, "bofi")[0]["iter"] == 6
 
 
 def test_trainer_graph_replay_matches_eager_steps(weight_cache, manifest):

@@ -9,9 +9,14 @@
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment) instead of ``nn.DataParallel``: every rank
 steps on its own shard of images and the gradients meet in one RCCL all-reduce over the flat gradient bucket
 (boficap_amd/trainer.py).  Data loading (lmdb / h5), language evaluation and the self-critical phase are outside this
-build: batches are synthetic captions in the loader's layout (boficap_amd/collate.py), which is what
-the training-path benchmark uses as well.  ``--cfg`` reads the keys of the reference's yml that this path uses.
-Checkpoints are the reference's files: ``model.pth`` (311-entry state_dict) and ``optimizer.pth``.
+build: batches are synthetic captions in the loader's layout (boficap_amd/collate.py), or -- with
+``--input_label_h5`` -- real captions from the preprocessing's label file (boficap_amd/data.py; region features stay synthetic,
+the feature directories being outside this build).  ``--cfg`` reads the reference's yml files including their ``_BASE_``
+inheritance (captioning/utils/config.py:35-95).  ``--self_critical_after N`` switches to the self-critical step (loss_wrapper.py:181-230,
+``structure_loss_weight: 1``) from iteration N on, scored by ``boficap_amd.loss_wrapper``'s installed scorer or, without one, by
+token overlap with the ground-truth captions (the reference's CIDEr-D scorer is an external package).
+Checkpoints are the reference's files (captioning/utils/misc.py:87-102): ``model.pth`` (311-entry state_dict), ``optimizer.pth``
+(NoamOpt / torch Adam layout), ``infos_<id>.pkl``, ``histories_<id>.pkl``; ``--start_from`` resumes from either code base's directory.
 """
 import argparse
 import os
@@ -41,10 +46,13 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--tiny", action="store_true", help="the small test configuration instead of the 512-d model")
     ap.add_argument("--no_graph", action="store_true", help="run the step eagerly instead of replaying one hipGraph per batch signature")
+    ap.add_argument("--input_label_h5", default="", help="label file of scripts/prepro_labels_stanford.py (captions and phrase cuts); needs h5py")
+    ap.add_argument("--self_critical_after", type=int, default=-1, help="iteration from which the self-critical step replaces the XE step (-1: never)")
+    ap.add_argument("--train_sample_n", type=int, default=5)
     args = ap.parse_args()
 
     import captioning.models as models
-    from boficap_amd import dp, weights as W
+    from boficap_amd import checkpoint as ck, dp, weights as W
     from boficap_amd.collate import synthetic_training_batch
     from boficap_amd.config import FULL, TINY
     from boficap_amd.trainer import XETrainer
@@ -54,15 +62,15 @@ def main():
     rank, local_rank, world = dp.init_from_env("nccl")
     opt = (TINY if args.tiny else FULL).to_opt()
     if args.cfg:
-        import yaml
-        with open(args.cfg) as f:
-            for k, v in (yaml.safe_load(f) or {}).items():
-                setattr(opt, k, v)
+        for k, v in ck.load_yaml_with_base(args.cfg).items():
+            setattr(opt, k, v)
     for k in ("batch_size", "seq_per_img"):
         if getattr(args, k) is not None:
             setattr(opt, k, getattr(args, k))
     opt.batch_size, opt.seq_per_img = getattr(opt, "batch_size", 10), getattr(opt, "seq_per_img", 5)
-    opt.seed = args.seed
+    # the dropout streams of the ranks differ (nn.DataParallel replicas draw from per-device generators); the weights' seed does not
+    opt.seed = args.seed + 1000003 * rank
+    opt.id, opt.checkpoint_path = args.id, args.checkpoint_path
     opt.bofi_train_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if not hasattr(opt, "vocab"):
         opt.vocab = {str(i): f"w{i}" for i in range(1, getattr(opt, "vocab_size", 9487) + 1)}
@@ -72,18 +80,59 @@ def main():
         model.load_state_dict(torch.load(os.path.join(args.start_from, "model.pth"), map_location="cpu"), strict=True)
     model.to(dev).train()
     trainer = XETrainer(model, opt, graph=not args.no_graph)
-    if args.start_from and os.path.exists(os.path.join(args.start_from, "optimizer.pth")):
-        trainer.load_state_dict(torch.load(os.path.join(args.start_from, "optimizer.pth"), map_location="cpu"))
+    infos, histories = {"iter": 0, "epoch": 0, "vocab": opt.vocab}, {}
+    if args.start_from:
+        if os.path.exists(os.path.join(args.start_from, "optimizer.pth")):
+            trainer.load_state_dict(torch.load(os.path.join(args.start_from, "optimizer.pth"), map_location="cpu", weights_only=False))
+        saved, histories = ck.load_infos(args.start_from, args.id)
+        if saved:
+            if "opt" in saved:
+                ck.check_resume_opts(saved["opt"], opt)            # tools/train.py:66-68
+            infos.update({k: saved[k] for k in ("iter", "epoch", "best_val_score") if k in saved})
+    for k in ("loss_history", "lr_history", "ss_prob_history", "val_result_history"):
+        histories.setdefault(k, {})
     cfg = model.cfg
+    store = None
+    if args.input_label_h5:
+        from boficap_amd.data import LabelStore
+        store = LabelStore(args.input_label_h5, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx, len_idx=cfg.len_idx)
     if rank == 0:
         print(f"{type(model).__name__}: {trainer.bucket.numel} parameters in one bucket, {world} rank(s), "
               f"{opt.batch_size} images x {opt.seq_per_img} captions per rank and step, GEMM operands {args.dtype}", flush=True)
 
+    import numpy as np
+    from boficap_amd import loss_wrapper as LW
     t0, first = time.time(), trainer._step
     for it in range(first, first + args.max_iters):
-        # a different synthetic shard per rank and step (the loader's role, dataloader.py:550-556)
+        # a different shard per rank and step (the loader's role, dataloader.py:550-556)
         seed = (it * world + rank) * 7919 + args.seed
-        host_batch = synthetic_training_batch(cfg, opt.batch_size, opt.seq_per_img, seed=seed)
+        gts = None
+        if store is None:
+            host_batch = synthetic_training_batch(cfg, opt.batch_size, opt.seq_per_img, seed=seed)
+        else:
+            rng = np.random.default_rng(seed)
+            host_batch = store.batch(rng.integers(0, store.num_images, opt.batch_size), opt.seq_per_img, rng)
+            gts = host_batch.pop("gts")
+        if 0 <= args.self_critical_after <= it:                 # struc_flag (tools/train.py:181-185)
+            att = torch.from_numpy(W.synthetic_att_feats(opt.batch_size, 36, cfg.att_feat_size, seed=seed)).to(dev)
+            refs = gts if gts is not None else [host_batch["labels"][b, :, 1:-1] for b in range(opt.batch_size)]
+            n = args.train_sample_n
+
+            def score(seq, refs=refs, n=n):
+                if LW._SCORER["fn"] is not None:
+                    return LW._SCORER["fn"](refs, seq)
+                out = torch.zeros(seq.shape[0])                  # stand-in: best token overlap with one of the image's captions
+                for i, s_ in enumerate(seq.numpy()):
+                    toks = set(int(t) for t in s_ if t > 0)
+                    out[i] = max((len(toks & set(int(t) for t in r if t > 0)) / max(1, len(toks)) for r in np.asarray(refs[i // n])), default=0.0)
+                return out
+            loss, rs, rn = trainer.rl_step(att, None, score, sample_n=n)
+            if (it + 1) % args.losses_log_every == 0 or it == first:
+                if rank == 0:
+                    print(f"iter {it + 1} lr {trainer.rate():.3e} struc_loss {float(loss):.4f} reward SAIC {float(rs):.4f} NAIC {float(rn):.4f} "
+                          f"{(time.time() - t0) / (it + 1 - first):.3f} s/it", flush=True)
+                histories["loss_history"][it + 1] = float(loss)
+            continue
         batch = {k: torch.from_numpy(v).to(dev) for k, v in host_batch.items()}
         batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
         batch["max_tokens"] = int((host_batch["phrase_length"].sum(-1) - 1).max())
@@ -98,21 +147,25 @@ def main():
                 detail = " ".join(f"{n}={float(p):.3f}" for n, p in zip(names, parts))
                 print(f"iter {it + 1} lr {trainer.rate():.3e} train_loss {mean_loss:.4f} ({detail}) "
                       f"{(time.time() - t0) / (it + 1 - first):.3f} s/it", flush=True)
+            histories["loss_history"][it + 1] = mean_loss         # tools/train.py:262-266
+            histories["lr_history"][it + 1] = trainer.rate()
+            histories["ss_prob_history"][it + 1] = model.ss_prob
+        infos["iter"] = it + 1                                   # tools/train.py:292-294
         if args.checkpoint_path and args.save_checkpoint_every and (it + 1) % args.save_checkpoint_every == 0 and rank == 0:
-            save(model, trainer, args.checkpoint_path)
+            infos["opt"] = _plain(opt)
+            ck.save_checkpoint(opt, model, infos, trainer, histories)
     if args.checkpoint_path and rank == 0:
-        save(model, trainer, args.checkpoint_path)
+        infos["opt"] = _plain(opt)
+        ck.save_checkpoint(opt, model, infos, trainer, histories)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
-def save(model, trainer, path):
-    """model.pth + optimizer.pth, captioning/utils/misc.py:87-102."""
-    os.makedirs(path, exist_ok=True)
-    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, os.path.join(path, "model.pth"))
-    torch.save(trainer.state_dict(), os.path.join(path, "optimizer.pth"))
-    print(f"checkpoint saved to {path}", flush=True)
+def _plain(opt):
+    """The opt namespace as it goes into infos['opt'] (tools/train.py:69): picklable values only (torch dtypes are this build's knobs)."""
+    from argparse import Namespace
+    return Namespace(**{k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, dict, list, tuple, type(None)))})
 
 
 if __name__ == "__main__":
