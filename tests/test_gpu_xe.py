@@ -345,7 +345,9 @@ def test_trainer_steps_reduce_loss_and_refresh_engine(weight_cache, manifest):
     assert torch.equal(seq1.cpu(), ref)                        # the engine repacked the trained weights
     assert not torch.equal(seq1, seq0) or losses[-1] < losses[0]
     sd = tr.state_dict()
-    assert sd["_step"] == 8 and sd["exp_avg"].shape == (tr.bucket.numel,)
+    assert sd["_step"] == 8 and sorted(sd["state"]) == [i for i, (n, _) in enumerate(model.named_parameters()) if not n.startswith(tr.bucket.DEAD_PREFIXES)]
+    p0 = next(model.parameters())
+    assert sd["state"][0]["exp_avg"].shape == p0.shape and float(sd["state"][0]["step"]) == 8.0
 
 
 def test_xe_step_bf16_operands_close_to_reference(weight_cache, manifest):

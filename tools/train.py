@@ -132,6 +132,7 @@ def main():
                     print(f"iter {it + 1} lr {trainer.rate():.3e} struc_loss {float(loss):.4f} reward SAIC {float(rs):.4f} NAIC {float(rn):.4f} "
                           f"{(time.time() - t0) / (it + 1 - first):.3f} s/it", flush=True)
                 histories["loss_history"][it + 1] = float(loss)
+            infos["iter"] = it + 1
             continue
         batch = {k: torch.from_numpy(v).to(dev) for k, v in host_batch.items()}
         batch["max_phrase_num"] = int(host_batch["phrase_num"].max())
