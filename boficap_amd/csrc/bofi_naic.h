@@ -28,11 +28,28 @@ struct SaicState {
     int* klen_dec;        // [B, L]  key-prefix length of row r of phrase_mask
 };
 
-struct BoundHeadWeights {   // float32
+struct BoundHeadWeights {   // float32 unless noted
     const float* norm_gain; const float* norm_bias;      // length_predictor.norm
     const float* w1t; const float* b1;                   // TRANSPOSED [d, 2*hh]: Length_classifier1 | Syntactic_classifier1
     const float* len_w2; const float* len_b2;            // [20, hh]
     const float* syn_w2; const float* syn_b2;            // [10, hh]
+    const void* w1p;                                     // w1t in the compute dtype, packed per thread of the tail kernel:
+                                                         // [8 K-slices][2*hh/4 groups][d/8 k][4 outputs] (launch_pack_w1p)
+};
+
+// arguments of the per-image tail kernel of a bounding iteration (naic.hip)
+struct BoundTailArgs {
+    const float* y; int yparts;          // HEADS: FFN output of row 0, [yparts][B][d] float32 partial slabs (summed in fixed order)
+    BoundHeadWeights w;
+    BoundState st; SaicState sa;
+    const int* ext_syn_in; const int* last_in;   // non-NULL: a given slot layout instead of the engine's state (stage API)
+    const void* q0; const void* kvtab;   // ATTN: query of row 0 [d]; K|V of every (position, label) row [L*10][2d]; compute dtype
+    const void* votab;                   // ATTN: Wo_self[:, h-block] . V[row, h-block]: [L*10][H][d], compute dtype
+    const float* x0b;                    // ATTN: x0 + bo_self [d]
+    float* y1; void* y1t; float* stats;  // ATTN outputs: y1 [B,d] float32, its compute-dtype copy (or NULL), partial (sum, sumsq) [B][d/32][2]
+    int B, L, S, d, hh, H, flags, iter;
+    float* len_logp; float* syn_logp;    // HEADS: optional outputs [B,20] / [B,10]
+    float* dbg_part;                     // developer aid: [B][8*2*hh + d] partial hidden sums and the normalised row, or NULL
 };
 
 int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_idx, hipStream_t s);
@@ -41,12 +58,14 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 // flags of launch_bound_tail
 #define BOUND_HEADS 1    /* final norm + heads + argmax on y */
 #define BOUND_UPDATE 2   /* apply the slot bookkeeping (needs BOUND_HEADS) */
-#define BOUND_ATTN 4     /* row-0 self-attention of the next iteration -> ctx */
+#define BOUND_ATTN 4     /* row-0 self-attention sublayer of the next iteration -> y1 (+ copy, + row statistics) */
 #define BOUND_EARLY 8    /* return at once when every image is finished */
 #define BOUND_SAIC 16    /* SAIC bookkeeping (TransformerModel.py:1910-1948) instead of NAIC's; early-out on the halt word */
-int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
-                      const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
-                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa = nullptr, int iter = 0, int yparts = 1);
+int launch_bound_tail(const BoundTailArgs& a, int dtype, hipStream_t s);
+// derived tables of the bound layer (repack.hip): the packed hidden weights of the heads, the projected V table, x0 + bo
+int launch_pack_w1p(const float* w1t, void* w1p, int dtype, int d, int nh, hipStream_t s);
+int launch_votab(const void* kvtab, const void* wo, const float* x0, const float* bo, void* votab, float* x0b, int dtype, int rows, int d, int H,
+                 hipStream_t s);
 // rows of pos_embed(tgt_embed(tok) [+ syn_embed(syn)]): row r = (b, t), ids read at [b*ld + off + t]; tok == NULL -> BOS
 int launch_embed_rows(const float* lut_tok, const float* lut_syn, const float* pe, const int* tok, const int* syn, int ld, int off,
                       int B, int T, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, const int* halt, hipStream_t s);

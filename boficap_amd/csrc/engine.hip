@@ -77,6 +77,9 @@ struct bofi_engine {
     bofi::BoundHeadWeights heads{};
     void *b_q0 = nullptr, *b_kvtab = nullptr;     // compute dtype: [d], [L*10, 2d]
     float* b_x0 = nullptr;                        // [d] residual input of row 0
+    void *b_votab = nullptr, *b_w1p = nullptr;    // compute dtype: Wo_self . V per (row, head) [L*10, H, d]; packed head hidden weights
+    float* b_x0b = nullptr;                       // [d] x0 + bo_self
+    float* dbg_part = nullptr;
 
     // workspace
     float *x_enc = nullptr, *x_fill = nullptr, *logits = nullptr;
@@ -259,6 +262,26 @@ struct bofi_engine {
         return BOFI_OK;
     }
 
+    // the per-image tail of a bounding iteration (naic.hip): heads on the FFN output `y`, bookkeeping, next self-attention sublayer
+    int bound_tail(const float* y, int yparts, const int* ext_syn_in, const int* last_in, int B, int flags, float* len_logp, float* syn_logp,
+                   hipStream_t s, bool saic = false, int iter = 0) {
+        bofi::BoundTailArgs a{};
+        a.y = y; a.yparts = yparts; a.w = heads; a.st = st; a.sa = saic ? sa : bofi::SaicState{};
+        a.ext_syn_in = ext_syn_in; a.last_in = last_in; a.q0 = b_q0; a.kvtab = b_kvtab; a.votab = b_votab; a.x0b = b_x0b;
+        a.y1 = by1; a.y1t = copy_t(byb); a.stats = st_b;
+        a.B = B; a.L = L; a.S = cfg.seq_length; a.d = cfg.d_model; a.hh = cfg.head_hidden; a.H = cfg.heads; a.flags = flags; a.iter = iter;
+        a.len_logp = len_logp; a.syn_logp = syn_logp;
+        static const bool want_dbg = getenv("BOFI_DBG_PART") != nullptr;
+        if (want_dbg && !dbg_part) ENG_OK(dalloc(&dbg_part, (size_t)cfg.max_batch * (16 * cfg.head_hidden + cfg.d_model)));
+        a.dbg_part = dbg_part;
+        return bofi::launch_bound_tail(a, cfg.dtype, s);
+    }
+    // tables derived from the bound layer's weights once kvtab exists (finalize and refresh_device)
+    int derive_bound_tables(hipStream_t s) {
+        ENG_OK(bofi::launch_pack_w1p(heads.w1t, b_w1p, cfg.dtype, cfg.d_model, 2 * cfg.head_hidden, s));
+        ENG_OK(bofi::launch_votab(b_kvtab, b_o_self.w, b_x0, b_o_self.b, b_votab, b_x0b, cfg.dtype, L * 10, cfg.d_model, cfg.heads, s));
+        return BOFI_OK;
+    }
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
                            float* syn_logp, bool early, hipStream_t s);
@@ -309,42 +332,40 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
 
 int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update,
                                     float* len_logp, float* syn_logp, bool early, hipStream_t s) {
-    // One bounding iteration AFTER the row-0 self-attention context (bctx) has been produced by the
-    // previous launch_bound_tail(..., BOUND_ATTN).
+    // One bounding iteration AFTER the row-0 self-attention sublayer output y1 (by1, its copy byb and row statistics st_b)
+    // has been produced by the previous bound_tail(..., BOUND_ATTN).
     const int d = cfg.d_model, dt = cfg.dtype;
     cur_B = B;
-    {   // y1 = x0 + (Wo ctx + bo): the row-0 residual input is the same vector for every image (ldr = 0)
-        LinOpt o; o.residual = b_x0; o.ldr = 0; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
-        ENG_OK(linear(bctx, dt, d, b_o_self, by1, BOFI_DT_F32, d, B, o, s));
-    }
-    { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
+    static const int dbg = [] { const char* v = getenv("BOFI_DBG_TAIL_ONLY"); return v ? atoi(v) : 0; }();     // developer knob: bit 0 on -> run only the stages whose bits (2,4,8,16,32) are set
+    const bool all = !(dbg & 1);
+    if (all || (dbg & 2)) { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
+    if (all || (dbg & 4)) {
     bofi::AttnArgs a{};
     a.q = bq2; a.ldq = d; a.k = kv; a.v = (char*)kv + (size_t)d * tsz; a.ldk = a.ldv = kv_all.N;
     a.out = bctx2; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = R;
     a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
     if (early) { a.skip_if_ge = st.counters; a.skip_threshold = B; }
     ENG_OK(bofi::launch_attention(a, s));
-    { LinOpt o; o.residual = by1; o.ldr = d; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
+    }
+    if (all || (dbg & 8)) { LinOpt o; o.residual = by1; o.ldr = d; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
       ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
-    { LinOpt o; o.relu = 1; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
+    if (all || (dbg & 16)) { LinOpt o; o.relu = 1; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
     const int w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;     // K = d_ff split 4 ways: 4x the workgroups, a quarter of the K loop
-    { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
+    if (all || (dbg & 32)) { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
     // heads + bookkeeping, fused with the next iteration's row-0 self-attention
     const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
-    ENG_OK(bofi::launch_bound_tail(by3, heads, st, update ? nullptr : ext_syn, update ? nullptr : last, b_q0, b_kvtab, bctx, dt, B, L,
-                                   cfg.seq_length, d, cfg.head_hidden, cfg.heads, flags, len_logp, syn_logp, s, nullptr, 0, w2parts));
+    ENG_OK(bound_tail(by3, w2parts, update ? nullptr : ext_syn, update ? nullptr : last, B, flags, len_logp, syn_logp, s));
     return BOFI_OK;
 }
 
 int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
                                 float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn,
                                 float* memory_out, int* bound_iters, hipStream_t s) {
-    const int d = cfg.d_model, dt = cfg.dtype, S = cfg.seq_length, M = B * S;
+    const int S = cfg.seq_length;
     ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, memory_out, s));
     // ---- bounding pass (core_NAIC TransformerModel.py:1833-1870)
     ENG_OK(bofi::launch_bound_init(st, B, L, cfg.pad_idx, cfg.len_idx, s));
-    ENG_OK(bofi::launch_bound_tail(nullptr, heads, st, nullptr, nullptr, b_q0, b_kvtab, bctx, dt, B, L, S, d, cfg.head_hidden,
-                                   cfg.heads, BOUND_ATTN, nullptr, nullptr, s));
+    ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
     for (int it = 0; it < S; ++it)
         ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
@@ -433,8 +454,7 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
         { LinOpt o; o.relu = 1; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
         const int w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;
         { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
-        ENG_OK(bofi::launch_bound_tail(by3, heads, st, nullptr, nullptr, b_q0, b_kvtab, bctx, dt, B, L, S, d, cfg.head_hidden, cfg.heads,
-                                       BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, &sa, it, w2parts));
+        ENG_OK(bound_tail(by3, w2parts, nullptr, nullptr, B, BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, true, it));
         // ---- decoder pass over all S positions (decode_SA :520-530) with the phrase-block mask as per-row key prefixes
         ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                        st_fill, halt, s));
@@ -519,6 +539,7 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->cap_stream = nullptr;
     e->run_stream = nullptr;
     e->is_fork = true;
+    e->dbg_part = nullptr;
     e->q1_group = 0;                             // per-call knobs are not inherited (the Python handle starts from the defaults)
     e->sample_temperature = 1.0f;
     e->sample_seed = 0;
@@ -593,7 +614,20 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
     ENG_OK(e->linear(e->d_xt, BOFI_DT_F32, d, e->t_kvself, e->b_kvtab, c.dtype, 2 * d, L * 10, o, s));
     ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, e->t_qself, e->b_q0, c.dtype, d, 1, o, s));
     ENG_OK(e->linear(e->b_x0_sa, BOFI_DT_F32, d, e->t_qself, e->b_q0_sa, c.dtype, d, 1, o, s));
+    ENG_OK(e->derive_bound_tables(s));
     e->host.clear();                          // the host copies are stale now; a later finalize needs set_weight again
+    return BOFI_OK;
+}
+
+// Developer aid: copy a workspace buffer of the bounding iteration into user memory (device to device, on `stream`).
+int bofi_engine_debug_copy(bofi_engine_t* e, const char* name, void* dst, int64_t bytes, void* stream) {
+    if (!e || !name || !dst) return fail(BOFI_ERR_ARG, "null argument");
+    const std::string n = name;
+    const void* src = n == "by1" ? (const void*)e->by1 : n == "byb" ? (const void*)e->byb : n == "st_b" ? (const void*)e->st_b :
+                      n == "bq2" ? (const void*)e->bq2 : n == "bctx2" ? (const void*)e->bctx2 : n == "by2" ? (const void*)e->by2 :
+                      n == "bh" ? (const void*)e->bh : n == "by3" ? (const void*)e->by3 : n == "dbg_part" ? (const void*)e->dbg_part : nullptr;
+    if (!src) return fail(BOFI_ERR_ARG, "unknown buffer");
+    ENG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BOFI_OK;
 }
 
@@ -718,7 +752,8 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->upload_f32(&p_w1, w1)); ENG_OK(e->upload_f32(&p_b1, b1));
         ENG_OK(e->upload_f32(&p_lw2, *lw2)); ENG_OK(e->upload_f32(&p_lb2, *lb2));
         ENG_OK(e->upload_f32(&p_sw2, *sw2)); ENG_OK(e->upload_f32(&p_sb2, *sb2));
-        e->heads = bofi::BoundHeadWeights{nf.g, nf.b, p_w1, p_b1, p_lw2, p_lb2, p_sw2, p_sb2};
+        ENG_OK(e->dalloc((char**)&e->b_w1p, (size_t)d * 2 * hh, e->tsz));
+        e->heads = bofi::BoundHeadWeights{nf.g, nf.b, p_w1, p_b1, p_lw2, p_lb2, p_sw2, p_sb2, e->b_w1p};
     }
 
     e->n_weight_allocs = e->allocs.size();      // everything allocated so far is weights (shared with forks)
@@ -754,6 +789,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->dalloc((char**)&e->b_q0_sa, (size_t)d, e->tsz));
         ENG_OK(e->linear(e->b_x0_sa, BOFI_DT_F32, d, qself, e->b_q0_sa, c.dtype, d, 1, o, nullptr));
         ENG_OK(e->make_lin(&e->b_kv_self, {bl + ".self_attn.linears.1", bl + ".self_attn.linears.2"}, d, d, bl + ".sublayer.0.norm"));
+        ENG_OK(e->dalloc((char**)&e->b_votab, (size_t)L * 10 * c.heads * d, e->tsz));
+        ENG_OK(e->dalloc(&e->b_x0b, (size_t)d));
+        ENG_OK(e->derive_bound_tables(nullptr));
         ENG_HIP(hipDeviceSynchronize());
     }
     // NB: hardware-queue assignment follows stream creation order; the capture stream is created here (and in
@@ -789,9 +827,7 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
     g_err.clear();
     ENG_OK(check_call(e, B, R));
     if (!ext_syn || !last || !len_logp || !syn_logp) return fail(BOFI_ERR_ARG, "null argument");
-    ENG_OK(bofi::launch_bound_tail(nullptr, e->heads, e->st, ext_syn, last, e->b_q0, e->b_kvtab, e->bctx, e->cfg.dtype, B, e->L,
-                                   e->cfg.seq_length, e->cfg.d_model, e->cfg.head_hidden, e->cfg.heads, BOUND_ATTN, nullptr, nullptr,
-                                   (hipStream_t)stream));
+    ENG_OK(e->bound_tail(nullptr, 1, ext_syn, last, B, BOUND_ATTN, nullptr, nullptr, (hipStream_t)stream));
     return e->enqueue_bound_iter(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, false, (hipStream_t)stream);
 }
 

@@ -66,6 +66,15 @@ struct Gemm2Params {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// counted wait that leaves `younger` slabs (LPS LDS-DMA instructions each) in flight, younger in [0, MAXY] (wave-uniform)
+template <int MAXY, int LPS> __device__ __forceinline__ void wait_slabs(int younger) {
+    if constexpr (MAXY <= 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (younger >= MAXY) wait_vmcnt<(MAXY * LPS < 63 ? MAXY * LPS : 63)>();
+        else wait_slabs<MAXY - 1, LPS>(younger);
+    }
+}
 
 // FEAT: the optional parts of the epilogue / control this instantiation carries (bit 0: folded LayerNorm in, 1: row statistics
 // and compute-dtype copy out, 2: padded-row zeroing, 3: dropout, 4: early-out word and developer ablations, 5: residual-as-mask).  A specialisation
@@ -206,9 +215,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     for (int kt = 0; kt < nk; ++kt) {
         // retire slab kt: at most min(NS-2, nk-1-kt) younger slabs may stay in flight
         const int younger = nk - 1 - kt;
-        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
-        else if (NS > 3 && younger == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
+        if constexpr (NS > 4) {
+            wait_slabs<NS - 2, LPS>(younger);            // deep ring (whole K in flight): every step waits for exactly its own slab
+        } else {
+            if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+            else if (NS > 3 && younger == 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, kt + NS - 1);
         if (p.dbg & 2) continue;
@@ -357,6 +370,10 @@ static bool launch_specialised(const Gemm2Params& p, int bm, int bn, int ns, int
     if (bm == 128 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 128, 64, 2, 4, 2, FEAT>(p, st); return true; }
     if (bm == 64 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 64, 64, 2, 4, 2, FEAT>(p, st); return true; }
     if (bm == 64 && bn == 32 && ns == 4 && nw == 4) { launch_one<T, 64, 32, 4, 2, 2, FEAT>(p, st); return true; }
+    if constexpr (sizeof(T) == 2) {      // M <= 64, K <= 512 per slice: all 8 slabs of the K extent in flight at once (108 / 90 KB of LDS)
+        if (bm == 64 && bn == 32 && ns == 9 && nw == 4) { launch_one<T, 64, 32, 9, 2, 2, FEAT>(p, st); return true; }
+        if (bm == 64 && bn == 16 && ns == 9 && nw == 2) { launch_one<T, 64, 16, 9, 2, 1, FEAT>(p, st); return true; }
+    }
     return false;
 }
 
@@ -370,7 +387,17 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
         // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop
         const long t = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-        if (p.M <= 64) { bm = 64; bn = 32; ns = 4; }
+        if (p.M <= 64) {
+            bm = 64; bn = 32; ns = 4;
+            // the bounding loop's GEMMs (64 rows, K = 512 per slice) are latency chains: one L2 round trip per slab with a 4-deep
+            // ring.  With the whole K extent (<= 8 slabs) issued up front the chain is one round trip; consumers that emit no row
+            // statistics take 16-column tiles (twice the workgroups, half the weight bytes per workgroup)
+            static const int deep = [] { const char* v = getenv("BOFI_GEMM_DEEP"); return v ? atoi(v) : 1; }();
+            if (deep && sizeof(T) == 2 && p.K / p.splitk <= 8 * 64) {
+                ns = 9;
+                if (!(p.stats_out || p.y2) && p.vec_ok && p.N % 16 == 0) { bn = 16; nw = 2; }
+            }
+        }
         else if (t >= 400) { bm = 128; bn = 64; ns = 2; nw = 8; }
         else { bm = 64; bn = 64; ns = 2; nw = 8; }          // 8 waves of 16x32 / 32x32: more waves per CU hide the slab latency
     }

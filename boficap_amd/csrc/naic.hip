@@ -55,21 +55,23 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 //   (HEADS) final norm of row 0 -> two 2-layer heads -> log-softmax -> first-max argmax
 //           (LengthPredictor_UIC.forward TransformerModel.py:375-383)
 //   (UPDATE) slot bookkeeping of core_NAIC (TransformerModel.py:1843-1869)
-//   (ATTN)  row-0 self-attention of the bound layer for the NEXT iteration.
-// The self-attention is exact for a one-layer bound network: the layer input at
-// position p is lut_syn[label_p]*sqrt(d) + pe[p], a function of (p, label) only, so K and V of
-// every possible row are tabulated once per model ("kvtab", [L*10, 2d]) and the query of row 0
-// ([LEN] at position 0) is a constant vector q0.  Row 0 sees keys p < last[b]
-// (tgt_mask[j, 0, :last] = True, TransformerModel.py:1859/1867).
-// One workgroup (256 threads) per image; heads in float32 (0.1 M parameters, stored transposed so
-// that consecutive lanes read consecutive outputs with 16-byte loads).
+//   (ATTN)  row-0 self-attention sublayer of the bound layer for the NEXT iteration, output projection and residual
+//           included: y1 = x0 + Wo . attn(q0, K, V) + bo.
+// The self-attention is exact for a one-layer bound network: the layer input at position p is
+// lut_syn[label_p]*sqrt(d) + pe[p], a function of (p, label) only, so K and V of every possible row are tabulated once per
+// model ("kvtab", [L*10, 2d]) and the query of row 0 ([LEN] at position 0) is a constant vector q0.  Row 0 sees keys
+// p < last[b] (tgt_mask[j, 0, :last] = True, TransformerModel.py:1859/1867).  The output projection is linear in V, so it is
+// tabulated as well: votab[row][h] = Wo[:, h-block] . V[row, h-block] (a d-vector per (row, head)), and
+//   y1 = (x0 + bo) + sum_h sum_j p[h][j] * votab[row_j][h]
+// -- one launch (and one chip-wide dependency) less per iteration than attention -> ctx -> GEMM.
+// One workgroup (512 threads) per image.  The hidden layer of the two heads is 0.1 M weights per head pair: packed per
+// thread ([slice][group][k][4 outputs], compute dtype) so that a thread's whole share is 32 16-byte loads, issued at kernel
+// entry -- they are in flight while the row of y arrives and is normalised.
 template <typename T>
-__global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict__ y, BoundHeadWeights w, BoundState st,
-                                                         const int* ext_syn_in, const int* last_in, const T* __restrict__ q0,
-                                                         const T* __restrict__ kvtab, T* __restrict__ ctx, int B, int L, int S,
-                                                         int d, int hh, int H, int flags, float* len_logp_out, float* syn_logp_out,
-                                                         SaicState sa, int iter, int yparts) {
+__global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int flags = a.flags, B = a.B, L = a.L, S = a.S, d = a.d, hh = a.hh, H = a.H;
+    const BoundState st = a.st;
     if ((flags & BOUND_EARLY) && ((flags & BOUND_SAIC) ? st.counters[2] >= 1 : st.counters[0] >= B)) return;
     const int nh = 2 * hh;
     float* xs = smem;                 // [d] normalised row
@@ -78,18 +80,45 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
     float* lg = hid + nh;             // [32] logits: 0..19 length, 20..29 label
     float* red = lg + 32;             // [16]
     int* sint = reinterpret_cast<int*>(red + 16);  // [0] = last, [1] = finished, [2..2+L) = ext_syn row
-    float* w2s = red + 16 + 64;       // [30][hh] output layers of both heads, staged once (coalesced)
+    float* w2s = red + 16 + 64;       // [30][hh+1] output layers of both heads, staged once (coalesced)
+    float* ps = w2s + 30 * (hh + 1);  // [H][64] attention probabilities
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int* ext_src = ext_syn_in ? ext_syn_in : st.ext_syn;
-    const int* last_src = last_in ? last_in : st.last;
+#ifdef BOFI_TAIL_POISON
+    for (int i = tid; i < d + 8 * nh + nh + 32 + 16 + 64 + 30 * (hh + 1) + H * 64; i += 512) smem[i] = __builtin_nanf("");
+    __syncthreads();
+#endif
+    const T* __restrict__ w1p = static_cast<const T*>(a.w.w1p);
+    const T* __restrict__ q0 = static_cast<const T*>(a.q0);
+    const T* __restrict__ kvtab = static_cast<const T*>(a.kvtab);
+    const T* __restrict__ votab = static_cast<const T*>(a.votab);
+
+    // ---- hidden-layer weights of this thread: (slice of K, group of 4 outputs); requested before anything else
+    constexpr int EPL = 16 / sizeof(T);           // elements per 16-byte load
+    constexpr int KPL = EPL / 4;                  // k values per load (4 outputs each)
+    constexpr int NLD = 32;                       // loads in flight per thread
+    const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng, kps = d / 8;
+    const int nld = kps / KPL;                    // loads per thread in all
+    const bool hw = (flags & BOUND_HEADS) && slice < 8;
+    const T* wbase = w1p + ((size_t)(slice * ng + grp) * kps) * 4;
+    u32x4 wv[NLD];
+#ifndef BOFI_TAIL_NOHOIST
+    if (hw) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) wv[u] = (u < nld) ? *reinterpret_cast<const u32x4*>(wbase + (size_t)u * EPL) : u32x4{0u, 0u, 0u, 0u};
+    }
+#endif
+
+    const int* ext_src = a.ext_syn_in ? a.ext_syn_in : st.ext_syn;
+    const int* last_src = a.last_in ? a.last_in : st.last;
     if (tid < L) sint[2 + tid] = ext_src[b * L + tid];
     if (tid == 0) { sint[0] = last_src[b]; sint[1] = (flags & BOUND_UPDATE) ? st.finished[b] : 0; }
 
     if (flags & BOUND_HEADS) {
+        const BoundHeadWeights& w = a.w;
+        const float* __restrict__ y = a.y;
         // (rows padded by one float: 30 threads each walk one row below, and a 100-float stride puts them on 8 of the 32 banks)
         for (int i = tid; i < 30 * hh; i += 512) w2s[(i / hh) * (hh + 1) + i % hh] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
-        // Everything this phase needs from global memory is requested up front (one round trip): the row of y
-        // (possibly split-K partial slabs [yparts][B][d], summed in fixed order), the norm vectors, the hidden bias.
+        // the row of y (possibly split-K partial slabs [yparts][B][d], summed in fixed order), the norm vectors, the hidden bias
         constexpr int KPT = 4;                        // columns per thread: d <= 512 * KPT
         float yv[KPT], gv[KPT], bvn[KPT];
 #pragma unroll
@@ -98,7 +127,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
             yv[c] = 0.f; gv[c] = 0.f; bvn[c] = 0.f;
             if (k < d) {
                 float acc = y[(size_t)b * d + k];
-                for (int pz = 1; pz < yparts; ++pz) acc += y[((size_t)pz * B + b) * d + k];
+                for (int pz = 1; pz < a.yparts; ++pz) acc += y[((size_t)pz * B + b) * d + k];
                 yv[c] = acc; gv[c] = w.norm_gain[k]; bvn[c] = w.norm_bias[k];
             }
         }
@@ -120,27 +149,40 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < KPT; ++c) if (tid + c * 512 < d) xs[tid + c * 512] = gv[c] * (yv[c] - mean) / den + bvn[c];
         __syncthreads();
-        // hidden layer of both heads: thread (slice, group) sums 4 outputs over an eighth of K
-        const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng;
-        if (slice < 8) {
-            const int k0 = slice * (d / 8), k1 = k0 + d / 8;
+        // hidden layer of both heads: thread (slice, group) sums 4 outputs over an eighth of K, k ascending
+        if (hw) {
+            const int k0 = slice * kps;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            // latency-bound weight stream: keep 32 independent 16-byte loads in flight per thread
-            for (int kb = k0; kb < k1; kb += 32) {
-                float4 wv[32];
+            for (int c0 = 0; c0 < nld; c0 += NLD) {
+#ifdef BOFI_TAIL_NOHOIST
+                {
+#else
+                if (c0 > 0) {
+#endif
 #pragma unroll
-                for (int u = 0; u < 32; ++u)
-                    wv[u] = (kb + u < k1) ? *reinterpret_cast<const float4*>(w.w1t + (size_t)(kb + u) * nh + grp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < NLD; ++u)
+                        wv[u] = (c0 + u < nld) ? *reinterpret_cast<const u32x4*>(wbase + (size_t)(c0 + u) * EPL) : u32x4{0u, 0u, 0u, 0u};
+                }
 #pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const float xv = (kb + u < k1) ? xs[kb + u] : 0.f;
-                    acc.x = fmaf(wv[u].x, xv, acc.x); acc.y = fmaf(wv[u].y, xv, acc.y);
-                    acc.z = fmaf(wv[u].z, xv, acc.z); acc.w = fmaf(wv[u].w, xv, acc.w);
+                for (int u = 0; u < NLD; ++u) {
+                    if (c0 + u >= nld) break;
+                    union { u32x4 v; T e[EPL]; } wu;
+                    wu.v = wv[u];
+#pragma unroll
+                    for (int kk = 0; kk < KPL; ++kk) {
+                        const float xv = xs[k0 + (c0 + u) * KPL + kk];
+                        acc.x = fmaf(ElemOps<T>::to_f32(wu.e[kk * 4 + 0]), xv, acc.x); acc.y = fmaf(ElemOps<T>::to_f32(wu.e[kk * 4 + 1]), xv, acc.y);
+                        acc.z = fmaf(ElemOps<T>::to_f32(wu.e[kk * 4 + 2]), xv, acc.z); acc.w = fmaf(ElemOps<T>::to_f32(wu.e[kk * 4 + 3]), xv, acc.w);
+                    }
                 }
             }
             *reinterpret_cast<float4*>(part + slice * nh + grp * 4) = acc;
         }
         __syncthreads();
+        if (a.dbg_part) {
+            for (int i = tid; i < 8 * nh; i += 512) a.dbg_part[(size_t)b * (8 * nh + d) + i] = part[i];
+            for (int i = tid; i < d; i += 512) a.dbg_part[(size_t)b * (8 * nh + d) + 8 * nh + i] = xs[i];
+        }
         if (tid < nh)
             hid[tid] = fmaxf((((part[tid] + part[nh + tid]) + (part[2 * nh + tid] + part[3 * nh + tid])) +
                               ((part[4 * nh + tid] + part[5 * nh + tid]) + (part[6 * nh + tid] + part[7 * nh + tid]))) + b1v, 0.f);
@@ -155,6 +197,8 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
         }
         __syncthreads();
         if (tid == 0) {
+            const SaicState& sa = a.sa;
+            const int iter = a.iter;
             int pick[2];
             for (int head = 0; head < 2; ++head) {
                 const int n = head ? 10 : 20;
@@ -166,8 +210,8 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
                 const float lse = logf(sum);
                 int best = 0;
                 float bv = -INFINITY;
-                float* out = head ? (syn_logp_out ? syn_logp_out + (size_t)b * 10 : nullptr)
-                                  : (len_logp_out ? len_logp_out + (size_t)b * 20 : nullptr);
+                float* out = head ? (a.syn_logp ? a.syn_logp + (size_t)b * 10 : nullptr)
+                                  : (a.len_logp ? a.len_logp + (size_t)b * 20 : nullptr);
                 for (int i = 0; i < n; ++i) {
                     const float lp = (v[i] - m) - lse;
                     if (out) out[i] = lp;
@@ -237,61 +281,73 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(const float* __restrict
     __syncthreads();
     if (!(flags & BOUND_ATTN) || sint[1]) return;           // a finished image's state is frozen: no further steps matter
 
-    // ---- row-0 self-attention over the (position, label) table, one wavefront per head
-    constexpr int EPC = 16 / sizeof(T);
+    // ---- row-0 self-attention over the (position, label) table: scores and softmax, one wavefront per head
     const int n = min(sint[0], L);
     for (int h = wave; h < H; h += 8) {
         float sc = -INFINITY;
-        int row = 0;
         if (lane < n) {
-            row = lane * 10 + sint[2 + lane];
+            const int row = lane * 10 + sint[2 + lane];
             const T* kr = kvtab + (size_t)row * 2 * d + h * 64;
             const T* qr = q0 + h * 64;
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < 64 / EPC; ++c) {
-                union { u32x4 v; T e[EPC]; } ku, qu;
-                ku.v = *reinterpret_cast<const u32x4*>(kr + c * EPC);
-                qu.v = *reinterpret_cast<const u32x4*>(qr + c * EPC);
+            for (int c = 0; c < 64 / EPL; ++c) {
+                union { u32x4 v; T e[EPL]; } ku, qu;
+                ku.v = *reinterpret_cast<const u32x4*>(kr + c * EPL);
+                qu.v = *reinterpret_cast<const u32x4*>(qr + c * EPL);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) acc = fmaf(ElemOps<T>::to_f32(qu.e[e]), ElemOps<T>::to_f32(ku.e[e]), acc);
+                for (int e = 0; e < EPL; ++e) acc = fmaf(ElemOps<T>::to_f32(qu.e[e]), ElemOps<T>::to_f32(ku.e[e]), acc);
             }
             sc = acc * 0.125f;
         }
         const float m = wave_max(sc);
         const float e = (lane < n) ? expf(sc - m) : 0.f;
         const float sum = wave_sum(e);
-        const float pr = ElemOps<T>::to_f32(ElemOps<T>::from_f32(e / sum));     // P is held in compute dtype, as in attn.hip
-        float o = 0.f;
-        for (int j0 = 0; j0 < n; j0 += 8) {            // 8 independent loads in flight (n <= L <= 60)
-            T vv[8];
+        ps[h * 64 + lane] = ElemOps<T>::to_f32(ElemOps<T>::from_f32(e / sum));     // P is held in compute dtype, as in attn.hip
+    }
+    __syncthreads();
+    // ---- y1 = (x0 + bo) + sum_j sum_h P[h][j] * votab[row_j][h]: thread c owns column c (fixed summation order j, h)
+    for (int c0 = 0; c0 < d; c0 += 512) {
+        const int c = c0 + tid;
+        if (c0 + (wave << 6) >= d) break;                  // whole wavefronts drop out (d % 64 == 0): the DPP reductions below need full ones
+        float acc = a.x0b[c];
+        for (int j = 0; j < n; ++j) {
+            const T* vr = votab + ((size_t)(j * 10 + sint[2 + j]) * H) * d + c;
+            for (int h0 = 0; h0 < H; h0 += 8) {
+                T vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int rj = __builtin_amdgcn_readlane(row, min(j0 + u, 63));       // (wave-uniform lane: a scalar read, no LDS permute)
-                vv[u] = kvtab[(size_t)rj * 2 * d + d + h * 64 + lane];
-            }
+                for (int u = 0; u < 8; ++u) vv[u] = (h0 + u < H) ? vr[(size_t)(h0 + u) * d] : T(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), min(j0 + u, 63)));
-                if (j0 + u < n) o = fmaf(pj, ElemOps<T>::to_f32(vv[u]), o);
+                for (int u = 0; u < 8; ++u) if (h0 + u < H) acc = fmaf(ps[(h0 + u) * 64 + j], ElemOps<T>::to_f32(vv[u]), acc);
             }
         }
-        ElemOps<T>::store(ctx + (size_t)b * d + h * 64 + lane, o);
+        a.y1[(size_t)b * d + c] = acc;
+        if (a.y1t) ElemOps<T>::store(static_cast<T*>(a.y1t) + (size_t)b * d + c, acc);
+        float s1 = acc, s2 = acc * acc;                    // partial (sum, sumsq) per 32 columns, as the GEMM epilogues write them
+#ifdef BOFI_TAIL_SHFL
+        for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+#else
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
+        s1 = xor16_sum(s1); s2 = xor16_sum(s2);
+#endif
+        if ((tid & 31) == 0) reinterpret_cast<float2*>(a.stats)[(size_t)b * (d >> 5) + (c >> 5)] = make_float2(s1, s2);
     }
+#ifdef BOFI_TAIL_FENCE
+    __threadfence();
+#endif
 }
 
-int launch_bound_tail(const float* y, const BoundHeadWeights& w, const BoundState& st, const int* ext_syn_in, const int* last_in,
-                      const void* q0, const void* kvtab, void* ctx, int dtype, int B, int L, int S, int d, int hh, int H, int flags,
-                      float* len_logp, float* syn_logp, hipStream_t s, const SaicState* sa, int iter, int yparts) {
-    const SaicState sav = sa ? *sa : SaicState{};
-    if (d > 2048 || (2 * hh) % 4 || d % 8 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60) return BOFI_ERR_ARG;
-    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1)) * sizeof(float);
-    if (dtype == BOFI_DT_F32)
-        hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const float*)q0,
-                           (const float*)kvtab, (float*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter, yparts > 1 ? yparts : 1);
-    else
-        hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(B), dim3(512), shm, s, y, w, st, ext_syn_in, last_in, (const bf16_t*)q0,
-                           (const bf16_t*)kvtab, (bf16_t*)ctx, B, L, S, d, hh, H, flags, len_logp, syn_logp, sav, iter, yparts > 1 ? yparts : 1);
+int launch_bound_tail(const BoundTailArgs& a, int dtype, hipStream_t s) {
+    const int d = a.d, hh = a.hh, L = a.L;
+    if (d > 2048 || (2 * hh) % 4 || d % 64 || (2 * hh / 4) * 8 > 512 || 2 * hh > 512 || L > 60 || a.H > 64 || a.H * 64 != d) return BOFI_ERR_ARG;
+    if ((d / 8) % (dtype == BOFI_DT_F32 ? 1 : 2)) return BOFI_ERR_ARG;
+    if ((a.flags & BOUND_ATTN) && (!a.votab || !a.x0b || !a.y1 || !a.stats || !a.q0 || !a.kvtab)) return BOFI_ERR_ARG;
+    if ((a.flags & BOUND_HEADS) && (!a.y || !a.w.w1p)) return BOFI_ERR_ARG;
+    BoundTailArgs v = a;
+    if (v.yparts < 1) v.yparts = 1;
+    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1) + a.H * 64) * sizeof(float);
+    if (dtype == BOFI_DT_F32) hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(a.B), dim3(512), shm, s, v);
+    else hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(a.B), dim3(512), shm, s, v);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

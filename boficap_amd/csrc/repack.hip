@@ -5,6 +5,7 @@
 // kernels, so that a training loop can decode with its current weights without a host round trip.
 #include "bofi_common.h"
 #include "bofi_kernels.h"
+#include "bofi_naic.h"
 
 namespace bofi {
 
@@ -84,6 +85,54 @@ int launch_bound_table(const float* lut_syn, const float* lut_tok, const float* 
                        hipStream_t st) {
     hipLaunchKernelGGL(bound_table_kernel, dim3((L * 10 * d + 255) / 256), dim3(256), 0, st, lut_syn, lut_tok, pe, xt, x0, x0_sa, L, d, len_idx,
                        (float)sqrt((double)d));
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// hidden weights of the bound heads for the tail kernel: w1p[((slice*ng + grp)*kps + k)*4 + o] = w1t[(slice*kps + k)*nh + grp*4 + o]
+template <typename T>
+__global__ void pack_w1p_kernel(const float* __restrict__ w1t, T* __restrict__ w1p, int d, int nh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d * nh) return;
+    const int ng = nh / 4, kps = d / 8;
+    const int o = i & 3, k = (i >> 2) % kps, sg = (i >> 2) / kps, grp = sg % ng, slice = sg / ng;
+    ElemOps<T>::store(w1p + i, w1t[(size_t)(slice * kps + k) * nh + grp * 4 + o]);
+}
+
+int launch_pack_w1p(const float* w1t, void* w1p, int dtype, int d, int nh, hipStream_t st) {
+    if (d % 8 || nh % 4) return BOFI_ERR_ARG;
+    const int n = d * nh;
+    if (dtype == BOFI_DT_F32) hipLaunchKernelGGL((pack_w1p_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, st, w1t, (float*)w1p, d, nh);
+    else hipLaunchKernelGGL((pack_w1p_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, st, w1t, (bf16_t*)w1p, d, nh);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// votab[row][h][c] = sum_e wo[c][h*64 + e] * V[row][h*64 + e] (V = second half of a kvtab row); x0b = x0 + bo.  Operands and
+// result in the compute dtype, float32 accumulation.  Grid (rows, H), one thread per output column.
+template <typename T>
+__global__ void votab_kernel(const T* __restrict__ kvtab, const T* __restrict__ wo, const float* __restrict__ x0, const float* __restrict__ bo,
+                             T* __restrict__ votab, float* __restrict__ x0b, int d, int H) {
+    __shared__ float vs[64];
+    const int row = blockIdx.x, h = blockIdx.y;
+    if (threadIdx.x < 64) vs[threadIdx.x] = ElemOps<T>::to_f32(kvtab[(size_t)row * 2 * d + d + h * 64 + threadIdx.x]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const T* wr = wo + (size_t)c * d + h * 64;
+        float acc = 0.f;
+        for (int e = 0; e < 64; ++e) acc = fmaf(ElemOps<T>::to_f32(wr[e]), vs[e], acc);
+        ElemOps<T>::store(votab + ((size_t)row * H + h) * d + c, acc);
+        if (row == 0 && h == 0) x0b[c] = x0[c] + bo[c];
+    }
+}
+
+int launch_votab(const void* kvtab, const void* wo, const float* x0, const float* bo, void* votab, float* x0b, int dtype, int rows, int d, int H,
+                 hipStream_t st) {
+    if (H * 64 != d || rows <= 0) return BOFI_ERR_ARG;
+    if (dtype == BOFI_DT_F32)
+        hipLaunchKernelGGL((votab_kernel<float>), dim3(rows, H), dim3(256), 0, st, (const float*)kvtab, (const float*)wo, x0, bo, (float*)votab, x0b, d, H);
+    else
+        hipLaunchKernelGGL((votab_kernel<bf16_t>), dim3(rows, H), dim3(256), 0, st, (const bf16_t*)kvtab, (const bf16_t*)wo, x0, bo, (bf16_t*)votab, x0b, d, H);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

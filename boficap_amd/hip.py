@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libboficap_hip.so")
+LIB_PATH = os.environ.get("BOFI_LIB_PATH") or os.path.join(HERE, "libboficap_hip.so")     # (the override is a developer knob for A/B runs)
 
 DT_F32, DT_BF16 = 0, 1
 FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
@@ -77,6 +77,7 @@ SIGNATURES = {
     "bofi_engine_decode_saic": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bofi_engine_encode": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "bofi_engine_bound_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bofi_engine_debug_copy": (_I, [_P, C.c_char_p, _P, _I64, _P]),
     "bofi_gemm_flops": (C.c_double, [_I, _P]),
     "bofi_engine_fill_naic": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
 }

@@ -335,6 +335,10 @@ int bofi_engine_encode(bofi_engine_t* e, const void* att_feats, int feats_dtype,
 int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last, int B, int R,
                            const int* att_len, float* len_logp, float* syn_logp, void* stream);
 
+/* Developer aid: copy one of the bounding iteration's workspace buffers ("by1", "byb", "st_b", "bq2", "bctx2", "by2", "bh", "by3")
+ * into user memory (device to device, on `stream`). */
+int bofi_engine_debug_copy(bofi_engine_t* e, const char* name, void* dst, int64_t bytes, void* stream);
+
 /* Measurement aid: GEMM FLOPs (2 M N K per launch of bofi_linear* / the weight-gradient GEMMs, engine calls included) enqueued
  * by this process since the last reset; host-side tally, not thread-safe.  Launches that carry an early-out word (loop
  * iterations that return at once when every image is finished) are tallied apart, into *skippable (may be NULL).

@@ -519,7 +519,7 @@ def test_optimizer_checkpoint_round_trips_with_torch_adam(weight_cache, manifest
     tr2.load_state_dict(tstate)
     assert tr2._step == 4
     live = tr.bucket.live_numel
-    assert _maxdiff(tr2.m[:live], tr.m[:live]) <= 2e-6 * float(tr.m.abs().max()) and _maxdiff(tr2.v[:live], tr.v[:live]) <= 2e-6 * float(tr.v.abs().max())
+    assert _maxdiff(tr2.m[:live], tr.m[:live]) <= 1e-5 * float(tr.m.abs().max()) and _maxdiff(tr2.v[:live], tr.v[:live]) <= 1e-5 * float(tr.v.abs().max())
     la, _ = tr.step(b)
     lb, _ = tr2.step(b)
     assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
