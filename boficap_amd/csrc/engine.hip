@@ -269,7 +269,8 @@ struct bofi_engine {
         a.y = y; a.yparts = yparts; a.w = heads; a.st = st; a.sa = saic ? sa : bofi::SaicState{};
         a.ext_syn_in = ext_syn_in; a.last_in = last_in; a.q0 = b_q0; a.kvtab = b_kvtab; a.votab = b_votab; a.x0b = b_x0b;
         a.y1 = by1; a.y1t = copy_t(byb); a.stats = st_b;
-        a.B = B; a.L = L; a.S = cfg.seq_length; a.d = cfg.d_model; a.hh = cfg.head_hidden; a.H = cfg.heads; a.flags = flags; a.iter = iter;
+        static const int tail_dbg = [] { const char* v = getenv("BOFI_TAIL_DBG"); return v ? atoi(v) : 0; }();     // developer ablations
+        a.B = B; a.L = L; a.S = cfg.seq_length; a.d = cfg.d_model; a.hh = cfg.head_hidden; a.H = cfg.heads; a.flags = flags | (tail_dbg << 8); a.iter = iter;
         a.len_logp = len_logp; a.syn_logp = syn_logp;
         static const bool want_dbg = getenv("BOFI_DBG_PART") != nullptr;
         if (want_dbg && !dbg_part) ENG_OK(dalloc(&dbg_part, (size_t)cfg.max_batch * (16 * cfg.head_hidden + cfg.d_model)));

@@ -67,9 +67,17 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
 // One workgroup (512 threads) per image.  The hidden layer of the two heads is 0.1 M weights per head pair: packed per
 // thread ([slice][group][k][4 outputs], compute dtype) so that a thread's whole share is 32 16-byte loads, issued at kernel
 // entry -- they are in flight while the row of y arrives and is normalised.
+// developer aid (BOFI_TAIL_DBG & 16, with BOFI_DBG_PART): cycle stamps of the phases, relative to kernel entry, from thread 0 of every image
+#define TAIL_STAMP(i)                                                                                         \
+    do {                                                                                                      \
+        if ((dbgm & 16) && a.dbg_part && tid == 0)                                                            \
+            a.dbg_part[(size_t)blockIdx.x * (8 * 2 * a.hh + a.d) + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_entry); \
+    } while (0)
+
 template <typename T>
 __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
     const int flags = a.flags, B = a.B, L = a.L, S = a.S, d = a.d, hh = a.hh, H = a.H;
     const BoundState st = a.st;
     if ((flags & BOUND_EARLY) && ((flags & BOUND_SAIC) ? st.counters[2] >= 1 : st.counters[0] >= B)) return;
@@ -80,11 +88,13 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
     float* lg = hid + nh;             // [32] logits: 0..19 length, 20..29 label
     float* red = lg + 32;             // [16]
     int* sint = reinterpret_cast<int*>(red + 16);  // [0] = last, [1] = finished, [2..2+L) = ext_syn row
-    float* w2s = red + 16 + 64;       // [30][hh+1] output layers of both heads, staged once (coalesced)
+    float* w2s = red + 16 + 64;       // (unused: the output layers are read straight into registers)
     float* ps = w2s + 30 * (hh + 1);  // [H][64] attention probabilities
+    float* ysum = ps + H * 64;        // [512 / (d/8)][d] partial sums of the self-attention sublayer output per key subset (16 KB)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dbgm = flags >> 8;       // developer ablations (BOFI_TAIL_DBG): 1 = no w2 staging / logits, 2 = no hidden loop, 4 = no serial head, 16 = stamps
 #ifdef BOFI_TAIL_POISON
-    for (int i = tid; i < d + 8 * nh + nh + 32 + 16 + 64 + 30 * (hh + 1) + H * 64; i += 512) smem[i] = __builtin_nanf("");
+    for (int i = tid; i < d + 8 * nh + nh + 32 + 16 + 64 + 30 * (hh + 1) + H * 64 + 4096; i += 512) smem[i] = __builtin_nanf("");
     __syncthreads();
 #endif
     const T* __restrict__ w1p = static_cast<const T*>(a.w.w1p);
@@ -99,25 +109,25 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
     const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng, kps = d / 8;
     const int nld = kps / KPL;                    // loads per thread in all
     const bool hw = (flags & BOUND_HEADS) && slice < 8;
-    const T* wbase = w1p + ((size_t)(slice * ng + grp) * kps) * 4;
+    // piece u of thread (slice, grp) sits at [(slice * nld + u) * ng + grp]: the 16-byte pieces a wave-instruction loads are adjacent
+    const T* wbase = w1p + ((size_t)slice * nld * ng + grp) * EPL;
+    const size_t wstep = (size_t)ng * EPL;
     u32x4 wv[NLD];
-#ifndef BOFI_TAIL_NOHOIST
-    if (hw) {
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) wv[u] = (u < nld) ? *reinterpret_cast<const u32x4*>(wbase + (size_t)u * EPL) : u32x4{0u, 0u, 0u, 0u};
-    }
-#endif
 
+    // the few words everything else waits for go first (vmcnt retires in order: behind the weight stream they would wait for all of it)
     const int* ext_src = a.ext_syn_in ? a.ext_syn_in : st.ext_syn;
     const int* last_src = a.last_in ? a.last_in : st.last;
-    if (tid < L) sint[2 + tid] = ext_src[b * L + tid];
-    if (tid == 0) { sint[0] = last_src[b]; sint[1] = (flags & BOUND_UPDATE) ? st.finished[b] : 0; }
+    int ext_v = 0, last_v = 0, fin_v = 0, pn_v = 0;
+    if (tid < L) ext_v = ext_src[b * L + tid];
+    if (tid == 0) { last_v = last_src[b]; fin_v = (flags & BOUND_UPDATE) ? st.finished[b] : 0; pn_v = (flags & BOUND_UPDATE) ? st.phrase_num[b] : 0; }
 
+    if (!(flags & BOUND_HEADS)) {
+        if (tid < L) sint[2 + tid] = ext_v;
+        if (tid == 0) { sint[0] = last_v; sint[1] = fin_v; }
+    }
     if (flags & BOUND_HEADS) {
         const BoundHeadWeights& w = a.w;
         const float* __restrict__ y = a.y;
-        // (rows padded by one float: 30 threads each walk one row below, and a 100-float stride puts them on 8 of the 32 banks)
-        for (int i = tid; i < 30 * hh; i += 512) w2s[(i / hh) * (hh + 1) + i % hh] = i < 20 * hh ? w.len_w2[i] : w.syn_w2[i - 20 * hh];
         // the row of y (possibly split-K partial slabs [yparts][B][d], summed in fixed order), the norm vectors, the hidden bias
         constexpr int KPT = 4;                        // columns per thread: d <= 512 * KPT
         float yv[KPT], gv[KPT], bvn[KPT];
@@ -132,6 +142,23 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
             }
         }
         const float b1v = tid < nh ? w.b1[tid] : 0.f;
+        // output layers of both heads: thread (o, q) of the first 480 sums every 16th term of output o (coalesced rows of 100 floats)
+        constexpr int W2T = 7;                         // terms per thread: hh <= 16 * W2T
+        const int w2o = tid >> 4, w2q = tid & 15;
+        float w2v[W2T];
+#pragma unroll
+        for (int t = 0; t < W2T; ++t) {
+            const int k = w2q + 16 * t;
+            w2v[t] = (w2o < 30 && k < hh) ? (w2o < 20 ? w.len_w2[w2o * hh + k] : w.syn_w2[(w2o - 20) * hh + k]) : 0.f;
+        }
+        const float w2b = w2o < 20 ? w.len_b2[w2o] : (w2o < 30 ? w.syn_b2[w2o - 20] : 0.f);
+        if (hw) {                                     // the hidden layer's weight stream, behind everything the first phases wait for
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) wv[u] = (u < nld) ? *reinterpret_cast<const u32x4*>(wbase + (size_t)u * wstep) : u32x4{0u, 0u, 0u, 0u};
+        }
+        TAIL_STAMP(1);
+        if (tid < L) sint[2 + tid] = ext_v;           // (first use is behind the barriers below: the wait for these words sits here, after every load has been issued)
+        if (tid == 0) { sint[0] = last_v; sint[1] = fin_v; }
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < KPT; ++c) s += yv[c];
@@ -139,6 +166,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
         if (lane == 0) red[wave] = s;
         __syncthreads();
         const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / (float)d;
+        TAIL_STAMP(2);
         float q = 0.f;
 #pragma unroll
         for (int c = 0; c < KPT; ++c) if (tid + c * 512 < d) { const float t = yv[c] - mean; q += t * t; }
@@ -149,19 +177,16 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
 #pragma unroll
         for (int c = 0; c < KPT; ++c) if (tid + c * 512 < d) xs[tid + c * 512] = gv[c] * (yv[c] - mean) / den + bvn[c];
         __syncthreads();
+        TAIL_STAMP(3);
         // hidden layer of both heads: thread (slice, group) sums 4 outputs over an eighth of K, k ascending
-        if (hw) {
+        if (hw && !(dbgm & 2)) {
             const int k0 = slice * kps;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int c0 = 0; c0 < nld; c0 += NLD) {
-#ifdef BOFI_TAIL_NOHOIST
-                {
-#else
                 if (c0 > 0) {
-#endif
 #pragma unroll
                     for (int u = 0; u < NLD; ++u)
-                        wv[u] = (c0 + u < nld) ? *reinterpret_cast<const u32x4*>(wbase + (size_t)(c0 + u) * EPL) : u32x4{0u, 0u, 0u, 0u};
+                        wv[u] = (c0 + u < nld) ? *reinterpret_cast<const u32x4*>(wbase + (size_t)(c0 + u) * wstep) : u32x4{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
                 for (int u = 0; u < NLD; ++u) {
@@ -178,8 +203,10 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
             }
             *reinterpret_cast<float4*>(part + slice * nh + grp * 4) = acc;
         }
+        TAIL_STAMP(4);
         __syncthreads();
-        if (a.dbg_part) {
+        TAIL_STAMP(5);
+        if (a.dbg_part && !(dbgm & 16)) {
             for (int i = tid; i < 8 * nh; i += 512) a.dbg_part[(size_t)b * (8 * nh + d) + i] = part[i];
             for (int i = tid; i < d; i += 512) a.dbg_part[(size_t)b * (8 * nh + d) + 8 * nh + i] = xs[i];
         }
@@ -187,38 +214,45 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
             hid[tid] = fmaxf((((part[tid] + part[nh + tid]) + (part[2 * nh + tid] + part[3 * nh + tid])) +
                               ((part[4 * nh + tid] + part[5 * nh + tid]) + (part[6 * nh + tid] + part[7 * nh + tid]))) + b1v, 0.f);
         __syncthreads();
-        if (tid < 30) {
-            const bool is_len = tid < 20;
-            const float* wr = w2s + tid * (hh + 1);
-            const float* hv = is_len ? hid : (hid + hh);
+        {   // output layers: 16 lanes per output, DPP row reduction (all 512 threads take part; outputs >= 30 are padding)
             float acc = 0.f;
-            for (int k = 0; k < hh; ++k) acc = fmaf(wr[k], hv[k], acc);
-            lg[tid] = acc + (is_len ? w.len_b2[tid] : w.syn_b2[tid - 20]);
+            if (!(dbgm & 1)) {
+                const float* hv = w2o < 20 ? hid : (hid + hh);
+#pragma unroll
+                for (int t = 0; t < W2T; ++t) { const int k = w2q + 16 * t; acc = fmaf(w2v[t], k < hh ? hv[k] : 0.f, acc); }
+            }
+            acc = row16_sum(acc);
+            if (w2q == 0 && w2o < 30) lg[w2o] = acc + w2b;
         }
         __syncthreads();
-        if (tid == 0) {
+        TAIL_STAMP(6);
+        // log-softmax and first-max pick of both heads in wavefront 0: lanes 0..19 the length head, lanes 32..41 the label head
+        // (each head inside one 32-lane half: reductions by row16 + xor16 steps).  torch.max semantics: the first NaN wins, else
+        // the first maximum (TransformerModel.py:380-383).
+        if (wave == 0 && !(dbgm & 4)) {
+            const int head = lane >> 5, li = lane & 31, nout = head ? 10 : 20;
+            const bool on = li < nout;
+            const float v = on ? lg[head * 20 + li] : -INFINITY;
+            float m = xor16_max(row16_max(v));                                     // fmaxf ignores a NaN unless every input is one
+            float e = on ? expf(v - m) : 0.f;
+            const float sum = xor16_sum(row16_sum(e));
+            const float lp = (v - m) - logf(sum);
+            float* out = head ? (a.syn_logp ? a.syn_logp + (size_t)b * 10 : nullptr) : (a.len_logp ? a.len_logp + (size_t)b * 20 : nullptr);
+            if (on && out) out[li] = lp;
+            const bool isnan_ = on && (lp != lp);
+            // index of the first NaN (if any), else of the first maximum: min over the half of a candidate index
+            float cand = isnan_ ? (float)li : 1e9f;
+            cand = -xor16_max(row16_max(-cand));
+            float cmax = (on && v == m) ? (float)li : 1e9f;
+            cmax = -xor16_max(row16_max(-cmax));
+            const int best = cand < 1e8f ? (int)cand : (cmax < 1e8f ? (int)cmax : 0);
+            if (li == 0) reinterpret_cast<int*>(lg)[30 + head] = best;        // (lg holds 30 logits; its last two words carry the picks)
+        }
+        __syncthreads();
+        if (tid == 0 && !(dbgm & 4)) {
             const SaicState& sa = a.sa;
             const int iter = a.iter;
-            int pick[2];
-            for (int head = 0; head < 2; ++head) {
-                const int n = head ? 10 : 20;
-                float* v = lg + (head ? 20 : 0);
-                float m = v[0];
-                for (int i = 1; i < n; ++i) m = fmaxf(m, v[i]);
-                float sum = 0.f;
-                for (int i = 0; i < n; ++i) sum += expf(v[i] - m);
-                const float lse = logf(sum);
-                int best = 0;
-                float bv = -INFINITY;
-                float* out = head ? (a.syn_logp ? a.syn_logp + (size_t)b * 10 : nullptr)
-                                  : (a.len_logp ? a.len_logp + (size_t)b * 20 : nullptr);
-                for (int i = 0; i < n; ++i) {
-                    const float lp = (v[i] - m) - lse;
-                    if (out) out[i] = lp;
-                    if (lp > bv || (lp != lp && bv == bv)) { bv = lp; best = i; }     // first max; a NaN wins once
-                }
-                pick[head] = best;
-            }
+            const int pick[2] = {reinterpret_cast<const int*>(lg)[30], reinterpret_cast<const int*>(lg)[31]};
             if (flags & BOUND_SAIC) {
                 // core_SAIC bookkeeping of iteration `iter` (TransformerModel.py:1910-1948)
                 if (b == 0) st.counters[1] += 1;
@@ -265,7 +299,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
                         fin = true;
                     } else {
                         if (ln + la >= S + 1) { ln = S + 1 - la; fin = true; }      // truncate (:1850-1855)
-                        const int slot = st.phrase_num[b];    // == iteration index while unfinished (Q3)
+                        const int slot = pn_v;                // == iteration index while unfinished (Q3); read at kernel entry
                         st.phrase_length[b * L + slot] = ln;
                         st.phrase_syn[b * L + slot] = sn;
                         st.phrase_num[b] = slot + 1;
@@ -279,6 +313,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
         }
     }
     __syncthreads();
+    TAIL_STAMP(7);
     if (!(flags & BOUND_ATTN) || sint[1]) return;           // a finished image's state is frozen: no further steps matter
 
     // ---- row-0 self-attention over the (position, label) table: scores and softmax, one wavefront per head
@@ -306,35 +341,72 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
         ps[h * 64 + lane] = ElemOps<T>::to_f32(ElemOps<T>::from_f32(e / sum));     // P is held in compute dtype, as in attn.hip
     }
     __syncthreads();
-    // ---- y1 = (x0 + bo) + sum_j sum_h P[h][j] * votab[row_j][h]: thread c owns column c (fixed summation order j, h)
+    TAIL_STAMP(8);
+    // ---- y1 = (x0 + bo) + sum_j sum_h P[h][j] * votab[row_j][h].  All table rows are requested in ONE round trip: a thread owns
+    // 8 columns (one 16-byte piece of a row in bf16) and every (512 / (d/8))-th key; its <= 3 keys x H heads are independent loads.
+    // The key subsets are then summed through LDS in fixed order.
+    {
+        constexpr int CPT = 8, LPT = CPT / EPL;            // columns per thread, 16-byte loads per row piece
+        constexpr int JB = 3;                              // keys per thread and batch
+        const int ncg = d / CPT, njs = 512 / ncg;          // column groups; key subsets (d = 512: 64 and 8)
+        const int cg = tid % ncg, js = tid / ncg;
+        float acc[CPT];
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+        if (js < njs) {
+            for (int jb = js; jb < n; jb += njs * JB) {
+                for (int h0 = 0; h0 < H; h0 += 8) {
+                    u32x4 vv[JB][8][LPT];
+#pragma unroll
+                    for (int t = 0; t < JB; ++t) {
+                        const int j = jb + t * njs;
+                        const int row = (j < n) ? j * 10 + sint[2 + j] : 0;
+                        const T* vr = votab + ((size_t)row * H) * d + cg * CPT;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+#pragma unroll
+                            for (int q = 0; q < LPT; ++q)
+                                vv[t][u][q] = (j < n && h0 + u < H) ? *reinterpret_cast<const u32x4*>(vr + (size_t)(h0 + u) * d + q * EPL) : u32x4{0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int t = 0; t < JB; ++t) {
+                        const int j = jb + t * njs;
+                        if (j >= n) break;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (h0 + u >= H) break;
+                            const float pj = ps[(h0 + u) * 64 + j];
+#pragma unroll
+                            for (int q = 0; q < LPT; ++q) {
+                                union { u32x4 v; T e[EPL]; } vu;
+                                vu.v = vv[t][u][q];
+#pragma unroll
+                                for (int e = 0; e < EPL; ++e) acc[q * EPL + e] = fmaf(pj, ElemOps<T>::to_f32(vu.e[e]), acc[q * EPL + e]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) ysum[js * d + cg * CPT + e] = acc[e];
+        }
+    }
+    __syncthreads();
+    TAIL_STAMP(9);
     for (int c0 = 0; c0 < d; c0 += 512) {
         const int c = c0 + tid;
         if (c0 + (wave << 6) >= d) break;                  // whole wavefronts drop out (d % 64 == 0): the DPP reductions below need full ones
         float acc = a.x0b[c];
-        for (int j = 0; j < n; ++j) {
-            const T* vr = votab + ((size_t)(j * 10 + sint[2 + j]) * H) * d + c;
-            for (int h0 = 0; h0 < H; h0 += 8) {
-                T vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = (h0 + u < H) ? vr[(size_t)(h0 + u) * d] : T(0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (h0 + u < H) acc = fmaf(ps[(h0 + u) * 64 + j], ElemOps<T>::to_f32(vv[u]), acc);
-            }
-        }
+        const int njs = 512 / (d / 8);
+        for (int q = 0; q < njs; ++q) acc += ysum[q * d + c];
         a.y1[(size_t)b * d + c] = acc;
         if (a.y1t) ElemOps<T>::store(static_cast<T*>(a.y1t) + (size_t)b * d + c, acc);
         float s1 = acc, s2 = acc * acc;                    // partial (sum, sumsq) per 32 columns, as the GEMM epilogues write them
-#ifdef BOFI_TAIL_SHFL
-        for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-#else
         s1 = row16_sum(s1); s2 = row16_sum(s2);
         s1 = xor16_sum(s1); s2 = xor16_sum(s2);
-#endif
         if ((tid & 31) == 0) reinterpret_cast<float2*>(a.stats)[(size_t)b * (d >> 5) + (c >> 5)] = make_float2(s1, s2);
     }
-#ifdef BOFI_TAIL_FENCE
-    __threadfence();
-#endif
+    TAIL_STAMP(10);
 }
 
 int launch_bound_tail(const BoundTailArgs& a, int dtype, hipStream_t s) {
@@ -345,7 +417,8 @@ int launch_bound_tail(const BoundTailArgs& a, int dtype, hipStream_t s) {
     if ((a.flags & BOUND_HEADS) && (!a.y || !a.w.w1p)) return BOFI_ERR_ARG;
     BoundTailArgs v = a;
     if (v.yparts < 1) v.yparts = 1;
-    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1) + a.H * 64) * sizeof(float);
+    if (d % 8 || 512 % (d / 8) || d / 8 > 256) return BOFI_ERR_ARG;
+    const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1) + a.H * 64 + 4096) * sizeof(float);
     if (dtype == BOFI_DT_F32) hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(a.B), dim3(512), shm, s, v);
     else hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(a.B), dim3(512), shm, s, v);
     BOFI_CHECK_LAUNCH();

@@ -89,14 +89,17 @@ int launch_bound_table(const float* lut_syn, const float* lut_tok, const float* 
     return BOFI_OK;
 }
 
-// hidden weights of the bound heads for the tail kernel: w1p[((slice*ng + grp)*kps + k)*4 + o] = w1t[(slice*kps + k)*nh + grp*4 + o]
+// hidden weights of the bound heads for the tail kernel.  Thread (slice, grp) of that kernel owns outputs grp*4 .. +3 over the k values
+// slice*kps .. +kps and reads them as 16-byte pieces of KPL k values x 4 outputs; piece u of all groups of a slice is contiguous
+// (a wave-instruction's pieces are adjacent): w1p[((slice*nld + u)*ng + grp)*EPL + kk*4 + o] = w1t[(slice*kps + u*KPL + kk)*nh + grp*4 + o]
 template <typename T>
 __global__ void pack_w1p_kernel(const float* __restrict__ w1t, T* __restrict__ w1p, int d, int nh) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d * nh) return;
-    const int ng = nh / 4, kps = d / 8;
-    const int o = i & 3, k = (i >> 2) % kps, sg = (i >> 2) / kps, grp = sg % ng, slice = sg / ng;
-    ElemOps<T>::store(w1p + i, w1t[(size_t)(slice * kps + k) * nh + grp * 4 + o]);
+    constexpr int EPL = 16 / sizeof(T), KPL = EPL / 4;
+    const int ng = nh / 4, kps = d / 8, nld = kps / KPL;
+    const int o = i & 3, kk = (i >> 2) % KPL, piece = i / EPL, grp = piece % ng, su = piece / ng, u = su % nld, slice = su / nld;
+    ElemOps<T>::store(w1p + i, w1t[(size_t)(slice * kps + u * KPL + kk) * nh + grp * 4 + o]);
 }
 
 int launch_pack_w1p(const float* w1t, void* w1p, int dtype, int d, int nh, hipStream_t st) {
