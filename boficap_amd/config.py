@@ -82,10 +82,8 @@ class BofiConfig:
                 "TransformerModel.py:1558-1568) is built; the ablation variants are out of scope")
         if self.decoder_input_mode != "add":
             raise NotImplementedError("decoder_input_mode must be 'add' (TransformerModel.py:576-577)")
-        if self.N_len != 1:
-            raise NotImplementedError(
-                "N_len must be 1: the row-0-only bound step is exact only for a one-layer bound "
-                "network (SURVEY.md §8a Q4)")
+        if self.N_len < 1:
+            raise NotImplementedError("N_len must be >= 1: the UIC model has a bounding network (TransformerModel.py:1558-1568)")
         if self.d_model % self.h:
             raise ValueError("d_model must be a multiple of num_att_heads")
 
@@ -114,3 +112,5 @@ FULL = BofiConfig()
 # reference config is (d_model 512, 8 heads).
 TINY = BofiConfig(vocab_size=60, att_feat_size=64, d_model=128, d_ff=256, h=2, N_enc=2, N_dec=2,
                   N_len=1, seq_length=20)
+# The small configuration with a two-layer bounding network (configs/uic_sd_N2.yml: N_len 2): the decode engine's dense bounding pass.
+TINY_N2 = dataclasses.replace(TINY, N_len=2)

@@ -15,6 +15,8 @@ struct BoundState {
     int* phrase_syn;      // [B, L]
     int* ext_syn;         // [B, L]  extend_phrase_syn: [LEN] id at 0, label of the slot covering p
     int* counters;        // [4]: 0 = images finished, 1 = bound iterations executed
+    int* klen;            // [B, L]  keys row r of the bound sequence may attend (tgt_mask rows are key prefixes, TransformerModel.py:1859-1867):
+                          //         maintained for the dense (N_len >= 2) bounding pass; may be NULL
 };
 
 // Extra per-image state of core_SAIC (reference TransformerModel.py:1879-1896), int32 on the device.
@@ -39,7 +41,8 @@ struct BoundHeadWeights {   // float32 unless noted
 
 // arguments of the per-image tail kernel of a bounding iteration (naic.hip)
 struct BoundTailArgs {
-    const float* y; int yparts;          // HEADS: FFN output of row 0, [yparts][B][d] float32 partial slabs (summed in fixed order)
+    const float* y; int yparts;          // HEADS: FFN output of row 0, [yparts][B][y_stride] float32 partial slabs (summed in fixed order)
+    int y_stride;                        // elements between the row-0 vectors of consecutive images (0: d)
     BoundHeadWeights w;
     BoundState st; SaicState sa;
     const int* ext_syn_in; const int* last_in;   // non-NULL: a given slot layout instead of the engine's state (stage API)

@@ -68,6 +68,9 @@ struct bofi_engine {
     Lin att_embed;
     std::vector<EncLayer> enc; Norm enc_norm;
     std::vector<DecLayer> dec; Norm dec_norm;
+    std::vector<DecLayer> blay;      // the bounding network's layers as full layers (dense form: N_len >= 2, or forced for a self-check)
+    int n_len = 1;
+    bool bound_dense = false;
     Lin kv_all;                      // stacked cross-attention K|V: bound layer, then decoder layers
     Lin gen;
     float *lut_syn = nullptr, *lut_tok = nullptr, *pe = nullptr;
@@ -232,7 +235,8 @@ struct bofi_engine {
     const bofi_config_t& c = cfg;
     const size_t Bm = c.max_batch, Rm = c.max_regions, Sq = c.seq_length;
     const int d = c.d_model, dff = c.d_ff;
-    const size_t rows = Bm * (Rm > Sq ? Rm : Sq);
+    const size_t Lm = Sq + 2;
+    const size_t rows = Bm * (Rm > Lm ? Rm : Lm);
     ENG_OK(dalloc(&x_enc, Bm * Rm * d));
     ENG_OK(dalloc(&x_fill, Bm * Sq * d));
     ENG_OK(dalloc(&logits, Bm * Sq * c.vocab));
@@ -253,7 +257,7 @@ struct bofi_engine {
     ENG_OK(dalloc((char**)&bctx2, Bm * d, tsz)); ENG_OK(dalloc((char**)&bh, Bm * dff, tsz));
     ENG_OK(dalloc(&st.last, Bm)); ENG_OK(dalloc(&st.finished, Bm)); ENG_OK(dalloc(&st.phrase_num, Bm));
     ENG_OK(dalloc(&st.phrase_length, Bm * L)); ENG_OK(dalloc(&st.phrase_syn, Bm * L));
-    ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 4));
+    ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 4)); ENG_OK(dalloc(&st.klen, Bm * L));
     ENG_OK(dalloc(&sa.seq_last, Bm)); ENG_OK(dalloc(&sa.seq, Bm * L)); ENG_OK(dalloc(&sa.ext_len, Bm * L));
     ENG_OK(dalloc(&sa.ext_phrase, Bm * L)); ENG_OK(dalloc(&sa.klen_dec, Bm * L));
     ENG_OK(dalloc(&xw, Bm * L * d)); ENG_OK(dalloc((char**)&xwb, Bm * L * d, tsz)); ENG_OK(dalloc(&st_w, Bm * L * (d / 32) * 2));
@@ -264,9 +268,9 @@ struct bofi_engine {
 
     // the per-image tail of a bounding iteration (naic.hip): heads on the FFN output `y`, bookkeeping, next self-attention sublayer
     int bound_tail(const float* y, int yparts, const int* ext_syn_in, const int* last_in, int B, int flags, float* len_logp, float* syn_logp,
-                   hipStream_t s, bool saic = false, int iter = 0) {
+                   hipStream_t s, bool saic = false, int iter = 0, int y_stride = 0) {
         bofi::BoundTailArgs a{};
-        a.y = y; a.yparts = yparts; a.w = heads; a.st = st; a.sa = saic ? sa : bofi::SaicState{};
+        a.y = y; a.yparts = yparts; a.y_stride = y_stride; a.w = heads; a.st = st; a.sa = saic ? sa : bofi::SaicState{};
         a.ext_syn_in = ext_syn_in; a.last_in = last_in; a.q0 = b_q0; a.kvtab = b_kvtab; a.votab = b_votab; a.x0b = b_x0b;
         a.y1 = by1; a.y1t = copy_t(byb); a.stats = st_b;
         static const int tail_dbg = [] { const char* v = getenv("BOFI_TAIL_DBG"); return v ? atoi(v) : 0; }();     // developer ablations
@@ -287,6 +291,7 @@ struct bofi_engine {
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
                            float* syn_logp, bool early, hipStream_t s);
     int enqueue_fill(const int* att_len, int B, int R, int flags, int64_t* seq, float* seq_logprob, hipStream_t s);
+    int enqueue_bound_dense(const int* att_len, int B, int R, hipStream_t s);
     int enqueue_decode_saic(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
                             float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn, int* bound_iters, hipStream_t s);
     int enqueue_decode(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
@@ -359,6 +364,47 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     return BOFI_OK;
 }
 
+// The bounding loop in its dense form (LengthPredictor_UIC.forward TransformerModel.py:357-383 as the reference runs it): per
+// iteration the whole bound sequence -- all L = S + 2 rows, pos_embed(syn_embed(extend_phrase_syn)) -- goes through every one of
+// the N_len layers (self-attention under tgt_mask, whose rows are key prefixes: BoundState.klen; cross-attention over the
+// memory; FFN), then the final norm, the heads and the bookkeeping on row 0 (the tail kernel without its self-attention part).
+// Needed for N_len >= 2, where the upper layers read the lower layers' outputs of every visible row; with
+// BOFI_BOUND_DENSE=1 it also serves N_len = 1 as a cross-check of the incremental form.
+int bofi_engine::enqueue_bound_dense(const int* att_len, int B, int R, hipStream_t s) {
+    const int d = cfg.d_model, dt = cfg.dtype, S = cfg.seq_length, M = B * L;
+    cur_B = B;
+    const void* xa = stream_t(xw, xwb);
+    for (int it = 0; it < S; ++it) {
+        // input rows: the syntactic table stands where launch_embed_rows takes the word table (no second term)
+        ENG_OK(bofi::launch_embed_rows(lut_syn, nullptr, pe, st.ext_syn, nullptr, L, 0, B, L, d, 0, xw, copy_t(xwb), dt, st_w, nullptr, s));
+        for (size_t li = 0; li < blay.size(); ++li) {
+            auto& l = blay[li];
+            { LinOpt o; o.early = true; o.ln_stats = st_w; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
+            bofi::AttnArgs a{};
+            a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
+            a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = L; a.Lk = L;
+            a.klen = st.klen; a.klen_sb = L; a.klen_sq = 1; a.skip_if_ge = st.counters; a.skip_threshold = B;
+            ENG_OK(bofi::launch_attention(a, s));
+            { LinOpt o; o.early = true; o.residual = xw; o.ldr = d; o.stats_out = st_w; o.y2 = copy_t(xwb);
+              ENG_OK(linear(ctx, dt, d, l.o, xw, BOFI_DT_F32, d, M, o, s)); }
+            { LinOpt o; o.early = true; o.ln_stats = st_w; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
+            bofi::AttnArgs c{};
+            c.q = qs; c.ldq = d;
+            c.k = (char*)kv + (size_t)li * 2 * d * tsz; c.v = (char*)kv + ((size_t)li * 2 * d + d) * tsz;
+            c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = L; c.Lk = R;
+            c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0; c.skip_if_ge = st.counters; c.skip_threshold = B;
+            ENG_OK(bofi::launch_attention(c, s));
+            { LinOpt o; o.early = true; o.residual = xw; o.ldr = d; o.stats_out = st_w; o.y2 = copy_t(xwb);
+              ENG_OK(linear(ctx, dt, d, l.o_src, xw, BOFI_DT_F32, d, M, o, s)); }
+            { LinOpt o; o.early = true; o.relu = 1; o.ln_stats = st_w; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+            { LinOpt o; o.early = true; o.residual = xw; o.ldr = d; o.stats_out = st_w; o.y2 = copy_t(xwb);
+              ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, xw, BOFI_DT_F32, d, M, o, s)); }
+        }
+        ENG_OK(bound_tail(xw, 1, nullptr, nullptr, B, BOUND_HEADS | BOUND_UPDATE | BOUND_EARLY, nullptr, nullptr, s, false, 0, L * d));
+    }
+    return BOFI_OK;
+}
+
 int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags, int64_t* seq,
                                 float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn,
                                 float* memory_out, int* bound_iters, hipStream_t s) {
@@ -366,9 +412,13 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, memory_out, s));
     // ---- bounding pass (core_NAIC TransformerModel.py:1833-1870)
     ENG_OK(bofi::launch_bound_init(st, B, L, cfg.pad_idx, cfg.len_idx, s));
-    ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
-    for (int it = 0; it < S; ++it)
-        ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
+    if (bound_dense) {
+        ENG_OK(enqueue_bound_dense(att_len, B, R, s));
+    } else {
+        ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
+        for (int it = 0; it < S; ++it)
+            ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
+    }
     ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
     ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
     return BOFI_OK;
@@ -400,7 +450,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
         bofi::AttnArgs c{};
         c.q = qs; c.ldq = d;
-        c.k = (char*)kv + (size_t)(1 + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(1 + li) * 2 * d + d) * tsz;
+        c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
         c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
         c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0;
         ENG_OK(bofi::launch_attention(c, s));
@@ -473,7 +523,7 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
             { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
             bofi::AttnArgs c{};
             c.q = qs; c.ldq = d;
-            c.k = (char*)kv + (size_t)(1 + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(1 + li) * 2 * d + d) * tsz;
+            c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
             c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
             c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0; c.skip_if_ge = halt; c.skip_threshold = 1;
             ENG_OK(bofi::launch_attention(c, s));
@@ -498,7 +548,7 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
 // ================================================================================================
 extern "C" {
 
-int bofi_abi_version(void) { return 1; }
+int bofi_abi_version(void) { return 2; }
 const char* bofi_last_error(void) { return g_err.c_str(); }
 
 int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
@@ -509,8 +559,11 @@ int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
     if (c->seq_length <= 0 || c->seq_length + 2 > 64) return fail(BOFI_ERR_ARG, "seq_length must be in 1..62");
     if (c->max_batch <= 0 || c->max_regions <= 0 || c->max_regions > 128) return fail(BOFI_ERR_ARG, "max_batch > 0, 0 < max_regions <= 128");
     if (c->vocab <= 0 || c->n_enc < 0 || c->n_dec < 0 || c->head_hidden <= 0) return fail(BOFI_ERR_ARG, "bad layer/vocab counts");
+    if (c->n_len < 1 || c->n_len > 8) return fail(BOFI_ERR_ARG, "n_len must be in 1..8");
     auto* e = new bofi_engine();
     e->cfg = *c;
+    e->n_len = c->n_len;
+    { const char* v = getenv("BOFI_BOUND_DENSE"); e->bound_dense = c->n_len > 1 || (v && atoi(v) != 0); }
     e->L = c->seq_length + 2;
     e->tsz = c->dtype == BOFI_DT_F32 ? 4 : 2;
     *out = e;
@@ -694,7 +747,23 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     }
     ENG_OK(e->make_norm(&e->enc_norm, "model.encoder.norm", d));
     const std::string bl = "model.length_predictor.LengthPredictor.0";
-    std::vector<std::string> kvs = {bl + ".src_attn.linears.1", bl + ".src_attn.linears.2"};
+    std::vector<std::string> kvs;                 // cross-attention K|V: the bound layers first, then the decoder layers
+    for (int l = 0; l < e->n_len; ++l) {
+        const std::string p = S("model.length_predictor.LengthPredictor.%d", l);
+        kvs.push_back(p + ".src_attn.linears.1");
+        kvs.push_back(p + ".src_attn.linears.2");
+    }
+    e->blay.assign(e->bound_dense ? e->n_len : 0, DecLayer());
+    for (size_t l = 0; l < e->blay.size(); ++l) {
+        auto& D = e->blay[l];
+        const std::string p = S("model.length_predictor.LengthPredictor.%d", (int)l);
+        ENG_OK(e->make_lin(&D.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
+        ENG_OK(e->make_lin(&D.o, {p + ".self_attn.linears.3"}, d, d));
+        ENG_OK(e->make_lin(&D.q_src, {p + ".src_attn.linears.0"}, d, d, p + ".sublayer.1.norm"));
+        ENG_OK(e->make_lin(&D.o_src, {p + ".src_attn.linears.3"}, d, d));
+        ENG_OK(e->make_lin(&D.w1, {p + ".ff.w_1"}, dff, d, p + ".sublayer.2.norm"));
+        ENG_OK(e->make_lin(&D.w2, {p + ".ff.w_2"}, d, dff));
+    }
     for (int l = 0; l < c.n_dec; ++l) {
         auto& D = e->dec[l];
         const std::string p = S("model.decoder.layers.%d", l);
@@ -828,6 +897,7 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
     g_err.clear();
     ENG_OK(check_call(e, B, R));
     if (!ext_syn || !last || !len_logp || !syn_logp) return fail(BOFI_ERR_ARG, "null argument");
+    if (e->bound_dense) return fail(BOFI_ERR_STATE, "bound_step is the incremental (N_len = 1) form's stage; the dense bounding pass runs inside decode_naic");
     ENG_OK(e->bound_tail(nullptr, 1, ext_syn, last, B, BOUND_ATTN, nullptr, nullptr, (hipStream_t)stream));
     return e->enqueue_bound_iter(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, false, (hipStream_t)stream);
 }
@@ -851,6 +921,7 @@ int bofi_engine_decode_saic(bofi_engine_t* e, const void* feats, int feats_dtype
     ENG_OK(check_call(e, B, R));
     ENG_OK(check_feats(e, feats, feats_dtype));
     if (!seq) return fail(BOFI_ERR_ARG, "null seq");
+    if (e->n_len != 1) return fail(BOFI_ERR_STATE, "the semi-autoregressive decode is built for a one-layer bounding network (N_len = 1)");
     return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
                                   bound_iters, (hipStream_t)stream);
 }

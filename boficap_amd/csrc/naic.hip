@@ -20,6 +20,7 @@ __global__ void bound_init_kernel(BoundState st, int B, int L, int pad_idx, int 
         st.phrase_length[i] = 0;
         st.phrase_syn[i] = pad_idx;
         st.ext_syn[i] = (i % L == 0) ? len_idx : pad_idx;     // position 0 is the [LEN] marker
+        if (st.klen) st.klen[i] = 1;                          // tgt_mask[:, :, 0] = True (TransformerModel.py:1836)
     }
 }
 
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
             const int k = tid + c * 512;
             yv[c] = 0.f; gv[c] = 0.f; bvn[c] = 0.f;
             if (k < d) {
-                float acc = y[(size_t)b * d + k];
-                for (int pz = 1; pz < a.yparts; ++pz) acc += y[((size_t)pz * B + b) * d + k];
+                const size_t ys = a.y_stride ? (size_t)a.y_stride : (size_t)d;
+                float acc = y[(size_t)b * ys + k];
+                for (int pz = 1; pz < a.yparts; ++pz) acc += y[((size_t)pz * B + b) * ys + k];
                 yv[c] = acc; gv[c] = w.norm_gain[k]; bvn[c] = w.norm_bias[k];
             }
         }
@@ -306,6 +308,10 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
                         for (int p = la; p < la + ln; ++p) { st.ext_syn[b * L + p] = sn; sint[2 + p] = sn; }
                         st.last[b] = la + ln;
                         sint[0] = la + ln;
+                        if (st.klen) {                        // tgt_mask[j, la:, :la+ln] = True; tgt_mask[j, 0, :la+ln] = True (:1859-1867)
+                            for (int r = la; r < L; ++r) st.klen[b * L + r] = la + ln;
+                            st.klen[b * L] = la + ln;
+                        }
                     }
                     if (fin) { st.finished[b] = 1; sint[1] = 1; atomicAdd(&st.counters[0], 1); }
                 }

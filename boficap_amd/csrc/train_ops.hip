@@ -107,8 +107,10 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention backward for the short sequences of this model (Lq, Lk <= 64, d_k = 64), float32, one workgroup per
-// (batch item, head): recompute P, then dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8.
+// Attention backward for the short sequences of this model (Lk <= 128 keys: up to max_boxes = 100 regions; d_k = 64), float32, one
+// workgroup per (batch item, head, chunk of LQ query rows): recompute P, then dV = P^T dO, dP = dO V^T,
+// dS = P (dP - rowsum(dP P)), dQ = dS K / 8, dK = dS^T Q / 8.  With more than one query chunk (or shared keys, kdiv > 1) the key-side
+// gradients of the chunks meet in float atomics: the caller passes zeroed dk / dv.
 struct AttnBwdParams {
     const float* q; int ldq; const float* k; int ldk; const float* v; int ldv;
     const float* dout; int ldo;
@@ -124,12 +126,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
     __shared__ float sq[LQ * DS], sdo[LQ * DS], sk[LK * DS], sv[LK * DS], sp[LQ * PS], sds[LQ * PS];
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H, tid = threadIdx.x;
     const int bk = b / p.kdiv;
-    const int Lq = p.q_start ? p.q_count[b] : p.Lq;
-    const size_t qrow0 = p.q_start ? (size_t)p.q_start[b] : (size_t)b * p.Lq;
+    const int Lq_all = p.q_start ? p.q_count[b] : p.Lq;         // the item's query rows; this workgroup takes rows qc0 .. qc0 + LQ
+    const size_t qrow_item = p.q_start ? (size_t)p.q_start[b] : (size_t)b * p.Lq;
+    const int qc0 = blockIdx.y * LQ;
     const bool kr = p.q_start && p.k_ragged;
-    const int Lk = kr ? Lq : p.Lk;
-    const size_t krow0 = kr ? qrow0 : (size_t)bk * p.Lk;
-    if (Lq <= 0) return;
+    const int Lk = kr ? Lq_all : p.Lk;
+    const size_t krow0 = kr ? qrow_item : (size_t)bk * p.Lk;
+    if (qc0 >= Lq_all) return;
+    const int Lq = min(LQ, Lq_all - qc0);
+    const size_t qrow0 = qrow_item + qc0;
+    const bool shared = p.kdiv > 1 || gridDim.y > 1;            // several workgroups add into the same dk / dv rows
     for (int i = tid; i < Lq * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         sq[r * DS + c] = p.q[(qrow0 + r) * p.ldq + h * 64 + c];
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
         const int i = tid >> 2, sub = tid & 3;
         if (i < Lq) {
             int kl = Lk;
-            if (p.klen) { kl = (p.q_start ? p.klen[qrow0 + i] : p.klen[b * p.klen_sb + i * p.klen_sq]) + p.klen_bias; kl = max(0, min(kl, Lk)); }
+            if (p.klen) { kl = (p.q_start ? p.klen[qrow0 + i] : p.klen[b * p.klen_sb + (qc0 + i) * p.klen_sq]) + p.klen_bias; kl = max(0, min(kl, Lk)); }
             float m = -INFINITY;
             for (int j = sub; j < kl; j += 4) m = fmaxf(m, sp[i * PS + j]);
             m = quad_max(m);
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
         for (int i = 0; i < Lq; ++i) { a = fmaf(sds[i * PS + r], sq[i * DS + c], a); g = fmaf(sp[i * PS + r], sdo[i * DS + c], g); }
         float* dkp = p.dk + (krow0 + r) * p.ldk + h * 64 + c;
         float* dvp = p.dv + (krow0 + r) * p.ldv + h * 64 + c;
-        if (p.kdiv > 1) { atomicAdd(dkp, a); atomicAdd(dvp, g); } else { *dkp = a; *dvp = g; }
+        if (shared) { atomicAdd(dkp, a); atomicAdd(dvp, g); } else { *dkp = a; *dvp = g; }
     }
 }
 
@@ -621,14 +627,18 @@ extern "C" int bofi_layernorm_bwd_ex(const float* x, const float* gain, const fl
 extern "C" int bofi_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* dout, int ldo,
                                   float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk, int kdiv, const int* klen, int klen_sb,
                                   int klen_sq, int klen_bias, const int* q_start, const int* q_count, int k_ragged, void* stream) {
-    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > 64 || Lk > 64 || kdiv <= 0) return BOFI_ERR_ARG;
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lk > 128 || kdiv <= 0) return BOFI_ERR_ARG;
+    if (k_ragged && q_start && Lq > 128) return BOFI_ERR_ARG;          // keys = the item's own rows: at most 128 of them
     if (B == 0) return BOFI_OK;
     if ((q_start != nullptr) != (q_count != nullptr)) return BOFI_ERR_ARG;
     AttnBwdParams p{q, ldq, k, ldk, v, ldv, dout, ldo, dq, dk, dv, B, H, Lq, Lk, kdiv, klen, klen_sb, klen_sq, klen_bias, q_start, q_count, k_ragged};
-    const dim3 grid(B * H), block(256);
-    if (Lq <= 32 && Lk <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 32>), grid, block, 0, (hipStream_t)stream, p);
-    else if (Lq <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 64>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attn_bwd_kernel<64, 64>), grid, block, 0, (hipStream_t)stream, p);
+    const dim3 block(256);
+    const int keys = (k_ragged && q_start) ? (Lq > Lk ? Lq : Lk) : Lk;    // the LDS tiles are sized for the most keys an item can have
+    // query rows in chunks of 32 or 64 (gridDim.y): more than one chunk -> dk / dv by atomics (the caller zeroed them)
+    if (keys > 64) hipLaunchKernelGGL((attn_bwd_kernel<32, 128>), dim3(B * H, (Lq + 31) / 32), block, 0, (hipStream_t)stream, p);
+    else if (Lq <= 32 && keys <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 32>), dim3(B * H), block, 0, (hipStream_t)stream, p);
+    else if (Lq <= 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 64>), dim3(B * H), block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_bwd_kernel<64, 64>), dim3(B * H, (Lq + 63) / 64), block, 0, (hipStream_t)stream, p);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -64,7 +64,7 @@ class BofiEngine:
             vocab=cfg.tgt_vocab, feat=cfg.att_feat_size, d_model=cfg.d_model, d_ff=cfg.d_ff, heads=cfg.h,
             n_enc=cfg.N_enc, n_dec=cfg.N_dec, seq_length=cfg.seq_length, pad_idx=cfg.pad_idx, bos_idx=cfg.bos_idx,
             eos_idx=cfg.eos_idx, len_idx=cfg.len_idx, head_hidden=cfg.head_hidden, max_batch=max_batch,
-            max_regions=max_regions, dtype={torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[dtype])
+            max_regions=max_regions, dtype={torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[dtype], n_len=cfg.N_len)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             hip.check(self._lib.bofi_engine_create(C.byref(c), C.byref(self._h)), "bofi_engine_create")

@@ -15,7 +15,7 @@ DT_F32, DT_BF16 = 0, 1
 FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
 FLAG_REFINE_SHIFT = 8
 FLAG_SAMPLE = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class BofiHipError(RuntimeError):
@@ -25,7 +25,7 @@ class BofiHipError(RuntimeError):
 class BofiConfigC(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "vocab", "feat", "d_model", "d_ff", "heads", "n_enc", "n_dec", "seq_length",
-        "pad_idx", "bos_idx", "eos_idx", "len_idx", "head_hidden", "max_batch", "max_regions", "dtype")]
+        "pad_idx", "bos_idx", "eos_idx", "len_idx", "head_hidden", "max_batch", "max_regions", "dtype", "n_len")]
 
 
 _P, _I, _I64 = C.c_void_p, C.c_int, C.c_int64

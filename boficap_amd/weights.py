@@ -92,7 +92,7 @@ def make_state_dict(cfg: BofiConfig, seed: int = 0, *, bound_preset: bool = True
     two output layers of the bound heads by the calibrated ones in
     ``presets/bound_heads_<preset_name>_seed<seed>.npz`` (written by oracle/calibrate_preset.py) so
     that phrase slots are actually produced -- random weights emit EOS at once, SURVEY.md §8c;
-    ``preset_name`` defaults to "full"/"tiny" by d_model.  ``gen_scale`` scales
+    ``preset_name`` defaults to "full"/"tiny" by d_model (+ "_n<N_len>" for a multi-layer bounding network).  ``gen_scale`` scales
     generator.proj.weight to widen the top-2 logit gap of the greedy argmax.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -115,7 +115,7 @@ def make_state_dict(cfg: BofiConfig, seed: int = 0, *, bound_preset: bool = True
     if gen_scale != 1.0:
         sd["model.generator.proj.weight"] = (sd["model.generator.proj.weight"] * np.float32(gen_scale)).astype(np.float32)
     if bound_preset:
-        name = preset_name or ("full" if cfg.d_model == 512 else "tiny")
+        name = preset_name or (("full" if cfg.d_model == 512 else "tiny") + ("" if cfg.N_len == 1 else f"_n{cfg.N_len}"))
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "presets",
                             f"bound_heads_{name}_seed{seed}.npz")
         if not os.path.exists(path):

@@ -466,7 +466,9 @@ class AttentionFn(Function):
             ctx.save_for_backward(qbuf, kvbuf)
         ctx.drop = drop
         ctx.meta = (qoff, koff, voff, B, H, Lq, Lk, kdiv, klen_sb, klen_sq, klen_bias)
-        ctx.mfma = bf16                                        # bf16 mode: backward on the matrix cores
+        # bf16 mode: backward on the matrix cores -- for up to 64 keys (and 64 query rows, or a row list); beyond that (up to 128 keys:
+        # max_boxes = 100 regions) the float32 kernel, which walks the query rows in chunks
+        ctx.mfma = bf16 and Lk <= 64 and (Lq <= 64 or (seg is not None and not seg[2]))
         ctx.seg = seg
         ctx.grad_bf16 = bool(grad_bf16)
         ctx.same = qbuf.data_ptr() == kvbuf.data_ptr()
@@ -482,7 +484,7 @@ class AttentionFn(Function):
         # the MFMA kernel writes every element of the q / k / v slices (no atomics); the VALU kernel accumulates shared keys
         covered = ctx.seg is None and ctx.mfma and ((ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64))
         sp = (hip.ptr(ctx.seg[0]), hip.ptr(ctx.seg[1]), int(bool(ctx.seg[2]))) if ctx.seg is not None else (None, None, 0)
-        alloc = torch.empty if covered else torch.zeros
+        alloc = torch.empty if covered else torch.zeros         # (the float32 kernel adds dk / dv with atomics when keys are shared or the query rows are chunked)
         tail = ctx.seg[3] if ctx.seg is not None and len(ctx.seg) > 3 else None
         fits = (ctx.same and ldq == 3 * H * 64) or (not ctx.same and ldq == H * 64 and ldk == 2 * H * 64)
         # grad_bf16: q (and, for a packed self-attention, k and v) come straight from a projection GEMM whose backward wants
@@ -961,6 +963,9 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok).  ``P``: a ``Params``."""
     dev = att_feats.device
     S, L, d = cfg.seq_length, cfg.seq_length + 2, cfg.d_model
+    if cfg.N_len != 1:
+        raise NotImplementedError("training with N_len >= 2: the teacher-forced bound passes run as row-0 queries, which is exact for a one-layer "
+                                  "bounding network only (SURVEY.md 8a Q4); the decode engine has the dense form, the training graph does not yet")
     if compute_dtype not in (torch.float32, torch.bfloat16):
         raise hip.BofiHipError(f"training compute dtype {compute_dtype}: float32 or bfloat16")
     _COMPUTE["dtype"] = compute_dtype

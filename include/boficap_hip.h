@@ -247,6 +247,9 @@ typedef struct bofi_config {
     int max_batch;    /* workspace is sized for this many images per call */
     int max_regions;  /* and this many regions per image (<= 128) */
     int dtype;        /* compute dtype: BOFI_DT_F32 (parity) or BOFI_DT_BF16 (throughput) */
+    int n_len;        /* layers of the bounding network (LengthPredictor_UIC N_len, TransformerModel.py:357-375): 1 (configs/uic_sd.yml) takes
+                         the row-0-only incremental form; >= 2 (configs/uic_sd_N2.yml) the dense form -- all S+2 rows through every layer
+                         per iteration, as the reference computes it (ABI version 2) */
 } bofi_config_t;
 
 /* Allocates device weights + workspace for one model replica on the current HIP device. */

@@ -27,7 +27,7 @@ sys.path.insert(0, HERE)
 
 import boficap_oracle as O                                   # noqa: E402
 from boficap_amd import weights as W                         # noqa: E402
-from boficap_amd.config import FULL, TINY                    # noqa: E402
+from boficap_amd.config import FULL, TINY, TINY_N2           # noqa: E402
 
 LEN_PRIOR = np.full((O.LENGTH_DIM,), -9.0, np.float32)
 LEN_PRIOR[:5] = [-0.9, 0.9, 1.1, 0.6, 0.1]
@@ -59,13 +59,7 @@ def row0_features(w, cfg, mem, sm, rng, n_layouts: int = 4):
                 last += ln
                 mask[b, 0, :last] = True
         x = O.add_pe(w, O.embed(w, "model.syn_embed", ext, cfg.d_model))
-        p = f"{lp}.LengthPredictor.0"
-        n = O.layer_norm(x, w, p + ".sublayer.0.norm")
-        x = x + O.attention(w, p + ".self_attn", n, n, mask, cfg.h)
-        n = O.layer_norm(x, w, p + ".sublayer.1.norm")
-        x = x + O.attention(w, p + ".src_attn", n, mem, sm, cfg.h)
-        x = x + O.feed_forward(w, p + ".ff", O.layer_norm(x, w, p + ".sublayer.2.norm"))
-        outs.append(O.layer_norm(x, w, lp + ".norm")[:, 0, :])
+        outs.append(O.bound_row0(w, cfg, x, mem, sm, mask))          # all N_len layers + the final norm, row 0
     return torch.cat(outs, 0)
 
 
@@ -75,6 +69,7 @@ def row0_features(w, cfg, mem, sm, rng, n_layouts: int = 4):
 KNOBS = {
     "tiny": dict(attn_gain=2.0, std=1.5, len0=0.8, syn1=-0.4),
     "full": dict(attn_gain=2.0, std=1.5, len0=0.8, syn1=-1.2),
+    "tiny_n2": dict(attn_gain=2.0, std=1.5, len0=0.8, syn1=-0.4),      # two-layer bounding network (configs/uic_sd_N2.yml)
 }
 
 
@@ -114,7 +109,10 @@ def main():
     import collections
     os.makedirs(os.path.join(os.path.dirname(HERE), "boficap_amd", "presets"), exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
-    for name, cfg in (("tiny", TINY), ("full", FULL)):
+    only = set(sys.argv[1:])
+    for name, cfg in (("tiny", TINY), ("full", FULL), ("tiny_n2", TINY_N2)):
+        if only and name not in only:
+            continue
         for seed in (0,):
             heads = calibrate(cfg, seed, KNOBS[name])
             path = os.path.join(os.path.dirname(HERE), "boficap_amd", "presets", f"bound_heads_{name}_seed{seed}.npz")

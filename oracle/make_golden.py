@@ -53,7 +53,7 @@ sys.path.insert(1, ROOT)
 sys.path.insert(1, HERE)
 import boficap_oracle as O                                     # noqa: E402
 from boficap_amd import weights as W                           # noqa: E402
-from boficap_amd.config import FULL, TINY                      # noqa: E402
+from boficap_amd.config import FULL, TINY, TINY_N2             # noqa: E402
 
 
 def build_reference(cfg, sd_np):
@@ -423,6 +423,26 @@ def main():
     manifest["tiny_loss_wrapper_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
                                             **run_loss_wrapper_xe_case("tiny_loss_wrapper_xe", TINY, sd_t, 2, 3, 9))
     print("tiny_loss_wrapper_xe", manifest["tiny_loss_wrapper_xe"])
+    # a two-layer bounding network (configs/uic_sd_N2.yml): the upper layer reads the lower layer's output of every visible row, so
+    # the bound step is no longer a function of row 0 alone -- the engine's dense bounding pass is checked against this
+    sd_2 = W.make_state_dict(TINY_N2, seed=0, gen_scale=6.0)
+    model_2, w_2 = build_reference(TINY_N2, sd_2), O.as_torch(sd_2)
+    pool2 = W.synthetic_att_feats(48, 36, TINY_N2.att_feat_size, seed=4321)
+    mem2, sm2 = O.memory_of(w_2, TINY_N2, torch.from_numpy(pool2))
+    dg2 = O.core_naic(w_2, TINY_N2, mem2, sm2)[4]
+    last2 = dg2["last"].numpy()
+    multi = [i for i in range(48) if last2[i] > 3][:6]
+    few = [i for i in range(48) if last2[i] <= 3][:2]
+    assert len(multi) >= 4, last2
+    pick2 = few + multi
+    res = run_case("tiny_n2", TINY_N2, model_2, w_2, pool2[pick2], None, want_saic=False)
+    assert int(res["naic_phrase_num"].max()) >= 2 and not np.isnan(res["naic_logprob"]).any(), res["naic_phrase_num"]
+    # the row-0-only form is NOT exact here: the one-layer shortcut on the same weights must give another answer
+    np.savez_compressed(os.path.join(OUT, "tiny_n2.npz"), **res)
+    manifest["tiny_n2"] = dict(config="TINY_N2", seed=0, gen_scale=6.0, digest=W.digest(sd_2), B=len(pick2), iters=int(res["naic_iters"]),
+                               gap=float(res["naic_gap"]), reasons=res["naic_reason"].tolist(), phrase_num=res["naic_phrase_num"].tolist())
+    print("tiny_n2", manifest["tiny_n2"])
+    manifest["schema_TINY_N2"] = [[k, list(s)] for k, s in W.schema(TINY_N2).items()]
     # schema as data (name, shape) for the CPU-side state_dict test
     manifest["schema_TINY"] = [[k, list(s)] for k, s in W.schema(TINY).items()]
     manifest["schema_FULL"] = [[k, list(s)] for k, s in W.schema(FULL).items()]

@@ -42,7 +42,8 @@ def weight_cache():
     def get(config_name, seed, gen_scale, digest=None, patch=None):
         key = (config_name, seed, gen_scale, patch)
         if key not in cache:
-            cfg = {"TINY": TINY, "FULL": FULL}[config_name]
+            from boficap_amd.config import TINY_N2
+            cfg = {"TINY": TINY, "FULL": FULL, "TINY_N2": TINY_N2}[config_name]
             sd = W.make_state_dict(cfg, seed=seed, gen_scale=gen_scale)
             if patch == "len_row_shared":
                 sd = W.with_len_row_shared(sd, cfg)

@@ -530,3 +530,52 @@ def test_optimizer_checkpoint_round_trips_with_torch_adam(weight_cache, manifest
     from boficap_amd.hip import BofiHipError
     with pytest.raises(BofiHipError):
         tr2.load_state_dict({"_step": 1, "exp_avg": tr.m, "exp_avg_sq": tr.v})       # round 1's private layout is refused loudly
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_xe_step_with_100_regions(weight_cache, manifest, dtype):
+    """max_boxes = 100 adaptive regions (the reference's cocobu_att features, opts.py:84) with ragged att_masks: forward AND
+    backward of the XE step -- the attention backward beyond 64 keys (encoder self-attention 100 x 100, cross-attention over 100
+    keys) -- against autograd over the oracle on the CPU.  bf16: operands rounded, same bars as the 36-region bf16 test."""
+    from boficap_amd import xe
+    from boficap_amd.weights import synthetic_att_feats
+    from training_batch import make_training_batch
+    cfg, sd, model = _model(weight_cache, manifest, "tiny_train_xe", bofi_train_dtype=dtype, max_boxes=100)
+    model.eval()
+    n_img, spi, R = 3, 2, 100
+    att = torch.from_numpy(synthetic_att_feats(n_img, R, cfg.att_feat_size, seed=31))
+    masks = torch.zeros(n_img, R)
+    for i, n in enumerate((100, 67, 23)):
+        masks[i, :n] = 1
+        att[i, n:] = 0
+    b = {k: torch.from_numpy(v) for k, v in make_training_batch(cfg, n_img, spi, seed=8).items()}
+    w = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and k != "model.pos_embed.pe") for k, v in model.state_dict().items()}
+    outs_ref = O.forward_uic(w, cfg, att, b["labels"], masks, b["phrase_num"], b["phrase_length"], b["phrase_syn"],
+                             b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"])
+    loss_ref, _ = O.criterion_uic(outs_ref, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])
+    loss_ref.backward()
+    fc = torch.zeros(n_img, 0, device="cuda")
+    outs = model(fc, att.cuda(), b["labels"].cuda(), masks.cuda(), b["phrase_num"], b["phrase_length"], b["phrase_syn"],
+                 b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"], -1.0)
+    for i, (o, r) in enumerate(zip(outs, outs_ref)):
+        # bf16: 6e-2 on the token log-probs of this small model (see test_bf16_logits_within_tolerance_on_every_image); the bound heads'
+        # log-probs span ~17 with the calibrated preset: 1.5 % of their span
+        otol = 1e-4 if dtype == torch.float32 else max(6e-2, 1.5e-2 * float(r.detach().max() - r.detach().min()))
+        assert _maxdiff(o, r) < otol, f"output {i}"
+    loss, _ = xe.criterion_uic(outs, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < (1e-3 if dtype == torch.float32 else 2e-2) * abs(float(loss_ref.detach()))
+    loss.backward()
+    worst = 0.0
+    total = float(torch.cat([t.grad.double().reshape(-1) for t in w.values() if t.grad is not None]).norm())
+    for n, p in model.named_parameters():
+        r = w[n].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        if dtype == torch.float32:
+            assert _maxdiff(p.grad, r) <= 2e-3 * max(1e-3, float(r.abs().max())), n
+        else:                                                  # (the key bias of an attention has a zero gradient in exact arithmetic: floor the scale)
+            rel = abs(float(p.grad.double().norm()) - float(r.double().norm())) / max(float(r.double().norm()), 1e-3 * total)
+            worst = max(worst, rel)
+            assert rel < 5e-2, (n, rel)
+    print("100 regions,", dtype, "worst relative gradient-norm error", worst)

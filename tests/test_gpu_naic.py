@@ -431,3 +431,58 @@ def test_dynamic_batching_with_refinement_rounds(weight_cache, manifest):
     both = eng.decode_naic(torch.cat([a, b]), refine_rounds=2, q1_group=4)
     assert torch.equal(both["seq"][:4], ra["seq"]) and torch.equal(both["seq"][4:], rb["seq"])
     assert torch.equal(both["phrase_length"][:4], ra["phrase_length"]) and torch.equal(both["phrase_length"][4:], rb["phrase_length"])
+
+
+def test_two_layer_bounding_network_dense_pass(weight_cache, manifest):
+    """N_len = 2 (configs/uic_sd_N2.yml): the engine's dense bounding pass against vectors recorded from the reference -- slots and
+    ids bit-exact, log-probs <= 1e-3, eager and graph; through the drop-in module as well; bf16 runs and agrees on most layouts."""
+    import captioning.models as models
+    from boficap_amd.engine import BofiEngine
+    from boficap_amd.hip import BofiHipError
+    m = manifest["tiny_n2"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    g = load_golden("tiny_n2")
+    att = torch.from_numpy(g["att_feats"]).cuda()
+    eng = BofiEngine(cfg, torch.float32, max_batch=16, max_regions=36)
+    eng.load_state_dict(sd)
+    r = None
+    for graph in (False, True, True):
+        r = eng.decode_naic(att, graph=graph, out=r if graph and r is not None and graph else None)
+        torch.cuda.synchronize()
+        assert (r["phrase_num"].cpu().numpy() == g["naic_phrase_num"]).all() and (r["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all()
+        assert (r["phrase_syn"].cpu().numpy() == g["naic_phrase_syn"]).all() and (r["seq"].cpu().numpy() == g["naic_seq"]).all()
+        assert int(r["bound_iters"]) == int(g["naic_iters"])
+        assert _close(r["seq_logprob"].cpu().numpy(), g["naic_logprob"], 0) < 1e-3
+    with pytest.raises(BofiHipError):
+        eng.decode_saic(att)                                   # the semi-autoregressive decode is built for N_len = 1
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    with torch.no_grad():
+        seq = model(torch.zeros(att.size(0), 0, device="cuda"), att, None, opt={"train_mode": "NAIC"}, mode="sample")[0]
+    assert (seq.cpu().numpy() == g["naic_seq"]).all()
+    b16 = BofiEngine(cfg, torch.bfloat16, max_batch=16, max_regions=36)
+    b16.load_state_dict(sd)
+    rb = b16.decode_naic(att.to(torch.bfloat16))
+    same = (rb["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all(1)
+    assert same.sum() >= len(same) - 2 and not rb["seq_logprob"].isnan().any()
+
+
+def test_dense_bounding_pass_equals_incremental_form(weight_cache, manifest, monkeypatch):
+    """BOFI_BOUND_DENSE=1 makes a one-layer model take the dense bounding pass (all rows through the layer every iteration, as
+    the reference computes it): same slots, ids and log-probs as the goldens -- a cross-check of the row-0-only incremental form,
+    of the key-prefix bookkeeping and of quirk Q4's exactness claim."""
+    from boficap_amd.engine import BofiEngine
+    monkeypatch.setenv("BOFI_BOUND_DENSE", "1")
+    for name in ("tiny_mix", "tiny_q1_last_shortest", "tiny_ragged"):
+        m = manifest[name]
+        cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+        g = load_golden(name)
+        att, att_len = _inputs(g)
+        eng = BofiEngine(cfg, torch.float32, max_batch=16, max_regions=36)
+        eng.load_state_dict(sd)
+        r = eng.decode_naic(att, att_len)
+        torch.cuda.synchronize()
+        assert (r["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all() and (r["phrase_syn"].cpu().numpy() == g["naic_phrase_syn"]).all(), name
+        assert (r["seq"].cpu().numpy() == g["naic_seq"]).all() and int(r["bound_iters"]) == int(g["naic_iters"])
+        assert _close(r["seq_logprob"].cpu().numpy(), g["naic_logprob"], 0) < 1e-3

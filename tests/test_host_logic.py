@@ -13,7 +13,10 @@ from boficap_amd.config import FULL, TINY, BofiConfig
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("cfg,key", [(TINY, "schema_TINY"), (FULL, "schema_FULL")])
+from boficap_amd.config import TINY_N2
+
+
+@pytest.mark.parametrize("cfg,key", [(TINY, "schema_TINY"), (FULL, "schema_FULL"), (TINY_N2, "schema_TINY_N2")])
 def test_schema_matches_reference_state_dict(cfg, key, manifest):
     """manifest[schema_*] was recorded from the reference model's state_dict() (oracle/make_golden.py)."""
     ours = [[k, list(s)] for k, s in W.schema(cfg).items()]

@@ -200,3 +200,17 @@ def test_oracle_xe_full_size(manifest, weight_cache):
             assert _close(o.gather(2, real.unsqueeze(2)).squeeze(2).numpy(), g[f"out{i}_picked"], 2e-5), i
     loss, parts = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
     assert abs(float(loss) - float(g["losses"][0])) < 1e-4 * float(g["losses"][0])
+
+
+def test_oracle_two_layer_bounding_network(manifest, weight_cache):
+    """configs/uic_sd_N2.yml's shape (N_len = 2) at the small size: the oracle's generic bound stack against the reference."""
+    m = manifest["tiny_n2"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    assert cfg.N_len == 2 and max(m["phrase_num"]) >= 8
+    w = O.as_torch(sd)
+    g = load_golden("tiny_n2")
+    att = torch.from_numpy(g["att_feats"])
+    seq, lp, pn, pl, ps, _ = O.sample_naic(w, cfg, att, None)
+    assert (seq.numpy() == g["naic_seq"]).all() and (pn.numpy() == g["naic_phrase_num"]).all()
+    assert (pl.numpy() == g["naic_phrase_length"]).all() and (ps.numpy() == g["naic_phrase_syn"]).all()
+    assert _close(lp.numpy(), g["naic_logprob"], 1e-5)
