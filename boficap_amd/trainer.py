@@ -262,6 +262,7 @@ class XETrainer:
         self.m = torch.zeros_like(self.bucket.flat)
         self.v = torch.zeros_like(self.bucket.flat)
         self._step = 0
+        self.rl_kl = bool(g("rl_kl", False))                   # self-critical step: + KL(SAIC || NAIC) over the SAIC captions' tokens (loss_wrapper.py:216-222)
         self.dp_chunks = int(g("bofi_dp_chunks", 4))           # collectives per step over the live gradient prefix
         self.dp_wire = g("bofi_dp_wire", None)                 # None: float32 all-reduce; 'bf16': mesh-direct bf16 exchange, fp32 accumulation
         self.graph = bool(graph)
@@ -582,6 +583,8 @@ class XETrainer:
             l1, r1 = xe.new_self_critical(lp_saic, b["seq_saic"], b["sc_saic"], sample_n)
             l2, r2 = xe.new_self_critical(lp_naic, b["seq_naic"], b["sc_naic"], sample_n)
             loss = l1 + l2
+            if self.rl_kl:
+                loss = loss + xe.rl_kl_term(lp_naic, lp_saic, b["seq_saic"])
             loss.backward()
             xe.flush_weight_grads()
         finally:
@@ -594,7 +597,7 @@ class XETrainer:
     def _rl_replay(self, b, sample_n):
         """The gradient pass of the self-critical step as one hipGraph per input signature (shapes are fixed by images x samples)."""
         keys = sorted(b)
-        key = ("rl", tuple((k, tuple(b[k].shape), b[k].dtype) for k in keys), sample_n, self.model.training, self.model.train_dtype)
+        key = ("rl", tuple((k, tuple(b[k].shape), b[k].dtype) for k in keys), sample_n, self.model.training, self.model.train_dtype, self.rl_kl)
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
             return self._rl_forward_backward(b, None, sample_n)
