@@ -546,7 +546,8 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine and C == 1:
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_decode")
+                tj = json.load(f)
+                traffic = tj.get("hbm_bytes_per_decode", tj.get("hbm_bytes_per_step"))
             tnote = (f"HBM-side bytes per decode, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, one-at-a-time run "
                      f"(profiles/{name}); algorithmic minimum = 9.4 MB features + 125 MB weights + 48.6 MB log-probs")
             break
