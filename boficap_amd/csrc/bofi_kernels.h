@@ -66,6 +66,32 @@ struct AttnArgs {
     int q_rows;                   // > 0 with q_start: rows of the q / out buffers; the bf16 kernels clear the rows behind the last item
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
+
+// bound_ops.hip: the row-0 stages of a bounding iteration for at most 64 images (bf16, d_model 512)
+struct BoundQAttnArgs {
+    const uint16_t* x;            // y1 in bf16 [B][d]
+    const float* stats;           // its row partial sums [B][d/32][2]
+    const uint16_t* wq; const float* bias; const float* colsum;     // Wq_src with sublayer[1].norm folded in (Lin of engine.hip)
+    const uint16_t* k; const uint16_t* v; int ldkv;                  // cross-attention K and V rows [B*R][ldkv]
+    const int* att_len;           // regions per image (NULL: R each)
+    uint16_t* out;                // attention output [B][d] (heads concatenated)
+    int B, R, d, H;
+    const int* skip_if_ge; int skip_threshold;
+};
+int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st);
+struct RowGemmArgs {
+    const uint16_t* x; int ldx;   // [M][K] bf16
+    const uint16_t* w;            // [N][K] bf16
+    const float* bias;
+    const float* stats; int stats_groups; const float* colsum;     // LayerNorm fold on x: [M][stats_groups][2] partial sums of the fp32 rows
+    const float* residual; int ldr;
+    float* y; int ldy;            // float32 output (split-K: `splitk` partial slabs [splitk][M][ldy], bias and residual in slab 0)
+    uint16_t* yb; int ldyb;       // bf16 output / copy
+    float* stats_out;             // [M][N/16][2] partial sums of the output rows
+    int M, N, K, splitk, relu;
+    const int* skip_if_ge; int skip_threshold;
+};
+int launch_rowgemm(const RowGemmArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,

@@ -1,0 +1,256 @@
+// Row-0 stages of one bounding iteration (LengthPredictor_UIC: DecoderLayer_UIC.sublayer[1], sublayer[2] of the reference,
+// TransformerModel.py:283-297) for a batch of at most 64 images, bf16 engine, d_model = 512.
+//
+// At most 64 activation rows: the LDS-DMA GEMM of gemm_glds.hip spends its time in ring fill, barriers and the staged
+// epilogue (≈5.3 us per launch inside a graph against a ≈3.8 us floor of any load-compute-store kernel).  Here nothing is
+// staged: both MFMA operands of v_mfma_f32_16x16x32_bf16 are loaded straight from global memory into the fragment layout
+// (A row / B column = lane & 15, eight consecutive k per lane quarter = one 16-byte load), every load of a wavefront is in
+// flight before the first MFMA, the four wavefronts of a workgroup split K and meet once in LDS, and the epilogue runs from
+// the accumulator layout (lane = image, four consecutive output columns).
+//
+//   bound_qattn_kernel   q = Wq_src . LN(y1) for one head and 8 images, then that head's cross-attention of the 8 query rows
+//                        over the image's regions: scores by lane = key, softmax in the wavefront, P.V by lane = (8-column
+//                        chunk, key subset).  Replaces one GEMM launch and one attention launch.
+//   rowgemm_kernel       y[M<=64][N] = epilogue(x . W^T): LayerNorm fold on the input rows, bias, ReLU, float32 residual,
+//                        bf16 copy, per-16-column row statistics for the next fold, split-K partial slabs.
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t rg_u32x4;
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// row mean and 1 / (std + eps) (unbiased std, eps = 1e-6: LayerNorm of TransformerModel.py:223-233) from `ng` partial (sum, sumsq)
+__device__ __forceinline__ void row_norm(const float* stats, int ng, int d, float& mean, float& rstd) {
+    const float4* sp = reinterpret_cast<const float4*>(stats);
+    float sm = 0.f, sq = 0.f;
+    for (int i = 0; i < (ng >> 1); ++i) { const float4 t = sp[i]; sm += t.x + t.z; sq += t.y + t.w; }
+    mean = sm / (float)d;
+    const float var = fmaxf((sq - sm * mean) / (float)(d - 1), 0.f);
+    rstd = 1.0f / (sqrtf(var) + 1e-6f);
+}
+
+__global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
+    constexpr int D = 512, DK = 64, G = 8;
+    __shared__ float4 red[4][4][64];          // [k quarter][16-column tile of the head][lane]
+    __shared__ float qs[G][DK];
+    __shared__ float ps[4][2][64];
+    __shared__ float s_mean[G], s_rstd[G];
+    if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int h = blockIdx.x, b0 = blockIdx.y * G, R = a.R;
+
+    // ---- every load of the kernel is issued here, in the order of use (vmcnt retires in order): GEMM operands, K rows
+    // (lane = key), V chunks (lane = chunk, key subset)
+    const int cch = (lane & 8) ? 7 - (lane & 7) : (lane & 7);          // row_mirror partners (l, 15 - l) hold the same chunk
+    const int js = ((lane >> 4) << 1) | ((lane >> 3) & 1);
+    bf16x8 fw[4][4], fx[4];
+    {
+        const int kq = wave * 128 + q * 8;
+        const bf16_t* xp = a.x + (size_t)min(b0 + (r & 7), a.B - 1) * D + kq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fx[s] = ld_frag(xp + s * 32);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const bf16_t* wp = a.wq + (size_t)(h * DK + nt * 16 + r) * D + kq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fw[nt][s] = ld_frag(wp + s * 32);
+        }
+    }
+    if (tid < G) {
+        float mean, rstd;
+        row_norm(a.stats + (size_t)min(b0 + tid, a.B - 1) * (D / 32) * 2, D / 32, D, mean, rstd);
+        s_mean[tid] = mean; s_rstd[tid] = rstd;
+    }
+    const int idx0 = tid * 2;                       // the two q values this thread finalises: image idx >> 6, column idx & 63
+    const float2 cs2 = *reinterpret_cast<const float2*>(a.colsum + h * DK + (idx0 & 63));
+    const float2 bs2 = *reinterpret_cast<const float2*>(a.bias + h * DK + (idx0 & 63));
+    int kl[2], bimg[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { bimg[u] = min(b0 + 2 * wave + u, a.B - 1); kl[u] = a.att_len ? max(0, min(a.att_len[bimg[u]], R)) : R; }
+
+    rg_u32x4 kk[2][8], vv[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const bf16_t* kp = a.k + ((size_t)bimg[u] * R + min(lane, R - 1)) * a.ldkv + h * DK;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kk[u][c] = reinterpret_cast<const rg_u32x4*>(kp)[c];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = min(js + 8 * t, R - 1);         // keys past R: the last row again, weighted 0 below
+            vv[u][t] = *reinterpret_cast<const rg_u32x4*>(a.v + ((size_t)bimg[u] * R + j) * a.ldkv + h * DK + cch * 8);
+        }
+    // ---- q = Wq . x over this wavefront's K quarter
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt][s], fx[s], acc[nt], 0, 0, 0);
+        red[wave][nt][lane] = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+    }
+    __syncthreads();
+    {
+        const int i = idx0 >> 6, n = idx0 & 63, nt = n >> 4, rr = n & 15, src = (rr >> 2) * 16 + i, comp = rr & 3;   // comp is 0 or 2
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* p = reinterpret_cast<const float*>(&red[w][nt][src]) + comp;
+            v0 += p[0]; v1 += p[1];
+        }
+        const float mu = s_mean[i], rs = s_rstd[i];
+        qs[i][n] = rs * (v0 - mu * cs2.x) + bs2.x;
+        qs[i][n + 1] = rs * (v1 - mu * cs2.y) + bs2.y;
+    }
+    __syncthreads();
+
+    // ---- attention of this wavefront's two images
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = 2 * wave + u;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 qa = *reinterpret_cast<const float4*>(&qs[i][c * 8]);
+            const float4 qb = *reinterpret_cast<const float4*>(&qs[i][c * 8 + 4]);
+            const rg_u32x4 kv = kk[u][c];
+            s += qa.x * bf_lo(kv[0]) + qa.y * bf_hi(kv[0]) + qa.z * bf_lo(kv[1]) + qa.w * bf_hi(kv[1]);
+            s += qb.x * bf_lo(kv[2]) + qb.y * bf_hi(kv[2]) + qb.z * bf_lo(kv[3]) + qb.w * bf_hi(kv[3]);
+        }
+        s *= 0.125f;                                      // / sqrt(d_k), d_k = 64
+        const bool live = lane < kl[u];
+        const float m = wave_max(live ? s : -INFINITY);
+        const float e = live ? expf(s - m) : 0.f;
+        const float sum = wave_sum(e);
+        float p = e / sum;                                // no visible region: NaN, as softmax over an all-masked row of -inf
+        ps[wave][u][lane] = p;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float p = ps[wave][u][js + 8 * t];       // 0 from the key count on (NaN everywhere for an image without regions)
+            const rg_u32x4 v = vv[u][t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[2 * e] += p * bf_lo(v[e]); o[2 * e + 1] += p * bf_hi(v[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = o[e];
+            v += dpp_f32<DPP_MIRROR>(v);
+            o[e] = xor32_sum(xor16_sum(v));
+        }
+        if (lane < 8 && b0 + 2 * wave + u < a.B) {
+            rg_u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f32_to_bf16(o[2 * e]) | ((uint32_t)f32_to_bf16(o[2 * e + 1]) << 16);
+            *reinterpret_cast<rg_u32x4*>(a.out + (size_t)(b0 + 2 * wave + u) * D + h * DK + cch * 8) = w;
+        }
+    }
+}
+
+int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st) {
+    if (a.d != 512 || a.H != 8 || a.R < 1 || a.R > 64 || a.B < 1 || a.ldkv % 8 || !a.x || !a.stats || !a.wq || !a.bias || !a.colsum ||
+        !a.k || !a.v || !a.out)
+        return BOFI_ERR_ARG;
+    hipLaunchKernelGGL(bound_qattn_kernel, dim3(a.H, (a.B + 7) / 8), dim3(256), 0, st, a);
+    (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.B * a.d * a.d;
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// y = epilogue(x . W^T) for M <= 64 rows; one workgroup per 16 output columns and K slice of 512 (blockIdx.y), its four wavefronts
+// take 128 k each.
+__global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
+    __shared__ float4 red[4][4][64];          // [k quarter][16-row group][lane]
+    if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, ks = blockIdx.y, ng = (a.M + 15) >> 4;
+    const int kq = ks * 512 + wave * 128 + q * 8;
+
+    bf16x8 fw[4], fx[4][4];
+    {
+        const bf16_t* wp = a.w + (size_t)(n0 + r) * a.K + kq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fw[s] = ld_frag(wp + s * 32);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (g < ng) {
+            const bf16_t* xp = a.x + (size_t)min(g * 16 + r, a.M - 1) * a.ldx + kq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fx[g][s] = ld_frag(xp + s * 32);
+        }
+    // epilogue operands of the row group this wavefront finalises (wave = group): image m, columns n .. n + 3
+    const int m = wave * 16 + r, n = n0 + q * 4;
+    const bool mine = wave < ng, rowok = m < a.M;
+    const int mc = min(m, a.M - 1);
+    float mean = 0.f, rstd = 1.f;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), bv = cs, rv = cs;
+    if (mine) {
+        if (a.stats) {
+            row_norm(a.stats + (size_t)mc * a.stats_groups * 2, a.stats_groups, a.K, mean, rstd);
+            cs = *reinterpret_cast<const float4*>(a.colsum + n);
+        }
+        if (ks == 0) {
+            bv = *reinterpret_cast<const float4*>(a.bias + n);
+            if (a.residual) rv = *reinterpret_cast<const float4*>(a.residual + (size_t)mc * a.ldr + n);
+        }
+    }
+
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (g < ng) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s], fx[g][s], acc, 0, 0, 0);
+            red[wave][g][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    __syncthreads();
+    if (!mine) return;
+    float4 v = red[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { const float4 t = red[w][wave][lane]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (a.stats) { v.x = rstd * (v.x - mean * cs.x); v.y = rstd * (v.y - mean * cs.y); v.z = rstd * (v.z - mean * cs.z); v.w = rstd * (v.w - mean * cs.w); }
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    if (a.stats_out) {                        // partial sums over the workgroup's 16 columns: lanes l, l ^ 16, l ^ 32, l ^ 48
+        const float psum = xor32_sum(xor16_sum((v.x + v.y) + (v.z + v.w)));
+        const float psq = xor32_sum(xor16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)));
+        if (q == 0 && rowok) reinterpret_cast<float2*>(a.stats_out)[(size_t)m * (a.N >> 4) + (n0 >> 4)] = make_float2(psum, psq);
+    }
+    if (!rowok) return;
+    if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)ks * a.M + m) * a.ldy + n) = v;
+    if (a.yb) {
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(a.yb + (size_t)m * a.ldyb + n) = o;
+    }
+}
+
+int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
+    const int splitk = a.splitk > 1 ? a.splitk : 1;
+    if (a.M < 1 || a.M > 64 || a.N % 16 || a.K != 512 * splitk || a.ldx % 8 || !a.x || !a.w || !a.bias || (!a.y && !a.yb)) return BOFI_ERR_ARG;
+    if (a.stats && (!a.colsum || a.stats_groups % 2 || splitk > 1)) return BOFI_ERR_ARG;
+    if (splitk > 1 && (a.relu || a.stats_out || a.yb || !a.y)) return BOFI_ERR_ARG;
+    if ((a.y && a.ldy % 4) || (a.yb && a.ldyb % 4) || (a.residual && a.ldr % 4)) return BOFI_ERR_ARG;
+    hipLaunchKernelGGL(rowgemm_kernel, dim3(a.N / 16, splitk), dim3(256), 0, st, a);
+    (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+}  // namespace bofi

@@ -90,6 +90,7 @@ struct bofi_engine {
     void* feats_t = nullptr;                                          // bf16 copy of float32 input features
     void *xb_enc = nullptr, *xb_fill = nullptr, *byb = nullptr;       // compute-dtype copies of the residual streams
     float *st_enc = nullptr, *st_fill = nullptr, *st_b = nullptr;     // row partial sums [rows][d/32][2]
+    float* st_b16 = nullptr;                                          // row partial sums per 16 columns [Bm][d/16][2] (bound_ops.hip)
     float *by1 = nullptr, *by2 = nullptr, *by3 = nullptr;
     void *bctx = nullptr, *bq2 = nullptr, *bctx2 = nullptr, *bh = nullptr;
     bofi::BoundState st{};
@@ -251,7 +252,7 @@ struct bofi_engine {
     ENG_OK(dalloc((char**)&byb, Bm * d, tsz));
     if (c.dtype == BOFI_DT_BF16) ENG_OK(dalloc((char**)&feats_t, Bm * Rm * (size_t)c.feat, 2));
     ENG_OK(dalloc(&st_enc, Bm * Rm * (d / 32) * 2)); ENG_OK(dalloc(&st_fill, Bm * Sq * (d / 32) * 2));
-    ENG_OK(dalloc(&st_b, Bm * (d / 32) * 2));
+    ENG_OK(dalloc(&st_b, Bm * (d / 32) * 2)); ENG_OK(dalloc(&st_b16, Bm * (d / 16) * 2));
     ENG_OK(dalloc(&by1, Bm * d)); ENG_OK(dalloc(&by2, Bm * d)); ENG_OK(dalloc(&by3, 4 * Bm * d));
     ENG_OK(dalloc((char**)&bctx, Bm * d, tsz)); ENG_OK(dalloc((char**)&bq2, Bm * d, tsz));
     ENG_OK(dalloc((char**)&bctx2, Bm * d, tsz)); ENG_OK(dalloc((char**)&bh, Bm * dff, tsz));
@@ -344,6 +345,34 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     cur_B = B;
     static const int dbg = [] { const char* v = getenv("BOFI_DBG_TAIL_ONLY"); return v ? atoi(v) : 0; }();     // developer knob: bit 0 on -> run only the stages whose bits (2,4,8,16,32) are set
     const bool all = !(dbg & 1);
+    // at most 64 images in bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
+    static const bool lean_on = [] { const char* v = getenv("BOFI_BOUND_LEAN"); return !v || atoi(v) != 0; }();
+    if (all && lean_on && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && B <= 64 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4) {
+        const int* skip = early ? st.counters : nullptr;
+        {   bofi::BoundQAttnArgs a{};
+            a.x = (const uint16_t*)byb; a.stats = st_b; a.wq = (const uint16_t*)b_q_src.w; a.bias = b_q_src.b; a.colsum = b_q_src.cs;
+            a.k = (const uint16_t*)kv; a.v = (const uint16_t*)kv + d; a.ldkv = kv_all.N; a.att_len = att_len; a.out = (uint16_t*)bctx2;
+            a.B = B; a.R = R; a.d = d; a.H = cfg.heads; a.skip_if_ge = skip; a.skip_threshold = B;
+            ENG_OK(bofi::launch_bound_qattn(a, s)); }
+        {   bofi::RowGemmArgs a{};                   // y2 = y1 + Wo_src . ctx2 + bo
+            a.x = (const uint16_t*)bctx2; a.ldx = d; a.w = (const uint16_t*)b_o_src.w; a.bias = b_o_src.b; a.residual = by1; a.ldr = d;
+            a.y = by2; a.ldy = d; a.yb = (uint16_t*)byb; a.ldyb = d; a.stats_out = st_b16; a.M = B; a.N = d; a.K = d; a.splitk = 1;
+            a.skip_if_ge = skip; a.skip_threshold = B;
+            ENG_OK(bofi::launch_rowgemm(a, s)); }
+        {   bofi::RowGemmArgs a{};                   // h = relu(W1 . LN(y2) + b1)
+            a.x = (const uint16_t*)byb; a.ldx = d; a.w = (const uint16_t*)b_w1.w; a.bias = b_w1.b; a.stats = st_b16; a.stats_groups = d / 16;
+            a.colsum = b_w1.cs; a.yb = (uint16_t*)bh; a.ldyb = cfg.d_ff; a.M = B; a.N = cfg.d_ff; a.K = d; a.splitk = 1; a.relu = 1;
+            a.skip_if_ge = skip; a.skip_threshold = B;
+            ENG_OK(bofi::launch_rowgemm(a, s)); }
+        const int parts = cfg.d_ff / 512;
+        {   bofi::RowGemmArgs a{};                   // y3 = y2 + W2 . h + b2 as `parts` partial slabs
+            a.x = (const uint16_t*)bh; a.ldx = cfg.d_ff; a.w = (const uint16_t*)b_w2.w; a.bias = b_w2.b; a.residual = by2; a.ldr = d;
+            a.y = by3; a.ldy = d; a.M = B; a.N = d; a.K = cfg.d_ff; a.splitk = parts;
+            a.skip_if_ge = skip; a.skip_threshold = B;
+            ENG_OK(bofi::launch_rowgemm(a, s)); }
+        const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
+        return bound_tail(by3, parts, update ? nullptr : ext_syn, update ? nullptr : last, B, flags, len_logp, syn_logp, s);
+    }
     if (all || (dbg & 2)) { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
     if (all || (dbg & 4)) {
     bofi::AttnArgs a{};

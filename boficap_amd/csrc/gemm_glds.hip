@@ -370,6 +370,20 @@ static bool launch_specialised(const Gemm2Params& p, int bm, int bn, int ns, int
     if (bm == 128 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 128, 64, 2, 4, 2, FEAT>(p, st); return true; }
     if (bm == 64 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 64, 64, 2, 4, 2, FEAT>(p, st); return true; }
     if (bm == 64 && bn == 32 && ns == 4 && nw == 4) { launch_one<T, 64, 32, 4, 2, 2, FEAT>(p, st); return true; }
+    if constexpr (sizeof(T) == 2 && FEAT < 3) {      // deeper rings / larger tiles for the encoder and fill GEMMs (one workgroup per CU)
+        if (nw == 8) {
+            if (bm == 64 && bn == 64 && ns == 4) { launch_one<T, 64, 64, 4, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 64 && bn == 64 && ns == 6) { launch_one<T, 64, 64, 6, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 64 && bn == 64 && ns == 9) { launch_one<T, 64, 64, 9, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 128 && bn == 64 && ns == 4) { launch_one<T, 128, 64, 4, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 128 && bn == 64 && ns == 6) { launch_one<T, 128, 64, 6, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 128 && bn == 128 && ns == 3) { launch_one<T, 128, 128, 3, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 128 && bn == 128 && ns == 4) { launch_one<T, 128, 128, 4, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 64 && bn == 128 && ns == 4) { launch_one<T, 64, 128, 4, 2, 4, FEAT>(p, st); return true; }
+            if (bm == 64 && bn == 128 && ns == 6) { launch_one<T, 64, 128, 6, 2, 4, FEAT>(p, st); return true; }
+            if (bm == 256 && bn == 128 && ns == 3) { launch_one<T, 256, 128, 3, 4, 2, FEAT>(p, st); return true; }
+        }
+    }
     if constexpr (sizeof(T) == 2) {      // M <= 64, K <= 512 per slice: all 8 slabs of the K extent in flight at once (108 / 90 KB of LDS)
         if (bm == 64 && bn == 32 && ns == 9 && nw == 4) { launch_one<T, 64, 32, 9, 2, 2, FEAT>(p, st); return true; }
         if (bm == 64 && bn == 16 && ns == 9 && nw == 2) { launch_one<T, 64, 16, 9, 2, 1, FEAT>(p, st); return true; }
@@ -382,11 +396,16 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     // developer override: BOFI_GEMM_TILE=<BM>x<BN>x<NS>
     int bm = 0, bn = 0, ns = 0;
     int nw = 4;
+    const int feat = (p.ln_stats ? 1 : 0) | ((p.stats_out || p.y2) ? 2 : 0) | (p.row_len ? 4 : 0) | (p.drop_thresh ? 8 : 0) |
+                     ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0);
     if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%dx%d", &bm, &bn, &ns, &nw); }
     if (!bm) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
         // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop
         const long t = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+        static const int heur2 = [] { const char* v = getenv("BOFI_GEMM_HEUR2"); return v ? atoi(v) : 1; }();
+        // 128-row tiles from 200 tiles on (round 2: the fill pass's qkv and w_1 at M = 1280 gain 15-25 % with four decodes in flight)
+        const long thr = heur2 ? 200 : 400;
         if (p.M <= 64) {
             bm = 64; bn = 32; ns = 4;
             // the bounding loop's GEMMs (64 rows, K = 512 per slice) are latency chains: one L2 round trip per slab with a 4-deep
@@ -398,12 +417,14 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
                 if (!(p.stats_out || p.y2) && p.vec_ok && p.N % 16 == 0) { bn = 16; nw = 2; }
             }
         }
-        else if (t >= 400) { bm = 128; bn = 64; ns = 2; nw = 8; }
+        else if (t >= thr) { bm = 128; bn = 64; ns = 2; nw = 8; }
         else { bm = 64; bn = 64; ns = 2; nw = 8; }          // 8 waves of 16x32 / 32x32: more waves per CU hide the slab latency
+        // long K on few tiles (FFN w_2, att_embed: N = 512, K = 2048): the loop is a chain of slab round trips, three slabs in
+        // flight instead of one (measured round 2, tools/mb_tiles2.py / mb_tiles3.py: 17.4 -> 11.6 us alone, 10.0 -> 7.6 us with
+        // four in flight at M = 1280; 18.3 -> 15.2 us alone at M = 2304)
+        if (heur2 && sizeof(T) == 2 && bm == 64 && bn == 64 && p.M > 64 && p.splitk == 1 && p.K >= 1024 && (feat < 3 || feat == 6)) ns = 4;
     }
     {
-        const int feat = (p.ln_stats ? 1 : 0) | ((p.stats_out || p.y2) ? 2 : 0) | (p.row_len ? 4 : 0) | (p.drop_thresh ? 8 : 0) |
-                         ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0);
         bool done = false;
         switch (feat) {
             case 0: done = launch_specialised<T, 0>(p, bm, bn, ns, nw, st); break;          // plain: bias / ReLU / residual
@@ -423,6 +444,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     switch (key) {
         case 100640642: launch_one<T, 64, 64, 2, 4, 2>(p, st); break;
         case 100640643: launch_one<T, 64, 64, 3, 4, 2>(p, st); break;
+        case 100640644: launch_one<T, 64, 64, 4, 4, 2>(p, st); break;
         case 101280643: launch_one<T, 128, 64, 3, 4, 2>(p, st); break;
         case 201281282: launch_one<T, 128, 128, 2, 4, 4>(p, st); break;    // 16 waves
         case 101281282: launch_one<T, 128, 128, 2, 4, 2>(p, st); break;     // 8 waves
