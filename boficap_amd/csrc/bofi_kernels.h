@@ -39,6 +39,9 @@ struct LinearArgs {
     // training backward through relu (+ dropout): != 0 turns `residual` into a MASK -- y = residual > 0 ? (x w^T) * mask_scale : 0
     // (residual = the forward activation: a dropped or clipped unit is 0 there; mask_scale = 1 / (1 - p))
     float mask_scale;
+    // row list (LDS-DMA kernel only): the GEMM covers rows row_idx[0 .. *m_dev) of x (both device memory; M is the capacity) and writes
+    // the same rows of y / y2 / stats_out; residual and ln_stats are read at those rows too
+    const int* row_idx; const int* m_dev;
 };
 int launch_linear(const LinearArgs& a, hipStream_t st);
 extern double g_gemm_flops, g_gemm_flops_skippable;   // GEMM FLOPs enqueued since the last reset (host-side tally; gemm.hip)
@@ -95,7 +98,8 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
-                          int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr);
+                          int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr,
+                          const int* row_idx = nullptr, const int* n_rows = nullptr);     // row list: rows row_idx[0 .. *n_rows) only
 
 // ---- device-side weight repack (repack.hip)
 struct PackLinArgs {
@@ -109,6 +113,8 @@ int launch_bound_table(const float* lut_syn, const float* lut_tok, const float* 
                        hipStream_t st);
 
 int launch_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok, int pad_idx,
-                        int64_t* out, hipStream_t st, const int* halt = nullptr);
+                        int64_t* out, hipStream_t st, const int* halt = nullptr, const int* row_idx = nullptr, const int* n_rows = nullptr,
+                        const uint64_t* seed_dev = nullptr);      // seed_dev: device word added to `seed` (so that a captured launch can draw anew)
+int launch_set_u64(uint64_t* p, uint64_t v, hipStream_t s);
 
 }  // namespace bofi

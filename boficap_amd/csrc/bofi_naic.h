@@ -76,6 +76,8 @@ int launch_saic_init(const BoundState& st, const SaicState& sa, int B, int L, in
 // after the decoder pass of iteration `iter`: copy the new phrase's tokens / log-probs (TransformerModel.py:1968-1977), set halt
 int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* tok, const float* logp, float* seq_logprob, int B, int L,
                      int S, int V, int iter, hipStream_t s);
+// decoder rows of the phrases placed in iteration `iter` (image-major), and their count
+int launch_saic_rows(const BoundState& st, int B, int L, int S, int iter, int* rows, int* n_rows, hipStream_t s);
 int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, int S, int64_t* seq, int* phrase_num,
                        int* phrase_length, int64_t* phrase_syn, int* iters, hipStream_t s);
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,

@@ -98,6 +98,10 @@ struct bofi_engine {
     float* xw = nullptr; void* xwb = nullptr; float* st_w = nullptr;   // SAIC bound input rows [B*L, d] (+copy, +stats)
     void* kvs = nullptr;                                                // their K|V [B*L, 2d]
     int64_t* tok64 = nullptr;                                           // greedy ids of one decoder pass [B*S]
+    std::vector<void*> qkv_dec;                                         // SAIC: q|k|v of every decoder layer [B*S, 3d] (the K / V cache)
+    int *sa_rows = nullptr, *sa_nrows = nullptr;                        // decoder rows of the iteration's new phrases, their count
+    uint64_t* d_seed = nullptr;                                         // per-call sampling seed (read by the captured sampling kernels)
+    bool saic_cache = true;
     Lin b_kv_self;                                                      // bound self-attention K|V with sublayer.0.norm folded in
     Lin t_kvself, t_qself; float* d_xt = nullptr; Norm head_norm;       // setup-time operands of the bound tables, kept for refreshes
     std::vector<LinRecipe> lin_recipes; std::vector<NormRecipe> norm_recipes;
@@ -205,6 +209,7 @@ struct bofi_engine {
         const float* ln_stats = nullptr;     // LayerNorm folded into the GEMM (Lin built with fold_norm)
         float* stats_out = nullptr;          // emit row partial sums of the output
         void* y2 = nullptr;                  // compute-dtype copy of the output
+        const int* row_idx = nullptr; const int* m_dev = nullptr;     // row list (LinearArgs)
     };
     int linear(const void* x, int x_dtype, int ldx, const Lin& l, void* y, int y_dtype, int ldy, int M, const LinOpt& o, hipStream_t s) {
         if (o.ln) {
@@ -219,7 +224,7 @@ struct bofi_engine {
         a.residual = o.residual; a.ldr = o.ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy;
         a.M = M; a.N = l.N; a.K = l.K; a.relu = o.relu; a.row_len = o.row_len; a.rows_per_group = o.rpg;
         a.ln_stats = o.ln_stats; a.ln_colsum = o.ln_stats ? l.cs : nullptr;
-        a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N; a.splitk = o.splitk;
+        a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N; a.splitk = o.splitk; a.row_idx = o.row_idx; a.m_dev = o.m_dev;
         if (o.early) { a.skip_if_ge = st.counters; a.skip_threshold = cur_B; }
         if (o.halt) { a.skip_if_ge = st.counters + 2; a.skip_threshold = 1; }
         return bofi::launch_linear(a, s);
@@ -263,6 +268,8 @@ struct bofi_engine {
     ENG_OK(dalloc(&sa.ext_phrase, Bm * L)); ENG_OK(dalloc(&sa.klen_dec, Bm * L));
     ENG_OK(dalloc(&xw, Bm * L * d)); ENG_OK(dalloc((char**)&xwb, Bm * L * d, tsz)); ENG_OK(dalloc(&st_w, Bm * L * (d / 32) * 2));
     ENG_OK(dalloc((char**)&kvs, Bm * L * 2 * (size_t)d, tsz)); ENG_OK(dalloc(&tok64, Bm * Sq));
+    ENG_OK(dalloc(&sa_rows, Bm * Sq)); ENG_OK(dalloc(&sa_nrows, 4)); ENG_OK(dalloc(&d_seed, 2));
+    qkv_dec.assign(c.n_dec, nullptr);                  // allocated by the first semi-autoregressive decode
 
         return BOFI_OK;
     }
@@ -509,6 +516,14 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
     const void* xwa = stream_t(xw, xwb);
     const void* xa = stream_t(x_fill, xb_fill);
     for (int it = 1; it <= S; ++it) {
+        // From the second iteration on only the rows of the phrases placed in this iteration go through the decoder's GEMMs and the
+        // vocabulary epilogue (row list; launch_saic_rows): a placed row's input, key set and therefore its K / V in every layer
+        // never change again, later rows are never attended, and only the new phrase's rows are copied out (:1968-1977).  The
+        // first iteration runs every row: it is the only one in which a row without any key (an image that opened no phrase)
+        // can raise the reference's "phrase nan!" return.
+        const bool rowlist = saic_cache && it >= 2;
+        const int* ri = rowlist ? sa_rows : nullptr;
+        const int* rn = rowlist ? sa_nrows : nullptr;
         // ---- bounding step on the words: K|V of all L rows, row-0 query attends keys < phrase_last
         ENG_OK(bofi::launch_embed_rows(lut_tok, nullptr, pe, sa.ext_len, nullptr, L, 0, B, L, d, cfg.bos_idx, xw, copy_t(xwb), dt, st_w, halt, s));
         { LinOpt o; o.halt = true; o.ln_stats = st_w; ENG_OK(linear(xwa, dt, d, b_kv_self, kvs, dt, 2 * d, B * L, o, s)); }
@@ -538,39 +553,68 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
         // ---- decoder pass over all S positions (decode_SA :520-530) with the phrase-block mask as per-row key prefixes
         ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                        st_fill, halt, s));
+        if (rowlist) ENG_OK(bofi::launch_saic_rows(st, B, L, S, it, sa_rows, sa_nrows, s));
         for (size_t li = 0; li < dec.size(); ++li) {
             auto& l = dec[li];
-            { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
+            void* qkv = qkv_dec[li];
+            { LinOpt o; o.halt = true; o.ln_stats = st_fill; o.row_idx = ri; o.m_dev = rn; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
             bofi::AttnArgs a{};
             a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
             a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
             // phrase_mask[:, 1:-1, 1:-1]: row t <- row t+1, one key column dropped
             a.klen = sa.klen_dec + 1; a.klen_sb = L; a.klen_sq = 1; a.klen_bias = -1; a.skip_if_ge = halt; a.skip_threshold = 1;
             ENG_OK(bofi::launch_attention(a, s));
-            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill); o.row_idx = ri; o.m_dev = rn;
               ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s)); }
-            { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
+            { LinOpt o; o.halt = true; o.ln_stats = st_fill; o.row_idx = ri; o.m_dev = rn; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
             bofi::AttnArgs c{};
             c.q = qs; c.ldq = d;
             c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
             c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
             c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0; c.skip_if_ge = halt; c.skip_threshold = 1;
             ENG_OK(bofi::launch_attention(c, s));
-            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill); o.row_idx = ri; o.m_dev = rn;
               ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, BOFI_DT_F32, d, M, o, s)); }
-            { LinOpt o; o.halt = true; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
-            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+            { LinOpt o; o.halt = true; o.relu = 1; o.ln_stats = st_fill; o.row_idx = ri; o.m_dev = rn; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+            { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill); o.row_idx = ri; o.m_dev = rn;
               ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
         }
-        { LinOpt o; o.halt = true; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, logits, BOFI_DT_F32, cfg.vocab, M, o, s)); }
+        { LinOpt o; o.halt = true; o.ln_stats = st_fill; o.row_idx = ri; o.m_dev = rn; ENG_OK(linear(xa, dt, d, gen, logits, BOFI_DT_F32, cfg.vocab, M, o, s)); }
         ENG_OK(bofi::launch_vocab_finalize(logits, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, nullptr, 0, cfg.pad_idx, tok64, s,
-                                           st.counters + 3, halt));
+                                           st.counters + 3, halt, ri, rn));
         if (flags & BOFI_FLAG_SAMPLE)          // sample_next_word 'sample' (CaptionModel.py:405-425): the drawn ids feed the next bound step
-            ENG_OK(bofi::launch_vocab_sample(logits, M, cfg.vocab, S, 1, sample_temperature, sample_seed + (uint64_t)it * 0x9E3779B97F4A7C15ull, nullptr,
-                                             cfg.pad_idx, tok64, s, halt));
+            ENG_OK(bofi::launch_vocab_sample(logits, M, cfg.vocab, S, 1, sample_temperature, (uint64_t)it * 0x9E3779B97F4A7C15ull, nullptr,
+                                             cfg.pad_idx, tok64, s, halt, ri, rn, d_seed));
         ENG_OK(bofi::launch_saic_copy(st, sa, tok64, logits, seq_logprob, B, L, S, cfg.vocab, it, s));
     }
     ENG_OK(bofi::launch_saic_export(st, sa, B, L, S, seq, phrase_num, phrase_length, phrase_syn, bound_iters, s));
+    return BOFI_OK;
+}
+
+// Replays the captured launch sequence stored under `key`, capturing it first (through `enqueue`, on the engine's capture stream)
+// when the key is new.  At most 8 captures are kept per engine.
+template <typename F>
+static int run_graphed(bofi_engine* e, const std::vector<uintptr_t>& key, hipStream_t s, F enqueue) {
+    for (auto& g : e->graphs)
+        if (g.key == key) { ENG_HIP(hipGraphLaunch(g.exec, s)); return BOFI_OK; }
+    GraphEntry g;
+    g.key = key;
+    // the capture stream is created lazily so that the run streams of an engine and its forks are
+    // created back to back (they then land on different hardware queues)
+    if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    ENG_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue(e->cap_stream);
+    hipError_t ee = hipStreamEndCapture(e->cap_stream, &g.graph);
+    if (rc != BOFI_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+    if (ee != hipSuccess) return fail(BOFI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+    ENG_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    if (e->graphs.size() >= 8) {                       // small cache: drop the oldest capture
+        (void)hipGraphExecDestroy(e->graphs.front().exec);
+        (void)hipGraphDestroy(e->graphs.front().graph);
+        e->graphs.erase(e->graphs.begin());
+    }
+    e->graphs.push_back(g);
+    ENG_HIP(hipGraphLaunch(g.exec, s));
     return BOFI_OK;
 }
 
@@ -593,6 +637,7 @@ int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
     e->cfg = *c;
     e->n_len = c->n_len;
     { const char* v = getenv("BOFI_BOUND_DENSE"); e->bound_dense = c->n_len > 1 || (v && atoi(v) != 0); }
+    { const char* v = getenv("BOFI_SAIC_CACHE"); e->saic_cache = !v || atoi(v) != 0; }     // 0: every row through the decoder in every iteration
     e->L = c->seq_length + 2;
     e->tsz = c->dtype == BOFI_DT_F32 ? 4 : 2;
     *out = e;
@@ -951,8 +996,21 @@ int bofi_engine_decode_saic(bofi_engine_t* e, const void* feats, int feats_dtype
     ENG_OK(check_feats(e, feats, feats_dtype));
     if (!seq) return fail(BOFI_ERR_ARG, "null seq");
     if (e->n_len != 1) return fail(BOFI_ERR_STATE, "the semi-autoregressive decode is built for a one-layer bounding network (N_len = 1)");
-    return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
-                                  bound_iters, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    for (auto& q : e->qkv_dec)                              // the per-layer q|k|v buffers of this mode (never inside a capture)
+        if (!q) ENG_OK(e->dalloc((char**)&q, (size_t)e->cfg.max_batch * e->cfg.seq_length * 3 * e->cfg.d_model, e->tsz));
+    if (flags & BOFI_FLAG_SAMPLE) ENG_OK(bofi::launch_set_u64(e->d_seed, e->sample_seed, s));     // outside the graph: fresh draws per call
+    if (!(flags & BOFI_FLAG_GRAPH))
+        return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
+                                      bound_iters, s);
+    uint32_t tbits; std::memcpy(&tbits, &e->sample_temperature, 4);
+    std::vector<uintptr_t> key = {(uintptr_t)1, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
+                                  (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
+                                  (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)bound_iters, (uintptr_t)tbits};
+    return run_graphed(e, key, s, [&](hipStream_t cs) {
+        return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
+                                      bound_iters, cs);
+    });
 }
 
 int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype, const int* att_len, int B, int R, int flags,
@@ -967,32 +1025,14 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, s);
     // graph path: the captured launch sequence is keyed by every argument that is baked into it
-    std::vector<uintptr_t> key = {(uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
+    std::vector<uintptr_t> key = {(uintptr_t)0, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
                                   (uintptr_t)e->q1_group};
-    for (auto& g : e->graphs)
-        if (g.key == key) { ENG_HIP(hipGraphLaunch(g.exec, s)); return BOFI_OK; }
-    GraphEntry g;
-    g.key = key;
-    // the capture stream is created lazily so that the run streams of an engine and its forks are
-    // created back to back (they then land on different hardware queues)
-    if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
-    ENG_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
-                                     phrase_syn, memory_out, bound_iters, e->cap_stream);
-    hipError_t ee = hipStreamEndCapture(e->cap_stream, &g.graph);
-    if (rc != BOFI_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
-    if (ee != hipSuccess) return fail(BOFI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
-    ENG_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-    if (e->graphs.size() >= 8) {                       // small cache: drop the oldest capture
-        (void)hipGraphExecDestroy(e->graphs.front().exec);
-        (void)hipGraphDestroy(e->graphs.front().graph);
-        e->graphs.erase(e->graphs.begin());
-    }
-    e->graphs.push_back(g);
-    ENG_HIP(hipGraphLaunch(g.exec, s));
-    return BOFI_OK;
+    return run_graphed(e, key, s, [&](hipStream_t cs) {
+        return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
+                                 phrase_syn, memory_out, bound_iters, cs);
+    });
 }
 
 }  // extern "C"

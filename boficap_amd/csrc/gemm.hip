@@ -297,7 +297,7 @@ int launch_linear(const LinearArgs& a, hipStream_t st) {
         const int rc = launch_linear_glds(a, st);          // operands already in the compute dtype: LDS-DMA kernel
         if (rc >= 0) return rc;
     }
-    if (a.ln_stats || a.stats_out || a.y2 || a.splitk > 1 || a.drop_thresh || a.mask_scale != 0.f) return BOFI_ERR_ARG;     // only the LDS-DMA kernel implements these
+    if (a.ln_stats || a.stats_out || a.y2 || a.splitk > 1 || a.drop_thresh || a.mask_scale != 0.f || a.row_idx) return BOFI_ERR_ARG;     // only the LDS-DMA kernel implements these
     const bool ln = a.ln_gain != nullptr;
     if (ln && (a.x_dtype != BOFI_DT_F32 || !a.ln_bias || a.K % 8)) return BOFI_ERR_ARG;
     GemmParams p;

@@ -63,6 +63,9 @@ struct Gemm2Params {
     const uint64_t* drop_step;
     float mask_scale;         // != 0: residual is a mask (see LinearArgs)
     int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
+    // row list (FEAT bit 6): the GEMM runs over rows row_idx[0 .. *m_dev) of x and writes the same rows of y / y2 / the statistics
+    // (p.M is the capacity the grid was sized for; tiles past *m_dev return at once)
+    const int* row_idx; const int* m_dev;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -77,9 +80,9 @@ template <int MAXY, int LPS> __device__ __forceinline__ void wait_slabs(int youn
 }
 
 // FEAT: the optional parts of the epilogue / control this instantiation carries (bit 0: folded LayerNorm in, 1: row statistics
-// and compute-dtype copy out, 2: padded-row zeroing, 3: dropout, 4: early-out word and developer ablations, 5: residual-as-mask).  A specialisation
+// and compute-dtype copy out, 2: padded-row zeroing, 3: dropout, 4: early-out word and developer ablations, 5: residual-as-mask, 6: row list).  A specialisation
 // drops the kernel arguments of the parts it does not carry, which is what matters: the full kernel spills scalar registers.
-constexpr int FEAT_ALL = 63;
+constexpr int FEAT_ALL = 127;
 template <typename T, int BM, int BN, int NS, int WM = 2, int WN = 2, int FEAT = FEAT_ALL>     // WM x WN wavefronts, each owns (BM/WM) x (BN/WN)
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) {
     if constexpr (!(FEAT & 1)) { p.ln_stats = nullptr; p.ln_colsum = nullptr; }
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     if constexpr (!(FEAT & 8)) { p.drop_thresh = 0; p.drop_step = nullptr; }
     if constexpr (!(FEAT & 16)) { p.skip_if_ge = nullptr; p.dbg = 0; }
     if constexpr (!(FEAT & 32)) { p.mask_scale = 0.f; }
+    if constexpr (!(FEAT & 64)) { p.row_idx = nullptr; p.m_dev = nullptr; }
     constexpr int NW = WM * WN;
     constexpr int EPC = 16 / sizeof(T);                 // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;                         // one 128-byte slab row
@@ -111,11 +115,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     // its L2 while the weight panel streams; bijective for any tile count.
     const int ntn = (p.N + BN - 1) / BN, ntiles = gridDim.x;
     int tile = blockIdx.x;
-    if (!(p.dbg & 16)) {
+    if (!(p.dbg & 16) && !p.m_dev) {                   // (a row list fills the first row tiles only: plain order spreads them over the XCDs)
         const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    if (p.m_dev) {
+        p.M = min(p.M, *p.m_dev);
+        if (m0 >= p.M) return;
+    }
+    auto row_of = [&](int m) { return p.row_idx ? p.row_idx[m < p.M ? m : p.M - 1] : m; };      // memory row of GEMM row m
 
     // LDS-DMA source pointers: wave-instruction j of this wave covers tile rows (wave*L + j)*8 .. +7;
     // lane i -> row +(i>>3), LDS chunk (i&7) <- global chunk (i&7) ^ (i>>3)   (XOR swizzle on the source)
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     for (int j = 0; j < LA; ++j) {
         int m = m0 + (wave * LA + j) * 8 + lrow;
         m = m < p.M ? m : p.M - 1;                      // clamp: rows past M are computed and dropped
+        m = row_of(m);
         asrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * EPC + (size_t)blockIdx.y * (p.K / p.splitk);
     }
 #pragma unroll
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = bv;
     float4 rv[NR];
     bool live[NR], zero[NR];
+    int mrow_out[NR];                                  // memory row of each of this lane's output rows
     if (p.vec_ok) {
         if (p.bias && ncol_ok) bv = *reinterpret_cast<const float4*>(p.bias + n);
         if (p.ln_stats && ncol_ok) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
@@ -181,7 +192,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
         for (int u = 0; u < NR; ++u) {
             const int r = wave * RPI + lr + u * NW * RPI, m = m0 + r;
             live[u] = m < p.M && ncol_ok;
-            rv[u] = (p.residual && live[u]) ? *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mrow_out[u] = row_of(m);
+            rv[u] = (p.residual && live[u]) ? *reinterpret_cast<const float4*>(p.residual + (size_t)mrow_out[u] * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             zero[u] = false;
             if (p.row_len && live[u]) {
                 const int grp = m / p.rows_per_group;
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
         float sm = 0.f, sq = 0.f;
         if (m < p.M) {
             const int np4 = p.K >> 6;                  // two (sum, sumsq) pairs per 16-byte load
-            const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)m * np4;
+            const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)row_of(m) * np4;
             for (int i = 0; i < np4; ++i) { const float4 t = sp[i]; sm += t.x + t.z; sq += t.y + t.w; }
         }
         const float mean = sm / (float)p.K;
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
                 float pq = live[u] ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
                 ps = oct_sum(ps); pq = oct_sum(pq);
                 if (live[u] && (lane & 7) == 0)
-                    reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 5) + (n >> 5)] = make_float2(ps, pq);
+                    reinterpret_cast<float2*>(p.stats_out)[(size_t)mrow_out[u] * (p.N >> 5) + (n >> 5)] = make_float2(ps, pq);
             }
             if (!live[u]) continue;
             if (p.y2) {
@@ -296,18 +308,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
                     uint2 o;
                     o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
                     o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y2) + (size_t)m * p.ldy2 + n) = o;
+                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y2) + (size_t)mrow_out[u] * p.ldy2 + n) = o;
                 } else {
-                    *reinterpret_cast<float4*>(static_cast<float*>(p.y2) + (size_t)m * p.ldy2 + n) = v;
+                    *reinterpret_cast<float4*>(static_cast<float*>(p.y2) + (size_t)mrow_out[u] * p.ldy2 + n) = v;
                 }
             }
             if (p.y_is_f32) {
-                *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)m * p.ldy + n) = v;
+                *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)mrow_out[u] * p.ldy + n) = v;
             } else if constexpr (sizeof(T) == 2) {
                 uint2 o;
                 o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
                 o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-                *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + (size_t)m * p.ldy + n) = o;
+                *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + (size_t)mrow_out[u] * p.ldy + n) = o;
             }
         }
         return;
@@ -325,9 +337,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     }
     float srv[NRS][NC];
     bool szero[NRS];
+    int smrow[NRS];
 #pragma unroll
     for (int u = 0; u < NRS; ++u) {
         const int m = m0 + wave + NW * u;
+        smrow[u] = row_of(m);
         szero[u] = false;
         if (p.row_len && m < p.M) {
             const int grp = m / p.rows_per_group;
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int n = n0 + c * 64 + lane;
-            srv[u][c] = (p.residual && m < p.M && c * 64 + lane < BN && n < p.N) ? p.residual[(size_t)m * p.ldr + n] : 0.f;
+            srv[u][c] = (p.residual && m < p.M && c * 64 + lane < BN && n < p.N) ? p.residual[(size_t)smrow[u] * p.ldr + n] : 0.f;
         }
     }
 #pragma unroll
@@ -353,8 +367,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
             if (p.drop_thresh) v = drop_hash(p.drop_seed + (p.drop_step ? *p.drop_step : 0ull), (uint64_t)m * p.N + n) >= p.drop_thresh ? v * p.drop_scale : 0.f;
             v = srv[u][c] + v;
             if (m >= p.M || c * 64 + lane >= BN || n >= p.N) continue;
-            if (p.y_is_f32) static_cast<float*>(p.y)[(size_t)m * p.ldy + n] = v;
-            else ElemOps<T>::store(static_cast<T*>(p.y) + (size_t)m * p.ldy + n, v);
+            if (p.y_is_f32) static_cast<float*>(p.y)[(size_t)smrow[u] * p.ldy + n] = v;
+            else ElemOps<T>::store(static_cast<T*>(p.y) + (size_t)smrow[u] * p.ldy + n, v);
         }
     }
 }
@@ -370,6 +384,9 @@ static bool launch_specialised(const Gemm2Params& p, int bm, int bn, int ns, int
     if (bm == 128 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 128, 64, 2, 4, 2, FEAT>(p, st); return true; }
     if (bm == 64 && bn == 64 && ns == 2 && nw == 8) { launch_one<T, 64, 64, 2, 4, 2, FEAT>(p, st); return true; }
     if (bm == 64 && bn == 32 && ns == 4 && nw == 4) { launch_one<T, 64, 32, 4, 2, 2, FEAT>(p, st); return true; }
+    if constexpr (sizeof(T) == 2 && (FEAT == 18 || FEAT == 82)) {     // the K >= 1024 rule inside the bounding / semi-autoregressive loops
+        if (nw == 8 && bm == 64 && bn == 64 && ns == 4) { launch_one<T, 64, 64, 4, 4, 2, FEAT>(p, st); return true; }
+    }
     if constexpr (sizeof(T) == 2 && FEAT < 3) {      // deeper rings / larger tiles for the encoder and fill GEMMs (one workgroup per CU)
         if (nw == 8) {
             if (bm == 64 && bn == 64 && ns == 4) { launch_one<T, 64, 64, 4, 4, 2, FEAT>(p, st); return true; }
@@ -397,7 +414,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     int bm = 0, bn = 0, ns = 0;
     int nw = 4;
     const int feat = (p.ln_stats ? 1 : 0) | ((p.stats_out || p.y2) ? 2 : 0) | (p.row_len ? 4 : 0) | (p.drop_thresh ? 8 : 0) |
-                     ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0);
+                     ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0) | (p.row_idx ? 64 : 0);
     if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%dx%d", &bm, &bn, &ns, &nw); }
     if (!bm) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
@@ -422,7 +439,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
         // long K on few tiles (FFN w_2, att_embed: N = 512, K = 2048): the loop is a chain of slab round trips, three slabs in
         // flight instead of one (measured round 2, tools/mb_tiles2.py / mb_tiles3.py: 17.4 -> 11.6 us alone, 10.0 -> 7.6 us with
         // four in flight at M = 1280; 18.3 -> 15.2 us alone at M = 2304)
-        if (heur2 && sizeof(T) == 2 && bm == 64 && bn == 64 && p.M > 64 && p.splitk == 1 && p.K >= 1024 && (feat < 3 || feat == 6)) ns = 4;
+        if (heur2 && sizeof(T) == 2 && bm == 64 && bn == 64 && p.M > 64 && p.splitk == 1 && p.K >= 1024 && (feat < 3 || feat == 6 || feat == 18 || feat == 82)) ns = 4;
     }
     {
         bool done = false;
@@ -436,6 +453,8 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
             case 8: done = launch_specialised<T, 8>(p, bm, bn, ns, nw, st); break;          // training: dropout (+ compute-dtype copy)
             case 10: done = launch_specialised<T, 10>(p, bm, bn, ns, nw, st); break;
             case 32: done = launch_specialised<T, 32>(p, bm, bn, ns, nw, st); break;        // training: dX through relu (+ dropout)
+            case 81: done = launch_specialised<T, 81>(p, bm, bn, ns, nw, st); break;        // SAIC decoder pass over a row list (+ halt word)
+            case 82: done = launch_specialised<T, 82>(p, bm, bn, ns, nw, st); break;
             default: break;
         }
         if (done) { BOFI_CHECK_LAUNCH(); return BOFI_OK; }
@@ -485,6 +504,8 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.splitk = a.splitk > 1 ? a.splitk : 1;
     p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
     p.mask_scale = a.mask_scale;
+    p.row_idx = a.row_idx; p.m_dev = a.m_dev;
+    if (p.row_idx && (!p.m_dev || a.row_len || a.drop_thresh || a.splitk > 1 || a.mask_scale != 0.f)) return BOFI_ERR_ARG;
     if (p.drop_thresh && (a.splitk > 1 || a.stats_out)) return BOFI_ERR_ARG;
     if (p.mask_scale != 0.f && (!a.residual || a.splitk > 1 || a.stats_out || a.ln_stats)) return BOFI_ERR_ARG;
     if (p.splitk > 1 && (a.y_dtype != BOFI_DT_F32 || a.relu || a.ln_stats || a.stats_out || a.y2 || a.row_len || (a.K / p.splitk) % bk || a.K % p.splitk))

@@ -514,6 +514,38 @@ int launch_embed_rows(const float* lut_tok, const float* lut_syn, const float* p
     return BOFI_OK;
 }
 
+// The decoder rows an iteration of the semi-autoregressive loop has to compute: the positions of the phrase each unfinished
+// image placed in this iteration (TransformerModel.py:1933-1948).  Every earlier row's input and key set are final once its phrase
+// is placed, so its K / V in every decoder layer are too; later rows are never attended.  One wavefront; rows image-major.
+__global__ __launch_bounds__(64) void saic_rows_kernel(BoundState st, int B, int L, int S, int iter, int* rows, int* n_rows) {
+    if (st.counters[2] >= 1) return;
+    int n = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + threadIdx.x;
+        const int cur = b < B ? st.phrase_length[b * L + iter] : 0, pl = b < B ? st.last[b] : 0;
+        int incl = cur;                                         // inclusive prefix sum over the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
+        const int base = n + incl - cur;
+        for (int k = 0; k < cur; ++k) rows[base + k] = b * S + pl - 1 + k;
+        n += __shfl(incl, 63, 64);
+    }
+    if (threadIdx.x == 0) *n_rows = n;
+}
+
+int launch_saic_rows(const BoundState& st, int B, int L, int S, int iter, int* rows, int* n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(saic_rows_kernel, dim3(1), dim3(64), 0, s, st, B, L, S, iter, rows, n_rows);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+__global__ void set_u64_kernel(uint64_t* p, uint64_t v) { *p = v; }
+int launch_set_u64(uint64_t* p, uint64_t v, hipStream_t s) {
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, s, p, v);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 __global__ void saic_init_kernel(BoundState st, SaicState sa, int B, int L, int pad_idx, int bos_idx, int len_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4) st.counters[i] = 0;
@@ -537,43 +569,48 @@ int launch_saic_init(const BoundState& st, const SaicState& sa, int B, int L, in
     return BOFI_OK;
 }
 
-// One workgroup per image.  tok/logp: greedy ids and log-probs of ALL S positions of this iteration's decoder pass.
+// tok/logp: ids and log-probs of this iteration's decoder pass (all S positions, or the new phrases' rows).  Grid (S + 1, B): block
+// (k < S, b) copies the log-prob row of the k-th token of image b's new phrase, block (S, b) its token ids.  No block writes what
+// another reads (st.last, st.phrase_length[iter]); the positions advance in saic_halt_kernel, the next launch.
 __global__ __launch_bounds__(256) void saic_copy_kernel(BoundState st, SaicState sa, const int64_t* __restrict__ tok,
                                                         const float* __restrict__ logp, float* __restrict__ seq_logprob, int B,
                                                         int L, int S, int V, int iter) {
     if (st.counters[2] >= 1) return;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
     const bool nan_seen = st.counters[3] != 0;                  // "phrase nan!": return before the copy (TransformerModel.py:1956-1958)
     const int cur = st.phrase_length[b * L + iter], pl = st.last[b];
-    if (!nan_seen && cur != 0) {
-        for (int k = 0; k < cur; ++k) {
-            const float* src = logp + ((size_t)b * S + pl - 1 + k) * V;
-            float* dst = seq_logprob + ((size_t)b * S + pl - 1 + k) * V;      // seq_logprobs[j, pl+k] -> returned slice [:, 1:-1]
-            if (seq_logprob) for (int i = tid; i < V; i += 256) dst[i] = src[i];
-        }
+    if (nan_seen || cur == 0) return;
+    if (k < S) {
+        if (k >= cur || !seq_logprob) return;
+        const float* src = logp + ((size_t)b * S + pl - 1 + k) * V;
+        float* dst = seq_logprob + ((size_t)b * S + pl - 1 + k) * V;          // seq_logprobs[j, pl+k] -> returned slice [:, 1:-1]
+        for (int i = tid; i < V; i += 256) dst[i] = src[i];
+        return;
     }
-    __syncthreads();                                            // every thread has read last/phrase_length before thread 0 updates them
-    if (tid == 0) {
+    for (int kk = tid; kk < cur; kk += 256) {
+        const int t = (int)tok[(size_t)b * S + pl - 1 + kk];
+        sa.seq[b * L + pl + kk] = t;
+        sa.ext_len[b * L + pl + kk] = t;
+    }
+}
+// after every block of saic_copy_kernel has read the old state: advance the images' positions, then the loop exit conditions
+__global__ void saic_halt_kernel(BoundState st, SaicState sa, int B, int L, int iter) {
+    if (st.counters[2] >= 1) return;
+    const bool nan_seen = st.counters[3] != 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int cur = st.phrase_length[b * L + iter];
         if (!nan_seen && cur != 0) {
-            for (int k = 0; k < cur; ++k) {
-                const int t = (int)tok[(size_t)b * S + pl - 1 + k];
-                sa.seq[b * L + pl + k] = t;
-                sa.ext_len[b * L + pl + k] = t;
-            }
-            st.last[b] = pl + cur;
+            st.last[b] += cur;
             sa.seq_last[b] += st.phrase_length[b * L + iter - 1];
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && (nan_seen || st.counters[0] >= B)) st.counters[2] = 1;
 }
-__global__ void saic_halt_kernel(BoundState st, int B) {       // after saic_copy of every image: loop exit conditions
-    if (st.counters[2] >= 1) return;
-    if (st.counters[3] != 0 || st.counters[0] >= B) st.counters[2] = 1;
-}
-
 int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* tok, const float* logp, float* seq_logprob, int B, int L,
                      int S, int V, int iter, hipStream_t s) {
-    hipLaunchKernelGGL(saic_copy_kernel, dim3(B), dim3(256), 0, s, st, sa, tok, logp, seq_logprob, B, L, S, V, iter);
-    hipLaunchKernelGGL(saic_halt_kernel, dim3(1), dim3(1), 0, s, st, B);
+    hipLaunchKernelGGL(saic_copy_kernel, dim3(S + 1, B), dim3(256), 0, s, st, sa, tok, logp, seq_logprob, B, L, S, V, iter);
+    hipLaunchKernelGGL(saic_halt_kernel, dim3(1), dim3(256), 0, s, st, sa, B, L, iter);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -607,11 +644,12 @@ int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, 
 template <int NPT>   // values per thread held in registers: V <= 512 * NPT (one HBM read + one write per value)
 __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__ logits, int V, int S, int log_softmax,
                                                              const int* ntok, int ntok_bias, int pad_idx, int64_t* seq,
-                                                             int* nan_flag, const int* halt) {
+                                                             int* nan_flag, const int* halt, const int* row_idx, const int* n_rows) {
     __shared__ float red[16];
     __shared__ int redi[16];
     if (halt && *halt >= 1) return;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n_rows && (int)blockIdx.x >= *n_rows) return;           // row list: rows row_idx[0 .. *n_rows) only
+    const int row = row_idx ? row_idx[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* x = logits + (size_t)row * V;
     float v[NPT];
     float m = -INFINITY;
@@ -678,12 +716,12 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
 }
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias, int pad_idx,
-                          int64_t* seq, hipStream_t st, int* nan_flag, const int* halt) {
+                          int64_t* seq, hipStream_t st, int* nan_flag, const int* halt, const int* row_idx, const int* n_rows) {
     if (!logits || !seq || rows < 0 || V <= 0 || S <= 0) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt);
-    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt);
-    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt);
+    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows);
+    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows);
+    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows);
     else return BOFI_ERR_ARG;
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
@@ -716,11 +754,14 @@ __global__ __launch_bounds__(256) void vocab_stats_kernel(const float* __restric
 // row b * n + c of the output (models/utils.py:3-14 repeats each image n times), ids past the image's token count are pad.
 __global__ __launch_bounds__(256) void vocab_sample_kernel(const float* __restrict__ logp, int V, int S, int n, float inv_temp, uint64_t seed,
                                                            const int* __restrict__ ntok, int pad_idx, int64_t* __restrict__ out,
-                                                           const int* halt) {
+                                                           const int* halt, const int* row_idx, const int* n_rows,
+                                                           const uint64_t* seed_dev) {
     __shared__ float redv[4];
     __shared__ int redi[4];
     if (halt && *halt >= 1) return;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n_rows && (int)blockIdx.x >= *n_rows) return;
+    if (seed_dev) seed += *seed_dev;                           // per-call part of the seed (a captured launch keeps the per-iteration part)
+    const int row = row_idx ? row_idx[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = row / S, t = row - b * S;
     const float* x = logp + (size_t)row * V;
     for (int c = 0; c < n; ++c) {
@@ -753,10 +794,10 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const float* __restri
 }
 
 int launch_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok, int pad_idx,
-                        int64_t* out, hipStream_t st, const int* halt) {
+                        int64_t* out, hipStream_t st, const int* halt, const int* row_idx, const int* n_rows, const uint64_t* seed_dev) {
     if (!logp || !out || rows < 0 || V <= 0 || S <= 0 || rows % S || n <= 0 || !(temperature > 0.f)) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    hipLaunchKernelGGL(vocab_sample_kernel, dim3(rows), dim3(256), 0, st, logp, V, S, n, 1.0f / temperature, seed, ntok, pad_idx, out, halt);
+    hipLaunchKernelGGL(vocab_sample_kernel, dim3(rows), dim3(256), 0, st, logp, V, S, n, 1.0f / temperature, seed, ntok, pad_idx, out, halt, row_idx, n_rows, seed_dev);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -773,7 +814,7 @@ extern "C" int bofi_vocab_stats(const float* logp, const int64_t* seq, int rows,
 
 extern "C" int bofi_vocab_sample(const float* logp, int rows, int V, int S, int n, float temperature, uint64_t seed, const int* ntok,
                                  int pad_idx, int64_t* out, void* stream) {
-    return bofi::launch_vocab_sample(logp, rows, V, S, n, temperature, seed, ntok, pad_idx, out, (hipStream_t)stream, nullptr);
+    return bofi::launch_vocab_sample(logp, rows, V, S, n, temperature, seed, ntok, pad_idx, out, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int bofi_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int pad_idx,

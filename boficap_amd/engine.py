@@ -198,21 +198,24 @@ class BofiEngine:
         return res
 
     def decode_saic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, raw_logits: bool = False,
-                    want_logprob: bool = True, sample: Optional[tuple] = None) -> dict:
+                    want_logprob: bool = True, sample: Optional[tuple] = None, graph: bool = False, out: Optional[dict] = None) -> dict:
         """Semi-autoregressive decode (core_SAIC), greedy or -- ``sample=(temperature, seed)`` -- with every phrase's tokens
         drawn from Categorical(logits / temperature) (the bound heads stay greedy, as in the reference).  Same result
-        layout as ``decode_naic``."""
+        layout as ``decode_naic``.  ``graph``: the launch sequence is captured once per argument set and replayed (pass the
+        previous result as ``out`` and keep the inputs in place); the sampling seed is read from device memory, so replays
+        draw anew."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
-        out = dict(
-            seq=torch.empty(B, S, dtype=torch.int64, device=dev),
-            seq_logprob=torch.empty(B, S, V, dtype=torch.float32, device=dev) if want_logprob else None,
-            phrase_num=torch.empty(B, dtype=torch.int32, device=dev),
-            phrase_length=torch.empty(B, S, dtype=torch.int32, device=dev),
-            phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
-            bound_iters=torch.empty(1, dtype=torch.int32, device=dev), memory=None)
-        flags = hip.FLAG_RAW_LOGITS if raw_logits else 0
+        if out is None:
+            out = dict(
+                seq=torch.empty(B, S, dtype=torch.int64, device=dev),
+                seq_logprob=torch.empty(B, S, V, dtype=torch.float32, device=dev) if want_logprob else None,
+                phrase_num=torch.empty(B, dtype=torch.int32, device=dev),
+                phrase_length=torch.empty(B, S, dtype=torch.int32, device=dev),
+                phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
+                bound_iters=torch.empty(1, dtype=torch.int32, device=dev), memory=None)
+        flags = (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0)
         if sample is not None:
             hip.check(self._lib.bofi_engine_set_sampling(self._h, float(sample[0]), int(sample[1]) & 0xFFFFFFFFFFFFFFFF), "bofi_engine_set_sampling")
             flags |= hip.FLAG_SAMPLE

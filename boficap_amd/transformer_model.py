@@ -132,6 +132,23 @@ class TransformerModel(nn.Module):
             att_feats = att_feats.float()
         return att_feats.contiguous()
 
+    def _decode_saic_graphed(self, eng, feats, lens, raw_logits, sample):
+        """The semi-autoregressive decode enqueues all seq_length iterations (≈60 launches each; iterations past the last live
+        one return at once), so launched one by one it is bound by the host's launch rate.  It is replayed as a hipGraph over
+        static input / output buffers per batch shape; the caller gets its own copies, as from the reference."""
+        key = (tuple(feats.shape), feats.dtype, lens is not None, bool(raw_logits), sample is not None)
+        cache = self.__dict__.setdefault("_saic_io", {})
+        if key not in cache:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            cache[key] = dict(feats=torch.empty_like(feats), lens=None if lens is None else torch.empty_like(lens), out=None)
+        io = cache[key]
+        io["feats"].copy_(feats)
+        if lens is not None:
+            io["lens"].copy_(lens)
+        io["out"] = eng.decode_saic(io["feats"], io["lens"], raw_logits=raw_logits, sample=sample, graph=True, out=io["out"])
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in io["out"].items()}
+
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel.py:307-338, 419-437 for train_mode 'NAIC' (bound+fill) and 'SAIC' (phrase by phrase)."""
         sample_method = opt.get("sample_method", "greedy")
@@ -155,7 +172,7 @@ class TransformerModel(nn.Module):
             r = eng.decode_naic(self._as_input(att_feats), self._att_len(att_masks), strict_q1=self.strict_reference,
                                 raw_logits=not output_logsoftmax)
         elif sample_method == "greedy":                           # core_SAIC, AttModel.py:430-437
-            r = eng.decode_saic(self._as_input(att_feats), self._att_len(att_masks), raw_logits=not output_logsoftmax)
+            r = self._decode_saic_graphed(eng, self._as_input(att_feats), self._att_len(att_masks), not output_logsoftmax, None)
         else:
             # sampled tokens feed the next bound step, so the sample_n copies of an image diverge: decode B * n rows
             # (the reference repeats features and masks the same way, AttModel.py:331-334)
@@ -167,7 +184,7 @@ class TransformerModel(nn.Module):
                 raise hip.BofiHipError(f"{feats.size(0)} sampled rows exceed bofi_max_batch={self.max_batch}")
             self._sample_calls = getattr(self, "_sample_calls", 0) + 1
             seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._sample_calls
-            r = eng.decode_saic(feats, lens, raw_logits=not output_logsoftmax, sample=(temperature, seed))
+            r = self._decode_saic_graphed(eng, feats, lens, not output_logsoftmax, (temperature, seed))
         torch.cuda.synchronize()
         end = time.time()
         if train_mode == "SAIC" and sample_method == "sample":

@@ -486,3 +486,43 @@ def test_dense_bounding_pass_equals_incremental_form(weight_cache, manifest, mon
         assert (r["phrase_length"].cpu().numpy() == g["naic_phrase_length"]).all() and (r["phrase_syn"].cpu().numpy() == g["naic_phrase_syn"]).all(), name
         assert (r["seq"].cpu().numpy() == g["naic_seq"]).all() and int(r["bound_iters"]) == int(g["naic_iters"])
         assert _close(r["seq_logprob"].cpu().numpy(), g["naic_logprob"], 0) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_saic_row_list_equals_full_decoder_passes(dtype, weight_cache, manifest, monkeypatch):
+    """From the second iteration on the semi-autoregressive decode runs only the new phrases' rows through the decoder (their K / V
+    join the per-layer cache); BOFI_SAIC_CACHE=0 re-runs every row in every iteration as the reference does (decode_SA
+    TransformerModel.py:520-530 inside core_SAIC :1949-1952).  Same ids, same slot layout, same log-probs — greedy and sampled."""
+    from boficap_amd.engine import BofiEngine
+    from boficap_amd import weights as W
+    m = manifest["full_saic_multi"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    g = load_golden("full_saic_multi")
+    att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
+    outs = []
+    for cache in ("1", "0"):
+        monkeypatch.setenv("BOFI_SAIC_CACHE", cache)
+        eng = BofiEngine(cfg, dtype, max_batch=16, max_regions=36)
+        eng.load_state_dict(sd)
+        r = eng.decode_saic(att)
+        rs = eng.decode_saic(att, sample=(1.0, 77))
+        if cache == "1":                                           # captured replay: same results, and a new seed draws anew
+            rg = eng.decode_saic(att, graph=True)
+            rg = eng.decode_saic(att, graph=True, out=rg)
+            rsg = eng.decode_saic(att, sample=(1.0, 77), graph=True)
+            rsg = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_saic(att, sample=(1.0, 77), graph=True, out=rsg).items()}
+            rs2 = eng.decode_saic(att, sample=(1.0, 78), graph=True, out=None)
+            torch.cuda.synchronize()
+            for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+                assert torch.equal(r[k], rg[k]) and torch.equal(rs[k], rsg[k]), k
+            assert torch.equal(r["seq_logprob"].nan_to_num(0.0), rg["seq_logprob"].nan_to_num(0.0))
+            assert not torch.equal(rs2["seq"], rs["seq"])
+        torch.cuda.synchronize()
+        outs.append((r, rs))
+    for a, b in zip(outs[0], outs[1]):
+        assert int(a["phrase_num"].sum()) > att.size(0)            # several phrases per image: the row-list iterations did run
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+            assert torch.equal(a[k], b[k]), k
+        assert int(a["bound_iters"]) == int(b["bound_iters"])
+        la, lb = a["seq_logprob"], b["seq_logprob"]
+        assert torch.equal(la.isnan(), lb.isnan()) and torch.equal(la.nan_to_num(0.0), lb.nan_to_num(0.0))

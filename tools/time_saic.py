@@ -15,9 +15,10 @@ if "--multi" in sys.argv:                   # keep images that open a phrase (on
     pool = torch.from_numpy(W.synthetic_att_feats(256, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16)
     pn = torch.cat([eng.decode_naic(c)["phrase_num"].clone() for c in pool.split(64)])
     att = pool[pn > 0][:64].contiguous()
-r = eng.decode_saic(att); torch.cuda.synchronize()
+graph = "--no-graph" not in sys.argv
+r = eng.decode_saic(att, graph=graph); torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10): r = eng.decode_saic(att)
+for _ in range(10): r = eng.decode_saic(att, graph=graph, out=r)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
 print(f"SAIC greedy B=64 bf16: {dt*1e3:.2f} ms/batch = {64/dt:.0f} images/s, iterations {int(r['bound_iters'])}, NaN {bool(r['seq_logprob'].isnan().any())}, "
