@@ -324,7 +324,10 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* att_feats, int feats_d
  * emitted so far (:1907-1926), the position-wise copy of the previous phrase (:1928-1948), a full decoder
  * pass (decode_SA :520-530) and the copy of the new phrase's tokens and log-probs (:1968-1977); stops
  * when every image is finished or a NaN appears (:1956-1958).  Outputs as for decode_naic
- * (seq_logprob rows never written stay 0, as in the reference). */
+ * (seq_logprob rows never written stay 0, as in the reference).  From the second phrase on only the new phrase's rows go
+ * through the decoder's GEMMs (their K / V join a per-layer cache; results identical to the all-rows form).  flags:
+ * BOFI_FLAG_RAW_LOGITS, BOFI_FLAG_SAMPLE (bofi_engine_set_sampling; the seed lives in device memory, so a replayed graph
+ * draws anew), BOFI_FLAG_GRAPH (captured once per argument set, as decode_naic). */
 int bofi_engine_decode_saic(bofi_engine_t* e, const void* att_feats, int feats_dtype, const int* att_len,
                             int B, int R, int flags, int64_t* seq, float* seq_logprob, int* phrase_num,
                             int* phrase_length, int64_t* phrase_syn, int* bound_iters, void* stream);
