@@ -66,6 +66,7 @@ struct Gemm2Params {
     // row list (FEAT bit 6): the GEMM runs over rows row_idx[0 .. *m_dev) of x and writes the same rows of y / y2 / the statistics
     // (p.M is the capacity the grid was sized for; tiles past *m_dev return at once)
     const int* row_idx; const int* m_dev;
+    int row_bands;            // XCD tile order: 8 (bands of A rows per XCD), 4, 2 or 1 (bands of weight columns per XCD)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -110,16 +111,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    // XCD-aware tile order (workgroup i runs on XCD i % 8, each XCD has its own 4 MiB L2): XCD x gets a
-    // CONTIGUOUS run of tiles in (m-tile major, n-tile minor) order, i.e. a band of A rows that stays in
-    // its L2 while the weight panel streams; bijective for any tile count.
+    // XCD-aware tile order (workgroup i runs on XCD i % 8, each XCD has its own 4 MiB L2 and fetches what it touches from the
+    // Infinity Cache itself): XCD x gets a CONTIGUOUS run of tiles of a linear order that walks `row_bands` bands of m-tiles one
+    // after the other, and inside a band n-tile major / m-tile minor.  With 8 bands an XCD owns a band of A rows and streams the
+    // whole weight panel (fetch = 8 W + A); with 1 band it owns a band of weight columns and streams all rows (W + 8 A); 2 and 4 are
+    // the 2-D splits in between (rb W + (8 / rb) A).  The host picks the cheapest; bijective for any tile count.
     const int ntn = (p.N + BN - 1) / BN, ntiles = gridDim.x;
     int tile = blockIdx.x;
+    int mt, nt;
     if (!(p.dbg & 16) && !p.m_dev) {                   // (a row list fills the first row tiles only: plain order spreads them over the XCDs)
         const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        const int ntm = ntiles / ntn, mb = (ntm + p.row_bands - 1) / p.row_bands;     // m-tiles per band (the last band may be shorter)
+        const int band = tile / (mb * ntn), local = tile - band * mb * ntn;
+        const int rows_here = min(mb, ntm - band * mb);
+        nt = local / rows_here;
+        mt = band * mb + (local - nt * rows_here);
+    } else {
+        mt = tile / ntn; nt = tile - mt * ntn;
     }
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int m0 = mt * BM, n0 = nt * BN;
     if (p.m_dev) {
         p.M = min(p.M, *p.m_dev);
         if (m0 >= p.M) return;
@@ -511,6 +522,13 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     if (p.splitk > 1 && (a.y_dtype != BOFI_DT_F32 || a.relu || a.ln_stats || a.stats_out || a.y2 || a.row_len || (a.K / p.splitk) % bk || a.K % p.splitk))
         return BOFI_ERR_ARG;
     { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }
+    {   // bytes an XCD layout makes the eight L2s fetch: rb * W + (8 / rb) * A
+        static const int forced = [] { const char* v = getenv("BOFI_GEMM_BANDS"); return v ? atoi(v) : 0; }();
+        const double wb = (double)a.N * a.K, ab = (double)a.M * a.K;
+        int best = 8; double cost = 8 * wb + ab;
+        for (int rb : {4, 2, 1}) { const double c = rb * wb + (8 / rb) * ab; if (c < 0.9 * cost) { best = rb; cost = c; } }
+        p.row_bands = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? forced : best;
+    }
     const int yel = p.y_is_f32 ? 4 : el;
     p.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && ((uintptr_t)a.y * 0 + (size_t)a.ldy * yel) % 8 == 0 &&
                (!a.bias || (uintptr_t)a.bias % 16 == 0) &&
