@@ -116,5 +116,6 @@ int launch_vocab_sample(const float* logp, int rows, int V, int S, int n, float 
                         int64_t* out, hipStream_t st, const int* halt = nullptr, const int* row_idx = nullptr, const int* n_rows = nullptr,
                         const uint64_t* seed_dev = nullptr);      // seed_dev: device word added to `seed` (so that a captured launch can draw anew)
 int launch_set_u64(uint64_t* p, uint64_t v, hipStream_t s);
+int launch_zero_f32(float* p, size_t n, hipStream_t s);
 
 }  // namespace bofi

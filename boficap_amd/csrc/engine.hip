@@ -512,7 +512,7 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
     const int* halt = st.counters + 2;
     ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, nullptr, s));
     ENG_OK(bofi::launch_saic_init(st, sa, B, L, cfg.pad_idx, cfg.bos_idx, cfg.len_idx, s));
-    if (seq_logprob) ENG_HIP(hipMemsetAsync(seq_logprob, 0, (size_t)M * cfg.vocab * sizeof(float), s));   // seq_logprobs = zeros (:1883)
+    if (seq_logprob) ENG_OK(bofi::launch_zero_f32(seq_logprob, (size_t)M * cfg.vocab, s));   // seq_logprobs = zeros (:1883); not a memset node
     const void* xwa = stream_t(xw, xwb);
     const void* xa = stream_t(x_fill, xb_fill);
     for (int it = 1; it <= S; ++it) {

@@ -539,6 +539,21 @@ int launch_saic_rows(const BoundState& st, int B, int L, int S, int iter, int* r
     return BOFI_OK;
 }
 
+// zero fill of a float buffer as a kernel of this library: inside a captured launch sequence a hipMemsetAsync becomes a memset
+// NODE, and replays of such a node were seen to fill with a stale pattern (pointer-like values) after host-side allocations --
+// a plain kernel node carries its arguments by value
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+int launch_zero_f32(float* p, size_t n, hipStream_t s) {
+    if (!n) return BOFI_OK;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, p, n);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 __global__ void set_u64_kernel(uint64_t* p, uint64_t v) { *p = v; }
 int launch_set_u64(uint64_t* p, uint64_t v, hipStream_t s) {
     hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, s, p, v);

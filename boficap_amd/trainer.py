@@ -530,10 +530,13 @@ class XETrainer:
         was_training = model.training
         model.eval()                                           # sampling runs on the inference engine (no dropout)
         with torch.no_grad():
-            opt = {"sample_method": "sample", "sample_n": sample_n, "temperature": temperature, "output_logsoftmax": 1}
-            ks = ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")
-            saic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="SAIC"), mode="sample")[:5]))
-            naic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
+            if getattr(model.opt, "bofi_rl_sample_pair", True):
+                saic, naic = model.sample_pair(att_feats, att_masks, sample_n, temperature)    # the two modes' decodes overlap
+            else:                                              # the reference's two calls, one after the other
+                opt = {"sample_method": "sample", "sample_n": sample_n, "temperature": temperature, "output_logsoftmax": 1}
+                ks = ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")
+                saic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="SAIC"), mode="sample")[:5]))
+                naic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
         model.train(was_training)
         seq_s, seq_n = saic["seq"].cpu(), naic["seq"].cpu()    # the scorer runs on the host
         S = model.cfg.seq_length

@@ -149,6 +149,40 @@ class TransformerModel(nn.Module):
         io["out"] = eng.decode_saic(io["feats"], io["lens"], raw_logits=raw_logits, sample=sample, graph=True, out=io["out"])
         return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in io["out"].items()}
 
+    def sample_pair(self, att_feats, att_masks=None, sample_n=5, temperature=1.0):
+        """What the self-critical step asks of the model (loss_wrapper.py:193-209): ``sample_n`` sampled captions per image in SAIC
+        mode and in NAIC mode.  Same results as two ``mode='sample'`` calls (same seeds); the two decodes are independent, so the
+        NAIC one runs on a fork of the engine on a second stream, under the semi-autoregressive loop's replayed graph.
+        Returns (saic, naic) dicts with seq, seq_logprob, phrase_num, phrase_length, phrase_syn."""
+        eng = self.engine()
+        side = self.__dict__.get("_side_engine")
+        if side is None or side[0] is not eng:
+            side = self.__dict__["_side_engine"] = (eng, eng.fork(), torch.cuda.Stream(device=eng.device))
+        _, eng2, s2 = side
+        feats, lens = self._as_input(att_feats), self._att_len(att_masks)
+        main = torch.cuda.current_stream(feats.device)
+        s2.wait_stream(main)                                      # inputs and (re-packed) weights are ready there
+        base = int(getattr(self.opt, "seed", 0)) << 32
+        self._sample_calls = getattr(self, "_sample_calls", 0) + 2
+        seed_saic, seed_naic = base + self._sample_calls - 1, base + self._sample_calls
+        rows, rlens = feats, lens
+        if sample_n > 1:
+            rows = feats.repeat_interleave(sample_n, dim=0).contiguous()
+            rlens = None if lens is None else lens.repeat_interleave(sample_n).contiguous()
+        if rows.size(0) > self.max_batch:
+            raise hip.BofiHipError(f"{rows.size(0)} sampled rows exceed bofi_max_batch={self.max_batch}")
+        saic = self._decode_saic_graphed(eng, rows, rlens, False, (float(temperature), seed_saic))
+        with torch.cuda.stream(s2):
+            r = eng2.decode_naic(feats, lens, strict_q1=self.strict_reference)
+            naic = {k: r[k] for k in ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")}
+            if sample_n > 1:                                      # the bound is deterministic: n identical layouts (models/utils.py:3-14)
+                naic = {k: v.repeat_interleave(sample_n, dim=0) for k, v in naic.items()}
+            naic["seq"] = eng2.sample_tokens(r, sample_n, float(temperature), seed_naic)
+        main.wait_stream(s2)
+        for v in list(naic.values()) + [feats] + ([lens] if lens is not None else []):
+            v.record_stream(main)                                 # allocated / read on s2, used on the caller's stream from here on
+        return saic, naic
+
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel.py:307-338, 419-437 for train_mode 'NAIC' (bound+fill) and 'SAIC' (phrase by phrase)."""
         sample_method = opt.get("sample_method", "greedy")

@@ -255,3 +255,23 @@ def test_rl_step_with_kl_term(weight_cache, manifest):
     assert float(l1) > float(l0) and abs(float(l1) - float(l2)) < 1e-5 * max(1.0, abs(float(l1)))
     assert float((t1.bucket.grad - t0.bucket.grad).abs().max()) > 0
     assert float((t2.bucket.grad - t1.bucket.grad).abs().max()) <= 1e-4 * float(t1.bucket.grad.abs().max())
+
+
+def test_sample_pair_equals_the_two_sample_calls(weight_cache, manifest):
+    """TransformerModel.sample_pair overlaps the two modes' sampling decodes (engine fork, second stream); it must return what
+    the reference's two mode='sample' calls (loss_wrapper.py:193-209) return with the same seeds."""
+    cfg, sd, model = _model(weight_cache, manifest)
+    att = _images().cuda()
+    n = 3
+    for rep in range(2):                                      # the second round replays the captured graph
+        model._sample_calls = 10 * rep
+        a_s = _sample(model, att, "SAIC", n, T=1.2)
+        a_n = _sample(model, att, "NAIC", n, T=1.2)
+        model._sample_calls = 10 * rep
+        with torch.no_grad():
+            b_s, b_n = model.sample_pair(att, None, n, 1.2)
+        torch.cuda.synchronize()
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+            assert torch.equal(a_s[k], b_s[k]) and torch.equal(a_n[k], b_n[k]), k
+        for a, b in ((a_s, b_s), (a_n, b_n)):
+            assert torch.equal(a["seq_logprob"].nan_to_num(0.0), b["seq_logprob"].nan_to_num(0.0))
