@@ -99,14 +99,14 @@ def cpu_baseline(cfg, sd, batch, seed, budget_s=20.0):
             "sample": f"{len(times)} x one batch of {batch} images, fp32 torch-CPU oracle, median, {torch.get_num_threads()} threads"}
 
 
-def gemm_rooflines(dtype, dev):
+def gemm_rooflines(dtype, dev, batches=1):
     """MFMA roofline of the GEMM kernel on the path's largest shapes: 100 dependent launches of one shape captured in
     a graph, HIP events around 20 replays on the launch stream (in-graph time per launch, launch boundary included)."""
     from boficap_amd import hip as H
     lib = H.lib()
     out = []
-    for name, M, N, K in (("cross K|V of all layers (kv_all)", 2304, 7168, 512), ("encoder FFN w_1", 2304, 2048, 512),
-                          ("encoder FFN w_2", 2304, 512, 2048), ("generator.proj", 1280, 9491, 512)):
+    for name, M, N, K in (("cross K|V of all layers (kv_all)", 2304 * batches, 7168, 512), ("encoder FFN w_1", 2304 * batches, 2048, 512),
+                          ("encoder FFN w_2", 2304 * batches, 512, 2048), ("generator.proj", 1280 * batches, 9491, 512)):
         x = torch.randn(M, K, device=dev).to(dtype)
         w = (torch.randn(N, K, device=dev) / K ** 0.5).to(dtype)
         b = torch.zeros(N, device=dev)
@@ -470,9 +470,11 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     log("building weights")
     sd = W.make_state_dict(cfg, seed=0)
+    import math
     C = max(1, args.coalesce)
-    if args.steps % C or args.warmup % C:
-        raise SystemExit("--steps and --warmup must be multiples of --coalesce")
+    if args.steps % C or args.warmup % C:                       # K steps = K / C launches: take the largest batch count that divides both
+        C = math.gcd(C, math.gcd(args.steps, args.warmup) if args.warmup else args.steps)
+        log(f"--steps / --warmup are not multiples of --coalesce {args.coalesce}: {C} batches per launch")
     eng = BofiEngine(cfg, tdt, max_batch=args.batch * C, max_regions=36, device=dev)
     eng.load_state_dict(sd)
     # every rank decodes its own shard of images (different seed per rank), already resident in HBM; with --coalesce the
@@ -483,6 +485,23 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # executed GEMM FLOPs of one decode: the library's tally over one eager call
     H.gemm_flops(reset=True)
     probe = eng.decode_naic(att, want_logprob=not args.ids_only, graph=False, refine_rounds=args.refine, q1_group=qg)
+    # quirk Q1: a batch whose LAST image lays out no phrase decodes to NaN as a whole (TransformerModel.py:1872-1873).  The slot
+    # layout of an image does not depend on its place, so such a batch gets one of its other images moved to the end.
+    pn = probe["phrase_num"].cpu()
+    moved = 0
+    for g0 in range(0, att.size(0), args.batch):
+        last = g0 + args.batch - 1
+        if int(pn[last]) == 0:
+            alive = [i for i in range(g0, last) if int(pn[i]) > 0]
+            if alive:
+                i = alive[-1]
+                att[[i, last]] = att[[last, i]]
+                moved += 1
+    if moved:
+        log(f"{moved} batch(es) ended on an image without phrases: reordered")
+        probe = eng.decode_naic(att, want_logprob=not args.ids_only, graph=False, refine_rounds=args.refine, q1_group=qg)
+        H.gemm_flops(reset=True)
+        probe = eng.decode_naic(att, want_logprob=not args.ids_only, graph=False, refine_rounds=args.refine, q1_group=qg)
     fl_fixed, fl_skip = H.gemm_flops(reset=True)
     T = int(probe["bound_iters"].item())
     del probe
@@ -542,14 +561,15 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         _barrier(world)
         single_ms = s0.elapsed_time(s1) / args.steps
     traffic, tnote = None, "no PMC pass committed for this configuration"
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):   # HBM bytes per decode from the newest committed PMC run
+    names = {1: ("r02_hbm_traffic.json", "r01_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",)}.get(C, ())
+    for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine and C == 1:
+        if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
             with open(tpath) as f:
                 tj = json.load(f)
                 traffic = tj.get("hbm_bytes_per_decode", tj.get("hbm_bytes_per_step"))
-            tnote = (f"HBM-side bytes per decode, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, one-at-a-time run "
-                     f"(profiles/{name}); algorithmic minimum = 9.4 MB features + 125 MB weights + 48.6 MB log-probs")
+            tnote = (f"HBM-side bytes per launch ({C} batch(es) of 64), rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, "
+                     f"one launch at a time (profiles/{name}); algorithmic minimum = {9.4 * C:.1f} MB features + 125 MB weights + {48.6 * C:.1f} MB log-probs")
             break
     ntok = float(out["phrase_length"].sum(1).float().mean().item())
     nan = bool(out["seq_logprob"].isnan().any().item()) if out["seq_logprob"] is not None else False
@@ -562,7 +582,8 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": traffic, "traffic_note": tnote,
             "kernel": ("whole decode = one hipGraph launch of the path's kernels" if graph else "whole decode (eager launches)")
-                      + (f", {len(engines)} decodes in flight" if len(engines) > 1 else ""),
+                      + (f", {C} batches of {args.batch} per launch (quirk Q1 per batch)" if C > 1 else "")
+                      + (f", {len(engines)} launches in flight" if len(engines) > 1 else ""),
             "flops_per_launch": flops_launch, "launch_ms": round(dev_ms, 4),
             "note": "algorithmic FLOPs F_alg(T)*batch (SURVEY.md 8d) / HIP-event time per decode on the launch stream; "
                     "achieved_executed: the GEMM FLOPs the decode launches (library tally, idle bound iterations weighted by T / seq_length) / the same time"}
@@ -582,11 +603,11 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                    "decodes_in_flight": len(engines), "batches_per_launch": C, "refine_rounds": args.refine,
                    "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                    "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
-                   "att_feats_seed": ATT_SEED, "nan_in_output": nan, "sharding": "images by rank, no collective"},
+                   "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
         "roofline": roof,
     }
     if world == 1 and gemm_roofline:
-        res["roofline_gemm"] = gemm_rooflines(tdt, dev)
+        res["roofline_gemm"] = gemm_rooflines(tdt, dev, C)
     log(f"gpu done: {res['value']} images/sec")
     if cpu and world == 1:
         log("timing the CPU oracle")
@@ -621,8 +642,9 @@ def main():
     ap.add_argument("--refine", type=int, default=0, help="extra filling rounds (BASELINE config 5 uses 3 rounds at batch 256)")
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")
-    ap.add_argument("--coalesce", type=int, default=1, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
-                    "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches")
+    ap.add_argument("--coalesce", type=int, default=None, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
+                    "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches.  "
+                    "Default 4 for the plain batch-64 decode (does not lean on the stream-to-hardware-queue placement), 1 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     ap.add_argument("--no-secondary", action="store_true", help="headline measurement only (no XE / RL / refinement lines)")
@@ -632,6 +654,9 @@ def main():
         sys.exit(self_launch(sys.argv[1:], args.gpus))
     if args.batch is None:
         args.batch = 10 if args.mode == "rl" else 64
+    default_coalesce = args.coalesce is None
+    if default_coalesce:
+        args.coalesce = 4 if (args.mode == "naic" and args.batch == 64 and not args.refine) else 1
     ctx = dist_setup(args)
     rank, world = ctx[0], ctx[2]
 
@@ -646,10 +671,13 @@ def main():
         res = run_rl(args, ctx, log, cpu)
     else:
         res = run_naic(args, ctx, log, cpu, not args.no_gemm_roofline)
-        plain = (args.batch == 64 and not args.refine and args.coalesce == 1 and args.dtype == "bf16" and not args.ids_only and not args.no_graph)
+        plain = (args.batch == 64 and not args.refine and default_coalesce and args.dtype == "bf16" and not args.ids_only and not args.no_graph)
         if world == 1 and plain and not args.no_secondary:
             import copy
             sec = {}
+            torch.cuda.empty_cache()
+            a = copy.copy(args); a.coalesce, a.steps, a.warmup = 1, 80, 16       # one batch of 64 per launch, 4 launches in flight (round-1 headline form)
+            sec["naic_one_batch_per_launch"] = _compact(run_naic(a, ctx, log, False, False))
             torch.cuda.empty_cache()
             a = copy.copy(args); a.mode, a.batch, a.steps, a.warmup = "xe", 64, 20, 5
             sec["xe_config3"] = _compact(run_xe(a, ctx, log, cpu))
@@ -657,10 +685,11 @@ def main():
             a = copy.copy(args); a.mode, a.batch, a.steps, a.warmup = "rl", 10, 10, 3
             sec["rl_config4"] = _compact(run_rl(a, ctx, log, cpu))
             torch.cuda.empty_cache()
-            a = copy.copy(args); a.batch, a.refine, a.steps, a.warmup = 256, 3, 40, 8
+            a = copy.copy(args); a.batch, a.refine, a.steps, a.warmup, a.coalesce = 256, 3, 40, 8, 1
             sec["refine_config5"] = _compact(run_naic(a, ctx, log, cpu, False))
             res["secondary"] = sec
-            res["secondary_note"] = ("driver-run lines of BASELINE configs 3, 4, 5 (short runs in the same process, after the headline measurement); "
+            res["secondary_note"] = ("naic_one_batch_per_launch: the headline workload with one batch of 64 per engine launch; then "
+                                     "driver-run lines of BASELINE configs 3, 4, 5 (short runs in the same process, after the headline measurement); "
                                      "config 5's 'autoregressive fallback' has no counterpart: a UIC checkpoint has no AR decode path in the reference "
                                      "(TransformerModel.py:1791-1804 needs EncoderDecoder.decode, :1287-1310)")
     if rank == 0 and res is not None:
