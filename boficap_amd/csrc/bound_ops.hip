@@ -1,7 +1,7 @@
 // Row-0 stages of one bounding iteration (LengthPredictor_UIC: DecoderLayer_UIC.sublayer[1], sublayer[2] of the reference,
-// TransformerModel.py:283-297) for a batch of at most 64 images, bf16 engine, d_model = 512.
+// TransformerModel.py:283-297): one activation row per image, bf16 engine, d_model = 512.
 //
-// At most 64 activation rows: the LDS-DMA GEMM of gemm_glds.hip spends its time in ring fill, barriers and the staged
+// A few dozen to a few hundred activation rows: the LDS-DMA GEMM of gemm_glds.hip spends its time in ring fill, barriers and the staged
 // epilogue (≈5.3 us per launch inside a graph against a ≈3.8 us floor of any load-compute-store kernel).  Here nothing is
 // staged: both MFMA operands of v_mfma_f32_16x16x32_bf16 are loaded straight from global memory into the fragment layout
 // (A row / B column = lane & 15, eight consecutive k per lane quarter = one 16-byte load), every load of a wavefront is in
@@ -11,7 +11,7 @@
 //   bound_qattn_kernel   q = Wq_src . LN(y1) for one head and 8 images, then that head's cross-attention of the 8 query rows
 //                        over the image's regions: scores by lane = key, softmax in the wavefront, P.V by lane = (8-column
 //                        chunk, key subset).  Replaces one GEMM launch and one attention launch.
-//   rowgemm_kernel       y[M<=64][N] = epilogue(x . W^T): LayerNorm fold on the input rows, bias, ReLU, float32 residual,
+//   rowgemm_kernel       y[M][N] = epilogue(x . W^T): LayerNorm fold on the input rows, bias, ReLU, float32 residual,
 //                        bf16 copy, per-16-column row statistics for the next fold, split-K partial slabs.
 #include "bofi_common.h"
 #include "bofi_kernels.h"
@@ -171,13 +171,13 @@ int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// y = epilogue(x . W^T) for M <= 64 rows; one workgroup per 16 output columns and K slice of 512 (blockIdx.y), its four wavefronts
-// take 128 k each.
+// y = epilogue(x . W^T) for a few rows (the bounding loop: one row per image); one workgroup per 16 output columns, K slice of 512
+// (blockIdx.y) and block of 64 rows (blockIdx.z), its four wavefronts take 128 k each.
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     __shared__ float4 red[4][4][64];          // [k quarter][16-row group][lane]
     if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, ks = blockIdx.y, ng = (a.M + 15) >> 4;
+    const int n0 = blockIdx.x * 16, ks = blockIdx.y, mbase = blockIdx.z * 64, ng = min(4, (a.M - mbase + 15) >> 4);
     const int kq = ks * 512 + wave * 128 + q * 8;
 
     bf16x8 fw[4], fx[4][4];
@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         if (g < ng) {
-            const bf16_t* xp = a.x + (size_t)min(g * 16 + r, a.M - 1) * a.ldx + kq;
+            const bf16_t* xp = a.x + (size_t)min(mbase + g * 16 + r, a.M - 1) * a.ldx + kq;
 #pragma unroll
             for (int s = 0; s < 4; ++s) fx[g][s] = ld_frag(xp + s * 32);
         }
     // epilogue operands of the row group this wavefront finalises (wave = group): image m, columns n .. n + 3
-    const int m = wave * 16 + r, n = n0 + q * 4;
+    const int m = mbase + wave * 16 + r, n = n0 + q * 4;
     const bool mine = wave < ng, rowok = m < a.M;
     const int mc = min(m, a.M - 1);
     float mean = 0.f, rstd = 1.f;
@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
     const int splitk = a.splitk > 1 ? a.splitk : 1;
-    if (a.M < 1 || a.M > 64 || a.N % 16 || a.K != 512 * splitk || a.ldx % 8 || !a.x || !a.w || !a.bias || (!a.y && !a.yb)) return BOFI_ERR_ARG;
+    if (a.M < 1 || a.N % 16 || a.K != 512 * splitk || a.ldx % 8 || !a.x || !a.w || !a.bias || (!a.y && !a.yb)) return BOFI_ERR_ARG;
     if (a.stats && (!a.colsum || a.stats_groups % 2 || splitk > 1)) return BOFI_ERR_ARG;
     if (splitk > 1 && (a.relu || a.stats_out || a.yb || !a.y)) return BOFI_ERR_ARG;
     if ((a.y && a.ldy % 4) || (a.yb && a.ldyb % 4) || (a.residual && a.ldr % 4)) return BOFI_ERR_ARG;
-    hipLaunchKernelGGL(rowgemm_kernel, dim3(a.N / 16, splitk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(rowgemm_kernel, dim3(a.N / 16, splitk, (a.M + 63) / 64), dim3(256), 0, st, a);
     (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }

@@ -352,9 +352,9 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     cur_B = B;
     static const int dbg = [] { const char* v = getenv("BOFI_DBG_TAIL_ONLY"); return v ? atoi(v) : 0; }();     // developer knob: bit 0 on -> run only the stages whose bits (2,4,8,16,32) are set
     const bool all = !(dbg & 1);
-    // at most 64 images in bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
+    // bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
     static const bool lean_on = [] { const char* v = getenv("BOFI_BOUND_LEAN"); return !v || atoi(v) != 0; }();
-    if (all && lean_on && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && B <= 64 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4) {
+    if (all && lean_on && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4) {
         const int* skip = early ? st.counters : nullptr;
         {   bofi::BoundQAttnArgs a{};
             a.x = (const uint16_t*)byb; a.stats = st_b; a.wq = (const uint16_t*)b_q_src.w; a.bias = b_q_src.b; a.colsum = b_q_src.cs;
