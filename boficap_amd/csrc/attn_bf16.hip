@@ -33,19 +33,15 @@ struct AttnParamsB {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// LDS row strides in elements.  Q and K are read row-wise (ds_read_b128): 64 + 8 pad = 144 B is conflict-free for those.  V is read
-// with the transposing read, which is banked per 32-lane half = 8 rows x 32 B (MI355X_MICROARCH.md, LDS): the 8 segments tile the
-// 256-byte bank row only if the stride is an odd multiple of 32 B -> 64 + 16 pad = 160 B.  With V at 144 B too,
-// SQ_LDS_BANK_CONFLICT was 25 % of this kernel's LDS cycles; with all three tiles at 160 B the extra LDS cost the decode a
-// workgroup per CU.
-constexpr int AROW = 72, VROW = 80;
+// LDS row stride of the V tile in elements.  It is read with the transposing read, which is banked per 32-lane half = 8 rows x 32 B
+// (MI355X_MICROARCH.md, LDS): the 8 segments tile the 256-byte bank row only if the stride is an odd multiple of 32 B -> 64 + 16 pad
+// = 160 B (with 144 B SQ_LDS_BANK_CONFLICT was 25 % of this kernel's LDS cycles).
+constexpr int VROW = 80;
 
 template <int NQT, int NKT, bool RAGGED = false>       // 16-row query tiles per block, 16-key tiles (even); RAGGED: per-item row ranges
 __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     static_assert(NKT % 2 == 0, "keys are consumed 32 at a time");
-    __shared__ __attribute__((aligned(16))) bf16_t sq[NQT * 16 * AROW];
-    __shared__ __attribute__((aligned(16))) bf16_t sk[NKT * 16 * AROW];
-    __shared__ __attribute__((aligned(16))) bf16_t sv[NKT * 16 * VROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sv[NKT * 16 * VROW];     // only V goes through LDS (transposing reads)
 
     if (p.skip_if_ge && *p.skip_if_ge >= p.skip_threshold) return;
     const int lane = threadIdx.x;
@@ -67,37 +63,40 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     int krow0 = bk * p.Lk, Lk = p.Lk;
     if constexpr (RAGGED) { if (p.k_ragged) { krow0 = qrow0; Lk = lq; } }
 
-    // ---- stage Q, K, V head slices (16-byte chunks; rows past the data are zero)
+    // ---- operands.  The Q and K fragments of the first product are rows of the head slices as they lie in memory (fragment row =
+    // lane & 15, eight consecutive d per lane quarter = one 16-byte load): they go straight into registers.  Only V is staged, for
+    // the transposing reads of the second product.  (With Q and K tiles in LDS as well a workgroup held 26 KB and six of them
+    // filled a CU; the kernel is a latency chain per wavefront, so the wavefronts in flight are what its throughput is.)
     const bf16_t* qg = p.q + ((size_t)qrow0 + q0) * p.ldq + h * 64;
     const bf16_t* kg = p.k + (size_t)krow0 * p.ldk + h * 64;
     const bf16_t* vg = p.v + (size_t)krow0 * p.ldv + h * 64;
     const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+    const int l15 = lane & 15, g = lane >> 4;
+    const bf16x8 zero8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 bq[NQT][2], ak[NKT][2];
 #pragma unroll
-    for (int c = lane; c < NQT * 16 * 8; c += 64) {
-        const int r = c >> 3, ch = c & 7;
-        *reinterpret_cast<u32x4*>(&sq[r * AROW + ch * 8]) = r < nq ? *reinterpret_cast<const u32x4*>(qg + (size_t)r * p.ldq + ch * 8) : zero4;
+    for (int qi = 0; qi < NQT; ++qi) {
+        const int r = qi * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bq[qi][s] = r < nq ? *reinterpret_cast<const bf16x8*>(qg + (size_t)r * p.ldq + s * 32 + g * 8) : zero8;
+    }
+#pragma unroll
+    for (int kj = 0; kj < NKT; ++kj) {
+        const int r = kj * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ak[kj][s] = r < Lk ? *reinterpret_cast<const bf16x8*>(kg + (size_t)r * p.ldk + s * 32 + g * 8) : zero8;
     }
 #pragma unroll
     for (int c = lane; c < NKT * 16 * 8; c += 64) {
         const int r = c >> 3, ch = c & 7;
-        const bool ok = r < Lk;
-        *reinterpret_cast<u32x4*>(&sk[r * AROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(kg + (size_t)r * p.ldk + ch * 8) : zero4;
-        *reinterpret_cast<u32x4*>(&sv[r * VROW + ch * 8]) = ok ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * p.ldv + ch * 8) : zero4;
+        *reinterpret_cast<u32x4*>(&sv[r * VROW + ch * 8]) = r < Lk ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * p.ldv + ch * 8) : zero4;
     }
-    __syncthreads();
 
-    const int l15 = lane & 15, g = lane >> 4;
     // ---- S^T[key][q] = K Q^T: A = K rows (key on the MFMA row), B = Q rows (query on the column)
-    bf16x8 bq[NQT][2];
-#pragma unroll
-    for (int qi = 0; qi < NQT; ++qi)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) bq[qi][s] = *reinterpret_cast<const bf16x8*>(&sq[(qi * 16 + l15) * AROW + s * 32 + g * 8]);
     f32x4 st[NKT][NQT];
 #pragma unroll
     for (int kj = 0; kj < NKT; ++kj) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&sk[(kj * 16 + l15) * AROW + g * 8]);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&sk[(kj * 16 + l15) * AROW + 32 + g * 8]);
+        const bf16x8 a0 = ak[kj][0], a1 = ak[kj][1];
 #pragma unroll
         for (int qi = 0; qi < NQT; ++qi) {
             f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -164,6 +163,7 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
     }
 
     // ---- O^T[d][q] = V^T P^T: A = V^T via the transposing read of the row-major V tile
+    __syncthreads();                                  // one wavefront: orders the V tile's writes before the transposing reads
     f32x4 ot[4][NQT];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)

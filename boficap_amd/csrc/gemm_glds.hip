@@ -403,6 +403,8 @@ static bool launch_specialised(const Gemm2Params& p, int bm, int bn, int ns, int
             if (bm == 64 && bn == 64 && ns == 4) { launch_one<T, 64, 64, 4, 4, 2, FEAT>(p, st); return true; }
             if (bm == 64 && bn == 64 && ns == 6) { launch_one<T, 64, 64, 6, 4, 2, FEAT>(p, st); return true; }
             if (bm == 64 && bn == 64 && ns == 9) { launch_one<T, 64, 64, 9, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 128 && bn == 64 && ns == 3) { launch_one<T, 128, 64, 3, 4, 2, FEAT>(p, st); return true; }
+            if (bm == 64 && bn == 64 && ns == 3) { launch_one<T, 64, 64, 3, 4, 2, FEAT>(p, st); return true; }
             if (bm == 128 && bn == 64 && ns == 4) { launch_one<T, 128, 64, 4, 4, 2, FEAT>(p, st); return true; }
             if (bm == 128 && bn == 64 && ns == 6) { launch_one<T, 128, 64, 6, 4, 2, FEAT>(p, st); return true; }
             if (bm == 128 && bn == 128 && ns == 3) { launch_one<T, 128, 128, 3, 4, 2, FEAT>(p, st); return true; }

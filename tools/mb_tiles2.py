@@ -8,7 +8,7 @@ import torch
 from boficap_amd import hip as H
 
 lib = H.lib()
-CONFIGS = ["64x64x2x8", "64x64x4x8", "64x64x6x8", "64x64x9x8", "128x64x2x8", "128x64x4x8", "128x64x6x8", "128x128x3x8", "128x128x4x8",
+CONFIGS = ["64x64x2x8", "64x64x3x8", "128x64x3x8", "64x64x4x8", "64x64x6x8", "64x64x9x8", "128x64x2x8", "128x64x4x8", "128x64x6x8", "128x128x3x8", "128x128x4x8",
            "64x128x4x8", "64x128x6x8", "256x128x3x8"]
 SHAPES = ["2304x1536x512xc", "2304x512x512xp", "2304x2048x512xc", "2304x512x2048xp", "1280x1536x512xc", "1280x512x512xp", "1280x512x512xc",
           "1280x2048x512xc", "1280x512x2048xp", "2304x7168x512xc"]
