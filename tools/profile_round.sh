@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root): kernel-trace statistics of the
-# headline bench (4 decodes in flight and one at a time), a one-decode timeline, HBM-side traffic and MFMA counters (separate
-# --pmc passes, counters only), and the XE step's kernel statistics.  Summaries land in gpurun_out/prof/ (copy into profiles/).
+# default bench (4 batches of 64 per launch: 4 launches in flight, and one launch at a time), a one-launch timeline, HBM-side traffic
+# (both batchings) and MFMA counters (separate --pmc passes, counters only), and the XE step's kernel statistics.
+# Summaries land in gpurun_out/prof/ (copy into profiles/).  "step" in the summaries = one engine launch.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
@@ -10,25 +11,28 @@ rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline"
 run() { name=$1; shift; rocprofv3 "$@" > $OUT/$name.log 2>&1 || { echo "rocprofv3 $name failed"; tail -5 $OUT/$name.log; }; }
-# 1. kernel statistics
+# 1. kernel statistics of the default command (coalesce 4): steps / 4 launches per leg
 run ks4 --kernel-trace --stats -d $OUT/ks4 -o ks4 -- $B --steps 200 --warmup 20
 run ks1 --kernel-trace --stats -d $OUT/ks1 -o ks1 -- $B --inflight 1 --steps 200 --warmup 20
-# 2. timeline of one decode
+# 2. timeline of one launch
 run tl --kernel-trace --output-format csv -d $OUT/tl -o tl -- $B --inflight 1 --steps 40 --warmup 8
-# 3. counters (own passes)
-run fetch --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- $B --inflight 1 --steps 20 --warmup 4
-run write --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- $B --inflight 1 --steps 20 --warmup 4
-run mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $OUT/mfma -o mfma -- $B --inflight 1 --steps 20 --warmup 4
+# 3. counters (own passes): default batching, and one batch per launch
+run fetch --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- $B --inflight 1 --steps 40 --warmup 8
+run write --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- $B --inflight 1 --steps 40 --warmup 8
+run fetch1 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch1 -o fetch -- $B --coalesce 1 --inflight 1 --steps 20 --warmup 4
+run write1 --pmc WRITE_SIZE --kernel-trace -d $OUT/write1 -o write -- $B --coalesce 1 --inflight 1 --steps 20 --warmup 4
+run mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $OUT/mfma -o mfma -- $B --inflight 1 --steps 40 --warmup 8
 # 4. XE step
 run xe --kernel-trace --stats -d $OUT/xe -o xe -- python3 $R/bench.py --mode xe --steps 10 --warmup 3 --no-cpu-baseline
 cd $R
 db() { ls $OUT/$1/*.db 2>/dev/null | head -1; }
-# the bench's in-flight run also times the same steps one at a time: 200 + 20 warm-up + 200 + 20 + 2 probes
-python tools/prof_db.py $(db ks4) 445 24 > $OUT/${TAG}_inflight4_kernel_stats.txt 2>&1
-python tools/prof_db.py $(db ks1) 222 24 > $OUT/${TAG}_one_at_a_time_kernel_stats.txt 2>&1
-python tools/prof_timeline.py $(ls $OUT/tl/*kernel_trace.csv | head -1) > $OUT/${TAG}_one_decode_timeline.txt 2>&1
-python tools/pmc_traffic.py $(db fetch) $(db write) 26 > $OUT/${TAG}_hbm_traffic.json 2>&1
+# launches per process: in-flight leg (5 + 50) + one-at-a-time leg (5 + 50) + 3 eager probes (two batches get reordered) + 4 captures; --inflight 1: 5 + 50 + 3 + 1
+python tools/prof_db.py $(db ks4) 117 24 > $OUT/${TAG}_inflight4_kernel_stats.txt 2>&1
+python tools/prof_db.py $(db ks1) 59 24 > $OUT/${TAG}_one_at_a_time_kernel_stats.txt 2>&1
+python tools/prof_timeline.py $(ls $OUT/tl/*kernel_trace.csv | head -1) > $OUT/${TAG}_one_launch_timeline.txt 2>&1
+python tools/pmc_traffic.py $(db fetch) $(db write) 16 > $OUT/${TAG}_hbm_traffic_coalesce4.json 2>&1
+python tools/pmc_traffic.py $(db fetch1) $(db write1) 26 > $OUT/${TAG}_hbm_traffic.json 2>&1
 python tools/pmc_summary.py $(db mfma) 16 > $OUT/${TAG}_mfma_util_pmc.json 2>&1
 python tools/prof_db.py $(db xe) 14 30 > $OUT/${TAG}_xe_step_kernel_stats.txt 2>&1
-rm -rf $OUT/ks4 $OUT/ks1 $OUT/tl $OUT/fetch $OUT/write $OUT/mfma $OUT/xe
+rm -rf $OUT/ks4 $OUT/ks1 $OUT/tl $OUT/fetch $OUT/write $OUT/fetch1 $OUT/write1 $OUT/mfma $OUT/xe
 ls -la $OUT
