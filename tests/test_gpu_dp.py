@@ -1,0 +1,106 @@
+"""Two data-parallel ranks on ONE MI355X (process group: gloo over device tensors -- RCCL refuses two ranks on one device, and the
+GPU box has a single card): XETrainer.step with the chunked gradient exchange and the per-chunk optimiser, eager and as a captured
+step graph.  The ranks' parameters must stay bit-equal, and equal -- to float32 summation order -- those of ONE process stepping on
+the concatenated batch (the mean of the per-rank gradients is the reference's loss.mean() over DataParallel replicas,
+tools/train.py:217; with equal token counts per shard that is the gradient of the concatenated batch)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_IMG, SPI, STEPS = 2, 3, 3
+
+
+def _setup(train_dtype):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import captioning.models as models
+    from boficap_amd import weights as W
+    from boficap_amd.config import TINY
+    cfg = TINY
+    sd = W.make_state_dict(cfg, 0, gen_scale=6.0)
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.cuda().eval()                                # eval: no dropout, so sharded and concatenated steps see the same function
+    model.train_dtype = train_dtype
+    model.opt.noamopt_warmup = 10                              # learning rates large enough to move float32 weights visibly
+    return cfg, model
+
+
+def _shard(cfg, rank, step):
+    """Rank `rank`'s batch of step `step`: the SAME captions on every rank (equal token counts), its own region features."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.weights import synthetic_att_feats
+    hb = synthetic_training_batch(cfg, N_IMG, SPI, seed=40 + step)
+    att = synthetic_att_feats(N_IMG, 36, cfg.att_feat_size, seed=1000 * rank + step)
+    return hb, att
+
+
+def _run_steps(cfg, model, graph, ranks):
+    from boficap_amd.trainer import XETrainer
+    tr = XETrainer(model, graph=graph)
+    for step in range(STEPS):
+        parts = [_shard(cfg, r, step) for r in ranks]
+        hb = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
+        batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+        batch["att_feats"] = torch.from_numpy(np.concatenate([p[1] for p in parts])).cuda()
+        batch["max_phrase_num"] = int(hb["phrase_num"].max())
+        tr.step(tr.add_token_rows(batch, hb))
+    torch.cuda.synchronize()
+    return tr.bucket.flat[:tr.bucket.live_numel].detach().cpu()
+
+
+def _worker(rank, world, port, ret, graph, wire):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    from boficap_amd import dp
+    torch.cuda.set_device(0)
+    dp.init_from_env("gloo")
+    cfg, model = _setup(torch.float32)
+    if wire:
+        model.opt.bofi_dp_wire = wire
+    flat = _run_steps(cfg, model, graph, [rank])
+    ret.put((rank, flat.numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_on_one_gpu_equal_one_process_on_the_concatenated_batch(graph):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")                              # fresh children: nothing of this process's HIP state is inherited
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, graph, None)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0], got[1]), "the ranks' parameters diverged"
+    cfg, model = _setup(torch.float32)
+    from boficap_amd.trainer import XETrainer                 # (the live prefix of a fresh bucket = the initial weights)
+    before = XETrainer(model).bucket
+    init = before.flat[:before.live_numel].detach().cpu().numpy().copy()
+    cfg, model = _setup(torch.float32)
+    one = _run_steps(cfg, model, graph, [0, 1]).numpy()
+    step_size = np.abs(one - init)
+    moved = step_size.max()
+    assert moved > 1e-4, "the optimiser did not move the weights"
+    # Adam normalises every gradient by its own magnitude: an element whose gradient is exactly zero in exact arithmetic (the key
+    # biases: softmax is shift-invariant) moves by +-lr on summation noise alone, with whichever sign the order of the additions
+    # produced.  So: nearly all elements agree tightly, the disagreeing rest is a sliver, and nothing differs by more than the
+    # two sign choices can explain.
+    d = np.abs(got[0] - one)
+    assert float((d > 2e-3 * moved).mean()) < 5e-3, (float((d > 2e-3 * moved).mean()), float(d.max()), float(moved))
+    assert float(d.mean()) < 2e-3 * float(step_size.mean()), (float(d.mean()), float(step_size.mean()))
+    assert float(d.max()) <= 2.2 * moved
