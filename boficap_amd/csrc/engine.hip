@@ -350,11 +350,9 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     // has been produced by the previous bound_tail(..., BOUND_ATTN).
     const int d = cfg.d_model, dt = cfg.dtype;
     cur_B = B;
-    static const int dbg = [] { const char* v = getenv("BOFI_DBG_TAIL_ONLY"); return v ? atoi(v) : 0; }();     // developer knob: bit 0 on -> run only the stages whose bits (2,4,8,16,32) are set
-    const bool all = !(dbg & 1);
     // bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
     static const bool lean_on = [] { const char* v = getenv("BOFI_BOUND_LEAN"); return !v || atoi(v) != 0; }();
-    if (all && lean_on && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4) {
+    if (lean_on && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4) {
         const int* skip = early ? st.counters : nullptr;
         {   bofi::BoundQAttnArgs a{};
             a.x = (const uint16_t*)byb; a.stats = st_b; a.wq = (const uint16_t*)b_q_src.w; a.bias = b_q_src.b; a.colsum = b_q_src.cs;
@@ -380,8 +378,8 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
         const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
         return bound_tail(by3, parts, update ? nullptr : ext_syn, update ? nullptr : last, B, flags, len_logp, syn_logp, s);
     }
-    if (all || (dbg & 2)) { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
-    if (all || (dbg & 4)) {
+    { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
+    {
     bofi::AttnArgs a{};
     a.q = bq2; a.ldq = d; a.k = kv; a.v = (char*)kv + (size_t)d * tsz; a.ldk = a.ldv = kv_all.N;
     a.out = bctx2; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = R;
@@ -389,11 +387,11 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     if (early) { a.skip_if_ge = st.counters; a.skip_threshold = B; }
     ENG_OK(bofi::launch_attention(a, s));
     }
-    if (all || (dbg & 8)) { LinOpt o; o.residual = by1; o.ldr = d; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
+    { LinOpt o; o.residual = by1; o.ldr = d; o.early = early; o.stats_out = st_b; o.y2 = copy_t(byb);
       ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
-    if (all || (dbg & 16)) { LinOpt o; o.relu = 1; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
+    { LinOpt o; o.relu = 1; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
     const int w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;     // K = d_ff split 4 ways: 4x the workgroups, a quarter of the K loop
-    if (all || (dbg & 32)) { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
+    { LinOpt o; o.residual = by2; o.ldr = d; o.early = early; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
     // heads + bookkeeping, fused with the next iteration's row-0 self-attention
     const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
     ENG_OK(bound_tail(by3, w2parts, update ? nullptr : ext_syn, update ? nullptr : last, B, flags, len_logp, syn_logp, s));
