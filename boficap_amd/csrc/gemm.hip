@@ -282,7 +282,8 @@ double g_gemm_flops = 0.0, g_gemm_flops_skippable = 0.0;
 int launch_linear(const LinearArgs& a, hipStream_t st) {
     if (!a.x || !a.w || !a.y || a.M < 0 || a.N <= 0 || a.K <= 0) return BOFI_ERR_ARG;
     if (a.M == 0) return BOFI_OK;
-    (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
+    // (a row-list launch covers *m_dev <= M rows, a number the host does not know: it is left out of the tally rather than counted at capacity)
+    if (!a.row_idx) (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
     const bool bf = a.w_dtype == BOFI_DT_BF16;
     if (!bf && a.w_dtype != BOFI_DT_F32) return BOFI_ERR_ARG;
     if (a.x_dtype != a.w_dtype && a.x_dtype != BOFI_DT_F32) return BOFI_ERR_ARG;
