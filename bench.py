@@ -420,7 +420,8 @@ def run_rl(args, ctx, log, cpu=True):
             "note": "latency-bound at 50 captions: two sampling decodes (20 enqueued iterations each; the semi-autoregressive one runs a decoder "
                     "pass per phrase) with a host round trip for the scores, then the gradient pass.  No reference-structured FLOP figure "
                     "exists for this step (SURVEY.md 8d prices decode and XE only): achieved_executed / frac_executed = GEMM FLOPs this "
-                    "build launches per step (library tally; early-out iterations weighted by the share of active ones) / wall time per step"}
+                    "build launches per step (library tally; early-out iterations weighted by the share of active ones; the row-list GEMMs of the "
+                    "semi-autoregressive iterations >= 2 are not counted -- their row count lives on the device) / wall time per step"}
     roof.update(_executed(fl_fixed, fl_skip, share, ms, args.dtype))
     res = {"metric": "images/sec self-critical step (SAIC + NAIC sampling, re-forward, new_self_critical, backward, all-reduce, Adam)",
            "value": round(n_img * world * args.steps / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
