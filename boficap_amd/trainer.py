@@ -300,7 +300,8 @@ class XETrainer:
         if self.graph and not self._capturing():
             self._fwd_calls += 1
             self._step_word.fill_(self._fwd_calls)             # outside any graph: every step draws new dropout masks
-            if batch.get("att_masks") is None and batch.get("max_phrase_num") is not None:
+            # (scheduled sampling decides on the host between its iterations: it cannot live in a captured graph)
+            if batch.get("att_masks") is None and batch.get("max_phrase_num") is not None and not getattr(self.model, "ss_prob", 0.0) > 0:
                 return self._replay(batch, glat_p)
         return self._forward_backward_eager(batch, glat_p)
 
@@ -372,6 +373,9 @@ class XETrainer:
         if batch.get("max_tokens") is not None:                # dynamic padding: decoder positions past the longest caption are skipped
             xe.HINTS["max_tokens"] = self._bucket(batch["max_tokens"], self.model.cfg.seq_length)
         compact = batch.get("token_rows") is not None and batch.get("max_tokens") is not None
+        if getattr(self.model, "ss_prob", 0.0) > 0:            # scheduled sampling: the SA branch follows the model's own layout, not the
+            compact = False                                    # loader's -- no row lists, the reference's dense criterion
+            xe.HINTS.pop("max_phrase_num", None); xe.HINTS.pop("max_tokens", None)
         if compact:                                            # project only the real tokens' rows onto the vocabulary
             xe.HINTS["token_rows"] = batch["token_rows"]
             if batch.get("row_cap") is not None:               # ... and run the decoder on those rows only

@@ -234,11 +234,9 @@ class TransformerModel(nn.Module):
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None, phrase_num=None, phrase_length=None, phrase_syn=None,
                  extend_phrase_syn_seq=None, extend_phrase_seq=None, extend_phrase_seq_mask=None, glat_p=-1.0):
-        """TransformerModel.py:1713-1724,1759-1775 (train_mode 'UIC', ss_prob 0): the six log-prob tensors, with the
+        """TransformerModel.py:1713-1724,1759-1775 (train_mode 'UIC'; ss_prob > 0: the scheduled-sampling form): the six log-prob tensors, with the
         autograd tape running over the HIP kernels (boficap_amd/xe.py).  float32."""
         from . import xe
-        if self.ss_prob > 0:
-            raise NotImplementedError("scheduled sampling (ss_SAIC, TransformerModel.py:1760-1766) is not built")
         if phrase_num is None:
             raise hip.BofiHipError("the UIC forward needs the phrase tensors of the loader (dataloader.py:343-428)")
         if next(self.parameters()).device.type != "cuda":
@@ -247,6 +245,10 @@ class TransformerModel(nn.Module):
         step_word = getattr(self, "_drop_step_word", None)     # set by a graph-capturing trainer: the step lives on the device
         base = int(getattr(self.opt, "seed", 0)) << 32
         seed = (base if step_word is not None else base + self._step) if self.training else None
+        if self.ss_prob > 0:                                   # scheduled sampling (tools/train.py:159-162): ss_SAIC for the SA branch
+            return xe.forward_uic_ss(xe.Params(self), self.cfg, att_feats, seq, att_masks, phrase_num, phrase_length, phrase_syn,
+                                     extend_phrase_syn_seq, ss_prob=float(self.ss_prob), draw=getattr(self, "_ss_draw", None),
+                                     training=self.training, seed=seed, compute_dtype=self.train_dtype, step_word=step_word)
         return xe.forward_uic(xe.Params(self), self.cfg, att_feats, seq, att_masks, phrase_num, phrase_length, phrase_syn,
                               extend_phrase_syn_seq, extend_phrase_seq, extend_phrase_seq_mask, glat_p=float(glat_p),
                               training=self.training, seed=seed, compute_dtype=self.train_dtype, step_word=step_word)

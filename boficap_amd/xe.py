@@ -892,7 +892,7 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     qv = q0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
     if _shadow(q0) is not None:                                 # bf16 mode: the virtual queries' bf16 copy, so that the bf16 / MFMA attention kernels run
         _register_shadow(qv, _shadow(q0).unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d))
-    xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d)
+    xv = x0.unsqueeze(1).expand(N, Pm, d).reshape(N * Pm, d).contiguous()     # (one pass: reshape alone would hand out the strided row-0 view)
     ctx = attention(qv, kv, 0, 0, d, N, H, Pm, L, 1, klen_pass, Pm, 1, 0, drop.attn())
     x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xv)
     xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
@@ -1076,6 +1076,182 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     x = decode_rows(P, cfg, drop, emb(fill_in, syn_mid, Sd), memory, kv_cache, N, Sd, R, spi, klen_na, att_len_cap, token_rows is None)
     na_tok = token_logprobs(x)
     return pad_slots(sa_len), pad_slots(sa_syn), sa_tok, pad_slots(na_len), pad_slots(na_syn), na_tok
+
+
+@_scoped_compute_dtype
+def forward_uic_ss(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, *, ss_prob: float,
+                   draw=None, training: bool = False, seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float32,
+                   step_word: Optional[torch.Tensor] = None):
+    """The six log-prob tensors of TransformerModel._forward with scheduled sampling on (ss_prob > 0, TransformerModel.py:1760-1766):
+    the SA branch is ss_SAIC (:1988-2121), the NA branch the teacher-forced one without a glancing pass.
+
+    ss_SAIC is a per-phrase loop whose every iteration runs a bounding step and a full decode_SA pass WITH the tape.  What it
+    differentiates, though, is a function of the loop's final inputs only: the bounding step of iteration i reads the words
+    emitted before it (its [LEN] row sees keys < phrase_last), and the decoder rows of phrase i see keys < its own end, all of
+    them final once the phrase is placed -- later iterations neither change those inputs nor those rows' masks.  So the loop runs
+    here WITHOUT the tape (decisions: greedy slots and tokens, the reference's bookkeeping on the host, ``draw()`` standing for
+    its ``random()`` calls in their order), and the tape then sees ONE batched bounding pass over (caption, iteration) queries
+    and ONE decoder pass on the final inputs; rows the loop never wrote are zero, as in the reference's zero-initialised
+    buffers.  Same outputs and gradients (tests/golden/tiny_ss.npz).  With dropout on, the decisions are taken without dropout
+    and the differentiated pass applies it (the reference does both in one stochastic pass)."""
+    import random as _random
+    import numpy as np
+    dev = att_feats.device
+    S, L, d = cfg.seq_length, cfg.seq_length + 2, cfg.d_model
+    if cfg.N_len != 1:
+        raise NotImplementedError("training with N_len >= 2 (see forward_uic)")
+    draw = draw if draw is not None else _random.random
+    for k in ("max_phrase_num", "max_tokens", "token_rows", "unpadded", "streams", "paired", "pick_labels", "paired_inputs"):
+        HINTS.pop(k, None)                                     # the row-list fast paths describe the ground-truth layout: not this pass
+    _COMPUTE["dtype"] = compute_dtype
+    _STEP_CACHE.clear()
+    _SHADOW_ONLY.clear()
+    if labels.dim() == 3:
+        labels = labels.reshape(-1, labels.shape[2])
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        phrase_syn = phrase_syn.reshape(-1, phrase_syn.shape[2])
+        extend_phrase_syn_seq = extend_phrase_syn_seq.reshape(-1, extend_phrase_syn_seq.shape[2])
+    att_len = None
+    if att_masks is not None:
+        max_len = int(att_masks.long().sum(1).max())
+        att_feats, att_masks = att_feats[:, :max_len].contiguous(), att_masks[:, :max_len]
+        att_len = att_masks.long().sum(1).to(torch.int32).contiguous()
+    att_feats = _need(att_feats.float() if att_feats.dtype != torch.float32 else att_feats, "att_feats")
+    B, R, _ = att_feats.shape
+    N = labels.shape[0]
+    spi = N // B
+    att_len_cap = None if att_len is None else att_len.repeat_interleave(spi).contiguous()
+    tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
+    pe = P["model.pos_embed.pe"]
+    lab_h = labels.cpu().numpy().astype(np.int64)
+    plen_h = phrase_length.cpu().numpy().astype(np.int64)
+    psyn_h = phrase_syn.cpu().numpy().astype(np.int64)
+
+    def make_emb(dr):
+        def emb(tok, syn, Lp):
+            x = embed(P[tname] if tok is not None else None, P[sname] if syn is not None else None, pe, tok, syn, Lp,
+                      P.g(tname) if tok is not None else None, P.g(sname) if syn is not None else None, None)
+            return dr(x) if dr.on and dr.p > 0.0 else x
+        return emb
+
+    t = lambda a, dt=torch.int64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+
+    # ---- the loop, no tape, no dropout (TransformerModel.py:2011-2119)
+    ppl = np.zeros((N, L), np.int64); pps = np.full((N, L), cfg.pad_idx, np.int64)
+    seq = np.full((N, L), cfg.pad_idx, np.int64)
+    ext_len = np.full((N, L), cfg.pad_idx, np.int64); ext_phrase = np.full((N, L), cfg.pad_idx, np.int64)
+    ext_syn = np.full((N, L), cfg.pad_idx, np.int64)
+    row_end = np.zeros((N, L), np.int64)                       # keys (a prefix) row r of phrase_mask sees
+    written = np.zeros((N, L), bool)
+    finished = np.zeros(N, bool)
+    label_last = np.zeros(N, np.int64); seq_last = np.zeros(N, np.int64); phrase_last = np.ones(N, np.int64)
+    seq[:, 0], ppl[:, 0], ext_len[:, 0] = cfg.bos_idx, 1, cfg.len_idx
+    klen_iters = []
+
+    def stretch(dst, pl, cur, src, s0, prev):                  # the position-wise copy (:2054-2067, :2079-2092)
+        if cur <= prev:
+            dst[pl:pl + cur] = src[s0 + prev - cur: s0 + prev]
+        else:
+            pre_less, times, copied = prev - (cur % prev), cur // prev, 0
+            for k in range(prev):
+                n = times if k < pre_less else times + 1
+                dst[pl + copied: pl + copied + n] = src[s0 + k]
+                copied += n
+
+    off = _Drop(cfg.dropout, cfg.drop_prob_lm, None, None)
+    emb0 = make_emb(off)
+    with torch.no_grad():
+        memory0 = encode_memory(P, cfg, att_feats, att_len, off)
+        kv0: dict = {}
+        for i in range(1, L):
+            klen_iters.append(phrase_last.copy())
+            len_lp, syn_lp = bound_teacher_forced(P, cfg, off, emb0(t(ext_len), None, L), memory0, kv0, N, L, R, spi,
+                                                  t(phrase_last.reshape(N, 1), torch.int32), att_len_cap)
+            len_n = len_lp.view(N, -1).cpu().numpy().argmax(1)           # first maximal index, as torch.max on the CPU
+            syn_n = syn_lp.view(N, -1).cpu().numpy().argmax(1)
+            for j in range(N):
+                if finished[j]:
+                    continue
+                ln, sn, pl = int(len_n[j]), int(syn_n[j]), int(phrase_last[j])
+                if ln == 0 or sn < 4 or sn > 6 or plen_h[j, i] == 0:     # SA_SYN_LOWER / SA_SYN_UPPER
+                    finished[j] = True
+                    continue
+                if ln + pl >= L - 1:
+                    ln = L - 1 - pl
+                    finished[j] = True
+                ppl[j, i], pps[j, i] = ln, sn
+            for j in range(N):
+                if ppl[j, i] == 0:
+                    continue
+                pl = int(phrase_last[j])
+                if draw() < ss_prob:
+                    cur = int(ppl[j, i])
+                    ext_syn[j, pl:pl + cur] = pps[j, i]
+                    if draw() < 0.5:
+                        stretch(ext_phrase[j], pl, cur, seq[j], int(seq_last[j]), int(ppl[j, i - 1]))
+                    else:
+                        ext_phrase[j, pl:pl + cur] = cfg.bos_idx
+                else:
+                    cur = min(int(plen_h[j, i]), L - 1 - pl)
+                    ppl[j, i] = cur
+                    ext_syn[j, pl:pl + cur] = psyn_h[j, i]
+                    stretch(ext_phrase[j], pl, cur, lab_h[j], int(label_last[j]), int(plen_h[j, i - 1]))
+                row_end[j, pl:] = pl + cur
+            klen_dec = np.maximum(row_end[:, 1:1 + S] - 1, 0)
+            if (klen_dec == 0).any():
+                raise FloatingPointError("ss_SAIC: a caption without any key -- NaN log-probs; the reference returns a malformed tuple here "
+                                         "(TransformerModel.py:2103-2105)")
+            x = decode_rows(P, cfg, off, emb0(t(ext_phrase[:, 1:-1]), t(ext_syn[:, 1:-1]), S), memory0, kv0, N, S, R, spi,
+                            t(klen_dec, torch.int32), att_len_cap)
+            tok = greedy_ids(P.lin(x, "model.generator.proj")).view(N, S).cpu().numpy()
+            for j in range(N):
+                cur = int(ppl[j, i])
+                if cur == 0:
+                    continue
+                pl = int(phrase_last[j])
+                seq[j, pl:pl + cur] = tok[j, pl - 1: pl - 1 + cur]
+                ext_len[j, pl:pl + cur] = tok[j, pl - 1: pl - 1 + cur]
+                written[j, pl:pl + cur] = True
+                phrase_last[j] = pl + cur
+                seq_last[j] += int(ppl[j, i - 1])
+                label_last[j] += int(plen_h[j, i - 1])
+            if finished.all():
+                break
+    n_it = len(klen_iters)
+
+    # ---- the differentiated passes
+    _STEP_CACHE.clear()
+    _SHADOW_ONLY.clear()
+    P._packed.clear()                                          # (stacked q|k|v operands made without the tape above carry no gradient)
+    drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None, step_word)
+    emb = make_emb(drop)
+    memory = encode_memory(P, cfg, att_feats, att_len, drop)
+    kv_cache: dict = {}
+
+    def pad_slots(x, Pm):
+        out = x.new_zeros(N, L - 1, x.shape[2])
+        out[:, :Pm] = x
+        return out
+
+    klen_pass = t(np.stack(klen_iters, 1), torch.int32)                     # [N, iterations]: keys of the [LEN] row per iteration
+    sa_len, sa_syn = bound_teacher_forced(P, cfg, drop, emb(t(ext_len), None, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
+    klen_dec = t(np.maximum(row_end[:, 1:1 + S] - 1, 0), torch.int32)
+    x = decode_rows(P, cfg, drop, emb(t(ext_phrase[:, 1:-1]), t(ext_syn[:, 1:-1]), S), memory, kv_cache, N, S, R, spi, klen_dec, att_len_cap)
+    sa_tok = log_softmax(P.lin(x, "model.generator.proj")).view(N, S, -1)
+    sa_tok = torch.where(t(written[:, 1:1 + S], torch.bool).unsqueeze(-1), sa_tok, torch.zeros_like(sa_tok))
+
+    # ---- non-autoregressive branch, teacher-forced (:1764-1766)
+    labels_d, phrase_num_d, phrase_length_d = labels.to(dev).long(), phrase_num.to(dev).long(), phrase_length.to(dev).long()
+    ext_syn_gt = extend_phrase_syn_seq.to(dev).long().contiguous()
+    klen_gt, last, Pm = bound_pass_klen(phrase_num_d, phrase_length_d)
+    na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn_gt, L), memory, kv_cache, N, L, R, spi, klen_gt, att_len_cap)
+    klen_na = (last - 1).unsqueeze(1).expand(N, S).contiguous()
+    fill_in = torch.full((N, S), cfg.bos_idx, dtype=torch.int64, device=dev)
+    x = decode_rows(P, cfg, drop, emb(fill_in, ext_syn_gt[:, 1:1 + S].contiguous(), S), memory, kv_cache, N, S, R, spi, klen_na, att_len_cap)
+    na_tok = log_softmax(P.lin(x, "model.generator.proj")).view(N, S, -1)
+    HINTS["ss_trace"] = dict(iters=n_it, emitted=seq[:, 1:-1].copy(), predict_phrase_length=ppl.copy())
+    return pad_slots(sa_len, n_it), pad_slots(sa_syn, n_it), sa_tok, pad_slots(na_len, Pm), pad_slots(na_syn, Pm), na_tok
 
 
 def _glance_draws(N: int, S: int, dev) -> torch.Tensor:

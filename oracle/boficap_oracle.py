@@ -452,6 +452,144 @@ def forward_uic(w: Weights, cfg, att_feats, labels, att_masks, phrase_num, phras
             na_len, na_syn, F.log_softmax(logit(w, na_phrase), dim=-1))
 
 
+def ss_saic(w: Weights, cfg, memory, src_mask, labels, phrase_num, phrase_length, phrase_syn, ss_prob: float, draw):
+    """Scheduled-sampling semi-autoregressive training pass, TransformerModel.ss_SAIC TM:1988-2121 (greedy, log-softmax): per phrase
+    a bounding step on the words emitted so far, then -- per caption -- with probability ss_prob the model's own slot (half of the
+    time with the previous emitted phrase copied position-wise as decoder input, otherwise [BOS] only), else the ground-truth slot
+    and the previous ground-truth phrase; a full decode_SA pass; the new phrase's greedy tokens and log-probs are kept.
+    ``draw()`` stands for ``random()`` (TM:2048,2049), called in the reference's order.  Gradients flow through the three
+    returned tensors as in the reference.  Returns (len_logp [B, L-1, 20], syn_logp [B, L-1, 10], tok_logp [B, S, V], trace)."""
+    B, L = phrase_length.shape
+    S = L - 2
+    V = w["model.generator.proj.weight"].size(0)
+    labels, phrase_length, phrase_syn = labels.long(), phrase_length.long(), phrase_syn.long()
+    ppn = torch.zeros(B, dtype=torch.int)
+    ppl = torch.zeros(B, L, dtype=torch.long)
+    pps = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    len_lps, syn_lps = [], []
+    seq = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    seq_logprobs = torch.zeros(B, L, V)
+    ext_len = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    ext_phrase = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    ext_syn = torch.full((B, L), cfg.pad_idx, dtype=torch.long)
+    len_mask = torch.zeros(B, L, L, dtype=torch.bool)
+    phrase_mask = torch.zeros(B, L, L, dtype=torch.bool)
+    finished = torch.zeros(B, dtype=torch.bool)
+    label_last = torch.zeros(B, dtype=torch.long)
+    seq_last = torch.zeros(B, dtype=torch.long)
+    phrase_last = torch.zeros(B, dtype=torch.long)
+    choices = []
+
+    def stretch(dst_row, pl, cur, src_row, s0, prev):        # the position-wise copy TM:2054-2067 / :2079-2092
+        if cur <= prev:
+            pre_pad = prev - cur
+            dst_row[pl:pl + cur] = src_row[s0 + pre_pad: s0 + pre_pad + cur]
+        else:
+            pre_less, times, copied = prev - (cur % prev), cur // prev, 0
+            for k in range(prev):
+                n = times if k < pre_less else times + 1
+                dst_row[pl + copied: pl + copied + n] = src_row[s0 + k]
+                copied += n
+
+    for i in range(1, L):
+        if i == 1:
+            seq[:, 0] = cfg.bos_idx
+            ppl[:, 0] = 1
+            ext_len[:, 0] = cfg.len_idx
+            len_mask[:, :, 0] = True
+            phrase_last[:] = 1
+        len_n, len_lp, syn_n, syn_lp = bound_step_sa(w, cfg, ext_len.clone(), memory, src_mask, len_mask)
+        len_lps.append(len_lp)
+        syn_lps.append(syn_lp)
+        for j in range(B):
+            if finished[j]:
+                continue
+            ln, sn, pl = int(len_n[j]), int(syn_n[j]), int(phrase_last[j])
+            if ln == 0 or sn < SYN_LOWER or sn > SYN_UPPER or int(phrase_length[j, i]) == 0:
+                finished[j] = True
+                continue
+            if ln + pl >= L - 1:
+                ln = L - 1 - pl
+                finished[j] = True
+            ppl[j, i], pps[j, i] = ln, sn
+            ppn[j] += 1
+        for j in range(B):
+            if int(ppl[j, i]) == 0:
+                continue
+            pl = int(phrase_last[j])
+            if draw() < ss_prob:
+                cur = int(ppl[j, i])
+                ext_syn[j, pl:pl + cur] = pps[j, i]
+                if draw() < 0.5:                               # the previous EMITTED phrase as input
+                    stretch(ext_phrase[j], pl, cur, seq[j], int(seq_last[j]), int(ppl[j, i - 1]))
+                    choices.append((i, j, "own"))
+                else:                                          # the slot's label only
+                    ext_phrase[j, pl:pl + cur] = cfg.bos_idx
+                    choices.append((i, j, "syn"))
+            else:                                              # ground truth as input
+                cur = min(int(phrase_length[j, i]), L - 1 - pl)
+                ppl[j, i] = cur
+                ext_syn[j, pl:pl + cur] = phrase_syn[j, i]
+                stretch(ext_phrase[j], pl, cur, labels[j], int(label_last[j]), int(phrase_length[j, i - 1]))
+                choices.append((i, j, "gt"))
+            phrase_mask[j, pl:, :pl + cur] = True
+        phrase = decode_sa(w, cfg, memory, ext_phrase.clone()[:, 1:-1], ext_syn.clone()[:, 1:-1], src_mask, phrase_mask[:, 1:-1, 1:-1])
+        phrase_logprobs = F.log_softmax(logit(w, phrase), dim=2)
+        if bool(phrase_logprobs.isnan().any()):
+            raise FloatingPointError("ss_SAIC: NaN log-probs (a caption without any key); the reference returns a malformed tuple here (TM:2103-2105)")
+        tok = torch.max(phrase_logprobs, 2)[1].long()
+        rows = torch.zeros(B, L, dtype=torch.bool)
+        for j in range(B):
+            cur = int(ppl[j, i])
+            if cur == 0:
+                continue
+            pl = int(phrase_last[j])
+            seq[j, pl:pl + cur] = tok[j, pl - 1: pl - 1 + cur]
+            rows[j, pl:pl + cur] = True
+            ext_len[j, pl:pl + cur] = tok[j, pl - 1: pl - 1 + cur]
+            len_mask[j, pl:, :pl + cur] = True
+            phrase_last[j] = pl + cur
+            len_mask[j, 0, :pl + cur] = True
+            seq_last[j] += int(ppl[j, i - 1])
+            label_last[j] += int(phrase_length[j, i - 1])
+        # seq_logprobs[j, pl:pl+cur] = phrase_logprobs[j, pl-1:pl-1+cur] for the rows just placed (out of place, for autograd)
+        shifted = torch.cat([torch.zeros(B, 1, V), phrase_logprobs, torch.zeros(B, 1, V)], 1)
+        seq_logprobs = torch.where(rows.unsqueeze(-1), shifted, seq_logprobs)
+        if bool(finished.all()):
+            break
+    n_it = len(len_lps)
+    pad = lambda xs, width: torch.cat([torch.stack(xs, 1), torch.zeros(B, L - 1 - n_it, width)], 1)
+    trace = dict(iters=n_it, choices=choices, seq=seq[:, 1:-1].clone(), predict_phrase_length=ppl.clone(), predict_phrase_num=ppn.clone())
+    return pad(len_lps, len_lps[0].shape[-1]), pad(syn_lps, syn_lps[0].shape[-1]), seq_logprobs[:, 1:-1, :], trace
+
+
+def forward_uic_ss(w: Weights, cfg, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq,
+                   ss_prob: float, draw):
+    """TransformerModel._forward with ss_prob > 0, TM:1760-1766: the SA branch from ss_saic, the NA branch teacher-forced without a
+    glancing pass.  Dropout off.  Returns the six log-prob tensors and ss_saic's trace."""
+    if labels.dim() == 3:
+        labels = labels.reshape(-1, labels.shape[2])
+        phrase_num = phrase_num.reshape(-1)
+        phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
+        phrase_syn = phrase_syn.reshape(-1, phrase_syn.shape[2])
+        extend_phrase_syn_seq = extend_phrase_syn_seq.reshape(-1, extend_phrase_syn_seq.shape[2])
+    x, src_mask = prepare_feature(w, cfg, att_feats, att_masks)
+    spi = labels.shape[0] // x.shape[0]
+    if spi > 1:
+        x = x.repeat_interleave(spi, dim=0)
+        src_mask = src_mask.repeat_interleave(spi, dim=0)
+    memory = encode(w, cfg, x, src_mask)
+    sa_len, sa_syn, sa_tok, trace = ss_saic(w, cfg, memory, src_mask, labels, phrase_num, phrase_length, phrase_syn, ss_prob, draw)
+    na_len, na_syn, last = _teacher_forced_bound(w, cfg, add_pe(w, embed(w, "model.syn_embed", extend_phrase_syn_seq, cfg.d_model)), memory,
+                                                 src_mask, phrase_num, phrase_length)
+    S = cfg.seq_length
+    syn_mask = torch.zeros(labels.shape[0], S, S, dtype=torch.bool)
+    for i in range(labels.shape[0]):
+        syn_mask[i, :, :int(last[i]) - 1] = True
+    na_phrase = decode_na(w, cfg, memory, extend_phrase_syn_seq[:, 1:-1], src_mask, syn_mask)
+    return (sa_len, sa_syn, sa_tok, na_len, na_syn, F.log_softmax(logit(w, na_phrase), dim=-1)), trace
+
+
 def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
     """LanguageModelCriterion_UIC.forward losses.py:319-369, reduction='mean', self_dis=False."""
     sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok = outs

@@ -239,6 +239,69 @@ def run_glat_case(name, cfg, sd, n_img, spi, seed, glat_p):
     return dict(n_img=n_img, spi=spi, glat_p=glat_p, loss=float(losses[0]), na_tok_change=changed)
 
 
+def run_ss_case(name, cfg, sd, n_img, spi, seed, ss_prob):
+    """XE forward + criterion + backward of the REAL reference with scheduled sampling on (model.ss_prob > 0: ss_SAIC TM:1988-2121
+    for the SA branch, TM:1760-1766), its ``random()`` draws (TM:2048-2049) replaced by an injected sequence; the oracle's loop
+    restatement must reproduce the six outputs and the loss from the same draws."""
+    import contextlib
+    import io
+    TMmod = sys.modules["captioning.models.TransformerModel"]      # (the package re-exports the class under the module's name)
+    from training_batch import make_training_batch
+    model = build_reference(cfg, sd)
+    model.ss_prob = ss_prob
+    w = O.as_torch(sd)
+    batch = make_training_batch(cfg, n_img, spi, seed=seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    att_np = W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=seed + 100)
+    att, fc = torch.from_numpy(att_np), torch.zeros(n_img, 0)
+    draws = np.random.default_rng(seed).random(4096)
+    args = (tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["extend_phrase_syn_seq"], tb["extend_phrase_seq"], tb["extend_phrase_seq_mask"])
+    used = [0]
+
+    def injected():
+        used[0] += 1
+        return float(draws[used[0] - 1])
+    real_random = TMmod.random
+    TMmod.random = injected
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            outs = model(fc, att, tb["labels"], None, *args)
+    finally:
+        TMmod.random = real_random
+    n_used = used[0]
+    it = iter(draws)
+    oouts, trace = O.forward_uic_ss(w, cfg, att, tb["labels"], None, tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"],
+                                    tb["extend_phrase_syn_seq"], ss_prob, lambda: float(next(it)))
+    kinds = {k: sum(1 for c in trace["choices"] if c[2] == k) for k in ("own", "syn", "gt")}
+    assert min(kinds.values()) >= 2, kinds                       # every input choice of TM:2048-2095 occurs
+    assert trace["iters"] >= 3 and int(trace["predict_phrase_num"].max()) >= 3, (trace["iters"], trace["predict_phrase_num"])
+    for i, (a, b) in enumerate(zip(outs, oouts)):
+        close(a, b, tol=1e-5, what=f"{name}: forward output {i}")
+    losses = LanguageModelCriterion_UIC()(*outs, tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["labels"])
+    ol, parts = O.criterion_uic(oouts, tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["labels"])
+    assert abs(float(losses[0]) - float(ol)) < 1e-5 and all(abs(float(a) - float(b)) < 1e-5 for a, b in zip(losses[1:], parts))
+    losses[0].backward()
+    res = {k: v for k, v in batch.items()}
+    res["att_feats"] = att_np
+    res["ss_prob"] = np.float32(ss_prob)
+    res["draws"] = draws[:n_used].astype(np.float64)
+    res["emitted_seq"] = trace["seq"].numpy()
+    for i, o in enumerate(outs):
+        res[f"out{i}"] = o.detach().numpy()
+    res["losses"] = np.array([float(x) for x in losses], np.float32)
+    names, norms, keep = [], [], {}
+    for k, p in model.named_parameters():
+        names.append(k)
+        norms.append(-1.0 if p.grad is None else float(p.grad.norm()))
+        if p.grad is not None and p.grad.numel() <= 4096:
+            keep["grad." + k] = p.grad.numpy().copy()
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array(norms, np.float32)
+    res.update(keep)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return dict(n_img=n_img, spi=spi, ss_prob=ss_prob, loss=float(losses[0]), draws_used=n_used, iters=trace["iters"], choices=kinds)
+
+
 def run_rl_loss_case(name, cfg, seed, n_img=3, sample_n=4):
     """The self-critical losses of the REAL reference on injected samples and scores:
       * StructureLosses('new_self_critical') (losses.py:37-51,157-176) with get_scores (the external CIDEr-D scorer,
@@ -418,6 +481,12 @@ def main():
     # the glancing pass of the XE forward with injected draws, the self-critical losses with injected scores, LossWrapper's XE branch
     manifest["tiny_glat"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t), **run_glat_case("tiny_glat", TINY, sd_t, 3, 2, 7, 0.5))
     print("tiny_glat", manifest["tiny_glat"])
+    # scheduled sampling (ss_prob > 0): the SA branch as ss_SAIC with injected draws; the [LEN]-row-shared weights make the
+    # semi-autoregressive bounding steps lay out several phrases (as tiny_saic_multi)
+    sd_ss = W.with_len_row_shared(W.make_state_dict(TINY, seed=0, gen_scale=1.0), TINY)
+    manifest["tiny_ss"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_ss), patch="len_row_shared",
+                               **run_ss_case("tiny_ss", TINY, sd_ss, 3, 2, 13, 0.5))
+    print("tiny_ss", manifest["tiny_ss"])
     manifest["tiny_rl_loss"] = dict(config="TINY", **run_rl_loss_case("tiny_rl_loss", TINY, 11))
     print("tiny_rl_loss", manifest["tiny_rl_loss"])
     manifest["tiny_loss_wrapper_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),

@@ -895,3 +895,62 @@ def test_attention_on_unpadded_rows(kdiv, self_attn, mfma):
         vval = kd.detach().bfloat16().float()[:, offs[2]:offs[2] + d]
         lhs, rhs = float((dout.cuda() * ob).sum()), float((vgrad * vval).sum())
         assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+def test_scheduled_sampling_step_vs_reference(weight_cache, manifest):
+    """model(..., mode='forward') with model.ss_prob > 0 (tools/train.py:159-162 -> TransformerModel.py:1760-1766, ss_SAIC
+    :1988-2121) against the REAL reference's outputs, loss and gradients for the same random() draws: the HIP path takes the
+    loop's decisions without the tape and differentiates one batched pass over its final inputs (xe.forward_uic_ss)."""
+    from boficap_amd import xe
+    cfg, model = _model(weight_cache, manifest, "tiny_ss")
+    model.eval()
+    g = load_golden("tiny_ss")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    fc = torch.zeros(g["att_feats"].shape[0], 0, device="cuda")
+    it = iter(g["draws"])
+    model.ss_prob = float(g["ss_prob"])
+    model._ss_draw = lambda: float(next(it))
+    outs = model(fc, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                 t("extend_phrase_syn_seq"), t("extend_phrase_seq"), t("extend_phrase_seq_mask"), -1.0)
+    assert next(it, None) is None                               # the reference's number of draws, in its order
+    assert (xe.HINTS.pop("ss_trace")["emitted"] == g["emitted_seq"]).all()
+    for i, o in enumerate(outs):
+        assert o.shape == g[f"out{i}"].shape
+        assert _maxdiff(o, torch.from_numpy(g[f"out{i}"])) < 1e-4, f"output {i}"
+    loss, parts = xe.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss.detach()) - float(g["losses"][0])) < 1e-3
+    loss.backward()
+    params = dict(model.named_parameters())
+    for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        p = params[n]
+        if ref_norm < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        assert abs(float(p.grad.double().norm()) - ref_norm) <= 2e-3 * max(ref_norm, 1e-3), (n, float(p.grad.double().norm()), float(ref_norm))
+        if "grad." + n in g:
+            ref_g = torch.from_numpy(g["grad." + n])
+            assert _maxdiff(p.grad, ref_g) <= 2e-3 * max(1e-3, float(ref_g.abs().max())), n
+
+
+def test_scheduled_sampling_trainer_step(weight_cache, manifest):
+    """XETrainer.step with ss_prob > 0 and dropout on, bf16 operands, graph=True requested: the step falls back to eager launches
+    (the loop decides on the host), the dense criterion, finite loss, weights move."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, model = _model(weight_cache, manifest, "tiny_ss")
+    model.train()
+    model.train_dtype = torch.bfloat16
+    model.ss_prob = 0.25
+    tr = XETrainer(model, graph=True)
+    hb = synthetic_training_batch(cfg, 3, 2, seed=3)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+    batch["att_feats"] = torch.from_numpy(synthetic_att_feats(3, 36, cfg.att_feat_size, seed=4)).cuda()
+    batch["max_phrase_num"] = int(hb["phrase_num"].max())
+    before = tr.bucket.flat.clone()
+    for _ in range(2):
+        loss, parts = tr.step(tr.add_token_rows(batch, hb))
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and len(tr._graphs) == 0
+    assert float((tr.bucket.flat - before).abs().max()) > 0

@@ -214,3 +214,32 @@ def test_oracle_two_layer_bounding_network(manifest, weight_cache):
     assert (seq.numpy() == g["naic_seq"]).all() and (pn.numpy() == g["naic_phrase_num"]).all()
     assert (pl.numpy() == g["naic_phrase_length"]).all() and (ps.numpy() == g["naic_phrase_syn"]).all()
     assert _close(lp.numpy(), g["naic_logprob"], 1e-5)
+
+
+def test_oracle_scheduled_sampling(manifest, weight_cache):
+    """TransformerModel._forward with ss_prob > 0 (ss_SAIC TM:1988-2121 for the SA branch), the reference's random() draws
+    injected: the six outputs, the loss and the gradient norms of the reference's own backward."""
+    m = manifest["tiny_ss"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    w = O.as_torch(sd)
+    for v in w.values():
+        v.requires_grad_(v.is_floating_point())
+    g = load_golden("tiny_ss")
+    assert min(m["choices"].values()) >= 2 and m["iters"] >= 3          # every input choice occurs, several phrases deep
+    t = lambda k: torch.from_numpy(g[k])
+    it = iter(g["draws"])
+    outs, trace = O.forward_uic_ss(w, cfg, t("att_feats"), t("labels"), None, t("phrase_num"), t("phrase_length"), t("phrase_syn"),
+                                   t("extend_phrase_syn_seq"), float(g["ss_prob"]), lambda: float(next(it)))
+    assert next(it, None) is None                                       # exactly the reference's number of draws
+    for i, o in enumerate(outs):
+        assert _close(o.detach().numpy(), g[f"out{i}"], 1e-5)
+    assert (trace["seq"].numpy() == g["emitted_seq"]).all()
+    loss, parts = O.criterion_uic(outs, t("phrase_num"), t("phrase_length"), t("phrase_syn"), t("labels"))
+    assert abs(float(loss) - float(g["losses"][0])) < 1e-4
+    loss.backward()
+    for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        p = w[n]
+        if ref_norm < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+        else:
+            assert abs(float(p.grad.norm()) - ref_norm) <= 1e-3 * max(float(ref_norm), 1e-3), n

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--input_label_h5", default="", help="label file of scripts/prepro_labels_stanford.py (captions and phrase cuts); needs h5py")
     ap.add_argument("--self_critical_after", type=int, default=-1, help="iteration from which the self-critical step replaces the XE step (-1: never)")
     ap.add_argument("--train_sample_n", type=int, default=5)
+    ap.add_argument("--scheduled_sampling_start", type=int, default=None, help="epoch from which ss_prob rises (opts.py:153-160; -1: never, the shipped configs)")
+    ap.add_argument("--iters_per_epoch", type=int, default=1000, help="the synthetic stream has no epochs of its own: iterations that count as one")
     args = ap.parse_args()
 
     import captioning.models as models
@@ -113,6 +115,13 @@ def main():
             rng = np.random.default_rng(seed)
             host_batch = store.batch(rng.integers(0, store.num_images, opt.batch_size), opt.seq_per_img, rng)
             gts = host_batch.pop("gts")
+        ss_start = args.scheduled_sampling_start if args.scheduled_sampling_start is not None else getattr(opt, "scheduled_sampling_start", -1)
+        epoch = it // max(1, args.iters_per_epoch)
+        infos["epoch"] = epoch
+        if ss_start >= 0 and epoch >= ss_start:                 # scheduled sampling probability (tools/train.py:159-162)
+            frac = (epoch - ss_start) // getattr(opt, "scheduled_sampling_increase_every", 5) + 1
+            opt.ss_prob = min(getattr(opt, "scheduled_sampling_increase_prob", 0.05) * frac, getattr(opt, "scheduled_sampling_max_prob", 0.25))
+            model.ss_prob = opt.ss_prob
         if 0 <= args.self_critical_after <= it:                 # struc_flag (tools/train.py:181-185)
             att = torch.from_numpy(W.synthetic_att_feats(opt.batch_size, 36, cfg.att_feat_size, seed=seed)).to(dev)
             refs = gts if gts is not None else [host_batch["labels"][b, :, 1:-1] for b in range(opt.batch_size)]
@@ -140,7 +149,16 @@ def main():
         batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(opt.batch_size, 36, cfg.att_feat_size, seed=seed)).to(dev)
         batch = trainer.add_token_rows(batch, host_batch)
         glat_p = args.unmasked_rate_start if args.glancing_token else -1.0          # train.py:165-170
-        loss, parts = trainer.step(batch, glat_p)
+        try:
+            loss, parts = trainer.step(batch, glat_p)
+        except FloatingPointError as e:                          # scheduled sampling on a model whose SA bounding step opens no phrase for
+            if not model.ss_prob > 0:                            # some caption: the reference crashes there (TransformerModel.py:2103-2105);
+                raise                                            # this batch is stepped teacher-forced instead
+            if rank == 0:
+                print(f"iter {it + 1}: {e}; teacher-forced step for this batch", flush=True)
+            keep, model.ss_prob = model.ss_prob, 0.0
+            loss, parts = trainer.step(batch, glat_p)
+            model.ss_prob = keep
         if (it + 1) % args.losses_log_every == 0 or it == 0:
             mean_loss = dp.reduce_scalar(float(loss), "sum", device=dev) / world
             if rank == 0:
