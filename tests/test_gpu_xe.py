@@ -954,3 +954,40 @@ def test_scheduled_sampling_trainer_step(weight_cache, manifest):
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and len(tr._graphs) == 0
     assert float((tr.bucket.flat - before).abs().max()) > 0
+
+
+def test_tools_eval_entry_point(tmp_path):
+    """python tools/eval.py (the reference's tools/eval.py:24-44,123 for this path): greedy NAIC decode of features with seeded
+    weights, per-image entropy / perplexity (eval_utils.py:463-464), predictions json, and -- with a label file in the schema of
+    scripts/prepro_labels_stanford.py:393-399 -- the validation loss of eval_split (eval_utils.py:440-453)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from boficap_amd.config import FULL as cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    S, N = cfg.seq_length, 8
+    ncap = np.full(N, 5)
+    M = int(ncap.sum())
+    labels, pnum = np.zeros((M, S), np.uint32), np.zeros(M, np.uint32)
+    plen, plab = np.zeros((M, S), np.uint32), np.zeros((M, S), np.uint32)
+    for m in range(M):
+        lens = rng.integers(1, 4, int(rng.integers(2, 6)))
+        pnum[m] = len(lens)
+        plen[m, :len(lens)] = lens
+        plab[m, :len(lens)] = rng.integers(4, 7, len(lens))
+        labels[m, :lens.sum()] = rng.integers(7, cfg.tgt_vocab, lens.sum())
+    end = np.cumsum(ncap).astype(np.uint32)
+    lab_path, out_path = str(tmp_path / "labels.npz"), str(tmp_path / "pred.json")
+    np.savez(lab_path, labels=labels, label_start_ix=(end - ncap + 1).astype(np.uint32), label_end_ix=end,
+             label_length=(labels > 0).sum(1).astype(np.uint32), phrase_num=pnum, phrase_length=plen, phrase_label=plab)
+    cmd = [sys.executable, os.path.join(root, "tools", "eval.py"), "--synthetic", str(N), "--batch_size", "8", "--dtype", "bf16",
+           "--input_label_npz", lab_path, "--dump_json", out_path]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f"decoded {N} images" in out.stdout
+    loss = float(out.stdout.split("validation loss")[1].split()[0])
+    assert np.isfinite(loss) and loss > 0
+    pred = json.load(open(out_path))
+    assert len(pred) == N and all(np.isfinite(p["entropy"]) and np.isfinite(p["perplexity"]) for p in pred if p["seq"])

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--batch_size", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--dump_json", default="")
+    ap.add_argument("--input_label_npz", default="", help="label arrays (schema of scripts/prepro_labels_stanford.py:393-399, as .npz, or .h5 with h5py): "
+                    "also report the validation loss of eval_split (eval_utils.py:440-453); image i of the features = image i of the file")
+    ap.add_argument("--seq_per_img", type=int, default=5)
     args = ap.parse_args()
 
     import captioning.models as models
@@ -56,11 +59,27 @@ def main():
     model.cuda().eval()
 
     feats = np.load(args.input_att_npy) if args.input_att_npy else W.synthetic_att_feats(args.synthetic, 36, model.cfg.att_feat_size, seed=1235)
+    store = None
+    if args.input_label_npz:
+        from boficap_amd.data import LabelStore
+        from boficap_amd.loss_wrapper import LanguageModelCriterion_UIC
+        c = model.cfg
+        src = args.input_label_npz if args.input_label_npz.endswith((".h5", ".hdf5")) else dict(np.load(args.input_label_npz))
+        store = LabelStore(src, pad_idx=c.pad_idx, bos_idx=c.bos_idx, eos_idx=c.eos_idx, len_idx=c.len_idx)
+        crit, rng, loss_sum, loss_evals = LanguageModelCriterion_UIC(), np.random.default_rng(0), 0.0, 0
     results, seconds = [], 0.0
     with torch.no_grad():
         for i in range(0, len(feats), args.batch_size):
             att = torch.from_numpy(np.ascontiguousarray(feats[i:i + args.batch_size])).cuda()
             fc = torch.zeros(att.size(0), 0, device="cuda")
+            if store is not None:                                # the loss of eval_split (verbose_loss), eval_utils.py:440-453
+                hb = store.batch(range(i, i + att.size(0)), args.seq_per_img, rng)
+                hb.pop("gts", None)
+                b = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+                outs = model(fc, att.float(), b["labels"], None, b["phrase_num"], b["phrase_length"], b["phrase_syn"],
+                             b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"])
+                loss_sum += float(crit(*outs, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])[0])
+                loss_evals += 1
             seq, lp, pn, pl, ps, t = model(fc, att, None, opt={"train_mode": args.inference_mode, "sample_method": "greedy", "sample_n": 1}, mode="sample")
             seconds += t
             # per-image entropy / perplexity as eval_utils.py:463-464, from the fused row reductions (bofi_vocab_stats)
@@ -73,6 +92,8 @@ def main():
                     entry["caption"] = " ".join(vocab.get(str(v), "UNK") for v in ids if v > 6)
                 results.append(entry)
     print(f"decoded {len(results)} images in {seconds:.4f} s ({len(results) / max(seconds, 1e-9):.1f} images/s incl. host sync)")
+    if store is not None:
+        print(f"validation loss {loss_sum / max(1, loss_evals):.4f} over {loss_evals} batches (LanguageModelCriterion_UIC)")
     if args.dump_json:
         with open(args.dump_json, "w") as f:
             json.dump(results, f)
