@@ -295,6 +295,36 @@ struct bofi_engine {
         ENG_OK(bofi::launch_votab(b_kvtab, b_o_self.w, b_x0, b_o_self.b, b_votab, b_x0b, cfg.dtype, L * 10, cfg.d_model, cfg.heads, s));
         return BOFI_OK;
     }
+    // y1 (by1 / byb / st_b) -> y3 partial slabs (by3): query projection + cross-attention, Wo_src, FFN, as the direct-operand kernels
+    // of bound_ops.hip.  Returns -1 when the configuration is not theirs (the caller takes the general kernels), else a status;
+    // *parts = number of slabs in by3.  `skip`: early-out word and threshold (NULL: none).
+    int bound_chain_lean(int B, int R, const int* att_len, const int* skip, int skip_thr, hipStream_t s, int* parts) {
+        static const bool lean_on = [] { const char* v = getenv("BOFI_BOUND_LEAN"); return !v || atoi(v) != 0; }();
+        const int d = cfg.d_model;
+        if (!(lean_on && cfg.dtype == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4)) return -1;
+        {   bofi::BoundQAttnArgs a{};
+            a.x = (const uint16_t*)byb; a.stats = st_b; a.wq = (const uint16_t*)b_q_src.w; a.bias = b_q_src.b; a.colsum = b_q_src.cs;
+            a.k = (const uint16_t*)kv; a.v = (const uint16_t*)kv + d; a.ldkv = kv_all.N; a.att_len = att_len; a.out = (uint16_t*)bctx2;
+            a.B = B; a.R = R; a.d = d; a.H = cfg.heads; a.skip_if_ge = skip; a.skip_threshold = skip_thr;
+            ENG_OK(bofi::launch_bound_qattn(a, s)); }
+        {   bofi::RowGemmArgs a{};                   // y2 = y1 + Wo_src . ctx2 + bo
+            a.x = (const uint16_t*)bctx2; a.ldx = d; a.w = (const uint16_t*)b_o_src.w; a.bias = b_o_src.b; a.residual = by1; a.ldr = d;
+            a.y = by2; a.ldy = d; a.yb = (uint16_t*)byb; a.ldyb = d; a.stats_out = st_b16; a.M = B; a.N = d; a.K = d; a.splitk = 1;
+            a.skip_if_ge = skip; a.skip_threshold = skip_thr;
+            ENG_OK(bofi::launch_rowgemm(a, s)); }
+        {   bofi::RowGemmArgs a{};                   // h = relu(W1 . LN(y2) + b1)
+            a.x = (const uint16_t*)byb; a.ldx = d; a.w = (const uint16_t*)b_w1.w; a.bias = b_w1.b; a.stats = st_b16; a.stats_groups = d / 16;
+            a.colsum = b_w1.cs; a.yb = (uint16_t*)bh; a.ldyb = cfg.d_ff; a.M = B; a.N = cfg.d_ff; a.K = d; a.splitk = 1; a.relu = 1;
+            a.skip_if_ge = skip; a.skip_threshold = skip_thr;
+            ENG_OK(bofi::launch_rowgemm(a, s)); }
+        *parts = cfg.d_ff / 512;
+        {   bofi::RowGemmArgs a{};                   // y3 = y2 + W2 . h + b2 as `parts` partial slabs
+            a.x = (const uint16_t*)bh; a.ldx = cfg.d_ff; a.w = (const uint16_t*)b_w2.w; a.bias = b_w2.b; a.residual = by2; a.ldr = d;
+            a.y = by3; a.ldy = d; a.M = B; a.N = d; a.K = cfg.d_ff; a.splitk = *parts;
+            a.skip_if_ge = skip; a.skip_threshold = skip_thr;
+            ENG_OK(bofi::launch_rowgemm(a, s)); }
+        return BOFI_OK;
+    }
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
                            float* syn_logp, bool early, hipStream_t s);
@@ -350,33 +380,14 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     // has been produced by the previous bound_tail(..., BOUND_ATTN).
     const int d = cfg.d_model, dt = cfg.dtype;
     cur_B = B;
-    // bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
-    static const bool lean_on = [] { const char* v = getenv("BOFI_BOUND_LEAN"); return !v || atoi(v) != 0; }();
-    if (lean_on && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4) {
-        const int* skip = early ? st.counters : nullptr;
-        {   bofi::BoundQAttnArgs a{};
-            a.x = (const uint16_t*)byb; a.stats = st_b; a.wq = (const uint16_t*)b_q_src.w; a.bias = b_q_src.b; a.colsum = b_q_src.cs;
-            a.k = (const uint16_t*)kv; a.v = (const uint16_t*)kv + d; a.ldkv = kv_all.N; a.att_len = att_len; a.out = (uint16_t*)bctx2;
-            a.B = B; a.R = R; a.d = d; a.H = cfg.heads; a.skip_if_ge = skip; a.skip_threshold = B;
-            ENG_OK(bofi::launch_bound_qattn(a, s)); }
-        {   bofi::RowGemmArgs a{};                   // y2 = y1 + Wo_src . ctx2 + bo
-            a.x = (const uint16_t*)bctx2; a.ldx = d; a.w = (const uint16_t*)b_o_src.w; a.bias = b_o_src.b; a.residual = by1; a.ldr = d;
-            a.y = by2; a.ldy = d; a.yb = (uint16_t*)byb; a.ldyb = d; a.stats_out = st_b16; a.M = B; a.N = d; a.K = d; a.splitk = 1;
-            a.skip_if_ge = skip; a.skip_threshold = B;
-            ENG_OK(bofi::launch_rowgemm(a, s)); }
-        {   bofi::RowGemmArgs a{};                   // h = relu(W1 . LN(y2) + b1)
-            a.x = (const uint16_t*)byb; a.ldx = d; a.w = (const uint16_t*)b_w1.w; a.bias = b_w1.b; a.stats = st_b16; a.stats_groups = d / 16;
-            a.colsum = b_w1.cs; a.yb = (uint16_t*)bh; a.ldyb = cfg.d_ff; a.M = B; a.N = cfg.d_ff; a.K = d; a.splitk = 1; a.relu = 1;
-            a.skip_if_ge = skip; a.skip_threshold = B;
-            ENG_OK(bofi::launch_rowgemm(a, s)); }
-        const int parts = cfg.d_ff / 512;
-        {   bofi::RowGemmArgs a{};                   // y3 = y2 + W2 . h + b2 as `parts` partial slabs
-            a.x = (const uint16_t*)bh; a.ldx = cfg.d_ff; a.w = (const uint16_t*)b_w2.w; a.bias = b_w2.b; a.residual = by2; a.ldr = d;
-            a.y = by3; a.ldy = d; a.M = B; a.N = d; a.K = cfg.d_ff; a.splitk = parts;
-            a.skip_if_ge = skip; a.skip_threshold = B;
-            ENG_OK(bofi::launch_rowgemm(a, s)); }
-        const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
-        return bound_tail(by3, parts, update ? nullptr : ext_syn, update ? nullptr : last, B, flags, len_logp, syn_logp, s);
+    {   // bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
+        int parts = 0;
+        const int rc = bound_chain_lean(B, R, att_len, early ? st.counters : nullptr, B, s, &parts);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            const int flags = BOUND_HEADS | (update ? (BOUND_UPDATE | BOUND_ATTN) : 0) | (early ? BOUND_EARLY : 0);
+            return bound_tail(by3, parts, update ? nullptr : ext_syn, update ? nullptr : last, B, flags, len_logp, syn_logp, s);
+        }
     }
     { LinOpt o; o.early = early; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
     {
@@ -534,19 +545,24 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
         }
         { LinOpt o; o.residual = b_x0_sa; o.ldr = 0; o.halt = true; o.stats_out = st_b; o.y2 = copy_t(byb);
           ENG_OK(linear(bctx, dt, d, b_o_self, by1, BOFI_DT_F32, d, B, o, s)); }
-        { LinOpt o; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
-        {
-            bofi::AttnArgs a{};
-            a.q = bq2; a.ldq = d; a.k = kv; a.v = (char*)kv + (size_t)d * tsz; a.ldk = a.ldv = kv_all.N;
-            a.out = bctx2; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = R;
-            a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0; a.skip_if_ge = halt; a.skip_threshold = 1;
-            ENG_OK(bofi::launch_attention(a, s));
+        int w2parts = 0;
+        const int lean_rc = bound_chain_lean(B, R, att_len, halt, 1, s, &w2parts);
+        if (lean_rc > 0) return lean_rc;
+        if (lean_rc < 0) {
+            { LinOpt o; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by1, byb), dt, d, b_q_src, bq2, dt, d, B, o, s)); }
+            {
+                bofi::AttnArgs a{};
+                a.q = bq2; a.ldq = d; a.k = kv; a.v = (char*)kv + (size_t)d * tsz; a.ldk = a.ldv = kv_all.N;
+                a.out = bctx2; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = 1; a.Lk = R;
+                a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0; a.skip_if_ge = halt; a.skip_threshold = 1;
+                ENG_OK(bofi::launch_attention(a, s));
+            }
+            { LinOpt o; o.residual = by1; o.ldr = d; o.halt = true; o.stats_out = st_b; o.y2 = copy_t(byb);
+              ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
+            { LinOpt o; o.relu = 1; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
+            w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;
+            { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
         }
-        { LinOpt o; o.residual = by1; o.ldr = d; o.halt = true; o.stats_out = st_b; o.y2 = copy_t(byb);
-          ENG_OK(linear(bctx2, dt, d, b_o_src, by2, BOFI_DT_F32, d, B, o, s)); }
-        { LinOpt o; o.relu = 1; o.halt = true; o.ln_stats = st_b; ENG_OK(linear(stream_t(by2, byb), dt, d, b_w1, bh, dt, cfg.d_ff, B, o, s)); }
-        const int w2parts = (cfg.d_ff % (4 * 128) == 0) ? 4 : 1;
-        { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
         ENG_OK(bound_tail(by3, w2parts, nullptr, nullptr, B, BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, true, it));
         // ---- decoder pass over all S positions (decode_SA :520-530) with the phrase-block mask as per-row key prefixes
         ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
