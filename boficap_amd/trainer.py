@@ -10,6 +10,8 @@ from __future__ import annotations
 import re
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import hip
@@ -325,8 +327,14 @@ class XETrainer:
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
             return self._forward_backward_eager(batch, glat_p)     # every capture pins its activations' pool: bound their number
+        layout = batch.get("_blob_layout")
         if entry is None:
-            static = {k: batch[k].clone() for k in list(self._KEYS) + opt_keys}
+            static = {}
+            if layout is not None:                             # the small inputs as views of ONE static buffer
+                static["_blob"] = batch["_blob"].clone()
+                static.update(self._blob_views(static["_blob"], layout))
+            static.update({k: batch[k].clone() for k in list(self._KEYS) + opt_keys if k not in static})
+            static["_blob_layout"] = layout
             static["max_phrase_num"] = int(batch["max_phrase_num"])
             static["max_tokens"] = batch.get("max_tokens")
             self._forward_backward_eager(static, glat_p)        # warm-up outside the capture (lazy initialisations, allocator)
@@ -336,7 +344,12 @@ class XETrainer:
                 loss, parts = self._forward_backward_eager(static, glat_p)
             entry = self._graphs[key] = (g, static, loss, parts)
         g, static, loss, parts = entry
-        pairs = [(static[k], batch[k]) for k in list(self._KEYS) + opt_keys if static[k].data_ptr() != batch[k].data_ptr()]
+        in_blob = ()
+        if layout is not None and os.environ.get("BOFI_XE_BLOB", "1") != "0" and static.get("_blob_layout") == layout and static["_blob"].data_ptr() != batch["_blob"].data_ptr() \
+                and all(batch[k].data_ptr() == batch["_blob"].data_ptr() + o for k, o, _, _, _ in layout):
+            static["_blob"].copy_(batch["_blob"], non_blocking=True)      # every small input in one copy
+            in_blob = {k for k, _, _, _, _ in layout}
+        pairs = [(static[k], batch[k]) for k in list(self._KEYS) + opt_keys if k not in in_blob and static[k].data_ptr() != batch[k].data_ptr()]
         if pairs:                                              # one multi-tensor copy instead of ~20 small launches
             torch._foreach_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs], non_blocking=True)
         g.replay()
@@ -428,14 +441,15 @@ class XETrainer:
         rows[:T], lab[:T], w[:T] = n_idx * Sd + t_idx, labels[n_idx, 1 + t_idx], 1.0
         dev = batch["att_feats"].device
         out = dict(batch)
-        out.update(max_tokens=int(ntok.max()), token_rows=torch.from_numpy(rows).to(dev), token_labels=torch.from_numpy(lab).to(dev),
-                   token_weight=torch.from_numpy(w).to(dev))
+        host = {}                                                  # every index tensor of the step, uploaded as ONE blob at the end
+        put = lambda **kw: host.update(kw)
+        out.update(max_tokens=int(ntok.max()))
+        put(token_rows=rows, token_labels=lab, token_weight=w)
         if self.unpadded:                                          # the decoder itself runs over these rows only (xe._fill_unpadded)
             cap, pos = np.zeros(Tp, np.int64), np.zeros(Tp, np.int64)
             cap[:T], pos[:T] = n_idx, t_idx
             start = np.concatenate([[0], np.cumsum(ntok)[:-1]]).astype(np.int32)
-            out.update(row_start=torch.from_numpy(start).to(dev), row_count=torch.from_numpy(ntok.astype(np.int32)).to(dev),
-                       row_cap=torch.from_numpy(cap).to(dev), row_pos=torch.from_numpy(pos).to(dev))
+            put(row_start=start, row_count=ntok.astype(np.int32), row_cap=cap, row_pos=pos)
         n_img = int(batch["att_feats"].shape[0])
         if self.paired and len(ntok) % n_img == 0:
             # both branches' rows as one list, captions image-major: image i's SA copies, then its NA copies
@@ -452,9 +466,9 @@ class XETrainer:
             lab2, w2 = lab[src], w[src]
             w2[T2:] = 0.0
             pstart = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
-            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            out.update(pair_start=t(pstart), pair_count=t(cnt.astype(np.int32)), pair_src=t(src), pair_na=t(na), pair_labels=t(lab2),
-                       pair_w_sa=t(w2 * ~na), pair_w_na=t(w2 * na))
+            t = lambda a: a
+            put(pair_start=t(pstart), pair_count=t(cnt.astype(np.int32)), pair_src=t(src), pair_na=t(na), pair_labels=t(lab2),
+                pair_w_sa=t(w2 * ~na), pair_w_na=t(w2 * na))
             if all(k in host_batch for k in ("phrase_num", "extend_phrase_syn_seq", "extend_phrase_seq", "extend_phrase_seq_mask")) \
                     and batch.get("max_phrase_num") is not None:
                 # ... and every index tensor the paired forward would otherwise derive on the device (xe._forward_paired): the bound
@@ -478,13 +492,43 @@ class XETrainer:
                 k_sa[:T], k_na[:T] = emask.sum(-1)[rc, rp], (last - 1)[rc]
                 syn_c[T:], seq_c[T:], k_sa[T:], k_na[T:] = esyn[0, 1], eseq[0, 0], emask.sum(-1)[0, 0], (last - 1)[0]   # (padding rows read row 0, as on the device)
                 pos_all = np.zeros(Tp, np.int64); pos_all[:T] = rp
-                out.update(prep_tok_b=t(np.where(cap_na[:, None], none, word[cap_n])), prep_syn_b=t(np.where(cap_na[:, None], esyn[cap_n], none)),
-                           prep_klen_b=t(klen_pass[cap_n].astype(np.int32)),
-                           prep_tok2=t(np.where(na, cfg.bos_idx, seq_c[src])), prep_syn2=t(syn_c[src]), prep_pos2=t(pos_all[src]),
-                           prep_klen2=t(np.where(na, k_na[src], k_sa[src]).astype(np.int32)),
-                           prep_img_start=t(pstart.reshape(-1, 2 * spi)[:, 0].astype(np.int32)),
-                           prep_img_count=t(cnt.reshape(-1, 2 * spi).sum(1).astype(np.int32)))
+                put(prep_tok_b=t(np.where(cap_na[:, None], none, word[cap_n])), prep_syn_b=t(np.where(cap_na[:, None], esyn[cap_n], none)),
+                    prep_klen_b=t(klen_pass[cap_n].astype(np.int32)),
+                    prep_tok2=t(np.where(na, cfg.bos_idx, seq_c[src])), prep_syn2=t(syn_c[src]), prep_pos2=t(pos_all[src]),
+                    prep_klen2=t(np.where(na, k_na[src], k_sa[src]).astype(np.int32)),
+                    prep_img_start=t(pstart.reshape(-1, 2 * spi)[:, 0].astype(np.int32)),
+                    prep_img_count=t(cnt.reshape(-1, 2 * spi).sum(1).astype(np.int32)))
+        # the loader's own label tensors ride in the blob too when the host copy matches what is on the device
+        for k in self._KEYS[1:]:
+            if k in host_batch and k in batch and torch.is_tensor(batch[k]):
+                a = np.asarray(host_batch[k])
+                if tuple(a.shape) == tuple(batch[k].shape) and torch.from_numpy(a[:0].copy()).dtype == batch[k].dtype:
+                    host[k] = a
+        out.update(self._upload_blob(host, dev))
         return out
+
+    @staticmethod
+    def _upload_blob(host, dev):
+        """One host->device copy for all of a step's small input tensors: they become typed views of one byte buffer (16-byte
+        aligned pieces), and a captured step refreshes its static inputs with ONE device copy of that buffer instead of one per
+        tensor (``_blob`` / ``_blob_layout`` travel with the batch)."""
+        import numpy as np
+        layout, off = [], 0
+        arrays = {k: np.ascontiguousarray(v) for k, v in host.items()}
+        for k, a in arrays.items():
+            layout.append((k, off, a.nbytes, torch.from_numpy(a[:0].copy()).dtype, tuple(a.shape)))
+            off = (off + a.nbytes + 15) & ~15
+        blob_h = np.zeros(max(off, 16), np.uint8)
+        for (k, o, nb, _, _), a in zip(layout, arrays.values()):
+            blob_h[o:o + nb] = a.reshape(-1).view(np.uint8)
+        blob = torch.from_numpy(blob_h).to(dev)
+        out = XETrainer._blob_views(blob, layout)
+        out["_blob"], out["_blob_layout"] = blob, tuple(layout)
+        return out
+
+    @staticmethod
+    def _blob_views(blob, layout):
+        return {k: blob[o:o + nb].view(dt).view(shape) for k, o, nb, dt, shape in layout}
 
     def optimizer_step(self, grad_scale: float = 1.0) -> float:
         self._step += 1

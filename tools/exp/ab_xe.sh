@@ -1,8 +1,8 @@
-B="python bench.py --mode xe --steps 40 --warmup 8 --no-cpu-baseline"
+B="python bench.py --mode xe --steps 60 --warmup 8 --no-cpu-baseline"
 p() { python -c "
 import sys, json
-d = json.loads(sys.stdin.readlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
+d = json.loads(sys.stdin.readlines()[-1]); print('$1', d['value'], d['ms_per_step'], d['config']['host_enqueue_ms_per_step'])"; }
+for i in 1 2; do
 $B 2>/dev/null | p default
-BOFI_LN_WS=0 $B 2>/dev/null | p ln_ws=0
-BOFI_GEMM_HEUR2=0 $B 2>/dev/null | p heur2=0
-BOFI_GEMM_HEUR2=0 BOFI_LN_WS=0 $B 2>/dev/null | p both_off
+env $1 $B 2>/dev/null | p "$1"
+done
