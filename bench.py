@@ -515,10 +515,24 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         streams = more if len(more) > len(streams) else streams
     log(f"{len(streams)} concurrent streams")
     engines = [eng] + [eng.fork() for _ in range(len(streams) - 1)]
+    # every launch in flight decodes features of its own (a rotation of the batches by whole batches, so the layouts and T stay
+    # those of the probe): none of them finds another's features warm in a cache
+    nb = att.size(0) // args.batch
+    atts = [att] + [torch.cat([att[(k % nb) * args.batch:], att[:(k % nb) * args.batch]]).contiguous() if nb > 1 else att.clone()
+                    for k in range(1, len(engines))]
+    if nb == 1:                                                 # one batch per launch: other images (same generator, other seeds), Q1-safe
+        for k in range(1, len(engines)):
+            cand = torch.from_numpy(W.synthetic_att_feats(args.batch, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank + 1000 * k)).to(dev).to(tdt)
+            pk = eng.decode_naic(cand, want_logprob=False, graph=False, refine_rounds=args.refine)
+            alive = (pk["phrase_num"] > 0).nonzero().flatten()
+            if int(pk["phrase_num"][-1]) == 0 and alive.numel():
+                i = int(alive[-1])
+                cand[[i, args.batch - 1]] = cand[[args.batch - 1, i]]
+            atts[k] = cand.contiguous()
     outs = []
-    for e, st in zip(engines, streams):
+    for e, st, a_k in zip(engines, streams, atts):
         with torch.cuda.stream(st):
-            outs.append(e.decode_naic(att, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine, q1_group=qg))
+            outs.append(e.decode_naic(a_k, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine, q1_group=qg))
     torch.cuda.synchronize()
     out = outs[0]
     log("warm-up + timed steps")
@@ -526,7 +540,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     def step(i):
         k = i % len(engines)
         with torch.cuda.stream(streams[k]):
-            engines[k].decode_naic(att, graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
+            engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
 
     launches = args.steps // C
     for i in range(args.warmup // C):
@@ -601,7 +615,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                                + (f", {args.refine} refinement rounds" if args.refine else ""),
                    "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
                    "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
-                   "decodes_in_flight": len(engines), "batches_per_launch": C, "refine_rounds": args.refine,
+                   "decodes_in_flight": len(engines), "features_per_launch_in_flight": "own tensor each", "batches_per_launch": C, "refine_rounds": args.refine,
                    "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                    "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
                    "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
