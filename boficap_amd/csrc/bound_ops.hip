@@ -254,3 +254,24 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace bofi
+
+extern "C" int bofi_rowgemm(const void* x, int ldx, const void* w, const float* bias, const float* stats, int stats_groups, const float* colsum,
+                            const float* residual, int ldr, float* y, int ldy, void* yb, int ldyb, float* stats_out, int M, int N, int K,
+                            int splitk, int relu, const int* skip, int skip_threshold, void* stream) {
+    bofi::RowGemmArgs a{};
+    a.x = (const uint16_t*)x; a.ldx = ldx; a.w = (const uint16_t*)w; a.bias = bias; a.stats = stats; a.stats_groups = stats_groups; a.colsum = colsum;
+    a.residual = residual; a.ldr = ldr; a.y = y; a.ldy = ldy; a.yb = (uint16_t*)yb; a.ldyb = ldyb; a.stats_out = stats_out;
+    a.M = M; a.N = N; a.K = K; a.splitk = splitk; a.relu = relu; a.skip_if_ge = skip; a.skip_threshold = skip_threshold;
+    return bofi::launch_rowgemm(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const float* bias, const float* colsum, const void* k,
+                                const void* v, int ldkv, const int* att_len, void* out, int B, int R, const int* skip, int skip_threshold,
+                                void* stream) {
+    bofi::BoundQAttnArgs a{};
+    a.x = (const uint16_t*)x; a.stats = stats; a.wq = (const uint16_t*)wq; a.bias = bias; a.colsum = colsum; a.k = (const uint16_t*)k;
+    a.v = (const uint16_t*)v; a.ldkv = ldkv; a.att_len = att_len; a.out = (uint16_t*)out; a.B = B; a.R = R; a.d = 512; a.H = 8;
+    a.skip_if_ge = skip; a.skip_threshold = skip_threshold;
+    return bofi::launch_bound_qattn(a, (hipStream_t)stream);
+}
+

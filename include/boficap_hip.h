@@ -341,6 +341,20 @@ int bofi_engine_encode(bofi_engine_t* e, const void* att_feats, int feats_dtype,
 int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last, int B, int R,
                            const int* att_len, float* len_logp, float* syn_logp, void* stream);
 
+/* The row-0 stages of a bounding iteration as operators (bound_ops.hip; bf16, d_model 512, 8 heads): one activation row per image.
+ * bofi_rowgemm: y[M, N] = epilogue(x[M, K] . w[N, K]^T), K = 512 * splitk.  stats (may be NULL): partial (sum, sum of squares) of the
+ * float32 rows behind x, [M][stats_groups][2] -> the LayerNorm folded into w / bias / colsum (y = rstd (acc - mean colsum) + bias);
+ * relu; residual float32 [M, ldr]; outputs: y float32 (splitk > 1: `splitk` partial slabs [splitk][M][ldy], bias and residual in
+ * slab 0), yb bf16 copy, stats_out [M][N/16][2] partial sums of the output rows.  skip (may be NULL): the launch returns at once when
+ * *skip >= skip_threshold.
+ * bofi_bound_qattn: out[B, 512] = per head softmax(q k^T / 8) v with q = LayerNorm-folded Wq x (as above, stats [B][16][2]), keys and
+ * values k, v [B * R, ldkv] (R <= 64 regions per image, att_len int32 [B] or NULL = R each). */
+int bofi_rowgemm(const void* x, int ldx, const void* w, const float* bias, const float* stats, int stats_groups, const float* colsum,
+                 const float* residual, int ldr, float* y, int ldy, void* yb, int ldyb, float* stats_out, int M, int N, int K, int splitk,
+                 int relu, const int* skip, int skip_threshold, void* stream);
+int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const float* bias, const float* colsum, const void* k, const void* v,
+                     int ldkv, const int* att_len, void* out, int B, int R, const int* skip, int skip_threshold, void* stream);
+
 /* Developer aid: copy one of the bounding iteration's workspace buffers ("by1", "byb", "st_b", "bq2", "bctx2", "by2", "bh", "by3")
  * into user memory (device to device, on `stream`). */
 int bofi_engine_debug_copy(bofi_engine_t* e, const char* name, void* dst, int64_t bytes, void* stream);

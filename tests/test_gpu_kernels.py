@@ -159,3 +159,107 @@ def test_vocab_finalize(H):
     torch.cuda.synchronize()
     assert torch.equal(x.cpu()[~torch.isnan(lg)], lg[~torch.isnan(lg)])
     assert seq[7].item() == 33 and seq[5].item() == 100
+
+
+def _row_stats(x32, groups):
+    """partial (sum, sum of squares) per row and column group, as the producers write them: [M][groups][2]"""
+    M, d = x32.shape
+    v = x32.view(M, groups, d // groups)
+    return torch.stack([v.sum(-1), (v * v).sum(-1)], -1).contiguous()
+
+
+@pytest.mark.parametrize("M", [1, 17, 64, 65, 256])
+@pytest.mark.parametrize("mode", ["plain", "ln_relu", "res_stats", "splitk"])
+def test_rowgemm(H, M, mode):
+    """bofi_rowgemm (bound_ops.hip): y = epilogue(x w^T) for a few rows, against float64 on the bf16-rounded operands: LayerNorm fold
+    from row statistics (16- and 32-column groups), ReLU, float32 residual, bf16 copy, output row statistics, split-K slabs; rows
+    that do not fill a 16-row MFMA group or a 64-row block."""
+    g = _rng(3 + M)
+    K = 2048 if mode == "splitk" else 512
+    N = 512 if mode in ("res_stats", "splitk") else 2048
+    splitk = K // 512
+    x32 = torch.randn(M, K, generator=g) * 1.5 + 0.2
+    x = x32.to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g)
+    acc = x.double() @ w.double().t()
+    kw = dict(stats=None, groups=0, colsum=None, residual=None, relu=0, y=None, yb=None, stats_out=None)
+    if mode == "plain":
+        ref = acc + bias.double()
+        kw.update(y=torch.empty(M, N, device="cuda"))
+    elif mode == "ln_relu":
+        groups = 32 if M % 2 else 16
+        mean = x32.double().mean(1, keepdim=True)
+        rstd = 1.0 / (x32.double().std(1, keepdim=True) + 1e-6)
+        colsum = w.double().sum(1)
+        ref = torch.relu(rstd * (acc - mean * colsum) + bias.double())
+        kw.update(stats=_row_stats(x32, groups).cuda(), groups=groups, colsum=colsum.float().cuda(), relu=1,
+                  yb=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"))
+    elif mode == "res_stats":
+        ref = acc + bias.double() + res.double()
+        kw.update(residual=res.cuda(), y=torch.empty(M, N, device="cuda"), yb=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"),
+                  stats_out=torch.zeros(M, N // 16, 2, device="cuda"))
+    else:
+        ref = acc + bias.double() + res.double()
+        kw.update(residual=res.cuda(), y=torch.empty(splitk, M, N, device="cuda"))
+    xc, wc, bc = x.cuda(), w.cuda(), bias.cuda()
+    H.check(H.lib().bofi_rowgemm(H.ptr(xc), K, H.ptr(wc), H.ptr(bc), H.ptr(kw["stats"]), kw["groups"], H.ptr(kw["colsum"]), H.ptr(kw["residual"]), N,
+                                 H.ptr(kw["y"]), N, H.ptr(kw["yb"]), N, H.ptr(kw["stats_out"]), M, N, K, splitk, kw["relu"], None, 0, H.stream_ptr()),
+            "bofi_rowgemm")
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    if kw["y"] is not None:
+        y = kw["y"].cpu().double()
+        y = y.sum(0) if mode == "splitk" else y
+        assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, scale) * (8 if mode == "ln_relu" else 1)
+    if kw["yb"] is not None:
+        assert float((kw["yb"].cpu().double() - ref).abs().max()) <= 1e-2 * max(1.0, scale)
+    if kw["stats_out"] is not None:
+        want = _row_stats(kw["y"].cpu(), N // 16)
+        assert torch.allclose(kw["stats_out"].cpu(), want, rtol=1e-4, atol=1e-3)
+    # the early-out word: nothing is written
+    if kw["y"] is not None:
+        kw["y"].fill_(7.0)
+        skip = torch.tensor([5], dtype=torch.int32, device="cuda")
+        H.check(H.lib().bofi_rowgemm(H.ptr(xc), K, H.ptr(wc), H.ptr(bc), H.ptr(kw["stats"]), kw["groups"], H.ptr(kw["colsum"]), H.ptr(kw["residual"]), N,
+                                     H.ptr(kw["y"]), N, H.ptr(kw["yb"]), N, H.ptr(kw["stats_out"]), M, N, K, splitk, kw["relu"], H.ptr(skip), 5,
+                                     H.stream_ptr()), "bofi_rowgemm")
+        torch.cuda.synchronize()
+        assert float((kw["y"] - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,R", [(1, 36), (7, 36), (64, 36), (13, 64), (256, 20)])
+def test_bound_qattn(H, B, R):
+    """bofi_bound_qattn (bound_ops.hip): folded-LayerNorm query projection + one query row of cross-attention per image and head,
+    ragged region counts (one image without regions -> NaN, as softmax over an all-masked row), against float64."""
+    g = _rng(11 + B)
+    d, Hh, ld = 512, 8, 1024 + 512
+    x32 = torch.randn(B, d, generator=g) * 1.2 + 0.1
+    x = x32.to(torch.bfloat16)
+    wq = (torch.randn(d, d, generator=g) / d ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(d, generator=g) * 0.1
+    kv = (torch.randn(B * R, ld, generator=g)).to(torch.bfloat16)
+    att_len = torch.randint(1, R + 1, (B,), generator=g).to(torch.int32)
+    if B > 2:
+        att_len[1] = 0
+        att_len[2] = R
+    mean = x32.double().mean(1, keepdim=True)
+    rstd = 1.0 / (x32.double().std(1, keepdim=True) + 1e-6)
+    q = rstd * (x.double() @ wq.double().t() - mean * wq.double().sum(1)) + bias.double()
+    k = kv[:, :d].double().view(B, R, Hh, 64)
+    v = kv[:, d:2 * d].double().view(B, R, Hh, 64)
+    sc = torch.einsum("bhe,brhe->bhr", q.view(B, Hh, 64), k) / 8.0
+    mask = torch.arange(R)[None, None, :] < att_len[:, None, None]
+    p = torch.softmax(sc.masked_fill(~mask, float("-inf")), -1)
+    ref = torch.einsum("bhr,brhe->bhe", p, v).reshape(B, d)
+    out = torch.empty(B, d, dtype=torch.bfloat16, device="cuda")
+    xc, wc, bc, cs, kvc, al = x.cuda(), wq.cuda(), bias.cuda(), wq.float().sum(1).cuda(), kv.cuda(), att_len.cuda()
+    st = _row_stats(x32, 16).cuda()
+    H.check(H.lib().bofi_bound_qattn(H.ptr(xc), H.ptr(st), H.ptr(wc), H.ptr(bc), H.ptr(cs), H.ptr(kvc), kvc.data_ptr() + d * 2, ld, H.ptr(al),
+                                     H.ptr(out), B, R, None, 0, H.stream_ptr()), "bofi_bound_qattn")
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    empty = att_len == 0
+    assert bool(got[empty].isnan().all()) and not bool(got[~empty].isnan().any())
+    assert float((got[~empty] - ref[~empty]).abs().max()) <= 2e-2 * max(1.0, float(ref[~empty].abs().max()))
