@@ -325,6 +325,16 @@ extern "C" int bofi_linear(const void* x, int x_dtype, int ldx, const void* w, i
     return bofi::launch_linear(a, (hipStream_t)stream);
 }
 
+extern "C" int bofi_linear_rows(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias, const float* residual, int ldr,
+                                void* y, int y_dtype, int ldy, int M, int N, int K, int relu, const int* row_idx, const int* n_rows, void* stream) {
+    if (!row_idx || !n_rows) return BOFI_ERR_ARG;
+    bofi::LinearArgs a{};
+    a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = w; a.w_dtype = w_dtype; a.bias = bias;
+    a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.relu = relu;
+    a.row_idx = row_idx; a.m_dev = n_rows;
+    return bofi::launch_linear(a, (hipStream_t)stream);
+}
+
 extern "C" int bofi_linear_masked(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* mask, int ldm, float scale, void* y,
                                   int y_dtype, int ldy, int M, int N, int K, void* stream) {
     if (!mask || !(scale > 0.f)) return BOFI_ERR_ARG;

@@ -204,6 +204,12 @@ int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w, int w_dty
  * scale = 1 / (1 - p)) -- mask [M, N] float32 is that forward activation (a clipped or dropped unit is 0 there), so the
  * gradient arrives already masked, e.g. in bf16 for the previous layer's backward GEMMs (nn.Linear backward followed by the
  * relu / dropout backward in the reference).  Operands in the compute dtype, N % 4 == 0. */
+/* bofi_linear over a ROW LIST: rows row_idx[0 .. *n_rows) of x (both in device memory; M = capacity the launch is sized for) are
+ * multiplied and written to the same rows of y (residual read at those rows); other rows of y stay untouched.  The count is read on the
+ * device, so a captured launch serves any list (the semi-autoregressive decode's per-iteration rows).  x and w in one dtype, K a
+ * multiple of the 128-byte slab. */
+int bofi_linear_rows(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* bias, const float* residual, int ldr,
+                     void* y, int y_dtype, int ldy, int M, int N, int K, int relu, const int* row_idx, const int* n_rows, void* stream);
 int bofi_linear_masked(const void* x, int x_dtype, int ldx, const void* w, int w_dtype, const float* mask, int ldm,
                        float scale, void* y, int y_dtype, int ldy, int M, int N, int K, void* stream);
 

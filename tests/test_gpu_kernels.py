@@ -263,3 +263,31 @@ def test_bound_qattn(H, B, R):
     empty = att_len == 0
     assert bool(got[empty].isnan().all()) and not bool(got[~empty].isnan().any())
     assert float((got[~empty] - ref[~empty]).abs().max()) <= 2e-2 * max(1.0, float(ref[~empty].abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_rows", [0, 1, 100, 640])
+def test_linear_over_a_row_list(H, dtype, n_rows):
+    """bofi_linear_rows: only the listed rows are multiplied and written (count read on the device), the listed rows equal the dense
+    bofi_linear's bit for bit, every other row of y keeps its old content."""
+    g = _rng(21 + n_rows)
+    M, N, K = 640, 512, 512
+    code = H.DT_F32 if dtype == torch.float32 else H.DT_BF16
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    dense = torch.empty(M, N, device="cuda")
+    H.check(H.lib().bofi_linear(H.ptr(x), code, K, H.ptr(w), code, H.ptr(bias), H.ptr(res), N, H.ptr(dense), H.DT_F32, N, M, N, K, 1, None, 0, H.stream_ptr()))
+    rows = torch.randperm(M, generator=g)[:n_rows].to(torch.int32)
+    idx = torch.zeros(M, dtype=torch.int32)
+    idx[:n_rows] = rows
+    idx_d, cnt = idx.cuda(), torch.tensor([n_rows], dtype=torch.int32, device="cuda")
+    y = torch.full((M, N), -3.0, device="cuda")
+    H.check(H.lib().bofi_linear_rows(H.ptr(x), code, K, H.ptr(w), code, H.ptr(bias), H.ptr(res), N, H.ptr(y), H.DT_F32, N, M, N, K, 1, H.ptr(idx_d),
+                                     H.ptr(cnt), H.stream_ptr()), "bofi_linear_rows")
+    torch.cuda.synchronize()
+    listed = torch.zeros(M, dtype=torch.bool)
+    listed[rows.long()] = True
+    assert torch.equal(y.cpu()[listed], dense.cpu()[listed])
+    assert float((y.cpu()[~listed] + 3.0).abs().max()) == 0.0 if (~listed).any() else True
