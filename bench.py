@@ -575,6 +575,24 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         s1.record()
         _barrier(world)
         single_ms = s0.elapsed_time(s1) / args.steps
+    # for the record: the same launches with the features starting in pinned HOST memory (a loader's numpy arrays), copied to the
+    # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
+    pcie_ms = None
+    if args.from_host:
+        hosts = [a_k.cpu().pin_memory() for a_k in atts]
+        def step_h(i):
+            k = i % len(engines)
+            with torch.cuda.stream(streams[k]):
+                atts[k].copy_(hosts[k], non_blocking=True)
+                engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
+        for i in range(args.warmup // C):
+            step_h(i)
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for i in range(launches):
+            step_h(i)
+        torch.cuda.synchronize()
+        pcie_ms = (time.perf_counter() - h0) / args.steps * 1e3
     traffic, tnote = None, "no PMC pass committed for this configuration"
     names = {1: ("r02_hbm_traffic.json", "r01_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",)}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
@@ -618,7 +636,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                    "decodes_in_flight": len(engines), "features_per_launch_in_flight": "own tensor each", "batches_per_launch": C, "refine_rounds": args.refine,
                    "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                    "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
-                   "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
+                   "features_from_pinned_host_ms_per_step": round(pcie_ms, 4) if pcie_ms else None, "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
         "roofline": roof,
     }
     if world == 1 and gemm_roofline:
@@ -660,6 +678,8 @@ def main():
     ap.add_argument("--coalesce", type=int, default=None, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
                     "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches.  "
                     "Default 4 for the plain batch-64 decode (does not lean on the stream-to-hardware-queue placement), 1 otherwise")
+    ap.add_argument("--from-host", action="store_true", help="also time the launches with the features copied from pinned host memory before each one "
+                    "(PCIe-inclusive rate, reported in config; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     ap.add_argument("--no-secondary", action="store_true", help="headline measurement only (no XE / RL / refinement lines)")
