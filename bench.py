@@ -140,11 +140,14 @@ def gemm_rooflines(dtype, dev, batches=1):
 
 def xe_traffic(args):
     """HBM bytes per XE step from the committed PMC passes -- for the configuration they were taken on only."""
-    path = os.path.join(ROOT, "profiles", "r01_xe_hbm_traffic.json")
-    if args.batch != 64 or args.seq_per_img != 5 or args.dtype != "bf16" or not os.path.exists(path):
+    if args.batch != 64 or args.seq_per_img != 5 or args.dtype != "bf16":
         return None
-    with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_step")
+    for name in ("r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f).get("hbm_bytes_per_step")
+    return None
 
 
 def f_alg_xe(cfg, seq_per_img: int, passes: float) -> float:
@@ -265,7 +268,7 @@ def run_xe(args, ctx, log, cpu=True):
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": xe_traffic(args),
             "traffic_note": "HBM-side bytes per step, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate "
-                            "passes (profiles/r01_xe_hbm_traffic.json, batch 64 x 5 bf16); null for other configurations",
+                            "passes (profiles/r02_xe_hbm_traffic.json, or round 1's; batch 64 x 5 bf16); null for other configurations",
             "kernel": "whole XE step (" + ("one hipGraph launch + all-reduce + Adam kernel" if tr.graph else "eager launches") + ")",
             "flops_per_launch": flops, "launch_ms": round(dev_ms, 3),
             "note": "achieved / frac: algorithmic FLOPs of the step AS THE REFERENCE COMPUTES IT (SURVEY.md 8d: encoder per caption copy, "

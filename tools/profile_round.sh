@@ -24,6 +24,8 @@ run write1 --pmc WRITE_SIZE --kernel-trace -d $OUT/write1 -o write -- $B --coale
 run mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $OUT/mfma -o mfma -- $B --inflight 1 --steps 40 --warmup 8
 # 4. XE step
 run xe --kernel-trace --stats -d $OUT/xe -o xe -- python3 $R/bench.py --mode xe --steps 10 --warmup 3 --no-cpu-baseline
+run xef --pmc FETCH_SIZE --kernel-trace -d $OUT/xef -o f -- python3 $R/bench.py --mode xe --steps 6 --warmup 2 --no-cpu-baseline
+run xew --pmc WRITE_SIZE --kernel-trace -d $OUT/xew -o w -- python3 $R/bench.py --mode xe --steps 6 --warmup 2 --no-cpu-baseline
 cd $R
 db() { ls $OUT/$1/*.db 2>/dev/null | head -1; }
 # launches per process: in-flight leg (5 + 50) + one-at-a-time leg (5 + 50) + 3 eager probes (two batches get reordered) + 4 captures; --inflight 1: 5 + 50 + 3 + 1
@@ -34,5 +36,6 @@ python tools/pmc_traffic.py $(db fetch) $(db write) 16 > $OUT/${TAG}_hbm_traffic
 python tools/pmc_traffic.py $(db fetch1) $(db write1) 26 > $OUT/${TAG}_hbm_traffic.json 2>&1
 python tools/pmc_summary.py $(db mfma) 16 > $OUT/${TAG}_mfma_util_pmc.json 2>&1
 python tools/prof_db.py $(db xe) 14 30 > $OUT/${TAG}_xe_step_kernel_stats.txt 2>&1
-rm -rf $OUT/ks4 $OUT/ks1 $OUT/tl $OUT/fetch $OUT/write $OUT/fetch1 $OUT/write1 $OUT/mfma $OUT/xe
+python tools/pmc_traffic.py $(db xef) $(db xew) 10 > $OUT/${TAG}_xe_hbm_traffic.json 2>&1      # 6 + 2 steps + the eager tally pass + the capture warm-up
+rm -rf $OUT/ks4 $OUT/ks1 $OUT/tl $OUT/fetch $OUT/write $OUT/fetch1 $OUT/write1 $OUT/mfma $OUT/xe $OUT/xef $OUT/xew
 ls -la $OUT
