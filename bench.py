@@ -476,9 +476,10 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     sd = W.make_state_dict(cfg, seed=0)
     import math
     C = max(1, args.coalesce)
-    if args.steps % C or args.warmup % C:                       # K steps = K / C launches: take the largest batch count that divides both
-        C = math.gcd(C, math.gcd(args.steps, args.warmup) if args.warmup else args.steps)
-        log(f"--steps / --warmup are not multiples of --coalesce {args.coalesce}: {C} batches per launch")
+    if args.steps % C:                                          # K timed steps = K / C launches: the largest batch count that divides K
+        C = math.gcd(C, args.steps)
+        log(f"--steps is not a multiple of --coalesce {args.coalesce}: {C} batches per launch")
+    warm_launches = (args.warmup + C - 1) // C                  # (the untimed warm-up is rounded UP to whole launches)
     eng = BofiEngine(cfg, tdt, max_batch=args.batch * C, max_regions=36, device=dev)
     eng.load_state_dict(sd)
     # every rank decodes its own shard of images (different seed per rank), already resident in HBM; with --coalesce the
@@ -546,7 +547,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
 
     launches = args.steps // C
-    for i in range(args.warmup // C):
+    for i in range(warm_launches):
         step(i)
     _barrier(world)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
@@ -568,7 +569,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # for the record: the same K steps strictly one at a time (latency view of the same workload), HIP events on the stream
     single_ms = None
     if len(engines) > 1:
-        for i in range(args.warmup // C):
+        for i in range(warm_launches):
             eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg)
         _barrier(world)
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -588,7 +589,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             with torch.cuda.stream(streams[k]):
                 atts[k].copy_(hosts[k], non_blocking=True)
                 engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
-        for i in range(args.warmup // C):
+        for i in range(warm_launches):
             step_h(i)
         torch.cuda.synchronize()
         h0 = time.perf_counter()
@@ -597,7 +598,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         torch.cuda.synchronize()
         pcie_ms = (time.perf_counter() - h0) / args.steps * 1e3
     traffic, tnote = None, "no PMC pass committed for this configuration"
-    names = {1: ("r02_hbm_traffic.json", "r01_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",)}.get(C, ())
+    names = {1: ("r02_hbm_traffic.json", "r01_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r02_hbm_traffic_coalesce5.json",)}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
@@ -680,7 +681,7 @@ def main():
                     "1 = strictly one decode at a time")
     ap.add_argument("--coalesce", type=int, default=None, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
                     "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches.  "
-                    "Default 4 for the plain batch-64 decode (does not lean on the stream-to-hardware-queue placement), 1 otherwise")
+                    "Default for the plain batch-64 decode: 5 or 4 (whichever divides --steps into evenly spread launches), 1 otherwise")
     ap.add_argument("--from-host", action="store_true", help="also time the launches with the features copied from pinned host memory before each one "
                     "(PCIe-inclusive rate, reported in config; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -694,7 +695,14 @@ def main():
         args.batch = 10 if args.mode == "rl" else 64
     default_coalesce = args.coalesce is None
     if default_coalesce:
-        args.coalesce = 4 if (args.mode == "naic" and args.batch == 64 and not args.refine) else 1
+        args.coalesce = 1
+        if args.mode == "naic" and args.batch == 64 and not args.refine:
+            # batches per launch: among 5, 4, 8, 2 the one that divides the timed steps and spreads the launches evenly over the
+            # streams (fewest rounds x batches per launch; the driver's --steps 20 -> 4 launches of 5 batches, one per stream)
+            cands = [c for c in (5, 4, 8, 2) if args.steps % c == 0]
+            if cands:
+                n_str = max(1, args.inflight)
+                args.coalesce = min(cands, key=lambda c: (-(-(args.steps // c) // n_str)) * c)
     ctx = dist_setup(args)
     rank, world = ctx[0], ctx[2]
 
