@@ -80,6 +80,9 @@ struct BoundQAttnArgs {
     uint16_t* out;                // attention output [B][d] (heads concatenated)
     int B, R, d, H;
     const int* skip_if_ge; int skip_threshold;
+    // query rows from a device-side list: rows row_idx[0 .. *n_rows) of x / stats / out (B = capacity); rows_per_image > 0: row r belongs
+    // to image r / rows_per_image (several query rows per image: the decoder's positions), else row = image
+    const int* row_idx; const int* n_rows; int rows_per_image;
 };
 int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st);
 struct RowGemmArgs {
@@ -93,6 +96,8 @@ struct RowGemmArgs {
     float* stats_out;             // [M][N/16][2] partial sums of the output rows
     int M, N, K, splitk, relu;
     const int* skip_if_ge; int skip_threshold;
+    const int* row_idx; const int* m_dev;     // row list: rows row_idx[0 .. *m_dev) of x / residual / statistics in, the same rows of the outputs
+    int kchunks;                              // (set by the launcher) K / (512 * splitk)
 };
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t st);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.hip; -1 = not eligible

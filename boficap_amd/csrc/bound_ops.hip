@@ -44,6 +44,12 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int h = blockIdx.x, b0 = blockIdx.y * G, R = a.R;
+    // query rows of this workgroup: b0 .. b0 + 7 of the batch, or of a device-side row list (rows of several per image: the image,
+    // whose regions are the keys, is row / rows_per_image)
+    const int nq = a.n_rows ? min(a.B, *a.n_rows) : a.B;
+    if (b0 >= nq) return;
+    auto mem_row = [&](int i) { i = min(i, nq - 1); return a.row_idx ? a.row_idx[i] : i; };
+    auto image_of = [&](int row) { return a.rows_per_image > 0 ? row / a.rows_per_image : row; };
 
     // ---- every load of the kernel is issued here, in the order of use (vmcnt retires in order): GEMM operands, K rows
     // (lane = key), V chunks (lane = chunk, key subset)
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
     bf16x8 fw[4][4], fx[4];
     {
         const int kq = wave * 128 + q * 8;
-        const bf16_t* xp = a.x + (size_t)min(b0 + (r & 7), a.B - 1) * D + kq;
+        const bf16_t* xp = a.x + (size_t)mem_row(b0 + (r & 7)) * D + kq;
 #pragma unroll
         for (int s = 0; s < 4; ++s) fx[s] = ld_frag(xp + s * 32);
 #pragma unroll
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
     }
     if (tid < G) {
         float mean, rstd;
-        row_norm(a.stats + (size_t)min(b0 + tid, a.B - 1) * (D / 32) * 2, D / 32, D, mean, rstd);
+        row_norm(a.stats + (size_t)mem_row(b0 + tid) * (D / 32) * 2, D / 32, D, mean, rstd);
         s_mean[tid] = mean; s_rstd[tid] = rstd;
     }
     const int idx0 = tid * 2;                       // the two q values this thread finalises: image idx >> 6, column idx & 63
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
     const float2 bs2 = *reinterpret_cast<const float2*>(a.bias + h * DK + (idx0 & 63));
     int kl[2], bimg[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { bimg[u] = min(b0 + 2 * wave + u, a.B - 1); kl[u] = a.att_len ? max(0, min(a.att_len[bimg[u]], R)) : R; }
+    for (int u = 0; u < 2; ++u) { bimg[u] = image_of(mem_row(b0 + 2 * wave + u)); kl[u] = a.att_len ? max(0, min(a.att_len[bimg[u]], R)) : R; }
 
     rg_u32x4 kk[2][8], vv[2][8];
 #pragma unroll
@@ -152,21 +158,22 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
             v += dpp_f32<DPP_MIRROR>(v);
             o[e] = xor32_sum(xor16_sum(v));
         }
-        if (lane < 8 && b0 + 2 * wave + u < a.B) {
+        if (lane < 8 && b0 + 2 * wave + u < nq) {
             rg_u32x4 w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f32_to_bf16(o[2 * e]) | ((uint32_t)f32_to_bf16(o[2 * e + 1]) << 16);
-            *reinterpret_cast<rg_u32x4*>(a.out + (size_t)(b0 + 2 * wave + u) * D + h * DK + cch * 8) = w;
+            *reinterpret_cast<rg_u32x4*>(a.out + (size_t)mem_row(b0 + 2 * wave + u) * D + h * DK + cch * 8) = w;
         }
     }
 }
 
 int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st) {
+    if ((a.row_idx != nullptr) != (a.n_rows != nullptr)) return BOFI_ERR_ARG;
     if (a.d != 512 || a.H != 8 || a.R < 1 || a.R > 64 || a.B < 1 || a.ldkv % 8 || !a.x || !a.stats || !a.wq || !a.bias || !a.colsum ||
         !a.k || !a.v || !a.out)
         return BOFI_ERR_ARG;
     hipLaunchKernelGGL(bound_qattn_kernel, dim3(a.H, (a.B + 7) / 8), dim3(256), 0, st, a);
-    (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.B * a.d * a.d;
+    if (!a.row_idx) (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.B * a.d * a.d;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
 
@@ -177,47 +184,60 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     __shared__ float4 red[4][4][64];          // [k quarter][16-row group][lane]
     if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, ks = blockIdx.y, mbase = blockIdx.z * 64, ng = min(4, (a.M - mbase + 15) >> 4);
-    const int kq = ks * 512 + wave * 128 + q * 8;
+    const int n0 = blockIdx.x * 16, ks = blockIdx.y, mbase = blockIdx.z * 64;
+    const int M = a.m_dev ? min(a.M, *a.m_dev) : a.M;        // row list: the count lives on the device (a.M sized the grid)
+    if (mbase >= M) return;
+    const int ng = min(4, (M - mbase + 15) >> 4);
+    auto mem_row = [&](int m) { m = min(m, M - 1); return a.row_idx ? a.row_idx[m] : m; };     // GEMM row -> row of x / y / residual / statistics
 
-    bf16x8 fw[4], fx[4][4];
-    {
-        const bf16_t* wp = a.w + (size_t)(n0 + r) * a.K + kq;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fw[s] = ld_frag(wp + s * 32);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        if (g < ng) {
-            const bf16_t* xp = a.x + (size_t)min(mbase + g * 16 + r, a.M - 1) * a.ldx + kq;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) fx[g][s] = ld_frag(xp + s * 32);
-        }
-    // epilogue operands of the row group this wavefront finalises (wave = group): image m, columns n .. n + 3
+    // epilogue operands of the row group this wavefront finalises (wave = group): row m, columns n .. n + 3
     const int m = mbase + wave * 16 + r, n = n0 + q * 4;
-    const bool mine = wave < ng, rowok = m < a.M;
-    const int mc = min(m, a.M - 1);
+    const bool mine = wave < ng, rowok = m < M;
+    const int mr = mem_row(m);
+    int xrow[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xrow[g] = mem_row(mbase + g * 16 + r);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mean = 0.f, rstd = 1.f;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), bv = cs, rv = cs;
-    if (mine) {
-        if (a.stats) {
-            row_norm(a.stats + (size_t)mc * a.stats_groups * 2, a.stats_groups, a.K, mean, rstd);
-            cs = *reinterpret_cast<const float4*>(a.colsum + n);
+    for (int c = 0; c < a.kchunks; ++c) {
+        const int kq = (ks * a.kchunks + c) * 512 + wave * 128 + q * 8;
+        bf16x8 fw[4], fx[4][4];
+        {
+            const bf16_t* wp = a.w + (size_t)(n0 + r) * a.K + kq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fw[s] = ld_frag(wp + s * 32);
         }
-        if (ks == 0) {
-            bv = *reinterpret_cast<const float4*>(a.bias + n);
-            if (a.residual) rv = *reinterpret_cast<const float4*>(a.residual + (size_t)mc * a.ldr + n);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (g < ng) {
+                const bf16_t* xp = a.x + (size_t)xrow[g] * a.ldx + kq;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fx[g][s] = ld_frag(xp + s * 32);
+            }
+        if (c == 0 && mine) {                  // requested behind the first chunk's operands: their round trip hides under the MFMAs
+            if (a.stats) {
+                row_norm(a.stats + (size_t)mr * a.stats_groups * 2, a.stats_groups, a.K, mean, rstd);
+                cs = *reinterpret_cast<const float4*>(a.colsum + n);
+            }
+            if (ks == 0) {
+                bv = *reinterpret_cast<const float4*>(a.bias + n);
+                if (a.residual) rv = *reinterpret_cast<const float4*>(a.residual + (size_t)mr * a.ldr + n);
+            }
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (g < ng) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s], fx[g][s], acc[g], 0, 0, 0);
+            }
     }
-
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        if (g < ng) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s], fx[g][s], acc, 0, 0, 0);
-            red[wave][g][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
+        if (g < ng) red[wave][g][lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
     __syncthreads();
     if (!mine) return;
     float4 v = red[0][wave][lane];
@@ -230,26 +250,29 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     if (a.stats_out) {                        // partial sums over the workgroup's 16 columns: lanes l, l ^ 16, l ^ 32, l ^ 48
         const float psum = xor32_sum(xor16_sum((v.x + v.y) + (v.z + v.w)));
         const float psq = xor32_sum(xor16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)));
-        if (q == 0 && rowok) reinterpret_cast<float2*>(a.stats_out)[(size_t)m * (a.N >> 4) + (n0 >> 4)] = make_float2(psum, psq);
+        if (q == 0 && rowok) reinterpret_cast<float2*>(a.stats_out)[(size_t)mr * (a.N >> 4) + (n0 >> 4)] = make_float2(psum, psq);
     }
     if (!rowok) return;
-    if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)ks * a.M + m) * a.ldy + n) = v;
+    if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)ks * a.M + mr) * a.ldy + n) = v;
     if (a.yb) {
         uint2 o;
         o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
         o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-        *reinterpret_cast<uint2*>(a.yb + (size_t)m * a.ldyb + n) = o;
+        *reinterpret_cast<uint2*>(a.yb + (size_t)mr * a.ldyb + n) = o;
     }
 }
 
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
     const int splitk = a.splitk > 1 ? a.splitk : 1;
-    if (a.M < 1 || a.N % 16 || a.K != 512 * splitk || a.ldx % 8 || !a.x || !a.w || !a.bias || (!a.y && !a.yb)) return BOFI_ERR_ARG;
+    RowGemmArgs b = a;
+    b.kchunks = a.K / (512 * splitk);                   // without split-K a workgroup walks the whole K in chunks of 512
+    if ((a.row_idx != nullptr) != (a.m_dev != nullptr)) return BOFI_ERR_ARG;
+    if (a.M < 1 || a.N % 16 || b.kchunks < 1 || a.K != 512 * splitk * b.kchunks || a.ldx % 8 || !a.x || !a.w || !a.bias || (!a.y && !a.yb)) return BOFI_ERR_ARG;
     if (a.stats && (!a.colsum || a.stats_groups % 2 || splitk > 1)) return BOFI_ERR_ARG;
     if (splitk > 1 && (a.relu || a.stats_out || a.yb || !a.y)) return BOFI_ERR_ARG;
     if ((a.y && a.ldy % 4) || (a.yb && a.ldyb % 4) || (a.residual && a.ldr % 4)) return BOFI_ERR_ARG;
-    hipLaunchKernelGGL(rowgemm_kernel, dim3(a.N / 16, splitk, (a.M + 63) / 64), dim3(256), 0, st, a);
-    (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
+    hipLaunchKernelGGL(rowgemm_kernel, dim3(a.N / 16, splitk, (a.M + 63) / 64), dim3(256), 0, st, b);
+    if (!a.row_idx) (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
 
@@ -257,8 +280,9 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
 
 extern "C" int bofi_rowgemm(const void* x, int ldx, const void* w, const float* bias, const float* stats, int stats_groups, const float* colsum,
                             const float* residual, int ldr, float* y, int ldy, void* yb, int ldyb, float* stats_out, int M, int N, int K,
-                            int splitk, int relu, const int* skip, int skip_threshold, void* stream) {
+                            int splitk, int relu, const int* skip, int skip_threshold, const int* row_idx, const int* n_rows, void* stream) {
     bofi::RowGemmArgs a{};
+    a.row_idx = row_idx; a.m_dev = n_rows;
     a.x = (const uint16_t*)x; a.ldx = ldx; a.w = (const uint16_t*)w; a.bias = bias; a.stats = stats; a.stats_groups = stats_groups; a.colsum = colsum;
     a.residual = residual; a.ldr = ldr; a.y = y; a.ldy = ldy; a.yb = (uint16_t*)yb; a.ldyb = ldyb; a.stats_out = stats_out;
     a.M = M; a.N = N; a.K = K; a.splitk = splitk; a.relu = relu; a.skip_if_ge = skip; a.skip_threshold = skip_threshold;
@@ -267,8 +291,9 @@ extern "C" int bofi_rowgemm(const void* x, int ldx, const void* w, const float* 
 
 extern "C" int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const float* bias, const float* colsum, const void* k,
                                 const void* v, int ldkv, const int* att_len, void* out, int B, int R, const int* skip, int skip_threshold,
-                                void* stream) {
+                                const int* row_idx, const int* n_rows, int rows_per_image, void* stream) {
     bofi::BoundQAttnArgs a{};
+    a.row_idx = row_idx; a.n_rows = n_rows; a.rows_per_image = rows_per_image;
     a.x = (const uint16_t*)x; a.stats = stats; a.wq = (const uint16_t*)wq; a.bias = bias; a.colsum = colsum; a.k = (const uint16_t*)k;
     a.v = (const uint16_t*)v; a.ldkv = ldkv; a.att_len = att_len; a.out = (uint16_t*)out; a.B = B; a.R = R; a.d = 512; a.H = 8;
     a.skip_if_ge = skip; a.skip_threshold = skip_threshold;

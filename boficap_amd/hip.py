@@ -41,8 +41,8 @@ SIGNATURES = {
     "bofi_attention_ex": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, C.c_float, C.c_uint64, _P, _P, _P, _I, _I, _P]),
     "bofi_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "bofi_linear_rows": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "bofi_rowgemm": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
-    "bofi_bound_qattn": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P]),
+    "bofi_rowgemm": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "bofi_bound_qattn": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P]),
     "bofi_layernorm_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, C.c_float, C.c_uint64, _P, _P]),
     "bofi_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P]),
     "bofi_attention_bwd_mfma": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, C.c_float, C.c_uint64,

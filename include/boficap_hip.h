@@ -351,15 +351,19 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
  * bofi_rowgemm: y[M, N] = epilogue(x[M, K] . w[N, K]^T), K = 512 * splitk.  stats (may be NULL): partial (sum, sum of squares) of the
  * float32 rows behind x, [M][stats_groups][2] -> the LayerNorm folded into w / bias / colsum (y = rstd (acc - mean colsum) + bias);
  * relu; residual float32 [M, ldr]; outputs: y float32 (splitk > 1: `splitk` partial slabs [splitk][M][ldy], bias and residual in
- * slab 0), yb bf16 copy, stats_out [M][N/16][2] partial sums of the output rows.  skip (may be NULL): the launch returns at once when
- * *skip >= skip_threshold.
+ * slab 0), yb bf16 copy, stats_out [M][N/16][2] partial sums of the output rows.  Without split-K any K = 512 * c is walked in chunks.
+ * skip (may be NULL): the launch returns at once when *skip >= skip_threshold.  row_idx / n_rows (both or neither; device memory): the
+ * GEMM covers rows row_idx[0 .. *n_rows) of x (and of residual / stats) and writes the same rows of the outputs; M is then the capacity.
  * bofi_bound_qattn: out[B, 512] = per head softmax(q k^T / 8) v with q = LayerNorm-folded Wq x (as above, stats [B][16][2]), keys and
- * values k, v [B * R, ldkv] (R <= 64 regions per image, att_len int32 [B] or NULL = R each). */
+ * values k, v [B * R, ldkv] (R <= 64 regions per image, att_len int32 [B] or NULL = R each).  row_idx / n_rows (both or neither): the query
+ * rows are rows row_idx[0 .. *n_rows) of x / stats / out (B = capacity); with rows_per_image > 0 row r attends the regions of image
+ * r / rows_per_image (a decoder layer's cross-attention over the rows of a list). */
 int bofi_rowgemm(const void* x, int ldx, const void* w, const float* bias, const float* stats, int stats_groups, const float* colsum,
                  const float* residual, int ldr, float* y, int ldy, void* yb, int ldyb, float* stats_out, int M, int N, int K, int splitk,
-                 int relu, const int* skip, int skip_threshold, void* stream);
+                 int relu, const int* skip, int skip_threshold, const int* row_idx, const int* n_rows, void* stream);
 int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const float* bias, const float* colsum, const void* k, const void* v,
-                     int ldkv, const int* att_len, void* out, int B, int R, const int* skip, int skip_threshold, void* stream);
+                     int ldkv, const int* att_len, void* out, int B, int R, const int* skip, int skip_threshold, const int* row_idx,
+                     const int* n_rows, int rows_per_image, void* stream);
 
 /* Developer aid: copy one of the bounding iteration's workspace buffers ("by1", "byb", "st_b", "bq2", "bctx2", "by2", "bh", "by3")
  * into user memory (device to device, on `stream`). */

@@ -205,8 +205,8 @@ def test_rowgemm(H, M, mode):
         kw.update(residual=res.cuda(), y=torch.empty(splitk, M, N, device="cuda"))
     xc, wc, bc = x.cuda(), w.cuda(), bias.cuda()
     H.check(H.lib().bofi_rowgemm(H.ptr(xc), K, H.ptr(wc), H.ptr(bc), H.ptr(kw["stats"]), kw["groups"], H.ptr(kw["colsum"]), H.ptr(kw["residual"]), N,
-                                 H.ptr(kw["y"]), N, H.ptr(kw["yb"]), N, H.ptr(kw["stats_out"]), M, N, K, splitk, kw["relu"], None, 0, H.stream_ptr()),
-            "bofi_rowgemm")
+                                 H.ptr(kw["y"]), N, H.ptr(kw["yb"]), N, H.ptr(kw["stats_out"]), M, N, K, splitk, kw["relu"], None, 0, None, None,
+                                 H.stream_ptr()), "bofi_rowgemm")
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
     if kw["y"] is not None:
@@ -224,7 +224,7 @@ def test_rowgemm(H, M, mode):
         skip = torch.tensor([5], dtype=torch.int32, device="cuda")
         H.check(H.lib().bofi_rowgemm(H.ptr(xc), K, H.ptr(wc), H.ptr(bc), H.ptr(kw["stats"]), kw["groups"], H.ptr(kw["colsum"]), H.ptr(kw["residual"]), N,
                                      H.ptr(kw["y"]), N, H.ptr(kw["yb"]), N, H.ptr(kw["stats_out"]), M, N, K, splitk, kw["relu"], H.ptr(skip), 5,
-                                     H.stream_ptr()), "bofi_rowgemm")
+                                     None, None, H.stream_ptr()), "bofi_rowgemm")
         torch.cuda.synchronize()
         assert float((kw["y"] - 7.0).abs().max()) == 0.0
 
@@ -257,7 +257,7 @@ def test_bound_qattn(H, B, R):
     xc, wc, bc, cs, kvc, al = x.cuda(), wq.cuda(), bias.cuda(), wq.float().sum(1).cuda(), kv.cuda(), att_len.cuda()
     st = _row_stats(x32, 16).cuda()
     H.check(H.lib().bofi_bound_qattn(H.ptr(xc), H.ptr(st), H.ptr(wc), H.ptr(bc), H.ptr(cs), H.ptr(kvc), kvc.data_ptr() + d * 2, ld, H.ptr(al),
-                                     H.ptr(out), B, R, None, 0, H.stream_ptr()), "bofi_bound_qattn")
+                                     H.ptr(out), B, R, None, 0, None, None, 0, H.stream_ptr()), "bofi_bound_qattn")
     torch.cuda.synchronize()
     got = out.cpu().double()
     empty = att_len == 0
@@ -291,3 +291,65 @@ def test_linear_over_a_row_list(H, dtype, n_rows):
     listed[rows.long()] = True
     assert torch.equal(y.cpu()[listed], dense.cpu()[listed])
     assert float((y.cpu()[~listed] + 3.0).abs().max()) == 0.0 if (~listed).any() else True
+
+
+@pytest.mark.parametrize("n_rows", [0, 3, 70, 200])
+def test_rowgemm_over_a_row_list_with_k_chunks(H, n_rows):
+    """bofi_rowgemm with a device-side row list and K = 2048 walked in four chunks by one workgroup (no split-K): the listed rows get
+    residual + x w^T + bias (float32 + bf16 copy + output statistics), every other row keeps its content."""
+    g = _rng(31 + n_rows)
+    M, N, K = 320, 512, 2048
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias, res = torch.randn(N, generator=g) * 0.1, torch.randn(M, N, generator=g)
+    ref = x.double() @ w.double().t() + bias.double() + res.double()
+    rows = torch.randperm(M, generator=g)[:n_rows].to(torch.int32)
+    idx = torch.zeros(M, dtype=torch.int32); idx[:n_rows] = rows
+    xc, wc, bc, idx_d, cnt = x.cuda(), w.cuda(), bias.cuda(), idx.cuda(), torch.tensor([n_rows], dtype=torch.int32, device="cuda")
+    y = res.clone().cuda()                                     # the residual stream, updated in place at the listed rows
+    yb = torch.full((M, N), -2.0, dtype=torch.bfloat16, device="cuda")
+    st = torch.full((M, N // 16, 2), -1.0, device="cuda")
+    H.check(H.lib().bofi_rowgemm(H.ptr(xc), K, H.ptr(wc), H.ptr(bc), None, 0, None, H.ptr(y), N, H.ptr(y), N, H.ptr(yb), N, H.ptr(st), M, N, K, 1, 0,
+                                 None, 0, H.ptr(idx_d), H.ptr(cnt), H.stream_ptr()), "bofi_rowgemm")
+    torch.cuda.synchronize()
+    listed = torch.zeros(M, dtype=torch.bool); listed[rows.long()] = True
+    got = y.cpu().double()
+    if n_rows:
+        assert float((got[listed] - ref[listed]).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max()))
+        assert torch.allclose(st.cpu()[listed], _row_stats(y.cpu(), N // 16)[listed], rtol=1e-4, atol=1e-3)
+        assert float((yb.cpu().double()[listed] - ref[listed]).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(y.cpu()[~listed], res[~listed]) and float((yb.cpu().float()[~listed] + 2.0).abs().max()) == 0.0
+    assert float((st.cpu()[~listed] + 1.0).abs().max()) == 0.0
+
+
+def test_bound_qattn_over_a_row_list(H):
+    """bofi_bound_qattn with a device-side list of query rows, several rows per image (a decoder layer's cross-attention on the rows of
+    the semi-autoregressive decode's new phrases): listed rows = the dense computation of those rows, others untouched."""
+    g = _rng(77)
+    Bimg, S, R, d, Hh, ld = 9, 20, 36, 512, 8, 1024
+    Mrows = Bimg * S
+    x32 = torch.randn(Mrows, d, generator=g) * 1.1
+    x = x32.to(torch.bfloat16)
+    wq = (torch.randn(d, d, generator=g) / d ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(d, generator=g) * 0.1
+    kv = torch.randn(Bimg * R, ld, generator=g).to(torch.bfloat16)
+    att_len = torch.randint(5, R + 1, (Bimg,), generator=g).to(torch.int32)
+    mean = x32.double().mean(1, keepdim=True); rstd = 1.0 / (x32.double().std(1, keepdim=True) + 1e-6)
+    q = (rstd * (x.double() @ wq.double().t() - mean * wq.double().sum(1)) + bias.double()).view(Mrows, Hh, 64)
+    img = torch.arange(Mrows) // S
+    k = kv[:, :d].double().view(Bimg, R, Hh, 64)[img]; v = kv[:, d:2 * d].double().view(Bimg, R, Hh, 64)[img]
+    sc = torch.einsum("mhe,mrhe->mhr", q, k) / 8.0
+    mask = torch.arange(R)[None, None, :] < att_len[img][:, None, None]
+    ref = torch.einsum("mhr,mrhe->mhe", torch.softmax(sc.masked_fill(~mask, float("-inf")), -1), v).reshape(Mrows, d)
+    rows = torch.randperm(Mrows, generator=g)[:37].to(torch.int32)
+    idx = torch.zeros(Mrows, dtype=torch.int32); idx[:37] = rows
+    out = torch.full((Mrows, d), -4.0, dtype=torch.bfloat16, device="cuda")
+    xc, wc, bc, cs, kvc, al, idx_d = x.cuda(), wq.cuda(), bias.cuda(), wq.float().sum(1).cuda(), kv.cuda(), att_len.cuda(), idx.cuda()
+    cnt, st = torch.tensor([37], dtype=torch.int32, device="cuda"), _row_stats(x32, 16).cuda()
+    H.check(H.lib().bofi_bound_qattn(H.ptr(xc), H.ptr(st), H.ptr(wc), H.ptr(bc), H.ptr(cs), H.ptr(kvc), kvc.data_ptr() + d * 2, ld, H.ptr(al),
+                                     H.ptr(out), Mrows, R, None, 0, H.ptr(idx_d), H.ptr(cnt), S, H.stream_ptr()), "bofi_bound_qattn")
+    torch.cuda.synchronize()
+    listed = torch.zeros(Mrows, dtype=torch.bool); listed[rows.long()] = True
+    got = out.cpu().double()
+    assert float((got[listed] - ref[listed]).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+    assert float((got[~listed] + 4.0).abs().max()) == 0.0
