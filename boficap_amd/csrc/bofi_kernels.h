@@ -30,6 +30,7 @@ struct LinearArgs {
     // ln_stats: float2 [M][K/32] partial (sum, sumsq) of the rows of the fp32 residual stream,
     // ln_colsum: float [N] column sums of the (rounded) scaled weight
     const float* ln_stats; const float* ln_colsum;
+    int ln_groups;            // partial-sum pairs per row of ln_stats (0: K / 32; the direct-operand kernels of bound_ops.hip write K / 16)
     float* stats_out;         // write partial (sum, sumsq) of the OUTPUT rows: float2 [M][N/32]
     void* y2; int ldy2;       // second copy of the output in the compute dtype (feeds the next folded GEMM)
     int splitk;               // > 1: K split over workgroups; y receives `splitk` float32 partial slabs [splitk][M][ldy]
@@ -83,6 +84,7 @@ struct BoundQAttnArgs {
     // query rows from a device-side list: rows row_idx[0 .. *n_rows) of x / stats / out (B = capacity); rows_per_image > 0: row r belongs
     // to image r / rows_per_image (several query rows per image: the decoder's positions), else row = image
     const int* row_idx; const int* n_rows; int rows_per_image;
+    int stats_groups;             // partial-sum pairs per row of `stats` (0: d / 32)
 };
 int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st);
 struct RowGemmArgs {

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
     }
     if (tid < G) {
         float mean, rstd;
-        row_norm(a.stats + (size_t)mem_row(b0 + tid) * (D / 32) * 2, D / 32, D, mean, rstd);
+        const int sg = a.stats_groups > 0 ? a.stats_groups : D / 32;
+        row_norm(a.stats + (size_t)mem_row(b0 + tid) * sg * 2, sg, D, mean, rstd);
         s_mean[tid] = mean; s_rstd[tid] = rstd;
     }
     const int idx0 = tid * 2;                       // the two q values this thread finalises: image idx >> 6, column idx & 63

@@ -90,6 +90,7 @@ struct bofi_engine {
     void* feats_t = nullptr;                                          // bf16 copy of float32 input features
     void *xb_enc = nullptr, *xb_fill = nullptr, *byb = nullptr;       // compute-dtype copies of the residual streams
     float *st_enc = nullptr, *st_fill = nullptr, *st_b = nullptr;     // row partial sums [rows][d/32][2]
+    float* st_fill16 = nullptr;                                       // the same for the decoder rows [Bm*Sq][d/16][2] (row-list iterations of the SAIC decode)
     float* st_b16 = nullptr;                                          // row partial sums per 16 columns [Bm][d/16][2] (bound_ops.hip)
     float *by1 = nullptr, *by2 = nullptr, *by3 = nullptr;
     void *bctx = nullptr, *bq2 = nullptr, *bctx2 = nullptr, *bh = nullptr;
@@ -101,7 +102,7 @@ struct bofi_engine {
     std::vector<void*> qkv_dec;                                         // SAIC: q|k|v of every decoder layer [B*S, 3d] (the K / V cache)
     int *sa_rows = nullptr, *sa_nrows = nullptr;                        // decoder rows of the iteration's new phrases, their count
     uint64_t* d_seed = nullptr;                                         // per-call sampling seed (read by the captured sampling kernels)
-    bool saic_cache = true;
+    bool saic_cache = true, saic_lean = true;
     Lin b_kv_self;                                                      // bound self-attention K|V with sublayer.0.norm folded in
     Lin t_kvself, t_qself; float* d_xt = nullptr; Norm head_norm;       // setup-time operands of the bound tables, kept for refreshes
     std::vector<LinRecipe> lin_recipes; std::vector<NormRecipe> norm_recipes;
@@ -210,6 +211,7 @@ struct bofi_engine {
         float* stats_out = nullptr;          // emit row partial sums of the output
         void* y2 = nullptr;                  // compute-dtype copy of the output
         const int* row_idx = nullptr; const int* m_dev = nullptr;     // row list (LinearArgs)
+        int ln_groups = 0;                   // partial-sum pairs per row of ln_stats (0: K / 32)
     };
     int linear(const void* x, int x_dtype, int ldx, const Lin& l, void* y, int y_dtype, int ldy, int M, const LinOpt& o, hipStream_t s) {
         if (o.ln) {
@@ -223,7 +225,7 @@ struct bofi_engine {
         a.x = x; a.x_dtype = x_dtype; a.ldx = ldx; a.w = l.w; a.w_dtype = cfg.dtype; a.bias = l.b;
         a.residual = o.residual; a.ldr = o.ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy;
         a.M = M; a.N = l.N; a.K = l.K; a.relu = o.relu; a.row_len = o.row_len; a.rows_per_group = o.rpg;
-        a.ln_stats = o.ln_stats; a.ln_colsum = o.ln_stats ? l.cs : nullptr;
+        a.ln_stats = o.ln_stats; a.ln_colsum = o.ln_stats ? l.cs : nullptr; a.ln_groups = o.ln_groups;
         a.stats_out = o.stats_out; a.y2 = o.y2; a.ldy2 = l.N; a.splitk = o.splitk; a.row_idx = o.row_idx; a.m_dev = o.m_dev;
         if (o.early) { a.skip_if_ge = st.counters; a.skip_threshold = cur_B; }
         if (o.halt) { a.skip_if_ge = st.counters + 2; a.skip_threshold = 1; }
@@ -269,6 +271,7 @@ struct bofi_engine {
     ENG_OK(dalloc(&xw, Bm * L * d)); ENG_OK(dalloc((char**)&xwb, Bm * L * d, tsz)); ENG_OK(dalloc(&st_w, Bm * L * (d / 32) * 2));
     ENG_OK(dalloc((char**)&kvs, Bm * L * 2 * (size_t)d, tsz)); ENG_OK(dalloc(&tok64, Bm * Sq));
     ENG_OK(dalloc(&sa_rows, Bm * Sq)); ENG_OK(dalloc(&sa_nrows, 4)); ENG_OK(dalloc(&d_seed, 2));
+    ENG_OK(dalloc(&st_fill16, Bm * Sq * (d / 16) * 2));
     qkv_dec.assign(c.n_dec, nullptr);                  // allocated by the first semi-autoregressive decode
 
         return BOFI_OK;
@@ -568,6 +571,45 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
         ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                        st_fill, halt, s));
         if (rowlist) ENG_OK(bofi::launch_saic_rows(st, B, L, S, it, sa_rows, sa_nrows, s));
+        // the row-list iterations in bf16 at the reference's width: a layer's six GEMMs as direct-operand row GEMMs (bound_ops.hip: no LDS
+        // staging, ~5 us per launch whatever the few hundred rows), query projection + cross-attention as one launch; their row
+        // statistics come in 16-column groups (st_fill16)
+        const bool lean = rowlist && saic_lean && dt == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0;
+        const float* fin_stats = st_fill; int fin_groups = 0;
+        if (lean) {
+            const float* cst = st_fill; int cg = d / 32;               // statistics of the rows' current stream: where, and in how many groups
+            auto rg = [&](const void* x, int ldx, const Lin& l, const float* stats, int groups, const float* residual, float* y, void* yb,
+                          int ldyb, float* stats_out, int relu) {
+                bofi::RowGemmArgs a{};
+                a.x = (const uint16_t*)x; a.ldx = ldx; a.w = (const uint16_t*)l.w; a.bias = l.b; a.stats = stats; a.stats_groups = groups;
+                a.colsum = stats ? l.cs : nullptr; a.residual = residual; a.ldr = d; a.y = y; a.ldy = d; a.yb = (uint16_t*)yb; a.ldyb = ldyb;
+                a.stats_out = stats_out; a.M = M; a.N = l.N; a.K = l.K; a.splitk = 1; a.relu = relu; a.skip_if_ge = halt; a.skip_threshold = 1;
+                a.row_idx = ri; a.m_dev = rn;
+                return bofi::launch_rowgemm(a, s);
+            };
+            for (size_t li = 0; li < dec.size(); ++li) {
+                auto& l = dec[li];
+                void* qkv = qkv_dec[li];
+                ENG_OK(rg(xb_fill, d, l.qkv, cst, cg, nullptr, nullptr, qkv, 3 * d, nullptr, 0));
+                bofi::AttnArgs a{};
+                a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
+                a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
+                a.klen = sa.klen_dec + 1; a.klen_sb = L; a.klen_sq = 1; a.klen_bias = -1; a.skip_if_ge = halt; a.skip_threshold = 1;
+                ENG_OK(bofi::launch_attention(a, s));
+                ENG_OK(rg(ctx, d, l.o, nullptr, 0, x_fill, x_fill, xb_fill, d, st_fill16, 0));
+                cst = st_fill16; cg = d / 16;
+                {   bofi::BoundQAttnArgs q{};
+                    q.x = (const uint16_t*)xb_fill; q.stats = cst; q.stats_groups = cg; q.wq = (const uint16_t*)l.q_src.w; q.bias = l.q_src.b; q.colsum = l.q_src.cs;
+                    q.k = (const uint16_t*)kv + (size_t)(n_len + li) * 2 * d; q.v = q.k + d; q.ldkv = kv_all.N; q.att_len = att_len; q.out = (uint16_t*)ctx;
+                    q.B = M; q.R = R; q.d = d; q.H = cfg.heads; q.skip_if_ge = halt; q.skip_threshold = 1;
+                    q.row_idx = ri; q.n_rows = rn; q.rows_per_image = S;
+                    ENG_OK(bofi::launch_bound_qattn(q, s)); }
+                ENG_OK(rg(ctx, d, l.o_src, nullptr, 0, x_fill, x_fill, xb_fill, d, st_fill16, 0));
+                ENG_OK(rg(xb_fill, d, l.w1, cst, cg, nullptr, nullptr, hdn, cfg.d_ff, nullptr, 1));
+                ENG_OK(rg(hdn, cfg.d_ff, l.w2, nullptr, 0, x_fill, x_fill, xb_fill, d, st_fill16, 0));
+            }
+            fin_stats = st_fill16; fin_groups = d / 16;
+        } else
         for (size_t li = 0; li < dec.size(); ++li) {
             auto& l = dec[li];
             void* qkv = qkv_dec[li];
@@ -593,7 +635,8 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
             { LinOpt o; o.halt = true; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill); o.row_idx = ri; o.m_dev = rn;
               ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
         }
-        { LinOpt o; o.halt = true; o.ln_stats = st_fill; o.row_idx = ri; o.m_dev = rn; ENG_OK(linear(xa, dt, d, gen, logits, BOFI_DT_F32, cfg.vocab, M, o, s)); }
+        { LinOpt o; o.halt = true; o.ln_stats = fin_stats; o.ln_groups = fin_groups; o.row_idx = ri; o.m_dev = rn;
+          ENG_OK(linear(xa, dt, d, gen, logits, BOFI_DT_F32, cfg.vocab, M, o, s)); }
         ENG_OK(bofi::launch_vocab_finalize(logits, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, nullptr, 0, cfg.pad_idx, tok64, s,
                                            st.counters + 3, halt, ri, rn));
         if (flags & BOFI_FLAG_SAMPLE)          // sample_next_word 'sample' (CaptionModel.py:405-425): the drawn ids feed the next bound step
@@ -652,6 +695,7 @@ int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
     e->n_len = c->n_len;
     { const char* v = getenv("BOFI_BOUND_DENSE"); e->bound_dense = c->n_len > 1 || (v && atoi(v) != 0); }
     { const char* v = getenv("BOFI_SAIC_CACHE"); e->saic_cache = !v || atoi(v) != 0; }     // 0: every row through the decoder in every iteration
+    { const char* v = getenv("BOFI_SAIC_LEAN"); e->saic_lean = !v || atoi(v) != 0; }       // 0: the row-list iterations on the general GEMM / attention kernels
     e->L = c->seq_length + 2;
     e->tsz = c->dtype == BOFI_DT_F32 ? 4 : 2;
     *out = e;

@@ -53,7 +53,7 @@ struct Gemm2Params {
     // folded pre-norm LayerNorm of the consumer: x is the RAW residual stream, w = W * gain, bias = c,
     // y = rstd[m] * (acc - mean[m] * colsum[n]) + c[n]; mean/rstd come from per-32-column partial
     // (sum, sum of squares) pairs written by the producer's epilogue
-    const float* ln_stats; const float* ln_colsum;
+    const float* ln_stats; const float* ln_colsum; int ln_groups;
     float* stats_out;         // this GEMM is a producer: partial (sum, sumsq) of its OUTPUT rows, [M][N/32][2]
     void* y2; int ldy2;       // optional second copy of the output in the compute dtype
     int splitk;               // > 1: blockIdx.y walks K slices; slice s writes its partial tile to y + s*M*ldy (f32),
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
         const int m = m0 + tid;
         float sm = 0.f, sq = 0.f;
         if (m < p.M) {
-            const int np4 = p.K >> 6;                  // two (sum, sumsq) pairs per 16-byte load
+            const int np4 = (p.ln_groups > 0 ? p.ln_groups : p.K >> 5) >> 1;      // two (sum, sumsq) pairs per 16-byte load
             const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)row_of(m) * np4;
             for (int i = 0; i < np4; ++i) { const float4 t = sp[i]; sm += t.x + t.z; sq += t.y + t.w; }
         }
@@ -513,7 +513,7 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
     p.y = a.y; p.ldy = a.ldy; p.y_is_f32 = a.y_dtype == BOFI_DT_F32; p.M = a.M; p.N = a.N; p.K = a.K;
     p.relu = a.relu; p.row_len = a.row_len; p.rows_per_group = a.rows_per_group;
     p.skip_if_ge = a.skip_if_ge; p.skip_threshold = a.skip_threshold;
-    p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
+    p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_colsum; p.ln_groups = a.ln_groups; p.stats_out = a.stats_out; p.y2 = a.y2; p.ldy2 = a.ldy2;
     p.splitk = a.splitk > 1 ? a.splitk : 1;
     p.drop_thresh = a.drop_thresh; p.drop_scale = a.drop_scale; p.drop_seed = a.drop_seed; p.drop_step = a.drop_step;
     p.mask_scale = a.mask_scale;

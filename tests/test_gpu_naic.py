@@ -500,6 +500,7 @@ def test_saic_row_list_equals_full_decoder_passes(dtype, weight_cache, manifest,
     g = load_golden("full_saic_multi")
     att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
     outs = []
+    monkeypatch.setenv("BOFI_SAIC_LEAN", "0")                  # same kernels on both sides: the row list alone must change nothing
     for cache in ("1", "0"):
         monkeypatch.setenv("BOFI_SAIC_CACHE", cache)
         eng = BofiEngine(cfg, dtype, max_batch=16, max_regions=36)
@@ -526,3 +527,31 @@ def test_saic_row_list_equals_full_decoder_passes(dtype, weight_cache, manifest,
         assert int(a["bound_iters"]) == int(b["bound_iters"])
         la, lb = a["seq_logprob"], b["seq_logprob"]
         assert torch.equal(la.isnan(), lb.isnan()) and torch.equal(la.nan_to_num(0.0), lb.nan_to_num(0.0))
+
+
+def test_saic_row_list_on_direct_operand_kernels(weight_cache, manifest, monkeypatch):
+    """bf16: the row-list iterations run their GEMMs and the cross-attention on the direct-operand kernels of bound_ops.hip (other
+    summation order than the LDS-DMA GEMM): against the same decode on the general kernels the captions agree except where a
+    near-tie flips (then everything after it differs by construction), and wherever a caption's ids agree its log-probs do to
+    bf16 accuracy."""
+    from boficap_amd.engine import BofiEngine
+    from boficap_amd import weights as W
+    m = manifest["full_saic_multi"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    pool = torch.from_numpy(W.synthetic_att_feats(96, 36, cfg.att_feat_size, seed=m["pool_seed"])).cuda()
+    res = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("BOFI_SAIC_LEAN", lean)
+        eng = BofiEngine(cfg, torch.bfloat16, max_batch=64, max_regions=36)
+        eng.load_state_dict(sd)
+        keep = eng.decode_naic(pool[:64])["phrase_num"] > 0 if not res else None
+        att = pool[:64][res[0][2]] if res else pool[:64][keep]
+        r = eng.decode_saic(att.contiguous())
+        torch.cuda.synchronize()
+        res.append((r["seq"].clone(), r["seq_logprob"].clone(), keep if keep is not None else res[0][2], r["phrase_num"].clone()))
+    (sa, la, _, pa), (sb, lb, _, pb) = res
+    assert int(pa.max()) >= 3                                      # several row-list iterations did run
+    same = (sa == sb).all(1)
+    assert float(same.float().mean()) >= 0.8, float(same.float().mean())
+    d = (la[same].nan_to_num(0.0) - lb[same].nan_to_num(0.0)).abs().max()
+    assert float(d) <= 6e-2, float(d)
