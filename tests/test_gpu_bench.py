@@ -1,0 +1,45 @@
+"""The driver's contract with bench.py: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line last, with the fields the
+driver parses, the roofline and CPU-baseline objects, and a config that names the workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]                          # progress goes to stderr
+    return json.loads(lines[-1])
+
+
+def test_bench_line_with_the_drivers_arguments():
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-secondary", "--cpu-budget", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]           # value = images per step / time per step
+    c = d["config"]
+    assert "workload" in c and "batch=64" in c["workload"] and c["images_per_step_per_gpu"] == 64 and not c["nan_in_output"]
+    assert c["batches_per_launch"] == 5 and c["decodes_in_flight"] >= 1              # 20 steps = 4 launches of 5 batches
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["flops_per_launch"] > 0 and r["launch_ms"] > 0 and "traffic" in r
+    b = d["cpu_baseline"]
+    assert b["kind"] == "port" and b["unit"] == "images/sec" and b["cores"] >= 1 and b["value"] > 0 and b["sample"]
+    assert d["value"] > 20 * b["value"]
+
+
+def test_bench_odd_step_counts_and_one_batch_per_launch():
+    d = _run("--steps", "7", "--warmup", "3", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline")
+    assert d["steps"] == 7 and d["config"]["batches_per_launch"] == 1 and d["value"] > 0
+    d = _run("--steps", "8", "--warmup", "2", "--inflight", "1", "--coalesce", "1", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--ids-only")
+    assert d["config"]["decodes_in_flight"] == 1 and d["config"]["seq_logprob_materialised"] is False
