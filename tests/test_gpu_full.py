@@ -579,3 +579,29 @@ def test_xe_step_with_100_regions(weight_cache, manifest, dtype):
             worst = max(worst, rel)
             assert rel < 5e-2, (n, rel)
     print("100 regions,", dtype, "worst relative gradient-norm error", worst)
+
+
+def test_five_batches_per_launch_equal_their_own_decodes(weight_cache):
+    """The default bench workload: 5 batches of 64 images in ONE engine call (q1_group = 64, 320 images: the bounding iteration's row
+    kernels take five 64-row blocks, the GEMMs other tiles than at 64 images) -- every batch's ids, slot layout and log-probs equal
+    its own separate decode, bf16, full size."""
+    from boficap_amd import weights as W
+    from boficap_amd.config import FULL as cfg
+    from boficap_amd.engine import BofiEngine
+    sd = W.make_state_dict(cfg, seed=0)
+    eng = BofiEngine(cfg, torch.bfloat16, max_batch=320, max_regions=36)
+    eng.load_state_dict(sd)
+    att = torch.from_numpy(W.synthetic_att_feats(320, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16).contiguous()
+    probe = eng.decode_naic(att, q1_group=64)["phrase_num"].cpu()
+    for g0 in range(0, 320, 64):                               # no batch may end on an image without phrases (quirk Q1: NaN batch)
+        if int(probe[g0 + 63]) == 0:
+            i = g0 + int((probe[g0:g0 + 63] > 0).nonzero()[-1])
+            att[[i, g0 + 63]] = att[[g0 + 63, i]]
+    allb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_naic(att, q1_group=64, graph=True).items()}
+    assert not bool(allb["seq_logprob"].isnan().any()) and int(allb["bound_iters"]) >= 8
+    for b in range(5):
+        sl = slice(64 * b, 64 * b + 64)
+        r = eng.decode_naic(att[sl].contiguous())
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+            assert torch.equal(allb[k][sl], r[k]), (b, k)
+        assert float((allb["seq_logprob"][sl] - r["seq_logprob"]).abs().max()) < 1e-3
