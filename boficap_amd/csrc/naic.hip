@@ -75,8 +75,13 @@ int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_n
             a.dbg_part[(size_t)blockIdx.x * (8 * 2 * a.hh + a.d) + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_entry); \
     } while (0)
 
-template <typename T>
-__global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
+// NLD = hidden-layer weight loads a thread keeps in flight.  32 (one batch in bf16, all requested at kernel entry) holds 128 VGPRs of
+// weights: one workgroup per CU, so launches of more than 256 images run in two rounds and nothing else shares the CU.  16 (two
+// batches, the second requested after the first has been summed: one more L2 round trip) fits 128 VGPRs in all: two workgroups per
+// CU.  Measured (tools/exp/ab_bench_c.sh): alone, the lean variant is 1 % slower per decode at 64 images, equal at 128 / 256 and
+// 3 % faster at 320; with four launches in flight it is 1.5 % faster at 128 and 256 as well.  It runs above 64 images.
+template <typename T, int NLD, int MINW>
+__global__ __launch_bounds__(512, MINW) void bound_tail_kernel(BoundTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
     const int flags = a.flags, B = a.B, L = a.L, S = a.S, d = a.d, hh = a.hh, H = a.H;
@@ -106,7 +111,6 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
     // ---- hidden-layer weights of this thread: (slice of K, group of 4 outputs); requested before anything else
     constexpr int EPL = 16 / sizeof(T);           // elements per 16-byte load
     constexpr int KPL = EPL / 4;                  // k values per load (4 outputs each)
-    constexpr int NLD = 32;                       // loads in flight per thread
     const int ng = nh / 4, slice = tid / ng, grp = tid - slice * ng, kps = d / 8;
     const int nld = kps / KPL;                    // loads per thread in all
     const bool hw = (flags & BOUND_HEADS) && slice < 8;
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512) void bound_tail_kernel(BoundTailArgs a) {
     // The key subsets are then summed through LDS in fixed order.
     {
         constexpr int CPT = 8, LPT = CPT / EPL;            // columns per thread, 16-byte loads per row piece
-        constexpr int JB = 3;                              // keys per thread and batch
+        constexpr int JB = NLD >= 32 ? 3 : 2;              // keys per thread and batch (8 x JB loads in flight)
         const int ncg = d / CPT, njs = 512 / ncg;          // column groups; key subsets (d = 512: 64 and 8)
         const int cg = tid % ncg, js = tid / ncg;
         float acc[CPT];
@@ -425,8 +429,14 @@ int launch_bound_tail(const BoundTailArgs& a, int dtype, hipStream_t s) {
     if (v.yparts < 1) v.yparts = 1;
     if (d % 8 || 512 % (d / 8) || d / 8 > 256) return BOFI_ERR_ARG;
     const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1) + a.H * 64 + 4096) * sizeof(float);
-    if (dtype == BOFI_DT_F32) hipLaunchKernelGGL((bound_tail_kernel<float>), dim3(a.B), dim3(512), shm, s, v);
-    else hipLaunchKernelGGL((bound_tail_kernel<bf16_t>), dim3(a.B), dim3(512), shm, s, v);
+    static const int small_at = [] { const char* e = getenv("BOFI_TAIL_SMALL_AT"); return e ? atoi(e) : 65; }();   // developer knob: images from which the two-per-CU variant runs
+    const bool small = a.B >= small_at;
+    if (dtype == BOFI_DT_F32) {                               // (float32 rows are twice as wide: no variant of it fits 128 VGPRs)
+        hipLaunchKernelGGL((bound_tail_kernel<float, 32, 1>), dim3(a.B), dim3(512), shm, s, v);
+    } else {
+        if (small) hipLaunchKernelGGL((bound_tail_kernel<bf16_t, 16, 4>), dim3(a.B), dim3(512), shm, s, v);
+        else hipLaunchKernelGGL((bound_tail_kernel<bf16_t, 32, 1>), dim3(a.B), dim3(512), shm, s, v);
+    }
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
