@@ -195,8 +195,8 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(ot[dt][qi][0]) | ((uint32_t)f32_to_bf16(ot[dt][qi][1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(ot[dt][qi][2]) | ((uint32_t)f32_to_bf16(ot[dt][qi][3]) << 16);
+            o.x = pack_bf16(ot[dt][qi][0], ot[dt][qi][1]);
+            o.y = pack_bf16(ot[dt][qi][2], ot[dt][qi][3]);
             *reinterpret_cast<uint2*>(og + (size_t)qrow * p.ldo + dt * 16 + g * 4) = o;
         }
     }

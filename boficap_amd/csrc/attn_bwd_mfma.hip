@@ -64,10 +64,10 @@ struct RowStage {
             if constexpr (sizeof(TIN) == 4) {
                 const u32x4 a = v[2 * t], b = v[2 * t + 1];
                 u32x4 o;
-                o[0] = (uint32_t)f32_to_bf16(__uint_as_float(a[0])) | ((uint32_t)f32_to_bf16(__uint_as_float(a[1])) << 16);
-                o[1] = (uint32_t)f32_to_bf16(__uint_as_float(a[2])) | ((uint32_t)f32_to_bf16(__uint_as_float(a[3])) << 16);
-                o[2] = (uint32_t)f32_to_bf16(__uint_as_float(b[0])) | ((uint32_t)f32_to_bf16(__uint_as_float(b[1])) << 16);
-                o[3] = (uint32_t)f32_to_bf16(__uint_as_float(b[2])) | ((uint32_t)f32_to_bf16(__uint_as_float(b[3])) << 16);
+                o[0] = pack_bf16(__uint_as_float(a[0]), __uint_as_float(a[1]));
+                o[1] = pack_bf16(__uint_as_float(a[2]), __uint_as_float(a[3]));
+                o[2] = pack_bf16(__uint_as_float(b[0]), __uint_as_float(b[1]));
+                o[3] = pack_bf16(__uint_as_float(b[2]), __uint_as_float(b[3]));
                 *reinterpret_cast<u32x4*>(dst + r * stride + c) = o;
             } else {
                 *reinterpret_cast<u32x4*>(dst + r * stride + c) = v[t];

@@ -23,11 +23,17 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even, NaN stays NaN (plain integer rounding would turn some NaNs into inf/0)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even, NaN stays NaN with the quiet bit set: gfx950's v_cvt_pk_bf16_f32.  It agrees with the integer form
+//   u > 0x7f800000 (NaN) ? (u >> 16) | 0x40 : (u + 0x7fff + ((u >> 16) & 1)) >> 16
+// on every one of the 2^32 float32 bit patterns (tools/exp/cvt_bf16_check.hip, run on the MI355X) at a seventh of the vector
+// instructions -- which is what the GEMM epilogues' time goes to at K = 512.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two at once: lo in bits 0..15, hi in bits 16..31 (one instruction)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    const f2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
 }
 
 template <typename T> struct ElemOps;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
         if (lane < 8 && b0 + 2 * wave + u < nq) {
             rg_u32x4 w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f32_to_bf16(o[2 * e]) | ((uint32_t)f32_to_bf16(o[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) w[e] = pack_bf16(o[2 * e], o[2 * e + 1]);
             *reinterpret_cast<rg_u32x4*>(a.out + (size_t)mem_row(b0 + 2 * wave + u) * D + h * DK + cch * 8) = w;
         }
     }
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)ks * a.M + mr) * a.ldy + n) = v;
     if (a.yb) {
         uint2 o;
-        o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-        o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        o.x = pack_bf16(v.x, v.y);
+        o.y = pack_bf16(v.z, v.w);
         *reinterpret_cast<uint2*>(a.yb + (size_t)mr * a.ldyb + n) = o;
     }
 }

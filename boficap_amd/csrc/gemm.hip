@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                     hi.z = g1.z * (hi.z - mean) / den + b1.z; hi.w = g1.w * (hi.w - mean) / den + b1.w;
                 }
                 u32x4 o;
-                o.x = (uint32_t)f32_to_bf16(lo.x) | ((uint32_t)f32_to_bf16(lo.y) << 16);
-                o.y = (uint32_t)f32_to_bf16(lo.z) | ((uint32_t)f32_to_bf16(lo.w) << 16);
-                o.z = (uint32_t)f32_to_bf16(hi.x) | ((uint32_t)f32_to_bf16(hi.y) << 16);
-                o.w = (uint32_t)f32_to_bf16(hi.z) | ((uint32_t)f32_to_bf16(hi.w) << 16);
+                o.x = pack_bf16(lo.x, lo.y);
+                o.y = pack_bf16(lo.z, lo.w);
+                o.z = pack_bf16(hi.x, hi.y);
+                o.w = pack_bf16(hi.z, hi.w);
                 *reinterpret_cast<u32x4*>(dst) = o;
             } else if constexpr (sizeof(T) == 2) {
                 *reinterpret_cast<u32x4*>(dst) = ra[i].v;
@@ -355,6 +355,16 @@ extern "C" int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w
     a.relu = relu; a.row_len = row_len; a.rows_per_group = rows_per_group;
     if (drop_p > 0.f) { a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.drop_step = drop_step; }
     a.y2 = y2; a.ldy2 = ldy2;
+    return bofi::launch_linear(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_linear_fused(const void* x, int ldx, const void* w, const float* bias, const float* residual, int ldr, void* y, int y_dtype, int ldy,
+                                 void* y2, int ldy2, const float* ln_stats, const float* ln_colsum, int ln_groups, float* stats_out, int M, int N, int K,
+                                 int relu, void* stream) {
+    bofi::LinearArgs a{};
+    a.x = x; a.x_dtype = BOFI_DT_BF16; a.ldx = ldx; a.w = w; a.w_dtype = BOFI_DT_BF16; a.bias = bias;
+    a.residual = residual; a.ldr = ldr; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.relu = relu;
+    a.y2 = y2; a.ldy2 = ldy2; a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.ln_groups = ln_groups; a.stats_out = stats_out;
     return bofi::launch_linear(a, (hipStream_t)stream);
 }
 

@@ -19,57 +19,10 @@
 
 #include "bofi_common.h"
 #include "bofi_kernels.h"
+#include "gemm2.h"
 
 namespace bofi {
 
-template <typename T> struct GMma;
-template <> struct GMma<bf16_t> {
-    typedef bf16x8 Frag;
-    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct GMma<float> {
-    typedef float4 Frag;     // lane quarter q holds k = 16g + 4q + s for step s, in A and in B alike
-    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
-        return c;
-    }
-};
-
-struct Gemm2Params {
-    const void* x; int ldx;
-    const void* w;
-    const float* bias;
-    const float* residual; int ldr;
-    void* y; int ldy; int y_is_f32;
-    int M, N, K;
-    int relu;
-    const int* row_len; int rows_per_group;
-    const int* skip_if_ge; int skip_threshold;
-    // folded pre-norm LayerNorm of the consumer: x is the RAW residual stream, w = W * gain, bias = c,
-    // y = rstd[m] * (acc - mean[m] * colsum[n]) + c[n]; mean/rstd come from per-32-column partial
-    // (sum, sum of squares) pairs written by the producer's epilogue
-    const float* ln_stats; const float* ln_colsum; int ln_groups;
-    float* stats_out;         // this GEMM is a producer: partial (sum, sumsq) of its OUTPUT rows, [M][N/32][2]
-    void* y2; int ldy2;       // optional second copy of the output in the compute dtype
-    int splitk;               // > 1: blockIdx.y walks K slices; slice s writes its partial tile to y + s*M*ldy (f32),
-                              // bias / residual are added by slice 0 only, the consumer sums the slabs
-    int vec_ok;               // N, ldy, ldr multiples of 4 and y/bias/residual 16-byte aligned
-    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;     // training dropout on act(..) before the residual (0: off)
-    const uint64_t* drop_step;
-    float mask_scale;         // != 0: residual is a mask (see LinearArgs)
-    int dbg;                  // developer ablation (BOFI_GEMM_DBG): 1 = no loads, 2 = no MFMA/ds_read
-    // row list (FEAT bit 6): the GEMM runs over rows row_idx[0 .. *m_dev) of x and writes the same rows of y / y2 / the statistics
-    // (p.M is the capacity the grid was sized for; tiles past *m_dev return at once)
-    const int* row_idx; const int* m_dev;
-    int row_bands;            // XCD tile order: 8 (bands of A rows per XCD), 4, 2 or 1 (bands of weight columns per XCD)
-};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // counted wait that leaves `younger` slabs (LPS LDS-DMA instructions each) in flight, younger in [0, MAXY] (wave-uniform)
 template <int MAXY, int LPS> __device__ __forceinline__ void wait_slabs(int younger) {
     if constexpr (MAXY <= 0) {
@@ -308,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
             }
             if (p.stats_out) {                         // partial sums over this lane's aligned 32-column group (8 lanes)
                 float ps = live[u] ? (v.x + v.y) + (v.z + v.w) : 0.f;
-                float pq = live[u] ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+                float pq = live[u] ? __fadd_rn(__fmaf_rn(v.x, v.x, __fmul_rn(v.y, v.y)), __fmaf_rn(v.z, v.z, __fmul_rn(v.w, v.w))) : 0.f;      // (contraction spelled out: the two GEMM kernels must agree bit for bit)
                 ps = oct_sum(ps); pq = oct_sum(pq);
                 if (live[u] && (lane & 7) == 0)
                     reinterpret_cast<float2*>(p.stats_out)[(size_t)mrow_out[u] * (p.N >> 5) + (n >> 5)] = make_float2(ps, pq);
@@ -317,8 +270,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
             if (p.y2) {
                 if constexpr (sizeof(T) == 2) {
                     uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                    o.x = pack_bf16(v.x, v.y);
+                    o.y = pack_bf16(v.z, v.w);
                     *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y2) + (size_t)mrow_out[u] * p.ldy2 + n) = o;
                 } else {
                     *reinterpret_cast<float4*>(static_cast<float*>(p.y2) + (size_t)mrow_out[u] * p.ldy2 + n) = v;
@@ -328,8 +281,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
                 *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)mrow_out[u] * p.ldy + n) = v;
             } else if constexpr (sizeof(T) == 2) {
                 uint2 o;
-                o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-                o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                o.x = pack_bf16(v.x, v.y);
+                o.y = pack_bf16(v.z, v.w);
                 *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + (size_t)mrow_out[u] * p.ldy + n) = o;
             }
         }
@@ -429,6 +382,19 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
     const int feat = (p.ln_stats ? 1 : 0) | ((p.stats_out || p.y2) ? 2 : 0) | (p.row_len ? 4 : 0) | (p.drop_thresh ? 8 : 0) |
                      ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0) | (p.row_idx ? 64 : 0);
     if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%dx%d", &bm, &bn, &ns, &nw); }
+    if constexpr (sizeof(T) == 2) {
+        // large-M GEMMs of the encoder / fill stacks: persistent 256 x 128 tiles with loader wavefronts (gemm_pers.hip; same bits).
+        // BOFI_GEMM_PERS=0 turns it off, BOFI_GEMM_PERS_MIN=<tiles> moves the threshold (developer knobs, read per call)
+        if (!bm && (feat & ~16) <= 3 && !p.skip_if_ge) {       // (feature bit 4 alone = developer ablations)
+            const char* e = getenv("BOFI_GEMM_PERS");
+            const char* m = getenv("BOFI_GEMM_PERS_MIN");
+            const long t256 = (long)((p.M + 255) / 256) * (p.N / 128);
+            if (e && atoi(e) && t256 >= (m ? atol(m) : 200)) {      // (off unless asked for: see DESIGN.md section 12.12)
+                const int r = launch_gemm_pers(p, feat & 3, st);
+                if (r != -1) return r;
+            }
+        }
+    }
     if (!bm) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
         // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop

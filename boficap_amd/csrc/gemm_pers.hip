@@ -1,0 +1,308 @@
+// y = act(x . w^T + bias) [+ residual] for the large-M bf16 GEMMs of the encoder / fill stacks (same arithmetic, same epilogue
+// order and so the same bits as gemm_glds.hip's kernel), as PERSISTENT workgroups with dedicated loader wavefronts.
+//
+// Why: at 128 x 64 tiles the one-tile-per-workgroup kernel moves (128 + 64) * 128 B from L2 per
+// 256 MFMA cycles of a SIMD = 96 B/clk per CU, against the 53 B/clk a CU takes in (profiles/r02_l2_stream_probe.txt) -- the loads,
+// not the matrix cores, bound it at half the dense rate, and its per-workgroup start-up and epilogue (9 + 8 of 34 us at
+// 9216 x 2048 x 512) overlap nothing.  Here:
+//   * 256 x 128 tiles (48 B/clk per CU at the full MFMA rate), 8 consumer wavefronts of 64 x 64 each (16 x 16 x 32 MFMA tiles,
+//     4 x 4 accumulators);
+//   * one workgroup per CU for the whole launch, walking tiles blockIdx.x, blockIdx.x + grid, ... of the same XCD-aware order;
+//   * 4 loader wavefronts that only issue LDS-DMA (global_load_lds_dwordx4, 12 pieces of 1 KiB each per 64-deep K slab) into a
+//     3-slot ring and wait on their OWN vmcnt: the slab stream runs across tile boundaries, so the first two slabs of the next
+//     tile land while the consumers run the epilogue of this one, and a consumer's vmcnt carries only its own epilogue operands
+//     and stores (a wavefront's vmcnt retires in order: in a one-role kernel stores would sit in front of the next slabs);
+//   * one workgroup barrier per K step (slab s landed; slot of slab s-1 free) and one per tile (every consumer has read the last
+//     slab: its slot becomes the epilogue's staging area, 16 rows x 64 columns of float32 per wavefront at a time, private to the
+//     wavefront: no barriers inside the epilogue).
+#include <cstdio>
+#include <cstdlib>
+
+#include "gemm2.h"
+
+namespace bofi {
+
+namespace {
+
+constexpr int PBM = 256, PBN = 128, PNS = 3, PBK = 64;
+constexpr int PSTAGE = (PBM + PBN) * 128;              // bytes per ring slot
+constexpr int PCONS = 8;                               // consumer wavefronts (PLOAD loader wavefronts behind them)
+constexpr int PES = 68;                                // staging row stride in floats (64 + 4 pad)
+
+// FEAT as in gemm_glds.hip: bit 0 = folded LayerNorm in, bit 1 = row statistics / compute-dtype copy out
+template <int FEAT, bool RES, int PLOAD, bool DEFER>
+__global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Params p) {
+    typedef bf16_t T;
+    constexpr int PLA = PBM / 8 / PLOAD, PLB = PBN / 8 / PLOAD;      // LDS-DMA pieces per loader per slab (4 loaders: 8 of A, 4 of W)
+    constexpr int PLPS = PLA + PLB;
+    if constexpr (!RES) p.residual = nullptr;
+    if constexpr (!(FEAT & 1)) { p.ln_stats = nullptr; p.ln_colsum = nullptr; }
+    if constexpr (!(FEAT & 2)) { p.stats_out = nullptr; p.y2 = nullptr; }
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[PNS * PSTAGE + PBM * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = p.N / PBN, ntm = (p.M + PBM - 1) / PBM, ntiles = ntn * ntm;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / PBK;
+    const int np4 = (p.ln_groups > 0 ? p.ln_groups : p.K >> 5) >> 1;      // two (sum, sumsq) pairs per 16-byte load
+    // tile v of the XCD-aware order of gemm_glds.hip (workgroup i runs on XCD i % 8; grid is a multiple of 8, so tile v is on XCD v % 8)
+    auto tile_coords = [&](int v, int& mt, int& nt) {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = v & 7, idx = v >> 3;
+        const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        const int mb = (ntm + p.row_bands - 1) / p.row_bands;
+        const int band = t / (mb * ntn), local = t - band * mb * ntn;
+        const int rows_here = min(mb, ntm - band * mb);
+        nt = local / rows_here;
+        mt = band * mb + (local - nt * rows_here);
+    };
+
+    // developer aid (BOFI_GEMM_DBG & 64 with BOFI_GEMM_DBG_BUF=<device address>): 100 MHz stamps of wavefront 0 of each role in
+    // workgroups 0..7: [workgroup][role][256] 64-bit words
+    unsigned long long* stamps = ((p.dbg & 64) && blockIdx.x < 8 && (wave == 0 || wave == PCONS) && lane == 0)
+                                     ? reinterpret_cast<unsigned long long*>(const_cast<int*>(p.skip_if_ge)) + (blockIdx.x * 2 + (wave ? 1 : 0)) * 256 : nullptr;
+    int n_stamp = 0;
+    auto stamp = [&]() { if (stamps && n_stamp < 256) stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); };
+    if (wave >= PCONS) {
+        // ------------------------------------------------------------------ loader wavefronts
+        const int lw = wave - PCONS;
+        const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);       // XOR swizzle on the source, as in gemm_glds.hip
+        const T* asrc[PLA];
+        const T* bsrc[PLB];
+        int i_tile = 0, i_kt = 0, i_slot = 0;
+        auto issue_next = [&]() {
+            if (i_tile >= my_tiles) return;
+            if (i_kt == 0) {
+                int mt, nt;
+                tile_coords((int)blockIdx.x + i_tile * G, mt, nt);
+#pragma unroll
+                for (int j = 0; j < PLA; ++j) {
+                    int m = mt * PBM + (lw * PLA + j) * 8 + lrow;
+                    m = m < p.M ? m : p.M - 1;              // rows past M are computed and dropped
+                    asrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * 8;
+                }
+#pragma unroll
+                for (int j = 0; j < PLB; ++j) {
+                    const int n = nt * PBN + (lw * PLB + j) * 8 + lrow;
+                    bsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * 8;
+                }
+            }
+            unsigned char* sa = smem + i_slot * PSTAGE + lw * PLA * 1024;
+            unsigned char* sb = smem + i_slot * PSTAGE + PBM * 128 + lw * PLB * 1024;
+            const int kk = i_kt;
+            if (!(p.dbg & 1)) {                             // (developer ablation BOFI_GEMM_DBG: 1 = no loads, 2 = no LDS reads / MFMA, 8 = no epilogue)
+#pragma unroll
+            for (int j = 0; j < PLA; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)kk * PBK),
+                                                 (__attribute__((address_space(3))) void*)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < PLB; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + (size_t)kk * PBK),
+                                                 (__attribute__((address_space(3))) void*)(sb + j * 1024), 16, 0, 0);
+            }
+            i_slot = i_slot + 1 == PNS ? 0 : i_slot + 1;
+            if (++i_kt == nk) { i_kt = 0; ++i_tile; }
+        };
+        const int total = my_tiles * nk;
+        issue_next();
+        issue_next();
+        // folded LayerNorm: the loaders also turn the producer's partial (sum, sumsq) pairs into the row mean / 1/(std+eps) of the tile
+        // the consumers are on (they have the registers to spare): 8 loads per lane behind the first step's slab, summed at the second
+        // step -- the counted wait of that step leaves them in flight with the slab
+        float* s_mean = reinterpret_cast<float*>(smem + PNS * PSTAGE);
+        float* s_rstd = s_mean + PBM;
+        // (the 8 loads and their wait are inline assembly: compiler-tracked loads would make it drain vmcnt to 0 -- the newest slab
+        // included -- at their first use and again before the next tile's loads overwrite the registers)
+        f32x4 st[8];
+        int kt = 0, c_tile = 0;
+        for (int s = 0; s < total; ++s) {
+            if (s + 1 >= total) wait_vmcnt<0>();
+            else if (p.ln_stats && lw < 4 && kt == 1) wait_vmcnt<PLPS + 8>();
+            else wait_vmcnt<PLPS>();                        // slab s has landed; slab s+1 may be in flight
+            stamp();
+            __builtin_amdgcn_s_barrier();                   // step barrier: the consumers are past slab s-1
+            stamp();
+            if (p.ln_stats && lw < 4 && kt == 1) {          // the statistics requested one step ago sit in front of slab s+1 (as gemm_glds.hip sums them)
+                if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : "n"(PLPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (i < np4) { sm += st[i][0] + st[i][2]; sq += st[i][1] + st[i][3]; }
+                const float mean = sm / (float)p.K;
+                const float var = fmaxf((sq - sm * mean) / (float)(p.K - 1), 0.f);
+                s_mean[lw * 64 + lane] = mean;
+                s_rstd[lw * 64 + lane] = 1.0f / (sqrtf(var) + 1e-6f);
+            }
+            if (p.ln_stats && lw < 4 && kt == 0) {
+                int mt, nt;
+                tile_coords((int)blockIdx.x + c_tile * G, mt, nt);
+                const int m = mt * PBM + lw * 64 + lane;
+                const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)(m < p.M ? m : p.M - 1) * np4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)                 // always 8 loads: the waits count them
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[i]) : "v"(sp + (i < np4 ? i : np4 - 1)) : "memory");
+            }
+            issue_next();                                   // slab s+2 -> the slot of slab s-1
+            stamp();
+            if (++kt == nk) { kt = 0; ++c_tile; __builtin_amdgcn_s_barrier(); }      // tile barrier
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer wavefronts
+    const int wr = wave >> 1, wc = wave & 1;                // 4 x 2 wavefronts, 64 x 64 each
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int lc = (lane & 15) * 4, lr = lane >> 4;         // epilogue: 16 lanes per row (4 columns each), 4 rows per wave instruction
+    const float* s_mean = reinterpret_cast<const float*>(smem + PNS * PSTAGE) + wr * 64;      // this wavefront's 64 rows (written by the loaders)
+    const float* s_rstd = s_mean + PBM;
+    int slot = 0;
+    // DEFER (bf16 output only, no second copy / statistics): a finished tile's 16 row-segment stores per lane are not issued at the
+    // tile's end -- every CU would write its 64 KiB at once, and the next tile's loads would queue behind them -- but spread over the
+    // K steps of the NEXT tile (2 per step at K = 512), from registers.
+    uint2 pend[16];
+    bf16_t* pbase = nullptr;
+    int pm0 = 0;
+    auto drip = [&](int lo, int hi) {                     // stores [lo, hi) of the pending tile
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            if (idx < lo || idx >= hi) continue;
+            const int r = (idx >> 2) * 16 + (idx & 3) * 4 + lr;
+            if (pm0 + r < p.M) *reinterpret_cast<uint2*>(pbase + (size_t)r * p.ldy) = pend[idx];
+        }
+    };
+    for (int jt = 0; jt < my_tiles; ++jt) {
+        int mt, nt;
+        tile_coords((int)blockIdx.x + jt * G, mt, nt);
+        const int m0 = mt * PBM + wr * 64, n = nt * PBN + wc * 64 + lc;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = bv;
+        float4 rv[4][4];
+        for (int kt = 0; kt < nk; ++kt) {
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            stamp();
+            if constexpr (DEFER) { if (pbase) drip((kt * 16) / nk, ((kt + 1) * 16) / nk); }
+            if (kt == nk - 1) {                             // the two small epilogue vectors ride under the last step
+                if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+                if (p.ln_stats) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+            }
+            const unsigned char* sa = smem + slot * PSTAGE + (wr * 64 + frow) * 128;
+            const unsigned char* sb = smem + slot * PSTAGE + PBM * 128 + (wc * 64 + frow) * 128;
+            if (!(p.dbg & 2)) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int coff = (((g * 4 + fq) ^ fx) << 4);
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + coff);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = GMma<bf16_t>::mma(fb[j], fa[i], acc[i][j]);   // D[n][m]: W is the MFMA "A"
+                if constexpr (DEFER) __builtin_amdgcn_sched_barrier(0);      // one fragment set live at a time: the pending tile's 32 registers have to fit
+            }
+            }
+            if (kt + 1 < nk) slot = slot + 1 == PNS ? 0 : slot + 1;
+        }
+        if constexpr (RES) {                                // the residual rows: requested once the fragments' registers are free, all before the first store
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int m = m0 + i * 16 + u * 4 + lr;
+                    rv[i][u] = *reinterpret_cast<const float4*>(p.residual + (size_t)(m < p.M ? m : p.M - 1) * p.ldr + n);
+                }
+        }
+        stamp();
+        __builtin_amdgcn_s_barrier();                       // tile barrier: every consumer has read the last slab; its slot is free until the next step barrier
+        float* es = reinterpret_cast<float*>(smem + slot * PSTAGE) + wave * (16 * PES);
+        slot = slot + 1 == PNS ? 0 : slot + 1;
+        if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; continue; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // C/D fragment of tile (i, j): row i*16 + (lane & 15), columns j*16 + (lane >> 4)*4 .. +3
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(&es[frow * PES + j * 16 + fq * 4]) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = u * 4 + lr, r = i * 16 + rr, m = m0 + r;      // r: row inside the wavefront's 64
+                const bool live = m < p.M;
+                float4 v = *reinterpret_cast<const float4*>(&es[rr * PES + lc]);
+                if (p.ln_stats) {
+                    const float mu = s_mean[r], rs = s_rstd[r];
+                    v.x = rs * (v.x - mu * cs.x); v.y = rs * (v.y - mu * cs.y); v.z = rs * (v.z - mu * cs.z); v.w = rs * (v.w - mu * cs.w);
+                }
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if constexpr (RES) { v.x = rv[i][u].x + v.x; v.y = rv[i][u].y + v.y; v.z = rv[i][u].z + v.z; v.w = rv[i][u].w + v.w; }
+                if (p.stats_out) {                         // partial sums over this lane's aligned 32-column group (8 lanes)
+                    float ps = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
+                    float pq = live ? __fadd_rn(__fmaf_rn(v.x, v.x, __fmul_rn(v.y, v.y)), __fmaf_rn(v.z, v.z, __fmul_rn(v.w, v.w))) : 0.f;      // (contraction spelled out: the two GEMM kernels must agree bit for bit)
+                    ps = oct_sum(ps); pq = oct_sum(pq);
+                    if (live && (lane & 7) == 0)
+                        reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 5) + (n >> 5)] = make_float2(ps, pq);
+                }
+                uint2 o;
+                o.x = pack_bf16(v.x, v.y);
+                o.y = pack_bf16(v.z, v.w);
+                if constexpr (DEFER) { pend[i * 4 + u] = o; continue; }
+                if (!live) continue;
+                if (p.y2) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y2) + (size_t)m * p.ldy2 + n) = o;
+                if (p.y_is_f32) *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)m * p.ldy + n) = v;
+                else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + (size_t)m * p.ldy + n) = o;
+            }
+        }
+        if constexpr (DEFER) { pbase = static_cast<bf16_t*>(p.y) + (size_t)m0 * p.ldy + n; pm0 = m0; }
+        stamp();
+    }
+    if constexpr (DEFER) { if (pbase) drip(0, 16); }
+}
+
+}  // namespace
+
+int launch_gemm_pers(const Gemm2Params& p_in, int feat, hipStream_t st) {
+    Gemm2Params p = p_in;
+    if (p.dbg & 64) { const char* b = getenv("BOFI_GEMM_DBG_BUF"); p.skip_if_ge = b ? reinterpret_cast<const int*>(strtoull(b, nullptr, 0)) : nullptr; if (!p.skip_if_ge) p.dbg &= ~64; }
+    if (feat > 3 || p.splitk != 1 || !p.vec_ok || p.N % PBN || p.K % PBK || p.K < PBK || p.row_len || p.row_idx || p.drop_thresh || p.mask_scale != 0.f ||
+        (p.skip_if_ge && !(p.dbg & 64)))
+        return -1;
+    if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if ((g & 1) || g > 16 || p.K < 2 * PBK) return -1; }
+    const int ntiles = (p.N / PBN) * ((p.M + PBM - 1) / PBM);
+    static const int cus = [] { const char* v = getenv("BOFI_GEMM_PERS_GRID"); return v ? atoi(v) : 256; }();
+    static const int nl = [] { const char* v = getenv("BOFI_GEMM_PERS_LOADERS"); return v ? atoi(v) : 4; }();
+    const dim3 g(ntiles < cus ? ntiles : cus), b(64 * (PCONS + (nl == 8 ? 8 : nl == 2 ? 2 : 4)));       // (the full grid is a multiple of 8: tile v stays on XCD v % 8)
+    static const int defer_ok = [] { const char* v = getenv("BOFI_GEMM_PERS_DEFER"); return v ? atoi(v) : 1; }();
+    const bool defer = defer_ok && !(feat & 2) && !p.y_is_f32 && !p.residual;
+#define PERS_CASE(F, R)                                                                             \
+    if constexpr (!((F) & 2) && !(R)) {                                                             \
+        if (defer) { hipLaunchKernelGGL((gemm_pers_kernel<F, R, 4, true>), g, b, 0, st, p); break; } \
+    }                                                                                               \
+    if (nl == 8) hipLaunchKernelGGL((gemm_pers_kernel<F, R, 8, false>), g, b, 0, st, p);            \
+    else if (nl == 2) hipLaunchKernelGGL((gemm_pers_kernel<F, R, 2, false>), g, b, 0, st, p);       \
+    else hipLaunchKernelGGL((gemm_pers_kernel<F, R, 4, false>), g, b, 0, st, p);                    \
+    break;
+    switch (feat * 2 + (p.residual ? 1 : 0)) {
+        case 0: PERS_CASE(0, false)
+        case 1: PERS_CASE(0, true)
+        case 2: PERS_CASE(1, false)
+        case 3: PERS_CASE(1, true)
+        case 4: PERS_CASE(2, false)
+        case 5: PERS_CASE(2, true)
+        case 6: PERS_CASE(3, false)
+        default: PERS_CASE(3, true)
+    }
+#undef PERS_CASE
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+}  // namespace bofi

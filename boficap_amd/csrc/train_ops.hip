@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
                 if (n + c < N) v[c] = drop_hash(drop_seed, (uint64_t)m * N + n + c) >= drop_thresh ? v[c] * drop_scale : 0.f;
         }
         uint2 o;
-        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        o.x = pack_bf16(v[0], v[1]);
+        o.y = pack_bf16(v[2], v[3]);
         *reinterpret_cast<uint2*>(y + (size_t)m * ldy + n) = o;              // ldy % 4 == 0 and n % 4 == 0
 #pragma unroll
         for (int c = 0; c < 4; ++c) s[c] += v[c];

@@ -200,6 +200,17 @@ int bofi_linear_ex(const void* x, int x_dtype, int ldx, const void* w, int w_dty
                    const int* row_len, int rows_per_group, float drop_p, uint64_t drop_seed, const uint64_t* drop_step, void* y2,
                    int ldy2, void* stream);
 
+/* The fused decode-path linear on bf16 operands (nn.Linear behind a pre-norm SublayerConnection, TransformerModel.py:1337-1363):
+ * ln_stats != NULL: x is the RAW residual stream in bf16 and the LayerNorm is folded in -- w must be W * gain, bias = W . beta + b,
+ * ln_colsum[n] = sum_k w[n][k], ln_stats = [M][ln_groups][2] partial (sum, sum of squares) pairs of the float32 rows (ln_groups 0: K / 32),
+ * y = rstd[m] * (x w^T - mean[m] * colsum) + bias;  then ReLU, then + residual (float32, may alias y);  y2 (may be NULL): a bf16 copy,
+ * stats_out (may be NULL): [M][N / 32][2] partial sums of the OUTPUT rows for the next folded LayerNorm.
+ * Large shapes (>= 200 tiles of 256 x 128, N % 128 == 0) run as persistent workgroups (gemm_pers.hip), the others one tile per
+ * workgroup (gemm_glds.hip): bit-identical results either way. */
+int bofi_linear_fused(const void* x, int ldx, const void* w, const float* bias, const float* residual, int ldr, void* y, int y_dtype, int ldy,
+                      void* y2, int ldy2, const float* ln_stats, const float* ln_colsum, int ln_groups, float* stats_out, int M, int N, int K,
+                      int relu, void* stream);
+
 /* y = mask > 0 ? (x w^T) * scale : 0 (no bias): the input gradient of a linear whose INPUT came out of relu (+ dropout with
  * scale = 1 / (1 - p)) -- mask [M, N] float32 is that forward activation (a clipped or dropped unit is 0 there), so the
  * gradient arrives already masked, e.g. in bf16 for the previous layer's backward GEMMs (nn.Linear backward followed by the

@@ -353,3 +353,53 @@ def test_bound_qattn_over_a_row_list(H):
     got = out.cpu().double()
     assert float((got[listed] - ref[listed]).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
     assert float((got[~listed] + 4.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(9216, 2048, 512), (11520 - 37, 1536, 512), (6600, 512, 2048), (2304, 6144, 512)])
+@pytest.mark.parametrize("mode", ["plain", "ln_relu", "res_stats"])
+def test_linear_fused_persistent_equals_one_tile_per_workgroup(H, M, N, K, mode, monkeypatch):
+    """bofi_linear_fused: the persistent 256 x 128 kernel (gemm_pers.hip: loader wavefronts, slab stream across tiles) against the
+    one-tile-per-workgroup kernel (gemm_glds.hip) on the same operands -- every output BIT-equal (same MFMA K order, same epilogue
+    order) -- and against float64 on the bf16-rounded operands.  Shapes: full tiles, a ragged last row tile, long K, wide N."""
+    g = _rng(M + N + K)
+    x32 = torch.randn(M, K, generator=g) * 1.5 + 0.2
+    x = x32.to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    acc = None
+
+    def run(pers):
+        monkeypatch.setenv("BOFI_GEMM_PERS", "1" if pers else "0")
+        kw = dict(res=None, y=None, y2=None, stats=None, colsum=None, groups=0, stats_out=None, relu=0, ydt=H.DT_F32)
+        if mode == "plain":
+            kw.update(y=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), ydt=H.DT_BF16)
+        elif mode == "ln_relu":
+            kw.update(stats=_row_stats(x32, K // 32).cuda(), colsum=w.double().sum(1).float(), relu=1,
+                      y=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), ydt=H.DT_BF16)
+        else:
+            res = torch.randn(M, N, generator=_rng(5)).cuda()
+            kw.update(res=res, y=res, y2=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), stats_out=torch.zeros(M, N // 32, 2, device="cuda"))     # in place, as the residual stream is
+        H.check(H.lib().bofi_linear_fused(H.ptr(x), K, H.ptr(w), H.ptr(bias), H.ptr(kw["res"]), N, H.ptr(kw["y"]), kw["ydt"], N, H.ptr(kw["y2"]), N,
+                                          H.ptr(kw["stats"]), H.ptr(kw["colsum"]), kw["groups"], H.ptr(kw["stats_out"]), M, N, K, kw["relu"], H.stream_ptr()),
+                "bofi_linear_fused")
+        torch.cuda.synchronize()
+        return kw
+
+    a, b = run(True), run(False)
+    for k in ("y", "y2", "stats_out"):
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), k
+    acc = (x.double() @ w.double().t()).cpu()
+    if mode == "plain":
+        ref = acc + bias.cpu().double()
+    elif mode == "ln_relu":
+        mean = x32.double().mean(1, keepdim=True)
+        rstd = 1.0 / (x32.double().std(1, keepdim=True) + 1e-6)
+        ref = torch.relu(rstd * (acc - mean * w.double().sum(1).cpu()) + bias.cpu().double())
+    else:
+        ref = acc + bias.cpu().double() + torch.randn(M, N, generator=_rng(5)).double()
+    scale = max(1.0, float(ref.abs().max()))
+    y = a["y"].cpu().double()
+    assert float((y - ref).abs().max()) <= (1e-2 if a["y"].dtype == torch.bfloat16 else 2e-5 * 8) * scale
+    if a["stats_out"] is not None:
+        assert torch.allclose(a["stats_out"].cpu(), _row_stats(a["y"].cpu(), N // 32), rtol=1e-4, atol=1e-3)
