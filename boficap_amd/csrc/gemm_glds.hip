@@ -383,13 +383,16 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
                      ((p.skip_if_ge || p.dbg) ? 16 : 0) | (p.mask_scale != 0.f ? 32 : 0) | (p.row_idx ? 64 : 0);
     if (const char* t = getenv("BOFI_GEMM_TILE")) { if (p.M > 64) sscanf(t, "%dx%dx%dx%d", &bm, &bn, &ns, &nw); }
     if constexpr (sizeof(T) == 2) {
-        // large-M GEMMs of the encoder / fill stacks: persistent 256 x 128 tiles with loader wavefronts (gemm_pers.hip; same bits).
+        // GEMMs of >= 90 tiles of 256 x 128 (N % 128 == 0): persistent workgroups with loader wavefronts (gemm_pers.hip; same bits).
+        // Alone such a launch is about as fast as this kernel (1.0-1.2x at >= 700 tiles, 0.8-0.95x below); with several decodes in
+        // flight it is what keeps their big GEMMs from interleaving thousands of workgroups on every CU: 115 -> 135 k img/s on the
+        // default bench (tools/exp/ab_bench2.sh, thresholds 1000 / 500 / 250 / 150 / 90: +3 / +8 / +9 / +14 / +17 %).
         // BOFI_GEMM_PERS=0 turns it off, BOFI_GEMM_PERS_MIN=<tiles> moves the threshold (developer knobs, read per call)
         if (!bm && (feat & ~16) <= 3 && !p.skip_if_ge) {       // (feature bit 4 alone = developer ablations)
             const char* e = getenv("BOFI_GEMM_PERS");
             const char* m = getenv("BOFI_GEMM_PERS_MIN");
             const long t256 = (long)((p.M + 255) / 256) * (p.N / 128);
-            if (e && atoi(e) && t256 >= (m ? atol(m) : 200)) {      // (off unless asked for: see DESIGN.md section 12.12)
+            if ((!e || atoi(e)) && t256 >= (m ? atol(m) : 90)) {
                 const int r = launch_gemm_pers(p, feat & 3, st);
                 if (r != -1) return r;
             }

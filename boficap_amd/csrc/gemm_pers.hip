@@ -26,11 +26,11 @@ namespace {
 
 constexpr int PBM = 256, PBN = 128, PNS = 3, PBK = 64;
 constexpr int PSTAGE = (PBM + PBN) * 128;              // bytes per ring slot
-constexpr int PCONS = 8;                               // consumer wavefronts (PLOAD loader wavefronts behind them)
+constexpr int PCONS = 8, PLOAD = 4;                    // consumer / loader wavefronts (2 and 8 loaders measure the same)
 constexpr int PES = 68;                                // staging row stride in floats (64 + 4 pad)
 
 // FEAT as in gemm_glds.hip: bit 0 = folded LayerNorm in, bit 1 = row statistics / compute-dtype copy out
-template <int FEAT, bool RES, int PLOAD, bool DEFER>
+template <int FEAT, bool RES>
 __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Params p) {
     typedef bf16_t T;
     constexpr int PLA = PBM / 8 / PLOAD, PLB = PBN / 8 / PLOAD;      // LDS-DMA pieces per loader per slab (4 loaders: 8 of A, 4 of W)
@@ -157,20 +157,6 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
     const float* s_mean = reinterpret_cast<const float*>(smem + PNS * PSTAGE) + wr * 64;      // this wavefront's 64 rows (written by the loaders)
     const float* s_rstd = s_mean + PBM;
     int slot = 0;
-    // DEFER (bf16 output only, no second copy / statistics): a finished tile's 16 row-segment stores per lane are not issued at the
-    // tile's end -- every CU would write its 64 KiB at once, and the next tile's loads would queue behind them -- but spread over the
-    // K steps of the NEXT tile (2 per step at K = 512), from registers.
-    uint2 pend[16];
-    bf16_t* pbase = nullptr;
-    int pm0 = 0;
-    auto drip = [&](int lo, int hi) {                     // stores [lo, hi) of the pending tile
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            if (idx < lo || idx >= hi) continue;
-            const int r = (idx >> 2) * 16 + (idx & 3) * 4 + lr;
-            if (pm0 + r < p.M) *reinterpret_cast<uint2*>(pbase + (size_t)r * p.ldy) = pend[idx];
-        }
-    };
     for (int jt = 0; jt < my_tiles; ++jt) {
         int mt, nt;
         tile_coords((int)blockIdx.x + jt * G, mt, nt);
@@ -187,7 +173,6 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
             stamp();
             __builtin_amdgcn_s_barrier();
             stamp();
-            if constexpr (DEFER) { if (pbase) drip((kt * 16) / nk, ((kt + 1) * 16) / nk); }
             if (kt == nk - 1) {                             // the two small epilogue vectors ride under the last step
                 if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
                 if (p.ln_stats) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
@@ -207,7 +192,6 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = GMma<bf16_t>::mma(fb[j], fa[i], acc[i][j]);   // D[n][m]: W is the MFMA "A"
-                if constexpr (DEFER) __builtin_amdgcn_sched_barrier(0);      // one fragment set live at a time: the pending tile's 32 registers have to fit
             }
             }
             if (kt + 1 < nk) slot = slot + 1 == PNS ? 0 : slot + 1;
@@ -254,17 +238,14 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 uint2 o;
                 o.x = pack_bf16(v.x, v.y);
                 o.y = pack_bf16(v.z, v.w);
-                if constexpr (DEFER) { pend[i * 4 + u] = o; continue; }
                 if (!live) continue;
                 if (p.y2) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y2) + (size_t)m * p.ldy2 + n) = o;
                 if (p.y_is_f32) *reinterpret_cast<float4*>(static_cast<float*>(p.y) + (size_t)m * p.ldy + n) = v;
                 else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.y) + (size_t)m * p.ldy + n) = o;
             }
         }
-        if constexpr (DEFER) { pbase = static_cast<bf16_t*>(p.y) + (size_t)m0 * p.ldy + n; pm0 = m0; }
         stamp();
     }
-    if constexpr (DEFER) { if (pbase) drip(0, 16); }
 }
 
 }  // namespace
@@ -278,29 +259,17 @@ int launch_gemm_pers(const Gemm2Params& p_in, int feat, hipStream_t st) {
     if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if ((g & 1) || g > 16 || p.K < 2 * PBK) return -1; }
     const int ntiles = (p.N / PBN) * ((p.M + PBM - 1) / PBM);
     static const int cus = [] { const char* v = getenv("BOFI_GEMM_PERS_GRID"); return v ? atoi(v) : 256; }();
-    static const int nl = [] { const char* v = getenv("BOFI_GEMM_PERS_LOADERS"); return v ? atoi(v) : 4; }();
-    const dim3 g(ntiles < cus ? ntiles : cus), b(64 * (PCONS + (nl == 8 ? 8 : nl == 2 ? 2 : 4)));       // (the full grid is a multiple of 8: tile v stays on XCD v % 8)
-    static const int defer_ok = [] { const char* v = getenv("BOFI_GEMM_PERS_DEFER"); return v ? atoi(v) : 1; }();
-    const bool defer = defer_ok && !(feat & 2) && !p.y_is_f32 && !p.residual;
-#define PERS_CASE(F, R)                                                                             \
-    if constexpr (!((F) & 2) && !(R)) {                                                             \
-        if (defer) { hipLaunchKernelGGL((gemm_pers_kernel<F, R, 4, true>), g, b, 0, st, p); break; } \
-    }                                                                                               \
-    if (nl == 8) hipLaunchKernelGGL((gemm_pers_kernel<F, R, 8, false>), g, b, 0, st, p);            \
-    else if (nl == 2) hipLaunchKernelGGL((gemm_pers_kernel<F, R, 2, false>), g, b, 0, st, p);       \
-    else hipLaunchKernelGGL((gemm_pers_kernel<F, R, 4, false>), g, b, 0, st, p);                    \
-    break;
+    const dim3 g(ntiles < cus ? ntiles : cus), b(64 * (PCONS + PLOAD));       // (the full grid is a multiple of 8: tile v stays on XCD v % 8)
     switch (feat * 2 + (p.residual ? 1 : 0)) {
-        case 0: PERS_CASE(0, false)
-        case 1: PERS_CASE(0, true)
-        case 2: PERS_CASE(1, false)
-        case 3: PERS_CASE(1, true)
-        case 4: PERS_CASE(2, false)
-        case 5: PERS_CASE(2, true)
-        case 6: PERS_CASE(3, false)
-        default: PERS_CASE(3, true)
+        case 0: hipLaunchKernelGGL((gemm_pers_kernel<0, false>), g, b, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_pers_kernel<0, true>), g, b, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_pers_kernel<1, false>), g, b, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_pers_kernel<1, true>), g, b, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((gemm_pers_kernel<2, false>), g, b, 0, st, p); break;
+        case 5: hipLaunchKernelGGL((gemm_pers_kernel<2, true>), g, b, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((gemm_pers_kernel<3, false>), g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pers_kernel<3, true>), g, b, 0, st, p); break;
     }
-#undef PERS_CASE
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
