@@ -30,7 +30,8 @@ constexpr int PCONS = 8, PLOAD = 4;                    // consumer / loader wave
 constexpr int PES = 68;                                // staging row stride in floats (64 + 4 pad)
 
 // FEAT as in gemm_glds.hip: bit 0 = folded LayerNorm in, bit 1 = row statistics / compute-dtype copy out
-template <int FEAT, bool RES>
+// FAST: bf16 output, no residual / second copy / statistics -- the epilogue stays in registers (see below)
+template <int FEAT, bool RES, bool FAST>
 __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Params p) {
     typedef bf16_t T;
     constexpr int PLA = PBM / 8 / PLOAD, PLB = PBN / 8 / PLOAD;      // LDS-DMA pieces per loader per slab (4 loaders: 8 of A, 4 of W)
@@ -46,7 +47,6 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
     const int G = gridDim.x;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
     const int nk = p.K / PBK;
-    const int np4 = (p.ln_groups > 0 ? p.ln_groups : p.K >> 5) >> 1;      // two (sum, sumsq) pairs per 16-byte load
     // tile v of the XCD-aware order of gemm_glds.hip (workgroup i runs on XCD i % 8; grid is a multiple of 8, so tile v is on XCD v % 8)
     auto tile_coords = [&](int v, int& mt, int& nt) {
         const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = v & 7, idx = v >> 3;
@@ -70,82 +70,115 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
         const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);       // XOR swizzle on the source, as in gemm_glds.hip
         const T* asrc[PLA];
         const T* bsrc[PLB];
+        const T* nasrc[PLA];                                // the NEXT tile's sources: worked out two slabs into the current tile, while the
+        const T* nbsrc[PLB];                                // loader would otherwise sit at the barrier (tile_coords is several integer divisions)
+        int srow = 0, nsrow = 0;                            // folded LayerNorm: first row of this loader's 64 rows of partial sums (tile being issued / next)
+        auto setup = [&](int t) {                           // -> nasrc / nbsrc / nsp of this workgroup's t-th tile
+            if (t >= my_tiles) return;
+            int mt, nt;
+            tile_coords((int)blockIdx.x + t * G, mt, nt);
+#pragma unroll
+            for (int j = 0; j < PLA; ++j) {
+                int m = mt * PBM + (lw * PLA + j) * 8 + lrow;
+                m = m < p.M ? m : p.M - 1;                  // rows past M are computed and dropped
+                nasrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * 8;
+            }
+#pragma unroll
+            for (int j = 0; j < PLB; ++j) {
+                const int n = nt * PBN + (lw * PLB + j) * 8 + lrow;
+                nbsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * 8;
+            }
+            nsrow = mt * PBM + lw * 64;
+        };
         int i_tile = 0, i_kt = 0, i_slot = 0;
+        const int pre_kt = nk > 2 ? 2 : nk - 1;
+        setup(0);
         auto issue_next = [&]() {
             if (i_tile >= my_tiles) return;
             if (i_kt == 0) {
-                int mt, nt;
-                tile_coords((int)blockIdx.x + i_tile * G, mt, nt);
 #pragma unroll
-                for (int j = 0; j < PLA; ++j) {
-                    int m = mt * PBM + (lw * PLA + j) * 8 + lrow;
-                    m = m < p.M ? m : p.M - 1;              // rows past M are computed and dropped
-                    asrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * 8;
-                }
+                for (int j = 0; j < PLA; ++j) asrc[j] = nasrc[j];
 #pragma unroll
-                for (int j = 0; j < PLB; ++j) {
-                    const int n = nt * PBN + (lw * PLB + j) * 8 + lrow;
-                    bsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * 8;
-                }
+                for (int j = 0; j < PLB; ++j) bsrc[j] = nbsrc[j];
+                srow = nsrow;
             }
             unsigned char* sa = smem + i_slot * PSTAGE + lw * PLA * 1024;
             unsigned char* sb = smem + i_slot * PSTAGE + PBM * 128 + lw * PLB * 1024;
-            const int kk = i_kt;
             if (!(p.dbg & 1)) {                             // (developer ablation BOFI_GEMM_DBG: 1 = no loads, 2 = no LDS reads / MFMA, 8 = no epilogue)
 #pragma unroll
             for (int j = 0; j < PLA; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)kk * PBK),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)i_kt * PBK),
                                                  (__attribute__((address_space(3))) void*)(sa + j * 1024), 16, 0, 0);
 #pragma unroll
             for (int j = 0; j < PLB; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + (size_t)kk * PBK),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + (size_t)i_kt * PBK),
                                                  (__attribute__((address_space(3))) void*)(sb + j * 1024), 16, 0, 0);
             }
+            if (i_kt == pre_kt) setup(i_tile + 1);
             i_slot = i_slot + 1 == PNS ? 0 : i_slot + 1;
             if (++i_kt == nk) { i_kt = 0; ++i_tile; }
         };
         const int total = my_tiles * nk;
         issue_next();
         issue_next();
-        // folded LayerNorm: the loaders also turn the producer's partial (sum, sumsq) pairs into the row mean / 1/(std+eps) of the tile
-        // the consumers are on (they have the registers to spare): 8 loads per lane behind the first step's slab, summed at the second
-        // step -- the counted wait of that step leaves them in flight with the slab
+        // folded LayerNorm (K >= 5 slabs, 16 partial-sum pairs per row): the loaders also turn the producer's partial (sum, sumsq) pairs
+        // into the row mean / 1/(std+eps) of the tile the consumers are on (they have the registers to spare).  A row's pairs are 128
+        // contiguous bytes: 8 loads of 8 rows each per loader (8 lanes per row, one 128-byte line each; one
+        // load per lane and ROW would touch 64 lines per instruction -- measured 1.3 us of issue per tile), requested in front of the
+        // slab the tile's first step issues -- so the counted wait of the second step leaves them in flight with that slab, and the wait
+        // of the third step (for that slab) covers them.  They are summed there: the 8 pieces of a row left to right, as gemm_glds.hip
+        // sums them, by a chain of row_shl DPP adds that ends in the row's first lane.
         float* s_mean = reinterpret_cast<float*>(smem + PNS * PSTAGE);
         float* s_rstd = s_mean + PBM;
-        // (the 8 loads and their wait are inline assembly: compiler-tracked loads would make it drain vmcnt to 0 -- the newest slab
-        // included -- at their first use and again before the next tile's loads overwrite the registers)
+        // (the 8 loads are inline assembly: compiler-tracked loads would make it drain vmcnt to 0 -- the newest slab included -- at
+        // their first use and again before the next tile's loads overwrite the registers)
         f32x4 st[8];
-        int kt = 0, c_tile = 0;
+        float row_sm = 0.f, row_sq = 0.f;
+        int kt = 0;
         for (int s = 0; s < total; ++s) {
             if (s + 1 >= total) wait_vmcnt<0>();
-            else if (p.ln_stats && lw < 4 && kt == 1) wait_vmcnt<PLPS + 8>();
+            else if (p.ln_stats && kt == 1) wait_vmcnt<PLPS + 8>();
             else wait_vmcnt<PLPS>();                        // slab s has landed; slab s+1 may be in flight
             stamp();
             __builtin_amdgcn_s_barrier();                   // step barrier: the consumers are past slab s-1
             stamp();
-            if (p.ln_stats && lw < 4 && kt == 1) {          // the statistics requested one step ago sit in front of slab s+1 (as gemm_glds.hip sums them)
-                if (s + 1 < total) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : "n"(PLPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
-                float sm = 0.f, sq = 0.f;
+            if (p.ln_stats && kt == 0) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) if (i < np4) { sm += st[i][0] + st[i][2]; sq += st[i][1] + st[i][3]; }
-                const float mean = sm / (float)p.K;
-                const float var = fmaxf((sq - sm * mean) / (float)(p.K - 1), 0.f);
+                for (int c = 0; c < 8; ++c) {               // always 8 loads: the waits count them
+                    const int m = srow + (lane >> 3) * 8 + c;      // load c: rows c, 8 + c, .. 56 + c of this loader's 64 (8 lanes per row)
+                    const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)(m < p.M ? m : p.M - 1) * 8 + (lane & 7);
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[c]) : "v"(sp) : "memory");
+                }
+            }
+            issue_next();                                   // slab s+2 -> the slot of slab s-1
+            if (p.ln_stats && kt == 2) {                    // (behind the issue: the slab should not wait for this arithmetic)
+                asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+#define BOFI_STAT_ROWS(c)                                                                                                   \
+                {                                                                                                           \
+                    const float a = st[c][0] + st[c][2], q = st[c][1] + st[c][3];                                           \
+                    float sm = 0.f + a, sq = 0.f + q;                                                                       \
+                    sm += dpp_f32<0x101>(a); sq += dpp_f32<0x101>(q);                                                       \
+                    sm += dpp_f32<0x102>(a); sq += dpp_f32<0x102>(q);                                                       \
+                    sm += dpp_f32<0x103>(a); sq += dpp_f32<0x103>(q);                                                       \
+                    sm += dpp_f32<0x104>(a); sq += dpp_f32<0x104>(q);                                                       \
+                    sm += dpp_f32<0x105>(a); sq += dpp_f32<0x105>(q);                                                       \
+                    sm += dpp_f32<0x106>(a); sq += dpp_f32<0x106>(q);                                                       \
+                    sm += dpp_f32<0x107>(a); sq += dpp_f32<0x107>(q);                                                       \
+                    /* row 8*j + c sits in lane 8*j: hand it to lane 8*j + c (row_shr: c): the divisions and the root then run once, lane = row */ \
+                    const float tm = (c) ? dpp_f32<0x110 + ((c) ? (c) : 1)>(sm) : sm, tq = (c) ? dpp_f32<0x110 + ((c) ? (c) : 1)>(sq) : sq; \
+                    if ((lane & 7) == (c)) { row_sm = tm; row_sq = tq; }                                                    \
+                }
+                BOFI_STAT_ROWS(0) BOFI_STAT_ROWS(1) BOFI_STAT_ROWS(2) BOFI_STAT_ROWS(3) BOFI_STAT_ROWS(4) BOFI_STAT_ROWS(5) BOFI_STAT_ROWS(6) BOFI_STAT_ROWS(7)
+#undef BOFI_STAT_ROWS
+            }
+            if (p.ln_stats && kt == 3) {                    // one step later: the two divisions and the root (K >= 5 slabs: the consumers read behind a later barrier)
+                const float mean = row_sm / (float)p.K;
+                const float var = fmaxf((row_sq - row_sm * mean) / (float)(p.K - 1), 0.f);
                 s_mean[lw * 64 + lane] = mean;
                 s_rstd[lw * 64 + lane] = 1.0f / (sqrtf(var) + 1e-6f);
             }
-            if (p.ln_stats && lw < 4 && kt == 0) {
-                int mt, nt;
-                tile_coords((int)blockIdx.x + c_tile * G, mt, nt);
-                const int m = mt * PBM + lw * 64 + lane;
-                const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)(m < p.M ? m : p.M - 1) * np4;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)                 // always 8 loads: the waits count them
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[i]) : "v"(sp + (i < np4 ? i : np4 - 1)) : "memory");
-            }
-            issue_next();                                   // slab s+2 -> the slot of slab s-1
             stamp();
-            if (++kt == nk) { kt = 0; ++c_tile; __builtin_amdgcn_s_barrier(); }      // tile barrier
+            if (++kt == nk) { kt = 0; if constexpr (!FAST) __builtin_amdgcn_s_barrier(); }      // tile barrier (the staged epilogue's)
         }
         return;
     }
@@ -169,13 +202,23 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
 
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = bv;
         float4 rv[4][4];
+        float4 bvf[4], csf[4];                              // FAST: bias / column sums of this lane's columns j*16 + (lane >> 4)*4 .. +3 in the C/D layout
+        const int nwv = nt * PBN + wc * 64;                 // first column of this wavefront
         for (int kt = 0; kt < nk; ++kt) {
             stamp();
             __builtin_amdgcn_s_barrier();
             stamp();
-            if (kt == nk - 1) {                             // the two small epilogue vectors ride under the last step
-                if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
-                if (p.ln_stats) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+            if (kt == nk - 1) {                             // the small epilogue vectors ride under the last step
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bvf[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nwv + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        csf[j] = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + nwv + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    if (p.ln_stats) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
+                }
             }
             const unsigned char* sa = smem + slot * PSTAGE + (wr * 64 + frow) * 128;
             const unsigned char* sb = smem + slot * PSTAGE + PBM * 128 + (wc * 64 + frow) * 128;
@@ -206,6 +249,48 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 }
         }
         stamp();
+        if constexpr (FAST) {
+            // Register epilogue.  The C/D fragment of tile (i, j) holds row i*16 + (lane & 15), columns j*16 + (lane >> 4)*4 .. +3: the
+            // arithmetic (same expressions, same order as the staged path: the same bits) runs right there, the results are packed to
+            // bf16 pairs, and a 4 x 4 transpose over (tile j, lane row lane >> 4) -- two v_permlane32_swap + two v_permlane16_swap per
+            // dword -- leaves every lane with 16 CONSECUTIVE columns of its row: two 16-byte stores per lane and 16-row group.  No LDS
+            // staging, no tile barrier: the epilogue is ~340 vector instructions per wavefront instead of ~540 plus 32 dependent LDS trips.
+            slot = slot + 1 == PNS ? 0 : slot + 1;
+            if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; continue; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float mu = 0.f, rs = 1.f;
+                if (p.ln_stats) { mu = s_mean[i * 16 + frow]; rs = s_rstd[i * 16 + frow]; }
+                uint32_t d[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    if (p.ln_stats) {
+                        v.x = rs * (v.x - mu * csf[j].x); v.y = rs * (v.y - mu * csf[j].y); v.z = rs * (v.z - mu * csf[j].z); v.w = rs * (v.w - mu * csf[j].w);
+                    }
+                    v.x += bvf[j].x; v.y += bvf[j].y; v.z += bvf[j].z; v.w += bvf[j].w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    d[j][0] = pack_bf16(v.x, v.y);
+                    d[j][1] = pack_bf16(v.z, v.w);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {               // d[j][c] in lane row q  ->  d[q][c] of lane row j
+                    auto s02 = __builtin_amdgcn_permlane32_swap(d[0][c], d[2][c], false, false);
+                    auto s13 = __builtin_amdgcn_permlane32_swap(d[1][c], d[3][c], false, false);
+                    auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                    auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                    d[0][c] = t01[0]; d[1][c] = t01[1]; d[2][c] = t23[0]; d[3][c] = t23[1];
+                }
+                const int m = m0 + i * 16 + frow;           // this lane now holds columns nwv + (lane >> 4)*16 .. +15 of row m
+                if (m < p.M) {
+                    bf16_t* dst = static_cast<bf16_t*>(p.y) + (size_t)m * p.ldy + nwv + fq * 16;
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(d[0][0], d[0][1], d[1][0], d[1][1]);
+                    *reinterpret_cast<uint4*>(dst + 8) = make_uint4(d[2][0], d[2][1], d[3][0], d[3][1]);
+                }
+            }
+            stamp();
+            continue;
+        }
         __builtin_amdgcn_s_barrier();                       // tile barrier: every consumer has read the last slab; its slot is free until the next step barrier
         float* es = reinterpret_cast<float*>(smem + slot * PSTAGE) + wave * (16 * PES);
         slot = slot + 1 == PNS ? 0 : slot + 1;
@@ -256,19 +341,25 @@ int launch_gemm_pers(const Gemm2Params& p_in, int feat, hipStream_t st) {
     if (feat > 3 || p.splitk != 1 || !p.vec_ok || p.N % PBN || p.K % PBK || p.K < PBK || p.row_len || p.row_idx || p.drop_thresh || p.mask_scale != 0.f ||
         (p.skip_if_ge && !(p.dbg & 64)))
         return -1;
-    if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if ((g & 1) || g > 16 || p.K < 2 * PBK) return -1; }
+    if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if (g != 16 || p.K < 5 * PBK) return -1; }      // (other group counts: gemm_glds.hip)
     const int ntiles = (p.N / PBN) * ((p.M + PBM - 1) / PBM);
     static const int cus = [] { const char* v = getenv("BOFI_GEMM_PERS_GRID"); return v ? atoi(v) : 256; }();
     const dim3 g(ntiles < cus ? ntiles : cus), b(64 * (PCONS + PLOAD));       // (the full grid is a multiple of 8: tile v stays on XCD v % 8)
+    static const int fast_ok = [] { const char* v = getenv("BOFI_GEMM_PERS_FAST"); return v ? atoi(v) : 1; }();      // developer knob: 0 = staged epilogue everywhere
+    const bool fast = fast_ok && !(feat & 2) && !p.residual && !p.y_is_f32 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0;
     switch (feat * 2 + (p.residual ? 1 : 0)) {
-        case 0: hipLaunchKernelGGL((gemm_pers_kernel<0, false>), g, b, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_pers_kernel<0, true>), g, b, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_pers_kernel<1, false>), g, b, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_pers_kernel<1, true>), g, b, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((gemm_pers_kernel<2, false>), g, b, 0, st, p); break;
-        case 5: hipLaunchKernelGGL((gemm_pers_kernel<2, true>), g, b, 0, st, p); break;
-        case 6: hipLaunchKernelGGL((gemm_pers_kernel<3, false>), g, b, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_pers_kernel<3, true>), g, b, 0, st, p); break;
+        case 0: if (fast) hipLaunchKernelGGL((gemm_pers_kernel<0, false, true>), g, b, 0, st, p);
+                else hipLaunchKernelGGL((gemm_pers_kernel<0, false, false>), g, b, 0, st, p);
+                break;
+        case 1: hipLaunchKernelGGL((gemm_pers_kernel<0, true, false>), g, b, 0, st, p); break;
+        case 2: if (fast) hipLaunchKernelGGL((gemm_pers_kernel<1, false, true>), g, b, 0, st, p);
+                else hipLaunchKernelGGL((gemm_pers_kernel<1, false, false>), g, b, 0, st, p);
+                break;
+        case 3: hipLaunchKernelGGL((gemm_pers_kernel<1, true, false>), g, b, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((gemm_pers_kernel<2, false, false>), g, b, 0, st, p); break;
+        case 5: hipLaunchKernelGGL((gemm_pers_kernel<2, true, false>), g, b, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((gemm_pers_kernel<3, false, false>), g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_pers_kernel<3, true, false>), g, b, 0, st, p); break;
     }
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;

@@ -6,6 +6,7 @@ from boficap_amd import hip as H
 lib = H.lib()
 M, N, K = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "11520x2048x512").split("x"))
 dbg = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+plain = len(sys.argv) > 3 and sys.argv[3] == "plain"          # no folded LayerNorm (no statistics loads in the loaders)
 buf = torch.zeros(8 * 2 * 256, dtype=torch.int64, device="cuda")
 os.environ["BOFI_GEMM_DBG"] = str(64 | dbg); os.environ["BOFI_GEMM_DBG_BUF"] = str(buf.data_ptr()); os.environ["BOFI_GEMM_PERS_MIN"] = "1"
 x = torch.randn(M, K, device="cuda").to(torch.bfloat16); w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
@@ -13,7 +14,7 @@ bias = torch.randn(N, device="cuda"); st = torch.rand(M, K // 32, 2, device="cud
 y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
 for rep in range(3):
     buf.zero_()
-    H.check(lib.bofi_linear_fused(H.ptr(x), K, H.ptr(w), H.ptr(bias), None, N, H.ptr(y), H.DT_BF16, N, None, N, H.ptr(st), H.ptr(cs), 0, None, M, N, K, 1, H.stream_ptr()))
+    H.check(lib.bofi_linear_fused(H.ptr(x), K, H.ptr(w), H.ptr(bias), None, N, H.ptr(y), H.DT_BF16, N, None, N, None if plain else H.ptr(st), None if plain else H.ptr(cs), 0, None, M, N, K, 1, H.stream_ptr()))
     torch.cuda.synchronize()
 b = buf.cpu().view(8, 2, 256)
 nk = K // 64
