@@ -176,6 +176,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(Gemm2Params p) 
         if (m < p.M) {
             const int np4 = (p.ln_groups > 0 ? p.ln_groups : p.K >> 5) >> 1;      // two (sum, sumsq) pairs per 16-byte load
             const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)row_of(m) * np4;
+            if (np4 == 8) {
+                // 16 pairs (d_model 512 in 32-column groups): summed as the balanced tree ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)) over the
+                // 8 loads -- the order an 8-lane DPP reduction produces, which is how gemm_pers.hip's loaders sum the same rows
+                float a[8], q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float4 t = sp[i]; a[i] = t.x + t.z; q[i] = t.y + t.w; }
+                sm = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[7] + a[6]) + (a[5] + a[4]));
+                sq = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[7] + q[6]) + (q[5] + q[4]));
+            } else
             for (int i = 0; i < np4; ++i) { const float4 t = sp[i]; sm += t.x + t.z; sq += t.y + t.w; }
         }
         const float mean = sm / (float)p.K;

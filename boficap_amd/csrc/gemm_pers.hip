@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
     if constexpr (!RES) p.residual = nullptr;
     if constexpr (!(FEAT & 1)) { p.ln_stats = nullptr; p.ln_colsum = nullptr; }
     if constexpr (!(FEAT & 2)) { p.stats_out = nullptr; p.y2 = nullptr; }
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[PNS * PSTAGE + PBM * 8];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[PNS * PSTAGE + PBM * 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
         const T* bsrc[PLB];
         const T* nasrc[PLA];                                // the NEXT tile's sources: worked out two slabs into the current tile, while the
         const T* nbsrc[PLB];                                // loader would otherwise sit at the barrier (tile_coords is several integer divisions)
-        int srow = 0, nsrow = 0;                            // folded LayerNorm: first row of this loader's 64 rows of partial sums (tile being issued / next)
+        int nsrow = 0;                                      // folded LayerNorm: first row of this loader's 64 rows of partial sums, of the tile setup() was last called for
         auto setup = [&](int t) {                           // -> nasrc / nbsrc / nsp of this workgroup's t-th tile
             if (t >= my_tiles) return;
             int mt, nt;
@@ -91,7 +91,6 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
             nsrow = mt * PBM + lw * 64;
         };
         int i_tile = 0, i_kt = 0, i_slot = 0;
-        const int pre_kt = nk > 2 ? 2 : nk - 1;
         setup(0);
         auto issue_next = [&]() {
             if (i_tile >= my_tiles) return;
@@ -100,7 +99,6 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 for (int j = 0; j < PLA; ++j) asrc[j] = nasrc[j];
 #pragma unroll
                 for (int j = 0; j < PLB; ++j) bsrc[j] = nbsrc[j];
-                srow = nsrow;
             }
             unsigned char* sa = smem + i_slot * PSTAGE + lw * PLA * 1024;
             unsigned char* sb = smem + i_slot * PSTAGE + PBM * 128 + lw * PLB * 1024;
@@ -114,71 +112,68 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + (size_t)i_kt * PBK),
                                                  (__attribute__((address_space(3))) void*)(sb + j * 1024), 16, 0, 0);
             }
-            if (i_kt == pre_kt) setup(i_tile + 1);
             i_slot = i_slot + 1 == PNS ? 0 : i_slot + 1;
             if (++i_kt == nk) { i_kt = 0; ++i_tile; }
         };
         const int total = my_tiles * nk;
-        issue_next();
-        issue_next();
-        // folded LayerNorm (K >= 5 slabs, 16 partial-sum pairs per row): the loaders also turn the producer's partial (sum, sumsq) pairs
-        // into the row mean / 1/(std+eps) of the tile the consumers are on (they have the registers to spare).  A row's pairs are 128
-        // contiguous bytes: 8 loads of 8 rows each per loader (8 lanes per row, one 128-byte line each; one
-        // load per lane and ROW would touch 64 lines per instruction -- measured 1.3 us of issue per tile), requested in front of the
-        // slab the tile's first step issues -- so the counted wait of the second step leaves them in flight with that slab, and the wait
-        // of the third step (for that slab) covers them.  They are summed there: the 8 pieces of a row left to right, as gemm_glds.hip
-        // sums them, by a chain of row_shl DPP adds that ends in the row's first lane.
-        float* s_mean = reinterpret_cast<float*>(smem + PNS * PSTAGE);
-        float* s_rstd = s_mean + PBM;
+        // folded LayerNorm (16 partial-sum pairs per row): the loaders also turn the producer's partial (sum, sumsq) pairs into the row
+        // mean / 1/(std+eps) the consumers' epilogue needs (they have the registers and, at a tile's first step, the time: the
+        // consumers are still in the previous tile's epilogue).  A row's pairs are 128 contiguous bytes: 8 loads of 8 rows each per
+        // loader (8 lanes per row, one line each; one load per lane and ROW would touch 64 lines per instruction -- measured 1.3 us of
+        // issue per tile).  The loads of tile c+1 go out at the first step of tile c, in front of the slab that step issues -- the
+        // counted wait of the second step leaves them in flight with that slab, every later wait covers them -- and are summed a tile
+        // later, in the idle time before tile c+1's first barrier: the 8 pieces of a row as the balanced tree an 8-lane DPP reduction
+        // gives (gemm_glds.hip sums its 8 loads in the same order); the results go to the half of s_mean / s_rstd the consumers are
+        // not reading.
         // (the 8 loads are inline assembly: compiler-tracked loads would make it drain vmcnt to 0 -- the newest slab included -- at
         // their first use and again before the next tile's loads overwrite the registers)
+        float* s_mean = reinterpret_cast<float*>(smem + PNS * PSTAGE);
         f32x4 st[8];
-        float row_sm = 0.f, row_sq = 0.f;
-        int kt = 0;
+        auto load_stats = [&]() {                           // rows of the tile setup() was last called for
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {                   // always 8 loads: the waits count them
+                const int m = nsrow + (lane >> 3) * 8 + c;  // load c: rows c, 8 + c, .. 56 + c of this loader's 64 (8 lanes per row)
+                const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)(m < p.M ? m : p.M - 1) * 8 + (lane & 7);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[c]) : "v"(sp) : "memory");
+            }
+        };
+        if (p.ln_stats) load_stats();                       // tile 0's: in front of the first slabs
+        issue_next();
+        issue_next();
+        int kt = 0, c_tile = 0;
         for (int s = 0; s < total; ++s) {
+            if (kt == 0) {
+                // first step of a tile: the consumers are still in the previous tile's epilogue
+                if (p.ln_stats) {
+                    if (s == 0) wait_vmcnt<2 * PLPS>();     // tile 0's statistics (the two slabs behind them may be in flight); later tiles': covered long ago
+                    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+                    float row_sm = 0.f, row_sq = 0.f;
+#define BOFI_STAT_ROWS(c)                                                                                                   \
+                    {   /* row 8*j + c: its 8 pieces sit in lanes 8*j .. 8*j+7; every one of them gets the sum, lane 8*j + c keeps it */ \
+                        const float sm = oct_sum(st[c][0] + st[c][2]), sq = oct_sum(st[c][1] + st[c][3]);                   \
+                        if ((lane & 7) == (c)) { row_sm = sm; row_sq = sq; }                                                \
+                    }
+                    BOFI_STAT_ROWS(0) BOFI_STAT_ROWS(1) BOFI_STAT_ROWS(2) BOFI_STAT_ROWS(3) BOFI_STAT_ROWS(4) BOFI_STAT_ROWS(5) BOFI_STAT_ROWS(6) BOFI_STAT_ROWS(7)
+#undef BOFI_STAT_ROWS
+                    const float mean = row_sm / (float)p.K;
+                    const float var = fmaxf((row_sq - row_sm * mean) / (float)(p.K - 1), 0.f);
+                    float* dst = s_mean + (c_tile & 1) * (2 * PBM) + lw * 64 + lane;
+                    dst[0] = mean;
+                    dst[PBM] = 1.0f / (sqrtf(var) + 1e-6f);
+                }
+                setup(c_tile + 1);                          // the next tile's sources (tile_coords is several integer divisions) ...
+            }
+            const bool stats_next = p.ln_stats && c_tile + 1 < my_tiles;
             if (s + 1 >= total) wait_vmcnt<0>();
-            else if (p.ln_stats && kt == 1) wait_vmcnt<PLPS + 8>();
+            else if (stats_next && kt == 1) wait_vmcnt<PLPS + 8>();
             else wait_vmcnt<PLPS>();                        // slab s has landed; slab s+1 may be in flight
             stamp();
+            if (kt == 0 && stats_next) load_stats();        // ... and its statistics, behind slab s+1, in front of slab s+2
             __builtin_amdgcn_s_barrier();                   // step barrier: the consumers are past slab s-1
             stamp();
-            if (p.ln_stats && kt == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {               // always 8 loads: the waits count them
-                    const int m = srow + (lane >> 3) * 8 + c;      // load c: rows c, 8 + c, .. 56 + c of this loader's 64 (8 lanes per row)
-                    const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)(m < p.M ? m : p.M - 1) * 8 + (lane & 7);
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[c]) : "v"(sp) : "memory");
-                }
-            }
             issue_next();                                   // slab s+2 -> the slot of slab s-1
-            if (p.ln_stats && kt == 2) {                    // (behind the issue: the slab should not wait for this arithmetic)
-                asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
-#define BOFI_STAT_ROWS(c)                                                                                                   \
-                {                                                                                                           \
-                    const float a = st[c][0] + st[c][2], q = st[c][1] + st[c][3];                                           \
-                    float sm = 0.f + a, sq = 0.f + q;                                                                       \
-                    sm += dpp_f32<0x101>(a); sq += dpp_f32<0x101>(q);                                                       \
-                    sm += dpp_f32<0x102>(a); sq += dpp_f32<0x102>(q);                                                       \
-                    sm += dpp_f32<0x103>(a); sq += dpp_f32<0x103>(q);                                                       \
-                    sm += dpp_f32<0x104>(a); sq += dpp_f32<0x104>(q);                                                       \
-                    sm += dpp_f32<0x105>(a); sq += dpp_f32<0x105>(q);                                                       \
-                    sm += dpp_f32<0x106>(a); sq += dpp_f32<0x106>(q);                                                       \
-                    sm += dpp_f32<0x107>(a); sq += dpp_f32<0x107>(q);                                                       \
-                    /* row 8*j + c sits in lane 8*j: hand it to lane 8*j + c (row_shr: c): the divisions and the root then run once, lane = row */ \
-                    const float tm = (c) ? dpp_f32<0x110 + ((c) ? (c) : 1)>(sm) : sm, tq = (c) ? dpp_f32<0x110 + ((c) ? (c) : 1)>(sq) : sq; \
-                    if ((lane & 7) == (c)) { row_sm = tm; row_sq = tq; }                                                    \
-                }
-                BOFI_STAT_ROWS(0) BOFI_STAT_ROWS(1) BOFI_STAT_ROWS(2) BOFI_STAT_ROWS(3) BOFI_STAT_ROWS(4) BOFI_STAT_ROWS(5) BOFI_STAT_ROWS(6) BOFI_STAT_ROWS(7)
-#undef BOFI_STAT_ROWS
-            }
-            if (p.ln_stats && kt == 3) {                    // one step later: the two divisions and the root (K >= 5 slabs: the consumers read behind a later barrier)
-                const float mean = row_sm / (float)p.K;
-                const float var = fmaxf((row_sq - row_sm * mean) / (float)(p.K - 1), 0.f);
-                s_mean[lw * 64 + lane] = mean;
-                s_rstd[lw * 64 + lane] = 1.0f / (sqrtf(var) + 1e-6f);
-            }
             stamp();
-            if (++kt == nk) { kt = 0; if constexpr (!FAST) __builtin_amdgcn_s_barrier(); }      // tile barrier (the staged epilogue's)
+            if (++kt == nk) { kt = 0; ++c_tile; if constexpr (!FAST) __builtin_amdgcn_s_barrier(); }      // tile barrier (the staged epilogue's)
         }
         return;
     }
@@ -187,12 +182,13 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
     const int wr = wave >> 1, wc = wave & 1;                // 4 x 2 wavefronts, 64 x 64 each
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int lc = (lane & 15) * 4, lr = lane >> 4;         // epilogue: 16 lanes per row (4 columns each), 4 rows per wave instruction
-    const float* s_mean = reinterpret_cast<const float*>(smem + PNS * PSTAGE) + wr * 64;      // this wavefront's 64 rows (written by the loaders)
-    const float* s_rstd = s_mean + PBM;
+    const float* s_stat = reinterpret_cast<const float*>(smem + PNS * PSTAGE) + wr * 64;      // this wavefront's 64 rows of [tile parity][mean | rstd][256] (written by the loaders)
     int slot = 0;
     for (int jt = 0; jt < my_tiles; ++jt) {
         int mt, nt;
         tile_coords((int)blockIdx.x + jt * G, mt, nt);
+        const float* s_mean = s_stat + (jt & 1) * (2 * PBM);
+        const float* s_rstd = s_mean + PBM;
         const int m0 = mt * PBM + wr * 64, n = nt * PBN + wc * 64 + lc;
         f32x4 acc[4][4];
 #pragma unroll
@@ -338,13 +334,19 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
 int launch_gemm_pers(const Gemm2Params& p_in, int feat, hipStream_t st) {
     Gemm2Params p = p_in;
     if (p.dbg & 64) { const char* b = getenv("BOFI_GEMM_DBG_BUF"); p.skip_if_ge = b ? reinterpret_cast<const int*>(strtoull(b, nullptr, 0)) : nullptr; if (!p.skip_if_ge) p.dbg &= ~64; }
-    if (feat > 3 || p.splitk != 1 || !p.vec_ok || p.N % PBN || p.K % PBK || p.K < PBK || p.row_len || p.row_idx || p.drop_thresh || p.mask_scale != 0.f ||
+    if (feat > 3 || p.splitk != 1 || !p.vec_ok || p.N % PBN || p.K % PBK || p.K < 3 * PBK || p.row_len || p.row_idx || p.drop_thresh || p.mask_scale != 0.f ||
         (p.skip_if_ge && !(p.dbg & 64)))
         return -1;
-    if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if (g != 16 || p.K < 5 * PBK) return -1; }      // (other group counts: gemm_glds.hip)
+    if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if (g != 16) return -1; }      // (other group counts: gemm_glds.hip)
     const int ntiles = (p.N / PBN) * ((p.M + PBM - 1) / PBM);
     static const int cus = [] { const char* v = getenv("BOFI_GEMM_PERS_GRID"); return v ? atoi(v) : 256; }();
-    const dim3 g(ntiles < cus ? ntiles : cus), b(64 * (PCONS + PLOAD));       // (the full grid is a multiple of 8: tile v stays on XCD v % 8)
+    // every workgroup walks `rounds` tiles: the grid is the smallest multiple of 8 (tile v stays on XCD v % 8) that covers the tiles in
+    // as many rounds as all CUs would need -- 540 tiles run on 184 CUs in 3 rounds, not on 256 in 3, and the rest stay free for the
+    // other decodes in flight
+    const int rounds = (ntiles + cus - 1) / cus;
+    int grid = ntiles;
+    if (ntiles > cus) { grid = (((ntiles + rounds - 1) / rounds + 7) / 8) * 8; if (grid > cus) grid = cus; }
+    const dim3 g(grid), b(64 * (PCONS + PLOAD));
     static const int fast_ok = [] { const char* v = getenv("BOFI_GEMM_PERS_FAST"); return v ? atoi(v) : 1; }();      // developer knob: 0 = staged epilogue everywhere
     const bool fast = fast_ok && !(feat & 2) && !p.residual && !p.y_is_f32 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0;
     switch (feat * 2 + (p.residual ? 1 : 0)) {
