@@ -132,7 +132,9 @@ def gemm_rooflines(dtype, dev, batches=1):
             torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / 2000
         tf = 2.0 * M * N * K / us / 1e6
-        out.append({"kernel": "gemm_glds_kernel", "shape": f"{name}: M={M} N={N} K={K}", "us_per_launch": round(us, 2),
+        pers = dtype == torch.bfloat16 and N % 128 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 128) >= 90 and os.environ.get("BOFI_GEMM_PERS", "1") != "0"
+        out.append({"kernel": "gemm_pers_kernel (persistent 256x128 tiles, loader wavefronts)" if pers else "gemm_glds_kernel (one 128x64 tile per workgroup)",
+                    "shape": f"{name}: M={M} N={N} K={K}", "us_per_launch": round(us, 2),
                     "achieved": round(tf, 1), "peak": MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], "unit": "TFLOP/s",
                     "frac": round(tf / MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], 4)})
     return out
