@@ -22,8 +22,7 @@
 
 namespace bofi {
 
-constexpr int PBM = 256, PBN = 128, PNS = 3, PBK = 64;
-constexpr int PSTAGE = (PBM + PBN) * 128;              // bytes per ring slot
+constexpr int PBN = 128, PNS = 3, PBK = 64;
 constexpr int PCONS = 8, PLOAD = 4;                    // consumer / loader wavefronts (2 and 8 loaders measure the same)
 constexpr int PES = 68;                                // staging row stride in floats (64 + 4 pad)
 
@@ -31,19 +30,26 @@ constexpr int PES = 68;                                // staging row stride in 
 // FAST: bf16 output, no residual / second copy / statistics -- the epilogue stays in registers (see below).  (Measured: with float32
 // output and a float32 residual the register form is SLOWER than the staged one, 52 against 44 us at 11520 x 512 x 2048 -- its loads and
 // stores are 64-byte row pieces, 16 lines per instruction, where the staged rows are 256 bytes -- so those GEMMs keep the staging.)
-template <int FEAT, bool RES, bool FAST>
+// BM: tile rows, 256 or 128 (128: shapes of at most 128 tiles of 256 rows -- twice the workgroups, half the K loop each)
+template <int FEAT, bool RES, bool FAST, int BM>
 __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Params p) {
     typedef bf16_t T;
-    constexpr int PLA = PBM / 8 / PLOAD, PLB = PBN / 8 / PLOAD;      // LDS-DMA pieces per loader per slab (4 loaders: 8 of A, 4 of W)
+    constexpr int TM = BM / 64;                          // 16-row MFMA tiles per consumer wavefront (its rows: BM / 4)
+    constexpr int WROWS = BM / 4;
+    constexpr int NLS = BM / 32;                         // statistics loads per loader (8 rows each)
+    constexpr int PSTAGE = (BM + PBN) * 128;             // bytes per ring slot
+    constexpr int PLA = BM / 8 / PLOAD, PLB = PBN / 8 / PLOAD;      // LDS-DMA pieces per loader per slab (4 loaders: 8 of A, 4 of W)
     constexpr int PLPS = PLA + PLB;
     if constexpr (!RES) p.residual = nullptr;
     if constexpr (!(FEAT & 1)) { p.ln_stats = nullptr; p.ln_colsum = nullptr; }
     if constexpr (!(FEAT & 2)) { p.stats_out = nullptr; p.y2 = nullptr; }
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[PNS * PSTAGE + PBM * 16];
+    // (128-row tiles: a ring slot is smaller than the staged epilogue's 8 x 16 x 68 floats -- they get an area of their own behind the statistics)
+    constexpr int ESTAGE = BM == 128 ? PCONS * 16 * PES * 4 : 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[PNS * PSTAGE + BM * 16 + ESTAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = p.N / PBN, ntm = (p.M + PBM - 1) / PBM, ntiles = ntn * ntm;
+    const int ntn = p.N / PBN, ntm = (p.M + BM - 1) / BM, ntiles = ntn * ntm;
     const int G = gridDim.x;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
     const int nk = p.K / PBK;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
             tile_coords((int)blockIdx.x + t * G, mt, nt);
 #pragma unroll
             for (int j = 0; j < PLA; ++j) {
-                int m = mt * PBM + (lw * PLA + j) * 8 + lrow;
+                int m = mt * BM + (lw * PLA + j) * 8 + lrow;
                 m = m < p.M ? m : p.M - 1;                  // rows past M are computed and dropped
                 nasrc[j] = static_cast<const T*>(p.x) + (size_t)m * p.ldx + lchunk * 8;
             }
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 const int n = nt * PBN + (lw * PLB + j) * 8 + lrow;
                 nbsrc[j] = static_cast<const T*>(p.w) + (size_t)n * p.K + lchunk * 8;
             }
-            nsrow = mt * PBM + lw * 64;
+            nsrow = mt * BM + lw * WROWS;
         };
         int i_tile = 0, i_kt = 0, i_slot = 0;
         setup(0);
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 for (int j = 0; j < PLB; ++j) bsrc[j] = nbsrc[j];
             }
             unsigned char* sa = smem + i_slot * PSTAGE + lw * PLA * 1024;
-            unsigned char* sb = smem + i_slot * PSTAGE + PBM * 128 + lw * PLB * 1024;
+            unsigned char* sb = smem + i_slot * PSTAGE + BM * 128 + lw * PLB * 1024;
             if (!(p.dbg & 1)) {                             // (developer ablation BOFI_GEMM_DBG: 1 = no loads, 2 = no LDS reads / MFMA, 8 = no epilogue)
 #pragma unroll
             for (int j = 0; j < PLA; ++j)
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
         f32x4 st[8];
         auto load_stats = [&]() {                           // rows of the tile setup() was last called for
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {                   // always 8 loads: the waits count them
-                const int m = nsrow + (lane >> 3) * 8 + c;  // load c: rows c, 8 + c, .. 56 + c of this loader's 64 (8 lanes per row)
+            for (int c = 0; c < NLS; ++c) {                 // always NLS loads: the waits count them
+                const int m = nsrow + (lane >> 3) * NLS + c;      // load c: rows c, NLS + c, .. 7*NLS + c of this loader's BM / 4 (8 lanes per row)
                 const float4* sp = reinterpret_cast<const float4*>(p.ln_stats) + (size_t)(m < p.M ? m : p.M - 1) * 8 + (lane & 7);
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[c]) : "v"(sp) : "memory");
             }
@@ -146,26 +152,30 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                 // first step of a tile: the consumers are still in the previous tile's epilogue
                 if (p.ln_stats) {
                     if (s == 0) wait_vmcnt<2 * PLPS>();     // tile 0's statistics (the two slabs behind them may be in flight); later tiles': covered long ago
-                    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+                    if constexpr (NLS == 8) asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+                    else asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]) : : "memory");
                     float row_sm = 0.f, row_sq = 0.f;
 #define BOFI_STAT_ROWS(c)                                                                                                   \
-                    {   /* row 8*j + c: its 8 pieces sit in lanes 8*j .. 8*j+7; every one of them gets the sum, lane 8*j + c keeps it */ \
+                    {   /* row NLS*j + c: its 8 pieces sit in lanes 8*j .. 8*j+7; every one of them gets the sum, lane 8*j + c keeps it */ \
                         const float sm = oct_sum(st[c][0] + st[c][2]), sq = oct_sum(st[c][1] + st[c][3]);                   \
                         if ((lane & 7) == (c)) { row_sm = sm; row_sq = sq; }                                                \
                     }
-                    BOFI_STAT_ROWS(0) BOFI_STAT_ROWS(1) BOFI_STAT_ROWS(2) BOFI_STAT_ROWS(3) BOFI_STAT_ROWS(4) BOFI_STAT_ROWS(5) BOFI_STAT_ROWS(6) BOFI_STAT_ROWS(7)
+                    BOFI_STAT_ROWS(0) BOFI_STAT_ROWS(1) BOFI_STAT_ROWS(2) BOFI_STAT_ROWS(3)
+                    if constexpr (NLS == 8) { BOFI_STAT_ROWS(4) BOFI_STAT_ROWS(5) BOFI_STAT_ROWS(6) BOFI_STAT_ROWS(7) }
 #undef BOFI_STAT_ROWS
                     const float mean = row_sm / (float)p.K;
                     const float var = fmaxf((row_sq - row_sm * mean) / (float)(p.K - 1), 0.f);
-                    float* dst = s_mean + (c_tile & 1) * (2 * PBM) + lw * 64 + lane;
-                    dst[0] = mean;
-                    dst[PBM] = 1.0f / (sqrtf(var) + 1e-6f);
+                    if ((lane & 7) < NLS) {                 // lane 8*j + c holds row NLS*j + c
+                        float* dst = s_mean + (c_tile & 1) * (2 * BM) + lw * WROWS + (lane >> 3) * NLS + (lane & 7);
+                        dst[0] = mean;
+                        dst[BM] = 1.0f / (sqrtf(var) + 1e-6f);
+                    }
                 }
                 setup(c_tile + 1);                          // the next tile's sources (tile_coords is several integer divisions) ...
             }
             const bool stats_next = p.ln_stats && c_tile + 1 < my_tiles;
             if (s + 1 >= total) wait_vmcnt<0>();
-            else if (stats_next && kt == 1) wait_vmcnt<PLPS + 8>();
+            else if (stats_next && kt == 1) wait_vmcnt<PLPS + NLS>();
             else wait_vmcnt<PLPS>();                        // slab s has landed; slab s+1 may be in flight
             stamp();
             if (kt == 0 && stats_next) load_stats();        // ... and its statistics, behind slab s+1, in front of slab s+2
@@ -182,22 +192,22 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
     const int wr = wave >> 1, wc = wave & 1;                // 4 x 2 wavefronts, 64 x 64 each
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int lc = (lane & 15) * 4, lr = lane >> 4;         // epilogue: 16 lanes per row (4 columns each), 4 rows per wave instruction
-    const float* s_stat = reinterpret_cast<const float*>(smem + PNS * PSTAGE) + wr * 64;      // this wavefront's 64 rows of [tile parity][mean | rstd][256] (written by the loaders)
+    const float* s_stat = reinterpret_cast<const float*>(smem + PNS * PSTAGE) + wr * WROWS;      // this wavefront's rows of [tile parity][mean | rstd][BM] (written by the loaders)
     int slot = 0;
     for (int jt = 0; jt < my_tiles; ++jt) {
         int mt, nt;
         tile_coords((int)blockIdx.x + jt * G, mt, nt);
-        const float* s_mean = s_stat + (jt & 1) * (2 * PBM);
-        const float* s_rstd = s_mean + PBM;
-        const int m0 = mt * PBM + wr * 64, n = nt * PBN + wc * 64 + lc;
-        f32x4 acc[4][4];
+        const float* s_mean = s_stat + (jt & 1) * (2 * BM);
+        const float* s_rstd = s_mean + BM;
+        const int m0 = mt * BM + wr * WROWS, n = nt * PBN + wc * 64 + lc;
+        f32x4 acc[TM][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = bv;
-        float4 rv[4][4];
+        float4 rv[TM][4];
         float4 bvf[4], csf[4];                              // FAST: bias / column sums of this lane's columns j*16 + (lane >> 4)*4 .. +3 in the C/D layout
         const int nwv = nt * PBN + wc * 64;                 // first column of this wavefront
         for (int kt = 0; kt < nk; ++kt) {
@@ -216,19 +226,19 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
                     if (p.ln_stats) cs = *reinterpret_cast<const float4*>(p.ln_colsum + n);
                 }
             }
-            const unsigned char* sa = smem + slot * PSTAGE + (wr * 64 + frow) * 128;
-            const unsigned char* sb = smem + slot * PSTAGE + PBM * 128 + (wc * 64 + frow) * 128;
+            const unsigned char* sa = smem + slot * PSTAGE + (wr * WROWS + frow) * 128;
+            const unsigned char* sb = smem + slot * PSTAGE + BM * 128 + (wc * 64 + frow) * 128;
             if (!(p.dbg & 2)) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int coff = (((g * 4 + fq) ^ fx) << 4);
-                bf16x8 fa[4], fb[4];
+                bf16x8 fa[TM], fb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + coff);
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + coff);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + coff);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = GMma<bf16_t>::mma(fb[j], fa[i], acc[i][j]);   // D[n][m]: W is the MFMA "A"
             }
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
         }
         if constexpr (RES) {                                // the residual rows: requested once the fragments' registers are free, all before the first store
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int m = m0 + i * 16 + u * 4 + lr;
@@ -252,9 +262,9 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
             // dword -- leaves every lane with 16 CONSECUTIVE columns of its row: two 16-byte stores per lane and 16-row group.  No LDS
             // staging, no tile barrier: the epilogue is ~340 vector instructions per wavefront instead of ~540 plus 32 dependent LDS trips.
             slot = slot + 1 == PNS ? 0 : slot + 1;
-            if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; continue; }
+            if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = acc[1][1][1] + acc[TM - 1][2][2]; continue; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 float mu = 0.f, rs = 1.f;
                 if (p.ln_stats) { mu = s_mean[i * 16 + frow]; rs = s_rstd[i * 16 + frow]; }
                 uint32_t d[4][2];
@@ -288,11 +298,11 @@ __global__ __launch_bounds__(64 * (PCONS + PLOAD)) void gemm_pers_kernel(Gemm2Pa
             continue;
         }
         __builtin_amdgcn_s_barrier();                       // tile barrier: every consumer has read the last slab; its slot is free until the next step barrier
-        float* es = reinterpret_cast<float*>(smem + slot * PSTAGE) + wave * (16 * PES);
+        float* es = reinterpret_cast<float*>(smem + (BM == 128 ? PNS * PSTAGE + BM * 16 : slot * PSTAGE)) + wave * (16 * PES);
         slot = slot + 1 == PNS ? 0 : slot + 1;
-        if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; continue; }
+        if (p.dbg & 8) { if (acc[0][0][0] == 123.456f) static_cast<float*>(p.y)[0] = acc[1][1][1] + acc[TM - 1][2][2]; continue; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TM; ++i) {
             // C/D fragment of tile (i, j): row i*16 + (lane & 15), columns j*16 + (lane >> 4)*4 .. +3
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -336,31 +346,37 @@ int launch_gemm_pers(const Gemm2Params& p_in, int feat, hipStream_t st) {
         (p.skip_if_ge && !(p.dbg & 64)))
         return -1;
     if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if (g != 16) return -1; }      // (other group counts: gemm_glds.hip)
-    const int ntiles = (p.N / PBN) * ((p.M + PBM - 1) / PBM);
+    // 128-row tiles where 256-row tiles would leave half of the chip idle (at most 128 of them: the fill pass's N = 512 GEMMs are 92)
+    static const int bm128_max = [] { const char* v = getenv("BOFI_GEMM_PERS_BM128"); return v ? atoi(v) : 128; }();      // developer knob: 0 = 256-row tiles only
+    const int t256 = (p.N / PBN) * ((p.M + 255) / 256);
+    const int bm = t256 <= bm128_max ? 128 : 256;
+    const int ntiles = (p.N / PBN) * ((p.M + bm - 1) / bm);
     static const int cus = [] { const char* v = getenv("BOFI_GEMM_PERS_GRID"); return v ? atoi(v) : 256; }();
     // every workgroup walks `rounds` tiles: the grid is the smallest multiple of 8 (tile v stays on XCD v % 8) that covers the tiles in
     // as many rounds as all CUs would need -- 540 tiles run on 184 CUs in 3 rounds, not on 256 in 3, and the rest stay free for the
     // other decodes in flight
-    const int rounds = (ntiles + cus - 1) / cus;
+    static const int min_rounds = [] { const char* v = getenv("BOFI_GEMM_PERS_ROUNDS"); return v ? atoi(v) : 1; }();      // developer knob: tiles per workgroup at least
+    int rounds = (ntiles + cus - 1) / cus;
+    if (rounds < min_rounds) rounds = min_rounds;
     int grid = ntiles;
-    if (ntiles > cus) { grid = (((ntiles + rounds - 1) / rounds + 7) / 8) * 8; if (grid > cus) grid = cus; }
+    if (ntiles > cus || rounds > 1) { grid = (((ntiles + rounds - 1) / rounds + 7) / 8) * 8; if (grid > cus) grid = cus; if (grid > ntiles) grid = ntiles; }
     const dim3 g(grid), b(64 * (PCONS + PLOAD));
     static const int fast_ok = [] { const char* v = getenv("BOFI_GEMM_PERS_FAST"); return v ? atoi(v) : 1; }();      // developer knob: 0 = staged epilogue everywhere
     const bool fast = fast_ok && !(feat & 2) && !p.residual && !p.y_is_f32 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0;
+#define PERS_LAUNCH(F, R, Q)                                                                       \
+    { if (bm == 128) hipLaunchKernelGGL((gemm_pers_kernel<F, R, Q, 128>), g, b, 0, st, p);          \
+      else hipLaunchKernelGGL((gemm_pers_kernel<F, R, Q, 256>), g, b, 0, st, p); }
     switch (feat * 2 + (p.residual ? 1 : 0)) {
-        case 0: if (fast) hipLaunchKernelGGL((gemm_pers_kernel<0, false, true>), g, b, 0, st, p);
-                else hipLaunchKernelGGL((gemm_pers_kernel<0, false, false>), g, b, 0, st, p);
-                break;
-        case 1: hipLaunchKernelGGL((gemm_pers_kernel<0, true, false>), g, b, 0, st, p); break;
-        case 2: if (fast) hipLaunchKernelGGL((gemm_pers_kernel<1, false, true>), g, b, 0, st, p);
-                else hipLaunchKernelGGL((gemm_pers_kernel<1, false, false>), g, b, 0, st, p);
-                break;
-        case 3: hipLaunchKernelGGL((gemm_pers_kernel<1, true, false>), g, b, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((gemm_pers_kernel<2, false, false>), g, b, 0, st, p); break;
-        case 5: hipLaunchKernelGGL((gemm_pers_kernel<2, true, false>), g, b, 0, st, p); break;
-        case 6: hipLaunchKernelGGL((gemm_pers_kernel<3, false, false>), g, b, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_pers_kernel<3, true, false>), g, b, 0, st, p); break;
+        case 0: if (fast) PERS_LAUNCH(0, false, true) else PERS_LAUNCH(0, false, false) break;
+        case 1: PERS_LAUNCH(0, true, false) break;
+        case 2: if (fast) PERS_LAUNCH(1, false, true) else PERS_LAUNCH(1, false, false) break;
+        case 3: PERS_LAUNCH(1, true, false) break;
+        case 4: PERS_LAUNCH(2, false, false) break;
+        case 5: PERS_LAUNCH(2, true, false) break;
+        case 6: PERS_LAUNCH(3, false, false) break;
+        default: PERS_LAUNCH(3, true, false) break;
     }
+#undef PERS_LAUNCH
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -355,12 +355,13 @@ def test_bound_qattn_over_a_row_list(H):
     assert float((got[~listed] + 4.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(9216, 2048, 512), (11520 - 37, 1536, 512), (6600, 512, 2048), (2304, 6144, 512)])
+@pytest.mark.parametrize("M,N,K", [(9216, 2048, 512), (11520 - 37, 1536, 512), (6600, 512, 2048), (2304, 6144, 512), (5760 - 37, 512, 512), (5760, 512, 2048)])
 @pytest.mark.parametrize("mode", ["plain", "ln_relu", "res_stats"])
 def test_linear_fused_persistent_equals_one_tile_per_workgroup(H, M, N, K, mode, monkeypatch):
     """bofi_linear_fused: the persistent 256 x 128 kernel (gemm_pers.hip: loader wavefronts, slab stream across tiles) against the
     one-tile-per-workgroup kernel (gemm_glds.hip) on the same operands -- every output BIT-equal (same MFMA K order, same epilogue
-    order) -- and against float64 on the bf16-rounded operands.  Shapes: full tiles, a ragged last row tile, long K, wide N."""
+    order) -- and against float64 on the bf16-rounded operands.  Shapes: full tiles, a ragged last row tile, long K, wide N, and two of
+    at most 128 tiles of 256 rows, which run on the 128-row form of the kernel (ragged, long K)."""
     g = _rng(M + N + K)
     x32 = torch.randn(M, K, generator=g) * 1.5 + 0.2
     x = x32.to(torch.bfloat16).cuda()
