@@ -106,7 +106,8 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.h
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
                           int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr,
-                          const int* row_idx = nullptr, const int* n_rows = nullptr);     // row list: rows row_idx[0 .. *n_rows) only
+                          const int* row_idx = nullptr, const int* n_rows = nullptr,      // row list: rows row_idx[0 .. *n_rows) only
+                          const float* src = nullptr, int ld_src = 0);                   // src: the logits are read from src (row pitch ld_src), results go to `logits` (pitch V)
 
 // ---- device-side weight repack (repack.hip)
 struct PackLinArgs {

@@ -39,7 +39,7 @@ uint16_t host_bf16(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; };   // cs: column sums when a LayerNorm is folded in
+struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; int Npad = 0; };   // cs: column sums when a LayerNorm is folded in; Npad > N: rows N .. Npad of w / b / cs exist and are zero
 struct Norm { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, w1, w2; Norm n0, n1; };
 struct DecLayer { Lin qkv, o, q_src, o_src, w1, w2; Norm n0, n1, n2; };
@@ -86,6 +86,7 @@ struct bofi_engine {
 
     // workspace
     float *x_enc = nullptr, *x_fill = nullptr, *logits = nullptr;
+    float* logits_pad = nullptr;         // bf16 engine: the generator's output with a pitch of gen.Npad (whole 128-column tiles: the persistent GEMM), read by vocab_finalize
     void *qkv = nullptr, *ctx = nullptr, *hdn = nullptr, *mem = nullptr, *kv = nullptr, *qs = nullptr, *xn = nullptr;
     void* feats_t = nullptr;                                          // bf16 copy of float32 input features
     void *xb_enc = nullptr, *xb_fill = nullptr, *byb = nullptr;       // compute-dtype copies of the residual streams
@@ -152,7 +153,7 @@ struct bofi_engine {
     // LayerNorm that feeds this layer is folded in (gemm_glds.hip): w <- w * a_2 (per input column),
     // bias <- bias + w . b_2, cs[n] <- sum_k of the ROUNDED scaled weight (so that the mean term of
     // the epilogue cancels exactly what the MFMA accumulated).
-    int make_lin(Lin* out, const std::vector<std::string>& prefixes, int n_each, int K, const std::string& fold_norm = "") {
+    int make_lin(Lin* out, const std::vector<std::string>& prefixes, int n_each, int K, const std::string& fold_norm = "", int pad_to = 0) {
         std::vector<float> w, b;
         for (const auto& p : prefixes) {
             const auto* pw = get(p + ".weight", (size_t)n_each * K);
@@ -163,6 +164,7 @@ struct bofi_engine {
         }
         out->N = n_each * (int)prefixes.size();
         out->K = K;
+        out->Npad = pad_to > 0 ? ((out->N + pad_to - 1) / pad_to) * pad_to : out->N;      // zero rows behind the N real ones (the repack on the device writes the first N only)
         if (!fold_norm.empty()) {
             const auto* g = get(fold_norm + ".a_2", K);
             const auto* bb = get(fold_norm + ".b_2", K);
@@ -181,8 +183,11 @@ struct bofi_engine {
                 b[n] = (float)c;
                 cs[n] = (float)s;
             }
+            cs.resize(out->Npad, 0.f);
             ENG_OK(upload_f32(&out->cs, cs));
         }
+        w.resize((size_t)out->Npad * K, 0.f);
+        b.resize(out->Npad, 0.f);
         ENG_OK(upload_t(&out->w, w));
         ENG_OK(upload_f32(&out->b, b));
         lin_recipes.push_back(LinRecipe{out, prefixes, n_each, K, fold_norm});
@@ -248,6 +253,7 @@ struct bofi_engine {
     ENG_OK(dalloc(&x_enc, Bm * Rm * d));
     ENG_OK(dalloc(&x_fill, Bm * Sq * d));
     ENG_OK(dalloc(&logits, Bm * Sq * c.vocab));
+    if (c.dtype == BOFI_DT_BF16 && gen.Npad > gen.N) ENG_OK(dalloc(&logits_pad, Bm * Sq * (size_t)gen.Npad));
     ENG_OK(dalloc((char**)&qkv, rows * 3 * d, tsz));
     ENG_OK(dalloc((char**)&ctx, rows * d, tsz));
     ENG_OK(dalloc((char**)&hdn, rows * dff, tsz));
@@ -509,8 +515,21 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
           ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
     }
     // ---- vocabulary projection (decoder.norm folded in), log-softmax, greedy pick, pad tail
-    { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s)); }
-    ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s));
+    // generator.  V = 9 491 is not a whole number of 128-column tiles and its rows are not 16-byte aligned: the bf16 engine runs the GEMM
+    // over the zero-padded weight rows into a buffer of pitch gen.Npad (persistent kernel, vector epilogue) and vocab_finalize reads
+    // that, writing the log-probs at the caller's pitch V -- the same reads and writes as in place.
+    static const int gen_pad = [] { const char* v = getenv("BOFI_GEN_PAD"); return v ? atoi(v) : 1; }();      // developer knob: 0 = in place, one-tile kernel
+    const float* lsrc = nullptr;
+    if (gen_pad && logits_pad) {
+        Lin gp = gen; gp.N = gen.Npad;
+        LinOpt o; o.ln_stats = st_fill;
+        ENG_OK(linear(xa, dt, d, gp, logits_pad, BOFI_DT_F32, gen.Npad, M, o, s));
+        lsrc = logits_pad;
+    } else {
+        LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s));
+    }
+    ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s, nullptr, nullptr, nullptr, nullptr,
+                                       lsrc, gen.Npad));
     }
     return BOFI_OK;
 }
@@ -913,7 +932,7 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     }
     ENG_OK(e->make_norm(&e->dec_norm, "model.decoder.norm", d));
     ENG_OK(e->make_lin(&e->kv_all, kvs, d, d, "model.encoder.norm"));
-    ENG_OK(e->make_lin(&e->gen, {"model.generator.proj"}, c.vocab, d, "model.decoder.norm"));
+    ENG_OK(e->make_lin(&e->gen, {"model.generator.proj"}, c.vocab, d, "model.decoder.norm", 128));      // padded to whole 128-column tiles (the persistent GEMM)
     {
         const auto* ls = e->get("model.syn_embed.lut.weight", (size_t)10 * d);
         const auto* lt = e->get("model.tgt_embed.lut.weight", (size_t)c.vocab * d);

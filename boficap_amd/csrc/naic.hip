@@ -669,20 +669,22 @@ int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, 
 template <int NPT>   // values per thread held in registers: V <= 512 * NPT (one HBM read + one write per value)
 __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__ logits, int V, int S, int log_softmax,
                                                              const int* ntok, int ntok_bias, int pad_idx, int64_t* seq,
-                                                             int* nan_flag, const int* halt, const int* row_idx, const int* n_rows) {
+                                                             int* nan_flag, const int* halt, const int* row_idx, const int* n_rows,
+                                                             const float* __restrict__ src, int ld_src) {
     __shared__ float red[16];
     __shared__ int redi[16];
     if (halt && *halt >= 1) return;
     if (n_rows && (int)blockIdx.x >= *n_rows) return;           // row list: rows row_idx[0 .. *n_rows) only
     const int row = row_idx ? row_idx[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* x = logits + (size_t)row * V;
+    const float* xin = src ? src + (size_t)row * ld_src : x;
     float v[NPT];
     float m = -INFINITY;
     int first_nan = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int idx = tid + i * 512;
-        v[i] = idx < V ? x[idx] : -INFINITY;
+        v[i] = idx < V ? xin[idx] : -INFINITY;
         if (v[i] != v[i]) first_nan = min(first_nan, idx);
         m = fmaxf(m, v[i]);
     }
@@ -716,6 +718,8 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
         if (log_softmax) {
             t = (first_nan != 0x7fffffff) ? __builtin_nanf("") : (t - m) - lse;    // one NaN poisons the row's softmax
             x[idx] = t;
+        } else if (src) {
+            x[idx] = t;                                 // raw logits asked for: the copy to the caller's pitch
         }
         if (t > bv) { bv = t; bi = idx; }             // idx ascends per thread: first max kept
     }
@@ -741,12 +745,13 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
 }
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias, int pad_idx,
-                          int64_t* seq, hipStream_t st, int* nan_flag, const int* halt, const int* row_idx, const int* n_rows) {
-    if (!logits || !seq || rows < 0 || V <= 0 || S <= 0) return BOFI_ERR_ARG;
+                          int64_t* seq, hipStream_t st, int* nan_flag, const int* halt, const int* row_idx, const int* n_rows, const float* src,
+                          int ld_src) {
+    if (!logits || !seq || rows < 0 || V <= 0 || S <= 0 || (src && ld_src < V)) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows);
-    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows);
-    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows);
+    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src);
+    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src);
+    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src);
     else return BOFI_ERR_ARG;
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
