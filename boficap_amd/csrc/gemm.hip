@@ -368,6 +368,9 @@ extern "C" int bofi_linear_fused(const void* x, int ldx, const void* w, const fl
     return bofi::launch_linear(a, (hipStream_t)stream);
 }
 
+namespace bofi { extern int g_env_generation; }
+extern "C" void bofi_reload_env(void) { ++bofi::g_env_generation; }
+
 extern "C" double bofi_gemm_flops(int reset, double* skippable) {
     const double v = bofi::g_gemm_flops;
     if (skippable) *skippable = bofi::g_gemm_flops_skippable;

@@ -55,6 +55,7 @@ struct Gemm2Params {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+extern int g_env_generation;
 int launch_gemm_pers(const Gemm2Params& p, int feat, hipStream_t st);      // gemm_pers.hip: -1 = shape / feature set not covered
 
 }  // namespace bofi

@@ -23,6 +23,8 @@
 
 namespace bofi {
 
+int g_env_generation = 0;      // bumped by bofi_reload_env(): cached developer knobs are read again
+
 // counted wait that leaves `younger` slabs (LPS LDS-DMA instructions each) in flight, younger in [0, MAXY] (wave-uniform)
 template <int MAXY, int LPS> __device__ __forceinline__ void wait_slabs(int younger) {
     if constexpr (MAXY <= 0) {
@@ -396,12 +398,17 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
         // Alone such a launch is about as fast as this kernel (1.0-1.2x at >= 700 tiles, 0.8-0.95x below); with several decodes in
         // flight it is what keeps their big GEMMs from interleaving thousands of workgroups on every CU: 115 -> 135 k img/s on the
         // default bench (tools/exp/ab_bench2.sh, thresholds 1000 / 500 / 250 / 150 / 90: +3 / +8 / +9 / +14 / +17 %).
-        // BOFI_GEMM_PERS=0 turns it off, BOFI_GEMM_PERS_MIN=<tiles> moves the threshold (developer knobs, read per call)
+        // BOFI_GEMM_PERS=0 turns it off, BOFI_GEMM_PERS_MIN=<tiles> moves the threshold (developer knobs)
         if (!bm && (feat & ~16) <= 3 && !p.skip_if_ge) {       // (feature bit 4 alone = developer ablations)
-            const char* e = getenv("BOFI_GEMM_PERS");
-            const char* m = getenv("BOFI_GEMM_PERS_MIN");
+            static int env_seen = -1, pers_on = 1;            // the two knobs are read once, and again after bofi_reload_env() (tests flip them)
+            static long pers_min = 90;
+            if (env_seen != g_env_generation) {
+                const char* e = getenv("BOFI_GEMM_PERS");
+                const char* m = getenv("BOFI_GEMM_PERS_MIN");
+                pers_on = !e || atoi(e); pers_min = m ? atol(m) : 90; env_seen = g_env_generation;
+            }
             const long t256 = (long)((p.M + 255) / 256) * (p.N / 128);
-            if ((!e || atoi(e)) && t256 >= (m ? atol(m) : 90)) {
+            if (pers_on && t256 >= pers_min) {
                 const int r = launch_gemm_pers(p, feat & 3, st);
                 if (r != -1) return r;
             }

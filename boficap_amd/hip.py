@@ -59,6 +59,7 @@ SIGNATURES = {
     "bofi_gemm_tn_acc": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
     "bofi_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bofi_cast_bf16": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, C.c_float, C.c_uint64, _P, _P]),
+    "bofi_reload_env": (None, []),
     "bofi_linear_fused": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "bofi_linear_ex": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, C.c_float, C.c_uint64, _P, _P, _I, _P]),
     "bofi_linear_masked": (_I, [_P, _I, _I, _P, _I, _P, _I, C.c_float, _P, _I, _I, _I, _I, _I, _P]),

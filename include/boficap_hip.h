@@ -211,6 +211,10 @@ int bofi_linear_fused(const void* x, int ldx, const void* w, const float* bias, 
                       void* y2, int ldy2, const float* ln_stats, const float* ln_colsum, int ln_groups, float* stats_out, int M, int N, int K,
                       int relu, void* stream);
 
+/* Developer knobs read from the environment (BOFI_GEMM_PERS, BOFI_GEMM_PERS_MIN) are cached at first use: after changing them in a
+ * running process call this to have them read again. */
+void bofi_reload_env(void);
+
 /* y = mask > 0 ? (x w^T) * scale : 0 (no bias): the input gradient of a linear whose INPUT came out of relu (+ dropout with
  * scale = 1 / (1 - p)) -- mask [M, N] float32 is that forward activation (a clipped or dropped unit is 0 there), so the
  * gradient arrives already masked, e.g. in bf16 for the previous layer's backward GEMMs (nn.Linear backward followed by the

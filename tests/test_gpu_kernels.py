@@ -371,6 +371,7 @@ def test_linear_fused_persistent_equals_one_tile_per_workgroup(H, M, N, K, mode,
 
     def run(pers):
         monkeypatch.setenv("BOFI_GEMM_PERS", "1" if pers else "0")
+        H.lib().bofi_reload_env()
         kw = dict(res=None, y=None, y2=None, stats=None, colsum=None, groups=0, stats_out=None, relu=0, ydt=H.DT_F32)
         if mode == "plain":
             kw.update(y=torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), ydt=H.DT_BF16)
@@ -387,6 +388,8 @@ def test_linear_fused_persistent_equals_one_tile_per_workgroup(H, M, N, K, mode,
         return kw
 
     a, b = run(True), run(False)
+    monkeypatch.delenv("BOFI_GEMM_PERS")
+    H.lib().bofi_reload_env()
     for k in ("y", "y2", "stats_out"):
         if a[k] is not None:
             assert torch.equal(a[k], b[k]), k

@@ -34,6 +34,7 @@ for M, N, K, mode in SHAPES:
     for pers in ("0", "1"):
         os.environ["BOFI_GEMM_PERS"] = pers
         os.environ["BOFI_GEMM_PERS_MIN"] = "1"
+        lib.bofi_reload_env()
         s = H.stream_ptr()
         for i in range(8):
             H.check(lib.bofi_linear_fused(*sets[i % NSET][0], s))
