@@ -107,6 +107,10 @@ def gemm_rooflines(dtype, dev, batches=1):
     out = []
     for name, M, N, K in (("cross K|V of all layers (kv_all)", 2304 * batches, 7168, 512), ("encoder FFN w_1", 2304 * batches, 2048, 512),
                           ("encoder FFN w_2", 2304 * batches, 512, 2048), ("generator.proj", 1280 * batches, 9491, 512)):
+        n_alg = N
+        if N % 128 and dtype == torch.bfloat16:                # as the bf16 engine runs it: weight rows zero-padded to whole 128-column tiles
+            N = (N + 127) // 128 * 128
+            name += f" (weight rows zero-padded {n_alg} -> {N}, as the engine runs it)"
         x = torch.randn(M, K, device=dev).to(dtype)
         w = (torch.randn(N, K, device=dev) / K ** 0.5).to(dtype)
         b = torch.zeros(N, device=dev)
@@ -131,10 +135,10 @@ def gemm_rooflines(dtype, dev, batches=1):
             e1.record(st)
             torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / 2000
-        tf = 2.0 * M * N * K / us / 1e6
+        tf = 2.0 * M * n_alg * K / us / 1e6                         # algorithmic FLOPs (the padding columns are not counted)
         pers = dtype == torch.bfloat16 and N % 128 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 128) >= 90 and os.environ.get("BOFI_GEMM_PERS", "1") != "0"
         out.append({"kernel": "gemm_pers_kernel (persistent 256x128 tiles, loader wavefronts)" if pers else "gemm_glds_kernel (one 128x64 tile per workgroup)",
-                    "shape": f"{name}: M={M} N={N} K={K}", "us_per_launch": round(us, 2),
+                    "shape": f"{name}: M={M} N={n_alg} K={K}", "us_per_launch": round(us, 2),
                     "achieved": round(tf, 1), "peak": MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], "unit": "TFLOP/s",
                     "frac": round(tf / MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], 4)})
     return out
