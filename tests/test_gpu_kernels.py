@@ -407,3 +407,72 @@ def test_linear_fused_persistent_equals_one_tile_per_workgroup(H, M, N, K, mode,
     assert float((y - ref).abs().max()) <= (1e-2 if a["y"].dtype == torch.bfloat16 else 2e-5 * 8) * scale
     if a["stats_out"] is not None:
         assert torch.allclose(a["stats_out"].cpu(), _row_stats(a["y"].cpu(), N // 32), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 192), (257, 256, 320), (64, 1024, 512), (1000, 384, 512)])
+@pytest.mark.parametrize("mode", ["plain", "ln", "res"])
+def test_linear_fused_persistent_small_and_ragged_shapes(H, M, N, K, mode, monkeypatch):
+    """The persistent kernel forced onto shapes it is not picked for (BOFI_GEMM_PERS_MIN=1): one or two row tiles, a single column tile,
+    the shortest K it takes (3 slabs), fewer rows than a tile -- bit-equal to the one-tile kernel.  (Folded LayerNorm needs 16 statistic
+    groups: K = 512 only; the other K values fall back to the one-tile kernel on both sides.)"""
+    g = _rng(7 * M + N + K)
+    x32 = torch.randn(M, K, generator=g) * 1.5 + 0.2
+    x = x32.to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    outs = []
+    for pers in ("1", "0"):
+        monkeypatch.setenv("BOFI_GEMM_PERS", pers); monkeypatch.setenv("BOFI_GEMM_PERS_MIN", "1")
+        H.lib().bofi_reload_env()
+        if mode == "res":
+            y = torch.randn(M, N, generator=_rng(5)).cuda()
+            y2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); so = torch.zeros(M, N // 32, 2, device="cuda")
+            args = (H.ptr(y), N, H.ptr(y), H.DT_F32, N, H.ptr(y2), N, None, None, 0, H.ptr(so))
+            keep = (y, y2, so)
+        else:
+            y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            st = _row_stats(x32, K // 32).cuda() if mode == "ln" else None
+            cs = w.double().sum(1).float() if mode == "ln" else None
+            args = (None, N, H.ptr(y), H.DT_BF16, N, None, N, H.ptr(st), H.ptr(cs), 0, None)
+            keep = (y,)
+        H.check(H.lib().bofi_linear_fused(H.ptr(x), K, H.ptr(w), H.ptr(bias), *args, M, N, K, 1 if mode == "ln" else 0, H.stream_ptr()), "bofi_linear_fused")
+        torch.cuda.synchronize()
+        outs.append(keep)
+    monkeypatch.delenv("BOFI_GEMM_PERS"); monkeypatch.delenv("BOFI_GEMM_PERS_MIN")
+    H.lib().bofi_reload_env()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = (x.double() @ w.double().t()).cpu() + bias.cpu().double()
+    if mode == "ln":
+        mean = x32.double().mean(1, keepdim=True); rstd = 1.0 / (x32.double().std(1, keepdim=True) + 1e-6)
+        ref = torch.relu(rstd * ((x.double() @ w.double().t()).cpu() - mean * w.double().sum(1).cpu()) + bias.cpu().double())
+    elif mode == "res":
+        ref = ref + torch.randn(M, N, generator=_rng(5)).double()
+    assert float((outs[0][0].cpu().double() - ref).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_vocab_finalize_reads_a_padded_source(H):
+    """bofi vocab_finalize with the logits in a buffer of another pitch (the bf16 engine's generator output, pitch 9 600): same ids and
+    log-probs as in place, through the engine: BOFI_GEN_PAD=0 (in place, one-tile GEMM) against the default on one decode."""
+    import os, subprocess, sys, json
+    code = (
+        "import os, sys, json, torch\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "from boficap_amd import weights as W\n"
+        "from boficap_amd.config import FULL as cfg\n"
+        "from boficap_amd.engine import BofiEngine\n"
+        "sd = W.make_state_dict(cfg, seed=0, gen_scale=6.0)\n"
+        "eng = BofiEngine(cfg, torch.bfloat16, max_batch=8, max_regions=36); eng.load_state_dict(sd)\n"
+        "att = torch.from_numpy(W.synthetic_att_feats(8, 36, cfg.att_feat_size, seed=77)).cuda().to(torch.bfloat16)\n"
+        "r = eng.decode_naic(att)\n"
+        "torch.cuda.synchronize()\n"
+        "seq, lp = r['seq'], r['seq_logprob']\n"
+        "print(json.dumps({'seq': seq.cpu().tolist(), 'lp_sum': float(torch.nan_to_num(lp.float()).double().sum()), 'lp_max': float(torch.nan_to_num(lp.float()).max())}))\n")
+    outs = []
+    for pad in ("1", "0"):
+        env = dict(os.environ, BOFI_GEN_PAD=pad)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0]["seq"] == outs[1]["seq"]
+    assert abs(outs[0]["lp_sum"] - outs[1]["lp_sum"]) <= 1e-3 * max(1.0, abs(outs[1]["lp_sum"]))
