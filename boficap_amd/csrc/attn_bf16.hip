@@ -135,19 +135,20 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
         for (int kj = 0; kj < NKT; ++kj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = (kj * 16 + g * 4 + r < kl) ? expf(st[kj][qi][r] - m) : 0.f;
+                const float e = (kj * 16 + g * 4 + r < kl) ? __expf(st[kj][qi][r] - m) : 0.f;      // v_exp_f32 (the probabilities end as bf16)
                 st[kj][qi][r] = e;
                 sum += e;
             }
         sum = xor32_sum(xor16_sum(sum));
         // an empty row gives 0/0 = NaN for every key, as softmax over all -inf does in the reference
+        const float inv_sum = 1.0f / sum;                 // (one division per row: 0 * (1/0) is NaN as 0/0 is)
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {
             bf16x8 f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int kj = 2 * s + (j >> 2), r = j & 3;
-                float pv = st[kj][qi][r] / sum;
+                float pv = st[kj][qi][r] * inv_sum;
                 if (kl == 0 && kj * 16 + g * 4 + r >= Lk) pv = 0.f;      // padded keys of an empty row: V is 0 there
                 if (p.drop_thresh) {                                     // training: dropout(p_attn)
                     // element id of the mask: (item, head, query, key), or (global query row, head, key) for unpadded rows --
