@@ -1,20 +1,24 @@
-// y = act(x . w^T + bias) [+ residual] for the large-M bf16 GEMMs of the encoder / fill stacks (same arithmetic, same epilogue
-// order and so the same bits as gemm_glds.hip's kernel), as PERSISTENT workgroups with dedicated loader wavefronts.
+// y = act(x . w^T + bias) [+ residual] for the large bf16 GEMMs of the encoder / fill stacks and the generator (same MFMA K order, same
+// epilogue expressions in the same order and so the same bits as gemm_glds.hip's kernel), as PERSISTENT workgroups with dedicated loader
+// wavefronts.  DESIGN.md section 12.12 has the measurements behind every choice below.
 //
-// Why: at 128 x 64 tiles the one-tile-per-workgroup kernel moves (128 + 64) * 128 B from L2 per
-// 256 MFMA cycles of a SIMD = 96 B/clk per CU, against the 53 B/clk a CU takes in (profiles/r02_l2_stream_probe.txt) -- the loads,
-// not the matrix cores, bound it at half the dense rate, and its per-workgroup start-up and epilogue (9 + 8 of 34 us at
-// 9216 x 2048 x 512) overlap nothing.  Here:
-//   * 256 x 128 tiles (48 B/clk per CU at the full MFMA rate), 8 consumer wavefronts of 64 x 64 each (16 x 16 x 32 MFMA tiles,
-//     4 x 4 accumulators);
-//   * one workgroup per CU for the whole launch, walking tiles blockIdx.x, blockIdx.x + grid, ... of the same XCD-aware order;
-//   * 4 loader wavefronts that only issue LDS-DMA (global_load_lds_dwordx4, 12 pieces of 1 KiB each per 64-deep K slab) into a
-//     3-slot ring and wait on their OWN vmcnt: the slab stream runs across tile boundaries, so the first two slabs of the next
-//     tile land while the consumers run the epilogue of this one, and a consumer's vmcnt carries only its own epilogue operands
-//     and stores (a wavefront's vmcnt retires in order: in a one-role kernel stores would sit in front of the next slabs);
-//   * one workgroup barrier per K step (slab s landed; slot of slab s-1 free) and one per tile (every consumer has read the last
-//     slab: its slot becomes the epilogue's staging area, 16 rows x 64 columns of float32 per wavefront at a time, private to the
-//     wavefront: no barriers inside the epilogue).
+// Why: at 128 x 64 tiles the one-tile-per-workgroup kernel moves (128 + 64) * 128 B from L2 per 256 MFMA cycles of a SIMD = 96 B/clk per
+// CU, against the 53 B/clk a CU takes in (profiles/r02_l2_stream_probe.txt); its per-workgroup start-up and epilogue overlap nothing
+// inside the workgroup; and with several decodes in flight thousands of workgroups of different GEMMs interleave on every CU.  Here:
+//   * 256 x 128 tiles (48 B/clk per CU at the full MFMA rate; 128 x 128 for shapes of at most 128 such tiles), 8 consumer wavefronts
+//     of (BM / 4) x 64 each (16 x 16 x 32 MFMA tiles, TM x 4 accumulators);
+//   * one workgroup per CU for the whole launch (grid = tiles / rounds), walking tiles blockIdx.x, blockIdx.x + grid, ... of the same
+//     XCD-aware order;
+//   * 4 loader wavefronts that only issue LDS-DMA (global_load_lds_dwordx4, 12 pieces of 1 KiB each per 64-deep K slab at 256 rows)
+//     into a 3-slot ring and wait on their OWN vmcnt: the slab stream runs across tile boundaries, so the first two slabs of the next
+//     tile land while the consumers run the epilogue of this one, and a consumer's vmcnt carries only its own epilogue operands and
+//     stores (a wavefront's vmcnt retires in order: in a one-role kernel stores would sit in front of the next slabs).  The loaders
+//     also turn the folded LayerNorm's partial sums into row mean / rstd, a tile ahead of their use;
+//   * one workgroup barrier per K step (slab s landed; slot of slab s-1 free);
+//   * epilogue: in registers where the output is bf16 without residual / copy / statistics (FAST: arithmetic in the MFMA C/D layout,
+//     bf16 pairs transposed by permlane swaps, 16-byte stores; no LDS, no extra barrier), else staged through LDS as in
+//     gemm_glds.hip -- 16 rows x 64 columns of float32 per wavefront at a time, private to the wavefront, in the slot of the tile's
+//     last slab (one more workgroup barrier per tile: every consumer has read that slab) or, at 128 rows, in an area of its own.
 #include <cstdio>
 #include <cstdlib>
 
