@@ -519,10 +519,27 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     log("engine ready; first decode (graph capture)")
     # streams that provably overlap (distinct hardware queues), found by timing a spin kernel on pairs
     from boficap_amd.engine import pick_concurrent_streams
-    streams = pick_concurrent_streams(args.inflight, dev) if args.inflight > 1 else [torch.cuda.current_stream(dev)]
-    if args.inflight > 1 and len(streams) < args.inflight:                       # an unlucky draw of hardware queues: look among more candidates once
-        more = pick_concurrent_streams(args.inflight, dev, candidates=48)
-        streams = more if len(more) > len(streams) else streams
+    if args.cu_partitions > 1:
+        # experiment: every stream is confined to one of P disjoint sets of CUs (hipExtStreamCreateWithCUMask; a mask must leave every XCD
+        # some CUs -- bit i is CU i / 8 of XCD i % 8 -- so a set is the same CU range of every XCD), stream k on set k % P
+        import ctypes
+        hiprt = ctypes.CDLL("libamdhip64.so")
+        hiprt.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        P, per = args.cu_partitions, 32 // args.cu_partitions
+        streams = []
+        for k in range(max(1, args.inflight)):
+            part = k % P
+            bits = {i for i in range(256) if part * per <= i // 8 < (part + 1) * per}
+            words = (ctypes.c_uint32 * 8)(*[sum((1 << b) for b in range(32) if (wd * 32 + b) in bits) for wd in range(8)])
+            h = ctypes.c_void_p()
+            if hiprt.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words) != 0:
+                raise RuntimeError("hipExtStreamCreateWithCUMask failed")
+            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+    else:
+        streams = pick_concurrent_streams(args.inflight, dev) if args.inflight > 1 else [torch.cuda.current_stream(dev)]
+        if args.inflight > 1 and len(streams) < args.inflight:                       # an unlucky draw of hardware queues: look among more candidates once
+            more = pick_concurrent_streams(args.inflight, dev, candidates=48)
+            streams = more if len(more) > len(streams) else streams
     log(f"{len(streams)} concurrent streams")
     engines = [eng] + [eng.fork() for _ in range(len(streams) - 1)]
     # every launch in flight decodes features of its own (a rotation of the batches by whole batches, so the layouts and T stay
@@ -685,6 +702,8 @@ def main():
     ap.add_argument("--refine", type=int, default=0, help="extra filling rounds (BASELINE config 5 uses 3 rounds at batch 256)")
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")
+    ap.add_argument("--cu-partitions", type=int, default=1, help="experiment: confine stream k to CU set k %% P of P disjoint sets (the same CU range of "
+                    "every XCD; set BOFI_GEMM_PERS_GRID to 256 / P with it); 1 = off")
     ap.add_argument("--coalesce", type=int, default=None, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
                     "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches.  "
                     "Default for the plain batch-64 decode: 5 or 4 (whichever divides --steps into evenly spread launches), 1 otherwise")
