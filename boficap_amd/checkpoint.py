@@ -1,91 +1,146 @@
-"""Checkpoint files of the reference (captioning/utils/misc.py:87-102, tools/train.py:62-69,117-128,292-367):
+"""The run directory both code bases agree on (file names and pickle protocol are the on-disk contract:
+reference captioning/utils/misc.py:87-102, tools/train.py:55-69,117-128):
 
-    model[-append].pth            model.state_dict()                       (311 entries)
-    optimizer[-append].pth        NoamOpt.state_dict() = torch Adam's state_dict + '_step'
-    infos_<id>[-append].pkl       {'iter', 'epoch', 'loader_state_dict', 'vocab', 'opt', 'best_val_score', ...}, pickle protocol 2
-    histories_<id>[-append].pkl   {'val_result_history', 'loss_history', 'lr_history', 'ss_prob_history'}
+    model[-tag].pth            state_dict of the 311-entry schema (boficap_amd/weights.py)
+    optimizer[-tag].pth        torch Adam state_dict + NoamOpt's '_step'
+    infos_<id>[-tag].pkl       iter / epoch / loader_state_dict / vocab / opt / best_val_score, pickle protocol 2
+    histories_<id>[-tag].pkl   val_result_history / loss_history / lr_history / ss_prob_history, pickle protocol 2
 
-written and read so that a run of either code base resumes from the other's directory (``--start_from``).
+Everything here is host glue; the bodies are this build's own.
 """
 from __future__ import annotations
 
 import os
 import pickle
+from argparse import Namespace
 
 import torch
 
+PICKLE_PROTOCOL = 2            # what the reference's loader expects (written by Python 2 era tooling too)
+
+# options a resumed run must share with the saved one, with the defaults the reference's option parser gives them
+# (captioning/utils/opts.py:60-67): a saved `opt` always carries all four, so that the reference's resume check finds them
+RESUME_KEYS = {"caption_model": "show_tell", "rnn_type": "lstm", "rnn_size": 512, "num_layers": 1}
+
+# keys the reference's training loop indexes without a default when it resumes (tools/train.py:55-60, 125)
+INFOS_SKELETON = {"iter": 0, "epoch": 0, "loader_state_dict": None}
+
 
 def pickle_dump(obj, f):
-    """misc.py:33-43: protocol 2."""
-    return pickle.dump(obj, f, protocol=2)
+    pickle.dump(obj, f, protocol=PICKLE_PROTOCOL)
 
 
 def pickle_load(f):
-    """misc.py:20-30: latin-1 for pickles written by Python 2."""
+    # latin-1 also opens pickles that Python 2 wrote
     return pickle.load(f, encoding="latin-1")
 
 
+def _tag(append: str) -> str:
+    return "-" + append if append else ""
+
+
+def run_files(directory: str, run_id: str, append: str = "") -> dict:
+    """Paths of the four files of a run directory, keyed by what they hold."""
+    t = _tag(append)
+    return {
+        "model": os.path.join(directory, f"model{t}.pth"),
+        "optimizer": os.path.join(directory, f"optimizer{t}.pth"),
+        "infos": os.path.join(directory, f"infos_{run_id}{t}.pkl"),
+        "histories": os.path.join(directory, f"histories_{run_id}{t}.pkl"),
+    }
+
+
+def new_infos(vocab=None) -> dict:
+    """An infos dict as a fresh run starts with: every key the reference's resume path reads unconditionally is present."""
+    infos = dict(INFOS_SKELETON)
+    infos["vocab"] = vocab
+    return infos
+
+
+def resume_opt(opt) -> Namespace:
+    """`opt` as it is stored in infos['opt']: plain picklable values only, and every RESUME_KEYS entry present."""
+    plain = {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, dict, list, tuple, type(None)))}
+    for key, default in RESUME_KEYS.items():
+        plain.setdefault(key, default)
+    return Namespace(**plain)
+
+
 def save_checkpoint(opt, model, infos, optimizer, histories=None, append=""):
-    """misc.py:87-102, same arguments; ``optimizer``: anything with the reference-layout ``state_dict()`` (XETrainer)."""
-    if len(append) > 0:
-        append = "-" + append
-    if not os.path.isdir(opt.checkpoint_path):
-        os.makedirs(opt.checkpoint_path)
-    checkpoint_path = os.path.join(opt.checkpoint_path, "model%s.pth" % append)
-    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, checkpoint_path)
-    print("model saved to {}".format(checkpoint_path))
-    torch.save(optimizer.state_dict(), os.path.join(opt.checkpoint_path, "optimizer%s.pth" % append))
-    with open(os.path.join(opt.checkpoint_path, "infos_" + opt.id + "%s.pkl" % append), "wb") as f:
-        pickle_dump(infos, f)
+    """Write the run directory `opt.checkpoint_path`.  `optimizer`: anything whose state_dict() has the reference layout
+    (XETrainer); `histories` is skipped when empty, as the reference does."""
+    paths = run_files(opt.checkpoint_path, opt.id, append)
+    os.makedirs(opt.checkpoint_path, exist_ok=True)
+    stored = dict(INFOS_SKELETON)
+    stored.update(infos)
+    writers = [
+        ("model", lambda p: torch.save({name: t.detach().cpu() for name, t in model.state_dict().items()}, p)),
+        ("optimizer", lambda p: torch.save(optimizer.state_dict(), p)),
+        ("infos", lambda p: _dump_to(p, stored)),
+    ]
     if histories:
-        with open(os.path.join(opt.checkpoint_path, "histories_" + opt.id + "%s.pkl" % append), "wb") as f:
-            pickle_dump(histories, f)
+        writers.append(("histories", lambda p: _dump_to(p, histories)))
+    for what, write in writers:
+        write(paths[what])
+    print(f"checkpoint written: {paths['model']} (+ {', '.join(w for w, _ in writers[1:])})")
+
+
+def _dump_to(path: str, obj) -> None:
+    with open(path, "wb") as f:
+        pickle_dump(obj, f)
 
 
 def load_infos(start_from: str, run_id: str, append: str = ""):
-    """tools/train.py:62-69, 74-77: (infos, histories) of a run directory; empty dicts for files that are not there."""
-    if append:
-        append = "-" + append
-    out = []
-    for stem in ("infos_", "histories_"):
-        path = os.path.join(start_from, stem + run_id + append + ".pkl")
-        if os.path.isfile(path):
-            with open(path, "rb") as f:
-                out.append(pickle_load(f))
+    """(infos, histories) of a run directory; a file that is not there gives an empty dict."""
+    paths = run_files(start_from, run_id, append)
+    loaded = []
+    for what in ("infos", "histories"):
+        if os.path.isfile(paths[what]):
+            with open(paths[what], "rb") as f:
+                loaded.append(pickle_load(f))
         else:
-            out.append({})
-    return tuple(out)
+            loaded.append({})
+    return loaded[0], loaded[1]
 
 
-def check_resume_opts(saved_opt, opt, need_be_same=("caption_model", "rnn_type", "rnn_size", "num_layers")):
-    """tools/train.py:66-68: the model-defining options of a resumed run must equal the saved ones."""
-    for k in need_be_same:
-        a, b = getattr(saved_opt, k, None), getattr(opt, k, None)
-        assert a == b, "Command line argument and saved model disagree on '%s' " % k
+def check_resume_opts(saved_opt, opt, need_be_same=tuple(RESUME_KEYS)):
+    """A resumed run must be the saved model: every option of `need_be_same` has to agree (an option one side lacks counts
+    as its parser default)."""
+    differing = [k for k in need_be_same
+                 if getattr(saved_opt, k, RESUME_KEYS.get(k)) != getattr(opt, k, RESUME_KEYS.get(k))]
+    assert not differing, f"cannot resume: saved run and this run differ in {differing}"
 
 
 def load_yaml_with_base(filename: str) -> dict:
-    """The reference's config files inherit through ``_BASE_`` (captioning/utils/config.py:35-95, CfgNode.load_yaml_with_base):
-    values of the file overwrite those of its base, recursively for nested dicts; the base path is relative to the file."""
+    """A config file with its `_BASE_` chain applied: the reference's yml files name a base file (relative to themselves, `~`
+    allowed) whose values they override, nested mappings key by key."""
     import yaml
-    with open(filename) as f:
-        cfg = yaml.safe_load(f) or {}
 
-    def merge(a, b):
-        for k, v in a.items():
-            if isinstance(v, dict) and k in b:
-                assert isinstance(b[k], dict), "Cannot inherit key '{}' from base!".format(k)
-                merge(v, b[k])
-            else:
-                b[k] = v
-
-    if "_BASE_" in cfg:
-        base = cfg.pop("_BASE_")
-        if base.startswith("~"):
+    chain, path, seen = [], filename, set()
+    while path is not None:
+        real = os.path.realpath(path)
+        if real in seen:
+            raise ValueError(f"_BASE_ chain of {filename} loops back to {path}")
+        seen.add(real)
+        with open(path) as f:
+            layer = yaml.safe_load(f) or {}
+        base = layer.pop("_BASE_", None)
+        chain.append(layer)
+        if base is None:
+            path = None
+        else:
             base = os.path.expanduser(base)
-        if not base.startswith("/"):
-            base = os.path.join(os.path.dirname(filename), base)
-        base_cfg = load_yaml_with_base(base)
-        merge(cfg, base_cfg)
-        return base_cfg
-    return cfg
+            path = base if os.path.isabs(base) else os.path.join(os.path.dirname(path), base)
+
+    def overlay(dst: dict, src: dict, where: str) -> None:
+        for key, val in src.items():
+            if isinstance(val, dict) and key in dst:
+                if not isinstance(dst[key], dict):
+                    raise AssertionError(f"{where}: '{key}' is a mapping here but a plain value in the base file")
+                overlay(dst[key], val, where)
+            else:
+                dst[key] = val
+
+    merged: dict = {}
+    for layer in reversed(chain):            # root base first, the file itself last
+        overlay(merged, layer, filename)
+    return merged

@@ -109,6 +109,32 @@ int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax
                           const int* row_idx = nullptr, const int* n_rows = nullptr,      // row list: rows row_idx[0 .. *n_rows) only
                           const float* src = nullptr, int ld_src = 0);                   // src: the logits are read from src (row pitch ld_src), results go to `logits` (pitch V)
 
+// ---- row-block sublayer kernels (rowblock.hip): bf16, d_model 512, weights in the fragment-major layout of launch_rb_pack_frag
+typedef __attribute__((ext_vector_type(4))) uint32_t rb_u32x4;
+struct RbFfnArgs {
+    const float* x; int ldx;                  // residual stream in [M][512] float32
+    const rb_u32x4* w1p; const float* c1; const float* cs1;      // w_1 (pre-norm folded in) fragment-major; its folded bias and column sums [dff]
+    const rb_u32x4* w2p; const float* b2;     // w_2 fragment-major; bias [512]
+    float* y; int ldy;                        // residual stream out (may be x: a workgroup reads its rows before it writes them)
+    uint16_t* yb; float* stats_out;           // optional: bf16 copy [M][512], partial sums [M][16][2]
+    int M, dff;
+};
+struct RbAttnArgs {
+    const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64
+    const uint16_t* k; int ldk;               // [B*Lk][ldk]
+    const uint16_t* v; int ldv;
+    int B, Lq, Lk;
+    const int* klen; int klen_sb, klen_sq, klen_bias, klen_shared_last;     // as AttnArgs
+    const rb_u32x4* wop; const float* bo;     // output projection [512][512] fragment-major, bias [512]
+    const float* x; int ldx;                  // residual stream in [B*Lq][512] float32
+    float* y; int ldy;                        // out (may be x)
+    uint16_t* yb; float* stats_out;           // optional, as RbFfnArgs
+    int dbg;                                  // developer ablation (BOFI_RB_DBG): 1 = no attention, 2 = no output projection, 4 = no closing stores, 16 = stamps
+};
+int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st);
+int launch_rb_attn(const RbAttnArgs& a, hipStream_t st);           // -1: shape not covered
+int launch_rb_pack_frag(const void* w, void* out, int N, int K, hipStream_t st);
+
 // ---- device-side weight repack (repack.hip)
 struct PackLinArgs {
     const float* w[16]; const float* b[16]; int nsrc, n_each, K;

@@ -39,13 +39,15 @@ uint16_t host_bf16(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; int Npad = 0; };   // cs: column sums when a LayerNorm is folded in; Npad > N: rows N .. Npad of w / b / cs exist and are zero
+struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; int Npad = 0; void* wp = nullptr; };   // cs: column sums when a LayerNorm is folded in; Npad > N: rows N .. Npad of w / b / cs exist and are zero; wp: fragment-major copy of w for the row-block kernels (rowblock.hip), bf16 engine only
 struct Norm { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, w1, w2; Norm n0, n1; };
 struct DecLayer { Lin qkv, o, q_src, o_src, w1, w2; Norm n0, n1, n2; };
 
 // how a packed weight was made from the named parameters: replayed on the device by bofi_engine_refresh_device
 struct LinRecipe { Lin* out; std::vector<std::string> prefixes; int n_each, K; std::string fold; };
+
+bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }
 struct NormRecipe { Norm* out; std::string prefix; int d; };
 
 struct GraphEntry {
@@ -153,7 +155,7 @@ struct bofi_engine {
     // LayerNorm that feeds this layer is folded in (gemm_glds.hip): w <- w * a_2 (per input column),
     // bias <- bias + w . b_2, cs[n] <- sum_k of the ROUNDED scaled weight (so that the mean term of
     // the epilogue cancels exactly what the MFMA accumulated).
-    int make_lin(Lin* out, const std::vector<std::string>& prefixes, int n_each, int K, const std::string& fold_norm = "", int pad_to = 0) {
+    int make_lin(Lin* out, const std::vector<std::string>& prefixes, int n_each, int K, const std::string& fold_norm = "", int pad_to = 0, bool frag = false) {
         std::vector<float> w, b;
         for (const auto& p : prefixes) {
             const auto* pw = get(p + ".weight", (size_t)n_each * K);
@@ -190,6 +192,11 @@ struct bofi_engine {
         b.resize(out->Npad, 0.f);
         ENG_OK(upload_t(&out->w, w));
         ENG_OK(upload_f32(&out->b, b));
+        out->wp = nullptr;
+        if (frag && cfg.dtype == BOFI_DT_BF16 && out->N % 64 == 0 && K % 32 == 0) {      // the layout the row-block sublayer kernels stream
+            ENG_OK(dalloc((char**)&out->wp, (size_t)out->N * K, 2));
+            ENG_OK(bofi::launch_rb_pack_frag(out->w, out->wp, out->N, K, nullptr));
+        }
         lin_recipes.push_back(LinRecipe{out, prefixes, n_each, K, fold_norm});
         return BOFI_OK;
     }
@@ -334,6 +341,32 @@ struct bofi_engine {
             ENG_OK(bofi::launch_rowgemm(a, s)); }
         return BOFI_OK;
     }
+    // ---- row-block sublayer kernels (rowblock.hip, bf16 engine at the reference's width): the attention sublayer (attention + output
+    // projection + residual) and the feed-forward sublayer as one launch each.  Return -1 when the configuration or the shape is not
+    // theirs (the caller then runs the separate attention / GEMM launches), else a status.  want_copy: the next consumer is a
+    // LayerNorm-folded GEMM (it reads the compute-dtype copy and the row statistics); a following ffn_sublayer reads the stream itself.
+    bool rb_ok() const { return cfg.dtype == BOFI_DT_BF16 && cfg.d_model == 512 && cfg.heads == 8; }
+    int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
+        static const bool on = env_on("BOFI_RB_ATTN");
+        if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh) return -1;
+        bofi::RbAttnArgs a{};
+        a.q = (const uint16_t*)at.q; a.ldq = at.ldq; a.k = (const uint16_t*)at.k; a.ldk = at.ldk; a.v = (const uint16_t*)at.v; a.ldv = at.ldv;
+        a.B = at.B; a.Lq = at.Lq; a.Lk = at.Lk; a.klen = at.klen; a.klen_sb = at.klen_sb; a.klen_sq = at.klen_sq; a.klen_bias = at.klen_bias;
+        a.klen_shared_last = at.klen_shared_last; a.wop = (const bofi::u32x4*)o.wp; a.bo = o.b; a.x = x; a.ldx = cfg.d_model; a.y = x; a.ldy = cfg.d_model;
+        a.yb = want_copy ? (uint16_t*)xb : nullptr; a.stats_out = want_copy ? stats : nullptr;
+        return bofi::launch_rb_attn(a, s);
+    }
+    bool ffn_sublayer_ok(const Lin& w1, const Lin& w2) const {
+        static const bool on = env_on("BOFI_RB_FFN");
+        return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560;
+    }
+    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s) {
+        if (!ffn_sublayer_ok(w1, w2)) return -1;
+        bofi::RbFfnArgs a{};
+        a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
+        a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
+        return bofi::launch_rb_ffn(a, s);
+    }
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
     int enqueue_bound_iter(int B, int R, const int* att_len, const int* ext_syn, const int* last, int update, float* len_logp,
                            float* syn_logp, bool early, hipStream_t s);
@@ -369,12 +402,21 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
         a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
-        ENG_OK(bofi::launch_attention(a, s));
-        { LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
-          ENG_OK(linear(ctx, dt, d, l.o, x_enc, BOFI_DT_F32, d, M, o, s)); }
-        { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
-        { LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
-          ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_enc, BOFI_DT_F32, d, M, o, s)); }
+        const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2);
+        int rc = attn_sublayer(a, l.o, x_enc, xb_enc, st_enc, !ffn_rb, s);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            ENG_OK(bofi::launch_attention(a, s));
+            LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
+            ENG_OK(linear(ctx, dt, d, l.o, x_enc, BOFI_DT_F32, d, M, o, s));
+        }
+        rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, xb_enc, st_enc, M, s) : -1;
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+            { LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
+              ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_enc, BOFI_DT_F32, d, M, o, s)); }
+        }
     }
     if (memory_out) ENG_OK(bofi::launch_layernorm(x_enc, enc_norm.g, enc_norm.b, memory_out, BOFI_DT_F32, M, d, s));
     // cross-attention K|V of the bound layer and of every decoder layer in one GEMM on memory =
@@ -498,21 +540,34 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         // syn_mask[i, :, :last-1] = True; strict mode reproduces the stale index of :1872-1873 (quirk Q1)
         a.klen = st.last; a.klen_sb = 1; a.klen_sq = 0; a.klen_bias = -1;
         a.klen_shared_last = (flags & BOFI_FLAG_STRICT_Q1) ? (q1_group > 0 ? q1_group : B) : 0;
-        ENG_OK(bofi::launch_attention(a, s));
-        { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
-          ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s)); }
+        int rc = attn_sublayer(a, l.o, x_fill, xb_fill, st_fill, true, s);           // (the query projection behind it is a folded GEMM)
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            ENG_OK(bofi::launch_attention(a, s));
+            LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+            ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s));
+        }
         { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
         bofi::AttnArgs c{};
         c.q = qs; c.ldq = d;
         c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
         c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
         c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0;
-        ENG_OK(bofi::launch_attention(c, s));
-        { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
-          ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, BOFI_DT_F32, d, M, o, s)); }
-        { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
-        { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
-          ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
+        const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2);
+        rc = attn_sublayer(c, l.o_src, x_fill, xb_fill, st_fill, !ffn_rb, s);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            ENG_OK(bofi::launch_attention(c, s));
+            LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+            ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, BOFI_DT_F32, d, M, o, s));
+        }
+        rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, xb_fill, st_fill, M, s) : -1;
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
+            { LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
+              ENG_OK(linear(hdn, dt, cfg.d_ff, l.w2, x_fill, BOFI_DT_F32, d, M, o, s)); }
+        }
     }
     // ---- vocabulary projection (decoder.norm folded in), log-softmax, greedy pick, pad tail
     // generator.  V = 9 491 is not a whole number of 128-column tiles and its rows are not 16-byte aligned: the bf16 engine runs the GEMM
@@ -788,6 +843,7 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
         }
         a.bout = r.out->b; a.cs = r.out->cs;
         ENG_OK(bofi::launch_pack_lin(a, r.out->w, c.dtype, s));
+        if (r.out->wp) ENG_OK(bofi::launch_rb_pack_frag(r.out->w, r.out->wp, r.out->N, r.out->K, s));
     }
     for (const auto& r : e->norm_recipes) {
         const float *g = get(r.prefix + ".a_2", r.d), *b = get(r.prefix + ".b_2", r.d);
@@ -890,9 +946,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         auto& E = e->enc[l];
         const std::string p = S("model.encoder.layers.%d", l);
         ENG_OK(e->make_lin(&E.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
-        ENG_OK(e->make_lin(&E.o, {p + ".self_attn.linears.3"}, d, d));
-        ENG_OK(e->make_lin(&E.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.1.norm"));
-        ENG_OK(e->make_lin(&E.w2, {p + ".feed_forward.w_2"}, d, dff));
+        ENG_OK(e->make_lin(&E.o, {p + ".self_attn.linears.3"}, d, d, "", 0, true));
+        ENG_OK(e->make_lin(&E.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.1.norm", 0, true));
+        ENG_OK(e->make_lin(&E.w2, {p + ".feed_forward.w_2"}, d, dff, "", 0, true));
         ENG_OK(e->make_norm(&E.n0, p + ".sublayer.0.norm", d));
         ENG_OK(e->make_norm(&E.n1, p + ".sublayer.1.norm", d));
     }
@@ -919,11 +975,11 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         auto& D = e->dec[l];
         const std::string p = S("model.decoder.layers.%d", l);
         ENG_OK(e->make_lin(&D.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
-        ENG_OK(e->make_lin(&D.o, {p + ".self_attn.linears.3"}, d, d));
+        ENG_OK(e->make_lin(&D.o, {p + ".self_attn.linears.3"}, d, d, "", 0, true));
         ENG_OK(e->make_lin(&D.q_src, {p + ".src_attn.linears.0"}, d, d, p + ".sublayer.1.norm"));
-        ENG_OK(e->make_lin(&D.o_src, {p + ".src_attn.linears.3"}, d, d));
-        ENG_OK(e->make_lin(&D.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.2.norm"));
-        ENG_OK(e->make_lin(&D.w2, {p + ".feed_forward.w_2"}, d, dff));
+        ENG_OK(e->make_lin(&D.o_src, {p + ".src_attn.linears.3"}, d, d, "", 0, true));
+        ENG_OK(e->make_lin(&D.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.2.norm", 0, true));
+        ENG_OK(e->make_lin(&D.w2, {p + ".feed_forward.w_2"}, d, dff, "", 0, true));
         ENG_OK(e->make_norm(&D.n0, p + ".sublayer.0.norm", d));
         ENG_OK(e->make_norm(&D.n1, p + ".sublayer.1.norm", d));
         ENG_OK(e->make_norm(&D.n2, p + ".sublayer.2.norm", d));

@@ -1,0 +1,565 @@
+// Row-block kernels of the bf16 decode path (round 3): a workgroup owns a block of activation rows for a whole SUBLAYER, keeps
+// the block in LDS, and streams every weight it needs from L2 straight into MFMA operand registers.
+//
+//   rb_ffn_kernel        x <- x + w_2 . relu(w_1 . LN(x) + b_1) + b_2      (PositionwiseFeedForward behind SublayerConnection,
+//                        reference TransformerModel.py:1477-1478, 1361-1377): 64 rows per workgroup; the 2 048-wide hidden rows
+//                        never leave the CU (LDS, 512 columns at a time), the row statistics of the LayerNorm are computed while
+//                        the block is staged; one launch instead of two GEMMs, no hidden tensor in HBM.
+//   rb_attn_kernel       x <- x + W_o . attention(q, k, v) + b_o             (MultiHeadedAttention.forward :1454-1467 behind the
+//                        sublayer's residual): a workgroup owns G images, wavefront = head; the heads' outputs meet in LDS and
+//                        the output projection runs on them in place: one launch instead of attention + GEMM, no ctx tensor.
+//   rb_pack_frag_kernel  the weight layout both read.
+//
+// Why this shape.  d_model = 512: a sublayer's weights are 0.5 - 4 MB -- they live in L2 / Infinity Cache, and at K = 512 a tiled
+// GEMM is all prologue and epilogue (8 K-steps between a cold first slab and a staged epilogue; the residual
+// GEMMs ran at 6 % of the MFMA peak).  Here the activation block is the resident operand and the weights are the stream:
+//   * weights are stored FRAGMENT-MAJOR (rb_pack_frag_kernel): [64-column chunk][k step of 32][16-column tile][lane][8 bf16], so a
+//     wavefront's weight stream is a linear run of 1-KiB wave loads, each landing in the v_mfma_f32_16x16x32_bf16 operand layout:
+//     no LDS staging of weights, no barrier in the K loop, every weight byte read once per workgroup;
+//   * the 8 wavefronts split the OUTPUT columns (64 each, 4 x MT accumulator tiles), so no two wavefronts load the same weight;
+//   * RB_PF steps (4 KiB each) of the stream are in flight per wavefront at any time, across segment and phase boundaries
+//     (the compiler's own vmcnt counting; a scheduling barrier per step keeps the loads where they are written);
+//   * the activation block sits in LDS with its 16-byte chunks XOR-swizzled by row, so the ds_read_b128 of an MFMA operand
+//     (16 rows x 64 B) is conflict-free.
+// Measured on MI355X: tools/exp/dw_gemm_probe.hip (the bare stream + MFMA loop), profiles/r03_*.
+#include <cstdlib>
+
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+
+namespace bofi {
+
+// developer aid (BOFI_RB_DBG & 16): s_memtime stamps of workgroup 0, [wave][slot], read back by bofi_rb_stamps
+__device__ unsigned long long g_rb_stamps[16 * 16];
+#define RB_STAMP(dbg, wave, lane, slot) do { if (((dbg) & 16) && blockIdx.x == 0 && (lane) == 0) g_rb_stamps[(wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+constexpr int RB_PF = 4;             // weight-stream steps in flight per wavefront (divides 16: a segment starts at slot 0)
+
+// byte offset of 16-byte chunk c of row r in a block of 1 024-byte rows
+__device__ __forceinline__ int rb_off(int r, int c) { return r * 1024 + ((c ^ (r & 15)) << 4); }
+
+__device__ __forceinline__ bf16x8 rb_ldw(const u32x4* p) { return __builtin_bit_cast(bf16x8, *p); }
+
+// the first RB_PF steps of a wavefront's first segment
+template <int NT>
+__device__ __forceinline__ void rb_prime(const u32x4* seg, bf16x8 (&wb)[RB_PF][NT]) {
+#pragma unroll
+    for (int p = 0; p < RB_PF; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wb[p][nt] = rb_ldw(seg + (p * 4 + nt) * 64);
+}
+
+// One SEGMENT of a wavefront's weight stream: 16 k-steps (K = 512) of 4 fragments = 64 output columns; acc[nt][mt] += W-tile nt .
+// block rows mt*16 .. +15.  `cur` is the segment (lane offset included), `nxt` the one that follows (its first RB_PF steps are
+// requested during this segment's last ones).  D[n][m]: the weight is the MFMA row operand, so lane (l15, g) ends with row
+// mt*16 + l15, columns nt*16 + g*4 .. +3.
+// A lane's MFMA-operand address in a block: row mt*16 + l15, chunk kb*4 + g swizzled by the row -> (rb_lane_base ^ (kb << 6)) + mt*16384:
+// the swizzle only touches bits 4..9, so a k-step costs one v_xor with an inline constant and the tile index rides in the offset field.
+__device__ __forceinline__ int rb_lane_base(int l15, int g) { return l15 * 1024 + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4)); }
+
+template <int MT, int NT = 4>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one)
+__device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, bf16x8 (&wb)[RB_PF][NT], const unsigned char* smem, int lbase,
+                                           f32x4 (&acc)[NT][MT]) {
+    asm volatile("" : "+v"(lbase));                   // (keeps the sixteen k-step addresses from being hoisted out of the caller's loops and spilled)
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        bf16x8 xa[MT];
+        const unsigned char* xp = smem + (lbase ^ (kb << 6));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 16384);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kb % RB_PF][nt], xa[mt], acc[nt][mt], 0, 0, 0);
+        const u32x4* src = kb + RB_PF < 16 ? cur + (kb + RB_PF) * 256 : nxt + (kb + RB_PF - 16) * 256;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wb[kb % RB_PF][nt] = rb_ldw(src + nt * 64);
+        __builtin_amdgcn_sched_barrier(0);            // the scheduler would sink the loads next to their use: the prefetch distance is the point
+    }
+}
+
+// Closing a sublayer: out = residual + (accumulators + bias), written as WHOLE ROWS.  The accumulator layout (lane = row, 4 columns)
+// makes 64-byte row pieces at best and the chip's store path is issue-bound on pieces (measured: the bf16 copy written 8 bytes per
+// lane cost 4 us per workgroup, the float32 rows 16 bytes per lane another 5).  So the tiles go through LDS once: 32 block rows per
+// pass, float32, row pitch 2 064 B (the 16-byte pad spreads the 16 rows of a tile over all banks), and every wavefront then owns
+// whole rows of the pass: a lane holds columns lane*4 .. +3 and 256 + lane*4 .. +3 of its row -- the residual is loaded and the
+// float32 row stored as 1-KiB wave accesses, the bf16 copy as 512-byte ones, and a 32-column statistics group is 8 adjacent lanes.
+constexpr int RB_SPITCH = 2064;
+struct RbOut {
+    const float* x; int ldx;                  // residual stream in
+    float* y; int ldy;                        // out (may be x: the residual of a pass is in registers before its rows are stored)
+    bf16_t* yb; float* stats;                 // optional: bf16 copy [M][512], partial (sum, sum of squares) per 32 columns [M][16][2]
+};
+
+// residual values of this wavefront's RPW rows of the pass whose first block row is `prow0` (issued BEFORE the staging barrier)
+template <int RPW>
+__device__ __forceinline__ void rb_pass_residual(const RbOut& o, int prow0, int m0, int rows_live, int wave, int lane, float4 (&res)[RPW][2]) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = prow0 + wave * RPW + j;
+        const float* xr = o.x + (size_t)(m0 + min(r, rows_live - 1)) * o.ldx + lane * 4;
+        res[j][0] = *reinterpret_cast<const float4*>(xr);
+        res[j][1] = *reinterpret_cast<const float4*>(xr + 256);
+    }
+}
+// one accumulator tile (+ bias) into the staging area: tile row tr (0 / 1 of the pass), columns col .. col + 3 of row tr*16 + l15
+__device__ __forceinline__ void rb_stage_tile(unsigned char* stage, int tr, int l15, int col, const f32x4& acc, const float4& bias) {
+    *reinterpret_cast<float4*>(stage + (tr * 16 + l15) * RB_SPITCH + col * 4) = make_float4(acc[0] + bias.x, acc[1] + bias.y, acc[2] + bias.z, acc[3] + bias.w);
+}
+// after the barrier behind the staging writes: this wavefront's rows of the pass -> memory
+template <int RPW>
+__device__ __forceinline__ void rb_pass_store(const unsigned char* stage, const RbOut& o, int prow0, int pass_rows, int m0, int rows_live, int wave, int lane,
+                                              const float4 (&res)[RPW][2]) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int lr = wave * RPW + j, r = prow0 + lr;             // row of the pass / of the block
+        const bool live = lr < pass_rows && r < rows_live;
+        const float4 s0 = *reinterpret_cast<const float4*>(stage + lr * RB_SPITCH + lane * 16);
+        const float4 s1 = *reinterpret_cast<const float4*>(stage + lr * RB_SPITCH + 1024 + lane * 16);
+        const float4 o0 = make_float4(res[j][0].x + s0.x, res[j][0].y + s0.y, res[j][0].z + s0.z, res[j][0].w + s0.w);
+        const float4 o1 = make_float4(res[j][1].x + s1.x, res[j][1].y + s1.y, res[j][1].z + s1.z, res[j][1].w + s1.w);
+        const size_t m = live ? (size_t)(m0 + r) : 0;
+        if (live) {
+            float* yr = o.y + m * o.ldy + lane * 4;
+            *reinterpret_cast<float4*>(yr) = o0;
+            *reinterpret_cast<float4*>(yr + 256) = o1;
+            if (o.yb) {
+                *reinterpret_cast<uint2*>(o.yb + m * 512 + lane * 4) = make_uint2(pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w));
+                *reinterpret_cast<uint2*>(o.yb + m * 512 + 256 + lane * 4) = make_uint2(pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w));
+            }
+        }
+        if (o.stats) {                        // groups of 32 columns = 8 adjacent lanes: groups lane / 8 and 8 + lane / 8
+            const float a0 = oct_sum((o0.x + o0.y) + (o0.z + o0.w)), q0 = oct_sum((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w));
+            const float a1 = oct_sum((o1.x + o1.y) + (o1.z + o1.w)), q1 = oct_sum((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
+            if (live && !(lane & 7)) {
+                float2* sp = reinterpret_cast<float2*>(o.stats + m * 32);
+                sp[lane >> 3] = make_float2(a0, q0);
+                sp[8 + (lane >> 3)] = make_float2(a1, q1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(512) void rb_ffn_kernel(RbFfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;                                  // LN input rows in bf16 (the raw stream: the norm is folded into w_1)
+    unsigned char* ht = smem + 65536;                          // 512 hidden columns of the block
+    float* c1s = reinterpret_cast<float*>(smem + 131072);      // [dff]
+    float* cs1s = c1s + a.dff;                                 // [dff]
+    float* b2s = cs1s + a.dff;                                 // [512]
+    float* s_mean = b2s + 512;                                 // [64]
+    float* s_rstd = s_mean + 64;                               // [64]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 64, rounds = a.dff >> 9, lbase = rb_lane_base(l15, g);
+    auto w1seg = [&](int r) { return a.w1p + (size_t)(r * 8 + wave) * (16 * 256) + lane; };
+    auto w2seg = [&](int r) { return a.w2p + ((size_t)wave * (a.dff >> 5) + r * 16) * 256 + lane; };
+    bf16x8 wb[RB_PF][4];
+    rb_prime<4>(w1seg(0), wb);
+
+    // ---- per-column constants
+    for (int i = tid; i < a.dff; i += 512) { c1s[i] = a.c1[i]; cs1s[i] = a.cs1[i]; }
+    b2s[tid] = a.b2[tid];
+    // ---- stage the block: wavefront w takes rows 8w .. 8w+7, eight lanes per row (128 contiguous bytes per row and load), row
+    // statistics on the way (unbiased std, eps on the std: LayerNorm of TransformerModel.py:1346-1349)
+    {
+        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+        }
+        sm = oct_sum(sm); sq = oct_sum(sq);
+        if (sub == 0) {
+            const float mean = sm * (1.0f / 512.0f);
+            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+            s_mean[r] = mean;
+            s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc2[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc2[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        // ---- hidden columns r*512 + wave*64 .. +63 of the block
+        f32x4 acc1[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb_segment<4>(w1seg(r), w2seg(r), wb, smem, lbase, acc1);
+        if (r > 0) __syncthreads();                            // every wavefront is through with the previous 512 hidden columns
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int hc = r * 512 + wave * 64 + nt * 16 + g * 4;
+            const float4 cc = *reinterpret_cast<const float4*>(c1s + hc);
+            const float4 cs = *reinterpret_cast<const float4*>(cs1s + hc);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float mu = s_mean[mt * 16 + l15], rs = s_rstd[mt * 16 + l15];
+                const f32x4 t = acc1[nt][mt];
+                const float h0 = fmaxf(rs * (t[0] - mu * cs.x) + cc.x, 0.f), h1 = fmaxf(rs * (t[1] - mu * cs.y) + cc.y, 0.f);
+                const float h2 = fmaxf(rs * (t[2] - mu * cs.z) + cc.z, 0.f), h3 = fmaxf(rs * (t[3] - mu * cs.w) + cc.w, 0.f);
+                *reinterpret_cast<uint2*>(ht + rb_off(mt * 16 + l15, wave * 8 + nt * 2 + (g >> 1)) + (g & 1) * 8) = make_uint2(pack_bf16(h0, h1), pack_bf16(h2, h3));
+            }
+        }
+        __syncthreads();
+        // ---- output columns wave*64 .. +63, K = this round's 512 hidden columns
+        rb_segment<4>(w2seg(r), r + 1 < rounds ? w1seg(r + 1) : w2seg(r), wb, smem, lbase + 65536, acc2);
+    }
+
+    // ---- closing epilogue: + b_2 + x -> stream (+ bf16 copy, + partial sums), two passes of 32 rows through LDS (the x and h blocks are dead)
+    const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
+    const int rows_live = min(64, a.M - m0);
+    float4 bb[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bb[nt] = *reinterpret_cast<const float4*>(b2s + wave * 64 + nt * 16 + g * 4);
+    __syncthreads();                                           // the last segment's reads of the h block are done everywhere
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        float4 res[4][2];
+        rb_pass_residual<4>(out, ps * 32, m0, rows_live, wave, lane, res);
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) rb_stage_tile(smem, tr, l15, wave * 64 + nt * 16 + g * 4, acc2[nt][ps * 2 + tr], bb[nt]);
+        __syncthreads();
+        rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
+        if (ps == 0) __syncthreads();
+    }
+}
+
+int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
+    if (a.M < 1 || a.dff < 512 || a.dff % 512 || a.dff > 2560 || !a.x || !a.w1p || !a.c1 || !a.cs1 || !a.w2p || !a.b2 || !a.y || a.ldx % 4 || a.ldy % 4)
+        return BOFI_ERR_ARG;
+    const size_t lds = 131072 + (size_t)a.dff * 8 + 2048 + 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Attention sublayer: x <- x + W_o . concat_h softmax(q_h k_h^T / 8, key-prefix mask) v_h + b_o for G images per workgroup.
+// Wavefront = head.  The attention itself is attn_bf16.hip's register-resident form (S^T = K Q^T with the key on the accumulator
+// rows, the probabilities feeding O^T = V^T P^T from the same registers, V^T by transposing LDS reads); the next image's Q / K / V
+// are requested while the current one is computed; a head's output goes to its 64 columns of the block in LDS instead of HBM.
+// Then all eight wavefronts run the output projection over the block (rb_segment) and close the sublayer (rb_pass_store).
+
+typedef __attribute__((ext_vector_type(4))) short rb_s16x4;
+constexpr int RB_VROW = 80;                   // bf16 elements per staged V row (160 B: an odd multiple of 32 B, attn_bf16.hip)
+
+// one (image, head): Q / K fragments straight from memory, V through the wavefront's LDS tile `sv` -> O^T in registers:
+// ot[dt][qi][c] = O[q = qi*16 + l15][d = dt*16 + g*4 + c]
+template <int NQT, int NKT>
+__device__ __forceinline__ void rb_attn_head(const RbAttnArgs& a, int img, int h, int lane, bf16_t* sv, const bf16_t* zrow, f32x4 (&ot)[4][NQT]) {
+    constexpr int VR = NKT == 4 ? 48 : 32;            // V rows staged (keys 48..63 of a four-tile call read the zero row)
+    constexpr int NKL = NKT == 4 ? 3 : NKT;           // key tiles that can hold keys
+    const int l15 = lane & 15, g = lane >> 4, Lk = a.Lk;
+    const bf16_t* qg = a.q + (size_t)img * a.Lq * a.ldq + h * 64;
+    const bf16_t* kg = a.k + (size_t)img * Lk * a.ldk + h * 64;
+    const bf16_t* vg = a.v + (size_t)img * Lk * a.ldv + h * 64;
+    const bf16x8 zero8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 bq[NQT][2], ak[NKL][2];
+#pragma unroll
+    for (int qi = 0; qi < NQT; ++qi) {
+        const int r = qi * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bq[qi][s] = r < a.Lq ? *reinterpret_cast<const bf16x8*>(qg + (size_t)r * a.ldq + s * 32 + g * 8) : zero8;
+    }
+#pragma unroll
+    for (int kj = 0; kj < NKL; ++kj) {
+        const int r = kj * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ak[kj][s] = r < Lk ? *reinterpret_cast<const bf16x8*>(kg + (size_t)r * a.ldk + s * 32 + g * 8) : zero8;
+    }
+#pragma unroll
+    for (int c = lane; c < VR * 8; c += 64) {
+        const int r = c >> 3, ch = c & 7;
+        *reinterpret_cast<u32x4*>(&sv[r * RB_VROW + ch * 8]) = r < Lk ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * a.ldv + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    // key counts.  Encoder, filling pass and cross-attention have ONE count per image (klen_sq == 0): it is read as a scalar and whole
+    // key tiles are then either unmasked, masked per element (the one tile the count falls into) or skipped -- the softmax is most of
+    // this phase's vector work.  Per-row counts (klen_sq != 0) mask every element.  All requested here, with the operands.
+    const bool uni = a.klen_sq == 0;
+    int klu = Lk, kls[NQT];
+    {
+        const int bi = a.klen_shared_last ? min(a.B, (img / a.klen_shared_last + 1) * a.klen_shared_last) - 1 : img;     // quirk Q1 per group
+        if (a.klen && uni) klu = __builtin_amdgcn_readfirstlane(max(0, min(a.klen[bi * a.klen_sb] + a.klen_bias, Lk)));
+#pragma unroll
+        for (int qi = 0; qi < NQT; ++qi) {
+            const int qrow = qi * 16 + l15;
+            kls[qi] = klu;
+            if (a.klen && !uni && qrow < a.Lq) kls[qi] = max(0, min(a.klen[bi * a.klen_sb + qrow * a.klen_sq] + a.klen_bias, Lk));
+        }
+    }
+    // ---- S^T[key][q] = K Q^T over the NKL key tiles that can hold keys (a four-tile call has Lk <= 48: its last tile is padding)
+    f32x4 st[NKL][NQT];
+#pragma unroll
+    for (int kj = 0; kj < NKL; ++kj)
+#pragma unroll
+        for (int qi = 0; qi < NQT; ++qi) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kj][0], bq[qi][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kj][1], bq[qi][1], c, 0, 0, 0);
+            st[kj][qi] = c;
+        }
+    // ---- softmax over the keys of each query column; a lane holds keys kj*16 + g*4 + r.  softmax(s / 8) = exp2((s - max s) * log2(e) / 8) / sum
+    constexpr float SC = 0.125f * 1.44269504088896340736f;
+    bf16x8 bp[NQT][NKT / 2];
+#pragma unroll
+    for (int qi = 0; qi < NQT; ++qi) {
+        const int kl = kls[qi];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kj = 0; kj < NKL; ++kj) {
+            if (uni && kj * 16 >= klu) continue;                          // (scalar conditions: whole tiles)
+            const bool whole = uni && kj * 16 + 16 <= klu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, (whole || kj * 16 + g * 4 + r < kl) ? st[kj][qi][r] : -INFINITY);
+        }
+        m = xor32_max(xor16_max(m));
+        const float mb = m * SC;
+        float sum = 0.f;
+#pragma unroll
+        for (int kj = 0; kj < NKL; ++kj) {
+            if (uni && kj * 16 >= klu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kj][qi][r] = 0.f;
+                continue;
+            }
+            const bool whole = uni && kj * 16 + 16 <= klu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kj][qi][r], SC, -mb));
+                if (!whole) e = (kj * 16 + g * 4 + r < kl) ? e : 0.f;
+                st[kj][qi][r] = e;
+                sum += e;
+            }
+        }
+        sum = xor32_sum(xor16_sum(sum));
+        const float inv_sum = 1.0f / sum;                 // an empty row: 0 * (1/0) = NaN for every key, as softmax over all -inf
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s) {
+            bf16x8 f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kj = 2 * s + (j >> 2), r = j & 3;
+                float pv = 0.f;
+                if (kj < NKL) {
+                    pv = st[kj][qi][r] * inv_sum;
+                    if ((kj + 1) * 16 > Lk && kl == 0 && kj * 16 + g * 4 + r >= Lk) pv = 0.f;      // padded keys of an empty row: V is 0 there
+                }
+                f[j] = (short)f32_to_bf16(pv);
+            }
+            bp[qi][s] = f;
+        }
+    }
+    // ---- O^T[d][q] = V^T P^T
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qi = 0; qi < NQT; ++qi) ot[dt][qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = l15 >> 2, tp = l15 & 3;
+#pragma unroll
+    for (int s = 0; s < NKT / 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16_t* a0p = &sv[(32 * s + 4 * g + tq) * RB_VROW + dt * 16 + 4 * tp];
+            const bf16_t* a1p = (NKT == 4 && s == 1) ? zrow + dt * 16 + 4 * tp : a0p + 16 * RB_VROW;
+            const rb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rb_s16x4*)a0p);
+            const rb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rb_s16x4*)a1p);
+            bf16x8 av;
+            av[0] = lo[0]; av[1] = lo[1]; av[2] = lo[2]; av[3] = lo[3];
+            av[4] = hi[0]; av[5] = hi[1]; av[6] = hi[2]; av[7] = hi[3];
+#pragma unroll
+            for (int qi = 0; qi < NQT; ++qi) ot[dt][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bp[qi][s], ot[dt][qi], 0, 0, 0);
+        }
+    __builtin_amdgcn_wave_barrier();                   // (the V tile is rewritten for the wavefront's next image only after these reads were issued)
+}
+
+// 16 wavefronts: wavefront (p, h) = wave >> 3, wave & 7 runs head h of images p, p + 2, ... of the workgroup's G (NR = G / 2 rounds);
+// the V tiles and the block share LDS (the block is written once every wavefront is through with its V tile); then every
+// wavefront takes 32 of the 512 output columns.
+template <int NQT, int NKT, int NR>
+__global__ __launch_bounds__(1024) void rb_attn_kernel(RbAttnArgs a) {
+    constexpr int MT = 5, G = 2 * NR, VR = NKT == 4 ? 48 : 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* blk = smem;                                              // [80 rows][512] bf16, swizzled  (aliases the V tiles)
+    bf16_t* svs = reinterpret_cast<bf16_t*>(smem);                          // 16 x [VR][RB_VROW]
+    constexpr int BODY = (16 * VR * RB_VROW * 2 > MT * 16384) ? 16 * VR * RB_VROW * 2 : MT * 16384;
+    float* bos = reinterpret_cast<float*>(smem + BODY);                     // [512]
+    bf16_t* zrow = reinterpret_cast<bf16_t*>(smem + BODY + 2048);           // 256 B of zeros
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int img0 = blockIdx.x * G, nimg = min(G, a.B - img0);
+    RB_STAMP(a.dbg, wave, lane, 0);
+    if (tid < 512) bos[tid] = a.bo[tid];
+    else if (tid < 576) reinterpret_cast<uint32_t*>(zrow)[tid - 512] = 0u;
+    __syncthreads();                                                        // (the zero row is read by every wavefront)
+
+    RB_STAMP(a.dbg, wave, lane, 1);
+    // ---- attention
+    const int h = wave & 7, p = wave >> 3;
+    bf16_t* sv = svs + wave * (VR * RB_VROW);
+    f32x4 ot[NR][4][NQT];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (p + 2 * r < nimg && !(a.dbg & 1)) rb_attn_head<NQT, NKT>(a, img0 + p + 2 * r, h, lane, sv, zrow, ot[r]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the output projection's weights: columns wave*32 .. +31 = tiles (wave & 1)*2, +1 of chunk wave >> 1
+    const u32x4* wo = a.wop + (size_t)(wave >> 1) * (16 * 256) + (wave & 1) * 128 + lane;
+    RB_STAMP(a.dbg, wave, lane, 2);
+    bf16x8 wb[RB_PF][2];
+    rb_prime<2>(wo, wb);
+    __syncthreads();                                                        // every V tile is dead: the block may overwrite them
+    RB_STAMP(a.dbg, wave, lane, 3);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (p + 2 * r >= nimg) continue;
+        const int row0 = (p + 2 * r) * a.Lq;
+#pragma unroll
+        for (int qi = 0; qi < NQT; ++qi) {
+            const int qrow = qi * 16 + l15;
+            if (qrow >= a.Lq) continue;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(blk + rb_off(row0 + qrow, h * 8 + dt * 2 + (g >> 1)) + (g & 1) * 8) =
+                    make_uint2(pack_bf16(ot[r][dt][qi][0], ot[r][dt][qi][1]), pack_bf16(ot[r][dt][qi][2], ot[r][dt][qi][3]));
+        }
+    }
+    __syncthreads();
+    RB_STAMP(a.dbg, wave, lane, 4);
+
+    // ---- output projection over the block
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 2)) rb_segment<MT, 2>(wo, wo, wb, smem, rb_lane_base(l15, g), acc);
+    RB_STAMP(a.dbg, wave, lane, 5);
+
+    // ---- close the sublayer: three passes of 32 / 32 / 16 rows through LDS (the block is dead once every wavefront has left the segment)
+    const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
+    const int rows_live = (a.dbg & 4) ? 0 : nimg * a.Lq, m0 = img0 * a.Lq, cb = wave * 32 + g * 4;
+    const float4 b0 = *reinterpret_cast<const float4*>(bos + cb), b1 = *reinterpret_cast<const float4*>(bos + cb + 16);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        float4 res[2][2];
+        rb_pass_residual<2>(out, ps * 32, m0, max(rows_live, 1), wave, lane, res);
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {
+            if (ps * 2 + tr >= MT) continue;
+            rb_stage_tile(smem, tr, l15, cb, acc[0][ps * 2 + tr < MT ? ps * 2 + tr : 0], b0);
+            rb_stage_tile(smem, tr, l15, cb + 16, acc[1][ps * 2 + tr < MT ? ps * 2 + tr : 0], b1);
+        }
+        __syncthreads();
+        RB_STAMP(a.dbg, wave, lane, 6 + 2 * ps);
+        rb_pass_store<2>(smem, out, ps * 32, ps == 2 ? 16 : 32, m0, rows_live, wave, lane, res);
+        if (ps < 2) __syncthreads();
+        RB_STAMP(a.dbg, wave, lane, 7 + 2 * ps);
+    }
+}
+
+template <int NQT, int NKT, int NR>
+static int launch_rb_attn_t(const RbAttnArgs& a, hipStream_t st) {
+    constexpr int VR = NKT == 4 ? 48 : 32;
+    constexpr size_t body = (16 * VR * RB_VROW * 2 > 5 * 16384) ? 16 * VR * RB_VROW * 2 : 5 * 16384;
+    constexpr size_t lds = body + 2048 + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_attn_kernel<NQT, NKT, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return BOFI_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rb_attn_kernel<NQT, NKT, NR>), dim3((a.B + 2 * NR - 1) / (2 * NR)), dim3(1024), lds, st, a);
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+// -1: shape not covered (the caller keeps attention + GEMM)
+int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
+    if (!a.q || !a.k || !a.v || !a.wop || !a.bo || !a.x || !a.y || a.B < 1 || a.Lq < 1 || a.Lk < 1 || a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldx % 4 || a.ldy % 4)
+        return BOFI_ERR_ARG;
+    if (a.Lq > 40 || a.Lk > 48) return -1;
+    int rc;
+    if (a.Lq <= 20 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 2>(a, st);           // 4 images of <= 20 rows per workgroup
+    else if (a.Lq <= 20) rc = launch_rb_attn_t<2, 4, 2>(a, st);
+    else if (a.Lq <= 32 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 1>(a, st);      // 2 images
+    else if (a.Lq <= 32) rc = launch_rb_attn_t<2, 4, 1>(a, st);
+    else rc = launch_rb_attn_t<3, 4, 1>(a, st);
+    if (rc == BOFI_OK) g_gemm_flops += 2.0 * a.B * a.Lq * 512.0 * 512.0;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// w [N][K] row-major bf16 -> fragment-major: [N/64 chunks][K/32 steps][4 tiles][64 lanes][8 bf16]; lane (l15, g) of a fragment holds
+// row chunk*64 + tile*16 + l15, k = step*32 + g*8 .. +7
+__global__ __launch_bounds__(256) void rb_pack_frag_kernel(const bf16_t* __restrict__ w, u32x4* __restrict__ out, int N, int K) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * K / 8) return;
+    const int lane = (int)(i & 63), nt = (int)((i >> 6) & 3);
+    const size_t t = i >> 8;
+    const int kb = (int)(t % (size_t)(K >> 5)), chunk = (int)(t / (size_t)(K >> 5));
+    const int n = chunk * 64 + nt * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8;
+    out[i] = *reinterpret_cast<const u32x4*>(w + (size_t)n * K + k);
+}
+
+int launch_rb_pack_frag(const void* w, void* out, int N, int K, hipStream_t st) {
+    if (!w || !out || N < 64 || N % 64 || K < 32 || K % 32) return BOFI_ERR_ARG;
+    const size_t n = (size_t)N * K / 8;
+    hipLaunchKernelGGL(rb_pack_frag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w, (u32x4*)out, N, K);
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+}  // namespace bofi
+
+extern "C" int bofi_rb_stamps(unsigned long long* host_out) {      // developer aid: the 16 x 16 stamps of the last BOFI_RB_DBG & 16 launch
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bofi::g_rb_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+extern "C" int bofi_pack_frag(const void* w, void* out, int N, int K, void* stream) {
+    return bofi::launch_rb_pack_frag(w, out, N, K, (hipStream_t)stream);
+}
+
+extern "C" int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen, int klen_sb,
+                               int klen_sq, int klen_bias, int klen_shared_last, const void* wop, const float* bo, const float* x, int ldx, float* y,
+                               int ldy, void* yb, float* stats_out, void* stream) {
+    bofi::RbAttnArgs a{};
+    a.q = (const bofi::bf16_t*)q; a.ldq = ldq; a.k = (const bofi::bf16_t*)k; a.ldk = ldk; a.v = (const bofi::bf16_t*)v; a.ldv = ldv;
+    a.B = B; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = klen_sq; a.klen_bias = klen_bias; a.klen_shared_last = klen_shared_last;
+    a.wop = (const bofi::u32x4*)wop; a.bo = bo; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.yb = (bofi::bf16_t*)yb; a.stats_out = stats_out;
+    { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
+    const int rc = bofi::launch_rb_attn(a, (hipStream_t)stream);
+    return rc < 0 ? BOFI_ERR_ARG : rc;
+}
+
+extern "C" int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,
+                              int ldy, void* yb, float* stats_out, int M, int dff, void* stream) {
+    bofi::RbFfnArgs a{};
+    a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
+    a.yb = (bofi::bf16_t*)yb; a.stats_out = stats_out; a.M = M; a.dff = dff;
+    return bofi::launch_rb_ffn(a, (hipStream_t)stream);
+}

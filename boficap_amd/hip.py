@@ -84,6 +84,9 @@ SIGNATURES = {
     "bofi_engine_bound_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "bofi_engine_debug_copy": (_I, [_P, C.c_char_p, _P, _I64, _P]),
     "bofi_gemm_flops": (C.c_double, [_I, _P]),
+    "bofi_pack_frag": (_I, [_P, _P, _I, _I, _P]),
+    "bofi_attn_block": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "bofi_ffn_block": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "bofi_engine_fill_naic": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
 }
 

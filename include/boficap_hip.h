@@ -380,6 +380,30 @@ int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const fl
                      int ldkv, const int* att_len, void* out, int B, int R, const int* skip, int skip_threshold, const int* row_idx,
                      const int* n_rows, int rows_per_image, void* stream);
 
+/* Row-block sublayer kernels (rowblock.hip; bf16 operands, d_model 512): a workgroup keeps a block of activation rows in LDS for a
+ * whole sublayer and streams the weights from L2 straight into MFMA operand registers.
+ * bofi_pack_frag: w [N, K] row-major bf16 -> the fragment-major layout those kernels stream
+ *   ([N/64][K/32][4 tiles][64 lanes][8 bf16]; N % 64 == 0, K % 32 == 0); out holds N*K bf16.
+ * bofi_ffn_block: y = x + w_2 relu(w_1 LN(x) + b_1) + b_2 -- PositionwiseFeedForward behind SublayerConnection
+ *   (TransformerModel.py:1477-1478, 1361-1377), one launch.  x, y float32 [M, 512] (y may be x); w1p = bofi_pack_frag of the
+ *   [dff, 512] weight with the norm's gain folded in, c1 = b_1 + w_1 b_ln, cs1 = column sums of the rounded folded weight
+ *   (float32 [dff]: the fold of gemm_glds.hip); w2p = bofi_pack_frag of the [512, dff] weight, b2 float32 [512]; dff % 512 == 0,
+ *   dff <= 2560.  Optional outputs (NULL to skip): yb bf16 [M, 512], stats_out float32 [M][16][2] partial (sum, sum of squares)
+ *   per 32 columns of y (what a LayerNorm-folded consumer GEMM reads).
+ * bofi_attn_block: y = x + W_o concat_h softmax(q_h k_h^T / 8) v_h + b_o -- MultiHeadedAttention (TransformerModel.py:1421-1432,
+ *   1454-1467) behind the sublayer's residual, one launch: 8 heads of 64, q [B*Lq, ldq], k / v [B*Lk, ldk / ldv] bf16 (head h at
+ *   columns h*64), Lq, Lk <= 48.  Key-prefix masks as bofi_attention: klen int32 (NULL: all Lk keys), entry
+ *   klen[bi * klen_sb + q * klen_sq] + klen_bias for query row q of image b, bi = b, or with klen_shared_last = G > 0 the last
+ *   image of b's group of G (quirk Q1, TransformerModel.py:1872-1873); a row without keys is NaN as in the reference.
+ *   wop = bofi_pack_frag of the [512, 512] output projection, bo float32 [512]; x, y float32 [B*Lq, 512] (y may be x); yb /
+ *   stats_out as bofi_ffn_block. */
+int bofi_pack_frag(const void* w, void* out, int N, int K, void* stream);
+int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen,
+                    int klen_sb, int klen_sq, int klen_bias, int klen_shared_last, const void* wop, const float* bo, const float* x,
+                    int ldx, float* y, int ldy, void* yb, float* stats_out, void* stream);
+int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
+                   float* y, int ldy, void* yb, float* stats_out, int M, int dff, void* stream);
+
 /* Developer aid: copy one of the bounding iteration's workspace buffers ("by1", "byb", "st_b", "bq2", "bctx2", "by2", "bh", "by3")
  * into user memory (device to device, on `stream`). */
 int bofi_engine_debug_copy(bofi_engine_t* e, const char* name, void* dst, int64_t bytes, void* stream);

@@ -86,3 +86,68 @@ def test_infos_histories_and_yaml_base(tmp_path):
     ck.check_resume_opts(Namespace(caption_model="transformer", rnn_size=2048, num_layers=6), Namespace(caption_model="transformer", rnn_size=2048, num_layers=6))
     with pytest.raises(AssertionError):
         ck.check_resume_opts(Namespace(caption_model="transformer", rnn_size=2048), Namespace(caption_model="transformer", rnn_size=512))
+
+
+def _reference_resume_lines(start_from, run_id, opt):
+    """tools/train.py:55-69,117-128 of the reference, restated: what it executes on a run directory before training resumes."""
+    import pickle as pk
+    infos = {"iter": 0, "epoch": 0, "loader_state_dict": None, "vocab": None}
+    path = os.path.join(start_from, "infos_" + run_id + ".pkl")
+    if os.path.isfile(path):
+        with open(path, "rb") as f:
+            infos = pk.load(f, encoding="latin-1")
+        saved_model_opt = infos["opt"]
+        for checkme in ["caption_model", "rnn_type", "rnn_size", "num_layers"]:
+            assert getattr(saved_model_opt, checkme) == getattr(opt, checkme), checkme      # no default: a missing attribute raises
+    histories = {}
+    hp = os.path.join(start_from, "histories_" + run_id + ".pkl")
+    if os.path.isfile(hp):
+        with open(hp, "rb") as f:
+            histories.update(pk.load(f, encoding="latin-1"))
+    iteration, epoch = infos["iter"], infos["epoch"]
+    if "iterators" in infos:
+        infos["loader_state_dict"] = {s: {"index_list": infos["split_ix"][s], "iter_counter": infos["iterators"][s]} for s in ["train", "val", "test"]}
+    loader_state = infos["loader_state_dict"]                      # unconditional index (train.py:125)
+    return iteration, epoch, loader_state, infos.get("best_val_score", None), histories
+
+
+def test_run_directory_written_as_tools_train_does_resumes_in_the_reference(tmp_path):
+    """The writer path of tools/train.py (checkpoint.new_infos / resume_opt / save_checkpoint) -> the reference's resume lines."""
+    from boficap_amd import checkpoint as ck
+    from boficap_amd.config import TINY
+    opt = TINY.to_opt()
+    opt.id, opt.checkpoint_path = "bofi", str(tmp_path / "run")
+    opt.bofi_train_dtype = torch.bfloat16                             # a knob that must not reach the pickle
+    infos = ck.new_infos({"1": "a"})
+    infos["iter"], infos["epoch"] = 7, 0
+    infos["opt"] = ck.resume_opt(opt)
+
+    class Opt:
+        def state_dict(self):
+            return {"state": {}, "param_groups": [{"params": []}], "_step": 7}
+    ck.save_checkpoint(opt, torch.nn.Linear(2, 2), infos, Opt(), {"loss_history": {7: 1.0}})
+    ref_opt = ck.resume_opt(opt)                                      # the reference run's own opt: same model-defining options
+    it, ep, loader_state, best, hist = _reference_resume_lines(opt.checkpoint_path, "bofi", ref_opt)
+    assert (it, ep, loader_state, best) == (7, 0, None, None) and hist["loss_history"] == {7: 1.0}
+    saved = ck.load_infos(opt.checkpoint_path, "bofi")[0]["opt"]
+    assert not hasattr(saved, "bofi_train_dtype")
+    for k in ck.RESUME_KEYS:
+        assert hasattr(saved, k), k
+    # an infos dict written WITHOUT the skeleton keys still gets them on disk
+    ck.save_checkpoint(opt, torch.nn.Linear(2, 2), {"iter": 1, "epoch": 0, "opt": ck.resume_opt(opt)}, Opt(), append="x")
+    assert "loader_state_dict" in ck.load_infos(opt.checkpoint_path, "bofi", "x")[0]
+
+
+def test_yaml_base_chain_of_three_and_a_loop(tmp_path):
+    from boficap_amd import checkpoint as ck
+    (tmp_path / "a.yml").write_text("x: 1\ny: {p: 1, q: 2}\n")
+    (tmp_path / "b.yml").write_text("_BASE_: a.yml\ny: {q: 3}\nz: 5\n")
+    (tmp_path / "c.yml").write_text("_BASE_: b.yml\nx: 9\n")
+    assert ck.load_yaml_with_base(str(tmp_path / "c.yml")) == {"x": 9, "y": {"p": 1, "q": 3}, "z": 5}
+    (tmp_path / "l1.yml").write_text("_BASE_: l2.yml\n")
+    (tmp_path / "l2.yml").write_text("_BASE_: l1.yml\n")
+    with pytest.raises(ValueError):
+        ck.load_yaml_with_base(str(tmp_path / "l1.yml"))
+    (tmp_path / "bad.yml").write_text("_BASE_: a.yml\nx: {k: 1}\n")
+    with pytest.raises(AssertionError):
+        ck.load_yaml_with_base(str(tmp_path / "bad.yml"))

@@ -1,0 +1,204 @@
+"""Row-block sublayer kernels (boficap_amd/csrc/rowblock.hip) on the MI355X, through the C ABI, against float64 torch
+restatements of the reference sublayers (TransformerModel.py:1361-1377 SublayerConnection, :1477-1478 PositionwiseFeedForward,
+:1454-1467 MultiHeadedAttention, :1346-1349 LayerNorm)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from boficap_amd import hip
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    hip.lib()
+    return hip
+
+
+def _rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _layer_norm64(x, gain, bias):
+    """LayerNorm of the reference: unbiased std, eps added to the std (TransformerModel.py:1346-1349)."""
+    x = x.double()
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)
+    return gain.double() * (x - mean) / (std + 1e-6) + bias.double()
+
+
+def _fold(w, b, gain, bln):
+    """The LayerNorm fold of engine.hip::make_lin: w' = w * gain (bf16), c = b + w . b_ln, cs = row sums of the ROUNDED w'."""
+    wf = _bf(w * gain[None, :])
+    c = (b.double() + w.double() @ bln.double()).float()
+    cs = wf.double().sum(1).float()
+    return wf, c, cs
+
+
+def pack_frag(H, w_bf16):
+    N, K = w_bf16.shape
+    out = torch.empty(N * K, dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().bofi_pack_frag(H.ptr(w_bf16), H.ptr(out), N, K, H.stream_ptr()))
+    return out
+
+
+def test_pack_frag_layout(H):
+    N, K = 128, 96
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K)
+    wb = (w % 251).to(torch.bfloat16).cuda()
+    out = pack_frag(H, wb).cpu().float().reshape(N // 64, K // 32, 4, 64, 8)
+    src = wb.cpu().float()
+    for chunk in range(N // 64):
+        for kb in range(K // 32):
+            for nt in range(4):
+                for lane in (0, 5, 17, 40, 63):
+                    n = chunk * 64 + nt * 16 + (lane & 15)
+                    k = kb * 32 + (lane >> 4) * 8
+                    assert torch.equal(out[chunk, kb, nt, lane], src[n, k:k + 8])
+
+
+@pytest.mark.parametrize("M,dff", [(64, 2048), (100, 2048), (2304, 2048), (37, 512), (129, 1024)])
+def test_ffn_block_vs_reference_sublayer(H, M, dff):
+    d = 512
+    g = _rng(M + dff)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w1, b1 = torch.randn(dff, d, generator=g) / math.sqrt(d), torch.randn(dff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, dff, generator=g) / math.sqrt(dff), torch.randn(d, generator=g) * 0.1
+    # the reference sublayer in float64 on the bf16-rounded weights (the engine's operands)
+    w1f, c1, cs1 = _fold(w1, b1, gain, bln)
+    w1_eff = w1f.double() / gain.double()[None, :]                      # what the folded, rounded weight stands for
+    h = torch.relu(_layer_norm64(x, gain, bln) @ w1_eff.T + b1.double())
+    ref = x.double() + h @ _bf(w2).double().T + b2.double()
+
+    xc = x.cuda()
+    w1p, w2p = pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda())
+    c1c, cs1c, b2c = c1.cuda(), cs1.cuda(), b2.cuda()
+    y = torch.full((M, d), float("nan"), device="cuda")
+    yb = torch.empty(M, d, dtype=torch.bfloat16, device="cuda")
+    st = torch.zeros(M, 16, 2, device="cuda")
+    H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y), d, H.ptr(yb), H.ptr(st),
+                                   M, dff, H.stream_ptr()))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    scale = (ref - x.double()).abs().max().item()
+    assert err < 2e-2 * max(1.0, scale), (err, scale)                  # bf16 operands and a bf16 hidden row, f32 accumulation
+    assert torch.equal(yb.cpu(), y.cpu().to(torch.bfloat16))
+    yc = y.cpu().double().reshape(M, 16, 32)
+    assert (st.cpu()[:, :, 0].double() - yc.sum(-1)).abs().max() < 1e-3
+    assert (st.cpu()[:, :, 1].double() - (yc * yc).sum(-1)).abs().max() < 1e-2 * max(1.0, float((yc * yc).sum(-1).max()) * 1e-2)
+    # in place, without the optional outputs: the same stream
+    H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(xc), d, None, None,
+                                   M, dff, H.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(xc.cpu(), y.cpu())
+
+
+def test_ffn_block_nan_row_stays_in_its_row(H):
+    """A NaN row (quirk Q1's fully masked image) must not leak into the other rows of its block."""
+    M, d, dff = 64, 512, 2048
+    g = _rng(7)
+    x = torch.randn(M, d, generator=g)
+    w1, w2 = torch.randn(dff, d, generator=g) / 22.0, torch.randn(d, dff, generator=g) / 45.0
+    ones, zeros = torch.ones(d), torch.zeros(d)
+    w1f, c1, cs1 = _fold(w1, torch.zeros(dff), ones, zeros)
+    w1p, w2p = pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda())
+    c1c, cs1c, b2c = c1.cuda(), cs1.cuda(), zeros.cuda()
+
+    def run(xin):
+        xc, y = xin.cuda(), torch.empty(M, d, device="cuda")
+        H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y), d, None, None, M, dff,
+                                       H.stream_ptr()))
+        torch.cuda.synchronize()
+        return y.cpu()
+
+    clean = run(x)
+    x2 = x.clone()
+    x2[13] = float("nan")
+    dirty = run(x2)
+    assert torch.isnan(dirty[13]).all()
+    keep = torch.arange(M) != 13
+    assert torch.equal(dirty[keep], clean[keep])
+
+
+def _attn_sublayer64(q, k, v, klens, wo, bo, x, B, Lq, Lk):
+    """x + W_o . concat_h softmax(q_h k_h^T / 8 under a key-prefix mask) v_h + b_o in float64; klens [B, Lq]."""
+    q, k, v = q.double().reshape(B, Lq, 8, 64), k.double().reshape(B, Lk, 8, 64), v.double().reshape(B, Lk, 8, 64)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q, k) / 8.0
+    mask = torch.arange(Lk)[None, None, None, :] < klens[:, None, :, None]
+    sc = sc.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(sc, -1)                                            # an all-masked row: NaN, as the reference
+    ctx = torch.einsum("bhqk,bkhd->bqhd", p, v).reshape(B * Lq, 512)
+    return x.double() + _bf(ctx.float()).double() @ wo.double().T + bo.double()
+
+
+@pytest.mark.parametrize("B,Lq,Lk,mode", [(5, 36, 36, "img"), (64, 36, 36, "none"), (9, 20, 20, "q1"), (7, 20, 36, "img"), (3, 20, 20, "row"),
+                                          (4, 24, 30, "img"), (2, 40, 48, "img"), (3, 30, 40, "img"), (1, 5, 3, "img")])
+def test_attn_block_vs_reference_sublayer(H, B, Lq, Lk, mode):
+    d = 512
+    g = _rng(B * 100 + Lq + Lk)
+    self_attn = Lq == Lk
+    if self_attn:
+        qkv = (torch.randn(B * Lq, 3 * d, generator=g)).to(torch.bfloat16)
+        q, k, v, ldq, ldk = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], 3 * d, 3 * d
+    else:
+        qb = torch.randn(B * Lq, d, generator=g).to(torch.bfloat16)
+        kvb = torch.randn(B * Lk, 7 * d, generator=g).to(torch.bfloat16)
+        q, k, v, ldq, ldk = qb, kvb[:, 2 * d:3 * d], kvb[:, 3 * d:4 * d], d, 7 * d
+    wo, bo = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g) * 0.1
+    x = torch.randn(B * Lq, d, generator=g)
+    kl_sb = kl_sq = kl_bias = shared = 0
+    klen_t = None
+    if mode == "img":                                        # one key count per image (region counts)
+        per = torch.randint(1, Lk + 1, (B,), generator=g)
+        klens, klen_t, kl_sb = per[:, None].expand(B, Lq), per.int(), 1
+    elif mode == "q1":                                       # fill mask: last - 1 of the LAST image of each group of 4 (quirk Q1), one group empty
+        last = torch.randint(2, Lk + 2, (B,), generator=g)
+        last[3] = 1                                          # -> key count 0 for images 0..3: NaN rows
+        grp_last = torch.tensor([min(B, (b // 4 + 1) * 4) - 1 for b in range(B)])
+        klens, klen_t, kl_sb, kl_bias, shared = (last[grp_last] - 1)[:, None].expand(B, Lq), last.int(), 1, -1, 4
+    elif mode == "row":                                      # one key count per query row
+        per = torch.randint(1, Lk + 1, (B, Lq + 2), generator=g)
+        klens, klen_t, kl_sb, kl_sq = per[:, :Lq], per.int(), Lq + 2, 1
+    else:
+        klens = torch.full((B, Lq), Lk)
+    ref = _attn_sublayer64(q.float(), k.float(), v.float(), klens, _bf(wo), bo, x, B, Lq, Lk)
+
+    dev = [t.cuda() for t in ((qkv,) if self_attn else (qb, kvb))]
+    if self_attn:
+        qd, kd, vd = dev[0], dev[0][:, d:], dev[0][:, 2 * d:]
+    else:
+        qd, kd, vd = dev[0], dev[1][:, 2 * d:], dev[1][:, 3 * d:]
+    wop = pack_frag(H, wo.to(torch.bfloat16).cuda())
+    boc, xc = bo.cuda(), x.cuda()
+    klc = None if klen_t is None else klen_t.cuda()
+    y = torch.full((B * Lq, d), float("nan"), device="cuda")
+    yb = torch.empty(B * Lq, d, dtype=torch.bfloat16, device="cuda")
+    st = torch.zeros(B * Lq, 16, 2, device="cuda")
+    H.check(H.lib().bofi_attn_block(H.ptr(qd), ldq, H.ptr(kd), ldk, H.ptr(vd), ldk, B, Lq, Lk, H.ptr(klc), kl_sb, kl_sq, kl_bias, shared,
+                                    H.ptr(wop), H.ptr(boc), H.ptr(xc), d, H.ptr(y), d, H.ptr(yb), H.ptr(st), H.stream_ptr()))
+    torch.cuda.synchronize()
+    yc = y.cpu().double()
+    nan_ref = torch.isnan(ref)
+    assert torch.equal(torch.isnan(yc), nan_ref)
+    if mode == "q1":
+        assert nan_ref[:4 * Lq].all() and not nan_ref[4 * Lq:].any()
+    ok = ~nan_ref
+    err = (yc[ok] - ref[ok]).abs().max().item()
+    assert err < 3e-2, err                                                # bf16 probabilities and context, f32 accumulation
+    assert torch.equal(yb.cpu()[ok], y.cpu().to(torch.bfloat16)[ok])
+    rows_ok = ok.all(1)
+    y3 = yc[rows_ok].reshape(-1, 16, 32)
+    assert (st.cpu()[rows_ok][:, :, 0].double() - y3.sum(-1)).abs().max() < 1e-3
+    assert (st.cpu()[rows_ok][:, :, 1].double() - (y3 * y3).sum(-1)).abs().max() < 1e-2
+    # in place, no optional outputs
+    H.check(H.lib().bofi_attn_block(H.ptr(qd), ldq, H.ptr(kd), ldk, H.ptr(vd), ldk, B, Lq, Lk, H.ptr(klc), kl_sb, kl_sq, kl_bias, shared,
+                                    H.ptr(wop), H.ptr(boc), H.ptr(xc), d, H.ptr(xc), d, None, None, H.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(xc.cpu()[rows_ok], y.cpu()[rows_ok])

@@ -610,6 +610,11 @@ def test_tools_train_entry_point_writes_reference_checkpoints(tmp_path):
     from boficap_amd.checkpoint import load_infos
     infos, hist = load_infos(ck, "bofi")
     assert infos["iter"] == 3 and infos["opt"].caption_model == "transformer" and sorted(hist["loss_history"]) == [1, 2, 3]
+    # the directory tools/train.py itself wrote goes through the reference's resume lines (tools/train.py:55-69,117-128 restated in
+    # tests/test_formats.py): 'loader_state_dict' is indexed and the four model options are read without defaults there
+    from test_formats import _reference_resume_lines
+    it, ep, loader_state, best, hist2 = _reference_resume_lines(ck, "bofi", infos["opt"])
+    assert (it, loader_state) == (3, None) and sorted(hist2["loss_history"]) == [1, 2, 3]
     out = subprocess.run(cmd + ["--start_from", ck, "--dtype", "f32", "--self_critical_after", "5", "--train_sample_n", "2"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -1,0 +1,92 @@
+"""Time the row-block sublayer kernels alone on the chip (in-graph time per launch, buffers rotated through the Infinity Cache).
+python tools/exp/mb_rowblock.py [ffn|attn]"""
+import math, sys
+import torch
+sys.path.insert(0, ".")
+from boficap_amd import hip as H
+
+H.lib()
+d, dff = 512, 2048
+dev = "cuda"
+
+
+def timed(fn, iters=50, rot=1):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for i in range(3):
+            fn(i % rot)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for i in range(iters):
+                fn(i % rot)
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s); g.replay(); e1.record(s); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def pack(w):
+    N, K = w.shape
+    out = torch.empty(N * K, dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().bofi_pack_frag(H.ptr(w), H.ptr(out), N, K, H.stream_ptr()))
+    return out
+
+
+def ffn(M):
+    rot = 4
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
+    ybs = [torch.empty(M, d, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+    sts = [torch.empty(M, 16, 2, device=dev) for _ in range(rot)]
+    w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+    w1p, w2p = pack(w1), pack(w2)
+    c1, cs1, b2 = torch.randn(dff, device=dev), w1.float().sum(1), torch.randn(d, device=dev)
+
+    def run(i):
+        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, H.ptr(ybs[i]),
+                                       H.ptr(sts[i]), M, dff, H.stream_ptr()))
+    t = timed(run, rot=rot)
+    print(f"ffn_block M {M:6d}: {t:7.2f} us  {4.0 * M * d * dff / t * 1e-6:7.1f} TFLOP/s  weight stream {4 * 1048576 / t * 1e-3:6.1f} GB/s per workgroup", flush=True)
+
+
+def attn(B, Lq, Lk, cross):
+    rot = 4
+    M = B * Lq
+    if cross:
+        qs = [torch.randn(M, d, device=dev).to(torch.bfloat16) for _ in range(rot)]
+        kvs = [torch.randn(B * Lk, 7168, device=dev).to(torch.bfloat16) for _ in range(rot)]
+    else:
+        qkvs = [torch.randn(M, 3 * d, device=dev).to(torch.bfloat16) for _ in range(rot)]
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ybs = [torch.empty(M, d, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
+    sts = [torch.empty(M, 16, 2, device=dev) for _ in range(rot)]
+    wop = pack((torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16))
+    bo = torch.randn(d, device=dev)
+    klen = torch.full((B,), Lk, dtype=torch.int32, device=dev)
+
+    def run(i):
+        if cross:
+            q, k, v, ldq, ldk = qs[i], kvs[i][:, 1024:], kvs[i][:, 1536:], d, 7168
+        else:
+            q, k, v, ldq, ldk = qkvs[i], qkvs[i][:, d:], qkvs[i][:, 2 * d:], 3 * d, 3 * d
+        import os
+        opt = int(os.environ.get("MB_OPT", "0"))
+        H.check(H.lib().bofi_attn_block(H.ptr(q), ldq, H.ptr(k), ldk, H.ptr(v), ldk, B, Lq, Lk, H.ptr(klen), 1, 0, 0, 0, H.ptr(wop), H.ptr(bo),
+                                        H.ptr(xs[i]), d, H.ptr(ys[i] if opt & 1 else xs[i]), d, None if opt & 2 else H.ptr(ybs[i]), None if opt & 4 else H.ptr(sts[i]), H.stream_ptr()))
+    t = timed(run, rot=rot)
+    print(f"attn_block B {B:4d} Lq {Lq} Lk {Lk} {'cross' if cross else 'self '}: {t:7.2f} us", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
+    if what == "ffn":
+        for M in (11520, 6400, 2304, 1280, 64):
+            ffn(M)
+    else:
+        for B in (320, 64, 2):
+            attn(B, 36, 36, False)
+            attn(B, 20, 20, False)
+            attn(B, 20, 36, True)

@@ -82,7 +82,7 @@ def main():
         model.load_state_dict(torch.load(os.path.join(args.start_from, "model.pth"), map_location="cpu"), strict=True)
     model.to(dev).train()
     trainer = XETrainer(model, opt, graph=not args.no_graph)
-    infos, histories = {"iter": 0, "epoch": 0, "vocab": opt.vocab}, {}
+    infos, histories = ck.new_infos(opt.vocab), {}           # incl. 'loader_state_dict': the reference's resume path indexes it (train.py:125)
     if args.start_from:
         if os.path.exists(os.path.join(args.start_from, "optimizer.pth")):
             trainer.load_state_dict(torch.load(os.path.join(args.start_from, "optimizer.pth"), map_location="cpu", weights_only=False))
@@ -171,20 +171,14 @@ def main():
             histories["ss_prob_history"][it + 1] = model.ss_prob
         infos["iter"] = it + 1                                   # tools/train.py:292-294
         if args.checkpoint_path and args.save_checkpoint_every and (it + 1) % args.save_checkpoint_every == 0 and rank == 0:
-            infos["opt"] = _plain(opt)
+            infos["opt"] = ck.resume_opt(opt)
             ck.save_checkpoint(opt, model, infos, trainer, histories)
     if args.checkpoint_path and rank == 0:
-        infos["opt"] = _plain(opt)
+        infos["opt"] = ck.resume_opt(opt)                     # plain values, every option of the reference's resume check present
         ck.save_checkpoint(opt, model, infos, trainer, histories)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-
-
-def _plain(opt):
-    """The opt namespace as it goes into infos['opt'] (tools/train.py:69): picklable values only (torch dtypes are this build's knobs)."""
-    from argparse import Namespace
-    return Namespace(**{k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, dict, list, tuple, type(None)))})
 
 
 if __name__ == "__main__":
