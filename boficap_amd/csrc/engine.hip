@@ -346,9 +346,12 @@ struct bofi_engine {
     // theirs (the caller then runs the separate attention / GEMM launches), else a status.  want_copy: the next consumer is a
     // LayerNorm-folded GEMM (it reads the compute-dtype copy and the row statistics); a following ffn_sublayer reads the stream itself.
     bool rb_ok() const { return cfg.dtype == BOFI_DT_BF16 && cfg.d_model == 512 && cfg.heads == 8; }
+    // the row-block kernels are a fixed latency chain per workgroup (one block of rows, the sublayer's whole weight stream): they pay
+    // from a few thousand rows on, where the tiled GEMMs' prologue / epilogue and the hidden tensor's round trip cost more
+    static int rb_min_rows() { static const int v = [] { const char* e = getenv("BOFI_RB_MIN_ROWS"); return e ? atoi(e) : 4096; }(); return v; }
     int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
         static const bool on = env_on("BOFI_RB_ATTN");
-        if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh) return -1;
+        if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh || at.B * at.Lq < rb_min_rows()) return -1;
         bofi::RbAttnArgs a{};
         a.q = (const uint16_t*)at.q; a.ldq = at.ldq; a.k = (const uint16_t*)at.k; a.ldk = at.ldk; a.v = (const uint16_t*)at.v; a.ldv = at.ldv;
         a.B = at.B; a.Lq = at.Lq; a.Lk = at.Lk; a.klen = at.klen; a.klen_sb = at.klen_sb; a.klen_sq = at.klen_sq; a.klen_bias = at.klen_bias;
@@ -356,12 +359,12 @@ struct bofi_engine {
         a.yb = want_copy ? (uint16_t*)xb : nullptr; a.stats_out = want_copy ? stats : nullptr;
         return bofi::launch_rb_attn(a, s);
     }
-    bool ffn_sublayer_ok(const Lin& w1, const Lin& w2) const {
+    bool ffn_sublayer_ok(const Lin& w1, const Lin& w2, int M) const {
         static const bool on = env_on("BOFI_RB_FFN");
-        return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560;
+        return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560 && M >= rb_min_rows();
     }
     int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s) {
-        if (!ffn_sublayer_ok(w1, w2)) return -1;
+        if (!ffn_sublayer_ok(w1, w2, M)) return -1;
         bofi::RbFfnArgs a{};
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
@@ -402,7 +405,7 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
         a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
-        const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2);
+        const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2, M);
         int rc = attn_sublayer(a, l.o, x_enc, xb_enc, st_enc, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {
@@ -553,7 +556,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
         c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
         c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0;
-        const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2);
+        const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2, M);
         rc = attn_sublayer(c, l.o_src, x_fill, xb_fill, st_fill, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {
