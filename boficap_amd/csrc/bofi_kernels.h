@@ -131,6 +131,13 @@ struct RbAttnArgs {
     uint16_t* yb; float* stats_out;           // optional, as RbFfnArgs
     int dbg;                                  // developer ablation (BOFI_RB_DBG): 1 = no attention, 2 = no output projection, 4 = no closing stores, 16 = stamps
 };
+struct RbGemmArgs {
+    const float* x; int ldx;                  // [M][512] float32 residual stream (the LayerNorm is folded into w / c / cs)
+    const rb_u32x4* wp; const float* c; const float* cs;      // fragment-major [N][512]; folded bias, column sums [N]
+    void* y; int ldy; int y_f32;              // bf16 (or float32) [M][ldy]
+    int M, N, relu;
+};
+int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st);
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st);
 int launch_rb_attn(const RbAttnArgs& a, hipStream_t st);           // -1: shape not covered
 int launch_rb_pack_frag(const void* w, void* out, int N, int K, hipStream_t st);

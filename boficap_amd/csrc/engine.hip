@@ -16,6 +16,8 @@
 #include "bofi_kernels.h"
 #include "bofi_naic.h"
 
+namespace bofi { extern int g_env_generation; }
+
 namespace {
 
 thread_local std::string g_err;
@@ -193,9 +195,9 @@ struct bofi_engine {
         ENG_OK(upload_t(&out->w, w));
         ENG_OK(upload_f32(&out->b, b));
         out->wp = nullptr;
-        if (frag && cfg.dtype == BOFI_DT_BF16 && out->N % 64 == 0 && K % 32 == 0) {      // the layout the row-block sublayer kernels stream
-            ENG_OK(dalloc((char**)&out->wp, (size_t)out->N * K, 2));
-            ENG_OK(bofi::launch_rb_pack_frag(out->w, out->wp, out->N, K, nullptr));
+        if (frag && cfg.dtype == BOFI_DT_BF16 && out->Npad % 64 == 0 && K % 32 == 0) {      // the layout the row-block kernels stream (zero rows included)
+            ENG_OK(dalloc((char**)&out->wp, (size_t)out->Npad * K, 2));
+            ENG_OK(bofi::launch_rb_pack_frag(out->w, out->wp, out->Npad, K, nullptr));
         }
         lin_recipes.push_back(LinRecipe{out, prefixes, n_each, K, fold_norm});
         return BOFI_OK;
@@ -348,7 +350,13 @@ struct bofi_engine {
     bool rb_ok() const { return cfg.dtype == BOFI_DT_BF16 && cfg.d_model == 512 && cfg.heads == 8; }
     // the row-block kernels are a fixed latency chain per workgroup (one block of rows, the sublayer's whole weight stream): they pay
     // from a few thousand rows on, where the tiled GEMMs' prologue / epilogue and the hidden tensor's round trip cost more
-    static int rb_min_rows() { static const int v = [] { const char* e = getenv("BOFI_RB_MIN_ROWS"); return e ? atoi(e) : 4096; }(); return v; }
+    // (BOFI_RB_MIN_ROWS: 0 = always, a huge value = never; re-read after bofi_reload_env.  Kernel family and launch size are then
+    // decoupled: under ONE family a row's result does not depend on what else is in the launch -- bit for bit)
+    static int rb_min_rows() {
+        static int gen = -1, v = 4096;
+        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_MIN_ROWS"); v = e ? atoi(e) : 4096; gen = bofi::g_env_generation; }
+        return v;
+    }
     int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
         static const bool on = env_on("BOFI_RB_ATTN");
         if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh || at.B * at.Lq < rb_min_rows()) return -1;
@@ -358,6 +366,18 @@ struct bofi_engine {
         a.klen_shared_last = at.klen_shared_last; a.wop = (const bofi::u32x4*)o.wp; a.bo = o.b; a.x = x; a.ldx = cfg.d_model; a.y = x; a.ldy = cfg.d_model;
         a.yb = want_copy ? (uint16_t*)xb : nullptr; a.stats_out = want_copy ? stats : nullptr;
         return bofi::launch_rb_attn(a, s);
+    }
+    // a LayerNorm-folded projection (K = d_model) of the residual stream x32 as a row-block kernel: it reads the float32 stream itself
+    // (no compute-dtype copy, no row statistics from the producer).  -1: not its configuration.
+    bool fold_rb_ok(const Lin& l, int M) const {
+        static const bool on = env_on("BOFI_RB_GEMM");
+        return on && rb_ok() && l.wp && l.cs && l.K == 512 && M >= rb_min_rows();
+    }
+    int fold_linear_rb(const float* x32, const Lin& l, void* y, int y_f32, int ldy, int M, hipStream_t s) {
+        if (!fold_rb_ok(l, M)) return -1;
+        bofi::RbGemmArgs a{};
+        a.x = x32; a.ldx = cfg.d_model; a.wp = (const bofi::u32x4*)l.wp; a.c = l.b; a.cs = l.cs; a.y = y; a.ldy = ldy; a.y_f32 = y_f32; a.M = M; a.N = l.Npad; a.relu = 0;
+        return bofi::launch_rb_gemm(a, s);
     }
     bool ffn_sublayer_ok(const Lin& w1, const Lin& w2, int M) const {
         static const bool on = env_on("BOFI_RB_FFN");
@@ -399,8 +419,11 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         ENG_OK(linear(feats, feats_dtype, cfg.feat, att_embed, x_enc, BOFI_DT_F32, d, M, o, s));
     }
     const void* xa = stream_t(x_enc, xb_enc);
+    const bool memory_out_needs_copy = false;           // (memory_out is a LayerNorm of the float32 stream itself)
     for (auto& l : enc) {
-        { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
+        {   int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
+            if (rc > 0) return rc;
+            if (rc < 0) { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
@@ -413,7 +436,9 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
             LinOpt o; o.residual = x_enc; o.ldr = d; o.stats_out = st_enc; o.y2 = copy_t(xb_enc);
             ENG_OK(linear(ctx, dt, d, l.o, x_enc, BOFI_DT_F32, d, M, o, s));
         }
-        rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, xb_enc, st_enc, M, s) : -1;
+        {   // the consumers of this layer's output: the next layer's q|k|v (or the stacked cross K|V): tiled GEMMs read the copy + statistics
+            const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;
+            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s) : -1; }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -424,7 +449,9 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
     if (memory_out) ENG_OK(bofi::launch_layernorm(x_enc, enc_norm.g, enc_norm.b, memory_out, BOFI_DT_F32, M, d, s));
     // cross-attention K|V of the bound layer and of every decoder layer in one GEMM on memory =
     // encoder.norm(x_enc), the norm folded in
-    { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, kv_all, kv, dt, kv_all.N, M, o, s)); }
+    {   int rc = fold_linear_rb(x_enc, kv_all, kv, 0, kv_all.N, M, s);
+        if (rc > 0) return rc;
+        if (rc < 0) { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, kv_all, kv, dt, kv_all.N, M, o, s)); } }
     return BOFI_OK;
 }
 
@@ -531,26 +558,33 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     const int rounds = 1 + ((flags >> BOFI_FLAG_REFINE_SHIFT) & 15);
     const void* xa = stream_t(x_fill, xb_fill);
     float* lg = seq_logprob ? seq_logprob : logits;
+    static const int gen_pad = [] { const char* v = getenv("BOFI_GEN_PAD"); return v ? atoi(v) : 1; }();      // developer knob: 0 = in place, one-tile kernel
+    const bool gen_rb = gen_pad && logits_pad && fold_rb_ok(gen, M);
     for (int round = 0; round < rounds; ++round) {
     ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                    st_fill, s));
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
-        { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); }
+        {   int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
+            if (rc > 0) return rc;
+            if (rc < 0) { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
         // syn_mask[i, :, :last-1] = True; strict mode reproduces the stale index of :1872-1873 (quirk Q1)
         a.klen = st.last; a.klen_sb = 1; a.klen_sq = 0; a.klen_bias = -1;
         a.klen_shared_last = (flags & BOFI_FLAG_STRICT_Q1) ? (q1_group > 0 ? q1_group : B) : 0;
-        int rc = attn_sublayer(a, l.o, x_fill, xb_fill, st_fill, true, s);           // (the query projection behind it is a folded GEMM)
+        const bool q_rb = fold_rb_ok(l.q_src, M);
+        int rc = attn_sublayer(a, l.o, x_fill, xb_fill, st_fill, !q_rb, s);          // (the query projection behind it is a folded GEMM)
         if (rc > 0) return rc;
         if (rc < 0) {
             ENG_OK(bofi::launch_attention(a, s));
             LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
             ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s));
         }
-        { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
+        rc = fold_linear_rb(x_fill, l.q_src, qs, 0, d, M, s);
+        if (rc > 0) return rc;
+        if (rc < 0) { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
         bofi::AttnArgs c{};
         c.q = qs; c.ldq = d;
         c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
@@ -564,7 +598,9 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
             LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
             ENG_OK(linear(ctx, dt, d, l.o_src, x_fill, BOFI_DT_F32, d, M, o, s));
         }
-        rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, xb_fill, st_fill, M, s) : -1;
+        {   // next consumer: the next layer's q|k|v or the generator
+            const bool need_copy = !(fold_rb_ok(l.qkv, M) && gen_rb);
+            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s) : -1; }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -576,12 +612,15 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     // generator.  V = 9 491 is not a whole number of 128-column tiles and its rows are not 16-byte aligned: the bf16 engine runs the GEMM
     // over the zero-padded weight rows into a buffer of pitch gen.Npad (persistent kernel, vector epilogue) and vocab_finalize reads
     // that, writing the log-probs at the caller's pitch V -- the same reads and writes as in place.
-    static const int gen_pad = [] { const char* v = getenv("BOFI_GEN_PAD"); return v ? atoi(v) : 1; }();      // developer knob: 0 = in place, one-tile kernel
     const float* lsrc = nullptr;
     if (gen_pad && logits_pad) {
-        Lin gp = gen; gp.N = gen.Npad;
-        LinOpt o; o.ln_stats = st_fill;
-        ENG_OK(linear(xa, dt, d, gp, logits_pad, BOFI_DT_F32, gen.Npad, M, o, s));
+        int rc = fold_linear_rb(x_fill, gen, logits_pad, 1, gen.Npad, M, s);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            Lin gp = gen; gp.N = gen.Npad;
+            LinOpt o; o.ln_stats = st_fill;
+            ENG_OK(linear(xa, dt, d, gp, logits_pad, BOFI_DT_F32, gen.Npad, M, o, s));
+        }
         lsrc = logits_pad;
     } else {
         LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s));
@@ -846,7 +885,7 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
         }
         a.bout = r.out->b; a.cs = r.out->cs;
         ENG_OK(bofi::launch_pack_lin(a, r.out->w, c.dtype, s));
-        if (r.out->wp) ENG_OK(bofi::launch_rb_pack_frag(r.out->w, r.out->wp, r.out->N, r.out->K, s));
+        if (r.out->wp) ENG_OK(bofi::launch_rb_pack_frag(r.out->w, r.out->wp, r.out->Npad, r.out->K, s));
     }
     for (const auto& r : e->norm_recipes) {
         const float *g = get(r.prefix + ".a_2", r.d), *b = get(r.prefix + ".b_2", r.d);
@@ -948,7 +987,7 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     for (int l = 0; l < c.n_enc; ++l) {
         auto& E = e->enc[l];
         const std::string p = S("model.encoder.layers.%d", l);
-        ENG_OK(e->make_lin(&E.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
+        ENG_OK(e->make_lin(&E.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm", 0, true));
         ENG_OK(e->make_lin(&E.o, {p + ".self_attn.linears.3"}, d, d, "", 0, true));
         ENG_OK(e->make_lin(&E.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.1.norm", 0, true));
         ENG_OK(e->make_lin(&E.w2, {p + ".feed_forward.w_2"}, d, dff, "", 0, true));
@@ -977,9 +1016,9 @@ int bofi_engine_finalize(bofi_engine_t* e) {
     for (int l = 0; l < c.n_dec; ++l) {
         auto& D = e->dec[l];
         const std::string p = S("model.decoder.layers.%d", l);
-        ENG_OK(e->make_lin(&D.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm"));
+        ENG_OK(e->make_lin(&D.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d, d, p + ".sublayer.0.norm", 0, true));
         ENG_OK(e->make_lin(&D.o, {p + ".self_attn.linears.3"}, d, d, "", 0, true));
-        ENG_OK(e->make_lin(&D.q_src, {p + ".src_attn.linears.0"}, d, d, p + ".sublayer.1.norm"));
+        ENG_OK(e->make_lin(&D.q_src, {p + ".src_attn.linears.0"}, d, d, p + ".sublayer.1.norm", 0, true));
         ENG_OK(e->make_lin(&D.o_src, {p + ".src_attn.linears.3"}, d, d, "", 0, true));
         ENG_OK(e->make_lin(&D.w1, {p + ".feed_forward.w_1"}, dff, d, p + ".sublayer.2.norm", 0, true));
         ENG_OK(e->make_lin(&D.w2, {p + ".feed_forward.w_2"}, d, dff, "", 0, true));
@@ -990,8 +1029,8 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         kvs.push_back(p + ".src_attn.linears.2");
     }
     ENG_OK(e->make_norm(&e->dec_norm, "model.decoder.norm", d));
-    ENG_OK(e->make_lin(&e->kv_all, kvs, d, d, "model.encoder.norm"));
-    ENG_OK(e->make_lin(&e->gen, {"model.generator.proj"}, c.vocab, d, "model.decoder.norm", 128));      // padded to whole 128-column tiles (the persistent GEMM)
+    ENG_OK(e->make_lin(&e->kv_all, kvs, d, d, "model.encoder.norm", 0, true));
+    ENG_OK(e->make_lin(&e->gen, {"model.generator.proj"}, c.vocab, d, "model.decoder.norm", 128, true));      // padded to whole 128-column tiles (the persistent GEMM)
     {
         const auto* ls = e->get("model.syn_embed.lut.weight", (size_t)10 * d);
         const auto* lt = e->get("model.tgt_embed.lut.weight", (size_t)c.vocab * d);

@@ -243,16 +243,182 @@ __global__ __launch_bounds__(512) void rb_ffn_kernel(RbFfnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same sublayer with the two GEMMs on different wavefronts (the default).  In rb_ffn_kernel every wavefront runs w_1, then the ReLU
+// epilogue, then w_2 of the same 512 hidden columns, two workgroup barriers per round: all eight wavefronts do their vector work at
+// the same time (the matrix pipes idle) and every weight stream pauses at every phase change (measured: 75 us per launch where the
+// 4 MB weight stream alone is ~35).  Here wavefronts 0-3 PRODUCE hidden columns (w_1, 256 per chunk, 64 each) and wavefronts 4-7 CONSUME
+// them (w_2, 128 output columns each, accumulators resident for the whole block); a SIMD holds one of each, so the producer's ReLU /
+// rounding epilogue runs beside the consumer's MFMAs, and neither stream waits for the other's phase.  The hidden chunks go through a
+// two-slot ring in LDS, handed over with two counters per slot (LDS atomics, polled with s_sleep): no workgroup barrier in the loop.
+constexpr int RB_HC = 256;                    // hidden columns per chunk
+__device__ __forceinline__ void rb_wait_ge(unsigned* flag, unsigned target) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void rb_signal(unsigned* flag, int lane) {      // behind this wavefront's LDS traffic (LDS serves a wavefront in order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;                                  // [64][512] bf16, swizzled, row pitch 1 024 B
+    unsigned char* hr = smem + 65536;                          // 2 slots x [64][256] bf16, swizzled, row pitch 512 B
+    float* c1s = reinterpret_cast<float*>(smem + 131072);      // [dff]
+    float* cs1s = c1s + a.dff;                                 // [dff]
+    float* b2s = cs1s + a.dff;                                 // [512]
+    float* s_mean = b2s + 512;                                 // [64]
+    float* s_rstd = s_mean + 64;                               // [64]
+    unsigned* flags = reinterpret_cast<unsigned*>(s_rstd + 64);      // full[2], empty[2]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 64, nch = a.dff / RB_HC;
+    const bool producer = wave < 4;
+    const int w4 = wave & 3;
+
+    // ---- the first steps of this wavefront's weight stream, then constants and the block (as rb_ffn_kernel)
+    bf16x8 wb1[RB_PF][4];                                      // producer: 4 steps x 4 fragments
+    bf16x8 wb2[2][8];                                          // consumer: 2 steps x 8 fragments
+    auto w1seg = [&](int c) { return a.w1p + (size_t)(c * 4 + w4) * (16 * 256) + lane; };       // 64-column chunk c*4 + w4 of w_1: 16 steps
+    const u32x4* w2s = a.w2p + (size_t)(2 * w4) * (a.dff >> 5) * 256 + lane;                    // 64-column chunks 2*w4, 2*w4 + 1 of w_2: step s at + s*256
+    const size_t w2j = (size_t)(a.dff >> 5) * 256;
+    if (producer) rb_prime<4>(w1seg(0), wb1);
+    else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int f = 0; f < 8; ++f) wb2[p][f] = rb_ldw(w2s + (f >> 2) * w2j + p * 256 + (f & 3) * 64);
+    }
+    for (int i = tid; i < a.dff; i += 512) { c1s[i] = a.c1[i]; cs1s[i] = a.cs1[i]; }
+    b2s[tid] = a.b2[tid];
+    if (tid < 4) flags[tid] = 0u;
+    {
+        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+        }
+        sm = oct_sum(sm); sq = oct_sum(sq);
+        if (sub == 0) {
+            const float mean = sm * (1.0f / 512.0f);
+            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+            s_mean[r] = mean;
+            s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc2[8][4];
+    if (producer) {
+        // ================= hidden chunk c: columns c*256 + w4*64 .. +63 of the block =================
+        const int lbase = rb_lane_base(l15, g);
+        float mu[4], rs[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            f32x4 acc1[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rb_segment<4, 4>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : c), wb1, smem, lbase, acc1);
+            if (c >= 2) rb_wait_ge(flags + 2 + (c & 1), 4u * (unsigned)(c >> 1));        // the consumers are through with chunk c - 2
+            unsigned char* hs = hr + (c & 1) * 32768;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int hc = c * RB_HC + w4 * 64 + nt * 16 + g * 4;
+                const float4 cc = *reinterpret_cast<const float4*>(c1s + hc);
+                const float4 cs = *reinterpret_cast<const float4*>(cs1s + hc);
+                const int ch = w4 * 8 + nt * 2 + (g >> 1);                               // 16-byte chunk of the slot's 512-byte rows
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 t = acc1[nt][mt];
+                    const float h0 = fmaxf(rs[mt] * (t[0] - mu[mt] * cs.x) + cc.x, 0.f), h1 = fmaxf(rs[mt] * (t[1] - mu[mt] * cs.y) + cc.y, 0.f);
+                    const float h2 = fmaxf(rs[mt] * (t[2] - mu[mt] * cs.z) + cc.z, 0.f), h3 = fmaxf(rs[mt] * (t[3] - mu[mt] * cs.w) + cc.w, 0.f);
+                    const int row = mt * 16 + l15;
+                    *reinterpret_cast<uint2*>(hs + row * 512 + ((ch ^ l15) << 4) + (g & 1) * 8) = make_uint2(pack_bf16(h0, h1), pack_bf16(h2, h3));
+                }
+            }
+            rb_signal(flags + (c & 1), lane);
+        }
+    } else {
+        // ================= output columns w4*128 .. +127, K = the hidden chunks as they arrive =================
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc2[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int hbase = 65536 + l15 * 512 + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4));
+        const int nsteps = nch * 8;
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            rb_wait_ge(flags + (c & 1), 4u * (unsigned)((c >> 1) + 1));                  // chunk c is in its slot
+            int hb = hbase + (c & 1) * 32768;
+            asm volatile("" : "+v"(hb));
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                bf16x8 xa[4];
+                const unsigned char* xp = smem + (hb ^ (kb << 6));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 8192);
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc2[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb2[kb & 1][f], xa[mt], acc2[f][mt], 0, 0, 0);
+                const int sn = min(c * 8 + kb + 2, nsteps - 1);                          // (the last two steps re-read the last one: never consumed)
+#pragma unroll
+                for (int f = 0; f < 8; ++f) wb2[kb & 1][f] = rb_ldw(w2s + (f >> 2) * w2j + (size_t)sn * 256 + (f & 3) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rb_signal(flags + 2 + (c & 1), lane);
+        }
+    }
+    __syncthreads();                                           // every hidden chunk consumed: x block and ring are dead
+
+    // ---- closing epilogue (as rb_ffn_kernel): the consumers stage their tiles, all eight wavefronts store whole rows
+    const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
+    const int rows_live = min(64, a.M - m0);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        float4 res[4][2];
+        rb_pass_residual<4>(out, ps * 32, m0, rows_live, wave, lane, res);
+        if (!producer) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const int col = w4 * 128 + f * 16 + g * 4;
+                const float4 bb = *reinterpret_cast<const float4*>(b2s + col);
+#pragma unroll
+                for (int tr = 0; tr < 2; ++tr) rb_stage_tile(smem, tr, l15, col, acc2[f][ps * 2 + tr], bb);
+            }
+        }
+        __syncthreads();
+        rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
+        if (ps == 0) __syncthreads();
+    }
+}
+
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
     if (a.M < 1 || a.dff < 512 || a.dff % 512 || a.dff > 2560 || !a.x || !a.w1p || !a.c1 || !a.cs1 || !a.w2p || !a.b2 || !a.y || a.ldx % 4 || a.ldy % 4)
         return BOFI_ERR_ARG;
-    const size_t lds = 131072 + (size_t)a.dff * 8 + 2048 + 512;
+    const size_t lds = 131072 + (size_t)a.dff * 8 + 2048 + 512 + 64;
+    static const int version = [] { const char* e = getenv("BOFI_RB_FFN_V"); return e ? atoi(e) : 2; }();      // developer knob: 1 = the phase-synchronous kernel
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return BOFI_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    if (version == 1) hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
     g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
@@ -515,6 +681,123 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// y[M][N] = epilogue(LN(x) . W^T) for K = 512 and any N % 64 == 0: the LayerNorm-folded projections of the path (q|k|v, the
+// cross-attention queries, the stacked cross K|V of all layers, the generator) as a row-block kernel: the 64-row block of the residual
+// stream is staged once (float32 -> bf16, row statistics on the way: no bf16 copy and no statistics from the producer), the eight
+// wavefronts take the 64-column chunks w, w + 8, ... of the weight (any chunk count), 16 k-steps each, and there is NO workgroup
+// barrier after the staging: a wavefront's epilogue (fold, bias, rounding, its own 9 KB of LDS to turn the accumulator layout into whole
+// 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs.  x may also be bf16 with no fold (plain bias).
+
+template <bool F32OUT>
+__global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
+    constexpr int SP = F32OUT ? 272 : 144;                     // staging row pitch (bytes): 64 columns + 16 B
+    constexpr int SROWS = F32OUT ? 32 : 64;                    // rows staged at a time
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;
+    unsigned char* stage_all = smem + 65536;
+    float* s_mean = reinterpret_cast<float*>(smem + 65536 + 8 * 9216);
+    float* s_rstd = s_mean + 64;
+    float* cst = s_rstd + 64;                                  // per wavefront [2][64]: c | cs of the current chunk
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 64, nchunks = a.N >> 6;
+    auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
+    bf16x8 wb[RB_PF][4];
+    if (wave < nchunks) rb_prime<4>(seg(wave), wb);
+    {   // stage the block (as rb_ffn_kernel)
+        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+        }
+        sm = oct_sum(sm); sq = oct_sum(sq);
+        if (sub == 0) {
+            const float mean = sm * (1.0f / 512.0f);
+            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+            s_mean[r] = mean;
+            s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+        }
+    }
+    __syncthreads();
+    float mu[4], rs[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
+    const int lbase = rb_lane_base(l15, g);
+    unsigned char* stage = stage_all + wave * 9216;
+    float* mycst = cst + wave * 128;
+    const int rows_live = min(64, a.M - m0);
+
+#pragma unroll 1
+    for (int ch = wave; ch < nchunks; ch += 8) {
+        // this chunk's column constants: requested now (older than the weight prefetch), parked in LDS at the epilogue
+        const float cv = a.c[ch * 64 + lane], csv = a.cs[ch * 64 + lane];
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb_segment<4, 4>(seg(ch), seg(ch + 8 < nchunks ? ch + 8 : ch), wb, smem, lbase, acc);
+        mycst[lane] = cv; mycst[64 + lane] = csv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int half = 0; half < (F32OUT ? 2 : 1); ++half) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float4 cc = *reinterpret_cast<const float4*>(mycst + nt * 16 + g * 4);
+                const float4 cs = *reinterpret_cast<const float4*>(mycst + 64 + nt * 16 + g * 4);
+#pragma unroll
+                for (int mh = 0; mh < (F32OUT ? 2 : 4); ++mh) {
+                    const int mt = F32OUT ? half * 2 + mh : mh;
+                    const f32x4 t = acc[nt][mt];
+                    float v0 = rs[mt] * (t[0] - mu[mt] * cs.x) + cc.x, v1 = rs[mt] * (t[1] - mu[mt] * cs.y) + cc.y;
+                    float v2 = rs[mt] * (t[2] - mu[mt] * cs.z) + cc.z, v3 = rs[mt] * (t[3] - mu[mt] * cs.w) + cc.w;
+                    if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    unsigned char* sp = stage + (mh * 16 + l15) * SP + (nt * 16 + g * 4) * (F32OUT ? 4 : 2);
+                    if constexpr (F32OUT) *reinterpret_cast<float4*>(sp) = make_float4(v0, v1, v2, v3);
+                    else *reinterpret_cast<uint2*>(sp) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // whole row pieces: bf16 8 lanes x 16 B = a row's 128 B (8 rows per instruction); float32 16 lanes x 16 B = 256 B (4 rows)
+            constexpr int LPR = F32OUT ? 16 : 8, RPI = 64 / LPR;
+#pragma unroll
+            for (int it = 0; it < SROWS / RPI; ++it) {
+                const int lr = it * RPI + lane / LPR, r = (F32OUT ? half * 32 : 0) + lr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stage + lr * SP + (lane % LPR) * 16);
+                if (r < rows_live)
+                    *reinterpret_cast<u32x4*>(static_cast<unsigned char*>(a.y) + ((size_t)(m0 + r) * a.ldy + ch * 64) * (F32OUT ? 4 : 2) + (lane % LPR) * 16) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
+    if (a.M < 1 || a.N < 64 || a.N % 64 || !a.x || !a.wp || !a.c || !a.cs || !a.y || a.ldx % 4 || a.ldy % 8) return BOFI_ERR_ARG;
+    const size_t lds = 65536 + 8 * 9216 + 512 + 8 * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return BOFI_ERR_HIP;
+        attr_set = true;
+    }
+    if (a.y_f32) hipLaunchKernelGGL(rb_gemm_kernel<true>, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(rb_gemm_kernel<false>, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    g_gemm_flops += 2.0 * a.M * 512.0 * a.N;
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // w [N][K] row-major bf16 -> fragment-major: [N/64 chunks][K/32 steps][4 tiles][64 lanes][8 bf16]; lane (l15, g) of a fragment holds
 // row chunk*64 + tile*16 + l15, k = step*32 + g*8 .. +7
 __global__ __launch_bounds__(256) void rb_pack_frag_kernel(const bf16_t* __restrict__ w, u32x4* __restrict__ out, int N, int K) {
@@ -554,6 +837,13 @@ extern "C" int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, c
     { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int rc = bofi::launch_rb_attn(a, (hipStream_t)stream);
     return rc < 0 ? BOFI_ERR_ARG : rc;
+}
+
+extern "C" int bofi_linear_block(const float* x, int ldx, const void* wp, const float* c, const float* cs, void* y, int ldy, int y_f32, int M, int N,
+                                 int relu, void* stream) {
+    bofi::RbGemmArgs a{};
+    a.x = x; a.ldx = ldx; a.wp = (const bofi::u32x4*)wp; a.c = c; a.cs = cs; a.y = y; a.ldy = ldy; a.y_f32 = y_f32; a.M = M; a.N = N; a.relu = relu;
+    return bofi::launch_rb_gemm(a, (hipStream_t)stream);
 }
 
 extern "C" int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,

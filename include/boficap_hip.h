@@ -396,8 +396,14 @@ int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const fl
  *   klen[bi * klen_sb + q * klen_sq] + klen_bias for query row q of image b, bi = b, or with klen_shared_last = G > 0 the last
  *   image of b's group of G (quirk Q1, TransformerModel.py:1872-1873); a row without keys is NaN as in the reference.
  *   wop = bofi_pack_frag of the [512, 512] output projection, bo float32 [512]; x, y float32 [B*Lq, 512] (y may be x); yb /
- *   stats_out as bofi_ffn_block. */
+ *   stats_out as bofi_ffn_block.
+ * bofi_linear_block: y[M, N] = act(W' LN(x) + b) for a LayerNorm-folded projection with K = 512 (the q|k|v, cross-query, stacked cross K|V
+ *   and generator projections: TransformerModel.py:1454-1456, AttModel.py:203-210 behind their pre-norms): x float32 [M, 512] -- the
+ *   row statistics are computed in the kernel --, wp = bofi_pack_frag of the folded [N, 512] weight (N % 64 == 0), c / cs its folded
+ *   bias and column sums, y bf16 or float32 (y_f32) [M, ldy], relu 0 / 1. */
 int bofi_pack_frag(const void* w, void* out, int N, int K, void* stream);
+int bofi_linear_block(const float* x, int ldx, const void* wp, const float* c, const float* cs, void* y, int ldy, int y_f32, int M, int N,
+                      int relu, void* stream);
 int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen,
                     int klen_sb, int klen_sq, int klen_bias, int klen_shared_last, const void* wop, const float* bo, const float* x,
                     int ldx, float* y, int ldy, void* yb, float* stats_out, void* stream);

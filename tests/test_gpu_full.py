@@ -581,27 +581,54 @@ def test_xe_step_with_100_regions(weight_cache, manifest, dtype):
     print("100 regions,", dtype, "worst relative gradient-norm error", worst)
 
 
-def test_five_batches_per_launch_equal_their_own_decodes(weight_cache):
+@pytest.mark.parametrize("family", ["row-block", "tiled", "by-size"])
+def test_five_batches_per_launch_equal_their_own_decodes(weight_cache, family, monkeypatch):
     """The default bench workload: 5 batches of 64 images in ONE engine call (q1_group = 64, 320 images: the bounding iteration's row
-    kernels take five 64-row blocks, the GEMMs other tiles than at 64 images) -- every batch's ids, slot layout and log-probs equal
-    its own separate decode, bf16, full size."""
+    kernels take five 64-row blocks, the GEMMs other tiles than at 64 images) against every batch's own separate decode, bf16, full size.
+    Under ONE kernel family -- the row-block sublayer kernels at every size (BOFI_RB_MIN_ROWS=0) or the tiled GEMM + attention kernels at
+    every size -- ids, slot layouts and log-probs are EQUAL: a row's result does not depend on what else is in the launch.  With the
+    default choice by launch size (row-block from 4 096 rows on) the 320-image launch and the 64-image decode run different kernels:
+    same slot layouts and ids except where a near-tie flips, log-probs within the bf16 bar on the images whose layouts agree."""
+    from boficap_amd import hip as H
     from boficap_amd import weights as W
     from boficap_amd.config import FULL as cfg
     from boficap_amd.engine import BofiEngine
-    sd = W.make_state_dict(cfg, seed=0)
-    eng = BofiEngine(cfg, torch.bfloat16, max_batch=320, max_regions=36)
-    eng.load_state_dict(sd)
-    att = torch.from_numpy(W.synthetic_att_feats(320, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16).contiguous()
-    probe = eng.decode_naic(att, q1_group=64)["phrase_num"].cpu()
-    for g0 in range(0, 320, 64):                               # no batch may end on an image without phrases (quirk Q1: NaN batch)
-        if int(probe[g0 + 63]) == 0:
-            i = g0 + int((probe[g0:g0 + 63] > 0).nonzero()[-1])
-            att[[i, g0 + 63]] = att[[g0 + 63, i]]
-    allb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_naic(att, q1_group=64, graph=True).items()}
-    assert not bool(allb["seq_logprob"].isnan().any()) and int(allb["bound_iters"]) >= 8
-    for b in range(5):
-        sl = slice(64 * b, 64 * b + 64)
-        r = eng.decode_naic(att[sl].contiguous())
-        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
-            assert torch.equal(allb[k][sl], r[k]), (b, k)
-        assert float((allb["seq_logprob"][sl] - r["seq_logprob"]).abs().max()) < 1e-3
+    if family != "by-size":
+        monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0" if family == "row-block" else "1000000000")
+    H.lib().bofi_reload_env()
+    try:
+        sd = W.make_state_dict(cfg, seed=0)
+        eng = BofiEngine(cfg, torch.bfloat16, max_batch=320, max_regions=36)
+        eng.load_state_dict(sd)
+        att = torch.from_numpy(W.synthetic_att_feats(320, 36, cfg.att_feat_size, seed=1235)).cuda().to(torch.bfloat16).contiguous()
+        probe = eng.decode_naic(att, q1_group=64)["phrase_num"].cpu()
+        for g0 in range(0, 320, 64):                               # no batch may end on an image without phrases (quirk Q1: NaN batch)
+            if int(probe[g0 + 63]) == 0:
+                i = g0 + int((probe[g0:g0 + 63] > 0).nonzero()[-1])
+                att[[i, g0 + 63]] = att[[g0 + 63, i]]
+        allb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_naic(att, q1_group=64, graph=True).items()}
+        assert not bool(allb["seq_logprob"].isnan().any()) and int(allb["bound_iters"]) >= 8
+        same_layout = checked = 0
+        for b in range(5):
+            sl = slice(64 * b, 64 * b + 64)
+            r = eng.decode_naic(att[sl].contiguous())
+            if family != "by-size":
+                for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+                    assert torch.equal(allb[k][sl], r[k]), (b, k)
+                assert float((allb["seq_logprob"][sl] - r["seq_logprob"]).abs().max()) < 1e-3
+                continue
+            # per image: the same slot layout unless a near-tie of the bound heads flips; the log-probs are compared where the image's
+            # layout AND the layout of its batch's LAST image (quirk Q1: every image's fill mask) agree
+            eq = torch.stack([(allb[k][sl] == r[k]).reshape(64, -1).all(1) for k in ("phrase_num", "phrase_length", "phrase_syn")]).all(0)
+            same_layout += int(eq.sum())
+            if bool(eq[63]) and bool(eq.any()):
+                checked += 1
+                d = (allb["seq_logprob"][sl] - r["seq_logprob"]).abs()[eq]
+                top = r["seq_logprob"][eq].max(-1).values
+                assert float(d[r["seq_logprob"][eq] > top.unsqueeze(-1) - 8.0].max()) < 2e-2      # bf16 bar (north_star) on the probable tokens
+        if family == "by-size":
+            print(f"by-size: {same_layout} of 320 images with the same slot layout, {checked} of 5 batches compared")
+            assert same_layout >= 256 and checked >= 2, (same_layout, checked)
+    finally:
+        monkeypatch.undo()
+        H.lib().bofi_reload_env()

@@ -202,3 +202,26 @@ def test_attn_block_vs_reference_sublayer(H, B, Lq, Lk, mode):
                                     H.ptr(wop), H.ptr(boc), H.ptr(xc), d, H.ptr(xc), d, None, None, H.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(xc.cpu()[rows_ok], y.cpu()[rows_ok])
+
+
+@pytest.mark.parametrize("M,N,f32out,relu", [(64, 512, False, 0), (200, 1536, False, 0), (2304, 7168, False, 0), (130, 9600, True, 0), (77, 2048, False, 1),
+                                               (5, 64, True, 1)])
+def test_linear_block_vs_reference_projection(H, M, N, f32out, relu):
+    d = 512
+    g = _rng(M + N)
+    x = torch.randn(M, d, generator=g) * 2.0 - 0.3
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w, b = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g) * 0.1
+    wf, c, cs = _fold(w, b, gain, bln)
+    w_eff = wf.double() / gain.double()[None, :]
+    ref = _layer_norm64(x, gain, bln) @ w_eff.T + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    xc, wp, cc, csc = x.cuda(), pack_frag(H, wf.to(torch.bfloat16).cuda()), c.cuda(), cs.cuda()
+    y = torch.full((M, N + 64), 7.0, dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")      # ldy > N: the pad columns stay untouched
+    H.check(H.lib().bofi_linear_block(H.ptr(xc), d, H.ptr(wp), H.ptr(cc), H.ptr(csc), H.ptr(y), N + 64, 1 if f32out else 0, M, N, relu, H.stream_ptr()))
+    torch.cuda.synchronize()
+    got = y.cpu().double()
+    assert (got[:, N:] == 7.0).all()
+    tol = 2e-2 if f32out else 6e-2                                        # bf16 operands; a bf16 result adds its own rounding at |y| ~ 4
+    assert (got[:, :N] - ref).abs().max() < tol, (got[:, :N] - ref).abs().max()

@@ -80,11 +80,27 @@ def attn(B, Lq, Lk, cross):
     print(f"attn_block B {B:4d} Lq {Lq} Lk {Lk} {'cross' if cross else 'self '}: {t:7.2f} us", flush=True)
 
 
+def gemm(M, N, f32out):
+    rot = 4
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, N, dtype=torch.float32 if f32out else torch.bfloat16, device=dev) for _ in range(rot)]
+    w = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    wp, c, cs = pack(w), torch.randn(N, device=dev), w.float().sum(1)
+
+    def run(i):
+        H.check(H.lib().bofi_linear_block(H.ptr(xs[i]), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(ys[i]), N, 1 if f32out else 0, M, N, 0, H.stream_ptr()))
+    t = timed(run, rot=rot)
+    print(f"linear_block M {M:6d} N {N:5d} {'f32 ' if f32out else 'bf16'}: {t:7.2f} us  {2.0 * M * d * N / t * 1e-6:7.1f} TFLOP/s", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
     if what == "ffn":
         for M in (11520, 6400, 2304, 1280, 64):
             ffn(M)
+    elif what == "gemm":
+        for M, N, f in ((11520, 1536, False), (6400, 1536, False), (6400, 512, False), (11520, 7168, False), (6400, 9600, True), (64, 1536, False), (64, 9600, True)):
+            gemm(M, N, f)
     else:
         for B in (320, 64, 2):
             attn(B, 36, 36, False)
