@@ -700,10 +700,12 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
     float* cst = s_rstd + 64;                                  // per wavefront [2][64]: c | cs of the current chunk
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * 64, nchunks = a.N >> 6;
+    // gridDim.y workgroups share a row block: workgroup y takes the chunk octets y, y + gridDim.y, ... (wide outputs on few row blocks:
+    // the generator's 2.4 MB of float32 logits per block leave a CU at ~25 GB/s -- two workgroups per block halve that tail)
+    const int m0 = blockIdx.x * 64, nchunks = a.N >> 6, ch0 = wave + 8 * blockIdx.y, chstep = 8 * gridDim.y;
     auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
     bf16x8 wb[RB_PF][4];
-    if (wave < nchunks) rb_prime<4>(seg(wave), wb);
+    if (ch0 < nchunks) rb_prime<4>(seg(ch0), wb);
     {   // stage the block (as rb_ffn_kernel)
         const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
         float4 v[16];
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
     const int rows_live = min(64, a.M - m0);
 
 #pragma unroll 1
-    for (int ch = wave; ch < nchunks; ch += 8) {
+    for (int ch = ch0; ch < nchunks; ch += chstep) {
         // this chunk's column constants: requested now (older than the weight prefetch), parked in LDS at the epilogue
         const float cv = a.c[ch * 64 + lane], csv = a.cs[ch * 64 + lane];
         f32x4 acc[4][4];
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb_segment<4, 4>(seg(ch), seg(ch + 8 < nchunks ? ch + 8 : ch), wb, smem, lbase, acc);
+        rb_segment<4, 4>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, smem, lbase, acc);
         mycst[lane] = cv; mycst[64 + lane] = csv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -791,8 +793,11 @@ int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
             return BOFI_ERR_HIP;
         attr_set = true;
     }
-    if (a.y_f32) hipLaunchKernelGGL(rb_gemm_kernel<true>, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(rb_gemm_kernel<false>, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    const int blocks = (a.M + 63) / 64, octets = (a.N / 64 + 7) / 8;
+    int split = 1;                                            // workgroups per row block: fill the chip when the row blocks alone do not
+    while (split < 4 && blocks * (split + 1) <= 256 && octets >= 6 * (split + 1)) ++split;
+    if (a.y_f32) hipLaunchKernelGGL(rb_gemm_kernel<true>, dim3(blocks, split), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(rb_gemm_kernel<false>, dim3(blocks, split), dim3(512), lds, st, a);
     g_gemm_flops += 2.0 * a.M * 512.0 * a.N;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
