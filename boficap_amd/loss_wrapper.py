@@ -30,14 +30,13 @@ def set_scorer(fn) -> None:
 
 
 class LanguageModelCriterion_UIC(torch.nn.Module):
-    """captioning/modules/losses.py:315-369, reduction 'mean', self_dis off: (loss, SA length, SA phrase, SA syn, NA length,
-    NA phrase, NA syn)."""
+    """captioning/modules/losses.py:315-369: (loss, SA length, SA phrase, SA syn, NA length, NA phrase, NA syn); with reduction
+    'none' the loss is one value per caption and the six parts are None, as in the reference (:357-361)."""
 
     def forward(self, sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok, phrase_num, phrase_length, phrase_syn, labels, reduction="mean", self_dis=False):
-        if reduction != "mean" or self_dis:
-            raise NotImplementedError("LanguageModelCriterion_UIC: reduction 'mean' without self-distillation is built (configs/uic_sd.yml)")
-        loss, parts = xe.criterion_uic((sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok), phrase_num, phrase_length, phrase_syn, labels)
-        return (loss, *parts)
+        loss, parts = xe.criterion_uic((sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok), phrase_num, phrase_length, phrase_syn, labels,
+                                       reduction=reduction, self_dis=self_dis)
+        return (loss, *(parts if parts is not None else [None] * 6))
 
 
 class StructureLosses(torch.nn.Module):
@@ -81,14 +80,13 @@ class LossWrapper(torch.nn.Module):
                 phrase_num=None, phrase_length=None, phrase_syn=None, extend_phrase_syn_seq=None, extend_phrase_seq=None,
                 extend_phrase_seq_mask=None, glat_p=0.3):
         opt = self.opt
-        if drop_worst_flag:
-            raise NotImplementedError("drop_worst (reduction 'none') is not built (off in configs/uic_sd.yml)")
+        reduction = "none" if drop_worst_flag else "mean"         # loss_wrapper.py:39: the caller keeps the best captions (tools/train.py:216-220)
         out = {}
         xe_args = (fc_feats, att_feats, labels, att_masks, phrase_num, phrase_length, phrase_syn, extend_phrase_syn_seq, extend_phrase_seq,
                    extend_phrase_seq_mask)
         if not struc_flag:                                        # loss_wrapper.py:231-244
             outs = self.model(*xe_args, glat_p)
-            loss, *parts = self.crit(*outs, phrase_num, phrase_length, phrase_syn, labels, self_dis=self.self_dis)
+            loss, *parts = self.crit(*outs, phrase_num, phrase_length, phrase_syn, labels, reduction=reduction, self_dis=self.self_dis)
             for k, v in zip(("SA_length_loss", "SA_phrase_loss", "SA_syn_loss", "NA_length_loss", "NA_phrase_loss", "NA_syn_loss"), parts):
                 out[k] = v
             out["loss"] = loss

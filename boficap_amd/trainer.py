@@ -257,9 +257,12 @@ class XETrainer:
             self.beta1, self.beta2, self.eps = 0.9, 0.98, 1e-9          # get_std_opt, misc.py:245-251
         else:
             self.beta1, self.beta2, self.eps = float(g("optim_alpha", 0.9)), float(g("optim_beta", 0.999)), float(g("optim_epsilon", 1e-8))
-        if g("grad_clip_mode", "value") != "value":
-            raise NotImplementedError("grad_clip_mode 'norm': the shipped configs clip by value (opts.py:98-101)")
+        self.clip_mode = g("grad_clip_mode", "value")          # opts.py:98-101; tools/train.py:225-226: torch.nn.utils.clip_grad_<mode>_
+        if self.clip_mode not in ("value", "norm"):
+            raise ValueError(f"grad_clip_mode {self.clip_mode!r}: 'value' or 'norm'")
         self.clip = float(g("grad_clip_value", 0.1))
+        self.self_dis = bool(g("self_dis", False))             # + KL(SA || NA) over the token positions (losses.py:336-339; configs uic_sd*)
+        self.drop_worst_rate = float(g("drop_worst_rate", 0.2))   # share of captions a drop_worst step leaves out (opts.py:167, train.py:216-220)
         self.bucket = FlatBucket(model)
         self.m = torch.zeros_like(self.bucket.flat)
         self.v = torch.zeros_like(self.bucket.flat)
@@ -295,10 +298,18 @@ class XETrainer:
                  "pair_start", "pair_count", "pair_src", "pair_na", "pair_labels", "pair_w_sa", "pair_w_na",
                  "prep_tok_b", "prep_syn_b", "prep_klen_b", "prep_tok2", "prep_syn2", "prep_pos2", "prep_klen2", "prep_img_start", "prep_img_count")
 
-    def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
-        """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars."""
+    def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, drop_worst: bool = False):
+        """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars.  ``drop_worst``: the loss is the mean of the
+        best (1 - drop_worst_rate) captions' own losses (criterion reduction 'none' + top-k, tools/train.py:216-220; parts are empty)."""
         if self.ops is not None and not self._capturing() and self.model.train_dtype == torch.bfloat16:
             self.ops.refresh_if_stale()
+        if drop_worst or self.self_dis or self.model.cfg.N_len != 1:
+            # these need the dense [N, S, V] log-probs of the two branches side by side (or, for a bounding network of N_len >= 2 layers,
+            # whole-sequence bound passes): the reference's own form of the step, run eagerly
+            if self.graph and not self._capturing():
+                self._fwd_calls += 1
+                self._step_word.fill_(self._fwd_calls)
+            return self._forward_backward_eager(batch, glat_p, dense="drop_worst" if drop_worst else "plain")
         if self.graph and not self._capturing():
             self._fwd_calls += 1
             self._step_word.fill_(self._fwd_calls)             # outside any graph: every step draws new dropout masks
@@ -355,7 +366,7 @@ class XETrainer:
         g.replay()
         return loss, parts
 
-    def _forward_backward_eager(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
+    def _forward_backward_eager(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, dense=None):
         from . import xe
         self.bucket.zero_grad()
         armed = self.ops is not None and self.model.train_dtype == torch.bfloat16
@@ -367,7 +378,7 @@ class XETrainer:
         if self.grouped_dw:
             xe._DEFER["list"] = []                             # weight gradients: one grouped launch after backward
         try:
-            out = self._forward_backward_armed(batch, glat_p)
+            out = self._forward_backward_armed(batch, glat_p, dense)
             xe.flush_weight_grads()
             return out
         finally:
@@ -376,7 +387,7 @@ class XETrainer:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()
 
-    def _forward_backward_armed(self, batch, glat_p):
+    def _forward_backward_armed(self, batch, glat_p, dense=None):
         from . import xe
         fc = batch.get("fc_feats")
         if fc is None:
@@ -386,8 +397,8 @@ class XETrainer:
         if batch.get("max_tokens") is not None:                # dynamic padding: decoder positions past the longest caption are skipped
             xe.HINTS["max_tokens"] = self._bucket(batch["max_tokens"], self.model.cfg.seq_length)
         compact = batch.get("token_rows") is not None and batch.get("max_tokens") is not None
-        if getattr(self.model, "ss_prob", 0.0) > 0:            # scheduled sampling: the SA branch follows the model's own layout, not the
-            compact = False                                    # loader's -- no row lists, the reference's dense criterion
+        if getattr(self.model, "ss_prob", 0.0) > 0 or dense:   # scheduled sampling: the SA branch follows the model's own layout, not the
+            compact = False                                    # loader's -- no row lists, the reference's dense criterion (as self_dis / drop_worst)
             xe.HINTS.pop("max_phrase_num", None); xe.HINTS.pop("max_tokens", None)
         if compact:                                            # project only the real tokens' rows onto the vocabulary
             xe.HINTS["token_rows"] = batch["token_rows"]
@@ -412,8 +423,14 @@ class XETrainer:
         elif compact:
             loss, parts = xe.criterion_uic_compact(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"],
                                                    batch["token_labels"], batch["token_weight"])
+        elif dense == "drop_worst":
+            per_cap, _ = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"], reduction="none",
+                                          self_dis=self.self_dis)
+            keep = int(per_cap.shape[0] * (1 - self.drop_worst_rate))
+            loss, parts = torch.topk(per_cap, k=keep, largest=False)[0].mean(), []
         else:
-            loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"])
+            loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"],
+                                           self_dis=self.self_dis)
         loss.backward()
         if self._side is not None:
             # the kernels accumulate parameter gradients themselves, so autograd sees no leaf on the side streams and does not
@@ -530,9 +547,21 @@ class XETrainer:
     def _blob_views(blob, layout):
         return {k: blob[o:o + nb].view(dt).view(shape) for k, o, nb, dt, shape in layout}
 
+    def _clip_by_norm(self, grad_scale: float) -> None:
+        """clip_grad_norm_ (tools/train.py:225-226 with grad_clip_mode 'norm') on the averaged gradient, without a host round trip: the
+        live gradients are scaled in place by min(1, clip / (||g||_2 + 1e-6)); the optimiser kernel then runs without its value clip."""
+        g = self.bucket.grad[:self.bucket.live_numel]
+        if grad_scale != 1.0:
+            g.mul_(grad_scale)
+        coef = (self.clip / (torch.linalg.vector_norm(g) + 1e-6)).clamp(max=1.0)
+        g.mul_(coef)
+
     def optimizer_step(self, grad_scale: float = 1.0) -> float:
         self._step += 1
         lr = self.rate()
+        if self.clip_mode == "norm" and self.clip != 0:
+            self._clip_by_norm(grad_scale)
+            grad_scale = 1.0
         self._adam_range(0, self.bucket.numel, lr, grad_scale)
         self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1     # the decode engine repacks on next use
         return lr
@@ -543,8 +572,9 @@ class XETrainer:
         b = self.bucket
         shadow = self.ops.shadow if self.ops is not None and self.ops._version is not None else None
         at = lambda t, es: None if t is None else C.c_void_p(t.data_ptr() + a * es)
+        clip = self.clip if self.clip_mode == "value" else 0.0          # (norm mode: the gradients were scaled before the kernel)
         hip.check(hip.lib().bofi_adam_step(at(b.flat, 4), at(b.grad, 4), at(self.m, 4), at(self.v, 4), at(shadow, 2), b_ - a, lr,
-                                           self.beta1, self.beta2, self.eps, self._step, self.clip, grad_scale, hip.stream_ptr()),
+                                           self.beta1, self.beta2, self.eps, self._step, clip, grad_scale, hip.stream_ptr()),
                   "bofi_adam_step")
 
     def reduce_and_step(self) -> float:
@@ -553,15 +583,21 @@ class XETrainer:
         (they see a zero gradient: Adam leaves them where they are, as in the reference where their .grad stays None)."""
         self._step += 1
         lr = self.rate()
-        for a, b_, scale in self.bucket.exchange(self.group, self.dp_chunks, self.dp_wire):
+        if self.clip_mode == "norm" and self.clip != 0:        # the norm is a property of the WHOLE averaged gradient: every chunk first
+            ranges = list(self.bucket.exchange(self.group, self.dp_chunks, self.dp_wire))
+            self._clip_by_norm(ranges[0][2] if ranges else 1.0)
+            ranges = [(a, b_, 1.0) for a, b_, _ in ranges]
+        else:
+            ranges = self.bucket.exchange(self.group, self.dp_chunks, self.dp_wire)
+        for a, b_, scale in ranges:
             self._adam_range(a, b_, lr, scale)
         self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1
         return lr
 
     # ------------------------------------------------------------------ the step
-    def step(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0):
+    def step(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, drop_worst: bool = False):
         """Returns (loss, parts) as device scalars of THIS rank's shard (no host sync inside)."""
-        loss, parts = self.forward_backward(batch, glat_p)
+        loss, parts = self.forward_backward(batch, glat_p, drop_worst)
         self.reduce_and_step()
         return loss, parts
 

@@ -900,6 +900,14 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
     x = _ffn(P, p + ".ff", drop, n_, xr)
     o = P.ln(x, lp + ".norm")
+    len_lp, syn_lp = _bound_heads(P, drop, o)
+    return len_lp.view(N, Pm, -1), syn_lp.view(N, Pm, -1)
+
+
+def _bound_heads(P, drop, o):
+    """Length / syntactic classifiers on the normalised [LEN] rows ``o`` [M, d] (LengthPredictor_UIC.forward TransformerModel.py:376-379)."""
+    lp = "model.length_predictor"
+    d = o.shape[1]
     # heads: hidden 100 is not a multiple of the GEMM K granule -> both first layers side by side in one padded GEMM
     # (small tensors; their gradients go through autograd's cat/slice nodes)
     w1l, w1s = P[lp + ".Length_classifier1.weight"], P[lp + ".Syntactic_classifier1.weight"]
@@ -915,6 +923,44 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     w2s_p = torch.cat([w2s.new_zeros(w2s.shape[0], hh), w2s, w2s.new_zeros(w2s.shape[0], Hp - 2 * hh)], 1)
     len_lp = log_softmax(linear(hid, w2l_p, P[lp + ".Length_classifier2.bias"]))
     syn_lp = log_softmax(linear(hid, w2s_p, P[lp + ".Syntactic_classifier2.bias"]))
+    return len_lp, syn_lp
+
+
+def bound_teacher_forced_dense(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap):
+    """The teacher-forced bound passes for a bounding network of N_len >= 2 layers (configs/uic_sd_N2.yml): the upper layers read the
+    lower layers' outputs of EVERY visible row, so a pass is the whole L-row sequence through every layer under that pass's tgt_mask
+    (LengthPredictor_UIC.forward TransformerModel.py:367-375 as called from :476-513 / :532-565), not a row-0 query.  The Pmax passes
+    of a caption run as Pmax sequences of one batch: same input rows, per-pass key counts.
+
+    tgt_mask of pass i (:478-506) as key-prefix counts: row 0 sees keys < cum[i]; row r >= 1 sees through the end of the laid-out block
+    it starts in or before -- cum[min(i, j(r))], j(r) = #{k : cum[k] <= r} -- and at least key 0 (:486)."""
+    d, H = cfg.d_model, cfg.h
+    Pm = klen_pass.shape[1]
+    dev = x_in.device
+    cum = klen_pass.long()                                     # [N, Pm]: cum[n, i] = 1 + sum of the first i phrase lengths
+    r = torch.arange(L, device=dev)
+    j = (cum.unsqueeze(2) <= r.view(1, 1, L)).sum(1)           # [N, L]
+    kstar = torch.minimum(torch.arange(Pm, device=dev).view(1, Pm, 1), j.view(N, 1, L).clamp(max=Pm - 1))
+    klen = cum.gather(1, kstar.reshape(N, Pm * L)).view(N, Pm, L)
+    klen[:, :, 0] = cum
+    klen = klen.clamp(max=L).to(torch.int32).reshape(N * Pm, L).contiguous()
+    M = N * Pm
+    x = x_in.view(N, 1, L, d).expand(N, Pm, L, d).reshape(M * L, d).contiguous()
+    cap = None if att_len_cap is None else att_len_cap.repeat_interleave(Pm).contiguous()
+    lp = "model.length_predictor"
+    for l in range(cfg.N_len):
+        p = f"{lp}.LengthPredictor.{l}"
+        xr, n_ = P.ln_res(x, p + ".sublayer.0.norm")
+        qkv = P.lin_packed(n_, p + ".self_attn", (0, 1, 2))
+        ctx = attention(qkv, qkv, 0, d, 2 * d, M, H, L, L, 1, klen, L, 1, 0, drop.attn(), None, True)
+        x = _sublayer_linear(P, drop, ctx, p + ".self_attn.linears.3", xr)
+        xr, n_ = P.ln_res(x, p + ".sublayer.1.norm")
+        x = _cross(P, p + ".src_attn", cfg, drop, n_, xr, memory, kv_cache, M, L, R, spi * Pm, cap)
+        xr, n_ = P.ln_res(x, p + ".sublayer.2.norm")
+        x = _ffn(P, p + ".ff", drop, n_, xr)
+    o_all = P.ln(x, lp + ".norm", gemm_only=False)
+    o = o_all.view(M, L, d)[:, 0, :].contiguous()
+    len_lp, syn_lp = _bound_heads(P, drop, o)
     return len_lp.view(N, Pm, -1), syn_lp.view(N, Pm, -1)
 
 
@@ -963,9 +1009,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     (sa_len [N,S+1,20], sa_syn [N,S+1,10], sa_tok [N,S,V], na_len, na_syn, na_tok).  ``P``: a ``Params``."""
     dev = att_feats.device
     S, L, d = cfg.seq_length, cfg.seq_length + 2, cfg.d_model
-    if cfg.N_len != 1:
-        raise NotImplementedError("training with N_len >= 2: the teacher-forced bound passes run as row-0 queries, which is exact for a one-layer "
-                                  "bounding network only (SURVEY.md 8a Q4); the decode engine has the dense form, the training graph does not yet")
+    dense_bound = cfg.N_len != 1         # a deeper bounding network: whole-sequence passes (bound_teacher_forced_dense), the plain form of the step
     if compute_dtype not in (torch.float32, torch.bfloat16):
         raise hip.BofiHipError(f"training compute dtype {compute_dtype}: float32 or bfloat16")
     _COMPUTE["dtype"] = compute_dtype
@@ -1012,6 +1056,12 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     streams = HINTS.pop("streams", None)
     paired = HINTS.pop("paired", None)
     pick_labels = HINTS.pop("pick_labels", None)
+    bound_fn = bound_teacher_forced
+    if dense_bound:
+        if prepared is not None:
+            klen_pass, last, Pm = bound_pass_klen(phrase_num, phrase_length, Pm)
+        prepared = token_rows = unpadded = streams = paired = pick_labels = None
+        bound_fn = bound_teacher_forced_dense
     tname, sname = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight"
     pe = P["model.pos_embed.pe"]
 
@@ -1039,8 +1089,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     # --- semi-autoregressive branch (TransformerModel.py:476-530)
     word_seq = labels.clone()
     word_seq[:, 0] = cfg.len_idx
-    sa_bound = lambda: bound_teacher_forced(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass,
-                                            att_len_cap)
+    sa_bound = lambda: bound_fn(P, cfg, drop, emb(word_seq.contiguous(), None, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
     if unpadded is not None and paired is not None:
         return _forward_paired(P, cfg, drop, emb, vocab, pad_slots, unpadded, paired, labels, word_seq, phrase_length, ext_syn, ext_seq,
                                extend_phrase_seq_mask.to(dev), last, memory, kv_cache, N, L, Sd, R, spi, att_len_cap, klen_pass, glat_p,
@@ -1059,7 +1108,7 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     sa_tok = token_logprobs(x)
 
     # --- non-autoregressive branch (:532-587)
-    na_len, na_syn = bound_teacher_forced(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
+    na_len, na_syn = bound_fn(P, cfg, drop, emb(None, ext_syn, L), memory, kv_cache, N, L, R, spi, klen_pass, att_len_cap)
     klen_na = (last - 1).unsqueeze(1).expand(N, Sd).contiguous()
     fill_in = torch.full((N, Sd), cfg.bos_idx, dtype=torch.int64, device=dev)
     if glat_p >= 0:                                            # glancing input (:437-463): reveal a share of the true tokens
@@ -1693,12 +1742,22 @@ def rl_kl_term(naic_logprobs, saic_logprobs, saic_seq):
     return torch.sum(kl * mask) / (torch.sum(mask) + 1e-6)
 
 
-def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
-    """LanguageModelCriterion_UIC.forward (captioning/modules/losses.py:319-369), reduction 'mean', self_dis off:
-    six masked NLL sums, each divided by the number of real caption tokens.  Index bookkeeping only (gathers and
-    masks on tensors of N x S elements); returns (loss, [6 parts])."""
+def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels, reduction: str = "mean", self_dis: bool = False):
+    """LanguageModelCriterion_UIC.forward (captioning/modules/losses.py:319-369): six masked NLL sums.
+
+    reduction 'mean' (:357-365): each sum divided by the number of real caption tokens of the batch; returns (loss, [6 parts]).
+    With ``self_dis`` (:336-339, 366-368; configs uic_sd*, opts.py:58) the self-distillation term is added:
+    KLDivLoss(NA token log-probs, exp(SA token log-probs).detach()) over the real token positions, summed over the vocabulary
+    and divided by the same token count -- the gradient reaches the NA branch only.
+    reduction 'none' (:357-361, drop_worst: tools/train.py:216-220): one value per caption, the caption's six sums divided by ITS
+    token count; returns (loss [N], None) as the reference does (its parts are None there, the KL term is not part of it).
+    Index bookkeeping only (gathers and masks on tensors of N x S elements) next to the dense KL when asked for."""
     sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok = outs
     dev = sa_tok.device
+    if reduction not in ("mean", "none"):
+        raise hip.BofiHipError(f"LanguageModelCriterion_UIC: reduction {reduction!r} (the reference has 'mean' and 'none')")
+    if sa_tok.dim() != 3:
+        raise hip.BofiHipError("criterion_uic takes the dense [N, S, V] token log-probs (criterion_uic_compact has the row-list form)")
     if phrase_length.dim() == 3:
         phrase_num = phrase_num.reshape(-1)
         phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
@@ -1712,11 +1771,19 @@ def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
     slot = torch.arange(phrase_length.shape[1] - 1, device=dev).unsqueeze(0)
     slot_mask = slot < phrase_num.unsqueeze(1)
     len_lab, syn_lab = phrase_length[:, 1:], phrase_syn[:, 1:]
+
+    def rows(lp, lab, mask):                                   # masked NLL per caption
+        return (-lp.gather(2, lab.unsqueeze(2)).squeeze(2) * mask).sum(1)
+
+    per_cap = [rows(sa_len, len_lab, slot_mask), rows(sa_tok, real, tok_mask), rows(sa_syn, syn_lab, slot_mask),
+               rows(na_len, len_lab, slot_mask), rows(na_tok, real, tok_mask), rows(na_syn, syn_lab, slot_mask)]
+    if reduction == "none":
+        return sum(per_cap) / tok_mask.sum(1), None
     denom = tok_mask.sum()
-
-    def nll(lp, lab, mask):
-        return (-lp.gather(2, lab.unsqueeze(2)).squeeze(2) * mask).sum() / denom
-
-    parts = [nll(sa_len, len_lab, slot_mask), nll(sa_tok, real, tok_mask), nll(sa_syn, syn_lab, slot_mask),
-             nll(na_len, len_lab, slot_mask), nll(na_tok, real, tok_mask), nll(na_syn, syn_lab, slot_mask)]
-    return sum(parts), parts
+    parts = [p.sum() / denom for p in per_cap]
+    loss = sum(parts)
+    if self_dis:
+        target_logp = sa_tok.detach()
+        kl = torch.where(target_logp > -float("inf"), target_logp.exp() * (target_logp - na_tok), torch.zeros_like(na_tok))     # xlogy: 0 where the target is 0
+        loss = loss + (kl.sum(2) * tok_mask).sum() / denom
+    return loss, parts

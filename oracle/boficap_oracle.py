@@ -590,8 +590,11 @@ def forward_uic_ss(w: Weights, cfg, att_feats, labels, att_masks, phrase_num, ph
     return (sa_len, sa_syn, sa_tok, na_len, na_syn, F.log_softmax(logit(w, na_phrase), dim=-1)), trace
 
 
-def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
-    """LanguageModelCriterion_UIC.forward losses.py:319-369, reduction='mean', self_dis=False."""
+def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels, reduction="mean", self_dis=False):
+    """LanguageModelCriterion_UIC.forward losses.py:319-369.  reduction 'mean' (:362-368) with the optional self-distillation term
+    (:336-339, 366-368: KLDivLoss(NA, exp(SA).detach()) masked to the token positions, / token count).  reduction 'none' (:357-361)
+    returns the per-caption value (six sums / the caption's token count) and None -- the reference's own 'none' branch ends in an
+    UnboundLocalError (its return statement :369 names the 'mean' branch's variables), so this branch states :358 alone."""
     sa_len, sa_syn, sa_tok, na_len, na_syn, na_tok = outs
     if phrase_length.dim() == 3:
         phrase_num = phrase_num.reshape(-1)
@@ -610,10 +613,18 @@ def criterion_uic(outs, phrase_num, phrase_length, phrase_syn, labels):
     for i in range(B):
         slot_mask[i, 0:int(phrase_num[i])] = True
     g = lambda lp, lab: -lp.gather(2, lab.unsqueeze(2)).squeeze(2) * slot_mask
+    if reduction == "none":
+        per = (sa_tok_loss.sum(1) + g(sa_len, len_lab).sum(1) + g(sa_syn, syn_lab).sum(1) + na_tok_loss.sum(1) + g(na_len, len_lab).sum(1)
+               + g(na_syn, syn_lab).sum(1)) / tok_mask.sum(1)
+        return per, None
     denom = tok_mask.sum()
     parts = [g(sa_len, len_lab).sum() / denom, sa_tok_loss.sum() / denom, g(sa_syn, syn_lab).sum() / denom,
              g(na_len, len_lab).sum() / denom, na_tok_loss.sum() / denom, g(na_syn, syn_lab).sum() / denom]
-    return sum(parts), parts
+    loss = sum(parts)
+    if self_dis:
+        kl = torch.nn.functional.kl_div(na_tok, sa_tok.exp().detach(), reduction="none") * tok_mask.unsqueeze(2)
+        loss = loss + kl.sum() / denom
+    return loss, parts
 
 
 # ----------------------------------------------------------------------------- self-critical losses (a16)

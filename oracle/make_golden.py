@@ -191,6 +191,65 @@ def run_train_case(name, cfg, sd, n_img, spi, seed, keep_numel=4096, full_output
     return dict(n_img=n_img, spi=spi, loss=float(losses[0]), no_grad=int(sum(n < 0 for n in norms)))
 
 
+def run_criterion_variants_case(name, cfg, sd, n_img, spi, seed, drop_worst_rate=0.34):
+    """The branches of LanguageModelCriterion_UIC beyond the default (losses.py:336-339, 357-361, 366-368) on one batch of the REAL
+    reference model (eval mode): self_dis=True -> loss, parts and every gradient norm from the reference itself; reduction='none' ->
+    the reference raises (its return names variables of the 'mean' branch), recorded as such, and the per-caption values +
+    the drop_worst loss of tools/train.py:216-220 come from the oracle's statement of :358 (gradients by autograd over the reference's
+    own outputs)."""
+    import contextlib
+    import io
+    from training_batch import make_training_batch
+    model = build_reference(cfg, sd)
+    batch = make_training_batch(cfg, n_img, spi, seed=seed)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    att_np = W.synthetic_att_feats(n_img, 36, cfg.att_feat_size, seed=seed + 100)
+    att, fc = torch.from_numpy(att_np), torch.zeros(n_img, 0)
+    args = (tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["extend_phrase_syn_seq"], tb["extend_phrase_seq"], tb["extend_phrase_seq_mask"])
+    crit = LanguageModelCriterion_UIC()
+    lab = (tb["phrase_num"], tb["phrase_length"], tb["phrase_syn"], tb["labels"])
+
+    def forward():
+        model.zero_grad()
+        with contextlib.redirect_stdout(io.StringIO()):
+            return model(fc, att, tb["labels"], None, *args)
+
+    def grad_norms():
+        return np.array([-1.0 if p.grad is None else float(p.grad.norm()) for _, p in model.named_parameters()], np.float32)
+
+    res = {k: v for k, v in batch.items()}
+    res["att_feats"] = att_np
+    res["grad_names"] = np.array([k for k, _ in model.named_parameters()])
+    # ---- self_dis (the reference's own branch)
+    outs = forward()
+    losses = crit(*outs, *lab, self_dis=True)
+    ol, parts = O.criterion_uic([o.detach() for o in outs], *lab, self_dis=True)
+    assert abs(float(losses[0]) - float(ol)) < 1e-5 and all(abs(float(a) - float(b)) < 1e-5 for a, b in zip(losses[1:], parts))
+    plain = crit(*[o.detach() for o in outs], *lab)[0]
+    assert float(losses[0]) > float(plain) + 1e-4, "the KL term must show"
+    losses[0].backward()
+    res["self_dis_losses"] = np.array([float(x) for x in losses], np.float32)
+    res["self_dis_grad_norms"] = grad_norms()
+    # ---- reduction 'none'
+    outs = forward()
+    try:
+        crit(*outs, *lab, reduction="none")
+        raised = ""
+    except (UnboundLocalError, NameError) as e:
+        raised = type(e).__name__
+    per, _ = O.criterion_uic(outs, *lab, reduction="none")
+    keep = int(per.shape[0] * (1 - drop_worst_rate))
+    dw = torch.topk(per, k=keep, largest=False)[0].mean()       # tools/train.py:218-219
+    dw.backward()
+    res["none_reference_raises"] = np.array(raised)
+    res["none_per_caption"] = per.detach().numpy()
+    res["drop_worst_rate"] = np.float32(drop_worst_rate)
+    res["drop_worst_loss"] = np.float32(float(dw))
+    res["drop_worst_grad_norms"] = grad_norms()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return dict(n_img=n_img, spi=spi, self_dis_loss=float(losses[0]), plain_loss=float(plain), none_reference_raises=raised, drop_worst_loss=float(dw))
+
+
 def run_glat_case(name, cfg, sd, n_img, spi, seed, glat_p):
     """XE forward with the glancing pass (TM:437-463) of the REAL reference, its torch.rand draw (TM:455) replaced by an
     injected tensor for the duration of the call; the oracle must reproduce the six outputs from the same draws."""
@@ -489,6 +548,9 @@ def main():
     print("tiny_ss", manifest["tiny_ss"])
     manifest["tiny_rl_loss"] = dict(config="TINY", **run_rl_loss_case("tiny_rl_loss", TINY, 11))
     print("tiny_rl_loss", manifest["tiny_rl_loss"])
+    manifest["tiny_criterion_variants"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
+                                               **run_criterion_variants_case("tiny_criterion_variants", TINY, sd_t, 3, 2, 13))
+    print("tiny_criterion_variants", manifest["tiny_criterion_variants"])
     manifest["tiny_loss_wrapper_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
                                             **run_loss_wrapper_xe_case("tiny_loss_wrapper_xe", TINY, sd_t, 2, 3, 9))
     print("tiny_loss_wrapper_xe", manifest["tiny_loss_wrapper_xe"])
@@ -511,6 +573,11 @@ def main():
     manifest["tiny_n2"] = dict(config="TINY_N2", seed=0, gen_scale=6.0, digest=W.digest(sd_2), B=len(pick2), iters=int(res["naic_iters"]),
                                gap=float(res["naic_gap"]), reasons=res["naic_reason"].tolist(), phrase_num=res["naic_phrase_num"].tolist())
     print("tiny_n2", manifest["tiny_n2"])
+    # ... and the XE training step through the two-layer bounding network (TransformerModel.py:367-375 under _forward :476-513, 532-565)
+    sd_2t = W.make_state_dict(TINY_N2, seed=0, gen_scale=1.0)
+    manifest["tiny_n2_train_xe"] = dict(config="TINY_N2", seed=0, gen_scale=1.0, digest=W.digest(sd_2t),
+                                        **run_train_case("tiny_n2_train_xe", TINY_N2, sd_2t, 3, 2, 5))
+    print("tiny_n2_train_xe", manifest["tiny_n2_train_xe"])
     manifest["schema_TINY_N2"] = [[k, list(s)] for k, s in W.schema(TINY_N2).items()]
     # schema as data (name, shape) for the CPU-side state_dict test
     manifest["schema_TINY"] = [[k, list(s)] for k, s in W.schema(TINY).items()]
