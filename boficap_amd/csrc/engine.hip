@@ -782,6 +782,7 @@ static int run_graphed(bofi_engine* e, const std::vector<uintptr_t>& key, hipStr
     if (ee != hipSuccess) return fail(BOFI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
     ENG_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
     if (e->graphs.size() >= 8) {                       // small cache: drop the oldest capture
+        ENG_HIP(hipDeviceSynchronize());               // (a launch of it may still be in flight on any of the caller's streams: rare path, wait it out)
         (void)hipGraphExecDestroy(e->graphs.front().exec);
         (void)hipGraphDestroy(e->graphs.front().graph);
         e->graphs.erase(e->graphs.begin());

@@ -125,3 +125,29 @@ def test_noam_rate_and_bucket_layout():
     assert torch.equal(net.weight, w0) and b.numel == 64 + 64 and net.weight.data_ptr() == b.flat.data_ptr()
     b.flat.zero_()
     assert float(net.weight.detach().abs().sum()) == 0.0                                                # the module sees the bucket
+
+
+def test_shipped_library_has_no_packed_f32_arithmetic(tmp_path):
+    """boficap_amd/build.py compiles without the SLP / loop vectorisers: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 in any kernel of
+    the shipped code objects.  Round 2 saw wrong sums from SLP-packed float32 chains in the bounding tail beside other kernels' MFMAs;
+    round 3 could not reproduce it (tools/exp/pk_fma_repro.py: 0 mismatches in 8 000 concurrent steps of the SLP build),
+    so the cause stays unestablished -- and beside MFMAs the packed forms cost issue slots anyway (MI355X_MICROARCH.md, cycle constants).
+    This pins the build so that a flag change cannot bring them back unnoticed."""
+    import glob
+    import shutil
+    import subprocess
+    from boficap_amd import hip
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(hip.LIB_PATH) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = glob.glob(str(tmp_path / "lib.so.*amdgcn*gfx950*"))
+    assert objs, "no gfx950 code object in the library"
+    packed, mfma = 0, 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        packed += sum(asm.count(op) for op in ("v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32"))
+        mfma += asm.count("v_mfma_f32_16x16x32_bf16")
+    assert mfma > 1000, mfma                                   # (the disassembly is the real thing)
+    assert packed == 0, packed

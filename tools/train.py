@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--self_critical_after", type=int, default=-1, help="iteration from which the self-critical step replaces the XE step (-1: never)")
     ap.add_argument("--train_sample_n", type=int, default=5)
     ap.add_argument("--scheduled_sampling_start", type=int, default=None, help="epoch from which ss_prob rises (opts.py:153-160; -1: never, the shipped configs)")
+    ap.add_argument("--drop_worst_after", type=int, default=None, help="epoch from which a step keeps the best (1 - drop_worst_rate) captions (opts.py:165-168, "
+                    "tools/train.py:186-189, 216-220; -1: never, the shipped configs)")
     ap.add_argument("--iters_per_epoch", type=int, default=1000, help="the synthetic stream has no epochs of its own: iterations that count as one")
     args = ap.parse_args()
 
@@ -149,15 +151,17 @@ def main():
         batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(opt.batch_size, 36, cfg.att_feat_size, seed=seed)).to(dev)
         batch = trainer.add_token_rows(batch, host_batch)
         glat_p = args.unmasked_rate_start if args.glancing_token else -1.0          # train.py:165-170
+        dw_after = args.drop_worst_after if args.drop_worst_after is not None else getattr(opt, "drop_worst_after", -1)
+        drop_worst = dw_after != -1 and epoch >= dw_after                         # train.py:186-189
         try:
-            loss, parts = trainer.step(batch, glat_p)
+            loss, parts = trainer.step(batch, glat_p, drop_worst)
         except FloatingPointError as e:                          # scheduled sampling on a model whose SA bounding step opens no phrase for
             if not model.ss_prob > 0:                            # some caption: the reference crashes there (TransformerModel.py:2103-2105);
                 raise                                            # this batch is stepped teacher-forced instead
             if rank == 0:
                 print(f"iter {it + 1}: {e}; teacher-forced step for this batch", flush=True)
             keep, model.ss_prob = model.ss_prob, 0.0
-            loss, parts = trainer.step(batch, glat_p)
+            loss, parts = trainer.step(batch, glat_p, drop_worst)
             model.ss_prob = keep
         if (it + 1) % args.losses_log_every == 0 or it == 0:
             mean_loss = dp.reduce_scalar(float(loss), "sum", device=dev) / world
