@@ -148,7 +148,7 @@ def xe_traffic(args):
     """HBM bytes per XE step from the committed PMC passes -- for the configuration they were taken on only."""
     if args.batch != 64 or args.seq_per_img != 5 or args.dtype != "bf16":
         return None
-    for name in ("r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
+    for name in ("r03_xe_hbm_traffic.json", "r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -303,6 +303,61 @@ def run_xe(args, ctx, log, cpu=True):
         log("xe: timing the CPU oracle")
         res["cpu_baseline"] = cpu_baseline_xe(cfg, sd, spi, budget_s=args.cpu_budget)
     return res
+
+
+def run_xe_dp(args, ctx, log):
+    """--gpus N > 1: BASELINE config 3 with its REAL exchange step (the decode shards with no collective, so the scaling run would never
+    exercise RCCL otherwise): XE 64 x 5 per rank, float32 ring all-reduce and the bf16 mesh-direct wire, each against the same step
+    WITHOUT the exchange (forward + backward + local optimiser): the difference is the collective time the step does not hide."""
+    from boficap_amd import dp
+    rank, local_rank, world, dev = ctx
+    import captioning.models as models
+    from boficap_amd import weights as W
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.config import FULL as cfg
+    from boficap_amd.trainer import XETrainer
+    sd = W.make_state_dict(cfg, seed=0)
+    out = {"rccl_ranks": world, "batch_per_rank": 64, "captions_per_image": 5}
+    for wire in (None, "bf16"):
+        opt = cfg.to_opt()
+        opt.seed = 42 + 1000003 * rank
+        opt.bofi_train_dtype = torch.bfloat16
+        opt.bofi_dp_wire = wire
+        model = models.setup(opt)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        model.to(dev).train()
+        tr = XETrainer(model, opt, graph=True)
+        hb = synthetic_training_batch(cfg, 64, 5, seed=100 + rank)
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in hb.items()}
+        batch["max_phrase_num"] = int(hb["phrase_num"].max())
+        batch["max_tokens"] = int((hb["phrase_length"].sum(-1) - 1).max())
+        batch["att_feats"] = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=ATT_SEED + 10 * rank)).to(dev)
+        batch["att_masks"] = None
+        batch = tr.add_token_rows(batch, hb)
+
+        def timed(fn, steps=10, warm=3):
+            for _ in range(warm):
+                fn()
+            _barrier(world)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            _barrier(world)
+            return dp.reduce_scalar((time.perf_counter() - t0) / steps * 1e3, "max", device=dev)
+
+        def local_step():
+            tr.forward_backward(batch)
+            tr.optimizer_step()
+        dp_ms = timed(lambda: tr.step(batch))
+        local_ms = timed(local_step)
+        key = "fp32_ring_all_reduce" if wire is None else "bf16_mesh_direct"
+        out[key] = {"step_ms": round(dp_ms, 3), "step_without_exchange_ms": round(local_ms, 3), "exposed_collective_ms": round(max(0.0, dp_ms - local_ms), 3),
+                    "images_per_sec": round(64 * world / dp_ms * 1e3, 1), "exchanged_bytes_per_rank": tr.bucket.live_numel * (4 if wire is None else 2),
+                    "chunks": tr.dp_chunks}
+        log(f"xe dp ({key}): {dp_ms:.2f} ms per step, {local_ms:.2f} without the exchange")
+        del tr, model
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline_rl(cfg, sd, n_img, n, budget_s=15.0):
@@ -556,18 +611,24 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                 i = int(alive[-1])
                 cand[[i, args.batch - 1]] = cand[[args.batch - 1, i]]
             atts[k] = cand.contiguous()
+    # ... and every stream alternates between TWO feature tensors (the second: the same batches in another order), so that consecutive
+    # launches of a stream do not replay one Infinity-Cache-resident input (round-2 VERDICT)
+    atts2 = [torch.cat([a_k[args.batch:], a_k[:args.batch]]).contiguous() if nb > 1 else a_k.clone() for a_k in atts]
     outs = []
-    for e, st, a_k in zip(engines, streams, atts):
+    for e, st, a_k, b_k in zip(engines, streams, atts, atts2):
         with torch.cuda.stream(st):
             outs.append(e.decode_naic(a_k, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine, q1_group=qg))
+            e.decode_naic(b_k, graph=graph, out=outs[-1], refine_rounds=args.refine, q1_group=qg)       # (captures the second input's graph)
+            e.decode_naic(a_k, graph=graph, out=outs[-1], refine_rounds=args.refine, q1_group=qg)
     torch.cuda.synchronize()
     out = outs[0]
     log("warm-up + timed steps")
 
     def step(i):
         k = i % len(engines)
+        feats = atts2[k] if (i // len(engines)) % 2 else atts[k]
         with torch.cuda.stream(streams[k]):
-            engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
+            engines[k].decode_naic(feats, graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
 
     launches = args.steps // C
     for i in range(warm_launches):
@@ -606,11 +667,11 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
     pcie_ms = None
     if args.from_host:
-        hosts = [a_k.cpu().pin_memory() for a_k in atts]
+        hosts = [(a_k.cpu().pin_memory(), b_k.cpu().pin_memory()) for a_k, b_k in zip(atts, atts2)]
         def step_h(i):
             k = i % len(engines)
             with torch.cuda.stream(streams[k]):
-                atts[k].copy_(hosts[k], non_blocking=True)
+                atts[k].copy_(hosts[k][(i // len(engines)) % 2], non_blocking=True)
                 engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
         for i in range(warm_launches):
             step_h(i)
@@ -621,7 +682,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         torch.cuda.synchronize()
         pcie_ms = (time.perf_counter() - h0) / args.steps * 1e3
     traffic, tnote = None, "no PMC pass committed for this configuration"
-    names = {1: ("r02_hbm_traffic.json", "r01_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r02_hbm_traffic_coalesce5.json",)}.get(C, ())
+    names = {1: ("r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
@@ -652,7 +713,9 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         one = flops_launch / C / (single_ms * 1e-3) / 1e12
         roof["one_at_a_time"] = {"launch_ms": round(single_ms * C, 4), "achieved": round(one, 2), "frac": round(one / MFMA_PEAK[args.dtype], 5)}
     res = {
-        "metric": "images/sec NAR bound+fill greedy decode (NAIC _sample)",
+        "metric": "images/sec NAR bound+fill greedy decode (NAIC _sample)"
+                  + (f"; dynamic batching: {C} batches of {args.batch} images per engine launch ({C * args.batch} images), " if C > 1 else f"; one batch of {args.batch} per launch, ")
+                  + f"{len(engines)} launch(es) in flight",
         "value": round(images / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -660,7 +723,8 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                                + (f", {args.refine} refinement rounds" if args.refine else ""),
                    "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
                    "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
-                   "decodes_in_flight": len(engines), "features_per_launch_in_flight": "own tensor each", "batches_per_launch": C, "refine_rounds": args.refine,
+                   "decodes_in_flight": len(engines), "features_per_launch_in_flight": "own tensors, two per stream, alternated", "batches_per_launch": C,
+                   "images_per_launch": C * args.batch, "refine_rounds": args.refine,
                    "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                    "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
                    "features_from_pinned_host_ms_per_step": round(pcie_ms, 4) if pcie_ms else None, "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
@@ -707,8 +771,9 @@ def main():
     ap.add_argument("--coalesce", type=int, default=None, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
                     "launch; quirk Q1 stays per batch (q1_group), so every step's outputs equal its own separate decode.  K steps = K/C launches.  "
                     "Default for the plain batch-64 decode: 5 or 4 (whichever divides --steps into evenly spread launches), 1 otherwise")
-    ap.add_argument("--from-host", action="store_true", help="also time the launches with the features copied from pinned host memory before each one "
-                    "(PCIe-inclusive rate, reported in config; never the headline value)")
+    ap.add_argument("--from-host", action="store_true", default=None, help="also time the launches with the features copied from pinned host memory "
+                    "before each one (PCIe-inclusive rate, reported in config; never the headline value).  Default: on for the plain headline run")
+    ap.add_argument("--no-from-host", dest="from_host", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     ap.add_argument("--no-secondary", action="store_true", help="headline measurement only (no XE / RL / refinement lines)")
@@ -718,6 +783,8 @@ def main():
         sys.exit(self_launch(sys.argv[1:], args.gpus))
     if args.batch is None:
         args.batch = 10 if args.mode == "rl" else 64
+    if args.from_host is None:
+        args.from_host = args.mode == "naic" and args.batch == 64 and not args.refine and args.coalesce is None and not args.no_secondary
     default_coalesce = args.coalesce is None
     if default_coalesce:
         args.coalesce = 1
@@ -759,10 +826,28 @@ def main():
             a = copy.copy(args); a.batch, a.refine, a.steps, a.warmup, a.coalesce = 256, 3, 40, 8, 1
             sec["refine_config5"] = _compact(run_naic(a, ctx, log, cpu, False))
             res["secondary"] = sec
+            # the driver's record keeps `config` whole: the secondary headline scalars ride there too
+            res["config"].update(one_batch_per_launch_img_s=sec["naic_one_batch_per_launch"]["value"],
+                                 xe_config3_ms_per_step=sec["xe_config3"]["ms_per_step"], xe_config3_img_s=sec["xe_config3"]["value"],
+                                 xe_config3_frac_executed=sec["xe_config3"]["roofline"].get("frac_executed"),
+                                 rl_config4_ms_per_step=sec["rl_config4"]["ms_per_step"],
+                                 refine_config5_img_s=sec["refine_config5"]["value"], refine_config5_ms_per_step=sec["refine_config5"]["ms_per_step"])
             res["secondary_note"] = ("naic_one_batch_per_launch: the headline workload with one batch of 64 per engine launch; then "
                                      "driver-run lines of BASELINE configs 3, 4, 5 (short runs in the same process, after the headline measurement); "
                                      "config 5's 'autoregressive fallback' has no counterpart: a UIC checkpoint has no AR decode path in the reference "
                                      "(TransformerModel.py:1791-1804 needs EncoderDecoder.decode, :1287-1310)")
+        if world > 1 and plain and not args.no_secondary:
+            # the decode shards with no collective: the scaling run exercises RCCL through this secondary (the XE step's gradient exchange)
+            try:
+                dp_res = run_xe_dp(args, ctx, log)
+                if rank == 0 and res is not None:
+                    res.setdefault("secondary", {})["xe_config3_dp"] = dp_res
+                    res["config"].update(xe_dp_step_ms=dp_res["fp32_ring_all_reduce"]["step_ms"], xe_dp_exposed_collective_ms=dp_res["fp32_ring_all_reduce"]["exposed_collective_ms"],
+                                         xe_dp_bf16_wire_step_ms=dp_res["bf16_mesh_direct"]["step_ms"])
+            except Exception as e:                          # never at the cost of the headline line
+                log(f"xe dp secondary failed: {type(e).__name__}: {e}")
+                if rank == 0 and res is not None:
+                    res.setdefault("secondary", {})["xe_config3_dp"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and res is not None:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -28,6 +28,24 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+def record_parity(name, measured, bar, note=""):
+    """Keep the MEASURED maximum behind a tolerance as evidence: appended to gpurun_out/parity_errors.json (merged back from the GPU
+    box by gpurun; the round's copy is committed as profiles/rNN_parity_errors.json).  A bar is meant to sit within ~2x of its
+    measurement -- the file shows whether it does."""
+    path = os.environ.get("BOFI_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity_errors.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[name] = {"measured": float(measured), "bar": float(bar), "bar_over_measured": (float(bar) / float(measured)) if measured else None, "note": note}
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 TINY_CASES = ["tiny_mix", "tiny_q1_last_shortest", "tiny_q1_last_empty_nan", "tiny_single",
               "tiny_ragged", "tiny_ragged_short", "tiny_saic_multi"]       # the last one: multi-phrase SAIC decodes (patched [LEN] row)
 

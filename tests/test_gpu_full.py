@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import boficap_oracle as O
-from conftest import load_golden
+from conftest import load_golden, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -270,6 +270,7 @@ def test_config5_batch256_refine3_bf16(config5):
     # scale -- shown there on 64 images by test_bf16_logits_within_tolerance_on_every_image and here on all 256
     gs = 4.0
     print(f"config 5 bf16: teacher-forced fill, max |dlogp| over all 256 images = {err:.3e} at generator scale {gs} (bar {2e-2 * gs:.0e})")
+    record_parity("bf16_config5_fill_teacher_forced_256_images", err, 2e-2 * gs, f"generator scale {gs}")
     assert err < 2e-2 * gs
     from boficap_amd import weights as W
     sd1 = W.make_state_dict(cfg, seed=0, gen_scale=1.0)        # natural scale: same bounding pass (the generator is not part of it)
@@ -286,12 +287,13 @@ def test_config5_batch256_refine3_bf16(config5):
 
 # ------------------------------------------------------------------------------------------------ fixtures at the full size
 def test_full_q1_shortening_and_saic_multi_fixture(weight_cache, manifest):
-    """full_b8 (its last image has ONE token: quirk Q1 cuts every image's fill mask to key 0) in float32, eager and graph, and
+    """full_b8 (captions of 0 .. 20 tokens, the LAST image a mid-length one: quirk Q1 cuts every longer image's fill mask to ITS length)
+    in float32, eager and graph, and
     the multi-phrase semi-autoregressive fixture at the full size (up to 10 phrases per image)."""
     from boficap_amd import weights as W
     from boficap_amd.engine import BofiEngine
     m, g = manifest["full_b8"], load_golden("full_b8")
-    assert m["last"][-1] == 2 and max(m["last"]) == 21
+    assert 2 < m["last"][-1] < 21 and max(m["last"]) == 21 and min(m["last"]) == 1      # a genuinely mid-length last row, truncation, an empty image
     cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
     eng = BofiEngine(cfg, torch.float32, max_batch=8, max_regions=36)
     eng.load_state_dict(sd)
@@ -351,13 +353,30 @@ def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, weight_ca
     flips = int(((free["phrase_length"].cpu() != opl).any(1) | (free["phrase_syn"].cpu() != ops).any(1)).sum())
     print(f"{config_name} bf16, all {B} images: first bound step |dlogp| len {e_len:.2e} syn {e_syn:.2e}; teacher-forced fill |dlogp| {e_fill:.2e}; "
           f"free decode: {flips}/{B} slot layouts differ from the float32 oracle's")
+    record_parity(f"bf16_fill_teacher_forced_{config_name}", e_fill, tol, "max |dlogp| over all 64 images x 20 positions x V vs the float32 oracle")
     assert e_fill < tol, e_fill
-    # the bound heads' log-probs come from the synthetic calibrated preset (oracle/calibrate_preset.py), whose output layers are
-    # rescaled until slots are produced: their log-probs span ~17 (the vocabulary log-probs of the same model span ~2), so the bar
-    # for them is relative -- 1.5 % of the span (bf16 has 8 significant bits: 0.4 % per rounding)
+    # the bound heads' log-probs: the classes that can win (lengths 0-4, 9; labels 4-6 [+ 1]) carry the decision, the other 14 + 6
+    # classes sit 9 and more below them by the preset's prior (oracle/calibrate_preset.py) and take the bulk of the span.  The bar on the
+    # LIVE classes is north_star's 2e-2 at the full size (their log-probs span ~5-7, as a trained head's do); the dead classes'
+    # error is reported and held to the same relative precision (bf16: 8 significant bits, 0.4 % per rounding).
+    live_len, live_syn = [0, 1, 2, 3, 4, 9], [1, 4, 5, 6]
+    e_len_live = float((llp.cpu() - o_llp)[:, live_len].abs().max())
+    e_syn_live = float((slp.cpu() - o_slp)[:, live_syn].abs().max())
     spread = float(o_llp.max() - o_llp.min())
-    print(f"{config_name}: bound-head log-probs span {spread:.1f}: errors are {100 * e_len / spread:.2f} % / {100 * e_syn / spread:.2f} % of it")
-    assert e_len < max(tol, 1.5e-2 * spread) and e_syn < max(tol, 1.5e-2 * spread), (e_len, e_syn, spread)
+    spread_live = float(o_llp[:, live_len].max() - o_llp[:, live_len].min())
+    print(f"{config_name}: bound-head log-probs span {spread:.1f} (live classes {spread_live:.1f}): live-class errors len {e_len_live:.2e} syn {e_syn_live:.2e}; "
+          f"all classes {100 * e_len / spread:.2f} % / {100 * e_syn / spread:.2f} % of the span")
+    # measured (profiles/r03_parity_errors.json): 0.031 / 0.034 at the full size on a live span of 6.6 -- 0.5 % of the span, bf16's
+    # precision through the chain of 13 bf16-operand GEMMs in front of the heads, amplified by the heads' output scale; the bar is 2.5x
+    # north_star's figure for vocabulary logits (whose own measured error, on a span of ~2.5, is 0.009)
+    live_bar = 2.5 * tol
+    record_parity(f"bf16_bound_heads_live_len_{config_name}", e_len_live, live_bar, f"first bounding step, live classes, span {spread_live:.1f}")
+    record_parity(f"bf16_bound_heads_live_syn_{config_name}", e_syn_live, live_bar, "first bounding step, live label classes")
+    record_parity(f"bf16_bound_heads_all_len_{config_name}", e_len, max(tol, 6e-3 * spread), f"all 20 classes, span {spread:.1f}: bar 0.6 % of the span")
+    record_parity(f"bf16_bound_heads_all_syn_{config_name}", e_syn, max(tol, 6e-3 * spread), "all 10 classes")
+    record_parity(f"bf16_free_decode_layout_flips_{config_name}", flips, 0.3 * B, f"images of {B} whose slot layout differs from the float32 oracle's")
+    assert e_len_live < live_bar and e_syn_live < live_bar, (e_len_live, e_syn_live)
+    assert e_len < max(tol, 6e-3 * spread) and e_syn < max(tol, 6e-3 * spread), (e_len, e_syn, spread)
     top = torch.topk(olp.nan_to_num(-1e30), 2, dim=2)[0]
     safe = (top[..., 0] - top[..., 1]) > 2 * tol
     assert torch.equal(seq.cpu()[safe], oseq[safe])
@@ -559,9 +578,13 @@ def test_xe_step_with_100_regions(weight_cache, manifest, dtype):
                  b["extend_phrase_syn_seq"], b["extend_phrase_seq"], b["extend_phrase_seq_mask"], -1.0)
     for i, (o, r) in enumerate(zip(outs, outs_ref)):
         # bf16: 6e-2 on the token log-probs of this small model (see test_bf16_logits_within_tolerance_on_every_image); the bound heads'
-        # log-probs span ~17 with the calibrated preset: 1.5 % of their span
-        otol = 1e-4 if dtype == torch.float32 else max(6e-2, 1.5e-2 * float(r.detach().max() - r.detach().min()))
-        assert _maxdiff(o, r) < otol, f"output {i}"
+        # log-probs (outputs 0, 1, 3, 4) span ~18 at this size: 1.2 % of their span (measured 0.9 % on the worst of them over the teacher-
+        # forced passes with 100 regions; the first decode step of the every-image test measures 0.5 %); the maxima are recorded
+        otol = 1e-4 if dtype == torch.float32 else max(6e-2, 1.2e-2 * float(r.detach().max() - r.detach().min()))
+        err = _maxdiff(o, r)
+        if dtype == torch.bfloat16:
+            record_parity(f"bf16_xe_100_regions_output{i}", err, otol, f"span {float(r.detach().max() - r.detach().min()):.1f}")
+        assert err < otol, f"output {i}"
     loss, _ = xe.criterion_uic(outs, b["phrase_num"], b["phrase_length"], b["phrase_syn"], b["labels"])
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < (1e-3 if dtype == torch.float32 else 2e-2) * abs(float(loss_ref.detach()))
     loss.backward()
@@ -579,6 +602,8 @@ def test_xe_step_with_100_regions(weight_cache, manifest, dtype):
             worst = max(worst, rel)
             assert rel < 5e-2, (n, rel)
     print("100 regions,", dtype, "worst relative gradient-norm error", worst)
+    if dtype == torch.bfloat16:
+        record_parity("bf16_xe_100_regions_worst_relative_gradient_norm_error", worst, 5e-2)
 
 
 @pytest.mark.parametrize("family", ["row-block", "tiled", "by-size"])

@@ -112,35 +112,24 @@ def test_golden_full_f32(engines, manifest):
     assert _close(top[0].numpy(), g["naic_top2_val"], 0) < 1e-3
 
 
-@pytest.mark.parametrize("config_name,tol", [("FULL", 2e-2), ("TINY", 6e-2)])
-def test_bf16_within_tolerance(config_name, tol, weight_cache):
-    """bf16 engine vs the fp32 CPU oracle, natural (Xavier) generator scale.
-
-    north_star: logits within 2e-2 for bf16.  That figure is for the reference-sized model, whose
-    logits have std 0.33; the TINY model's logits have std 1.37 (4.1x), hence its 6e-2.
-    bf16 rounding can flip a near-tie in the bounding pass, which changes that image's slot
-    layout; with the per-row fill mask (strict_q1=False / fix_q1) images are independent, so the
-    logits are compared on the images whose layout agrees and the agreement rate is bounded."""
+def test_bf16_engine_takes_float32_or_bf16_features(weight_cache):
+    """A bf16 engine converts float32 features once (engine.hip: launch_cast_bf16): the decode equals the one on features the caller
+    rounded.  (The bf16 tolerance itself is shown on EVERY image, teacher-forced, in test_gpu_full.py::
+    test_bf16_logits_within_tolerance_on_every_image -- this test used to bound it on the 70 % of images whose layouts survived.)"""
     from boficap_amd import weights as W
     from boficap_amd.engine import BofiEngine
-    cfg, sd = weight_cache(config_name, 0, 1.0)
-    w = O.as_torch(sd)
-    B = 32
-    att_np = W.synthetic_att_feats(B, 36, cfg.att_feat_size, seed=99)
-    oseq, olp, opn, opl, ops, _ = O.sample_naic(w, cfg, torch.from_numpy(att_np), fix_q1=True)
-    eng = BofiEngine(cfg, torch.bfloat16, max_batch=B, max_regions=36)
+    from boficap_amd.config import FULL as cfg
+    sd = weight_cache("FULL", 0, 1.0)[1]
+    att_np = W.synthetic_att_feats(32, 36, cfg.att_feat_size, seed=99)
+    eng = BofiEngine(cfg, torch.bfloat16, max_batch=32, max_regions=36)
     eng.load_state_dict(sd)
-    for feats in (torch.from_numpy(att_np).cuda(), torch.from_numpy(att_np).cuda().to(torch.bfloat16)):
-        r = eng.decode_naic(feats, strict_q1=False, want_memory=True)
-        torch.cuda.synchronize()
-        same = (r["phrase_length"].cpu() == opl).all(1) & (r["phrase_syn"].cpu() == ops).all(1)
-        assert int(same.sum()) >= 0.7 * B, f"only {int(same.sum())}/{B} slot layouts survive bf16"
-        lp = r["seq_logprob"].cpu()
-        assert torch.equal(lp[same].isnan(), olp[same].isnan())
-        err = float((lp[same] - olp[same]).nan_to_num().abs().max())
-        assert err < tol, err
-        agree = float((r["seq"].cpu()[same] == oseq[same]).float().mean())
-        assert agree > 0.95, agree
+    a = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.decode_naic(torch.from_numpy(att_np).cuda(), strict_q1=False).items()}
+    b = eng.decode_naic(torch.from_numpy(att_np).cuda().to(torch.bfloat16), strict_q1=False)
+    torch.cuda.synchronize()
+    for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["seq_logprob"].isnan(), b["seq_logprob"].isnan())
+    assert float((a["seq_logprob"] - b["seq_logprob"]).nan_to_num().abs().max()) == 0.0
 
 
 def test_full_batch_properties(engines, weight_cache):
@@ -251,8 +240,8 @@ def test_ragged_regions_full_config(dtype, weight_cache):
             assert torch.equal(r["phrase_length"].cpu(), opl) and torch.equal(r["phrase_syn"].cpu(), ops)
             assert float((r["seq_logprob"].cpu() - olp).nan_to_num().abs().max()) < 1e-3
         else:
-            same = (r["phrase_length"].cpu() == opl).all(1)
-            assert int(same.sum()) >= len(same) - 1
+            same = (r["phrase_length"].cpu() == opl).all(1) & (r["phrase_syn"].cpu() == ops).all(1)      # (a flipped label changes the fill input)
+            assert int(same.sum()) >= len(same) - 2                # (free decode: ~10 % of the layouts flip on a near-tie in bf16, test_gpu_full's every-image test)
             assert float((r["seq_logprob"].cpu()[same] - olp[same]).nan_to_num().abs().max()) < 2e-2
 
 

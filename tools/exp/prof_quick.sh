@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/prof
 TAG=${1:-quick}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline"
+B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline --no-from-host"
 rocprofv3 --kernel-trace --stats -d $OUT/ks1 -o ks1 -- $B --inflight 1 --steps 200 --warmup 20 > $OUT/ks1.log 2>&1 || tail -5 $OUT/ks1.log
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o tl -- $B --inflight 1 --steps 40 --warmup 10 > $OUT/tl.log 2>&1 || tail -5 $OUT/tl.log
 cd $R

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof
 TAG=${1:-r02}
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline"
+B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline --no-from-host"
 run() { name=$1; shift; rocprofv3 "$@" > $OUT/$name.log 2>&1 || { echo "rocprofv3 $name failed"; tail -5 $OUT/$name.log; }; }
 # 1. kernel statistics of the default command (5 batches per launch): steps / 5 launches per leg
 run ks4 --kernel-trace --stats -d $OUT/ks4 -o ks4 -- $B --steps 200 --warmup 20
