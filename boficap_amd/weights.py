@@ -116,6 +116,8 @@ def make_state_dict(cfg: BofiConfig, seed: int = 0, *, bound_preset: bool = True
         sd["model.generator.proj.weight"] = (sd["model.generator.proj.weight"] * np.float32(gen_scale)).astype(np.float32)
     if bound_preset:
         name = preset_name or (("full" if cfg.d_model == 512 else "tiny") + ("" if cfg.N_len == 1 else f"_n{cfg.N_len}"))
+        if name == "full" and os.environ.get("BOFI_PRESET_FULL"):      # developer knob for A/B runs: "full_r2" = round 2's bimodal preset
+            name = os.environ["BOFI_PRESET_FULL"]
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "presets",
                             f"bound_heads_{name}_seed{seed}.npz")
         if not os.path.exists(path):

@@ -6,7 +6,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
-TAG=${1:-r02}
+TAG=${1:-r03}
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline --no-from-host"
@@ -28,12 +28,12 @@ run xef --pmc FETCH_SIZE --kernel-trace -d $OUT/xef -o f -- python3 $R/bench.py 
 run xew --pmc WRITE_SIZE --kernel-trace -d $OUT/xew -o w -- python3 $R/bench.py --mode xe --steps 6 --warmup 2 --no-cpu-baseline
 cd $R
 db() { ls $OUT/$1/*.db 2>/dev/null | head -1; }
-# launches per process: in-flight leg (4 + 40) + one-at-a-time leg (4 + 40) + eager probes (1, or 3 when batches get reordered) + 4 captures; --inflight 1: 4 + 40 + probes + 1
-python tools/prof_db.py $(db ks4) 95 24 > $OUT/${TAG}_inflight4_kernel_stats.txt 2>&1
+# launches per process: in-flight leg (4 + 40) + one-at-a-time leg (4 + 40) + 1 eager probe (3 when batches get reordered) + 3 capture / warm launches per engine (two inputs per stream); --inflight 1: 4 + 40 + 1 + 3
+python tools/prof_db.py $(db ks4) 101 24 > $OUT/${TAG}_inflight4_kernel_stats.txt 2>&1
 python tools/prof_db.py $(db ks1) 48 24 > $OUT/${TAG}_one_at_a_time_kernel_stats.txt 2>&1
 python tools/prof_timeline.py $(ls $OUT/tl/*kernel_trace.csv | head -1) > $OUT/${TAG}_one_launch_timeline.txt 2>&1
 python tools/pmc_traffic.py $(db fetch) $(db write) 14 > $OUT/${TAG}_hbm_traffic_coalesce5.json 2>&1
-python tools/pmc_traffic.py $(db fetch1) $(db write1) 26 > $OUT/${TAG}_hbm_traffic.json 2>&1
+python tools/pmc_traffic.py $(db fetch1) $(db write1) 28 > $OUT/${TAG}_hbm_traffic.json 2>&1
 python tools/pmc_summary.py $(db mfma) 14 > $OUT/${TAG}_mfma_util_pmc.json 2>&1
 python tools/prof_db.py $(db xe) 14 30 > $OUT/${TAG}_xe_step_kernel_stats.txt 2>&1
 python tools/pmc_traffic.py $(db xef) $(db xew) 10 > $OUT/${TAG}_xe_hbm_traffic.json 2>&1      # 6 + 2 steps + the eager tally pass + the capture warm-up
