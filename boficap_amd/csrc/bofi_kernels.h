@@ -118,6 +118,7 @@ struct RbFfnArgs {
     float* y; int ldy;                        // residual stream out (may be x: a workgroup reads its rows before it writes them)
     uint16_t* yb; float* stats_out;           // optional: bf16 copy [M][512], partial sums [M][16][2]
     int M, dff;
+    int dbg;                                  // developer aid (BOFI_RB_DBG & 16): in-kernel stamps
 };
 struct RbAttnArgs {
     const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64

@@ -41,12 +41,12 @@ __device__ __forceinline__ int rb_off(int r, int c) { return r * 1024 + ((c ^ (r
 __device__ __forceinline__ bf16x8 rb_ldw(const u32x4* p) { return __builtin_bit_cast(bf16x8, *p); }
 
 // the first RB_PF steps of a wavefront's first segment
-template <int NT>
-__device__ __forceinline__ void rb_prime(const u32x4* seg, bf16x8 (&wb)[RB_PF][NT]) {
+template <int NT, int PF = RB_PF>
+__device__ __forceinline__ void rb_prime(const u32x4* seg, bf16x8 (&wb)[PF * NT]) {      // (flat: slot p, fragment nt at p*NT + nt)
 #pragma unroll
-    for (int p = 0; p < RB_PF; ++p)
+    for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wb[p][nt] = rb_ldw(seg + (p * 4 + nt) * 64);
+        for (int nt = 0; nt < NT; ++nt) wb[p * NT + nt] = rb_ldw(seg + (p * 4 + nt) * 64);
 }
 
 // One SEGMENT of a wavefront's weight stream: 16 k-steps (K = 512) of 4 fragments = 64 output columns; acc[nt][mt] += W-tile nt .
@@ -57,8 +57,8 @@ __device__ __forceinline__ void rb_prime(const u32x4* seg, bf16x8 (&wb)[RB_PF][N
 // the swizzle only touches bits 4..9, so a k-step costs one v_xor with an inline constant and the tile index rides in the offset field.
 __device__ __forceinline__ int rb_lane_base(int l15, int g) { return l15 * 1024 + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4)); }
 
-template <int MT, int NT = 4>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one)
-__device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, bf16x8 (&wb)[RB_PF][NT], const unsigned char* smem, int lbase,
+template <int MT, int NT = 4, int PF = RB_PF>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one); PF divides 16
+__device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, bf16x8 (&wb)[PF * NT], const unsigned char* smem, int lbase,
                                            f32x4 (&acc)[NT][MT]) {
     asm volatile("" : "+v"(lbase));                   // (keeps the sixteen k-step addresses from being hoisted out of the caller's loops and spilled)
 #pragma unroll
@@ -70,10 +70,10 @@ __device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, b
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kb % RB_PF][nt], xa[mt], acc[nt][mt], 0, 0, 0);
-        const u32x4* src = kb + RB_PF < 16 ? cur + (kb + RB_PF) * 256 : nxt + (kb + RB_PF - 16) * 256;
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(kb % PF) * NT + nt], xa[mt], acc[nt][mt], 0, 0, 0);
+        const u32x4* src = kb + PF < 16 ? cur + (kb + PF) * 256 : nxt + (kb + PF - 16) * 256;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wb[kb % RB_PF][nt] = rb_ldw(src + nt * 64);
+        for (int nt = 0; nt < NT; ++nt) wb[(kb % PF) * NT + nt] = rb_ldw(src + nt * 64);
         __builtin_amdgcn_sched_barrier(0);            // the scheduler would sink the loads next to their use: the prefetch distance is the point
     }
 }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void rb_ffn_kernel(RbFfnArgs a) {
     const int m0 = blockIdx.x * 64, rounds = a.dff >> 9, lbase = rb_lane_base(l15, g);
     auto w1seg = [&](int r) { return a.w1p + (size_t)(r * 8 + wave) * (16 * 256) + lane; };
     auto w2seg = [&](int r) { return a.w2p + ((size_t)wave * (a.dff >> 5) + r * 16) * 256 + lane; };
-    bf16x8 wb[RB_PF][4];
+    bf16x8 wb[RB_PF * 4];
     rb_prime<4>(w1seg(0), wb);
 
     // ---- per-column constants
@@ -276,35 +276,40 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
     const int m0 = blockIdx.x * 64, nch = a.dff / RB_HC;
     const bool producer = wave < 4;
     const int w4 = wave & 3;
+    if ((a.dbg & 16) && blockIdx.x == 0 && lane == 0) g_rb_stamps[wave * 16 + 15] = __builtin_amdgcn_s_memtime();      // entry
 
     // ---- the first steps of this wavefront's weight stream, then constants and the block (as rb_ffn_kernel)
-    bf16x8 wb1[RB_PF][4];                                      // producer: 4 steps x 4 fragments
-    bf16x8 wb2[2][8];                                          // consumer: 2 steps x 8 fragments
+    constexpr int PPF = 4;                                     // producer: 4 steps x 4 fragments in flight (8 measured SLOWER: 66 against 53 us per workgroup)
+    bf16x8 wbuf[PPF * 4];                                      // ONE ring for both roles (two arrays would both be live across the shared staging code);
+                                                               // the consumer uses its first 16 entries as 2 steps x 8 fragments
     auto w1seg = [&](int c) { return a.w1p + (size_t)(c * 4 + w4) * (16 * 256) + lane; };       // 64-column chunk c*4 + w4 of w_1: 16 steps
     const u32x4* w2s = a.w2p + (size_t)(2 * w4) * (a.dff >> 5) * 256 + lane;                    // 64-column chunks 2*w4, 2*w4 + 1 of w_2: step s at + s*256
     const size_t w2j = (size_t)(a.dff >> 5) * 256;
-    if (producer) rb_prime<4>(w1seg(0), wb1);
+    if (producer) rb_prime<4, PPF>(w1seg(0), wbuf);
     else {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int f = 0; f < 8; ++f) wb2[p][f] = rb_ldw(w2s + (f >> 2) * w2j + p * 256 + (f & 3) * 64);
+            for (int f = 0; f < 8; ++f) wbuf[p * 8 + f] = rb_ldw(w2s + (f >> 2) * w2j + p * 256 + (f & 3) * 64);
     }
     for (int i = tid; i < a.dff; i += 512) { c1s[i] = a.c1[i]; cs1s[i] = a.cs1[i]; }
     b2s[tid] = a.b2[tid];
     if (tid < 4) flags[tid] = 0u;
     {
         const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
-        float4 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float sm = 0.f, sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+        for (int half = 0; half < 2; ++half) {                  // (two batches of eight loads: the weight ring already holds 128 registers)
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + (half * 8 + j) * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+                sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+                *reinterpret_cast<uint2*>(xt + rb_off(r, (half * 8 + j) * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+            }
         }
         sm = oct_sum(sm); sq = oct_sum(sq);
         if (sub == 0) {
@@ -330,7 +335,8 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rb_segment<4, 4>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : c), wb1, smem, lbase, acc1);
+            rb_segment<4, 4, PPF>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : c), wbuf, smem, lbase, acc1);
+            RB_STAMP(a.dbg, wave, lane, 2 * c);
             if (c >= 2) rb_wait_ge(flags + 2 + (c & 1), 4u * (unsigned)(c >> 1));        // the consumers are through with chunk c - 2
             unsigned char* hs = hr + (c & 1) * 32768;
 #pragma unroll
@@ -349,6 +355,7 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
                 }
             }
             rb_signal(flags + (c & 1), lane);
+            RB_STAMP(a.dbg, wave, lane, 2 * c + 1);
         }
     } else {
         // ================= output columns w4*128 .. +127, K = the hidden chunks as they arrive =================
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             rb_wait_ge(flags + (c & 1), 4u * (unsigned)((c >> 1) + 1));                  // chunk c is in its slot
+            RB_STAMP(a.dbg, wave, lane, 2 * c);
             int hb = hbase + (c & 1) * 32768;
             asm volatile("" : "+v"(hb));
 #pragma unroll
@@ -372,13 +380,14 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
 #pragma unroll
                 for (int f = 0; f < 8; ++f)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc2[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb2[kb & 1][f], xa[mt], acc2[f][mt], 0, 0, 0);
+                    for (int mt = 0; mt < 4; ++mt) acc2[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[(kb & 1) * 8 + f], xa[mt], acc2[f][mt], 0, 0, 0);
                 const int sn = min(c * 8 + kb + 2, nsteps - 1);                          // (the last two steps re-read the last one: never consumed)
 #pragma unroll
-                for (int f = 0; f < 8; ++f) wb2[kb & 1][f] = rb_ldw(w2s + (f >> 2) * w2j + (size_t)sn * 256 + (f & 3) * 64);
+                for (int f = 0; f < 8; ++f) wbuf[(kb & 1) * 8 + f] = rb_ldw(w2s + (f >> 2) * w2j + (size_t)sn * 256 + (f & 3) * 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
             rb_signal(flags + 2 + (c & 1), lane);
+            RB_STAMP(a.dbg, wave, lane, 2 * c + 1);
         }
     }
     __syncthreads();                                           // every hidden chunk consumed: x block and ring are dead
@@ -417,8 +426,10 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
             return BOFI_ERR_HIP;
         attr_set = true;
     }
-    if (version == 1) hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, a);
+    RbFfnArgs b = a;
+    { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
+    if (version == 1) hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    else hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
     g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(1024) void rb_attn_kernel(RbAttnArgs a) {
     // the output projection's weights: columns wave*32 .. +31 = tiles (wave & 1)*2, +1 of chunk wave >> 1
     const u32x4* wo = a.wop + (size_t)(wave >> 1) * (16 * 256) + (wave & 1) * 128 + lane;
     RB_STAMP(a.dbg, wave, lane, 2);
-    bf16x8 wb[RB_PF][2];
+    bf16x8 wb[RB_PF * 2];
     rb_prime<2>(wo, wb);
     __syncthreads();                                                        // every V tile is dead: the block may overwrite them
     RB_STAMP(a.dbg, wave, lane, 3);
@@ -704,7 +715,7 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
     // the generator's 2.4 MB of float32 logits per block leave a CU at ~25 GB/s -- two workgroups per block halve that tail)
     const int m0 = blockIdx.x * 64, nchunks = a.N >> 6, ch0 = wave + 8 * blockIdx.y, chstep = 8 * gridDim.y;
     auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
-    bf16x8 wb[RB_PF][4];
+    bf16x8 wb[RB_PF * 4];
     if (ch0 < nchunks) rb_prime<4>(seg(ch0), wb);
     {   // stage the block (as rb_ffn_kernel)
         const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
