@@ -97,6 +97,28 @@ class FlatBucket:
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / dist.get_world_size(group)
 
+    def encoder_end(self) -> int:
+        """Offset behind the last parameter of att_embed + encoder (they open the bucket): gradients in [encoder_end, live_numel) are final
+        once the backward has passed the encoder's output."""
+        k = 0
+        while k < len(self.names) and self.names[k].startswith(("att_embed.", "model.encoder.")):
+            k += 1
+        return self.offsets[k] if k < len(self.offsets) else self.numel
+
+    def exchange_range(self, a: int, b: int, group=None, chunks: int = 2):
+        """Start the float32 sum all-reduce of gradient elements [a, b) as ``chunks`` asynchronous collectives (last part first);
+        returns [(start, end, work)] -- wait on a work before touching its range.  World size 1: []."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or b <= a:
+            return []
+        gran = 4096
+        per = ((b - a + max(1, chunks) - 1) // max(1, chunks) + gran - 1) // gran * gran
+        cuts, o = [], a
+        while o < b:
+            cuts.append((o, min(o + per, b)))
+            o += per
+        return [(x, y, dist.all_reduce(self.grad[x:y], op=dist.ReduceOp.SUM, group=group, async_op=True)) for x, y in cuts[::-1]]
+
     def chunk_bounds(self, chunks: int):
         """The live prefix cut into ``chunks`` near-equal pieces on 16 KiB boundaries: [(start, end)], in bucket order."""
         chunks = max(1, int(chunks))
@@ -270,6 +292,9 @@ class XETrainer:
         self.rl_kl = bool(g("rl_kl", False))                   # self-critical step: + KL(SAIC || NAIC) over the SAIC captions' tokens (loss_wrapper.py:216-222)
         self.dp_chunks = int(g("bofi_dp_chunks", 4))           # collectives per step over the live gradient prefix
         self.dp_wire = g("bofi_dp_wire", None)                 # None: float32 all-reduce; 'bf16': mesh-direct bf16 exchange, fp32 accumulation
+        # data-parallel: backward in two stages around the encoder's output; the decoder-side gradients (2/3 of the bucket) go on the wire
+        # while the encoder's backward runs (float32 wire, value clipping; see step())
+        self.dp_overlap = bool(g("bofi_dp_overlap", True))
         self.graph = bool(graph)
         self.unpadded = bool(unpadded)                         # add_token_rows: run the decoder over the captions' real positions only
         # bf16 mode: weight operands of the GEMMs come from a bf16 copy of the bucket the optimiser kernel maintains
@@ -298,7 +323,12 @@ class XETrainer:
                  "pair_start", "pair_count", "pair_src", "pair_na", "pair_labels", "pair_w_sa", "pair_w_na",
                  "prep_tok_b", "prep_syn_b", "prep_klen_b", "prep_tok2", "prep_syn2", "prep_pos2", "prep_klen2", "prep_img_start", "prep_img_count")
 
-    def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, drop_worst: bool = False):
+    def _overlap_on(self) -> bool:
+        import torch.distributed as dist
+        return (self.dp_overlap and self.dp_wire is None and self.clip_mode == "value" and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size(self.group) > 1 and self.model.cfg.N_len == 1 and not getattr(self.model, "ss_prob", 0.0) > 0)
+
+    def forward_backward(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, drop_worst: bool = False, between=None):
         """zero-grad, forward, criterion, backward.  Returns (loss, parts) as device scalars.  ``drop_worst``: the loss is the mean of the
         best (1 - drop_worst_rate) captions' own losses (criterion reduction 'none' + top-k, tools/train.py:216-220; parts are empty)."""
         if self.ops is not None and not self._capturing() and self.model.train_dtype == torch.bfloat16:
@@ -315,8 +345,8 @@ class XETrainer:
             self._step_word.fill_(self._fwd_calls)             # outside any graph: every step draws new dropout masks
             # (scheduled sampling decides on the host between its iterations: it cannot live in a captured graph)
             if batch.get("att_masks") is None and batch.get("max_phrase_num") is not None and not getattr(self.model, "ss_prob", 0.0) > 0:
-                return self._replay(batch, glat_p)
-        return self._forward_backward_eager(batch, glat_p)
+                return self._replay(batch, glat_p, between)
+        return self._forward_backward_eager(batch, glat_p, between=between)
 
     @staticmethod
     def _bucket(v, cap: int, step: int = 4) -> int:
@@ -328,16 +358,16 @@ class XETrainer:
     def _capturing() -> bool:
         return torch.cuda.is_current_stream_capturing()
 
-    def _replay(self, batch, glat_p):
+    def _replay(self, batch, glat_p, between=None):
         S = self.model.cfg.seq_length
         key = (tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._KEYS), self._bucket(batch["max_phrase_num"], S + 1),
                self._bucket(batch["max_tokens"], S) if batch.get("max_tokens") else 0, round(float(glat_p), 6),
-               self.model.training, self.model.train_dtype)
+               self.model.training, self.model.train_dtype, between is not None)
         opt_keys = [k for k in self._OPT_KEYS if batch.get(k) is not None]
         key = key + tuple((k, tuple(batch[k].shape)) for k in opt_keys)
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
-            return self._forward_backward_eager(batch, glat_p)     # every capture pins its activations' pool: bound their number
+            return self._forward_backward_eager(batch, glat_p, between=between)     # every capture pins its activations' pool: bound their number
         layout = batch.get("_blob_layout")
         if entry is None:
             static = {}
@@ -351,10 +381,21 @@ class XETrainer:
             self._forward_backward_eager(static, glat_p)        # warm-up outside the capture (lazy initialisations, allocator)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                loss, parts = self._forward_backward_eager(static, glat_p)
-            entry = self._graphs[key] = (g, static, loss, parts)
-        g, static, loss, parts = entry
+            g2 = None
+            if between is None:
+                with torch.cuda.graph(g):
+                    loss, parts = self._forward_backward_eager(static, glat_p)
+            else:
+                # two graphs around the encoder's output: [zero-grad, forward, criterion, backward down to it, decoder-side weight
+                # gradients] and [the encoder's backward, its weight gradients]; the caller's `between` runs between their replays
+                stage2 = {}
+                with torch.cuda.graph(g):
+                    loss, parts = self._forward_backward_eager(static, glat_p, between=stage2)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    self._backward_stage2(stage2)
+            entry = self._graphs[key] = (g, static, loss, parts, g2)
+        g, static, loss, parts, g2 = entry
         in_blob = ()
         if layout is not None and os.environ.get("BOFI_XE_BLOB", "1") != "0" and static.get("_blob_layout") == layout and static["_blob"].data_ptr() != batch["_blob"].data_ptr() \
                 and all(batch[k].data_ptr() == batch["_blob"].data_ptr() + o for k, o, _, _, _ in layout):
@@ -364,9 +405,31 @@ class XETrainer:
         if pairs:                                              # one multi-tensor copy instead of ~20 small launches
             torch._foreach_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs], non_blocking=True)
         g.replay()
+        if g2 is not None:
+            between()
+            g2.replay()
         return loss, parts
 
-    def _forward_backward_eager(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, dense=None):
+    def _backward_stage2(self, stage2) -> None:
+        """The encoder's part of the backward (see xe.forward_uic, split_memory) and its weight gradients."""
+        from . import xe
+        armed = self.ops is not None and self.model.train_dtype == torch.bfloat16
+        if armed:
+            xe._WEIGHTS["provider"] = self.ops
+        if self.grouped_dw:
+            xe._DEFER["list"] = []
+        try:
+            torch.autograd.backward(stage2["memory"], stage2["memory_detached"].grad)
+            xe.flush_weight_grads()
+        finally:
+            xe._DEFER["list"] = None
+            if armed:
+                xe._WEIGHTS["provider"] = None
+        stage2.clear()
+
+    def _forward_backward_eager(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, dense=None, between=None):
+        """``between``: None = one backward; a callable = two-stage backward with ``between()`` called after the decoder-side gradients
+        are final (eager mode); a dict = stage 1 only, the split tensors are left in it (the captured form: _replay runs stage 2)."""
         from . import xe
         self.bucket.zero_grad()
         armed = self.ops is not None and self.model.train_dtype == torch.bfloat16
@@ -378,8 +441,17 @@ class XETrainer:
         if self.grouped_dw:
             xe._DEFER["list"] = []                             # weight gradients: one grouped launch after backward
         try:
-            out = self._forward_backward_armed(batch, glat_p, dense)
+            stage2 = between if isinstance(between, dict) else ({} if between is not None and dense is None else None)
+            out = self._forward_backward_armed(batch, glat_p, dense, stage2)
             xe.flush_weight_grads()
+            if stage2 is not None and not isinstance(between, dict):
+                between()
+                if armed:
+                    xe._WEIGHTS["provider"] = None
+                xe._DEFER["list"] = None
+                self._backward_stage2(stage2)
+            elif between is not None and not isinstance(between, dict):
+                between()                                      # (a dense step has no split: the whole gradient is final here)
             return out
         finally:
             xe._DEFER["list"] = None
@@ -387,8 +459,10 @@ class XETrainer:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()
 
-    def _forward_backward_armed(self, batch, glat_p, dense=None):
+    def _forward_backward_armed(self, batch, glat_p, dense=None, stage2=None):
         from . import xe
+        if stage2 is not None:
+            xe.HINTS["split_memory"] = stage2
         fc = batch.get("fc_feats")
         if fc is None:
             fc = torch.zeros(batch["att_feats"].shape[0], 0, device=batch["att_feats"].device)
@@ -594,9 +668,35 @@ class XETrainer:
         self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1
         return lr
 
+    def _step_overlapped(self, batch, glat_p):
+        """The data-parallel step with the exchange started INSIDE the backward: once the backward has passed the encoder's output the
+        gradients of everything behind it (decoder, generator, embeddings, bounding network: the bucket from encoder_end() on) are
+        final and go on the wire as asynchronous all-reduces, while the encoder's backward runs; the encoder's third follows, and
+        the optimiser runs per chunk as it arrives.  Same gradients and parameters as the plain step (tests/test_gpu_dp.py)."""
+        import torch.distributed as dist
+        b = self.bucket
+        cut, late = b.encoder_end(), []
+        world = dist.get_world_size(self.group)
+
+        def between():
+            late.extend(b.exchange_range(cut, b.live_numel, self.group, max(1, self.dp_chunks - 1)))
+        loss, parts = self.forward_backward(batch, glat_p, between=between)
+        if not late:                                           # (a path without the split, e.g. no graph for this signature and a dense step)
+            between()
+        early = b.exchange_range(0, cut, self.group, 1)
+        self._step += 1
+        lr = self.rate()
+        for x, y, work in late + early:
+            work.wait()
+            self._adam_range(x, y, lr, 1.0 / world)
+        self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1
+        return loss, parts
+
     # ------------------------------------------------------------------ the step
     def step(self, batch: Dict[str, torch.Tensor], glat_p: float = -1.0, drop_worst: bool = False):
         """Returns (loss, parts) as device scalars of THIS rank's shard (no host sync inside)."""
+        if self._overlap_on() and not drop_worst and not self.self_dis:
+            return self._step_overlapped(batch, glat_p)
         loss, parts = self.forward_backward(batch, glat_p, drop_worst)
         self.reduce_and_step()
         return loss, parts

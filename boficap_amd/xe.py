@@ -1035,6 +1035,17 @@ def forward_uic(P, cfg, att_feats, labels, att_masks, phrase_num, phrase_length,
     spi = N // B
     drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None, step_word)
     memory = encode_memory(P, cfg, att_feats, att_len, drop)
+    split = HINTS.pop("split_memory", None)
+    if split is not None:
+        # two-stage backward (XETrainer, data-parallel): everything behind the encoder hangs off a DETACHED copy of its output, so that
+        # loss.backward() stops there with every decoder-side gradient final -- their exchange starts while the encoder's backward
+        # (memory.backward(memory_detached.grad)) still runs
+        sh = _shadow(memory)
+        split["memory"] = memory
+        memory = memory.detach().requires_grad_(True)
+        if sh is not None:
+            _register_shadow(memory, sh)
+        split["memory_detached"] = memory
     att_len_cap = None if att_len is None else att_len.repeat_interleave(spi).contiguous()
     kv_cache: dict = {}
 

@@ -172,3 +172,59 @@ def test_chunked_and_bf16_exchange_equal_the_flat_all_reduce():
         assert tiled and untouched and agree and reversed_order, (chunks, wire)
         assert n <= chunks
         assert err == 0.0 if wire is None else err < 2e-2 * scale, (chunks, wire, err)
+
+
+def _two_phase_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import captioning.models as models
+    from boficap_amd import dp
+    from boficap_amd.config import TINY
+    from boficap_amd.trainer import FlatBucket
+    torch.set_num_threads(1)
+    dp.init_from_env("gloo")
+    torch.manual_seed(0)
+    bucket = FlatBucket(models.setup(TINY.to_opt()))
+    enc, live = bucket.encoder_end(), bucket.live_numel
+    k = bucket.offsets.index(enc)
+    boundary_ok = (all(n.startswith(("att_embed.", "model.encoder.")) for n in bucket.names[:k])
+                   and not any(n.startswith(("att_embed.", "model.encoder.")) for n in bucket.names[k:]) and 0 < enc < live)
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.zeros(bucket.numel)
+    local[:live] = torch.randn(live, generator=g)
+    bucket.grad.copy_(local)
+    bucket.all_reduce()
+    want = bucket.grad.clone()
+    # the overlapped step's order: the decoder side [enc, live) goes on the wire while the encoder's gradients are still being written ...
+    bucket.grad.copy_(local)
+    bucket.grad[:enc] = float("nan")                                      # ... so nothing of [0, enc) may be read by the first phase
+    late = bucket.exchange_range(enc, live, None, 3)
+    bucket.grad[:enc] = local[:enc]                                       # "the second stage of the backward" fills them in
+    early = bucket.exchange_range(0, enc, None, 2)
+    spans = []
+    for a, b, w in late + early:
+        w.wait()
+        spans.append((a, b))
+    cov = sorted(spans)
+    tiled = cov[0][0] == 0 and cov[-1][1] == live and all(cov[i][1] == cov[i + 1][0] for i in range(len(cov) - 1))
+    if rank == 0:
+        ret.put((boundary_ok, tiled, bool(torch.equal(bucket.grad, want)), len(late), len(early), bucket.exchange_range(5, 5) == []))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_exchange_in_two_phases_around_the_encoder_boundary_equals_the_flat_all_reduce():
+    """The exchange started inside backward (XETrainer._step_overlapped): [encoder_end, live) first, [0, encoder_end) after the second
+    stage, each as its own asynchronous collectives, on the UIC model's own parameter bucket -- bit-equal to the flat all-reduce."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_two_phase_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    boundary_ok, tiled, equal, n_late, n_early, empty = ret.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert boundary_ok and tiled and equal and empty
+    assert 1 <= n_late <= 3 and 1 <= n_early <= 2
