@@ -179,19 +179,23 @@ int launch_bound_qattn(const BoundQAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// y = epilogue(x . W^T) for a few rows (the bounding loop: one row per image); one workgroup per 16 output columns, K slice of 512
+// y = epilogue(x . W^T) for a few rows (the bounding loop: one row per image); one workgroup per NT * 16 output columns, K slice of 512
 // (blockIdx.y) and block of 64 rows (blockIdx.z), its four wavefronts take 128 k each.
+// NT: the chip starts about one workgroup per 8 ns (tools/exp/mb_rowgemm.py: 4.8 us up to 256 workgroups, 7.1 at 320, 9.7 at 640, 14.8 at
+// 1 280), so a launch of these latency-bound kernels wants at most one workgroup per CU: the launcher picks the narrowest tile that gets there.
+template <int NT>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
-    __shared__ float4 red[4][4][64];          // [k quarter][16-row group][lane]
+    extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];
+    float4 (*red)[4][NT][64] = reinterpret_cast<float4 (*)[4][NT][64]>(rg_smem);          // [k quarter][16-row group][column tile][lane]
     if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, ks = blockIdx.y, mbase = blockIdx.z * 64;
+    const int n0 = blockIdx.x * 16 * NT, ks = blockIdx.y, mbase = blockIdx.z * 64;
     const int M = a.m_dev ? min(a.M, *a.m_dev) : a.M;        // row list: the count lives on the device (a.M sized the grid)
     if (mbase >= M) return;
     const int ng = min(4, (M - mbase + 15) >> 4);
     auto mem_row = [&](int m) { m = min(m, M - 1); return a.row_idx ? a.row_idx[m] : m; };     // GEMM row -> row of x / y / residual / statistics
 
-    // epilogue operands of the row group this wavefront finalises (wave = group): row m, columns n .. n + 3
+    // epilogue operands of the row group this wavefront finalises (wave = group): row m, columns n .. n + 3 of every column tile
     const int m = mbase + wave * 16 + r, n = n0 + q * 4;
     const bool mine = wave < ng, rowok = m < M;
     const int mr = mem_row(m);
@@ -199,18 +203,20 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) xrow[g] = mem_row(mbase + g * 16 + r);
 
-    f32x4 acc[4];
+    f32x4 acc[4][NT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mean = 0.f, rstd = 1.f;
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), bv = cs, rv = cs;
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[g][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 sv[16];                             // the row's partial (sum, sum of squares) pairs, two per float4 (stats_groups <= 32)
     for (int c = 0; c < a.kchunks; ++c) {
         const int kq = (ks * a.kchunks + c) * 512 + wave * 128 + q * 8;
-        bf16x8 fw[4], fx[4][4];
-        {
-            const bf16_t* wp = a.w + (size_t)(n0 + r) * a.K + kq;
+        bf16x8 fw[NT][4], fx[4][4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) fw[s] = ld_frag(wp + s * 32);
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16_t* wp = a.w + (size_t)(n0 + nt * 16 + r) * a.K + kq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fw[nt][s] = ld_frag(wp + s * 32);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -219,48 +225,81 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) fx[g][s] = ld_frag(xp + s * 32);
             }
-        if (c == 0 && mine) {                  // requested behind the first chunk's operands: their round trip hides under the MFMAs
-            if (a.stats) {
-                row_norm(a.stats + (size_t)mr * a.stats_groups * 2, a.stats_groups, a.K, mean, rstd);
-                cs = *reinterpret_cast<const float4*>(a.colsum + n);
-            }
-            if (ks == 0) {
-                bv = *reinterpret_cast<const float4*>(a.bias + n);
-                if (a.residual) rv = *reinterpret_cast<const float4*>(a.residual + (size_t)mr * a.ldr + n);
-            }
+        if (c == 0 && mine && a.stats) {       // requested behind the first chunk's operands, all at once: one round trip under the MFMAs
+            const float4* sp = reinterpret_cast<const float4*>(a.stats + (size_t)mr * a.stats_groups * 2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[i] = (2 * i < a.stats_groups) ? sp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (g < ng) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s], fx[g][s], acc[g], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt][s], fx[g][s], acc[g][nt], 0, 0, 0);
             }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        if (g < ng) red[wave][g][lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        if (g < ng) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) red[wave][g][nt][lane] = make_float4(acc[g][nt][0], acc[g][nt][1], acc[g][nt][2], acc[g][nt][3]);
+        }
+    // the epilogue's column constants and the residual: requested before the barrier, used behind it
+    float4 cs[NT], bv[NT], rv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cs[nt] = bv[nt] = rv[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!mine) continue;
+        if (a.stats) cs[nt] = *reinterpret_cast<const float4*>(a.colsum + n + nt * 16);
+        if (ks == 0) {
+            bv[nt] = *reinterpret_cast<const float4*>(a.bias + n + nt * 16);
+            if (a.residual) rv[nt] = *reinterpret_cast<const float4*>(a.residual + (size_t)mr * a.ldr + n + nt * 16);
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (mine && a.stats) {                     // (sums in the order of row_norm: pairs ascending)
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sm += sv[i].x + sv[i].z; sq += sv[i].y + sv[i].w; }
+        mean = sm / (float)a.K;
+        const float var = fmaxf((sq - sm * mean) / (float)(a.K - 1), 0.f);
+        rstd = 1.0f / (sqrtf(var) + 1e-6f);
+    }
     __syncthreads();
     if (!mine) return;
-    float4 v = red[0][wave][lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) { const float4 t = red[w][wave][lane]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    if (a.stats) { v.x = rstd * (v.x - mean * cs.x); v.y = rstd * (v.y - mean * cs.y); v.z = rstd * (v.z - mean * cs.z); v.w = rstd * (v.w - mean * cs.w); }
-    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-    if (a.stats_out) {                        // partial sums over the workgroup's 16 columns: lanes l, l ^ 16, l ^ 32, l ^ 48
-        const float psum = xor32_sum(xor16_sum((v.x + v.y) + (v.z + v.w)));
-        const float psq = xor32_sum(xor16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)));
-        if (q == 0 && rowok) reinterpret_cast<float2*>(a.stats_out)[(size_t)mr * (a.N >> 4) + (n0 >> 4)] = make_float2(psum, psq);
+    for (int nt = 0; nt < NT; ++nt) {
+        float4 v = red[0][wave][nt][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 t = red[w][wave][nt][lane]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (a.stats) {
+            v.x = rstd * (v.x - mean * cs[nt].x); v.y = rstd * (v.y - mean * cs[nt].y);
+            v.z = rstd * (v.z - mean * cs[nt].z); v.w = rstd * (v.w - mean * cs[nt].w);
+        }
+        v.x += bv[nt].x; v.y += bv[nt].y; v.z += bv[nt].z; v.w += bv[nt].w;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        v.x += rv[nt].x; v.y += rv[nt].y; v.z += rv[nt].z; v.w += rv[nt].w;
+        const int nn = n + nt * 16;
+        if (a.stats_out) {                    // partial sums over 16 columns: lanes l, l ^ 16, l ^ 32, l ^ 48
+            const float psum = xor32_sum(xor16_sum((v.x + v.y) + (v.z + v.w)));
+            const float psq = xor32_sum(xor16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)));
+            if (q == 0 && rowok) reinterpret_cast<float2*>(a.stats_out)[(size_t)mr * (a.N >> 4) + (n0 >> 4) + nt] = make_float2(psum, psq);
+        }
+        if (!rowok) continue;
+        if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)ks * a.M + mr) * a.ldy + nn) = v;
+        if (a.yb) {
+            uint2 o;
+            o.x = pack_bf16(v.x, v.y);
+            o.y = pack_bf16(v.z, v.w);
+            *reinterpret_cast<uint2*>(a.yb + (size_t)mr * a.ldyb + nn) = o;
+        }
     }
-    if (!rowok) return;
-    if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)ks * a.M + mr) * a.ldy + n) = v;
-    if (a.yb) {
-        uint2 o;
-        o.x = pack_bf16(v.x, v.y);
-        o.y = pack_bf16(v.z, v.w);
-        *reinterpret_cast<uint2*>(a.yb + (size_t)mr * a.ldyb + n) = o;
-    }
+}
+
+template <int NT>
+static void launch_rowgemm_t(const RowGemmArgs& b, int splitk, hipStream_t st) {
+    hipLaunchKernelGGL((rowgemm_kernel<NT>), dim3(b.N / (16 * NT), splitk, (b.M + 63) / 64), dim3(256), (size_t)NT * 16384, st, b);
 }
 
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
@@ -269,10 +308,19 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
     b.kchunks = a.K / (512 * splitk);                   // without split-K a workgroup walks the whole K in chunks of 512
     if ((a.row_idx != nullptr) != (a.m_dev != nullptr)) return BOFI_ERR_ARG;
     if (a.M < 1 || a.N % 16 || b.kchunks < 1 || a.K != 512 * splitk * b.kchunks || a.ldx % 8 || !a.x || !a.w || !a.bias || (!a.y && !a.yb)) return BOFI_ERR_ARG;
-    if (a.stats && (!a.colsum || a.stats_groups % 2 || splitk > 1)) return BOFI_ERR_ARG;
+    if (a.stats && (!a.colsum || a.stats_groups % 2 || a.stats_groups > 32 || splitk > 1)) return BOFI_ERR_ARG;
     if (splitk > 1 && (a.relu || a.stats_out || a.yb || !a.y)) return BOFI_ERR_ARG;
     if ((a.y && a.ldy % 4) || (a.yb && a.ldyb % 4) || (a.residual && a.ldr % 4)) return BOFI_ERR_ARG;
-    hipLaunchKernelGGL(rowgemm_kernel, dim3(a.N / 16, splitk, (a.M + 63) / 64), dim3(256), 0, st, b);
+    // column tile: the narrowest of 16 / 32 / 64 columns that keeps the launch within one workgroup per CU (a tile's sums do not depend on it:
+    // every output element is the same four k-quarter sums whatever the tile)
+    static const int forced = [] { const char* v = getenv("BOFI_ROWGEMM_NT"); return v ? atoi(v) : 0; }();      // developer knob: 1, 2 or 4
+    const int per_tile = splitk * ((a.M + 63) / 64);
+    int nt = 1;
+    while (nt < 4 && a.N % (32 * nt) == 0 && (a.N / (16 * nt)) * per_tile > 256) nt *= 2;
+    if (forced && a.N % (16 * forced) == 0) nt = forced;
+    if (nt == 4) launch_rowgemm_t<4>(b, splitk, st);
+    else if (nt == 2) launch_rowgemm_t<2>(b, splitk, st);
+    else launch_rowgemm_t<1>(b, splitk, st);
     if (!a.row_idx) (a.skip_if_ge ? g_gemm_flops_skippable : g_gemm_flops) += 2.0 * a.M * a.N * a.K;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }

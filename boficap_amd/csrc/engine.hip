@@ -357,8 +357,10 @@ struct bofi_engine {
         if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_MIN_ROWS"); v = e ? atoi(e) : 4096; gen = bofi::g_env_generation; }
         return v;
     }
+    static bool exp_skip(const char* what) { const char* v = getenv("BOFI_EXP_SKIP"); return v && strstr(v, what); }
     int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
         static const bool on = env_on("BOFI_RB_ATTN");
+        if (exp_skip("attn")) return BOFI_OK;
         if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh || at.B * at.Lq < rb_min_rows()) return -1;
         bofi::RbAttnArgs a{};
         a.q = (const uint16_t*)at.q; a.ldq = at.ldq; a.k = (const uint16_t*)at.k; a.ldk = at.ldk; a.v = (const uint16_t*)at.v; a.ldv = at.ldv;
@@ -375,6 +377,7 @@ struct bofi_engine {
     }
     int fold_linear_rb(const float* x32, const Lin& l, void* y, int y_f32, int ldy, int M, hipStream_t s) {
         if (!fold_rb_ok(l, M)) return -1;
+        if (exp_skip(y_f32 ? "gen" : l.Npad <= 1536 ? "qkv" : "kv")) return BOFI_OK;
         bofi::RbGemmArgs a{};
         a.x = x32; a.ldx = cfg.d_model; a.wp = (const bofi::u32x4*)l.wp; a.c = l.b; a.cs = l.cs; a.y = y; a.ldy = ldy; a.y_f32 = y_f32; a.M = M; a.N = l.Npad; a.relu = 0;
         return bofi::launch_rb_gemm(a, s);
@@ -385,6 +388,7 @@ struct bofi_engine {
     }
     int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s) {
         if (!ffn_sublayer_ok(w1, w2, M)) return -1;
+        if (exp_skip("ffn")) return BOFI_OK;
         bofi::RbFfnArgs a{};
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
@@ -461,6 +465,7 @@ int bofi_engine::enqueue_bound_iter(int B, int R, const int* att_len, const int*
     // has been produced by the previous bound_tail(..., BOUND_ATTN).
     const int d = cfg.d_model, dt = cfg.dtype;
     cur_B = B;
+    if (exp_skip("loop")) return BOFI_OK;
     {   // bf16 at the reference's width: the four stages as the direct-operand kernels of bound_ops.hip
         int parts = 0;
         const int rc = bound_chain_lean(B, R, att_len, early ? st.counters : nullptr, B, s, &parts);

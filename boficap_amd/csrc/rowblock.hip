@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
     const int m0 = blockIdx.x * 64, nch = a.dff / RB_HC;
     const bool producer = wave < 4;
     const int w4 = wave & 3;
-    if ((a.dbg & 16) && blockIdx.x == 0 && lane == 0) g_rb_stamps[wave * 16 + 15] = __builtin_amdgcn_s_memtime();      // entry
+    if ((a.dbg & 16) && blockIdx.x == 0 && lane == 0) g_rb_stamps[(8 + wave) * 16] = __builtin_amdgcn_s_memtime();      // entry (rows 8-15: this kernel has 8 wavefronts)
 
     // ---- the first steps of this wavefront's weight stream, then constants and the block (as rb_ffn_kernel)
     constexpr int PPF = 4;                                     // producer: 4 steps x 4 fragments in flight (8 measured SLOWER: 66 against 53 us per workgroup)
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
         rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
         if (ps == 0) __syncthreads();
     }
+    RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // exit
 }
 
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
