@@ -24,11 +24,16 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-// row mean and 1 / (std + eps) (unbiased std, eps = 1e-6: LayerNorm of TransformerModel.py:223-233) from `ng` partial (sum, sumsq)
+// row mean and 1 / (std + eps) (unbiased std, eps = 1e-6: LayerNorm of TransformerModel.py:223-233) from `ng` <= 32 partial (sum, sumsq)
+// pairs: every pair is requested before the first is summed (a loop over a run-time count waits for each load in turn: 8-16 L2 round trips)
 __device__ __forceinline__ void row_norm(const float* stats, int ng, int d, float& mean, float& rstd) {
     const float4* sp = reinterpret_cast<const float4*>(stats);
+    float4 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = (2 * i < ng) ? sp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float sm = 0.f, sq = 0.f;
-    for (int i = 0; i < (ng >> 1); ++i) { const float4 t = sp[i]; sm += t.x + t.z; sq += t.y + t.w; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sm += t[i].x + t[i].z; sq += t[i].y + t[i].w; }
     mean = sm / (float)d;
     const float var = fmaxf((sq - sm * mean) / (float)(d - 1), 0.f);
     rstd = 1.0f / (sqrtf(var) + 1e-6f);
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void bound_qattn_kernel(BoundQAttnArgs a) {
     __shared__ float qs[G][DK];
     __shared__ float ps[4][2][64];
     __shared__ float s_mean[G], s_rstd[G];
-    if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
+    if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;      // (before any load: an idle launch must not pull the kernel's operands)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int h = blockIdx.x, b0 = blockIdx.y * G, R = a.R;
@@ -187,7 +192,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];
     float4 (*red)[4][NT][64] = reinterpret_cast<float4 (*)[4][NT][64]>(rg_smem);          // [k quarter][16-row group][column tile][lane]
-    if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;
+    if (a.skip_if_ge && *a.skip_if_ge >= a.skip_threshold) return;      // (before any load: an idle launch must not pull the kernel's operands)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16 * NT, ks = blockIdx.y, mbase = blockIdx.z * 64;
     const int M = a.m_dev ? min(a.M, *a.m_dev) : a.M;        // row list: the count lives on the device (a.M sized the grid)

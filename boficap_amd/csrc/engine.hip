@@ -547,7 +547,8 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
         ENG_OK(enqueue_bound_dense(att_len, B, R, s));
     } else {
         ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
-        for (int it = 0; it < S; ++it)
+        static const int exp_iters = [] { const char* v = getenv("BOFI_EXP_ITERS"); return v ? atoi(v) : 0; }();     // timing experiment: fewer iterations enqueued
+        for (int it = 0; it < (exp_iters ? exp_iters : S); ++it)
             ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     }
     ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));

@@ -143,7 +143,15 @@ __global__ __launch_bounds__(512, MINW) void bound_tail_kernel(BoundTailArgs a) 
             if (k < d) {
                 const size_t ys = a.y_stride ? (size_t)a.y_stride : (size_t)d;
                 float acc = y[(size_t)b * ys + k];
-                for (int pz = 1; pz < a.yparts; ++pz) acc += y[((size_t)pz * B + b) * ys + k];
+                if (a.yparts <= 4) {                  // the slabs are requested together (a loop over a run-time count waits for each in turn)
+                    float pv[3];
+#pragma unroll
+                    for (int pz = 1; pz < 4; ++pz) pv[pz - 1] = pz < a.yparts ? y[((size_t)pz * B + b) * ys + k] : 0.f;
+#pragma unroll
+                    for (int pz = 1; pz < 4; ++pz) if (pz < a.yparts) acc += pv[pz - 1];
+                } else {
+                    for (int pz = 1; pz < a.yparts; ++pz) acc += y[((size_t)pz * B + b) * ys + k];
+                }
                 yv[c] = acc; gv[c] = w.norm_gain[k]; bvn[c] = w.norm_bias[k];
             }
         }
