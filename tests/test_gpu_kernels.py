@@ -168,7 +168,7 @@ def _row_stats(x32, groups):
     return torch.stack([v.sum(-1), (v * v).sum(-1)], -1).contiguous()
 
 
-@pytest.mark.parametrize("M", [1, 17, 64, 65, 256])
+@pytest.mark.parametrize("M", [1, 17, 64, 65, 256, 320])
 @pytest.mark.parametrize("mode", ["plain", "ln_relu", "res_stats", "splitk"])
 def test_rowgemm(H, M, mode):
     """bofi_rowgemm (bound_ops.hip): y = epilogue(x w^T) for a few rows, against float64 on the bf16-rounded operands: LayerNorm fold
