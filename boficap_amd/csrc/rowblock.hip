@@ -861,6 +861,9 @@ __device__ __forceinline__ void rb_seg(const u32x4* cur, const u32x4* nxt, bf16x
     }
 }
 
+// element by element: a vector-typed `+=` is emitted as v_pk_add_f32 whatever the vectoriser flags say (build.py, test_shipped_library_has_no_packed_f32_arithmetic)
+__device__ __forceinline__ void rb_add4(f32x4& v, const float4& b) { v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+
 __device__ __forceinline__ bf16x8 rb_pack8(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
     const u32x4 v = {pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(b0, b1), pack_bf16(b2, b3)};
     return __builtin_bit_cast(bf16x8, v);
@@ -1076,8 +1079,7 @@ __global__ __launch_bounds__(512) void rb_encoder_kernel(RbEncArgs a) {
             rb_seg<5, 4, 16, 16384, false>(woseg(ly), w2seg(ly, 0), w4r, xb, lbase, xr);
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
-                xr[0][mt] += f32x4{b0.x, b0.y, b0.z, b0.w}; xr[1][mt] += f32x4{b1.x, b1.y, b1.z, b1.w};
-                xr[2][mt] += f32x4{b2.x, b2.y, b2.z, b2.w}; xr[3][mt] += f32x4{b3.x, b3.y, b3.z, b3.w};
+                rb_add4(xr[0][mt], b0); rb_add4(xr[1][mt], b1); rb_add4(xr[2][mt], b2); rb_add4(xr[3][mt], b3);
             }
         }
         __syncthreads();                                                    // the heads' outputs are read: the block may take the new x
@@ -1143,8 +1145,7 @@ __global__ __launch_bounds__(512) void rb_encoder_kernel(RbEncArgs a) {
             const float4 b2 = *reinterpret_cast<const float4*>(ly.b2 + wave * 64 + 32 + g * 4), b3 = *reinterpret_cast<const float4*>(ly.b2 + wave * 64 + 48 + g * 4);
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
-                xr[0][mt] += f32x4{b0.x, b0.y, b0.z, b0.w}; xr[1][mt] += f32x4{b1.x, b1.y, b1.z, b1.w};
-                xr[2][mt] += f32x4{b2.x, b2.y, b2.z, b2.w}; xr[3][mt] += f32x4{b3.x, b3.y, b3.z, b3.w};
+                rb_add4(xr[0][mt], b0); rb_add4(xr[1][mt], b1); rb_add4(xr[2][mt], b2); rb_add4(xr[3][mt], b3);
             }
         }
         __syncthreads();                                                    // (the next layer's block write must not overtake a slow wavefront's w_1 reads)

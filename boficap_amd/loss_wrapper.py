@@ -6,7 +6,8 @@ same constructor, same ``forward`` signature, same keys in the returned dict, so
 
 XE branch (struc_flag False): pinned to the reference by tests/golden/tiny_loss_wrapper_xe (the reference's LossWrapper
 around the reference model).  RL branch (struc_flag True): its loss arithmetic is pinned by tests/golden/tiny_rl_loss
-(StructureLosses 'new_self_critical' and the rl_kl term with injected samples and scores); the caption scorer itself
+(StructureLosses 'new_self_critical' and the rl_kl term with injected samples and scores) and tests/golden/tiny_structure_losses (the other
+structure_loss_types); the caption scorer itself
 (``get_scores``: CIDEr-D / BLEU of the external ``cider`` and ``coco-caption`` packages, captioning/utils/rewards.py:86-131) is
 not part of this build -- pass ``opt.bofi_score_fn(gts, seq) -> [N] floats`` or install one with ``set_scorer``.
 
@@ -40,7 +41,8 @@ class LanguageModelCriterion_UIC(torch.nn.Module):
 
 
 class StructureLosses(torch.nn.Module):
-    """captioning/modules/losses.py:29-179 for ``structure_loss_type: new_self_critical`` (configs/uic_sd_kd100_sd_nscl.yml)."""
+    """captioning/modules/losses.py:29-179: every ``structure_loss_type`` (configs/uic_sd_kd100_sd_nscl.yml uses 'new_self_critical'),
+    the entropy reward and reduction 'none' (xe.structure_loss).  Not built: the self-CIDEr reward term (:167-171, another external scorer)."""
 
     def __init__(self, opt):
         super().__init__()
@@ -48,10 +50,8 @@ class StructureLosses(torch.nn.Module):
         self.loss_type = getattr(opt, "structure_loss_type", "seqnll")
 
     def forward(self, input, seq, data_gts, reduction="mean"):
-        if self.loss_type != "new_self_critical" or reduction != "mean":
-            raise NotImplementedError(f"structure_loss_type {self.loss_type!r} / reduction {reduction!r}: 'new_self_critical' with 'mean' is built")
-        if getattr(self.opt, "entropy_reward_weight", 0) > 0 or getattr(self.opt, "self_cider_reward_weight", 0) > 0:
-            raise NotImplementedError("entropy / self-CIDEr reward terms are not built (0 in the shipped configs)")
+        if getattr(self.opt, "self_cider_reward_weight", 0) > 0:
+            raise NotImplementedError("the self-CIDEr reward term is not built (0 in the shipped configs)")
         n = input.size(0) // len(data_gts)
         assert n == self.opt.train_sample_n, n                   # losses.py:45
         fn = getattr(self.opt, "bofi_score_fn", None) or _SCORER["fn"]
@@ -59,7 +59,8 @@ class StructureLosses(torch.nn.Module):
             raise hip.BofiHipError("no caption scorer: the reference's CIDEr-D scorer is an external package (captioning/utils/rewards.py:163-170); "
                                    "pass opt.bofi_score_fn or call boficap_amd.loss_wrapper.set_scorer")
         scores = fn(data_gts, seq.detach().cpu())
-        loss, reward = xe.new_self_critical(input, seq, scores, n)
+        loss, reward = xe.structure_loss(self.loss_type, input, seq, scores, n, reduction=reduction,
+                                         entropy_reward_weight=float(getattr(self.opt, "entropy_reward_weight", 0) or 0))
         return {"loss": loss, "reward": reward}
 
 

@@ -301,6 +301,11 @@ class XETrainer:
         self.ops = WeightOperands(self.bucket) if prepared_weights else None
         self.paired = bool(paired) and self.unpadded            # add_token_rows: SA and NA branch as one batch (xe._forward_paired)
         self.grouped_dw = bool(grouped_dw)                     # bf16 mode: all weight-gradient GEMMs of a step in a few grouped launches
+        # ... or, with dw_every > 0, started during the backward every `dw_every` problems on a side stream.  Off by default: measured SLOWER
+        # as a branch of the captured step (7.02 ms -> 7.13 / 7.24 / 7.60 ms at 24 / 12 / 6 problems per launch, profiles/r03_xe_dw_aside.txt --
+        # every fork / join of the graph costs about 50 us, more than the overlap returns); kept as a tested option
+        self.dw_every = int(os.environ.get("BOFI_XE_DW_EVERY", g("bofi_dw_every", 0)))
+        self._dw_stream = None
         # the forward's four branches (and with them the backward's) on HIP streams of their own (xe._Fork); needs the bucket-level
         # weight operands: per-use casts / transposes of a weight two branches share would race
         self._side = [torch.cuda.Stream() for _ in range(3)] if streams and self.ops is not None else None
@@ -419,10 +424,14 @@ class XETrainer:
         if self.grouped_dw:
             xe._DEFER["list"] = []
         try:
+            self._arm_dw_stream()
             torch.autograd.backward(stage2["memory"], stage2["memory_detached"].grad)
-            xe.flush_weight_grads()
+            xe.flush_weight_grads_aside(final=True)
+            xe.join_weight_grads()
         finally:
             xe._DEFER["list"] = None
+            xe._DEFER["side"] = None
+            xe._DEFER["held"] = []
             if armed:
                 xe._WEIGHTS["provider"] = None
         stage2.clear()
@@ -439,11 +448,13 @@ class XETrainer:
             self.ops.launch_transposes()
             xe._WEIGHTS["provider"] = self.ops
         if self.grouped_dw:
-            xe._DEFER["list"] = []                             # weight gradients: one grouped launch after backward
+            xe._DEFER["list"] = []                             # weight gradients: grouped launches beside / after backward
+            self._arm_dw_stream()
         try:
             stage2 = between if isinstance(between, dict) else ({} if between is not None and dense is None else None)
             out = self._forward_backward_armed(batch, glat_p, dense, stage2)
-            xe.flush_weight_grads()
+            xe.flush_weight_grads_aside(final=True)
+            xe.join_weight_grads()
             if stage2 is not None and not isinstance(between, dict):
                 between()
                 if armed:
@@ -455,9 +466,19 @@ class XETrainer:
             return out
         finally:
             xe._DEFER["list"] = None
+            xe._DEFER["side"] = None
+            xe._DEFER["held"] = []
             if armed:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()
+
+    def _arm_dw_stream(self) -> None:
+        """Weight-gradient launches go beside the backward on a stream of their own, `dw_every` problems at a time (xe._DEFER)."""
+        from . import xe
+        if self.dw_every > 0 and self.grouped_dw:
+            if self._dw_stream is None:
+                self._dw_stream = torch.cuda.Stream()
+            xe._DEFER["side"], xe._DEFER["every"], xe._DEFER["held"] = self._dw_stream, self.dw_every, []
 
     def _forward_backward_armed(self, batch, glat_p, dense=None, stage2=None):
         from . import xe

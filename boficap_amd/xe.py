@@ -91,9 +91,14 @@ _SHADOW_ONLY: set = set()
 # forward + backward.  None: every weight is cast / transposed on first use in the step (the _STEP_CACHE path).
 _WEIGHTS = {"provider": None}
 
-# Weight-gradient GEMMs put off to one grouped launch after backward (flush_weight_grads): a list of
+# Weight-gradient GEMMs put off to grouped launches (flush_weight_grads): a list of
 # (dz operand, ld, x operand, ld, target, ldc, M, N, K, bias target) while a trainer collects them, else None.
-_DEFER = {"list": None}
+# "side" / "every": with a side stream set, LinearFn.backward hands the list over every `every` problems and the grouped launch runs on
+# that stream BESIDE the rest of the backward (the dX / LayerNorm / attention chain is a sequence of latency-bound launches that leave most
+# of the chip idle; the weight gradients are throughput work nothing in the backward waits for).  "held": the handed-over operands, kept
+# alive until the streams are joined (join_weight_grads) -- the allocator may hand a block freed on the main stream to the next main-stream
+# kernel while the side stream still reads it.
+_DEFER = {"list": None, "side": None, "every": 0, "held": []}
 
 
 def flush_weight_grads():
@@ -111,6 +116,29 @@ def flush_weight_grads():
     _DEFER["list"] = []
     _chk(rc, "bofi_gemm_tn_grouped")
     return n
+
+
+def flush_weight_grads_aside(final: bool = False):
+    """The collected weight-gradient GEMMs as one grouped launch on the side stream, ordered behind everything the current stream has
+    enqueued so far (their operands are complete there); a no-op below `every` problems unless ``final``.  Without a side stream the
+    final call is flush_weight_grads()."""
+    side, todo = _DEFER["side"], _DEFER["list"]
+    if side is None:
+        return flush_weight_grads() if final else 0
+    if not todo or (not final and len(todo) < _DEFER["every"]):
+        return 0
+    side.wait_stream(torch.cuda.current_stream())
+    _DEFER["held"].append(todo)
+    with torch.cuda.stream(side):
+        return flush_weight_grads()
+
+
+def join_weight_grads():
+    """The current stream waits for the side stream's weight-gradient launches; the operands they read may go after this point."""
+    side = _DEFER["side"]
+    if side is not None and _DEFER["held"]:
+        torch.cuda.current_stream().wait_stream(side)
+    _DEFER["held"] = []
 
 
 def _register_shadow(t, shadow, only=False):
@@ -316,6 +344,7 @@ class LinearFn(Function):
                     dw = target = _zeros(x, N, K)
                 if _DEFER["list"] is not None and ctx.gw is not None:
                     _DEFER["list"].append((dzo, Np, xo, Kp, target, K, M, N, K, bsum))      # with the step's other weight gradients
+                    flush_weight_grads_aside()
                 else:
                     _chk(L.bofi_gemm_tn_acc(hip.ptr(dzo), Np, Np, hip.ptr(xo), Kp, Kp, hip.ptr(target), K, M, N, K, hip.ptr(bsum), st), "bofi_gemm_tn_acc")
             return (dx, dw, db) + tail
@@ -1741,6 +1770,57 @@ def new_self_critical(logprobs, seq, scores, sample_n: int):
     picked = logprobs.gather(2, seq.unsqueeze(2)).squeeze(2)
     loss = (-picked * mask * reward.view(-1, 1)).sum() / mask.sum()
     return loss, sc
+
+
+STRUCTURE_LOSS_TYPES = ("seqnll", "risk", "max_margin", "multi_margin", "softmax_margin", "real_softmax_margin", "new_self_critical")
+
+
+def structure_loss(loss_type: str, logprobs, seq, scores, sample_n: int, reduction: str = "mean", entropy_reward_weight: float = 0.0):
+    """StructureLosses.forward for every ``structure_loss_type`` of the reference (captioning/modules/losses.py:38-179): the sequence-level
+    losses of Edunov et al. over the ``sample_n`` sampled captions of an image -- 'seqnll' (:72-79), 'risk' (:81-87), 'max_margin' (:96-106),
+    'multi_margin' (:118-128), 'softmax_margin' (:136-144), 'real_softmax_margin' (:146-155), 'new_self_critical' (:157-176) -- with the
+    entropy reward (:53-57) and reduction 'none' where the reference has it.  ``logprobs`` [N, S, V] (what the type takes: log-softmax or
+    logits), ``scores`` [N] from the caption scorer.  The reference AS SHIPPED raises a NameError for every type but 'new_self_critical'
+    (its losses.py never imports ``F``); the formulas are pinned by tests/golden/tiny_structure_losses, recorded from the reference's code
+    with that import supplied.  Index bookkeeping on [N, S] tensors; returns (loss, reward [B, n] = the raw scores)."""
+    if loss_type not in STRUCTURE_LOSS_TYPES:
+        raise ValueError(f"structure_loss_type {loss_type!r}: one of {STRUCTURE_LOSS_TYPES}")
+    if reduction not in ("mean", "none") or (reduction == "none" and loss_type in ("risk", "max_margin", "multi_margin")):
+        raise ValueError(f"structure_loss_type {loss_type!r} has no reduction {reduction!r} (losses.py:87,105,127)")
+    if sample_n < 2 and loss_type == "new_self_critical":
+        raise ValueError("new_self_critical needs at least two samples per image")
+    Fn = torch.nn.functional
+    seq = seq.to(logprobs.device).long()
+    mask = (seq > 0).to(logprobs.dtype)
+    mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1)
+    sc = torch.as_tensor(scores, dtype=logprobs.dtype, device=logprobs.device).view(-1, sample_n)
+    reward = sc
+    if entropy_reward_weight > 0:
+        with torch.no_grad():
+            entropy = -(Fn.softmax(logprobs, dim=2) * Fn.log_softmax(logprobs, dim=2)).sum(2)
+            entropy = (entropy * mask).sum(1) / mask.sum(1)
+        sc = sc + entropy_reward_weight * entropy.view(-1, sample_n)
+    costs = -sc
+    if loss_type in ("risk", "softmax_margin"):
+        costs = costs - costs.min(1, keepdim=True)[0]
+        costs = costs / costs.max(1, keepdim=True)[0]
+    picked = logprobs.gather(2, seq.unsqueeze(2)).squeeze(2)
+    if loss_type == "new_self_critical":
+        adv = sc - (sc.sum(1, keepdim=True) - sc) / (sample_n - 1)
+        out = -picked * mask * adv.view(-1, 1)
+        return (out.sum(1) / mask.sum(1) if reduction == "none" else out.sum() / mask.sum()), reward
+    picked = picked * mask
+    if loss_type == "risk":
+        cap = picked.sum(1).view(-1, sample_n)
+        return (Fn.softmax(cap.exp(), dim=1) * costs).sum(1).mean(), reward
+    cap = (picked.sum(1) / mask.sum(1)).view(-1, sample_n)
+    if loss_type == "seqnll":
+        return Fn.cross_entropy(cap, costs.min(1)[1], reduction=reduction), reward
+    if loss_type in ("max_margin", "multi_margin"):
+        best, idx = costs.min(1, keepdim=True)
+        hinge = Fn.relu(costs - best - cap.gather(1, idx) + cap)
+        return ((hinge.max(1)[0] / 2).mean() if loss_type == "max_margin" else hinge.mean()), reward
+    return Fn.cross_entropy(cap + costs, costs.min(1)[1], reduction=reduction), reward
 
 
 def rl_kl_term(naic_logprobs, saic_logprobs, saic_seq):

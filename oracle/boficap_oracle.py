@@ -643,6 +643,51 @@ def new_self_critical(logprobs, seq, scores, sample_n: int):
     return torch.sum(output) / torch.sum(mask), sc                                    # :176
 
 
+STRUCTURE_LOSS_TYPES = ("seqnll", "risk", "max_margin", "multi_margin", "softmax_margin", "real_softmax_margin", "new_self_critical")
+
+
+def structure_loss(loss_type: str, input, seq, scores, sample_n: int, reduction: str = "mean", entropy_reward_weight: float = 0.0):
+    """StructureLosses.forward for every ``structure_loss_type`` (captioning/modules/losses.py:38-179; self_cider_reward_weight 0).
+    ``input``: [N, S, V] logits or log-softmax as the type expects; ``scores`` [N] from the caption scorer (get_scores, external).
+    Returns (loss, reward [B, n] = the raw scores, stored before entropy / rescaling / baseline touch them, :51-52)."""
+    if loss_type not in STRUCTURE_LOSS_TYPES:
+        raise ValueError(loss_type)
+    F = torch.nn.functional
+    mask = (seq > 0).to(input)
+    mask = torch.cat([mask.new_full((mask.size(0), 1), 1), mask[:, :-1]], 1)        # :47-48
+    sc = torch.as_tensor(scores).type_as(input).view(-1, sample_n)                    # :50-51
+    reward = sc
+    if entropy_reward_weight > 0:                                                     # :53-57
+        entropy = -(F.softmax(input, dim=2) * F.log_softmax(input, dim=2)).sum(2).detach()
+        entropy = (entropy * mask).sum(1) / mask.sum(1)
+        sc = sc + entropy_reward_weight * entropy.view(-1, sample_n)
+    costs = -sc                                                                       # :59
+    if loss_type in ("risk", "softmax_margin"):                                       # :60-62: rescaled to [0, 1] per image
+        costs = costs - costs.min(1, keepdim=True)[0]
+        costs = costs / costs.max(1, keepdim=True)[0]
+    x = input.gather(2, seq.unsqueeze(2)).squeeze(2)                                  # :70
+    if loss_type == "new_self_critical":                                              # :157-176
+        adv = sc - (sc.sum(1, keepdim=True) - sc) / (sc.shape[1] - 1)
+        out = -x * mask * adv.view(-1, 1)
+        if reduction == "none":
+            return out.sum(1) / mask.sum(1), reward
+        return torch.sum(out) / torch.sum(mask), reward
+    x = x * mask
+    if loss_type == "risk":                                                           # :81-87: caption log-prob, not averaged
+        x = x.sum(1).view(-1, sample_n)
+        assert reduction == "mean"
+        return (F.softmax(x.exp(), dim=1) * costs).sum(1).mean(), reward            # (the implicit dim of a 2-D softmax is 1)
+    x = (x.sum(1) / mask.sum(1)).view(-1, sample_n)                                   # every other type: mean token value per caption
+    if loss_type == "seqnll":                                                         # :72-79
+        return F.cross_entropy(x, costs.min(1)[1], reduction=reduction), reward
+    if loss_type in ("max_margin", "multi_margin"):                                   # :96-128
+        costs_star, idx = costs.min(1, keepdim=True)
+        hinge = F.relu(costs - costs_star - x.gather(1, idx) + x)
+        assert reduction == "mean"
+        return (hinge.max(1)[0] / 2).mean() if loss_type == "max_margin" else hinge.mean(), reward
+    return F.cross_entropy(x + costs, costs.min(1)[1], reduction=reduction), reward  # softmax_margin :136-144, real_softmax_margin :146-155
+
+
 def rl_kl_term(naic_logprobs, saic_logprobs, saic_seq):
     """LossWrapper UIC branch with rl_kl (captioning/modules/loss_wrapper.py:216-222): KL(SAIC || NAIC) per vocabulary
     entry, nn.KLDivLoss(reduction='none') = target * (log target - input), masked by the SAIC caption's tokens."""

@@ -435,6 +435,77 @@ def run_rl_loss_case(name, cfg, seed, n_img=3, sample_n=4):
     return dict(n_img=n_img, sample_n=sample_n, nsc_loss=float(res["nsc_loss"]), lw_loss=float(res["lw_loss"]), lw_kl_loss=float(res["lw_kl_loss"]))
 
 
+def run_structure_loss_types_case(name, cfg, seed, n_img=3, sample_n=4):
+    """StructureLosses of the REAL reference for every structure_loss_type (losses.py:72-176) on injected samples and scores
+    (get_scores replaced as in run_rl_loss_case): loss, reward, d loss / d input at the sampled ids; reduction 'none' where the
+    reference has it; one variant with entropy_reward_weight > 0 (its gradient is taken through the detached entropy, :54)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    N, S, V = n_img * sample_n, cfg.seq_length, cfg.tgt_vocab
+    lp = F.log_softmax(torch.randn(N, S, V, generator=g) * 1.5, dim=2)
+    seq = torch.randint(1, V, (N, S), generator=g)
+    ntok = torch.randint(1, S + 1, (N,), generator=g)
+    for i in range(N):
+        seq[i, int(ntok[i]):] = 0
+    sc = torch.rand(N, generator=g).numpy().astype(np.float64)
+    res = dict(logprob=lp.numpy(), seq=seq.numpy(), scores=sc.astype(np.float32), sample_n=np.int32(sample_n))
+    gts = [[np.zeros(3, np.int64)] for _ in range(n_img)]
+    queue = []
+    real_get_scores = ref_losses.get_scores
+    ref_losses.get_scores = lambda data_gts, gen_result, opt_: queue.pop(0)
+    cases = [(t, "mean", 0.0) for t in O.STRUCTURE_LOSS_TYPES] + [("seqnll", "none", 0.0), ("softmax_margin", "none", 0.0),
+                                                                   ("new_self_critical", "none", 0.0), ("new_self_critical", "mean", 0.3),
+                                                                   ("risk", "mean", 0.3)]
+    summary = {}
+    import contextlib, io
+    # The reference's losses.py never imports torch.nn.functional as F (losses.py:1-4), so AS SHIPPED every type but
+    # 'new_self_critical' (and the entropy branch, :54) dies with a NameError at its first F.* call -- recorded in the fixture.  The
+    # formulas themselves are pinned with the obviously intended import injected into the module's namespace by this harness
+    # (nothing in /root/reference is touched).
+    had_F = hasattr(ref_losses, "F")
+    raises = []
+    if not had_F:
+        for loss_type in O.STRUCTURE_LOSS_TYPES:
+            queue.append(sc.copy())
+            try:
+                ref_losses.StructureLosses(cfg.to_opt(structure_loss_type=loss_type, train_sample_n=sample_n, entropy_reward_weight=0,
+                                                      structure_loss_weight=1, self_cider_reward_weight=0))(lp.clone(), seq, gts)
+            except NameError:
+                raises.append(loss_type)
+            queue.clear()
+        assert raises == [t for t in O.STRUCTURE_LOSS_TYPES if t != "new_self_critical"], raises
+        ref_losses.F = F
+    res["reference_raises_name_error"] = np.array(raises)
+    try:
+        for loss_type, reduction, ent in cases:
+            opt = cfg.to_opt(structure_loss_type=loss_type, train_sample_n=sample_n, entropy_reward_weight=ent, structure_loss_weight=1,
+                             self_cider_reward_weight=0)
+            crit = ref_losses.StructureLosses(opt)
+            a = lp.clone().requires_grad_(True)
+            queue.append(sc.copy())
+            with contextlib.redirect_stdout(io.StringIO()):      # (the entropy branch prints)
+                out = crit(a, seq, gts, reduction=reduction)
+            w = torch.linspace(0.5, 1.5, out["loss"].numel()).view_as(out["loss"]) if reduction == "none" else None
+            (out["loss"] * w).sum().backward() if w is not None else out["loss"].backward()
+            ol, orw = O.structure_loss(loss_type, lp, seq, sc, sample_n, reduction=reduction, entropy_reward_weight=ent)
+            assert torch.allclose(out["loss"], ol.type_as(out["loss"]), atol=1e-6, rtol=1e-5), (loss_type, reduction, out["loss"], ol)
+            assert torch.equal(out["reward"], orw.type_as(out["reward"]))
+            assert int((a.grad != 0).sum()) <= N * S               # the gradient lives on the sampled ids only
+            tag = f"{loss_type}_{reduction}" + ("_ent" if ent else "")
+            res[tag + "_loss"] = out["loss"].detach().numpy().astype(np.float32)
+            res[tag + "_grad_picked"] = a.grad.gather(2, seq.unsqueeze(2)).squeeze(2).numpy()
+            res[tag + "_entropy_weight"] = np.float32(ent)
+            summary[tag] = float(out["loss"].detach().sum())
+        res["reward"] = out["reward"].numpy()
+    finally:
+        ref_losses.get_scores = real_get_scores
+        if not had_F and hasattr(ref_losses, "F"):
+            del ref_losses.F
+    assert not queue
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return dict(n_img=n_img, sample_n=sample_n, losses=summary, reference_raises_name_error=raises)
+
+
 def run_loss_wrapper_xe_case(name, cfg, sd, n_img, spi, seed):
     """LossWrapper.forward, train_mode 'UIC', struc_flag=False (loss_wrapper.py:231-244) around the REAL reference model:
     the out dict of one XE batch (eval mode, glat_p < 0)."""
@@ -548,6 +619,8 @@ def main():
     print("tiny_ss", manifest["tiny_ss"])
     manifest["tiny_rl_loss"] = dict(config="TINY", **run_rl_loss_case("tiny_rl_loss", TINY, 11))
     print("tiny_rl_loss", manifest["tiny_rl_loss"])
+    manifest["tiny_structure_losses"] = dict(config="TINY", **run_structure_loss_types_case("tiny_structure_losses", TINY, 13))
+    print("tiny_structure_losses", manifest["tiny_structure_losses"])
     manifest["tiny_criterion_variants"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
                                                **run_criterion_variants_case("tiny_criterion_variants", TINY, sd_t, 3, 2, 13))
     print("tiny_criterion_variants", manifest["tiny_criterion_variants"])

@@ -450,6 +450,41 @@ def test_self_critical_losses_vs_reference(manifest):
             assert _maxdiff(ls.grad.gather(2, t("saic_seq").unsqueeze(2)).squeeze(2), torch.from_numpy(g["lw_kl_grad_saic_picked"])) < 1e-7
 
 
+def test_structure_loss_types_vs_reference(manifest):
+    """xe.structure_loss / the StructureLosses mirror on the device: every structure_loss_type, reduction 'none' and the entropy reward
+    against the values and gradients recorded from the reference's code (tests/golden/tiny_structure_losses)."""
+    from argparse import Namespace
+    from boficap_amd import xe
+    from boficap_amd.loss_wrapper import StructureLosses
+    g = load_golden("tiny_structure_losses")
+    n = int(g["sample_n"])
+    seq = torch.from_numpy(g["seq"]).cuda()
+    seen = set()
+    for key in list(g):
+        if not key.endswith("_loss"):
+            continue
+        tag = key[:-5]
+        ent = float(g[tag + "_entropy_weight"])
+        loss_type, reduction = (tag[:-4] if tag.endswith("_ent") else tag).rsplit("_", 1)
+        seen.add(loss_type)
+        a = torch.from_numpy(g["logprob"]).cuda().requires_grad_(True)
+        if reduction == "mean" and not ent:                       # through the module, the scorer injected
+            crit = StructureLosses(Namespace(structure_loss_type=loss_type, train_sample_n=n, entropy_reward_weight=0, self_cider_reward_weight=0,
+                                             bofi_score_fn=lambda gts, s: g["scores"]))
+            out = crit(a, seq, [None] * (a.size(0) // n))
+            loss, reward = out["loss"], out["reward"]
+        else:
+            loss, reward = xe.structure_loss(loss_type, a, seq, g["scores"], n, reduction=reduction, entropy_reward_weight=ent)
+        assert np.allclose(loss.detach().cpu().numpy(), g[tag + "_loss"], rtol=2e-5, atol=2e-6), tag
+        assert np.allclose(reward.cpu().numpy(), g["reward"])
+        w = torch.linspace(0.5, 1.5, loss.numel()).view_as(loss).cuda() if reduction == "none" else None
+        ((loss * w).sum() if w is not None else loss).backward()
+        assert _maxdiff(a.grad.gather(2, seq.unsqueeze(2)).squeeze(2), torch.from_numpy(g[tag + "_grad_picked"])) < 2e-6, tag
+    assert seen == set(xe.STRUCTURE_LOSS_TYPES)
+    with pytest.raises(ValueError):
+        xe.structure_loss("risk", a, seq, g["scores"], n, reduction="none")
+
+
 def test_loss_wrapper_xe_branch_vs_reference(weight_cache, manifest):
     """captioning.modules.loss_wrapper.LossWrapper (the drop-in mirror) around the drop-in model, train_mode UIC, struc_flag
     False: the seven entries of the out dict the REFERENCE's LossWrapper produced for the same batch."""

@@ -784,6 +784,37 @@ def test_forward_branches_on_streams_leave_the_step_unchanged(weight_cache, mani
     assert torch.isfinite(lg) and torch.isfinite(tb.bucket.grad).all()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_weight_gradients_beside_the_backward_leave_the_step_unchanged(weight_cache, manifest, graph):
+    """XETrainer.dw_every: the grouped weight-gradient launches started during the backward on a side stream (a few problems at a
+    time) against the two launches after the backward: same loss, same gradients up to the order of the float atomics, dropout on,
+    eager and as a forked branch of the captured step graph (two signatures, replays included)."""
+    from boficap_amd.collate import synthetic_training_batch
+    from boficap_amd.trainer import XETrainer
+    from boficap_amd.weights import synthetic_att_feats
+    cfg, a = _model(weight_cache, manifest, "tiny_train_xe")
+    _, b = _model(weight_cache, manifest, "tiny_train_xe")
+    for m in (a, b):
+        m.train()
+        m.train_dtype = torch.bfloat16
+        m.opt.seed = 5
+    ta, tb = XETrainer(a, graph=graph), XETrainer(b, graph=graph)
+    ta.dw_every, tb.dw_every = 0, 3
+    for step in range(4):
+        hb = synthetic_training_batch(cfg, 4, 3, seed=70 + step // 2)
+        batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
+        batch["att_feats"] = torch.from_numpy(synthetic_att_feats(4, 36, cfg.att_feat_size, seed=19 + step)).cuda()
+        batch["max_phrase_num"] = int(hb["phrase_num"].max())
+        batch["max_tokens"] = int((hb["phrase_length"].sum(-1) - 1).max())
+        la, pa = ta.forward_backward(ta.add_token_rows(batch, hb))
+        lb, pb = tb.forward_backward(tb.add_token_rows(batch, hb))
+        torch.cuda.synchronize()
+        assert tb._dw_stream is not None and ta._dw_stream is None
+        assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la))), step
+        assert _maxdiff(tb.bucket.grad, ta.bucket.grad) <= 4e-4 * max(1e-3, float(ta.bucket.grad.abs().max())), step
+        assert float((tb.bucket.grad - ta.bucket.grad).abs().mean()) <= 2e-6 * max(1e-3, float(ta.bucket.grad.abs().max())), step
+
+
 def test_bucket_weight_operands_match_per_use_casts(weight_cache, manifest):
     """WeightOperands (bf16 copy of the bucket kept by the optimiser kernel, all transposed weights from one launch) against
     the per-use casts / transposes: same loss and gradients step after step, the copy follows the optimiser and notices

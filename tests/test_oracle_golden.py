@@ -167,6 +167,36 @@ def test_oracle_self_critical_losses(manifest):
             assert _close(ls.grad.gather(2, t("saic_seq").unsqueeze(2)).squeeze(2).numpy(), g["lw_kl_grad_saic_picked"], 1e-7)
 
 
+def _structure_loss_cases(g):
+    for key in list(g):
+        if key.endswith("_loss") and key != "reward":
+            tag = key[:-5]
+            ent = float(g[tag + "_entropy_weight"])
+            body = tag[:-4] if tag.endswith("_ent") else tag
+            loss_type, reduction = body.rsplit("_", 1)
+            yield tag, loss_type, reduction, ent
+
+
+def test_oracle_structure_loss_types(manifest):
+    """Every structure_loss_type of StructureLosses (losses.py:72-176), reductions and the entropy reward: loss, reward and the gradient
+    at the sampled ids as recorded from the reference's own code (tests/golden/tiny_structure_losses; the fixture also records that
+    the reference as shipped raises NameError for every type but new_self_critical)."""
+    g = load_golden("tiny_structure_losses")
+    n = int(g["sample_n"])
+    assert sorted(g["reference_raises_name_error"].tolist()) == sorted(t for t in O.STRUCTURE_LOSS_TYPES if t != "new_self_critical")
+    seq = torch.from_numpy(g["seq"])
+    cases = list(_structure_loss_cases(g))
+    assert {c[1] for c in cases} == set(O.STRUCTURE_LOSS_TYPES) and len(cases) == 12
+    for tag, loss_type, reduction, ent in cases:
+        a = torch.from_numpy(g["logprob"]).clone().requires_grad_(True)
+        loss, reward = O.structure_loss(loss_type, a, seq, g["scores"], n, reduction=reduction, entropy_reward_weight=ent)
+        assert np.allclose(loss.detach().numpy(), g[tag + "_loss"], rtol=1e-5, atol=1e-6), tag
+        assert np.allclose(reward.numpy(), g["reward"])
+        w = torch.linspace(0.5, 1.5, loss.numel()).view_as(loss) if reduction == "none" else None
+        ((loss * w).sum() if w is not None else loss).backward()
+        assert _close(a.grad.gather(2, seq.unsqueeze(2)).squeeze(2).numpy(), g[tag + "_grad_picked"], 1e-6), tag
+
+
 def test_oracle_loss_wrapper_xe_branch(manifest, weight_cache):
     """LossWrapper.forward (train_mode UIC, struc_flag False): the seven entries of its out dict."""
     m = manifest["tiny_loss_wrapper_xe"]

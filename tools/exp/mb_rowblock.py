@@ -93,11 +93,64 @@ def gemm(M, N, f32out):
     print(f"linear_block M {M:6d} N {N:5d} {'f32 ' if f32out else 'bf16'}: {t:7.2f} us  {2.0 * M * d * N / t * 1e-6:7.1f} TFLOP/s", flush=True)
 
 
+def encoder(B, R=36, nlayers=6):
+    """rb_encoder_kernel: the whole encoder stack as one launch (random weights, timing only)."""
+    import ctypes as C
+    rot = 4
+    xs = [torch.randn(B * R, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(B * R, d, device=dev) for _ in range(rot)]
+    keep, arrs = [], {k: [] for k in ("wqkv", "cqkv", "csqkv", "wo", "bo", "w1", "c1", "cs1", "w2", "b2")}
+    for _ in range(nlayers):
+        wqkv = (torch.randn(3 * d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        wo = (torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+        t = {"wqkv": pack(wqkv), "cqkv": torch.randn(3 * d, device=dev) * 0.1, "csqkv": wqkv.float().sum(1), "wo": pack(wo), "bo": torch.randn(d, device=dev) * 0.1,
+             "w1": pack(w1), "c1": torch.randn(dff, device=dev) * 0.1, "cs1": w1.float().sum(1), "w2": pack(w2), "b2": torch.randn(d, device=dev) * 0.1}
+        keep.append(t)
+        for k, v in t.items():
+            arrs[k].append(H.ptr(v))
+    ptrs = {k: (C.c_void_p * nlayers)(*v) for k, v in arrs.items()}
+    klen = torch.full((B,), R, dtype=torch.int32, device=dev)
+
+    def run(i):
+        H.check(H.lib().bofi_encoder_block(H.ptr(xs[i]), H.ptr(ys[i]), H.ptr(klen), B, R, nlayers, ptrs["wqkv"], ptrs["cqkv"], ptrs["csqkv"], ptrs["wo"], ptrs["bo"],
+                                           ptrs["w1"], ptrs["c1"], ptrs["cs1"], ptrs["w2"], ptrs["b2"], dff, H.stream_ptr()))
+    t = timed(run, iters=20, rot=rot)
+    fl = nlayers * 2.0 * B * R * d * (3 * d + d + 2 * dff)
+    print(f"encoder_block B {B:4d} R {R} layers {nlayers}: {t:8.2f} us  {fl / t * 1e-6:7.1f} TFLOP/s  weight stream {nlayers * 6.29e6 / t * 1e-3:6.1f} GB/s per workgroup", flush=True)
+
+
+def train_shapes():
+    """The XE step's forward / dX shapes (K = 512): the tiled GEMM (bf16 operand in, float32 out) against the row-block projection
+    kernel (float32 stream in with the LayerNorm fold, float32 / bf16 out)."""
+    rot = 4
+    for M in (5120, 2304):
+        for N in (512, 1536, 2048):
+            xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+            xbs = [x.bfloat16() for x in xs]
+            w = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+            wp, c, cs = pack(w), torch.randn(N, device=dev), w.float().sum(1)
+            y32 = [torch.empty(M, N, device=dev) for _ in range(rot)]
+            y16 = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+            t_tiled = timed(lambda i: H.check(H.lib().bofi_linear(H.ptr(xbs[i]), H.dtype_code(xbs[i]), d, H.ptr(w), H.dtype_code(w), H.ptr(c), None, N, H.ptr(y32[i]), 0, N,
+                                                                  M, N, d, 0, None, 0, H.stream_ptr())), rot=rot)
+            t_rb32 = timed(lambda i: H.check(H.lib().bofi_linear_block(H.ptr(xs[i]), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(y32[i]), N, 1, M, N, 0, H.stream_ptr())), rot=rot)
+            t_rb16 = timed(lambda i: H.check(H.lib().bofi_linear_block(H.ptr(xs[i]), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(y16[i]), N, 0, M, N, 0, H.stream_ptr())), rot=rot)
+            print(f"M {M:5d} N {N:5d} K 512: tiled bf16->f32 {t_tiled:6.2f} us | row-block f32->f32 {t_rb32:6.2f} us | row-block f32->bf16 {t_rb16:6.2f} us", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
     if what == "ffn":
         for M in (11520, 6400, 2304, 1280, 64):
             ffn(M)
+    elif what == "train":
+        train_shapes()
+    elif what == "enc":
+        for B in (320, 512, 64, 2):
+            encoder(B)
+        encoder(320, nlayers=1)
     elif what == "gemm":
         for M, N, f in ((11520, 1536, False), (6400, 1536, False), (6400, 512, False), (11520, 7168, False), (6400, 9600, True), (64, 1536, False), (64, 9600, True)):
             gemm(M, N, f)

@@ -22,6 +22,8 @@ _s = TransformerModel._sample
 def sample(self, fc, att, masks=None, opt={}):
     return timed("sample_" + opt.get("train_mode", "?"), _s)(self, fc, att, masks, opt)
 TransformerModel._sample = sample
+if hasattr(TransformerModel, "sample_pair"):
+    TransformerModel.sample_pair = timed("sample_pair", TransformerModel.sample_pair)
 T.XETrainer._rl_replay = timed("grad_graph", T.XETrainer._rl_replay)
 T.XETrainer.reduce_and_step = timed("reduce_and_step", T.XETrainer.reduce_and_step)
 import boficap_amd.xe as xe
