@@ -54,12 +54,19 @@ def dist_setup(args):
     world = max(world, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BOFI_BENCH_REHEARSAL=1 (tests, one-GPU boxes): every rank on device 0 over gloo -- RCCL refuses two ranks on one device.  It walks the
+    # whole N > 1 path of this script (self-launch, sharding, barriers, the max over ranks, the XE exchange secondary); its numbers mean nothing
+    # and the line says so (config.rehearsal)
+    rehearsal = os.environ.get("BOFI_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=dev)    # RCCL
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)    # RCCL
     return rank, local_rank, world, dev
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense TFLOP/s, MI355X_MICROARCH.md
 
@@ -849,6 +856,8 @@ def main():
                 if rank == 0 and res is not None:
                     res.setdefault("secondary", {})["xe_config3_dp"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and res is not None:
+        if os.environ.get("BOFI_BENCH_REHEARSAL") == "1":
+            res["config"]["rehearsal"] = "all ranks on one device over gloo: a walk through the N > 1 code path, not a measurement"
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -11,10 +11,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=ROOT)
+def _run(*flags, env=None):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    lines = [l for l in out.stdout.strip().splitlines() if l.strip() and not l.startswith("[Gloo]")]     # (the rehearsal's transport announces itself on stdout)
     assert len(lines) == 1, lines[:3]                          # progress goes to stderr
     return json.loads(lines[-1])
 
@@ -43,3 +44,17 @@ def test_bench_odd_step_counts_and_one_batch_per_launch():
     assert d["steps"] == 7 and d["config"]["batches_per_launch"] == 1 and d["value"] > 0
     d = _run("--steps", "8", "--warmup", "2", "--inflight", "1", "--coalesce", "1", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--ids-only")
     assert d["config"]["decodes_in_flight"] == 1 and d["config"]["seq_logprob_materialised"] is False
+
+
+def test_bench_two_ranks_walk_the_multi_gpu_path_on_one_device():
+    """`python bench.py --gpus 2` as the driver starts it (self-launch through torch.distributed.run, one process per rank), rehearsed on
+    the one GPU of the box: both ranks on device 0 over gloo (RCCL refuses two ranks on one device).  Checks what a scaling run needs:
+    ONE line from rank 0, n_gpus 2, value = the images of BOTH ranks over the slowest rank's time, and the XE exchange secondary."""
+    d = _run("--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-gemm-roofline", "--no-from-host",
+             env={"BOFI_BENCH_REHEARSAL": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d["config"]
+    assert abs(d["value"] - 2 * 64 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]       # whole-job aggregate: 64 images per rank and step
+    dp = d["secondary"]["xe_config3_dp"]
+    assert "error" not in dp, dp
+    assert dp["rccl_ranks"] == 2 and dp["fp32_ring_all_reduce"]["step_ms"] > 0 and dp["bf16_mesh_direct"]["step_ms"] > 0
+    assert dp["fp32_ring_all_reduce"]["exchanged_bytes_per_rank"] == 2 * dp["bf16_mesh_direct"]["exchanged_bytes_per_rank"]
