@@ -32,7 +32,8 @@ batch = tr.add_token_rows(batch, hb)
 for _ in range(3):
     tr._forward_backward_eager(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     tr._forward_backward_eager(batch)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
@@ -43,10 +44,17 @@ for ev in prof.events():
     if own <= 0:
         continue
     frame = "?"
-    for fr in ev.stack or []:
-        if "boficap_amd" in fr or "captioning/" in fr:
-            frame = fr.split("/")[-1]
-            break
+    node = ev
+    while node is not None and frame == "?":                     # the op's own stack, else its callers' (autograd nodes run under backward())
+        for fr in node.stack or []:
+            if "boficap_amd" in fr or "captioning/" in fr:
+                frame = fr.split("/")[-1]
+                break
+        if frame == "?" and not (node.stack or []):
+            nm = getattr(node.cpu_parent, "name", None)
+            if nm and not nm.startswith("aten::"):
+                frame = "under " + nm[:60]
+        node = node.cpu_parent
     key = (ev.name, tuple(k.name[:40] for k in ev.kernels)[:1], frame)
     agg[key][0] += 1
     agg[key][1] += own
