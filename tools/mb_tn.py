@@ -25,7 +25,8 @@ for M, NI, NJ in ((6400, 512, 512), (6400, 1536, 512), (6400, 2048, 512), (6400,
 
 # the step's weight gradients as ONE grouped call (bofi_gemm_tn_grouped): 24 decoder-sized problems
 import ctypes as C
-probs = [(5120, 512, 512)] * 12 + [(5120, 1536, 512)] * 4 + [(5120, 2048, 512)] * 4 + [(5120, 512, 2048)] * 4
+MBM = int(os.environ.get("MB_M", "5120"))                    # rows of the grouped problems (half the rows = half the loop, the same epilogue)
+probs = [(MBM, 512, 512)] * 12 + [(MBM, 1536, 512)] * 4 + [(MBM, 2048, 512)] * 4 + [(MBM, 512, 2048)] * 4
 ts = [(torch.randn(M, NI, device="cuda").bfloat16(), torch.randn(M, NJ, device="cuda").bfloat16(), torch.zeros(NI, NJ, device="cuda")) for M, NI, NJ in probs]
 n = len(probs)
 vp, ci = C.c_void_p * n, C.c_int * n
@@ -44,4 +45,4 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 20
 fl = sum(2.0 * M * NI * NJ for M, NI, NJ in probs)
-print(f"grouped x{n}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  (BOFI_TN_DBG={os.environ.get('BOFI_TN_DBG', '0')}, BOFI_TN_WT={os.environ.get('BOFI_TN_WT', 'auto')})", flush=True)
+print(f"grouped x{n} M={MBM}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  (BOFI_TN_DBG={os.environ.get('BOFI_TN_DBG', '0')}, BOFI_TN_WT={os.environ.get('BOFI_TN_WT', 'auto')})", flush=True)
