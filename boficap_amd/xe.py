@@ -933,6 +933,19 @@ def bound_teacher_forced(P, cfg, drop, x_in, memory, kv_cache, N, L, R, spi, kle
     return len_lp.view(N, Pm, -1), syn_lp.view(N, Pm, -1)
 
 
+_ZERO_CONST: dict = {}
+
+
+def _zero_const(ref: torch.Tensor, *shape) -> torch.Tensor:
+    """A constant block of zeros (padding of a concatenation; never written, no gradient): made once per shape, not filled by a launch of its own
+    in every step."""
+    key = (ref.device, ref.dtype, shape)
+    z = _ZERO_CONST.get(key)
+    if z is None:
+        z = _ZERO_CONST[key] = torch.zeros(*shape, dtype=ref.dtype, device=ref.device)
+    return z
+
+
 def _bound_heads(P, drop, o):
     """Length / syntactic classifiers on the normalised [LEN] rows ``o`` [M, d] (LengthPredictor_UIC.forward TransformerModel.py:376-379)."""
     lp = "model.length_predictor"
@@ -942,14 +955,14 @@ def _bound_heads(P, drop, o):
     w1l, w1s = P[lp + ".Length_classifier1.weight"], P[lp + ".Syntactic_classifier1.weight"]
     hh = w1l.shape[0]
     Hp = _pad_k(2 * hh)
-    w1 = torch.cat([w1l, w1s, w1l.new_zeros(Hp - 2 * hh, d)], 0)
-    b1 = torch.cat([P[lp + ".Length_classifier1.bias"], P[lp + ".Syntactic_classifier1.bias"], w1l.new_zeros(Hp - 2 * hh)], 0)
+    w1 = torch.cat([w1l, w1s, _zero_const(w1l, Hp - 2 * hh, d)], 0)
+    b1 = torch.cat([P[lp + ".Length_classifier1.bias"], P[lp + ".Syntactic_classifier1.bias"], _zero_const(w1l, Hp - 2 * hh)], 0)
     hid = linear(o, w1, b1, relu=True)
     if drop.on and drop.p > 0.0:
         hid = drop(hid)
     w2l, w2s = P[lp + ".Length_classifier2.weight"], P[lp + ".Syntactic_classifier2.weight"]
-    w2l_p = torch.cat([w2l, w2l.new_zeros(w2l.shape[0], Hp - hh)], 1)
-    w2s_p = torch.cat([w2s.new_zeros(w2s.shape[0], hh), w2s, w2s.new_zeros(w2s.shape[0], Hp - 2 * hh)], 1)
+    w2l_p = torch.cat([w2l, _zero_const(w2l, w2l.shape[0], Hp - hh)], 1)
+    w2s_p = torch.cat([_zero_const(w2s, w2s.shape[0], hh), w2s, _zero_const(w2s, w2s.shape[0], Hp - 2 * hh)], 1)
     len_lp = log_softmax(linear(hid, w2l_p, P[lp + ".Length_classifier2.bias"]))
     syn_lp = log_softmax(linear(hid, w2s_p, P[lp + ".Syntactic_classifier2.bias"]))
     return len_lp, syn_lp
