@@ -1607,10 +1607,20 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
         phrase_length = phrase_length.reshape(-1, phrase_length.shape[2])
         phrase_syn = phrase_syn.reshape(-1, phrase_syn.shape[2])
     phrase_num, phrase_length, phrase_syn = phrase_num.to(dev).long(), phrase_length.to(dev).long(), phrase_syn.to(dev).long()
+    pair = isinstance(token_weight, (tuple, list))             # both branches in one tensor (_forward_paired): (SA weights, NA weights)
+    if pair:
+        if sa_tok is not na_tok:
+            raise hip.BofiHipError("a pair of token weights goes with the paired log-probs of _forward_paired")
+        made = getattr(sa_tok, "_bofi_picked", None)              # picked inside the forward (HINTS["pick_labels"]): fused backward
+        if made is not None and made[1] is token_labels and sa_len.dim() == 3 and sa_len.shape[1] + 1 <= phrase_length.shape[1]:
+            # everything the criterion needs is at hand as small tensors: one launch (and one in the backward); the slot masks and the
+            # token count of the general form below are not even made
+            loss, parts = UicCriterionFn.apply(sa_len, sa_syn, na_len, na_syn, made[0], phrase_num, phrase_length, phrase_syn,
+                                               token_weight[0], token_weight[1])
+            return loss.squeeze(0), list(parts.unbind(0))
     slot = torch.arange(phrase_length.shape[1] - 1, device=dev).unsqueeze(0)
     slot_mask = slot < phrase_num.unsqueeze(1)
     len_lab, syn_lab = phrase_length[:, 1:], phrase_syn[:, 1:]
-    pair = isinstance(token_weight, (tuple, list))             # both branches in one tensor (_forward_paired): (SA weights, NA weights)
     denom = token_weight[0].sum() if pair else token_weight.sum()
 
     def nll(lp, lab, mask):
@@ -1621,14 +1631,6 @@ def criterion_uic_compact(outs, phrase_num, phrase_length, phrase_syn, token_lab
         return (-lp.gather(1, token_labels.unsqueeze(1)).squeeze(1) * token_weight).sum() / denom
 
     if pair:
-        if sa_tok is not na_tok:
-            raise hip.BofiHipError("a pair of token weights goes with the paired log-probs of _forward_paired")
-        made = getattr(sa_tok, "_bofi_picked", None)              # picked inside the forward (HINTS["pick_labels"]): fused backward
-        if made is not None and made[1] is token_labels and sa_len.dim() == 3 and sa_len.shape[1] + 1 <= phrase_length.shape[1]:
-            # everything the criterion needs is at hand as small tensors: one launch (and one in the backward)
-            loss, parts = UicCriterionFn.apply(sa_len, sa_syn, na_len, na_syn, made[0], phrase_num, phrase_length, phrase_syn,
-                                               token_weight[0], token_weight[1])
-            return loss.squeeze(0), list(parts.unbind(0))
         if made is not None and made[1] is token_labels:
             picked = -made[0]
         else:
