@@ -119,6 +119,10 @@ struct RbFfnArgs {
     uint16_t* yb; float* stats_out;           // optional: bf16 copy [M][512], partial sums [M][16][2]
     int M, dff;
     int dbg;                                  // developer aid (BOFI_RB_DBG & 16): in-kernel stamps
+    // optional: a LayerNorm-folded projection of the sublayer's OUTPUT rows in the same launch (the next layer's q|k|v): the block of new rows
+    // stays in LDS -- no second launch, no re-staging of the float32 stream.  pwp = fragment-major [pN][512] (NULL: off), pc / pcs its folded bias
+    // and column sums, py bf16 [M][pldy], pN % 64 == 0.  Same values as launch_rb_gemm on y, bit for bit.
+    const rb_u32x4* pwp; const float* pc; const float* pcs; void* py; int pldy; int pN;
 };
 struct RbAttnArgs {
     const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64

@@ -386,12 +386,26 @@ struct bofi_engine {
         static const bool on = env_on("BOFI_RB_FFN");
         return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560 && M >= rb_min_rows();
     }
-    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s) {
+    // next / next_y / next_ldy: the LayerNorm-folded projection that reads this sublayer's output rows (the next layer's q|k|v), run in the same
+    // launch while the rows are still in LDS (ffn_next_ok); the caller then skips its own launch of that projection
+    bool ffn_next_ok(const Lin& w1, const Lin& w2, const Lin& next, int M) const {
+        // BOFI_RB_FFN_NEXT=1 turns it on (re-read after bofi_reload_env).  OFF by default: exact (tests/test_gpu_rowblock.py) and 5 us faster than the two
+        // launches alone, but slower in the decode -- 200.5 k against 204.5 k img/s, 0.554 against 0.546 ms per batch one at a time
+        // (profiles/r03_ffn_next_projection.txt): the fused kernel's main loop runs 6 % slower (the compiler allocates registers for its largest
+        // phase) and its closing epilogue 11 k ticks longer, which is what staging the block from memory cost in the first place
+        static int gen = -1, on = 0;
+        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_FFN_NEXT"); on = e ? atoi(e) : 0; gen = bofi::g_env_generation; }
+        static const int version = [] { const char* e = getenv("BOFI_RB_FFN_V"); return e ? atoi(e) : 2; }();
+        return on && version == 2 && cfg.d_ff == 2048 && ffn_sublayer_ok(w1, w2, M) && fold_rb_ok(next, M) && next.Npad % 64 == 0 && !exp_skip("ffn") && !exp_skip("qkv");
+    }
+    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s, const Lin* next = nullptr, void* next_y = nullptr,
+                     int next_ldy = 0) {
         if (!ffn_sublayer_ok(w1, w2, M)) return -1;
         if (exp_skip("ffn")) return BOFI_OK;
         bofi::RbFfnArgs a{};
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
+        if (next) { a.pwp = (const bofi::u32x4*)next->wp; a.pc = next->b; a.pcs = next->cs; a.py = next_y; a.pldy = next_ldy; a.pN = next->Npad; }
         return bofi::launch_rb_ffn(a, s);
     }
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
@@ -424,10 +438,14 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
     }
     const void* xa = stream_t(x_enc, xb_enc);
     const bool memory_out_needs_copy = false;           // (memory_out is a LayerNorm of the float32 stream itself)
-    for (auto& l : enc) {
-        {   int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
+    bool qkv_made = false;                               // this layer's q|k|v came out of the previous layer's feed-forward launch
+    for (size_t li = 0; li < enc.size(); ++li) {
+        auto& l = enc[li];
+        if (!qkv_made) {
+            int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
             if (rc > 0) return rc;
             if (rc < 0) { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
+        qkv_made = false;
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
@@ -442,7 +460,9 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         }
         {   // the consumers of this layer's output: the next layer's q|k|v (or the stacked cross K|V): tiled GEMMs read the copy + statistics
             const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;
-            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s) : -1; }
+            const Lin* next = (li + 1 < enc.size() && l.qkv.Npad == 3 * d && ffn_next_ok(l.w1, l.w2, enc[li + 1].qkv, M)) ? &enc[li + 1].qkv : nullptr;
+            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s, next, qkv, 3 * d) : -1;
+            qkv_made = rc == BOFI_OK && next != nullptr; }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -569,11 +589,14 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     for (int round = 0; round < rounds; ++round) {
     ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                    st_fill, s));
+    bool qkv_made = false;                               // this layer's q|k|v came out of the previous layer's feed-forward launch
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
-        {   int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
+        if (!qkv_made) {
+            int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
             if (rc > 0) return rc;
             if (rc < 0) { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
+        qkv_made = false;
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
@@ -606,7 +629,9 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         }
         {   // next consumer: the next layer's q|k|v or the generator
             const bool need_copy = !(fold_rb_ok(l.qkv, M) && gen_rb);
-            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s) : -1; }
+            const Lin* next = (li + 1 < dec.size() && ffn_next_ok(l.w1, l.w2, dec[li + 1].qkv, M)) ? &dec[li + 1].qkv : nullptr;
+            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s, next, qkv, 3 * d) : -1;
+            qkv_made = rc == BOFI_OK && next != nullptr; }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }

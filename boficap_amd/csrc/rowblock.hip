@@ -140,6 +140,76 @@ __device__ __forceinline__ void rb_pass_store(const unsigned char* stage, const 
     }
 }
 
+// rb_pass_store that ALSO leaves the new rows in LDS for a projection fused behind the sublayer (rb_ffn2_kernel<true>): bf16, in the block
+// layout rb_segment reads (nblk), with the row statistics of the LayerNorm fold in s_mean / s_rstd -- summed in the order rb_gemm_kernel's
+// staging sums them (a lane group's 16 four-column pieces, 32 columns apart, one after the other; then the 8 lane groups as oct_sum does), so
+// that the fused projection equals rb_gemm_kernel on the stored rows bit for bit.  sc: 2 KiB of LDS of this wavefront's own ([4 rows][16
+// pieces][8 lane groups] floats: lanes 0-31 then each walk one (row, lane group) chain).
+template <int RPW>
+__device__ __forceinline__ void rb_pass_store_blk(const unsigned char* stage, const RbOut& o, int prow0, int pass_rows, int m0, int rows_live, int wave, int lane,
+                                                  const float4 (&res)[RPW][2], unsigned char* nblk, unsigned char* sc, float* s_mean, float* s_rstd) {
+    static_assert(RPW == 4, "the statistics scratch is laid out for four rows per wavefront and pass");
+    float* scf = reinterpret_cast<float*>(sc);
+    float ps[RPW][2], pq[RPW][2];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int lr = wave * RPW + j, r = prow0 + lr;             // row of the pass / of the block
+        const bool live = lr < pass_rows && r < rows_live;
+        const float4 s0 = *reinterpret_cast<const float4*>(stage + lr * RB_SPITCH + lane * 16);
+        const float4 s1 = *reinterpret_cast<const float4*>(stage + lr * RB_SPITCH + 1024 + lane * 16);
+        float4 o0 = make_float4(res[j][0].x + s0.x, res[j][0].y + s0.y, res[j][0].z + s0.z, res[j][0].w + s0.w);
+        float4 o1 = make_float4(res[j][1].x + s1.x, res[j][1].y + s1.y, res[j][1].z + s1.z, res[j][1].w + s1.w);
+        const size_t m = live ? (size_t)(m0 + r) : 0;
+        if (live) {
+            float* yr = o.y + m * o.ldy + lane * 4;
+            *reinterpret_cast<float4*>(yr) = o0;
+            *reinterpret_cast<float4*>(yr + 256) = o1;
+            if (o.yb) {
+                *reinterpret_cast<uint2*>(o.yb + m * 512 + lane * 4) = make_uint2(pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w));
+                *reinterpret_cast<uint2*>(o.yb + m * 512 + 256 + lane * 4) = make_uint2(pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w));
+            }
+        } else {                                                  // rows past the batch: zeros, as rb_gemm_kernel stages them
+            o0 = make_float4(0.f, 0.f, 0.f, 0.f); o1 = o0;
+        }
+        if (o.stats) {
+            const float a0 = oct_sum((o0.x + o0.y) + (o0.z + o0.w)), q0 = oct_sum((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w));
+            const float a1 = oct_sum((o1.x + o1.y) + (o1.z + o1.w)), q1 = oct_sum((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
+            if (live && !(lane & 7)) {
+                float2* sp = reinterpret_cast<float2*>(o.stats + m * 32);
+                sp[lane >> 3] = make_float2(a0, q0);
+                sp[8 + (lane >> 3)] = make_float2(a1, q1);
+            }
+        }
+        // columns lane*4 .. +3 and 256 + lane*4 .. +3: 16-byte chunks lane >> 1 and 32 + (lane >> 1), half lane & 1
+        *reinterpret_cast<uint2*>(nblk + rb_off(r, lane >> 1) + (lane & 1) * 8) = make_uint2(pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w));
+        *reinterpret_cast<uint2*>(nblk + rb_off(r, 32 + (lane >> 1)) + (lane & 1) * 8) = make_uint2(pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w));
+        ps[j][0] = (o0.x + o0.y) + (o0.z + o0.w); pq[j][0] = (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w);
+        ps[j][1] = (o1.x + o1.y) + (o1.z + o1.w); pq[j][1] = (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
+    }
+    // lane = piece (lane >> 3) of lane group (lane & 7); its second value is piece 8 + (lane >> 3): offsets lane and 64 + lane of the row's 128
+    const int rr = (lane >> 3) & 3, sub = lane & 7;
+    float tot[2];
+#pragma unroll
+    for (int what = 0; what < 2; ++what) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) { scf[j * 128 + lane] = what ? pq[j][0] : ps[j][0]; scf[j * 128 + 64 + lane] = what ? pq[j][1] : ps[j][1]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float t = 0.f;
+#pragma unroll
+        for (int pc = 0; pc < 16; ++pc) t += scf[rr * 128 + pc * 8 + sub];
+        tot[what] = oct_sum(t);
+        __builtin_amdgcn_wave_barrier();                          // (the second round reuses the scratch)
+    }
+    if (lane < 32 && sub == 0) {
+        const int r = prow0 + wave * RPW + rr;
+        const float mean = tot[0] * (1.0f / 512.0f);
+        const float var = fmaxf((tot[1] - tot[0] * mean) * (1.0f / 511.0f), 0.f);
+        s_mean[r] = mean;
+        s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(512) void rb_ffn_kernel(RbFfnArgs a) {
@@ -261,6 +331,11 @@ __device__ __forceinline__ void rb_signal(unsigned* flag, int lane) {      // be
     if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+template <bool F32OUT>
+__device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsigned char* blk, unsigned char* stage_all, float* cst, const float* s_mean,
+                                               const float* s_rstd, int m0, int wave, int lane, int ch0, int chstep, bf16x8 (&wb)[RB_PF * 4]);      // (below, with rb_gemm_kernel)
+
+template <bool PROJ>
 __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;                                  // [64][512] bf16, swizzled, row pitch 1 024 B
@@ -391,7 +466,13 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
         }
     }
     __syncthreads();                                           // every hidden chunk consumed: x block and ring are dead
+    RB_STAMP(a.dbg, 8 + wave, lane, 4);
 
+    // PROJ: a projection of the NEW rows follows in this launch.  LDS from here on: [0, 66 048) the float32 row staging of the passes, then
+    // the projection's per-wavefront 9 KB; [73 728, 139 264) the new rows as a bf16 block (over the dead hidden ring and c1s);
+    // [139 264, 147 456) and [154 624, 162 816) 2 KiB of statistics scratch per wavefront (the first over the dead cs1s); b2s / s_mean / s_rstd /
+    // flags stay; column constants of the projection at 150 528.  (dff = 2 048: the launcher checks.)
+    unsigned char* nblk = smem + 73728;
     // ---- closing epilogue (as rb_ffn_kernel): the consumers stage their tiles, all eight wavefronts store whole rows
     const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
     const int rows_live = min(64, a.M - m0);
@@ -409,8 +490,22 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
             }
         }
         __syncthreads();
-        rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
-        if (ps == 0) __syncthreads();
+        RB_STAMP(a.dbg, 8 + wave, lane, 5 + 2 * ps);            // (5, 7: tiles staged; 6: first pass stored)
+        if constexpr (PROJ) rb_pass_store_blk<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res, nblk, smem + (wave < 4 ? 139264 : 154624 - 8192) + wave * 2048, s_mean, s_rstd);
+        else rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
+        if (ps == 0) { RB_STAMP(a.dbg, 8 + wave, lane, 6); __syncthreads(); }
+    }
+    if constexpr (!PROJ) RB_STAMP(a.dbg, 8 + wave, lane, 2);
+    if constexpr (PROJ) {
+        RB_STAMP(a.dbg, 8 + wave, lane, 2);                    // rows stored (the chunk stamps 0 .. 5 of the wavefront's row are the projection's from here on)
+        __syncthreads();                                       // the new block and its statistics are complete; the row staging area is free
+        RB_STAMP(a.dbg, 8 + wave, lane, 3);                    // projection starts
+        // (inlined: as a real call -- __attribute__((noinline)) -- the projection costs the sublayer's main loop 25 %, inlined 6 %: the register
+        // allocation of the whole kernel follows its largest phase)
+        RbGemmArgs pj{};
+        pj.wp = a.pwp; pj.c = a.pc; pj.cs = a.pcs; pj.y = a.py; pj.ldy = a.pldy; pj.y_f32 = 0; pj.M = a.M; pj.N = a.pN; pj.relu = 0; pj.dbg = a.dbg;
+        if (wave < (pj.N >> 6)) rb_prime<4>(pj.wp + (size_t)wave * (16 * 256) + lane, wbuf);
+        rb_gemm_chunks<false>(pj, nblk, smem, reinterpret_cast<float*>(smem + 150528), s_mean, s_rstd, m0, wave, lane, wave, 8, wbuf);
     }
     RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // exit
 }
@@ -423,14 +518,20 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return BOFI_ERR_HIP;
         attr_set = true;
     }
     RbFfnArgs b = a;
     { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
-    if (version == 1) hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
-    else hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    if (a.pwp) {                                               // with the projection of the new rows behind it (rb_ffn2_kernel<true>: its LDS map assumes dff = 2 048)
+        if (version == 1 || a.dff != 2048 || !a.pc || !a.pcs || !a.py || a.pN < 64 || a.pN % 64 || a.pldy % 8) return BOFI_ERR_ARG;
+        hipLaunchKernelGGL(rb_ffn2_kernel<true>, dim3((a.M + 63) / 64), dim3(512), 162816, st, b);
+        g_gemm_flops += 2.0 * a.M * 512.0 * a.pN;
+    }
+    else if (version == 1) hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    else hipLaunchKernelGGL(rb_ffn2_kernel<false>, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
     g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
@@ -693,55 +794,17 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// y[M][N] = epilogue(LN(x) . W^T) for K = 512 and any N % 64 == 0: the LayerNorm-folded projections of the path (q|k|v, the
-// cross-attention queries, the stacked cross K|V of all layers, the generator) as a row-block kernel: the 64-row block of the residual
-// stream is staged once (float32 -> bf16, row statistics on the way: no bf16 copy and no statistics from the producer), the eight
-// wavefronts take the 64-column chunks w, w + 8, ... of the weight (any chunk count), 16 k-steps each, and there is NO workgroup
-// barrier after the staging: a wavefront's epilogue (fold, bias, rounding, its own 9 KB of LDS to turn the accumulator layout into whole
-// 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs.  x may also be bf16 with no fold (plain bias).
-
+// The column loop of the LayerNorm-folded projection over a staged block (rb_gemm_kernel, and rb_ffn2_kernel's fused projection): the
+// wavefront takes the 64-column chunks ch0, ch0 + chstep, ... of the weight, 16 k-steps each; its epilogue (fold, bias, rounding, its own
+// 9 KB of LDS to turn the accumulator layout into whole 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs -- no workgroup
+// barrier.  blk: the block (64 rows x 1 KiB, swizzled); wb: the ring, primed with chunk ch0's first steps.
 template <bool F32OUT>
-__global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
+__device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsigned char* blk, unsigned char* stage_all, float* cst, const float* s_mean,
+                                               const float* s_rstd, int m0, int wave, int lane, int ch0, int chstep, bf16x8 (&wb)[RB_PF * 4]) {
     constexpr int SP = F32OUT ? 272 : 144;                     // staging row pitch (bytes): 64 columns + 16 B
     constexpr int SROWS = F32OUT ? 32 : 64;                    // rows staged at a time
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xt = smem;
-    unsigned char* stage_all = smem + 65536;
-    float* s_mean = reinterpret_cast<float*>(smem + 65536 + 8 * 9216);
-    float* s_rstd = s_mean + 64;
-    float* cst = s_rstd + 64;                                  // per wavefront [2][64]: c | cs of the current chunk
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    // gridDim.y workgroups share a row block: workgroup y takes the chunk octets y, y + gridDim.y, ... (wide outputs on few row blocks:
-    // the generator's 2.4 MB of float32 logits per block leave a CU at ~25 GB/s -- two workgroups per block halve that tail)
-    const int m0 = blockIdx.x * 64, nchunks = a.N >> 6, ch0 = wave + 8 * blockIdx.y, chstep = 8 * gridDim.y;
+    const int l15 = lane & 15, g = lane >> 4, nchunks = a.N >> 6;
     auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
-    RB_STAMP(a.dbg, 8 + wave, lane, 0);                        // entry (rows 8-15: this kernel has 8 wavefronts)
-    bf16x8 wb[RB_PF * 4];
-    if (ch0 < nchunks) rb_prime<4>(seg(ch0), wb);
-    {   // stage the block (as rb_ffn_kernel)
-        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
-        float4 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float sm = 0.f, sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
-        }
-        sm = oct_sum(sm); sq = oct_sum(sq);
-        if (sub == 0) {
-            const float mean = sm * (1.0f / 512.0f);
-            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
-            s_mean[r] = mean;
-            s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
-        }
-    }
-    __syncthreads();
-    RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // block staged
     float mu[4], rs[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
@@ -760,7 +823,7 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb_segment<4, 4>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, smem, lbase, acc);
+        rb_segment<4, 4>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, blk, lbase, acc);
         if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp);            // chunk's MFMAs issued
         mycst[lane] = cv; mycst[64 + lane] = csv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -799,6 +862,56 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
         if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp + 1);        // chunk stored
         ++nstamp;
     }
+}
+
+// y[M][N] = epilogue(LN(x) . W^T) for K = 512 and any N % 64 == 0: the LayerNorm-folded projections of the path (q|k|v, the
+// cross-attention queries, the stacked cross K|V of all layers, the generator) as a row-block kernel: the 64-row block of the residual
+// stream is staged once (float32 -> bf16, row statistics on the way: no bf16 copy and no statistics from the producer), the eight
+// wavefronts take the 64-column chunks w, w + 8, ... of the weight (any chunk count), 16 k-steps each, and there is NO workgroup
+// barrier after the staging: a wavefront's epilogue (fold, bias, rounding, its own 9 KB of LDS to turn the accumulator layout into whole
+// 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs.  x may also be bf16 with no fold (plain bias).
+
+template <bool F32OUT>
+__global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;
+    unsigned char* stage_all = smem + 65536;
+    float* s_mean = reinterpret_cast<float*>(smem + 65536 + 8 * 9216);
+    float* s_rstd = s_mean + 64;
+    float* cst = s_rstd + 64;                                  // per wavefront [2][64]: c | cs of the current chunk
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // gridDim.y workgroups share a row block: workgroup y takes the chunk octets y, y + gridDim.y, ... (wide outputs on few row blocks:
+    // the generator's 2.4 MB of float32 logits per block leave a CU at ~25 GB/s -- two workgroups per block halve that tail)
+    const int m0 = blockIdx.x * 64, nchunks = a.N >> 6, ch0 = wave + 8 * blockIdx.y, chstep = 8 * gridDim.y;
+    auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
+    RB_STAMP(a.dbg, 8 + wave, lane, 0);                        // entry (rows 8-15: this kernel has 8 wavefronts)
+    bf16x8 wb[RB_PF * 4];
+    if (ch0 < nchunks) rb_prime<4>(seg(ch0), wb);
+    {   // stage the block (as rb_ffn_kernel)
+        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+        }
+        sm = oct_sum(sm); sq = oct_sum(sq);
+        if (sub == 0) {
+            const float mean = sm * (1.0f / 512.0f);
+            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+            s_mean[r] = mean;
+            s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+        }
+    }
+    __syncthreads();
+    RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // block staged
+    rb_gemm_chunks<F32OUT>(a, smem, stage_all, cst, s_mean, s_rstd, m0, wave, lane, ch0, chstep, wb);
     RB_STAMP(a.dbg, 8 + wave, lane, 2);                        // exit
 }
 
@@ -1244,6 +1357,15 @@ extern "C" int bofi_linear_block(const float* x, int ldx, const void* wp, const 
     a.x = x; a.ldx = ldx; a.wp = (const bofi::u32x4*)wp; a.c = c; a.cs = cs; a.y = y; a.ldy = ldy; a.y_f32 = y_f32; a.M = M; a.N = N; a.relu = relu;
     { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
     return bofi::launch_rb_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_ffn_proj_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,
+                                   int ldy, const void* pwp, const float* pc, const float* pcs, void* py, int pldy, int pN, int M, int dff, void* stream) {
+    if (!pwp) return BOFI_ERR_ARG;
+    bofi::RbFfnArgs a{};
+    a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
+    a.M = M; a.dff = dff; a.pwp = (const bofi::u32x4*)pwp; a.pc = pc; a.pcs = pcs; a.py = py; a.pldy = pldy; a.pN = pN;
+    return bofi::launch_rb_ffn(a, (hipStream_t)stream);
 }
 
 extern "C" int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,

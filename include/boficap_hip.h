@@ -397,6 +397,10 @@ int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const fl
  *   image of b's group of G (quirk Q1, TransformerModel.py:1872-1873); a row without keys is NaN as in the reference.
  *   wop = bofi_pack_frag of the [512, 512] output projection, bo float32 [512]; x, y float32 [B*Lq, 512] (y may be x); yb /
  *   stats_out as bofi_ffn_block.
+ * bofi_ffn_proj_block: bofi_ffn_block followed, in the SAME launch, by the LayerNorm-folded projection of the sublayer's output rows
+ *   (EncoderLayer / DecoderLayer: the feed-forward sublayer of layer l and the q|k|v projection of layer l + 1, TransformerModel.py:1408-1413,
+ *   1454-1456): py[M, pN] bf16 = W' LN(y) + b with pwp / pc / pcs as bofi_linear_block's wp / c / cs (pN % 64 == 0).  The new rows stay in LDS as
+ *   the projection's block: one launch, and no second pass over the float32 stream.  Bit for bit bofi_ffn_block then bofi_linear_block.  dff = 2048.
  * bofi_linear_block: y[M, N] = act(W' LN(x) + b) for a LayerNorm-folded projection with K = 512 (the q|k|v, cross-query, stacked cross K|V
  *   and generator projections: TransformerModel.py:1454-1456, AttModel.py:203-210 behind their pre-norms): x float32 [M, 512] -- the
  *   row statistics are computed in the kernel --, wp = bofi_pack_frag of the folded [N, 512] weight (N % 64 == 0), c / cs its folded
@@ -415,6 +419,8 @@ int bofi_encoder_block(const float* x, float* y, const int* klen, int B, int R, 
 int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen,
                     int klen_sb, int klen_sq, int klen_bias, int klen_shared_last, const void* wop, const float* bo, const float* x,
                     int ldx, float* y, int ldy, void* yb, float* stats_out, void* stream);
+int bofi_ffn_proj_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,
+                        int ldy, const void* pwp, const float* pc, const float* pcs, void* py, int pldy, int pN, int M, int dff, void* stream);
 int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
                    float* y, int ldy, void* yb, float* stats_out, int M, int dff, void* stream);
 

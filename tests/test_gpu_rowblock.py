@@ -100,6 +100,53 @@ def test_ffn_block_vs_reference_sublayer(H, M, dff):
     assert torch.equal(xc.cpu(), y.cpu())
 
 
+@pytest.mark.parametrize("M,N", [(64, 1536), (200, 1536), (6400, 1536), (130, 512), (11520, 1536), (77, 64)])
+def test_ffn_proj_block_equals_ffn_block_then_linear_block(H, M, N):
+    """bofi_ffn_proj_block: the feed-forward sublayer and the LayerNorm-folded projection of its output rows (the next layer's q|k|v) in one
+    launch = bofi_ffn_block followed by bofi_linear_block on the stored stream, BIT FOR BIT (the block's row statistics are summed in the
+    projection kernel's own order), ragged last blocks and a NaN row included; in place."""
+    d, dff = 512, 2048
+    g = _rng(M + N)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
+    if M > 70:
+        x[69] = float("nan")                                              # quirk Q1's fully masked image: its rows are NaN, the others untouched
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w1, b1 = torch.randn(dff, d, generator=g) / math.sqrt(d), torch.randn(dff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, dff, generator=g) / math.sqrt(dff), torch.randn(d, generator=g) * 0.1
+    g2, bl2 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    wp_, bp_ = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g) * 0.1
+    w1f, c1, cs1 = _fold(w1, b1, gain, bln)
+    wpf, cp, csp = _fold(wp_, bp_, g2, bl2)
+    w1p, w2p, wpp = pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda()), pack_frag(H, wpf.to(torch.bfloat16).cuda())
+    c1c, cs1c, b2c, cpc, cspc = c1.cuda(), cs1.cuda(), b2.cuda(), cp.cuda(), csp.cuda()
+    xc = x.cuda()
+    # separate launches
+    y_ref = torch.full((M, d), 3.0, device="cuda")
+    q_ref = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y_ref), d, None, None, M, dff, H.stream_ptr()))
+    H.check(H.lib().bofi_linear_block(H.ptr(y_ref), d, H.ptr(wpp), H.ptr(cpc), H.ptr(cspc), H.ptr(q_ref), N + 64, 0, M, N, 0, H.stream_ptr()))
+    # one launch
+    y = torch.full((M, d), 3.0, device="cuda")
+    q = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().bofi_ffn_proj_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y), d,
+                                        H.ptr(wpp), H.ptr(cpc), H.ptr(cspc), H.ptr(q), N + 64, N, M, dff, H.stream_ptr()))
+    torch.cuda.synchronize()
+    eq = lambda a, b: torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16), b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))
+    nan_rows = torch.isnan(y_ref).any(1)
+    assert int(nan_rows.sum()) == (1 if M > 70 else 0)
+    assert torch.equal(torch.isnan(y), torch.isnan(y_ref)) and eq(y[~nan_rows], y_ref[~nan_rows])
+    assert (q[:, N:] == 7.0).all() and (q_ref[:, N:] == 7.0).all()                                      # the pad columns stay untouched
+    assert torch.equal(torch.isnan(q), torch.isnan(q_ref)) and eq(q[~nan_rows], q_ref[~nan_rows])
+    assert bool(torch.isnan(q[nan_rows][:, :N]).all())
+    # in place
+    x2 = xc.clone()
+    q2 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().bofi_ffn_proj_block(H.ptr(x2), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(x2), d,
+                                        H.ptr(wpp), H.ptr(cpc), H.ptr(cspc), H.ptr(q2), N + 64, N, M, dff, H.stream_ptr()))
+    torch.cuda.synchronize()
+    assert eq(x2[~nan_rows], y_ref[~nan_rows]) and eq(q2[~nan_rows], q_ref[~nan_rows])
+
+
 def test_ffn_block_nan_row_stays_in_its_row(H):
     """A NaN row (quirk Q1's fully masked image) must not leak into the other rows of its block."""
     M, d, dff = 64, 512, 2048

@@ -140,11 +140,37 @@ def train_shapes():
             print(f"M {M:5d} N {N:5d} K 512: tiled bf16->f32 {t_tiled:6.2f} us | row-block f32->f32 {t_rb32:6.2f} us | row-block f32->bf16 {t_rb16:6.2f} us", flush=True)
 
 
+def ffn_proj(M, N=1536):
+    """The feed-forward sublayer + the next layer's q|k|v: two launches against the fused one."""
+    rot = 4
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
+    qs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+    w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+    wq = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    w1p, w2p, wqp = pack(w1), pack(w2), pack(wq)
+    c1, cs1, b2, cq, csq = torch.randn(dff, device=dev), w1.float().sum(1), torch.randn(d, device=dev), torch.randn(N, device=dev), wq.float().sum(1)
+
+    def two(i):
+        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, None, None, M, dff, H.stream_ptr()))
+        H.check(H.lib().bofi_linear_block(H.ptr(ys[i]), d, H.ptr(wqp), H.ptr(cq), H.ptr(csq), H.ptr(qs[i]), N, 0, M, N, 0, H.stream_ptr()))
+
+    def one(i):
+        H.check(H.lib().bofi_ffn_proj_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d,
+                                            H.ptr(wqp), H.ptr(cq), H.ptr(csq), H.ptr(qs[i]), N, N, M, dff, H.stream_ptr()))
+    t2, t1 = timed(two, rot=rot), timed(one, rot=rot)
+    print(f"ffn + projection N {N} M {M:6d}: two launches {t2:7.2f} us, one launch {t1:7.2f} us", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
     if what == "ffn":
         for M in (11520, 6400, 2304, 1280, 64):
             ffn(M)
+    elif what == "ffnp":
+        for M in (11520, 6400, 2304, 64):
+            ffn_proj(M)
     elif what == "train":
         train_shapes()
     elif what == "enc":
