@@ -117,6 +117,7 @@ struct bofi_engine {
     int q1_group = 0;                     // > 0: the call carries several independent batches of this many images (quirk Q1 per batch)
     float sample_temperature = 1.0f;      // BOFI_FLAG_SAMPLE: token draws inside the semi-autoregressive loop
     uint64_t sample_seed = 0;
+    int saic_it_begin = 1, saic_it_end = 0;   // iterations the next semi-autoregressive decode enqueues (bofi_engine_set_saic_range; end 0 = seq_length)
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
 
@@ -669,12 +670,19 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
                                      hipStream_t s) {
     const int d = cfg.d_model, dt = cfg.dtype, S = cfg.seq_length, M = B * S;
     const int* halt = st.counters + 2;
+    // iterations it_first .. it_last of the loop (bofi_engine_set_saic_range).  Every iteration past the last live one returns at once but still
+    // costs its ~60 launches' dispatch; a caller that knows how long its captions run enqueues fewer and, when the count of live iterations
+    // (bound_iters) says the loop may not be through, the REST in a second call: the loop's state lives in the workspace, so [1, c] then
+    // [c + 1, S] is the same computation as [1, S]
+    const int it_first = saic_it_begin > 1 ? saic_it_begin : 1, it_last = saic_it_end > 0 && saic_it_end < S ? saic_it_end : S;
+    if (it_first == 1) {
     ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, nullptr, s));
     ENG_OK(bofi::launch_saic_init(st, sa, B, L, cfg.pad_idx, cfg.bos_idx, cfg.len_idx, s));
     if (seq_logprob) ENG_OK(bofi::launch_zero_f32(seq_logprob, (size_t)M * cfg.vocab, s));   // seq_logprobs = zeros (:1883); not a memset node
+    }
     const void* xwa = stream_t(xw, xwb);
     const void* xa = stream_t(x_fill, xb_fill);
-    for (int it = 1; it <= S; ++it) {
+    for (int it = it_first; it <= it_last; ++it) {
         // From the second iteration on only the rows of the phrases placed in this iteration go through the decoder's GEMMs and the
         // vocabulary epilogue (row list; launch_saic_rows): a placed row's input, key set and therefore its K / V in every layer
         // never change again, later rows are never attended, and only the new phrase's rows are copied out (:1968-1977).  The
@@ -972,6 +980,15 @@ int bofi_engine_set_q1_group(bofi_engine_t* e, int group) {
     return BOFI_OK;
 }
 
+int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end) {
+    g_err.clear();
+    if (!e) return fail(BOFI_ERR_ARG, "null engine");
+    if (it_begin < 1 || it_begin > e->cfg.seq_length || it_end < 0 || (it_end > 0 && it_end < it_begin)) return fail(BOFI_ERR_ARG, "saic range: 1 <= begin <= end <= seq_length, or end 0");
+    e->saic_it_begin = it_begin;
+    e->saic_it_end = it_end;
+    return BOFI_OK;
+}
+
 int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed) {
     if (!e || !(temperature > 0.f)) return fail(BOFI_ERR_ARG, "temperature must be positive");
     e->sample_temperature = temperature;
@@ -1213,7 +1230,8 @@ int bofi_engine_decode_saic(bofi_engine_t* e, const void* feats, int feats_dtype
     uint32_t tbits; std::memcpy(&tbits, &e->sample_temperature, 4);
     std::vector<uintptr_t> key = {(uintptr_t)1, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
-                                  (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)bound_iters, (uintptr_t)tbits};
+                                  (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)bound_iters, (uintptr_t)tbits,
+                                  (uintptr_t)e->saic_it_begin, (uintptr_t)e->saic_it_end};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
                                       bound_iters, cs);

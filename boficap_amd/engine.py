@@ -198,15 +198,20 @@ class BofiEngine:
         return res
 
     def decode_saic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, raw_logits: bool = False,
-                    want_logprob: bool = True, sample: Optional[tuple] = None, graph: bool = False, out: Optional[dict] = None) -> dict:
+                    want_logprob: bool = True, sample: Optional[tuple] = None, graph: bool = False, out: Optional[dict] = None,
+                    it_range: Optional[tuple] = None) -> dict:
         """Semi-autoregressive decode (core_SAIC), greedy or -- ``sample=(temperature, seed)`` -- with every phrase's tokens
         drawn from Categorical(logits / temperature) (the bound heads stay greedy, as in the reference).  Same result
         layout as ``decode_naic``.  ``graph``: the launch sequence is captured once per argument set and replayed (pass the
         previous result as ``out`` and keep the inputs in place); the sampling seed is read from device memory, so replays
-        draw anew."""
+        draw anew.  ``it_range`` = (first, last) iterations of the loop (bofi_engine_set_saic_range): (1, c) enqueues c iterations,
+        (c + 1, S) with the same arguments and ``out`` continues that decode where it stopped -- together the whole loop, exactly;
+        ``out["bound_iters"]`` (live iterations so far) < c says the first part was all of it."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
+        if it_range is not None and (out is None and it_range[0] > 1):
+            raise hip.BofiHipError("a continued semi-autoregressive decode needs the first part's `out`")
         if out is None:
             out = dict(
                 seq=torch.empty(B, S, dtype=torch.int64, device=dev),
@@ -219,10 +224,15 @@ class BofiEngine:
         if sample is not None:
             hip.check(self._lib.bofi_engine_set_sampling(self._h, float(sample[0]), int(sample[1]) & 0xFFFFFFFFFFFFFFFF), "bofi_engine_set_sampling")
             flags |= hip.FLAG_SAMPLE
-        hip.check(self._lib.bofi_engine_decode_saic(
-            self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, flags,
-            hip.ptr(out["seq"]), hip.ptr(out["seq_logprob"]), hip.ptr(out["phrase_num"]), hip.ptr(out["phrase_length"]),
-            hip.ptr(out["phrase_syn"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_saic")
+        first, last = it_range if it_range is not None else (1, 0)
+        hip.check(self._lib.bofi_engine_set_saic_range(self._h, int(first), int(last) if last < S else 0), "bofi_engine_set_saic_range")
+        try:
+            hip.check(self._lib.bofi_engine_decode_saic(
+                self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, flags,
+                hip.ptr(out["seq"]), hip.ptr(out["seq_logprob"]), hip.ptr(out["phrase_num"]), hip.ptr(out["phrase_length"]),
+                hip.ptr(out["phrase_syn"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_saic")
+        finally:
+            self._lib.bofi_engine_set_saic_range(self._h, 1, 0)
         return out
 
     def encode(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -72,6 +72,7 @@ SIGNATURES = {
     "bofi_engine_refresh_device": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_I64), _P]),
     "bofi_engine_set_q1_group": (_I, [_P, _I]),
     "bofi_engine_set_sampling": (_I, [_P, C.c_float, C.c_uint64]),
+    "bofi_engine_set_saic_range": (_I, [_P, _I, _I]),
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),

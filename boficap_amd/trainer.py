@@ -736,24 +736,45 @@ class XETrainer:
         model.eval()                                           # sampling runs on the inference engine (no dropout)
         with torch.no_grad():
             if getattr(model.opt, "bofi_rl_sample_pair", True):
-                saic, naic = model.sample_pair(att_feats, att_masks, sample_n, temperature)    # the two modes' decodes overlap
+                # the two modes' decodes overlap; the semi-autoregressive loop enqueues as many iterations as recent steps needed + 2
+                # (model.saic_finish below enqueues the rest if this step's captions run longer: exact either way)
+                adaptive = bool(getattr(model.opt, "bofi_rl_saic_adaptive", True)) and os.environ.get("BOFI_RL_SAIC_ADAPTIVE", "1") != "0"
+                saic, naic = model.sample_pair(att_feats, att_masks, sample_n, temperature, saic_cap=model.saic_cap() if adaptive else None)
             else:                                              # the reference's two calls, one after the other
                 opt = {"sample_method": "sample", "sample_n": sample_n, "temperature": temperature, "output_logsoftmax": 1}
                 ks = ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")
                 saic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="SAIC"), mode="sample")[:5]))
                 naic = dict(zip(ks, model(fc, att_feats, att_masks, opt=dict(opt, train_mode="NAIC"), mode="sample")[:5]))
         model.train(was_training)
-        seq_s, seq_n = saic["seq"].cpu(), naic["seq"].cpu()    # the scorer runs on the host
+        dev = att_feats.device
         S = model.cfg.seq_length
+        # the scorer and the collate of the sampled layouts run on the host.  The non-autoregressive samples' part of it goes first, on the
+        # pinned copies sample_pair left behind an event on its side stream: it runs while the (much longer) semi-autoregressive decode does
+        early = getattr(model, "_naic_ready", None) if getattr(model.opt, "bofi_rl_sample_pair", True) and os.environ.get("BOFI_RL_EARLY_NAIC", "1") != "0" else None
+        prep = {}
+        if early is not None:
+            model._naic_ready = None
+            early[0].synchronize()
+            naic_host = early[1]
+            seq_n = naic_host["seq"]
+            s_naic = score_fn(seq_n)
+            prep.update(xe.rl_prepare(model.cfg, None, naic_host, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
+        else:
+            seq_n = naic["seq"].cpu()
+            s_naic = score_fn(seq_n)
+            prep.update(xe.rl_prepare(model.cfg, None, naic, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
+        if "_capped" in saic or getattr(model.opt, "bofi_rl_sample_pair", True):
+            saic = model.saic_finish(saic) if "bound_iters" in saic else saic
+        seq_s = saic["seq"].cpu()
+        s_saic = score_fn(seq_s)
+        prep.update(xe.rl_prepare(model.cfg, saic, None, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
         self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean(),
                          # share of the semi-autoregressive loop's S enqueued iterations in which some caption was still open
                          "active_share": min(S, int(saic["phrase_num"].max()) + 1) / S}
-        s_saic, s_naic = score_fn(seq_s), score_fn(seq_n)
-        dev = att_feats.device
         # the gradient pass reads tensors only: the samples' index tensors (host collate of the sampled layouts) and the scores
         b = {"att_feats": att_feats, "seq_saic": saic["seq"].to(dev).long(), "seq_naic": naic["seq"].to(dev).long(),
              "sc_saic": torch.as_tensor(s_saic, dtype=torch.float32).to(dev), "sc_naic": torch.as_tensor(s_naic, dtype=torch.float32).to(dev)}
-        b.update(xe.rl_prepare(model.cfg, saic, naic, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
+        b.update(prep)
         self._fwd_calls += 1
         step_word = getattr(self, "_step_word", None)
         if step_word is not None:

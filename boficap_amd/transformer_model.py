@@ -132,7 +132,7 @@ class TransformerModel(nn.Module):
             att_feats = att_feats.float()
         return att_feats.contiguous()
 
-    def _decode_saic_graphed(self, eng, feats, lens, raw_logits, sample):
+    def _decode_saic_graphed(self, eng, feats, lens, raw_logits, sample, cap=None):
         """The semi-autoregressive decode enqueues all seq_length iterations (≈60 launches each; iterations past the last live
         one return at once), so launched one by one it is bound by the host's launch rate.  It is replayed as a hipGraph over
         static input / output buffers per batch shape; the caller gets its own copies, as from the reference."""
@@ -146,14 +146,46 @@ class TransformerModel(nn.Module):
         io["feats"].copy_(feats)
         if lens is not None:
             io["lens"].copy_(lens)
-        io["out"] = eng.decode_saic(io["feats"], io["lens"], raw_logits=raw_logits, sample=sample, graph=True, out=io["out"])
-        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in io["out"].items()}
+        S = self.cfg.seq_length
+        cap = None if cap is None or cap >= S else max(1, int(cap))
+        io["out"] = eng.decode_saic(io["feats"], io["lens"], raw_logits=raw_logits, sample=sample, graph=True, out=io["out"],
+                                    it_range=None if cap is None else (1, cap))
+        res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in io["out"].items()}
+        if cap is not None:                                     # what saic_finish needs to enqueue the rest of the loop
+            res["_capped"] = (eng, key, cap, bool(raw_logits), sample)
+        return res
 
-    def sample_pair(self, att_feats, att_masks=None, sample_n=5, temperature=1.0):
+    # ---- the semi-autoregressive loop with fewer iterations enqueued than seq_length (the self-critical step: XETrainer.rl_step).  Every
+    # iteration past the last live one returns at once but still costs ~60 launches' dispatch (0.27 ms); captions that end after 12
+    # iterations leave 8 of them.  saic_cap() proposes a bound from the recent decodes, saic_finish() looks at the count of live iterations
+    # the capped decode reports and, if the loop may not be through, enqueues the REST on the state the engine still holds -- the same
+    # computation as the whole loop, exactly (tests/test_gpu_rl.py).
+    def saic_cap(self):
+        recent = self.__dict__.get("_saic_recent")
+        if not recent or len(recent) < 3:
+            return None
+        return min(self.cfg.seq_length, max(recent) + 2)
+
+    def saic_finish(self, res):
+        """``res``: a result of _decode_saic_graphed.  Returns the complete result (after a device -> host read of the iteration count)."""
+        capped = res.pop("_capped", None)
+        live = int(res["bound_iters"])
+        if capped is not None and live >= capped[2]:
+            eng, key, cap, raw_logits, sample = capped
+            io = self.__dict__["_saic_io"][key]
+            eng.decode_saic(io["feats"], io["lens"], raw_logits=raw_logits, sample=sample, graph=True, out=io["out"], it_range=(cap + 1, self.cfg.seq_length))
+            res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in io["out"].items()}
+            live = int(res["bound_iters"])
+        from collections import deque
+        self.__dict__.setdefault("_saic_recent", deque(maxlen=8)).append(live)
+        return res
+
+    def sample_pair(self, att_feats, att_masks=None, sample_n=5, temperature=1.0, saic_cap=None):
         """What the self-critical step asks of the model (loss_wrapper.py:193-209): ``sample_n`` sampled captions per image in SAIC
         mode and in NAIC mode.  Same results as two ``mode='sample'`` calls (same seeds); the two decodes are independent, so the
         NAIC one runs on a fork of the engine on a second stream, under the semi-autoregressive loop's replayed graph.
-        Returns (saic, naic) dicts with seq, seq_logprob, phrase_num, phrase_length, phrase_syn."""
+        Returns (saic, naic) dicts with seq, seq_logprob, phrase_num, phrase_length, phrase_syn.  ``saic_cap``: enqueue that many iterations
+        of the semi-autoregressive loop only -- the caller then passes ``saic`` through saic_finish() before it reads it."""
         eng = self.engine()
         side = self.__dict__.get("_side_engine")
         if side is None or side[0] is not eng:
@@ -171,13 +203,24 @@ class TransformerModel(nn.Module):
             rlens = None if lens is None else lens.repeat_interleave(sample_n).contiguous()
         if rows.size(0) > self.max_batch:
             raise hip.BofiHipError(f"{rows.size(0)} sampled rows exceed bofi_max_batch={self.max_batch}")
-        saic = self._decode_saic_graphed(eng, rows, rlens, False, (float(temperature), seed_saic))
+        saic = self._decode_saic_graphed(eng, rows, rlens, False, (float(temperature), seed_saic), cap=saic_cap)
         with torch.cuda.stream(s2):
             r = eng2.decode_naic(feats, lens, strict_q1=self.strict_reference)
             naic = {k: r[k] for k in ("seq", "seq_logprob", "phrase_num", "phrase_length", "phrase_syn")}
             if sample_n > 1:                                      # the bound is deterministic: n identical layouts (models/utils.py:3-14)
                 naic = {k: v.repeat_interleave(sample_n, dim=0) for k, v in naic.items()}
             naic["seq"] = eng2.sample_tokens(r, sample_n, float(temperature), seed_naic)
+            # the non-autoregressive samples are ready long before the semi-autoregressive decode ends: their host copies leave on THIS stream
+            # (pinned memory, an event behind them), so that a caller can score / collate them while the other decode still runs
+            host = self.__dict__.setdefault("_naic_host", {})
+            for k, v in naic.items():
+                hb = host.get(k)
+                if hb is None or hb.shape != v.shape or hb.dtype != v.dtype:
+                    hb = host[k] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                hb.copy_(v, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(s2)
+        self._naic_ready = (ready, dict(host))
         main.wait_stream(s2)
         for v in list(naic.values()) + [feats] + ([lens] if lens is not None else []):
             v.record_stream(main)                                 # allocated / read on s2, used on the caller's stream from here on

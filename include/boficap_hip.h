@@ -306,6 +306,12 @@ int bofi_engine_set_q1_group(bofi_engine_t* e, int group);
 
 /* Temperature (> 0) and seed of the token draws of a decode called with BOFI_FLAG_SAMPLE. */
 int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed);
+/* The iterations the following bofi_engine_decode_saic calls enqueue: it_begin .. it_end of core_SAIC's loop (TransformerModel.py:1903-1984; 1-based,
+ * it_end 0 = seq_length; the default is the whole loop, 1 .. seq_length).  A call with it_begin == 1 encodes and initialises; one with
+ * it_begin > 1 continues the PREVIOUS call's loop on the state left in the engine's workspace (same arguments, no other decode in between) and
+ * exports again: [1, c] followed by [c + 1, seq_length] is the same computation as the whole loop.  Iterations past the last live one return
+ * at once but still cost their launches; *bound_iters (live iterations so far) < c after [1, c] means the loop has ended. */
+int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end);
 
 /* Device pointer of the engine's own [max_batch * S, V] float32 log-prob workspace: where a decode called WITHOUT a
  * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of

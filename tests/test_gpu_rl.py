@@ -275,3 +275,48 @@ def test_sample_pair_equals_the_two_sample_calls(weight_cache, manifest):
             assert torch.equal(a_s[k], b_s[k]) and torch.equal(a_n[k], b_n[k]), k
         for a, b in ((a_s, b_s), (a_n, b_n)):
             assert torch.equal(a["seq_logprob"].nan_to_num(0.0), b["seq_logprob"].nan_to_num(0.0))
+
+
+def test_capped_semi_autoregressive_loop_with_its_continuation_equals_the_whole_loop(weight_cache, manifest):
+    """bofi_engine_set_saic_range / sample_pair(saic_cap=c) + saic_finish: the loop's first c iterations, then -- when the count of live
+    iterations says it may not be through -- the rest on the state the engine still holds: ids, layouts and log-probs of the whole loop,
+    bit for bit, sampled and greedy, whatever c; a cap past the last live iteration needs no second part."""
+    cfg, sd, model = _model(weight_cache, manifest)
+    att = _images().cuda()
+    n, S = 3, cfg.seq_length
+    model._sample_calls = 40
+    with torch.no_grad():
+        ref_s, _ = model.sample_pair(att, None, n, 1.2)
+    ref_s = model.saic_finish(ref_s)
+    live = int(ref_s["bound_iters"])
+    assert 2 <= live < S                                       # (the fixture's captions end after a few phrases)
+    for cap in (1, live - 1, live, live + 1, S - 1, S):
+        model._sample_calls = 40
+        with torch.no_grad():
+            got, _ = model.sample_pair(att, None, n, 1.2, saic_cap=cap)
+        second = cap < S and cap <= live                       # live iterations == cap: "may not be through"
+        assert ("_capped" in got) == (cap < S)
+        partial = int(got["bound_iters"])
+        assert partial == min(cap, live)
+        got = model.saic_finish(got)
+        assert int(got["bound_iters"]) == live, (cap, second)
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+            assert torch.equal(got[k], ref_s[k]), (cap, k)
+        assert torch.equal(got["seq_logprob"].nan_to_num(0.0), ref_s["seq_logprob"].nan_to_num(0.0)), cap
+    # the engine entry itself, greedy, without the graph
+    eng = model.engine()
+    feats = model._as_input(att)
+    whole = eng.decode_saic(feats, None)
+    part = eng.decode_saic(feats, None, it_range=(1, 2))
+    assert int(part["bound_iters"]) == 2
+    rest = eng.decode_saic(feats, None, out=part, it_range=(3, S))
+    torch.cuda.synchronize()
+    for k in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
+        assert torch.equal(rest[k], whole[k]), k
+    assert torch.equal(rest["seq_logprob"].nan_to_num(0.0), whole["seq_logprob"].nan_to_num(0.0))
+    # the proposal follows the recent decodes
+    model.__dict__.pop("_saic_recent", None)
+    assert model.saic_cap() is None
+    for _ in range(3):
+        model.saic_finish(dict(ref_s))
+    assert model.saic_cap() == min(S, live + 2)
