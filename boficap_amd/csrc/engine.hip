@@ -118,6 +118,7 @@ struct bofi_engine {
     float sample_temperature = 1.0f;      // BOFI_FLAG_SAMPLE: token draws inside the semi-autoregressive loop
     uint64_t sample_seed = 0;
     int saic_it_begin = 1, saic_it_end = 0;   // iterations the next semi-autoregressive decode enqueues (bofi_engine_set_saic_range; end 0 = seq_length)
+    int bound_iter_cap = 0;               // bounding iterations the non-autoregressive decode enqueues (bofi_engine_set_bound_iter_cap; 0 = seq_length)
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
 
@@ -569,7 +570,11 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     } else {
         ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
         static const int exp_iters = [] { const char* v = getenv("BOFI_EXP_ITERS"); return v ? atoi(v) : 0; }();     // timing experiment: fewer iterations enqueued
-        for (int it = 0; it < (exp_iters ? exp_iters : S); ++it)
+        // (bofi_engine_set_bound_iter_cap: a caller that knows how many iterations its captions take enqueues that many + a margin instead of
+        // all S -- an iteration past the last live one is five launches that return at once -- and decodes again without the cap when the
+        // count of live iterations, *bound_iters, reaches the cap: the loop may then not have ended)
+        const int n_iters = exp_iters ? exp_iters : (bound_iter_cap > 0 && bound_iter_cap < S ? bound_iter_cap : S);
+        for (int it = 0; it < n_iters; ++it)
             ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     }
     ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
@@ -980,6 +985,14 @@ int bofi_engine_set_q1_group(bofi_engine_t* e, int group) {
     return BOFI_OK;
 }
 
+int bofi_engine_set_bound_iter_cap(bofi_engine_t* e, int cap) {
+    g_err.clear();
+    if (!e) return fail(BOFI_ERR_ARG, "null engine");
+    if (cap < 0) return fail(BOFI_ERR_ARG, "bound iteration cap: >= 0 (0 = seq_length)");
+    e->bound_iter_cap = cap;
+    return BOFI_OK;
+}
+
 int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end) {
     g_err.clear();
     if (!e) return fail(BOFI_ERR_ARG, "null engine");
@@ -1253,7 +1266,7 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
     std::vector<uintptr_t> key = {(uintptr_t)0, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
-                                  (uintptr_t)e->q1_group};
+                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, cs);

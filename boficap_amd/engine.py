@@ -132,14 +132,16 @@ class BofiEngine:
 
     def decode_naic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, strict_q1: bool = True,
                     want_logprob: bool = True, want_memory: bool = False, raw_logits: bool = False, graph: bool = False,
-                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0) -> dict:
+                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0, iter_cap: int = 0) -> dict:
         """Greedy NAIC bound+fill decode.  Returns a dict of device tensors: seq [B,S] int64,
         seq_logprob [B,S,V] float32 (or None), phrase_num [B] int32, phrase_length [B,S] int32,
         phrase_syn [B,S] int64, bound_iters [1] int32, memory [B,R,d] float32 (or None).
         Pass the previous result as ``out`` to reuse its buffers (required for graph replay).
         ``refine_rounds`` extra filling passes feed the previous ids back as decoder input (BASELINE config 5).
         ``q1_group`` > 0: the call carries B / q1_group independent batches (dynamic batching); quirk Q1 applies per batch,
-        so each batch's outputs equal its own separate decode."""
+        so each batch's outputs equal its own separate decode.
+        ``iter_cap`` > 0: enqueue that many bounding iterations instead of seq_length (bofi_engine_set_bound_iter_cap); the result is the
+        reference's iff ``bound_iters`` < iter_cap afterwards -- the caller checks and decodes again without the cap otherwise."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
@@ -157,6 +159,9 @@ class BofiEngine:
         if q1_group != getattr(self, "_q1_group", 0):
             hip.check(self._lib.bofi_engine_set_q1_group(self._h, int(q1_group)), "bofi_engine_set_q1_group")
             self._q1_group = q1_group
+        if int(iter_cap) != getattr(self, "_iter_cap", 0):
+            hip.check(self._lib.bofi_engine_set_bound_iter_cap(self._h, int(iter_cap)), "bofi_engine_set_bound_iter_cap")
+            self._iter_cap = int(iter_cap)
         flags = ((hip.FLAG_STRICT_Q1 if strict_q1 else 0) | (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0)
                  | (refine_rounds << hip.FLAG_REFINE_SHIFT))
         hip.check(self._lib.bofi_engine_decode_naic(

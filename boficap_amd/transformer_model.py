@@ -246,8 +246,23 @@ class TransformerModel(nn.Module):
         torch.cuda.synchronize()                                  # the reference does (AttModel.py:337)
         start = time.time()
         if train_mode == "NAIC":
-            r = eng.decode_naic(self._as_input(att_feats), self._att_len(att_masks), strict_q1=self.strict_reference,
-                                raw_logits=not output_logsoftmax)
+            # the bounding loop is enqueued for as many iterations as the recent decodes' captions took + 2, not for all seq_length (an
+            # iteration past the last live one is five launches that return at once); the count of live iterations tells whether that was
+            # enough -- if not, the decode is repeated without the cap, so the result is the reference's either way (opt.bofi_naic_iter_cap:
+            # None = adaptive, 0 = never cap, c = always c)
+            S = self.cfg.seq_length
+            forced = getattr(self.opt, "bofi_naic_iter_cap", None)
+            recent = self.__dict__.setdefault("_naic_recent", [])
+            cap = int(forced) if forced is not None else (min(S, max(recent) + 2) if len(recent) >= 3 else 0)
+            cap = 0 if cap >= S else cap
+            feats_in, lens_in = self._as_input(att_feats), self._att_len(att_masks)
+            r = eng.decode_naic(feats_in, lens_in, strict_q1=self.strict_reference, raw_logits=not output_logsoftmax, iter_cap=cap)
+            live = int(r["bound_iters"])                          # (a device -> host read: the reference synchronises here too, AttModel.py:337)
+            if cap and live >= cap:
+                r = eng.decode_naic(feats_in, lens_in, strict_q1=self.strict_reference, raw_logits=not output_logsoftmax, out=r, iter_cap=0)
+                live = int(r["bound_iters"])
+            recent.append(live)
+            del recent[:-8]
         elif sample_method == "greedy":                           # core_SAIC, AttModel.py:430-437
             r = self._decode_saic_graphed(eng, self._as_input(att_feats), self._att_len(att_masks), not output_logsoftmax, None)
         else:

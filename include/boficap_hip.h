@@ -312,6 +312,11 @@ int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed)
  * exports again: [1, c] followed by [c + 1, seq_length] is the same computation as the whole loop.  Iterations past the last live one return
  * at once but still cost their launches; *bound_iters (live iterations so far) < c after [1, c] means the loop has ended. */
 int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end);
+/* Bounding iterations the following bofi_engine_decode_naic calls enqueue (core_NAIC's loop, TransformerModel.py:1843-1869; 0 = all seq_length,
+ * the default).  The loop exits when every image is finished; enqueued iterations past that point return at once but still cost their five
+ * launches.  With a cap c the decode is the reference's if and only if the loop ended within c iterations: *bound_iters (iterations in which
+ * some image was live) < c.  Otherwise decode again with cap 0. */
+int bofi_engine_set_bound_iter_cap(bofi_engine_t* e, int cap);
 
 /* Device pointer of the engine's own [max_batch * S, V] float32 log-prob workspace: where a decode called WITHOUT a
  * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of

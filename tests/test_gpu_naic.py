@@ -291,6 +291,37 @@ def test_drop_in_module_sample(weight_cache, manifest):
         model(fc, att, None, opt={"train_mode": "AIC"}, mode="sample")
 
 
+def test_bounding_loop_with_fewer_iterations_enqueued(weight_cache, manifest):
+    """bofi_engine_set_bound_iter_cap through model(..., mode='sample'): the loop enqueued for c iterations, the count of live iterations
+    read back, the decode repeated without the cap when c was not enough -- the reference's 6-tuple whatever c (opt.bofi_naic_iter_cap),
+    and the adaptive choice (recent decodes + 2) after three calls."""
+    import captioning.models as models
+    m = manifest["tiny_mix"]
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    g = load_golden("tiny_mix")
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    att = torch.from_numpy(g["att_feats"]).cuda()
+    fc = torch.zeros(att.size(0), 0, device="cuda")
+    eng = model.engine()
+    whole = eng.decode_naic(model._as_input(att), None)
+    live = int(whole["bound_iters"])
+    assert 1 <= live < cfg.seq_length
+    short = eng.decode_naic(model._as_input(att), None, iter_cap=1)
+    assert int(short["bound_iters"]) == 1                              # "may not be through": the caller decodes again
+    enough = eng.decode_naic(model._as_input(att), None, iter_cap=live + 1)
+    assert int(enough["bound_iters"]) == live and torch.equal(enough["seq"], whole["seq"]) and torch.equal(enough["phrase_length"], whole["phrase_length"])
+    for cap in (None, 0, 1, live, live + 1, cfg.seq_length, None, None, None):
+        model.opt.bofi_naic_iter_cap = cap
+        with torch.no_grad():
+            seq, lp, pn, pl, ps, _ = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "greedy", "sample_n": 1}, mode="sample")
+        assert (seq.cpu().numpy() == g["naic_seq"]).all() and (pl.cpu().numpy() == g["naic_phrase_length"]).all(), cap
+        assert (pn.cpu().numpy() == g["naic_phrase_num"]).all() and (ps.cpu().numpy() == g["naic_phrase_syn"]).all(), cap
+        assert _close(lp.cpu().numpy(), g["naic_logprob"], 0) < 1e-3
+    assert model._naic_recent[-1] == live and eng._iter_cap == min(cfg.seq_length, live + 2) % cfg.seq_length      # the last calls ran under the adaptive cap
+
+
 def test_entropy_perplexity_without_materialising_logprobs(engines):
     """eval's per-image entropy / perplexity (eval_utils.py:463-464) from the fused row reductions, with the log-prob
     tensor in user memory and with it left in the engine's workspace."""
