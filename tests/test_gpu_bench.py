@@ -15,7 +15,9 @@ def _run(*flags, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.strip() and not l.startswith("[Gloo]")]     # (the rehearsal's transport announces itself on stdout)
+    lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    if env and env.get("BOFI_BENCH_REHEARSAL") == "1":         # the rehearsal's transport (gloo) announces itself on stdout, the ranks' lines interleaved
+        lines = [l for l in lines if l.startswith("{")]
     assert len(lines) == 1, lines[:3]                          # progress goes to stderr
     return json.loads(lines[-1])
 
