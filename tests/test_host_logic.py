@@ -151,3 +151,68 @@ def test_shipped_library_has_no_packed_f32_arithmetic(tmp_path):
         mfma += asm.count("v_mfma_f32_16x16x32_bf16")
     assert mfma > 1000, mfma                                   # (the disassembly is the real thing)
     assert packed == 0, packed
+
+
+def test_persistent_gemm_statistics_registers_are_never_copied_or_spilled(tmp_path):
+    """gemm_pers.hip's loader wavefronts read the LayerNorm statistics with inline-assembly loads whose completion only a hand-counted
+    s_waitcnt covers (compiler-tracked loads would drain the slab ring): the compiler believes the destination registers defined at the asm
+    statement.  That is safe as long as it never MOVES or SPILLS them between the load and the wait -- a copy would read registers whose data has
+    not arrived.  Pinned on the shipped code objects: every load site writes the same registers, and inside the loaders' code no move / accumulator
+    copy / scratch / LDS store / lane-permute instruction names one of them (the sums and the loads' own address arithmetic are all that touches them)."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from boficap_amd import hip
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(hip.LIB_PATH) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    lib = shutil.copy(hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    checked = 0
+    for o in glob.glob(str(tmp_path / "lib.so.*amdgcn*gfx950*")):
+        asm = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        if "gemm_pers_kernel" not in asm:
+            continue
+        funcs = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm)
+        for f in funcs:
+            head = f.split("\n", 1)[0]
+            if not re.search(r"gemm_pers_kernelILi[13]E", head):            # FEAT bit 0: the folded LayerNorm
+                continue
+            lines = [l.split("//")[0].strip() for l in f.split("\n")[1:]]
+            # the asm loads: runs of 4 or 8 loads without offset or cache modifiers, nothing but address arithmetic between them (the
+            # compiler's own zero-offset loads come singly or in pairs, next to their offset: siblings)
+            runs, run = [], []
+            for i, l in enumerate(lines):
+                m = re.fullmatch(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", l)
+                if m:
+                    run.append((i, int(m.group(1)), int(m.group(2))))
+                elif l.startswith(("global_", "buffer_", "scratch_", "flat_", "s_barrier", "s_cbranch", "s_branch", "s_endpgm")):      # (a wait the compiler puts between them is safe)
+                    if run:
+                        runs.append(run)
+                    run = []
+            # every load site (tile 0's, and the loop's copies) lands in the SAME registers, in the same order -- no copies between sites: the
+            # statistics loads are the run that REPEATS (the residual variants' epilogue has a run of compiler loads of its own, once)
+            from collections import Counter
+            cand = Counter(tuple((a, b) for _, a, b in r) for r in runs if len(r) in (4, 8))
+            assert cand and cand.most_common(1)[0][1] >= 2, (head, cand)
+            stat_dst = cand.most_common(1)[0][0]
+            assert sum(1 for d, n in cand.items() if n >= 2) == 1, (head, cand)      # one repeating run only
+            sites = [r for r in runs if tuple((a, b) for _, a, b in r) == stat_dst]
+            dsts = [stat_dst]
+            regs = {r for a, b in dsts[0] for r in range(a, b + 1)}
+            first = sites[0][0][0]
+            end = next(i for i in range(first, len(lines)) if lines[i].startswith("s_endpgm"))
+            bad = ("v_mov_b32", "v_accvgpr", "scratch_", "buffer_store", "global_store", "ds_write", "ds_store", "v_swap", "v_permlane", "v_readlane", "v_writelane", "v_readfirstlane")
+
+            def names(l):
+                out = set()
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", l):
+                    out.update(range(int(a), int(b) + 1))
+                out.update(int(x) for x in re.findall(r"\bv(\d+)\b", l))
+                return out
+            for l in lines[first:end]:
+                if l.startswith(bad) and names(l) & regs:
+                    raise AssertionError(f"{head}: {l!r} touches a statistics register")
+            checked += 1
+    assert checked >= 4, checked
