@@ -578,6 +578,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     fl_fixed, fl_skip = H.gemm_flops(reset=True)
     T = int(probe["bound_iters"].item())
     del probe
+    T_all = T                                                   # ... over every input set a launch will carry (the one-batch form decodes other images per stream)
     log("engine ready; first decode (graph capture)")
     # streams that provably overlap (distinct hardware queues), found by timing a spin kernel on pairs
     from boficap_amd.engine import pick_concurrent_streams
@@ -617,17 +618,36 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             if int(pk["phrase_num"][-1]) == 0 and alive.numel():
                 i = int(alive[-1])
                 cand[[i, args.batch - 1]] = cand[[args.batch - 1, i]]
+            T_all = max(T_all, int(pk["bound_iters"].item()))   # (an image's layout, and with it its iteration count, does not depend on its place)
             atts[k] = cand.contiguous()
     # ... and every stream alternates between TWO feature tensors (the second: the same batches in another order), so that consecutive
     # launches of a stream do not replay one Infinity-Cache-resident input (round-2 VERDICT)
     atts2 = [torch.cat([a_k[args.batch:], a_k[:args.batch]]).contiguous() if nb > 1 else a_k.clone() for a_k in atts]
+    # iteration budget: T_all + 2 bounding iterations enqueued instead of seq_length; every decode reports into `live_word` (atomic max)
+    S_it = cfg.seq_length
+    cap = T_all + 2 if args.iter_budget == "auto" and T_all + 2 < S_it else 0
+    if cap and os.environ.get("BOFI_BENCH_ITER_CAP"):           # (tests: a budget the decodes outrun, to walk the re-run)
+        cap = int(os.environ["BOFI_BENCH_ITER_CAP"])
+    live_word = torch.zeros(1, dtype=torch.int32, device=dev)
+    for e in engines:
+        e.watch_live_iterations(live_word)
+
+    def budget_held(leg):
+        """after a leg's synchronisation: did every decode since the last check end inside the budget?"""
+        mx = int(live_word.item())
+        live_word.zero_()
+        if cap and mx >= cap:
+            log(f"iteration budget {cap} missed in the {leg} leg (a decode had {mx} live iterations)")
+            return False
+        return True
     outs = []
     for e, st, a_k, b_k in zip(engines, streams, atts, atts2):
         with torch.cuda.stream(st):
-            outs.append(e.decode_naic(a_k, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine, q1_group=qg))
-            e.decode_naic(b_k, graph=graph, out=outs[-1], refine_rounds=args.refine, q1_group=qg)       # (captures the second input's graph)
-            e.decode_naic(a_k, graph=graph, out=outs[-1], refine_rounds=args.refine, q1_group=qg)
+            outs.append(e.decode_naic(a_k, want_logprob=not args.ids_only, graph=graph, refine_rounds=args.refine, q1_group=qg, iter_cap=cap))
+            e.decode_naic(b_k, graph=graph, out=outs[-1], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)       # (captures the second input's graph)
+            e.decode_naic(a_k, graph=graph, out=outs[-1], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
     torch.cuda.synchronize()
+    budget_ok = budget_held("capture")
     out = outs[0]
     log("warm-up + timed steps")
 
@@ -635,7 +655,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         k = i % len(engines)
         feats = atts2[k] if (i // len(engines)) % 2 else atts[k]
         with torch.cuda.stream(streams[k]):
-            engines[k].decode_naic(feats, graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
+            engines[k].decode_naic(feats, graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
 
     launches = args.steps // C
     for i in range(warm_launches):
@@ -656,20 +676,22 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # in flight it is the longest stream's span divided by all the decodes (steady-state time per decode)
     dev_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / launches
     elapsed = dp.reduce_scalar(elapsed, "max", device=dev)
+    budget_ok = budget_held("timed") and budget_ok
 
     # for the record: the same K steps strictly one at a time (latency view of the same workload), HIP events on the stream
     single_ms = None
     if len(engines) > 1:
         for i in range(warm_launches):
-            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg)
+            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
         _barrier(world)
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()
         for i in range(launches):
-            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg)
+            eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
         s1.record()
         _barrier(world)
         single_ms = s0.elapsed_time(s1) / args.steps
+        budget_ok = budget_held("one-at-a-time") and budget_ok
     # for the record: the same launches with the features starting in pinned HOST memory (a loader's numpy arrays), copied to the
     # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
     pcie_ms = None
@@ -679,7 +701,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             k = i % len(engines)
             with torch.cuda.stream(streams[k]):
                 atts[k].copy_(hosts[k][(i // len(engines)) % 2], non_blocking=True)
-                engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg)
+                engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
         for i in range(warm_launches):
             step_h(i)
         torch.cuda.synchronize()
@@ -688,6 +710,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             step_h(i)
         torch.cuda.synchronize()
         pcie_ms = (time.perf_counter() - h0) / args.steps * 1e3
+        budget_ok = budget_held("from-host") and budget_ok
     traffic, tnote = None, "no PMC pass committed for this configuration"
     names = {1: ("r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
@@ -699,6 +722,15 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             tnote = (f"HBM-side bytes per launch ({C} batch(es) of 64), rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, "
                      f"one launch at a time (profiles/{name}); algorithmic minimum = {9.4 * C:.1f} MB features + 125 MB weights + {48.6 * C:.1f} MB log-probs")
             break
+    if dp.reduce_scalar(0.0 if budget_ok else 1.0, "max", device=dev) > 0:      # some rank's decode outran the budget: the whole measurement again, every iteration enqueued
+        import copy
+        for e in engines:
+            e.watch_live_iterations(None)
+        del engines, outs
+        torch.cuda.empty_cache()
+        a = copy.copy(args)
+        a.iter_budget = "off"
+        return run_naic(a, ctx, log, cpu, gemm_roofline)
     ntok = float(out["phrase_length"].sum(1).float().mean().item())
     nan = bool(out["seq_logprob"].isnan().any().item()) if out["seq_logprob"] is not None else False
     if rank != 0:
@@ -728,7 +760,12 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"batch={args.batch} NAR bound+fill inference, 36x2048 regions, d_model=512 6+6 layers(+1 bound layer), {args.dtype}"
                                + (f", {args.refine} refinement rounds" if args.refine else ""),
-                   "images_per_step_per_gpu": args.batch, "bound_iterations": T, "mean_tokens_per_image": round(ntok, 2),
+                   "images_per_step_per_gpu": args.batch, "bound_iterations": T, "bound_iterations_enqueued": cap if cap else cfg.seq_length,
+                   "iteration_budget": (f"{cap} of {cfg.seq_length} bounding iterations enqueued per decode (largest live count of the probe decodes + 2; the reference's loop "
+                                        "stops when every image is finished, TransformerModel.py:1869); every decode folds its live-iteration count into a device word "
+                                        "(atomic max) that was read after each leg: all below the budget, else this line would come from a full re-run without it"
+                                        if cap else "off: every decode enqueues all seq_length iterations"),
+                   "mean_tokens_per_image": round(ntok, 2),
                    "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
                    "decodes_in_flight": len(engines), "features_per_launch_in_flight": "own tensors, two per stream, alternated", "batches_per_launch": C,
                    "images_per_launch": C * args.batch, "refine_rounds": args.refine,
@@ -781,6 +818,11 @@ def main():
     ap.add_argument("--from-host", action="store_true", default=None, help="also time the launches with the features copied from pinned host memory "
                     "before each one (PCIe-inclusive rate, reported in config; never the headline value).  Default: on for the plain headline run")
     ap.add_argument("--no-from-host", dest="from_host", action="store_false")
+    ap.add_argument("--iter-budget", default="auto", choices=["auto", "off"],
+                    help="naic: bounding iterations ENQUEUED per decode.  off = all seq_length of them, as round 2 (an iteration past the last live one is five "
+                         "launches that return at once).  auto = the largest count of live iterations among the probe decodes + 2; every decode folds its own "
+                         "count into a device word (atomic max) that is read after each timed leg: were a decode to need more, the whole measurement is redone "
+                         "without the budget.  The reference's loop stops when every image is finished (TransformerModel.py:1869) -- it never runs the idle ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the per-shape GEMM timing (use under rocprofv3 so that the trace holds decodes only)")
     ap.add_argument("--no-secondary", action="store_true", help="headline measurement only (no XE / RL / refinement lines)")

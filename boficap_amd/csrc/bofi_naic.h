@@ -57,7 +57,7 @@ struct BoundTailArgs {
 
 int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_idx, hipStream_t s);
 int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_num, int* phrase_length,
-                        int64_t* phrase_syn, int* iters, hipStream_t s);
+                        int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max = nullptr);
 // flags of launch_bound_tail
 #define BOUND_HEADS 1    /* final norm + heads + argmax on y */
 #define BOUND_UPDATE 2   /* apply the slot bookkeeping (needs BOUND_HEADS) */

@@ -119,6 +119,7 @@ struct bofi_engine {
     uint64_t sample_seed = 0;
     int saic_it_begin = 1, saic_it_end = 0;   // iterations the next semi-autoregressive decode enqueues (bofi_engine_set_saic_range; end 0 = seq_length)
     int bound_iter_cap = 0;               // bounding iterations the non-autoregressive decode enqueues (bofi_engine_set_bound_iter_cap; 0 = seq_length)
+    int* live_max = nullptr;              // optional device word: max over decodes of their live-iteration counts (bofi_engine_set_live_iterations_max)
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
 
@@ -578,7 +579,7 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
             ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     }
     ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
-    ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s));
+    ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s, live_max));
     return BOFI_OK;
 }
 
@@ -993,6 +994,13 @@ int bofi_engine_set_bound_iter_cap(bofi_engine_t* e, int cap) {
     return BOFI_OK;
 }
 
+int bofi_engine_set_live_iterations_max(bofi_engine_t* e, int* live_max) {
+    g_err.clear();
+    if (!e) return fail(BOFI_ERR_ARG, "null engine");
+    e->live_max = live_max;
+    return BOFI_OK;
+}
+
 int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end) {
     g_err.clear();
     if (!e) return fail(BOFI_ERR_ARG, "null engine");
@@ -1266,7 +1274,7 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
     std::vector<uintptr_t> key = {(uintptr_t)0, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
-                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap};
+                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, cs);

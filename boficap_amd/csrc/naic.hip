@@ -32,9 +32,10 @@ int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_i
 }
 
 __global__ void bound_export_kernel(BoundState st, int B, int L, int S, int* phrase_num, int* phrase_length,
-                                    int64_t* phrase_syn, int* iters) {
+                                    int64_t* phrase_syn, int* iters, int* live_max) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && iters) *iters = st.counters[1];
+    if (i == 0 && live_max) atomicMax(live_max, st.counters[1]);      // the largest live-iteration count of every decode since the caller cleared the word
     if (i < B && phrase_num) phrase_num[i] = st.phrase_num[i];
     if (i < B * S) {
         const int b = i / S, t = i - b * S;                      // reference returns [:, :-2]
@@ -44,9 +45,9 @@ __global__ void bound_export_kernel(BoundState st, int B, int L, int S, int* phr
 }
 
 int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_num, int* phrase_length,
-                        int64_t* phrase_syn, int* iters, hipStream_t s) {
+                        int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max) {
     hipLaunchKernelGGL(bound_export_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, st, B, L, S, phrase_num,
-                       phrase_length, phrase_syn, iters);
+                       phrase_length, phrase_syn, iters, live_max);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

@@ -170,6 +170,14 @@ class BofiEngine:
             hip.ptr(out["memory"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_naic")
         return out
 
+    def watch_live_iterations(self, word: Optional[torch.Tensor]) -> None:
+        """``word`` (int32 [1] on the device, or None to stop): every following decode_naic folds its live-iteration count into it by atomic
+        max -- a pipeline of capped decodes (``iter_cap``) is verified with ONE read after the last of them (clear the word first)."""
+        if word is not None and (word.dtype != torch.int32 or word.numel() != 1 or not word.is_cuda):
+            raise hip.BofiHipError("watch_live_iterations: an int32 [1] device tensor")
+        self._live_word = word                                  # (kept alive)
+        hip.check(self._lib.bofi_engine_set_live_iterations_max(self._h, hip.ptr(word)), "bofi_engine_set_live_iterations_max")
+
     def row_stats(self, out: dict):
         """(sum_v p log p, log-prob of the emitted id) per position, float32 [B, S] each, of the decode that produced ``out`` --
         from its seq_logprob tensor, or from the engine's own workspace when that was not materialised."""

@@ -74,6 +74,7 @@ SIGNATURES = {
     "bofi_engine_set_sampling": (_I, [_P, C.c_float, C.c_uint64]),
     "bofi_engine_set_saic_range": (_I, [_P, _I, _I]),
     "bofi_engine_set_bound_iter_cap": (_I, [_P, _I]),
+    "bofi_engine_set_live_iterations_max": (_I, [_P, _P]),
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),

@@ -317,6 +317,10 @@ int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end);
  * launches.  With a cap c the decode is the reference's if and only if the loop ended within c iterations: *bound_iters (iterations in which
  * some image was live) < c.  Otherwise decode again with cap 0. */
 int bofi_engine_set_bound_iter_cap(bofi_engine_t* e, int cap);
+/* With a pipeline of capped decodes whose results are consumed later: `live_max` (device int32, NULL = off) receives, by atomic max, the
+ * live-iteration count of every following bofi_engine_decode_naic -- one read after the last decode tells whether ALL of them ended inside the
+ * cap (the caller clears the word first). */
+int bofi_engine_set_live_iterations_max(bofi_engine_t* e, int* live_max);
 
 /* Device pointer of the engine's own [max_batch * S, V] float32 log-prob workspace: where a decode called WITHOUT a
  * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of

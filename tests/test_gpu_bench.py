@@ -33,6 +33,7 @@ def test_bench_line_with_the_drivers_arguments():
     c = d["config"]
     assert "workload" in c and "batch=64" in c["workload"] and c["images_per_step_per_gpu"] == 64 and not c["nan_in_output"]
     assert c["batches_per_launch"] == 5 and c["decodes_in_flight"] >= 1              # 20 steps = 4 launches of 5 batches
+    assert c["bound_iterations"] < c["bound_iterations_enqueued"] <= 20 and "iteration_budget" in c      # verified budget (or all 20 enqueued)
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["flops_per_launch"] > 0 and r["launch_ms"] > 0 and "traffic" in r
@@ -44,8 +45,9 @@ def test_bench_line_with_the_drivers_arguments():
 def test_bench_odd_step_counts_and_one_batch_per_launch():
     d = _run("--steps", "7", "--warmup", "3", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline")
     assert d["steps"] == 7 and d["config"]["batches_per_launch"] == 1 and d["value"] > 0
-    d = _run("--steps", "8", "--warmup", "2", "--inflight", "1", "--coalesce", "1", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--ids-only")
-    assert d["config"]["decodes_in_flight"] == 1 and d["config"]["seq_logprob_materialised"] is False
+    d = _run("--steps", "8", "--warmup", "2", "--inflight", "1", "--coalesce", "1", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--ids-only",
+             "--iter-budget", "off")
+    assert d["config"]["decodes_in_flight"] == 1 and d["config"]["seq_logprob_materialised"] is False and d["config"]["bound_iterations_enqueued"] == 20
 
 
 def test_bench_two_ranks_walk_the_multi_gpu_path_on_one_device():
@@ -60,3 +62,12 @@ def test_bench_two_ranks_walk_the_multi_gpu_path_on_one_device():
     assert "error" not in dp, dp
     assert dp["rccl_ranks"] == 2 and dp["fp32_ring_all_reduce"]["step_ms"] > 0 and dp["bf16_mesh_direct"]["step_ms"] > 0
     assert dp["fp32_ring_all_reduce"]["exchanged_bytes_per_rank"] == 2 * dp["bf16_mesh_direct"]["exchanged_bytes_per_rank"]
+
+
+def test_bench_reruns_without_the_iteration_budget_when_a_decode_outruns_it():
+    """--iter-budget auto enqueues (live iterations of the probe + 2) bounding iterations per decode and checks the device-side maximum of the
+    decodes' live-iteration counts after every leg; with a budget the decodes cannot meet (forced here) the line must come from the re-run
+    that enqueues all of them."""
+    d = _run("--steps", "10", "--warmup", "5", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--no-from-host", env={"BOFI_BENCH_ITER_CAP": "3"})
+    c = d["config"]
+    assert c["bound_iterations"] > 3 and c["bound_iterations_enqueued"] == 20 and c["iteration_budget"].startswith("off") and not c["nan_in_output"]
