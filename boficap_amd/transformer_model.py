@@ -161,10 +161,18 @@ class TransformerModel(nn.Module):
     # the capped decode reports and, if the loop may not be through, enqueues the REST on the state the engine still holds -- the same
     # computation as the whole loop, exactly (tests/test_gpu_rl.py).
     def saic_cap(self):
+        """The budget for the next decode: recent live iterations + 2, in steps of 4 and STICKY -- every distinct value is a graph of its own
+        (a capture costs tens of milliseconds): raised as soon as the recent decodes ask for more, lowered only after eight decodes that
+        would all have fitted the next lower step.  None: no budget (the first two decodes, or captions that use the whole loop)."""
+        S = self.cfg.seq_length
         recent = self.__dict__.get("_saic_recent")
-        if not recent or len(recent) < 3:
+        if not recent or len(recent) < 2:
             return None
-        return min(self.cfg.seq_length, max(recent) + 2)
+        want = -(-(max(recent) + 2) // 4) * 4
+        cur = self.__dict__.get("_saic_cap_cur")
+        if cur is None or want > cur or (len(recent) >= 8 and want <= cur - 4):
+            cur = self.__dict__["_saic_cap_cur"] = want
+        return None if cur >= S else cur
 
     def saic_finish(self, res):
         """``res``: a result of _decode_saic_graphed.  Returns the complete result (after a device -> host read of the iteration count)."""
