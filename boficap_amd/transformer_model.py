@@ -272,7 +272,11 @@ class TransformerModel(nn.Module):
             recent.append(live)
             del recent[:-8]
         elif sample_method == "greedy":                           # core_SAIC, AttModel.py:430-437
-            r = self._decode_saic_graphed(eng, self._as_input(att_feats), self._att_len(att_masks), not output_logsoftmax, None)
+            # (the loop is enqueued for the iterations recent decodes needed, the rest only if this one needs them: saic_cap / saic_finish)
+            adaptive = getattr(self.opt, "bofi_saic_iter_budget", True)
+            r = self._decode_saic_graphed(eng, self._as_input(att_feats), self._att_len(att_masks), not output_logsoftmax, None,
+                                          cap=self.saic_cap() if adaptive else None)
+            r = self.saic_finish(r)
         else:
             # sampled tokens feed the next bound step, so the sample_n copies of an image diverge: decode B * n rows
             # (the reference repeats features and masks the same way, AttModel.py:331-334)
@@ -284,7 +288,9 @@ class TransformerModel(nn.Module):
                 raise hip.BofiHipError(f"{feats.size(0)} sampled rows exceed bofi_max_batch={self.max_batch}")
             self._sample_calls = getattr(self, "_sample_calls", 0) + 1
             seed = (int(getattr(self.opt, "seed", 0)) << 32) + self._sample_calls
-            r = self._decode_saic_graphed(eng, feats, lens, not output_logsoftmax, (temperature, seed))
+            adaptive = getattr(self.opt, "bofi_saic_iter_budget", True)
+            r = self._decode_saic_graphed(eng, feats, lens, not output_logsoftmax, (temperature, seed), cap=self.saic_cap() if adaptive else None)
+            r = self.saic_finish(r)
         torch.cuda.synchronize()
         end = time.time()
         if train_mode == "SAIC" and sample_method == "sample":
