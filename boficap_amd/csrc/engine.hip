@@ -663,7 +663,10 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     } else {
         LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s));
     }
-    ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : 1, st.last, -1, cfg.pad_idx, seq, s, nullptr, nullptr, nullptr, nullptr,
+    // (a round that another one follows: its ids are all the next round reads -- the log-probs it would write are overwritten: not stored)
+    static const int ids_only_on = [] { const char* v = getenv("BOFI_REFINE_IDS_ONLY"); return v ? atoi(v) : 1; }();      // developer knob: 0 = every round stores its log-probs
+    const int lsm = (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : ((ids_only_on && round + 1 < rounds && lsrc) ? 2 : 1);
+    ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, lsm, st.last, -1, cfg.pad_idx, seq, s, nullptr, nullptr, nullptr, nullptr,
                                        lsrc, gen.Npad));
     }
     return BOFI_OK;

@@ -726,7 +726,8 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
         float t = v[i];
         if (log_softmax) {
             t = (first_nan != 0x7fffffff) ? __builtin_nanf("") : (t - m) - lse;    // one NaN poisons the row's softmax
-            x[idx] = t;
+            if (log_softmax != 2) x[idx] = t;           // 2: the ids only (a refinement round whose log-probs the next round overwrites): the same
+                                                        // comparison values, no store
         } else if (src) {
             x[idx] = t;                                 // raw logits asked for: the copy to the caller's pitch
         }
