@@ -47,6 +47,32 @@ def pick_concurrent_streams(n: int, device=None, candidates: int = 16, spin_cycl
     return chosen
 
 
+def pick_stream_beside(main, device=None, candidates: int = 12, spin_cycles: int = 400_000):
+    """A new HIP stream that really runs BESIDE ``main`` (same probe as pick_concurrent_streams: a freshly created stream may share main's
+    hardware queue -- which one it gets depends on how many streams the process has made before -- and then serialises behind it).  Falls back
+    to the last candidate if none overlaps."""
+    import time
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    with torch.cuda.device(dev):
+        def span(streams):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin_cycles)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        span([main])
+        one = min(span([main]) for _ in range(3))
+        cand = None
+        for _ in range(candidates):
+            cand = torch.cuda.Stream(device=dev)
+            if min(span([main, cand]) for _ in range(2)) < 1.5 * one:
+                return cand
+    return cand
+
+
 class BofiEngine:
     def __init__(self, cfg: BofiConfig, dtype: torch.dtype = torch.bfloat16, max_batch: int = 64,
                  max_regions: int = 36, device: Optional[torch.device] = None):

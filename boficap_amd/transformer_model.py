@@ -197,7 +197,8 @@ class TransformerModel(nn.Module):
         eng = self.engine()
         side = self.__dict__.get("_side_engine")
         if side is None or side[0] is not eng:
-            side = self.__dict__["_side_engine"] = (eng, eng.fork(), torch.cuda.Stream(device=eng.device))
+            from .engine import pick_stream_beside              # (a stream that overlaps the caller's, found by probing: not any new stream does)
+            side = self.__dict__["_side_engine"] = (eng, eng.fork(), pick_stream_beside(torch.cuda.current_stream(eng.device), eng.device))
         _, eng2, s2 = side
         feats, lens = self._as_input(att_feats), self._att_len(att_masks)
         main = torch.cuda.current_stream(feats.device)
