@@ -19,13 +19,15 @@ OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libboficap_hip.so")
 SOURCES = ["ln.hip", "gemm.hip", "gemm_glds.hip", "gemm_pers.hip", "attn.hip", "attn_bf16.hip", "naic.hip", "train_ops.hip", "gemm_tn.hip", "attn_bwd_mfma.hip", "repack.hip", "bound_ops.hip", "rowblock.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -fno-slp-vectorize -fno-vectorize: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32.  Measured on MI355X (round 2, tools/exp/dbg_step*.py): a wavefront
+# -fno-slp-vectorize -fno-vectorize: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32.  Measured on MI355X (round 2, dev/exp/dbg_step*.py): a wavefront
 # whose float32 FMA chains were packed by the SLP vectoriser (v_pk_fma_f32 with op_sel operands) computed wrong sums in lanes 48-63
 # of one accumulator -- only while wavefronts of OTHER kernels were issuing MFMAs on the same SIMD (several decodes in flight),
 # never alone and never beside copies of itself.  Without the packed forms the results are bit-stable under any concurrency.  (The
 # packed forms buy nothing here anyway: the VALU work of these kernels sits beside MFMA or memory latency.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fno-vectorize", "-Wall", "-Wno-unused-function",
          f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+if os.environ.get("BOFI_EXPERIMENTS") == "1":       # developer build: the timing-only ablation switches of engine.hip (BOFI_EXP_SKIP / BOFI_EXP_ITERS); use with --force
+    FLAGS.append("-DBOFI_EXPERIMENTS")
 
 
 def _newer(target: str, deps) -> bool:

@@ -119,10 +119,6 @@ struct RbFfnArgs {
     uint16_t* yb; float* stats_out;           // optional: bf16 copy [M][512], partial sums [M][16][2]
     int M, dff;
     int dbg;                                  // developer aid (BOFI_RB_DBG & 16): in-kernel stamps
-    // optional: a LayerNorm-folded projection of the sublayer's OUTPUT rows in the same launch (the next layer's q|k|v): the block of new rows
-    // stays in LDS -- no second launch, no re-staging of the float32 stream.  pwp = fragment-major [pN][512] (NULL: off), pc / pcs its folded bias
-    // and column sums, py bf16 [M][pldy], pN % 64 == 0.  Same values as launch_rb_gemm on y, bit for bit.
-    const rb_u32x4* pwp; const float* pc; const float* pcs; void* py; int pldy; int pN;
 };
 struct RbAttnArgs {
     const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64
@@ -144,20 +140,6 @@ struct RbGemmArgs {
     int dbg;                                  // developer aid (BOFI_RB_DBG & 16: in-kernel stamps, set by the C entry)
 };
 int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st);
-// the whole encoder stack as ONE launch (rowblock.hip, rb_encoder_kernel): a workgroup keeps two images' rows for every layer
-struct RbEncLayer {
-    const rb_u32x4* wqkv; const float* cqkv; const float* csqkv;      // q|k|v [1536][512] fragment-major, LayerNorm-folded bias / column sums [1536]
-    const rb_u32x4* wo; const float* bo;                              // [512][512], bias
-    const rb_u32x4* w1; const float* c1; const float* cs1;            // [dff][512], folded bias / column sums [dff]
-    const rb_u32x4* w2; const float* b2;                              // [512][dff], bias
-};
-struct RbEncArgs {
-    RbEncLayer layer[8]; int nlayers;
-    const float* x; float* y;                 // residual stream in / out [B*R][512] float32 (may be the same)
-    const int* klen;                          // keys per image (att_len) or null = R
-    int B, R, dff, dbg;
-};
-int launch_rb_encoder(const RbEncArgs& a, hipStream_t st);           // -1: shape not covered
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st);
 int launch_rb_attn(const RbAttnArgs& a, hipStream_t st);           // -1: shape not covered
 int launch_rb_pack_frag(const void* w, void* out, int N, int K, hipStream_t st);

@@ -360,7 +360,15 @@ struct bofi_engine {
         if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_MIN_ROWS"); v = e ? atoi(e) : 4096; gen = bofi::g_env_generation; }
         return v;
     }
-    static bool exp_skip(const char* what) { const char* v = getenv("BOFI_EXP_SKIP"); return v && strstr(v, what); }
+    // timing-only ablation switches (results INVALID): compiled in only by `BOFI_EXPERIMENTS=1 python -m boficap_amd.build --force`
+#ifdef BOFI_EXPERIMENTS
+    static bool exp_skip(const char* what) {
+        static const char* v = [] { const char* e = getenv("BOFI_EXP_SKIP"); if (e) fprintf(stderr, "[boficap_hip] BOFI_EXP_SKIP=%s: kernels skipped, RESULTS INVALID\n", e); return e; }();
+        return v && strstr(v, what);
+    }
+#else
+    static constexpr bool exp_skip(const char*) { return false; }
+#endif
     int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
         static const bool on = env_on("BOFI_RB_ATTN");
         if (exp_skip("attn")) return BOFI_OK;
@@ -389,26 +397,12 @@ struct bofi_engine {
         static const bool on = env_on("BOFI_RB_FFN");
         return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560 && M >= rb_min_rows();
     }
-    // next / next_y / next_ldy: the LayerNorm-folded projection that reads this sublayer's output rows (the next layer's q|k|v), run in the same
-    // launch while the rows are still in LDS (ffn_next_ok); the caller then skips its own launch of that projection
-    bool ffn_next_ok(const Lin& w1, const Lin& w2, const Lin& next, int M) const {
-        // BOFI_RB_FFN_NEXT=1 turns it on (re-read after bofi_reload_env).  OFF by default: exact (tests/test_gpu_rowblock.py) and 5 us faster than the two
-        // launches alone, but slower in the decode -- 200.5 k against 204.5 k img/s, 0.554 against 0.546 ms per batch one at a time
-        // (profiles/r03_ffn_next_projection.txt): the fused kernel's main loop runs 6 % slower (the compiler allocates registers for its largest
-        // phase) and its closing epilogue 11 k ticks longer, which is what staging the block from memory cost in the first place
-        static int gen = -1, on = 0;
-        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_FFN_NEXT"); on = e ? atoi(e) : 0; gen = bofi::g_env_generation; }
-        static const int version = [] { const char* e = getenv("BOFI_RB_FFN_V"); return e ? atoi(e) : 2; }();
-        return on && version == 2 && cfg.d_ff == 2048 && ffn_sublayer_ok(w1, w2, M) && fold_rb_ok(next, M) && next.Npad % 64 == 0 && !exp_skip("ffn") && !exp_skip("qkv");
-    }
-    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s, const Lin* next = nullptr, void* next_y = nullptr,
-                     int next_ldy = 0) {
+    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s) {
         if (!ffn_sublayer_ok(w1, w2, M)) return -1;
         if (exp_skip("ffn")) return BOFI_OK;
         bofi::RbFfnArgs a{};
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
-        if (next) { a.pwp = (const bofi::u32x4*)next->wp; a.pc = next->b; a.pcs = next->cs; a.py = next_y; a.pldy = next_ldy; a.pN = next->Npad; }
         return bofi::launch_rb_ffn(a, s);
     }
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
@@ -441,14 +435,11 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
     }
     const void* xa = stream_t(x_enc, xb_enc);
     const bool memory_out_needs_copy = false;           // (memory_out is a LayerNorm of the float32 stream itself)
-    bool qkv_made = false;                               // this layer's q|k|v came out of the previous layer's feed-forward launch
     for (size_t li = 0; li < enc.size(); ++li) {
         auto& l = enc[li];
-        if (!qkv_made) {
-            int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
+        {   int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
             if (rc > 0) return rc;
             if (rc < 0) { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
-        qkv_made = false;
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
@@ -463,9 +454,7 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         }
         {   // the consumers of this layer's output: the next layer's q|k|v (or the stacked cross K|V): tiled GEMMs read the copy + statistics
             const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;
-            const Lin* next = (li + 1 < enc.size() && l.qkv.Npad == 3 * d && ffn_next_ok(l.w1, l.w2, enc[li + 1].qkv, M)) ? &enc[li + 1].qkv : nullptr;
-            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s, next, qkv, 3 * d) : -1;
-            qkv_made = rc == BOFI_OK && next != nullptr; }
+            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s) : -1; }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -570,7 +559,11 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
         ENG_OK(enqueue_bound_dense(att_len, B, R, s));
     } else {
         ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
-        static const int exp_iters = [] { const char* v = getenv("BOFI_EXP_ITERS"); return v ? atoi(v) : 0; }();     // timing experiment: fewer iterations enqueued
+#ifdef BOFI_EXPERIMENTS
+        static const int exp_iters = [] { const char* v = getenv("BOFI_EXP_ITERS"); if (v) fprintf(stderr, "[boficap_hip] BOFI_EXP_ITERS=%s: bounding loop truncated, RESULTS INVALID\n", v); return v ? atoi(v) : 0; }();
+#else
+        constexpr int exp_iters = 0;                 // (timing experiment, experiments build only)
+#endif
         // (bofi_engine_set_bound_iter_cap: a caller that knows how many iterations its captions take enqueues that many + a margin instead of
         // all S -- an iteration past the last live one is five launches that return at once -- and decodes again without the cap when the
         // count of live iterations, *bound_iters, reaches the cap: the loop may then not have ended)
@@ -596,14 +589,11 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     for (int round = 0; round < rounds; ++round) {
     ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                    st_fill, s));
-    bool qkv_made = false;                               // this layer's q|k|v came out of the previous layer's feed-forward launch
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
-        if (!qkv_made) {
-            int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
+        {   int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
             if (rc > 0) return rc;
             if (rc < 0) { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
-        qkv_made = false;
         bofi::AttnArgs a{};
         a.q = qkv; a.k = (char*)qkv + (size_t)d * tsz; a.v = (char*)qkv + (size_t)2 * d * tsz;
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = S; a.Lk = S;
@@ -636,9 +626,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         }
         {   // next consumer: the next layer's q|k|v or the generator
             const bool need_copy = !(fold_rb_ok(l.qkv, M) && gen_rb);
-            const Lin* next = (li + 1 < dec.size() && ffn_next_ok(l.w1, l.w2, dec[li + 1].qkv, M)) ? &dec[li + 1].qkv : nullptr;
-            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s, next, qkv, 3 * d) : -1;
-            qkv_made = rc == BOFI_OK && next != nullptr; }
+            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s) : -1; }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -894,6 +882,10 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->q1_group = 0;                             // per-call knobs are not inherited (the Python handle starts from the defaults)
     e->sample_temperature = 1.0f;
     e->sample_seed = 0;
+    e->bound_iter_cap = 0;                       // (a capped parent must not truncate the fork's bounding loop)
+    e->live_max = nullptr;                       // (a raw device pointer the fork's handle does not keep alive)
+    e->saic_it_begin = 1;
+    e->saic_it_end = 0;
     e->st = bofi::BoundState{};
     int rc = e->alloc_workspace();
     if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");

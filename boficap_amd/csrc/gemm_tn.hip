@@ -158,131 +158,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     gemm_tn_tile<2>(p, blockIdx.x * 64, blockIdx.y * 64, m_begin, min(p.M, m_begin + p.m_per_block), blockIdx.y == 0);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// The same product with the operands brought in by LDS-DMA (global_load_lds_dwordx4: no register staging) into a ring of NS stages of
-// 32 contraction rows, 256 x 256 outputs per workgroup (8 wavefronts as 4 x 2, each 64 x 128 = 4 x 8 MFMA tiles).
-// Why: the register-staged kernel above keeps ONE 64-row step in flight, and a step's MFMA work (1-2 k cycles per SIMD) is shorter than
-// a load's round trip to the Infinity Cache -- every step waits for its operands (80 steps x ~3 us = the 255 us of 24 decoder-sized
-// problems, whatever the tile: profiles/r03_tn_tile_256.txt).  Little's law: a CU that eats B bytes per clock needs B x latency bytes
-// in flight; 256 x 256 outputs eat 30 B/clk at the full MFMA rate (128 x 128: 60), three stages of 32 KB in flight cover ~3 k cycles.
-// A DMA instruction writes 1 KiB lane-linearly = 2 rows of 512 B: lane l -> row l >> 5, LDS chunk l & 31, which receives SOURCE chunk
-// (l & 31) ^ key(row) (the swizzle of the transposing reads, applied to the source address as in gemm_glds.hip).
-// Needs M % 32 == 0 per row block (DMA cannot write the zeros a ragged last step needs); operand columns past a_cols / b_cols are
-// clamped to the last chunk (they only feed outputs that are never stored).
-constexpr int TND_NS = 4, TND_TM = 32, TND_T = 256;
-constexpr int TND_STAGE = 2 * TND_TM * TND_T * 2;                // bytes per stage: A tile + B tile
-
-__device__ __forceinline__ void gemm_tn_tile_dma(const GemmTnParams& p, int i0, int j0, int m_begin, int m_end, bool first_col) {
-    constexpr int T = TND_T, TM = TND_TM, NS = TND_NS;
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * TND_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
-    if (m_begin >= m_end) return;
-    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 128;
-    auto key = [](int r) { return (r & 7) << 1; };
-    // DMA sources: per stage 16 + 16 wave instructions (2 rows each); wave w issues A rows 4w .. 4w+3 and B rows 4w .. 4w+3 (2 + 2 instructions)
-    const int lrow = lane >> 5, lch = lane & 31;
-    const bf16_t* asrc[2];
-    const bf16_t* bsrc[2];
-    const int a_chunks = p.a_cols >> 3, b_chunks = p.b_cols >> 3;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = wave * 4 + u * 2 + lrow;                   // row of the stage
-        const int ca = min((i0 >> 3) + (lch ^ key(r)), a_chunks - 1), cb = min((j0 >> 3) + (lch ^ key(r)), b_chunks - 1);
-        asrc[u] = p.a + (size_t)(m_begin + r) * p.lda + (size_t)ca * 8;
-        bsrc[u] = p.b + (size_t)(m_begin + r) * p.ldb + (size_t)cb * 8;
-    }
-    const int nsteps = (m_end - m_begin) / TM;
-    auto issue = [&](int slot, int st) {
-        unsigned char* sa = ring + slot * TND_STAGE + (wave * 4) * (T * 2);
-        unsigned char* sb = sa + TM * T * 2;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[u] + (size_t)st * TM * p.lda),
-                                             (__attribute__((address_space(3))) void*)(sa + u * 1024), 16, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[u] + (size_t)st * TM * p.ldb),
-                                             (__attribute__((address_space(3))) void*)(sb + u * 1024), 16, 0, 0);
-    };
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int row0 = 4 * g + tq, rsw = key(row0);                // (row0 + 16 swizzles like row0)
-    auto frag = [&](const bf16_t* tile, int col) -> bf16x8 {
-        const bf16_t* p0 = tile + row0 * T + (((col >> 3) ^ rsw) << 3) + (col & 7);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * T));
-        bf16x8 f;
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        return f;
-    };
-    const bool do_colsum = p.colsum != nullptr && first_col;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};                        // thread -> columns (tid & 63) + 64 q, rows (tid >> 6) * 4 .. + 3 of a stage
-    const int cc = tid & 63, crg = tid >> 6;
-
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st)
-        if (st < nsteps) issue(st, st);
-    for (int st = 0; st < nsteps; ++st) {
-        // retire stage st: at most min(NS - 2, nsteps - 1 - st) younger stages (4 DMA instructions each) stay in flight
-        const int younger = nsteps - 1 - st;
-        if (younger >= 2) wait_vmcnt<8>();
-        else if (younger == 1) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                            // stage st has landed everywhere; everyone is through with stage st - 1
-        if (st + NS - 1 < nsteps) issue((st + NS - 1) % NS, st + NS - 1);
-        const bf16_t* ta = reinterpret_cast<const bf16_t*>(ring + (st % NS) * TND_STAGE);
-        const bf16_t* tb = ta + TM * T;
-        bf16x8 fa[4], fb[8];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fa[t] = frag(ta, wi + t * 16 + 4 * tp);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) fb[t] = frag(tb, wj + t * 16 + 4 * tp);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-        if (do_colsum) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int hh = 0; hh < 4; ++hh) {
-                    const int r = crg * 4 + hh, c = cc + 64 * q;
-                    csum[q] += bf16_to_f32(ta[r * T + ((((c >> 3) ^ key(r))) << 3) + (c & 7)]);
-                }
-        }
-    }
-    if (do_colsum) {                                              // combine the 8 row groups, one atomic per column
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(ring);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) red[crg * T + cc + 64 * q] = csum[q];
-        __syncthreads();
-        if (tid < T && i0 + tid < p.NI) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) t += red[w * T + tid];
-            atomicAdd(&p.colsum[i0 + tid], t);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int j = j0 + wj + b * 16 + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + wi + a * 16 + 4 * g + r;
-                if (i < p.NI && j < p.NJ) atomicAdd(&p.c[(size_t)i * p.ldc + j], acc[a][b][r]);
-            }
-        }
-}
-
 // Many independent weight-gradient GEMMs in one launch.  A training step has ~126 of them (one per Linear use), each a
 // small output with a long contraction; launched one by one every GEMM is a latency chain of its own with two workgroups
 // per CU at best.  Grouped, the step's weight gradients are ~15 000 tiles in a few launches: no row split (no extra atomics),
@@ -318,23 +193,6 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const GemmTnGroup 
     gemm_tn_tile<WT>(q, (local / tj) * T, (local % tj) * T, m_begin, min(q.M, m_begin + q.m_per_block), local % tj == 0);
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_grouped_dma_kernel(const GemmTnGroup grp) {
-    int t = blockIdx.x;
-    {   // XCD-aware order, as gemm_tn_grouped_kernel
-        const int nt = gridDim.x, q8 = nt >> 3, r8 = nt & 7, xcd = t & 7, idx = t >> 3;
-        t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    }
-    int lo = 0, hi = grp.n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (grp.tile_first[mid] <= t) lo = mid; else hi = mid - 1;
-    }
-    const GemmTnParams& q = grp.prob[lo];
-    const int local = t - grp.tile_first[lo], tj = (q.NJ + TND_T - 1) / TND_T;
-    const int m_begin = blockIdx.y * q.m_per_block;
-    gemm_tn_tile_dma(q, (local / tj) * TND_T, (local % tj) * TND_T, m_begin, min(q.M, m_begin + q.m_per_block), local % tj == 0);
-}
-
 static int check_tn(const void* a, int lda, int a_cols, const void* b, int ldb, int b_cols, const float* c, int ldc, int M, int NI, int NJ) {
     if (!a || !b || !c || M < 0 || NI <= 0 || NJ <= 0 || ldc < NJ) return BOFI_ERR_ARG;
     if (a_cols < NI || b_cols < NJ || a_cols % 8 || b_cols % 8 || lda < a_cols || ldb < b_cols || lda % 8 || ldb % 8) return BOFI_ERR_ARG;
@@ -350,22 +208,15 @@ int launch_gemm_tn_grouped(int n, const void* const* a, const int* lda, const in
         if (int rc = check_tn(a[e], lda[e], a_cols[e], b[e], ldb[e], b_cols[e], c[e], ldc[e], M[e], NI[e], NJ[e])) return rc;
     for (int e = 0; e < n; ++e) g_gemm_flops += 2.0 * M[e] * NI[e] * NJ[e];
     static const int forced_wt = [] { const char* v = getenv("BOFI_TN_WT"); return v ? atoi(v) : 0; }();   // developer knob: 2 or 4 = one register-staged tile class for everything
-    // BOFI_TN_DMA=1: the LDS-DMA class (read again after bofi_reload_env(): the tests flip it).  OFF by default: correct, and no faster --
-    // 24 decoder-sized problems 292 against 262 us, XE step 7.13 against 6.90 ms (profiles/r03_tn_tile_256.txt).  Its three stages in
-    // flight did not shorten the 1.8 us a CU spends per 32-row stage, so the premise in its header (one step in flight = the bound) is
-    // wrong; FETCH_SIZE says 476-525 MB per launch for 420 MB of operands (no re-fetch problem either) at ~1.9 TB/s HBM-side: the open
-    // question is why 224-896 workgroups that each walk 256-512-byte pieces of rows 1-4 KB apart get no more than that.
-    static int env_seen = -1, dma_on = 0;
-    if (env_seen != g_env_generation) { const char* v = getenv("BOFI_TN_DMA"); dma_on = v ? atoi(v) : 0; env_seen = g_env_generation; }
-    // three classes of problems: outputs of at least 256 x 256 over a multiple of 32 rows take the LDS-DMA ring kernel (256 x 256 tiles, 512
-    // threads), other outputs of at least 128 x 128 the register-staged 128 x 128 tile, the small ones (classifier heads) 64 x 64
+    // two classes of problems: outputs of at least 128 x 128 take the register-staged 128 x 128 tile, the small ones (classifier heads) 64 x 64.
+    // (Round 3's third class -- 256 x 256 outputs fed by an LDS-DMA ring -- measured no faster, 292 against 262 us on 24 decoder-sized problems,
+    // and left the library in round 4: profiles/r03_tn_tile_256.txt, docs/history/r03.md.)
     auto cls_of = [&](int e) {
         if (forced_wt) return forced_wt == 4 ? 1 : 0;
-        if (dma_on && NI[e] >= 256 && NJ[e] >= 256 && M[e] % 32 == 0) return 2;
         return (NI[e] >= 128 && NJ[e] >= 128) ? 1 : 0;
     };
-    for (int cls = 2; cls >= 0; --cls) {
-        const int T = cls == 2 ? 256 : cls == 1 ? 128 : 64;
+    for (int cls = 1; cls >= 0; --cls) {
+        const int T = cls == 1 ? 128 : 64;
         int e = 0;
         while (e < n) {
             GemmTnGroup g;
@@ -383,13 +234,10 @@ int launch_gemm_tn_grouped(int n, const void* const* a, const int* lda, const in
             if (!g.n) break;
             g.tile_first[g.n] = tiles;
             // enough workgroups to fill the CUs (LDS: 1 / 2 / 5 workgroups per CU); a split costs one more tile of atomics per output tile
-            static const int want2 = [] { const char* v = getenv("BOFI_TN_WANT"); return v ? atoi(v) : 256; }();
-            const int want = cls == 2 ? want2 : cls == 1 ? 512 : 1280;
+            const int want = cls == 1 ? 512 : 1280;
             g.splits = max(1, min(min(8, (max_m + 255) / 256), (want + tiles - 1) / tiles));
-            // (row blocks in multiples of 64: the DMA class's 32-row stages divide them, its last block ends at M, a multiple of 32)
             for (int k = 0; k < g.n; ++k) g.prob[k].m_per_block = ((g.prob[k].M + g.splits - 1) / g.splits + 63) / 64 * 64;
-            if (cls == 2) hipLaunchKernelGGL(gemm_tn_grouped_dma_kernel, dim3(tiles, g.splits), dim3(512), 0, st, g);
-            else if (cls == 1) hipLaunchKernelGGL(gemm_tn_grouped_kernel<4>, dim3(tiles, g.splits), dim3(256), 0, st, g);
+            if (cls == 1) hipLaunchKernelGGL(gemm_tn_grouped_kernel<4>, dim3(tiles, g.splits), dim3(256), 0, st, g);
             else hipLaunchKernelGGL(gemm_tn_grouped_kernel<2>, dim3(tiles, g.splits), dim3(256), 0, st, g);
             BOFI_CHECK_LAUNCH();
         }

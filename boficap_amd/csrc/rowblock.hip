@@ -140,179 +140,6 @@ __device__ __forceinline__ void rb_pass_store(const unsigned char* stage, const 
     }
 }
 
-// rb_pass_store that ALSO leaves the new rows in LDS for a projection fused behind the sublayer (rb_ffn2_kernel<true>): bf16, in the block
-// layout rb_segment reads (nblk), with the row statistics of the LayerNorm fold in s_mean / s_rstd -- summed in the order rb_gemm_kernel's
-// staging sums them (a lane group's 16 four-column pieces, 32 columns apart, one after the other; then the 8 lane groups as oct_sum does), so
-// that the fused projection equals rb_gemm_kernel on the stored rows bit for bit.  sc: 2 KiB of LDS of this wavefront's own ([4 rows][16
-// pieces][8 lane groups] floats: lanes 0-31 then each walk one (row, lane group) chain).
-template <int RPW>
-__device__ __forceinline__ void rb_pass_store_blk(const unsigned char* stage, const RbOut& o, int prow0, int pass_rows, int m0, int rows_live, int wave, int lane,
-                                                  const float4 (&res)[RPW][2], unsigned char* nblk, unsigned char* sc, float* s_mean, float* s_rstd) {
-    static_assert(RPW == 4, "the statistics scratch is laid out for four rows per wavefront and pass");
-    float* scf = reinterpret_cast<float*>(sc);
-    float ps[RPW][2], pq[RPW][2];
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int lr = wave * RPW + j, r = prow0 + lr;             // row of the pass / of the block
-        const bool live = lr < pass_rows && r < rows_live;
-        const float4 s0 = *reinterpret_cast<const float4*>(stage + lr * RB_SPITCH + lane * 16);
-        const float4 s1 = *reinterpret_cast<const float4*>(stage + lr * RB_SPITCH + 1024 + lane * 16);
-        float4 o0 = make_float4(res[j][0].x + s0.x, res[j][0].y + s0.y, res[j][0].z + s0.z, res[j][0].w + s0.w);
-        float4 o1 = make_float4(res[j][1].x + s1.x, res[j][1].y + s1.y, res[j][1].z + s1.z, res[j][1].w + s1.w);
-        const size_t m = live ? (size_t)(m0 + r) : 0;
-        if (live) {
-            float* yr = o.y + m * o.ldy + lane * 4;
-            *reinterpret_cast<float4*>(yr) = o0;
-            *reinterpret_cast<float4*>(yr + 256) = o1;
-            if (o.yb) {
-                *reinterpret_cast<uint2*>(o.yb + m * 512 + lane * 4) = make_uint2(pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w));
-                *reinterpret_cast<uint2*>(o.yb + m * 512 + 256 + lane * 4) = make_uint2(pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w));
-            }
-        } else {                                                  // rows past the batch: zeros, as rb_gemm_kernel stages them
-            o0 = make_float4(0.f, 0.f, 0.f, 0.f); o1 = o0;
-        }
-        if (o.stats) {
-            const float a0 = oct_sum((o0.x + o0.y) + (o0.z + o0.w)), q0 = oct_sum((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w));
-            const float a1 = oct_sum((o1.x + o1.y) + (o1.z + o1.w)), q1 = oct_sum((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
-            if (live && !(lane & 7)) {
-                float2* sp = reinterpret_cast<float2*>(o.stats + m * 32);
-                sp[lane >> 3] = make_float2(a0, q0);
-                sp[8 + (lane >> 3)] = make_float2(a1, q1);
-            }
-        }
-        // columns lane*4 .. +3 and 256 + lane*4 .. +3: 16-byte chunks lane >> 1 and 32 + (lane >> 1), half lane & 1
-        *reinterpret_cast<uint2*>(nblk + rb_off(r, lane >> 1) + (lane & 1) * 8) = make_uint2(pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w));
-        *reinterpret_cast<uint2*>(nblk + rb_off(r, 32 + (lane >> 1)) + (lane & 1) * 8) = make_uint2(pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w));
-        ps[j][0] = (o0.x + o0.y) + (o0.z + o0.w); pq[j][0] = (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w);
-        ps[j][1] = (o1.x + o1.y) + (o1.z + o1.w); pq[j][1] = (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
-    }
-    // lane = piece (lane >> 3) of lane group (lane & 7); its second value is piece 8 + (lane >> 3): offsets lane and 64 + lane of the row's 128
-    const int rr = (lane >> 3) & 3, sub = lane & 7;
-    float tot[2];
-#pragma unroll
-    for (int what = 0; what < 2; ++what) {
-#pragma unroll
-        for (int j = 0; j < RPW; ++j) { scf[j * 128 + lane] = what ? pq[j][0] : ps[j][0]; scf[j * 128 + 64 + lane] = what ? pq[j][1] : ps[j][1]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        float t = 0.f;
-#pragma unroll
-        for (int pc = 0; pc < 16; ++pc) t += scf[rr * 128 + pc * 8 + sub];
-        tot[what] = oct_sum(t);
-        __builtin_amdgcn_wave_barrier();                          // (the second round reuses the scratch)
-    }
-    if (lane < 32 && sub == 0) {
-        const int r = prow0 + wave * RPW + rr;
-        const float mean = tot[0] * (1.0f / 512.0f);
-        const float var = fmaxf((tot[1] - tot[0] * mean) * (1.0f / 511.0f), 0.f);
-        s_mean[r] = mean;
-        s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(512) void rb_ffn_kernel(RbFfnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xt = smem;                                  // LN input rows in bf16 (the raw stream: the norm is folded into w_1)
-    unsigned char* ht = smem + 65536;                          // 512 hidden columns of the block
-    float* c1s = reinterpret_cast<float*>(smem + 131072);      // [dff]
-    float* cs1s = c1s + a.dff;                                 // [dff]
-    float* b2s = cs1s + a.dff;                                 // [512]
-    float* s_mean = b2s + 512;                                 // [64]
-    float* s_rstd = s_mean + 64;                               // [64]
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * 64, rounds = a.dff >> 9, lbase = rb_lane_base(l15, g);
-    auto w1seg = [&](int r) { return a.w1p + (size_t)(r * 8 + wave) * (16 * 256) + lane; };
-    auto w2seg = [&](int r) { return a.w2p + ((size_t)wave * (a.dff >> 5) + r * 16) * 256 + lane; };
-    bf16x8 wb[RB_PF * 4];
-    rb_prime<4>(w1seg(0), wb);
-
-    // ---- per-column constants
-    for (int i = tid; i < a.dff; i += 512) { c1s[i] = a.c1[i]; cs1s[i] = a.cs1[i]; }
-    b2s[tid] = a.b2[tid];
-    // ---- stage the block: wavefront w takes rows 8w .. 8w+7, eight lanes per row (128 contiguous bytes per row and load), row
-    // statistics on the way (unbiased std, eps on the std: LayerNorm of TransformerModel.py:1346-1349)
-    {
-        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
-        float4 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float sm = 0.f, sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
-        }
-        sm = oct_sum(sm); sq = oct_sum(sq);
-        if (sub == 0) {
-            const float mean = sm * (1.0f / 512.0f);
-            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
-            s_mean[r] = mean;
-            s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
-        }
-    }
-    __syncthreads();
-
-    f32x4 acc2[4][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc2[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 1
-    for (int r = 0; r < rounds; ++r) {
-        // ---- hidden columns r*512 + wave*64 .. +63 of the block
-        f32x4 acc1[4][4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb_segment<4>(w1seg(r), w2seg(r), wb, smem, lbase, acc1);
-        if (r > 0) __syncthreads();                            // every wavefront is through with the previous 512 hidden columns
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int hc = r * 512 + wave * 64 + nt * 16 + g * 4;
-            const float4 cc = *reinterpret_cast<const float4*>(c1s + hc);
-            const float4 cs = *reinterpret_cast<const float4*>(cs1s + hc);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float mu = s_mean[mt * 16 + l15], rs = s_rstd[mt * 16 + l15];
-                const f32x4 t = acc1[nt][mt];
-                const float h0 = fmaxf(rs * (t[0] - mu * cs.x) + cc.x, 0.f), h1 = fmaxf(rs * (t[1] - mu * cs.y) + cc.y, 0.f);
-                const float h2 = fmaxf(rs * (t[2] - mu * cs.z) + cc.z, 0.f), h3 = fmaxf(rs * (t[3] - mu * cs.w) + cc.w, 0.f);
-                *reinterpret_cast<uint2*>(ht + rb_off(mt * 16 + l15, wave * 8 + nt * 2 + (g >> 1)) + (g & 1) * 8) = make_uint2(pack_bf16(h0, h1), pack_bf16(h2, h3));
-            }
-        }
-        __syncthreads();
-        // ---- output columns wave*64 .. +63, K = this round's 512 hidden columns
-        rb_segment<4>(w2seg(r), r + 1 < rounds ? w1seg(r + 1) : w2seg(r), wb, smem, lbase + 65536, acc2);
-    }
-
-    // ---- closing epilogue: + b_2 + x -> stream (+ bf16 copy, + partial sums), two passes of 32 rows through LDS (the x and h blocks are dead)
-    const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
-    const int rows_live = min(64, a.M - m0);
-    float4 bb[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bb[nt] = *reinterpret_cast<const float4*>(b2s + wave * 64 + nt * 16 + g * 4);
-    __syncthreads();                                           // the last segment's reads of the h block are done everywhere
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        float4 res[4][2];
-        rb_pass_residual<4>(out, ps * 32, m0, rows_live, wave, lane, res);
-#pragma unroll
-        for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) rb_stage_tile(smem, tr, l15, wave * 64 + nt * 16 + g * 4, acc2[nt][ps * 2 + tr], bb[nt]);
-        __syncthreads();
-        rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
-        if (ps == 0) __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------------------
 // The same sublayer with the two GEMMs on different wavefronts (the default).  In rb_ffn_kernel every wavefront runs w_1, then the ReLU
 // epilogue, then w_2 of the same 512 hidden columns, two workgroup barriers per round: all eight wavefronts do their vector work at
@@ -331,11 +158,6 @@ __device__ __forceinline__ void rb_signal(unsigned* flag, int lane) {      // be
     if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool F32OUT>
-__device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsigned char* blk, unsigned char* stage_all, float* cst, const float* s_mean,
-                                               const float* s_rstd, int m0, int wave, int lane, int ch0, int chstep, bf16x8 (&wb)[RB_PF * 4]);      // (below, with rb_gemm_kernel)
-
-template <bool PROJ>
 __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;                                  // [64][512] bf16, swizzled, row pitch 1 024 B
@@ -468,12 +290,7 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
     __syncthreads();                                           // every hidden chunk consumed: x block and ring are dead
     RB_STAMP(a.dbg, 8 + wave, lane, 4);
 
-    // PROJ: a projection of the NEW rows follows in this launch.  LDS from here on: [0, 66 048) the float32 row staging of the passes, then
-    // the projection's per-wavefront 9 KB; [73 728, 139 264) the new rows as a bf16 block (over the dead hidden ring and c1s);
-    // [139 264, 147 456) and [154 624, 162 816) 2 KiB of statistics scratch per wavefront (the first over the dead cs1s); b2s / s_mean / s_rstd /
-    // flags stay; column constants of the projection at 150 528.  (dff = 2 048: the launcher checks.)
-    unsigned char* nblk = smem + 73728;
-    // ---- closing epilogue (as rb_ffn_kernel): the consumers stage their tiles, all eight wavefronts store whole rows
+    // ---- closing epilogue: the consumers stage their tiles, all eight wavefronts store whole rows
     const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
     const int rows_live = min(64, a.M - m0);
 #pragma unroll
@@ -491,22 +308,10 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
         }
         __syncthreads();
         RB_STAMP(a.dbg, 8 + wave, lane, 5 + 2 * ps);            // (5, 7: tiles staged; 6: first pass stored)
-        if constexpr (PROJ) rb_pass_store_blk<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res, nblk, smem + (wave < 4 ? 139264 : 154624 - 8192) + wave * 2048, s_mean, s_rstd);
-        else rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
+        rb_pass_store<4>(smem, out, ps * 32, 32, m0, rows_live, wave, lane, res);
         if (ps == 0) { RB_STAMP(a.dbg, 8 + wave, lane, 6); __syncthreads(); }
     }
-    if constexpr (!PROJ) RB_STAMP(a.dbg, 8 + wave, lane, 2);
-    if constexpr (PROJ) {
-        RB_STAMP(a.dbg, 8 + wave, lane, 2);                    // rows stored (the chunk stamps 0 .. 5 of the wavefront's row are the projection's from here on)
-        __syncthreads();                                       // the new block and its statistics are complete; the row staging area is free
-        RB_STAMP(a.dbg, 8 + wave, lane, 3);                    // projection starts
-        // (inlined: as a real call -- __attribute__((noinline)) -- the projection costs the sublayer's main loop 25 %, inlined 6 %: the register
-        // allocation of the whole kernel follows its largest phase)
-        RbGemmArgs pj{};
-        pj.wp = a.pwp; pj.c = a.pc; pj.cs = a.pcs; pj.y = a.py; pj.ldy = a.pldy; pj.y_f32 = 0; pj.M = a.M; pj.N = a.pN; pj.relu = 0; pj.dbg = a.dbg;
-        if (wave < (pj.N >> 6)) rb_prime<4>(pj.wp + (size_t)wave * (16 * 256) + lane, wbuf);
-        rb_gemm_chunks<false>(pj, nblk, smem, reinterpret_cast<float*>(smem + 150528), s_mean, s_rstd, m0, wave, lane, wave, 8, wbuf);
-    }
+    RB_STAMP(a.dbg, 8 + wave, lane, 2);
     RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // exit
 }
 
@@ -514,24 +319,14 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
     if (a.M < 1 || a.dff < 512 || a.dff % 512 || a.dff > 2560 || !a.x || !a.w1p || !a.c1 || !a.cs1 || !a.w2p || !a.b2 || !a.y || a.ldx % 4 || a.ldy % 4)
         return BOFI_ERR_ARG;
     const size_t lds = 131072 + (size_t)a.dff * 8 + 2048 + 512 + 64;
-    static const int version = [] { const char* e = getenv("BOFI_RB_FFN_V"); return e ? atoi(e) : 2; }();      // developer knob: 1 = the phase-synchronous kernel
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return BOFI_ERR_HIP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
         attr_set = true;
     }
     RbFfnArgs b = a;
     { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
-    if (a.pwp) {                                               // with the projection of the new rows behind it (rb_ffn2_kernel<true>: its LDS map assumes dff = 2 048)
-        if (version == 1 || a.dff != 2048 || !a.pc || !a.pcs || !a.py || a.pN < 64 || a.pN % 64 || a.pldy % 8) return BOFI_ERR_ARG;
-        hipLaunchKernelGGL(rb_ffn2_kernel<true>, dim3((a.M + 63) / 64), dim3(512), 162816, st, b);
-        g_gemm_flops += 2.0 * a.M * 512.0 * a.pN;
-    }
-    else if (version == 1) hipLaunchKernelGGL(rb_ffn_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
-    else hipLaunchKernelGGL(rb_ffn2_kernel<false>, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
     g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
@@ -935,367 +730,6 @@ int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The ENCODER STACK as one launch (Encoder.forward TransformerModel.py:1391-1395 over EncoderLayer :1408-1413: x <- x + self_attn(LN x),
-// x <- x + ffn(LN x), N layers; the final norm is folded into the consumers of the output).  A workgroup (8 wavefronts) owns TWO images
-// (<= 80 rows) for ALL layers:
-//   * the float32 residual stream never leaves the registers: xr[nt][mt] is the accumulator layout of rb_segment (wavefront w: columns
-//     w*64 .. +63 of all 80 rows), so the output projection and w_2 accumulate straight onto it -- the residual add is free, nothing is
-//     stored between sublayers, and the stream is read and written ONCE per stack instead of four times per layer;
-//   * per sublayer the block goes to LDS as bf16 (the MFMA operand) with its row statistics (LayerNorm fold, as the other kernels);
-//   * attention, wavefront = head, both images: Q^T = Wq_h x^T and K^T = Wk_h x^T come out of rb_seg in the accumulator layout
-//     (lane = row, four consecutive d) -- two d-tiles rounded to bf16 ARE an MFMA operand with k = d in the order {4g..4g+3, 16+4g..16+4g+3},
-//     the same order on both sides, so S^T = K Q^T needs no LDS and no shuffle; V = x Wv_h^T with the operands swapped lands as
-//     lane = d, four consecutive keys: two key tiles are the V^T operand of O^T = V^T P^T, P^T chained from S^T as in rb_attn_head.
-//     q, k, v never exist in memory;
-//   * feed-forward: 256 hidden columns per round through a 40 KB LDS block (row pitch 512 B), w_1 round c+1 and w_2 round c chained
-//     in two register rings (2-tile and 4-tile) that run across phases and layers.
-// Rows of an image must sit in tiles {0,1,2} (image 0) / {2,3,4} (image 1): 32 <= R <= 40.
-// ------------------------------------------------------------------------------------------------------------------------------
-template <int MT, int NT, int KSTEPS, int TSTRIDE, bool SWAP, int PF = RB_PF>
-__device__ __forceinline__ void rb_seg(const u32x4* cur, const u32x4* nxt, bf16x8 (&wb)[PF * NT], const unsigned char* blk, int lbase, f32x4 (&acc)[NT][MT]) {
-    static_assert(KSTEPS % PF == 0, "a segment starts at ring slot 0");
-    asm volatile("" : "+v"(lbase));
-#pragma unroll
-    for (int kb = 0; kb < KSTEPS; ++kb) {
-        bf16x8 xa[MT];
-        const unsigned char* xp = blk + (lbase ^ (kb << 6));
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xp + mt * TSTRIDE);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[nt][mt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[mt], wb[(kb % PF) * NT + nt], acc[nt][mt], 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(kb % PF) * NT + nt], xa[mt], acc[nt][mt], 0, 0, 0);
-        const u32x4* src = kb + PF < KSTEPS ? cur + (kb + PF) * 256 : nxt + (kb + PF - KSTEPS) * 256;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wb[(kb % PF) * NT + nt] = rb_ldw(src + nt * 64);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// element by element: a vector-typed `+=` is emitted as v_pk_add_f32 whatever the vectoriser flags say (build.py, test_shipped_library_has_no_packed_f32_arithmetic)
-__device__ __forceinline__ void rb_add4(f32x4& v, const float4& b) { v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-
-__device__ __forceinline__ bf16x8 rb_pack8(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
-    const u32x4 v = {pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(b0, b1), pack_bf16(b2, b3)};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// S^T and softmax of image P (key / query tiles 2P .. 2P+2 of the block; keys lo <= row < hi) -> P^T operands bp[qi][s]
-template <int P>
-__device__ __forceinline__ void enc_scores(const bf16x8 (&ak)[5][2], const bf16x8 (&bq)[5][2], int lo, int hi, int g, bf16x8 (&bp)[3][2]) {
-    constexpr float SC = 0.125f * 1.44269504088896340736f;
-#pragma unroll
-    for (int qi = 0; qi < 3; ++qi) {
-        f32x4 st[3];
-#pragma unroll
-        for (int kj = 0; kj < 3; ++kj) {
-            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[2 * P + kj][0], bq[2 * P + qi][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[2 * P + kj][1], bq[2 * P + qi][1], c, 0, 0, 0);
-            st[kj] = c;
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int kj = 0; kj < 3; ++kj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = (2 * P + kj) * 16 + g * 4 + r;
-                m = fmaxf(m, (key >= lo && key < hi) ? st[kj][r] : -INFINITY);
-            }
-        m = xor32_max(xor16_max(m));
-        const float mb = m * SC;
-        float sum = 0.f;
-#pragma unroll
-        for (int kj = 0; kj < 3; ++kj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = (2 * P + kj) * 16 + g * 4 + r;
-                const float e = (key >= lo && key < hi) ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[kj][r], SC, -mb)) : 0.f;
-                st[kj][r] = e;
-                sum += e;
-            }
-        sum = xor32_sum(xor16_sum(sum));
-        const float inv = 1.0f / sum;                    // an image without regions: 0 * (1/0) = NaN on every key, as softmax over all -inf
-        bp[qi][0] = rb_pack8(st[0][0] * inv, st[0][1] * inv, st[0][2] * inv, st[0][3] * inv, st[1][0] * inv, st[1][1] * inv, st[1][2] * inv, st[1][3] * inv);
-        bp[qi][1] = rb_pack8(st[2][0] * inv, st[2][1] * inv, st[2][2] * inv, st[2][3] * inv, 0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// V of image P for the two d-tiles of one half (vf: folded values, [nt][key tile][4 keys]) -> O^T tiles, rounded: ctx[nt][qi] = 4 bf16 (d = 4g .. 4g+3 of tile nt)
-template <int P>
-__device__ __forceinline__ void enc_context(const f32x4 (&vf)[2][5], const bf16x8 (&bp)[3][2], uint2 (&ctx)[2][3]) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 &v0 = vf[nt][2 * P], &v1 = vf[nt][2 * P + 1], &v2 = vf[nt][2 * P + 2];
-        const bf16x8 a0 = rb_pack8(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
-        const bf16x8 a1 = rb_pack8(v2[0], v2[1], v2[2], v2[3], 0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int qi = 0; qi < 3; ++qi) {
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bp[qi][0], o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bp[qi][1], o, 0, 0, 0);
-            ctx[nt][qi] = make_uint2(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]));
-        }
-    }
-}
-
-__global__ __launch_bounds__(512) void rb_encoder_kernel(RbEncArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xb = smem;                                               // [80][512] bf16, swizzled, row pitch 1 024 B (x, then the heads' outputs)
-    unsigned char* hb = smem + 81920;                                       // [80][256] bf16, swizzled, row pitch 512 B (hidden columns of a round)
-    float* s_mean = reinterpret_cast<float*>(smem + 81920 + 40960);        // [80]
-    float* s_rstd = s_mean + 80;                                            // [80]
-    float2* part = reinterpret_cast<float2*>(s_rstd + 80);                  // [8][80] partial (sum, sum of squares) per wavefront's 64 columns
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int img0 = blockIdx.x * 2, nimg = min(2, a.B - img0), R = a.R, rows_live = nimg * R, m0 = img0 * R;
-    int kl0 = R, kl1 = nimg > 1 ? R : 0;
-    if (a.klen) { kl0 = max(0, min(a.klen[img0], R)); if (nimg > 1) kl1 = max(0, min(a.klen[img0 + 1], R)); }
-    const int lbase = rb_lane_base(l15, g);
-    const int lbase_h = l15 * 512 + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4));
-    RB_STAMP(a.dbg, wave, lane, 0);
-
-    // ---- the stream: wavefront w holds columns w*64 + nt*16 + g*4 .. +3 of rows mt*16 + l15
-    f32x4 xr[4][5];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            const int row = mt * 16 + l15;
-            const float4 v = row < rows_live ? *reinterpret_cast<const float4*>(a.x + (size_t)(m0 + row) * 512 + wave * 64 + nt * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            xr[nt][mt] = f32x4{v.x, v.y, v.z, v.w};
-        }
-    auto qkvseg = [&](const RbEncLayer& ly, int which, int j) { return ly.wqkv + (size_t)(which * 8 + wave) * (16 * 256) + j * 128 + lane; };
-    auto w1seg = [&](const RbEncLayer& ly, int c) { return ly.w1 + (size_t)(c * 4 + (wave >> 1)) * (16 * 256) + (wave & 1) * 128 + lane; };
-    auto w2seg = [&](const RbEncLayer& ly, int c) { return ly.w2 + ((size_t)wave * (a.dff >> 5) + c * 8) * 256 + lane; };
-    auto woseg = [&](const RbEncLayer& ly) { return ly.wo + (size_t)wave * (16 * 256) + lane; };
-    const int rounds = a.dff >> 8;
-    bf16x8 w2r[RB_PF * 2], w4r[RB_PF * 4];                                  // the 2-tile ring (q, k, v halves, w_1) and the 4-tile ring (W_o, w_2)
-    rb_prime<2>(qkvseg(a.layer[0], 0, 0), w2r);
-
-#pragma unroll 1
-    for (int L = 0; L < a.nlayers; ++L) {
-        const RbEncLayer& ly = a.layer[L];
-        const RbEncLayer& lnext = a.layer[L + 1 < a.nlayers ? L + 1 : L];
-        // ================= self-attention sublayer
-        // ---- block + row statistics
-#pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 v = xr[nt][mt];
-                sm += (v[0] + v[1]) + (v[2] + v[3]);
-                sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                *reinterpret_cast<uint2*>(xb + rb_off(mt * 16 + l15, wave * 8 + nt * 2 + (g >> 1)) + (g & 1) * 8) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-            }
-            sm = xor32_sum(xor16_sum(sm)); sq = xor32_sum(xor16_sum(sq));
-            if (g == 0) part[wave * 80 + mt * 16 + l15] = make_float2(sm, sq);
-        }
-        __syncthreads();
-        if (tid < 80) {
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { const float2 t = part[w * 80 + tid]; sm += t.x; sq += t.y; }
-            const float mean = sm * (1.0f / 512.0f);
-            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
-            s_mean[tid] = mean;
-            s_rstd[tid] = 1.0f / (sqrtf(var) + 1e-6f);
-        }
-        __syncthreads();
-        RB_STAMP(a.dbg, wave, lane, 1);
-        uint2 ctx[2][2][2][3];                                              // [image][d half][d tile of the half][query tile]: 4 bf16 each
-        {
-            float mu[5], rs[5];
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
-            // ---- Q^T and K^T of head `wave`, both images: operands bq / ak [row tile][d half]
-            bf16x8 bq[5][2], ak[5][2];
-#pragma unroll
-            for (int which = 0; which < 2; ++which)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = which * 512 + wave * 64 + j * 32 + g * 4;
-                    const float4 cc0 = *reinterpret_cast<const float4*>(ly.cqkv + col), cc1 = *reinterpret_cast<const float4*>(ly.cqkv + col + 16);
-                    const float4 cs0 = *reinterpret_cast<const float4*>(ly.csqkv + col), cs1 = *reinterpret_cast<const float4*>(ly.csqkv + col + 16);
-                    f32x4 acc[2][5];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const u32x4* nx = j == 0 ? qkvseg(ly, which, 1) : qkvseg(ly, which + 1, 0);
-                    rb_seg<5, 2, 16, 16384, false>(qkvseg(ly, which, j), nx, w2r, xb, lbase, acc);
-#pragma unroll
-                    for (int mt = 0; mt < 5; ++mt) {
-                        const f32x4 t0 = acc[0][mt], t1 = acc[1][mt];
-                        const bf16x8 o = rb_pack8(rs[mt] * (t0[0] - mu[mt] * cs0.x) + cc0.x, rs[mt] * (t0[1] - mu[mt] * cs0.y) + cc0.y,
-                                                  rs[mt] * (t0[2] - mu[mt] * cs0.z) + cc0.z, rs[mt] * (t0[3] - mu[mt] * cs0.w) + cc0.w,
-                                                  rs[mt] * (t1[0] - mu[mt] * cs1.x) + cc1.x, rs[mt] * (t1[1] - mu[mt] * cs1.y) + cc1.y,
-                                                  rs[mt] * (t1[2] - mu[mt] * cs1.z) + cc1.z, rs[mt] * (t1[3] - mu[mt] * cs1.w) + cc1.w);
-                        if (which == 0) bq[mt][j] = o; else ak[mt][j] = o;
-                    }
-                }
-            // ---- scores and probabilities of both images
-            bf16x8 bp0[3][2], bp1[3][2];
-            enc_scores<0>(ak, bq, 0, kl0, g, bp0);
-            if (nimg > 1) enc_scores<1>(ak, bq, R, R + kl1, g, bp1);
-            else {
-#pragma unroll
-                for (int qi = 0; qi < 3; ++qi) { bp1[qi][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; bp1[qi][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
-            }
-            // ---- V (lane = d, four consecutive keys) in two halves of 32 d, then O^T
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = 1024 + wave * 64 + j * 32 + l15;
-                const float cv0 = ly.cqkv[col], cv1 = ly.cqkv[col + 16], sv0 = ly.csqkv[col], sv1 = ly.csqkv[col + 16];
-                f32x4 acc[2][5];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const u32x4* nx = j == 0 ? qkvseg(ly, 2, 1) : w1seg(ly, 0);
-                rb_seg<5, 2, 16, 16384, true>(qkvseg(ly, 2, j), nx, w2r, xb, lbase, acc);
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(s_mean + mt * 16 + g * 4), r4 = *reinterpret_cast<const float4*>(s_rstd + mt * 16 + g * 4);
-                    acc[0][mt] = f32x4{r4.x * (acc[0][mt][0] - m4.x * sv0) + cv0, r4.y * (acc[0][mt][1] - m4.y * sv0) + cv0,
-                                       r4.z * (acc[0][mt][2] - m4.z * sv0) + cv0, r4.w * (acc[0][mt][3] - m4.w * sv0) + cv0};
-                    acc[1][mt] = f32x4{r4.x * (acc[1][mt][0] - m4.x * sv1) + cv1, r4.y * (acc[1][mt][1] - m4.y * sv1) + cv1,
-                                       r4.z * (acc[1][mt][2] - m4.z * sv1) + cv1, r4.w * (acc[1][mt][3] - m4.w * sv1) + cv1};
-                }
-                enc_context<0>(acc, bp0, ctx[0][j]);
-                enc_context<1>(acc, bp1, ctx[1][j]);
-            }
-        }
-        rb_prime<4>(woseg(ly), w4r);                                        // (not earlier: 64 registers that the attention phase does not have)
-        __syncthreads();                                                    // every wavefront is through with x: the heads' outputs take the block
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int qi = 0; qi < 3; ++qi) {
-                const int row = (2 * p + qi) * 16 + l15;
-                if (p >= nimg || row < p * R || row >= p * R + R) continue;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        *reinterpret_cast<uint2*>(xb + rb_off(row, wave * 8 + j * 4 + nt * 2 + (g >> 1)) + (g & 1) * 8) = ctx[p][j][nt][qi];
-            }
-        __syncthreads();
-        RB_STAMP(a.dbg, wave, lane, 2);
-        // ---- output projection onto the stream
-        {
-            const float4 b0 = *reinterpret_cast<const float4*>(ly.bo + wave * 64 + g * 4), b1 = *reinterpret_cast<const float4*>(ly.bo + wave * 64 + 16 + g * 4);
-            const float4 b2 = *reinterpret_cast<const float4*>(ly.bo + wave * 64 + 32 + g * 4), b3 = *reinterpret_cast<const float4*>(ly.bo + wave * 64 + 48 + g * 4);
-            rb_seg<5, 4, 16, 16384, false>(woseg(ly), w2seg(ly, 0), w4r, xb, lbase, xr);
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) {
-                rb_add4(xr[0][mt], b0); rb_add4(xr[1][mt], b1); rb_add4(xr[2][mt], b2); rb_add4(xr[3][mt], b3);
-            }
-        }
-        __syncthreads();                                                    // the heads' outputs are read: the block may take the new x
-        RB_STAMP(a.dbg, wave, lane, 3);
-        // ================= feed-forward sublayer
-#pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 v = xr[nt][mt];
-                sm += (v[0] + v[1]) + (v[2] + v[3]);
-                sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                *reinterpret_cast<uint2*>(xb + rb_off(mt * 16 + l15, wave * 8 + nt * 2 + (g >> 1)) + (g & 1) * 8) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-            }
-            sm = xor32_sum(xor16_sum(sm)); sq = xor32_sum(xor16_sum(sq));
-            if (g == 0) part[wave * 80 + mt * 16 + l15] = make_float2(sm, sq);
-        }
-        __syncthreads();
-        if (tid < 80) {
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { const float2 t = part[w * 80 + tid]; sm += t.x; sq += t.y; }
-            const float mean = sm * (1.0f / 512.0f);
-            const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
-            s_mean[tid] = mean;
-            s_rstd[tid] = 1.0f / (sqrtf(var) + 1e-6f);
-        }
-        __syncthreads();
-        {
-            float mu[5], rs[5];
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
-#pragma unroll 1
-            for (int c = 0; c < rounds; ++c) {
-                // ---- hidden columns c*256 + wave*32 .. +31
-                const int hc = c * 256 + wave * 32 + g * 4;
-                const float4 cc0 = *reinterpret_cast<const float4*>(ly.c1 + hc), cc1 = *reinterpret_cast<const float4*>(ly.c1 + hc + 16);
-                const float4 cs0 = *reinterpret_cast<const float4*>(ly.cs1 + hc), cs1 = *reinterpret_cast<const float4*>(ly.cs1 + hc + 16);
-                f32x4 acc[2][5];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb_seg<5, 2, 16, 16384, false>(w1seg(ly, c), c + 1 < rounds ? w1seg(ly, c + 1) : qkvseg(lnext, 0, 0), w2r, xb, lbase, acc);
-                if (c > 0) __syncthreads();                                 // every wavefront is through with the previous round's hidden columns
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) {
-                    const f32x4 t0 = acc[0][mt], t1 = acc[1][mt];
-                    unsigned char* hp = hb + (mt * 16 + l15) * 512 + (g & 1) * 8;
-                    *reinterpret_cast<uint2*>(hp + (((wave * 4 + (g >> 1)) ^ l15) << 4)) =
-                        make_uint2(pack_bf16(fmaxf(rs[mt] * (t0[0] - mu[mt] * cs0.x) + cc0.x, 0.f), fmaxf(rs[mt] * (t0[1] - mu[mt] * cs0.y) + cc0.y, 0.f)),
-                                   pack_bf16(fmaxf(rs[mt] * (t0[2] - mu[mt] * cs0.z) + cc0.z, 0.f), fmaxf(rs[mt] * (t0[3] - mu[mt] * cs0.w) + cc0.w, 0.f)));
-                    *reinterpret_cast<uint2*>(hp + (((wave * 4 + 2 + (g >> 1)) ^ l15) << 4)) =
-                        make_uint2(pack_bf16(fmaxf(rs[mt] * (t1[0] - mu[mt] * cs1.x) + cc1.x, 0.f), fmaxf(rs[mt] * (t1[1] - mu[mt] * cs1.y) + cc1.y, 0.f)),
-                                   pack_bf16(fmaxf(rs[mt] * (t1[2] - mu[mt] * cs1.z) + cc1.z, 0.f), fmaxf(rs[mt] * (t1[3] - mu[mt] * cs1.w) + cc1.w, 0.f)));
-                }
-                __syncthreads();
-                // ---- onto the stream: output columns wave*64 .. +63, K = this round's 256 hidden columns
-                rb_seg<5, 4, 8, 8192, false>(w2seg(ly, c), w2seg(ly, c + 1 < rounds ? c + 1 : c), w4r, hb, lbase_h, xr);
-            }
-            const float4 b0 = *reinterpret_cast<const float4*>(ly.b2 + wave * 64 + g * 4), b1 = *reinterpret_cast<const float4*>(ly.b2 + wave * 64 + 16 + g * 4);
-            const float4 b2 = *reinterpret_cast<const float4*>(ly.b2 + wave * 64 + 32 + g * 4), b3 = *reinterpret_cast<const float4*>(ly.b2 + wave * 64 + 48 + g * 4);
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) {
-                rb_add4(xr[0][mt], b0); rb_add4(xr[1][mt], b1); rb_add4(xr[2][mt], b2); rb_add4(xr[3][mt], b3);
-            }
-        }
-        __syncthreads();                                                    // (the next layer's block write must not overtake a slow wavefront's w_1 reads)
-        RB_STAMP(a.dbg, wave, lane, 4 + (L & 7));
-    }
-    // ---- the stream goes back
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            const int row = mt * 16 + l15;
-            if (row < rows_live)
-                *reinterpret_cast<float4*>(a.y + (size_t)(m0 + row) * 512 + wave * 64 + nt * 16 + g * 4) = make_float4(xr[nt][mt][0], xr[nt][mt][1], xr[nt][mt][2], xr[nt][mt][3]);
-        }
-    RB_STAMP(a.dbg, wave, lane, 12);
-}
-
-int launch_rb_encoder(const RbEncArgs& a, hipStream_t st) {
-    if (!a.x || !a.y || a.B < 1 || a.nlayers < 1 || a.nlayers > 8 || a.dff < 256 || a.dff % 256) return BOFI_ERR_ARG;
-    if (a.R < 32 || a.R > 40) return -1;
-    for (int l = 0; l < a.nlayers; ++l) {
-        const RbEncLayer& y = a.layer[l];
-        if (!y.wqkv || !y.cqkv || !y.csqkv || !y.wo || !y.bo || !y.w1 || !y.c1 || !y.cs1 || !y.w2 || !y.b2) return BOFI_ERR_ARG;
-    }
-    const size_t lds = 81920 + 40960 + 2 * 80 * 4 + 8 * 80 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(rb_encoder_kernel, dim3((a.B + 1) / 2), dim3(512), lds, st, a);
-    const double rows = (double)a.B * a.R;
-    g_gemm_flops += a.nlayers * 2.0 * rows * 512.0 * (1536.0 + 512.0 + 2.0 * a.dff);
-    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
 // w [N][K] row-major bf16 -> fragment-major: [N/64 chunks][K/32 steps][4 tiles][64 lanes][8 bf16]; lane (l15, g) of a fragment holds
 // row chunk*64 + tile*16 + l15, k = step*32 + g*8 .. +7
 __global__ __launch_bounds__(256) void rb_pack_frag_kernel(const bf16_t* __restrict__ w, u32x4* __restrict__ out, int N, int K) {
@@ -1316,20 +750,6 @@ int launch_rb_pack_frag(const void* w, void* out, int N, int K, hipStream_t st) 
 }
 
 }  // namespace bofi
-
-extern "C" int bofi_encoder_block(const float* x, float* y, const int* klen, int B, int R, int nlayers, const void* const* wqkv, const float* const* cqkv,
-                                  const float* const* csqkv, const void* const* wo, const float* const* bo, const void* const* w1, const float* const* c1,
-                                  const float* const* cs1, const void* const* w2, const float* const* b2, int dff, void* stream) {
-    if (nlayers < 1 || nlayers > 8 || !wqkv || !cqkv || !csqkv || !wo || !bo || !w1 || !c1 || !cs1 || !w2 || !b2) return BOFI_ERR_ARG;
-    bofi::RbEncArgs a{};
-    for (int l = 0; l < nlayers; ++l)
-        a.layer[l] = bofi::RbEncLayer{(const bofi::u32x4*)wqkv[l], cqkv[l], csqkv[l], (const bofi::u32x4*)wo[l], bo[l], (const bofi::u32x4*)w1[l], c1[l], cs1[l],
-                                      (const bofi::u32x4*)w2[l], b2[l]};
-    a.nlayers = nlayers; a.x = x; a.y = y; a.klen = klen; a.B = B; a.R = R; a.dff = dff;
-    { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
-    const int rc = bofi::launch_rb_encoder(a, (hipStream_t)stream);
-    return rc == -1 ? BOFI_ERR_ARG : rc;
-}
 
 extern "C" int bofi_rb_stamps(unsigned long long* host_out) {      // developer aid: the 16 x 16 stamps of the last BOFI_RB_DBG & 16 launch
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bofi::g_rb_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
@@ -1357,15 +777,6 @@ extern "C" int bofi_linear_block(const float* x, int ldx, const void* wp, const 
     a.x = x; a.ldx = ldx; a.wp = (const bofi::u32x4*)wp; a.c = c; a.cs = cs; a.y = y; a.ldy = ldy; a.y_f32 = y_f32; a.M = M; a.N = N; a.relu = relu;
     { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
     return bofi::launch_rb_gemm(a, (hipStream_t)stream);
-}
-
-extern "C" int bofi_ffn_proj_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,
-                                   int ldy, const void* pwp, const float* pc, const float* pcs, void* py, int pldy, int pN, int M, int dff, void* stream) {
-    if (!pwp) return BOFI_ERR_ARG;
-    bofi::RbFfnArgs a{};
-    a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
-    a.M = M; a.dff = dff; a.pwp = (const bofi::u32x4*)pwp; a.pc = pc; a.pcs = pcs; a.py = py; a.pldy = pldy; a.pN = pN;
-    return bofi::launch_rb_ffn(a, (hipStream_t)stream);
 }
 
 extern "C" int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,

@@ -103,6 +103,7 @@ class BofiEngine:
         f = object.__new__(BofiEngine)
         f.cfg, f.dtype, f.device, f.max_batch, f.max_regions = self.cfg, self.dtype, self.device, self.max_batch, self.max_regions
         f._lib, f._finalized, f._parent = self._lib, True, self        # keeps the parent (weights) alive
+        f._iter_cap, f._q1_group, f._live_word = 0, 0, None           # per-call knobs start from the defaults (bofi_engine_fork resets them too)
         f._h = C.c_void_p()
         with torch.cuda.device(self.device):
             hip.check(self._lib.bofi_engine_fork(self._h, C.byref(f._h)), "bofi_engine_fork")

@@ -1,0 +1,187 @@
+"""Time the row-block sublayer kernels alone on the chip (in-graph time per launch, buffers rotated through the Infinity Cache).
+python dev/exp/mb_rowblock.py [ffn|attn]"""
+import math, sys
+import torch
+sys.path.insert(0, ".")
+from boficap_amd import hip as H
+
+H.lib()
+d, dff = 512, 2048
+dev = "cuda"
+
+
+def timed(fn, iters=50, rot=1):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for i in range(3):
+            fn(i % rot)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for i in range(iters):
+                fn(i % rot)
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s); g.replay(); e1.record(s); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def pack(w):
+    N, K = w.shape
+    out = torch.empty(N * K, dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().bofi_pack_frag(H.ptr(w), H.ptr(out), N, K, H.stream_ptr()))
+    return out
+
+
+def ffn(M):
+    rot = 4
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
+    ybs = [torch.empty(M, d, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+    sts = [torch.empty(M, 16, 2, device=dev) for _ in range(rot)]
+    w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+    w1p, w2p = pack(w1), pack(w2)
+    c1, cs1, b2 = torch.randn(dff, device=dev), w1.float().sum(1), torch.randn(d, device=dev)
+
+    def run(i):
+        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, H.ptr(ybs[i]),
+                                       H.ptr(sts[i]), M, dff, H.stream_ptr()))
+    t = timed(run, rot=rot)
+    print(f"ffn_block M {M:6d}: {t:7.2f} us  {4.0 * M * d * dff / t * 1e-6:7.1f} TFLOP/s  weight stream {4 * 1048576 / t * 1e-3:6.1f} GB/s per workgroup", flush=True)
+
+
+def attn(B, Lq, Lk, cross):
+    rot = 4
+    M = B * Lq
+    if cross:
+        qs = [torch.randn(M, d, device=dev).to(torch.bfloat16) for _ in range(rot)]
+        kvs = [torch.randn(B * Lk, 7168, device=dev).to(torch.bfloat16) for _ in range(rot)]
+    else:
+        qkvs = [torch.randn(M, 3 * d, device=dev).to(torch.bfloat16) for _ in range(rot)]
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ybs = [torch.empty(M, d, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
+    sts = [torch.empty(M, 16, 2, device=dev) for _ in range(rot)]
+    wop = pack((torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16))
+    bo = torch.randn(d, device=dev)
+    klen = torch.full((B,), Lk, dtype=torch.int32, device=dev)
+
+    def run(i):
+        if cross:
+            q, k, v, ldq, ldk = qs[i], kvs[i][:, 1024:], kvs[i][:, 1536:], d, 7168
+        else:
+            q, k, v, ldq, ldk = qkvs[i], qkvs[i][:, d:], qkvs[i][:, 2 * d:], 3 * d, 3 * d
+        import os
+        opt = int(os.environ.get("MB_OPT", "0"))
+        H.check(H.lib().bofi_attn_block(H.ptr(q), ldq, H.ptr(k), ldk, H.ptr(v), ldk, B, Lq, Lk, H.ptr(klen), 1, 0, 0, 0, H.ptr(wop), H.ptr(bo),
+                                        H.ptr(xs[i]), d, H.ptr(ys[i] if opt & 1 else xs[i]), d, None if opt & 2 else H.ptr(ybs[i]), None if opt & 4 else H.ptr(sts[i]), H.stream_ptr()))
+    t = timed(run, rot=rot)
+    print(f"attn_block B {B:4d} Lq {Lq} Lk {Lk} {'cross' if cross else 'self '}: {t:7.2f} us", flush=True)
+
+
+def gemm(M, N, f32out):
+    rot = 4
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, N, dtype=torch.float32 if f32out else torch.bfloat16, device=dev) for _ in range(rot)]
+    w = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    wp, c, cs = pack(w), torch.randn(N, device=dev), w.float().sum(1)
+
+    def run(i):
+        H.check(H.lib().bofi_linear_block(H.ptr(xs[i]), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(ys[i]), N, 1 if f32out else 0, M, N, 0, H.stream_ptr()))
+    t = timed(run, rot=rot)
+    print(f"linear_block M {M:6d} N {N:5d} {'f32 ' if f32out else 'bf16'}: {t:7.2f} us  {2.0 * M * d * N / t * 1e-6:7.1f} TFLOP/s", flush=True)
+
+
+def encoder(B, R=36, nlayers=6):
+    """rb_encoder_kernel: the whole encoder stack as one launch (random weights, timing only)."""
+    import ctypes as C
+    rot = 4
+    xs = [torch.randn(B * R, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(B * R, d, device=dev) for _ in range(rot)]
+    keep, arrs = [], {k: [] for k in ("wqkv", "cqkv", "csqkv", "wo", "bo", "w1", "c1", "cs1", "w2", "b2")}
+    for _ in range(nlayers):
+        wqkv = (torch.randn(3 * d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        wo = (torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+        t = {"wqkv": pack(wqkv), "cqkv": torch.randn(3 * d, device=dev) * 0.1, "csqkv": wqkv.float().sum(1), "wo": pack(wo), "bo": torch.randn(d, device=dev) * 0.1,
+             "w1": pack(w1), "c1": torch.randn(dff, device=dev) * 0.1, "cs1": w1.float().sum(1), "w2": pack(w2), "b2": torch.randn(d, device=dev) * 0.1}
+        keep.append(t)
+        for k, v in t.items():
+            arrs[k].append(H.ptr(v))
+    ptrs = {k: (C.c_void_p * nlayers)(*v) for k, v in arrs.items()}
+    klen = torch.full((B,), R, dtype=torch.int32, device=dev)
+
+    def run(i):
+        H.check(H.lib().bofi_encoder_block(H.ptr(xs[i]), H.ptr(ys[i]), H.ptr(klen), B, R, nlayers, ptrs["wqkv"], ptrs["cqkv"], ptrs["csqkv"], ptrs["wo"], ptrs["bo"],
+                                           ptrs["w1"], ptrs["c1"], ptrs["cs1"], ptrs["w2"], ptrs["b2"], dff, H.stream_ptr()))
+    t = timed(run, iters=20, rot=rot)
+    fl = nlayers * 2.0 * B * R * d * (3 * d + d + 2 * dff)
+    print(f"encoder_block B {B:4d} R {R} layers {nlayers}: {t:8.2f} us  {fl / t * 1e-6:7.1f} TFLOP/s  weight stream {nlayers * 6.29e6 / t * 1e-3:6.1f} GB/s per workgroup", flush=True)
+
+
+def train_shapes():
+    """The XE step's forward / dX shapes (K = 512): the tiled GEMM (bf16 operand in, float32 out) against the row-block projection
+    kernel (float32 stream in with the LayerNorm fold, float32 / bf16 out)."""
+    rot = 4
+    for M in (5120, 2304):
+        for N in (512, 1536, 2048):
+            xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+            xbs = [x.bfloat16() for x in xs]
+            w = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+            wp, c, cs = pack(w), torch.randn(N, device=dev), w.float().sum(1)
+            y32 = [torch.empty(M, N, device=dev) for _ in range(rot)]
+            y16 = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+            t_tiled = timed(lambda i: H.check(H.lib().bofi_linear(H.ptr(xbs[i]), H.dtype_code(xbs[i]), d, H.ptr(w), H.dtype_code(w), H.ptr(c), None, N, H.ptr(y32[i]), 0, N,
+                                                                  M, N, d, 0, None, 0, H.stream_ptr())), rot=rot)
+            t_rb32 = timed(lambda i: H.check(H.lib().bofi_linear_block(H.ptr(xs[i]), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(y32[i]), N, 1, M, N, 0, H.stream_ptr())), rot=rot)
+            t_rb16 = timed(lambda i: H.check(H.lib().bofi_linear_block(H.ptr(xs[i]), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(y16[i]), N, 0, M, N, 0, H.stream_ptr())), rot=rot)
+            print(f"M {M:5d} N {N:5d} K 512: tiled bf16->f32 {t_tiled:6.2f} us | row-block f32->f32 {t_rb32:6.2f} us | row-block f32->bf16 {t_rb16:6.2f} us", flush=True)
+
+
+def ffn_proj(M, N=1536):
+    """The feed-forward sublayer + the next layer's q|k|v: two launches against the fused one."""
+    rot = 4
+    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
+    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
+    qs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
+    w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+    wq = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+    w1p, w2p, wqp = pack(w1), pack(w2), pack(wq)
+    c1, cs1, b2, cq, csq = torch.randn(dff, device=dev), w1.float().sum(1), torch.randn(d, device=dev), torch.randn(N, device=dev), wq.float().sum(1)
+
+    def two(i):
+        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, None, None, M, dff, H.stream_ptr()))
+        H.check(H.lib().bofi_linear_block(H.ptr(ys[i]), d, H.ptr(wqp), H.ptr(cq), H.ptr(csq), H.ptr(qs[i]), N, 0, M, N, 0, H.stream_ptr()))
+
+    def one(i):
+        H.check(H.lib().bofi_ffn_proj_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d,
+                                            H.ptr(wqp), H.ptr(cq), H.ptr(csq), H.ptr(qs[i]), N, N, M, dff, H.stream_ptr()))
+    t2, t1 = timed(two, rot=rot), timed(one, rot=rot)
+    print(f"ffn + projection N {N} M {M:6d}: two launches {t2:7.2f} us, one launch {t1:7.2f} us", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
+    if what == "ffn":
+        for M in (11520, 6400, 2304, 1280, 64):
+            ffn(M)
+    elif what == "ffnp":
+        for M in (11520, 6400, 2304, 64):
+            ffn_proj(M)
+    elif what == "train":
+        train_shapes()
+    elif what == "enc":
+        for B in (320, 512, 64, 2):
+            encoder(B)
+        encoder(320, nlayers=1)
+    elif what == "gemm":
+        for M, N, f in ((11520, 1536, False), (6400, 1536, False), (6400, 512, False), (11520, 7168, False), (6400, 9600, True), (64, 1536, False), (64, 9600, True)):
+            gemm(M, N, f)
+    else:
+        for B in (320, 64, 2):
+            attn(B, 36, 36, False)
+            attn(B, 20, 20, False)
+            attn(B, 20, 36, True)

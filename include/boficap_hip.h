@@ -412,30 +412,16 @@ int bofi_bound_qattn(const void* x, const float* stats, const void* wq, const fl
  *   image of b's group of G (quirk Q1, TransformerModel.py:1872-1873); a row without keys is NaN as in the reference.
  *   wop = bofi_pack_frag of the [512, 512] output projection, bo float32 [512]; x, y float32 [B*Lq, 512] (y may be x); yb /
  *   stats_out as bofi_ffn_block.
- * bofi_ffn_proj_block: bofi_ffn_block followed, in the SAME launch, by the LayerNorm-folded projection of the sublayer's output rows
- *   (EncoderLayer / DecoderLayer: the feed-forward sublayer of layer l and the q|k|v projection of layer l + 1, TransformerModel.py:1408-1413,
- *   1454-1456): py[M, pN] bf16 = W' LN(y) + b with pwp / pc / pcs as bofi_linear_block's wp / c / cs (pN % 64 == 0).  The new rows stay in LDS as
- *   the projection's block: one launch, and no second pass over the float32 stream.  Bit for bit bofi_ffn_block then bofi_linear_block.  dff = 2048.
  * bofi_linear_block: y[M, N] = act(W' LN(x) + b) for a LayerNorm-folded projection with K = 512 (the q|k|v, cross-query, stacked cross K|V
  *   and generator projections: TransformerModel.py:1454-1456, AttModel.py:203-210 behind their pre-norms): x float32 [M, 512] -- the
  *   row statistics are computed in the kernel --, wp = bofi_pack_frag of the folded [N, 512] weight (N % 64 == 0), c / cs its folded
- *   bias and column sums, y bf16 or float32 (y_f32) [M, ldy], relu 0 / 1.
- * bofi_encoder_block: the whole encoder stack (Encoder.forward TransformerModel.py:1391-1395 over EncoderLayer :1408-1413, without the
- *   final norm) in ONE launch: x, y float32 [B*R, 512] (y may be x), R regions per image with 32 <= R <= 40 (two images per
- *   workgroup), klen int32 [B] keys per image or NULL; per layer l < nlayers <= 8: wqkv[l] = bofi_pack_frag of the LayerNorm-folded
- *   q|k|v weight [1536, 512] with cqkv[l] / csqkv[l] its folded bias and column sums, wo[l] / bo[l] the output projection, w1[l] /
- *   c1[l] / cs1[l] the folded first feed-forward layer [dff, 512], w2[l] / b2[l] the second [512, dff]; dff % 256 == 0. */
+ *   bias and column sums, y bf16 or float32 (y_f32) [M, ldy], relu 0 / 1. */
 int bofi_pack_frag(const void* w, void* out, int N, int K, void* stream);
 int bofi_linear_block(const float* x, int ldx, const void* wp, const float* c, const float* cs, void* y, int ldy, int y_f32, int M, int N,
                       int relu, void* stream);
-int bofi_encoder_block(const float* x, float* y, const int* klen, int B, int R, int nlayers, const void* const* wqkv, const float* const* cqkv,
-                       const float* const* csqkv, const void* const* wo, const float* const* bo, const void* const* w1, const float* const* c1,
-                       const float* const* cs1, const void* const* w2, const float* const* b2, int dff, void* stream);
 int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen,
                     int klen_sb, int klen_sq, int klen_bias, int klen_shared_last, const void* wop, const float* bo, const float* x,
                     int ldx, float* y, int ldy, void* yb, float* stats_out, void* stream);
-int bofi_ffn_proj_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,
-                        int ldy, const void* pwp, const float* pc, const float* pcs, void* py, int pldy, int pN, int M, int dff, void* stream);
 int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
                    float* y, int ldy, void* yb, float* stats_out, int M, int dff, void* stream);
 

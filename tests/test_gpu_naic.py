@@ -322,6 +322,30 @@ def test_bounding_loop_with_fewer_iterations_enqueued(weight_cache, manifest):
     assert model._naic_recent[-1] == live and eng._iter_cap == min(cfg.seq_length, live + 2) % cfg.seq_length      # the last calls ran under the adaptive cap
 
 
+def test_fork_right_after_a_capped_decode_does_not_inherit_the_cap(engines):
+    """bofi_engine_fork copies the parent's struct: the per-call knobs (bounding-iteration cap, live-iteration word, semi-autoregressive
+    range) must start from their defaults in the fork, or a fork made behind a capped decode (sample_pair in the self-critical step behind a
+    periodic eval) runs a truncated bounding loop that nobody checks."""
+    cfg, sd, eng = engines("tiny_mix", torch.float32)
+    att, att_len = _inputs(load_golden("tiny_mix"))
+    whole = eng.decode_naic(att, att_len)
+    live = int(whole["bound_iters"])
+    assert live >= 2
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.watch_live_iterations(word)
+    short = eng.decode_naic(att, att_len, iter_cap=1)                  # leaves cap = 1 and the word set on the parent
+    assert int(short["bound_iters"]) == 1 and int(word) == 1
+    f = eng.fork()
+    assert (f._iter_cap, f._q1_group, f._live_word) == (0, 0, None)
+    word.zero_()
+    r = f.decode_naic(att, att_len)                                    # iter_cap = 0 == the handle's default: no call resets the native cap
+    assert int(r["bound_iters"]) == live and int(word) == 0           # the whole loop, and the parent's word left alone
+    for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+        assert torch.equal(r[k], whole[k]), k
+    eng.watch_live_iterations(None)
+    eng.decode_naic(att, att_len)                                      # (parent back to its defaults for the tests that share it)
+
+
 def test_entropy_perplexity_without_materialising_logprobs(engines):
     """eval's per-image entropy / perplexity (eval_utils.py:463-464) from the fused row reductions, with the log-prob
     tensor in user memory and with it left in the engine's workspace."""

@@ -100,53 +100,6 @@ def test_ffn_block_vs_reference_sublayer(H, M, dff):
     assert torch.equal(xc.cpu(), y.cpu())
 
 
-@pytest.mark.parametrize("M,N", [(64, 1536), (200, 1536), (6400, 1536), (130, 512), (11520, 1536), (77, 64)])
-def test_ffn_proj_block_equals_ffn_block_then_linear_block(H, M, N):
-    """bofi_ffn_proj_block: the feed-forward sublayer and the LayerNorm-folded projection of its output rows (the next layer's q|k|v) in one
-    launch = bofi_ffn_block followed by bofi_linear_block on the stored stream, BIT FOR BIT (the block's row statistics are summed in the
-    projection kernel's own order), ragged last blocks and a NaN row included; in place."""
-    d, dff = 512, 2048
-    g = _rng(M + N)
-    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
-    if M > 70:
-        x[69] = float("nan")                                              # quirk Q1's fully masked image: its rows are NaN, the others untouched
-    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
-    w1, b1 = torch.randn(dff, d, generator=g) / math.sqrt(d), torch.randn(dff, generator=g) * 0.1
-    w2, b2 = torch.randn(d, dff, generator=g) / math.sqrt(dff), torch.randn(d, generator=g) * 0.1
-    g2, bl2 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
-    wp_, bp_ = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g) * 0.1
-    w1f, c1, cs1 = _fold(w1, b1, gain, bln)
-    wpf, cp, csp = _fold(wp_, bp_, g2, bl2)
-    w1p, w2p, wpp = pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda()), pack_frag(H, wpf.to(torch.bfloat16).cuda())
-    c1c, cs1c, b2c, cpc, cspc = c1.cuda(), cs1.cuda(), b2.cuda(), cp.cuda(), csp.cuda()
-    xc = x.cuda()
-    # separate launches
-    y_ref = torch.full((M, d), 3.0, device="cuda")
-    q_ref = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
-    H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y_ref), d, None, None, M, dff, H.stream_ptr()))
-    H.check(H.lib().bofi_linear_block(H.ptr(y_ref), d, H.ptr(wpp), H.ptr(cpc), H.ptr(cspc), H.ptr(q_ref), N + 64, 0, M, N, 0, H.stream_ptr()))
-    # one launch
-    y = torch.full((M, d), 3.0, device="cuda")
-    q = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
-    H.check(H.lib().bofi_ffn_proj_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y), d,
-                                        H.ptr(wpp), H.ptr(cpc), H.ptr(cspc), H.ptr(q), N + 64, N, M, dff, H.stream_ptr()))
-    torch.cuda.synchronize()
-    eq = lambda a, b: torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16), b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))
-    nan_rows = torch.isnan(y_ref).any(1)
-    assert int(nan_rows.sum()) == (1 if M > 70 else 0)
-    assert torch.equal(torch.isnan(y), torch.isnan(y_ref)) and eq(y[~nan_rows], y_ref[~nan_rows])
-    assert (q[:, N:] == 7.0).all() and (q_ref[:, N:] == 7.0).all()                                      # the pad columns stay untouched
-    assert torch.equal(torch.isnan(q), torch.isnan(q_ref)) and eq(q[~nan_rows], q_ref[~nan_rows])
-    assert bool(torch.isnan(q[nan_rows][:, :N]).all())
-    # in place
-    x2 = xc.clone()
-    q2 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
-    H.check(H.lib().bofi_ffn_proj_block(H.ptr(x2), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(x2), d,
-                                        H.ptr(wpp), H.ptr(cpc), H.ptr(cspc), H.ptr(q2), N + 64, N, M, dff, H.stream_ptr()))
-    torch.cuda.synchronize()
-    assert eq(x2[~nan_rows], y_ref[~nan_rows]) and eq(q2[~nan_rows], q_ref[~nan_rows])
-
-
 def test_ffn_block_nan_row_stays_in_its_row(H):
     """A NaN row (quirk Q1's fully masked image) must not leak into the other rows of its block."""
     M, d, dff = 64, 512, 2048
@@ -272,82 +225,3 @@ def test_linear_block_vs_reference_projection(H, M, N, f32out, relu):
     assert (got[:, N:] == 7.0).all()
     tol = 2e-2 if f32out else 6e-2                                        # bf16 operands; a bf16 result adds its own rounding at |y| ~ 4
     assert (got[:, :N] - ref).abs().max() < tol, (got[:, :N] - ref).abs().max()
-
-
-def _encoder_reference(x, layers, B, R, klen):
-    """Encoder.forward (TransformerModel.py:1391-1395) without the final norm, float64 on the bf16-rounded weights."""
-    d, H_, dk = 512, 8, 64
-    x = x.double().clone()
-    for ly in layers:
-        n = _layer_norm64(x, ly["g1"], ly["bl1"])
-        qkv = n @ ly["wqkv_eff"].T + ly["bqkv"].double()
-        q, k, v = (t.reshape(B, R, H_, dk).transpose(1, 2) for t in qkv.split(d, dim=1))
-        s = q @ k.transpose(-1, -2) / 8.0
-        mask = torch.arange(R)[None, :] >= klen[:, None]                     # [B, R] keys past the image's count
-        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
-        ctx = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * R, d)
-        x = x + ctx @ _bf(ly["wo"]).double().T + ly["bo"].double()
-        n = _layer_norm64(x, ly["g2"], ly["bl2"])
-        h = torch.relu(n @ ly["w1_eff"].T + ly["b1"].double())
-        x = x + h @ _bf(ly["w2"]).double().T + ly["b2"].double()
-    return x
-
-
-@pytest.mark.parametrize("B,R,nlayers,ragged", [(2, 36, 1, False), (5, 36, 2, True), (4, 40, 2, True), (3, 32, 1, False), (64, 36, 6, True)])
-def test_encoder_block_vs_reference_stack(H, B, R, nlayers, ragged):
-    """rb_encoder_kernel: N encoder layers in one launch, two images per workgroup, the stream in registers -- against the float64
-    restatement; also in place, and an image's rows must not depend on the image it shares a workgroup with."""
-    import ctypes as C
-    d, dff = 512, 2048
-    g = _rng(B * 100 + R + nlayers)
-    x = torch.randn(B * R, d, generator=g) * 1.2 + 0.1
-    klen = torch.full((B,), R, dtype=torch.int64)
-    if ragged:
-        klen = torch.randint(R // 2, R + 1, (B,), generator=g)
-        klen[0] = R
-    layers, keep = [], []
-    arrs = {k: [] for k in ("wqkv", "cqkv", "csqkv", "wo", "bo", "w1", "c1", "cs1", "w2", "b2")}
-    for _ in range(nlayers):
-        ly = {"g1": torch.rand(d, generator=g) + 0.5, "bl1": torch.randn(d, generator=g) * 0.1, "g2": torch.rand(d, generator=g) + 0.5,
-              "bl2": torch.randn(d, generator=g) * 0.1, "wqkv": torch.randn(3 * d, d, generator=g) / math.sqrt(d), "bqkv": torch.randn(3 * d, generator=g) * 0.1,
-              "wo": torch.randn(d, d, generator=g) / math.sqrt(d), "bo": torch.randn(d, generator=g) * 0.1,
-              "w1": torch.randn(dff, d, generator=g) / math.sqrt(d), "b1": torch.randn(dff, generator=g) * 0.1,
-              "w2": torch.randn(d, dff, generator=g) / math.sqrt(dff), "b2": torch.randn(d, generator=g) * 0.1}
-        wq, cq, csq = _fold(ly["wqkv"], ly["bqkv"], ly["g1"], ly["bl1"])
-        w1f, c1, cs1 = _fold(ly["w1"], ly["b1"], ly["g2"], ly["bl2"])
-        ly["wqkv_eff"], ly["w1_eff"] = wq.double() / ly["g1"].double()[None, :], w1f.double() / ly["g2"].double()[None, :]
-        layers.append(ly)
-        dev = {"wqkv": pack_frag(H, wq.to(torch.bfloat16).cuda()), "cqkv": cq.cuda(), "csqkv": csq.cuda(), "wo": pack_frag(H, ly["wo"].to(torch.bfloat16).cuda()),
-               "bo": ly["bo"].cuda(), "w1": pack_frag(H, w1f.to(torch.bfloat16).cuda()), "c1": c1.cuda(), "cs1": cs1.cuda(),
-               "w2": pack_frag(H, ly["w2"].to(torch.bfloat16).cuda()), "b2": ly["b2"].cuda()}
-        keep.append(dev)
-        for k, t in dev.items():
-            arrs[k].append(H.ptr(t))
-    ptrs = {k: (C.c_void_p * nlayers)(*v) for k, v in arrs.items()}
-    kl = klen.to(torch.int32).cuda()
-
-    def run(xin, nb, klc):
-        y = torch.full_like(xin, float("nan"))
-        H.check(H.lib().bofi_encoder_block(H.ptr(xin), H.ptr(y), H.ptr(klc), nb, R, nlayers, ptrs["wqkv"], ptrs["cqkv"], ptrs["csqkv"], ptrs["wo"], ptrs["bo"],
-                                           ptrs["w1"], ptrs["c1"], ptrs["cs1"], ptrs["w2"], ptrs["b2"], dff, H.stream_ptr()))
-        torch.cuda.synchronize()
-        return y
-    xc = x.cuda()
-    y = run(xc, B, kl)
-    ref = _encoder_reference(x, layers, B, R, klen)
-    err = (y.cpu().double() - ref).abs().max().item()
-    scale = ref.abs().max().item()
-    assert err < 1.5e-2 * nlayers * max(1.0, scale / 4), (err, scale)
-    # an image in the same half of its workgroup's block but without / with another partner: its rows bit for bit (a row's sums do not
-    # depend on the other rows of a tile); in the OTHER half its keys sit at other accumulator positions -- the same sums in another order
-    if B >= 3:
-        one = run(xc[2 * R:3 * R].contiguous(), 1, kl[2:3].contiguous())
-        assert torch.equal(one, y[2 * R:3 * R])
-    odd = run(xc[R:2 * R].contiguous(), 1, kl[1:2].contiguous())
-    assert float((odd - y[R:2 * R]).abs().max()) < 2e-3 * nlayers * max(1.0, scale / 4)
-    # in place
-    x2 = xc.clone()
-    H.check(H.lib().bofi_encoder_block(H.ptr(x2), H.ptr(x2), H.ptr(kl), B, R, nlayers, ptrs["wqkv"], ptrs["cqkv"], ptrs["csqkv"], ptrs["wo"], ptrs["bo"],
-                                       ptrs["w1"], ptrs["c1"], ptrs["cs1"], ptrs["w2"], ptrs["b2"], dff, H.stream_ptr()))
-    torch.cuda.synchronize()
-    assert torch.equal(x2, y)

@@ -515,19 +515,15 @@ def test_ffn_input_gradient_arrives_masked_from_the_second_linear(p_drop):
         assert _maxdiff(a, c) <= 1e-5 * max(1.0, float(c.abs().max()))
 
 
-@pytest.mark.parametrize("n,dma", [(3, 1), (45, 1), (45, 0)])
-def test_grouped_weight_gradient_gemms(n, dma, monkeypatch):
+@pytest.mark.parametrize("n", [3, 45])
+def test_grouped_weight_gradient_gemms(n):
     """bofi_gemm_tn_grouped: n problems of mixed sizes (ragged tiles, empty row sets, two problems adding into the same
-    target, with and without column sums) = the problems run one by one; 45 spans several launches.  Outputs of at least 256 x 256 over
-    a multiple of 32 rows take the LDS-DMA ring kernel when it is switched on (BOFI_TN_DMA=1; off by default -- correct, not faster):
-    256 x 256 tiles, ragged edge tiles, one / few / many 32-row stages, row splits."""
+    target, with and without column sums) = the problems run one by one; 45 spans several launches."""
     from boficap_amd import hip, xe
-    monkeypatch.setenv("BOFI_TN_DMA", str(dma))
-    hip.lib().bofi_reload_env()
     g = torch.Generator().manual_seed(n)
     pad = lambda v: (v + 63) // 64 * 64
     shapes = [(300, 70, 130), (0, 64, 64), (129, 20, 64), (1000, 128, 65), (64, 64, 192), (500, 200, 130), (257, 128, 256),    # the last two: 128 x 128 tiles
-              (704, 300, 520), (32, 256, 256), (2560, 512, 264), (96, 1000, 256), (1024, 256, 256)]                                # LDS-DMA class (M % 32 == 0)
+              (704, 300, 520), (32, 256, 256), (2560, 512, 264), (96, 1000, 256), (1024, 256, 256)]                                # large outputs, M % 32 == 0
     todo, refs, targets = [], [], {}
     for e in range(n):
         M, NI, NJ = shapes[e % len(shapes)]
@@ -549,8 +545,6 @@ def test_grouped_weight_gradient_gemms(n, dma, monkeypatch):
         assert xe.flush_weight_grads() == n and xe._DEFER["list"] == []
     finally:
         xe._DEFER["list"] = None
-        monkeypatch.delenv("BOFI_TN_DMA")
-        hip.lib().bofi_reload_env()
     for c, cs, rc, rcs in targets.values():
         assert _maxdiff(c, rc) < 2e-3 * max(1.0, float(rc.abs().max()))
         assert _maxdiff(cs, rcs) < 2e-3 * max(1.0, float(rcs.abs().max()))
