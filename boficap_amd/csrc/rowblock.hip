@@ -29,6 +29,8 @@
 
 namespace bofi {
 
+extern int g_env_generation;                   // bumped by bofi_reload_env (gemm_glds.hip)
+
 // developer aid (BOFI_RB_DBG & 16): s_memtime stamps of workgroup 0, [wave][slot], read back by bofi_rb_stamps
 __device__ unsigned long long g_rb_stamps[16 * 16];
 #define RB_STAMP(dbg, wave, lane, slot) do { if (((dbg) & 16) && blockIdx.x == 0 && (lane) == 0) g_rb_stamps[(wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -57,20 +59,27 @@ __device__ __forceinline__ void rb_prime(const u32x4* seg, bf16x8 (&wb)[PF * NT]
 // the swizzle only touches bits 4..9, so a k-step costs one v_xor with an inline constant and the tile index rides in the offset field.
 __device__ __forceinline__ int rb_lane_base(int l15, int g) { return l15 * 1024 + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4)); }
 
-template <int MT, int NT = 4, int PF = RB_PF>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one); PF divides 16
+template <int MT, int NT = 4, int PF = RB_PF, int MH = MT>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one); PF divides 16;
+                                                                  // MH: row tiles per operand batch (MH < MT: fewer operand registers live at a time)
 __device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, bf16x8 (&wb)[PF * NT], const unsigned char* smem, int lbase,
                                            f32x4 (&acc)[NT][MT]) {
+    static_assert(MT % MH == 0, "operand batches divide the row tiles");
     asm volatile("" : "+v"(lbase));                   // (keeps the sixteen k-step addresses from being hoisted out of the caller's loops and spilled)
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
-        bf16x8 xa[MT];
-        const unsigned char* xp = smem + (lbase ^ (kb << 6));
+        int ad = lbase ^ (kb << 6);
+        if constexpr (MT > 6) asm volatile("" : "+v"(ad));     // (eight row tiles: offsets past the 16-bit field -- computed here, per step, not sixteen steps ahead)
+        const unsigned char* xp = smem + ad;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 16384);
+        for (int mb = 0; mb < MT; mb += MH) {
+            bf16x8 xa[MH];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int mt = 0; mt < MH; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xp + (mb + mt) * 16384);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(kb % PF) * NT + nt], xa[mt], acc[nt][mt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MH; ++mt) acc[nt][mb + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(kb % PF) * NT + nt], xa[mt], acc[nt][mb + mt], 0, 0, 0);
+        }
         const u32x4* src = kb + PF < 16 ? cur + (kb + PF) * 256 : nxt + (kb + PF - 16) * 256;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wb[(kb % PF) * NT + nt] = rb_ldw(src + nt * 64);
@@ -315,18 +324,306 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
     RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // exit
 }
 
+// developer aid (BOFI_RB_DBG & 16): wavefronts 0 (producer) and 4 (consumer) of workgroup 0 append s_memtime stamps: [0..127] / [128..255]
+#define RB3_STAMP(on, n) do { if ((on) && (n) < 126) g_rb_stamps[stamp_base + (n)++] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same sublayer on 80-ROW blocks, able to walk several of them (round 4; the default from 4 096 rows on).
+// What round 4 measured on the 64-row kernel first (profiles/r04_ffn_*.txt, dev/exp/mb_rowblock.py ffn4, dev/exp/rb_ffn_stamps.py):
+//   * its workgroup lives 110 k cycles of which 65.5 k are MFMA issue -- staging 11-18 k before the first chunk exists, closing epilogue 12.5 k
+//     (residual in, rows out through a workgroup-wide LDS transposition, three barriers) -- and a row-block workgroup owns its CU;
+//   * a persistent form that stages block j + 1 beside the consumers' last chunks of block j and closes blocks without loads (below) cut the
+//     CU-time per block from 110 k to 87 k cycles -- and changed NOTHING with four launches in flight (44-46 us per 11 520-row launch, four
+//     concurrent feed-forward streams, one, two or three blocks per workgroup): the chip is not CU-time-bound there.  Neither do 20 % fewer
+//     weight bytes per row (these 80-row blocks) move that four-stream figure; what they move is the whole decode, +3 %, one block per
+//     workgroup (more blocks per workgroup lose: the launch's latency chain grows).  The 64-row persistent kernel left the library again.
+// What is kept from it:
+//   * the consumers' accumulators START from the residual rows (x, loaded in the accumulator layout straight into the accumulator
+//     registers -- for a next block right behind the staging of this block's tiles, register by register), so closing a block needs no
+//     loads and no workgroup barrier: tiles go through 2.3 KB of the wavefront's own LDS (16 rows x 32 columns, 128-byte row pieces) + b_2
+//     (from LDS: a global load there would sit in the vmcnt queue in front of the residual loads and every store would wait for those);
+//   * the producers stage the next block as soon as THEY are through with this one's last chunk (a producers-only barrier in LDS);
+//   * nothing in the closing code may be a loop invariant of the block loop (row pointers, bias): hoisted above the chunk loop it is spilled,
+//     and a scratch reload is an s_waitcnt vmcnt(0) that drains the loads just issued (measured: 20 k cycles per block instead of 4 k);
+//   * the consumer's weight stream as buffer loads (scalar resource + one vector offset): with 64-bit global addresses the allocator spills a
+//     weight fragment inside the MFMA loop at 160 accumulator + 64 ring registers.
+// Five row tiles are what the consumer's registers hold (8 x 5 accumulator tiles = 160, + the 64 of its weight ring); the hidden ring is three
+// slots of 128 columns (60 KB) beside the 80 KB block.  Sums: a row's result is (x + sum of the MFMA partial sums in chunk order) + b_2,
+// whatever block or workgroup it sits in.
+//   producers (wavefronts 0-3): stage the block (20 rows each), then per chunk 32 hidden columns each: w_1 tiles (c*2 + (w >> 1), (w & 1)*2 ..+1)
+//   consumers (wavefronts 4-7): 128 output columns each, K = the chunks as they arrive.
+constexpr int R5_ROWS = 80, R5_HC = 128, R5_SLOTS = 3, R5_SLOT = R5_ROWS * 256;
+constexpr int R5_HR = R5_ROWS * 1024;                                  // hidden ring behind the block
+constexpr int R5_CST = R5_HR + R5_SLOTS * R5_SLOT, R5_CSTW = 16 * 144; // consumer staging: [4 wavefronts][16 rows][144 B]
+constexpr int R5_PC = R5_CST + 4 * R5_CSTW;                            // producer constants: [4 wavefronts][c[32] | cs[32]] floats
+constexpr int R5_STAT = R5_PC + 4 * 256;                               // s_mean[80], s_rstd[80]
+constexpr int R5_FLAG = R5_STAT + 2 * R5_ROWS * 4;                     // full[3], empty[3], producer barrier
+constexpr int R5_B2 = R5_FLAG + 64;                                    // b_2 [512]
+constexpr int R5_LDS = R5_B2 + 2048;
+static_assert(R5_LDS <= 160 * 1024, "one workgroup per CU");
+
+template <bool EXTRA, bool STAMPS>             // EXTRA: the optional bf16 copy / partial sums are written; STAMPS: the developer timeline (BOFI_RB_DBG & 16)
+__global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;                                  // [80][512] bf16, swizzled, row pitch 1 024 B
+    unsigned char* hr = smem + R5_HR;                          // 3 slots x [80][128] bf16, swizzled, row pitch 256 B
+    float* s_mean = reinterpret_cast<float*>(smem + R5_STAT);
+    float* s_rstd = s_mean + R5_ROWS;
+    unsigned* flags = reinterpret_cast<unsigned*>(smem + R5_FLAG);      // full[0..2], empty[3..5], producer barrier [6]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int nblocks = (a.M + R5_ROWS - 1) / R5_ROWS, nch = a.dff / R5_HC;
+    const bool producer = wave < 4;
+    const int w4 = wave & 3;
+    const bool stamps = STAMPS && blockIdx.x == 0 && lane == 0 && w4 == 0;
+    const int stamp_base = __builtin_amdgcn_readfirstlane(producer ? 0 : 128);
+    int nst = 0;
+    RB3_STAMP(stamps, nst);                                    // entry
+    unsigned long long rt0 = 0;                                // (the 100 MHz constant clock beside the shader clock: the clock the chip holds under this load)
+    if (stamps) rt0 = __builtin_amdgcn_s_memrealtime();
+
+    bf16x8 wbuf[16];                                           // producer: 8 steps x 2 fragments; consumer: 2 steps x 8 fragments
+    auto w1seg = [&](int c) { return a.w1p + (size_t)(c * 2 + (w4 >> 1)) * (16 * 256) + (w4 & 1) * 128 + lane; };
+    // the consumer's weight stream as BUFFER loads: a scalar resource over the wavefront's two 64-column chunks of w_2 (one after the other), the step in
+    // a scalar offset, the lane's 16 bytes in ONE vector register -- global loads cost a 64-bit address pair per base, and at 160 accumulator + 64
+    // ring registers the allocator then spills a weight fragment inside the loop
+    const size_t w2j = (size_t)(a.dff >> 5) * 4096;           // bytes from a chunk to the next
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(a.w2p + (size_t)(2 * __builtin_amdgcn_readfirstlane(w4)) * (a.dff >> 5) * 256), 0, (int)(2 * w2j), 0x00020000);
+    const int lo16 = lane * 16;
+    auto w2frag = [&](int step, int f) {
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, lo16 + (f & 3) * 1024, (int)((f >> 2) * w2j) + step * 4096, 0));
+    };
+    if (producer) rb_prime<2, 8>(w1seg(0), wbuf);
+    else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int f = 0; f < 8; ++f) wbuf[p * 8 + f] = w2frag(p, f);
+    }
+    if (tid < 8) flags[tid] = 0u;
+    reinterpret_cast<float*>(smem + R5_B2)[tid] = a.b2[tid];
+    __syncthreads();                                           // (the only workgroup barrier of the kernel)
+
+    if (producer) {
+        const int lbase = rb_lane_base(l15, g);
+        float* mycst = reinterpret_cast<float*>(smem + R5_PC) + w4 * 64;
+        unsigned q = 0, pb = 0;                                // chunks handed over so far / producer-barrier generation
+#pragma unroll 1
+        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+            const int m0 = blk * R5_ROWS;
+            if (blk != (int)blockIdx.x) { ++pb; rb_signal(flags + 6, lane); rb_wait_ge(flags + 6, 4u * pb); }      // every producer is through with the previous block
+            RB3_STAMP(stamps, nst);                            // staging starts
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass) {              // wavefront w4: rows 20*w4 .. +19, eight at a time, eight lanes per row
+                const int lr = pass * 8 + (lane >> 3), r = w4 * 20 + lr, sub = lane & 7, m = m0 + r;
+                const bool mine = lr < 20;
+                float4 v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    v[j] = (mine && m < a.M) ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+                    sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+                    if (mine) *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+                }
+                sm = oct_sum(sm); sq = oct_sum(sq);
+                if (mine && sub == 0) {
+                    const float mean = sm * (1.0f / 512.0f);
+                    const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+                    s_mean[r] = mean;
+                    s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+                }
+            }
+            ++pb; rb_signal(flags + 6, lane); rb_wait_ge(flags + 6, 4u * pb);                                      // block and statistics complete
+            RB3_STAMP(stamps, nst);                            // block staged
+            float mu[5], rs[5];
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
+#pragma unroll 1
+            for (int c = 0; c < nch; ++c, ++q) {
+                const int col = c * R5_HC + w4 * 32 + (lane & 31);
+                const float cv = lane < 32 ? a.c1[col] : a.cs1[col];                          // (requested before the segment's weight loads)
+                f32x4 acc1[2][5];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rb_segment<5, 2, 8>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : 0), wbuf, smem, lbase, acc1);
+                if (!(c & 1)) RB3_STAMP(stamps, nst);          // segment done
+                mycst[lane] = cv;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const unsigned slot = q % R5_SLOTS, round = q / R5_SLOTS;
+                if (round) rb_wait_ge(flags + 3 + slot, 4u * round);                         // the consumers are through with chunk q - 3
+                unsigned char* hs = hr + slot * R5_SLOT;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float4 cc = *reinterpret_cast<const float4*>(mycst + nt * 16 + g * 4);
+                    const float4 cs = *reinterpret_cast<const float4*>(mycst + 32 + nt * 16 + g * 4);
+                    const int ch = w4 * 4 + nt * 2 + (g >> 1);                               // 16-byte chunk of the slot's 256-byte rows
+#pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) {
+                        const f32x4 t = acc1[nt][mt];
+                        const float h0 = fmaxf(rs[mt] * (t[0] - mu[mt] * cs.x) + cc.x, 0.f), h1 = fmaxf(rs[mt] * (t[1] - mu[mt] * cs.y) + cc.y, 0.f);
+                        const float h2 = fmaxf(rs[mt] * (t[2] - mu[mt] * cs.z) + cc.z, 0.f), h3 = fmaxf(rs[mt] * (t[3] - mu[mt] * cs.w) + cc.w, 0.f);
+                        const int row = mt * 16 + l15;
+                        *reinterpret_cast<uint2*>(hs + row * 256 + ((ch ^ l15) << 4) + (g & 1) * 8) = make_uint2(pack_bf16(h0, h1), pack_bf16(h2, h3));
+                    }
+                }
+                rb_signal(flags + slot, lane);
+                if (!(c & 1)) RB3_STAMP(stamps, nst);          // chunk handed over
+            }
+        }
+    } else {
+        const int nsteps = nch * 4;
+        const int er = lane >> 3, ec = lane & 7;               // closing layout: row it*8 + er of a 16-row tile, 16-byte piece ec of its 32 columns
+        // the accumulators start from the residual rows (dead rows of a ragged last block: the batch's last row -- never stored)
+        f32x4 acc2[8][5];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            const float* xn = a.x + (size_t)min((int)blockIdx.x * R5_ROWS + mt * 16 + l15, a.M - 1) * a.ldx + w4 * 128 + g * 4;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const float4 v = *reinterpret_cast<const float4*>(xn + f * 16);
+                acc2[f][mt] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        unsigned q = 0;
+#pragma unroll 1
+        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+            const int m0 = blk * R5_ROWS, rows_live = min(R5_ROWS, a.M - m0);
+            const int blk_next = blk + (int)gridDim.x;
+#pragma unroll 1
+            for (int c = 0; c < nch; ++c, ++q) {
+                const unsigned slot = q % R5_SLOTS, round = q / R5_SLOTS;
+                rb_wait_ge(flags + slot, 4u * (round + 1));                                 // chunk q is in its slot
+                if (!(c & 1)) RB3_STAMP(stamps, nst);          // chunk arrived
+                int hl = l15, hg = g;                          // (recomputed per chunk: kept across the loop it is spilled, and its reload drains the weight ring)
+                asm volatile("" : "+v"(hl), "+v"(hg));
+                int hb = R5_HR + (int)slot * R5_SLOT + hl * 256 + (((hl >> 2) << 6) | ((hg ^ (hl & 3)) << 4));
+                asm volatile("" : "+v"(hb));
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const unsigned char* xp = smem + (hb ^ (kb << 6));
+#pragma unroll
+                    for (int mb = 0; mb < 5; mb += 2) {         // (row tiles 0-1, 2-3, 4: few operand registers -- the kernel sits at 256)
+                        bf16x8 xa[2];
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2)
+                            if (mb + m2 < 5) xa[m2] = *reinterpret_cast<const bf16x8*>(xp + (mb + m2) * 4096);
+#pragma unroll
+                        for (int f = 0; f < 8; ++f)
+#pragma unroll
+                            for (int m2 = 0; m2 < 2; ++m2)
+                                if (mb + m2 < 5) acc2[f][mb + m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[(kb & 1) * 8 + f], xa[m2], acc2[f][mb + m2], 0, 0, 0);
+                    }
+                    int sn = c * 4 + kb + 2;                                                // (the stream wraps: the next block reads the same weights)
+                    sn = sn >= nsteps ? sn - nsteps : sn;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) wbuf[(kb & 1) * 8 + f] = w2frag(sn, f);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                rb_signal(flags + 3 + slot, lane);
+                if (!(c & 1)) RB3_STAMP(stamps, nst);          // chunk consumed
+            }
+            // ---- close the block: 16 rows x 32 columns of the wavefront's own LDS at a time (+ b_2) -> 128-byte row pieces -> memory; the freed
+            // accumulator registers take the next block's residual rows at once
+            int erv = er, ecv = ec, gv = g, lv = l15;
+            asm volatile("" : "+v"(erv), "+v"(ecv), "+v"(gv), "+v"(lv));
+            const int ws = __builtin_amdgcn_readfirstlane(w4);
+            const size_t ystep = (size_t)8 * a.ldy;
+            float* yp = a.y + (size_t)(m0 + erv) * a.ldy + ws * 128 + ecv * 4;
+            int rr = erv;                                      // row of the block this lane closes next
+            unsigned char* sw = smem + R5_CST + ws * R5_CSTW + lv * 144 + gv * 16;
+            const unsigned char* sr = smem + R5_CST + ws * R5_CSTW + erv * 144 + ecv * 16;
+            const float* b2l = reinterpret_cast<const float*>(smem + R5_B2) + ws * 128 + ecv * 4;
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                const float* xn = a.x + (size_t)min(blk_next * R5_ROWS + mt * 16 + lv, a.M - 1) * a.ldx + ws * 128 + gv * 4;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {               // columns qq*32 .. +31 of the wavefront's 128: fragments 2 qq, 2 qq + 1
+#pragma unroll
+                    for (int fq = 0; fq < 2; ++fq) {
+                        const f32x4 t = acc2[qq * 2 + fq][mt];
+                        *reinterpret_cast<float4*>(sw + fq * 64) = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                    if (blk_next < nblocks) {
+#pragma unroll
+                        for (int fq = 0; fq < 2; ++fq) {
+                            const float4 v = *reinterpret_cast<const float4*>(xn + (qq * 2 + fq) * 16);
+                            acc2[qq * 2 + fq][mt] = f32x4{v.x, v.y, v.z, v.w};
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 bb = *reinterpret_cast<const float4*>(b2l + qq * 32);
+                    float4 sv[2];
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) sv[it] = *reinterpret_cast<const float4*>(sr + it * 8 * 144);
+                    float* yq = yp;
+                    int rq = rr;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it, yq += ystep, rq += 8) {
+                        const float4 o = make_float4(sv[it].x + bb.x, sv[it].y + bb.y, sv[it].z + bb.z, sv[it].w + bb.w);
+                        const bool live = rq < rows_live;
+                        if (live) *reinterpret_cast<float4*>(yq + qq * 32) = o;
+                        if constexpr (EXTRA) {
+                            const size_t m = live ? (size_t)(m0 + rq) : 0;
+                            const int cb = ws * 128 + qq * 32 + ecv * 4;
+                            if (live && a.yb) *reinterpret_cast<uint2*>(a.yb + m * 512 + cb) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                            if (a.stats_out) {                 // a 32-column group = the 8 lanes of a row piece
+                                const float s1 = oct_sum((o.x + o.y) + (o.z + o.w)), s2 = oct_sum((o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                                if (live && !ecv) reinterpret_cast<float2*>(a.stats_out + m * 32)[cb >> 5] = make_float2(s1, s2);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();           // (the next group rewrites the staging rows)
+                }
+                yp += 2 * ystep; rr += 16;
+            }
+            RB3_STAMP(stamps, nst);                            // block closed
+        }
+    }
+    if (stamps && nst < 126) {
+        g_rb_stamps[stamp_base + nst] = 0ull;                   // terminator
+        g_rb_stamps[stamp_base + 126] = __builtin_amdgcn_s_memrealtime() - rt0;      // 10 ns ticks from entry to exit ...
+        g_rb_stamps[stamp_base + 127] = __builtin_amdgcn_s_memtime();               // ... and the shader clock at exit (entry: stamp 0)
+    }
+}
+
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
     if (a.M < 1 || a.dff < 512 || a.dff % 512 || a.dff > 2560 || !a.x || !a.w1p || !a.c1 || !a.cs1 || !a.w2p || !a.b2 || !a.y || a.ldx % 4 || a.ldy % 4)
         return BOFI_ERR_ARG;
     const size_t lds = 131072 + (size_t)a.dff * 8 + 2048 + 512 + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
         attr_set = true;
+    }
+    // knobs (read again after bofi_reload_env): BOFI_RB_FFN_V = 5 (default): 80-row blocks -- +3 % on the decode with launches in flight; 2: one
+    // 64-row block per workgroup (round 3's kernel) -- 6-12 us faster per launch when ONE decode runs alone (62 against 68 us at 11 520 rows);
+    // BOFI_RB_FFN_BPW = row blocks a workgroup of the 80-row kernel walks (default 1; grid = blocks / that)
+    static int env_seen = -1, version = 5, bpw = 1;
+    if (env_seen != g_env_generation) {
+        const char* e = getenv("BOFI_RB_FFN_V"); version = e ? atoi(e) : 5;
+        e = getenv("BOFI_RB_FFN_BPW"); bpw = e ? max(1, atoi(e)) : 1;
+        env_seen = g_env_generation;
     }
     RbFfnArgs b = a;
     { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    if (version == 2) hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    else {
+        const int grid = ((a.M + R5_ROWS - 1) / R5_ROWS + bpw - 1) / bpw;
+        if (a.yb || a.stats_out) hipLaunchKernelGGL((rb_ffn5_kernel<true, false>), dim3(grid), dim3(512), R5_LDS, st, b);
+        else if (b.dbg & 16) hipLaunchKernelGGL((rb_ffn5_kernel<false, true>), dim3(grid), dim3(512), R5_LDS, st, b);
+        else hipLaunchKernelGGL((rb_ffn5_kernel<false, false>), dim3(grid), dim3(512), R5_LDS, st, b);
+    }
     g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
@@ -589,52 +886,84 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The column loop of the LayerNorm-folded projection over a staged block (rb_gemm_kernel, and rb_ffn2_kernel's fused projection): the
-// wavefront takes the 64-column chunks ch0, ch0 + chstep, ... of the weight, 16 k-steps each; its epilogue (fold, bias, rounding, its own
-// 9 KB of LDS to turn the accumulator layout into whole 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs -- no workgroup
-// barrier.  blk: the block (64 rows x 1 KiB, swizzled); wb: the ring, primed with chunk ch0's first steps.
-template <bool F32OUT>
+// y[M][N] = epilogue(LN(x) . W^T) for K = 512 and any N % 64 == 0: the LayerNorm-folded projections of the path (q|k|v, the
+// cross-attention queries, the stacked cross K|V of all layers, the generator) as a row-block kernel: the block of the residual
+// stream is staged once (float32 -> bf16, row statistics on the way: no bf16 copy and no statistics from the producer), the eight
+// wavefronts take the 64-column chunks w, w + 8, ... of the weight (any chunk count), 16 k-steps each, and there is NO workgroup
+// barrier after the staging: a wavefront's epilogue (fold, bias, rounding, its own LDS to turn the accumulator layout into whole
+// 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs.
+// MT = row tiles per block: 4 (64 rows) or 8 (128 rows, bf16 outputs).  Every workgroup streams the WHOLE weight through its CU's vector
+// memory path (64 B per clock): at 64 rows that path and the MFMA pipes saturate together, and with every CU streaming the chip
+// delivers ~16 TB/s of weights whatever the kernels do (round 4: four concurrent feed-forward streams, dev/exp/mb_rowblock.py ffn4) --
+// the projections are bound by weight bytes per row.  128 rows per block halve them (128 KB of LDS for the block, 16 rows of staging per
+// wavefront at a time, operands read four tiles at a time to stay within 256 registers).
+template <bool F32OUT, int MT>
+struct RbGemmCfg {
+    static constexpr int BR = MT * 16;                          // rows per block
+    static constexpr int SP = F32OUT ? 272 : 144;               // staging row pitch (bytes): 64 columns + 16 B
+    static constexpr int TPS = MT == 8 ? 1 : MT == 6 ? 2 : (F32OUT ? 2 : 4);      // row tiles staged at a time
+    static constexpr int STG = TPS * 16 * SP;                   // staging bytes per wavefront
+    static constexpr int XT = BR * 1024;
+    static constexpr int STAT = XT + 8 * STG;                   // s_mean[BR], s_rstd[BR]
+    static constexpr int CST = STAT + BR * 8;                   // per wavefront [2][64]: c | cs of the current chunk
+    static constexpr int LDS = CST + 8 * 512;
+};
+
+template <bool F32OUT, int MT>
 __device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsigned char* blk, unsigned char* stage_all, float* cst, const float* s_mean,
                                                const float* s_rstd, int m0, int wave, int lane, int ch0, int chstep, bf16x8 (&wb)[RB_PF * 4]) {
-    constexpr int SP = F32OUT ? 272 : 144;                     // staging row pitch (bytes): 64 columns + 16 B
-    constexpr int SROWS = F32OUT ? 32 : 64;                    // rows staged at a time
+    using Cfg = RbGemmCfg<F32OUT, MT>;
+    constexpr int SP = Cfg::SP, TPS = Cfg::TPS;
     const int l15 = lane & 15, g = lane >> 4, nchunks = a.N >> 6;
     auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
-    float mu[4], rs[4];
+    constexpr bool STATS_IN_REGS = MT <= 6;                    // (128-row blocks: the 16 statistics registers are what the accumulators need -- read per pass from LDS)
+    float mu[STATS_IN_REGS ? MT : 1], rs[STATS_IN_REGS ? MT : 1];
+    if constexpr (STATS_IN_REGS) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
+        for (int mt = 0; mt < MT; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
+    }
     const int lbase = rb_lane_base(l15, g);
-    unsigned char* stage = stage_all + wave * 9216;
+    unsigned char* stage = stage_all + wave * Cfg::STG;
     int nstamp = 0;
     float* mycst = cst + wave * 128;
-    const int rows_live = min(64, a.M - m0);
+    const int rows_live = min(Cfg::BR, a.M - m0);
 
 #pragma unroll 1
     for (int ch = ch0; ch < nchunks; ch += chstep) {
         // this chunk's column constants: requested now (older than the weight prefetch), parked in LDS at the epilogue
         const float cv = a.c[ch * 64 + lane], csv = a.cs[ch * 64 + lane];
-        f32x4 acc[4][4];
+        f32x4 acc[4][MT];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb_segment<4, 4>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, blk, lbase, acc);
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb_segment<MT, 4, RB_PF, (MT > 4 ? MT / 2 : MT)>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, blk, lbase, acc);
         if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp);            // chunk's MFMAs issued
         mycst[lane] = cv; mycst[64 + lane] = csv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // (the row pointers of the stores hang on a lane value the compiler cannot see through and advance by additions: as invariants of the chunk
+        // loop they are hoisted above it -- two registers per store -- and the accumulators spill)
+        constexpr int LPR = F32OUT ? 16 : 8, RPI = 64 / LPR;
+        int lnv = lane;
+        asm volatile("" : "+v"(lnv));
+        int rrow = lnv / LPR;                                  // row of the block this lane stores next
+        unsigned char* yp = static_cast<unsigned char*>(a.y) + ((size_t)(m0 + rrow) * a.ldy + ch * 64) * (F32OUT ? 4 : 2) + (lnv % LPR) * 16;
+        const size_t ystep = (size_t)RPI * a.ldy * (F32OUT ? 4 : 2);
+        const unsigned char* srd = stage + rrow * SP + (lnv % LPR) * 16;
 #pragma unroll
-        for (int half = 0; half < (F32OUT ? 2 : 1); ++half) {
+        for (int pass = 0; pass < MT / TPS; ++pass) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const float4 cc = *reinterpret_cast<const float4*>(mycst + nt * 16 + g * 4);
                 const float4 cs = *reinterpret_cast<const float4*>(mycst + 64 + nt * 16 + g * 4);
 #pragma unroll
-                for (int mh = 0; mh < (F32OUT ? 2 : 4); ++mh) {
-                    const int mt = F32OUT ? half * 2 + mh : mh;
+                for (int mh = 0; mh < TPS; ++mh) {
+                    const int mt = pass * TPS + mh;
                     const f32x4 t = acc[nt][mt];
-                    float v0 = rs[mt] * (t[0] - mu[mt] * cs.x) + cc.x, v1 = rs[mt] * (t[1] - mu[mt] * cs.y) + cc.y;
-                    float v2 = rs[mt] * (t[2] - mu[mt] * cs.z) + cc.z, v3 = rs[mt] * (t[3] - mu[mt] * cs.w) + cc.w;
+                    const float mu_ = STATS_IN_REGS ? mu[STATS_IN_REGS ? mt : 0] : s_mean[mt * 16 + l15], rs_ = STATS_IN_REGS ? rs[STATS_IN_REGS ? mt : 0] : s_rstd[mt * 16 + l15];
+                    float v0 = rs_ * (t[0] - mu_ * cs.x) + cc.x, v1 = rs_ * (t[1] - mu_ * cs.y) + cc.y;
+                    float v2 = rs_ * (t[2] - mu_ * cs.z) + cc.z, v3 = rs_ * (t[3] - mu_ * cs.w) + cc.w;
                     if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                     unsigned char* sp = stage + (mh * 16 + l15) * SP + (nt * 16 + g * 4) * (F32OUT ? 4 : 2);
                     if constexpr (F32OUT) *reinterpret_cast<float4*>(sp) = make_float4(v0, v1, v2, v3);
@@ -644,13 +973,10 @@ __device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsign
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // whole row pieces: bf16 8 lanes x 16 B = a row's 128 B (8 rows per instruction); float32 16 lanes x 16 B = 256 B (4 rows)
-            constexpr int LPR = F32OUT ? 16 : 8, RPI = 64 / LPR;
 #pragma unroll
-            for (int it = 0; it < SROWS / RPI; ++it) {
-                const int lr = it * RPI + lane / LPR, r = (F32OUT ? half * 32 : 0) + lr;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(stage + lr * SP + (lane % LPR) * 16);
-                if (r < rows_live)
-                    *reinterpret_cast<u32x4*>(static_cast<unsigned char*>(a.y) + ((size_t)(m0 + r) * a.ldy + ch * 64) * (F32OUT ? 4 : 2) + (lane % LPR) * 16) = v;
+            for (int it = 0; it < TPS * 16 / RPI; ++it, yp += ystep, rrow += RPI) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(srd + it * RPI * SP);
+                if (rrow < rows_live) *reinterpret_cast<u32x4*>(yp) = v;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -659,45 +985,42 @@ __device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsign
     }
 }
 
-// y[M][N] = epilogue(LN(x) . W^T) for K = 512 and any N % 64 == 0: the LayerNorm-folded projections of the path (q|k|v, the
-// cross-attention queries, the stacked cross K|V of all layers, the generator) as a row-block kernel: the 64-row block of the residual
-// stream is staged once (float32 -> bf16, row statistics on the way: no bf16 copy and no statistics from the producer), the eight
-// wavefronts take the 64-column chunks w, w + 8, ... of the weight (any chunk count), 16 k-steps each, and there is NO workgroup
-// barrier after the staging: a wavefront's epilogue (fold, bias, rounding, its own 9 KB of LDS to turn the accumulator layout into whole
-// 128- / 256-byte row pieces) runs beside its SIMD partner's MFMAs.  x may also be bf16 with no fold (plain bias).
-
-template <bool F32OUT>
+template <bool F32OUT, int MT>
 __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
+    using Cfg = RbGemmCfg<F32OUT, MT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;
-    unsigned char* stage_all = smem + 65536;
-    float* s_mean = reinterpret_cast<float*>(smem + 65536 + 8 * 9216);
-    float* s_rstd = s_mean + 64;
-    float* cst = s_rstd + 64;                                  // per wavefront [2][64]: c | cs of the current chunk
+    unsigned char* stage_all = smem + Cfg::XT;
+    float* s_mean = reinterpret_cast<float*>(smem + Cfg::STAT);
+    float* s_rstd = s_mean + Cfg::BR;
+    float* cst = reinterpret_cast<float*>(smem + Cfg::CST);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // gridDim.y workgroups share a row block: workgroup y takes the chunk octets y, y + gridDim.y, ... (wide outputs on few row blocks:
     // the generator's 2.4 MB of float32 logits per block leave a CU at ~25 GB/s -- two workgroups per block halve that tail)
-    const int m0 = blockIdx.x * 64, nchunks = a.N >> 6, ch0 = wave + 8 * blockIdx.y, chstep = 8 * gridDim.y;
+    const int m0 = blockIdx.x * Cfg::BR, nchunks = a.N >> 6, ch0 = wave + 8 * blockIdx.y, chstep = 8 * gridDim.y;
     auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
     RB_STAMP(a.dbg, 8 + wave, lane, 0);                        // entry (rows 8-15: this kernel has 8 wavefronts)
     bf16x8 wb[RB_PF * 4];
     if (ch0 < nchunks) rb_prime<4>(seg(ch0), wb);
-    {   // stage the block (as rb_ffn_kernel)
-        const int r = wave * 8 + (lane >> 3), sub = lane & 7, m = m0 + r;
+    constexpr int RPW = MT * 2;                                // rows a wavefront stages
+#pragma unroll
+    for (int pass = 0; pass < (RPW + 7) / 8; ++pass) {         // stage the block: wavefront w takes rows RPW*w .. +RPW-1, eight at a time, eight lanes per row
+        const int lr = pass * 8 + (lane >> 3), r = wave * RPW + lr, sub = lane & 7, m = m0 + r;
+        const bool mine = lr < RPW;
         float4 v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            v[j] = m < a.M ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[j] = (mine && m < a.M) ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + j * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float sm = 0.f, sq = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
             sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-            *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+            if (mine) *reinterpret_cast<uint2*>(xt + rb_off(r, j * 4 + (sub >> 1)) + (sub & 1) * 8) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
         }
         sm = oct_sum(sm); sq = oct_sum(sq);
-        if (sub == 0) {
+        if (mine && sub == 0) {
             const float mean = sm * (1.0f / 512.0f);
             const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
             s_mean[r] = mean;
@@ -706,27 +1029,43 @@ __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
     }
     __syncthreads();
     RB_STAMP(a.dbg, 8 + wave, lane, 1);                        // block staged
-    rb_gemm_chunks<F32OUT>(a, smem, stage_all, cst, s_mean, s_rstd, m0, wave, lane, ch0, chstep, wb);
+    rb_gemm_chunks<F32OUT, MT>(a, smem, stage_all, cst, s_mean, s_rstd, m0, wave, lane, ch0, chstep, wb);
     RB_STAMP(a.dbg, 8 + wave, lane, 2);                        // exit
+}
+
+template <bool F32OUT, int MT>
+static int launch_rb_gemm_t(const RbGemmArgs& a, hipStream_t st) {
+    using Cfg = RbGemmCfg<F32OUT, MT>;
+    static_assert(Cfg::LDS <= 160 * 1024, "one workgroup per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_gemm_kernel<F32OUT, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
+        attr_set = true;
+    }
+    const int blocks = (a.M + Cfg::BR - 1) / Cfg::BR, octets = (a.N / 64 + 7) / 8;
+    int split = 1;                                            // workgroups per row block: fill the chip when the row blocks alone do not
+    while (split < 4 && blocks * (split + 1) <= 256 && octets >= 6 * (split + 1)) ++split;
+    hipLaunchKernelGGL((rb_gemm_kernel<F32OUT, MT>), dim3(blocks, split), dim3(512), Cfg::LDS, st, a);
+    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
 
 int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
     if (a.M < 1 || a.N < 64 || a.N % 64 || !a.x || !a.wp || !a.c || !a.cs || !a.y || a.ldx % 4 || a.ldy % 8) return BOFI_ERR_ARG;
-    const size_t lds = 65536 + 8 * 9216 + 512 + 8 * 512;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return BOFI_ERR_HIP;
-        attr_set = true;
+    // developer knob (read again after bofi_reload_env): BOFI_RB_GEMM_MT = 4: 64-row blocks everywhere; 6 (default) / 8: 96- / 128-row blocks for bf16
+    // outputs from BOFI_RB_GEMM_MT8_ROWS rows on (below that the 64-row blocks' larger number of workgroups wins)
+    static int env_seen = -1, mt = 6, mt8_rows = 4096;
+    if (env_seen != g_env_generation) {
+        const char* e = getenv("BOFI_RB_GEMM_MT"); mt = e ? atoi(e) : 6;
+        e = getenv("BOFI_RB_GEMM_MT8_ROWS"); mt8_rows = e ? atoi(e) : 4096;
+        env_seen = g_env_generation;
     }
-    const int blocks = (a.M + 63) / 64, octets = (a.N / 64 + 7) / 8;
-    int split = 1;                                            // workgroups per row block: fill the chip when the row blocks alone do not
-    while (split < 4 && blocks * (split + 1) <= 256 && octets >= 6 * (split + 1)) ++split;
-    if (a.y_f32) hipLaunchKernelGGL(rb_gemm_kernel<true>, dim3(blocks, split), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(rb_gemm_kernel<false>, dim3(blocks, split), dim3(512), lds, st, a);
-    g_gemm_flops += 2.0 * a.M * 512.0 * a.N;
-    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+    int rc;
+    if (a.y_f32) rc = launch_rb_gemm_t<true, 4>(a, st);
+    else if (mt == 8 && a.M >= mt8_rows) rc = launch_rb_gemm_t<false, 8>(a, st);
+    else if (mt == 6 && a.M >= mt8_rows) rc = launch_rb_gemm_t<false, 6>(a, st);
+    else rc = launch_rb_gemm_t<false, 4>(a, st);
+    if (rc == BOFI_OK) g_gemm_flops += 2.0 * a.M * 512.0 * a.N;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Time the row-block sublayer kernels alone on the chip (in-graph time per launch, buffers rotated through the Infinity Cache).
-python dev/exp/mb_rowblock.py [ffn|attn]"""
-import math, sys
+python dev/exp/mb_rowblock.py [ffn|attn|gemm|train]   (BOFI_RB_FFN_V / BOFI_RB_FFN_BPW / BOFI_RB_GEMM_BPW select the kernel forms)"""
+import math, os, sys
 import torch
 sys.path.insert(0, ".")
 from boficap_amd import hip as H
@@ -44,11 +44,64 @@ def ffn(M):
     w1p, w2p = pack(w1), pack(w2)
     c1, cs1, b2 = torch.randn(dff, device=dev), w1.float().sum(1), torch.randn(d, device=dev)
 
+    import os
+    extra = os.environ.get("MB_EXTRA", "0") == "1"                  # the optional bf16 copy + partial sums (the engine writes neither at 320 images)
+
     def run(i):
-        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, H.ptr(ybs[i]),
-                                       H.ptr(sts[i]), M, dff, H.stream_ptr()))
+        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, H.ptr(ybs[i]) if extra else None,
+                                       H.ptr(sts[i]) if extra else None, M, dff, H.stream_ptr()))
     t = timed(run, rot=rot)
     print(f"ffn_block M {M:6d}: {t:7.2f} us  {4.0 * M * d * dff / t * 1e-6:7.1f} TFLOP/s  weight stream {4 * 1048576 / t * 1e-3:6.1f} GB/s per workgroup", flush=True)
+
+
+def ffn_streams(M, nstr=4, nl=12):
+    """nstr streams each replay a graph of nl feed-forward launches (two weight sets alternating, own activations) at once, as decodes in
+    flight do: aggregate time per launch."""
+    xs = [[torch.randn(M, d, device=dev) for _ in range(2)] for _ in range(nstr)]
+    ws = []
+    for _ in range(2):
+        w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+        ws.append((pack(w1), torch.randn(dff, device=dev), w1.float().sum(1), pack(w2), torch.randn(d, device=dev)))
+    streams = [torch.cuda.Stream() for _ in range(nstr)]
+    graphs = []
+    for si, st in enumerate(streams):
+        def run(j):
+            w1p, c1, cs1, w2p, b2 = ws[j % 2]
+            x = xs[si][j % 2]
+            H.check(H.lib().bofi_ffn_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, None, None, M, dff, H.stream_ptr()))
+        with torch.cuda.stream(st):
+            run(0); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for j in range(nl):
+                    run(j)
+            graphs.append(g)
+    def replay_all(n):
+        for _ in range(n):
+            for st, g in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    g.replay()
+    replay_all(2); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for st in streams:
+        st.wait_event(e0)
+    replay_all(10)
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e3 / 10 / nl / nstr
+    clk = ""
+    if os.environ.get("BOFI_RB_DBG") == "16":                      # the stamped kernel: shader clock of workgroup 0's last launch (s_memtime against the 100 MHz s_memrealtime)
+        import ctypes as C
+        buf = (C.c_ulonglong * 256)()
+        H.lib().bofi_rb_stamps.restype = C.c_int; H.lib().bofi_rb_stamps.argtypes = [C.c_void_p]
+        H.check(H.lib().bofi_rb_stamps(buf))
+        for base in (0, 128):
+            if buf[base + 126]:
+                clk += f"  [{'producer' if base == 0 else 'consumer'} wavefront: {(buf[base + 127] - buf[base]) / (buf[base + 126] * 10.0):.3f} GHz over {buf[base + 126] / 100.0:.1f} us]"
+    print(f"ffn_block M {M:6d} x {nstr} streams: {t:7.2f} us per launch aggregate  {4.0 * M * d * dff / t * 1e-6:7.1f} TFLOP/s{clk}", flush=True)
 
 
 def attn(B, Lq, Lk, cross):
@@ -93,34 +146,6 @@ def gemm(M, N, f32out):
     print(f"linear_block M {M:6d} N {N:5d} {'f32 ' if f32out else 'bf16'}: {t:7.2f} us  {2.0 * M * d * N / t * 1e-6:7.1f} TFLOP/s", flush=True)
 
 
-def encoder(B, R=36, nlayers=6):
-    """rb_encoder_kernel: the whole encoder stack as one launch (random weights, timing only)."""
-    import ctypes as C
-    rot = 4
-    xs = [torch.randn(B * R, d, device=dev) for _ in range(rot)]
-    ys = [torch.empty(B * R, d, device=dev) for _ in range(rot)]
-    keep, arrs = [], {k: [] for k in ("wqkv", "cqkv", "csqkv", "wo", "bo", "w1", "c1", "cs1", "w2", "b2")}
-    for _ in range(nlayers):
-        wqkv = (torch.randn(3 * d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
-        wo = (torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
-        w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
-        w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
-        t = {"wqkv": pack(wqkv), "cqkv": torch.randn(3 * d, device=dev) * 0.1, "csqkv": wqkv.float().sum(1), "wo": pack(wo), "bo": torch.randn(d, device=dev) * 0.1,
-             "w1": pack(w1), "c1": torch.randn(dff, device=dev) * 0.1, "cs1": w1.float().sum(1), "w2": pack(w2), "b2": torch.randn(d, device=dev) * 0.1}
-        keep.append(t)
-        for k, v in t.items():
-            arrs[k].append(H.ptr(v))
-    ptrs = {k: (C.c_void_p * nlayers)(*v) for k, v in arrs.items()}
-    klen = torch.full((B,), R, dtype=torch.int32, device=dev)
-
-    def run(i):
-        H.check(H.lib().bofi_encoder_block(H.ptr(xs[i]), H.ptr(ys[i]), H.ptr(klen), B, R, nlayers, ptrs["wqkv"], ptrs["cqkv"], ptrs["csqkv"], ptrs["wo"], ptrs["bo"],
-                                           ptrs["w1"], ptrs["c1"], ptrs["cs1"], ptrs["w2"], ptrs["b2"], dff, H.stream_ptr()))
-    t = timed(run, iters=20, rot=rot)
-    fl = nlayers * 2.0 * B * R * d * (3 * d + d + 2 * dff)
-    print(f"encoder_block B {B:4d} R {R} layers {nlayers}: {t:8.2f} us  {fl / t * 1e-6:7.1f} TFLOP/s  weight stream {nlayers * 6.29e6 / t * 1e-3:6.1f} GB/s per workgroup", flush=True)
-
-
 def train_shapes():
     """The XE step's forward / dX shapes (K = 512): the tiled GEMM (bf16 operand in, float32 out) against the row-block projection
     kernel (float32 stream in with the LayerNorm fold, float32 / bf16 out)."""
@@ -140,43 +165,17 @@ def train_shapes():
             print(f"M {M:5d} N {N:5d} K 512: tiled bf16->f32 {t_tiled:6.2f} us | row-block f32->f32 {t_rb32:6.2f} us | row-block f32->bf16 {t_rb16:6.2f} us", flush=True)
 
 
-def ffn_proj(M, N=1536):
-    """The feed-forward sublayer + the next layer's q|k|v: two launches against the fused one."""
-    rot = 4
-    xs = [torch.randn(M, d, device=dev) for _ in range(rot)]
-    ys = [torch.empty(M, d, device=dev) for _ in range(rot)]
-    qs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(rot)]
-    w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
-    w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
-    wq = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
-    w1p, w2p, wqp = pack(w1), pack(w2), pack(wq)
-    c1, cs1, b2, cq, csq = torch.randn(dff, device=dev), w1.float().sum(1), torch.randn(d, device=dev), torch.randn(N, device=dev), wq.float().sum(1)
-
-    def two(i):
-        H.check(H.lib().bofi_ffn_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d, None, None, M, dff, H.stream_ptr()))
-        H.check(H.lib().bofi_linear_block(H.ptr(ys[i]), d, H.ptr(wqp), H.ptr(cq), H.ptr(csq), H.ptr(qs[i]), N, 0, M, N, 0, H.stream_ptr()))
-
-    def one(i):
-        H.check(H.lib().bofi_ffn_proj_block(H.ptr(xs[i]), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(ys[i]), d,
-                                            H.ptr(wqp), H.ptr(cq), H.ptr(csq), H.ptr(qs[i]), N, N, M, dff, H.stream_ptr()))
-    t2, t1 = timed(two, rot=rot), timed(one, rot=rot)
-    print(f"ffn + projection N {N} M {M:6d}: two launches {t2:7.2f} us, one launch {t1:7.2f} us", flush=True)
-
-
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
     if what == "ffn":
         for M in (11520, 6400, 2304, 1280, 64):
             ffn(M)
-    elif what == "ffnp":
-        for M in (11520, 6400, 2304, 64):
-            ffn_proj(M)
+    elif what == "ffn4":
+        for M in (11520, 6400):
+            for n in (1, 2, 4):
+                ffn_streams(M, n)
     elif what == "train":
         train_shapes()
-    elif what == "enc":
-        for B in (320, 512, 64, 2):
-            encoder(B)
-        encoder(320, nlayers=1)
     elif what == "gemm":
         for M, N, f in ((11520, 1536, False), (6400, 1536, False), (6400, 512, False), (11520, 7168, False), (6400, 9600, True), (64, 1536, False), (64, 9600, True)):
             gemm(M, N, f)

@@ -1,7 +1,10 @@
-"""In-kernel timeline of the feed-forward sublayer kernel rb_ffn2_kernel (workgroup 0; s_memtime stamps, BOFI_RB_DBG=16):
-    python dev/exp/rb_ffn_stamps.py [M ...]
+"""In-kernel timeline of the persistent feed-forward sublayer kernel rb_ffn3_kernel (workgroup 0; s_memtime stamps, BOFI_RB_DBG=16):
+    BOFI_RB_FFN_BPW=3 python dev/exp/rb_ffn_stamps.py [M ...]
 Per hidden chunk (256 columns) a SIMD runs one producer wavefront (64 rows x 64 hidden columns x K 512 = 256 MFMA 16x16x32) and one
-consumer wavefront (64 rows x 128 output columns x K 256 = 256 MFMA): 512 MFMA x 16 cycles = 8 192 cycles if the pipe never waits."""
+consumer wavefront (64 rows x 128 output columns x K 256 = 256 MFMA): 512 MFMA x 16 cycles = 8 192 cycles if the pipe never waits;
+a 64-row block is 8 chunks = 65.5 k cycles of MFMA issue per SIMD.
+Stamps: producer wavefront 0: entry, then per block [staging starts, block staged, (segment done, chunk handed over) x 8];
+consumer wavefront 4: entry, then per block [(chunk arrived, chunk consumed) x 8, block closed]."""
 import ctypes as C, math, os, sys
 import torch
 sys.path.insert(0, ".")
@@ -31,11 +34,25 @@ for M in [int(v) for v in sys.argv[1:]] or [64, 11520]:
     us = e0.elapsed_time(e1) * 50.0
     buf = (C.c_ulonglong * 256)()
     H.check(L.bofi_rb_stamps(buf))
-    t0 = min(buf[(8 + w) * 16] for w in range(8))
-    t1 = max(buf[(8 + w) * 16 + 1] for w in range(8))
-    print(f"M {M} ({(M + 63) // 64} workgroups): {us:.1f} us per launch (events, back to back); workgroup 0 lives {t1 - t0} s_memtime ticks")
-    print("  cycles after the first wavefront's entry; producer wavefront 0 (segment done | chunk handed over), consumer wavefront 4 (chunk arrived | chunk consumed)")
-    for c in range(8):
-        print(f"  chunk {c}: producer {buf[0 * 16 + 2 * c] - t0:7d} {buf[0 * 16 + 2 * c + 1] - t0:7d}   consumer {buf[4 * 16 + 2 * c] - t0:7d} {buf[4 * 16 + 2 * c + 1] - t0:7d}")
-    per = (buf[4 * 16 + 15] - buf[4 * 16 + 1]) / 7.0
-    print(f"  steady state: {per:.0f} ticks per chunk at the consumer against 8 192 MFMA cycles per SIMD per chunk")
+    def row(base):
+        out = []
+        for i in range(128):
+            if buf[base + i] == 0:
+                break
+            out.append(buf[base + i])
+        return out
+    P, Cn = row(0), row(128)
+    t0 = min(P[0], Cn[0])
+    print(f"M {M} ({(M + 63) // 64} row blocks, BOFI_RB_FFN_BPW={os.environ.get('BOFI_RB_FFN_BPW', 'default')}): {us:.1f} us per launch (events, back to back); "
+          f"workgroup 0: {max(P[-1], Cn[-1]) - t0} ticks from entry to its last stamp")
+    nb = (len(P) - 1) // 18
+    for j in range(nb):
+        p = P[1 + 18 * j: 1 + 18 * (j + 1)]
+        c = Cn[1 + 17 * j: 1 + 17 * (j + 1)]
+        print(f"  block {j}: staging {p[0] - t0:7d} .. {p[1] - t0:7d}   closed by the consumer at {c[16] - t0:7d}" if len(c) == 17 else f"  block {j}: (stamps ran out)")
+        for k in range(8):
+            if len(c) == 17:
+                print(f"    chunk {k}: producer {p[2 + 2 * k] - t0:7d} {p[3 + 2 * k] - t0:7d}   consumer {c[2 * k] - t0:7d} {c[2 * k + 1] - t0:7d}")
+    if nb >= 2 and len(Cn) >= 1 + 17 * nb:
+        per = (Cn[17 * nb] - Cn[17]) / (nb - 1)
+        print(f"  block to block (closed -> closed): {per:.0f} ticks against 65 536 MFMA cycles per SIMD per block")

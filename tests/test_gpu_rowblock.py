@@ -100,6 +100,41 @@ def test_ffn_block_vs_reference_sublayer(H, M, dff):
     assert torch.equal(xc.cpu(), y.cpu())
 
 
+@pytest.mark.parametrize("M", [700, 2304])
+def test_ffn_block_rows_do_not_depend_on_the_grid(H, M, monkeypatch):
+    """rb_ffn5_kernel walks row blocks blockIdx.x, + gridDim.x, ...: whatever the number of blocks per workgroup (BOFI_RB_FFN_BPW) every row is
+    the same sum -- bit for bit across grids (a ragged last block, the next block's residual rows prefetched into the accumulators, in place)."""
+    d, dff = 512, 2048
+    g = _rng(M)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w1, b1 = torch.randn(dff, d, generator=g) / math.sqrt(d), torch.randn(dff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, dff, generator=g) / math.sqrt(dff), torch.randn(d, generator=g) * 0.1
+    w1f, c1, cs1 = _fold(w1, b1, gain, bln)
+    w1p, w2p = pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda())
+    c1c, cs1c, b2c = c1.cuda(), cs1.cuda(), b2.cuda()
+    outs = []
+    try:
+        for version in (5,):
+            monkeypatch.setenv("BOFI_RB_FFN_V", str(version))
+            for bpw in (1, 2, 3, 5, 64):
+                monkeypatch.setenv("BOFI_RB_FFN_BPW", str(bpw))
+                H.lib().bofi_reload_env()
+                xc = x.cuda()
+                H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(xc), d, None, None, M, dff, H.stream_ptr()))
+                torch.cuda.synchronize()
+                outs.append(xc.cpu())
+    finally:
+        monkeypatch.delenv("BOFI_RB_FFN_BPW")
+        monkeypatch.delenv("BOFI_RB_FFN_V")
+        H.lib().bofi_reload_env()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+    w1_eff = w1f.double() / gain.double()[None, :]
+    ref = x.double() + torch.relu(_layer_norm64(x, gain, bln) @ w1_eff.T + b1.double()) @ _bf(w2).double().T + b2.double()
+    assert (outs[0].double() - ref).abs().max() < 2e-2 * max(1.0, float((ref - x.double()).abs().max()))
+
+
 def test_ffn_block_nan_row_stays_in_its_row(H):
     """A NaN row (quirk Q1's fully masked image) must not leak into the other rows of its block."""
     M, d, dff = 64, 512, 2048
@@ -225,3 +260,38 @@ def test_linear_block_vs_reference_projection(H, M, N, f32out, relu):
     assert (got[:, N:] == 7.0).all()
     tol = 2e-2 if f32out else 6e-2                                        # bf16 operands; a bf16 result adds its own rounding at |y| ~ 4
     assert (got[:, :N] - ref).abs().max() < tol, (got[:, :N] - ref).abs().max()
+
+
+@pytest.mark.parametrize("M,N,relu", [(700, 1536, 0), (96, 64, 1), (6400, 512, 0), (333, 7168, 0)])
+def test_linear_block_rows_per_block_agree(H, M, N, relu, monkeypatch):
+    """rb_gemm_kernel<MT>: 64-, 96- and 128-row blocks (BOFI_RB_GEMM_MT = 4 / 6 / 8) give every output element the same sums -- bit for bit
+    (ragged last blocks, a wavefront staging fewer than eight rows in its last pass)."""
+    d = 512
+    g = _rng(M * 3 + N)
+    x = torch.randn(M, d, generator=g) * 2.0 - 0.3
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w, b = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g) * 0.1
+    wf, c, cs = _fold(w, b, gain, bln)
+    xc, wp, cc, csc = x.cuda(), pack_frag(H, wf.to(torch.bfloat16).cuda()), c.cuda(), cs.cuda()
+    outs = []
+    monkeypatch.setenv("BOFI_RB_GEMM_MT8_ROWS", "1")
+    try:
+        for mt in (4, 6, 8):
+            monkeypatch.setenv("BOFI_RB_GEMM_MT", str(mt))
+            H.lib().bofi_reload_env()
+            y = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+            H.check(H.lib().bofi_linear_block(H.ptr(xc), d, H.ptr(wp), H.ptr(cc), H.ptr(csc), H.ptr(y), N + 64, 0, M, N, relu, H.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append(y.cpu())
+    finally:
+        monkeypatch.delenv("BOFI_RB_GEMM_MT")
+        monkeypatch.delenv("BOFI_RB_GEMM_MT8_ROWS")
+        H.lib().bofi_reload_env()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16))
+    w_eff = wf.double() / gain.double()[None, :]
+    ref = _layer_norm64(x, gain, bln) @ w_eff.T + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    assert (outs[0][:, N:] == 7.0).all()
+    assert (outs[0][:, :N].double() - ref).abs().max() < 6e-2
