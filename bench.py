@@ -117,26 +117,20 @@ def cpu_baseline(cfg, sd, batch, seed, budget_s=20.0):
 
 
 def gemm_rooflines(dtype, dev, batches=1):
-    """MFMA roofline of the GEMM kernel on the path's largest shapes: 100 dependent launches of one shape captured in
-    a graph, HIP events around 20 replays on the launch stream (in-graph time per launch, launch boundary included)."""
+    """MFMA roofline of the GEMM-shaped kernels THE ENGINE RUNS at the measured launch size, on the path's largest shapes: from 4 096 rows
+    on (bf16) the row-block sublayer kernels -- bofi_linear_block (LayerNorm-folded projection reading the float32 stream) and
+    bofi_ffn_block (the whole feed-forward sublayer) --, below that the tiled / persistent GEMM (bofi_linear).  100 dependent launches
+    of one shape captured in a graph, HIP events around 20 replays on the launch stream (in-graph time per launch, launch boundary
+    included)."""
     from boficap_amd import hip as H
     lib = H.lib()
     out = []
-    for name, M, N, K in (("cross K|V of all layers (kv_all)", 2304 * batches, 7168, 512), ("encoder FFN w_1", 2304 * batches, 2048, 512),
-                          ("encoder FFN w_2", 2304 * batches, 512, 2048), ("generator.proj", 1280 * batches, 9491, 512)):
-        n_alg = N
-        if N % 128 and dtype == torch.bfloat16:                # as the bf16 engine runs it: weight rows zero-padded to whole 128-column tiles
-            N = (N + 127) // 128 * 128
-            name += f" (weight rows zero-padded {n_alg} -> {N}, as the engine runs it)"
-        x = torch.randn(M, K, device=dev).to(dtype)
-        w = (torch.randn(N, K, device=dev) / K ** 0.5).to(dtype)
-        b = torch.zeros(N, device=dev)
-        y = torch.empty(M, N, device=dev, dtype=dtype)
+    peak = MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"]
+    rb_min = int(os.environ.get("BOFI_RB_MIN_ROWS", "4096"))
+
+    def timed(run):
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
-            def run():
-                H.check(lib.bofi_linear(H.ptr(x), H.dtype_code(x), K, H.ptr(w), H.dtype_code(w), H.ptr(b), None, N, H.ptr(y), H.dtype_code(y), N,
-                                        M, N, K, 0, None, 0, H.stream_ptr()))
             run(); torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
@@ -151,13 +145,54 @@ def gemm_rooflines(dtype, dev, batches=1):
                 g.replay()
             e1.record(st)
             torch.cuda.synchronize(dev)
-        us = e0.elapsed_time(e1) * 1e3 / 2000
-        tf = 2.0 * M * n_alg * K / us / 1e6                         # algorithmic FLOPs (the padding columns are not counted)
+        return e0.elapsed_time(e1) * 1e3 / 2000
+
+    def pack(w):
+        o = torch.empty(w.numel(), dtype=torch.bfloat16, device=dev)
+        H.check(lib.bofi_pack_frag(H.ptr(w), H.ptr(o), w.shape[0], w.shape[1], H.stream_ptr()))
+        return o
+
+    def entry(kernel, shape, us, flops):
+        tf = flops / us / 1e6
+        out.append({"kernel": kernel, "shape": shape, "us_per_launch": round(us, 2), "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)})
+
+    m_enc, m_fill = 2304 * batches, 1280 * batches
+    row_block = dtype == torch.bfloat16 and m_fill >= rb_min
+    if row_block:
+        d, dff = 512, 2048
+        for name, M, N, f32out in (("cross K|V of all layers (kv_all)", m_enc, 7168, False), ("encoder q|k|v", m_enc, 1536, False),
+                                   ("generator.proj (weight rows zero-padded 9491 -> 9600, float32 logits)", m_fill, 9600, True)):
+            x = torch.randn(M, d, device=dev)
+            w = (torch.randn(N, d, device=dev) / d ** 0.5).to(torch.bfloat16)
+            wp, c, cs = pack(w), torch.zeros(N, device=dev), w.float().sum(1)
+            y = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+            us = timed(lambda: H.check(lib.bofi_linear_block(H.ptr(x), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(y), N, 1 if f32out else 0, M, N, 0, H.stream_ptr())))
+            n_alg = 9491 if f32out else N
+            entry("rb_gemm_kernel (row-block projection, LayerNorm folded, float32 stream in)", f"{name}: M={M} N={n_alg} K=512", us, 2.0 * M * n_alg * d)
+        for name, M in (("encoder feed-forward sublayer (w_1, ReLU, w_2, residual)", m_enc), ("filling-pass feed-forward sublayer", m_fill)):
+            x = torch.randn(M, d, device=dev)
+            w1 = (torch.randn(dff, d, device=dev) / d ** 0.5).to(torch.bfloat16)
+            w2 = (torch.randn(d, dff, device=dev) / dff ** 0.5).to(torch.bfloat16)
+            w1p, w2p, c1, cs1, b2 = pack(w1), pack(w2), torch.zeros(dff, device=dev), w1.float().sum(1), torch.zeros(d, device=dev)
+            us = timed(lambda: H.check(lib.bofi_ffn_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, None, None, M, dff,
+                                                           H.stream_ptr())))
+            entry("rb_ffn5_kernel (row-block feed-forward sublayer, 80-row blocks)", f"{name}: M={M} d=512 d_ff=2048", us, 4.0 * M * d * dff)
+        return out
+    for name, M, N, K in (("cross K|V of all layers (kv_all)", m_enc, 7168, 512), ("encoder FFN w_1", m_enc, 2048, 512),
+                          ("encoder FFN w_2", m_enc, 512, 2048), ("generator.proj", m_fill, 9491, 512)):
+        n_alg = N
+        if N % 128 and dtype == torch.bfloat16:                # as the bf16 engine runs it: weight rows zero-padded to whole 128-column tiles
+            N = (N + 127) // 128 * 128
+            name += f" (weight rows zero-padded {n_alg} -> {N}, as the engine runs it)"
+        x = torch.randn(M, K, device=dev).to(dtype)
+        w = (torch.randn(N, K, device=dev) / K ** 0.5).to(dtype)
+        b = torch.zeros(N, device=dev)
+        y = torch.empty(M, N, device=dev, dtype=dtype)
+        us = timed(lambda: H.check(lib.bofi_linear(H.ptr(x), H.dtype_code(x), K, H.ptr(w), H.dtype_code(w), H.ptr(b), None, N, H.ptr(y), H.dtype_code(y), N,
+                                                   M, N, K, 0, None, 0, H.stream_ptr())))
         pers = dtype == torch.bfloat16 and N % 128 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 128) >= 90 and os.environ.get("BOFI_GEMM_PERS", "1") != "0"
-        out.append({"kernel": "gemm_pers_kernel (persistent 256x128 tiles, loader wavefronts)" if pers else "gemm_glds_kernel (one 128x64 tile per workgroup)",
-                    "shape": f"{name}: M={M} N={n_alg} K={K}", "us_per_launch": round(us, 2),
-                    "achieved": round(tf, 1), "peak": MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_PEAK["bf16" if dtype == torch.bfloat16 else "f32"], 4)})
+        entry("gemm_pers_kernel (persistent 256x128 tiles, loader wavefronts)" if pers else "gemm_glds_kernel (one 128x64 tile per workgroup)",
+              f"{name}: M={M} N={n_alg} K={K}", us, 2.0 * M * n_alg * K)
     return out
 
 
@@ -351,6 +386,16 @@ def run_xe_dp(args, ctx, log):
         batch["att_masks"] = None
         batch = tr.add_token_rows(batch, hb)
 
+        def agreed(what, fn):
+            """run a phase WITHOUT collectives on every rank, then agree on its outcome: one rank's exception must not leave the others in the next collective"""
+            err = None
+            try:
+                fn()
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
+            if dp.reduce_scalar(1.0 if err else 0.0, "max", device=dev) > 0:
+                raise RuntimeError(f"{what} failed on rank {rank}: {err}" if err else f"{what} failed on another rank")
+
         def timed(fn, steps=10, warm=3):
             for _ in range(warm):
                 fn()
@@ -364,6 +409,7 @@ def run_xe_dp(args, ctx, log):
         def local_step():
             tr.forward_backward(batch)
             tr.optimizer_step()
+        agreed("a local step (forward + backward + optimiser, no exchange)", local_step)      # graph capture and kernels work on every rank before any rank enters a collective
         dp_ms = timed(lambda: tr.step(batch))
         local_ms = timed(local_step)
         key = "fp32_ring_all_reduce" if wire is None else "bf16_mesh_direct"
@@ -666,24 +712,34 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             engines[k].decode_naic(feats, graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
 
     launches = args.steps // C
+    # untimed warm-up: at least --warmup steps, rounded up to whole rounds over the streams (EVERY stream replays its graph before the clock starts)
+    warm_launches = (warm_launches + len(engines) - 1) // len(engines) * len(engines)
     for i in range(warm_launches):
         step(i)
-    _barrier(world)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
-    t0 = time.perf_counter()
-    for st, e in zip(streams, ev0):
-        e.record(st)
-    for i in range(launches):
-        step(i)
-    for st, e in zip(streams, ev1):
-        e.record(st)
-    _barrier(world)
-    elapsed = time.perf_counter() - t0
-    # HIP events on the launch streams: with one stream this is the device time per decode; with several
-    # in flight it is the longest stream's span divided by all the decodes (steady-state time per decode)
-    dev_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / launches
-    elapsed = dp.reduce_scalar(elapsed, "max", device=dev)
+    # the timed region = exactly --steps steps between a barrier + synchronisation on both sides.  A short region (the driver's 20 steps are 4
+    # launches = 6 ms) is one sample of a noisy quantity: it is then measured `regions` times back to back, each bracketed the same way, and
+    # the MEDIAN region is reported (config.timed_regions / region_ms say so)
+    regions = 5 if launches <= 4 * len(engines) else 1
+    spans = []
+    for rep in range(regions):
+        _barrier(world)
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        t0 = time.perf_counter()
+        for st, e in zip(streams, ev0):
+            e.record(st)
+        for i in range(launches):
+            step(i)
+        for st, e in zip(streams, ev1):
+            e.record(st)
+        _barrier(world)
+        el = dp.reduce_scalar(time.perf_counter() - t0, "max", device=dev)
+        # HIP events on the launch streams: with one stream this is the device time per decode; with several
+        # in flight it is the longest stream's span divided by all the decodes (steady-state time per decode)
+        spans.append((el, max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / launches))
+    spans.sort()
+    elapsed, dev_ms = spans[len(spans) // 2]
+    region_ms = [round(e * 1e3, 3) for e, _ in spans]
     budget_ok = budget_held("timed") and budget_ok
 
     # for the record: the same K steps strictly one at a time (latency view of the same workload), HIP events on the stream
@@ -776,6 +832,9 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                    "mean_tokens_per_image": round(ntok, 2),
                    "vocab": cfg.tgt_vocab, "seq_logprob_materialised": not args.ids_only, "hip_graph": graph,
                    "decodes_in_flight": len(engines), "features_per_launch_in_flight": "own tensors, two per stream, alternated", "batches_per_launch": C,
+                   "timed_regions": regions, "region_ms": region_ms, "warmup_steps_run": warm_launches * C,
+                   "timing": (f"the {args.steps}-step region ({launches} launches) timed {regions} times back to back, each between a barrier + synchronisation; value / "
+                              "ms_per_step are the MEDIAN region's" if regions > 1 else f"one region of {args.steps} steps ({launches} launches)"),
                    "images_per_launch": C * args.batch, "refine_rounds": args.refine,
                    "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                    "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
@@ -904,17 +963,38 @@ def main():
                                      "leg after all of them); config 5's 'autoregressive fallback' has no counterpart: a UIC checkpoint has no AR decode path in the reference "
                                      "(TransformerModel.py:1791-1804 needs EncoderDecoder.decode, :1287-1310)")
         if world > 1 and plain and not args.no_secondary:
-            # the decode shards with no collective: the scaling run exercises RCCL through this secondary (the XE step's gradient exchange)
+            # the decode shards with no collective: the scaling run exercises RCCL through this secondary (the XE step's gradient exchange).
+            # Never at the cost of the headline line, and never silently: the line says how many ranks the collective backend saw
+            # (config.rccl_ranks / dist_backend) and carries config.xe_dp_error when the exchange failed.  A rank that fails INSIDE a step leaves the
+            # others in a collective -- a hang, not an exception -- so every rank arms a watchdog: past its limit rank 0 prints the headline line
+            # with the error and every process leaves.
+            import threading
+            import torch.distributed as dist
+            if rank == 0 and res is not None:
+                res["config"].update(rccl_ranks=dist.get_world_size(), dist_backend=dist.get_backend())
+            limit = float(os.environ.get("BOFI_BENCH_DP_LIMIT_S", "420"))
+
+            def give_up():
+                if rank == 0 and res is not None:
+                    res["config"]["xe_dp_error"] = f"no result within {limit:.0f} s: a rank hung or failed inside the exchange"
+                    print(json.dumps(res), flush=True)
+                os._exit(0)
+            dog = threading.Timer(limit, give_up)
+            dog.daemon = True
+            dog.start()
             try:
                 dp_res = run_xe_dp(args, ctx, log)
                 if rank == 0 and res is not None:
                     res.setdefault("secondary", {})["xe_config3_dp"] = dp_res
                     res["config"].update(xe_dp_step_ms=dp_res["fp32_ring_all_reduce"]["step_ms"], xe_dp_exposed_collective_ms=dp_res["fp32_ring_all_reduce"]["exposed_collective_ms"],
-                                         xe_dp_bf16_wire_step_ms=dp_res["bf16_mesh_direct"]["step_ms"])
-            except Exception as e:                          # never at the cost of the headline line
+                                         xe_dp_bf16_wire_step_ms=dp_res["bf16_mesh_direct"]["step_ms"], xe_dp_img_s=dp_res["fp32_ring_all_reduce"]["images_per_sec"])
+            except Exception as e:
                 log(f"xe dp secondary failed: {type(e).__name__}: {e}")
                 if rank == 0 and res is not None:
                     res.setdefault("secondary", {})["xe_config3_dp"] = {"error": f"{type(e).__name__}: {e}"}
+                    res["config"]["xe_dp_error"] = f"{type(e).__name__}: {e}"
+            finally:
+                dog.cancel()
     _run_cpu_legs(log)                                           # (those not run yet: the headline's, or a single mode's)
     if rank == 0 and res is not None:
         if os.environ.get("BOFI_BENCH_REHEARSAL") == "1":

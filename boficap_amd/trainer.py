@@ -100,10 +100,16 @@ class FlatBucket:
     def encoder_end(self) -> int:
         """Offset behind the last parameter of att_embed + encoder (they open the bucket): gradients in [encoder_end, live_numel) are final
         once the backward has passed the encoder's output."""
+        enc = ("att_embed.", "model.encoder.")
         k = 0
-        while k < len(self.names) and self.names[k].startswith(("att_embed.", "model.encoder.")):
+        while k < len(self.names) and self.names[k].startswith(enc):
             k += 1
-        return self.offsets[k] if k < len(self.offsets) else self.numel
+        cut = self.offsets[k] if k < len(self.offsets) else self.numel
+        # the two-stage backward sends [cut, live_numel) while the encoder's backward still runs: an encoder parameter behind the cut would be
+        # exchanged before its gradient exists -- silently.  The bucket order is a property of this build (weights.schema); hold it here.
+        if any(n.startswith(enc) for n in self.names[k:]) or not 0 < cut < self.live_numel:
+            raise RuntimeError("gradient bucket: att_embed / encoder parameters must open it as one contiguous run (two-stage exchange)")
+        return cut
 
     def exchange_range(self, a: int, b: int, group=None, chunks: int = 2):
         """Start the float32 sum all-reduce of gradient elements [a, b) as ``chunks`` asynchronous collectives (last part first);
@@ -521,8 +527,21 @@ class XETrainer:
         elif dense == "drop_worst":
             per_cap, _ = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"], reduction="none",
                                           self_dis=self.self_dis)
-            keep = int(per_cap.shape[0] * (1 - self.drop_worst_rate))
-            loss, parts = torch.topk(per_cap, k=keep, largest=False)[0].mean(), []
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            if world > 1:
+                # the reference gathers every replica's per-caption losses and takes ONE top-k over the whole batch (tools/train.py:216-220): the k-th
+                # smallest loss of all ranks is the threshold here, each rank keeps its captions up to it, and the loss is scaled so that the
+                # rank-averaged gradient is that of mean(global top-k)
+                allc = [torch.empty_like(per_cap) for _ in range(world)]
+                dist.all_gather(allc, per_cap.detach())
+                allc = torch.cat(allc)
+                keep = int(allc.numel() * (1 - self.drop_worst_rate))
+                thr = torch.topk(allc, k=keep, largest=False)[0][-1]
+                loss, parts = (per_cap * (per_cap.detach() <= thr)).sum() * (world / keep), []
+            else:
+                keep = int(per_cap.shape[0] * (1 - self.drop_worst_rate))
+                loss, parts = torch.topk(per_cap, k=keep, largest=False)[0].mean(), []
         else:
             loss, parts = xe.criterion_uic(outs, batch["phrase_num"], batch["phrase_length"], batch["phrase_syn"], batch["labels"],
                                            self_dis=self.self_dis)

@@ -43,7 +43,7 @@ def _shard(cfg, rank, step):
     return hb, att
 
 
-def _run_steps(cfg, model, graph, ranks):
+def _run_steps(cfg, model, graph, ranks, drop_worst=False):
     from boficap_amd.trainer import XETrainer
     tr = XETrainer(model, graph=graph)
     for step in range(STEPS):
@@ -52,12 +52,12 @@ def _run_steps(cfg, model, graph, ranks):
         batch = {k: torch.from_numpy(v).cuda() for k, v in hb.items()}
         batch["att_feats"] = torch.from_numpy(np.concatenate([p[1] for p in parts])).cuda()
         batch["max_phrase_num"] = int(hb["phrase_num"].max())
-        tr.step(tr.add_token_rows(batch, hb))
+        tr.step(tr.add_token_rows(batch, hb), drop_worst=drop_worst)
     torch.cuda.synchronize()
     return tr.bucket.flat[:tr.bucket.live_numel].detach().cpu()
 
 
-def _worker(rank, world, port, ret, graph, wire, overlap=True, dtype="float32"):
+def _worker(rank, world, port, ret, graph, wire, overlap=True, dtype="float32", drop_worst=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -69,7 +69,7 @@ def _worker(rank, world, port, ret, graph, wire, overlap=True, dtype="float32"):
     if wire:
         model.opt.bofi_dp_wire = wire
     model.opt.bofi_dp_overlap = overlap
-    flat = _run_steps(cfg, model, graph, [rank])
+    flat = _run_steps(cfg, model, graph, [rank], drop_worst)
     ret.put((rank, flat.numpy()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -139,3 +139,27 @@ def test_exchange_started_inside_backward_equals_the_plain_step(graph, dtype):
     init = b.flat[:b.live_numel].detach().cpu().numpy().copy()
     del b, model
     _assert_same_training(_two_ranks(graph, True, dtype), _two_ranks(graph, False, dtype), init)
+
+
+def test_drop_worst_under_data_parallel_is_the_top_k_of_the_whole_batch():
+    """tools/train.py:216-220 gathers the replicas' per-caption losses and takes ONE top-k over the whole batch: two ranks (the threshold
+    from the all-gathered losses, each rank's kept captions, the loss scaled for the rank average) against one process on the concatenated
+    batch -- 12 captions, the 9 best kept, whichever rank they sit on."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, False, None, True, "float32", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0], got[1]), "the ranks' parameters diverged"
+    cfg, model = _setup(torch.float32)
+    from boficap_amd.trainer import XETrainer
+    before = XETrainer(model).bucket
+    init = before.flat[:before.live_numel].detach().cpu().numpy().copy()
+    cfg, model = _setup(torch.float32)
+    one = _run_steps(cfg, model, False, [0, 1], drop_worst=True).numpy()
+    _assert_same_training(got[0], one, init)
