@@ -823,36 +823,65 @@ __global__ __launch_bounds__(1024) void rb_attn_kernel(RbAttnArgs a) {
     __syncthreads();
     RB_STAMP(a.dbg, wave, lane, 4);
 
-    // ---- output projection over the block
+    // ---- output projection over the block.  The accumulators START from the residual rows (loaded in the accumulator layout, 16 rows x 64 bytes
+    // per instruction; in flight during the projection's first steps), so closing the sublayer needs no loads
+    const int rows_live = (a.dbg & 4) ? 0 : nimg * a.Lq, m0 = img0 * a.Lq;
     f32x4 acc[2][MT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = mt * 16 + l15;
+        const float* xr = a.x + (size_t)(m0 + min(r, max(rows_live, 1) - 1)) * a.ldx + wave * 32 + g * 4;      // (dead rows: the block's last live row -- never stored)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 2; ++nt) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + nt * 16);
+            acc[nt][mt] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    }
     if (!(a.dbg & 2)) rb_segment<MT, 2>(wo, wo, wb, smem, rb_lane_base(l15, g), acc);
     RB_STAMP(a.dbg, wave, lane, 5);
 
-    // ---- close the sublayer: three passes of 32 / 32 / 16 rows through LDS (the block is dead once every wavefront has left the segment)
-    const RbOut out{a.x, a.ldx, a.y, a.ldy, a.yb, a.stats_out};
-    const int rows_live = (a.dbg & 4) ? 0 : nimg * a.Lq, m0 = img0 * a.Lq, cb = wave * 32 + g * 4;
-    const float4 b0 = *reinterpret_cast<const float4*>(bos + cb), b1 = *reinterpret_cast<const float4*>(bos + cb + 16);
+    // ---- close the sublayer: the block is dead once every wavefront has left the segment; each wavefront then turns its 32 columns of a row
+    // tile into 128-byte row pieces through 2.3 KB of LDS of its own (+ b_o) -- no further workgroup barrier (round 3: three passes of 32 rows
+    // through a shared staging area, residual loads and two barriers per pass: 13 k of the kernel's 54 k cycles)
     __syncthreads();
+    RB_STAMP(a.dbg, wave, lane, 6);
+    {
+        unsigned char* stg = smem + wave * (16 * 144);
+        const int er = lane >> 3, ec = lane & 7, cb = wave * 32 + ec * 4;
+        const float4 bb = *reinterpret_cast<const float4*>(bos + cb);
+        const size_t ystep = (size_t)8 * a.ldy;
+        float* yp = a.y + (size_t)(m0 + er) * a.ldy + cb;
+        int rr = er;
 #pragma unroll
-    for (int ps = 0; ps < 3; ++ps) {
-        float4 res[2][2];
-        rb_pass_residual<2>(out, ps * 32, m0, max(rows_live, 1), wave, lane, res);
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int tr = 0; tr < 2; ++tr) {
-            if (ps * 2 + tr >= MT) continue;
-            rb_stage_tile(smem, tr, l15, cb, acc[0][ps * 2 + tr < MT ? ps * 2 + tr : 0], b0);
-            rb_stage_tile(smem, tr, l15, cb + 16, acc[1][ps * 2 + tr < MT ? ps * 2 + tr : 0], b1);
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 t = acc[nt][mt];
+                *reinterpret_cast<float4*>(stg + l15 * 144 + nt * 64 + g * 16) = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float4 sv[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) sv[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + er) * 144 + ec * 16);
+#pragma unroll
+            for (int it = 0; it < 2; ++it, yp += ystep, rr += 8) {
+                const float4 o = make_float4(sv[it].x + bb.x, sv[it].y + bb.y, sv[it].z + bb.z, sv[it].w + bb.w);
+                const bool live = rr < rows_live;
+                const size_t m = live ? (size_t)(m0 + rr) : 0;
+                if (live) {
+                    *reinterpret_cast<float4*>(yp) = o;
+                    if (a.yb) *reinterpret_cast<uint2*>(a.yb + m * 512 + cb) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                }
+                if (a.stats_out) {                         // the wavefront's 32 columns are one statistics group: the 8 lanes of a row piece
+                    const float s1 = oct_sum((o.x + o.y) + (o.z + o.w)), s2 = oct_sum((o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                    if (live && !ec) reinterpret_cast<float2*>(a.stats_out + m * 32)[wave] = make_float2(s1, s2);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();               // (the next row tile rewrites the staging rows)
         }
-        __syncthreads();
-        RB_STAMP(a.dbg, wave, lane, 6 + 2 * ps);
-        rb_pass_store<2>(smem, out, ps * 32, ps == 2 ? 16 : 32, m0, rows_live, wave, lane, res);
-        if (ps < 2) __syncthreads();
-        RB_STAMP(a.dbg, wave, lane, 7 + 2 * ps);
     }
+    RB_STAMP(a.dbg, wave, lane, 7);
 }
 
 template <int NQT, int NKT, int NR>
