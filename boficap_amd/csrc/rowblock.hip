@@ -770,24 +770,29 @@ __device__ __forceinline__ void rb_attn_head(const RbAttnArgs& a, int img, int h
     __builtin_amdgcn_wave_barrier();                   // (the V tile is rewritten for the wavefront's next image only after these reads were issued)
 }
 
-// 16 wavefronts: wavefront (p, h) = wave >> 3, wave & 7 runs head h of images p, p + 2, ... of the workgroup's G (NR = G / 2 rounds);
-// the V tiles and the block share LDS (the block is written once every wavefront is through with its V tile); then every
-// wavefront takes 32 of the 512 output columns.
-template <int NQT, int NKT, int NR>
-__global__ __launch_bounds__(1024) void rb_attn_kernel(RbAttnArgs a) {
-    constexpr int MT = 5, G = 2 * NR, VR = NKT == 4 ? 48 : 32;
+// W wavefronts (16 or 8): wavefront (p, h) = wave >> 3, wave & 7 runs head h of images p, p + W/8, ... of the workgroup's G = NR * W/8 images (NR rounds);
+// the V tiles and the block share LDS (the block is written once every wavefront is through with its V tile); then every wavefront takes
+// 512 / W of the 512 output columns.  W = 8 (round 4): half the images per workgroup, at most half the LDS and registers of a CU -- TWO workgroups per
+// CU, so one's attention phase (vector work and load latency: 26 k of a 16-wavefront workgroup's 54 k cycles, the MFMA pipes idle) runs beside the
+// other's output projection; the price is the output projection's weights streamed once per G/2 images more.
+template <int NQT, int NKT, int NR, int W>
+__global__ __launch_bounds__(W * 64, 4) void rb_attn_kernel(RbAttnArgs a) {      // (4 wavefronts per SIMD: 128 registers, so that two 8-wavefront workgroups share a CU)
+    constexpr int IPR = W / 8, G = NR * IPR, VR = NKT == 4 ? 48 : 32;      // images per round / per workgroup
+    constexpr int LQM = NR == 2 ? 20 : (NQT == 2 ? 32 : 40);              // query rows per image this instantiation is launched for
+    constexpr int MT = (G * LQM + 15) / 16;
+    constexpr int NT = 32 / W;                                             // 16-column tiles of the output projection per wavefront: 2 (W = 16) or 4 (W = 8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* blk = smem;                                              // [80 rows][512] bf16, swizzled  (aliases the V tiles)
-    bf16_t* svs = reinterpret_cast<bf16_t*>(smem);                          // 16 x [VR][RB_VROW]
-    constexpr int BODY = (16 * VR * RB_VROW * 2 > MT * 16384) ? 16 * VR * RB_VROW * 2 : MT * 16384;
+    unsigned char* blk = smem;                                              // [MT*16 rows][512] bf16, swizzled  (aliases the V tiles)
+    bf16_t* svs = reinterpret_cast<bf16_t*>(smem);                          // W x [VR][RB_VROW]
+    constexpr int BODY = (W * VR * RB_VROW * 2 > MT * 16384) ? W * VR * RB_VROW * 2 : MT * 16384;
     float* bos = reinterpret_cast<float*>(smem + BODY);                     // [512]
     bf16_t* zrow = reinterpret_cast<bf16_t*>(smem + BODY + 2048);           // 256 B of zeros
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int img0 = blockIdx.x * G, nimg = min(G, a.B - img0);
     RB_STAMP(a.dbg, wave, lane, 0);
-    if (tid < 512) bos[tid] = a.bo[tid];
-    else if (tid < 576) reinterpret_cast<uint32_t*>(zrow)[tid - 512] = 0u;
+    for (int i = tid; i < 512; i += W * 64) bos[i] = a.bo[i];
+    if (tid < 64) reinterpret_cast<uint32_t*>(zrow)[tid] = 0u;
     __syncthreads();                                                        // (the zero row is read by every wavefront)
 
     RB_STAMP(a.dbg, wave, lane, 1);
@@ -797,20 +802,21 @@ __global__ __launch_bounds__(1024) void rb_attn_kernel(RbAttnArgs a) {
     f32x4 ot[NR][4][NQT];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        if (p + 2 * r < nimg && !(a.dbg & 1)) rb_attn_head<NQT, NKT>(a, img0 + p + 2 * r, h, lane, sv, zrow, ot[r]);
+        if (p + IPR * r < nimg && !(a.dbg & 1)) rb_attn_head<NQT, NKT>(a, img0 + p + IPR * r, h, lane, sv, zrow, ot[r]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the output projection's weights: columns wave*32 .. +31 = tiles (wave & 1)*2, +1 of chunk wave >> 1
-    const u32x4* wo = a.wop + (size_t)(wave >> 1) * (16 * 256) + (wave & 1) * 128 + lane;
+    // the output projection's weights: columns wave*(512/W) .. = tiles of chunk (wave * NT) / 4
+    const u32x4* wo = a.wop + (size_t)((wave * NT) >> 2) * (16 * 256) + ((wave * NT) & 3) * 64 + lane;
     RB_STAMP(a.dbg, wave, lane, 2);
-    bf16x8 wb[RB_PF * 2];
-    rb_prime<2>(wo, wb);
+    constexpr int OPF = NT == 4 ? 2 : RB_PF;                                // ring steps in flight: 32 registers either way (the kernel lives in 128)
+    bf16x8 wb[OPF * NT];
+    if constexpr (NT == 2) rb_prime<NT, OPF>(wo, wb);                       // (four tiles: primed once the heads' outputs have left the registers)
     __syncthreads();                                                        // every V tile is dead: the block may overwrite them
     RB_STAMP(a.dbg, wave, lane, 3);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        if (p + 2 * r >= nimg) continue;
-        const int row0 = (p + 2 * r) * a.Lq;
+        if (p + IPR * r >= nimg) continue;
+        const int row0 = (p + IPR * r) * a.Lq;
 #pragma unroll
         for (int qi = 0; qi < NQT; ++qi) {
             const int qrow = qi * 16 + l15;
@@ -821,82 +827,89 @@ __global__ __launch_bounds__(1024) void rb_attn_kernel(RbAttnArgs a) {
                     make_uint2(pack_bf16(ot[r][dt][qi][0], ot[r][dt][qi][1]), pack_bf16(ot[r][dt][qi][2], ot[r][dt][qi][3]));
         }
     }
+    if constexpr (NT == 4) rb_prime<NT, OPF>(wo, wb);
     __syncthreads();
     RB_STAMP(a.dbg, wave, lane, 4);
 
     // ---- output projection over the block.  The accumulators START from the residual rows (loaded in the accumulator layout, 16 rows x 64 bytes
     // per instruction; in flight during the projection's first steps), so closing the sublayer needs no loads
-    const int rows_live = (a.dbg & 4) ? 0 : nimg * a.Lq, m0 = img0 * a.Lq;
-    f32x4 acc[2][MT];
+    const int rows_live = (a.dbg & 4) ? 0 : nimg * a.Lq, m0 = img0 * a.Lq, c0 = wave * (512 / W);
+    f32x4 acc[NT][MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int r = mt * 16 + l15;
-        const float* xr = a.x + (size_t)(m0 + min(r, max(rows_live, 1) - 1)) * a.ldx + wave * 32 + g * 4;      // (dead rows: the block's last live row -- never stored)
+        const float* xr = a.x + (size_t)(m0 + min(r, max(rows_live, 1) - 1)) * a.ldx + c0 + g * 4;      // (dead rows: the block's last live row -- never stored)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const float4 v = *reinterpret_cast<const float4*>(xr + nt * 16);
             acc[nt][mt] = f32x4{v.x, v.y, v.z, v.w};
         }
     }
-    if (!(a.dbg & 2)) rb_segment<MT, 2>(wo, wo, wb, smem, rb_lane_base(l15, g), acc);
+    if (!(a.dbg & 2)) rb_segment<MT, NT, OPF>(wo, wo, wb, smem, rb_lane_base(l15, g), acc);
     RB_STAMP(a.dbg, wave, lane, 5);
 
-    // ---- close the sublayer: the block is dead once every wavefront has left the segment; each wavefront then turns its 32 columns of a row
-    // tile into 128-byte row pieces through 2.3 KB of LDS of its own (+ b_o) -- no further workgroup barrier (round 3: three passes of 32 rows
-    // through a shared staging area, residual loads and two barriers per pass: 13 k of the kernel's 54 k cycles)
+    // ---- close the sublayer: the block is dead once every wavefront has left the segment; each wavefront then turns 32 columns of a row
+    // tile at a time into 128-byte row pieces through 2.3 KB of LDS of its own (+ b_o) -- no further workgroup barrier (round 3: three passes of
+    // 32 rows through a shared staging area, residual loads and two barriers per pass: 13 k of the kernel's 54 k cycles)
     __syncthreads();
     RB_STAMP(a.dbg, wave, lane, 6);
     {
         unsigned char* stg = smem + wave * (16 * 144);
-        const int er = lane >> 3, ec = lane & 7, cb = wave * 32 + ec * 4;
-        const float4 bb = *reinterpret_cast<const float4*>(bos + cb);
+        const int er = lane >> 3, ec = lane & 7;
         const size_t ystep = (size_t)8 * a.ldy;
-        float* yp = a.y + (size_t)(m0 + er) * a.ldy + cb;
-        int rr = er;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int half = 0; half < NT / 2; ++half) {            // 32 columns (two tiles) at a time
+            const int cb = c0 + half * 32 + ec * 4;
+            const float4 bb = *reinterpret_cast<const float4*>(bos + cb);
+            float* yp = a.y + (size_t)(m0 + er) * a.ldy + cb;
+            int rr = er;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 t = acc[nt][mt];
-                *reinterpret_cast<float4*>(stg + l15 * 144 + nt * 64 + g * 16) = make_float4(t[0], t[1], t[2], t[3]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float4 sv[2];
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) sv[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + er) * 144 + ec * 16);
-#pragma unroll
-            for (int it = 0; it < 2; ++it, yp += ystep, rr += 8) {
-                const float4 o = make_float4(sv[it].x + bb.x, sv[it].y + bb.y, sv[it].z + bb.z, sv[it].w + bb.w);
-                const bool live = rr < rows_live;
-                const size_t m = live ? (size_t)(m0 + rr) : 0;
-                if (live) {
-                    *reinterpret_cast<float4*>(yp) = o;
-                    if (a.yb) *reinterpret_cast<uint2*>(a.yb + m * 512 + cb) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 t = acc[half * 2 + nt][mt];
+                    *reinterpret_cast<float4*>(stg + l15 * 144 + nt * 64 + g * 16) = make_float4(t[0], t[1], t[2], t[3]);
                 }
-                if (a.stats_out) {                         // the wavefront's 32 columns are one statistics group: the 8 lanes of a row piece
-                    const float s1 = oct_sum((o.x + o.y) + (o.z + o.w)), s2 = oct_sum((o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
-                    if (live && !ec) reinterpret_cast<float2*>(a.stats_out + m * 32)[wave] = make_float2(s1, s2);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float4 sv2[2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) sv2[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + er) * 144 + ec * 16);
+#pragma unroll
+                for (int it = 0; it < 2; ++it, yp += ystep, rr += 8) {
+                    const float4 o = make_float4(sv2[it].x + bb.x, sv2[it].y + bb.y, sv2[it].z + bb.z, sv2[it].w + bb.w);
+                    const bool live = rr < rows_live;
+                    const size_t m = live ? (size_t)(m0 + rr) : 0;
+                    if (live) {
+                        *reinterpret_cast<float4*>(yp) = o;
+                        if (a.yb) *reinterpret_cast<uint2*>(a.yb + m * 512 + cb) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                    }
+                    if (a.stats_out) {                     // 32 columns are one statistics group: the 8 lanes of a row piece
+                        const float s1 = oct_sum((o.x + o.y) + (o.z + o.w)), s2 = oct_sum((o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                        if (live && !ec) reinterpret_cast<float2*>(a.stats_out + m * 32)[cb >> 5] = make_float2(s1, s2);
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();           // (the next row tile rewrites the staging rows)
             }
-            __builtin_amdgcn_wave_barrier();               // (the next row tile rewrites the staging rows)
         }
     }
     RB_STAMP(a.dbg, wave, lane, 7);
 }
 
-template <int NQT, int NKT, int NR>
+template <int NQT, int NKT, int NR, int W>
 static int launch_rb_attn_t(const RbAttnArgs& a, hipStream_t st) {
-    constexpr int VR = NKT == 4 ? 48 : 32;
-    constexpr size_t body = (16 * VR * RB_VROW * 2 > 5 * 16384) ? 16 * VR * RB_VROW * 2 : 5 * 16384;
+    constexpr int IPR = W / 8, G = NR * IPR, VR = NKT == 4 ? 48 : 32;
+    constexpr int LQM = NR == 2 ? 20 : (NQT == 2 ? 32 : 40);              // query rows per image this instantiation is launched for
+    constexpr int MT = (G * LQM + 15) / 16;
+    constexpr size_t body = (W * VR * RB_VROW * 2 > MT * 16384) ? W * VR * RB_VROW * 2 : MT * 16384;
     constexpr size_t lds = body + 2048 + 256;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_attn_kernel<NQT, NKT, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_attn_kernel<NQT, NKT, NR, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return BOFI_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL((rb_attn_kernel<NQT, NKT, NR>), dim3((a.B + 2 * NR - 1) / (2 * NR)), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((rb_attn_kernel<NQT, NKT, NR, W>), dim3((a.B + G - 1) / G), dim3(W * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
 
@@ -905,12 +918,26 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
     if (!a.q || !a.k || !a.v || !a.wop || !a.bo || !a.x || !a.y || a.B < 1 || a.Lq < 1 || a.Lk < 1 || a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldx % 4 || a.ldy % 4)
         return BOFI_ERR_ARG;
     if (a.Lq > 40 || a.Lk > 48) return -1;
+    // BOFI_RB_ATTN_W (developer knob, read again after bofi_reload_env) = 16: one 16-wavefront workgroup per CU (round 3), 8: 8-wavefront workgroups of
+    // half the images, two per CU; default (0): 8 for query blocks of <= 20 rows (the filling pass: 25.9 -> 20.3 / 31.9 -> 24.7 us per launch at 320
+    // images), 16 for the encoder's 36 (28.1 against 29.6 us; with four launches in flight the 8-wavefront form there costs 1-2 %)
+    static int env_seen = -1, wenv = 0;
+    if (env_seen != g_env_generation) { const char* e = getenv("BOFI_RB_ATTN_W"); wenv = e ? atoi(e) : 0; env_seen = g_env_generation; }
+    const int w = wenv ? wenv : (a.Lq <= 20 ? 8 : 16);
     int rc;
-    if (a.Lq <= 20 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 2>(a, st);           // 4 images of <= 20 rows per workgroup
-    else if (a.Lq <= 20) rc = launch_rb_attn_t<2, 4, 2>(a, st);
-    else if (a.Lq <= 32 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 1>(a, st);      // 2 images
-    else if (a.Lq <= 32) rc = launch_rb_attn_t<2, 4, 1>(a, st);
-    else rc = launch_rb_attn_t<3, 4, 1>(a, st);
+    if (w == 16) {
+        if (a.Lq <= 20 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 2, 16>(a, st);       // 4 images of <= 20 rows per workgroup
+        else if (a.Lq <= 20) rc = launch_rb_attn_t<2, 4, 2, 16>(a, st);
+        else if (a.Lq <= 32 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 1, 16>(a, st);  // 2 images
+        else if (a.Lq <= 32) rc = launch_rb_attn_t<2, 4, 1, 16>(a, st);
+        else rc = launch_rb_attn_t<3, 4, 1, 16>(a, st);
+    } else {
+        if (a.Lq <= 20 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 2, 8>(a, st);        // 2 images of <= 20 rows per workgroup
+        else if (a.Lq <= 20) rc = launch_rb_attn_t<2, 4, 2, 8>(a, st);
+        else if (a.Lq <= 32 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 1, 8>(a, st);   // 1 image
+        else if (a.Lq <= 32) rc = launch_rb_attn_t<2, 4, 1, 8>(a, st);
+        else rc = launch_rb_attn_t<3, 4, 1, 8>(a, st);
+    }
     if (rc == BOFI_OK) g_gemm_flops += 2.0 * a.B * a.Lq * 512.0 * 512.0;
     return rc;
 }

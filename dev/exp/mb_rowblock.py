@@ -1,4 +1,4 @@
-"""Time the row-block sublayer kernels alone on the chip (in-graph time per launch, buffers rotated through the Infinity Cache).
+"""Time the row-block sublayer kernels alone on the chip (BOFI_RB_ATTN_W=16|8: attention workgroup shape) (in-graph time per launch, buffers rotated through the Infinity Cache).
 python dev/exp/mb_rowblock.py [ffn|attn|gemm|train]   (BOFI_RB_FFN_V / BOFI_RB_FFN_BPW / BOFI_RB_GEMM_BPW select the kernel forms)"""
 import math, os, sys
 import torch

@@ -175,7 +175,11 @@ def _attn_sublayer64(q, k, v, klens, wo, bo, x, B, Lq, Lk):
 
 @pytest.mark.parametrize("B,Lq,Lk,mode", [(5, 36, 36, "img"), (64, 36, 36, "none"), (9, 20, 20, "q1"), (7, 20, 36, "img"), (3, 20, 20, "row"),
                                           (4, 24, 30, "img"), (2, 40, 48, "img"), (3, 30, 40, "img"), (1, 5, 3, "img")])
-def test_attn_block_vs_reference_sublayer(H, B, Lq, Lk, mode):
+@pytest.mark.parametrize("W", [8, 16])
+def test_attn_block_vs_reference_sublayer(H, B, Lq, Lk, mode, W, monkeypatch):
+    """W: wavefronts per workgroup of rb_attn_kernel (8 = the default: one image column per workgroup, two workgroups per CU; 16 = round 3's)."""
+    monkeypatch.setenv("BOFI_RB_ATTN_W", str(W))
+    H.lib().bofi_reload_env()
     d = 512
     g = _rng(B * 100 + Lq + Lk)
     self_attn = Lq == Lk
@@ -237,6 +241,8 @@ def test_attn_block_vs_reference_sublayer(H, B, Lq, Lk, mode):
                                     H.ptr(wop), H.ptr(boc), H.ptr(xc), d, H.ptr(xc), d, None, None, H.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(xc.cpu()[rows_ok], y.cpu()[rows_ok])
+    monkeypatch.undo()
+    H.lib().bofi_reload_env()
 
 
 @pytest.mark.parametrize("M,N,f32out,relu", [(64, 512, False, 0), (200, 1536, False, 0), (2304, 7168, False, 0), (130, 9600, True, 0), (77, 2048, False, 1),
