@@ -422,6 +422,7 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
                                 hipStream_t s) {
     const int d = cfg.d_model, dt = cfg.dtype, M = B * R;
     cur_B = B;
+    if (exp_skip("encoder")) return BOFI_OK;           // (experiments build: the whole encoder phase)
     // The residual stream x_enc stays float32; every GEMM that closes a sublayer also writes a copy in
     // the compute dtype (xb_enc) and per-row partial sums (st_enc), from which the next pre-norm
     // LayerNorm is applied inside the consuming GEMM's epilogue (no LayerNorm launches).
@@ -581,6 +582,7 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
 // of decode_NA :570-574 -- the reference has no refinement loop itself)
 int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64_t* seq, float* seq_logprob, hipStream_t s) {
     const int d = cfg.d_model, dt = cfg.dtype, S = cfg.seq_length, M = B * S;
+    if (exp_skip("filling")) return BOFI_OK;           // (experiments build: the whole filling pass incl. the vocabulary epilogue)
     const int rounds = 1 + ((flags >> BOFI_FLAG_REFINE_SHIFT) & 15);
     const void* xa = stream_t(x_fill, xb_fill);
     float* lg = seq_logprob ? seq_logprob : logits;
