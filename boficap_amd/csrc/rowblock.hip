@@ -1,17 +1,18 @@
-// Row-block kernels of the bf16 decode path (round 3): a workgroup owns a block of activation rows for a whole SUBLAYER, keeps
+// Row-block kernels of the bf16 decode path (rounds 3 and 4): a workgroup owns a block of activation rows for a whole SUBLAYER, keeps
 // the block in LDS, and streams every weight it needs from L2 straight into MFMA operand registers.
 //
-//   rb_ffn_kernel        x <- x + w_2 . relu(w_1 . LN(x) + b_1) + b_2      (PositionwiseFeedForward behind SublayerConnection,
-//                        reference TransformerModel.py:1477-1478, 1361-1377): 64 rows per workgroup; the 2 048-wide hidden rows
-//                        never leave the CU (LDS, 512 columns at a time), the row statistics of the LayerNorm are computed while
-//                        the block is staged; one launch instead of two GEMMs, no hidden tensor in HBM.
+//   rb_ffn5_kernel       x <- x + w_2 . relu(w_1 . LN(x) + b_1) + b_2      (PositionwiseFeedForward behind SublayerConnection,
+//   (rb_ffn2_kernel)     reference TransformerModel.py:1477-1478, 1361-1377): 80 (64) rows per workgroup; the 2 048-wide hidden rows
+//                        never leave the CU (a ring in LDS between producer and consumer wavefronts), the row statistics of the LayerNorm
+//                        are computed while the block is staged; one launch instead of two GEMMs, no hidden tensor in HBM.
 //   rb_attn_kernel       x <- x + W_o . attention(q, k, v) + b_o             (MultiHeadedAttention.forward :1454-1467 behind the
-//                        sublayer's residual): a workgroup owns G images, wavefront = head; the heads' outputs meet in LDS and
+//                        sublayer's residual): a workgroup owns G images, wavefront = (image, head); the heads' outputs meet in LDS and
 //                        the output projection runs on them in place: one launch instead of attention + GEMM, no ctx tensor.
-//   rb_pack_frag_kernel  the weight layout both read.
+//   rb_gemm_kernel       y <- act(W' . LN(x) + c): the LayerNorm-folded projections reading the float32 stream (96- / 64-row blocks).
+//   rb_pack_frag_kernel  the weight layout all of them read.
 //
 // Why this shape.  d_model = 512: a sublayer's weights are 0.5 - 4 MB -- they live in L2 / Infinity Cache, and at K = 512 a tiled
-// GEMM is all prologue and epilogue (8 K-steps between a cold first slab and a staged epilogue; the residual
+// GEMM is all prologue and epilogue (docs/history/r02.md 12.9: 8 K-steps between a cold first slab and a staged epilogue; the residual
 // GEMMs ran at 6 % of the MFMA peak).  Here the activation block is the resident operand and the weights are the stream:
 //   * weights are stored FRAGMENT-MAJOR (rb_pack_frag_kernel): [64-column chunk][k step of 32][16-column tile][lane][8 bf16], so a
 //     wavefront's weight stream is a linear run of 1-KiB wave loads, each landing in the v_mfma_f32_16x16x32_bf16 operand layout:

@@ -11,7 +11,7 @@ structure_loss_types); the caption scorer itself
 (``get_scores``: CIDEr-D / BLEU of the external ``cider`` and ``coco-caption`` packages, captioning/utils/rewards.py:86-131) is
 not part of this build -- pass ``opt.bofi_score_fn(gts, seq) -> [N] floats`` or install one with ``set_scorer``.
 
-One difference in kind from the reference's RL branch, as in ``XETrainer.rl_step`` (DESIGN.md 11): the reference samples with the
+One difference in kind from the reference's RL branch, as in ``XETrainer.rl_step`` (DESIGN.md 7): the reference samples with the
 autograd tape running (and dropout active) and differentiates that same pass; here the samples come from the decode engine
 (no tape) and ``xe.sampled_logprobs`` recomputes their log-probs with the tape.
 """

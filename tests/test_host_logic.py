@@ -130,7 +130,7 @@ def test_noam_rate_and_bucket_layout():
 def test_shipped_library_has_no_packed_f32_arithmetic(tmp_path):
     """boficap_amd/build.py compiles without the SLP / loop vectorisers: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 in any kernel of
     the shipped code objects.  Round 2 saw wrong sums from SLP-packed float32 chains in the bounding tail beside other kernels' MFMAs;
-    round 3 could not reproduce it (dev/exp/pk_fma_repro.py: 0 mismatches in 8 000 concurrent steps of the SLP build),
+    round 3 could not reproduce it (dev/exp/pk_fma_repro.py: 0 mismatches in 8 000 concurrent steps of the SLP build, docs/history/r03.md 13.7),
     so the cause stays unestablished -- and beside MFMAs the packed forms cost issue slots anyway (MI355X_MICROARCH.md, cycle constants).
     This pins the build so that a flag change cannot bring them back unnoticed."""
     import glob
