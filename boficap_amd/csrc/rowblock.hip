@@ -959,7 +959,7 @@ template <bool F32OUT, int MT>
 struct RbGemmCfg {
     static constexpr int BR = MT * 16;                          // rows per block
     static constexpr int SP = F32OUT ? 272 : 144;               // staging row pitch (bytes): 64 columns + 16 B
-    static constexpr int TPS = MT == 8 ? 1 : MT == 6 ? 2 : (F32OUT ? 2 : 4);      // row tiles staged at a time
+    static constexpr int TPS = MT == 8 ? 1 : MT == 6 ? (F32OUT ? 1 : 2) : (F32OUT ? 2 : 4);      // row tiles staged at a time
     static constexpr int STG = TPS * 16 * SP;                   // staging bytes per wavefront
     static constexpr int XT = BR * 1024;
     static constexpr int STAT = XT + 8 * STG;                   // s_mean[BR], s_rstd[BR]
@@ -1111,15 +1111,16 @@ int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
     if (a.M < 1 || a.N < 64 || a.N % 64 || !a.x || !a.wp || !a.c || !a.cs || !a.y || a.ldx % 4 || a.ldy % 8) return BOFI_ERR_ARG;
     // developer knob (read again after bofi_reload_env): BOFI_RB_GEMM_MT = 4: 64-row blocks everywhere; 6 (default) / 8: 96- / 128-row blocks for bf16
     // outputs from BOFI_RB_GEMM_MT8_ROWS rows on (below that the 64-row blocks' larger number of workgroups wins)
-    static int env_seen = -1, mt = 6, mt8_rows = 4096, mt_min_n = 0;
+    static int env_seen = -1, mt = 6, mt8_rows = 4096, mt_min_n = 0, gen6 = 0;
     if (env_seen != g_env_generation) {
         const char* e = getenv("BOFI_RB_GEMM_MT"); mt = e ? atoi(e) : 6;
         e = getenv("BOFI_RB_GEMM_MT8_ROWS"); mt8_rows = e ? atoi(e) : 4096;
         e = getenv("BOFI_RB_GEMM_MT_MIN_N"); mt_min_n = e ? atoi(e) : 0;   // output columns from which the larger blocks run
+        e = getenv("BOFI_RB_GEN_MT6"); gen6 = e ? atoi(e) : 0;             // float32 outputs (the generator) on 96-row blocks too
         env_seen = g_env_generation;
     }
     int rc;
-    if (a.y_f32) rc = launch_rb_gemm_t<true, 4>(a, st);
+    if (a.y_f32) rc = (mt == 6 && gen6 && a.M >= mt8_rows) ? launch_rb_gemm_t<true, 6>(a, st) : launch_rb_gemm_t<true, 4>(a, st);
     else if (mt == 8 && a.M >= mt8_rows && a.N >= mt_min_n) rc = launch_rb_gemm_t<false, 8>(a, st);
     else if (mt == 6 && a.M >= mt8_rows && a.N >= mt_min_n) rc = launch_rb_gemm_t<false, 6>(a, st);
     else rc = launch_rb_gemm_t<false, 4>(a, st);
