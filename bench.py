@@ -200,7 +200,7 @@ def xe_traffic(args):
     """HBM bytes per XE step from the committed PMC passes -- for the configuration they were taken on only."""
     if args.batch != 64 or args.seq_per_img != 5 or args.dtype != "bf16":
         return None
-    for name in ("r03_xe_hbm_traffic.json", "r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
+    for name in ("r04_xe_hbm_traffic.json", "r03_xe_hbm_traffic.json", "r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -326,7 +326,7 @@ def run_xe(args, ctx, log, cpu=True):
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK[args.dtype], "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK[args.dtype], 5), "traffic": xe_traffic(args),
             "traffic_note": "HBM-side bytes per step, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate "
-                            "passes (profiles/r02_xe_hbm_traffic.json, or round 1's; batch 64 x 5 bf16); null for other configurations",
+                            "passes (the newest profiles/r0N_xe_hbm_traffic.json; batch 64 x 5 bf16); null for other configurations",
             "kernel": "whole XE step (" + ("one hipGraph launch + all-reduce + Adam kernel" if tr.graph else "eager launches") + ")",
             "flops_per_launch": flops, "launch_ms": round(dev_ms, 3),
             "note": "achieved / frac: algorithmic FLOPs of the step AS THE REFERENCE COMPUTES IT (SURVEY.md 8d: encoder per caption copy, "
@@ -776,7 +776,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         pcie_ms = (time.perf_counter() - h0) / args.steps * 1e3
         budget_ok = budget_held("from-host") and budget_ok
     traffic, tnote = None, "no PMC pass committed for this configuration"
-    names = {1: ("r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
+    names = {1: ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:

@@ -6,7 +6,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
-TAG=${1:-r03}
+TAG=${1:-r04}
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline --no-from-host"
