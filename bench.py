@@ -642,11 +642,13 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         import ctypes
         hiprt = ctypes.CDLL("libamdhip64.so")
         hiprt.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        by_xcd = os.environ.get("BOFI_BENCH_PARTITION_BY_XCD") == "1"      # experiment: stream k on XCDs {k*8/P ..} only (its weights alone in those L2s)
         P, per = args.cu_partitions, 32 // args.cu_partitions
         streams = []
         for k in range(max(1, args.inflight)):
             part = k % P
-            bits = {i for i in range(256) if part * per <= i // 8 < (part + 1) * per}
+            bits = ({i for i in range(256) if part * (8 // P) <= i % 8 < (part + 1) * (8 // P)} if by_xcd
+                    else {i for i in range(256) if part * per <= i // 8 < (part + 1) * per})
             words = (ctypes.c_uint32 * 8)(*[sum((1 << b) for b in range(32) if (wd * 32 + b) in bits) for wd in range(8)])
             h = ctypes.c_void_p()
             if hiprt.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words) != 0:
