@@ -661,6 +661,8 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
             streams = more if len(more) > len(streams) else streams
     log(f"{len(streams)} concurrent streams")
     engines = [eng] + [eng.fork() for _ in range(len(streams) - 1)]
+    for e in engines:
+        e.set_decodes_in_flight(len(engines))
     # every launch in flight decodes features of its own (a rotation of the batches by whole batches, so the layouts and T stay
     # those of the probe): none of them finds another's features warm in a cache
     nb = att.size(0) // args.batch
@@ -747,7 +749,9 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # for the record: the same K steps strictly one at a time (latency view of the same workload), HIP events on the stream
     single_ms = None
     if len(engines) > 1:
-        for i in range(warm_launches):
+        # (a caller that runs one decode at a time says so: the engine then takes the sublayer kernels' latency forms -- a hint, part of the graph key)
+        eng.set_decodes_in_flight(1)
+        for i in range(max(warm_launches, 3)):
             eng.decode_naic(att, graph=graph, out=outs[0], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
         _barrier(world)
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -758,6 +762,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         _barrier(world)
         single_ms = s0.elapsed_time(s1) / args.steps
         budget_ok = budget_held("one-at-a-time") and budget_ok
+        eng.set_decodes_in_flight(len(engines))
     # for the record: the same launches with the features starting in pinned HOST memory (a loader's numpy arrays), copied to the
     # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
     pcie_ms = None

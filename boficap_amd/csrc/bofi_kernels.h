@@ -119,6 +119,7 @@ struct RbFfnArgs {
     uint16_t* yb; float* stats_out;           // optional: bf16 copy [M][512], partial sums [M][16][2]
     int M, dff;
     int dbg;                                  // developer aid (BOFI_RB_DBG & 16): in-kernel stamps
+    int alone;                                // 1: this launch runs with nothing beside it (bofi_engine_set_decodes_in_flight(1)): the 64-row kernel's shorter chain
 };
 struct RbAttnArgs {
     const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64
@@ -138,6 +139,7 @@ struct RbGemmArgs {
     void* y; int ldy; int y_f32;              // bf16 (or float32) [M][ldy]
     int M, N, relu;
     int dbg;                                  // developer aid (BOFI_RB_DBG & 16: in-kernel stamps, set by the C entry)
+    int alone;                                // 1: nothing runs beside this launch: 64-row blocks (more, shorter workgroups)
 };
 int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st);
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st);

@@ -119,6 +119,7 @@ struct bofi_engine {
     uint64_t sample_seed = 0;
     int saic_it_begin = 1, saic_it_end = 0;   // iterations the next semi-autoregressive decode enqueues (bofi_engine_set_saic_range; end 0 = seq_length)
     int bound_iter_cap = 0;               // bounding iterations the non-autoregressive decode enqueues (bofi_engine_set_bound_iter_cap; 0 = seq_length)
+    int in_flight = 0;                    // decodes the caller keeps in flight (bofi_engine_set_decodes_in_flight; 0 = unknown: throughput forms)
     int* live_max = nullptr;              // optional device word: max over decodes of their live-iteration counts (bofi_engine_set_live_iterations_max)
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
@@ -391,6 +392,7 @@ struct bofi_engine {
         if (exp_skip(y_f32 ? "gen" : l.Npad <= 1536 ? "qkv" : "kv")) return BOFI_OK;
         bofi::RbGemmArgs a{};
         a.x = x32; a.ldx = cfg.d_model; a.wp = (const bofi::u32x4*)l.wp; a.c = l.b; a.cs = l.cs; a.y = y; a.ldy = ldy; a.y_f32 = y_f32; a.M = M; a.N = l.Npad; a.relu = 0;
+        a.alone = in_flight == 1;
         return bofi::launch_rb_gemm(a, s);
     }
     bool ffn_sublayer_ok(const Lin& w1, const Lin& w2, int M) const {
@@ -403,6 +405,7 @@ struct bofi_engine {
         bofi::RbFfnArgs a{};
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
+        a.alone = in_flight == 1;
         return bofi::launch_rb_ffn(a, s);
     }
     int enqueue_encode(const void* feats, int feats_dtype, const int* att_len, int B, int R, float* memory_out, hipStream_t s);
@@ -885,6 +888,7 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->sample_temperature = 1.0f;
     e->sample_seed = 0;
     e->bound_iter_cap = 0;                       // (a capped parent must not truncate the fork's bounding loop)
+    e->in_flight = 0;
     e->live_max = nullptr;                       // (a raw device pointer the fork's handle does not keep alive)
     e->saic_it_begin = 1;
     e->saic_it_end = 0;
@@ -980,6 +984,13 @@ int bofi_engine_debug_copy(bofi_engine_t* e, const char* name, void* dst, int64_
 int bofi_engine_set_q1_group(bofi_engine_t* e, int group) {
     if (!e || group < 0) return fail(BOFI_ERR_ARG, "group must be >= 0");
     e->q1_group = group;
+    return BOFI_OK;
+}
+
+int bofi_engine_set_decodes_in_flight(bofi_engine_t* e, int n) {
+    g_err.clear();
+    if (!e || n < 0) return fail(BOFI_ERR_ARG, "decodes in flight: >= 0 (0 = unknown)");
+    e->in_flight = n;
     return BOFI_OK;
 }
 
@@ -1271,7 +1282,7 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
     std::vector<uintptr_t> key = {(uintptr_t)0, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
-                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max};
+                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max, (uintptr_t)e->in_flight};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, cs);

@@ -610,16 +610,16 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
     // knobs (read again after bofi_reload_env): BOFI_RB_FFN_V = 5 (default): 80-row blocks -- +3 % on the decode with launches in flight; 2: one
     // 64-row block per workgroup (round 3's kernel) -- 6-12 us faster per launch when ONE decode runs alone (62 against 68 us at 11 520 rows);
     // BOFI_RB_FFN_BPW = row blocks a workgroup of the 80-row kernel walks (default 1; grid = blocks / that)
-    static int env_seen = -1, version = 5, bpw = 1, v5_rows = 0;
+    static int env_seen = -1, version = 5, bpw = 1, v5_rows = 0, forced = 0;
     if (env_seen != g_env_generation) {
-        const char* e = getenv("BOFI_RB_FFN_V"); version = e ? atoi(e) : 5;
+        const char* e = getenv("BOFI_RB_FFN_V"); version = e ? atoi(e) : 5; forced = e != nullptr;
         e = getenv("BOFI_RB_FFN_BPW"); bpw = e ? max(1, atoi(e)) : 1;
         e = getenv("BOFI_RB_FFN_V5_ROWS"); v5_rows = e ? atoi(e) : 0;      // rows from which the 80-row kernel runs (below: the 64-row kernel)
         env_seen = g_env_generation;
     }
     RbFfnArgs b = a;
     { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
-    if (version == 2 || a.M < v5_rows) hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    if (version == 2 || a.M < v5_rows || (a.alone && !forced)) hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
     else {
         const int grid = ((a.M + R5_ROWS - 1) / R5_ROWS + bpw - 1) / bpw;
         if (a.yb || a.stats_out) hipLaunchKernelGGL((rb_ffn5_kernel<true, false>), dim3(grid), dim3(512), R5_LDS, st, b);
@@ -1122,7 +1122,7 @@ int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
     int rc;
     if (a.y_f32) rc = (mt == 6 && gen6 && a.M >= mt8_rows) ? launch_rb_gemm_t<true, 6>(a, st) : launch_rb_gemm_t<true, 4>(a, st);
     else if (mt == 8 && a.M >= mt8_rows && a.N >= mt_min_n) rc = launch_rb_gemm_t<false, 8>(a, st);
-    else if (mt == 6 && a.M >= mt8_rows && a.N >= mt_min_n) rc = launch_rb_gemm_t<false, 6>(a, st);
+    else if (mt == 6 && a.M >= mt8_rows && a.N >= mt_min_n && !(a.alone && a.N < 2048)) rc = launch_rb_gemm_t<false, 6>(a, st);      // (alone: 96-row blocks only where they win alone)
     else rc = launch_rb_gemm_t<false, 4>(a, st);
     if (rc == BOFI_OK) g_gemm_flops += 2.0 * a.M * 512.0 * a.N;
     return rc;

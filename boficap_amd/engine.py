@@ -197,6 +197,11 @@ class BofiEngine:
             hip.ptr(out["memory"]), hip.ptr(out["bound_iters"]), hip.stream_ptr()), "bofi_engine_decode_naic")
         return out
 
+    def set_decodes_in_flight(self, n: int) -> None:
+        """A hint for the kernel choice (bofi_engine_set_decodes_in_flight): 1 = this engine's launches run alone on the device (shorter
+        workgroup chains), 0 / > 1 = throughput forms (fewer weight bytes per row).  Part of the graph key: a captured launch is replayed under the hint it was captured with."""
+        hip.check(self._lib.bofi_engine_set_decodes_in_flight(self._h, int(n)), "bofi_engine_set_decodes_in_flight")
+
     def watch_live_iterations(self, word: Optional[torch.Tensor]) -> None:
         """``word`` (int32 [1] on the device, or None to stop): every following decode_naic folds its live-iteration count into it by atomic
         max -- a pipeline of capped decodes (``iter_cap``) is verified with ONE read after the last of them (clear the word first)."""

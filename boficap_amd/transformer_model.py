@@ -101,6 +101,8 @@ class TransformerModel(nn.Module):
             if self._engine is None or self._engine_key[1:] != key[1:]:
                 self._engine = BofiEngine(self.cfg, self.compute_dtype, self.max_batch, self.max_regions, device=dev)
                 self._engine.load_state_dict(self.state_dict())
+                # mode='sample' synchronises after every decode as the reference does (AttModel.py:337): one decode at a time on the device
+                self._engine.set_decodes_in_flight(int(getattr(self.opt, "bofi_decodes_in_flight", 1)))
             else:                                              # same engine, new values: re-pack on the device (no host round trip)
                 self._engine.refresh_from_device({k: v.detach() for k, v in self.named_parameters()})
             self._engine_key = key

@@ -304,6 +304,12 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
  * equals its own separate decode.  0 (default): the whole call is one batch. */
 int bofi_engine_set_q1_group(bofi_engine_t* e, int group);
 
+/* A hint, not a semantic: how many decodes the caller keeps in flight on this device (engine + forks on their own streams).  1: this engine's
+ * launches run with nothing beside them -- from 4 096 rows on the sublayer kernels then take 64-row blocks (more, shorter workgroups: 62 against 68 us
+ * for the encoder's feed-forward sublayer at 11 520 rows) where the default, n = 0 (unknown) or n > 1, takes the 80- / 96-row blocks that move fewer weight
+ * bytes per row (+3.5 % images/s with four launches in flight).  Results under either choice agree as bf16 kernels of different summation order do. */
+int bofi_engine_set_decodes_in_flight(bofi_engine_t* e, int n);
+
 /* Temperature (> 0) and seed of the token draws of a decode called with BOFI_FLAG_SAMPLE. */
 int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed);
 /* The iterations the following bofi_engine_decode_saic calls enqueue: it_begin .. it_end of core_SAIC's loop (TransformerModel.py:1903-1984; 1-based,

@@ -599,3 +599,39 @@ def test_saic_row_list_on_direct_operand_kernels(weight_cache, manifest, monkeyp
     assert float(same.float().mean()) >= 0.8, float(same.float().mean())
     d = (la[same].nan_to_num(0.0) - lb[same].nan_to_num(0.0)).abs().max()
     assert float(d) <= 6e-2, float(d)
+
+
+def test_decodes_in_flight_hint_changes_kernels_not_results(engines):
+    """bofi_engine_set_decodes_in_flight: a hint for the kernel choice (64-row blocks for a decode that runs alone, 80- / 96-row blocks otherwise),
+    part of the graph key.  Under the row-block family (forced here: 64 images are below its size threshold) the same hint gives the same bits eager
+    or replayed, hints 0 and 4 are the same kernels, and hint 1 differs as two bf16 summation orders do (same layouts on nearly every image, log-probs
+    within the bf16 bar where the layouts agree); a fork starts from the default hint."""
+    from boficap_amd import hip as H
+    from boficap_amd import weights as W
+    import os
+    cfg, sd, eng = engines("full_b8", torch.bfloat16)
+    att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=99)).cuda().to(torch.bfloat16)
+    os.environ["BOFI_RB_MIN_ROWS"] = "0"
+    H.lib().bofi_reload_env()
+    try:
+        outs = []
+        for n, graph in ((0, False), (1, False), (4, False), (1, True)):
+            eng.set_decodes_in_flight(n)
+            r = eng.decode_naic(att, strict_q1=False, graph=graph)
+            torch.cuda.synchronize()
+            outs.append({k: r[k].clone() for k in ("seq", "phrase_length", "phrase_syn", "seq_logprob")})
+        for k in ("seq", "phrase_length", "phrase_syn"):
+            assert torch.equal(outs[0][k], outs[2][k]) and torch.equal(outs[1][k], outs[3][k])
+        assert torch.equal(outs[1]["seq_logprob"].nan_to_num(), outs[3]["seq_logprob"].nan_to_num())          # same hint, eager / replayed: bit for bit
+        assert torch.equal(outs[0]["seq_logprob"].nan_to_num(), outs[2]["seq_logprob"].nan_to_num())          # 0 and 4: the same (throughput) forms
+        same = (outs[0]["phrase_length"] == outs[1]["phrase_length"]).all(1) & (outs[0]["phrase_syn"] == outs[1]["phrase_syn"]).all(1)
+        assert int(same.sum()) >= 58, int(same.sum())                                                        # near-ties may flip between two bf16 kernels
+        d = (outs[0]["seq_logprob"][same] - outs[1]["seq_logprob"][same]).nan_to_num().abs().max()
+        assert 0 < float(d) < 4e-2, float(d)                                                                # two bf16 results, each within 2e-2 of the float32 one (measured: 0.023)
+        f = eng.fork()
+        r = f.decode_naic(att, strict_q1=False)
+        assert torch.equal(r["seq_logprob"].nan_to_num(), outs[0]["seq_logprob"].nan_to_num())
+    finally:
+        os.environ.pop("BOFI_RB_MIN_ROWS")
+        H.lib().bofi_reload_env()
+        eng.set_decodes_in_flight(0)
