@@ -9,7 +9,7 @@ L.bofi_rb_stamps.restype = C.c_int; L.bofi_rb_stamps.argtypes = [C.c_void_p]
 B, Lq, Lk = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (320, 36, 36)
 d, dev = 512, "cuda"
 M = B * Lq
-qkv = torch.randn(M, 3 * d, device=dev).to(torch.bfloat16)
+qkv = torch.randn(B * max(Lq, Lk), 3 * d, device=dev).to(torch.bfloat16)      # (keys / values: B * Lk rows -- the cross shapes read past B * Lq)
 x = torch.randn(M, d, device=dev)
 wop = torch.empty(d * d, dtype=torch.bfloat16, device=dev)
 w = (torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
@@ -22,8 +22,9 @@ for it in range(5):
     torch.cuda.synchronize()
 buf = (C.c_ulonglong * 256)()
 H.check(L.bofi_rb_stamps(buf))
-names = ["entry", "consts+barrier", "attention", "barrier (V dead)", "block written + barrier", "output projection", "p0 staged", "p0 stored", "p1 staged", "p1 stored", "p2 staged", "p2 stored"]
-t0 = min(buf[w * 16] for w in range(16))
-print(f"B {B} Lq {Lq} Lk {Lk}: stamps in ns after the first wavefront's entry (s_memtime ticks of 10 ns), wavefronts 0, 7, 8, 15")
+names = ["entry", "consts + barrier", "attention done", "barrier (V dead)", "block written + barrier", "output projection done", "barrier (block dead)", "rows stored"]
+nw = 16 if (int(os.environ.get("BOFI_RB_ATTN_W", "0")) or (8 if Lq <= 20 else 16)) == 16 else 8
+t0 = min(buf[w * 16] for w in range(nw))
+print(f"B {B} Lq {Lq} Lk {Lk}: s_memtime ticks (shader cycles) after the first wavefront's entry; wavefronts 0, {nw // 2 - 1}, {nw // 2}, {nw - 1} of {nw}")
 for i, n in enumerate(names):
-    print(f"  {n:26s}" + "".join(f"{(buf[w * 16 + i] - t0) * 10:8d}" for w in (0, 7, 8, 15)))
+    print(f"  {n:26s}" + "".join(f"{buf[w * 16 + i] - t0:8d}" for w in (0, nw // 2 - 1, nw // 2, nw - 1)))
