@@ -65,7 +65,7 @@ def test_bench_two_ranks_walk_the_multi_gpu_path_on_one_device():
 
 
 def test_bench_reruns_without_the_iteration_budget_when_a_decode_outruns_it():
-    """--iter-budget auto enqueues (live iterations of the probe + 2) bounding iterations per decode and checks the device-side maximum of the
+    """--iter-budget auto enqueues (live iterations of the probe + 1) bounding iterations per decode and checks the device-side maximum of the
     decodes' live-iteration counts after every leg; with a budget the decodes cannot meet (forced here) the line must come from the re-run
     that enqueues all of them."""
     d = _run("--steps", "10", "--warmup", "5", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--no-from-host", env={"BOFI_BENCH_ITER_CAP": "3"})
