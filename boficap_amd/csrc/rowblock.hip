@@ -60,12 +60,38 @@ __device__ __forceinline__ void rb_prime(const u32x4* seg, bf16x8 (&wb)[PF * NT]
 // the swizzle only touches bits 4..9, so a k-step costs one v_xor with an inline constant and the tile index rides in the offset field.
 __device__ __forceinline__ int rb_lane_base(int l15, int g) { return l15 * 1024 + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4)); }
 
-template <int MT, int NT = 4, int PF = RB_PF, int MH = MT>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one); PF divides 16;
-                                                                  // MH: row tiles per operand batch (MH < MT: fewer operand registers live at a time)
+template <int MT, int NT = 4, int PF = RB_PF, int MH = MT, bool PIPE = false>      // NT < 4: the wavefront takes NT of a step's four 16-column tiles (cur / nxt point at its first one); PF divides 16;
+                                                                  // MH: row tiles per operand batch (MH < MT: fewer operand registers live at a time);
+                                                                  // PIPE: the NEXT k-step's block operands are requested before this step's MFMAs (MT * 4 more registers): the LDS
+                                                                  // latency of a step no longer sits between its reads and its MFMAs
 __device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, bf16x8 (&wb)[PF * NT], const unsigned char* smem, int lbase,
-                                           f32x4 (&acc)[NT][MT]) {
+                                           f32x4 (&acc)[NT][MT], int kstride = 256) {      // kstride: u32x4 per k-step of the stream (256; 0 = a diagnostic that re-reads step 0)
     static_assert(MT % MH == 0, "operand batches divide the row tiles");
+    static_assert(!PIPE || MH == MT, "the pipelined form reads a whole step's operands at once");
     asm volatile("" : "+v"(lbase));                   // (keeps the sixteen k-step addresses from being hoisted out of the caller's loops and spilled)
+    if constexpr (PIPE) {
+        bf16x8 xa[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xa[0][mt] = *reinterpret_cast<const bf16x8*>(smem + lbase + mt * 16384);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            if (kb + 1 < 16) {
+                const unsigned char* xn = smem + (lbase ^ ((kb + 1) << 6));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xa[(kb + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(xn + mt * 16384);
+                __builtin_amdgcn_sched_barrier(0);            // (the scheduler sinks these reads behind this step's MFMAs otherwise: the point is that they fly meanwhile)
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(kb % PF) * NT + nt], xa[kb & 1][mt], acc[nt][mt], 0, 0, 0);
+            const u32x4* src = kb + PF < 16 ? cur + (kb + PF) * kstride : nxt + (kb + PF - 16) * kstride;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wb[(kb % PF) * NT + nt] = rb_ldw(src + nt * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
         int ad = lbase ^ (kb << 6);
@@ -81,7 +107,7 @@ __device__ __forceinline__ void rb_segment(const u32x4* cur, const u32x4* nxt, b
 #pragma unroll
                 for (int mt = 0; mt < MH; ++mt) acc[nt][mb + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[(kb % PF) * NT + nt], xa[mt], acc[nt][mb + mt], 0, 0, 0);
         }
-        const u32x4* src = kb + PF < 16 ? cur + (kb + PF) * 256 : nxt + (kb + PF - 16) * 256;
+        const u32x4* src = kb + PF < 16 ? cur + (kb + PF) * kstride : nxt + (kb + PF - 16) * kstride;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wb[(kb % PF) * NT + nt] = rb_ldw(src + nt * 64);
         __builtin_amdgcn_sched_barrier(0);            // the scheduler would sink the loads next to their use: the prefetch distance is the point
@@ -354,6 +380,9 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
 //   producers (wavefronts 0-3): stage the block (20 rows each), then per chunk 32 hidden columns each: w_1 tiles (c*2 + (w >> 1), (w & 1)*2 ..+1)
 //   consumers (wavefronts 4-7): 128 output columns each, K = the chunks as they arrive.
 constexpr int R5_ROWS = 80, R5_HC = 128, R5_SLOTS = 3, R5_SLOT = R5_ROWS * 256;
+#ifndef R5_PIPE
+#define R5_PIPE true
+#endif
 constexpr int R5_HR = R5_ROWS * 1024;                                  // hidden ring behind the block
 constexpr int R5_CST = R5_HR + R5_SLOTS * R5_SLOT, R5_CSTW = 16 * 144; // consumer staging: [4 wavefronts][16 rows][144 B]
 constexpr int R5_PC = R5_CST + 4 * R5_CSTW;                            // producer constants: [4 wavefronts][c[32] | cs[32]] floats
@@ -383,8 +412,11 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
     unsigned long long rt0 = 0;                                // (the 100 MHz constant clock beside the shader clock: the clock the chip holds under this load)
     if (stamps) rt0 = __builtin_amdgcn_s_memrealtime();
 
+    // (developer diagnostic, stamped build only, BOFI_RB_DBG & 32: every wavefront re-reads the FIRST step of its weight stream -- the kernel without its
+    // weight traffic, results meaningless)
+    const int wmul = (STAMPS && (a.dbg & 32)) ? 0 : 1;
     bf16x8 wbuf[16];                                           // producer: 8 steps x 2 fragments; consumer: 2 steps x 8 fragments
-    auto w1seg = [&](int c) { return a.w1p + (size_t)(c * 2 + (w4 >> 1)) * (16 * 256) + (w4 & 1) * 128 + lane; };
+    auto w1seg = [&](int c) { return a.w1p + (size_t)((c * 2 + (w4 >> 1)) * wmul) * (16 * 256) + (w4 & 1) * 128 + lane; };
     // the consumer's weight stream as BUFFER loads: a scalar resource over the wavefront's two 64-column chunks of w_2 (one after the other), the step in
     // a scalar offset, the lane's 16 bytes in ONE vector register -- global loads cost a 64-bit address pair per base, and at 160 accumulator + 64
     // ring registers the allocator then spills a weight fragment inside the loop
@@ -393,7 +425,7 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
         const_cast<u32x4*>(a.w2p + (size_t)(2 * __builtin_amdgcn_readfirstlane(w4)) * (a.dff >> 5) * 256), 0, (int)(2 * w2j), 0x00020000);
     const int lo16 = lane * 16;
     auto w2frag = [&](int step, int f) {
-        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, lo16 + (f & 3) * 1024, (int)((f >> 2) * w2j) + step * 4096, 0));
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, lo16 + (f & 3) * 1024, (int)((f >> 2) * w2j) + step * 4096 * wmul, 0));
     };
     if (producer) rb_prime<2, 8>(w1seg(0), wbuf);
     else {
@@ -406,6 +438,8 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
     reinterpret_cast<float*>(smem + R5_B2)[tid] = a.b2[tid];
     __syncthreads();                                           // (the only workgroup barrier of the kernel)
 
+    // (experiment, BOFI_RB_DBG & 64 / & 128: static issue priority for the producer / consumer wavefronts -- the two of a SIMD share its matrix pipe)
+    if (producer ? (a.dbg & 64) : (a.dbg & 128)) __builtin_amdgcn_s_setprio(1);
     if (producer) {
         const int lbase = rb_lane_base(l15, g);
         float* mycst = reinterpret_cast<float*>(smem + R5_PC) + w4 * 64;
@@ -452,7 +486,8 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 5; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb_segment<5, 2, 8>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : 0), wbuf, smem, lbase, acc1);
+                if constexpr (STAMPS) rb_segment<5, 2, 8, 5, R5_PIPE>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : 0), wbuf, smem, lbase, acc1, 256 * wmul);
+                else rb_segment<5, 2, 8, 5, R5_PIPE>(w1seg(c), w1seg(c + 1 < nch ? c + 1 : 0), wbuf, smem, lbase, acc1);
                 if (!(c & 1)) RB3_STAMP(stamps, nst);          // segment done
                 mycst[lane] = cv;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
