@@ -34,7 +34,14 @@ def test_bench_line_with_the_drivers_arguments():
     assert "workload" in c and "batch=64" in c["workload"] and c["images_per_step_per_gpu"] == 64 and not c["nan_in_output"]
     assert c["batches_per_launch"] == 5 and c["decodes_in_flight"] >= 1              # 20 steps = 4 launches of 5 batches
     assert c["bound_iterations"] < c["bound_iterations_enqueued"] <= 20 and "iteration_budget" in c      # verified budget (or all 20 enqueued)
+    # a short region is timed five times back to back and the median reported; every stream is warmed
+    assert c["timed_regions"] == 5 and len(c["region_ms"]) == 5 and c["region_ms"] == sorted(c["region_ms"]) and c["warmup_steps_run"] >= 5 * c["decodes_in_flight"]
+    assert abs(d["ms_per_step"] * 20 - c["region_ms"][2]) < 0.02 * c["region_ms"][2]
+    # roofline_gemm times the kernels the engine RUNS at the measured size: the row-block sublayer kernels at 5 batches per launch
+    assert any("rb_ffn" in g["kernel"] for g in d["roofline_gemm"]) and any("rb_gemm" in g["kernel"] for g in d["roofline_gemm"])
+    assert all(0 < g["frac"] < 1 and g["us_per_launch"] > 0 for g in d["roofline_gemm"])
     r = d["roofline"]
+    assert r["one_at_a_time"]["frac"] > 0 and r["one_at_a_time"]["launch_ms"] > r["launch_ms"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["flops_per_launch"] > 0 and r["launch_ms"] > 0 and "traffic" in r
     b = d["cpu_baseline"]
@@ -61,6 +68,7 @@ def test_bench_two_ranks_walk_the_multi_gpu_path_on_one_device():
     dp = d["secondary"]["xe_config3_dp"]
     assert "error" not in dp, dp
     assert dp["rccl_ranks"] == 2 and dp["fp32_ring_all_reduce"]["step_ms"] > 0 and dp["bf16_mesh_direct"]["step_ms"] > 0
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["dist_backend"] == "gloo" and "xe_dp_error" not in d["config"] and d["config"]["xe_dp_step_ms"] > 0
     assert dp["fp32_ring_all_reduce"]["exchanged_bytes_per_rank"] == 2 * dp["bf16_mesh_direct"]["exchanged_bytes_per_rank"]
 
 
