@@ -120,6 +120,9 @@ struct RbFfnArgs {
     int M, dff;
     int dbg;                                  // developer aid (BOFI_RB_DBG & 16): in-kernel stamps
     int alone;                                // 1: this launch runs with nothing beside it (bofi_engine_set_decodes_in_flight(1)): the 64-row kernel's shorter chain
+    // optional: the LayerNorm-folded projection that reads this sublayer's output (the next layer's q|k|v, the stacked cross K|V) computed from the
+    // closed block while it is still in LDS: pj_y[M][pj_ldy] bf16 = W_pj . LN(y) + c_pj (what launch_rb_gemm would compute from y)
+    const rb_u32x4* pj_wp; const float* pj_c; const float* pj_cs; void* pj_y; int pj_ldy, pj_N;
 };
 struct RbAttnArgs {
     const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64

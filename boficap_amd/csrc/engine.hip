@@ -399,10 +399,23 @@ struct bofi_engine {
         static const bool on = env_on("BOFI_RB_FFN");
         return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560 && M >= rb_min_rows();
     }
-    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s) {
+    // pj (optional): the LayerNorm-folded projection that reads this sublayer's output next (the next layer's q|k|v, the stacked cross K|V), computed by
+    // the SAME launch from each closed block while it sits in LDS (pj_y, pitch pj_ldy); ffn_proj_ok says when the feed-forward kernel takes it
+    // (BOFI_RB_FFN_PROJ, re-read after bofi_reload_env: 0 = never, 1 (default) = when launches overlap, 2 = always)
+    bool ffn_proj_ok(const Lin& w1, const Lin& w2, const Lin& pj, int M) const {
+        static int gen = -1, v = 1;
+        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_FFN_PROJ"); v = e ? atoi(e) : 1; gen = bofi::g_env_generation; }
+        // (a decode running alone keeps the separate launches of 64-row blocks: measured 0.515 against 0.523 ms per batch with the narrow projections fused,
+        // 0.536 with all of them)
+        return v && (v == 2 || in_flight != 1) && ffn_sublayer_ok(w1, w2, M) && fold_rb_ok(pj, M) && pj.Npad >= 512 && !exp_skip("ffn") && !exp_skip("qkv") &&
+               !exp_skip("kv");
+    }
+    int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s, const Lin* pj = nullptr, void* pj_y = nullptr,
+                     int pj_ldy = 0) {
         if (!ffn_sublayer_ok(w1, w2, M)) return -1;
         if (exp_skip("ffn")) return BOFI_OK;
         bofi::RbFfnArgs a{};
+        if (pj) { a.pj_wp = (const bofi::u32x4*)pj->wp; a.pj_c = pj->b; a.pj_cs = pj->cs; a.pj_y = pj_y; a.pj_ldy = pj_ldy; a.pj_N = pj->Npad; }
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
         a.alone = in_flight == 1;
@@ -439,9 +452,11 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
     }
     const void* xa = stream_t(x_enc, xb_enc);
     const bool memory_out_needs_copy = false;           // (memory_out is a LayerNorm of the float32 stream itself)
+    bool proj_made = false;                              // this layer's q|k|v (after the last layer: the cross K|V) came out of the previous feed-forward launch
     for (size_t li = 0; li < enc.size(); ++li) {
         auto& l = enc[li];
-        {   int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
+        if (!proj_made) {
+            int rc = fold_linear_rb(x_enc, l.qkv, qkv, 0, 3 * d, M, s);
             if (rc > 0) return rc;
             if (rc < 0) { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
         bofi::AttnArgs a{};
@@ -458,7 +473,11 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         }
         {   // the consumers of this layer's output: the next layer's q|k|v (or the stacked cross K|V): tiled GEMMs read the copy + statistics
             const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;
-            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s) : -1; }
+            const bool last = li + 1 == enc.size();
+            const Lin& nxt = last ? kv_all : enc[li + 1].qkv;
+            proj_made = !need_copy && ffn_proj_ok(l.w1, l.w2, nxt, M);
+            rc = !ffn_rb ? -1 : proj_made ? ffn_sublayer(l.w1, l.w2, x_enc, nullptr, nullptr, M, s, &nxt, last ? kv : qkv, last ? kv_all.N : 3 * d)
+                                          : ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s); }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -469,7 +488,8 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
     if (memory_out) ENG_OK(bofi::launch_layernorm(x_enc, enc_norm.g, enc_norm.b, memory_out, BOFI_DT_F32, M, d, s));
     // cross-attention K|V of the bound layer and of every decoder layer in one GEMM on memory =
     // encoder.norm(x_enc), the norm folded in
-    {   int rc = fold_linear_rb(x_enc, kv_all, kv, 0, kv_all.N, M, s);
+    if (!proj_made) {
+        int rc = fold_linear_rb(x_enc, kv_all, kv, 0, kv_all.N, M, s);
         if (rc > 0) return rc;
         if (rc < 0) { LinOpt o; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, kv_all, kv, dt, kv_all.N, M, o, s)); } }
     return BOFI_OK;
@@ -594,9 +614,11 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     for (int round = 0; round < rounds; ++round) {
     ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                    st_fill, s));
+    bool proj_made = false;                              // this layer's q|k|v came out of the previous layer's feed-forward launch
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
-        {   int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
+        if (!proj_made) {
+            int rc = fold_linear_rb(x_fill, l.qkv, qkv, 0, 3 * d, M, s);
             if (rc > 0) return rc;
             if (rc < 0) { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.qkv, qkv, dt, 3 * d, M, o, s)); } }
         bofi::AttnArgs a{};
@@ -631,7 +653,9 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         }
         {   // next consumer: the next layer's q|k|v or the generator
             const bool need_copy = !(fold_rb_ok(l.qkv, M) && gen_rb);
-            rc = ffn_rb ? ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s) : -1; }
+            proj_made = !need_copy && li + 1 < dec.size() && ffn_proj_ok(l.w1, l.w2, dec[li + 1].qkv, M);
+            rc = !ffn_rb ? -1 : proj_made ? ffn_sublayer(l.w1, l.w2, x_fill, nullptr, nullptr, M, s, &dec[li + 1].qkv, qkv, 3 * d)
+                                          : ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s); }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }

@@ -355,6 +355,97 @@ __global__ __launch_bounds__(512) void rb_ffn2_kernel(RbFfnArgs a) {
 #define RB3_STAMP(on, n) do { if ((on) && (n) < 126) g_rb_stamps[stamp_base + (n)++] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The chunk loop of the LayerNorm-folded projections (rb_gemm_kernel below; also the projection tail of rb_ffn5_kernel): a block of bf16 rows
+// in LDS, its row statistics, and a wavefront's 64-column chunks of the fragment-major weight.
+template <bool F32OUT, int MT>
+struct RbGemmCfg {
+    static constexpr int BR = MT * 16;                          // rows per block
+    static constexpr int SP = F32OUT ? 272 : 144;               // staging row pitch (bytes): 64 columns + 16 B
+    static constexpr int TPS = (MT == 8 || MT == 5) ? 1 : MT == 6 ? (F32OUT ? 1 : 2) : (F32OUT ? 2 : 4);      // row tiles staged at a time (divides MT)
+    static constexpr int STG = TPS * 16 * SP;                   // staging bytes per wavefront
+    static constexpr int XT = BR * 1024;
+    static constexpr int STAT = XT + 8 * STG;                   // s_mean[BR], s_rstd[BR]
+    static constexpr int CST = STAT + BR * 8;                   // per wavefront [2][64]: c | cs of the current chunk
+    static constexpr int LDS = CST + 8 * 512;
+};
+
+template <bool F32OUT, int MT>
+__device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsigned char* blk, unsigned char* stage_all, float* cst, const float* s_mean,
+                                               const float* s_rstd, int m0, int wave, int lane, int ch0, int chstep, bf16x8 (&wb)[RB_PF * 4]) {
+    using Cfg = RbGemmCfg<F32OUT, MT>;
+    constexpr int SP = Cfg::SP, TPS = Cfg::TPS;
+    const int l15 = lane & 15, g = lane >> 4, nchunks = a.N >> 6;
+    auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
+    constexpr bool STATS_IN_REGS = MT <= 6;                    // (128-row blocks: the 16 statistics registers are what the accumulators need -- read per pass from LDS)
+    float mu[STATS_IN_REGS ? MT : 1], rs[STATS_IN_REGS ? MT : 1];
+    if constexpr (STATS_IN_REGS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
+    }
+    const int lbase = rb_lane_base(l15, g);
+    unsigned char* stage = stage_all + wave * Cfg::STG;
+    int nstamp = 0;
+    float* mycst = cst + wave * 128;
+    const int rows_live = min(Cfg::BR, a.M - m0);
+
+#pragma unroll 1
+    for (int ch = ch0; ch < nchunks; ch += chstep) {
+        // this chunk's column constants: requested now (older than the weight prefetch), parked in LDS at the epilogue
+        const float cv = a.c[ch * 64 + lane], csv = a.cs[ch * 64 + lane];
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb_segment<MT, 4, RB_PF, (MT == 5 ? 5 : MT > 4 ? MT / 2 : MT)>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, blk, lbase, acc);
+        if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp);            // chunk's MFMAs issued
+        mycst[lane] = cv; mycst[64 + lane] = csv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (the row pointers of the stores hang on a lane value the compiler cannot see through and advance by additions: as invariants of the chunk
+        // loop they are hoisted above it -- two registers per store -- and the accumulators spill)
+        constexpr int LPR = F32OUT ? 16 : 8, RPI = 64 / LPR;
+        int lnv = lane;
+        asm volatile("" : "+v"(lnv));
+        int rrow = lnv / LPR;                                  // row of the block this lane stores next
+        unsigned char* yp = static_cast<unsigned char*>(a.y) + ((size_t)(m0 + rrow) * a.ldy + ch * 64) * (F32OUT ? 4 : 2) + (lnv % LPR) * 16;
+        const size_t ystep = (size_t)RPI * a.ldy * (F32OUT ? 4 : 2);
+        const unsigned char* srd = stage + rrow * SP + (lnv % LPR) * 16;
+#pragma unroll
+        for (int pass = 0; pass < MT / TPS; ++pass) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float4 cc = *reinterpret_cast<const float4*>(mycst + nt * 16 + g * 4);
+                const float4 cs = *reinterpret_cast<const float4*>(mycst + 64 + nt * 16 + g * 4);
+#pragma unroll
+                for (int mh = 0; mh < TPS; ++mh) {
+                    const int mt = pass * TPS + mh;
+                    const f32x4 t = acc[nt][mt];
+                    const float mu_ = STATS_IN_REGS ? mu[STATS_IN_REGS ? mt : 0] : s_mean[mt * 16 + l15], rs_ = STATS_IN_REGS ? rs[STATS_IN_REGS ? mt : 0] : s_rstd[mt * 16 + l15];
+                    float v0 = rs_ * (t[0] - mu_ * cs.x) + cc.x, v1 = rs_ * (t[1] - mu_ * cs.y) + cc.y;
+                    float v2 = rs_ * (t[2] - mu_ * cs.z) + cc.z, v3 = rs_ * (t[3] - mu_ * cs.w) + cc.w;
+                    if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    unsigned char* sp = stage + (mh * 16 + l15) * SP + (nt * 16 + g * 4) * (F32OUT ? 4 : 2);
+                    if constexpr (F32OUT) *reinterpret_cast<float4*>(sp) = make_float4(v0, v1, v2, v3);
+                    else *reinterpret_cast<uint2*>(sp) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // whole row pieces: bf16 8 lanes x 16 B = a row's 128 B (8 rows per instruction); float32 16 lanes x 16 B = 256 B (4 rows)
+#pragma unroll
+            for (int it = 0; it < TPS * 16 / RPI; ++it, yp += ystep, rrow += RPI) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(srd + it * RPI * SP);
+                if (rrow < rows_live) *reinterpret_cast<u32x4*>(yp) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp + 1);        // chunk stored
+        ++nstamp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // The same sublayer on 80-ROW blocks, able to walk several of them (round 4; the default from 4 096 rows on).
 // What round 4 measured on the 64-row kernel first (profiles/r04_ffn_*.txt, dev/exp/mb_rowblock.py ffn4, dev/exp/rb_ffn_stamps.py):
 //   * its workgroup lives 110 k cycles of which 65.5 k are MFMA issue -- staging 11-18 k before the first chunk exists, closing epilogue 12.5 k
@@ -390,9 +481,51 @@ constexpr int R5_STAT = R5_PC + 4 * 256;                               // s_mean
 constexpr int R5_FLAG = R5_STAT + 2 * R5_ROWS * 4;                     // full[3], empty[3], producer barrier
 constexpr int R5_B2 = R5_FLAG + 64;                                    // b_2 [512]
 constexpr int R5_LDS = R5_B2 + 2048;
-static_assert(R5_LDS <= 160 * 1024, "one workgroup per CU");
+constexpr int R5_PJS = R5_LDS;                                         // projection tail: per consumer wavefront (sum, sum of squares) of its 128 columns of every row [4][80]
+constexpr int R5_LDS_PJ = R5_PJS + 4 * R5_ROWS * 8;
+static_assert(R5_LDS_PJ <= 160 * 1024, "one workgroup per CU");
+static_assert(8 * RbGemmCfg<false, 5>::STG + 8 * 512 <= R5_SLOTS * R5_SLOT, "the tail's staging and constants fit the hidden ring");
 
-template <bool EXTRA, bool STAMPS>             // EXTRA: the optional bf16 copy / partial sums are written; STAMPS: the developer timeline (BOFI_RB_DBG & 16)
+// The projection tail of rb_ffn5_kernel<PROJ>: pj_y = W_pj . LN(y) + c_pj for the block the consumers just closed (bf16 rows back in the block's LDS, their
+// share of the row sums beside it), all eight wavefronts, chunks w, w + 8, ... as rb_gemm_kernel; staging and chunk constants live in the hidden ring.
+// The wavefront's first weight steps are requested before the barrier: the producers get here while the consumers still close.  Called at the END OF EACH
+// ROLE'S BRANCH (both reach the one barrier): behind the join of the two, the allocator spilled 43-340 registers in the feed-forward loops.
+template <int ROLE>      // (a different instruction stream per caller: identical tails of the two branches are merged behind their join, see above)
+__device__ __forceinline__ void rb_ffn5_proj_tail(const u32x4* pj_wp, const float* pj_c, const float* pj_cs, void* pj_y, int pj_ldy, int pj_N, int M, bf16x8 (&wb)[RB_PF * 4]) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_mean = reinterpret_cast<float*>(smem + R5_STAT);
+    float* s_rstd = s_mean + R5_ROWS;
+    int tid = threadIdx.x;
+    if constexpr (ROLE == 0) asm volatile("; projection tail, producers" : "+v"(tid));      // (nothing of the tail is computed ahead of the feed-forward loops and kept in registers through them)
+    else asm volatile("; projection tail, consumers" : "+v"(tid));
+    const int wave = tid >> 6, lane = tid & 63;
+    rb_prime<4>(pj_wp + (size_t)wave * (16 * 256) + lane, wb);
+    __syncthreads();
+    {   // every wavefront derives all 80 row statistics itself (the same values to the same words)
+        const float2* pjs = reinterpret_cast<const float2*>(smem + R5_PJS);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = i * 64 + lane;
+            if (r < R5_ROWS) {
+                const float2 p0 = pjs[r], p1 = pjs[R5_ROWS + r], p2 = pjs[2 * R5_ROWS + r], p3 = pjs[3 * R5_ROWS + r];
+                const float sm = (p0.x + p1.x) + (p2.x + p3.x), sq = (p0.y + p1.y) + (p2.y + p3.y);
+                const float mean = sm * (1.0f / 512.0f);
+                const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+                s_mean[r] = mean;
+                s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    RbGemmArgs ga{};
+    ga.wp = pj_wp; ga.c = pj_c; ga.cs = pj_cs; ga.y = pj_y; ga.ldy = pj_ldy; ga.M = M; ga.N = pj_N;
+    rb_gemm_chunks<false, 5>(ga, smem, smem + R5_HR, reinterpret_cast<float*>(smem + R5_HR + 8 * RbGemmCfg<false, 5>::STG), s_mean, s_rstd,
+                             (int)blockIdx.x * R5_ROWS, wave, lane, wave, 8, wb);
+}
+
+template <bool EXTRA, bool STAMPS, bool PROJ = false, bool ONE = PROJ>   // ONE: one block per workgroup (no block loop: nothing is kept for a next block); EXTRA: the optional bf16 copy / partial sums are written; STAMPS: the developer timeline (BOFI_RB_DBG & 16);
+                                                        // PROJ: the projection tail (a.pj_*; one block per workgroup)
 __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;                                  // [80][512] bf16, swizzled, row pitch 1 024 B
@@ -445,7 +578,7 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
         float* mycst = reinterpret_cast<float*>(smem + R5_PC) + w4 * 64;
         unsigned q = 0, pb = 0;                                // chunks handed over so far / producer-barrier generation
 #pragma unroll 1
-        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        for (int blk = blockIdx.x; blk < nblocks; blk = ONE ? nblocks : blk + (int)gridDim.x) {      // (ONE: no back edge, nothing kept for a next block)
             const int m0 = blk * R5_ROWS;
             if (blk != (int)blockIdx.x) { ++pb; rb_signal(flags + 6, lane); rb_wait_ge(flags + 6, 4u * pb); }      // every producer is through with the previous block
             RB3_STAMP(stamps, nst);                            // staging starts
@@ -513,6 +646,7 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
                 if (!(c & 1)) RB3_STAMP(stamps, nst);          // chunk handed over
             }
         }
+        if constexpr (PROJ) rb_ffn5_proj_tail<0>(a.pj_wp, a.pj_c, a.pj_cs, a.pj_y, a.pj_ldy, a.pj_N, a.M, wbuf);      // (the weights fly while the consumers close the block)
     } else {
         const int nsteps = nch * 4;
         const int er = lane >> 3, ec = lane & 7;               // closing layout: row it*8 + er of a 16-row tile, 16-byte piece ec of its 32 columns
@@ -529,9 +663,9 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
         }
         unsigned q = 0;
 #pragma unroll 1
-        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        for (int blk = blockIdx.x; blk < nblocks; blk = ONE ? nblocks : blk + (int)gridDim.x) {      // (ONE: no back edge, nothing kept for a next block)
             const int m0 = blk * R5_ROWS, rows_live = min(R5_ROWS, a.M - m0);
-            const int blk_next = blk + (int)gridDim.x;
+            const int blk_next = ONE ? nblocks : blk + (int)gridDim.x;
 #pragma unroll 1
             for (int c = 0; c < nch; ++c, ++q) {
                 const unsigned slot = q % R5_SLOTS, round = q / R5_SLOTS;
@@ -576,8 +710,13 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
             unsigned char* sw = smem + R5_CST + ws * R5_CSTW + lv * 144 + gv * 16;
             const unsigned char* sr = smem + R5_CST + ws * R5_CSTW + erv * 144 + ecv * 16;
             const float* b2l = reinterpret_cast<const float*>(smem + R5_B2) + ws * 128 + ecv * 4;
+            // (projection tail: the closed rows also go back into the block as bf16 -- every producer is through with it once the last chunk is full --
+            // and the wavefront's share of their LayerNorm sums into LDS)
+            unsigned char* xw = smem + erv * 1024 + (ecv & 1) * 8;
+            const int xc = ws * 16 + (ecv >> 1);
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
+                float ps1[2] = {0.f, 0.f}, ps2[2] = {0.f, 0.f};
                 const float* xn = a.x + (size_t)min(blk_next * R5_ROWS + mt * 16 + lv, a.M - 1) * a.ldx + ws * 128 + gv * 4;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {               // columns qq*32 .. +31 of the wavefront's 128: fragments 2 qq, 2 qq + 1
@@ -606,6 +745,11 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
                         const float4 o = make_float4(sv[it].x + bb.x, sv[it].y + bb.y, sv[it].z + bb.z, sv[it].w + bb.w);
                         const bool live = rq < rows_live;
                         if (live) *reinterpret_cast<float4*>(yq + qq * 32) = o;
+                        if constexpr (PROJ) {                 // block row mt*16 + it*8 + er (its low four bits: it*8 + er), 16-byte chunk xc + qq*4
+                            *reinterpret_cast<uint2*>(xw + (mt * 16 + it * 8) * 1024 + (((xc + qq * 4) ^ (it * 8 + erv)) << 4)) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                            ps1[it] += (o.x + o.y) + (o.z + o.w);
+                            ps2[it] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                        }
                         if constexpr (EXTRA) {
                             const size_t m = live ? (size_t)(m0 + rq) : 0;
                             const int cb = ws * 128 + qq * 32 + ecv * 4;
@@ -618,10 +762,18 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
                     }
                     __builtin_amdgcn_wave_barrier();           // (the next group rewrites the staging rows)
                 }
+                if constexpr (PROJ) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const float s1 = oct_sum(ps1[it]), s2 = oct_sum(ps2[it]);
+                        if (!ecv) reinterpret_cast<float2*>(smem + R5_PJS)[ws * R5_ROWS + rr + it * 8] = make_float2(s1, s2);
+                    }
+                }
                 yp += 2 * ystep; rr += 16;
             }
             RB3_STAMP(stamps, nst);                            // block closed
         }
+        if constexpr (PROJ) rb_ffn5_proj_tail<1>(a.pj_wp, a.pj_c, a.pj_cs, a.pj_y, a.pj_ldy, a.pj_N, a.M, wbuf);
     }
     if (stamps && nst < 126) {
         g_rb_stamps[stamp_base + nst] = 0ull;                   // terminator
@@ -639,26 +791,36 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
         attr_set = true;
     }
     // knobs (read again after bofi_reload_env): BOFI_RB_FFN_V = 5 (default): 80-row blocks -- +3 % on the decode with launches in flight; 2: one
     // 64-row block per workgroup (round 3's kernel) -- 6-12 us faster per launch when ONE decode runs alone (62 against 68 us at 11 520 rows);
     // BOFI_RB_FFN_BPW = row blocks a workgroup of the 80-row kernel walks (default 1; grid = blocks / that)
-    static int env_seen = -1, version = 5, bpw = 1, v5_rows = 0, forced = 0;
+    static int env_seen = -1, version = 5, bpw = 1, v5_rows = 0, forced = 0, one_on = 1;
     if (env_seen != g_env_generation) {
         const char* e = getenv("BOFI_RB_FFN_V"); version = e ? atoi(e) : 5; forced = e != nullptr;
         e = getenv("BOFI_RB_FFN_BPW"); bpw = e ? max(1, atoi(e)) : 1;
+        e = getenv("BOFI_RB_FFN_ONE"); one_on = e ? atoi(e) : 1;           // 0: the block-walking build of the kernel also at one block per workgroup
         e = getenv("BOFI_RB_FFN_V5_ROWS"); v5_rows = e ? atoi(e) : 0;      // rows from which the 80-row kernel runs (below: the 64-row kernel)
         env_seen = g_env_generation;
     }
     RbFfnArgs b = a;
     { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
-    if (version == 2 || a.M < v5_rows || (a.alone && !forced)) hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
+    if (a.pj_wp) {                                            // with the projection tail: the 80-row kernel, one block per workgroup
+        if (!a.pj_c || !a.pj_cs || !a.pj_y || a.pj_N < 512 || a.pj_N % 64 || a.pj_ldy % 8 || a.yb || a.stats_out) return BOFI_ERR_ARG;
+        hipLaunchKernelGGL((rb_ffn5_kernel<false, false, true>), dim3((a.M + R5_ROWS - 1) / R5_ROWS), dim3(512), R5_LDS_PJ, st, b);
+        g_gemm_flops += 2.0 * a.M * 512.0 * a.pj_N;
+    } else if (version == 2 || a.M < v5_rows || (a.alone && !forced)) hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
     else {
         const int grid = ((a.M + R5_ROWS - 1) / R5_ROWS + bpw - 1) / bpw;
-        if (a.yb || a.stats_out) hipLaunchKernelGGL((rb_ffn5_kernel<true, false>), dim3(grid), dim3(512), R5_LDS, st, b);
+        if ((a.yb || a.stats_out) && bpw == 1 && one_on) hipLaunchKernelGGL((rb_ffn5_kernel<true, false, false, true>), dim3(grid), dim3(512), R5_LDS, st, b);
+        else if (a.yb || a.stats_out) hipLaunchKernelGGL((rb_ffn5_kernel<true, false>), dim3(grid), dim3(512), R5_LDS, st, b);
         else if (b.dbg & 16) hipLaunchKernelGGL((rb_ffn5_kernel<false, true>), dim3(grid), dim3(512), R5_LDS, st, b);
+        else if (bpw == 1 && one_on) hipLaunchKernelGGL((rb_ffn5_kernel<false, false, false, true>), dim3(grid), dim3(512), R5_LDS, st, b);
         else hipLaunchKernelGGL((rb_ffn5_kernel<false, false>), dim3(grid), dim3(512), R5_LDS, st, b);
     }
     g_gemm_flops += 4.0 * a.M * 512.0 * a.dff;
@@ -991,94 +1153,6 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
 // the projections are bound by weight bytes per row.  128 rows per block halve them (128 KB of LDS for the block, 16 rows of staging per
 // wavefront at a time, operands read four tiles at a time to stay within 256 registers).
 template <bool F32OUT, int MT>
-struct RbGemmCfg {
-    static constexpr int BR = MT * 16;                          // rows per block
-    static constexpr int SP = F32OUT ? 272 : 144;               // staging row pitch (bytes): 64 columns + 16 B
-    static constexpr int TPS = MT == 8 ? 1 : MT == 6 ? (F32OUT ? 1 : 2) : (F32OUT ? 2 : 4);      // row tiles staged at a time
-    static constexpr int STG = TPS * 16 * SP;                   // staging bytes per wavefront
-    static constexpr int XT = BR * 1024;
-    static constexpr int STAT = XT + 8 * STG;                   // s_mean[BR], s_rstd[BR]
-    static constexpr int CST = STAT + BR * 8;                   // per wavefront [2][64]: c | cs of the current chunk
-    static constexpr int LDS = CST + 8 * 512;
-};
-
-template <bool F32OUT, int MT>
-__device__ __forceinline__ void rb_gemm_chunks(const RbGemmArgs& a, const unsigned char* blk, unsigned char* stage_all, float* cst, const float* s_mean,
-                                               const float* s_rstd, int m0, int wave, int lane, int ch0, int chstep, bf16x8 (&wb)[RB_PF * 4]) {
-    using Cfg = RbGemmCfg<F32OUT, MT>;
-    constexpr int SP = Cfg::SP, TPS = Cfg::TPS;
-    const int l15 = lane & 15, g = lane >> 4, nchunks = a.N >> 6;
-    auto seg = [&](int ch) { return a.wp + (size_t)ch * (16 * 256) + lane; };
-    constexpr bool STATS_IN_REGS = MT <= 6;                    // (128-row blocks: the 16 statistics registers are what the accumulators need -- read per pass from LDS)
-    float mu[STATS_IN_REGS ? MT : 1], rs[STATS_IN_REGS ? MT : 1];
-    if constexpr (STATS_IN_REGS) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { mu[mt] = s_mean[mt * 16 + l15]; rs[mt] = s_rstd[mt * 16 + l15]; }
-    }
-    const int lbase = rb_lane_base(l15, g);
-    unsigned char* stage = stage_all + wave * Cfg::STG;
-    int nstamp = 0;
-    float* mycst = cst + wave * 128;
-    const int rows_live = min(Cfg::BR, a.M - m0);
-
-#pragma unroll 1
-    for (int ch = ch0; ch < nchunks; ch += chstep) {
-        // this chunk's column constants: requested now (older than the weight prefetch), parked in LDS at the epilogue
-        const float cv = a.c[ch * 64 + lane], csv = a.cs[ch * 64 + lane];
-        f32x4 acc[4][MT];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb_segment<MT, 4, RB_PF, (MT > 4 ? MT / 2 : MT)>(seg(ch), seg(ch + chstep < nchunks ? ch + chstep : ch), wb, blk, lbase, acc);
-        if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp);            // chunk's MFMAs issued
-        mycst[lane] = cv; mycst[64 + lane] = csv;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // (the row pointers of the stores hang on a lane value the compiler cannot see through and advance by additions: as invariants of the chunk
-        // loop they are hoisted above it -- two registers per store -- and the accumulators spill)
-        constexpr int LPR = F32OUT ? 16 : 8, RPI = 64 / LPR;
-        int lnv = lane;
-        asm volatile("" : "+v"(lnv));
-        int rrow = lnv / LPR;                                  // row of the block this lane stores next
-        unsigned char* yp = static_cast<unsigned char*>(a.y) + ((size_t)(m0 + rrow) * a.ldy + ch * 64) * (F32OUT ? 4 : 2) + (lnv % LPR) * 16;
-        const size_t ystep = (size_t)RPI * a.ldy * (F32OUT ? 4 : 2);
-        const unsigned char* srd = stage + rrow * SP + (lnv % LPR) * 16;
-#pragma unroll
-        for (int pass = 0; pass < MT / TPS; ++pass) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float4 cc = *reinterpret_cast<const float4*>(mycst + nt * 16 + g * 4);
-                const float4 cs = *reinterpret_cast<const float4*>(mycst + 64 + nt * 16 + g * 4);
-#pragma unroll
-                for (int mh = 0; mh < TPS; ++mh) {
-                    const int mt = pass * TPS + mh;
-                    const f32x4 t = acc[nt][mt];
-                    const float mu_ = STATS_IN_REGS ? mu[STATS_IN_REGS ? mt : 0] : s_mean[mt * 16 + l15], rs_ = STATS_IN_REGS ? rs[STATS_IN_REGS ? mt : 0] : s_rstd[mt * 16 + l15];
-                    float v0 = rs_ * (t[0] - mu_ * cs.x) + cc.x, v1 = rs_ * (t[1] - mu_ * cs.y) + cc.y;
-                    float v2 = rs_ * (t[2] - mu_ * cs.z) + cc.z, v3 = rs_ * (t[3] - mu_ * cs.w) + cc.w;
-                    if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                    unsigned char* sp = stage + (mh * 16 + l15) * SP + (nt * 16 + g * 4) * (F32OUT ? 4 : 2);
-                    if constexpr (F32OUT) *reinterpret_cast<float4*>(sp) = make_float4(v0, v1, v2, v3);
-                    else *reinterpret_cast<uint2*>(sp) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // whole row pieces: bf16 8 lanes x 16 B = a row's 128 B (8 rows per instruction); float32 16 lanes x 16 B = 256 B (4 rows)
-#pragma unroll
-            for (int it = 0; it < TPS * 16 / RPI; ++it, yp += ystep, rrow += RPI) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(srd + it * RPI * SP);
-                if (rrow < rows_live) *reinterpret_cast<u32x4*>(yp) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (nstamp < 8) RB_STAMP(a.dbg, wave, lane, 2 * nstamp + 1);        // chunk stored
-        ++nstamp;
-    }
-}
-
-template <bool F32OUT, int MT>
 __global__ __launch_bounds__(512) void rb_gemm_kernel(RbGemmArgs a) {
     using Cfg = RbGemmCfg<F32OUT, MT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1218,5 +1292,16 @@ extern "C" int bofi_ffn_block(const float* x, int ldx, const void* w1p, const fl
     bofi::RbFfnArgs a{};
     a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
     a.yb = (bofi::bf16_t*)yb; a.stats_out = stats_out; a.M = M; a.dff = dff;
+    return bofi::launch_rb_ffn(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_ffn_linear_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2, float* y,
+                                     int ldy, int M, int dff, const void* pj_wp, const float* pj_c, const float* pj_cs, void* pj_y, int pj_ldy, int pj_N,
+                                     void* stream) {
+    if (!pj_wp) return BOFI_ERR_ARG;
+    bofi::RbFfnArgs a{};
+    a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
+    a.M = M; a.dff = dff;
+    a.pj_wp = (const bofi::u32x4*)pj_wp; a.pj_c = pj_c; a.pj_cs = pj_cs; a.pj_y = pj_y; a.pj_ldy = pj_ldy; a.pj_N = pj_N;
     return bofi::launch_rb_ffn(a, (hipStream_t)stream);
 }

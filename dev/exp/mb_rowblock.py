@@ -165,9 +165,65 @@ def train_shapes():
             print(f"M {M:5d} N {N:5d} K 512: tiled bf16->f32 {t_tiled:6.2f} us | row-block f32->f32 {t_rb32:6.2f} us | row-block f32->bf16 {t_rb16:6.2f} us", flush=True)
 
 
+def ffn_proj(M, N, nstr=1, nl=12):
+    """The feed-forward sublayer + the projection that reads its output: two launches (ffn_block, linear_block) against the one fused launch
+    (ffn_linear_block); nstr streams replaying graphs of nl sublayers at once (1 = alone)."""
+    res = {}
+    ws = []
+    for _ in range(2):
+        w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+        wj = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        ws.append((pack(w1), torch.randn(dff, device=dev), w1.float().sum(1), pack(w2), torch.randn(d, device=dev), pack(wj), torch.randn(N, device=dev), wj.float().sum(1)))
+    xs = [[torch.randn(M, d, device=dev) for _ in range(2)] for _ in range(nstr)]
+    ps = [[torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2)] for _ in range(nstr)]
+    streams = [torch.cuda.Stream() for _ in range(nstr)]
+    for fused in (0, 1):
+        graphs = []
+        for si, st in enumerate(streams):
+            def run(j):
+                w1p, c1, cs1, w2p, b2, wjp, cj, csj = ws[j % 2]
+                x, pj = xs[si][j % 2], ps[si][j % 2]
+                if fused:
+                    H.check(H.lib().bofi_ffn_linear_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, M, dff,
+                                                          H.ptr(wjp), H.ptr(cj), H.ptr(csj), H.ptr(pj), N, N, H.stream_ptr()))
+                else:
+                    H.check(H.lib().bofi_ffn_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, None, None, M, dff, H.stream_ptr()))
+                    H.check(H.lib().bofi_linear_block(H.ptr(x), d, H.ptr(wjp), H.ptr(cj), H.ptr(csj), H.ptr(pj), N, 0, M, N, 0, H.stream_ptr()))
+            with torch.cuda.stream(st):
+                run(0); torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    for j in range(nl):
+                        run(j)
+                graphs.append(g)
+        def replay_all(n):
+            for _ in range(n):
+                for st, g in zip(streams, graphs):
+                    with torch.cuda.stream(st):
+                        g.replay()
+        replay_all(2); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for st in streams:
+            st.wait_event(e0)
+        replay_all(10)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        e1.record(); torch.cuda.synchronize()
+        res[fused] = e0.elapsed_time(e1) * 1e3 / 10 / nl / nstr
+    fl = (4.0 * M * d * dff + 2.0 * M * d * N)
+    print(f"ffn + projection M {M:6d} N {N:5d} x {nstr} streams: two launches {res[0]:7.2f} us ({fl / res[0] * 1e-6:6.1f} TFLOP/s) | one launch {res[1]:7.2f} us "
+          f"({fl / res[1] * 1e-6:6.1f} TFLOP/s)  per sublayer, aggregate", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "ffn"
-    if what == "ffn":
+    if what == "ffnproj":
+        for M, N in ((11520, 1536), (11520, 7168), (6400, 1536)):
+            for n in (1, 2, 4):
+                ffn_proj(M, N, n)
+    elif what == "ffn":
         for M in (11520, 6400, 2304, 1280, 64):
             ffn(M)
     elif what == "ffn4":

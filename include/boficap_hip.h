@@ -430,6 +430,13 @@ int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* 
                     int ldx, float* y, int ldy, void* yb, float* stats_out, void* stream);
 int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
                    float* y, int ldy, void* yb, float* stats_out, int M, int dff, void* stream);
+/* bofi_ffn_linear_block: bofi_ffn_block followed by bofi_linear_block on its output, ONE launch -- the feed-forward sublayer and the
+ *   LayerNorm-folded projection that reads the stream next (the next layer's q|k|v, TransformerModel.py:1454-1456 behind :1361-1377; after the
+ *   last encoder layer the stacked cross K|V): y as bofi_ffn_block, pj_y bf16 [M, pj_ldy] = W_pj' LN(y) + c_pj (pj_wp / pj_c / pj_cs as
+ *   bofi_linear_block's wp / c / cs; pj_N % 64 == 0, pj_N >= 512, pj_ldy % 8 == 0).  Each 80-row block is projected while it is still in LDS. */
+int bofi_ffn_linear_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
+                          float* y, int ldy, int M, int dff, const void* pj_wp, const float* pj_c, const float* pj_cs, void* pj_y,
+                          int pj_ldy, int pj_N, void* stream);
 
 /* Developer aid: copy one of the bounding iteration's workspace buffers ("by1", "byb", "st_b", "bq2", "bctx2", "by2", "bh", "by3")
  * into user memory (device to device, on `stream`). */

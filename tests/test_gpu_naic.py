@@ -635,3 +635,33 @@ def test_decodes_in_flight_hint_changes_kernels_not_results(engines):
         os.environ.pop("BOFI_RB_MIN_ROWS")
         H.lib().bofi_reload_env()
         eng.set_decodes_in_flight(0)
+
+
+def test_projection_tail_of_the_feed_forward_kernel_changes_launches_not_results(engines):
+    """BOFI_RB_FFN_PROJ: the next layer's q|k|v (after the last encoder layer the stacked cross K|V) computed by the feed-forward launch from each
+    closed block (rb_ffn5_kernel<PROJ>) against the separate projection launches: the residual stream is the same bit for bit, the projections differ
+    in the summation order of the LayerNorm statistics only, which flips bf16 roundings of a few q / k / v values: two bf16 results, each within the
+    bar of the float32 one (measured between them: 0.022, as between the 64- and 80-row kernel families) -- same layouts on nearly every image."""
+    from boficap_amd import hip as H
+    from boficap_amd import weights as W
+    import os
+    cfg, sd, eng = engines("full_b8", torch.bfloat16)
+    att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=77)).cuda().to(torch.bfloat16)
+    os.environ["BOFI_RB_MIN_ROWS"] = "0"
+    outs = {}
+    try:
+        for v in ("0", "1"):
+            os.environ["BOFI_RB_FFN_PROJ"] = v
+            H.lib().bofi_reload_env()
+            r = eng.decode_naic(att, strict_q1=False, graph=False)
+            torch.cuda.synchronize()
+            outs[v] = {k: r[k].clone() for k in ("seq", "phrase_length", "phrase_syn", "seq_logprob")}
+        a, b = outs["0"], outs["1"]
+        same = (a["phrase_length"] == b["phrase_length"]).all(1) & (a["phrase_syn"] == b["phrase_syn"]).all(1)
+        assert int(same.sum()) >= 60, int(same.sum())
+        d = (a["seq_logprob"][same] - b["seq_logprob"][same]).nan_to_num().abs().max()
+        assert 0 < float(d) < 4e-2, float(d)                                                                 # (> 0: the fused launches did run)
+    finally:
+        os.environ.pop("BOFI_RB_MIN_ROWS")
+        os.environ.pop("BOFI_RB_FFN_PROJ", None)
+        H.lib().bofi_reload_env()

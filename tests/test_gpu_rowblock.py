@@ -268,6 +268,54 @@ def test_linear_block_vs_reference_projection(H, M, N, f32out, relu):
     assert (got[:, :N] - ref).abs().max() < tol, (got[:, :N] - ref).abs().max()
 
 
+@pytest.mark.parametrize("M,dff,N", [(80, 2048, 1536), (700, 2048, 1536), (6400, 2048, 512), (333, 1024, 4096), (11520, 2048, 1536)])
+def test_ffn_linear_block_is_the_two_launches(H, M, dff, N, monkeypatch):
+    """bofi_ffn_linear_block (rb_ffn5_kernel<PROJ>): the residual stream is the 80-row feed-forward kernel's bit for bit; the projection of each closed
+    block (bf16 rows back in LDS, LayerNorm sums from the closing wavefronts) against the float64 reference and against bofi_linear_block on that
+    stream -- the two differ only in the order of the row sums behind the LayerNorm statistics."""
+    d = 512
+    g = _rng(M + dff + N)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w1, b1 = torch.randn(dff, d, generator=g) / math.sqrt(d), torch.randn(dff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, dff, generator=g) / math.sqrt(dff), torch.randn(d, generator=g) * 0.1
+    gain2, bln2 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    wj, bj = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g) * 0.1
+    w1f, c1, cs1 = _fold(w1, b1, gain, bln)
+    wjf, cj, csj = _fold(wj, bj, gain2, bln2)
+    xc = x.cuda()
+    w1p, w2p, wjp = pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda()), pack_frag(H, wjf.to(torch.bfloat16).cuda())
+    c1c, cs1c, b2c, cjc, csjc = c1.cuda(), cs1.cuda(), b2.cuda(), cj.cuda(), csj.cuda()
+    monkeypatch.setenv("BOFI_RB_FFN_V", "5")
+    H.lib().bofi_reload_env()
+    try:
+        y0 = torch.full((M, d), float("nan"), device="cuda")
+        H.check(H.lib().bofi_ffn_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y0), d, None, None, M, dff, H.stream_ptr()))
+        p0 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        H.check(H.lib().bofi_linear_block(H.ptr(y0), d, H.ptr(wjp), H.ptr(cjc), H.ptr(csjc), H.ptr(p0), N + 64, 0, M, N, 0, H.stream_ptr()))
+        y1 = torch.full((M, d), float("nan"), device="cuda")
+        p1 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        H.check(H.lib().bofi_ffn_linear_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y1), d, M, dff,
+                                              H.ptr(wjp), H.ptr(cjc), H.ptr(csjc), H.ptr(p1), N + 64, N, H.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(y1.cpu(), y0.cpu())
+        assert (p1.cpu()[:, N:].float() == 7.0).all()
+        a, b = p1.cpu()[:, :N].double(), p0.cpu()[:, :N].double()
+        assert (a - b).abs().max() <= 0.0625, (a - b).abs().max()            # a few results one bf16 step apart (|y| < 8) where the statistics' last bits differ
+        assert ((a - b).abs() > 0).double().mean() < 0.02
+        w_eff = wjf.double() / gain2.double()[None, :]
+        ref = _layer_norm64(y0.cpu(), gain2, bln2) @ w_eff.T + bj.double()
+        assert (a - ref).abs().max() < 6e-2, (a - ref).abs().max()
+        # in place, as the engine runs it
+        H.check(H.lib().bofi_ffn_linear_block(H.ptr(xc), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(xc), d, M, dff,
+                                              H.ptr(wjp), H.ptr(cjc), H.ptr(csjc), H.ptr(p0), N + 64, N, H.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(xc.cpu(), y0.cpu()) and torch.equal(p0.cpu().view(torch.int16), p1.cpu().view(torch.int16))
+    finally:
+        monkeypatch.delenv("BOFI_RB_FFN_V")
+        H.lib().bofi_reload_env()
+
+
 @pytest.mark.parametrize("M,N,relu", [(700, 1536, 0), (96, 64, 1), (6400, 512, 0), (333, 7168, 0)])
 def test_linear_block_rows_per_block_agree(H, M, N, relu, monkeypatch):
     """rb_gemm_kernel<MT>: 64-, 96- and 128-row blocks (BOFI_RB_GEMM_MT = 4 / 6 / 8) give every output element the same sums -- bit for bit
