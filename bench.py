@@ -160,7 +160,7 @@ def gemm_rooflines(dtype, dev, batches=1):
     row_block = dtype == torch.bfloat16 and m_fill >= rb_min
     if row_block:
         d, dff = 512, 2048
-        for name, M, N, f32out in (("cross K|V of all layers (kv_all)", m_enc, 7168, False), ("encoder q|k|v", m_enc, 1536, False),
+        for name, M, N, f32out in (("encoder q|k|v, first layer", m_enc, 1536, False), ("filling-pass q|k|v, first layer", m_fill, 1536, False),
                                    ("generator.proj (weight rows zero-padded 9491 -> 9600, float32 logits)", m_fill, 9600, True)):
             x = torch.randn(M, d, device=dev)
             w = (torch.randn(N, d, device=dev) / d ** 0.5).to(torch.bfloat16)
@@ -169,14 +169,25 @@ def gemm_rooflines(dtype, dev, batches=1):
             us = timed(lambda: H.check(lib.bofi_linear_block(H.ptr(x), d, H.ptr(wp), H.ptr(c), H.ptr(cs), H.ptr(y), N, 1 if f32out else 0, M, N, 0, H.stream_ptr())))
             n_alg = 9491 if f32out else N
             entry("rb_gemm_kernel (row-block projection, LayerNorm folded, float32 stream in)", f"{name}: M={M} N={n_alg} K=512", us, 2.0 * M * n_alg * d)
-        for name, M in (("encoder feed-forward sublayer (w_1, ReLU, w_2, residual)", m_enc), ("filling-pass feed-forward sublayer", m_fill)):
+        # the feed-forward sublayers: with launches in flight (the headline) each but the filling pass's last also computes the projection that reads
+        # its output next (the next layer's q|k|v; after the last encoder layer the stacked cross K|V) from the closed block -- one launch
+        for name, M, N in (("encoder feed-forward sublayer + next layer's q|k|v", m_enc, 1536), ("last encoder feed-forward sublayer + cross K|V of all layers", m_enc, 7168),
+                           ("filling-pass feed-forward sublayer + next layer's q|k|v", m_fill, 1536), ("filling-pass feed-forward sublayer, last layer", m_fill, 0)):
             x = torch.randn(M, d, device=dev)
             w1 = (torch.randn(dff, d, device=dev) / d ** 0.5).to(torch.bfloat16)
             w2 = (torch.randn(d, dff, device=dev) / dff ** 0.5).to(torch.bfloat16)
             w1p, w2p, c1, cs1, b2 = pack(w1), pack(w2), torch.zeros(dff, device=dev), w1.float().sum(1), torch.zeros(d, device=dev)
-            us = timed(lambda: H.check(lib.bofi_ffn_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, None, None, M, dff,
-                                                           H.stream_ptr())))
-            entry("rb_ffn5_kernel (row-block feed-forward sublayer, 80-row blocks)", f"{name}: M={M} d=512 d_ff=2048", us, 4.0 * M * d * dff)
+            if N:
+                wj = (torch.randn(N, d, device=dev) / d ** 0.5).to(torch.bfloat16)
+                wjp, cj, csj, pj = pack(wj), torch.zeros(N, device=dev), wj.float().sum(1), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+                us = timed(lambda: H.check(lib.bofi_ffn_linear_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, M, dff,
+                                                                      H.ptr(wjp), H.ptr(cj), H.ptr(csj), H.ptr(pj), N, N, H.stream_ptr())))
+                entry("rb_ffn5_kernel<projection tail> (row-block feed-forward sublayer on 80-row blocks + the LayerNorm-folded projection of each closed block)",
+                      f"{name}: M={M} d=512 d_ff=2048 N={N}", us, 4.0 * M * d * dff + 2.0 * M * d * N)
+            else:
+                us = timed(lambda: H.check(lib.bofi_ffn_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, None, None, M, dff,
+                                                               H.stream_ptr())))
+                entry("rb_ffn5_kernel (row-block feed-forward sublayer, 80-row blocks)", f"{name}: M={M} d=512 d_ff=2048", us, 4.0 * M * d * dff)
         return out
     for name, M, N, K in (("cross K|V of all layers (kv_all)", m_enc, 7168, 512), ("encoder FFN w_1", m_enc, 2048, 512),
                           ("encoder FFN w_2", m_enc, 512, 2048), ("generator.proj", m_fill, 9491, 512)):
