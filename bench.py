@@ -546,6 +546,21 @@ def run_rl(args, ctx, log, cpu=True):
         loss, rs, rn = tr.rl_step(att, None, score, sample_n=n)
     _barrier(world)
     elapsed = dp.reduce_scalar(time.perf_counter() - t0, "max", device=dev)
+    last_default = dict(tr._last_rl)
+    # the same step with the reference's estimator (opt.bofi_rl_reference_estimator: every token drawn from the gradient pass's own dropout-perturbed rows,
+    # one tape-free training forward per phrase): a few steps, reported beside the headline form
+    model.opt.bofi_rl_reference_estimator = True
+    tr.rl_step(att, None, score, sample_n=n)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        tr.rl_step(att, None, score, sample_n=n)
+    torch.cuda.synchronize(dev)
+    ref_ms = (time.perf_counter() - t1) / 3 * 1e3
+    ref_info = {"ms_per_step": round(ref_ms, 2), "drawn_rows_vs_gradient_pass_rows_max_abs": tr._last_rl["reference_gap"],
+                "training_forwards_per_step": tr._last_rl["training_forwards"]}
+    model.opt.bofi_rl_reference_estimator = False
+    tr._last_rl = last_default
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -569,7 +584,10 @@ def run_rl(args, ctx, log, cpu=True):
                       "images_per_step_per_gpu": n_img, "samples_per_image": n, "final_loss": round(float(loss), 5),
                       "saic_tokens_per_sample": round(float(tr._last_rl["saic_tokens"]), 2), "naic_tokens_per_sample": round(float(tr._last_rl["naic_tokens"]), 2),
                       "scorer": "host-side stand-in (the reference's CIDEr-D scorer is external)", "hip_graph": bool(graph),
-                      "active_iteration_share": round(share, 3)},
+                      "active_iteration_share": round(share, 3),
+                      "estimator": "sampler = inference engine (no dropout), gradient pass with dropout (DESIGN.md 7); reference_estimator = the reference's "
+                                   "own (loss_wrapper.py:193-209), opt.bofi_rl_reference_estimator",
+                      "reference_estimator": ref_info},
            "roofline": roof}
     if cpu and world == 1:
         _cpu_leg(res, lambda: cpu_baseline_rl(cfg, sd, n_img, n, budget_s=args.cpu_budget))

@@ -78,6 +78,7 @@ int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* t
                      int S, int V, int iter, hipStream_t s);
 // decoder rows of the phrases placed in iteration `iter` (image-major), and their count
 int launch_saic_rows(const BoundState& st, int B, int L, int S, int iter, int* rows, int* n_rows, hipStream_t s);
+int launch_saic_put_words(const BoundState& st, const SaicState& sa, const int64_t* seq, int B, int L, int S, hipStream_t s);
 int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, int S, int64_t* seq, int* phrase_num,
                        int* phrase_length, int64_t* phrase_syn, int* iters, hipStream_t s);
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,

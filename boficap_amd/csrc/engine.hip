@@ -1042,6 +1042,13 @@ int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end) {
     return BOFI_OK;
 }
 
+int bofi_engine_saic_put_words(bofi_engine_t* e, const int64_t* seq, int B, void* stream) {
+    g_err.clear();
+    if (!e || !seq) return fail(BOFI_ERR_ARG, "null argument");
+    if (B < 1 || B > e->cfg.max_batch || B != e->cur_B) return fail(BOFI_ERR_ARG, "saic_put_words: B must be the batch of the decode it continues");
+    return bofi::launch_saic_put_words(e->st, e->sa, seq, B, e->L, e->cfg.seq_length, (hipStream_t)stream);
+}
+
 int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed) {
     if (!e || !(temperature > 0.f)) return fail(BOFI_ERR_ARG, "temperature must be positive");
     e->sample_temperature = temperature;

@@ -662,6 +662,21 @@ __global__ void saic_export_kernel(BoundState st, SaicState sa, int B, int L, in
     }
 }
 
+// The tokens emitted so far replaced by the caller's (seq int64 [B, S], the layout of the exported seq): positions 1 .. last - 1 of sa.seq and of
+// the bounding step's input sa.ext_len.  Between two calls that each enqueue part of the loop (bofi_engine_set_saic_range): a caller that draws
+// the phrase's words itself -- from its own distribution over the same layout -- and lets the loop continue on THOSE words.
+__global__ void saic_put_words_kernel(BoundState st, SaicState sa, const int64_t* __restrict__ seq, int B, int L, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S) return;
+    const int b = i / S, p = i - b * S + 1;
+    if (p < st.last[b]) { const int t = (int)seq[i]; sa.seq[b * L + p] = t; sa.ext_len[b * L + p] = t; }
+}
+int launch_saic_put_words(const BoundState& st, const SaicState& sa, const int64_t* seq, int B, int L, int S, hipStream_t s) {
+    hipLaunchKernelGGL(saic_put_words_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, st, sa, seq, B, L, S);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, int S, int64_t* seq, int* phrase_num,
                        int* phrase_length, int64_t* phrase_syn, int* iters, hipStream_t s) {
     hipLaunchKernelGGL(saic_export_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, st, sa, B, L, S, seq, phrase_num, phrase_length,

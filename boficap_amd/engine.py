@@ -280,6 +280,13 @@ class BofiEngine:
             self._lib.bofi_engine_set_saic_range(self._h, 1, 0)
         return out
 
+    def saic_put_words(self, seq: torch.Tensor) -> None:
+        """Between two partial ``decode_saic`` calls (``it_range``): replace the tokens emitted so far by ``seq`` (int64 [B, S], the layout of
+        ``out["seq"]``) -- the loop continues on the caller's words (bofi_engine_saic_put_words)."""
+        if seq.dtype != torch.int64 or seq.dim() != 2 or seq.size(1) != self.cfg.seq_length or not seq.is_cuda or not seq.is_contiguous():
+            raise hip.BofiHipError("saic_put_words: contiguous int64 [B, seq_length] on the device")
+        hip.check(self._lib.bofi_engine_saic_put_words(self._h, hip.ptr(seq), int(seq.size(0)), hip.stream_ptr()), "bofi_engine_saic_put_words")
+
     def encode(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Encoder output (float32 [B, R, d]); also leaves memory + cross K/V in the engine workspace."""
         self._check_feats(att_feats, att_len)

@@ -750,6 +750,8 @@ class XETrainer:
         Returns (loss, mean SAIC score, mean NAIC score)."""
         from . import xe
         model = self.model
+        if getattr(model.opt, "bofi_rl_reference_estimator", False):
+            return self._rl_reference_step(att_feats, att_masks, score_fn, sample_n, temperature)
         fc = torch.zeros(att_feats.shape[0], 0, device=att_feats.device)
         was_training = model.training
         model.eval()                                           # sampling runs on the inference engine (no dropout)
@@ -806,6 +808,128 @@ class XETrainer:
             loss, m1, m2 = self._rl_forward_backward(b, att_masks, sample_n)
         self.reduce_and_step()
         return loss, m1, m2
+
+    def _rl_reference_step(self, att_feats, att_masks, score_fn, sample_n, temperature):
+        """The self-critical step with the REFERENCE's estimator (``opt.bofi_rl_reference_estimator``; loss_wrapper.py:193-209 calls
+        ``model(..., mode='sample')`` in train mode with the tape running and differentiates THAT pass): every sampled token is drawn from the
+        distribution the gradient pass differentiates -- the training forward's rows under this step's dropout masks -- instead of the inference
+        engine's dropout-free one.
+
+        The masks are counter-based (seed, site, element), so the training forward run twice on the same inputs gives the same rows bit for bit,
+        and a row of phrase i depends only on the layout and the words up to phrase i - 1 (key-prefix masks, row-wise sublayers).  So:
+          * non-autoregressive branch: the engine's bounding loop gives the layout (greedy heads: one per image, no gradient reaches it in the
+            reference either); one tape-free training forward gives the fill rows; the words are drawn from them;
+          * semi-autoregressive branch: the engine's loop runs ONE iteration per call (bofi_engine_set_saic_range): its bounding step lays the next
+            phrase out on the words so far; a tape-free training forward (same seed) gives that phrase's rows; its words are drawn from them and
+            handed back to the engine (bofi_engine_saic_put_words), whose next bounding step reads them -- core_SAIC's own process
+            (TransformerModel.py:1903-1984) with the fill distribution of the training pass;
+          * then the gradient pass: the same forward once more WITH the tape -- its rows at the drawn tokens are the rows they were drawn from
+            (``last_rl["reference_gap"]``, 0) --, new_self_critical on both branches, backward, all-reduce, Adam.
+        What stays different from the reference: the bound heads decide on the engine (no dropout in the bounding steps); they are argmax decisions
+        without gradient.  Cost: one training forward per phrase (no graph replay: the host scorer and the draws sit between the passes)."""
+        from . import xe
+        model, cfg = self.model, self.model.cfg
+        S, dev = cfg.seq_length, att_feats.device
+        eng = model.engine()
+        feats_in, lens_in = model._as_input(att_feats), model._att_len(att_masks)
+        B = feats_in.size(0)
+        N = B * sample_n
+        if N > model.max_batch:
+            raise hip.BofiHipError(f"{N} sampled rows exceed bofi_max_batch={model.max_batch}")
+        with torch.no_grad():
+            r = eng.decode_naic(feats_in, lens_in, strict_q1=model.strict_reference)
+            na = {k: r[k].repeat_interleave(sample_n, dim=0).contiguous() for k in ("phrase_length", "phrase_syn")}
+            na["seq"] = torch.zeros(N, S, dtype=torch.int64, device=dev)
+            feats_rep = feats_in.repeat_interleave(sample_n, dim=0).contiguous()
+            lens_rep = None if lens_in is None else lens_in.repeat_interleave(sample_n).contiguous()
+        self._fwd_calls += 1
+        step_word = getattr(self, "_step_word", None)
+        if step_word is not None:
+            step_word.fill_(self._fwd_calls)
+        base = int(getattr(model.opt, "seed", 0)) << 32
+        seed = base if step_word is not None else base + self._fwd_calls
+        gen = torch.Generator(device=dev)
+        gen.manual_seed((base + 0x5EED0000 + self._fwd_calls) & 0x7FFFFFFFFFFFFFFF)
+        armed = self.ops is not None and model.train_dtype == torch.bfloat16
+        self.bucket.zero_grad()
+        if armed:
+            self.ops.refresh_if_stale()
+            self.ops.launch_transposes()
+            xe._WEIGHTS["provider"] = self.ops
+        if self.grouped_dw:
+            xe._DEFER["list"] = []
+        P = xe.Params(model)
+        pos = torch.arange(S, device=dev)[None]
+
+        def rows_of(prep):
+            return xe.sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, sample_n=sample_n, training=model.training, seed=seed,
+                                                compute_dtype=model.train_dtype, step_word=step_word)
+
+        def draw(lp, mask, seq, drawn):
+            idx = mask.nonzero(as_tuple=True)
+            if idx[0].numel():
+                rows = lp[idx].float()
+                tok = torch.multinomial(torch.softmax(rows / temperature, dim=-1), 1, generator=gen).squeeze(1)
+                seq[idx] = tok
+                drawn[idx] = rows.gather(1, tok[:, None]).squeeze(1)
+
+        try:
+            prep_na = xe.rl_prepare(cfg, None, na, sample_n=sample_n, strict_q1=model.strict_reference, device=dev)
+            seq_s = torch.zeros(N, S, dtype=torch.int64, device=dev)
+            seq_n = torch.zeros(N, S, dtype=torch.int64, device=dev)
+            drawn_s = torch.zeros(N, S, device=dev)
+            drawn_n = torch.zeros(N, S, device=dev)
+            mask_s = torch.zeros(N, S, dtype=torch.bool, device=dev)
+            mask_n = pos < na["phrase_length"].long().sum(1)[:, None]
+            out = None
+            self._sample_calls_ref = getattr(self, "_sample_calls_ref", 0) + 1
+            passes = 0
+            for it in range(1, S + 1):
+                with torch.no_grad():
+                    out = eng.decode_saic(feats_rep, lens_rep, sample=(temperature, base + self._sample_calls_ref), it_range=(it, it), out=out, want_logprob=False)
+                    if int(out["bound_iters"]) < it:                     # no caption was open in this iteration: the loop is through
+                        break
+                    pl = out["phrase_length"].long()
+                    prep = xe.rl_prepare(cfg, {"seq": seq_s, "phrase_length": pl, "phrase_syn": out["phrase_syn"]}, None, sample_n=sample_n,
+                                         strict_q1=model.strict_reference, device=dev)
+                    prep.update(prep_na)
+                    lp_s, lp_n = rows_of(prep)
+                    passes += 1
+                    start = pl[:, :it - 1].sum(1)[:, None]
+                    new = (pos >= start) & (pos < start + pl[:, it - 1:it])
+                    draw(lp_s, new, seq_s, drawn_s)
+                    mask_s |= new
+                    eng.saic_put_words(seq_s)
+                    if it == 1:
+                        draw(lp_n, mask_n, seq_n, drawn_n)
+            saic = {"seq": seq_s, "phrase_length": out["phrase_length"], "phrase_syn": out["phrase_syn"]}
+            s_saic, s_naic = score_fn(seq_s.cpu()), score_fn(seq_n.cpu())
+            prep = xe.rl_prepare(cfg, saic, None, sample_n=sample_n, strict_q1=model.strict_reference, device=dev)
+            prep.update(prep_na)
+            sc_s = torch.as_tensor(s_saic, dtype=torch.float32).to(dev)
+            sc_n = torch.as_tensor(s_naic, dtype=torch.float32).to(dev)
+            lp_saic, lp_naic = rows_of(prep)                              # the gradient pass: the same rows, with the tape
+            with torch.no_grad():
+                g_s = (lp_saic.detach().float().gather(2, seq_s[..., None]).squeeze(2) - drawn_s)[mask_s]
+                g_n = (lp_naic.detach().float().gather(2, seq_n[..., None]).squeeze(2) - drawn_n)[mask_n]
+                gap = max(float(g_s.abs().max()) if g_s.numel() else 0.0, float(g_n.abs().max()) if g_n.numel() else 0.0)
+            l1, r1 = xe.new_self_critical(lp_saic, seq_s, sc_s, sample_n)
+            l2, r2 = xe.new_self_critical(lp_naic, seq_n, sc_n, sample_n)
+            loss = l1 + l2
+            if self.rl_kl:
+                loss = loss + xe.rl_kl_term(lp_naic, lp_saic, seq_s)
+            loss.backward()
+            xe.flush_weight_grads()
+        finally:
+            xe._DEFER["list"] = None
+            if armed:
+                xe._WEIGHTS["provider"] = None
+                self.ops.end_step()
+        self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean(),
+                         "active_share": min(S, int(out["phrase_num"].max()) + 1) / S, "reference_gap": gap, "training_forwards": passes + 1,
+                         "seq_saic": seq_s, "seq_naic": seq_n, "phrase_length_saic": out["phrase_length"], "phrase_syn_saic": out["phrase_syn"]}
+        self.reduce_and_step()
+        return loss.detach(), r1.mean(), r2.mean()
 
     def _rl_forward_backward(self, b, att_masks, sample_n):
         """zero-grad, differentiable re-forward of the sampled captions, new_self_critical for both modes, backward (tensors in,

@@ -318,6 +318,12 @@ int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed)
  * exports again: [1, c] followed by [c + 1, seq_length] is the same computation as the whole loop.  Iterations past the last live one return
  * at once but still cost their launches; *bound_iters (live iterations so far) < c after [1, c] means the loop has ended. */
 int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end);
+/* Between two partial bofi_engine_decode_saic calls: the tokens emitted so far (positions before the end of the last placed phrase) are replaced by
+ * seq int64 [B, seq_length] (device memory, the layout of the exported seq), in the emitted caption and in the bounding step's input
+ * (extend_phrase_len, TransformerModel.py:1959-1966): the loop continues on the caller's words.  For a caller that draws each phrase itself over the
+ * engine's layout -- the self-critical step's reference-estimator mode draws from the TRAINING forward's dropout-perturbed distribution
+ * (loss_wrapper.py:193-209 samples in train mode), boficap_amd/trainer.py. */
+int bofi_engine_saic_put_words(bofi_engine_t* e, const int64_t* seq, int B, void* stream);
 /* Bounding iterations the following bofi_engine_decode_naic calls enqueue (core_NAIC's loop, TransformerModel.py:1843-1869; 0 = all seq_length,
  * the default).  The loop exits when every image is finished; enqueued iterations past that point return at once but still cost their five
  * launches.  With a cap c the decode is the reference's if and only if the loop ended within c iterations: *bound_iters (iterations in which

@@ -188,6 +188,13 @@ def test_rl_step_with_ragged_regions_and_bf16(weight_cache, manifest):
     model.train()
     loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
     assert torch.isfinite(loss)
+    # the reference-estimator form of the step on the same inputs: bf16 operands and ragged regions leave the drawn rows the gradient pass's rows
+    model.opt.bofi_rl_reference_estimator = True
+    try:
+        loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
+        assert torch.isfinite(loss) and tr._last_rl["reference_gap"] == 0.0, tr._last_rl["reference_gap"]
+    finally:
+        model.opt.bofi_rl_reference_estimator = False
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -328,3 +335,67 @@ def test_capped_semi_autoregressive_loop_with_its_continuation_equals_the_whole_
     assert before == (want if want < S else None)
     low = -(-(max(1, live - 5) + 2) // 4) * 4
     assert model.saic_cap() == (low if low < S else None) and low <= want
+
+
+def test_reference_estimator_draws_every_token_from_the_gradient_pass(weight_cache, manifest):
+    """opt.bofi_rl_reference_estimator: the reference samples in train mode and differentiates that same pass (loss_wrapper.py:193-209).  Here every
+    token of both branches is drawn from the training forward's rows under the step's dropout masks, phrase by phrase, and the gradient pass is that
+    forward once more with the tape: its rows at the drawn tokens ARE the rows they were drawn from (gap 0), and they are not the inference engine's
+    dropout-free rows."""
+    from boficap_amd import xe
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, model = _model(weight_cache, manifest)
+    opt = cfg.to_opt()
+    opt.noamopt, opt.learning_rate = False, 1e-4
+    model.opt.bofi_rl_reference_estimator = True
+    tr = XETrainer(model, opt)
+    att = _images().cuda()
+    w0 = tr.bucket.flat.clone()
+
+    def score(seq):
+        return (seq == 11).float().sum(1) / (seq > 0).float().sum(1).clamp(min=1)
+
+    model.train()
+    assert cfg.dropout > 0
+    n = 4
+    for _ in range(2):
+        loss, rs, rn = tr.rl_step(att, None, score, sample_n=n, temperature=1.0)
+        last = tr._last_rl
+        assert torch.isfinite(loss) and last["reference_gap"] == 0.0, last["reference_gap"]
+        assert last["training_forwards"] >= 3                                 # several phrases -> several tape-free forwards + the gradient pass
+        assert last["seq_saic"].shape == (att.size(0) * n, cfg.seq_length) and int((last["seq_saic"] > 0).sum()) > att.size(0)
+        assert int((last["seq_naic"] > 0).sum()) > 0
+    assert model.training and float((tr.bucket.flat - w0).abs().max()) > 0
+    length_w = dict(model.named_parameters())["model.length_predictor.Length_classifier2.weight"]
+    assert torch.equal(length_w.detach().cpu(), torch.from_numpy(sd["model.length_predictor.Length_classifier2.weight"]))
+    # the drawn captions' rows under dropout are not the dropout-free rows of the same captions
+    saic = {"seq": last["seq_saic"], "phrase_length": last["phrase_length_saic"], "phrase_syn": last["phrase_syn_saic"]}
+    with torch.no_grad():
+        a, _ = xe.sampled_logprobs(xe.Params(model), cfg, att, None, saic, None, sample_n=n, training=True, seed=12345)
+        b, _ = xe.sampled_logprobs(xe.Params(model), cfg, att, None, saic, None, sample_n=n, training=False)
+    live = last["seq_saic"] > 0
+    assert float((a - b)[live].abs().max()) > 1e-3
+
+
+def test_reference_estimator_cold_and_without_dropout_is_the_greedy_decode(weight_cache, manifest):
+    """The phrase-by-phrase process of the reference-estimator step (engine bounding step -> training-forward rows -> draw -> words handed back to the
+    engine) at temperature -> 0 in eval mode is core_SAIC's greedy decode (and the greedy fill of the non-autoregressive layout): layouts and tokens
+    equal the engine's own greedy results."""
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, model = _model(weight_cache, manifest)
+    opt = cfg.to_opt()
+    opt.noamopt, opt.learning_rate = False, 1e-5
+    model.opt.bofi_rl_reference_estimator = True
+    tr = XETrainer(model, opt)
+    att = _images().cuda()
+    fc = torch.zeros(att.size(0), 0, device="cuda")
+    with torch.no_grad():
+        gs = model(fc, att, None, opt={"train_mode": "SAIC", "sample_method": "greedy"}, mode="sample")
+        gn = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "greedy"}, mode="sample")
+    n = 2
+    tr.rl_step(att, None, lambda seq: (seq > 0).float().mean(1), sample_n=n, temperature=1e-3)
+    last = tr._last_rl
+    assert torch.equal(last["phrase_length_saic"].long(), gs[3].long().repeat_interleave(n, 0))
+    assert torch.equal(last["seq_saic"], gs[0].repeat_interleave(n, 0))
+    assert torch.equal(last["seq_naic"], gn[0].repeat_interleave(n, 0))
+    assert last["reference_gap"] == 0.0
