@@ -691,7 +691,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     log(f"{len(streams)} concurrent streams")
     engines = [eng] + [eng.fork() for _ in range(len(streams) - 1)]
     for e in engines:
-        e.set_decodes_in_flight(len(engines))
+        e.set_decodes_in_flight(args.hint or len(engines))    # (--hint: a profiling run that serialises launches but wants the headline's kernel forms)
     # every launch in flight decodes features of its own (a rotation of the batches by whole batches, so the layouts and T stay
     # those of the probe): none of them finds another's features warm in a cache
     nb = att.size(0) // args.batch
@@ -922,6 +922,8 @@ def main():
     ap.add_argument("--refine", type=int, default=0, help="extra filling rounds (BASELINE config 5 uses 3 rounds at batch 256)")
     ap.add_argument("--inflight", type=int, default=4, help="decodes in flight on separate HIP streams (engine forks sharing the weights); "
                     "1 = strictly one decode at a time")
+    ap.add_argument("--hint", type=int, default=0, help="profiling: the decodes-in-flight hint handed to the engines whatever --inflight says (0 = --inflight): "
+                    "`--inflight 1 --hint 4` runs the headline's throughput kernel forms one launch at a time (counter passes serialise anyway)")
     ap.add_argument("--cu-partitions", type=int, default=1, help="experiment: confine stream k to CU set k %% P of P disjoint sets (the same CU range of "
                     "every XCD; set BOFI_GEMM_PERS_GRID to 256 / P with it); 1 = off")
     ap.add_argument("--coalesce", type=int, default=None, help="dynamic batching: C consecutive steps (batches of --batch images) share ONE engine "
