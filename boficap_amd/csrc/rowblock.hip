@@ -4,7 +4,9 @@
 //   rb_ffn5_kernel       x <- x + w_2 . relu(w_1 . LN(x) + b_1) + b_2      (PositionwiseFeedForward behind SublayerConnection,
 //   (rb_ffn2_kernel)     reference TransformerModel.py:1477-1478, 1361-1377): 80 (64) rows per workgroup; the 2 048-wide hidden rows
 //                        never leave the CU (a ring in LDS between producer and consumer wavefronts), the row statistics of the LayerNorm
-//                        are computed while the block is staged; one launch instead of two GEMMs, no hidden tensor in HBM.
+//                        are computed while the block is staged; one launch instead of two GEMMs, no hidden tensor in HBM.  With the projection
+//                        tail (rb_ffn5_kernel<PROJ>, bofi_ffn_linear_block) the same launch also computes the LayerNorm-folded projection that
+//                        reads the sublayer's output next -- the next layer's q|k|v (:1454-1456), the stacked cross K|V -- from each closed block.
 //   rb_attn_kernel       x <- x + W_o . attention(q, k, v) + b_o             (MultiHeadedAttention.forward :1454-1467 behind the
 //                        sublayer's residual): a workgroup owns G images, wavefront = (image, head); the heads' outputs meet in LDS and
 //                        the output projection runs on them in place: one launch instead of attention + GEMM, no ctx tensor.
@@ -22,7 +24,7 @@
 //     (the compiler's own vmcnt counting; a scheduling barrier per step keeps the loads where they are written);
 //   * the activation block sits in LDS with its 16-byte chunks XOR-swizzled by row, so the ds_read_b128 of an MFMA operand
 //     (16 rows x 64 B) is conflict-free.
-// Measured on MI355X: tools/exp/dw_gemm_probe.hip (the bare stream + MFMA loop), profiles/r03_*.
+// Measured on MI355X: dev/exp/dw_gemm_probe.hip (the bare stream + MFMA loop), profiles/r03_*, profiles/r04_*.
 #include <cstdlib>
 
 #include "bofi_common.h"
