@@ -156,6 +156,18 @@ struct PackLinArgs {
     float* bout; float* cs;
 };
 int launch_pack_lin(const PackLinArgs& a, void* wout, int dtype, hipStream_t st);
+// the whole refresh of an engine's Linears as ONE launch each for the packed weights and for their fragment-major copies, and one for the
+// small float32 vectors (norm vectors, head layers): descriptor tables in device memory (repack.hip)
+struct PackLinDesc {
+    PackLinArgs a; void* wout; void* wp;          // wp: fragment-major copy of wout [Npad][K] bf16 (or null)
+    int Npad;
+    int row0;                                     // first row of this entry in the launch's row numbering (a multiple of 4)
+    int blk0;                                     // first 256-thread block of this entry in the fragment-major launch
+};
+struct CopyDesc { const float* src; float* dst; int n; int blk0; };      // blk0: first 256-element block in the launch
+int launch_pack_lin_multi(const PackLinDesc* tab_dev, int n_ent, int total_rows, int dtype, hipStream_t st);
+int launch_pack_frag_multi(const PackLinDesc* tab_dev, int n_ent, int total_blocks, hipStream_t st);
+int launch_copy_multi(const CopyDesc* tab_dev, int n_ent, int total_blocks, hipStream_t st);
 int launch_pack_heads(const float* lw1, const float* sw1, const float* lb1, const float* sb1, float* w1t, float* b1, int d, int hh, hipStream_t st);
 int launch_bound_table(const float* lut_syn, const float* lut_tok, const float* pe, float* xt, float* x0, float* x0_sa, int L, int d, int len_idx,
                        hipStream_t st);

@@ -255,6 +255,8 @@ struct bofi_engine {
     int cur_B = 0;
     bool is_fork = false;
     size_t n_weight_allocs = 0;          // allocs[0 .. n) are weights (owned by the parent), the rest workspace
+    // bofi_engine_refresh_device: descriptor tables of the batched repack launches (device copy, pinned staging, what was uploaded last)
+    void* rt_dev = nullptr; void* rt_pin = nullptr; size_t rt_bytes = 0; std::vector<char> rt_cache;
 
     // workspace of one in-flight decode (a forked engine has its own, and shares the weights)
     int alloc_workspace() {
@@ -893,6 +895,7 @@ void bofi_engine_destroy(bofi_engine_t* e) {
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->run_stream) (void)hipStreamDestroy(e->run_stream);
     for (void* p : e->allocs) (void)hipFree(p);
+    if (!e->is_fork) { if (e->rt_dev) (void)hipFree(e->rt_dev); if (e->rt_pin) (void)hipHostFree(e->rt_pin); }
     delete e;
 }
 
@@ -907,6 +910,7 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->cap_stream = nullptr;
     e->run_stream = nullptr;
     e->is_fork = true;
+    e->rt_dev = nullptr; e->rt_pin = nullptr; e->rt_bytes = 0; e->rt_cache.clear();
     e->dbg_part = nullptr;
     e->q1_group = 0;                             // per-call knobs are not inherited (the Python handle starts from the defaults)
     e->sample_temperature = 1.0f;
@@ -940,8 +944,16 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
         if (it->second.second != numel) { g_err = "weight " + name + " has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel); return nullptr; }
         return it->second.first;
     };
+    // Every Linear's repack (stack, fold the pre-norm, cast, column sums), the fragment-major copies and the small float32 vectors as THREE launches
+    // over descriptor tables in device memory (they were ~230 launches and copies: 1.5 ms of a training step that decodes with its current weights).
+    // The tables hold the caller's pointers: uploaded again only when one of them changed.
+    std::vector<bofi::PackLinDesc> lt;
+    std::vector<bofi::CopyDesc> ct;
+    int rows = 0, fblocks = 0, cblocks = 0;
+    auto add_copy = [&](const float* src, float* dst, int n) { ct.push_back(bofi::CopyDesc{src, dst, n, cblocks}); cblocks += (n + 255) / 256; };
     for (const auto& r : e->lin_recipes) {
-        bofi::PackLinArgs a{};
+        bofi::PackLinDesc dsc{};
+        bofi::PackLinArgs& a = dsc.a;
         a.nsrc = (int)r.prefixes.size(); a.n_each = r.n_each; a.K = r.K;
         if (a.nsrc > 16) return fail(BOFI_ERR_STATE, "too many stacked matrices");
         for (int i = 0; i < a.nsrc; ++i) {
@@ -955,33 +967,60 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
             if (!a.gain || !a.bln) return BOFI_ERR_STATE;
         }
         a.bout = r.out->b; a.cs = r.out->cs;
-        ENG_OK(bofi::launch_pack_lin(a, r.out->w, c.dtype, s));
-        if (r.out->wp) ENG_OK(bofi::launch_rb_pack_frag(r.out->w, r.out->wp, r.out->Npad, r.out->K, s));
+        if (!r.out->w || !a.bout || (a.gain && !a.cs)) return fail(BOFI_ERR_STATE, "refresh: a packed weight is missing");
+        dsc.wout = r.out->w; dsc.wp = r.out->wp; dsc.Npad = r.out->Npad;
+        dsc.row0 = rows; rows += (a.n_each * a.nsrc + 3) / 4 * 4;
+        dsc.blk0 = fblocks; if (dsc.wp) fblocks += (int)(((size_t)dsc.Npad * r.K / 8 + 255) / 256);
+        lt.push_back(dsc);
     }
     for (const auto& r : e->norm_recipes) {
         const float *g = get(r.prefix + ".a_2", r.d), *b = get(r.prefix + ".b_2", r.d);
         if (!g || !b) return BOFI_ERR_STATE;
-        ENG_HIP(hipMemcpyAsync(r.out->g, g, (size_t)r.d * 4, hipMemcpyDeviceToDevice, s));
-        ENG_HIP(hipMemcpyAsync(r.out->b, b, (size_t)r.d * 4, hipMemcpyDeviceToDevice, s));
+        add_copy(g, r.out->g, r.d);
+        add_copy(b, r.out->b, r.d);
     }
-    const float *ls = get("model.syn_embed.lut.weight", (int64_t)10 * d), *lt = get("model.tgt_embed.lut.weight", (int64_t)c.vocab * d);
-    if (!ls || !lt) return BOFI_ERR_STATE;
-    ENG_HIP(hipMemcpyAsync(e->lut_syn, ls, (size_t)10 * d * 4, hipMemcpyDeviceToDevice, s));
-    ENG_HIP(hipMemcpyAsync(e->lut_tok, lt, (size_t)c.vocab * d * 4, hipMemcpyDeviceToDevice, s));
+    const float *ls = get("model.syn_embed.lut.weight", (int64_t)10 * d), *lt_w = get("model.tgt_embed.lut.weight", (int64_t)c.vocab * d);
+    if (!ls || !lt_w) return BOFI_ERR_STATE;
+    add_copy(ls, e->lut_syn, 10 * d);
+    const float *lw1, *lb1, *sw1, *sb1;
     {
         const std::string lp = "model.length_predictor";
-        const float *lw1 = get(lp + ".Length_classifier1.weight", (int64_t)hh * d), *lb1 = get(lp + ".Length_classifier1.bias", hh);
-        const float *sw1 = get(lp + ".Syntactic_classifier1.weight", (int64_t)hh * d), *sb1 = get(lp + ".Syntactic_classifier1.bias", hh);
+        lw1 = get(lp + ".Length_classifier1.weight", (int64_t)hh * d); lb1 = get(lp + ".Length_classifier1.bias", hh);
+        sw1 = get(lp + ".Syntactic_classifier1.weight", (int64_t)hh * d); sb1 = get(lp + ".Syntactic_classifier1.bias", hh);
         const float *lw2 = get(lp + ".Length_classifier2.weight", (int64_t)20 * hh), *lb2 = get(lp + ".Length_classifier2.bias", 20);
         const float *sw2 = get(lp + ".Syntactic_classifier2.weight", (int64_t)10 * hh), *sb2 = get(lp + ".Syntactic_classifier2.bias", 10);
         if (!lw1 || !lb1 || !sw1 || !sb1 || !lw2 || !lb2 || !sw2 || !sb2) return BOFI_ERR_STATE;
         auto& h = e->heads;
-        ENG_OK(bofi::launch_pack_heads(lw1, sw1, lb1, sb1, const_cast<float*>(h.w1t), const_cast<float*>(h.b1), d, hh, s));
-        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.len_w2), lw2, (size_t)20 * hh * 4, hipMemcpyDeviceToDevice, s));
-        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.len_b2), lb2, 20 * 4, hipMemcpyDeviceToDevice, s));
-        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.syn_w2), sw2, (size_t)10 * hh * 4, hipMemcpyDeviceToDevice, s));
-        ENG_HIP(hipMemcpyAsync(const_cast<float*>(h.syn_b2), sb2, 10 * 4, hipMemcpyDeviceToDevice, s));
+        add_copy(lw2, const_cast<float*>(h.len_w2), 20 * hh); add_copy(lb2, const_cast<float*>(h.len_b2), 20);
+        add_copy(sw2, const_cast<float*>(h.syn_w2), 10 * hh); add_copy(sb2, const_cast<float*>(h.syn_b2), 10);
     }
+    {   // [PackLinDesc x n][CopyDesc x m] in one buffer
+        const size_t lb = lt.size() * sizeof(bofi::PackLinDesc), cb = ct.size() * sizeof(bofi::CopyDesc), bytes = lb + cb;
+        std::vector<char> img(bytes);
+        memcpy(img.data(), lt.data(), lb);
+        memcpy(img.data() + lb, ct.data(), cb);
+        if (img != e->rt_cache) {
+            ENG_HIP(hipStreamSynchronize(s));                 // (rare: a previous upload from the pinned buffer may still be in flight)
+            if (bytes > e->rt_bytes) {
+                if (e->rt_dev) (void)hipFree(e->rt_dev);
+                if (e->rt_pin) (void)hipHostFree(e->rt_pin);
+                e->rt_dev = e->rt_pin = nullptr; e->rt_bytes = 0;
+                ENG_HIP(hipMalloc(&e->rt_dev, bytes));
+                ENG_HIP(hipHostMalloc(&e->rt_pin, bytes, hipHostMallocDefault));
+                e->rt_bytes = bytes;
+            }
+            memcpy(e->rt_pin, img.data(), bytes);
+            ENG_HIP(hipMemcpyAsync(e->rt_dev, e->rt_pin, bytes, hipMemcpyHostToDevice, s));
+            e->rt_cache.swap(img);
+        }
+        const auto* ltab = static_cast<const bofi::PackLinDesc*>(e->rt_dev);
+        const auto* ctab = reinterpret_cast<const bofi::CopyDesc*>(static_cast<const char*>(e->rt_dev) + lb);
+        ENG_OK(bofi::launch_pack_lin_multi(ltab, (int)lt.size(), rows, c.dtype, s));
+        ENG_OK(bofi::launch_pack_frag_multi(ltab, (int)lt.size(), fblocks, s));
+        ENG_OK(bofi::launch_copy_multi(ctab, (int)ct.size(), cblocks, s));
+    }
+    ENG_HIP(hipMemcpyAsync(e->lut_tok, lt_w, (size_t)c.vocab * d * 4, hipMemcpyDeviceToDevice, s));
+    ENG_OK(bofi::launch_pack_heads(lw1, sw1, lb1, sb1, const_cast<float*>(e->heads.w1t), const_cast<float*>(e->heads.b1), d, hh, s));
     // the bound layer's input-independent tables (as at the end of finalize)
     ENG_OK(bofi::launch_bound_table(e->lut_syn, e->lut_tok, e->pe, e->d_xt, e->b_x0, e->b_x0_sa, L, d, c.len_idx, s));
     bofi_engine::LinOpt o; o.ln = &e->b_n0;

@@ -41,6 +41,87 @@ __global__ __launch_bounds__(256) void pack_lin_kernel(PackLinArgs a, T* __restr
     }
 }
 
+// ---- the batched forms (bofi_engine_refresh_device: ~230 launches and copies of a refresh as three): a workgroup finds its entry by bisection
+// over the table's first rows / blocks
+template <typename F>
+__device__ __forceinline__ int find_entry(int n_ent, int x, F first) {      // largest e with first(e) <= x
+    int lo = 0, hi = n_ent - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first(mid) <= x) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_lin_multi_kernel(const PackLinDesc* __restrict__ tab, int n_ent) {
+    const int lane = threadIdx.x & 63, grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int e = find_entry(n_ent, grow, [&](int i) { return tab[i].row0; });
+    const PackLinArgs& a = tab[e].a;
+    const int n = grow - tab[e].row0;
+    if (n >= a.n_each * a.nsrc) return;
+    const int src = n / a.n_each, r = n - src * a.n_each;
+    const float* row = a.w[src] + (size_t)r * a.K;
+    T* out = static_cast<T*>(tab[e].wout) + (size_t)n * a.K;
+    double c = 0.0, s = 0.0;
+    for (int k = lane; k < a.K; k += 64) {            // (the same sums in the same order as pack_lin_kernel)
+        float wv = row[k];
+        if (a.gain) {
+            c += (double)a.bln[k] * (double)wv;
+            wv = wv * a.gain[k];
+        }
+        ElemOps<T>::store(out + k, wv);
+        float rv = wv;
+        if constexpr (sizeof(T) == 2) rv = bf16_to_f32(f32_to_bf16(wv));
+        s += (double)rv;
+    }
+    if (a.gain) { c = wave_sum_f64(c); s = wave_sum_f64(s); }
+    if (lane == 0) {
+        a.bout[n] = (float)((double)a.b[src][r] + c);
+        if (a.gain) a.cs[n] = (float)s;
+    }
+}
+
+int launch_pack_lin_multi(const PackLinDesc* tab_dev, int n_ent, int total_rows, int dtype, hipStream_t st) {
+    if (!tab_dev || n_ent <= 0 || total_rows <= 0 || total_rows % 4) return BOFI_ERR_ARG;
+    if (dtype == BOFI_DT_F32) hipLaunchKernelGGL((pack_lin_multi_kernel<float>), dim3(total_rows / 4), dim3(256), 0, st, tab_dev, n_ent);
+    else hipLaunchKernelGGL((pack_lin_multi_kernel<bf16_t>), dim3(total_rows / 4), dim3(256), 0, st, tab_dev, n_ent);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// the fragment-major copies of every entry that has one (the layout of rowblock.hip's rb_pack_frag_kernel: [N/64 chunks][K/32 steps][4 tiles][64 lanes][8 bf16])
+typedef __attribute__((ext_vector_type(4))) uint32_t rp_u32x4;
+__global__ __launch_bounds__(256) void pack_frag_multi_kernel(const PackLinDesc* __restrict__ tab, int n_ent) {
+    const int e = find_entry(n_ent, (int)blockIdx.x, [&](int i) { return tab[i].blk0; });
+    const int N = tab[e].Npad, K = tab[e].a.K;
+    const size_t i = (size_t)((int)blockIdx.x - tab[e].blk0) * 256 + threadIdx.x;
+    if (!tab[e].wp || i >= (size_t)N * K / 8) return;
+    const int lane = (int)(i & 63), nt = (int)((i >> 6) & 3);
+    const size_t t = i >> 8;
+    const int kb = (int)(t % (size_t)(K >> 5)), chunk = (int)(t / (size_t)(K >> 5));
+    const int n = chunk * 64 + nt * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8;
+    static_cast<rp_u32x4*>(tab[e].wp)[i] = *reinterpret_cast<const rp_u32x4*>(static_cast<const bf16_t*>(tab[e].wout) + (size_t)n * K + k);
+}
+
+int launch_pack_frag_multi(const PackLinDesc* tab_dev, int n_ent, int total_blocks, hipStream_t st) {
+    if (!tab_dev || n_ent <= 0) return BOFI_ERR_ARG;
+    if (total_blocks <= 0) return BOFI_OK;
+    hipLaunchKernelGGL(pack_frag_multi_kernel, dim3(total_blocks), dim3(256), 0, st, tab_dev, n_ent);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyDesc* __restrict__ tab, int n_ent) {
+    const int e = find_entry(n_ent, (int)blockIdx.x, [&](int i) { return tab[i].blk0; });
+    const int i = ((int)blockIdx.x - tab[e].blk0) * 256 + threadIdx.x;
+    if (i < tab[e].n) tab[e].dst[i] = tab[e].src[i];
+}
+
+int launch_copy_multi(const CopyDesc* tab_dev, int n_ent, int total_blocks, hipStream_t st) {
+    if (!tab_dev || n_ent <= 0 || total_blocks <= 0) return BOFI_ERR_ARG;
+    hipLaunchKernelGGL(copy_multi_kernel, dim3(total_blocks), dim3(256), 0, st, tab_dev, n_ent);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 int launch_pack_lin(const PackLinArgs& a, void* wout, int dtype, hipStream_t st) {
     const int N = a.n_each * a.nsrc;
     if (N <= 0 || a.K <= 0 || a.nsrc > 16 || !wout || !a.bout || (a.gain && (!a.bln || !a.cs))) return BOFI_ERR_ARG;

@@ -138,13 +138,17 @@ class BofiEngine:
         if not self._finalized:
             raise hip.BofiHipError("the first load goes through load_state_dict")
         items = [(k, v) for k, v in named.items() if k != "model.pos_embed.pe"]
-        for k, v in items:
-            if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous():
-                raise hip.BofiHipError(f"{k}: contiguous float32 tensor on the HIP device expected")
-        n = len(items)
-        names = (C.c_char_p * n)(*[k.encode() for k, _ in items])
-        ptrs = (C.c_void_p * n)(*[v.data_ptr() for _, v in items])
-        numels = (C.c_int64 * n)(*[v.numel() for _, v in items])
+        # (a training loop refreshes after every optimiser step with the same tensors: the checked argument arrays are kept per set of addresses)
+        key = tuple(v.data_ptr() for _, v in items)
+        cached = getattr(self, "_refresh_args", None)
+        if cached is None or cached[0] != key:
+            for k, v in items:
+                if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous():
+                    raise hip.BofiHipError(f"{k}: contiguous float32 tensor on the HIP device expected")
+            n = len(items)
+            cached = self._refresh_args = (key, n, (C.c_char_p * n)(*[k.encode() for k, _ in items]), (C.c_void_p * n)(*key),
+                                           (C.c_int64 * n)(*[v.numel() for _, v in items]))
+        _, n, names, ptrs, numels = cached
         with torch.cuda.device(self.device):
             hip.check(self._lib.bofi_engine_refresh_device(self._h, n, names, ptrs, numels, hip.stream_ptr()), "bofi_engine_refresh_device")
 

@@ -321,19 +321,19 @@ def test_capped_semi_autoregressive_loop_with_its_continuation_equals_the_whole_
     for k in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
         assert torch.equal(rest[k], whole[k]), k
     assert torch.equal(rest["seq_logprob"].nan_to_num(0.0), whole["seq_logprob"].nan_to_num(0.0))
-    # the proposal follows the recent decodes, in steps of 4, and stays put (every value is a captured graph of its own)
+    # the proposal follows the recent decodes, in steps of 2, and stays put (every value is a captured graph of its own)
     model.__dict__.pop("_saic_recent", None); model.__dict__.pop("_saic_cap_cur", None)
     assert model.saic_cap() is None
     for _ in range(2):
         model.saic_finish(dict(ref_s))
-    want = -(-(live + 2) // 4) * 4
+    want = -(-(live + 2) // 2) * 2
     assert model.saic_cap() == (want if want < S else None)
     for _ in range(8):                                         # shorter captions for eight decodes in a row: one step down at most, only then
         r = dict(ref_s); r["bound_iters"] = torch.tensor([max(1, live - 5)], dtype=torch.int32)
         before = model.saic_cap()
         model.saic_finish(r)
     assert before == (want if want < S else None)
-    low = -(-(max(1, live - 5) + 2) // 4) * 4
+    low = -(-(max(1, live - 5) + 2) // 2) * 2
     assert model.saic_cap() == (low if low < S else None) and low <= want
 
 
