@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libboficap_hip.so")
-SOURCES = ["ln.hip", "gemm.hip", "gemm_glds.hip", "gemm_pers.hip", "attn.hip", "attn_bf16.hip", "naic.hip", "train_ops.hip", "gemm_tn.hip", "attn_bwd_mfma.hip", "repack.hip", "bound_ops.hip", "rowblock.hip", "engine.hip"]
+SOURCES = ["ln.hip", "gemm.hip", "gemm_glds.hip", "gemm_pers.hip", "attn.hip", "attn_bf16.hip", "naic.hip", "train_ops.hip", "gemm_tn.hip", "attn_bwd_mfma.hip", "repack.hip", "bound_ops.hip", "bound_loop.hip", "rowblock.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize -fno-vectorize: no v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32.  Measured on MI355X (round 2, dev/exp/dbg_step*.py): a wavefront
 # whose float32 FMA chains were packed by the SLP vectoriser (v_pk_fma_f32 with op_sel operands) computed wrong sums in lanes 48-63

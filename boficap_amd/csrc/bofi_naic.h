@@ -55,6 +55,39 @@ struct BoundTailArgs {
     float* dbg_part;                     // developer aid: [B][8*2*hh + d] partial hidden sums and the normalised row, or NULL
 };
 
+// arguments of the persistent bounding-loop kernel (bound_loop.hip): one workgroup per 16 images runs every iteration of core_NAIC's loop
+typedef __attribute__((ext_vector_type(4))) uint32_t bl_u32x4;
+struct BoundLoopArgs {
+    // fp16 fragment-major weights of the bounding layer (launch_pack_frag16) and their float32 epilogue vectors
+    const bl_u32x4* wo_self; const float* x0b;           // y1 = (x0 + bo_self) + Wo_self . ctx                  [512][512], [512]
+    const bl_u32x4* wq_src; const float* cq;              // q = Wq_src' . LN(y1) + c (sublayer[1].norm folded)   [512][512], [512]
+    const bl_u32x4* wo_src; const float* bo_src;          // y2 = y1 + Wo_src . ctx2 + bo
+    const bl_u32x4* w1; const float* c1;                  // h = relu(W1' . LN(y2) + c) (sublayer[2].norm folded) [dff][512], [dff]
+    const bl_u32x4* w2; const float* b2;                  // y3 = y2 + W2 . h + b2                                [512][dff], [512]
+    const bl_u32x4* wh; const float* ch;                  // heads' hidden layers, length | label, final norm folded [256][512] (rows >= 2*hh zero), [256]
+    const float* len_w2; const float* len_b2; const float* syn_w2; const float* syn_b2;      // output layers, float32 [20][hh], [20], [10][hh], [10]
+    const float* sctab; const float* vtab;                // launch_bound_tables: [L*10][8], [L*10][512] float32
+    const uint16_t* k; const uint16_t* v; int ldkv;       // cross-attention K and V rows of the images [B*R][ldkv] bf16
+    const int* att_len;                                   // regions per image (NULL: R each)
+    BoundState st;                                        // update != 0: slot state in (after launch_bound_init) and out
+    const int* ext_syn_in; const int* last_in;            // update == 0 (stage API): the slot layout to evaluate
+    float* len_logp; float* syn_logp;                     // optional [B][20] / [B][10]: log-probabilities of the first iteration run
+    int B, R, L, S, hh, dff;
+    int max_iters;                                        // iterations at most (seq_length; 1 for the stage API)
+    int update;                                           // apply the slot bookkeeping and loop until the group's images are finished
+};
+int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s);
+struct Pack16Entry { const float* w[2]; const float* gain; void* out; int n_each, nsrc, K, Npad, blk0; };      // blk0: set by the launcher
+struct Pack16Table { Pack16Entry e[8]; int n; };
+int launch_pack_frag16(const Pack16Table& t, hipStream_t s);
+struct BoundTablesArgs {
+    const float* xt; const float* x0; int rows;           // layer inputs [rows][512], the row-0 input [512]
+    const float* n0g; const float* n0b;                   // sublayer[0].norm
+    const float* wq; const float* bq; const float* wk; const float* bk; const float* wv; const float* bv;      // self_attn.linears.0-2, float32 [512][512]
+    float* q0; float* sctab; float* vtab;                 // out: [512], [rows][8], [rows][512]
+};
+int launch_bound_tables(const BoundTablesArgs& a, hipStream_t s);
+
 int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_idx, hipStream_t s);
 int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_num, int* phrase_length,
                         int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max = nullptr);

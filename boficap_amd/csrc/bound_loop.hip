@@ -1,0 +1,613 @@
+// The whole bounding loop of core_NAIC (reference TransformerModel.py:1833-1869) for a GROUP of 16 images as ONE persistent workgroup
+// (round 5): every iteration's five stages -- row-0 self-attention of the one-layer bounding network (LengthPredictor_UIC.forward
+// :357-383 -> DecoderLayer_UIC :283-297), its output projection, the cross-attention over the image's regions, the feed-forward
+// sublayer, the final norm + two heads + log-softmax + first-max pick (:375-383) and the slot bookkeeping (:1843-1869) -- run inside
+// the workgroup, which leaves the loop when its own 16 images are finished.  No grid barrier, no co-residency requirement: workgroups
+// never wait for each other.
+//
+// Why: as 5 launches per iteration (bound_ops.hip + naic.hip's tail kernel) the loop was 55 chip-wide bursts of 64-160 workgroups per
+// 320-image decode, each holding its CUs while it waited on L2 -- 22 % of the time of a decode in flight for 2.3 % of its FLOPs
+// (profiles/r04_ablations.txt).  Here a 320-image decode's loop occupies 20 CUs and nothing else; the other decodes in flight keep the
+// rest of the chip.
+//
+// Shape of the work: one activation ROW per image.  The 16 rows of the group are the B operand (columns) of v_mfma_f32_16x16x32_f16,
+// the weights -- fragment-major, the layout of rowblock.hip's rb_pack_frag_kernel -- are the A operand streamed from L2 straight into
+// operand registers: the 8 wavefronts split the OUTPUT columns, a ring of BL_PF k-steps per wavefront stays in flight ACROSS stage
+// boundaries (the last segment of a stage requests the first steps of the next stage's stream: a weight address never depends on data).
+// Per iteration a workgroup streams 5.75 MB of weights (3 x 0.5 MB projections, 2 + 2 MB feed-forward, 0.25 MB head hidden layers) and
+// reads its images' cross-attention K|V rows (16 x 36 x 2 KB).
+//
+// Precision: the bounding network's operands are FP16 here, not bf16 -- same bytes and MFMA rate, 8x finer rounding
+// (weights |w| < 1, LayerNorm-ed activations O(1), everything clamped to the fp16 range on conversion; NaN passes).  LayerNorms are
+// applied explicitly in float32 (two-pass mean / unbiased std, eps on the std: TransformerModel.py:1346-1349) on the float32 residual
+// rows held in LDS, the gain folded into the consumer's weights and gain-bias into its bias (c = b + W . b_ln); the self-attention
+// scores of row 0 come from a float32 table (position, label, head) and its values from a float32 V table (bound_tables_kernel below);
+// softmaxes, the heads' output layers and log-softmax are float32.  What stays bf16: the cross-attention K|V rows (they are the
+// encoder's kv_all projection, written by the row-block kernels).
+#include "bofi_common.h"
+#include "bofi_kernels.h"
+#include "bofi_naic.h"
+
+namespace bofi {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int BL_G = 16;            // images per workgroup (one 16-column MFMA tile)
+constexpr int BL_PF = 4;            // k-steps of the weight stream in flight per wavefront (divides 16)
+constexpr int BL_YP = 516;          // float pitch of the float32 row tiles in LDS (2 064 B: the 16 rows of a tile spread over all banks)
+constexpr int BL_HP = 260;          // float pitch of the heads' hidden rows
+constexpr int BL_LMAX = 24;         // positions per image held in LDS (L = seq_length + 2 <= 24)
+// LDS map (bytes)
+constexpr int BL_OFF_Y = 0;                              // float32 [16][516] residual rows
+constexpr int BL_OFF_X = BL_OFF_Y + BL_G * BL_YP * 4;    // fp16 [16][512] GEMM input rows, 16-byte chunks XOR-swizzled by row (rowblock.hip's rb_off)
+constexpr int BL_OFF_BIG = BL_OFF_X + BL_G * 1024;       // 64 KiB: fp16 hidden rows [16][dff] | float32 queries + probabilities | heads' hidden + logits
+constexpr int BL_OFF_SCT = BL_OFF_BIG + 65536;           // float32 [L*10][8] self-attention scores of row 0 by (position, label, head)
+constexpr int BL_OFF_W2O = BL_OFF_SCT + BL_LMAX * 10 * 8 * 4;      // float32 [30][hh] output layers of both heads, then their 30 biases
+constexpr int BL_OFF_ST = BL_OFF_W2O + (30 * 128 + 32) * 4;        // int32 slot state
+constexpr int BL_ST_INTS = 4 * BL_G + BL_G * BL_LMAX + 2 * BL_G + 16;
+constexpr int BL_SMEM = BL_OFF_ST + BL_ST_INTS * 4;
+
+__device__ __forceinline__ float bl_clamp16(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }      // (a NaN fails both tests and passes)
+__device__ __forceinline__ uint32_t bl_pack(float lo, float hi) {
+    const f32x2 v = {bl_clamp16(lo), bl_clamp16(hi)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ f16x8 bl_ldw(const u32x4* p) { return __builtin_bit_cast(f16x8, *p); }
+__device__ __forceinline__ float bl_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bl_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// byte offset of a lane's MFMA B-operand piece (row l15, 16-byte chunk kb*4 + g) in a swizzled tile of `pitch`-byte rows: base ^ (kb << 6)
+__device__ __forceinline__ int bl_lane_base(int l15, int g, int pitch) { return l15 * pitch + (((l15 >> 2) << 6) | ((g ^ (l15 & 3)) << 4)); }
+
+// the 16 B-operand pieces (K = 512) of this lane from a swizzled tile
+__device__ __forceinline__ void bl_load_x(const unsigned char* tile, int lbase, f16x8 (&xb)[16]) {
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) xb[kb] = *reinterpret_cast<const f16x8*>(tile + (lbase ^ (kb << 6)));
+}
+
+// One SEGMENT of a wavefront's weight stream: 16 k-steps of four 16-column tiles (64 output columns x K = 512).  `cur` / `nxt`: this segment and the one
+// that follows in the stream (lane offset included; step kb at + kb*256, tile nt at + nt*64); the ring wb holds steps kb .. kb + BL_PF - 1.
+// Both are WAVE-UNIFORM pointers (scalar registers); the lane rides in the load's vector offset: no per-load address registers.
+__device__ __forceinline__ void bl_seg(const u32x4* cur, const u32x4* nxt, int lane, f16x8 (&wb)[BL_PF * 4], const f16x8 (&xb)[16], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(kb % BL_PF) * 4 + nt], xb[kb], acc[nt], 0, 0, 0);
+        const u32x4* src = kb + BL_PF < 16 ? cur + (kb + BL_PF) * 256 : nxt + (kb + BL_PF - 16) * 256;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wb[(kb % BL_PF) * 4 + nt] = bl_ldw(src + nt * 64 + lane);
+        __builtin_amdgcn_sched_barrier(0);            // (the scheduler would sink the loads next to their use: the prefetch distance is the point)
+    }
+}
+
+__global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    float* Y = reinterpret_cast<float*>(sm + BL_OFF_Y);
+    unsigned char* X16 = sm + BL_OFF_X;
+    unsigned char* BIG = sm + BL_OFF_BIG;
+    float* Q = reinterpret_cast<float*>(BIG);                       // cross-attention queries [16][516]
+    float* PX = reinterpret_cast<float*>(BIG + BL_G * BL_YP * 4);   // cross-attention probabilities [8 wavefronts][64]
+    float* PSELF = reinterpret_cast<float*>(BIG);                   // self-attention probabilities [16][8][32]
+    float* HID = reinterpret_cast<float*>(BIG);                     // heads' hidden rows [16][260]
+    float* LG = HID + BL_G * BL_HP;                                 // logits [16][32]: 0..19 length, 20..29 label
+    float* SCT = reinterpret_cast<float*>(sm + BL_OFF_SCT);
+    float* W2O = reinterpret_cast<float*>(sm + BL_OFF_W2O);
+    int* s_last = reinterpret_cast<int*>(sm + BL_OFF_ST);
+    int* s_fin = s_last + BL_G;
+    int* s_pn = s_fin + BL_G;
+    int* s_attl = s_pn + BL_G;
+    int* s_ext = s_attl + BL_G;                                     // [16][24]
+    int* s_pick = s_ext + BL_G * BL_LMAX;                           // [16][2]
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;      // (wave in a scalar register: stream pointers stay scalar)
+    const int B = a.B, L = a.L, S = a.S, R = a.R, hh = a.hh, dff = a.dff;
+    const int b0 = blockIdx.x * BL_G;
+    const BoundState st = a.st;
+
+    // ---- this wavefront's weight streams (a weight address never depends on data: the ring runs ahead across stages)
+    const int nc1 = dff >> 9;                                       // 64-column chunks of w_1 per wavefront (dff / 64 / 8) = 512-wide K segments of w_2
+    const u32x4* wo_self_s = a.wo_self + (size_t)wave * 4096;       // (wave-uniform; the lane is added by the loads)
+    const u32x4* wq_s = a.wq_src + (size_t)wave * 4096;
+    const u32x4* wo_src_s = a.wo_src + (size_t)wave * 4096;
+    const u32x4* w1_s = a.w1 + (size_t)wave * nc1 * 4096;           // chunk cc at + cc*4096
+    const u32x4* w2_s = a.w2 + (size_t)wave * (dff >> 5) * 256;     // K segment sg at + sg*4096
+    const u32x4* wh_s = a.wh + (size_t)(wave & 3) * 4096;           // the heads' hidden layers: 256 columns, wavefronts 0-3
+    f16x8 wb[BL_PF * 4];
+#pragma unroll
+    for (int p = 0; p < BL_PF; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wb[p * 4 + nt] = bl_ldw(wo_self_s + p * 256 + nt * 64 + lane0);
+
+    // ---- tables and state into LDS
+    for (int i = tid; i < L * 10 * 8; i += 512) SCT[i] = a.sctab[i];
+    for (int i = tid; i < 30 * hh; i += 512) W2O[i] = i < 20 * hh ? a.len_w2[i] : a.syn_w2[i - 20 * hh];
+    if (tid < 30) W2O[30 * hh + tid] = tid < 20 ? a.len_b2[tid] : a.syn_b2[tid - 20];
+    {
+        const int* ext_src = a.ext_syn_in ? a.ext_syn_in : st.ext_syn;
+        for (int i = tid; i < BL_G * BL_LMAX; i += 512) {
+            const int im = i / BL_LMAX, p = i - im * BL_LMAX;
+            s_ext[i] = (b0 + im < B && p < L) ? ext_src[(size_t)(b0 + im) * L + p] : 0;
+        }
+        if (tid < BL_G) {
+            const int b = b0 + tid;
+            const bool valid = b < B;
+            s_last[tid] = valid ? (a.last_in ? a.last_in[b] : st.last[b]) : 1;
+            s_fin[tid] = valid ? (a.update ? st.finished[b] : 0) : 1;
+            s_pn[tid] = (valid && a.update) ? st.phrase_num[b] : 0;
+            s_attl[tid] = valid ? (a.att_len ? max(0, min(a.att_len[b], R)) : R) : R;
+        }
+    }
+    __syncthreads();
+
+    int it_done = 0;
+
+    // LayerNorm (no gain / bias: they live in the consumer's weights) of the 16 rows of Y -> X16; wavefront w owns rows 2w, 2w + 1
+    auto norm_rows = [&](int lane) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = 2 * wave + u;
+            const float4 v0 = *reinterpret_cast<const float4*>(Y + row * BL_YP + lane * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(Y + row * BL_YP + lane * 8 + 4);
+            const float mean = wave_sum(((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) * (1.0f / 512.0f);
+            const float d0 = v0.x - mean, d1 = v0.y - mean, d2 = v0.z - mean, d3 = v0.w - mean;
+            const float d4 = v1.x - mean, d5 = v1.y - mean, d6 = v1.z - mean, d7 = v1.w - mean;
+            const float var = wave_sum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / 511.0f);
+            const float rs = 1.0f / (sqrtf(var) + 1e-6f);
+            u32x4 o;
+            o[0] = bl_pack(d0 * rs, d1 * rs); o[1] = bl_pack(d2 * rs, d3 * rs); o[2] = bl_pack(d4 * rs, d5 * rs); o[3] = bl_pack(d6 * rs, d7 * rs);
+            *reinterpret_cast<u32x4*>(X16 + row * 1024 + ((lane ^ (row & 15)) << 4)) = o;
+        }
+    };
+
+    const int max_iters = a.max_iters;
+#pragma unroll 1
+    for (int it = 0; it < max_iters; ++it) {
+        {   // every image of the group finished: the loop is over (TransformerModel.py:1869, per group)
+            int nf = 0;
+#pragma unroll
+            for (int i = 0; i < BL_G; ++i) nf += s_fin[i];
+            if (nf == BL_G) break;
+        }
+        ++it_done;
+        // (lane-derived addresses are re-derived per iteration from a value the optimiser cannot see through: hoisted out of the loop they are
+        // spilled at the cross-attention's register peak, and a scratch reload drains the weight ring)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int l15 = lane & 15, g = lane >> 4;
+        const int xbase = bl_lane_base(l15, g, 1024);
+        const int ncol = wave * 64 + g * 4;                         // first output column of tile 0 of this lane (tile nt: + nt*16) in a 512-wide stage
+        // ================= S1: row-0 self-attention over the (position, label) tables =================
+        {   // probabilities: a 32-lane half per (image, head), lane = key position (row 0 sees keys p < last: tgt_mask[j, 0, :last])
+            const int hw = wave * 2 + (lane >> 5), li = lane & 31;
+#pragma unroll 1
+            for (int rnd = 0; rnd < 8; ++rnd) {
+                const int pair = rnd * 16 + hw, i = pair >> 3, h = pair & 7;
+                const int n = min(s_last[i], L);
+                const float sc = li < n ? SCT[(li * 10 + s_ext[i * BL_LMAX + li]) * 8 + h] : -INFINITY;
+                const float m = xor16_max(row16_max(sc));
+                const float e = li < n ? expf(sc - m) : 0.f;
+                const float sum = xor16_sum(row16_sum(e));
+                PSELF[(i * 8 + h) * 32 + li] = e / sum;
+            }
+        }
+        __syncthreads();
+        {   // ctx = P . V rows of the float32 table: wavefront w owns images 2w, 2w + 1, a lane 8 columns (head lane / 8)
+            const int h = lane >> 3;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * wave + u, n = min(s_last[i], L);
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                if (!s_fin[i]) {
+                    for (int j0 = 0; j0 < n; j0 += 4) {
+                        float4 v0[4], v1[4];
+                        float p[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int jj = min(j0 + t, n - 1);
+                            const float* vr = a.vtab + (size_t)(jj * 10 + s_ext[i * BL_LMAX + jj]) * 512 + lane * 8;
+                            v0[t] = *reinterpret_cast<const float4*>(vr);
+                            v1[t] = *reinterpret_cast<const float4*>(vr + 4);
+                            p[t] = j0 + t < n ? PSELF[(i * 8 + h) * 32 + j0 + t] : 0.f;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc[0] = fmaf(p[t], v0[t].x, acc[0]); acc[1] = fmaf(p[t], v0[t].y, acc[1]); acc[2] = fmaf(p[t], v0[t].z, acc[2]); acc[3] = fmaf(p[t], v0[t].w, acc[3]);
+                            acc[4] = fmaf(p[t], v1[t].x, acc[4]); acc[5] = fmaf(p[t], v1[t].y, acc[5]); acc[6] = fmaf(p[t], v1[t].z, acc[6]); acc[7] = fmaf(p[t], v1[t].w, acc[7]);
+                        }
+                    }
+                }
+                u32x4 o;
+                o[0] = bl_pack(acc[0], acc[1]); o[1] = bl_pack(acc[2], acc[3]); o[2] = bl_pack(acc[4], acc[5]); o[3] = bl_pack(acc[6], acc[7]);
+                *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = o;
+            }
+        }
+        __syncthreads();
+        f16x8 xb[16];
+        f32x4 acc[4];
+        // ================= S2: y1 = (x0 + bo_self) + Wo_self . ctx =================
+        {
+            float4 cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.x0b + ncol + nt * 16);
+            bl_load_x(X16, xbase, xb);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bl_seg(wo_self_s, wq_s, lane, wb, xb, acc);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<float4*>(Y + l15 * BL_YP + ncol + nt * 16) = make_float4(acc[nt][0] + cv[nt].x, acc[nt][1] + cv[nt].y, acc[nt][2] + cv[nt].z, acc[nt][3] + cv[nt].w);
+        }
+        __syncthreads();
+        norm_rows(lane);
+        __syncthreads();
+        // ================= S3: q = Wq_src' . LN(y1) + c =================
+        {
+            float4 cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.cq + ncol + nt * 16);
+            bl_load_x(X16, xbase, xb);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bl_seg(wq_s, wo_src_s, lane, wb, xb, acc);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<float4*>(Q + l15 * BL_YP + ncol + nt * 16) = make_float4(acc[nt][0] + cv[nt].x, acc[nt][1] + cv[nt].y, acc[nt][2] + cv[nt].z, acc[nt][3] + cv[nt].w);
+        }
+        __syncthreads();
+        // ================= S4: cross-attention of the 16 query rows over their images' regions (keys: lane = region) =================
+        {
+            asm volatile("" : "+v"(lane));
+            const int cch = (lane & 8) ? 7 - (lane & 7) : (lane & 7);          // row_mirror partners (l, 15 - l) hold the same 8-column chunk
+            const int js = ((lane >> 4) << 1) | ((lane >> 3) & 1);             // key subset of the P.V sums
+            float* ps = PX + wave * 64;
+            // lane offsets (elements) into an (image, head)'s K / V rows: the same for every unit; the unit's base is wave-uniform
+            const int koff = min(lane, R - 1) * a.ldkv;
+            int voff[8];
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) voff[tt] = min(js + 8 * tt, R - 1) * a.ldkv + cch * 8;      // keys past R: the last row again, weighted 0 below
+            auto issue = [&](int t, u32x4 (&kk)[8], u32x4 (&vv)[8]) {
+                const int i = 2 * wave + (t >> 3), h = t & 7, bi = min(b0 + i, B - 1);
+                const bf16_t* kp = a.k + (size_t)bi * R * a.ldkv + h * 64;
+                const bf16_t* vp = a.v + (size_t)bi * R * a.ldkv + h * 64;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const u32x4*>(kp + koff + c * 8);
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) vv[tt] = *reinterpret_cast<const u32x4*>(vp + voff[tt]);
+            };
+            auto compute = [&](int t, const u32x4 (&kk)[8], const u32x4 (&vv)[8]) {
+                const int i = 2 * wave + (t >> 3), h = t & 7, kl = s_attl[i];
+                const float* qr = Q + i * BL_YP + h * 64;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 qa = *reinterpret_cast<const float4*>(qr + c * 8);
+                    const float4 qb = *reinterpret_cast<const float4*>(qr + c * 8 + 4);
+                    const u32x4 kv = kk[c];
+                    s += qa.x * bl_lo(kv[0]) + qa.y * bl_hi(kv[0]) + qa.z * bl_lo(kv[1]) + qa.w * bl_hi(kv[1]);
+                    s += qb.x * bl_lo(kv[2]) + qb.y * bl_hi(kv[2]) + qb.z * bl_lo(kv[3]) + qb.w * bl_hi(kv[3]);
+                }
+                s *= 0.125f;                                              // / sqrt(d_k), d_k = 64
+                const bool live = lane < kl;
+                const float m = wave_max(live ? s : -INFINITY);
+                const float e = live ? expf(s - m) : 0.f;
+                const float sum = wave_sum(e);
+                ps[lane] = e / sum;                                       // no visible region: NaN, as softmax over an all-masked row of -inf
+                __builtin_amdgcn_wave_barrier();
+                float o[8];
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) o[e8] = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) {
+                    const float p = ps[js + 8 * tt];                      // 0 from the key count on (NaN everywhere for an image without regions)
+                    const u32x4 v = vv[tt];
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) { o[2 * e4] += p * bl_lo(v[e4]); o[2 * e4 + 1] += p * bl_hi(v[e4]); }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    float v = o[e8];
+                    v += dpp_f32<DPP_MIRROR>(v);
+                    o[e8] = xor32_sum(xor16_sum(v));
+                }
+                if (lane < 8) {
+                    u32x4 w;
+                    w[0] = bl_pack(o[0], o[1]); w[1] = bl_pack(o[2], o[3]); w[2] = bl_pack(o[4], o[5]); w[3] = bl_pack(o[6], o[7]);
+                    *reinterpret_cast<u32x4*>(X16 + i * 1024 + (((h * 8 + cch) ^ (i & 15)) << 4)) = w;
+                }
+            };
+            u32x4 ka[8], va[8], kc[8], vc[8];
+            issue(0, ka, va);
+#pragma unroll 1
+            for (int t = 0; t < 16; t += 2) {
+                issue(t + 1, kc, vc);
+                compute(t, ka, va);
+                if (t + 2 < 16) issue(t + 2, ka, va);
+                compute(t + 1, kc, vc);
+            }
+        }
+        __syncthreads();
+        // ================= S5: y2 = y1 + Wo_src . ctx2 + bo =================
+        {
+            float4 cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.bo_src + ncol + nt * 16);
+            bl_load_x(X16, xbase, xb);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bl_seg(wo_src_s, w1_s, lane, wb, xb, acc);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float4* yp = reinterpret_cast<float4*>(Y + l15 * BL_YP + ncol + nt * 16);
+                const float4 y = *yp;
+                *yp = make_float4(y.x + (acc[nt][0] + cv[nt].x), y.y + (acc[nt][1] + cv[nt].y), y.z + (acc[nt][2] + cv[nt].z), y.w + (acc[nt][3] + cv[nt].w));
+            }
+        }
+        __syncthreads();
+        norm_rows(lane);
+        __syncthreads();
+        // ================= S6: h = relu(W1' . LN(y2) + c1): hidden columns (wave*nc1 + cc)*64 .. +63 =================
+        bl_load_x(X16, xbase, xb);
+#pragma unroll 1
+        for (int cc = 0; cc < nc1; ++cc) {
+            const int hc = (wave * nc1 + cc) * 64 + g * 4;
+            float4 cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.c1 + hc + nt * 16);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bl_seg(w1_s + (size_t)cc * 4096, cc + 1 < nc1 ? w1_s + (size_t)(cc + 1) * 4096 : w2_s, lane, wb, xb, acc);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = hc + nt * 16;                                   // 4 columns n .. n + 3 of row l15: half of 16-byte chunk n >> 3
+                const uint2 o = make_uint2(bl_pack(fmaxf(acc[nt][0] + cv[nt].x, 0.f), fmaxf(acc[nt][1] + cv[nt].y, 0.f)),
+                                           bl_pack(fmaxf(acc[nt][2] + cv[nt].z, 0.f), fmaxf(acc[nt][3] + cv[nt].w, 0.f)));
+                *reinterpret_cast<uint2*>(BIG + l15 * (dff * 2) + (((n >> 3) ^ l15) << 4) + (n & 4) * 2) = o;
+            }
+        }
+        __syncthreads();
+        // ================= S7: y3 = y2 + W2 . h + b2 =================
+        {
+            float4 cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.b2 + ncol + nt * 16);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int hbase = bl_lane_base(l15, g, dff * 2);
+#pragma unroll 1
+            for (int sg = 0; sg < nc1; ++sg) {
+                bl_load_x(BIG, hbase ^ (sg << 10), xb);
+                const u32x4* nxt = sg + 1 < nc1 ? w2_s + (size_t)(sg + 1) * 4096 : (wave < 4 ? wh_s : wo_self_s);
+                bl_seg(w2_s + (size_t)sg * 4096, nxt, lane, wb, xb, acc);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float4* yp = reinterpret_cast<float4*>(Y + l15 * BL_YP + ncol + nt * 16);
+                const float4 y = *yp;
+                *yp = make_float4(y.x + (acc[nt][0] + cv[nt].x), y.y + (acc[nt][1] + cv[nt].y), y.z + (acc[nt][2] + cv[nt].z), y.w + (acc[nt][3] + cv[nt].w));
+            }
+        }
+        __syncthreads();
+        norm_rows(lane);
+        __syncthreads();
+        // ================= S8: heads.  hidden = relu(W1h' . LN(y3) + c) (both heads side by side, 256 columns: wavefronts 0-3) =================
+        if (wave < 4) {
+            float4 cv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.ch + ncol + nt * 16);
+            bl_load_x(X16, xbase, xb);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bl_seg(wh_s, wo_self_s, lane, wb, xb, acc);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<float4*>(HID + l15 * BL_HP + ncol + nt * 16) = make_float4(fmaxf(acc[nt][0] + cv[nt].x, 0.f), fmaxf(acc[nt][1] + cv[nt].y, 0.f),
+                                                                                              fmaxf(acc[nt][2] + cv[nt].z, 0.f), fmaxf(acc[nt][3] + cv[nt].w, 0.f));
+        }
+        __syncthreads();
+        if (tid < BL_G * 30) {          // output layers (float32): thread = (image, output)
+            const int i = tid / 30, o = tid - i * 30;
+            const float* hv = HID + i * BL_HP + (o < 20 ? 0 : hh);
+            const float* w = W2O + o * hh;
+            float s0 = 0.f, s1 = 0.f;
+            int k = 0;
+            for (; k + 1 < hh; k += 2) { s0 = fmaf(w[k], hv[k], s0); s1 = fmaf(w[k + 1], hv[k + 1], s1); }
+            if (k < hh) s0 = fmaf(w[k], hv[k], s0);
+            LG[i * 32 + o] = (s0 + s1) + W2O[30 * hh + o];
+        }
+        __syncthreads();
+        {   // log-softmax and first-max pick: a 32-lane half per (image, head); torch.max semantics: the first NaN wins, else the first maximum (:380-383)
+            const int hw = wave * 2 + (lane >> 5), li = lane & 31;
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                const int unit = rnd * 16 + hw, i = unit >> 1, head = unit & 1, nout = head ? 10 : 20;
+                const bool on = li < nout;
+                const float v = on ? LG[i * 32 + head * 20 + li] : -INFINITY;
+                const float m = xor16_max(row16_max(v));                      // fmaxf ignores a NaN unless every input is one
+                const float e = on ? expf(v - m) : 0.f;
+                const float sum = xor16_sum(row16_sum(e));
+                const float lp = (v - m) - logf(sum);
+                if (it == 0 && on && b0 + i < B) {
+                    if (!head && a.len_logp) a.len_logp[(size_t)(b0 + i) * 20 + li] = lp;
+                    if (head && a.syn_logp) a.syn_logp[(size_t)(b0 + i) * 10 + li] = lp;
+                }
+                const bool isnan_ = on && (lp != lp);
+                float cand = isnan_ ? (float)li : 1e9f;
+                cand = -xor16_max(row16_max(-cand));
+                float cmax = (on && v == m) ? (float)li : 1e9f;
+                cmax = -xor16_max(row16_max(-cmax));
+                const int best = cand < 1e8f ? (int)cand : (cmax < 1e8f ? (int)cmax : 0);
+                if (li == 0) s_pick[i * 2 + head] = best;
+            }
+        }
+        __syncthreads();
+        if (tid < BL_G && a.update && b0 + tid < B && !s_fin[tid]) {      // slot bookkeeping of core_NAIC (TransformerModel.py:1843-1869), one thread per image
+            const int i = tid, b = b0 + i;
+            int ln = s_pick[i * 2];
+            const int sn = s_pick[i * 2 + 1], la = s_last[i];
+            bool fin = false;
+            if (ln == 0 || sn < 4 || sn > 6) {                              // EOS (:1846-1849)
+                fin = true;
+            } else {
+                if (ln + la >= S + 1) { ln = S + 1 - la; fin = true; }      // truncate (:1850-1855)
+                const int slot = s_pn[i];                                   // == iteration index while unfinished (Q3)
+                st.phrase_length[(size_t)b * L + slot] = ln;
+                st.phrase_syn[(size_t)b * L + slot] = sn;
+                st.phrase_num[b] = slot + 1;
+                s_pn[i] = slot + 1;
+                for (int p = la; p < la + ln; ++p) { st.ext_syn[(size_t)b * L + p] = sn; s_ext[i * BL_LMAX + p] = sn; }
+                st.last[b] = la + ln;
+                s_last[i] = la + ln;
+                if (st.klen) {                                              // tgt_mask[j, la:, :la+ln] = True; tgt_mask[j, 0, :la+ln] = True (:1859-1867)
+                    for (int r = la; r < L; ++r) st.klen[(size_t)b * L + r] = la + ln;
+                    st.klen[(size_t)b * L] = la + ln;
+                }
+            }
+            if (fin) { st.finished[b] = 1; s_fin[i] = 1; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && a.update) {
+        atomicMax(&st.counters[1], it_done);                               // iterations in which some image (of any group) was active
+        int nf = 0;
+        for (int i = 0; i < BL_G; ++i) nf += (b0 + i < B) ? s_fin[i] : 0;
+        atomicAdd(&st.counters[0], nf);
+    }
+}
+
+int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
+    if (a.B < 1 || a.R < 1 || a.R > 64 || a.L < 3 || a.L > BL_LMAX || a.S != a.L - 2 || a.hh < 1 || a.hh > 128 || 2 * a.hh > 256 || a.dff < 512 || a.dff > 2048 ||
+        a.dff % 512 || a.ldkv % 8 || a.max_iters < 1)
+        return BOFI_ERR_ARG;
+    if (!a.wo_self || !a.x0b || !a.wq_src || !a.cq || !a.wo_src || !a.bo_src || !a.w1 || !a.c1 || !a.w2 || !a.b2 || !a.wh || !a.ch || !a.len_w2 || !a.len_b2 ||
+        !a.syn_w2 || !a.syn_b2 || !a.sctab || !a.vtab || !a.k || !a.v)
+        return BOFI_ERR_ARG;
+    if (a.update && (!a.st.last || !a.st.finished || !a.st.phrase_num || !a.st.phrase_length || !a.st.phrase_syn || !a.st.ext_syn || !a.st.counters)) return BOFI_ERR_ARG;
+    if (!a.update && (!a.ext_syn_in || !a.last_in)) return BOFI_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess) return BOFI_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bound_loop_kernel, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, a);
+    BOFI_CHECK_LAUNCH();
+    // FLOP tally: the GEMM work of the iterations is data-dependent; counted as skippable work of max_iters iterations like the launches it replaces
+    g_gemm_flops_skippable += (double)a.max_iters * a.B * (2.0 * 3 * 512 * 512 + 4.0 * 512 * a.dff);
+    return BOFI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// fp16 fragment-major copies of the bounding network's weights, straight from the float32 parameters (finalize: uploaded temporaries; refresh:
+// the trainer's tensors): out[i] of [Npad/64 chunks][K/32 steps][4 tiles][64 lanes][8 halves] = fp16(w[n][k .. k+7] * gain[k .. k+7]), rows >= n_each*nsrc zero
+__global__ __launch_bounds__(256) void pack_frag16_kernel(Pack16Table t) {
+    int e = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < t.n && (int)blockIdx.x >= t.e[i].blk0) e = i;
+    const Pack16Entry& d = t.e[e];
+    const size_t i = (size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x;
+    if (i >= (size_t)d.Npad * d.K / 8) return;
+    const int lane = (int)(i & 63), nt = (int)((i >> 6) & 3);
+    const size_t tt = i >> 8;
+    const int kb = (int)(tt % (size_t)(d.K >> 5)), chunk = (int)(tt / (size_t)(d.K >> 5));
+    const int n = chunk * 64 + nt * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (n < d.n_each * d.nsrc) {
+        const int src = n / d.n_each, r = n - src * d.n_each;
+        const float* row = d.w[src] + (size_t)r * d.K + k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = d.gain ? row[j] * d.gain[k + j] : row[j];
+    }
+    u32x4 o;
+    o[0] = bl_pack(v[0], v[1]); o[1] = bl_pack(v[2], v[3]); o[2] = bl_pack(v[4], v[5]); o[3] = bl_pack(v[6], v[7]);
+    reinterpret_cast<u32x4*>(d.out)[i] = o;
+}
+
+int launch_pack_frag16(const Pack16Table& t, hipStream_t s) {
+    if (t.n < 1 || t.n > 8) return BOFI_ERR_ARG;
+    Pack16Table v = t;
+    int blocks = 0;
+    for (int i = 0; i < v.n; ++i) {
+        Pack16Entry& d = v.e[i];
+        if (!d.w[0] || !d.out || d.nsrc < 1 || d.nsrc > 2 || (d.nsrc == 2 && !d.w[1]) || d.K % 32 || d.Npad % 64 || d.n_each * d.nsrc > d.Npad) return BOFI_ERR_ARG;
+        d.blk0 = blocks;
+        blocks += (int)(((size_t)d.Npad * d.K / 8 + 255) / 256);
+    }
+    hipLaunchKernelGGL(pack_frag16_kernel, dim3(blocks), dim3(256), 0, s, v);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Input-independent float32 tables of the bounding layer's row-0 self-attention: the layer input at (position p, label s) is
+// xt[p*10 + s] = lut_syn[s]*sqrt(d) + pe[p]; with xn = LN_0(xt[row]) (sublayer[0].norm, TransformerModel.py:1346-1349):
+//   q0 = Wq . LN_0(x0) + bq                       (x0: row (0, [LEN]))
+//   sctab[row][h] = q0[h] . (Wk . xn + bk)[h] / 8 (the score row 0 gives key `row` in head h)
+//   vtab[row] = Wv . xn + bv
+// d = 512, 8 heads.  Grid: rows + 1 workgroups of 512 threads; workgroup `rows` computes q0 first -- the others need it: two launches.
+__device__ __forceinline__ void bl_ln_row(const float* x, const float* gain, const float* bias, float* xs, int tid, float* red) {
+    const float v = x[tid];
+    float s = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) * (1.0f / 512.0f);
+    const float dlt = v - mean;
+    float q = wave_sum(dlt * dlt);
+    if ((tid & 63) == 0) red[8 + (tid >> 6)] = q;
+    __syncthreads();
+    const float var = (((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]))) * (1.0f / 511.0f);
+    xs[tid] = gain[tid] * dlt / (sqrtf(var) + 1e-6f) + bias[tid];
+    __syncthreads();
+}
+__device__ __forceinline__ float bl_dot512(const float* wrow, const float* xs, int lane) {      // every lane ends with the sum
+    const float4 w0 = *reinterpret_cast<const float4*>(wrow + lane * 8), w1 = *reinterpret_cast<const float4*>(wrow + lane * 8 + 4);
+    const float4 x0 = *reinterpret_cast<const float4*>(xs + lane * 8), x1 = *reinterpret_cast<const float4*>(xs + lane * 8 + 4);
+    float s = w0.x * x0.x;
+    s = fmaf(w0.y, x0.y, s); s = fmaf(w0.z, x0.z, s); s = fmaf(w0.w, x0.w, s);
+    s = fmaf(w1.x, x1.x, s); s = fmaf(w1.y, x1.y, s); s = fmaf(w1.z, x1.z, s); s = fmaf(w1.w, x1.w, s);
+    return wave_sum(s);
+}
+__global__ __launch_bounds__(512) void bound_q0_kernel(BoundTablesArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[512];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    bl_ln_row(a.x0, a.n0g, a.n0b, xs, tid, red);
+    for (int j = 0; j < 64; ++j) {
+        const int n = wave * 64 + j;
+        const float s = bl_dot512(a.wq + (size_t)n * 512, xs, lane);
+        if (lane == 0) a.q0[n] = s + a.bq[n];
+    }
+}
+__global__ __launch_bounds__(512) void bound_tables_kernel(BoundTablesArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[512];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = blockIdx.x;
+    bl_ln_row(a.xt + (size_t)row * 512, a.n0g, a.n0b, xs, tid, red);
+    float sc = 0.f;
+    for (int j = 0; j < 64; ++j) {            // head `wave` of K
+        const int n = wave * 64 + j;
+        const float kv = bl_dot512(a.wk + (size_t)n * 512, xs, lane) + a.bk[n];
+        sc = fmaf(a.q0[n], kv, sc);
+    }
+    if (lane == 0) a.sctab[(size_t)row * 8 + wave] = sc * 0.125f;
+    for (int j = 0; j < 64; ++j) {
+        const int n = wave * 64 + j;
+        const float vv = bl_dot512(a.wv + (size_t)n * 512, xs, lane) + a.bv[n];
+        if (lane == 0) a.vtab[(size_t)row * 512 + n] = vv;
+    }
+}
+
+int launch_bound_tables(const BoundTablesArgs& a, hipStream_t s) {
+    if (a.rows < 1 || !a.xt || !a.x0 || !a.n0g || !a.n0b || !a.wq || !a.bq || !a.wk || !a.bk || !a.wv || !a.bv || !a.q0 || !a.sctab || !a.vtab) return BOFI_ERR_ARG;
+    hipLaunchKernelGGL(bound_q0_kernel, dim3(1), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(bound_tables_kernel, dim3(a.rows), dim3(512), 0, s, a);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
+}  // namespace bofi

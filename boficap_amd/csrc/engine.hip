@@ -41,7 +41,7 @@ uint16_t host_bf16(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; int Npad = 0; void* wp = nullptr; };   // cs: column sums when a LayerNorm is folded in; Npad > N: rows N .. Npad of w / b / cs exist and are zero; wp: fragment-major copy of w for the row-block kernels (rowblock.hip), bf16 engine only
+struct Lin { void* w = nullptr; float* b = nullptr; float* cs = nullptr; int N = 0, K = 0; int Npad = 0; void* wp = nullptr; void* wp16 = nullptr; };   // cs: column sums when a LayerNorm is folded in; Npad > N: rows N .. Npad of w / b / cs exist and are zero; wp: fragment-major copy of w for the row-block kernels (rowblock.hip), bf16 engine only; wp16: fragment-major FP16 copy made from the float32 parameters (bound_loop.hip), the bounding layer's Linears of a bf16 engine only
 struct Norm { float* g = nullptr; float* b = nullptr; };
 struct EncLayer { Lin qkv, o, w1, w2; Norm n0, n1; };
 struct DecLayer { Lin qkv, o, q_src, o_src, w1, w2; Norm n0, n1, n2; };
@@ -86,6 +86,10 @@ struct bofi_engine {
     float* b_x0 = nullptr;                        // [d] residual input of row 0
     void *b_votab = nullptr, *b_w1p = nullptr;    // compute dtype: Wo_self . V per (row, head) [L*10, H, d]; packed head hidden weights
     float* b_x0b = nullptr;                       // [d] x0 + bo_self
+    // the persistent bounding-loop kernel (bound_loop.hip; bf16 engine at the reference's width): float32 tables of the row-0 self-attention
+    Lin b_heads;                                  // hidden layers of both heads stacked, length_predictor.norm folded in (its wp16 and folded bias are what the loop kernel reads)
+    float *b_q0_32 = nullptr, *b_sctab = nullptr, *b_vtab = nullptr;      // [d], [L*10][H], [L*10][d]
+    bool loop_ready = false;
     float* dbg_part = nullptr;
 
     // workspace
@@ -199,6 +203,7 @@ struct bofi_engine {
         ENG_OK(upload_t(&out->w, w));
         ENG_OK(upload_f32(&out->b, b));
         out->wp = nullptr;
+        out->wp16 = nullptr;
         if (frag && cfg.dtype == BOFI_DT_BF16 && out->Npad % 64 == 0 && K % 32 == 0) {      // the layout the row-block kernels stream (zero rows included)
             ENG_OK(dalloc((char**)&out->wp, (size_t)out->Npad * K, 2));
             ENG_OK(bofi::launch_rb_pack_frag(out->w, out->wp, out->Npad, K, nullptr));
@@ -318,6 +323,63 @@ struct bofi_engine {
         ENG_OK(bofi::launch_pack_w1p(heads.w1t, b_w1p, cfg.dtype, cfg.d_model, 2 * cfg.head_hidden, s));
         ENG_OK(bofi::launch_votab(b_kvtab, b_o_self.w, b_x0, b_o_self.b, b_votab, b_x0b, cfg.dtype, L * 10, cfg.d_model, cfg.heads, s));
         return BOFI_OK;
+    }
+    // ---- the persistent bounding-loop kernel's operands: fp16 fragment-major copies of the bounding layer's Linears and the float32 self-attention
+    // tables, all derived on the device from the float32 parameters (finalize: uploaded temporaries; refresh_device: the caller's tensors)
+    struct BoundSrc {
+        const float *wq_self, *bq_self, *wk_self, *bk_self, *wv_self, *bv_self, *n0g, *n0b;
+        const float *wo_self, *wq_src, *n1g, *wo_src, *w1, *n2g, *w2, *lw1, *sw1, *hng;
+    };
+    bool loop_config_ok() const {
+        return cfg.dtype == BOFI_DT_BF16 && cfg.d_model == 512 && cfg.heads == 8 && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2048 && L <= 24 && cfg.head_hidden <= 128 &&
+               n_len == 1 && !bound_dense;
+    }
+    int derive_bound_f16(const BoundSrc& b, hipStream_t s) {
+        if (!loop_config_ok()) return BOFI_OK;
+        const int d = cfg.d_model, dff = cfg.d_ff, hh = cfg.head_hidden;
+        bofi::Pack16Table t{};
+        auto ent = [&](const float* w0, const float* w1_, int n_each, int nsrc, int K, int Npad, const float* gain, void* out) {
+            bofi::Pack16Entry& q = t.e[t.n++];
+            q.w[0] = w0; q.w[1] = w1_; q.gain = gain; q.out = out; q.n_each = n_each; q.nsrc = nsrc; q.K = K; q.Npad = Npad; q.blk0 = 0;
+        };
+        ent(b.wo_self, nullptr, d, 1, d, d, nullptr, b_o_self.wp16);
+        ent(b.wq_src, nullptr, d, 1, d, d, b.n1g, b_q_src.wp16);
+        ent(b.wo_src, nullptr, d, 1, d, d, nullptr, b_o_src.wp16);
+        ent(b.w1, nullptr, dff, 1, d, dff, b.n2g, b_w1.wp16);
+        ent(b.w2, nullptr, d, 1, dff, d, nullptr, b_w2.wp16);
+        ent(b.lw1, b.sw1, hh, 2, d, 256, b.hng, b_heads.wp16);
+        ENG_OK(bofi::launch_pack_frag16(t, s));
+        bofi::BoundTablesArgs a{};
+        a.xt = d_xt; a.x0 = b_x0; a.rows = L * 10; a.n0g = b.n0g; a.n0b = b.n0b;
+        a.wq = b.wq_self; a.bq = b.bq_self; a.wk = b.wk_self; a.bk = b.bk_self; a.wv = b.wv_self; a.bv = b.bv_self;
+        a.q0 = b_q0_32; a.sctab = b_sctab; a.vtab = b_vtab;
+        ENG_OK(bofi::launch_bound_tables(a, s));
+        loop_ready = true;
+        return BOFI_OK;
+    }
+    // BOFI_BOUND_LOOP (re-read after bofi_reload_env): 0 = the five-launch iterations of rounds 2-4, 1 (default) = the persistent loop kernel
+    static int bound_loop_knob() {
+        static int gen = -1, v = 1;
+        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_BOUND_LOOP"); v = e ? atoi(e) : 1; gen = bofi::g_env_generation; }
+        return v;
+    }
+    bool bound_loop_ok(int R) const { return loop_ready && loop_config_ok() && R <= 64 && bound_loop_knob() != 0; }
+    // update != 0: the whole loop on the engine's slot state (after launch_bound_init); update == 0: one iteration on a given layout, log-probabilities out
+    int bound_loop(int B, int R, const int* att_len, const int* ext_syn_in, const int* last_in, int update, float* len_logp, float* syn_logp, hipStream_t s) {
+        bofi::BoundLoopArgs a{};
+        a.wo_self = (const bofi::bl_u32x4*)b_o_self.wp16; a.x0b = b_x0b;
+        a.wq_src = (const bofi::bl_u32x4*)b_q_src.wp16; a.cq = b_q_src.b;
+        a.wo_src = (const bofi::bl_u32x4*)b_o_src.wp16; a.bo_src = b_o_src.b;
+        a.w1 = (const bofi::bl_u32x4*)b_w1.wp16; a.c1 = b_w1.b;
+        a.w2 = (const bofi::bl_u32x4*)b_w2.wp16; a.b2 = b_w2.b;
+        a.wh = (const bofi::bl_u32x4*)b_heads.wp16; a.ch = b_heads.b;
+        a.len_w2 = heads.len_w2; a.len_b2 = heads.len_b2; a.syn_w2 = heads.syn_w2; a.syn_b2 = heads.syn_b2;
+        a.sctab = b_sctab; a.vtab = b_vtab;
+        a.k = (const uint16_t*)kv; a.v = (const uint16_t*)kv + cfg.d_model; a.ldkv = kv_all.N; a.att_len = att_len;
+        a.st = st; a.ext_syn_in = ext_syn_in; a.last_in = last_in; a.len_logp = len_logp; a.syn_logp = syn_logp;
+        a.B = B; a.R = R; a.L = L; a.S = cfg.seq_length; a.hh = cfg.head_hidden; a.dff = cfg.d_ff;
+        a.max_iters = update ? cfg.seq_length : 1; a.update = update;
+        return bofi::launch_bound_loop(a, s);
     }
     // y1 (by1 / byb / st_b) -> y3 partial slabs (by3): query projection + cross-attention, Wo_src, FFN, as the direct-operand kernels
     // of bound_ops.hip.  Returns -1 when the configuration is not theirs (the caller takes the general kernels), else a status;
@@ -583,6 +645,9 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     ENG_OK(bofi::launch_bound_init(st, B, L, cfg.pad_idx, cfg.len_idx, s));
     if (bound_dense) {
         ENG_OK(enqueue_bound_dense(att_len, B, R, s));
+    } else if (bound_loop_ok(R) && !exp_skip("loop")) {
+        // one launch: a workgroup per 16 images runs every iteration and leaves when its images are finished (no iteration budget to enqueue)
+        ENG_OK(bound_loop(B, R, att_len, nullptr, nullptr, 1, nullptr, nullptr, s));
     } else {
         ENG_OK(bound_tail(nullptr, 1, nullptr, nullptr, B, BOUND_ATTN, nullptr, nullptr, s));
 #ifdef BOFI_EXPERIMENTS
@@ -1028,6 +1093,25 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
     ENG_OK(e->linear(e->b_x0, BOFI_DT_F32, d, e->t_qself, e->b_q0, c.dtype, d, 1, o, s));
     ENG_OK(e->linear(e->b_x0_sa, BOFI_DT_F32, d, e->t_qself, e->b_q0_sa, c.dtype, d, 1, o, s));
     ENG_OK(e->derive_bound_tables(s));
+    if (e->loop_config_ok()) {
+        const std::string bl = "model.length_predictor.LengthPredictor.0", lp = "model.length_predictor";
+        const int dff = c.d_ff;
+        bofi_engine::BoundSrc b{};
+        b.wq_self = get(bl + ".self_attn.linears.0.weight", (int64_t)d * d); b.bq_self = get(bl + ".self_attn.linears.0.bias", d);
+        b.wk_self = get(bl + ".self_attn.linears.1.weight", (int64_t)d * d); b.bk_self = get(bl + ".self_attn.linears.1.bias", d);
+        b.wv_self = get(bl + ".self_attn.linears.2.weight", (int64_t)d * d); b.bv_self = get(bl + ".self_attn.linears.2.bias", d);
+        b.n0g = get(bl + ".sublayer.0.norm.a_2", d); b.n0b = get(bl + ".sublayer.0.norm.b_2", d);
+        b.wo_self = get(bl + ".self_attn.linears.3.weight", (int64_t)d * d);
+        b.wq_src = get(bl + ".src_attn.linears.0.weight", (int64_t)d * d); b.n1g = get(bl + ".sublayer.1.norm.a_2", d);
+        b.wo_src = get(bl + ".src_attn.linears.3.weight", (int64_t)d * d);
+        b.w1 = get(bl + ".ff.w_1.weight", (int64_t)dff * d); b.n2g = get(bl + ".sublayer.2.norm.a_2", d);
+        b.w2 = get(bl + ".ff.w_2.weight", (int64_t)d * dff);
+        b.lw1 = lw1; b.sw1 = sw1; b.hng = get(lp + ".norm.a_2", d);
+        if (!b.wq_self || !b.bq_self || !b.wk_self || !b.bk_self || !b.wv_self || !b.bv_self || !b.n0g || !b.n0b || !b.wo_self || !b.wq_src || !b.n1g || !b.wo_src ||
+            !b.w1 || !b.n2g || !b.w2 || !b.hng)
+            return BOFI_ERR_STATE;
+        ENG_OK(e->derive_bound_f16(b, s));
+    }
     e->host.clear();                          // the host copies are stale now; a later finalize needs set_weight again
     return BOFI_OK;
 }
@@ -1221,6 +1305,12 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->upload_f32(&p_sw2, *sw2)); ENG_OK(e->upload_f32(&p_sb2, *sb2));
         ENG_OK(e->dalloc((char**)&e->b_w1p, (size_t)d * 2 * hh, e->tsz));
         e->heads = bofi::BoundHeadWeights{nf.g, nf.b, p_w1, p_b1, p_lw2, p_lb2, p_sw2, p_sb2, e->b_w1p};
+        e->loop_ready = false;
+        if (e->loop_config_ok()) {      // the persistent loop kernel's operands (filled by derive_bound_f16 below)
+            ENG_OK(e->make_lin(&e->b_heads, {lp + ".Length_classifier1", lp + ".Syntactic_classifier1"}, hh, d, lp + ".norm", 256));
+            for (Lin* l : {&e->b_o_self, &e->b_q_src, &e->b_o_src, &e->b_w1, &e->b_w2, &e->b_heads}) ENG_OK(e->dalloc((char**)&l->wp16, (size_t)l->Npad * l->K, 2));
+            ENG_OK(e->dalloc(&e->b_q0_32, (size_t)d)); ENG_OK(e->dalloc(&e->b_sctab, (size_t)L * 10 * c.heads)); ENG_OK(e->dalloc(&e->b_vtab, (size_t)L * 10 * d));
+        }
     }
 
     e->n_weight_allocs = e->allocs.size();      // everything allocated so far is weights (shared with forks)
@@ -1261,6 +1351,34 @@ int bofi_engine_finalize(bofi_engine_t* e) {
         ENG_OK(e->derive_bound_tables(nullptr));
         ENG_HIP(hipDeviceSynchronize());
     }
+    if (e->loop_config_ok()) {      // fp16 copies and float32 tables of the bounding layer from the float32 parameters (temporaries on the device)
+        std::vector<void*> tmp;
+        auto up = [&](const std::string& name, const float** out) -> int {
+            auto it = e->host.find(name);
+            if (it == e->host.end()) return fail(BOFI_ERR_STATE, "missing weight " + name);
+            void* q = nullptr;
+            ENG_HIP(hipMalloc(&q, it->second.size() * 4));
+            tmp.push_back(q);
+            ENG_HIP(hipMemcpy(q, it->second.data(), it->second.size() * 4, hipMemcpyHostToDevice));
+            *out = (const float*)q;
+            return BOFI_OK;
+        };
+        bofi_engine::BoundSrc b{};
+        const std::string lp = "model.length_predictor";
+        int rc = BOFI_OK;
+        const std::pair<std::string, const float**> items[] = {
+            {bl + ".self_attn.linears.0.weight", &b.wq_self}, {bl + ".self_attn.linears.0.bias", &b.bq_self}, {bl + ".self_attn.linears.1.weight", &b.wk_self},
+            {bl + ".self_attn.linears.1.bias", &b.bk_self}, {bl + ".self_attn.linears.2.weight", &b.wv_self}, {bl + ".self_attn.linears.2.bias", &b.bv_self},
+            {bl + ".sublayer.0.norm.a_2", &b.n0g}, {bl + ".sublayer.0.norm.b_2", &b.n0b}, {bl + ".self_attn.linears.3.weight", &b.wo_self},
+            {bl + ".src_attn.linears.0.weight", &b.wq_src}, {bl + ".sublayer.1.norm.a_2", &b.n1g}, {bl + ".src_attn.linears.3.weight", &b.wo_src},
+            {bl + ".ff.w_1.weight", &b.w1}, {bl + ".sublayer.2.norm.a_2", &b.n2g}, {bl + ".ff.w_2.weight", &b.w2},
+            {lp + ".Length_classifier1.weight", &b.lw1}, {lp + ".Syntactic_classifier1.weight", &b.sw1}, {lp + ".norm.a_2", &b.hng}};
+        for (const auto& it : items) if (rc == BOFI_OK) rc = up(it.first, it.second);
+        if (rc == BOFI_OK) rc = e->derive_bound_f16(b, nullptr);
+        (void)hipDeviceSynchronize();
+        for (void* q : tmp) (void)hipFree(q);
+        if (rc != BOFI_OK) return rc;
+    }
     // NB: hardware-queue assignment follows stream creation order; the capture stream is created here (and in
     // fork) because that order measured best with 4 decodes in flight on torch's pooled streams
     if (!e->cap_stream) ENG_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1295,6 +1413,8 @@ int bofi_engine_bound_step(bofi_engine_t* e, const int* ext_syn, const int* last
     ENG_OK(check_call(e, B, R));
     if (!ext_syn || !last || !len_logp || !syn_logp) return fail(BOFI_ERR_ARG, "null argument");
     if (e->bound_dense) return fail(BOFI_ERR_STATE, "bound_step is the incremental (N_len = 1) form's stage; the dense bounding pass runs inside decode_naic");
+    e->cur_B = B;
+    if (e->bound_loop_ok(R)) return e->bound_loop(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, (hipStream_t)stream);
     ENG_OK(e->bound_tail(nullptr, 1, ext_syn, last, B, BOUND_ATTN, nullptr, nullptr, (hipStream_t)stream));
     return e->enqueue_bound_iter(B, R, att_len, ext_syn, last, 0, len_logp, syn_logp, false, (hipStream_t)stream);
 }
@@ -1330,7 +1450,7 @@ int bofi_engine_decode_saic(bofi_engine_t* e, const void* feats, int feats_dtype
     std::vector<uintptr_t> key = {(uintptr_t)1, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)bound_iters, (uintptr_t)tbits,
-                                  (uintptr_t)e->saic_it_begin, (uintptr_t)e->saic_it_end};
+                                  (uintptr_t)e->saic_it_begin, (uintptr_t)e->saic_it_end, (uintptr_t)e->in_flight, (uintptr_t)bofi::g_env_generation};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode_saic(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length, phrase_syn,
                                       bound_iters, cs);
@@ -1352,7 +1472,8 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
     std::vector<uintptr_t> key = {(uintptr_t)0, (uintptr_t)feats, (uintptr_t)feats_dtype, (uintptr_t)att_len, (uintptr_t)B, (uintptr_t)R,
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
-                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max, (uintptr_t)e->in_flight};
+                                  (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max, (uintptr_t)e->in_flight,
+                                  (uintptr_t)bofi::g_env_generation};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, cs);
