@@ -28,11 +28,20 @@
 #include "bofi_kernels.h"
 #include "bofi_naic.h"
 
+#include <cstdlib>
+
 namespace bofi {
+
+extern int g_env_generation;                   // bumped by bofi_reload_env (gemm_glds.hip)
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// developer aid (BOFI_BL_DBG=1): s_memtime stamps of workgroup 0, wavefront 0, for kernel entry ([0]), loop exit ([1]) and the stage ends of iteration
+// a.dbg - 1 ([2 + i]); read back by bofi_bl_stamps
+__device__ unsigned long long g_bl_stamps[32];
+#define BL_STAMP(i) do { if (a.dbg && it == a.dbg - 1 && blockIdx.x == 0 && tid == 0) g_bl_stamps[2 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 constexpr int BL_G = 16;            // images per workgroup (one 16-column MFMA tile)
 constexpr int BL_PF = 4;            // k-steps of the weight stream in flight per wavefront (divides 16)
@@ -44,9 +53,8 @@ constexpr int BL_OFF_Y = 0;                              // float32 [16][516] re
 constexpr int BL_OFF_X = BL_OFF_Y + BL_G * BL_YP * 4;    // fp16 [16][512] GEMM input rows, 16-byte chunks XOR-swizzled by row (rowblock.hip's rb_off)
 constexpr int BL_OFF_BIG = BL_OFF_X + BL_G * 1024;       // 64 KiB: fp16 hidden rows [16][dff] | float32 queries + probabilities | heads' hidden + logits
 constexpr int BL_OFF_SCT = BL_OFF_BIG + 65536;           // float32 [L*10][8] self-attention scores of row 0 by (position, label, head)
-constexpr int BL_OFF_W2O = BL_OFF_SCT + BL_LMAX * 10 * 8 * 4;      // float32 [30][hh] output layers of both heads, then their 30 biases
-constexpr int BL_OFF_ST = BL_OFF_W2O + (30 * 128 + 32) * 4;        // int32 slot state
-constexpr int BL_ST_INTS = 4 * BL_G + BL_G * BL_LMAX + 2 * BL_G + 16;
+constexpr int BL_OFF_ST = BL_OFF_SCT + BL_LMAX * 10 * 8 * 4;       // int32 slot state: last, finished, phrase_num, att_len [16]; ext_syn, phrase_length, phrase_syn [16][24]; picks [16][2]
+constexpr int BL_ST_INTS = 4 * BL_G + 3 * BL_G * BL_LMAX + 2 * BL_G + 16;
 constexpr int BL_SMEM = BL_OFF_ST + BL_ST_INTS * 4;
 
 __device__ __forceinline__ float bl_clamp16(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }      // (a NaN fails both tests and passes)
@@ -82,29 +90,31 @@ __device__ __forceinline__ void bl_seg(const u32x4* cur, const u32x4* nxt, int l
     }
 }
 
+template <int NTT>      // the cross-attention's row batching: 5 = at most 36 regions (every BASELINE config), 8 = at most 64
 __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     float* Y = reinterpret_cast<float*>(sm + BL_OFF_Y);
     unsigned char* X16 = sm + BL_OFF_X;
     unsigned char* BIG = sm + BL_OFF_BIG;
     float* Q = reinterpret_cast<float*>(BIG);                       // cross-attention queries [16][516]
-    float* PX = reinterpret_cast<float*>(BIG + BL_G * BL_YP * 4);   // cross-attention probabilities [8 wavefronts][64]
     float* PSELF = reinterpret_cast<float*>(BIG);                   // self-attention probabilities [16][8][32]
     float* HID = reinterpret_cast<float*>(BIG);                     // heads' hidden rows [16][260]
     float* LG = HID + BL_G * BL_HP;                                 // logits [16][32]: 0..19 length, 20..29 label
     float* SCT = reinterpret_cast<float*>(sm + BL_OFF_SCT);
-    float* W2O = reinterpret_cast<float*>(sm + BL_OFF_W2O);
     int* s_last = reinterpret_cast<int*>(sm + BL_OFF_ST);
     int* s_fin = s_last + BL_G;
     int* s_pn = s_fin + BL_G;
     int* s_attl = s_pn + BL_G;
     int* s_ext = s_attl + BL_G;                                     // [16][24]
-    int* s_pick = s_ext + BL_G * BL_LMAX;                           // [16][2]
+    int* s_plen = s_ext + BL_G * BL_LMAX;                           // [16][24] phrase_length by slot
+    int* s_psyn = s_plen + BL_G * BL_LMAX;                          // [16][24] phrase_syn by slot
+    int* s_pick = s_psyn + BL_G * BL_LMAX;                          // [16][2]
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;      // (wave in a scalar register: stream pointers stay scalar)
     const int B = a.B, L = a.L, S = a.S, R = a.R, hh = a.hh, dff = a.dff;
     const int b0 = blockIdx.x * BL_G;
     const BoundState st = a.st;
+    if (a.dbg && blockIdx.x == 0 && tid == 0) g_bl_stamps[0] = __builtin_amdgcn_s_memtime();
 
     // ---- this wavefront's weight streams (a weight address never depends on data: the ring runs ahead across stages)
     const int nc1 = dff >> 9;                                       // 64-column chunks of w_1 per wavefront (dff / 64 / 8) = 512-wide K segments of w_2
@@ -122,13 +132,24 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 
     // ---- tables and state into LDS
     for (int i = tid; i < L * 10 * 8; i += 512) SCT[i] = a.sctab[i];
-    for (int i = tid; i < 30 * hh; i += 512) W2O[i] = i < 20 * hh ? a.len_w2[i] : a.syn_w2[i - 20 * hh];
-    if (tid < 30) W2O[30 * hh + tid] = tid < 20 ? a.len_b2[tid] : a.syn_b2[tid - 20];
+    // output layers of both heads (float32): thread (o, q) = (tid >> 4, tid & 15) of the first 480 holds every 16th weight of output o for the whole loop
+    constexpr int W2T = 8;                                          // terms per thread: hh <= 16 * W2T
+    const int w2o = tid >> 4, w2q = tid & 15;
+    float w2v[W2T];
+#pragma unroll
+    for (int t = 0; t < W2T; ++t) {
+        const int k = w2q + 16 * t;
+        w2v[t] = (w2o < 30 && k < hh) ? (w2o < 20 ? a.len_w2[w2o * hh + k] : a.syn_w2[(w2o - 20) * hh + k]) : 0.f;
+    }
+    const float w2b = w2o < 20 ? a.len_b2[w2o] : (w2o < 30 ? a.syn_b2[w2o - 20] : 0.f);
     {
         const int* ext_src = a.ext_syn_in ? a.ext_syn_in : st.ext_syn;
         for (int i = tid; i < BL_G * BL_LMAX; i += 512) {
             const int im = i / BL_LMAX, p = i - im * BL_LMAX;
-            s_ext[i] = (b0 + im < B && p < L) ? ext_src[(size_t)(b0 + im) * L + p] : 0;
+            const bool in = b0 + im < B && p < L;
+            s_ext[i] = in ? ext_src[(size_t)(b0 + im) * L + p] : 0;
+            s_plen[i] = (in && a.update) ? st.phrase_length[(size_t)(b0 + im) * L + p] : 0;
+            s_psyn[i] = (in && a.update) ? st.phrase_syn[(size_t)(b0 + im) * L + p] : 0;
         }
         if (tid < BL_G) {
             const int b = b0 + tid;
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         const int l15 = lane & 15, g = lane >> 4;
         const int xbase = bl_lane_base(l15, g, 1024);
         const int ncol = wave * 64 + g * 4;                         // first output column of tile 0 of this lane (tile nt: + nt*16) in a 512-wide stage
+        BL_STAMP(0);
         // ================= S1: row-0 self-attention over the (position, label) tables =================
         {   // probabilities: a 32-lane half per (image, head), lane = key position (row 0 sees keys p < last: tgt_mask[j, 0, :last])
             const int hw = wave * 2 + (lane >> 5), li = lane & 31;
@@ -193,6 +215,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             }
         }
         __syncthreads();
+        BL_STAMP(1);
         {   // ctx = P . V rows of the float32 table: wavefront w owns images 2w, 2w + 1, a lane 8 columns (head lane / 8)
             const int h = lane >> 3;
 #pragma unroll
@@ -202,11 +225,11 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = 0.f;
                 if (!s_fin[i]) {
-                    for (int j0 = 0; j0 < n; j0 += 4) {
-                        float4 v0[4], v1[4];
-                        float p[4];
+                    for (int j0 = 0; j0 < n; j0 += 8) {
+                        float4 v0[8], v1[8];
+                        float p[8];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < 8; ++t) {
                             const int jj = min(j0 + t, n - 1);
                             const float* vr = a.vtab + (size_t)(jj * 10 + s_ext[i * BL_LMAX + jj]) * 512 + lane * 8;
                             v0[t] = *reinterpret_cast<const float4*>(vr);
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                             p[t] = j0 + t < n ? PSELF[(i * 8 + h) * 32 + j0 + t] : 0.f;
                         }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < 8; ++t) {
                             acc[0] = fmaf(p[t], v0[t].x, acc[0]); acc[1] = fmaf(p[t], v0[t].y, acc[1]); acc[2] = fmaf(p[t], v0[t].z, acc[2]); acc[3] = fmaf(p[t], v0[t].w, acc[3]);
                             acc[4] = fmaf(p[t], v1[t].x, acc[4]); acc[5] = fmaf(p[t], v1[t].y, acc[5]); acc[6] = fmaf(p[t], v1[t].z, acc[6]); acc[7] = fmaf(p[t], v1[t].w, acc[7]);
                         }
@@ -226,6 +249,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             }
         }
         __syncthreads();
+        BL_STAMP(2);
         f16x8 xb[16];
         f32x4 acc[4];
         // ================= S2: y1 = (x0 + bo_self) + Wo_self . ctx =================
@@ -242,8 +266,10 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                 *reinterpret_cast<float4*>(Y + l15 * BL_YP + ncol + nt * 16) = make_float4(acc[nt][0] + cv[nt].x, acc[nt][1] + cv[nt].y, acc[nt][2] + cv[nt].z, acc[nt][3] + cv[nt].w);
         }
         __syncthreads();
+        BL_STAMP(3);
         norm_rows(lane);
         __syncthreads();
+        BL_STAMP(4);
         // ================= S3: q = Wq_src' . LN(y1) + c =================
         {
             float4 cv[4];
@@ -258,79 +284,74 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                 *reinterpret_cast<float4*>(Q + l15 * BL_YP + ncol + nt * 16) = make_float4(acc[nt][0] + cv[nt].x, acc[nt][1] + cv[nt].y, acc[nt][2] + cv[nt].z, acc[nt][3] + cv[nt].w);
         }
         __syncthreads();
-        // ================= S4: cross-attention of the 16 query rows over their images' regions (keys: lane = region) =================
+        BL_STAMP(5);
+        // ================= S4: cross-attention of the 16 query rows over their images' regions =================
+        // Wavefront w owns images 2w, 2w + 1.  A lane owns 8 columns (lane*8 .. +7: head lane / 8) of EVERY region row: a load instruction of the
+        // wavefront is one whole 1-KiB K (or V) row.  A key's score is the sum over the 8 lanes of its head's octet (three DPP steps); the softmax runs
+        // in the lane (the octet's lanes hold the same numbers), P.V accumulates in the lane: no cross-lane traffic besides the octet sums, no LDS.
+        // Rows go through two register buffers of BR rows, NB batches per pass (NB even: the buffers alternate across the K pass, the V pass and
+        // the next image without a drain); every load is unconditional (rows past R: the last row again, weighted 0) so that the waits count exactly.
         {
             asm volatile("" : "+v"(lane));
-            const int cch = (lane & 8) ? 7 - (lane & 7) : (lane & 7);          // row_mirror partners (l, 15 - l) hold the same 8-column chunk
-            const int js = ((lane >> 4) << 1) | ((lane >> 3) & 1);             // key subset of the P.V sums
-            float* ps = PX + wave * 64;
-            // lane offsets (elements) into an (image, head)'s K / V rows: the same for every unit; the unit's base is wave-uniform
-            const int koff = min(lane, R - 1) * a.ldkv;
-            int voff[8];
+            constexpr int BR = NTT == 5 ? 9 : 8, NB = NTT == 5 ? 4 : 8, RMAX = BR * NB;      // 36 rows (every BASELINE config) or 64
+            const bf16_t* kbase = a.k + lane * 8;
+            const bf16_t* vbase = a.v + lane * 8;
+            u32x4 buf[2][BR];
+            auto issue = [&](u32x4 (&bb)[BR], const bf16_t* base, int bi, int j0) {
+                const bf16_t* p = base + (size_t)bi * R * a.ldkv;
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) voff[tt] = min(js + 8 * tt, R - 1) * a.ldkv + cch * 8;      // keys past R: the last row again, weighted 0 below
-            auto issue = [&](int t, u32x4 (&kk)[8], u32x4 (&vv)[8]) {
-                const int i = 2 * wave + (t >> 3), h = t & 7, bi = min(b0 + i, B - 1);
-                const bf16_t* kp = a.k + (size_t)bi * R * a.ldkv + h * 64;
-                const bf16_t* vp = a.v + (size_t)bi * R * a.ldkv + h * 64;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) kk[c] = *reinterpret_cast<const u32x4*>(kp + koff + c * 8);
-#pragma unroll
-                for (int tt = 0; tt < 8; ++tt) vv[tt] = *reinterpret_cast<const u32x4*>(vp + voff[tt]);
+                for (int r = 0; r < BR; ++r) bb[r] = *reinterpret_cast<const u32x4*>(p + (size_t)min(j0 + r, R - 1) * a.ldkv);
             };
-            auto compute = [&](int t, const u32x4 (&kk)[8], const u32x4 (&vv)[8]) {
-                const int i = 2 * wave + (t >> 3), h = t & 7, kl = s_attl[i];
-                const float* qr = Q + i * BL_YP + h * 64;
-                float s = 0.f;
+            issue(buf[0], kbase, min(b0 + 2 * wave, B - 1), 0);
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * wave + u, bi = min(b0 + i, B - 1), kl = s_attl[i];
+                const float4 qa = *reinterpret_cast<const float4*>(Q + i * BL_YP + lane * 8);
+                const float4 qb = *reinterpret_cast<const float4*>(Q + i * BL_YP + lane * 8 + 4);
+                float sc[RMAX];
+                float m = -INFINITY;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float4 qa = *reinterpret_cast<const float4*>(qr + c * 8);
-                    const float4 qb = *reinterpret_cast<const float4*>(qr + c * 8 + 4);
-                    const u32x4 kv = kk[c];
-                    s += qa.x * bl_lo(kv[0]) + qa.y * bl_hi(kv[0]) + qa.z * bl_lo(kv[1]) + qa.w * bl_hi(kv[1]);
-                    s += qb.x * bl_lo(kv[2]) + qb.y * bl_hi(kv[2]) + qb.z * bl_lo(kv[3]) + qb.w * bl_hi(kv[3]);
+                for (int bt = 0; bt < NB; ++bt) {
+                    if (bt + 1 < NB) issue(buf[(bt + 1) & 1], kbase, bi, (bt + 1) * BR);
+                    else issue(buf[0], vbase, bi, 0);
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) {
+                        const u32x4 kv = buf[bt & 1][r];
+                        float d = qa.x * bl_lo(kv[0]);
+                        d = fmaf(qa.y, bl_hi(kv[0]), d); d = fmaf(qa.z, bl_lo(kv[1]), d); d = fmaf(qa.w, bl_hi(kv[1]), d);
+                        d = fmaf(qb.x, bl_lo(kv[2]), d); d = fmaf(qb.y, bl_hi(kv[2]), d); d = fmaf(qb.z, bl_lo(kv[3]), d); d = fmaf(qb.w, bl_hi(kv[3]), d);
+                        d = oct_sum(d) * 0.125f;                              // / sqrt(d_k), d_k = 64
+                        const int j = bt * BR + r;
+                        sc[j] = j < kl ? d : -INFINITY;
+                        m = fmaxf(m, sc[j]);
+                    }
                 }
-                s *= 0.125f;                                              // / sqrt(d_k), d_k = 64
-                const bool live = lane < kl;
-                const float m = wave_max(live ? s : -INFINITY);
-                const float e = live ? expf(s - m) : 0.f;
-                const float sum = wave_sum(e);
-                ps[lane] = e / sum;                                       // no visible region: NaN, as softmax over an all-masked row of -inf
-                __builtin_amdgcn_wave_barrier();
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < RMAX; ++j) { sc[j] = j < kl ? expf(sc[j] - m) : 0.f; sum += sc[j]; }
+                const float inv = 1.0f / sum;                                 // no visible region: 0 * (1 / 0) = NaN, as softmax over an all-masked row of -inf
                 float o[8];
 #pragma unroll
                 for (int e8 = 0; e8 < 8; ++e8) o[e8] = 0.f;
 #pragma unroll
-                for (int tt = 0; tt < 8; ++tt) {
-                    const float p = ps[js + 8 * tt];                      // 0 from the key count on (NaN everywhere for an image without regions)
-                    const u32x4 v = vv[tt];
+                for (int bt = 0; bt < NB; ++bt) {
+                    if (bt + 1 < NB) issue(buf[(bt + 1) & 1], vbase, bi, (bt + 1) * BR);
+                    else issue(buf[0], kbase, min(bi + 1, B - 1), 0);         // the next image's first K rows (after the last image: a redundant batch)
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) { o[2 * e4] += p * bl_lo(v[e4]); o[2 * e4 + 1] += p * bl_hi(v[e4]); }
-                }
-                __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < BR; ++r) {
+                        const u32x4 v = buf[bt & 1][r];
+                        const float p = sc[bt * BR + r] * inv;
 #pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    float v = o[e8];
-                    v += dpp_f32<DPP_MIRROR>(v);
-                    o[e8] = xor32_sum(xor16_sum(v));
+                        for (int e4 = 0; e4 < 4; ++e4) { o[2 * e4] = fmaf(p, bl_lo(v[e4]), o[2 * e4]); o[2 * e4 + 1] = fmaf(p, bl_hi(v[e4]), o[2 * e4 + 1]); }
+                    }
                 }
-                if (lane < 8) {
-                    u32x4 w;
-                    w[0] = bl_pack(o[0], o[1]); w[1] = bl_pack(o[2], o[3]); w[2] = bl_pack(o[4], o[5]); w[3] = bl_pack(o[6], o[7]);
-                    *reinterpret_cast<u32x4*>(X16 + i * 1024 + (((h * 8 + cch) ^ (i & 15)) << 4)) = w;
-                }
-            };
-            u32x4 ka[8], va[8], kc[8], vc[8];
-            issue(0, ka, va);
-#pragma unroll 1
-            for (int t = 0; t < 16; t += 2) {
-                issue(t + 1, kc, vc);
-                compute(t, ka, va);
-                if (t + 2 < 16) issue(t + 2, ka, va);
-                compute(t + 1, kc, vc);
+                u32x4 w;
+                w[0] = bl_pack(o[0], o[1]); w[1] = bl_pack(o[2], o[3]); w[2] = bl_pack(o[4], o[5]); w[3] = bl_pack(o[6], o[7]);
+                *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = w;
             }
         }
         __syncthreads();
+        BL_STAMP(6);
         // ================= S5: y2 = y1 + Wo_src . ctx2 + bo =================
         {
             float4 cv[4];
@@ -348,8 +369,10 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             }
         }
         __syncthreads();
+        BL_STAMP(7);
         norm_rows(lane);
         __syncthreads();
+        BL_STAMP(8);
         // ================= S6: h = relu(W1' . LN(y2) + c1): hidden columns (wave*nc1 + cc)*64 .. +63 =================
         bl_load_x(X16, xbase, xb);
 #pragma unroll 1
@@ -370,6 +393,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             }
         }
         __syncthreads();
+        BL_STAMP(9);
         // ================= S7: y3 = y2 + W2 . h + b2 =================
         {
             float4 cv[4];
@@ -392,8 +416,10 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             }
         }
         __syncthreads();
+        BL_STAMP(10);
         norm_rows(lane);
         __syncthreads();
+        BL_STAMP(11);
         // ================= S8: heads.  hidden = relu(W1h' . LN(y3) + c) (both heads side by side, 256 columns: wavefronts 0-3) =================
         if (wave < 4) {
             float4 cv[4];
@@ -409,17 +435,20 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                                                                                               fmaxf(acc[nt][2] + cv[nt].z, 0.f), fmaxf(acc[nt][3] + cv[nt].w, 0.f));
         }
         __syncthreads();
-        if (tid < BL_G * 30) {          // output layers (float32): thread = (image, output)
-            const int i = tid / 30, o = tid - i * 30;
-            const float* hv = HID + i * BL_HP + (o < 20 ? 0 : hh);
-            const float* w = W2O + o * hh;
-            float s0 = 0.f, s1 = 0.f;
-            int k = 0;
-            for (; k + 1 < hh; k += 2) { s0 = fmaf(w[k], hv[k], s0); s1 = fmaf(w[k + 1], hv[k + 1], s1); }
-            if (k < hh) s0 = fmaf(w[k], hv[k], s0);
-            LG[i * 32 + o] = (s0 + s1) + W2O[30 * hh + o];
+        BL_STAMP(12);
+        {   // output layers (float32): 16 lanes per output, their weights in registers; one DPP row reduction per image
+            const float* hv = HID + (w2o < 20 ? 0 : hh);
+#pragma unroll 4
+            for (int i = 0; i < BL_G; ++i) {
+                float s0 = 0.f;
+#pragma unroll
+                for (int t = 0; t < W2T; ++t) { const int k = w2q + 16 * t; s0 = fmaf(w2v[t], k < hh ? hv[i * BL_HP + k] : 0.f, s0); }
+                s0 = row16_sum(s0);
+                if (w2q == 0 && w2o < 30) LG[i * 32 + w2o] = s0 + w2b;
+            }
         }
         __syncthreads();
+        BL_STAMP(13);
         {   // log-softmax and first-max pick: a 32-lane half per (image, head); torch.max semantics: the first NaN wins, else the first maximum (:380-383)
             const int hw = wave * 2 + (lane >> 5), li = lane & 31;
 #pragma unroll
@@ -445,8 +474,9 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             }
         }
         __syncthreads();
-        if (tid < BL_G && a.update && b0 + tid < B && !s_fin[tid]) {      // slot bookkeeping of core_NAIC (TransformerModel.py:1843-1869), one thread per image
-            const int i = tid, b = b0 + i;
+        BL_STAMP(14);
+        if (tid < BL_G && a.update && b0 + tid < B && !s_fin[tid]) {      // slot bookkeeping of core_NAIC (TransformerModel.py:1843-1869), one thread per image, in LDS
+            const int i = tid;
             int ln = s_pick[i * 2];
             const int sn = s_pick[i * 2 + 1], la = s_last[i];
             bool fin = false;
@@ -455,21 +485,27 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             } else {
                 if (ln + la >= S + 1) { ln = S + 1 - la; fin = true; }      // truncate (:1850-1855)
                 const int slot = s_pn[i];                                   // == iteration index while unfinished (Q3)
-                st.phrase_length[(size_t)b * L + slot] = ln;
-                st.phrase_syn[(size_t)b * L + slot] = sn;
-                st.phrase_num[b] = slot + 1;
+                s_plen[i * BL_LMAX + slot] = ln;
+                s_psyn[i * BL_LMAX + slot] = sn;
                 s_pn[i] = slot + 1;
-                for (int p = la; p < la + ln; ++p) { st.ext_syn[(size_t)b * L + p] = sn; s_ext[i * BL_LMAX + p] = sn; }
-                st.last[b] = la + ln;
-                s_last[i] = la + ln;
-                if (st.klen) {                                              // tgt_mask[j, la:, :la+ln] = True; tgt_mask[j, 0, :la+ln] = True (:1859-1867)
-                    for (int r = la; r < L; ++r) st.klen[(size_t)b * L + r] = la + ln;
-                    st.klen[(size_t)b * L] = la + ln;
-                }
+                for (int p = la; p < la + ln; ++p) s_ext[i * BL_LMAX + p] = sn;
+                s_last[i] = la + ln;                                        // (tgt_mask[j, 0, :la+ln] = True :1859-1867: row 0 sees keys p < last)
             }
-            if (fin) { st.finished[b] = 1; s_fin[i] = 1; }
+            if (fin) s_fin[i] = 1;
         }
         __syncthreads();
+        BL_STAMP(15);
+    }
+    if (a.dbg && blockIdx.x == 0 && tid == 0) { g_bl_stamps[1] = __builtin_amdgcn_s_memtime(); g_bl_stamps[31] = (unsigned long long)it_done; }
+    if (a.update) {      // the group's slot state back to the engine's arrays (the filling pass and the export read them)
+        for (int i = tid; i < BL_G * BL_LMAX; i += 512) {
+            const int im = i / BL_LMAX, p = i - im * BL_LMAX;
+            if (b0 + im < B && p < L) {
+                const size_t o = (size_t)(b0 + im) * L + p;
+                st.ext_syn[o] = s_ext[i]; st.phrase_length[o] = s_plen[i]; st.phrase_syn[o] = s_psyn[i];
+            }
+        }
+        if (tid < BL_G && b0 + tid < B) { st.last[b0 + tid] = s_last[tid]; st.finished[b0 + tid] = s_fin[tid]; st.phrase_num[b0 + tid] = s_pn[tid]; }
     }
     if (tid == 0 && a.update) {
         atomicMax(&st.counters[1], it_done);                               // iterations in which some image (of any group) was active
@@ -490,10 +526,15 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
     if (!a.update && (!a.ext_syn_in || !a.last_in)) return BOFI_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess) return BOFI_ERR_HIP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess)
+            return BOFI_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(bound_loop_kernel, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, a);
+    BoundLoopArgs v = a;
+    { static int gen = -1, dbg = 0; if (gen != g_env_generation) { const char* e = getenv("BOFI_BL_DBG"); dbg = e ? atoi(e) : 0; gen = g_env_generation; } v.dbg = dbg; }
+    if (a.R <= 36) hipLaunchKernelGGL(bound_loop_kernel<5>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
+    else hipLaunchKernelGGL(bound_loop_kernel<8>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
     BOFI_CHECK_LAUNCH();
     // FLOP tally: the GEMM work of the iterations is data-dependent; counted as skippable work of max_iters iterations like the launches it replaces
     g_gemm_flops_skippable += (double)a.max_iters * a.B * (2.0 * 3 * 512 * 512 + 4.0 * 512 * a.dff);
@@ -611,3 +652,7 @@ int launch_bound_tables(const BoundTablesArgs& a, hipStream_t s) {
 }
 
 }  // namespace bofi
+
+extern "C" int bofi_bl_stamps(unsigned long long* host_out) {      // developer aid: the 32 stamps of the last BOFI_BL_DBG launch
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bofi::g_bl_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
+}
