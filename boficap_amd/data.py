@@ -20,6 +20,19 @@ import numpy as np
 
 from .collate import phrase_collate
 
+def collate_regions(att_list: Sequence[np.ndarray]):
+    """The region side of the loader's collate (captioning/data/dataloader.py:326-338): images' region features [r_i, F] stacked into a zero-padded
+    float32 [B, max r_i, F] and a float32 mask [B, max r_i] of ones over the real regions -- ``None`` when every image has the same count, as the
+    loader returns it (the model then builds an all-ones mask itself, TransformerModel.py:1684-1686).  Pinned by tests/golden/tiny_collate.npz."""
+    R = max(a.shape[0] for a in att_list)
+    feats = np.zeros((len(att_list), R, att_list[0].shape[1]), np.float32)
+    masks = np.zeros((len(att_list), R), np.float32)
+    for i, a in enumerate(att_list):
+        feats[i, :a.shape[0]] = a
+        masks[i, :a.shape[0]] = 1
+    return feats, (None if masks.sum() == masks.size else masks)
+
+
 FIELDS = ("labels", "label_start_ix", "label_end_ix", "label_length", "phrase_num", "phrase_length", "phrase_label")
 
 

@@ -10,7 +10,11 @@ the committed .npz files travel instead).  For every case it
   5. stores inputs + reference outputs as data.
 
 Harness-side shims (none touches the reference's files): empty stand-in modules
-for the unused imports ``turtle``/``thop``, and a no-op ``torch.cuda.synchronize``.
+for the unused imports ``turtle``/``thop``, and a no-op ``torch.cuda.synchronize``.  For the collate case
+(``tiny_collate``: the reference's own ``Dataset.collate_func``, dataloader.py:231-452) also empty stand-ins for
+``h5py`` / ``lmdbdict`` / ``lmdbdict.methods`` -- imported by dataloader.py at module level, used only by the
+file readers, never by ``collate_func`` -- and a plain namespace in place of ``self`` that carries the attributes
+the function reads, INCLUDING ``len_idx``, which the shipped ``Dataset.__init__`` never sets.
 
 Run:  python oracle/make_golden.py
 """
@@ -34,6 +38,15 @@ sys.dont_write_bytecode = True
 sys.path = [REF] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
 _t = types.ModuleType("turtle"); _t.Turtle = object; sys.modules["turtle"] = _t
 _p = types.ModuleType("thop"); _p.profile = lambda *a, **k: None; sys.modules["thop"] = _p
+
+# (collate case) module-level imports of captioning/data/dataloader.py that collate_func never touches
+for _name in ("h5py", "lmdbdict", "lmdbdict.methods"):
+    if _name not in sys.modules:
+        _m = types.ModuleType(_name)
+        sys.modules[_name] = _m
+sys.modules["lmdbdict"].lmdbdict = object
+sys.modules["lmdbdict.methods"].DUMPS_FUNC = {}
+sys.modules["lmdbdict.methods"].LOADS_FUNC = {}
 
 import torch                                                   # noqa: E402
 
@@ -539,6 +552,67 @@ def run_loss_wrapper_xe_case(name, cfg, sd, n_img, spi, seed):
     return dict(n_img=n_img, spi=spi, loss=float(o["loss"]))
 
 
+def run_collate_case(name, cfg, seed, n_img=6, spi=5):
+    """The reference's own collate (captioning/data/dataloader.py:231-452, ``Dataset.collate_func`` called unbound on a namespace) on
+    sampled captions that hit both branches of the previous-phrase copy (:396-412: squeeze when cur <= prev, position-wise stretch with and
+    without a remainder when cur > prev), ragged region counts (att_masks built, :326-338) and a batch of equal counts (att_masks None).
+    Stored: the loader-side inputs and every tensor the reference returns; asserted: oracle/training_batch.py::collate_loops reproduces them."""
+    import captioning.data.dataloader as ref_dl
+    from training_batch import collate_loops
+    assert os.path.abspath(ref_dl.__file__).startswith(REF), ref_dl.__file__
+    rng = np.random.default_rng(seed)
+    S, L = cfg.seq_length, cfg.seq_length + 2
+    n_cap = n_img * spi
+    seqs = np.zeros((n_cap, S), np.int64)
+    plen = np.zeros((n_cap, S), np.int64)
+    psyn = np.zeros((n_cap, S), np.int64)
+    pnum = np.zeros(n_cap, np.int64)
+    for n in range(n_cap):
+        lens = rng.integers(1, 8, int(rng.integers(1, 9)))          # phrases of 1..7 tokens: squeeze, exact stretch and stretch with remainder all occur
+        while lens.sum() > S:
+            lens = lens[:-1]
+        P = len(lens)
+        pnum[n], plen[n, :P], psyn[n, :P] = P, lens, rng.integers(4, 7, P)
+        seqs[n, :lens.sum()] = rng.integers(7, cfg.tgt_vocab, lens.sum())
+    stretch_exact = stretch_rem = squeeze = 0
+    for n in range(n_cap):
+        pl = [1] + plen[n, :pnum[n]].tolist()
+        for j in range(1, len(pl)):
+            if pl[j] <= pl[j - 1]: squeeze += 1
+            elif pl[j] % pl[j - 1] == 0: stretch_exact += 1
+            else: stretch_rem += 1
+    assert squeeze and stretch_exact and stretch_rem, (squeeze, stretch_exact, stretch_rem)
+    out = {}
+    for tag, regions in (("ragged", rng.integers(10, 37, n_img)), ("full", np.full(n_img, 36))):
+        feats = [np.abs(rng.standard_normal((int(r), 8))).astype(np.float32) for r in regions]
+        me = types.SimpleNamespace(
+            seq_per_img=spi, seq_length=S, pp_mode="phrase", train_mode="UIC", h5_label_file=True, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx,
+            pad_idx=cfg.pad_idx, len_idx=cfg.len_idx,
+            label=seqs, label_start_ix=np.arange(n_img) * spi + 1, label_end_ix=(np.arange(n_img) + 1) * spi,
+            info={"images": [{"id": 1000 + i, "file_path": "img%d.jpg" % i} for i in range(n_img)]}, split_ix={"train": list(range(n_img))})
+        batch = []
+        for i in range(n_img):
+            sl = slice(i * spi, (i + 1) * spi)
+            batch.append((np.zeros((0,), np.float32), feats[i], seqs[sl], pnum[sl], plen[sl], psyn[sl], i, i + 1, False))
+        data = ref_dl.Dataset.collate_func(me, batch, "train")
+        flat = lambda t: t.numpy().reshape(n_cap, *t.shape[2:])
+        chk = collate_loops(cfg, flat(data["labels"]), pnum, plen, psyn)
+        assert tuple(data["extend_phrase_seq_mask"].shape) == (n_img, spi, S * S)      # the loader hands the [S, S] masks over FLATTENED (:440); _forward restores them (TransformerModel.py:1722)
+        for k, v in chk.items():
+            ref_v = flat(data[k]).reshape(v.shape) if k == "extend_phrase_seq_mask" else flat(data[k])
+            assert v.shape == ref_v.shape and (v == ref_v).all(), (tag, k)
+        assert (data["att_masks"] is None) == (tag == "full")
+        for k in ("labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq", "extend_phrase_seq_mask", "masks", "phrase"):
+            out[f"{tag}_{k}"] = data[k].numpy()
+        out[f"{tag}_att_feats"] = data["att_feats"].numpy()
+        out[f"{tag}_att_masks"] = data["att_masks"].numpy() if data["att_masks"] is not None else np.zeros((0,), np.float32)
+        out[f"{tag}_regions"] = np.asarray(regions, np.int64)
+        out[f"{tag}_gts_first"] = np.asarray(data["gts"][0])
+    out.update(in_seqs=seqs, in_phrase_num=pnum, in_phrase_length=plen, in_phrase_syn=psyn)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    return dict(n_img=n_img, seq_per_img=spi, seed=seed, squeeze=squeeze, stretch_exact=stretch_exact, stretch_with_remainder=stretch_rem)
+
+
 def main():
     only = set(a for a in sys.argv[1:] if not a.startswith("-"))          # developer convenience: regenerate the named cases only
     os.makedirs(OUT, exist_ok=True)
@@ -627,6 +701,9 @@ def main():
     manifest["tiny_loss_wrapper_xe"] = dict(config="TINY", seed=0, gen_scale=1.0, digest=W.digest(sd_t),
                                             **run_loss_wrapper_xe_case("tiny_loss_wrapper_xe", TINY, sd_t, 2, 3, 9))
     print("tiny_loss_wrapper_xe", manifest["tiny_loss_wrapper_xe"])
+    # the loader's phrase-aware collate (dataloader.py:231-452): the reference's own function on sampled captions
+    manifest["tiny_collate"] = dict(config="TINY", **run_collate_case("tiny_collate", TINY, 17))
+    print("tiny_collate", manifest["tiny_collate"])
     # a two-layer bounding network (configs/uic_sd_N2.yml): the upper layer reads the lower layer's output of every visible row, so
     # the bound step is no longer a function of row 0 alone -- the engine's dense bounding pass is checked against this
     sd_2 = W.make_state_dict(TINY_N2, seed=0, gen_scale=6.0)

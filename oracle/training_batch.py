@@ -3,6 +3,10 @@
 Restates captioning/data/dataloader.py:343-428 (the phrase-aware part of collate_func) for captions
 drawn at random: per caption 2..6 phrases of 1..3 tokens, labels [N, S+2] with
 [BOS] at position 0, the tokens from position 1 and [EOS] at position S+1 (dataloader.py:295-300).
+
+PINNED (round 5): oracle/make_golden.py calls the reference's own ``Dataset.collate_func`` (dataloader.py:231-452) on sampled captions
+that take both branches of the previous-phrase copy, asserts ``collate_loops`` reproduces every tensor it returns and stores them as
+tests/golden/tiny_collate.npz; tests/test_oracle_golden.py re-checks this file against that fixture.
 """
 from __future__ import annotations
 

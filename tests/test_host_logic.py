@@ -114,6 +114,43 @@ def test_vectorised_phrase_collate_equals_the_loops():
         phrase_collate(np.zeros((1, S + 2), np.int64), np.array([[0, 2] + [0] * (S - 2)]), np.zeros((1, S), np.int64))
 
 
+def test_collate_against_the_reference_loader(manifest):
+    """tests/golden/tiny_collate.npz holds what the REFERENCE's Dataset.collate_func (captioning/data/dataloader.py:231-452) returned for sampled
+    captions (squeeze, exact stretch and stretch with a remainder all present) and ragged / equal region counts: the vectorised phrase collate, the
+    label store's batch and the region collate must reproduce it."""
+    from boficap_amd.collate import phrase_collate
+    from boficap_amd.config import TINY
+    from boficap_amd.data import LabelStore, collate_regions
+    from conftest import load_golden
+    g = load_golden("tiny_collate")
+    man = manifest["tiny_collate"]
+    assert man["squeeze"] > 0 and man["stretch_exact"] > 0 and man["stretch_with_remainder"] > 0
+    n_img, spi, S = man["n_img"], man["seq_per_img"], TINY.seq_length
+    n_cap = n_img * spi
+    seqs, pn, pl, ps = g["in_seqs"], g["in_phrase_num"], g["in_phrase_length"], g["in_phrase_syn"]
+    labels = np.zeros((n_cap, S + 2), np.int64)
+    labels[:, 1:S + 1], labels[:, 0], labels[:, S + 1] = seqs, TINY.bos_idx, TINY.eos_idx
+    b = phrase_collate(labels, pl, ps, pad_idx=TINY.pad_idx, bos_idx=TINY.bos_idx, eos_idx=TINY.eos_idx, len_idx=TINY.len_idx)
+    for tag in ("ragged", "full"):
+        for k, v in b.items():
+            ref = g[f"{tag}_{k}"].reshape(v.shape)               # (the loader hands the [S, S] masks over flattened, dataloader.py:440)
+            assert (v == ref).all(), (tag, k)
+        regions = g[f"{tag}_regions"]
+        feats, masks = collate_regions([g[f"{tag}_att_feats"][i, :int(r)] for i, r in enumerate(regions)])
+        assert feats.shape == g[f"{tag}_att_feats"].shape and (feats == g[f"{tag}_att_feats"]).all()
+        if tag == "full":
+            assert masks is None and g["full_att_masks"].size == 0
+        else:
+            assert (masks == g["ragged_att_masks"]).all()
+    # the label store on the same captions as a label file (image i owns captions i*spi .. +spi: the run it draws is the whole range)
+    store = LabelStore(dict(labels=seqs, label_start_ix=np.arange(n_img) * spi + 1, label_end_ix=(np.arange(n_img) + 1) * spi, phrase_num=pn,
+                            phrase_length=pl, phrase_label=ps), pad_idx=TINY.pad_idx, bos_idx=TINY.bos_idx, eos_idx=TINY.eos_idx, len_idx=TINY.len_idx)
+    sb = store.batch(list(range(n_img)), spi, np.random.default_rng(0))
+    for k in ("labels", "phrase_num", "phrase_length", "phrase_syn", "extend_phrase_syn_seq", "extend_phrase_seq", "extend_phrase_seq_mask"):
+        assert (sb[k].reshape(g[f"full_{k}"].shape) == g[f"full_{k}"]).all(), k
+    assert (sb["gts"][0] == g["full_gts_first"]).all()
+
+
 def test_noam_rate_and_bucket_layout():
     from boficap_amd.trainer import FlatBucket, noam_rate
     assert abs(noam_rate(1, 512, 1.0, 20000) - 512 ** -0.5 * 20000 ** -1.5) < 1e-15          # misc.py:179-185

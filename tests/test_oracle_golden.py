@@ -273,3 +273,19 @@ def test_oracle_scheduled_sampling(manifest, weight_cache):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
         else:
             assert abs(float(p.grad.norm()) - ref_norm) <= 1e-3 * max(float(ref_norm), 1e-3), n
+
+
+def test_oracle_collate_matches_the_reference_loader(manifest):
+    """oracle/training_batch.py::collate_loops (the checker of boficap_amd.collate) against what the reference's own
+    Dataset.collate_func returned (tests/golden/tiny_collate.npz, captioning/data/dataloader.py:231-452)."""
+    from boficap_amd.config import TINY
+    from training_batch import collate_loops
+    g = load_golden("tiny_collate")
+    S = TINY.seq_length
+    n_cap = g["in_seqs"].shape[0]
+    labels = np.zeros((n_cap, S + 2), np.int64)
+    labels[:, 1:S + 1], labels[:, 0], labels[:, S + 1] = g["in_seqs"], TINY.bos_idx, TINY.eos_idx
+    assert (labels == g["ragged_labels"].reshape(n_cap, S + 2)).all()                  # the loader's [BOS] / [EOS] framing (:295-300)
+    out = collate_loops(TINY, labels, g["in_phrase_num"], g["in_phrase_length"], g["in_phrase_syn"])
+    for k, v in out.items():
+        assert (v == g["ragged_" + k].reshape(v.shape)).all() and (v == g["full_" + k].reshape(v.shape)).all(), k
