@@ -367,6 +367,9 @@ def run_xe(args, ctx, log, cpu=True):
     return res
 
 
+DP_PHASE = ["not started"]      # where the data-parallel secondary is (read by the watchdog of main(): a hang's last phase goes into the record)
+
+
 def run_xe_dp(args, ctx, log):
     """--gpus N > 1: BASELINE config 3 with its REAL exchange step (the decode shards with no collective, so the scaling run would never
     exercise RCCL otherwise): XE 64 x 5 per rank, float32 ring all-reduce and the bf16 mesh-direct wire, each against the same step
@@ -381,6 +384,8 @@ def run_xe_dp(args, ctx, log):
     sd = W.make_state_dict(cfg, seed=0)
     out = {"rccl_ranks": world, "batch_per_rank": 64, "captions_per_image": 5}
     for wire in (None, "bf16"):
+        wname = "fp32 ring all-reduce" if wire is None else "bf16 mesh-direct wire"
+        DP_PHASE[0] = f"{wname}: building the model and the trainer"
         opt = cfg.to_opt()
         opt.seed = 42 + 1000003 * rank
         opt.bofi_train_dtype = torch.bfloat16
@@ -420,8 +425,11 @@ def run_xe_dp(args, ctx, log):
         def local_step():
             tr.forward_backward(batch)
             tr.optimizer_step()
+        DP_PHASE[0] = f"{wname}: a local step (graph capture, no exchange)"
         agreed("a local step (forward + backward + optimiser, no exchange)", local_step)      # graph capture and kernels work on every rank before any rank enters a collective
+        DP_PHASE[0] = f"{wname}: timed steps WITH the gradient exchange (collectives)"
         dp_ms = timed(lambda: tr.step(batch))
+        DP_PHASE[0] = f"{wname}: timed steps without the exchange"
         local_ms = timed(local_step)
         key = "fp32_ring_all_reduce" if wire is None else "bf16_mesh_direct"
         out[key] = {"step_ms": round(dp_ms, 3), "step_without_exchange_ms": round(local_ms, 3), "exposed_collective_ms": round(max(0.0, dp_ms - local_ms), 3),
@@ -549,16 +557,20 @@ def run_rl(args, ctx, log, cpu=True):
     last_default = dict(tr._last_rl)
     # the same step with the reference's estimator (opt.bofi_rl_reference_estimator: every token drawn from the gradient pass's own dropout-perturbed rows,
     # one tape-free training forward per phrase): a few steps, reported beside the headline form
-    model.opt.bofi_rl_reference_estimator = True
-    tr.rl_step(att, None, score, sample_n=n)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for _ in range(3):
+    try:                                                       # (a failure of this leg must not lose the headline line: it is reported beside it)
+        model.opt.bofi_rl_reference_estimator = True
         tr.rl_step(att, None, score, sample_n=n)
-    torch.cuda.synchronize(dev)
-    ref_ms = (time.perf_counter() - t1) / 3 * 1e3
-    ref_info = {"ms_per_step": round(ref_ms, 2), "drawn_rows_vs_gradient_pass_rows_max_abs": tr._last_rl["reference_gap"],
-                "training_forwards_per_step": tr._last_rl["training_forwards"]}
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            tr.rl_step(att, None, score, sample_n=n)
+        torch.cuda.synchronize(dev)
+        ref_ms = (time.perf_counter() - t1) / 3 * 1e3
+        ref_info = {"ms_per_step": round(ref_ms, 2), "drawn_rows_vs_gradient_pass_rows_max_abs": tr._last_rl["reference_gap"],
+                    "training_forwards_per_step": tr._last_rl["training_forwards"]}
+    except Exception as e:
+        log(f"rl: the reference-estimator leg failed: {type(e).__name__}: {e}")
+        ref_info = {"error": f"{type(e).__name__}: {e}"}
     model.opt.bofi_rl_reference_estimator = False
     tr._last_rl = last_default
     if rank != 0:
@@ -714,6 +726,11 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # stays BELOW the budget provably ended inside it; T_all is exact -- the probe decodes ran these very inputs); every decode reports into `live_word` (atomic max)
     S_it = cfg.seq_length
     cap = T_all + 1 if args.iter_budget == "auto" and T_all + 1 < S_it else 0
+    # round 5: under the hint of several decodes in flight the bounding loop is ONE persistent kernel per 16 images that leaves when its images are
+    # finished (bound_loop.hip): nothing is enqueued per iteration, so there is no budget to set (the engine would ignore it)
+    loop_kernel = all(e.bound_loop_active(36) for e in engines)
+    if loop_kernel:
+        cap = 0
     if cap and os.environ.get("BOFI_BENCH_ITER_CAP"):           # (tests: a budget the decodes outrun, to walk the re-run)
         cap = int(os.environ["BOFI_BENCH_ITER_CAP"])
     live_word = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -861,8 +878,11 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"batch={args.batch} NAR bound+fill inference, 36x2048 regions, d_model=512 6+6 layers(+1 bound layer), {args.dtype}"
                                + (f", {args.refine} refinement rounds" if args.refine else ""),
-                   "images_per_step_per_gpu": args.batch, "bound_iterations": T, "bound_iterations_enqueued": cap if cap else cfg.seq_length,
-                   "iteration_budget": (f"{cap} of {cfg.seq_length} bounding iterations enqueued per decode (largest live count of the probe decodes + 1; the reference's loop "
+                   "images_per_step_per_gpu": args.batch, "bound_iterations": T, "bound_iterations_enqueued": None if loop_kernel else (cap if cap else cfg.seq_length),
+                   "bound_loop": ("one persistent kernel per 16 images runs every iteration of core_NAIC's loop and leaves when its images are finished (bound_loop.hip; "
+                                  "fp16 operands from the float32 parameters)" if loop_kernel else "five launches per iteration (bound_ops.hip, naic.hip)"),
+                   "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("BOFI_")},
+                   "iteration_budget": ("not applicable: the loop kernel ends by itself" if loop_kernel else f"{cap} of {cfg.seq_length} bounding iterations enqueued per decode (largest live count of the probe decodes + 1; the reference's loop "
                                         "stops when every image is finished, TransformerModel.py:1869); every decode folds its live-iteration count into a device word "
                                         "(atomic max) that was read after each leg: all below the budget, else this line would come from a full re-run without it"
                                         if cap else "off: every decode enqueues all seq_length iterations"),
@@ -1014,10 +1034,14 @@ def main():
             limit = float(os.environ.get("BOFI_BENCH_DP_LIMIT_S", "420"))
 
             def give_up():
+                # a rank stuck in a collective (or in a GPU kernel) after touching the GPU: the headline line still goes out (rank 0), with the phase that was
+                # reached, and EVERY process ends with a non-zero status -- the launcher and the driver must see the failure
+                sys.stderr.write(f"[bench rank {rank}] data-parallel secondary: no result within {limit:.0f} s; last phase reached: {DP_PHASE[0]}\n")
+                sys.stderr.flush()
                 if rank == 0 and res is not None:
-                    res["config"]["xe_dp_error"] = f"no result within {limit:.0f} s: a rank hung or failed inside the exchange"
+                    res["config"]["xe_dp_error"] = f"no result within {limit:.0f} s: a rank hung or failed inside the exchange (rank 0's last phase: {DP_PHASE[0]}); exit status 3"
                     print(json.dumps(res), flush=True)
-                os._exit(0)
+                os._exit(3)
             dog = threading.Timer(limit, give_up)
             dog.daemon = True
             dog.start()

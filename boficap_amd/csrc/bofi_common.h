@@ -122,6 +122,17 @@ __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t i) {
 
 }  // namespace bofi
 
+// host-side: an integer developer knob from the environment, read again after bofi_reload_env (no knob is latched for the life of the process: the
+// value a launch sees is the value of the last reload -- VERDICT r4 item 9b).  Every use site has its own cache (statics of its own lambda).
+#include <cstdlib>
+namespace bofi { extern int g_env_generation; }      // bumped by bofi_reload_env (gemm_glds.hip)
+#define BOFI_ENV_INT(name, dflt)                                                                                       \
+    ([]() -> int {                                                                                                     \
+        static int gen__ = -1, v__ = (dflt);                                                                           \
+        if (gen__ != bofi::g_env_generation) { const char* e__ = getenv(name); v__ = e__ ? atoi(e__) : (dflt); gen__ = bofi::g_env_generation; } \
+        return v__;                                                                                                    \
+    }())
+
 // host-side launch check: kernels are enqueued on a stream, so this only catches launch errors
 #define BOFI_CHECK_LAUNCH()                                   \
     do {                                                      \

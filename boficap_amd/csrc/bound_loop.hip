@@ -62,6 +62,7 @@ __device__ __forceinline__ uint32_t bl_pack(float lo, float hi) {
     const f32x2 v = {bl_clamp16(lo), bl_clamp16(hi)};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
+__device__ __forceinline__ float bl_relu(float v) { return v < 0.f ? 0.f : v; }      // torch.relu: a NaN stays a NaN (fmaxf would turn it into 0)
 __device__ __forceinline__ f16x8 bl_ldw(const u32x4* p) { return __builtin_bit_cast(f16x8, *p); }
 __device__ __forceinline__ float bl_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bl_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n = hc + nt * 16;                                   // 4 columns n .. n + 3 of row l15: half of 16-byte chunk n >> 3
-                const uint2 o = make_uint2(bl_pack(fmaxf(acc[nt][0] + cv[nt].x, 0.f), fmaxf(acc[nt][1] + cv[nt].y, 0.f)),
-                                           bl_pack(fmaxf(acc[nt][2] + cv[nt].z, 0.f), fmaxf(acc[nt][3] + cv[nt].w, 0.f)));
+                const uint2 o = make_uint2(bl_pack(bl_relu(acc[nt][0] + cv[nt].x), bl_relu(acc[nt][1] + cv[nt].y)),
+                                           bl_pack(bl_relu(acc[nt][2] + cv[nt].z), bl_relu(acc[nt][3] + cv[nt].w)));
                 *reinterpret_cast<uint2*>(BIG + l15 * (dff * 2) + (((n >> 3) ^ l15) << 4) + (n & 4) * 2) = o;
             }
         }
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             bl_seg(wh_s, wo_self_s, lane, wb, xb, acc);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<float4*>(HID + l15 * BL_HP + ncol + nt * 16) = make_float4(fmaxf(acc[nt][0] + cv[nt].x, 0.f), fmaxf(acc[nt][1] + cv[nt].y, 0.f),
-                                                                                              fmaxf(acc[nt][2] + cv[nt].z, 0.f), fmaxf(acc[nt][3] + cv[nt].w, 0.f));
+                *reinterpret_cast<float4*>(HID + l15 * BL_HP + ncol + nt * 16) = make_float4(bl_relu(acc[nt][0] + cv[nt].x), bl_relu(acc[nt][1] + cv[nt].y),
+                                                                                              bl_relu(acc[nt][2] + cv[nt].z), bl_relu(acc[nt][3] + cv[nt].w));
         }
         __syncthreads();
         BL_STAMP(12);
@@ -532,7 +533,7 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
         attr_set = true;
     }
     BoundLoopArgs v = a;
-    { static int gen = -1, dbg = 0; if (gen != g_env_generation) { const char* e = getenv("BOFI_BL_DBG"); dbg = e ? atoi(e) : 0; gen = g_env_generation; } v.dbg = dbg; }
+    v.dbg = BOFI_ENV_INT("BOFI_BL_DBG", 0);
     if (a.R <= 36) hipLaunchKernelGGL(bound_loop_kernel<5>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
     else hipLaunchKernelGGL(bound_loop_kernel<8>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
     BOFI_CHECK_LAUNCH();

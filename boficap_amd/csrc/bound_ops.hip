@@ -318,7 +318,7 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
     if ((a.y && a.ldy % 4) || (a.yb && a.ldyb % 4) || (a.residual && a.ldr % 4)) return BOFI_ERR_ARG;
     // column tile: the narrowest of 16 / 32 / 64 columns that keeps the launch within one workgroup per CU (a tile's sums do not depend on it:
     // every output element is the same four k-quarter sums whatever the tile)
-    static const int forced = [] { const char* v = getenv("BOFI_ROWGEMM_NT"); return v ? atoi(v) : 0; }();      // developer knob: 1, 2 or 4
+    const int forced = BOFI_ENV_INT("BOFI_ROWGEMM_NT", 0);      // developer knob: 1, 2 or 4
     const int per_tile = splitk * ((a.M + 63) / 64);
     int nt = 1;
     while (nt < 4 && a.N % (32 * nt) == 0 && (a.N / (16 * nt)) * per_tile > 256) nt *= 2;

@@ -16,7 +16,6 @@
 #include "bofi_kernels.h"
 #include "bofi_naic.h"
 
-namespace bofi { extern int g_env_generation; }
 
 namespace {
 
@@ -49,7 +48,6 @@ struct DecLayer { Lin qkv, o, q_src, o_src, w1, w2; Norm n0, n1, n2; };
 // how a packed weight was made from the named parameters: replayed on the device by bofi_engine_refresh_device
 struct LinRecipe { Lin* out; std::vector<std::string> prefixes; int n_each, K; std::string fold; };
 
-bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }
 struct NormRecipe { Norm* out; std::string prefix; int d; };
 
 struct GraphEntry {
@@ -310,10 +308,10 @@ struct bofi_engine {
         a.y = y; a.yparts = yparts; a.y_stride = y_stride; a.w = heads; a.st = st; a.sa = saic ? sa : bofi::SaicState{};
         a.ext_syn_in = ext_syn_in; a.last_in = last_in; a.q0 = b_q0; a.kvtab = b_kvtab; a.votab = b_votab; a.x0b = b_x0b;
         a.y1 = by1; a.y1t = copy_t(byb); a.stats = st_b;
-        static const int tail_dbg = [] { const char* v = getenv("BOFI_TAIL_DBG"); return v ? atoi(v) : 0; }();     // developer ablations
+        const int tail_dbg = BOFI_ENV_INT("BOFI_TAIL_DBG", 0);     // developer ablations
         a.B = B; a.L = L; a.S = cfg.seq_length; a.d = cfg.d_model; a.hh = cfg.head_hidden; a.H = cfg.heads; a.flags = flags | (tail_dbg << 8); a.iter = iter;
         a.len_logp = len_logp; a.syn_logp = syn_logp;
-        static const bool want_dbg = getenv("BOFI_DBG_PART") != nullptr;
+        const bool want_dbg = BOFI_ENV_INT("BOFI_DBG_PART", 0) != 0;
         if (want_dbg && !dbg_part) ENG_OK(dalloc(&dbg_part, (size_t)cfg.max_batch * (16 * cfg.head_hidden + cfg.d_model)));
         a.dbg_part = dbg_part;
         return bofi::launch_bound_tail(a, cfg.dtype, s);
@@ -357,13 +355,14 @@ struct bofi_engine {
         loop_ready = true;
         return BOFI_OK;
     }
-    // BOFI_BOUND_LOOP (re-read after bofi_reload_env): 0 = the five-launch iterations of rounds 2-4, 1 (default) = the persistent loop kernel
-    static int bound_loop_knob() {
-        static int gen = -1, v = 1;
-        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_BOUND_LOOP"); v = e ? atoi(e) : 1; gen = bofi::g_env_generation; }
-        return v;
+    // BOFI_BOUND_LOOP (re-read after bofi_reload_env): 0 = the five-launch iterations of rounds 2-4 always, 1 (default) = the persistent loop kernel unless the caller
+    // said its decodes run alone (bofi_engine_set_decodes_in_flight(1): the five launches are the shorter chain there -- 0.65 against 0.95 ms per 320 images),
+    // 2 = the loop kernel whatever the hint
+    static int bound_loop_knob() { return BOFI_ENV_INT("BOFI_BOUND_LOOP", 1); }
+    bool bound_loop_ok(int R) const {
+        const int k = bound_loop_knob();
+        return loop_ready && loop_config_ok() && R <= 64 && k != 0 && (k == 2 || in_flight != 1);
     }
-    bool bound_loop_ok(int R) const { return loop_ready && loop_config_ok() && R <= 64 && bound_loop_knob() != 0; }
     // update != 0: the whole loop on the engine's slot state (after launch_bound_init); update == 0: one iteration on a given layout, log-probabilities out
     int bound_loop(int B, int R, const int* att_len, const int* ext_syn_in, const int* last_in, int update, float* len_logp, float* syn_logp, hipStream_t s) {
         bofi::BoundLoopArgs a{};
@@ -385,7 +384,7 @@ struct bofi_engine {
     // of bound_ops.hip.  Returns -1 when the configuration is not theirs (the caller takes the general kernels), else a status;
     // *parts = number of slabs in by3.  `skip`: early-out word and threshold (NULL: none).
     int bound_chain_lean(int B, int R, const int* att_len, const int* skip, int skip_thr, hipStream_t s, int* parts) {
-        static const bool lean_on = [] { const char* v = getenv("BOFI_BOUND_LEAN"); return !v || atoi(v) != 0; }();
+        const bool lean_on = BOFI_ENV_INT("BOFI_BOUND_LEAN", 1) != 0;
         const int d = cfg.d_model;
         if (!(lean_on && cfg.dtype == BOFI_DT_BF16 && d == 512 && cfg.heads == 8 && R <= 64 && cfg.d_ff % 512 == 0 && cfg.d_ff / 512 <= 4)) return -1;
         {   bofi::BoundQAttnArgs a{};
@@ -421,9 +420,7 @@ struct bofi_engine {
     // (BOFI_RB_MIN_ROWS: 0 = always, a huge value = never; re-read after bofi_reload_env.  Kernel family and launch size are then
     // decoupled: under ONE family a row's result does not depend on what else is in the launch -- bit for bit)
     static int rb_min_rows() {
-        static int gen = -1, v = 4096;
-        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_MIN_ROWS"); v = e ? atoi(e) : 4096; gen = bofi::g_env_generation; }
-        return v;
+        return BOFI_ENV_INT("BOFI_RB_MIN_ROWS", 4096);
     }
     // timing-only ablation switches (results INVALID): compiled in only by `BOFI_EXPERIMENTS=1 python -m boficap_amd.build --force`
 #ifdef BOFI_EXPERIMENTS
@@ -435,7 +432,7 @@ struct bofi_engine {
     static constexpr bool exp_skip(const char*) { return false; }
 #endif
     int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
-        static const bool on = env_on("BOFI_RB_ATTN");
+        const bool on = BOFI_ENV_INT("BOFI_RB_ATTN", 1) != 0;
         if (exp_skip("attn")) return BOFI_OK;
         if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh || at.B * at.Lq < rb_min_rows()) return -1;
         bofi::RbAttnArgs a{};
@@ -448,7 +445,7 @@ struct bofi_engine {
     // a LayerNorm-folded projection (K = d_model) of the residual stream x32 as a row-block kernel: it reads the float32 stream itself
     // (no compute-dtype copy, no row statistics from the producer).  -1: not its configuration.
     bool fold_rb_ok(const Lin& l, int M) const {
-        static const bool on = env_on("BOFI_RB_GEMM");
+        const bool on = BOFI_ENV_INT("BOFI_RB_GEMM", 1) != 0;
         return on && rb_ok() && l.wp && l.cs && l.K == 512 && M >= rb_min_rows();
     }
     int fold_linear_rb(const float* x32, const Lin& l, void* y, int y_f32, int ldy, int M, hipStream_t s) {
@@ -460,15 +457,14 @@ struct bofi_engine {
         return bofi::launch_rb_gemm(a, s);
     }
     bool ffn_sublayer_ok(const Lin& w1, const Lin& w2, int M) const {
-        static const bool on = env_on("BOFI_RB_FFN");
+        const bool on = BOFI_ENV_INT("BOFI_RB_FFN", 1) != 0;
         return on && rb_ok() && w1.wp && w2.wp && w1.cs && cfg.d_ff % 512 == 0 && cfg.d_ff <= 2560 && M >= rb_min_rows();
     }
     // pj (optional): the LayerNorm-folded projection that reads this sublayer's output next (the next layer's q|k|v, the stacked cross K|V), computed by
     // the SAME launch from each closed block while it sits in LDS (pj_y, pitch pj_ldy); ffn_proj_ok says when the feed-forward kernel takes it
     // (BOFI_RB_FFN_PROJ, re-read after bofi_reload_env: 0 = never, 1 (default) = when launches overlap, 2 = always)
     bool ffn_proj_ok(const Lin& w1, const Lin& w2, const Lin& pj, int M) const {
-        static int gen = -1, v = 1;
-        if (gen != bofi::g_env_generation) { const char* e = getenv("BOFI_RB_FFN_PROJ"); v = e ? atoi(e) : 1; gen = bofi::g_env_generation; }
+        const int v = BOFI_ENV_INT("BOFI_RB_FFN_PROJ", 1);
         // (a decode running alone keeps the separate launches of 64-row blocks: measured 0.515 against 0.523 ms per batch with the narrow projections fused,
         // 0.536 with all of them)
         return v && (v == 2 || in_flight != 1) && ffn_sublayer_ok(w1, w2, M) && fold_rb_ok(pj, M) && pj.Npad >= 512 && !exp_skip("ffn") && !exp_skip("qkv") &&
@@ -676,7 +672,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     const int rounds = 1 + ((flags >> BOFI_FLAG_REFINE_SHIFT) & 15);
     const void* xa = stream_t(x_fill, xb_fill);
     float* lg = seq_logprob ? seq_logprob : logits;
-    static const int gen_pad = [] { const char* v = getenv("BOFI_GEN_PAD"); return v ? atoi(v) : 1; }();      // developer knob: 0 = in place, one-tile kernel
+    const int gen_pad = BOFI_ENV_INT("BOFI_GEN_PAD", 1);      // developer knob: 0 = in place, one-tile kernel
     const bool gen_rb = gen_pad && logits_pad && fold_rb_ok(gen, M);
     for (int round = 0; round < rounds; ++round) {
     ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
@@ -748,7 +744,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, gen, lg, BOFI_DT_F32, cfg.vocab, M, o, s));
     }
     // (a round that another one follows: its ids are all the next round reads -- the log-probs it would write are overwritten: not stored)
-    static const int ids_only_on = [] { const char* v = getenv("BOFI_REFINE_IDS_ONLY"); return v ? atoi(v) : 1; }();      // developer knob: 0 = every round stores its log-probs
+    const int ids_only_on = BOFI_ENV_INT("BOFI_REFINE_IDS_ONLY", 1);      // developer knob: 0 = every round stores its log-probs
     const int lsm = (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : ((ids_only_on && round + 1 < rounds && lsrc) ? 2 : 1);
     ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, lsm, st.last, -1, cfg.pad_idx, seq, s, nullptr, nullptr, nullptr, nullptr,
                                        lsrc, gen.Npad));
@@ -927,7 +923,7 @@ static int run_graphed(bofi_engine* e, const std::vector<uintptr_t>& key, hipStr
 // ================================================================================================
 extern "C" {
 
-int bofi_abi_version(void) { return 2; }
+int bofi_abi_version(void) { return 3; }
 const char* bofi_last_error(void) { return g_err.c_str(); }
 
 int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
@@ -1065,7 +1061,9 @@ int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names
         memcpy(img.data(), lt.data(), lb);
         memcpy(img.data() + lb, ct.data(), cb);
         if (img != e->rt_cache) {
-            ENG_HIP(hipStreamSynchronize(s));                 // (rare: a previous upload from the pinned buffer may still be in flight)
+            // (rare path: the pack kernels of a previous refresh -- possibly issued on ANOTHER stream -- may still be reading the table, and its upload the
+            // pinned buffer: the whole device is waited out before either is touched)
+            ENG_HIP(hipDeviceSynchronize());
             if (bytes > e->rt_bytes) {
                 if (e->rt_dev) (void)hipFree(e->rt_dev);
                 if (e->rt_pin) (void)hipHostFree(e->rt_pin);
@@ -1140,6 +1138,8 @@ int bofi_engine_set_decodes_in_flight(bofi_engine_t* e, int n) {
     e->in_flight = n;
     return BOFI_OK;
 }
+
+int bofi_engine_bound_loop_active(bofi_engine_t* e, int R) { return e && e->finalized && e->bound_loop_ok(R) ? 1 : 0; }
 
 int bofi_engine_set_bound_iter_cap(bofi_engine_t* e, int cap) {
     g_err.clear();

@@ -418,7 +418,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
         // measured on MI355X (tools/microbench_ops.py, round 1): occupancy beats ring depth at K = 512;
         // 2 stages keep 3-5 workgroups per CU so that one's prologue/epilogue hides under another's loop
         const long t = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-        static const int heur2 = [] { const char* v = getenv("BOFI_GEMM_HEUR2"); return v ? atoi(v) : 1; }();
+        const int heur2 = BOFI_ENV_INT("BOFI_GEMM_HEUR2", 1);
         // 128-row tiles from 200 tiles on (round 2: the fill pass's qkv and w_1 at M = 1280 gain 15-25 % with four decodes in flight)
         const long thr = heur2 ? 200 : 400;
         if (p.M <= 64) {
@@ -426,7 +426,7 @@ static int launch_glds_t(const Gemm2Params& p, hipStream_t st) {
             // the bounding loop's GEMMs (64 rows, K = 512 per slice) are latency chains: one L2 round trip per slab with a 4-deep
             // ring.  With the whole K extent (<= 8 slabs) issued up front the chain is one round trip; consumers that emit no row
             // statistics take 16-column tiles (twice the workgroups, half the weight bytes per workgroup)
-            static const int deep = [] { const char* v = getenv("BOFI_GEMM_DEEP"); return v ? atoi(v) : 1; }();
+            const int deep = BOFI_ENV_INT("BOFI_GEMM_DEEP", 1);
             if (deep && sizeof(T) == 2 && p.K / p.splitk <= 8 * 64) {
                 ns = 9;
                 if (!(p.stats_out || p.y2) && p.vec_ok && p.N % 16 == 0) { bn = 16; nw = 2; }
@@ -510,7 +510,7 @@ int launch_linear_glds(const LinearArgs& a, hipStream_t st) {
         return BOFI_ERR_ARG;
     { const char* dv = getenv("BOFI_GEMM_DBG"); p.dbg = dv ? atoi(dv) : 0; }
     {   // bytes an XCD layout makes the eight L2s fetch: rb * W + (8 / rb) * A
-        static const int forced = [] { const char* v = getenv("BOFI_GEMM_BANDS"); return v ? atoi(v) : 0; }();
+        const int forced = BOFI_ENV_INT("BOFI_GEMM_BANDS", 0);
         const double wb = (double)a.N * a.K, ab = (double)a.M * a.K;
         int best = 8; double cost = 8 * wb + ab;
         for (int rb : {4, 2, 1}) { const double c = rb * wb + (8 / rb) * ab; if (c < 0.9 * cost) { best = rb; cost = c; } }

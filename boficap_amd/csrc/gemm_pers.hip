@@ -351,21 +351,21 @@ int launch_gemm_pers(const Gemm2Params& p_in, int feat, hipStream_t st) {
         return -1;
     if (p.ln_stats) { const int g = p.ln_groups > 0 ? p.ln_groups : p.K >> 5; if (g != 16) return -1; }      // (other group counts: gemm_glds.hip)
     // 128-row tiles where 256-row tiles would leave half of the chip idle (at most 128 of them: the fill pass's N = 512 GEMMs are 92)
-    static const int bm128_max = [] { const char* v = getenv("BOFI_GEMM_PERS_BM128"); return v ? atoi(v) : 128; }();      // developer knob: 0 = 256-row tiles only
+    const int bm128_max = BOFI_ENV_INT("BOFI_GEMM_PERS_BM128", 128);      // developer knob: 0 = 256-row tiles only
     const int t256 = (p.N / PBN) * ((p.M + 255) / 256);
     const int bm = t256 <= bm128_max ? 128 : 256;
     const int ntiles = (p.N / PBN) * ((p.M + bm - 1) / bm);
-    static const int cus = [] { const char* v = getenv("BOFI_GEMM_PERS_GRID"); return v ? atoi(v) : 256; }();
+    const int cus = BOFI_ENV_INT("BOFI_GEMM_PERS_GRID", 256);
     // every workgroup walks `rounds` tiles: the grid is the smallest multiple of 8 (tile v stays on XCD v % 8) that covers the tiles in
     // as many rounds as all CUs would need -- 540 tiles run on 184 CUs in 3 rounds, not on 256 in 3, and the rest stay free for the
     // other decodes in flight
-    static const int min_rounds = [] { const char* v = getenv("BOFI_GEMM_PERS_ROUNDS"); return v ? atoi(v) : 1; }();      // developer knob: tiles per workgroup at least
+    const int min_rounds = BOFI_ENV_INT("BOFI_GEMM_PERS_ROUNDS", 1);      // developer knob: tiles per workgroup at least
     int rounds = (ntiles + cus - 1) / cus;
     if (rounds < min_rounds) rounds = min_rounds;
     int grid = ntiles;
     if (ntiles > cus || rounds > 1) { grid = (((ntiles + rounds - 1) / rounds + 7) / 8) * 8; if (grid > cus) grid = cus; if (grid > ntiles) grid = ntiles; }
     const dim3 g(grid), b(64 * (PCONS + PLOAD));
-    static const int fast_ok = [] { const char* v = getenv("BOFI_GEMM_PERS_FAST"); return v ? atoi(v) : 1; }();      // developer knob: 0 = staged epilogue everywhere
+    const int fast_ok = BOFI_ENV_INT("BOFI_GEMM_PERS_FAST", 1);      // developer knob: 0 = staged epilogue everywhere
     const bool fast = fast_ok && !(feat & 2) && !p.residual && !p.y_is_f32 && p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0;
 #define PERS_LAUNCH(F, R, Q)                                                                       \
     { if (bm == 128) hipLaunchKernelGGL((gemm_pers_kernel<F, R, Q, 128>), g, b, 0, st, p);          \

@@ -207,7 +207,7 @@ int launch_gemm_tn_grouped(int n, const void* const* a, const int* lda, const in
     for (int e = 0; e < n; ++e)
         if (int rc = check_tn(a[e], lda[e], a_cols[e], b[e], ldb[e], b_cols[e], c[e], ldc[e], M[e], NI[e], NJ[e])) return rc;
     for (int e = 0; e < n; ++e) g_gemm_flops += 2.0 * M[e] * NI[e] * NJ[e];
-    static const int forced_wt = [] { const char* v = getenv("BOFI_TN_WT"); return v ? atoi(v) : 0; }();   // developer knob: 2 or 4 = one register-staged tile class for everything
+    const int forced_wt = BOFI_ENV_INT("BOFI_TN_WT", 0);   // developer knob: 2 or 4 = one register-staged tile class for everything
     // two classes of problems: outputs of at least 128 x 128 take the register-staged 128 x 128 tile, the small ones (classifier heads) 64 x 64.
     // (Round 3's third class -- 256 x 256 outputs fed by an LDS-DMA ring -- measured no faster, 292 against 262 us on 24 decoder-sized problems,
     // and left the library in round 4: profiles/r03_tn_tile_256.txt, docs/history/r03.md.)
@@ -255,7 +255,7 @@ int launch_gemm_tn(const void* a, int lda, int a_cols, const void* b, int ldb, i
     const int ti = (NI + 63) / 64, tj = (NJ + 63) / 64;
     // workgroups to aim for: every extra row split adds a tile of atomics, so small outputs (<= 128 tiles) take half as many
     // (measured, tools/mb_tn.py: 512x512 20.0 -> 17.1 us, 1024x512 over 2304 rows 17.1 -> 12.8 us; larger outputs prefer 1024)
-    static const int forced_wgs = [] { const char* v = getenv("BOFI_TN_WGS"); return v ? atoi(v) : 0; }();   // developer knob
+    const int forced_wgs = BOFI_ENV_INT("BOFI_TN_WGS", 0);   // developer knob
     const int target_wgs = forced_wgs ? forced_wgs : (ti * tj <= 128 ? 512 : 1024);
     int splits = target_wgs / (ti * tj);
     splits = max(1, min(splits, (M + 127) / 128));                 // at least 4 tiles of rows per workgroup

@@ -438,7 +438,7 @@ int launch_bound_tail(const BoundTailArgs& a, int dtype, hipStream_t s) {
     if (v.yparts < 1) v.yparts = 1;
     if (d % 8 || 512 % (d / 8) || d / 8 > 256) return BOFI_ERR_ARG;
     const size_t shm = (size_t)(d + 8 * 2 * hh + 2 * hh + 32 + 16 + 64 + 30 * (hh + 1) + a.H * 64 + 4096) * sizeof(float);
-    static const int small_at = [] { const char* e = getenv("BOFI_TAIL_SMALL_AT"); return e ? atoi(e) : 65; }();   // developer knob: images from which the two-per-CU variant runs
+    const int small_at = BOFI_ENV_INT("BOFI_TAIL_SMALL_AT", 65);   // developer knob: images from which the two-per-CU variant runs
     const bool small = a.B >= small_at;
     if (dtype == BOFI_DT_F32) {                               // (float32 rows are twice as wide: no variant of it fits 128 VGPRs)
         hipLaunchKernelGGL((bound_tail_kernel<float, 32, 1>), dim3(a.B), dim3(512), shm, s, v);

@@ -139,14 +139,16 @@ class BofiEngine:
             raise hip.BofiHipError("the first load goes through load_state_dict")
         items = [(k, v) for k, v in named.items() if k != "model.pos_embed.pe"]
         # (a training loop refreshes after every optimiser step with the same tensors: the checked argument arrays are kept per set of addresses)
-        key = tuple(v.data_ptr() for _, v in items)
+        # (the key holds everything the check looks at: the caching allocator hands addresses out again -- tensors of another dtype, size or name at
+        # the same addresses must not ride on an old validation)
+        key = tuple((k, v.data_ptr(), v.numel(), v.dtype, v.is_cuda, v.is_contiguous()) for k, v in items)
         cached = getattr(self, "_refresh_args", None)
         if cached is None or cached[0] != key:
             for k, v in items:
                 if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous():
                     raise hip.BofiHipError(f"{k}: contiguous float32 tensor on the HIP device expected")
             n = len(items)
-            cached = self._refresh_args = (key, n, (C.c_char_p * n)(*[k.encode() for k, _ in items]), (C.c_void_p * n)(*key),
+            cached = self._refresh_args = (key, n, (C.c_char_p * n)(*[k.encode() for k, _ in items]), (C.c_void_p * n)(*[v.data_ptr() for _, v in items]),
                                            (C.c_int64 * n)(*[v.numel() for _, v in items]))
         _, n, names, ptrs, numels = cached
         with torch.cuda.device(self.device):
@@ -205,6 +207,10 @@ class BofiEngine:
         """A hint for the kernel choice (bofi_engine_set_decodes_in_flight): 1 = this engine's launches run alone on the device (shorter
         workgroup chains), 0 / > 1 = throughput forms (fewer weight bytes per row).  Part of the graph key: a captured launch is replayed under the hint it was captured with."""
         hip.check(self._lib.bofi_engine_set_decodes_in_flight(self._h, int(n)), "bofi_engine_set_decodes_in_flight")
+
+    def bound_loop_active(self, R: int) -> bool:
+        """Does a decode of R regions per image run the bounding loop as the persistent per-16-image kernel (bofi_engine_bound_loop_active)?"""
+        return bool(self._lib.bofi_engine_bound_loop_active(self._h, int(R)))
 
     def watch_live_iterations(self, word: Optional[torch.Tensor]) -> None:
         """``word`` (int32 [1] on the device, or None to stop): every following decode_naic folds its live-iteration count into it by atomic

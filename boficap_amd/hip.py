@@ -15,7 +15,7 @@ DT_F32, DT_BF16 = 0, 1
 FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
 FLAG_REFINE_SHIFT = 8
 FLAG_SAMPLE = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BofiHipError(RuntimeError):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "bofi_engine_refresh_device": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_I64), _P]),
     "bofi_engine_set_q1_group": (_I, [_P, _I]),
     "bofi_engine_set_decodes_in_flight": (_I, [_P, _I]),
+    "bofi_engine_bound_loop_active": (_I, [_P, _I]),
     "bofi_engine_saic_put_words": (_I, [_P, _P, _I, _P]),
     "bofi_engine_set_sampling": (_I, [_P, C.c_float, C.c_uint64]),
     "bofi_engine_set_saic_range": (_I, [_P, _I, _I]),

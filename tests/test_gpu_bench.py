@@ -33,7 +33,12 @@ def test_bench_line_with_the_drivers_arguments():
     c = d["config"]
     assert "workload" in c and "batch=64" in c["workload"] and c["images_per_step_per_gpu"] == 64 and not c["nan_in_output"]
     assert c["batches_per_launch"] == 5 and c["decodes_in_flight"] >= 1              # 20 steps = 4 launches of 5 batches
-    assert c["bound_iterations"] < c["bound_iterations_enqueued"] <= 20 and "iteration_budget" in c      # verified budget (or all 20 enqueued)
+    # round 5: the bounding loop is one persistent kernel that ends by itself (no iterations are enqueued, no budget); were it off, a verified budget
+    assert "bound_loop" in c and "knobs" in c and "iteration_budget" in c
+    if c["bound_iterations_enqueued"] is None:
+        assert "persistent kernel" in c["bound_loop"] and 1 <= c["bound_iterations"] <= 20
+    else:
+        assert c["bound_iterations"] < c["bound_iterations_enqueued"] <= 20
     # a short region is timed five times back to back and the median reported; every stream is warmed
     assert c["timed_regions"] == 5 and len(c["region_ms"]) == 5 and c["region_ms"] == sorted(c["region_ms"]) and c["warmup_steps_run"] >= 5 * c["decodes_in_flight"]
     assert abs(d["ms_per_step"] * 20 - c["region_ms"][2]) < 0.02 * c["region_ms"][2]
@@ -75,7 +80,9 @@ def test_bench_two_ranks_walk_the_multi_gpu_path_on_one_device():
 def test_bench_reruns_without_the_iteration_budget_when_a_decode_outruns_it():
     """--iter-budget auto enqueues (live iterations of the probe + 1) bounding iterations per decode and checks the device-side maximum of the
     decodes' live-iteration counts after every leg; with a budget the decodes cannot meet (forced here) the line must come from the re-run
-    that enqueues all of them."""
-    d = _run("--steps", "10", "--warmup", "5", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--no-from-host", env={"BOFI_BENCH_ITER_CAP": "3"})
+    that enqueues all of them.  (The budget belongs to the five-launch iterations: BOFI_BOUND_LOOP=0; the persistent loop kernel ends by itself.)"""
+    d = _run("--steps", "10", "--warmup", "5", "--no-secondary", "--no-cpu-baseline", "--no-gemm-roofline", "--no-from-host",
+             env={"BOFI_BENCH_ITER_CAP": "3", "BOFI_BOUND_LOOP": "0"})
     c = d["config"]
+    assert c["knobs"].get("BOFI_BOUND_LOOP") == "0" and "five launches" in c["bound_loop"]
     assert c["bound_iterations"] > 3 and c["bound_iterations_enqueued"] == 20 and c["iteration_budget"].startswith("off") and not c["nan_in_output"]

@@ -319,20 +319,23 @@ def test_full_q1_shortening_and_saic_multi_fixture(weight_cache, manifest):
 
 
 # ------------------------------------------------------------------------------------------------ bf16 tolerance on every image
-@pytest.mark.parametrize("config_name,tol,family", [("FULL", 2e-2, "tiled"), ("FULL", 2e-2, "row-block"), ("TINY", 6e-2, "tiled")])
+@pytest.mark.parametrize("config_name,tol,family", [("FULL", 2e-2, "tiled"), ("FULL", 2e-2, "row-block"), ("FULL", 2e-2, "five-launch"), ("TINY", 6e-2, "tiled")])
 def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, family, weight_cache, monkeypatch):
     """north_star: logits within 2e-2 for bf16 -- shown on ALL images, nothing filtered: (1) the bound heads' log-probs of the
     first bounding step, (2) the fill pass with the float32 oracle's slot layout teacher-forced (bofi_engine_fill_naic), so
     that a near-tie flipped by bf16 rounding in the bounding pass cannot hide or excuse anything.  The flip rate of the free
     decode is reported separately.  (The TINY model's logits have 4.1x the spread of the full model's: 6e-2 there.)
     family: 64 images are below the size from which the engine takes the row-block sublayer kernels -- "row-block" forces them
-    (BOFI_RB_MIN_ROWS=0), so both kernel families are held to the same bars on the same images."""
+    (BOFI_RB_MIN_ROWS=0), so both kernel families are held to the same bars on the same images.  At the full size the bounding step is
+    round 5's persistent loop kernel (fp16 operands from the float32 parameters, float32 self-attention tables); "five-launch" is the
+    chain of rounds 2-4 (bf16 operands; what a decode that runs alone still takes) on the tiled family."""
     from boficap_amd import hip as H
     from boficap_amd import weights as W
     from boficap_amd.engine import BofiEngine
     monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0" if family == "row-block" else "1000000000")
+    monkeypatch.setenv("BOFI_BOUND_LOOP", "0" if family == "five-launch" else "2")
     H.lib().bofi_reload_env()
-    config_tag = config_name + ("_row_block" if family == "row-block" else "")
+    config_tag = config_name + ("_row_block" if family == "row-block" else "_five_launch" if family == "five-launch" else "")
     cfg, sd = weight_cache(config_name, 0, 1.0)
     w = O.as_torch(sd)
     B = 64
@@ -347,6 +350,8 @@ def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, family, w
         _, _, _, _, dg = O.core_naic(w, cfg, memory, src_mask, fix_q1=True)
     eng = BofiEngine(cfg, torch.bfloat16, max_batch=B, max_regions=36)
     eng.load_state_dict(sd)
+    loop_kernel = eng.bound_loop_active(36)
+    assert loop_kernel == (config_name == "FULL" and family != "five-launch")
     att = torch.from_numpy(att_np).cuda().to(torch.bfloat16)
     mem_e = eng.encode(att).cpu()
     llp, slp = eng.bound_step(ext0.to(torch.int32).cuda(), torch.ones(B, dtype=torch.int32, device="cuda"), 36)
@@ -382,26 +387,32 @@ def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, family, w
     # operands (memory rms error 0.1 % of its range) through heads whose gain is ||W2|| ||W1|| = 12.7 on a log-prob span of 16.4 -- so north_star's
     # 2e-2 is out of reach for these heads whatever the bounding kernels do; their OWN error (engine against the float32 chain on the same
     # memory) is 0.030 / 0.023.  Both shares are recorded and held to the bar.
-    live_bar = 2.5 * tol
+    # round 5: with the loop kernel the bounding layer's own share is 0.013-0.017 (fp16 operands; what is left is the bf16 K|V of the
+    # cross-attention and fp16's own rounding), the total 0.020-0.025: the bars are now 1.3x the measurement (profiles/r05_parity_errors.json) -- 0.032 on the
+    # total and on the encoder's share (0.024-0.027, unchanged: the encoder's bf16 operands), 0.023 on the kernel's own share; the five-launch chain and the
+    # TINY model (not the loop kernel's shape) keep round 4's 2.5 x tol
+    live_bar = 0.032 if loop_kernel else 2.5 * tol
+    own_bar = 0.023 if loop_kernel else live_bar
     enc_len = float((c_llp - o_llp)[:, live_len].abs().max()); enc_syn = float((c_slp - o_slp)[:, live_syn].abs().max())
     own_len = float((llp.cpu() - c_llp)[:, live_len].abs().max()); own_syn = float((slp.cpu() - c_slp)[:, live_syn].abs().max())
     print(f"{config_name}: of which the encoder's memory alone (float32 bounding layer on it): len {enc_len:.2e} syn {enc_syn:.2e}; the bounding kernels' own: len {own_len:.2e} syn {own_syn:.2e}")
     record_parity(f"bf16_bound_heads_live_encoder_share_len_{config_tag}", enc_len, live_bar, "the engine's memory through the float32 bounding layer + heads vs the float32 oracle")
     record_parity(f"bf16_bound_heads_live_encoder_share_syn_{config_tag}", enc_syn, live_bar, "as above, label head")
-    record_parity(f"bf16_bound_heads_live_own_len_{config_tag}", own_len, live_bar, "engine vs the float32 bounding layer + heads on the engine's own memory")
-    record_parity(f"bf16_bound_heads_live_own_syn_{config_tag}", own_syn, live_bar, "as above, label head")
-    assert max(enc_len, enc_syn, own_len, own_syn) < live_bar
+    record_parity(f"bf16_bound_heads_live_own_len_{config_tag}", own_len, own_bar, "engine vs the float32 bounding layer + heads on the engine's own memory")
+    record_parity(f"bf16_bound_heads_live_own_syn_{config_tag}", own_syn, own_bar, "as above, label head")
+    assert max(enc_len, enc_syn) < live_bar and max(own_len, own_syn) < own_bar
     record_parity(f"bf16_bound_heads_live_len_{config_tag}", e_len_live, live_bar, f"first bounding step, live classes, span {spread_live:.1f}")
     record_parity(f"bf16_bound_heads_live_syn_{config_tag}", e_syn_live, live_bar, "first bounding step, live label classes")
     record_parity(f"bf16_bound_heads_all_len_{config_tag}", e_len, max(tol, 6e-3 * spread), f"all 20 classes, span {spread:.1f}: bar 0.6 % of the span")
     record_parity(f"bf16_bound_heads_all_syn_{config_tag}", e_syn, max(tol, 6e-3 * spread), "all 10 classes")
-    record_parity(f"bf16_free_decode_layout_flips_{config_tag}", flips, 0.3 * B, f"images of {B} whose slot layout differs from the float32 oracle's")
+    flip_bar = 5 if loop_kernel else 0.3 * B                     # (measured: 3-4 of 64 with the loop kernel, 6 with the five-launch chain)
+    record_parity(f"bf16_free_decode_layout_flips_{config_tag}", flips, flip_bar, f"images of {B} whose slot layout differs from the float32 oracle's")
     assert e_len_live < live_bar and e_syn_live < live_bar, (e_len_live, e_syn_live)
     assert e_len < max(tol, 6e-3 * spread) and e_syn < max(tol, 6e-3 * spread), (e_len, e_syn, spread)
     top = torch.topk(olp.nan_to_num(-1e30), 2, dim=2)[0]
     safe = (top[..., 0] - top[..., 1]) > 2 * tol
     assert torch.equal(seq.cpu()[safe], oseq[safe])
-    assert flips <= 0.3 * B
+    assert flips <= flip_bar
     monkeypatch.undo()
     H.lib().bofi_reload_env()
 
