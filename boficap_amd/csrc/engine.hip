@@ -636,8 +636,13 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
                                 float* seq_logprob, int* phrase_num, int* phrase_length, int64_t* phrase_syn,
                                 float* memory_out, int* bound_iters, hipStream_t s) {
     const int S = cfg.seq_length;
-    ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, memory_out, s));
+    // phases (BOFI_FLAG_PHASE_*): none of the bits = the whole decode; else only the named parts (a pipelining caller enqueues them as separate calls)
+    const int ph = flags & (BOFI_FLAG_PHASE_ENCODE | BOFI_FLAG_PHASE_BOUND | BOFI_FLAG_PHASE_FILL);
+    const bool do_enc = !ph || (ph & BOFI_FLAG_PHASE_ENCODE), do_bound = !ph || (ph & BOFI_FLAG_PHASE_BOUND), do_fill = !ph || (ph & BOFI_FLAG_PHASE_FILL);
+    cur_B = B;
+    if (do_enc) ENG_OK(enqueue_encode(feats, feats_dtype, att_len, B, R, memory_out, s));
     // ---- bounding pass (core_NAIC TransformerModel.py:1833-1870)
+    if (do_bound) {
     ENG_OK(bofi::launch_bound_init(st, B, L, cfg.pad_idx, cfg.len_idx, s));
     if (bound_dense) {
         ENG_OK(enqueue_bound_dense(att_len, B, R, s));
@@ -658,8 +663,11 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
         for (int it = 0; it < n_iters; ++it)
             ENG_OK(enqueue_bound_iter(B, R, att_len, st.ext_syn, st.last, 1, nullptr, nullptr, true, s));
     }
-    ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
-    ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s, live_max));
+    }
+    if (do_fill) {
+        ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
+        ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s, live_max));
+    }
     return BOFI_OK;
 }
 

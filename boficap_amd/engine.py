@@ -165,7 +165,7 @@ class BofiEngine:
 
     def decode_naic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, strict_q1: bool = True,
                     want_logprob: bool = True, want_memory: bool = False, raw_logits: bool = False, graph: bool = False,
-                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0, iter_cap: int = 0) -> dict:
+                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0, iter_cap: int = 0, phases: str = "") -> dict:
         """Greedy NAIC bound+fill decode.  Returns a dict of device tensors: seq [B,S] int64,
         seq_logprob [B,S,V] float32 (or None), phrase_num [B] int32, phrase_length [B,S] int32,
         phrase_syn [B,S] int64, bound_iters [1] int32, memory [B,R,d] float32 (or None).
@@ -174,7 +174,9 @@ class BofiEngine:
         ``q1_group`` > 0: the call carries B / q1_group independent batches (dynamic batching); quirk Q1 applies per batch,
         so each batch's outputs equal its own separate decode.
         ``iter_cap`` > 0: enqueue that many bounding iterations instead of seq_length (bofi_engine_set_bound_iter_cap); the result is the
-        reference's iff ``bound_iters`` < iter_cap afterwards -- the caller checks and decodes again without the cap otherwise."""
+        reference's iff ``bound_iters`` < iter_cap afterwards -- the caller checks and decodes again without the cap otherwise.
+        ``phases``: "" = the whole decode; a subset of "ebf" = only the encode / bounding loop / filling pass + export of it (BOFI_FLAG_PHASE_*): a pipelining
+        caller enqueues the three on the same engine in that order (its streams / events order them) with the same arguments."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
@@ -197,6 +199,10 @@ class BofiEngine:
             self._iter_cap = int(iter_cap)
         flags = ((hip.FLAG_STRICT_Q1 if strict_q1 else 0) | (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0)
                  | (refine_rounds << hip.FLAG_REFINE_SHIFT))
+        if phases:
+            if set(phases) - set("ebf"):
+                raise hip.BofiHipError("phases: a subset of 'ebf'")
+            flags |= ((hip.FLAG_PHASE_ENCODE if "e" in phases else 0) | (hip.FLAG_PHASE_BOUND if "b" in phases else 0) | (hip.FLAG_PHASE_FILL if "f" in phases else 0))
         hip.check(self._lib.bofi_engine_decode_naic(
             self._h, hip.ptr(att_feats), hip.dtype_code(att_feats), hip.ptr(att_len), B, R, flags, hip.ptr(out["seq"]),
             hip.ptr(out["seq_logprob"]), hip.ptr(out["phrase_num"]), hip.ptr(out["phrase_length"]), hip.ptr(out["phrase_syn"]),

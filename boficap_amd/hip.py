@@ -15,6 +15,7 @@ DT_F32, DT_BF16 = 0, 1
 FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
 FLAG_REFINE_SHIFT = 8
 FLAG_SAMPLE = 16
+FLAG_PHASE_ENCODE, FLAG_PHASE_BOUND, FLAG_PHASE_FILL = 32, 64, 128
 ABI_VERSION = 3
 
 

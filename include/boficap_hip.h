@@ -360,6 +360,12 @@ void* bofi_engine_stream(bofi_engine_t* e);
 #define BOFI_FLAG_REFINE_SHIFT 8   /* bits 8..11: extra filling rounds; round r > 0 feeds round r-1's ids back as the
                                       decoder input tokens (decode_NA's glat_input, TransformerModel.py:570-574).  The
                                       reference has no refinement loop: parity of rounds > 0 is pinned to the oracle only. */
+/* bofi_engine_decode_naic in PHASES (none of the three bits = the whole decode).  A caller that pipelines decodes enqueues the phases of one decode
+ * as separate calls on the same engine -- encode, then bound, then fill, ordered by the caller's streams / events -- so that the bounding loop (a few
+ * workgroups for ~1 ms) can run on a side stream while the launch stream already encodes the next batch on another fork: */
+#define BOFI_FLAG_PHASE_ENCODE 32   /* _prepare_feature + Encoder + the stacked cross K|V (TransformerModel.py:1674-1690, 1332-1336) */
+#define BOFI_FLAG_PHASE_BOUND 64    /* the bounding loop of core_NAIC (:1833-1869) on the preceding encode of this engine */
+#define BOFI_FLAG_PHASE_FILL 128    /* decode_NA + logit + greedy pick + the slot-state export (:570-587, 1872-1876) on the preceding two */
 
 /* model(fc, att, att_masks, opt={'train_mode':'NAIC','sample_method':'greedy'}, mode='sample'):
  * AttModel._sample AttModel.py:307-338,419-429 -> _prepare_feature TransformerModel.py:1674-1690
