@@ -812,23 +812,25 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         eng.set_decodes_in_flight(len(engines))
     # for the record: the same launches with the features starting in pinned HOST memory (a loader's numpy arrays), copied to the
     # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
-    pcie_ms = None
+    pcie_ms, pcie_note = None, None
     if args.from_host:
-        hosts = [(a_k.cpu().pin_memory(), b_k.cpu().pin_memory()) for a_k, b_k in zip(atts, atts2)]
-        def step_h(i):
-            k = i % len(engines)
-            with torch.cuda.stream(streams[k]):
-                atts[k].copy_(hosts[k][(i // len(engines)) % 2], non_blocking=True)
-                engines[k].decode_naic(atts[k], graph=graph, out=outs[k], refine_rounds=args.refine, q1_group=qg, iter_cap=cap)
-        for i in range(warm_launches):
-            step_h(i)
+        # through boficap_amd.engine.DecodePipeline -- what tools/eval.py and TransformerModel.decode_many run: 3 launches in flight of 8 batches each, the
+        # features copied from pinned host memory on a copy stream ahead of the launches (3 launch streams + the copy stream = the runtime's 4 hardware
+        # queues), ids / slot layouts / per-image entropy and perplexity back on the host per batch
+        from boficap_amd.engine import DecodePipeline
+        pipe = DecodePipeline(eng, in_flight=3, batches_per_launch=8)
+        pool = torch.cat(atts).cpu()
+        pool = torch.cat([pool] * (-(-64 * 96 // pool.size(0)))).pin_memory()                 # >= 96 batches of 64 (12 launches), whatever --steps says
+        hb = [pool[i:i + args.batch] for i in range(0, pool.size(0) - args.batch + 1, args.batch)]
+        for _ in pipe.run(hb[:48]):
+            pass
         torch.cuda.synchronize()
         h0 = time.perf_counter()
-        for i in range(launches):
-            step_h(i)
-        torch.cuda.synchronize()
-        pcie_ms = (time.perf_counter() - h0) / args.steps * 1e3
-        budget_ok = budget_held("from-host") and budget_ok
+        n_img = sum(r["seq"].size(0) for r in pipe.run(hb))
+        pcie_ms = (time.perf_counter() - h0) / (n_img / args.batch) * 1e3
+        pcie_note = f"{len(hb)} batches of {args.batch} through DecodePipeline (3 launches in flight x 8 batches, copy stream ahead, results on the host)"
+        del pipe, pool, hb
+        torch.cuda.empty_cache()
     traffic, tnote = None, "no PMC pass committed for this configuration"
     names = {1: ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
@@ -895,7 +897,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                    "images_per_launch": C * args.batch, "refine_rounds": args.refine,
                    "one_at_a_time_ms_per_step": round(single_ms, 4) if single_ms else round(elapsed / args.steps * 1e3, 4),
                    "weights": "seeded Xavier init + calibrated bound heads (boficap_amd.weights, seed 0)",
-                   "features_from_pinned_host_ms_per_step": round(pcie_ms, 4) if pcie_ms else None, "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
+                   "features_from_pinned_host_ms_per_step": round(pcie_ms, 4) if pcie_ms else None, "features_from_pinned_host_how": pcie_note, "att_feats_seed": ATT_SEED, "batches_reordered_for_q1": moved, "nan_in_output": nan, "sharding": "images by rank, no collective"},
         "roofline": roof,
     }
     if world == 1 and gemm_roofline:

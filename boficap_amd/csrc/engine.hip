@@ -968,10 +968,11 @@ void bofi_engine_destroy(bofi_engine_t* e) {
     delete e;
 }
 
-int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
+int bofi_engine_fork_sized(bofi_engine_t* parent, int max_batch, bofi_engine_t** out) {
     g_err.clear();
     if (!parent || !out) return fail(BOFI_ERR_ARG, "null argument");
     if (!parent->finalized) return fail(BOFI_ERR_STATE, "fork needs a finalized engine");
+    if (max_batch < 0) return fail(BOFI_ERR_ARG, "fork: max_batch >= 0 (0 = the parent's)");
     auto* e = new bofi_engine(*parent);          // copies config and every weight pointer
     e->host.clear();
     e->allocs.clear();                           // owns nothing of the parent's
@@ -990,12 +991,15 @@ int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) {
     e->saic_it_begin = 1;
     e->saic_it_end = 0;
     e->st = bofi::BoundState{};
+    if (max_batch > 0) e->cfg.max_batch = max_batch;          // (the weights do not depend on it: only the workspace is sized by it)
     int rc = e->alloc_workspace();
     if (rc == BOFI_OK && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(BOFI_ERR_HIP, "hipStreamCreate");
     if (rc != BOFI_OK) { bofi_engine_destroy(e); return rc; }
     *out = e;
     return BOFI_OK;
 }
+
+int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out) { return bofi_engine_fork_sized(parent, 0, out); }
 
 int bofi_engine_refresh_device(bofi_engine_t* e, int n, const char* const* names, const float* const* ptrs, const int64_t* numels, void* stream) {
     if (!e || !names || !ptrs || !numels || n <= 0) return fail(BOFI_ERR_ARG, "null argument");

@@ -96,17 +96,18 @@ class BofiEngine:
             hip.check(self._lib.bofi_engine_create(C.byref(c), C.byref(self._h)), "bofi_engine_create")
         self._finalized = False
 
-    def fork(self) -> "BofiEngine":
-        """A second engine sharing this one's weights with its own workspace (one per in-flight batch)."""
+    def fork(self, max_batch: Optional[int] = None) -> "BofiEngine":
+        """A second engine sharing this one's weights with its own workspace (one per in-flight batch); ``max_batch``: images per call the fork's
+        workspace is sized for (default: this engine's) -- a pipeline that coalesces several loader batches per call forks larger."""
         if not self._finalized:
             raise hip.BofiHipError("fork() needs loaded weights")
         f = object.__new__(BofiEngine)
-        f.cfg, f.dtype, f.device, f.max_batch, f.max_regions = self.cfg, self.dtype, self.device, self.max_batch, self.max_regions
-        f._lib, f._finalized, f._parent = self._lib, True, self        # keeps the parent (weights) alive
+        f.cfg, f.dtype, f.device, f.max_batch, f.max_regions = self.cfg, self.dtype, self.device, int(max_batch or self.max_batch), self.max_regions
+        f._lib, f._finalized, f._parent = self._lib, True, getattr(self, "_parent", self)        # keeps the weights' owner alive
         f._iter_cap, f._q1_group, f._live_word = 0, 0, None           # per-call knobs start from the defaults (bofi_engine_fork resets them too)
         f._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            hip.check(self._lib.bofi_engine_fork(self._h, C.byref(f._h)), "bofi_engine_fork")
+            hip.check(self._lib.bofi_engine_fork_sized(self._h, int(max_batch or 0), C.byref(f._h)), "bofi_engine_fork_sized")
         return f
 
     def stream(self) -> "torch.cuda.Stream":
@@ -337,3 +338,130 @@ class BofiEngine:
         hip.check(self._lib.bofi_engine_fill_naic(self._h, hip.ptr(ext_syn.contiguous()), hip.ptr(last.contiguous()), B, R, hip.ptr(att_len), flags,
                                                   hip.ptr(seq), hip.ptr(lp), hip.stream_ptr()), "bofi_engine_fill_naic")
         return seq, lp
+
+
+class DecodePipeline:
+    """Many loader batches through the NAIC bound+fill decode at the engine's throughput: what ``tools/eval.py`` and
+    ``TransformerModel.decode_many`` run instead of one synchronised ``mode='sample'`` call per batch (the reference's eval loop,
+    eval_utils.py:456-460 under tools/eval.py:123).
+
+      * ``in_flight`` engine forks on streams that provably overlap, one launch each (default 3: with the copy stream that is the runtime's four
+        hardware queues -- a fourth launch stream would share a queue with the copies: 161 against 210 k images/s, profiles/r05_decode_many.txt);
+      * ``batches_per_launch`` consecutive loader batches of one shape ride ONE launch (dynamic batching: quirk Q1 stays per batch, so every
+        batch's result is its own decode's -- bit for bit under the same kernel family and hint);
+      * features are double-buffered per fork and copied from (pinned) host memory on a copy stream that runs ahead of the launches; the small
+        outputs (ids, slot layout, per-image entropy / perplexity) come back through pinned buffers behind an event, the 48.6 MB of log-probs per
+        batch stay on the device unless asked for.
+
+    ``run(batches)`` is a generator: one dict per input batch, in input order, as soon as its launch is through -- while later launches are
+    already in flight."""
+
+    def __init__(self, engine: "BofiEngine", *, in_flight: int = 3, batches_per_launch: int = 8, strict_q1: bool = True, stats: bool = True,
+                 keep_logprob: bool = False):
+        if in_flight < 1 or batches_per_launch < 1:
+            raise hip.BofiHipError("in_flight and batches_per_launch must be >= 1")
+        self.root, self.nf, self.bpl = engine, int(in_flight), int(batches_per_launch)
+        self.strict_q1, self.stats, self.keep_logprob = strict_q1, stats, keep_logprob
+        self.dev = engine.device
+        self._slots = None                                       # built for the first launch's shape
+
+    def _build(self, rows_max: int):
+        streams = pick_concurrent_streams(self.nf, self.dev) if self.nf > 1 else [torch.cuda.Stream(self.dev)]
+        while len(streams) < self.nf:                            # (fewer hardware queues than launches in flight: the extra ones share)
+            streams.append(torch.cuda.Stream(self.dev))
+        self.copy_stream = torch.cuda.Stream(self.dev)
+        self._slots = []
+        for k in range(self.nf):
+            e = self.root.fork(max_batch=rows_max)
+            e.set_decodes_in_flight(self.nf)
+            self._slots.append(dict(eng=e, stream=streams[k], feats=[None, None], lens=[None, None], out=None, host=None, copied=[torch.cuda.Event(), torch.cuda.Event()],
+                                    done=torch.cuda.Event(), busy=False))
+        self.rows_max = rows_max
+
+    @staticmethod
+    def _as_host_or_device(x):
+        return torch.from_numpy(x) if not torch.is_tensor(x) else x
+
+    def run(self, batches):
+        """``batches``: iterable of ``att_feats`` or ``(att_feats, att_len)``: [b, R, F] tensors / arrays in the engine's compute dtype or float32, on
+        the host (pinned: the copy is asynchronous) or the device; ``att_len`` int32 [b] region counts or None."""
+        pending = []                                             # launches in flight: (slot, [batch sizes], has_len)
+        group, gkey = [], None
+        j = 0
+
+        def flush():
+            nonlocal j, group
+            if not group:
+                return
+            k, p = j % self.nf, (j // self.nf) % 2
+            if j >= self.nf:
+                yield from self._finish(pending.pop(0))
+            self._launch(k, p, group)
+            pending.append((k, [g[0].shape[0] for g in group]))
+            j += 1
+            group = []
+
+        for item in batches:
+            att, lens = item if isinstance(item, (tuple, list)) else (item, None)
+            att = self._as_host_or_device(att)
+            lens = None if lens is None else self._as_host_or_device(lens).to(torch.int32)
+            key = (tuple(att.shape), att.dtype, lens is None)
+            if group and (key != gkey or len(group) >= self.bpl):
+                yield from flush()
+            group.append((att, lens))
+            gkey = key
+        yield from flush()
+        while pending:
+            yield from self._finish(pending.pop(0))
+
+    def _launch(self, k, p, group):
+        b, R, F = group[0][0].shape
+        nb, rows = len(group), len(group) * group[0][0].shape[0]
+        if self._slots is None:
+            self._build(max(rows, self.bpl * b))
+        if rows > self.rows_max:
+            raise hip.BofiHipError(f"a launch of {rows} images exceeds the pipeline's {self.rows_max} (first batch x batches_per_launch)")
+        sl = self._slots[k]
+        e, st = sl["eng"], sl["stream"]
+        dt = group[0][0].dtype
+        if sl["feats"][p] is None or sl["feats"][p].shape[1:] != (R, F) or sl["feats"][p].dtype != dt:
+            sl["feats"][p] = torch.empty(self.rows_max, R, F, dtype=dt, device=self.dev)
+        has_len = group[0][1] is not None
+        if has_len and sl["lens"][p] is None:
+            sl["lens"][p] = torch.empty(self.rows_max, dtype=torch.int32, device=self.dev)
+        feats, lens = sl["feats"][p][:rows], (sl["lens"][p][:rows] if has_len else None)
+        cs = self.copy_stream
+        with torch.cuda.stream(cs):
+            cs.wait_event(sl["done"])                            # the launch that last read this slot's buffers is through (it was finished before this one is issued)
+            for i, (att, ln) in enumerate(group):
+                feats[i * b:(i + 1) * b].copy_(att, non_blocking=True)
+                if has_len:
+                    lens[i * b:(i + 1) * b].copy_(ln, non_blocking=True)
+            sl["copied"][p].record(cs)
+        with torch.cuda.stream(st):
+            st.wait_event(sl["copied"][p])
+            sl["out"] = e.decode_naic(feats, lens, strict_q1=self.strict_q1, graph=True, out=sl["out"] if sl["out"] is not None and sl["out"]["seq"].shape[0] == rows else None,
+                                      q1_group=b if nb > 1 else 0)
+            out = sl["out"]
+            small = {k2: out[k2] for k2 in ("seq", "phrase_num", "phrase_length", "phrase_syn")}
+            if self.stats:
+                small["entropy"], small["perplexity"] = e.entropy_perplexity(out)
+            if sl["host"] is None or sl["host"]["seq"].shape[0] != rows:
+                sl["host"] = {k2: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k2, v in small.items()}
+            for k2, v in small.items():
+                sl["host"][k2].copy_(v, non_blocking=True)
+            sl["lp"] = out["seq_logprob"].clone() if self.keep_logprob else None
+            sl["done"].record(st)
+
+    def _finish(self, launch):
+        k, sizes = launch
+        sl = self._slots[k]
+        sl["done"].synchronize()
+        mine = {k2: v.clone() for k2, v in sl["host"].items()}      # (one private copy per launch: the pinned buffers are the next launch's; batches are views of it)
+        o = 0
+        for b in sizes:
+            res = {k2: v[o:o + b] for k2, v in mine.items()}
+            if sl["lp"] is not None:
+                res["seq_logprob"] = sl["lp"][o:o + b]
+            o += b
+            yield res

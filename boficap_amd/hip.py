@@ -82,6 +82,7 @@ SIGNATURES = {
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),
+    "bofi_engine_fork_sized": (_I, [_P, _I, C.POINTER(_P)]),
     "bofi_engine_stream": (_P, [_P]),
     "bofi_engine_set_weight": (_I, [_P, C.c_char_p, _P, _I64]),
     "bofi_engine_finalize": (_I, [_P]),

@@ -239,6 +239,37 @@ class TransformerModel(nn.Module):
             v.record_stream(main)                                 # allocated / read on s2, used on the caller's stream from here on
         return saic, naic
 
+    def decode_many(self, batches, *, batches_per_launch: int = 8, in_flight: int = 3, stats: bool = True, keep_logprob: bool = False):
+        """Greedy NAIC decode of MANY loader batches at the engine's throughput -- the eval loop of the reference (eval_utils.py:456-460: one synchronised
+        ``model(..., mode='sample')`` per batch, which is what ``_sample`` reproduces) as a pipeline: ``in_flight`` engine forks on overlapping streams,
+        ``batches_per_launch`` consecutive batches per launch (quirk Q1 per batch: every batch's result is its own decode's), features copied from (pinned)
+        host memory on a copy stream ahead of the launches (``boficap_amd.engine.DecodePipeline``).
+
+        ``batches``: iterable of ``att_feats`` or ``(att_feats, att_masks)`` -- [b, R, F] float32 / compute-dtype tensors or arrays on the host or the device,
+        masks [b, R] as the loader builds them (prefix-structured, clipped to the batch's longest image by the caller as AttModel.clip_att does).
+        Yields one dict per batch, in order: seq [b, S] int64, phrase_num [b] int32, phrase_length [b, S] int32, phrase_syn [b, S] int64 (+ entropy,
+        perplexity [b] as eval_utils.py:463-464 with ``stats``; + seq_logprob [b, S, V] on the device with ``keep_logprob``), host tensors."""
+        from .engine import DecodePipeline
+        eng = self.engine()
+        key = (id(eng), batches_per_launch, in_flight, stats, keep_logprob, self.strict_reference)
+        cached = self.__dict__.get("_pipeline")
+        if cached is None or cached[0] != key:
+            cached = self.__dict__["_pipeline"] = (key, DecodePipeline(eng, in_flight=in_flight, batches_per_launch=batches_per_launch, strict_q1=self.strict_reference,
+                                                                       stats=stats, keep_logprob=keep_logprob))
+
+        def items():
+            for it in batches:
+                att, masks = it if isinstance(it, (tuple, list)) else (it, None)
+                att = torch.from_numpy(att) if not torch.is_tensor(att) else att
+                if att.dtype not in (torch.float32, self.compute_dtype):
+                    att = att.float()
+                if masks is None:
+                    yield att.contiguous()
+                else:
+                    masks = torch.from_numpy(masks) if not torch.is_tensor(masks) else masks
+                    yield att.contiguous(), masks.long().sum(1).to(torch.int32).contiguous()
+        return cached[1].run(items())
+
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel.py:307-338, 419-437 for train_mode 'NAIC' (bound+fill) and 'SAIC' (phrase by phrase)."""
         sample_method = opt.get("sample_method", "greedy")

@@ -291,6 +291,9 @@ int bofi_engine_finalize(bofi_engine_t* e);
  * CUs idle; a batch in another stream fills them).  The parent must outlive its forks and must not be
  * re-finalized while they exist.  Destroy a fork with bofi_engine_destroy. */
 int bofi_engine_fork(bofi_engine_t* parent, bofi_engine_t** out);
+/* The same with a workspace for up to max_batch images per call (0 = the parent's): dynamic batching puts several loader batches into one decode call
+ * (bofi_engine_set_q1_group), which a model built for one batch per call has no workspace for -- its weights serve either size. */
+int bofi_engine_fork_sized(bofi_engine_t* parent, int max_batch, bofi_engine_t** out);
 
 /* Re-pack the engine's weights from float32 parameters that live on the DEVICE (reference names, as set_weight): the
  * packing of bofi_engine_finalize (q|k|v stacking, LayerNorm folding, compute-dtype cast, bound tables) as kernels on

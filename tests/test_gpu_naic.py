@@ -665,3 +665,46 @@ def test_projection_tail_of_the_feed_forward_kernel_changes_launches_not_results
         os.environ.pop("BOFI_RB_MIN_ROWS")
         os.environ.pop("BOFI_RB_FFN_PROJ", None)
         H.lib().bofi_reload_env()
+
+
+def test_decode_many_equals_one_decode_per_batch(weight_cache, monkeypatch):
+    """TransformerModel.decode_many (engine forks in flight, several loader batches per launch with quirk Q1 per batch, features from pinned host memory on a
+    copy stream) against one decode per batch on the same kernel family and hint: bit for bit, in input order, ragged batches and a short last batch included."""
+    import captioning.models as models
+    from boficap_amd import hip as H
+    from boficap_amd import weights as W
+    from boficap_amd.engine import BofiEngine
+    monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0")                 # one kernel family whatever the launch size (a row's result then does not depend on the launch)
+    monkeypatch.setenv("BOFI_BOUND_LOOP", "2")
+    H.lib().bofi_reload_env()
+    cfg, sd = weight_cache("FULL", 0, 1.0)
+    opt = cfg.to_opt()
+    opt.bofi_compute_dtype, opt.bofi_max_batch, opt.bofi_max_regions = torch.bfloat16, 16, 36
+    model = models.setup(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    feats = torch.from_numpy(W.synthetic_att_feats(16 * 7 + 5, 36, cfg.att_feat_size, seed=77)).to(torch.bfloat16).pin_memory()
+    batches = [feats[i:i + 16] for i in range(0, feats.size(0), 16)]           # 7 batches of 16 and one of 5
+    masks = torch.ones(16, 36)
+    masks[3, 20:] = 0; masks[9, 7:] = 0
+    items = [b if i != 2 else (b, masks) for i, b in enumerate(batches)]          # one ragged batch in the middle (breaks the coalescing there)
+    got = list(model.decode_many(items, batches_per_launch=3, in_flight=2, keep_logprob=True))
+    assert len(got) == len(batches)
+    ref = BofiEngine(cfg, torch.bfloat16, max_batch=16, max_regions=36)
+    ref.load_state_dict(sd)
+    ref.set_decodes_in_flight(2)
+    for i, (b, r) in enumerate(zip(batches, got)):
+        lens = masks.sum(1).to(torch.int32).cuda() if i == 2 else None
+        w = ref.decode_naic(b.cuda(), lens)
+        ent, ppl = ref.entropy_perplexity(w)
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+            assert torch.equal(r[k], w[k].cpu()), (i, k)
+        a, c = r["seq_logprob"].cpu(), w["seq_logprob"].cpu()
+        assert torch.equal(a.isnan(), c.isnan()) and torch.equal(a.nan_to_num(), c.nan_to_num()), i
+        assert torch.equal(r["entropy"].isnan(), ent.cpu().isnan()) and torch.equal(r["entropy"].nan_to_num(), ent.cpu().nan_to_num())
+        assert torch.equal(r["perplexity"].nan_to_num(), ppl.cpu().nan_to_num())
+    # again through the same pipeline (replayed graphs, reused buffers): the same results
+    again = list(model.decode_many(items, batches_per_launch=3, in_flight=2))
+    assert all(torch.equal(x["seq"], y["seq"]) and torch.equal(x["phrase_length"], y["phrase_length"]) for x, y in zip(again, got))
+    monkeypatch.undo()
+    H.lib().bofi_reload_env()
