@@ -54,7 +54,7 @@ constexpr int BL_OFF_X = BL_OFF_Y + BL_G * BL_YP * 4;    // fp16 [16][512] GEMM 
 constexpr int BL_OFF_BIG = BL_OFF_X + BL_G * 1024;       // 64 KiB: fp16 hidden rows [16][dff] | float32 queries + probabilities | heads' hidden + logits
 constexpr int BL_OFF_SCT = BL_OFF_BIG + 65536;           // float32 [L*10][8] self-attention scores of row 0 by (position, label, head)
 constexpr int BL_OFF_ST = BL_OFF_SCT + BL_LMAX * 10 * 8 * 4;       // int32 slot state: last, finished, phrase_num, att_len [16]; ext_syn, phrase_length, phrase_syn [16][24]; picks [16][2]
-constexpr int BL_ST_INTS = 4 * BL_G + 3 * BL_G * BL_LMAX + 2 * BL_G + 16;
+constexpr int BL_ST_INTS = 4 * BL_G + 3 * BL_G * BL_LMAX + 2 * BL_G + BL_G + 16;
 constexpr int BL_SMEM = BL_OFF_ST + BL_ST_INTS * 4;
 
 __device__ __forceinline__ float bl_clamp16(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }      // (a NaN fails both tests and passes)
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     int* s_plen = s_ext + BL_G * BL_LMAX;                           // [16][24] phrase_length by slot
     int* s_psyn = s_plen + BL_G * BL_LMAX;                          // [16][24] phrase_syn by slot
     int* s_pick = s_psyn + BL_G * BL_LMAX;                          // [16][2]
+    int* s_act = s_pick + 2 * BL_G;                                 // [16] the group's unfinished images, compacted; [16] = their count
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;      // (wave in a scalar register: stream pointers stay scalar)
     const int B = a.B, L = a.L, S = a.S, R = a.R, hh = a.hh, dff = a.dff;
@@ -193,6 +194,14 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
             if (nf == BL_G) break;
         }
         ++it_done;
+        // the unfinished images, compacted: the per-image stages (self-attention values, cross-attention) give wavefront w the entries w and w + 8, so a group
+        // with <= 8 images left runs them in one round (the list is read behind the barrier that follows the self-attention probabilities)
+        if (tid < 64) {
+            const bool act = tid < BL_G && !s_fin[tid];
+            const unsigned long long mask = __ballot(act);
+            if (act) s_act[__popcll(mask & ((1ull << tid) - 1ull))] = tid;
+            if (tid == 0) s_act[BL_G] = __popcll(mask);
+        }
         // (lane-derived addresses are re-derived per iteration from a value the optimiser cannot see through: hoisted out of the loop they are
         // spilled at the cross-attention's register peak, and a scratch reload drains the weight ring)
         int lane = lane0;
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 #pragma unroll 1
             for (int rnd = 0; rnd < 8; ++rnd) {
                 const int pair = rnd * 16 + hw, i = pair >> 3, h = pair & 7;
+                if (s_fin[i]) continue;                                   // (the wavefront's two halves hold the same image)
                 const int n = min(s_last[i], L);
                 const float sc = li < n ? SCT[(li * 10 + s_ext[i * BL_LMAX + li]) * 8 + h] : -INFINITY;
                 const float m = xor16_max(row16_max(sc));
@@ -217,37 +227,36 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         }
         __syncthreads();
         BL_STAMP(1);
-        {   // ctx = P . V rows of the float32 table: wavefront w owns images 2w, 2w + 1, a lane 8 columns (head lane / 8)
-            const int h = lane >> 3;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = 2 * wave + u, n = min(s_last[i], L);
+        {   // ctx = P . V rows of the float32 table: wavefront w owns the active images w and w + 8, a lane 8 columns (head lane / 8)
+            const int h = lane >> 3, n_act = s_act[BL_G];
+#pragma unroll 1
+            for (int idx = wave; idx < n_act; idx += 8) {
+                const int i = s_act[idx], n = min(s_last[i], L);
                 float acc[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-                if (!s_fin[i]) {
-                    for (int j0 = 0; j0 < n; j0 += 8) {
-                        float4 v0[8], v1[8];
-                        float p[8];
+                for (int j0 = 0; j0 < n; j0 += 8) {
+                    float4 v0[8], v1[8];
+                    float p[8];
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const int jj = min(j0 + t, n - 1);
-                            const float* vr = a.vtab + (size_t)(jj * 10 + s_ext[i * BL_LMAX + jj]) * 512 + lane * 8;
-                            v0[t] = *reinterpret_cast<const float4*>(vr);
-                            v1[t] = *reinterpret_cast<const float4*>(vr + 4);
-                            p[t] = j0 + t < n ? PSELF[(i * 8 + h) * 32 + j0 + t] : 0.f;
-                        }
+                    for (int t = 0; t < 8; ++t) {
+                        const int jj = min(j0 + t, n - 1);
+                        const float* vr = a.vtab + (size_t)(jj * 10 + s_ext[i * BL_LMAX + jj]) * 512 + lane * 8;
+                        v0[t] = *reinterpret_cast<const float4*>(vr);
+                        v1[t] = *reinterpret_cast<const float4*>(vr + 4);
+                        p[t] = j0 + t < n ? PSELF[(i * 8 + h) * 32 + j0 + t] : 0.f;
+                    }
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            acc[0] = fmaf(p[t], v0[t].x, acc[0]); acc[1] = fmaf(p[t], v0[t].y, acc[1]); acc[2] = fmaf(p[t], v0[t].z, acc[2]); acc[3] = fmaf(p[t], v0[t].w, acc[3]);
-                            acc[4] = fmaf(p[t], v1[t].x, acc[4]); acc[5] = fmaf(p[t], v1[t].y, acc[5]); acc[6] = fmaf(p[t], v1[t].z, acc[6]); acc[7] = fmaf(p[t], v1[t].w, acc[7]);
-                        }
+                    for (int t = 0; t < 8; ++t) {
+                        acc[0] = fmaf(p[t], v0[t].x, acc[0]); acc[1] = fmaf(p[t], v0[t].y, acc[1]); acc[2] = fmaf(p[t], v0[t].z, acc[2]); acc[3] = fmaf(p[t], v0[t].w, acc[3]);
+                        acc[4] = fmaf(p[t], v1[t].x, acc[4]); acc[5] = fmaf(p[t], v1[t].y, acc[5]); acc[6] = fmaf(p[t], v1[t].z, acc[6]); acc[7] = fmaf(p[t], v1[t].w, acc[7]);
                     }
                 }
                 u32x4 o;
                 o[0] = bl_pack(acc[0], acc[1]); o[1] = bl_pack(acc[2], acc[3]); o[2] = bl_pack(acc[4], acc[5]); o[3] = bl_pack(acc[6], acc[7]);
                 *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = o;
             }
+            // (rows of finished images keep what they held: their MFMA columns are never read)
         }
         __syncthreads();
         BL_STAMP(2);
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         __syncthreads();
         BL_STAMP(5);
         // ================= S4: cross-attention of the 16 query rows over their images' regions =================
-        // Wavefront w owns images 2w, 2w + 1.  A lane owns 8 columns (lane*8 .. +7: head lane / 8) of EVERY region row: a load instruction of the
+        // Wavefront w owns the active images w and w + 8 of the compacted list.  A lane owns 8 columns (lane*8 .. +7: head lane / 8) of EVERY region row: a load instruction of the
         // wavefront is one whole 1-KiB K (or V) row.  A key's score is the sum over the 8 lanes of its head's octet (three DPP steps); the softmax runs
         // in the lane (the octet's lanes hold the same numbers), P.V accumulates in the lane: no cross-lane traffic besides the octet sums, no LDS.
         // Rows go through two register buffers of BR rows, NB batches per pass (NB even: the buffers alternate across the K pass, the V pass and
@@ -303,10 +312,12 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 #pragma unroll
                 for (int r = 0; r < BR; ++r) bb[r] = *reinterpret_cast<const u32x4*>(p + (size_t)min(j0 + r, R - 1) * a.ldkv);
             };
-            issue(buf[0], kbase, min(b0 + 2 * wave, B - 1), 0);
+            const int n_act = s_act[BL_G];
+            if (wave < n_act) issue(buf[0], kbase, min(b0 + s_act[wave], B - 1), 0);
 #pragma unroll 1
-            for (int u = 0; u < 2; ++u) {
-                const int i = 2 * wave + u, bi = min(b0 + i, B - 1), kl = s_attl[i];
+            for (int idx = wave; idx < n_act; idx += 8) {
+                const int i = s_act[idx], bi = min(b0 + i, B - 1), kl = s_attl[i];
+                const int bi_next = min(b0 + s_act[min(idx + 8, n_act - 1)], B - 1);       // (after the last image: a redundant batch of its own rows)
                 const float4 qa = *reinterpret_cast<const float4*>(Q + i * BL_YP + lane * 8);
                 const float4 qb = *reinterpret_cast<const float4*>(Q + i * BL_YP + lane * 8 + 4);
                 float sc[RMAX];
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
                     if (bt + 1 < NB) issue(buf[(bt + 1) & 1], vbase, bi, (bt + 1) * BR);
-                    else issue(buf[0], kbase, min(bi + 1, B - 1), 0);         // the next image's first K rows (after the last image: a redundant batch)
+                    else issue(buf[0], kbase, bi_next, 0);                    // the next image's first K rows
 #pragma unroll
                     for (int r = 0; r < BR; ++r) {
                         const u32x4 v = buf[bt & 1][r];
@@ -437,14 +448,15 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         }
         __syncthreads();
         BL_STAMP(12);
-        {   // output layers (float32): 16 lanes per output, their weights in registers; one DPP row reduction per image
-            const float* hv = HID + (w2o < 20 ? 0 : hh);
+        {   // output layers (float32): 16 lanes per output, their weights in registers; one DPP row reduction per image.  (Terms k >= hh carry weight 0 and
+            // read the row's other columns: finite ReLU outputs, or NaN on a NaN row, where every logit is NaN anyway.)
+            const float* hv = HID + (w2o < 20 ? 0 : hh) + w2q;
 #pragma unroll 4
             for (int i = 0; i < BL_G; ++i) {
-                float s0 = 0.f;
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                for (int t = 0; t < W2T; ++t) { const int k = w2q + 16 * t; s0 = fmaf(w2v[t], k < hh ? hv[i * BL_HP + k] : 0.f, s0); }
-                s0 = row16_sum(s0);
+                for (int t = 0; t < W2T; t += 2) { s0 = fmaf(w2v[t], hv[i * BL_HP + 16 * t], s0); s1 = fmaf(w2v[t + 1], hv[i * BL_HP + 16 * t + 16], s1); }
+                s0 = row16_sum(s0 + s1);
                 if (w2q == 0 && w2o < 30) LG[i * 32 + w2o] = s0 + w2b;
             }
         }
