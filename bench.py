@@ -559,23 +559,25 @@ def run_rl(args, ctx, log, cpu=True):
     _barrier(world)
     elapsed = dp.reduce_scalar(time.perf_counter() - t0, "max", device=dev)
     last_default = dict(tr._last_rl)
-    # the same step with the reference's estimator (opt.bofi_rl_reference_estimator: every token drawn from the gradient pass's own dropout-perturbed rows,
-    # one tape-free training forward per phrase): a few steps, reported beside the headline form
+    ref_info = {"drawn_rows_vs_gradient_pass_rows_max_abs": last_default.get("reference_gap"), "training_forwards_per_step": last_default.get("training_forwards")}
+    # the fast form of rounds 1-4 beside it (opt.bofi_rl_reference_estimator = False: samples from the dropout-free inference engine, ONE gradient pass with
+    # dropout, replayed as a hipGraph): a few steps
     try:                                                       # (a failure of this leg must not lose the headline line: it is reported beside it)
-        model.opt.bofi_rl_reference_estimator = True
-        tr.rl_step(att, None, score, sample_n=n)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
+        model.opt.bofi_rl_reference_estimator = False
         for _ in range(3):
             tr.rl_step(att, None, score, sample_n=n)
         torch.cuda.synchronize(dev)
-        ref_ms = (time.perf_counter() - t1) / 3 * 1e3
-        ref_info = {"ms_per_step": round(ref_ms, 2), "drawn_rows_vs_gradient_pass_rows_max_abs": tr._last_rl["reference_gap"],
-                    "training_forwards_per_step": tr._last_rl["training_forwards"]}
+        t1 = time.perf_counter()
+        for _ in range(10):
+            tr.rl_step(att, None, score, sample_n=n)
+        torch.cuda.synchronize(dev)
+        fast_info = {"ms_per_step": round((time.perf_counter() - t1) / 10 * 1e3, 2),
+                     "what": "samples from the inference engine (no dropout), one gradient pass with dropout as a hipGraph: an importance-weight log-std of ~0.65 per caption "
+                             "against the reference's estimator (dev/exp/rl_dropout_gap.py)"}
     except Exception as e:
-        log(f"rl: the reference-estimator leg failed: {type(e).__name__}: {e}")
-        ref_info = {"error": f"{type(e).__name__}: {e}"}
-    model.opt.bofi_rl_reference_estimator = False
+        log(f"rl: the fast-estimator leg failed: {type(e).__name__}: {e}")
+        fast_info = {"error": f"{type(e).__name__}: {e}"}
+    del model.opt.bofi_rl_reference_estimator
     tr._last_rl = last_default
     if rank != 0:
         return None
@@ -601,9 +603,10 @@ def run_rl(args, ctx, log, cpu=True):
                       "saic_tokens_per_sample": round(float(tr._last_rl["saic_tokens"]), 2), "naic_tokens_per_sample": round(float(tr._last_rl["naic_tokens"]), 2),
                       "scorer": "host-side stand-in (the reference's CIDEr-D scorer is external)", "hip_graph": bool(graph),
                       "active_iteration_share": round(share, 3),
-                      "estimator": "sampler = inference engine (no dropout), gradient pass with dropout (DESIGN.md 7); reference_estimator = the reference's "
-                                   "own (loss_wrapper.py:193-209), opt.bofi_rl_reference_estimator",
-                      "reference_estimator": ref_info},
+                      "estimator": "the reference's own (loss_wrapper.py:193-209; the default since round 5): every token of both branches drawn from the rows the gradient "
+                                   "pass differentiates (one tape-free training forward per phrase under the step's counter-based dropout masks), then that forward with the tape; "
+                                   "fast_estimator = rounds 1-4's form, opt.bofi_rl_reference_estimator = False",
+                      "reference_estimator": ref_info, "fast_estimator": fast_info},
            "roofline": roof}
     if cpu and world == 1:
         _cpu_leg(res, lambda: cpu_baseline_rl(cfg, sd, n_img, n, budget_s=args.cpu_budget))

@@ -750,7 +750,10 @@ class XETrainer:
         Returns (loss, mean SAIC score, mean NAIC score)."""
         from . import xe
         model = self.model
-        if getattr(model.opt, "bofi_rl_reference_estimator", False):
+        # round 5: the REFERENCE's estimator is the default (every token drawn from the rows the gradient pass differentiates, loss_wrapper.py:193-209;
+        # _rl_reference_step below); opt.bofi_rl_reference_estimator = False selects the fast form of rounds 1-4 (samples from the dropout-free inference
+        # engine, gradient pass with dropout: 11.5 against ~50 ms per step at 10 x 5, an importance-weight log-std of ~0.65 per caption between the two)
+        if getattr(model.opt, "bofi_rl_reference_estimator", True):
             return self._rl_reference_step(att_feats, att_masks, score_fn, sample_n, temperature)
         fc = torch.zeros(att_feats.shape[0], 0, device=att_feats.device)
         was_training = model.training
@@ -861,9 +864,11 @@ class XETrainer:
         P = xe.Params(model)
         pos = torch.arange(S, device=dev)[None]
 
-        def rows_of(prep):
+        shared: dict = {}                                       # the encoder's memory and the cross K|V of the tape-free per-phrase forwards (same in each of them)
+
+        def rows_of(prep, reuse=None):
             return xe.sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, sample_n=sample_n, training=model.training, seed=seed,
-                                                compute_dtype=model.train_dtype, step_word=step_word)
+                                                compute_dtype=model.train_dtype, step_word=step_word, reuse=reuse)
 
         def draw(lp, mask, seq, drawn):
             idx = mask.nonzero(as_tuple=True)
@@ -893,7 +898,7 @@ class XETrainer:
                     prep = xe.rl_prepare(cfg, {"seq": seq_s, "phrase_length": pl, "phrase_syn": out["phrase_syn"]}, None, sample_n=sample_n,
                                          strict_q1=model.strict_reference, device=dev)
                     prep.update(prep_na)
-                    lp_s, lp_n = rows_of(prep)
+                    lp_s, lp_n = rows_of(prep, shared)
                     passes += 1
                     start = pl[:, :it - 1].sum(1)[:, None]
                     new = (pos >= start) & (pos < start + pl[:, it - 1:it])

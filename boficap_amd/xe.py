@@ -1683,9 +1683,20 @@ def rl_prepare(cfg, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool 
 
 @_scoped_compute_dtype
 def sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, *, sample_n: int = 1, training: bool = False, seed: Optional[int] = None,
-                              compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None):
+                              compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None, reuse: Optional[dict] = None):
+    out = _sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, sample_n=sample_n, training=training, seed=seed, compute_dtype=compute_dtype,
+                                     step_word=step_word, reuse=reuse)
+    if reuse is not None and "shadows" not in reuse:            # the bf16 operands the cross K|V were made as (kept by their producers in the step cache, which
+        reuse["shadows"] = [(t, _shadow(t), t.data_ptr() in _SHADOW_ONLY) for t in reuse["kv_cache"].values()]      # every call clears): registered again by the next calls
+    return out
+
+
+def _sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, *, sample_n: int = 1, training: bool = False, seed: Optional[int] = None,
+                               compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None, reuse: Optional[dict] = None):
     """Device half of ``sampled_logprobs``: tensors in, log-probs out, no host work (``att_masks`` None) -- what a captured
-    self-critical step replays.  ``prep``: rl_prepare's dict."""
+    self-critical step replays.  ``prep``: rl_prepare's dict.  ``reuse`` (tape-free callers only: a dict kept across calls on the SAME inputs, weights and
+    seed): the encoder's memory and the decoder layers' cross K|V do not depend on the captions -- under the counter-based dropout masks they are the same
+    tensors in every call -- so the per-phrase forwards of the reference-estimator step compute them once."""
     dev = att_feats.device
     S, d = cfg.seq_length, cfg.d_model
     if compute_dtype not in (torch.float32, torch.bfloat16):
@@ -1702,9 +1713,20 @@ def sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, *, sample_n: i
     B, R, _ = att_feats.shape
     N = B * sample_n
     drop = _Drop(cfg.dropout, cfg.drop_prob_lm, seed if training else None, step_word)
-    memory = encode_memory(P, cfg, att_feats, att_len, drop)
+    if reuse is not None and torch.is_grad_enabled():
+        raise hip.BofiHipError("reuse: tape-free calls only (the gradient pass needs its own graph through the encoder)")
+    if reuse is not None and "memory" in reuse:
+        memory, kv_cache = reuse["memory"], reuse["kv_cache"]
+        drop.k = reuse["drop_sites"]                          # (the decoder's dropout sites keep the numbers they have behind the encoder's: the same masks)
+        for t, sh, only in reuse.get("shadows", ()):
+            if sh is not None:
+                _register_shadow(t, sh, only)
+    else:
+        memory = encode_memory(P, cfg, att_feats, att_len, drop)
+        kv_cache = {}
+        if reuse is not None:
+            reuse["memory"], reuse["kv_cache"], reuse["drop_sites"] = memory, kv_cache, drop.k
     att_len_cap = None if att_len is None else att_len.repeat_interleave(sample_n).contiguous()
-    kv_cache: dict = {}
     tname, sname, pe = "model.tgt_embed.lut.weight", "model.syn_embed.lut.weight", P["model.pos_embed.pe"]
 
     def emb(tok, syn):

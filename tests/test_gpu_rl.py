@@ -186,15 +186,15 @@ def test_rl_step_with_ragged_regions_and_bf16(weight_cache, manifest):
     opt.noamopt, opt.learning_rate = False, 1e-4
     tr = XETrainer(model, opt, graph=True)
     model.train()
-    loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
-    assert torch.isfinite(loss)
-    # the reference-estimator form of the step on the same inputs: bf16 operands and ragged regions leave the drawn rows the gradient pass's rows
-    model.opt.bofi_rl_reference_estimator = True
+    model.opt.bofi_rl_reference_estimator = False               # the fast form of rounds 1-4 (opt-in since round 5): engine samples, re-forward with the tape
     try:
         loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
-        assert torch.isfinite(loss) and tr._last_rl["reference_gap"] == 0.0, tr._last_rl["reference_gap"]
+        assert torch.isfinite(loss) and "reference_gap" not in tr._last_rl
     finally:
-        model.opt.bofi_rl_reference_estimator = False
+        del model.opt.bofi_rl_reference_estimator
+    # the DEFAULT: the reference's estimator on the same inputs: bf16 operands and ragged regions leave the drawn rows the gradient pass's rows
+    loss, _, _ = tr.rl_step(att, masks, lambda seq: (seq % 7 == 0).float().mean(1), sample_n=3)
+    assert torch.isfinite(loss) and tr._last_rl["reference_gap"] == 0.0, tr._last_rl["reference_gap"]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
