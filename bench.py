@@ -839,7 +839,8 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         del pipe, pool, hb
         torch.cuda.empty_cache()
     traffic, tnote = None, "no PMC pass committed for this configuration"
-    names = {1: ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",), 5: ("r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
+    names = {1: ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",),
+             5: ("r05_hbm_traffic_coalesce5.json", "r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
