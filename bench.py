@@ -211,7 +211,7 @@ def xe_traffic(args):
     """HBM bytes per XE step from the committed PMC passes -- for the configuration they were taken on only."""
     if args.batch != 64 or args.seq_per_img != 5 or args.dtype != "bf16":
         return None
-    for name in ("r04_xe_hbm_traffic.json", "r03_xe_hbm_traffic.json", "r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
+    for name in ("r05_xe_hbm_traffic.json", "r04_xe_hbm_traffic.json", "r03_xe_hbm_traffic.json", "r02_xe_hbm_traffic.json", "r01_xe_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
