@@ -821,21 +821,21 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
     pcie_ms, pcie_note = None, None
     if args.from_host:
-        # through boficap_amd.engine.DecodePipeline -- what tools/eval.py and TransformerModel.decode_many run: 3 launches in flight of 8 batches each, the
+        # through boficap_amd.engine.DecodePipeline -- what tools/eval.py and TransformerModel.decode_many run: 3 launches in flight of 10 batches each, the
         # features copied from pinned host memory on a copy stream ahead of the launches (3 launch streams + the copy stream = the runtime's 4 hardware
         # queues), ids / slot layouts / per-image entropy and perplexity back on the host per batch
         from boficap_amd.engine import DecodePipeline
-        pipe = DecodePipeline(eng, in_flight=3, batches_per_launch=8)
+        pipe = DecodePipeline(eng, in_flight=3, batches_per_launch=10)
         pool = torch.cat(atts).cpu()
-        pool = torch.cat([pool] * (-(-64 * 96 // pool.size(0)))).pin_memory()                 # >= 96 batches of 64 (12 launches), whatever --steps says
+        pool = torch.cat([pool] * (-(-64 * 160 // pool.size(0)))).pin_memory()                # >= 160 batches of 64 (16 launches), whatever --steps says
         hb = [pool[i:i + args.batch] for i in range(0, pool.size(0) - args.batch + 1, args.batch)]
-        for _ in pipe.run(hb[:48]):
+        for _ in pipe.run(hb[:60]):
             pass
         torch.cuda.synchronize()
         h0 = time.perf_counter()
         n_img = sum(r["seq"].size(0) for r in pipe.run(hb))
         pcie_ms = (time.perf_counter() - h0) / (n_img / args.batch) * 1e3
-        pcie_note = f"{len(hb)} batches of {args.batch} through DecodePipeline (3 launches in flight x 8 batches, copy stream ahead, results on the host)"
+        pcie_note = f"{len(hb)} batches of {args.batch} through DecodePipeline (3 launches in flight x 10 batches, copy stream ahead, results on the host)"
         del pipe, pool, hb
         torch.cuda.empty_cache()
     traffic, tnote = None, "no PMC pass committed for this configuration"

@@ -356,8 +356,11 @@ class DecodePipeline:
     ``run(batches)`` is a generator: one dict per input batch, in input order, as soon as its launch is through -- while later launches are
     already in flight."""
 
-    def __init__(self, engine: "BofiEngine", *, in_flight: int = 3, batches_per_launch: int = 8, strict_q1: bool = True, stats: bool = True,
+    def __init__(self, engine: "BofiEngine", *, in_flight: Optional[int] = None, batches_per_launch: int = 10, strict_q1: bool = True, stats: bool = True,
                  keep_logprob: bool = False):
+        if in_flight is None:                                    # 3 launch streams + the copy stream = the runtime's default of 4 hardware queues; a process started
+            import os                                            # with GPU_MAX_HW_QUEUES >= 5 (tools/eval.py sets 8) has room for a fourth launch stream
+            in_flight = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 5 else 3
         if in_flight < 1 or batches_per_launch < 1:
             raise hip.BofiHipError("in_flight and batches_per_launch must be >= 1")
         self.root, self.nf, self.bpl = engine, int(in_flight), int(batches_per_launch)
