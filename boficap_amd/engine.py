@@ -369,10 +369,12 @@ class DecodePipeline:
         self._slots = None                                       # built for the first launch's shape
 
     def _build(self, rows_max: int):
-        streams = pick_concurrent_streams(self.nf, self.dev) if self.nf > 1 else [torch.cuda.Stream(self.dev)]
+        # launch streams AND the copy stream on hardware queues of their own, found by probing (two streams on one queue serialise: a copy stream that
+        # shares a queue with a launch stream costs a quarter of the throughput)
+        streams = pick_concurrent_streams(self.nf + 1, self.dev, candidates=24)
+        self.copy_stream = streams.pop() if len(streams) == self.nf + 1 else torch.cuda.Stream(self.dev)
         while len(streams) < self.nf:                            # (fewer hardware queues than launches in flight: the extra ones share)
             streams.append(torch.cuda.Stream(self.dev))
-        self.copy_stream = torch.cuda.Stream(self.dev)
         self._slots = []
         for k in range(self.nf):
             e = self.root.fork(max_batch=rows_max)
