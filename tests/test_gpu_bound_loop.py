@@ -176,3 +176,56 @@ def test_refresh_from_device_rebuilds_the_loop_kernels_operands(weight_cache):
     # (the two paths fold the LayerNorms with sums of different order: a few folded biases / bf16 weights of the ENCODER differ in their last bit, as in
     # test_device_side_weight_refresh_equals_a_fresh_load; stale operands would be off by whole units)
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 5e-3 and float((outs[0][1] - outs[1][1]).abs().max()) < 5e-3
+
+
+def test_decode_in_phases_equals_the_whole_decode(weight_cache):
+    """BOFI_FLAG_PHASE_ENCODE / _BOUND / _FILL: the three parts of a decode as separate calls on one engine (a pipelining caller's form) give the whole
+    decode's outputs bit for bit, eager and replayed from their own graphs."""
+    from boficap_amd import weights as W
+    cfg, sd, eng = _engine(weight_cache, 48, 36)
+    att = torch.from_numpy(W.synthetic_att_feats(48, 36, cfg.att_feat_size, seed=3)).cuda().to(torch.bfloat16)
+    whole = eng.decode_naic(att, q1_group=16)
+    ref = {k: v.clone() for k, v in whole.items() if torch.is_tensor(v)}
+    for graph in (False, True, True):
+        out = {k: (torch.zeros_like(v) if torch.is_tensor(v) else v) for k, v in whole.items()}
+        for ph in ("e", "b", "f"):
+            eng.decode_naic(att, q1_group=16, out=out, phases=ph, graph=graph)
+        torch.cuda.synchronize()
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
+            assert torch.equal(out[k], ref[k]), (graph, k)
+        assert torch.equal(out["seq_logprob"].nan_to_num(), ref["seq_logprob"].nan_to_num())
+    with pytest.raises(Exception):
+        eng.decode_naic(att, phases="x")
+
+
+@pytest.mark.parametrize("d_ff", [512, 1024])
+def test_loop_kernel_with_a_narrower_feed_forward(d_ff, weight_cache):
+    """The loop kernel serves d_ff = 512 ... 2048 in steps of 512 (chunks of w_1 per wavefront, K segments of w_2): a model with a narrower
+    feed-forward layer everywhere, its first bounding step against the float32 oracle."""
+    import dataclasses
+    import boficap_oracle as O
+    from boficap_amd import weights as W
+    from boficap_amd.config import FULL
+    from boficap_amd.engine import BofiEngine
+    cfg = dataclasses.replace(FULL, d_ff=d_ff, vocab_size=996)
+    sd = W.make_state_dict(cfg, seed=1, bound_preset=False)
+    B = 19
+    att_np = W.synthetic_att_feats(B, 36, cfg.att_feat_size, seed=8)
+    w = O.as_torch(sd)
+    L = cfg.seq_length + 2
+    ext = torch.zeros(B, L, dtype=torch.long); ext[:, 0] = cfg.len_idx
+    ext[:, 1:3] = 5; ext[:, 3:6] = 4
+    last = 6
+    tm = torch.zeros(B, L, L, dtype=torch.bool); tm[:, :, 0] = True
+    tm[:, 0, :last] = True                                      # row 0 sees the keys laid out so far (TransformerModel.py:1859-1867; only row 0 is read, SURVEY.md Q4)
+    with torch.no_grad():
+        memory, src_mask = O.memory_of(w, cfg, torch.from_numpy(att_np))
+        _, o_llp, _, o_slp = O.bound_step_na(w, cfg, ext, memory, src_mask, tm)
+    eng = BofiEngine(cfg, torch.bfloat16, max_batch=B, max_regions=36)
+    eng.load_state_dict(sd)
+    assert eng.bound_loop_active(36)
+    eng.encode(torch.from_numpy(att_np).cuda().to(torch.bfloat16))
+    llp, slp = eng.bound_step(ext.to(torch.int32).cuda(), torch.full((B,), last, dtype=torch.int32, device="cuda"), 36)
+    e_len, e_syn = float((llp.cpu() - o_llp).abs().max()), float((slp.cpu() - o_slp).abs().max())
+    print(f"d_ff {d_ff}: loop kernel vs the float32 oracle, bound step on a three-slot layout: |dlogp| len {e_len:.2e} syn {e_syn:.2e}")
+    assert e_len < 5e-2 and e_syn < 5e-2, (e_len, e_syn)     # (uncalibrated heads: all 20 / 10 classes live; bf16 encoder in front)
