@@ -1,5 +1,5 @@
 // bf16 attention core for the short sequences of the bound+fill path -- the throughput kernel
-// (attn.hip is the generic one: f32 engine, > 64 keys).  Same contract as attn.hip:
+// (attn.hip is the generic one: f32 engine, > 128 keys).  Same contract as attn.hip:
 //   softmax(q k^T / 8, key-prefix mask per query row) v,  d_k = 64,  NaN for a fully masked row
 // (reference attention() captioning/models/TransformerModel.py:1421-1432).
 //
@@ -212,7 +212,7 @@ static void launch_ab(const AttnParamsB& p, hipStream_t st) {
 
 // returns -1 when the call is not eligible (then attn.hip handles it)
 int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
-    if (a.dtype != BOFI_DT_BF16 || a.Lk > 64 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
+    if (a.dtype != BOFI_DT_BF16 || a.Lk > 128 || a.ldo % 4 || ((uintptr_t)a.out % 8)) return -1;
     AttnParamsB p;
     p.q = (const bf16_t*)a.q; p.ldq = a.ldq; p.k = (const bf16_t*)a.k; p.ldk = a.ldk; p.v = (const bf16_t*)a.v; p.ldv = a.ldv;
     p.out = (bf16_t*)a.out; p.ldo = a.ldo; p.B = a.B; p.H = a.H; p.Lq = a.Lq; p.Lk = a.Lk;
@@ -223,9 +223,15 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st) {
     if ((a.q_start != nullptr) != (a.q_count != nullptr)) return BOFI_ERR_ARG;
     p.q_start = a.q_start; p.q_count = a.q_count; p.k_ragged = a.k_ragged; p.q_rows = a.q_rows;
     if (a.q_rows > 0 && (a.ldo % 8 || ((uintptr_t)a.out % 16))) return BOFI_ERR_ARG;
-    const int nkt = a.Lk <= 32 ? 2 : 4;
-    const int nqt = a.Lq <= 16 ? 1 : (a.Lq <= 32 ? 2 : 3);
+    // 65 .. 128 keys (round 5: real bottom-up features have up to 100 regions, captioning/utils/opts.py:84): six or eight key tiles, at most two query
+    // tiles per wavefront (the scores alone are 8 x 2 accumulator tiles); longer query blocks go over blockIdx.y
+    const int nkt = a.Lk <= 32 ? 2 : a.Lk <= 64 ? 4 : a.Lk <= 96 ? 6 : 8;
+    const int nqt = a.Lq <= 16 ? 1 : ((a.Lq <= 32 || nkt > 4) ? 2 : 3);
     switch (nqt * 10 + nkt) {
+        case 16: launch_ab<1, 6>(p, st); break;
+        case 18: launch_ab<1, 8>(p, st); break;
+        case 26: launch_ab<2, 6>(p, st); break;
+        case 28: launch_ab<2, 8>(p, st); break;
         case 12: launch_ab<1, 2>(p, st); break;
         case 14: launch_ab<1, 4>(p, st); break;
         case 22: launch_ab<2, 2>(p, st); break;

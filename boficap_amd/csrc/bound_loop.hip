@@ -91,7 +91,7 @@ __device__ __forceinline__ void bl_seg(const u32x4* cur, const u32x4* nxt, int l
     }
 }
 
-template <int NTT>      // the cross-attention's row batching: 5 = at most 36 regions (every BASELINE config), 8 = at most 64
+template <int NTT>      // the cross-attention's form: 5 = at most 36 regions (every BASELINE config), 8 = at most 64 (scores of an image in registers), 0 = any count (online softmax)
 __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     float* Y = reinterpret_cast<float*>(sm + BL_OFF_Y);
@@ -301,6 +301,77 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         // in the lane (the octet's lanes hold the same numbers), P.V accumulates in the lane: no cross-lane traffic besides the octet sums, no LDS.
         // Rows go through two register buffers of BR rows, NB batches per pass (NB even: the buffers alternate across the K pass, the V pass and
         // the next image without a drain); every load is unconditional (rows past R: the last row again, weighted 0) so that the waits count exactly.
+        if constexpr (NTT == 0) {
+            // any region count (real bottom-up features have up to 100, captioning/utils/opts.py:84): K and V rows in batches of 6 through two register buffers, an
+            // ONLINE softmax per image (running maximum m and sum l, the accumulated P.V rescaled when the maximum moves): the scores of a whole image need not fit
+            // the registers.  Same lane layout and load discipline as the fixed forms below.
+            asm volatile("" : "+v"(lane));
+            constexpr int BR = 6;
+            const bf16_t* kbase = a.k + lane * 8;
+            const bf16_t* vbase = a.v + lane * 8;
+            u32x4 kb[2][BR], vb[2][BR];
+            const int nb = (R + BR - 1) / BR;
+            auto issue = [&](u32x4 (&kk)[BR], u32x4 (&vv)[BR], int bi, int j0) {
+                const size_t base = (size_t)bi * R * a.ldkv;
+#pragma unroll
+                for (int r = 0; r < BR; ++r) kk[r] = *reinterpret_cast<const u32x4*>(kbase + base + (size_t)min(j0 + r, R - 1) * a.ldkv);
+#pragma unroll
+                for (int r = 0; r < BR; ++r) vv[r] = *reinterpret_cast<const u32x4*>(vbase + base + (size_t)min(j0 + r, R - 1) * a.ldkv);
+            };
+            const int n_act = s_act[BL_G];
+            if (wave < n_act) issue(kb[0], vb[0], min(b0 + s_act[wave], B - 1), 0);
+#pragma unroll 1
+            for (int idx = wave; idx < n_act; idx += 8) {
+                const int i = s_act[idx], bi = min(b0 + i, B - 1), kl = s_attl[i];
+                const int bi_next = min(b0 + s_act[min(idx + 8, n_act - 1)], B - 1);
+                const float4 qa = *reinterpret_cast<const float4*>(Q + i * BL_YP + lane * 8);
+                const float4 qb = *reinterpret_cast<const float4*>(Q + i * BL_YP + lane * 8 + 4);
+                float m = -INFINITY, l = 0.f;
+                float o[8];
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) o[e8] = 0.f;
+                auto compute = [&](const u32x4 (&kk)[BR], const u32x4 (&vv)[BR], int j0) {
+                    float sc[BR];
+                    float mb = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) {
+                        const u32x4 kv = kk[r];
+                        float d = qa.x * bl_lo(kv[0]);
+                        d = fmaf(qa.y, bl_hi(kv[0]), d); d = fmaf(qa.z, bl_lo(kv[1]), d); d = fmaf(qa.w, bl_hi(kv[1]), d);
+                        d = fmaf(qb.x, bl_lo(kv[2]), d); d = fmaf(qb.y, bl_hi(kv[2]), d); d = fmaf(qb.z, bl_lo(kv[3]), d); d = fmaf(qb.w, bl_hi(kv[3]), d);
+                        d = oct_sum(d) * 0.125f;
+                        sc[r] = (j0 + r < kl) ? d : -INFINITY;           // (rows past R were loaded as the last row: j0 + r >= R >= kl masks them)
+                        mb = fmaxf(mb, sc[r]);
+                    }
+                    const float m_new = fmaxf(m, mb);
+                    const float scale = (m_new == -INFINITY) ? 1.f : expf(m - m_new);      // nothing seen yet: nothing to rescale
+                    l *= scale;
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) o[e8] *= scale;
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) {
+                        const float p = (j0 + r < kl) ? expf(sc[r] - m_new) : 0.f;
+                        l += p;
+                        const u32x4 v = vv[r];
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) { o[2 * e4] = fmaf(p, bl_lo(v[e4]), o[2 * e4]); o[2 * e4 + 1] = fmaf(p, bl_hi(v[e4]), o[2 * e4 + 1]); }
+                    }
+                    m = m_new;
+                };
+#pragma unroll 1
+                for (int bt = 0; bt < nb; bt += 2) {
+                    issue(kb[1], vb[1], bi, min(bt + 1, nb - 1) * BR);          // (an odd count: the last batch again, not consumed)
+                    compute(kb[0], vb[0], bt * BR);
+                    const bool more = bt + 2 < nb;
+                    issue(kb[0], vb[0], more ? bi : bi_next, more ? (bt + 2) * BR : 0);      // the next pair's first batch, or the next image's
+                    if (bt + 1 < nb) compute(kb[1], vb[1], (bt + 1) * BR);
+                }
+                const float inv = 1.0f / l;                                   // no visible region: 0 * (1 / 0) = NaN, as softmax over an all-masked row of -inf
+                u32x4 w;
+                w[0] = bl_pack(o[0] * inv, o[1] * inv); w[1] = bl_pack(o[2] * inv, o[3] * inv); w[2] = bl_pack(o[4] * inv, o[5] * inv); w[3] = bl_pack(o[6] * inv, o[7] * inv);
+                *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = w;
+            }
+        } else
         {
             asm volatile("" : "+v"(lane));
             constexpr int BR = NTT == 5 ? 9 : 8, NB = NTT == 5 ? 4 : 8, RMAX = BR * NB;      // 36 rows (every BASELINE config) or 64
@@ -529,7 +600,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 }
 
 int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
-    if (a.B < 1 || a.R < 1 || a.R > 64 || a.L < 3 || a.L > BL_LMAX || a.S != a.L - 2 || a.hh < 1 || a.hh > 128 || 2 * a.hh > 256 || a.dff < 512 || a.dff > 2048 ||
+    if (a.B < 1 || a.R < 1 || a.R > 128 || a.L < 3 || a.L > BL_LMAX || a.S != a.L - 2 || a.hh < 1 || a.hh > 128 || 2 * a.hh > 256 || a.dff < 512 || a.dff > 2048 ||
         a.dff % 512 || a.ldkv % 8 || a.max_iters < 1)
         return BOFI_ERR_ARG;
     if (!a.wo_self || !a.x0b || !a.wq_src || !a.cq || !a.wo_src || !a.bo_src || !a.w1 || !a.c1 || !a.w2 || !a.b2 || !a.wh || !a.ch || !a.len_w2 || !a.len_b2 ||
@@ -540,14 +611,16 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(bound_loop_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, BL_SMEM) != hipSuccess)
             return BOFI_ERR_HIP;
         attr_set = true;
     }
     BoundLoopArgs v = a;
     v.dbg = BOFI_ENV_INT("BOFI_BL_DBG", 0);
     if (a.R <= 36) hipLaunchKernelGGL(bound_loop_kernel<5>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
-    else hipLaunchKernelGGL(bound_loop_kernel<8>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
+    else if (a.R <= 64) hipLaunchKernelGGL(bound_loop_kernel<8>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
+    else hipLaunchKernelGGL(bound_loop_kernel<0>, dim3((a.B + BL_G - 1) / BL_G), dim3(512), BL_SMEM, s, v);
     BOFI_CHECK_LAUNCH();
     // FLOP tally: the GEMM work of the iterations is data-dependent; counted as skippable work of max_iters iterations like the launches it replaces
     g_gemm_flops_skippable += (double)a.max_iters * a.B * (2.0 * 3 * 512 * 512 + 4.0 * 512 * a.dff);

@@ -361,7 +361,7 @@ struct bofi_engine {
     static int bound_loop_knob() { return BOFI_ENV_INT("BOFI_BOUND_LOOP", 1); }
     bool bound_loop_ok(int R) const {
         const int k = bound_loop_knob();
-        return loop_ready && loop_config_ok() && R <= 64 && k != 0 && (k == 2 || in_flight != 1);
+        return loop_ready && loop_config_ok() && R <= 128 && k != 0 && (k == 2 || in_flight != 1);
     }
     // update != 0: the whole loop on the engine's slot state (after launch_bound_init); update == 0: one iteration on a given layout, log-probabilities out
     int bound_loop(int B, int R, const int* att_len, const int* ext_syn_in, const int* last_in, int update, float* len_logp, float* syn_logp, hipStream_t s) {

@@ -316,7 +316,7 @@ int bofi_engine_set_decodes_in_flight(bofi_engine_t* e, int n);
 /* 1 when a bofi_engine_decode_naic of R regions per image would run core_NAIC's bounding loop (TransformerModel.py:1833-1869) as the persistent
  * kernel of round 5 -- one workgroup per 16 images runs every iteration (row-0 self-attention, cross-attention, feed-forward, heads, slot bookkeeping)
  * and leaves when its images are finished; fp16 operands derived from the float32 parameters -- under the engine's current decodes-in-flight hint:
- * bf16 engine at the reference's width (d_model 512, 8 heads, d_ff <= 2048 a multiple of 512, seq_length <= 22, N_len = 1), R <= 64, and the
+ * bf16 engine at the reference's width (d_model 512, 8 heads, d_ff <= 2048 a multiple of 512, seq_length <= 22, N_len = 1), R <= 128, and the
  * hint is not 1 (a decode that runs alone keeps the five launches per iteration: shorter latency); environment knob BOFI_BOUND_LOOP: 0 = never,
  * 2 = whatever the hint (read again by bofi_reload_env).  The bound-iteration cap (bofi_engine_set_bound_iter_cap) does not apply to that kernel.  0 otherwise. */
 int bofi_engine_bound_loop_active(bofi_engine_t* e, int R);

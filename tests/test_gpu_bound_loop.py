@@ -60,7 +60,7 @@ def _host_replay(eng, cfg, B, R, att_len):
     return pn, plen, psyn, iters
 
 
-@pytest.mark.parametrize("B,R,ragged", [(37, 36, True), (64, 36, False), (21, 50, True)])
+@pytest.mark.parametrize("B,R,ragged", [(37, 36, True), (64, 36, False), (21, 50, True), (19, 100, True), (5, 67, False)])
 def test_loop_kernel_bookkeeping_equals_a_host_replay(B, R, ragged, weight_cache, monkeypatch):
     from boficap_amd import hip as H
     from boficap_amd import weights as W
@@ -133,7 +133,7 @@ def test_kernel_choice_follows_hint_and_knob(weight_cache, monkeypatch):
     from boficap_amd import hip as H
     from boficap_amd.engine import BofiEngine
     cfg, sd, eng = _engine(weight_cache, 16, 36)
-    assert eng.bound_loop_active(36) and not eng.bound_loop_active(65)
+    assert eng.bound_loop_active(36) and eng.bound_loop_active(100) and not eng.bound_loop_active(129)
     eng.set_decodes_in_flight(1)                               # a decode that runs alone keeps the five launches per iteration (shorter chain)
     assert not eng.bound_loop_active(36)
     eng.set_decodes_in_flight(4)

@@ -105,7 +105,7 @@ def _attention_ref(q, k, v, klen, h):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("B,h,Lq,Lk", [(5, 8, 36, 36), (3, 8, 20, 20), (4, 2, 22, 22), (6, 8, 20, 36), (7, 8, 1, 36), (2, 8, 100, 100), (2, 4, 20, 90)])
+@pytest.mark.parametrize("B,h,Lq,Lk", [(5, 8, 36, 36), (3, 8, 20, 20), (4, 2, 22, 22), (6, 8, 20, 36), (7, 8, 1, 36), (2, 8, 100, 100), (2, 4, 20, 90), (3, 8, 1, 100), (2, 8, 40, 128), (2, 8, 33, 70)])
 def test_attention(H, dt, B, h, Lq, Lk):
     g = _rng(B * 100 + Lq + Lk)
     d = h * 64
