@@ -901,7 +901,7 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
 }
 
 // Replays the captured launch sequence stored under `key`, capturing it first (through `enqueue`, on the engine's capture stream)
-// when the key is new.  At most 8 captures are kept per engine.
+// when the key is new.  At most 16 captures are kept per engine (a pipeline over ragged loader batches holds two inputs x a few region buckets).
 template <typename F>
 static int run_graphed(bofi_engine* e, const std::vector<uintptr_t>& key, hipStream_t s, F enqueue) {
     for (auto& g : e->graphs)
@@ -917,7 +917,7 @@ static int run_graphed(bofi_engine* e, const std::vector<uintptr_t>& key, hipStr
     if (rc != BOFI_OK) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
     if (ee != hipSuccess) return fail(BOFI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
     ENG_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-    if (e->graphs.size() >= 8) {                       // small cache: drop the oldest capture
+    if (e->graphs.size() >= 16) {                      // small cache: drop the oldest capture
         ENG_HIP(hipDeviceSynchronize());               // (a launch of it may still be in flight on any of the caller's streams: rare path, wait it out)
         (void)hipGraphExecDestroy(e->graphs.front().exec);
         (void)hipGraphDestroy(e->graphs.front().graph);

@@ -357,7 +357,7 @@ class DecodePipeline:
     already in flight."""
 
     def __init__(self, engine: "BofiEngine", *, in_flight: Optional[int] = None, batches_per_launch: int = 10, strict_q1: bool = True, stats: bool = True,
-                 keep_logprob: bool = False):
+                 keep_logprob: bool = False, region_buckets=(36, 48, 64, 80, 100, 128)):
         if in_flight is None:                                    # 3 launch streams + the copy stream = the runtime's default of 4 hardware queues; a process started
             import os                                            # with GPU_MAX_HW_QUEUES >= 5 (tools/eval.py sets 8) has room for a fourth launch stream
             in_flight = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 5 else 3
@@ -366,6 +366,9 @@ class DecodePipeline:
         self.root, self.nf, self.bpl = engine, int(in_flight), int(batches_per_launch)
         self.strict_q1, self.stats, self.keep_logprob = strict_q1, stats, keep_logprob
         self.dev = engine.device
+        # ragged loader batches (att_masks given: every batch is clipped to ITS longest image, AttModel.py:113-120) are padded to the next of a few region counts, so that
+        # consecutive batches share launches and captured graphs; the padding rows are masked by the region counts like any short image's
+        self.buckets = sorted({int(r) for r in region_buckets if int(r) <= engine.max_regions} | {int(engine.max_regions)})
         self._slots = None                                       # built for the first launch's shape
 
     def _build(self, rows_max: int):
@@ -379,7 +382,7 @@ class DecodePipeline:
         for k in range(self.nf):
             e = self.root.fork(max_batch=rows_max)
             e.set_decodes_in_flight(self.nf)
-            self._slots.append(dict(eng=e, stream=streams[k], feats=[None, None], lens=[None, None], out=None, host=None, copied=[torch.cuda.Event(), torch.cuda.Event()],
+            self._slots.append(dict(eng=e, stream=streams[k], feats=[{}, {}], lens=[None, None], out=None, host=None, copied=[torch.cuda.Event(), torch.cuda.Event()],
                                     done=torch.cuda.Event(), busy=False))
         self.rows_max = rows_max
 
@@ -387,10 +390,16 @@ class DecodePipeline:
     def _as_host_or_device(x):
         return torch.from_numpy(x) if not torch.is_tensor(x) else x
 
+    def _bucket(self, r: int) -> int:
+        for b in self.buckets:
+            if b >= r:
+                return b
+        raise hip.BofiHipError(f"{r} regions exceed the engine's max_regions={self.root.max_regions}")
+
     def run(self, batches):
         """``batches``: iterable of ``att_feats`` or ``(att_feats, att_len)``: [b, R, F] tensors / arrays in the engine's compute dtype or float32, on
-        the host (pinned: the copy is asynchronous) or the device; ``att_len`` int32 [b] region counts or None."""
-        pending = []                                             # launches in flight: (slot, [batch sizes], has_len)
+        the host (pinned: the copy is asynchronous) or the device; ``att_len`` int32 [b] region counts or None (every image has R regions)."""
+        pending = []                                             # launches in flight: (slot, [batch sizes])
         group, gkey = [], None
         j = 0
 
@@ -401,7 +410,7 @@ class DecodePipeline:
             k, p = j % self.nf, (j // self.nf) % 2
             if j >= self.nf:
                 yield from self._finish(pending.pop(0))
-            self._launch(k, p, group)
+            self._launch(k, p, group, gkey)
             pending.append((k, [g[0].shape[0] for g in group]))
             j += 1
             group = []
@@ -410,7 +419,8 @@ class DecodePipeline:
             att, lens = item if isinstance(item, (tuple, list)) else (item, None)
             att = self._as_host_or_device(att)
             lens = None if lens is None else self._as_host_or_device(lens).to(torch.int32)
-            key = (tuple(att.shape), att.dtype, lens is None)
+            b, r = att.shape[0], att.shape[1]
+            key = (b, r if lens is None else self._bucket(r), att.shape[2], att.dtype, lens is None)
             if group and (key != gkey or len(group) >= self.bpl):
                 yield from flush()
             group.append((att, lens))
@@ -419,27 +429,27 @@ class DecodePipeline:
         while pending:
             yield from self._finish(pending.pop(0))
 
-    def _launch(self, k, p, group):
-        b, R, F = group[0][0].shape
-        nb, rows = len(group), len(group) * group[0][0].shape[0]
+    def _launch(self, k, p, group, key):
+        b, R, F, dt, no_len = key
+        nb, rows = len(group), len(group) * b
         if self._slots is None:
             self._build(max(rows, self.bpl * b))
         if rows > self.rows_max:
             raise hip.BofiHipError(f"a launch of {rows} images exceeds the pipeline's {self.rows_max} (first batch x batches_per_launch)")
         sl = self._slots[k]
         e, st = sl["eng"], sl["stream"]
-        dt = group[0][0].dtype
-        if sl["feats"][p] is None or sl["feats"][p].shape[1:] != (R, F) or sl["feats"][p].dtype != dt:
-            sl["feats"][p] = torch.empty(self.rows_max, R, F, dtype=dt, device=self.dev)
-        has_len = group[0][1] is not None
+        buf = sl["feats"][p].get((R, F, dt))
+        if buf is None:
+            buf = sl["feats"][p][(R, F, dt)] = torch.zeros(self.rows_max, R, F, dtype=dt, device=self.dev)
+        has_len = not no_len
         if has_len and sl["lens"][p] is None:
             sl["lens"][p] = torch.empty(self.rows_max, dtype=torch.int32, device=self.dev)
-        feats, lens = sl["feats"][p][:rows], (sl["lens"][p][:rows] if has_len else None)
+        feats, lens = buf[:rows], (sl["lens"][p][:rows] if has_len else None)
         cs = self.copy_stream
         with torch.cuda.stream(cs):
             cs.wait_event(sl["done"])                            # the launch that last read this slot's buffers is through (it was finished before this one is issued)
             for i, (att, ln) in enumerate(group):
-                feats[i * b:(i + 1) * b].copy_(att, non_blocking=True)
+                feats[i * b:(i + 1) * b, :att.shape[1]].copy_(att, non_blocking=True)      # (a batch clipped below the bucket leaves padding rows: masked by its counts)
                 if has_len:
                     lens[i * b:(i + 1) * b].copy_(ln, non_blocking=True)
             sl["copied"][p].record(cs)

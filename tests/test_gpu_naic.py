@@ -688,6 +688,14 @@ def test_decode_many_equals_one_decode_per_batch(weight_cache, monkeypatch):
     masks = torch.ones(16, 36)
     masks[3, 20:] = 0; masks[9, 7:] = 0
     items = [b if i != 2 else (b, masks) for i, b in enumerate(batches)]          # one ragged batch in the middle (breaks the coalescing there)
+    # ... and two ragged batches CLIPPED to their longest image as the loader's consumer does (AttModel.clip_att): 30 and 33 regions, padded by the
+    # pipeline to one region bucket (36) so that they share a launch; the padding is masked by the counts
+    clip_masks = []
+    for i, rmax in ((4, 30), (5, 33)):
+        m = torch.ones(16, rmax)
+        m[1, rmax // 2:] = 0; m[7, 5:] = 0
+        clip_masks.append(m)
+        items[i] = (batches[i][:, :rmax].contiguous().pin_memory(), m)
     got = list(model.decode_many(items, batches_per_launch=3, in_flight=2, keep_logprob=True))
     assert len(got) == len(batches)
     ref = BofiEngine(cfg, torch.bfloat16, max_batch=16, max_regions=36)
@@ -695,6 +703,9 @@ def test_decode_many_equals_one_decode_per_batch(weight_cache, monkeypatch):
     ref.set_decodes_in_flight(2)
     for i, (b, r) in enumerate(zip(batches, got)):
         lens = masks.sum(1).to(torch.int32).cuda() if i == 2 else None
+        if i in (4, 5):                                          # the clipped batch decoded alone at ITS region count
+            m = clip_masks[i - 4]
+            b, lens = b[:, :m.size(1)].contiguous(), m.sum(1).to(torch.int32).cuda()
         w = ref.decode_naic(b.cuda(), lens)
         ent, ppl = ref.entropy_perplexity(w)
         for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
