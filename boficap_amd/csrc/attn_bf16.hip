@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64) void attn_bf16_kernel(AttnParamsB p) {
         for (int s = 0; s < 2; ++s) ak[kj][s] = r < Lk ? *reinterpret_cast<const bf16x8*>(kg + (size_t)r * p.ldk + s * 32 + g * 8) : zero8;
     }
 #pragma unroll
-    for (int c = lane; c < NKT * 16 * 8; c += 64) {
+    for (int it = 0; it < NKT * 2; ++it) {             // NKT * 16 rows x 8 sixteen-byte pieces, 64 per pass
+        const int c = lane + it * 64;
         const int r = c >> 3, ch = c & 7;
         *reinterpret_cast<u32x4*>(&sv[r * VROW + ch * 8]) = r < Lk ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * p.ldv + ch * 8) : zero4;
     }
