@@ -438,15 +438,16 @@ class DecodePipeline:
             raise hip.BofiHipError(f"a launch of {rows} images exceeds the pipeline's {self.rows_max} (first batch x batches_per_launch)")
         sl = self._slots[k]
         e, st = sl["eng"], sl["stream"]
-        buf = sl["feats"][p].get((R, F, dt))
-        if buf is None:
-            buf = sl["feats"][p][(R, F, dt)] = torch.zeros(self.rows_max, R, F, dtype=dt, device=self.dev)
         has_len = not no_len
-        if has_len and sl["lens"][p] is None:
-            sl["lens"][p] = torch.empty(self.rows_max, dtype=torch.int32, device=self.dev)
-        feats, lens = buf[:rows], (sl["lens"][p][:rows] if has_len else None)
         cs = self.copy_stream
         with torch.cuda.stream(cs):
+            # (the buffers are created -- and zero-filled -- ON the copy stream: a fill enqueued on the caller's stream would race the copies below)
+            buf = sl["feats"][p].get((R, F, dt))
+            if buf is None:
+                buf = sl["feats"][p][(R, F, dt)] = torch.zeros(self.rows_max, R, F, dtype=dt, device=self.dev)
+            if has_len and sl["lens"][p] is None:
+                sl["lens"][p] = torch.zeros(self.rows_max, dtype=torch.int32, device=self.dev)
+            feats, lens = buf[:rows], (sl["lens"][p][:rows] if has_len else None)
             cs.wait_event(sl["done"])                            # the launch that last read this slot's buffers is through (it was finished before this one is issued)
             for i, (att, ln) in enumerate(group):
                 feats[i * b:(i + 1) * b, :att.shape[1]].copy_(att, non_blocking=True)      # (a batch clipped below the bucket leaves padding rows: masked by its counts)
