@@ -703,7 +703,8 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                 raise RuntimeError("hipExtStreamCreateWithCUMask failed")
             streams.append(torch.cuda.ExternalStream(h.value, device=dev))
     else:
-        streams = pick_concurrent_streams(args.inflight, dev) if args.inflight > 1 else [torch.cuda.current_stream(dev)]
+        prio = [int(v) for v in os.environ.get("BOFI_BENCH_STREAM_PRIO", "").split(",") if v.strip()] or None      # experiment: stream priorities (-1 = high), e.g. "-1,0"
+        streams = pick_concurrent_streams(args.inflight, dev, priorities=prio) if args.inflight > 1 else [torch.cuda.current_stream(dev)]
         if args.inflight > 1 and len(streams) < args.inflight:                       # an unlucky draw of hardware queues: look among more candidates once
             more = pick_concurrent_streams(args.inflight, dev, candidates=48)
             streams = more if len(more) > len(streams) else streams

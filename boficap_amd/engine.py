@@ -15,7 +15,7 @@ from . import hip
 from .config import BofiConfig
 
 
-def pick_concurrent_streams(n: int, device=None, candidates: int = 16, spin_cycles: int = 400_000):
+def pick_concurrent_streams(n: int, device=None, candidates: int = 16, spin_cycles: int = 400_000, priorities=None):
     """``n`` HIP streams that really run side by side.
 
     ROCm multiplexes streams onto a few hardware queues and two streams on one queue serialise; which
@@ -25,7 +25,8 @@ def pick_concurrent_streams(n: int, device=None, candidates: int = 16, spin_cycl
     import time
     dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     with torch.cuda.device(dev):
-        cands = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+        # (priorities: experiment -- candidate i is created with priorities[i % len]; 0 = default, -1 = high)
+        cands = [torch.cuda.Stream(device=dev) if not priorities else torch.cuda.Stream(device=dev, priority=int(priorities[i % len(priorities)])) for i in range(candidates)]
 
         def span(streams):
             torch.cuda.synchronize(dev)
@@ -346,9 +347,11 @@ class DecodePipeline:
     eval_utils.py:456-460 under tools/eval.py:123).
 
       * ``in_flight`` engine forks on streams that provably overlap, one launch each (default 3: with the copy stream that is the runtime's four
-        hardware queues -- a fourth launch stream would share a queue with the copies: 161 against 210 k images/s, profiles/r05_decode_many.txt);
-      * ``batches_per_launch`` consecutive loader batches of one shape ride ONE launch (dynamic batching: quirk Q1 stays per batch, so every
-        batch's result is its own decode's -- bit for bit under the same kernel family and hint);
+        hardware queues -- a copy stream that shares a queue with a launch stream: 161 against 210 k images/s, profiles/r05_decode_many.txt; 4 when the
+        process was started with GPU_MAX_HW_QUEUES >= 5).  Launch streams and the copy stream are found by probing for queues of their own;
+      * ``batches_per_launch`` (default 10) consecutive loader batches of one shape ride ONE launch (dynamic batching: quirk Q1 stays per batch, so every
+        batch's result is its own decode's -- bit for bit under the same kernel family and hint); ragged batches (region counts given) are padded to the
+        next of ``region_buckets`` so that differently clipped batches share launches and captured graphs (the padding is masked by the counts);
       * features are double-buffered per fork and copied from (pinned) host memory on a copy stream that runs ahead of the launches; the small
         outputs (ids, slot layout, per-image entropy / perplexity) come back through pinned buffers behind an event, the 48.6 MB of log-probs per
         batch stay on the device unless asked for.
@@ -383,7 +386,7 @@ class DecodePipeline:
             e = self.root.fork(max_batch=rows_max)
             e.set_decodes_in_flight(self.nf)
             self._slots.append(dict(eng=e, stream=streams[k], feats=[{}, {}], lens=[None, None], out=None, host=None, copied=[torch.cuda.Event(), torch.cuda.Event()],
-                                    done=torch.cuda.Event(), busy=False))
+                                    done=torch.cuda.Event()))
         self.rows_max = rows_max
 
     @staticmethod
