@@ -913,28 +913,43 @@ class XETrainer:
             prep.update(prep_na)
             sc_s = torch.as_tensor(s_saic, dtype=torch.float32).to(dev)
             sc_n = torch.as_tensor(s_naic, dtype=torch.float32).to(dev)
-            lp_saic, lp_naic = rows_of(prep)                              # the gradient pass: the same rows, with the tape
-            with torch.no_grad():
-                g_s = (lp_saic.detach().float().gather(2, seq_s[..., None]).squeeze(2) - drawn_s)[mask_s]
-                g_n = (lp_naic.detach().float().gather(2, seq_n[..., None]).squeeze(2) - drawn_n)[mask_n]
-                gap = max(float(g_s.abs().max()) if g_s.numel() else 0.0, float(g_n.abs().max()) if g_n.numel() else 0.0)
-            l1, r1 = xe.new_self_critical(lp_saic, seq_s, sc_s, sample_n)
-            l2, r2 = xe.new_self_critical(lp_naic, seq_n, sc_n, sample_n)
-            loss = l1 + l2
-            if self.rl_kl:
-                loss = loss + xe.rl_kl_term(lp_naic, lp_saic, seq_s)
-            loss.backward()
-            xe.flush_weight_grads()
+            replayed = self.graph and att_masks is None and not self._capturing()
+            if not replayed:
+                lp_saic, lp_naic = rows_of(prep)                          # the gradient pass: the same rows, with the tape
+                with torch.no_grad():
+                    g_s = (lp_saic.detach().float().gather(2, seq_s[..., None]).squeeze(2) - drawn_s)[mask_s]
+                    g_n = (lp_naic.detach().float().gather(2, seq_n[..., None]).squeeze(2) - drawn_n)[mask_n]
+                    gap = max(float(g_s.abs().max()) if g_s.numel() else 0.0, float(g_n.abs().max()) if g_n.numel() else 0.0)
+                l1, r1 = xe.new_self_critical(lp_saic, seq_s, sc_s, sample_n)
+                l2, r2 = xe.new_self_critical(lp_naic, seq_n, sc_n, sample_n)
+                loss = l1 + l2
+                if self.rl_kl:
+                    loss = loss + xe.rl_kl_term(lp_naic, lp_saic, seq_s)
+                loss.backward()
+                xe.flush_weight_grads()
+                loss, m1, m2 = loss.detach(), r1.mean(), r2.mean()
         finally:
             xe._DEFER["list"] = None
             if armed:
                 xe._WEIGHTS["provider"] = None
                 self.ops.end_step()
+        if replayed:
+            # the gradient pass as the captured graph of the fast form (the same forward under the same seed and dropout masks + new_self_critical + backward):
+            # its log-probs at the drawn tokens come back in the graph's "picked" buffers
+            b = {"att_feats": att_feats, "seq_saic": seq_s, "seq_naic": seq_n, "sc_saic": sc_s, "sc_naic": sc_n,
+                 "picked_saic": torch.zeros(N, S, device=dev), "picked_naic": torch.zeros(N, S, device=dev)}
+            b.update(prep)
+            loss, m1, m2 = self._rl_replay(b, sample_n)
+            st = self._rl_static
+            with torch.no_grad():
+                g_s, g_n = (st["picked_saic"] - drawn_s)[mask_s], (st["picked_naic"] - drawn_n)[mask_n]
+                gap = max(float(g_s.abs().max()) if g_s.numel() else 0.0, float(g_n.abs().max()) if g_n.numel() else 0.0)
         self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean(),
                          "active_share": min(S, int(out["phrase_num"].max()) + 1) / S, "reference_gap": gap, "training_forwards": passes + 1,
+                         "gradient_pass_replayed": bool(replayed),
                          "seq_saic": seq_s, "seq_naic": seq_n, "phrase_length_saic": out["phrase_length"], "phrase_syn_saic": out["phrase_syn"]}
         self.reduce_and_step()
-        return loss.detach(), r1.mean(), r2.mean()
+        return loss, m1, m2
 
     def _rl_forward_backward(self, b, att_masks, sample_n):
         """zero-grad, differentiable re-forward of the sampled captions, new_self_critical for both modes, backward (tensors in,
@@ -957,6 +972,10 @@ class XETrainer:
                                                             training=model.training,
                                                             seed=base if step_word is not None else base + self._fwd_calls,
                                                             compute_dtype=model.train_dtype, step_word=step_word)
+            if "picked_saic" in b:                             # (the reference-estimator step checks the drawn rows against these: the gradient pass's own log-probs at the drawn tokens)
+                with torch.no_grad():
+                    b["picked_saic"].copy_(lp_saic.detach().float().gather(2, b["seq_saic"][..., None]).squeeze(2))
+                    b["picked_naic"].copy_(lp_naic.detach().float().gather(2, b["seq_naic"][..., None]).squeeze(2))
             l1, r1 = xe.new_self_critical(lp_saic, b["seq_saic"], b["sc_saic"], sample_n)
             l2, r2 = xe.new_self_critical(lp_naic, b["seq_naic"], b["sc_naic"], sample_n)
             loss = l1 + l2
@@ -991,6 +1010,7 @@ class XETrainer:
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs], non_blocking=True)
         g.replay()
+        self._rl_static = static                               # (the graph's input / output buffers: "picked_*" are read from here)
         return out
 
     # ------------------------------------------------------------------ checkpoint (optimizer.pth of misc.py:87-102)

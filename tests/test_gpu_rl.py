@@ -337,18 +337,19 @@ def test_capped_semi_autoregressive_loop_with_its_continuation_equals_the_whole_
     assert model.saic_cap() == (low if low < S else None) and low <= want
 
 
-def test_reference_estimator_draws_every_token_from_the_gradient_pass(weight_cache, manifest):
+@pytest.mark.parametrize("graph", [False, True])
+def test_reference_estimator_draws_every_token_from_the_gradient_pass(graph, weight_cache, manifest):
     """opt.bofi_rl_reference_estimator: the reference samples in train mode and differentiates that same pass (loss_wrapper.py:193-209).  Here every
     token of both branches is drawn from the training forward's rows under the step's dropout masks, phrase by phrase, and the gradient pass is that
     forward once more with the tape: its rows at the drawn tokens ARE the rows they were drawn from (gap 0), and they are not the inference engine's
-    dropout-free rows."""
+    dropout-free rows.  graph: the gradient pass replayed from a captured hipGraph (device-side step word for the masks) -- the same rows still."""
     from boficap_amd import xe
     from boficap_amd.trainer import XETrainer
     cfg, sd, model = _model(weight_cache, manifest)
     opt = cfg.to_opt()
     opt.noamopt, opt.learning_rate = False, 1e-4
     model.opt.bofi_rl_reference_estimator = True
-    tr = XETrainer(model, opt)
+    tr = XETrainer(model, opt, graph=graph)
     att = _images().cuda()
     w0 = tr.bucket.flat.clone()
 
@@ -362,6 +363,7 @@ def test_reference_estimator_draws_every_token_from_the_gradient_pass(weight_cac
         loss, rs, rn = tr.rl_step(att, None, score, sample_n=n, temperature=1.0)
         last = tr._last_rl
         assert torch.isfinite(loss) and last["reference_gap"] == 0.0, last["reference_gap"]
+        assert last["gradient_pass_replayed"] == graph
         assert last["training_forwards"] >= 3                                 # several phrases -> several tape-free forwards + the gradient pass
         assert last["seq_saic"].shape == (att.size(0) * n, cfg.seq_length) and int((last["seq_saic"] > 0).sum()) > att.size(0)
         assert int((last["seq_naic"] > 0).sum()) > 0
