@@ -108,6 +108,7 @@ int launch_embed_rows(const float* lut_tok, const float* lut_syn, const float* p
                       int B, int T, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, const int* halt, hipStream_t s);
 int launch_saic_init(const BoundState& st, const SaicState& sa, int B, int L, int pad_idx, int bos_idx, int len_idx, hipStream_t s);
 // after the decoder pass of iteration `iter`: copy the new phrase's tokens / log-probs (TransformerModel.py:1968-1977), set halt
+int launch_saic_halt(const BoundState& st, const SaicState& sa, int B, int L, int iter, hipStream_t s);
 int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* tok, const float* logp, float* seq_logprob, int B, int L,
                      int S, int V, int iter, hipStream_t s);
 // decoder rows of the phrases placed in iteration `iter` (image-major), and their count

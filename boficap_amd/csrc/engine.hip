@@ -819,6 +819,10 @@ int bofi_engine::enqueue_decode_saic(const void* feats, int feats_dtype, const i
             { LinOpt o; o.residual = by2; o.ldr = d; o.halt = true; o.splitk = w2parts; ENG_OK(linear(bh, dt, cfg.d_ff, b_w2, by3, BOFI_DT_F32, d, B, o, s)); }
         }
         ENG_OK(bound_tail(by3, w2parts, nullptr, nullptr, B, BOUND_HEADS | BOUND_UPDATE | BOUND_SAIC | BOUND_EARLY, nullptr, nullptr, s, true, it));
+        if (flags & BOFI_FLAG_SAIC_LAYOUT_ONLY) {      // the caller draws this phrase's words itself (bofi_engine_saic_put_words before the next call): layout + positions only
+            ENG_OK(bofi::launch_saic_halt(st, sa, B, L, it, s));
+            continue;
+        }
         // ---- decoder pass over all S positions (decode_SA :520-530) with the phrase-block mask as per-row key prefixes
         ENG_OK(bofi::launch_embed_rows(lut_tok, lut_syn, pe, sa.ext_phrase, st.ext_syn, L, 1, B, S, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
                                        st_fill, halt, s));

@@ -641,6 +641,12 @@ __global__ void saic_halt_kernel(BoundState st, SaicState sa, int B, int L, int 
     __syncthreads();
     if (threadIdx.x == 0 && (nan_seen || st.counters[0] >= B)) st.counters[2] = 1;
 }
+// the second half of launch_saic_copy alone: an iteration whose words come from the caller (BOFI_FLAG_SAIC_LAYOUT_ONLY: no decoder pass ran)
+int launch_saic_halt(const BoundState& st, const SaicState& sa, int B, int L, int iter, hipStream_t s) {
+    hipLaunchKernelGGL(saic_halt_kernel, dim3(1), dim3(256), 0, s, st, sa, B, L, iter);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
 int launch_saic_copy(const BoundState& st, const SaicState& sa, const int64_t* tok, const float* logp, float* seq_logprob, int B, int L,
                      int S, int V, int iter, hipStream_t s) {
     hipLaunchKernelGGL(saic_copy_kernel, dim3(S + 1, B), dim3(256), 0, s, st, sa, tok, logp, seq_logprob, B, L, S, V, iter);

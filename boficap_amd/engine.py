@@ -262,14 +262,15 @@ class BofiEngine:
 
     def decode_saic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, raw_logits: bool = False,
                     want_logprob: bool = True, sample: Optional[tuple] = None, graph: bool = False, out: Optional[dict] = None,
-                    it_range: Optional[tuple] = None) -> dict:
+                    it_range: Optional[tuple] = None, layout_only: bool = False) -> dict:
         """Semi-autoregressive decode (core_SAIC), greedy or -- ``sample=(temperature, seed)`` -- with every phrase's tokens
         drawn from Categorical(logits / temperature) (the bound heads stay greedy, as in the reference).  Same result
         layout as ``decode_naic``.  ``graph``: the launch sequence is captured once per argument set and replayed (pass the
         previous result as ``out`` and keep the inputs in place); the sampling seed is read from device memory, so replays
         draw anew.  ``it_range`` = (first, last) iterations of the loop (bofi_engine_set_saic_range): (1, c) enqueues c iterations,
         (c + 1, S) with the same arguments and ``out`` continues that decode where it stopped -- together the whole loop, exactly;
-        ``out["bound_iters"]`` (live iterations so far) < c says the first part was all of it."""
+        ``out["bound_iters"]`` (live iterations so far) < c says the first part was all of it.  ``layout_only``: the enqueued iterations lay their phrases out and stop
+        (BOFI_FLAG_SAIC_LAYOUT_ONLY: no decoder pass, no tokens) -- for a caller that draws the words itself and hands them back with ``saic_put_words``."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
@@ -283,7 +284,7 @@ class BofiEngine:
                 phrase_length=torch.empty(B, S, dtype=torch.int32, device=dev),
                 phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
                 bound_iters=torch.empty(1, dtype=torch.int32, device=dev), memory=None)
-        flags = (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0)
+        flags = (hip.FLAG_RAW_LOGITS if raw_logits else 0) | (hip.FLAG_GRAPH if graph else 0) | (hip.FLAG_SAIC_LAYOUT_ONLY if layout_only else 0)
         if sample is not None:
             hip.check(self._lib.bofi_engine_set_sampling(self._h, float(sample[0]), int(sample[1]) & 0xFFFFFFFFFFFFFFFF), "bofi_engine_set_sampling")
             flags |= hip.FLAG_SAMPLE

@@ -16,6 +16,7 @@ FLAG_STRICT_Q1, FLAG_RAW_LOGITS, FLAG_GRAPH = 1, 2, 4
 FLAG_REFINE_SHIFT = 8
 FLAG_SAMPLE = 16
 FLAG_PHASE_ENCODE, FLAG_PHASE_BOUND, FLAG_PHASE_FILL = 32, 64, 128
+FLAG_SAIC_LAYOUT_ONLY = 4096
 ABI_VERSION = 3
 
 

@@ -906,7 +906,8 @@ class XETrainer:
             passes = 0
             for it in range(1, S + 1):
                 with torch.no_grad():
-                    out = eng.decode_saic(feats_rep, lens_rep, sample=(temperature, base + self._sample_calls_ref), it_range=(it, it), out=out, want_logprob=False)
+                    # (the engine lays the next phrase out on the words so far and stops: this step draws the words itself, from the training forward's rows)
+                    out = eng.decode_saic(feats_rep, lens_rep, it_range=(it, it), out=out, want_logprob=False, layout_only=True)
                     if int(out["bound_iters"]) < it:                     # no caption was open in this iteration: the loop is through
                         break
                     pl = out["phrase_length"].long()

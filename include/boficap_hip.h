@@ -368,6 +368,9 @@ void* bofi_engine_stream(bofi_engine_t* e);
  * workgroups for ~1 ms) can run on a side stream while the launch stream already encodes the next batch on another fork: */
 #define BOFI_FLAG_PHASE_ENCODE 32   /* _prepare_feature + Encoder + the stacked cross K|V (TransformerModel.py:1674-1690, 1332-1336) */
 #define BOFI_FLAG_PHASE_BOUND 64    /* the bounding loop of core_NAIC (:1833-1869) on the preceding encode of this engine */
+#define BOFI_FLAG_SAIC_LAYOUT_ONLY 4096 /* decode_saic: every enqueued iteration lays its phrase out (bounding step + bookkeeping, TransformerModel.py:1903-1948) and stops there --
+                                          no decoder pass, no tokens: the caller draws the phrase's words from its own distribution and hands them back with
+                                          bofi_engine_saic_put_words before the next call (the reference-estimator self-critical step) */
 #define BOFI_FLAG_PHASE_FILL 128    /* decode_NA + logit + greedy pick + the slot-state export (:570-587, 1872-1876) on the preceding two */
 
 /* model(fc, att, att_masks, opt={'train_mode':'NAIC','sample_method':'greedy'}, mode='sample'):
