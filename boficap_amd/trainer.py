@@ -877,21 +877,24 @@ class XETrainer:
         if self.graph and att_masks is None and step_word is not None and not self._capturing() and getattr(model.opt, "bofi_rl_graph_forwards", True):
             fwd_graphs = self._rl_forward_graphs(rows_of, att_feats, N, S, dev, sample_n)
 
-        def rows_graphed(prep, first):
-            g_a, g_b, st_prep, st_feats, out_a, out_b = fwd_graphs
+        def rows_graphed(seq, out, prep_na, first):
+            # (the graphs read the words so far and the engine's layout from static buffers and collate them on the device: no host round trip per phrase)
+            g_a, g_b, st_in, st_feats, out_a, out_b = fwd_graphs
             if first:
                 st_feats.copy_(att_feats)
-            torch._foreach_copy_([st_prep[k] for k in sorted(st_prep)], [prep[k] for k in sorted(st_prep)], non_blocking=True)
+                st_in["na_syn"].copy_(prep_na["na_syn"]); st_in["na_klen"].copy_(prep_na["na_klen"])
+            torch._foreach_copy_([st_in["seq"], st_in["pl"], st_in["psyn"]], [seq, out["phrase_length"], out["phrase_syn"]], non_blocking=True)
             (g_a if first else g_b).replay()
             return out_a if first else out_b
 
         def draw(lp, mask, seq, drawn):
-            idx = mask.nonzero(as_tuple=True)
-            if idx[0].numel():
-                rows = lp[idx].float()
-                tok = torch.multinomial(torch.softmax(rows / temperature, dim=-1), 1, generator=gen).squeeze(1)
-                seq[idx] = tok
-                drawn[idx] = rows.gather(1, tok[:, None]).squeeze(1)
+            # one multinomial over every slot, kept where ``mask`` is set (no index list, so no host synchronisation; slots outside the mask draw from a
+            # uniform row: their rows may be anything)
+            lpf = lp.float()
+            p = torch.where(mask[..., None], torch.softmax(lpf / temperature, dim=-1), torch.ones((), device=dev))
+            tok = torch.multinomial(p.view(-1, p.size(-1)), 1, generator=gen).view(mask.shape)
+            seq.copy_(torch.where(mask, tok, seq))
+            drawn.copy_(torch.where(mask, lpf.gather(2, tok[..., None]).squeeze(2), drawn))
 
         try:
             prep_na = xe.rl_prepare(cfg, None, na, sample_n=sample_n, strict_q1=model.strict_reference, device=dev)
@@ -911,10 +914,12 @@ class XETrainer:
                     if int(out["bound_iters"]) < it:                     # no caption was open in this iteration: the loop is through
                         break
                     pl = out["phrase_length"].long()
-                    prep = xe.rl_prepare(cfg, {"seq": seq_s, "phrase_length": pl, "phrase_syn": out["phrase_syn"]}, None, sample_n=sample_n,
-                                         strict_q1=model.strict_reference, device=dev)
-                    prep.update(prep_na)
-                    lp_s, lp_n = rows_graphed(prep, passes == 0) if fwd_graphs is not None else rows_of(prep, shared)
+                    if fwd_graphs is not None:
+                        lp_s, lp_n = rows_graphed(seq_s, out, prep_na, passes == 0)
+                    else:
+                        prep = xe.rl_prepare_saic_device(cfg, seq_s, pl, out["phrase_syn"])
+                        prep.update(prep_na)
+                        lp_s, lp_n = rows_of(prep, shared)
                     passes += 1
                     start = pl[:, :it - 1].sum(1)[:, None]
                     new = (pos >= start) & (pos < start + pl[:, it - 1:it])
@@ -925,7 +930,7 @@ class XETrainer:
                         draw(lp_n, mask_n, seq_n, drawn_n)
             saic = {"seq": seq_s, "phrase_length": out["phrase_length"], "phrase_syn": out["phrase_syn"]}
             s_saic, s_naic = score_fn(seq_s.cpu()), score_fn(seq_n.cpu())
-            prep = xe.rl_prepare(cfg, saic, None, sample_n=sample_n, strict_q1=model.strict_reference, device=dev)
+            prep = xe.rl_prepare_saic_device(cfg, seq_s, out["phrase_length"], out["phrase_syn"])
             prep.update(prep_na)
             sc_s = torch.as_tensor(s_saic, dtype=torch.float32).to(dev)
             sc_n = torch.as_tensor(s_naic, dtype=torch.float32).to(dev)
@@ -968,7 +973,7 @@ class XETrainer:
         return loss, m1, m2
 
     def _rl_forward_graphs(self, rows_of, att_feats, N, S, dev, sample_n):
-        """(graph A, graph B, static prep tensors, static features, outputs of A, outputs of B) of the reference-estimator step's tape-free forwards for this
+        """(graph A, graph B, static inputs -- words so far, the engine's layout, the NA branch's index tensors --, static features, outputs of A, outputs of B) of the reference-estimator step's tape-free forwards for this
         input signature; captured on first use (after one eager pass of both forms), kept with the trainer's other graphs."""
         model = self.model
         key = ("rlref", tuple(att_feats.shape), att_feats.dtype, N, S, sample_n, model.training, model.train_dtype)
@@ -977,22 +982,31 @@ class XETrainer:
             return entry
         if len(self._graphs) >= self.max_graphs:
             return None
+        from . import xe
+        cfg = model.cfg
         i64 = lambda: torch.zeros(N, S, dtype=torch.int64, device=dev)
-        i32 = lambda: torch.ones(N, S, dtype=torch.int32, device=dev)
-        st_prep = {"sa_syn": i64(), "sa_seq": i64(), "sa_klen": i32(), "na_syn": i64(), "na_klen": i32()}
+        i32 = lambda: torch.zeros(N, S, dtype=torch.int32, device=dev)
+        st_in = {"seq": i64(), "pl": i32(), "psyn": i64(), "na_syn": i64(), "na_klen": i32()}
+        st_in["pl"][:, 0] = 1; st_in["na_klen"].fill_(1)          # (the warm-up passes see a one-word layout)
         st_feats = att_feats.clone()
+
+        def rows_dev(shared):
+            prep = xe.rl_prepare_saic_device(cfg, st_in["seq"], st_in["pl"], st_in["psyn"])
+            prep["na_syn"], prep["na_klen"] = st_in["na_syn"], st_in["na_klen"]
+            return rows_of(prep, shared, st_feats)
+
         with torch.no_grad():
             warm: dict = {}
-            rows_of(st_prep, warm, st_feats); rows_of(st_prep, warm, st_feats)      # both forms once outside any capture
+            rows_dev(warm); rows_dev(warm)                          # both forms once outside any capture
             torch.cuda.synchronize()
             shared: dict = {}
             g_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_a):
-                out_a = rows_of(st_prep, shared, st_feats)
+                out_a = rows_dev(shared)
             g_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_b, pool=g_a.pool()):
-                out_b = rows_of(st_prep, shared, st_feats)
-        entry = self._graphs[key] = (g_a, g_b, st_prep, st_feats, out_a, out_b, shared)[:6] + ()
+                out_b = rows_dev(shared)
+        entry = self._graphs[key] = (g_a, g_b, st_in, st_feats, out_a, out_b)
         self._rl_ref_shared = shared                            # (keeps graph A's memory / cross K|V alive: graph B reads them)
         return entry
 

@@ -1681,6 +1681,44 @@ def rl_prepare(cfg, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool 
     return out
 
 
+def rl_prepare_saic_device(cfg, seq: torch.Tensor, phrase_length: torch.Tensor, phrase_syn: torch.Tensor):
+    """``rl_prepare``'s semi-autoregressive half as tensor operations on the device (no host round trip, no synchronisation: it can sit inside a captured
+    graph): ``seq`` int64 [N, S] sampled tokens, ``phrase_length`` / ``phrase_syn`` [N, S] as the engine exports them -> {sa_syn, sa_seq int64 [N, S],
+    sa_klen int32 [N, S]} -- the loader's collate of those captions (captioning/data/dataloader.py:343-428; the index arithmetic of
+    boficap_amd.collate.phrase_collate, checked against it in tests/test_gpu_rl.py)."""
+    N, S = seq.shape
+    L = S + 2
+    dev = seq.device
+    plen = phrase_length.long()
+    psyn = torch.where(plen > 0, phrase_syn.long(), torch.zeros_like(plen))
+    labels = torch.zeros(N, L, dtype=torch.int64, device=dev)
+    labels[:, 0] = cfg.bos_idx
+    labels[:, 1:S + 1] = seq
+    ntok = plen.sum(1)
+    ends = plen.cumsum(1)
+    t = torch.arange(S, device=dev)[None, :]
+    valid = t < ntok[:, None]
+    pid = (ends[:, None, :] <= t[:, :, None]).sum(2).clamp(max=S - 1)      # phrase of token position t
+    zero = torch.zeros_like(pid)
+    sa_syn = torch.where(valid, psyn.gather(1, pid), zero)
+    start = ends - plen
+    cur = plen.gather(1, pid)
+    k = t - start.gather(1, pid)
+    first = pid == 0
+    pm1 = (pid - 1).clamp(min=0)
+    prev = torch.where(first, torch.ones_like(pid), plen.gather(1, pm1))
+    prev_start = torch.where(first, zero, 1 + start.gather(1, pm1))
+    cur_s, prev_s = cur.clamp(min=1), prev.clamp(min=1)
+    times = torch.div(cur_s, prev_s, rounding_mode="floor")
+    pre_less = prev_s - cur_s % prev_s
+    stretched = torch.where(k < pre_less * times, torch.div(k, times.clamp(min=1), rounding_mode="floor"),
+                            pre_less + torch.div(k - pre_less * times, times + 1, rounding_mode="floor"))
+    src = torch.where(cur <= prev, prev - cur + k, stretched)
+    sa_seq = torch.where(valid, labels.gather(1, (prev_start + src).clamp(0, L - 1)), zero)
+    sa_klen = torch.where(valid, ends.gather(1, pid), ntok[:, None].expand(N, S)).to(torch.int32)
+    return {"sa_syn": sa_syn.contiguous(), "sa_seq": sa_seq.contiguous(), "sa_klen": sa_klen.contiguous()}
+
+
 @_scoped_compute_dtype
 def sampled_logprobs_prepared(P, cfg, att_feats, att_masks, prep, *, sample_n: int = 1, training: bool = False, seed: Optional[int] = None,
                               compute_dtype: torch.dtype = torch.float32, step_word: Optional[torch.Tensor] = None, reuse: Optional[dict] = None):

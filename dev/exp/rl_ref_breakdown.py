@@ -19,6 +19,11 @@ def timed(name, fn):
         return r
     return w
 xe.rl_prepare = timed("rl_prepare (host collate)", xe.rl_prepare)
+xe.rl_prepare_saic_device = timed("rl_prepare_saic_device (eager calls only)", xe.rl_prepare_saic_device)
+torch.cuda.CUDAGraph.replay = timed("graph replays (13 forwards + the gradient pass + optimiser)", torch.cuda.CUDAGraph.replay)
+torch._foreach_copy_ = timed("foreach copies into static buffers", torch._foreach_copy_)
+_sm = torch.softmax
+torch.softmax = timed("softmax of the draw", _sm)
 xe.sampled_logprobs_prepared = timed("training forward (per phrase + gradient pass)", xe.sampled_logprobs_prepared)
 xe.new_self_critical = timed("new_self_critical", xe.new_self_critical)
 BofiEngine.decode_saic = timed("engine: one SAIC iteration", BofiEngine.decode_saic)

@@ -401,3 +401,28 @@ def test_reference_estimator_cold_and_without_dropout_is_the_greedy_decode(weigh
     assert torch.equal(last["seq_saic"], gs[0].repeat_interleave(n, 0))
     assert torch.equal(last["seq_naic"], gn[0].repeat_interleave(n, 0))
     assert last["reference_gap"] == 0.0
+
+
+def test_device_side_layout_collate_equals_the_host_collate():
+    """xe.rl_prepare_saic_device (tensor operations on the device, usable inside a captured graph) against xe.rl_prepare (the host collate through
+    boficap_amd.collate.phrase_collate, itself pinned to the reference's collate_func): random layouts with squeezes, stretches, empty captions."""
+    from boficap_amd import xe
+    from boficap_amd.config import FULL as cfg
+    rng = np.random.default_rng(3)
+    S, N = cfg.seq_length, 60
+    seq = np.zeros((N, S), np.int64); plen = np.zeros((N, S), np.int32); psyn = np.zeros((N, S), np.int64)
+    for n in range(N):
+        if n % 11 == 0:
+            continue                                             # a caption without phrases
+        lens = rng.integers(1, 8, int(rng.integers(1, 9)))
+        while lens.sum() > S:
+            lens = lens[:-1]
+        P = len(lens)
+        plen[n, :P], psyn[n, :P] = lens, rng.integers(4, 7, P)
+        psyn[n, P:] = rng.integers(0, 9, S - P)                  # (entries behind the last phrase are not read)
+        seq[n, :lens.sum()] = rng.integers(7, cfg.tgt_vocab, lens.sum())
+    r = {"seq": torch.from_numpy(seq).cuda(), "phrase_length": torch.from_numpy(plen).cuda(), "phrase_syn": torch.from_numpy(psyn).cuda()}
+    host = xe.rl_prepare(cfg, r, None, sample_n=1, device="cuda")
+    dev = xe.rl_prepare_saic_device(cfg, r["seq"], r["phrase_length"], r["phrase_syn"])
+    for k in ("sa_syn", "sa_seq", "sa_klen"):
+        assert dev[k].dtype == host[k].dtype and torch.equal(dev[k], host[k]), k
