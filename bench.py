@@ -822,25 +822,26 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     # device on the launch's own stream before every launch -- the PCIe-inclusive rate (never `value`)
     pcie_ms, pcie_note = None, None
     if args.from_host:
-        # through boficap_amd.engine.DecodePipeline -- what tools/eval.py and TransformerModel.decode_many run: 3 launches in flight of 10 batches each, the
+        # through boficap_amd.engine.DecodePipeline -- what tools/eval.py and TransformerModel.decode_many run: 3 launches in flight of 16 batches each, the
         # features copied from pinned host memory on a copy stream ahead of the launches (3 launch streams + the copy stream = the runtime's 4 hardware
         # queues), ids / slot layouts / per-image entropy and perplexity back on the host per batch
         from boficap_amd.engine import DecodePipeline
-        pipe = DecodePipeline(eng, in_flight=3, batches_per_launch=10)
+        pipe = DecodePipeline(eng, in_flight=3, batches_per_launch=16)
         pool = torch.cat(atts).cpu()
-        pool = torch.cat([pool] * (-(-64 * 160 // pool.size(0)))).pin_memory()                # >= 160 batches of 64 (16 launches), whatever --steps says
+        pool = torch.cat([pool] * (-(-64 * 320 // pool.size(0)))).pin_memory()                # >= 320 batches of 64 (20 launches), whatever --steps says
         hb = [pool[i:i + args.batch] for i in range(0, pool.size(0) - args.batch + 1, args.batch)]
-        for _ in pipe.run(hb[:60]):
+        for _ in pipe.run(hb[:96]):
             pass
         torch.cuda.synchronize()
         h0 = time.perf_counter()
         n_img = sum(r["seq"].size(0) for r in pipe.run(hb))
         pcie_ms = (time.perf_counter() - h0) / (n_img / args.batch) * 1e3
-        pcie_note = f"{len(hb)} batches of {args.batch} through DecodePipeline (3 launches in flight x 10 batches, copy stream ahead, results on the host)"
+        pcie_note = f"{len(hb)} batches of {args.batch} through DecodePipeline (3 launches in flight x 16 batches, copy stream ahead, results on the host)"
         del pipe, pool, hb
         torch.cuda.empty_cache()
     traffic, tnote = None, "no PMC pass committed for this configuration"
     names = {1: ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",),
+             16: ("r05_hbm_traffic_coalesce16.json",),
              5: ("r05_hbm_traffic_coalesce5.json", "r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
@@ -943,8 +944,8 @@ def main():
                     help="naic: bound+fill decode (headline); xe: XE training step (config 3); rl: self-critical step (config 4)")
     ap.add_argument("--seq-per-img", type=int, default=5)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=320)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=None, help="images per step and GPU (default: 64; 10 in rl mode)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ids-only", action="store_true", help="do not materialise the [B,20,V] log-prob tensor")
@@ -983,9 +984,11 @@ def main():
     if default_coalesce:
         args.coalesce = 1
         if args.mode == "naic" and args.batch == 64 and not args.refine:
-            # batches per launch: among 5, 4, 8, 2 the one that divides the timed steps and spreads the launches evenly over the
-            # streams (fewest rounds x batches per launch; the driver's --steps 20 -> 4 launches of 5 batches, one per stream)
-            cands = [c for c in (5, 4, 8, 2) if args.steps % c == 0]
+            # batches per launch: among 16, 20, 10, 8, 5, 4, 2 the one that divides the timed steps and spreads the launches evenly over the
+            # streams (fewest rounds x batches per launch, the first of equals: the default --steps 320 -> 20 launches of 16 batches, five per stream; the
+            # driver's --steps 20 -> 4 launches of 5 batches, one per stream).  Round 5: the chip wants ~3 000 images in flight -- 254 k img/s at 10 batches
+            # per launch, 260 k at 12, 262 k at 16-20 against 239-243 k at 5 (profiles/r05_launch_shape_sweep.txt)
+            cands = [c for c in (16, 20, 10, 8, 5, 4, 2) if args.steps % c == 0]
             if cands:
                 n_str = max(1, args.inflight)
                 args.coalesce = min(cands, key=lambda c: (-(-(args.steps // c) // n_str)) * c)

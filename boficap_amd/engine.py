@@ -360,7 +360,7 @@ class DecodePipeline:
     ``run(batches)`` is a generator: one dict per input batch, in input order, as soon as its launch is through -- while later launches are
     already in flight."""
 
-    def __init__(self, engine: "BofiEngine", *, in_flight: Optional[int] = None, batches_per_launch: int = 10, strict_q1: bool = True, stats: bool = True,
+    def __init__(self, engine: "BofiEngine", *, in_flight: Optional[int] = None, batches_per_launch: int = 16, strict_q1: bool = True, stats: bool = True,
                  keep_logprob: bool = False, region_buckets=(36, 48, 64, 80, 100, 128)):
         if in_flight is None:                                    # 3 launch streams + the copy stream = the runtime's default of 4 hardware queues; a process started
             import os                                            # with GPU_MAX_HW_QUEUES >= 5 (tools/eval.py sets 8) has room for a fourth launch stream

@@ -239,7 +239,7 @@ class TransformerModel(nn.Module):
             v.record_stream(main)                                 # allocated / read on s2, used on the caller's stream from here on
         return saic, naic
 
-    def decode_many(self, batches, *, batches_per_launch: int = 10, in_flight: Optional[int] = None, stats: bool = True, keep_logprob: bool = False):
+    def decode_many(self, batches, *, batches_per_launch: int = 16, in_flight: Optional[int] = None, stats: bool = True, keep_logprob: bool = False):
         """Greedy NAIC decode of MANY loader batches at the engine's throughput -- the eval loop of the reference (eval_utils.py:456-460: one synchronised
         ``model(..., mode='sample')`` per batch, which is what ``_sample`` reproduces) as a pipeline: ``in_flight`` engine forks on overlapping streams,
         ``batches_per_launch`` consecutive batches per launch (quirk Q1 per batch: every batch's result is its own decode's), features copied from (pinned)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM-side traffic per step from two rocprofv3 --pmc passes (FETCH_SIZE in one, WRITE_SIZE in the other; both in KiB).
-usage: pmc_traffic.py FETCH.db WRITE.db NSTEPS  -- FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B,
+usage: pmc_traffic.py FETCH.db WRITE.db NSTEPS|auto  -- FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B,
 MI355X_MICROARCH.md).  Prints a JSON object with bytes per step and the top kernels of each direction."""
 import json, re, sqlite3, sys
 from collections import defaultdict
@@ -14,7 +14,10 @@ def total(path, counter):
     return sum(per.values()), sorted(per.items(), key=lambda kv: -kv[1])[:6]
 
 
-n = float(sys.argv[3])
+if sys.argv[3] == "auto":                                    # engine launches in the trace = dispatches of bound_init_kernel
+    n = float(sqlite3.connect(sys.argv[1]).execute("select count(distinct dispatch_id) from counters_collection where kernel_name like '%bound_init_kernel%'").fetchone()[0])
+else:
+    n = float(sys.argv[3])
 f, ftop = total(sys.argv[1], "FETCH_SIZE")
 w, wtop = total(sys.argv[2], "WRITE_SIZE")
 print(json.dumps({"hbm_bytes_per_step": round((2.0 * f + w) * 1024.0 / n), "fetch_size_kb_per_step": round(f / n, 1), "write_size_kb_per_step": round(w / n, 1),
