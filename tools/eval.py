@@ -37,11 +37,11 @@ def main():
     ap.add_argument("--input_label_npz", default="", help="label arrays (schema of scripts/prepro_labels_stanford.py:393-399, as .npz, or .h5 with h5py): "
                     "also report the validation loss of eval_split (eval_utils.py:440-453); image i of the features = image i of the file")
     ap.add_argument("--seq_per_img", type=int, default=5)
-    ap.add_argument("--pipeline", type=int, default=1, help="1 (default, NAIC): the batches go through TransformerModel.decode_many -- 3 launches in flight, 16 batches per "
+    ap.add_argument("--pipeline", type=int, default=1, help="1 (default, NAIC): the batches go through TransformerModel.decode_many -- 4 launches in flight, 16 batches per "
                     "launch, features copied from pinned host memory ahead of the launches; 0: one synchronised mode='sample' call per batch as the reference's eval loop "
                     "(eval_utils.py:456-460)")
     ap.add_argument("--batches_per_launch", type=int, default=16)
-    ap.add_argument("--in_flight", type=int, default=3, help="launch streams (this script starts the runtime with 8 hardware queues: launch streams and the copy stream get one each)")
+    ap.add_argument("--in_flight", type=int, default=4, help="launch streams (this script starts the runtime with 8 hardware queues: launch streams and the copy stream get one each)")
     args = ap.parse_args()
 
     import captioning.models as models
