@@ -1351,8 +1351,8 @@ __global__ __launch_bounds__(512, 4) void rb_dec_attn_kernel(RbDecArgs d) {
                     }
                     __builtin_amdgcn_wave_barrier();                        // (the previous image's V^T reads were issued before these writes)
 #pragma unroll
-                    for (int c = lnv; c < VRC * 8; c += 64) {
-                        const int r = c >> 3, ch = c & 7;
+                    for (int it = 0; it < VRC * 8 / 64; ++it) {
+                        const int c = lnv + it * 64, r = c >> 3, ch = c & 7;
                         *reinterpret_cast<u32x4*>(&sv[r * RB_VROW + ch * 8]) = r < Lk ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * d.ldc + ch * 8) : u32x4{0u, 0u, 0u, 0u};
                     }
                     klu = Lk;
