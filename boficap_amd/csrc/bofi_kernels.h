@@ -136,6 +136,9 @@ struct RbAttnArgs {
     uint16_t* yb; float* stats_out;           // optional, as RbFfnArgs
     int dbg;                                  // developer ablation (BOFI_RB_DBG): 1 = no attention, 2 = no output projection, 4 = no closing stores, 16 = stamps
     int alone;                                // 1: nothing runs beside this launch (query blocks of <= 20 rows then take the 8-wavefront workgroups: shorter, but W_o streamed twice as often)
+    // optional projection tail (query blocks of <= 20 rows, keys <= 32, the 16-wavefront form): pj_y[B*Lq][pj_ldy] bf16 = W' . LN(y) + c for a LayerNorm-folded
+    // [512][512] projection of the sublayer's OUTPUT (the decoder layer's cross-attention queries), computed from each block while it sits in LDS
+    const rb_u32x4* pj_wp; const float* pj_c; const float* pj_cs; uint16_t* pj_y; int pj_ldy;
 };
 struct RbGemmArgs {
     const float* x; int ldx;                  // [M][512] float32 residual stream (the LayerNorm is folded into w / c / cs)

@@ -431,7 +431,18 @@ struct bofi_engine {
 #else
     static constexpr bool exp_skip(const char*) { return false; }
 #endif
-    int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s) {
+    // pj (optional): the LayerNorm-folded [512, 512] projection that reads this sublayer's output next (the decoder layer's cross-attention queries), computed by the SAME
+    // launch from each block while it sits in LDS (pj_y bf16, pitch pj_ldy); attn_proj_ok says when the attention kernel takes it (BOFI_RB_ATTN_PROJ, re-read after
+    // bofi_reload_env: 0 = never, 1 (default) = when launches overlap, 2 = always)
+    bool attn_proj_ok(const bofi::AttnArgs& at, const Lin& o, const Lin& pj) const {
+        const int v = BOFI_ENV_INT("BOFI_RB_ATTN_PROJ", 1);
+        const int M = at.B * at.Lq;
+        return v && (v == 2 || in_flight != 1) && BOFI_ENV_INT("BOFI_RB_ATTN", 1) != 0 && BOFI_ENV_INT("BOFI_RB_ATTN_W", 0) == 0 && rb_ok() && o.wp && fold_rb_ok(pj, M) &&
+               pj.Npad == 512 && !at.skip_if_ge && at.kdiv <= 1 && !at.q_start && !at.drop_thresh && !at.klen_sq && at.Lq <= 20 && at.Lk <= 32 && M >= rb_min_rows() &&
+               !exp_skip("attn") && !exp_skip("qkv");
+    }
+    int attn_sublayer(const bofi::AttnArgs& at, const Lin& o, float* x, void* xb, float* stats, bool want_copy, hipStream_t s, const Lin* pj = nullptr, void* pj_y = nullptr,
+                      int pj_ldy = 0) {
         const bool on = BOFI_ENV_INT("BOFI_RB_ATTN", 1) != 0;
         if (exp_skip("attn")) return BOFI_OK;
         if (!on || !rb_ok() || !o.wp || at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh || at.B * at.Lq < rb_min_rows()) return -1;
@@ -441,6 +452,7 @@ struct bofi_engine {
         a.klen_shared_last = at.klen_shared_last; a.wop = (const bofi::u32x4*)o.wp; a.bo = o.b; a.x = x; a.ldx = cfg.d_model; a.y = x; a.ldy = cfg.d_model;
         a.yb = want_copy ? (uint16_t*)xb : nullptr; a.stats_out = want_copy ? stats : nullptr;
         a.alone = in_flight == 1;
+        if (pj) { a.pj_wp = (const bofi::u32x4*)pj->wp; a.pj_c = pj->b; a.pj_cs = pj->cs; a.pj_y = (uint16_t*)pj_y; a.pj_ldy = pj_ldy; a.yb = nullptr; a.stats_out = nullptr; }
         return bofi::launch_rb_attn(a, s);
     }
     // both attention sublayers of decoder layer `l` of the filling pass as ONE launch (rowblock.hip rb_dec_attn_kernel; `at`: the self-attention as attn_sublayer
@@ -729,16 +741,20 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         int rc = dec_attn_sublayers(a, l, att_len, li, R, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {                                        // ... or as attention sublayer + folded query projection + attention sublayer
-        rc = attn_sublayer(a, l.o, x_fill, xb_fill, st_fill, !q_rb, s);             // (the query projection behind it is a folded GEMM)
+        const bool q_tail = attn_proj_ok(a, l.o, l.q_src);      // the cross-attention's query projection rides the self-attention launch
+        rc = q_tail ? attn_sublayer(a, l.o, x_fill, nullptr, nullptr, false, s, &l.q_src, qs, d)
+                    : attn_sublayer(a, l.o, x_fill, xb_fill, st_fill, !q_rb, s);   // (the query projection behind it is a folded GEMM)
         if (rc > 0) return rc;
         if (rc < 0) {
             ENG_OK(bofi::launch_attention(a, s));
             LinOpt o; o.residual = x_fill; o.ldr = d; o.stats_out = st_fill; o.y2 = copy_t(xb_fill);
             ENG_OK(linear(ctx, dt, d, l.o, x_fill, BOFI_DT_F32, d, M, o, s));
         }
+        if (!(q_tail && rc == 0)) {
         rc = fold_linear_rb(x_fill, l.q_src, qs, 0, d, M, s);
         if (rc > 0) return rc;
         if (rc < 0) { LinOpt o; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.q_src, qs, dt, d, M, o, s)); }
+        }
         bofi::AttnArgs c{};
         c.q = qs; c.ldq = d;
         c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;

@@ -975,7 +975,11 @@ __device__ __forceinline__ void rb_attn_head(const RbAttnArgs& a, int img, int h
 // 512 / W of the 512 output columns.  W = 8 (round 4): half the images per workgroup, at most half the LDS and registers of a CU -- TWO workgroups per
 // CU, so one's attention phase (vector work and load latency: 26 k of a 16-wavefront workgroup's 54 k cycles, the MFMA pipes idle) runs beside the
 // other's output projection; the price is the output projection's weights streamed once per G/2 images more.
-template <int NQT, int NKT, int NR, int W>
+// PJ (round 5): the projection that reads the sublayer's output next -- the decoder layer's LayerNorm-folded cross-attention query projection -- from the block while it
+// sits in LDS: y as bf16 back into the block with its row statistics (a wavefront's share of a row's sums through LDS), the closing stores through staging rows of their
+// own, then one more weight segment and the fold; the queries go to memory as 8-byte pieces.  The same weight bytes per row as the 96-row projection launch it replaces
+// (0.5 MB per 80 rows), one launch and one pass over the stream less per decoder layer.
+template <int NQT, int NKT, int NR, int W, bool PJ = false>
 __global__ __launch_bounds__(W * 64, 4) void rb_attn_kernel(RbAttnArgs a) {      // (4 wavefronts per SIMD: 128 registers, so that two 8-wavefront workgroups share a CU)
     constexpr int IPR = W / 8, G = NR * IPR, VR = NKT == 4 ? 48 : 32;      // images per round / per workgroup
     constexpr int LQM = NR == 2 ? 20 : (NQT == 2 ? 32 : 40);              // query rows per image this instantiation is launched for
@@ -987,11 +991,17 @@ __global__ __launch_bounds__(W * 64, 4) void rb_attn_kernel(RbAttnArgs a) {     
     constexpr int BODY = (W * VR * RB_VROW * 2 > MT * 16384) ? W * VR * RB_VROW * 2 : MT * 16384;
     float* bos = reinterpret_cast<float*>(smem + BODY);                     // [512]
     bf16_t* zrow = reinterpret_cast<bf16_t*>(smem + BODY + 2048);           // 256 B of zeros
+    // projection tail: staging rows of the closing stores (the block stays live), a wavefront's (sum, sum of squares) per row, the fold's constants
+    unsigned char* pj_stg = smem + BODY + 2048 + 256;                       // [W][16 rows][144 B]
+    float2* pj_part = reinterpret_cast<float2*>(pj_stg + W * 16 * 144);     // [W][MT*16]
+    float* pj_cc = reinterpret_cast<float*>(pj_part + W * MT * 16);         // c[512] | cs[512]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int img0 = blockIdx.x * G, nimg = min(G, a.B - img0);
     RB_STAMP(a.dbg, wave, lane, 0);
     for (int i = tid; i < 512; i += W * 64) bos[i] = a.bo[i];
+    if constexpr (PJ)
+        for (int i = tid; i < 512; i += W * 64) { pj_cc[i] = a.pj_c[i]; pj_cc[512 + i] = a.pj_cs[i]; }
     if (tid < 64) reinterpret_cast<uint32_t*>(zrow)[tid] = 0u;
     __syncthreads();                                                        // (the zero row is read by every wavefront)
 
@@ -1045,7 +1055,9 @@ __global__ __launch_bounds__(W * 64, 4) void rb_attn_kernel(RbAttnArgs a) {     
             acc[nt][mt] = f32x4{v.x, v.y, v.z, v.w};
         }
     }
-    if (!(a.dbg & 2)) rb_segment<MT, NT, OPF>(wo, wo, wb, smem, rb_lane_base(l15, g), acc);
+    const u32x4* wq = nullptr;
+    if constexpr (PJ) wq = a.pj_wp + (size_t)((wave * NT) >> 2) * (16 * 256) + ((wave * NT) & 3) * 64 + lane;
+    if (!(a.dbg & 2)) rb_segment<MT, NT, OPF>(wo, PJ ? wq : wo, wb, smem, rb_lane_base(l15, g), acc);      // (PJ: its last steps request the projection's first ones)
     RB_STAMP(a.dbg, wave, lane, 5);
 
     // ---- close the sublayer: the block is dead once every wavefront has left the segment; each wavefront then turns 32 columns of a row
@@ -1053,14 +1065,33 @@ __global__ __launch_bounds__(W * 64, 4) void rb_attn_kernel(RbAttnArgs a) {     
     // 32 rows through a shared staging area, residual loads and two barriers per pass: 13 k of the kernel's 54 k cycles)
     __syncthreads();
     RB_STAMP(a.dbg, wave, lane, 6);
+    if constexpr (PJ) {                                         // y = accumulators + b_o: into the block as bf16, this wavefront's share of the row sums beside it
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = mt * 16 + l15;
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bb = *reinterpret_cast<const float4*>(bos + c0 + nt * 16 + g * 4);
+                f32x4 t = acc[nt][mt];
+                t[0] += bb.x; t[1] += bb.y; t[2] += bb.z; t[3] += bb.w;
+                acc[nt][mt] = t;
+                sm += (t[0] + t[1]) + (t[2] + t[3]);
+                sq += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+                *reinterpret_cast<uint2*>(blk + rb_off(r, (c0 >> 3) + nt * 2 + (g >> 1)) + (g & 1) * 8) = make_uint2(pack_bf16(t[0], t[1]), pack_bf16(t[2], t[3]));
+            }
+            sm = xor32_sum(xor16_sum(sm)); sq = xor32_sum(xor16_sum(sq));
+            if (g == 0) pj_part[wave * (MT * 16) + r] = make_float2(sm, sq);
+        }
+    }
     {
-        unsigned char* stg = smem + wave * (16 * 144);
+        unsigned char* stg = PJ ? pj_stg + wave * (16 * 144) : smem + wave * (16 * 144);
         const int er = lane >> 3, ec = lane & 7;
         const size_t ystep = (size_t)8 * a.ldy;
 #pragma unroll
         for (int half = 0; half < NT / 2; ++half) {            // 32 columns (two tiles) at a time
             const int cb = c0 + half * 32 + ec * 4;
-            const float4 bb = *reinterpret_cast<const float4*>(bos + cb);
+            const float4 bb = PJ ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bos + cb);      // (PJ: the accumulators hold the bias already)
             float* yp = a.y + (size_t)(m0 + er) * a.ldy + cb;
             int rr = er;
 #pragma unroll
@@ -1094,22 +1125,59 @@ __global__ __launch_bounds__(W * 64, 4) void rb_attn_kernel(RbAttnArgs a) {     
         }
     }
     RB_STAMP(a.dbg, wave, lane, 7);
+    if constexpr (PJ) {
+        __syncthreads();                                        // the block holds y as bf16, the partial sums are in place
+        float mu[MT], rs[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { const float2 p = pj_part[w * (MT * 16) + mt * 16 + l15]; s1 += p.x; s2 += p.y; }
+            const float mean = s1 * (1.0f / 512.0f);
+            const float var = fmaxf((s2 - s1 * mean) * (1.0f / 511.0f), 0.f);
+            mu[mt] = mean; rs[mt] = 1.0f / (sqrtf(var) + 1e-6f);
+            asm volatile("" : "+v"(mu[mt]), "+v"(rs[mt]));      // (computed here, not behind the segment: the partial sums would wait in registers)
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb_segment<MT, NT, OPF>(wq, wq, wb, smem, rb_lane_base(l15, g), acc);
+        int cofs = c0 + g * 4;
+        asm volatile("" : "+v"(cofs));
+        unsigned short* qy = a.pj_y + (size_t)m0 * a.pj_ldy + cofs;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float4 cc = *reinterpret_cast<const float4*>(pj_cc + cofs + nt * 16);
+            const float4 cs = *reinterpret_cast<const float4*>(pj_cc + 512 + cofs + nt * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 t = acc[nt][mt];
+                const float v0 = rs[mt] * (t[0] - mu[mt] * cs.x) + cc.x, v1 = rs[mt] * (t[1] - mu[mt] * cs.y) + cc.y;
+                const float v2 = rs[mt] * (t[2] - mu[mt] * cs.z) + cc.z, v3 = rs[mt] * (t[3] - mu[mt] * cs.w) + cc.w;
+                const int r = mt * 16 + l15;
+                if (r < rows_live) *reinterpret_cast<uint2*>(qy + (size_t)r * a.pj_ldy + nt * 16) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+            }
+        }
+        RB_STAMP(a.dbg, wave, lane, 8);
+    }
 }
 
-template <int NQT, int NKT, int NR, int W>
+template <int NQT, int NKT, int NR, int W, bool PJ = false>
 static int launch_rb_attn_t(const RbAttnArgs& a, hipStream_t st) {
     constexpr int IPR = W / 8, G = NR * IPR, VR = NKT == 4 ? 48 : 32;
     constexpr int LQM = NR == 2 ? 20 : (NQT == 2 ? 32 : 40);              // query rows per image this instantiation is launched for
     constexpr int MT = (G * LQM + 15) / 16;
     constexpr size_t body = (W * VR * RB_VROW * 2 > MT * 16384) ? W * VR * RB_VROW * 2 : MT * 16384;
-    constexpr size_t lds = body + 2048 + 256;
+    constexpr size_t lds = body + 2048 + 256 + (PJ ? W * 16 * 144 + W * MT * 16 * 8 + 4096 : 0);
+    static_assert(lds <= 160 * 1024, "fits a CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_attn_kernel<NQT, NKT, NR, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_attn_kernel<NQT, NKT, NR, W, PJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return BOFI_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL((rb_attn_kernel<NQT, NKT, NR, W>), dim3((a.B + G - 1) / G), dim3(W * 64), lds, st, a);
+    hipLaunchKernelGGL((rb_attn_kernel<NQT, NKT, NR, W, PJ>), dim3((a.B + G - 1) / G), dim3(W * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
 }
 
@@ -1127,6 +1195,13 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
     // the filling pass too, +1.3 % on the headline, profiles/r05_weight_bytes_ab.txt; a launch that runs alone keeps the 8-wavefront form)
     const int w = wenv ? wenv : (a.Lq <= 20 && a.alone ? 8 : 16);
     int rc;
+    if (a.pj_wp) {                                              // with the projection tail: the 16-wavefront form of the filling pass's self-attention only
+        if (!a.pj_c || !a.pj_cs || !a.pj_y || a.pj_ldy % 4 || a.yb || a.stats_out) return BOFI_ERR_ARG;
+        if (a.Lq > 20 || a.Lk > 32) return -1;
+        rc = launch_rb_attn_t<2, 2, 2, 16, true>(a, st);
+        if (rc == BOFI_OK) g_gemm_flops += 2 * 2.0 * a.B * a.Lq * 512.0 * 512.0;
+        return rc;
+    }
     if (w == 16) {
         if (a.Lq <= 20 && a.Lk <= 32) rc = launch_rb_attn_t<2, 2, 2, 16>(a, st);       // 4 images of <= 20 rows per workgroup
         else if (a.Lq <= 20) rc = launch_rb_attn_t<2, 4, 2, 16>(a, st);
@@ -1670,6 +1745,20 @@ extern "C" int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, c
     a.wop = (const bofi::u32x4*)wop; a.bo = bo; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.yb = (bofi::bf16_t*)yb; a.stats_out = stats_out;
     { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.alone = 1;                                               // (the direct entry: a launch of its own; BOFI_RB_ATTN_W picks the other form)
+    const int rc = bofi::launch_rb_attn(a, (hipStream_t)stream);
+    return rc < 0 ? BOFI_ERR_ARG : rc;
+}
+
+extern "C" int bofi_attn_linear_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen, int klen_sb,
+                                      int klen_bias, int klen_shared_last, const void* wop, const float* bo, float* x, int ldx, const void* pj_wp, const float* pj_c,
+                                      const float* pj_cs, void* pj_y, int pj_ldy, void* stream) {
+    if (!pj_wp) return BOFI_ERR_ARG;
+    bofi::RbAttnArgs a{};
+    a.q = (const bofi::bf16_t*)q; a.ldq = ldq; a.k = (const bofi::bf16_t*)k; a.ldk = ldk; a.v = (const bofi::bf16_t*)v; a.ldv = ldv;
+    a.B = B; a.Lq = Lq; a.Lk = Lk; a.klen = klen; a.klen_sb = klen_sb; a.klen_sq = 0; a.klen_bias = klen_bias; a.klen_shared_last = klen_shared_last;
+    a.wop = (const bofi::u32x4*)wop; a.bo = bo; a.x = x; a.ldx = ldx; a.y = x; a.ldy = ldx;
+    a.pj_wp = (const bofi::u32x4*)pj_wp; a.pj_c = pj_c; a.pj_cs = pj_cs; a.pj_y = (bofi::bf16_t*)pj_y; a.pj_ldy = pj_ldy;
+    { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int rc = bofi::launch_rb_attn(a, (hipStream_t)stream);
     return rc < 0 ? BOFI_ERR_ARG : rc;
 }

@@ -454,6 +454,13 @@ int bofi_linear_block(const float* x, int ldx, const void* wp, const float* c, c
 int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen,
                     int klen_sb, int klen_sq, int klen_bias, int klen_shared_last, const void* wop, const float* bo, const float* x,
                     int ldx, float* y, int ldy, void* yb, float* stats_out, void* stream);
+/* bofi_attn_linear_block: bofi_attn_block (in place, one key count per image, Lq <= 20, Lk <= 32: the filling pass's self-attention) followed by bofi_linear_block
+ *   (N = 512) on its output, ONE launch -- the decoder layer's self-attention sublayer and the LayerNorm-folded query projection of its cross-attention
+ *   (TransformerModel.py:1408-1413 around :1454-1456): x as bofi_attn_block's y, pj_y bf16 [B*Lq, pj_ldy] = W_pj' LN(x) + c_pj.  Each 80-row block (four images per
+ *   workgroup) is projected while it sits in LDS; the projection differs from the two-launch form in the summation order of the row statistics. */
+int bofi_attn_linear_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen, int klen_sb,
+                           int klen_bias, int klen_shared_last, const void* wop, const float* bo, float* x, int ldx, const void* pj_wp, const float* pj_c,
+                           const float* pj_cs, void* pj_y, int pj_ldy, void* stream);
 /* bofi_decoder_attn_block: BOTH attention sublayers of a decoder layer of the filling pass, ONE launch (DecoderLayer.forward TransformerModel.py:1398-1413:
  *   x <- x + self_attn(LN x); x <- x + src_attn(LN x, memory) -- sublayers 0 and 1 around MultiHeadedAttention.forward :1454-1467):
  *   y1 = x + W_o1 selfattn(q, k, v) + b_o1 with q | k | v = qkv[:, 0:512 | 512:1024 | 1024:1536] (bf16 [B*S, ldqkv], the LayerNorm-folded projection of x that the

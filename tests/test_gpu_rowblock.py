@@ -429,3 +429,51 @@ def test_decoder_attn_block_is_the_three_launches(H, B, S, R, masks):
                                           None, None, H.stream_ptr()))
         torch.cuda.synchronize()
         assert torch.equal(xc.cpu(), xb.cpu()[keep])
+
+
+@pytest.mark.parametrize("B,S,masks", [(9, 20, "q1"), (64, 20, "none"), (6, 17, "q1"), (3, 5, "none"), (5, 16, "q1")])
+def test_attn_linear_block_is_the_two_launches(H, B, S, masks):
+    """bofi_attn_linear_block (rb_attn_kernel<2, 2, 2, 16, PJ>: the filling pass's self-attention sublayer with the cross-attention's folded query projection as a tail on
+    each 80-row block): the residual stream is bofi_attn_block's bit for bit; the projection against bofi_linear_block on that stream (they differ in the summation order of
+    the row statistics) and against the float64 reference."""
+    d = 512
+    g = _rng(B * 77 + S)
+    qkv = torch.randn(B * S, 3 * d, generator=g).to(torch.bfloat16)
+    wo, bo = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g) * 0.1
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    wq, bq = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g) * 0.1
+    wqf, cq, csq = _fold(wq, bq, gain, bln)
+    x = torch.randn(B * S, d, generator=g)
+    klen_t, kl_bias, shared, kl_sb = None, 0, 0, 0
+    if masks == "q1":
+        last = torch.randint(2, S + 2, (B,), generator=g)
+        if B > 4:
+            last[3] = 1                                                          # images 0..3 without keys: NaN rows
+        klen_t, kl_bias, shared, kl_sb = last.int(), -1, 4, 1
+    qd = qkv.cuda()
+    wop, wqp = pack_frag(H, wo.to(torch.bfloat16).cuda()), pack_frag(H, wqf.to(torch.bfloat16).cuda())
+    boc, cqc, csqc = bo.cuda(), cq.cuda(), csq.cuda()
+    klc = None if klen_t is None else klen_t.cuda()
+    L = H.lib()
+    xa, xb = x.cuda(), x.cuda()
+    qa = torch.full((B * S, d + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    qb = torch.full((B * S, d + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    H.check(L.bofi_attn_block(H.ptr(qd), 3 * d, H.ptr(qd[:, d:]), 3 * d, H.ptr(qd[:, 2 * d:]), 3 * d, B, S, S, H.ptr(klc), kl_sb, 0, kl_bias, shared, H.ptr(wop), H.ptr(boc),
+                              H.ptr(xa), d, H.ptr(xa), d, None, None, H.stream_ptr()))
+    H.check(L.bofi_linear_block(H.ptr(xa), d, H.ptr(wqp), H.ptr(cqc), H.ptr(csqc), H.ptr(qa), d + 8, 0, B * S, d, 0, H.stream_ptr()))
+    H.check(L.bofi_attn_linear_block(H.ptr(qd), 3 * d, H.ptr(qd[:, d:]), 3 * d, H.ptr(qd[:, 2 * d:]), 3 * d, B, S, S, H.ptr(klc), kl_sb, kl_bias, shared, H.ptr(wop), H.ptr(boc),
+                                     H.ptr(xb), d, H.ptr(wqp), H.ptr(cqc), H.ptr(csqc), H.ptr(qb), d + 8, H.stream_ptr()))
+    torch.cuda.synchronize()
+    ya, yb = xa.cpu(), xb.cpu()
+    nan = torch.isnan(ya)
+    assert torch.equal(torch.isnan(yb), nan) and torch.equal(ya[~nan], yb[~nan])             # the stream: bit for bit
+    if masks == "q1" and B > 4:
+        assert nan[:4 * S].all() and not nan[4 * S:].any()
+    rows_ok = ~nan.any(1)
+    pa, pb = qa.cpu().float(), qb.cpu().float()
+    assert (pa[:, d:] == 7.0).all() and (pb[:, d:] == 7.0).all()                              # the pad columns stay untouched
+    assert (pa[rows_ok, :d] - pb[rows_ok, :d]).abs().max() < 6e-2                             # one bf16 step at |q| ~ 4
+    assert ((pa[rows_ok, :d] - pb[rows_ok, :d]) != 0).float().mean() < 0.05
+    ref = _layer_norm64(ya[rows_ok], gain, bln) @ (_bf(wqf).double() / gain.double()[None, :]).T + bq.double()
+    assert (pb[rows_ok, :d].double() - ref).abs().max() < 6e-2
+    assert torch.isnan(pb[~rows_ok, :d]).all()
