@@ -117,6 +117,6 @@ int launch_saic_put_words(const BoundState& st, const SaicState& sa, const int64
 int launch_saic_export(const BoundState& st, const SaicState& sa, int B, int L, int S, int64_t* seq, int* phrase_num,
                        int* phrase_length, int64_t* phrase_syn, int* iters, hipStream_t s);
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,
-                      int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s);
+                      int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s, const void* qkv_tab = nullptr, void* qkv_out = nullptr, int nq = 0);
 
 }  // namespace bofi

@@ -87,6 +87,10 @@ struct bofi_engine {
     // the persistent bounding-loop kernel (bound_loop.hip; bf16 engine at the reference's width): float32 tables of the row-0 self-attention
     Lin b_heads;                                  // hidden layers of both heads stacked, length_predictor.norm folded in (its wp16 and folded bias are what the loop kernel reads)
     float *b_q0_32 = nullptr, *b_sctab = nullptr, *b_vtab = nullptr;      // [d], [L*10][H], [L*10][d]
+    // filling pass, round 0: every word is BOS (decode_NA TransformerModel.py:570-577), so the first decoder layer's input row -- and with it its q|k|v row -- depends on
+    // (label, position) only: f_qkv0[(label*S + t)][3d] in the compute dtype, made by the SAME row-block projection kernel a decode would run on those rows (a row's
+    // result does not depend on the launch), gathered by embed_fill instead of a 10-GFLOP projection per 320 images.  Rebuilt by finalize / refresh_device.
+    void* f_qkv0 = nullptr; float* f_x0 = nullptr; int* f_syn = nullptr; bool fill_tab_ready = false;
     bool loop_ready = false;
     float* dbg_part = nullptr;
 
@@ -320,6 +324,18 @@ struct bofi_engine {
     int derive_bound_tables(hipStream_t s) {
         ENG_OK(bofi::launch_pack_w1p(heads.w1t, b_w1p, cfg.dtype, cfg.d_model, 2 * cfg.head_hidden, s));
         ENG_OK(bofi::launch_votab(b_kvtab, b_o_self.w, b_x0, b_o_self.b, b_votab, b_x0b, cfg.dtype, L * 10, cfg.d_model, cfg.heads, s));
+        return derive_fill_table(s);
+    }
+    int derive_fill_table(hipStream_t s) {
+        fill_tab_ready = false;
+        if (!f_qkv0 || !rb_ok() || dec.empty() || !dec[0].qkv.wp || !dec[0].qkv.cs || dec[0].qkv.Npad != 3 * cfg.d_model) return BOFI_OK;
+        const int d = cfg.d_model, S = cfg.seq_length;
+        // the input rows of 10 pseudo-images whose slots all carry one label, then their q|k|v by the row-block projection kernel
+        ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, f_syn, nullptr, 10, S, L, d, cfg.bos_idx, f_x0, nullptr, cfg.dtype, nullptr, s));
+        bofi::RbGemmArgs a{};
+        a.x = f_x0; a.ldx = d; a.wp = (const bofi::u32x4*)dec[0].qkv.wp; a.c = dec[0].qkv.b; a.cs = dec[0].qkv.cs; a.y = f_qkv0; a.ldy = 3 * d; a.y_f32 = 0; a.M = 10 * S; a.N = 3 * d;
+        ENG_OK(bofi::launch_rb_gemm(a, s));
+        fill_tab_ready = true;
         return BOFI_OK;
     }
     // ---- the persistent bounding-loop kernel's operands: fp16 fragment-major copies of the bounding layer's Linears and the float32 self-attention
@@ -720,9 +736,11 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     const int gen_pad = BOFI_ENV_INT("BOFI_GEN_PAD", 1);      // developer knob: 0 = in place, one-tile kernel
     const bool gen_rb = gen_pad && logits_pad && fold_rb_ok(gen, M);
     for (int round = 0; round < rounds; ++round) {
+    // (round 0 under the row-block family: layer 0's q|k|v rows come out of the (label, position) table with the embedding launch -- BOFI_FILL_QKV_TAB=0: the projection)
+    const bool qkv_tab = round == 0 && fill_tab_ready && !dec.empty() && fold_rb_ok(dec[0].qkv, M) && BOFI_ENV_INT("BOFI_FILL_QKV_TAB", 1) != 0 && !exp_skip("qkv");
     ENG_OK(bofi::launch_embed_fill(lut_tok, lut_syn, pe, st.ext_syn, round ? seq : nullptr, B, S, L, d, cfg.bos_idx, x_fill, copy_t(xb_fill), dt,
-                                   st_fill, s));
-    bool proj_made = false;                              // this layer's q|k|v came out of the previous layer's feed-forward launch
+                                   st_fill, s, qkv_tab ? f_qkv0 : nullptr, qkv_tab ? qkv : nullptr, 3 * d));
+    bool proj_made = qkv_tab;                            // this layer's q|k|v came out of the previous layer's feed-forward launch (layer 0: out of the table)
     for (size_t li = 0; li < dec.size(); ++li) {
         auto& l = dec[li];
         if (!proj_made) {
@@ -1372,6 +1390,14 @@ int bofi_engine_finalize(bofi_engine_t* e) {
             ENG_OK(e->make_lin(&e->b_heads, {lp + ".Length_classifier1", lp + ".Syntactic_classifier1"}, hh, d, lp + ".norm", 256));
             for (Lin* l : {&e->b_o_self, &e->b_q_src, &e->b_o_src, &e->b_w1, &e->b_w2, &e->b_heads}) ENG_OK(e->dalloc((char**)&l->wp16, (size_t)l->Npad * l->K, 2));
             ENG_OK(e->dalloc(&e->b_q0_32, (size_t)d)); ENG_OK(e->dalloc(&e->b_sctab, (size_t)L * 10 * c.heads)); ENG_OK(e->dalloc(&e->b_vtab, (size_t)L * 10 * d));
+        }
+        if (e->rb_ok()) {               // the filling pass's layer-0 q|k|v by (label, position) (derive_fill_table)
+            ENG_OK(e->dalloc((char**)&e->f_qkv0, (size_t)10 * c.seq_length * 3 * d, e->tsz));
+            ENG_OK(e->dalloc(&e->f_x0, (size_t)10 * c.seq_length * d));
+            ENG_OK(e->dalloc((char**)&e->f_syn, (size_t)10 * L, sizeof(int)));
+            std::vector<int> pat((size_t)10 * L);
+            for (int b = 0; b < 10; ++b) for (int t = 0; t < L; ++t) pat[(size_t)b * L + t] = b;
+            ENG_HIP(hipMemcpy(e->f_syn, pat.data(), pat.size() * sizeof(int), hipMemcpyHostToDevice));
         }
     }
 

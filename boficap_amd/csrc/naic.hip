@@ -457,7 +457,8 @@ template <typename T>
 __global__ __launch_bounds__(128) void embed_fill_kernel(const float* __restrict__ lut_tok, const float* __restrict__ lut_syn,
                                                          const float* __restrict__ pe, const int* __restrict__ ext_syn,
                                                          const int64_t* tok, int B, int S, int L, int d, int bos_idx, float sqrt_d,
-                                                         float* __restrict__ x, T* __restrict__ xt, float* __restrict__ stats) {
+                                                         float* __restrict__ x, T* __restrict__ xt, float* __restrict__ stats,
+                                                         const T* __restrict__ qkv_tab, T* __restrict__ qkv_out, int nq) {
     const int row = blockIdx.x;                       // (b, t)
     const int b = row / S, t = row - b * S;
     const int syn = ext_syn[b * L + t + 1];           // extend_phrase_syn[:, 1:-1]
@@ -476,18 +477,23 @@ __global__ __launch_bounds__(128) void embed_fill_kernel(const float* __restrict
             if ((threadIdx.x & 31) == 0) reinterpret_cast<float2*>(stats)[(size_t)row * (d >> 5) + (k >> 5)] = make_float2(ps, pq);
         }
     }
+    if (qkv_tab) {                                    // layer 0's q|k|v row of (label, position): word = BOS everywhere in this call
+        const u32x4* src = reinterpret_cast<const u32x4*>(qkv_tab + ((size_t)syn * S + t) * nq);
+        u32x4* dst = reinterpret_cast<u32x4*>(qkv_out + (size_t)row * nq);
+        for (int k = threadIdx.x; k < nq * (int)sizeof(T) / 16; k += 128) dst[k] = src[k];
+    }
 }
 
 int launch_embed_fill(const float* lut_tok, const float* lut_syn, const float* pe, const int* ext_syn, const int64_t* tok,
-                      int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s) {
-    if (d % 128) return BOFI_ERR_ARG;
+                      int B, int S, int L, int d, int bos_idx, float* x, void* xt, int dtype, float* stats, hipStream_t s, const void* qkv_tab, void* qkv_out, int nq) {
+    if (d % 128 || (qkv_tab && (tok || !qkv_out || nq % 8))) return BOFI_ERR_ARG;
     const float sqrt_d = (float)sqrt((double)d);
     if (dtype == BOFI_DT_F32)
         hipLaunchKernelGGL((embed_fill_kernel<float>), dim3(B * S), dim3(128), 0, s, lut_tok, lut_syn, pe, ext_syn, tok, B, S, L, d,
-                           bos_idx, sqrt_d, x, (float*)xt, stats);
+                           bos_idx, sqrt_d, x, (float*)xt, stats, (const float*)qkv_tab, (float*)qkv_out, nq);
     else
         hipLaunchKernelGGL((embed_fill_kernel<bf16_t>), dim3(B * S), dim3(128), 0, s, lut_tok, lut_syn, pe, ext_syn, tok, B, S, L, d,
-                           bos_idx, sqrt_d, x, (bf16_t*)xt, stats);
+                           bos_idx, sqrt_d, x, (bf16_t*)xt, stats, (const bf16_t*)qkv_tab, (bf16_t*)qkv_out, nq);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }

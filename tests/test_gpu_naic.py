@@ -667,6 +667,57 @@ def test_projection_tail_of_the_feed_forward_kernel_changes_launches_not_results
         H.lib().bofi_reload_env()
 
 
+def test_layer0_qkv_table_of_the_filling_pass_changes_launches_not_results(engines):
+    """BOFI_FILL_QKV_TAB: in the filling pass's first round every word is BOS, so decoder layer 0's q|k|v row depends on (label, position) only -- a 200-row table made
+    by the row-block projection kernel at finalize / refresh, gathered by the embedding launch -- against the projection launch on all B * 20 rows: bit for bit (a row's
+    result does not depend on the launch), also in-flight forms, after a weight refresh (the table is rebuilt) and with refinement rounds (rounds >= 1 read tokens: the
+    projection runs there)."""
+    from boficap_amd import hip as H
+    from boficap_amd import weights as W
+    import os
+    cfg, sd, eng = engines("full_b8", torch.bfloat16)
+    att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=78)).cuda().to(torch.bfloat16)
+    os.environ["BOFI_RB_MIN_ROWS"] = "0"
+    keys = ("seq", "phrase_length", "phrase_syn", "seq_logprob")
+    try:
+        for hint, rounds in ((1, 0), (4, 0), (4, 2)):
+            eng.set_decodes_in_flight(hint)
+            outs = {}
+            for v in ("0", "1"):
+                os.environ["BOFI_FILL_QKV_TAB"] = v
+                H.lib().bofi_reload_env()
+                H.gemm_flops(reset=True)
+                r = eng.decode_naic(att, strict_q1=False, graph=False, refine_rounds=rounds)
+                torch.cuda.synchronize()
+                outs[v] = ({k: r[k].clone() for k in keys}, H.gemm_flops(reset=True)[0])
+            for k in keys:
+                assert torch.equal(outs["0"][0][k].nan_to_num() if outs["0"][0][k].is_floating_point() else outs["0"][0][k],
+                                   outs["1"][0][k].nan_to_num() if outs["1"][0][k].is_floating_point() else outs["1"][0][k]), (hint, rounds, k)
+            assert outs["1"][1] < outs["0"][1]                                  # (the table path did run: one projection less in the tally)
+        # after a device-side weight refresh with OTHER weights the table is the new weights' (a stale one would change the log-probs by whole units)
+        from boficap_amd.engine import BofiEngine
+        sd2 = W.make_state_dict(cfg, seed=0)
+        rng = np.random.default_rng(1)
+        for k in ("model.decoder.layers.0.self_attn.linears.0.weight", "model.decoder.layers.0.self_attn.linears.2.weight", "model.syn_embed.lut.weight"):
+            sd2[k] = (sd2[k] + 0.05 * rng.standard_normal(sd2[k].shape)).astype(np.float32)
+        e2 = BofiEngine(cfg, torch.bfloat16, max_batch=64, max_regions=36)
+        e2.load_state_dict(sd)
+        e2.refresh_from_device({k: torch.from_numpy(v).cuda() for k, v in sd2.items()})
+        outs = {}
+        for v in ("0", "1"):
+            os.environ["BOFI_FILL_QKV_TAB"] = v
+            H.lib().bofi_reload_env()
+            r = e2.decode_naic(att, strict_q1=False, graph=False)
+            torch.cuda.synchronize()
+            outs[v] = r["seq_logprob"].clone()
+        assert torch.equal(outs["0"].nan_to_num(), outs["1"].nan_to_num())
+    finally:
+        os.environ.pop("BOFI_RB_MIN_ROWS")
+        os.environ.pop("BOFI_FILL_QKV_TAB", None)
+        H.lib().bofi_reload_env()
+        eng.set_decodes_in_flight(0)
+
+
 def test_decode_many_equals_one_decode_per_batch(weight_cache, monkeypatch):
     """TransformerModel.decode_many (engine forks in flight, several loader batches per launch with quirk Q1 per batch, features from pinned host memory on a
     copy stream) against one decode per batch on the same kernel family and hint: bit for bit, in input order, ragged batches and a short last batch included."""
