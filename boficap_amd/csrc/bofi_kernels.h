@@ -107,7 +107,8 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t st);     // attn_bf16.h
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias,
                           int pad_idx, int64_t* seq, hipStream_t st, int* nan_flag = nullptr, const int* halt = nullptr,
                           const int* row_idx = nullptr, const int* n_rows = nullptr,      // row list: rows row_idx[0 .. *n_rows) only
-                          const float* src = nullptr, int ld_src = 0);                   // src: the logits are read from src (row pitch ld_src), results go to `logits` (pitch V)
+                          const float* src = nullptr, int ld_src = 0,                    // src: the logits are read from src (row pitch ld_src), results go to `logits` (pitch V)
+                          float* row_plogp = nullptr, float* row_chosen = nullptr);      // optional (log_softmax != 0): per row sum_v p log p and the log-prob of the emitted id (what bofi_vocab_stats reads back out of the tensor)
 
 // ---- row-block sublayer kernels (rowblock.hip): bf16, d_model 512, weights in the fragment-major layout of launch_rb_pack_frag
 typedef __attribute__((ext_vector_type(4))) uint32_t rb_u32x4;

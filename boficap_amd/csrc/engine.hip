@@ -91,6 +91,9 @@ struct bofi_engine {
     // (label, position) only: f_qkv0[(label*S + t)][3d] in the compute dtype, made by the SAME row-block projection kernel a decode would run on those rows (a row's
     // result does not depend on the launch), gathered by embed_fill instead of a 10-GFLOP projection per 320 images.  Rebuilt by finalize / refresh_device.
     void* f_qkv0 = nullptr; float* f_x0 = nullptr; int* f_syn = nullptr; bool fill_tab_ready = false;
+    // per-call (bofi_engine_set_row_stats_out; part of the graph key): where the filling pass's epilogue leaves, per position, sum_v p log p and the log-prob of the
+    // emitted id -- eval's entropy / perplexity (eval_utils.py:463-464) without a second pass over the log-probs
+    float *row_plogp_out = nullptr, *row_chosen_out = nullptr;
     bool loop_ready = false;
     float* dbg_part = nullptr;
 
@@ -819,7 +822,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
     const int ids_only_on = BOFI_ENV_INT("BOFI_REFINE_IDS_ONLY", 1);      // developer knob: 0 = every round stores its log-probs
     const int lsm = (flags & BOFI_FLAG_RAW_LOGITS) ? 0 : ((ids_only_on && round + 1 < rounds && lsrc) ? 2 : 1);
     ENG_OK(bofi::launch_vocab_finalize(lg, M, cfg.vocab, S, lsm, st.last, -1, cfg.pad_idx, seq, s, nullptr, nullptr, nullptr, nullptr,
-                                       lsrc, gen.Npad));
+                                       lsrc, gen.Npad, lsm ? row_plogp_out : nullptr, lsm ? row_chosen_out : nullptr));
     }
     return BOFI_OK;
 }
@@ -1054,6 +1057,7 @@ int bofi_engine_fork_sized(bofi_engine_t* parent, int max_batch, bofi_engine_t**
     e->sample_temperature = 1.0f;
     e->sample_seed = 0;
     e->bound_iter_cap = 0;                       // (a capped parent must not truncate the fork's bounding loop)
+    e->row_plogp_out = nullptr; e->row_chosen_out = nullptr;
     e->in_flight = 0;
     e->live_max = nullptr;                       // (a raw device pointer the fork's handle does not keep alive)
     e->saic_it_begin = 1;
@@ -1256,6 +1260,13 @@ int bofi_engine_set_sampling(bofi_engine_t* e, float temperature, uint64_t seed)
     if (!e || !(temperature > 0.f)) return fail(BOFI_ERR_ARG, "temperature must be positive");
     e->sample_temperature = temperature;
     e->sample_seed = seed;
+    return BOFI_OK;
+}
+
+int bofi_engine_set_row_stats_out(bofi_engine_t* e, float* row_plogp, float* row_chosen) {
+    if (!e || (!row_plogp != !row_chosen)) return fail(BOFI_ERR_ARG, "row statistics: both buffers or none");
+    e->row_plogp_out = row_plogp;
+    e->row_chosen_out = row_chosen;
     return BOFI_OK;
 }
 
@@ -1561,7 +1572,7 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
                                   (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max, (uintptr_t)e->in_flight,
-                                  (uintptr_t)bofi::g_env_generation};
+                                  (uintptr_t)bofi::g_env_generation, (uintptr_t)e->row_plogp_out, (uintptr_t)e->row_chosen_out};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, cs);

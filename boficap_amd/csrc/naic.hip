@@ -706,9 +706,11 @@ template <int NPT>   // values per thread held in registers: V <= 512 * NPT (one
 __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__ logits, int V, int S, int log_softmax,
                                                              const int* ntok, int ntok_bias, int pad_idx, int64_t* seq,
                                                              int* nan_flag, const int* halt, const int* row_idx, const int* n_rows,
-                                                             const float* __restrict__ src, int ld_src) {
+                                                             const float* __restrict__ src, int ld_src, float* __restrict__ row_plogp,
+                                                             float* __restrict__ row_chosen) {
     __shared__ float red[16];
     __shared__ int redi[16];
+    __shared__ float s_tpad;                                    // the log-prob at pad_idx (the emitted id of a row past the image's token count)
     if (halt && *halt >= 1) return;
     if (n_rows && (int)blockIdx.x >= *n_rows) return;           // row list: rows row_idx[0 .. *n_rows) only
     const int row = row_idx ? row_idx[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -733,15 +735,22 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
 #pragma unroll
     for (int w = 1; w < 8; ++w) { m = fmaxf(m, red[w]); first_nan = min(first_nan, redi[w]); }
     __syncthreads();
-    float lse = 0.f;
+    float lse = 0.f, plogp = 0.f;
     if (log_softmax) {
-        float s = 0.f;
+        float s = 0.f, u = 0.f;                                 // u: sum of e_i * (x_i - max) -- with it sum_i p_i log p_i = u / s - lse, no second exponential, no second pass
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) s += (tid + i * 512 < V) ? expf(v[i] - m) : 0.f;
+        for (int i = 0; i < NPT; ++i) {
+            const float e = (tid + i * 512 < V) ? expf(v[i] - m) : 0.f;
+            s += e;
+            if (row_plogp && tid + i * 512 < V) u += e * (v[i] - m);
+        }
         s = wave_sum(s);
-        if (lane == 0) red[wave] = s;
+        if (row_plogp) u = wave_sum(u);
+        if (lane == 0) { red[wave] = s; red[8 + wave] = u; }
         __syncthreads();
-        lse = logf(((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
+        const float sum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+        lse = logf(sum);
+        plogp = (((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]))) / sum - lse;
         __syncthreads();
     }
     float bv = -INFINITY;
@@ -758,6 +767,7 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
         } else if (src) {
             x[idx] = t;                                 // raw logits asked for: the copy to the caller's pitch
         }
+        if (row_chosen && idx == pad_idx) s_tpad = t;
         if (t > bv) { bv = t; bi = idx; }             // idx ascends per thread: first max kept
     }
 #pragma unroll
@@ -771,24 +781,29 @@ __global__ __launch_bounds__(512) void vocab_finalize_kernel(float* __restrict__
     if (tid == 0) {
         for (int w = 1; w < 8; ++w)
             if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
-        if (first_nan != 0x7fffffff) { bi = log_softmax ? 0 : first_nan; if (nan_flag) atomicOr(nan_flag, 1); }
+        if (first_nan != 0x7fffffff) { bi = log_softmax ? 0 : first_nan; bv = __builtin_nanf(""); if (nan_flag) atomicOr(nan_flag, 1); }
         if (bi == 0x7fffffff) bi = 0;                 // all -inf row: torch.max returns index 0
+        bool padded = false;
         if (ntok) {
             const int b = row / S, t = row - b * S;
-            if (t >= ntok[b] + ntok_bias) bi = pad_idx;
+            if (t >= ntok[b] + ntok_bias) { bi = pad_idx; padded = true; }
         }
         seq[row] = bi;
+        if (row_plogp && log_softmax) {                 // what bofi_vocab_stats computes from the finished tensor: sum_v p log p and the log-prob of the emitted id
+            row_plogp[row] = first_nan != 0x7fffffff ? __builtin_nanf("") : plogp;
+            row_chosen[row] = padded ? s_tpad : bv;
+        }
     }
 }
 
 int launch_vocab_finalize(float* logits, int rows, int V, int S, int log_softmax, const int* ntok, int ntok_bias, int pad_idx,
                           int64_t* seq, hipStream_t st, int* nan_flag, const int* halt, const int* row_idx, const int* n_rows, const float* src,
-                          int ld_src) {
-    if (!logits || !seq || rows < 0 || V <= 0 || S <= 0 || (src && ld_src < V)) return BOFI_ERR_ARG;
+                          int ld_src, float* row_plogp, float* row_chosen) {
+    if (!logits || !seq || rows < 0 || V <= 0 || S <= 0 || (src && ld_src < V) || (!row_plogp != !row_chosen) || (row_plogp && (pad_idx < 0 || pad_idx >= V))) return BOFI_ERR_ARG;
     if (rows == 0) return BOFI_OK;
-    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src);
-    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src);
-    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src);
+    if (V <= 512 * 4) hipLaunchKernelGGL((vocab_finalize_kernel<4>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src, row_plogp, row_chosen);
+    else if (V <= 512 * 20) hipLaunchKernelGGL((vocab_finalize_kernel<20>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src, row_plogp, row_chosen);
+    else if (V <= 512 * 64) hipLaunchKernelGGL((vocab_finalize_kernel<64>), dim3(rows), dim3(512), 0, st, logits, V, S, log_softmax, ntok, ntok_bias, pad_idx, seq, nan_flag, halt, row_idx, n_rows, src, ld_src, row_plogp, row_chosen);
     else return BOFI_ERR_ARG;
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;

@@ -167,7 +167,7 @@ class BofiEngine:
 
     def decode_naic(self, att_feats: torch.Tensor, att_len: Optional[torch.Tensor] = None, *, strict_q1: bool = True,
                     want_logprob: bool = True, want_memory: bool = False, raw_logits: bool = False, graph: bool = False,
-                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0, iter_cap: int = 0, phases: str = "") -> dict:
+                    refine_rounds: int = 0, out: Optional[dict] = None, q1_group: int = 0, iter_cap: int = 0, phases: str = "", row_stats: bool = False) -> dict:
         """Greedy NAIC bound+fill decode.  Returns a dict of device tensors: seq [B,S] int64,
         seq_logprob [B,S,V] float32 (or None), phrase_num [B] int32, phrase_length [B,S] int32,
         phrase_syn [B,S] int64, bound_iters [1] int32, memory [B,R,d] float32 (or None).
@@ -178,7 +178,9 @@ class BofiEngine:
         ``iter_cap`` > 0: enqueue that many bounding iterations instead of seq_length (bofi_engine_set_bound_iter_cap); the result is the
         reference's iff ``bound_iters`` < iter_cap afterwards -- the caller checks and decodes again without the cap otherwise.
         ``phases``: "" = the whole decode; a subset of "ebf" = only the encode / bounding loop / filling pass + export of it (BOFI_FLAG_PHASE_*): a pipelining
-        caller enqueues the three on the same engine in that order (its streams / events order them) with the same arguments."""
+        caller enqueues the three on the same engine in that order (its streams / events order them) with the same arguments.
+        ``row_stats``: the vocabulary epilogue also leaves, per position, sum_v p log p and the log-prob of the emitted id in ``out['row_plogp']`` / ``out['row_chosen']``
+        (float32 [B, S]; bofi_engine_set_row_stats_out) -- what ``row_stats(out)`` / ``entropy_perplexity(out)`` otherwise read back out of the log-prob tensor."""
         self._check_feats(att_feats, att_len)
         B, R, _ = att_feats.shape
         S, V, dev = self.cfg.seq_length, self.cfg.tgt_vocab, att_feats.device
@@ -193,6 +195,17 @@ class BofiEngine:
                 memory=torch.empty(B, R, self.cfg.d_model, dtype=torch.float32, device=dev) if want_memory else None)
         if not 0 <= refine_rounds <= 15:
             raise hip.BofiHipError("refine_rounds must be in 0..15")
+        if row_stats and raw_logits:
+            raise hip.BofiHipError("row_stats: of log-probs, not of raw logits")
+        if row_stats and "row_plogp" not in out:
+            out["row_plogp"] = torch.empty(B, S, dtype=torch.float32, device=dev)
+            out["row_chosen"] = torch.empty(B, S, dtype=torch.float32, device=dev)
+        rs = (out["row_plogp"].data_ptr(), out["row_chosen"].data_ptr()) if row_stats else (0, 0)
+        if rs != getattr(self, "_row_stats_ptrs", (0, 0)):
+            hip.check(self._lib.bofi_engine_set_row_stats_out(self._h, hip.ptr(out["row_plogp"]) if row_stats else None, hip.ptr(out["row_chosen"]) if row_stats else None),
+                      "bofi_engine_set_row_stats_out")
+            self._row_stats_ptrs = rs
+        out["_row_stats_fused"] = bool(row_stats)
         if q1_group != getattr(self, "_q1_group", 0):
             hip.check(self._lib.bofi_engine_set_q1_group(self._h, int(q1_group)), "bofi_engine_set_q1_group")
             self._q1_group = q1_group
@@ -233,6 +246,8 @@ class BofiEngine:
         from its seq_logprob tensor, or from the engine's own workspace when that was not materialised."""
         seq = out["seq"]
         B, S = seq.shape
+        if out.get("_row_stats_fused"):                          # the decode's own epilogue left them (decode_naic(row_stats=True))
+            return out["row_plogp"], out["row_chosen"]
         lp = out.get("seq_logprob")
         src = hip.ptr(lp) if lp is not None else self._lib.bofi_engine_logprob(self._h)
         plogp = torch.empty(B, S, dtype=torch.float32, device=seq.device)
@@ -461,7 +476,7 @@ class DecodePipeline:
         with torch.cuda.stream(st):
             st.wait_event(sl["copied"][p])
             sl["out"] = e.decode_naic(feats, lens, strict_q1=self.strict_q1, graph=True, out=sl["out"] if sl["out"] is not None and sl["out"]["seq"].shape[0] == rows else None,
-                                      q1_group=b if nb > 1 else 0)
+                                      q1_group=b if nb > 1 else 0, row_stats=self.stats)
             out = sl["out"]
             small = {k2: out[k2] for k2 in ("seq", "phrase_num", "phrase_length", "phrase_syn")}
             if self.stats:

@@ -96,6 +96,7 @@ SIGNATURES = {
     "bofi_pack_frag": (_I, [_P, _P, _I, _I, _P]),
     "bofi_attn_block": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "bofi_linear_block": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "bofi_engine_set_row_stats_out": (_I, [_P, _P, _P]),
     "bofi_attn_linear_block": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "bofi_decoder_attn_block": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "bofi_ffn_block": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),

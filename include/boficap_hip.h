@@ -349,6 +349,10 @@ int bofi_engine_set_live_iterations_max(bofi_engine_t* e, int* live_max);
  * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of
  * bofi_vocab_stats / bofi_vocab_sample when the 48.6 MB tensor is not wanted in user memory. */
 const float* bofi_engine_logprob(bofi_engine_t* e);
+/* The same two per-position figures straight out of a NAIC decode's vocabulary epilogue (no second pass over the [B, S, V] tensor): float32 [B * S] device buffers
+ * that every following bofi_engine_decode_naic of this engine fills (greedy decodes with log-softmax; NULL, NULL: off -- the default, also of a fork).  Per-call state,
+ * part of the graph key.  sum_v p log p is formed as sum_v e_v (x_v - max) / sum_v e_v - lse in the pass that sums the exponentials. */
+int bofi_engine_set_row_stats_out(bofi_engine_t* e, float* row_plogp, float* row_chosen);
 
 /* A HIP stream owned by the engine (hipStream_t as void*), for callers that keep one decode per engine in
  * flight and want each on its own hardware queue. */

@@ -363,6 +363,25 @@ def test_entropy_perplexity_without_materialising_logprobs(engines):
     assert r2["seq_logprob"] is None and torch.equal(r2["seq"], seq)
     ent2, ppl2 = eng.entropy_perplexity(r2)
     assert _close(ent2.cpu().numpy(), ent_ref.cpu().numpy(), 0) < 1e-4 and _close(ppl2.cpu().numpy(), ppl_ref.cpu().numpy(), 0) < 1e-4
+    # ... and straight out of the decode's vocabulary epilogue (bofi_engine_set_row_stats_out: no second pass over the tensor), eager and replayed, with refinement
+    # rounds, with the log-probs materialised or not; the per-position figures against the read-back kernel's
+    for kw in (dict(), dict(want_logprob=False), dict(graph=True), dict(refine_rounds=1)):
+        plain = eng.decode_naic(att, att_len, **kw)
+        p_ref, c_ref = eng.row_stats(plain)
+        p_ref, c_ref = p_ref.clone(), c_ref.clone()
+        r3 = eng.decode_naic(att, att_len, row_stats=True, **kw)
+        if kw.get("graph"):
+            r3 = eng.decode_naic(att, att_len, row_stats=True, out=r3, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(r3["seq"], plain["seq"]) and r3["_row_stats_fused"]
+        p3, c3 = eng.row_stats(r3)
+        assert p3.data_ptr() == r3["row_plogp"].data_ptr()
+        assert float((p3 - p_ref).abs().max()) < 2e-5 and torch.equal(c3, c_ref)
+        if not kw:
+            ent3, ppl3 = eng.entropy_perplexity(r3)
+            assert _close(ent3.cpu().numpy(), ent_ref.cpu().numpy(), 0) < 1e-4 and _close(ppl3.cpu().numpy(), ppl_ref.cpu().numpy(), 0) < 1e-4
+    r4 = eng.decode_naic(att, att_len)                          # (off again: the next plain decode leaves the buffers alone)
+    assert not r4["_row_stats_fused"]
 
 
 def test_sampled_tokens_follow_the_fill_distribution(weight_cache, manifest):
@@ -763,7 +782,9 @@ def test_decode_many_equals_one_decode_per_batch(weight_cache, monkeypatch):
             assert torch.equal(r[k], w[k].cpu()), (i, k)
         a, c = r["seq_logprob"].cpu(), w["seq_logprob"].cpu()
         assert torch.equal(a.isnan(), c.isnan()) and torch.equal(a.nan_to_num(), c.nan_to_num()), i
-        assert torch.equal(r["entropy"].isnan(), ent.cpu().isnan()) and torch.equal(r["entropy"].nan_to_num(), ent.cpu().nan_to_num())
+        # (the pipeline's entropy comes out of the vocabulary epilogue -- sum e (x - max) / sum e - lse --, the reference engine's here out of the read-back kernel --
+        # sum exp(logp) logp --: the same figure up to float32 rounding; the emitted ids' log-probs are the same bits)
+        assert torch.equal(r["entropy"].isnan(), ent.cpu().isnan()) and float((r["entropy"].nan_to_num() - ent.cpu().nan_to_num()).abs().max()) <= 1e-5 * float(ent.nan_to_num().abs().max())
         assert torch.equal(r["perplexity"].nan_to_num(), ppl.cpu().nan_to_num())
     # again through the same pipeline (replayed graphs, reused buffers): the same results
     again = list(model.decode_many(items, batches_per_launch=3, in_flight=2))
