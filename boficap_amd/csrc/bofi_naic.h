@@ -76,6 +76,7 @@ struct BoundLoopArgs {
     int max_iters;                                        // iterations at most (seq_length; 1 for the stage API)
     int update;                                           // apply the slot bookkeeping and loop until the group's images are finished
     int dbg;                                              // developer aid (BOFI_BL_DBG = i + 1: in-kernel stamps of iteration i), set by the launcher
+    int xcds;                                             // 1..8 (BOFI_BL_XCDS, set by the launcher): the groups' workgroups on that many of the eight XCDs (8: every workgroup takes a group)
 };
 int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s);
 struct Pack16Entry { const float* w[2]; const float* gain; void* out; int n_each, nsrc, K, Npad, blk0; };      // blk0: set by the launcher
