@@ -663,6 +663,43 @@ static int fill_crit(UicCritArgs& a, const float* sa_len, const float* sa_syn, c
     return BOFI_OK;
 }
 
+// The loader's phrase-aware collate of SAMPLED captions (captioning/data/dataloader.py:343-428, the semi-autoregressive half: boficap_amd.collate.phrase_collate's
+// index arithmetic) as one launch: thread (n, t) -> the decoder input token, label and key count of position t of caption n.  What the self-critical step's per-phrase
+// forwards read (xe.rl_prepare_saic_device, whose tensor-op form is the test's reference: 35 launches inside every replayed forward).
+__global__ __launch_bounds__(256) void saic_collate_kernel(const int64_t* __restrict__ seq, const int* __restrict__ plen, const int64_t* __restrict__ psyn, int N, int S,
+                                                           int bos_idx, int64_t* __restrict__ sa_syn, int64_t* __restrict__ sa_seq, int* __restrict__ sa_klen) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * S) return;
+    const int n = i / S, t = i - n * S, L = S + 2;
+    const int* pl = plen + (size_t)n * S;
+    int ntok = 0, pid = 0;
+    for (int j = 0; j < S; ++j) { ntok += pl[j]; if (ntok <= t) ++pid; }          // phrases that end at or before t
+    pid = min(pid, S - 1);
+    int start = 0;
+    for (int j = 0; j < pid; ++j) start += pl[j];
+    const int cur = pl[pid], end = start + cur, k = t - start;
+    const bool valid = t < ntok, first = pid == 0;
+    const int prev = first ? 1 : pl[pid - 1];
+    const int prev_start = first ? 0 : 1 + (start - pl[pid - 1]);
+    const int cur_s = max(cur, 1), prev_s = max(prev, 1), times = cur_s / prev_s, pre_less = prev_s - cur_s % prev_s;
+    const int stretched = k < pre_less * times ? k / max(times, 1) : pre_less + (k - pre_less * times) / (times + 1);
+    const int src = cur <= prev ? prev - cur + k : stretched;
+    const int idx = min(max(prev_start + src, 0), L - 1);                           // position in [BOS, the S sampled tokens, 0]
+    const int64_t word = idx == 0 ? (int64_t)bos_idx : (idx <= S ? seq[(size_t)n * S + idx - 1] : 0);
+    sa_seq[i] = valid ? word : 0;
+    sa_syn[i] = valid && cur > 0 ? psyn[(size_t)n * S + pid] : 0;
+    sa_klen[i] = valid ? end : ntok;
+}
+
+extern "C" int bofi_saic_collate(const int64_t* seq, const int* phrase_length, const int64_t* phrase_syn, int N, int S, int bos_idx, int64_t* sa_syn, int64_t* sa_seq,
+                                 int* sa_klen, void* stream) {
+    if (!seq || !phrase_length || !phrase_syn || !sa_syn || !sa_seq || !sa_klen || N < 0 || S < 1) return BOFI_ERR_ARG;
+    if (N == 0) return BOFI_OK;
+    hipLaunchKernelGGL(saic_collate_kernel, dim3((N * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, seq, phrase_length, phrase_syn, N, S, bos_idx, sa_syn, sa_seq, sa_klen);
+    BOFI_CHECK_LAUNCH();
+    return BOFI_OK;
+}
+
 extern "C" int bofi_uic_criterion(const float* sa_len, const float* sa_syn, const float* na_len, const float* na_syn, int N, int Pm, int c_len,
                                   int c_syn, const int64_t* phrase_num, const int64_t* phrase_length, const int64_t* phrase_syn, int L,
                                   const float* picked, const float* w_sa, const float* w_na, int T, float* out8, void* stream) {

@@ -902,7 +902,7 @@ class XETrainer:
             drawn.copy_(torch.where(mask, lpf.gather(2, tok[..., None]).squeeze(2), drawn))
 
         try:
-            prep_na = xe.rl_prepare(cfg, None, na, sample_n=sample_n, strict_q1=model.strict_reference, device=dev)
+            prep_na = xe.rl_prepare_naic_device(cfg, na["phrase_length"], na["phrase_syn"], strict_q1=model.strict_reference)
             seq_s = torch.zeros(N, S, dtype=torch.int64, device=dev)
             seq_n = torch.zeros(N, S, dtype=torch.int64, device=dev)
             drawn_s = torch.zeros(N, S, device=dev)

@@ -1681,12 +1681,34 @@ def rl_prepare(cfg, saic=None, naic=None, *, sample_n: int = 1, strict_q1: bool 
     return out
 
 
+def rl_prepare_naic_device(cfg, phrase_length: torch.Tensor, phrase_syn: torch.Tensor, *, strict_q1: bool = True):
+    """``rl_prepare``'s non-autoregressive half on the device: the slot layout [N, S] -> {na_syn int64 [N, S], na_klen int32 [N, S]} (the labels of the collate -- the
+    semi-autoregressive kernel's, its token output unused -- and quirk Q1's fill mask: every row takes the LAST row's token count when ``strict_q1``,
+    TransformerModel.py:1859-1873)."""
+    N, S = phrase_length.shape
+    zeros = torch.zeros(N, S, dtype=torch.int64, device=phrase_length.device)
+    na_syn = rl_prepare_saic_device(cfg, zeros, phrase_length, phrase_syn)["sa_syn"]
+    ntok = phrase_length.to(torch.int32).sum(1, dtype=torch.int32)
+    fill = ntok[-1:].expand(N) if strict_q1 else ntok
+    return {"na_syn": na_syn, "na_klen": fill[:, None].expand(N, S).contiguous()}
+
+
+_COLLATE = {"tensor_ops": False}      # tests: True = rl_prepare_saic_device as tensor operations (the kernel's reference)
+
+
 def rl_prepare_saic_device(cfg, seq: torch.Tensor, phrase_length: torch.Tensor, phrase_syn: torch.Tensor):
-    """``rl_prepare``'s semi-autoregressive half as tensor operations on the device (no host round trip, no synchronisation: it can sit inside a captured
-    graph): ``seq`` int64 [N, S] sampled tokens, ``phrase_length`` / ``phrase_syn`` [N, S] as the engine exports them -> {sa_syn, sa_seq int64 [N, S],
+    """``rl_prepare``'s semi-autoregressive half on the device (one launch, bofi_saic_collate; no host round trip, no synchronisation: it can sit inside a captured
+    graph; the tensor-operation form below is its reference and what a CPU tensor gets): ``seq`` int64 [N, S] sampled tokens, ``phrase_length`` / ``phrase_syn`` [N, S] as the engine exports them -> {sa_syn, sa_seq int64 [N, S],
     sa_klen int32 [N, S]} -- the loader's collate of those captions (captioning/data/dataloader.py:343-428; the index arithmetic of
     boficap_amd.collate.phrase_collate, checked against it in tests/test_gpu_rl.py)."""
     N, S = seq.shape
+    if seq.is_cuda and not _COLLATE["tensor_ops"]:              # one launch (train_ops.hip saic_collate_kernel) instead of ~35 tensor operations
+        seq_c, pl_c, ps_c = seq.contiguous(), phrase_length.to(torch.int32).contiguous(), phrase_syn.to(torch.int64).contiguous()
+        out = {"sa_syn": torch.empty(N, S, dtype=torch.int64, device=seq.device), "sa_seq": torch.empty(N, S, dtype=torch.int64, device=seq.device),
+               "sa_klen": torch.empty(N, S, dtype=torch.int32, device=seq.device)}
+        hip.check(hip.lib().bofi_saic_collate(hip.ptr(seq_c), hip.ptr(pl_c), hip.ptr(ps_c), N, S, cfg.bos_idx, hip.ptr(out["sa_syn"]), hip.ptr(out["sa_seq"]),
+                                              hip.ptr(out["sa_klen"]), hip.stream_ptr()), "bofi_saic_collate")
+        return out
     L = S + 2
     dev = seq.device
     plen = phrase_length.long()

@@ -130,6 +130,12 @@ int bofi_attention_bwd_mfma(const void* q, int ldq, const void* k, int ldk, cons
                             const int* q_count, int k_ragged, int q_rows, void* stream);
 /* backward of log_softmax given the log-probabilities y: dx = dy - exp(y) * rowsum(dy) */
 int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, int V, void* stream);
+/* The loader's phrase-aware collate (captioning/data/dataloader.py:343-428) of SAMPLED captions, semi-autoregressive half, on the device: seq int64 [N, S] (tokens),
+ * phrase_length int32 / phrase_syn int64 [N, S] (slot layout, real phrases first) -> per position the decoder input token (sa_seq: the previous phrase squeezed or
+ * stretched over this one, BOS before the first), the phrase's label (sa_syn) and the number of visible keys (sa_klen).  The self-critical step's per-phrase forwards
+ * read these (loss_wrapper.py:193-209 behind TransformerModel.py:1903-1984); no host round trip, capturable. */
+int bofi_saic_collate(const int64_t* seq, const int* phrase_length, const int64_t* phrase_syn, int N, int S, int bos_idx, int64_t* sa_syn, int64_t* sa_seq,
+                      int* sa_klen, void* stream);
 /* backward of picked[r] = y[r][labels[r]] straight through the log_softmax that made y (the token terms of
  * LanguageModelCriterion_UIC, losses.py:341-347: gather on the log-probs): dx[r][c] = dpicked[r] * ((c == labels[r]) - exp(y[r][c])).
  * labels must lie in [0, V).  dx: float32 [rows, V] (lddx == V), or bf16 [rows, lddx] with lddx >= V and the columns V..lddx-1

@@ -423,6 +423,16 @@ def test_device_side_layout_collate_equals_the_host_collate():
         seq[n, :lens.sum()] = rng.integers(7, cfg.tgt_vocab, lens.sum())
     r = {"seq": torch.from_numpy(seq).cuda(), "phrase_length": torch.from_numpy(plen).cuda(), "phrase_syn": torch.from_numpy(psyn).cuda()}
     host = xe.rl_prepare(cfg, r, None, sample_n=1, device="cuda")
-    dev = xe.rl_prepare_saic_device(cfg, r["seq"], r["phrase_length"], r["phrase_syn"])
-    for k in ("sa_syn", "sa_seq", "sa_klen"):
-        assert dev[k].dtype == host[k].dtype and torch.equal(dev[k], host[k]), k
+    for tensor_ops in (False, True):                             # the one-launch kernel (bofi_saic_collate) and its tensor-operation reference
+        xe._COLLATE["tensor_ops"] = tensor_ops
+        try:
+            dev = xe.rl_prepare_saic_device(cfg, r["seq"], r["phrase_length"], r["phrase_syn"])
+        finally:
+            xe._COLLATE["tensor_ops"] = False
+        for k in ("sa_syn", "sa_seq", "sa_klen"):
+            assert dev[k].dtype == host[k].dtype and torch.equal(dev[k], host[k]), (tensor_ops, k)
+    for strict in (True, False):                                 # the non-autoregressive half (labels + quirk Q1's fill mask)
+        host_na = xe.rl_prepare(cfg, None, r, sample_n=1, strict_q1=strict, device="cuda")
+        dev_na = xe.rl_prepare_naic_device(cfg, r["phrase_length"], r["phrase_syn"], strict_q1=strict)
+        for k in ("na_syn", "na_klen"):
+            assert dev_na[k].dtype == host_na[k].dtype and torch.equal(dev_na[k], host_na[k]), (strict, k)
