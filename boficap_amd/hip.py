@@ -50,6 +50,7 @@ SIGNATURES = {
     "bofi_attention_bwd_mfma": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, C.c_float, C.c_uint64,
                                      _P, _P, _P, _I, _I, _P]),
     "bofi_logsoftmax_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "bofi_rl_take_draws": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "bofi_saic_collate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "bofi_nll_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "bofi_uic_criterion": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),

@@ -789,9 +789,12 @@ class XETrainer:
             prep.update(xe.rl_prepare(model.cfg, None, naic, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
         if "_capped" in saic or getattr(model.opt, "bofi_rl_sample_pair", True):
             saic = model.saic_finish(saic) if "bound_iters" in saic else saic
+        if saic["seq"].is_cuda:                                # the semi-autoregressive samples' collate: one launch on the device, issued before the host waits for the ids
+            prep.update(xe.rl_prepare_saic_device(model.cfg, saic["seq"].long(), saic["phrase_length"], saic["phrase_syn"]))
         seq_s = saic["seq"].cpu()
         s_saic = score_fn(seq_s)
-        prep.update(xe.rl_prepare(model.cfg, saic, None, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
+        if not saic["seq"].is_cuda:
+            prep.update(xe.rl_prepare(model.cfg, saic, None, sample_n=sample_n, strict_q1=model.strict_reference, device=dev))
         self._last_rl = {"saic_tokens": (seq_s > 0).float().sum(1).mean(), "naic_tokens": (seq_n > 0).float().sum(1).mean(),
                          # share of the semi-autoregressive loop's S enqueued iterations in which some caption was still open
                          "active_share": min(S, int(saic["phrase_num"].max()) + 1) / S}
@@ -887,19 +890,19 @@ class XETrainer:
 
         draws = [0]
 
-        def draw(lp, mask, seq, drawn):
+        def draw(lp, plen, p0, p1, seq, drawn, mask):
             # one draw per slot from Categorical(logits = row / temperature) by the library's one-pass Gumbel-max sampler (bofi_vocab_sample: counter-hash uniforms, a NaN
-            # log-prob counts as -10 as in CaptionModel.py:419-425), kept where ``mask`` is set: no index list, no host synchronisation, one read of the rows (torch's
-            # softmax + multinomial were five passes: 0.18 ms per phrase)
+            # log-prob counts as -10 as in CaptionModel.py:419-425), kept at the positions of phrases [p0, p1) (bofi_rl_take_draws: ids, their log-probs under the rows they
+            # were drawn from, the sampled mask): no index list, no host synchronisation, two launches per phrase
             lpf = lp if lp.dtype == torch.float32 and lp.is_contiguous() else lp.float().contiguous()
-            rows, V = lpf.shape[0] * lpf.shape[1], lpf.shape[2]
-            tok = torch.empty(mask.shape, dtype=torch.int64, device=dev)
+            n_, s_, V = lpf.shape
+            tok = torch.empty(n_, s_, dtype=torch.int64, device=dev)
             draws[0] += 1
             sseed = (base + 0x5EED0000 + (self._fwd_calls << 8) + draws[0]) & 0xFFFFFFFFFFFFFFFF
-            hip.check(hip.lib().bofi_vocab_sample(hip.ptr(lpf), rows, V, lpf.shape[1], 1, float(temperature), sseed, None, cfg.pad_idx, hip.ptr(tok), hip.stream_ptr()),
+            hip.check(hip.lib().bofi_vocab_sample(hip.ptr(lpf), n_ * s_, V, s_, 1, float(temperature), sseed, None, cfg.pad_idx, hip.ptr(tok), hip.stream_ptr()),
                       "bofi_vocab_sample")
-            seq.copy_(torch.where(mask, tok, seq))
-            drawn.copy_(torch.where(mask, lpf.gather(2, tok[..., None]).squeeze(2), drawn))
+            hip.check(hip.lib().bofi_rl_take_draws(hip.ptr(lpf), hip.ptr(tok), hip.ptr(plen), n_, s_, V, int(p0), int(p1), hip.ptr(seq), hip.ptr(drawn), hip.ptr(mask),
+                                                   hip.stream_ptr()), "bofi_rl_take_draws")
 
         try:
             prep_na = xe.rl_prepare_naic_device(cfg, na["phrase_length"], na["phrase_syn"], strict_q1=model.strict_reference)
@@ -909,6 +912,7 @@ class XETrainer:
             drawn_n = torch.zeros(N, S, device=dev)
             mask_s = torch.zeros(N, S, dtype=torch.bool, device=dev)
             mask_n = pos < na["phrase_length"].long().sum(1)[:, None]
+            na_plen = na["phrase_length"].to(torch.int32).contiguous()
             out = None
             self._sample_calls_ref = getattr(self, "_sample_calls_ref", 0) + 1
             passes = 0
@@ -918,21 +922,17 @@ class XETrainer:
                     out = eng.decode_saic(feats_rep, lens_rep, it_range=(it, it), out=out, want_logprob=False, layout_only=True)
                     if int(out["bound_iters"]) < it:                     # no caption was open in this iteration: the loop is through
                         break
-                    pl = out["phrase_length"].long()
                     if fwd_graphs is not None:
                         lp_s, lp_n = rows_graphed(seq_s, out, prep_na, passes == 0)
                     else:
-                        prep = xe.rl_prepare_saic_device(cfg, seq_s, pl, out["phrase_syn"])
+                        prep = xe.rl_prepare_saic_device(cfg, seq_s, out["phrase_length"], out["phrase_syn"])
                         prep.update(prep_na)
                         lp_s, lp_n = rows_of(prep, shared)
                     passes += 1
-                    start = pl[:, :it - 1].sum(1)[:, None]
-                    new = (pos >= start) & (pos < start + pl[:, it - 1:it])
-                    draw(lp_s, new, seq_s, drawn_s)
-                    mask_s |= new
+                    draw(lp_s, out["phrase_length"], it - 1, it, seq_s, drawn_s, mask_s)       # phrase `it`'s positions
                     eng.saic_put_words(seq_s)
                     if it == 1:
-                        draw(lp_n, mask_n, seq_n, drawn_n)
+                        draw(lp_n, na_plen, 0, S, seq_n, drawn_n, None)                    # every laid-out position of the non-autoregressive branch
             saic = {"seq": seq_s, "phrase_length": out["phrase_length"], "phrase_syn": out["phrase_syn"]}
             s_saic, s_naic = score_fn(seq_s.cpu()), score_fn(seq_n.cpu())
             prep = xe.rl_prepare_saic_device(cfg, seq_s, out["phrase_length"], out["phrase_syn"])

@@ -134,6 +134,10 @@ int bofi_logsoftmax_bwd(const float* y, const float* dy, float* dx, int rows, in
  * phrase_length int32 / phrase_syn int64 [N, S] (slot layout, real phrases first) -> per position the decoder input token (sa_seq: the previous phrase squeezed or
  * stretched over this one, BOS before the first), the phrase's label (sa_syn) and the number of visible keys (sa_klen).  The self-critical step's per-phrase forwards
  * read these (loss_wrapper.py:193-209 behind TransformerModel.py:1903-1984); no host round trip, capturable. */
+/* The self-critical step's bookkeeping behind a draw: positions of phrases [p0, p1) of every caption (phrase_length int32 [N, S]) take tok int64 [N, S] into seq, the
+ * token's log-prob lp[n, t, tok] (float32 [N, S, V]) into drawn, and set mask (bool [N, S], or NULL); the other positions are left alone. */
+int bofi_rl_take_draws(const float* lp, const int64_t* tok, const int* phrase_length, int N, int S, int V, int p0, int p1, int64_t* seq, float* drawn, void* mask,
+                       void* stream);
 int bofi_saic_collate(const int64_t* seq, const int* phrase_length, const int64_t* phrase_syn, int N, int S, int bos_idx, int64_t* sa_syn, int64_t* sa_seq,
                       int* sa_klen, void* stream);
 /* backward of picked[r] = y[r][labels[r]] straight through the log_softmax that made y (the token terms of
