@@ -686,6 +686,38 @@ def test_projection_tail_of_the_feed_forward_kernel_changes_launches_not_results
         H.lib().bofi_reload_env()
 
 
+def test_query_projection_tail_of_the_attention_kernel_changes_launches_not_results(engines):
+    """BOFI_RB_ATTN_PROJ: the decoder layers' cross-attention query projection computed by the self-attention launch from each 80-row block (rb_attn_kernel<.., PJ>)
+    against the separate projection launch: the residual stream is the same bit for bit, the queries differ in the summation order of the LayerNorm statistics only
+    (a bf16 rounding here and there): same layouts (the bounding loop does not see the filling pass), log-probs within the families' mutual distance."""
+    from boficap_amd import hip as H
+    from boficap_amd import weights as W
+    import os
+    cfg, sd, eng = engines("full_b8", torch.bfloat16)
+    att = torch.from_numpy(W.synthetic_att_feats(64, 36, cfg.att_feat_size, seed=79)).cuda().to(torch.bfloat16)
+    os.environ["BOFI_RB_MIN_ROWS"] = "0"
+    eng.set_decodes_in_flight(4)
+    outs = {}
+    try:
+        for v in ("0", "2"):
+            os.environ["BOFI_RB_ATTN_PROJ"] = v
+            H.lib().bofi_reload_env()
+            H.gemm_flops(reset=True)
+            r = eng.decode_naic(att, strict_q1=False, graph=False)
+            torch.cuda.synchronize()
+            outs[v] = {k: r[k].clone() for k in ("seq", "phrase_length", "phrase_syn", "seq_logprob")}
+        a, b = outs["0"], outs["2"]
+        assert torch.equal(a["phrase_length"], b["phrase_length"]) and torch.equal(a["phrase_syn"], b["phrase_syn"])
+        d = (a["seq_logprob"] - b["seq_logprob"]).nan_to_num().abs().max()
+        assert 0 < float(d) < 4e-2, float(d)                                                                 # (> 0: the fused launches did run)
+        assert float((a["seq"] == b["seq"]).float().mean()) > 0.98
+    finally:
+        os.environ.pop("BOFI_RB_MIN_ROWS")
+        os.environ.pop("BOFI_RB_ATTN_PROJ", None)
+        H.lib().bofi_reload_env()
+        eng.set_decodes_in_flight(0)
+
+
 def test_layer0_qkv_table_of_the_filling_pass_changes_launches_not_results(engines):
     """BOFI_FILL_QKV_TAB: in the filling pass's first round every word is BOS, so decoder layer 0's q|k|v row depends on (label, position) only -- a 200-row table made
     by the row-block projection kernel at finalize / refresh, gathered by the embedding launch -- against the projection launch on all B * 20 rows: bit for bit (a row's
