@@ -1,6 +1,7 @@
 """Decode throughput against the number of regions per image (real bottom-up features have 10-100; every BASELINE config has 36):
     python dev/exp/regions_sweep.py
-images/s and rows/s of 320-image launches, 4 in flight (engine forks, graphs), by R; which kernels serve the attention sublayers and the bounding loop."""
+    python dev/exp/regions_sweep.py [images per launch, default 320]
+images/s and rows/s of 320-image (or larger) launches, 4 in flight (engine forks, graphs), by R; which kernels serve the attention sublayers and the bounding loop."""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -8,7 +9,7 @@ from boficap_amd import weights as W
 from boficap_amd.config import FULL as cfg
 from boficap_amd.engine import BofiEngine, pick_concurrent_streams
 sd = W.make_state_dict(cfg, seed=0)
-B = 320
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 320
 for R in (36, 48, 50, 64, 100):
     root = BofiEngine(cfg, torch.bfloat16, max_batch=B, max_regions=R)
     root.load_state_dict(sd)
@@ -31,6 +32,6 @@ for R in (36, 48, 50, 64, 100):
             engs[k].decode_naic(atts[k], graph=True, q1_group=64, out=outs[k])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"R {R:3d}: {n * B / dt:10.1f} img/s  {n * B * R / dt / 1e6:7.2f} M region rows/s  ({dt / n * 1e3:.3f} ms per 320-image launch; loop kernel: {root.bound_loop_active(R)})", flush=True)
+    print(f"R {R:3d}: {n * B / dt:10.1f} img/s  {n * B * R / dt / 1e6:7.2f} M region rows/s  ({dt / n * 1e3:.3f} ms per {B}-image launch; loop kernel: {root.bound_loop_active(R)})", flush=True)
     del engs, root, outs, atts
     torch.cuda.empty_cache()
