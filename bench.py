@@ -938,6 +938,16 @@ def _compact(res):
     return out
 
 
+def choose_coalesce(steps: int, inflight: int) -> int:
+    """Batches of 64 per engine launch for a timed region of ``steps`` batches on ``inflight`` streams: among 16, 20, 10, 8, 5, 4, 2 the count that divides the steps and
+    spreads the launches evenly over the streams (fewest rounds x batches per launch), the first of equals; 1 when none divides."""
+    cands = [c for c in (16, 20, 10, 8, 5, 4, 2) if steps % c == 0]
+    if not cands:
+        return 1
+    n_str = max(1, inflight)
+    return min(cands, key=lambda c: (-(-(steps // c) // n_str)) * c)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="naic", choices=["naic", "xe", "rl"],
@@ -988,10 +998,7 @@ def main():
             # streams (fewest rounds x batches per launch, the first of equals: the default --steps 320 -> 20 launches of 16 batches, five per stream; the
             # driver's --steps 20 -> 4 launches of 5 batches, one per stream).  Round 5: the chip wants ~3 000 images in flight -- 254 k img/s at 10 batches
             # per launch, 260 k at 12, 262 k at 16-20 against 239-243 k at 5 (profiles/r05_launch_shape_sweep.txt)
-            cands = [c for c in (16, 20, 10, 8, 5, 4, 2) if args.steps % c == 0]
-            if cands:
-                n_str = max(1, args.inflight)
-                args.coalesce = min(cands, key=lambda c: (-(-(args.steps // c) // n_str)) * c)
+            args.coalesce = choose_coalesce(args.steps, args.inflight)
     ctx = dist_setup(args)
     rank, world = ctx[0], ctx[2]
 

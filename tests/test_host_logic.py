@@ -253,3 +253,16 @@ def test_persistent_gemm_statistics_registers_are_never_copied_or_spilled(tmp_pa
                     raise AssertionError(f"{head}: {l!r} touches a statistics register")
             checked += 1
     assert checked >= 4, checked
+
+
+def test_bench_batches_per_launch_rule():
+    """bench.py's dynamic batching: 16 batches per launch for the default 320 steps (20 launches, five per stream), 5 for the driver's 20 steps (one launch per stream: a
+    region cannot hold more images in flight than it times), and a count that divides whatever else is asked for."""
+    import importlib, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    assert bench.choose_coalesce(320, 4) == 16 and bench.choose_coalesce(20, 4) == 5 and bench.choose_coalesce(200, 4) == 10
+    assert bench.choose_coalesce(7, 4) == 1 and bench.choose_coalesce(8, 4) == 2 and bench.choose_coalesce(400, 4) == 20
+    for k in (20, 40, 64, 100, 320, 480):
+        c = bench.choose_coalesce(k, 4)
+        assert k % c == 0
