@@ -14,7 +14,8 @@ struct BoundState {
     int* phrase_length;   // [B, L]
     int* phrase_syn;      // [B, L]
     int* ext_syn;         // [B, L]  extend_phrase_syn: [LEN] id at 0, label of the slot covering p
-    int* counters;        // [4]: 0 = images finished, 1 = bound iterations executed
+    int* counters;        // [8]: 0 = images finished, 1 = bound iterations executed, (2, 3: the semi-autoregressive loop's halt / NaN words), 4 = fp16 saturation word of the
+                          //      persistent bounding-loop kernel (BoundLoopArgs.sat), zeroed by launch_bound_init like the others
     int* klen;            // [B, L]  keys row r of the bound sequence may attend (tgt_mask rows are key prefixes, TransformerModel.py:1859-1867):
                           //         maintained for the dense (N_len >= 2) bounding pass; may be NULL
 };
@@ -77,10 +78,13 @@ struct BoundLoopArgs {
     int update;                                           // apply the slot bookkeeping and loop until the group's images are finished
     int dbg;                                              // developer aid (BOFI_BL_DBG = i + 1: in-kernel stamps of iteration i), set by the launcher
     int xcds;                                             // 1..8 (BOFI_BL_XCDS, set by the launcher): the groups' workgroups on that many of the eight XCDs (8: every workgroup takes a group)
+    int* sat;                                             // fp16 saturation word (round 6; NULL: a scratch word of the library): bit 0 is OR-ed in when an activation (attention context, hidden
+                                                          // row) was clamped to +-65 504 on its way into an fp16 MFMA operand, bit 1 when the fp16 weight copies were clamped at pack time (*wsat != 0)
+    const int* wsat;                                      // the pack-time word of launch_pack_frag16 (may be NULL)
 };
 int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s);
 struct Pack16Entry { const float* w[2]; const float* gain; void* out; int n_each, nsrc, K, Npad, blk0; };      // blk0: set by the launcher
-struct Pack16Table { Pack16Entry e[8]; int n; };
+struct Pack16Table { Pack16Entry e[8]; int n; int* sat; };      // sat (may be NULL): set to 1 when a weight (times its folded gain) left the fp16 range and was clamped; the launcher zeroes it first
 int launch_pack_frag16(const Pack16Table& t, hipStream_t s);
 struct BoundTablesArgs {
     const float* xt; const float* x0; int rows;           // layer inputs [rows][512], the row-0 input [512]
@@ -92,7 +96,7 @@ int launch_bound_tables(const BoundTablesArgs& a, hipStream_t s);
 
 int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_idx, hipStream_t s);
 int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_num, int* phrase_length,
-                        int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max = nullptr);
+                        int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max = nullptr, int* sat_out = nullptr);
 // flags of launch_bound_tail
 #define BOUND_HEADS 1    /* final norm + heads + argmax on y */
 #define BOUND_UPDATE 2   /* apply the slot bookkeeping (needs BOUND_HEADS) */

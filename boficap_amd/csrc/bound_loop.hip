@@ -62,6 +62,11 @@ __device__ __forceinline__ uint32_t bl_pack(float lo, float hi) {
     const f32x2 v = {bl_clamp16(lo), bl_clamp16(hi)};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
+// fp16 saturation bookkeeping (round 6): the largest magnitude about to be converted; fmaxf drops a NaN operand (a NaN is not a saturation: it passes through
+// bl_clamp16 as the reference's NaN would); one branch per group of values, taken only when a clamp really fires
+__device__ __forceinline__ float bl_amax(float m, float v) { return fmaxf(m, fabsf(v)); }
+__device__ __forceinline__ void bl_note(int* sat, float m) { if (m > 65504.f) atomicOr(sat, 1); }
+__device__ int g_bl_sat_scratch;               // where the kernel notes saturations when the caller gave no word
 __device__ __forceinline__ float bl_relu(float v) { return v < 0.f ? 0.f : v; }      // torch.relu: a NaN stays a NaN (fmaxf would turn it into 0)
 __device__ __forceinline__ f16x8 bl_ldw(const u32x4* p) { return __builtin_bit_cast(f16x8, *p); }
 __device__ __forceinline__ float bl_lo(uint32_t u) { return __uint_as_float(u << 16); }
@@ -125,6 +130,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     }
     const int b0 = grp * BL_G;
     const BoundState st = a.st;
+    if (tid == 0 && a.wsat && *a.wsat) atomicOr(a.sat, 2);          // the fp16 weight copies themselves were clamped when they were packed
     if (a.dbg && blockIdx.x == 0 && tid == 0) g_bl_stamps[0] = __builtin_amdgcn_s_memtime();
 
     // ---- this wavefront's weight streams (a weight address never depends on data: the ring runs ahead across stages)
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                     }
                 }
                 u32x4 o;
+                bl_note(a.sat, bl_amax(bl_amax(bl_amax(fabsf(acc[0]), acc[1]), bl_amax(fabsf(acc[2]), acc[3])), bl_amax(bl_amax(fabsf(acc[4]), acc[5]), bl_amax(fabsf(acc[6]), acc[7]))));
                 o[0] = bl_pack(acc[0], acc[1]); o[1] = bl_pack(acc[2], acc[3]); o[2] = bl_pack(acc[4], acc[5]); o[3] = bl_pack(acc[6], acc[7]);
                 *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = o;
             }
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                 }
                 const float inv = 1.0f / l;                                   // no visible region: 0 * (1 / 0) = NaN, as softmax over an all-masked row of -inf
                 u32x4 w;
+                bl_note(a.sat, bl_amax(bl_amax(bl_amax(fabsf(o[0]), o[1]), bl_amax(fabsf(o[2]), o[3])), bl_amax(bl_amax(fabsf(o[4]), o[5]), bl_amax(fabsf(o[6]), o[7]))) * fabsf(inv));
                 w[0] = bl_pack(o[0] * inv, o[1] * inv); w[1] = bl_pack(o[2] * inv, o[3] * inv); w[2] = bl_pack(o[4] * inv, o[5] * inv); w[3] = bl_pack(o[6] * inv, o[7] * inv);
                 *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = w;
             }
@@ -438,6 +446,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
                     }
                 }
                 u32x4 w;
+                bl_note(a.sat, bl_amax(bl_amax(bl_amax(fabsf(o[0]), o[1]), bl_amax(fabsf(o[2]), o[3])), bl_amax(bl_amax(fabsf(o[4]), o[5]), bl_amax(fabsf(o[6]), o[7]))));
                 w[0] = bl_pack(o[0], o[1]); w[1] = bl_pack(o[2], o[3]); w[2] = bl_pack(o[4], o[5]); w[3] = bl_pack(o[6], o[7]);
                 *reinterpret_cast<u32x4*>(X16 + i * 1024 + ((lane ^ (i & 15)) << 4)) = w;
             }
@@ -476,13 +485,16 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             bl_seg(w1_s + (size_t)cc * 4096, cc + 1 < nc1 ? w1_s + (size_t)(cc + 1) * 4096 : w2_s, lane, wb, xb, acc);
+            float hmax = 0.f;                                                 // (hidden values are >= 0 after the ReLU: only the upper end can saturate)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n = hc + nt * 16;                                   // 4 columns n .. n + 3 of row l15: half of 16-byte chunk n >> 3
-                const uint2 o = make_uint2(bl_pack(bl_relu(acc[nt][0] + cv[nt].x), bl_relu(acc[nt][1] + cv[nt].y)),
-                                           bl_pack(bl_relu(acc[nt][2] + cv[nt].z), bl_relu(acc[nt][3] + cv[nt].w)));
+                const float h0 = bl_relu(acc[nt][0] + cv[nt].x), h1 = bl_relu(acc[nt][1] + cv[nt].y), h2 = bl_relu(acc[nt][2] + cv[nt].z), h3 = bl_relu(acc[nt][3] + cv[nt].w);
+                hmax = fmaxf(fmaxf(hmax, fmaxf(h0, h1)), fmaxf(h2, h3));
+                const uint2 o = make_uint2(bl_pack(h0, h1), bl_pack(h2, h3));
                 *reinterpret_cast<uint2*>(BIG + l15 * (dff * 2) + (((n >> 3) ^ l15) << 4) + (n & 4) * 2) = o;
             }
+            bl_note(a.sat, hmax);
         }
         __syncthreads();
         BL_STAMP(9);
@@ -626,6 +638,11 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
         attr_set = true;
     }
     BoundLoopArgs v = a;
+    if (!v.sat) {
+        static int* scratch = nullptr;
+        if (!scratch && hipGetSymbolAddress(reinterpret_cast<void**>(&scratch), HIP_SYMBOL(g_bl_sat_scratch)) != hipSuccess) return BOFI_ERR_HIP;
+        v.sat = scratch;
+    }
     v.dbg = BOFI_ENV_INT("BOFI_BL_DBG", 0);
     v.xcds = BOFI_ENV_INT("BOFI_BL_XCDS", 8);
     if (v.xcds < 1 || v.xcds > 8) v.xcds = 8;
@@ -664,9 +681,11 @@ __global__ __launch_bounds__(256) void pack_frag16_kernel(Pack16Table t) {
         for (int j = 0; j < 8; ++j) v[j] = d.gain ? row[j] * d.gain[k + j] : row[j];
     }
     u32x4 o;
+    if (t.sat) bl_note(t.sat, bl_amax(bl_amax(bl_amax(fabsf(v[0]), v[1]), bl_amax(fabsf(v[2]), v[3])), bl_amax(bl_amax(fabsf(v[4]), v[5]), bl_amax(fabsf(v[6]), v[7]))));
     o[0] = bl_pack(v[0], v[1]); o[1] = bl_pack(v[2], v[3]); o[2] = bl_pack(v[4], v[5]); o[3] = bl_pack(v[6], v[7]);
     reinterpret_cast<u32x4*>(d.out)[i] = o;
 }
+__global__ void bl_zero_word_kernel(int* w) { *w = 0; }
 
 int launch_pack_frag16(const Pack16Table& t, hipStream_t s) {
     if (t.n < 1 || t.n > 8) return BOFI_ERR_ARG;
@@ -678,6 +697,7 @@ int launch_pack_frag16(const Pack16Table& t, hipStream_t s) {
         d.blk0 = blocks;
         blocks += (int)(((size_t)d.Npad * d.K / 8 + 255) / 256);
     }
+    if (v.sat) hipLaunchKernelGGL(bl_zero_word_kernel, dim3(1), dim3(1), 0, s, v.sat);       // (a kernel, not a memset node: this runs inside captured refreshes too)
     hipLaunchKernelGGL(pack_frag16_kernel, dim3(blocks), dim3(256), 0, s, v);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;

@@ -130,6 +130,9 @@ struct bofi_engine {
     int bound_iter_cap = 0;               // bounding iterations the non-autoregressive decode enqueues (bofi_engine_set_bound_iter_cap; 0 = seq_length)
     int in_flight = 0;                    // decodes the caller keeps in flight (bofi_engine_set_decodes_in_flight; 0 = unknown: throughput forms)
     int* live_max = nullptr;              // optional device word: max over decodes of their live-iteration counts (bofi_engine_set_live_iterations_max)
+    int* sat_out = nullptr;               // optional device word: fp16 saturation status of the following NAIC decodes' bounding loop (bofi_engine_set_saturation_out)
+    int loop_mode = -1;                   // bofi_engine_set_bound_loop: -1 = BOFI_BOUND_LOOP / hint decide, 0 = five-launch iterations, 2 = the persistent loop kernel
+    int* b_wsat = nullptr;                // [1] set by pack_frag16 when an fp16 weight copy was clamped (shared with forks, like the weights)
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
 
@@ -296,7 +299,7 @@ struct bofi_engine {
     ENG_OK(dalloc((char**)&bctx2, Bm * d, tsz)); ENG_OK(dalloc((char**)&bh, Bm * dff, tsz));
     ENG_OK(dalloc(&st.last, Bm)); ENG_OK(dalloc(&st.finished, Bm)); ENG_OK(dalloc(&st.phrase_num, Bm));
     ENG_OK(dalloc(&st.phrase_length, Bm * L)); ENG_OK(dalloc(&st.phrase_syn, Bm * L));
-    ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 4)); ENG_OK(dalloc(&st.klen, Bm * L));
+    ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 8)); ENG_OK(dalloc(&st.klen, Bm * L));
     ENG_OK(dalloc(&sa.seq_last, Bm)); ENG_OK(dalloc(&sa.seq, Bm * L)); ENG_OK(dalloc(&sa.ext_len, Bm * L));
     ENG_OK(dalloc(&sa.ext_phrase, Bm * L)); ENG_OK(dalloc(&sa.klen_dec, Bm * L));
     ENG_OK(dalloc(&xw, Bm * L * d)); ENG_OK(dalloc((char**)&xwb, Bm * L * d, tsz)); ENG_OK(dalloc(&st_w, Bm * L * (d / 32) * 2));
@@ -365,6 +368,7 @@ struct bofi_engine {
         ent(b.w1, nullptr, dff, 1, d, dff, b.n2g, b_w1.wp16);
         ent(b.w2, nullptr, d, 1, dff, d, nullptr, b_w2.wp16);
         ent(b.lw1, b.sw1, hh, 2, d, 256, b.hng, b_heads.wp16);
+        t.sat = b_wsat;
         ENG_OK(bofi::launch_pack_frag16(t, s));
         bofi::BoundTablesArgs a{};
         a.xt = d_xt; a.x0 = b_x0; a.rows = L * 10; a.n0g = b.n0g; a.n0b = b.n0b;
@@ -379,7 +383,7 @@ struct bofi_engine {
     // 2 = the loop kernel whatever the hint
     static int bound_loop_knob() { return BOFI_ENV_INT("BOFI_BOUND_LOOP", 1); }
     bool bound_loop_ok(int R) const {
-        const int k = bound_loop_knob();
+        const int k = loop_mode >= 0 ? loop_mode : bound_loop_knob();
         return loop_ready && loop_config_ok() && R <= 128 && k != 0 && (k == 2 || in_flight != 1);
     }
     // update != 0: the whole loop on the engine's slot state (after launch_bound_init); update == 0: one iteration on a given layout, log-probabilities out
@@ -397,6 +401,7 @@ struct bofi_engine {
         a.st = st; a.ext_syn_in = ext_syn_in; a.last_in = last_in; a.len_logp = len_logp; a.syn_logp = syn_logp;
         a.B = B; a.R = R; a.L = L; a.S = cfg.seq_length; a.hh = cfg.head_hidden; a.dff = cfg.d_ff;
         a.max_iters = update ? cfg.seq_length : 1; a.update = update;
+        a.sat = st.counters + 4; a.wsat = b_wsat;             // (zeroed by launch_bound_init; the export hands it to the caller's word)
         return bofi::launch_bound_loop(a, s);
     }
     // y1 (by1 / byb / st_b) -> y3 partial slabs (by3): query projection + cross-attention, Wo_src, FFN, as the direct-operand kernels
@@ -722,7 +727,7 @@ int bofi_engine::enqueue_decode(const void* feats, int feats_dtype, const int* a
     }
     if (do_fill) {
         ENG_OK(enqueue_fill(att_len, B, R, flags, seq, seq_logprob, s));
-        ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s, live_max));
+        ENG_OK(bofi::launch_bound_export(st, B, L, S, phrase_num, phrase_length, phrase_syn, bound_iters, s, live_max, sat_out));
     }
     return BOFI_OK;
 }
@@ -1002,7 +1007,7 @@ static int run_graphed(bofi_engine* e, const std::vector<uintptr_t>& key, hipStr
 // ================================================================================================
 extern "C" {
 
-int bofi_abi_version(void) { return 3; }
+int bofi_abi_version(void) { return 4; }
 const char* bofi_last_error(void) { return g_err.c_str(); }
 
 int bofi_engine_create(const bofi_config_t* c, bofi_engine_t** out) {
@@ -1060,6 +1065,8 @@ int bofi_engine_fork_sized(bofi_engine_t* parent, int max_batch, bofi_engine_t**
     e->row_plogp_out = nullptr; e->row_chosen_out = nullptr;
     e->in_flight = 0;
     e->live_max = nullptr;                       // (a raw device pointer the fork's handle does not keep alive)
+    e->sat_out = nullptr;
+    e->loop_mode = -1;
     e->saic_it_begin = 1;
     e->saic_it_end = 0;
     e->st = bofi::BoundState{};
@@ -1240,6 +1247,20 @@ int bofi_engine_set_live_iterations_max(bofi_engine_t* e, int* live_max) {
     return BOFI_OK;
 }
 
+int bofi_engine_set_saturation_out(bofi_engine_t* e, int* word) {
+    g_err.clear();
+    if (!e) return fail(BOFI_ERR_ARG, "null engine");
+    e->sat_out = word;
+    return BOFI_OK;
+}
+
+int bofi_engine_set_bound_loop(bofi_engine_t* e, int mode) {
+    g_err.clear();
+    if (!e || (mode != -1 && mode != 0 && mode != 2)) return fail(BOFI_ERR_ARG, "bound loop mode: -1 (environment / hint), 0 (five-launch iterations) or 2 (persistent loop kernel)");
+    e->loop_mode = mode;
+    return BOFI_OK;
+}
+
 int bofi_engine_set_saic_range(bofi_engine_t* e, int it_begin, int it_end) {
     g_err.clear();
     if (!e) return fail(BOFI_ERR_ARG, "null engine");
@@ -1401,6 +1422,7 @@ int bofi_engine_finalize(bofi_engine_t* e) {
             ENG_OK(e->make_lin(&e->b_heads, {lp + ".Length_classifier1", lp + ".Syntactic_classifier1"}, hh, d, lp + ".norm", 256));
             for (Lin* l : {&e->b_o_self, &e->b_q_src, &e->b_o_src, &e->b_w1, &e->b_w2, &e->b_heads}) ENG_OK(e->dalloc((char**)&l->wp16, (size_t)l->Npad * l->K, 2));
             ENG_OK(e->dalloc(&e->b_q0_32, (size_t)d)); ENG_OK(e->dalloc(&e->b_sctab, (size_t)L * 10 * c.heads)); ENG_OK(e->dalloc(&e->b_vtab, (size_t)L * 10 * d));
+            ENG_OK(e->dalloc(&e->b_wsat, 4));
         }
         if (e->rb_ok()) {               // the filling pass's layer-0 q|k|v by (label, position) (derive_fill_table)
             ENG_OK(e->dalloc((char**)&e->f_qkv0, (size_t)10 * c.seq_length * 3 * d, e->tsz));
@@ -1572,7 +1594,8 @@ int bofi_engine_decode_naic(bofi_engine_t* e, const void* feats, int feats_dtype
                                   (uintptr_t)flags, (uintptr_t)seq, (uintptr_t)seq_logprob, (uintptr_t)phrase_num,
                                   (uintptr_t)phrase_length, (uintptr_t)phrase_syn, (uintptr_t)memory_out, (uintptr_t)bound_iters,
                                   (uintptr_t)e->q1_group, (uintptr_t)e->bound_iter_cap, (uintptr_t)e->live_max, (uintptr_t)e->in_flight,
-                                  (uintptr_t)bofi::g_env_generation, (uintptr_t)e->row_plogp_out, (uintptr_t)e->row_chosen_out};
+                                  (uintptr_t)bofi::g_env_generation, (uintptr_t)e->row_plogp_out, (uintptr_t)e->row_chosen_out,
+                                  (uintptr_t)e->sat_out, (uintptr_t)(e->loop_mode + 1)};
     return run_graphed(e, key, s, [&](hipStream_t cs) {
         return e->enqueue_decode(feats, feats_dtype, att_len, B, R, flags, seq, seq_logprob, phrase_num, phrase_length,
                                  phrase_syn, memory_out, bound_iters, cs);

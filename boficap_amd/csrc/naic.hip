@@ -14,7 +14,7 @@ namespace bofi {
 // ------------------------------------------------------------------------------------------------
 __global__ void bound_init_kernel(BoundState st, int B, int L, int pad_idx, int len_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 4) st.counters[i] = 0;
+    if (i < 8) st.counters[i] = 0;
     if (i < B) { st.last[i] = 1; st.finished[i] = 0; st.phrase_num[i] = 0; }
     if (i < B * L) {
         st.phrase_length[i] = 0;
@@ -25,16 +25,17 @@ __global__ void bound_init_kernel(BoundState st, int B, int L, int pad_idx, int 
 }
 
 int launch_bound_init(const BoundState& st, int B, int L, int pad_idx, int len_idx, hipStream_t s) {
-    const int n = max(B * L, 4);
+    const int n = max(B * L, 8);
     hipLaunchKernelGGL(bound_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, B, L, pad_idx, len_idx);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
 
 __global__ void bound_export_kernel(BoundState st, int B, int L, int S, int* phrase_num, int* phrase_length,
-                                    int64_t* phrase_syn, int* iters, int* live_max) {
+                                    int64_t* phrase_syn, int* iters, int* live_max, int* sat_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && iters) *iters = st.counters[1];
+    if (i == 0 && sat_out) *sat_out = st.counters[4];                 // fp16 saturation status of this decode's bounding loop (0 unless the loop kernel clamped something)
     if (i == 0 && live_max) atomicMax(live_max, st.counters[1]);      // the largest live-iteration count of every decode since the caller cleared the word
     if (i < B && phrase_num) phrase_num[i] = st.phrase_num[i];
     if (i < B * S) {
@@ -45,9 +46,9 @@ __global__ void bound_export_kernel(BoundState st, int B, int L, int S, int* phr
 }
 
 int launch_bound_export(const BoundState& st, int B, int L, int S, int* phrase_num, int* phrase_length,
-                        int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max) {
+                        int64_t* phrase_syn, int* iters, hipStream_t s, int* live_max, int* sat_out) {
     hipLaunchKernelGGL(bound_export_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, st, B, L, S, phrase_num,
-                       phrase_length, phrase_syn, iters, live_max);
+                       phrase_length, phrase_syn, iters, live_max, sat_out);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;
 }
@@ -588,7 +589,7 @@ int launch_set_u64(uint64_t* p, uint64_t v, hipStream_t s) {
 
 __global__ void saic_init_kernel(BoundState st, SaicState sa, int B, int L, int pad_idx, int bos_idx, int len_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 4) st.counters[i] = 0;
+    if (i < 8) st.counters[i] = 0;
     if (i < B) { st.last[i] = 1; st.finished[i] = 0; st.phrase_num[i] = 0; sa.seq_last[i] = 0; }
     if (i < B * L) {
         const bool first = (i % L) == 0;
@@ -603,7 +604,7 @@ __global__ void saic_init_kernel(BoundState st, SaicState sa, int B, int L, int 
 }
 
 int launch_saic_init(const BoundState& st, const SaicState& sa, int B, int L, int pad_idx, int bos_idx, int len_idx, hipStream_t s) {
-    const int n = max(B * L, 4);
+    const int n = max(B * L, 8);
     hipLaunchKernelGGL(saic_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, sa, B, L, pad_idx, bos_idx, len_idx);
     BOFI_CHECK_LAUNCH();
     return BOFI_OK;

@@ -133,6 +133,7 @@ class BofiEngine:
         with torch.cuda.device(self.device):
             hip.check(self._lib.bofi_engine_finalize(self._h), "bofi_engine_finalize")
         self._finalized = True
+        self._weights_changed()
 
     def refresh_from_device(self, named: Dict[str, torch.Tensor]) -> None:
         """Re-pack the weights from float32 tensors on the device (e.g. ``dict(model.named_parameters())``): kernels only,
@@ -155,6 +156,12 @@ class BofiEngine:
         _, n, names, ptrs, numels = cached
         with torch.cuda.device(self.device):
             hip.check(self._lib.bofi_engine_refresh_device(self._h, n, names, ptrs, numels, hip.stream_ptr()), "bofi_engine_refresh_device")
+        self._weights_changed()
+
+    def _weights_changed(self):
+        if getattr(self, "_loop_mode_sticky", False):            # (a fallback taken because the OLD weights' fp16 copies were clamped: the new ones get their own verdict)
+            self._loop_mode_sticky = False
+            self.set_bound_loop(-1)
 
     # ---------------------------------------------------------------- calls
     def _check_feats(self, att_feats, att_len):
@@ -175,8 +182,9 @@ class BofiEngine:
         ``refine_rounds`` extra filling passes feed the previous ids back as decoder input (BASELINE config 5).
         ``q1_group`` > 0: the call carries B / q1_group independent batches (dynamic batching); quirk Q1 applies per batch,
         so each batch's outputs equal its own separate decode.
-        ``iter_cap`` > 0: enqueue that many bounding iterations instead of seq_length (bofi_engine_set_bound_iter_cap); the result is the
-        reference's iff ``bound_iters`` < iter_cap afterwards -- the caller checks and decodes again without the cap otherwise.
+        ``iter_cap`` > 0 (the five-launch bounding iterations only; the persistent loop kernel -- ``bound_loop_active(R)`` -- ends by itself, ignores the
+        budget and its result is always complete): enqueue that many bounding iterations instead of seq_length (bofi_engine_set_bound_iter_cap); the result is
+        then the reference's iff ``bound_iters`` < iter_cap afterwards -- the caller checks and decodes again without the cap otherwise.
         ``phases``: "" = the whole decode; a subset of "ebf" = only the encode / bounding loop / filling pass + export of it (BOFI_FLAG_PHASE_*): a pipelining
         caller enqueues the three on the same engine in that order (its streams / events order them) with the same arguments.
         ``row_stats``: the vocabulary epilogue also leaves, per position, sum_v p log p and the log-prob of the emitted id in ``out['row_plogp']`` / ``out['row_chosen']``
@@ -193,6 +201,11 @@ class BofiEngine:
                 phrase_syn=torch.empty(B, S, dtype=torch.int64, device=dev),
                 bound_iters=torch.empty(1, dtype=torch.int32, device=dev),
                 memory=torch.empty(B, R, self.cfg.d_model, dtype=torch.float32, device=dev) if want_memory else None)
+        if out.get("bound_saturated") is None:                   # fp16 saturation status of this decode's bounding loop (bofi_engine_set_saturation_out): see ``saturated``
+            out["bound_saturated"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        if out["bound_saturated"].data_ptr() != getattr(self, "_sat_ptr", 0):
+            hip.check(self._lib.bofi_engine_set_saturation_out(self._h, hip.ptr(out["bound_saturated"])), "bofi_engine_set_saturation_out")
+            self._sat_ptr = out["bound_saturated"].data_ptr()
         if not 0 <= refine_rounds <= 15:
             raise hip.BofiHipError("refine_rounds must be in 0..15")
         if row_stats and raw_logits:
@@ -232,6 +245,45 @@ class BofiEngine:
     def bound_loop_active(self, R: int) -> bool:
         """Does a decode of R regions per image run the bounding loop as the persistent per-16-image kernel (bofi_engine_bound_loop_active)?"""
         return bool(self._lib.bofi_engine_bound_loop_active(self._h, int(R)))
+
+    def set_bound_loop(self, mode: int) -> None:
+        """The bounding loop's form for this engine's following decodes (bofi_engine_set_bound_loop): -1 = BOFI_BOUND_LOOP and the decodes-in-flight hint decide,
+        0 = the five-launch bf16 iterations, 2 = the persistent fp16 loop kernel whatever the hint."""
+        hip.check(self._lib.bofi_engine_set_bound_loop(self._h, int(mode)), "bofi_engine_set_bound_loop")
+        self._loop_mode = int(mode)
+
+    def saturated(self, out: dict) -> int:
+        """fp16 saturation status of the decode that produced ``out`` (a device -> host read: call it where the caller synchronises anyway): 0 = clean; bit 0 = the
+        persistent bounding-loop kernel clamped an activation to +-65 504 on its way into an fp16 MFMA operand; bit 1 = its fp16 weight copies were clamped when they
+        were packed.  Either way the slot layout may differ from what bf16 operands (float32's exponent range) give: decode again under ``set_bound_loop(0)``
+        -- ``decode_naic_checked`` does both."""
+        w = out.get("bound_saturated")
+        return int(w) if w is not None else 0
+
+    def decode_naic_checked(self, att_feats, att_len=None, **kw) -> dict:
+        """``decode_naic`` + the saturation check + the fallback: when the loop kernel reports a clamp, a warning is issued and the batch is decoded again
+        with the five-launch bf16 bounding iterations; a clamp of the WEIGHT copies (bit 1) keeps this engine on that form until its weights change.  Synchronises (reads one word)."""
+        r = self.decode_naic(att_feats, att_len, **kw)
+        sat = self.saturated(r)
+        if sat:
+            r = self._redo_without_loop_kernel(sat, lambda: self.decode_naic(att_feats, att_len, **dict(kw, out=r)))
+        return r
+
+    def _redo_without_loop_kernel(self, sat: int, decode):
+        import warnings
+        warnings.warn("boficap_amd: the fp16 bounding-loop kernel clamped " + ("its weight copies" if sat & 2 else "an activation") +
+                      " to +-65 504 (a bounding layer outside fp16's range); this decode is repeated with the five-launch bf16 iterations" +
+                      (" and the engine stays on them until its weights change" if sat & 2 else ""), RuntimeWarning, stacklevel=3)
+        before = getattr(self, "_loop_mode", -1)
+        self.set_bound_loop(0)
+        try:
+            r = decode()
+        finally:
+            if not sat & 2:
+                self.set_bound_loop(before)
+            else:
+                self._loop_mode_sticky = True
+        return r
 
     def watch_live_iterations(self, word: Optional[torch.Tensor]) -> None:
         """``word`` (int32 [1] on the device, or None to stop): every following decode_naic folds its live-iteration count into it by atomic
@@ -459,6 +511,7 @@ class DecodePipeline:
         e, st = sl["eng"], sl["stream"]
         has_len = not no_len
         cs = self.copy_stream
+        caller = torch.cuda.current_stream(self.dev)
         with torch.cuda.stream(cs):
             # (the buffers are created -- and zero-filled -- ON the copy stream: a fill enqueued on the caller's stream would race the copies below)
             buf = sl["feats"][p].get((R, F, dt))
@@ -469,30 +522,49 @@ class DecodePipeline:
             feats, lens = buf[:rows], (sl["lens"][p][:rows] if has_len else None)
             cs.wait_event(sl["done"])                            # the launch that last read this slot's buffers is through (it was finished before this one is issued)
             for i, (att, ln) in enumerate(group):
+                for src in (att, ln):                            # a DEVICE batch was produced on its caller's stream: the copy waits for that stream, and the caching
+                    if src is not None and src.is_cuda:          # allocator must not hand the batch's memory out again while the copy is pending
+                        cs.wait_stream(caller)
+                        src.record_stream(cs)
                 feats[i * b:(i + 1) * b, :att.shape[1]].copy_(att, non_blocking=True)      # (a batch clipped below the bucket leaves padding rows: masked by its counts)
                 if has_len:
                     lens[i * b:(i + 1) * b].copy_(ln, non_blocking=True)
             sl["copied"][p].record(cs)
+        sl["last"] = (feats, lens, b, nb, rows)                  # (kept for the fallback decode of _finish: this slot's buffers stay untouched until its next launch)
         with torch.cuda.stream(st):
             st.wait_event(sl["copied"][p])
-            sl["out"] = e.decode_naic(feats, lens, strict_q1=self.strict_q1, graph=True, out=sl["out"] if sl["out"] is not None and sl["out"]["seq"].shape[0] == rows else None,
-                                      q1_group=b if nb > 1 else 0, row_stats=self.stats)
-            out = sl["out"]
-            small = {k2: out[k2] for k2 in ("seq", "phrase_num", "phrase_length", "phrase_syn")}
-            if self.stats:
-                small["entropy"], small["perplexity"] = e.entropy_perplexity(out)
-            if sl["host"] is None or sl["host"]["seq"].shape[0] != rows:
-                sl["host"] = {k2: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k2, v in small.items()}
-            for k2, v in small.items():
-                sl["host"][k2].copy_(v, non_blocking=True)
-            sl["lp"] = out["seq_logprob"].clone() if self.keep_logprob else None
+            self._decode_and_copy_out(sl)
             sl["done"].record(st)
+
+    def _decode_and_copy_out(self, sl):
+        e = sl["eng"]
+        feats, lens, b, nb, rows = sl["last"]
+        sl["out"] = e.decode_naic(feats, lens, strict_q1=self.strict_q1, graph=True, out=sl["out"] if sl["out"] is not None and sl["out"]["seq"].shape[0] == rows else None,
+                                  q1_group=b if nb > 1 else 0, row_stats=self.stats, want_logprob=self.keep_logprob)
+        out = sl["out"]
+        small = {k2: out[k2] for k2 in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_saturated")}
+        if self.stats:
+            small["entropy"], small["perplexity"] = e.entropy_perplexity(out)
+        if sl["host"] is None or sl["host"]["seq"].shape[0] != rows:
+            sl["host"] = {k2: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k2, v in small.items()}
+        for k2, v in small.items():
+            sl["host"][k2].copy_(v, non_blocking=True)
+        sl["lp"] = out["seq_logprob"].clone() if self.keep_logprob else None
 
     def _finish(self, launch):
         k, sizes = launch
         sl = self._slots[k]
         sl["done"].synchronize()
-        mine = {k2: v.clone() for k2, v in sl["host"].items()}      # (one private copy per launch: the pinned buffers are the next launch's; batches are views of it)
+        sat = int(sl["host"]["bound_saturated"][0])
+        if sat:                                                  # the fp16 loop kernel clamped something (BofiEngine.saturated): this launch again with the bf16 iterations
+
+            def again():
+                with torch.cuda.stream(sl["stream"]):
+                    self._decode_and_copy_out(sl)
+                    sl["done"].record(sl["stream"])
+                sl["done"].synchronize()
+            sl["eng"]._redo_without_loop_kernel(sat, again)
+        mine = {k2: v.clone() for k2, v in sl["host"].items() if k2 != "bound_saturated"}      # (one private copy per launch: the pinned buffers are the next launch's; batches are views of it)
         o = 0
         for b in sizes:
             res = {k2: v[o:o + b] for k2, v in mine.items()}

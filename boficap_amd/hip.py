@@ -17,7 +17,7 @@ FLAG_REFINE_SHIFT = 8
 FLAG_SAMPLE = 16
 FLAG_PHASE_ENCODE, FLAG_PHASE_BOUND, FLAG_PHASE_FILL = 32, 64, 128
 FLAG_SAIC_LAYOUT_ONLY = 4096
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class BofiHipError(RuntimeError):
@@ -82,6 +82,8 @@ SIGNATURES = {
     "bofi_engine_set_saic_range": (_I, [_P, _I, _I]),
     "bofi_engine_set_bound_iter_cap": (_I, [_P, _I]),
     "bofi_engine_set_live_iterations_max": (_I, [_P, _P]),
+    "bofi_engine_set_saturation_out": (_I, [_P, _P]),
+    "bofi_engine_set_bound_loop": (_I, [_P, _I]),
     "bofi_engine_create": (_I, [C.POINTER(BofiConfigC), C.POINTER(_P)]),
     "bofi_engine_destroy": (None, [_P]),
     "bofi_engine_fork": (_I, [_P, C.POINTER(_P)]),

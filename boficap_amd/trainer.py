@@ -317,6 +317,7 @@ class XETrainer:
         self._side = [torch.cuda.Stream() for _ in range(3)] if streams and self.ops is not None else None
         self.max_graphs = 8                                    # batch signatures (shapes x max phrase count x GLAT rate) kept as graphs
         self._graphs = {}
+        self._rl_static = None                                 # (set by _rl_replay: the dict whose "picked_*" buffers the last gradient pass filled)
         self._fwd_calls = 0
         if self.graph:
             dev = self.bucket.flat.device
@@ -1060,6 +1061,7 @@ class XETrainer:
         key = ("rl", tuple((k, tuple(b[k].shape), b[k].dtype) for k in keys), sample_n, self.model.training, self.model.train_dtype, self.rl_kl)
         entry = self._graphs.get(key)
         if entry is None and len(self._graphs) >= self.max_graphs:
+            self._rl_static = b                                    # (graph cache full: the eager pass fills the caller's own "picked_*" buffers)
             return self._rl_forward_backward(b, None, sample_n)
         if entry is None:
             static = {k: b[k].clone() for k in keys}

@@ -300,8 +300,14 @@ class TransformerModel(nn.Module):
             cap = int(forced) if forced is not None else (min(S, max(recent) + 2) if len(recent) >= 3 else 0)
             cap = 0 if cap >= S else cap
             feats_in, lens_in = self._as_input(att_feats), self._att_len(att_masks)
+            if cap and eng.bound_loop_active(feats_in.size(1)):  # the persistent loop kernel ends by itself and ignores the budget: the first decode IS complete
+                cap = 0                                          # (a repeat on live >= cap would be a redundant second decode)
             r = eng.decode_naic(feats_in, lens_in, strict_q1=self.strict_reference, raw_logits=not output_logsoftmax, iter_cap=cap)
             live = int(r["bound_iters"])                          # (a device -> host read: the reference synchronises here too, AttModel.py:337)
+            sat = eng.saturated(r)                                # fp16 saturation word of the loop kernel (0 for every model seen so far): fall back to the bf16 iterations
+            if sat:
+                r = eng._redo_without_loop_kernel(sat, lambda: eng.decode_naic(feats_in, lens_in, strict_q1=self.strict_reference, raw_logits=not output_logsoftmax, out=r, iter_cap=0))
+                live = int(r["bound_iters"])
             if cap and live >= cap:
                 r = eng.decode_naic(feats_in, lens_in, strict_q1=self.strict_reference, raw_logits=not output_logsoftmax, out=r, iter_cap=0)
                 live = int(r["bound_iters"])

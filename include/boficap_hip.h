@@ -280,7 +280,7 @@ typedef struct bofi_config {
     int dtype;        /* compute dtype: BOFI_DT_F32 (parity) or BOFI_DT_BF16 (throughput) */
     int n_len;        /* layers of the bounding network (LengthPredictor_UIC N_len, TransformerModel.py:357-375): 1 (configs/uic_sd.yml) takes
                          the row-0-only incremental form; >= 2 (configs/uic_sd_N2.yml) the dense form -- all S+2 rows through every layer
-                         per iteration, as the reference computes it (ABI version 2) */
+                         per iteration, as the reference computes it (a field since ABI version 2; the library is at version 3: bofi_abi_version) */
 } bofi_config_t;
 
 /* Allocates device weights + workspace for one model replica on the current HIP device. */
@@ -354,6 +354,19 @@ int bofi_engine_set_bound_iter_cap(bofi_engine_t* e, int cap);
  * live-iteration count of every following bofi_engine_decode_naic -- one read after the last decode tells whether ALL of them ended inside the
  * cap (the caller clears the word first). */
 int bofi_engine_set_live_iterations_max(bofi_engine_t* e, int* live_max);
+
+/* fp16 saturation status of the persistent bounding-loop kernel (round 6; ABI version 4).  That kernel computes the bounding network with FP16 operands
+ * (fp16 copies of the float32 parameters, activations converted on their way into the MFMAs) and clamps to +-65 504 on conversion; a model whose bounding
+ * layer leaves that range -- none here does: |y| < 30 -- would get a silently different slot layout where the bf16 kernels (same exponent range as float32) would not.
+ * `word` (device int32, NULL = off -- the default, also of a fork): every following bofi_engine_decode_naic WRITES its status there (beside bound_iters): 0 = nothing was
+ * clamped (always 0 when the decode ran the five-launch bf16 iterations), bit 0 = an activation (attention context or hidden row of the bounding layer) was clamped
+ * during this decode, bit 1 = the fp16 weight copies were clamped when they were packed (finalize / refresh_device).  A caller that reads a non-zero word decodes that
+ * batch again under bofi_engine_set_bound_loop(e, 0) (boficap_amd/engine.py does, with a warning).  Per-call state, part of the graph key.
+ * Replaces nothing in the reference (TransformerModel.py:357-383 runs in float32 there); it guards this library's own precision choice. */
+int bofi_engine_set_saturation_out(bofi_engine_t* e, int* word);
+/* Per-engine choice of the bounding loop's form for the following decodes: -1 (default, also of a fork) = BOFI_BOUND_LOOP and the decodes-in-flight hint decide
+ * (bofi_engine_bound_loop_active), 0 = the five-launch bf16 iterations, 2 = the persistent fp16 loop kernel whatever the hint.  Part of the graph key. */
+int bofi_engine_set_bound_loop(bofi_engine_t* e, int mode);
 
 /* Device pointer of the engine's own [max_batch * S, V] float32 log-prob workspace: where a decode called WITHOUT a
  * seq_logprob buffer leaves the distribution (valid until the next decode on this engine) -- input of

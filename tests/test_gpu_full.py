@@ -565,6 +565,44 @@ def test_loss_wrapper_rl_branch(weight_cache, manifest):
         g = p["model.length_predictor.Length_classifier2.weight"].grad
         assert g is None or float(g.abs().max()) == 0.0
     assert seen == [(B * 3, cfg.seq_length)] * 4
+    assert lw.last_rl["reference_gap"] is None                   # eval mode: no dropout anywhere, the fast form (sampler = gradient pass's policy)
+    # ---- train mode (what tools/train.py runs): the REFERENCE's estimator (loss_wrapper.py:193-209 samples in train mode with the tape and differentiates that pass) --
+    # every token of both branches drawn from the rows the returned log-probs differentiate: gap 0.0 between drawn rows and gradient-pass rows,
+    # as tests/test_gpu_rl.py asserts for XETrainer.rl_step
+    assert cfg.dropout > 0
+    model.train()
+    for dtype in (torch.float32, torch.bfloat16):
+        model.train_dtype = dtype
+        for rl_kl in (False, True):
+            model.opt.rl_kl = rl_kl
+            lw = LossWrapper(model, model.opt)
+            model.zero_grad()
+            del seen[:]
+            out = lw(fc, att, None, None, None, gts, torch.arange(B), False, True, False)
+            assert lw.last_rl["reference_gap"] == 0.0, lw.last_rl
+            assert lw.last_rl["training_forwards"] >= 3          # several phrases: a tape-free forward per phrase + the gradient pass
+            assert sorted(out.keys()) == ["lm_loss", "loss", "reward", "struc_loss"] and torch.isfinite(out["loss"]) and out["reward"].shape == (B, 3)
+            assert seen == [(B * 3, cfg.seq_length)] * 2
+            out["loss"].backward()
+            p = dict(model.named_parameters())
+            assert float(p["model.decoder.layers.0.feed_forward.w_1.weight"].grad.abs().max()) > 0
+            g = p["model.length_predictor.Length_classifier2.weight"].grad
+            assert g is None or float(g.abs().max()) == 0.0
+    # ragged regions through the same branch
+    masks = torch.ones(B, att.size(1), device="cuda"); masks[0, 20:] = 0
+    model.zero_grad()
+    out = lw(fc, att, None, None, masks, gts, torch.arange(B), False, True, False)
+    assert lw.last_rl["reference_gap"] == 0.0 and torch.isfinite(out["loss"])
+    # opt.bofi_rl_reference_estimator = False: the fast form of rounds 1-5 (engine samples, re-forward with dropout)
+    model.opt.bofi_rl_reference_estimator = False
+    lw = LossWrapper(model, model.opt)
+    model.zero_grad()
+    out = lw(fc, att, None, None, None, gts, torch.arange(B), False, True, False)
+    assert lw.last_rl["reference_gap"] is None and torch.isfinite(out["loss"]) and model.training
+    out["loss"].backward()
+    model.opt.bofi_rl_reference_estimator = True
+    model.train_dtype = torch.float32
+    model.eval()
 
 
 def test_optimizer_checkpoint_round_trips_with_torch_adam(weight_cache, manifest):

@@ -1,4 +1,6 @@
 """End-to-end NAIC bound+fill parity on the MI355X through the C ABI / the drop-in module."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -289,6 +291,63 @@ def test_drop_in_module_sample(weight_cache, manifest):
     assert (seq.cpu().numpy() == g["saic_seq"]).all() and (pl.cpu().numpy() == g["saic_phrase_length"]).all()
     with pytest.raises(NotImplementedError):
         model(fc, att, None, opt={"train_mode": "AIC"}, mode="sample")
+
+
+def _integration_stub_b():
+    """The fenced python block of INTEGRATION.md section B (the ctypes stub a maintainer of the reference would paste into AttModel.py)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "INTEGRATION.md")) as f:
+        text = f.read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "replacement for the 'NAIC' branch of _sample" in b]
+    assert len(stub) == 1, "INTEGRATION.md: stub B not found"
+    return stub[0], root
+
+
+def test_integration_stub_b(weight_cache, manifest):
+    """the binding INTEGRATION.md documents is EXECUTED -- the block is extracted from the file, pointed at the built library, given an object that
+    carries the attributes the reference's model has (AttModel.py:56-79, TransformerModel.py:1631-1640) and its state_dict, and compared with model(..., mode='sample') and the
+    REFERENCE's full_b8 fixture: float32 engine, ids and slot layout bit-exact, log-probs <= 1e-3 (AttModel.py:419-429)."""
+    import types
+    import captioning.models as models
+    from boficap_amd import hip, weights as W
+    src, root = _integration_stub_b()
+    assert "bofi_abi_version() == %d" % hip.ABI_VERSION in src, "stub B asserts another ABI version than the library's"
+    lib_path = os.path.join(root, "boficap_amd", "libboficap_hip.so")
+    src = src.replace('C.CDLL("libboficap_hip.so")', "C.CDLL(%r)" % lib_path)
+    ns = {}
+    exec(compile(src, "INTEGRATION.md:stub_b", "exec"), ns)
+    ns["_DTYPE"] = 0                                             # the bit-exact parity engine
+    m, g = manifest["full_b8"], load_golden("full_b8")
+    cfg, sd = weight_cache(m["config"], m["seed"], m["gen_scale"], m["digest"], m.get("patch"))
+    model = models.setup(cfg.to_opt())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.cuda().eval()
+    # what the pasted functions read from `self` in the reference's class
+    ref_self = types.SimpleNamespace(tgt_vocab=cfg.tgt_vocab, att_feat_size=cfg.att_feat_size, d_model=cfg.d_model, d_ff=cfg.d_ff, h=cfg.h, N_enc=cfg.N_enc,
+                                     N_dec=cfg.N_dec, N_len=cfg.N_len, seq_length=cfg.seq_length, state_dict=model.state_dict)
+    ref_self._bofi = ns["_engine"](ref_self)
+    att = torch.from_numpy(W.synthetic_att_feats(m["pool_size"], 36, cfg.att_feat_size, seed=m["pool_seed"])[g["pool_index"]]).cuda()
+    fc = torch.zeros(att.size(0), 0, device="cuda")
+    seq, logp, pn, pl, ps = ns["_sample_naic"](ref_self, att, None)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        mseq, mlp, mpn, mpl, mps, _ = model(fc, att, None, opt={"train_mode": "NAIC", "sample_method": "greedy", "sample_n": 1}, mode="sample")
+    for a, b, name in ((seq, mseq, "seq"), (pn, mpn, "phrase_num"), (pl, mpl, "phrase_length"), (ps, mps, "phrase_syn")):
+        assert a.dtype == b.dtype and torch.equal(a, b), name
+    assert _close(logp.cpu().numpy(), mlp.cpu().numpy(), 0) < 1e-3
+    # ... and the reference's own outputs for these images
+    assert (seq.cpu().numpy() == g["naic_seq"]).all() and (pn.cpu().numpy() == g["naic_phrase_num"]).all()
+    assert (pl.cpu().numpy() == g["naic_phrase_length"]).all() and (ps.cpu().numpy() == g["naic_phrase_syn"]).all()
+    assert _close(torch.topk(logp.cpu(), 2, dim=2)[0].numpy(), g["naic_top2_val"], 0) < 1e-3
+    # ragged regions through the stub's att_masks argument: the model's own answer on the same call
+    masks = torch.ones(att.size(0), 36, device="cuda"); masks[1, 20:] = 0; masks[3, 30:] = 0
+    seq2, logp2, pn2, pl2, ps2 = ns["_sample_naic"](ref_self, att, masks)
+    with torch.no_grad():
+        mseq2, mlp2, mpn2, mpl2, _, _ = model(fc, att, masks, opt={"train_mode": "NAIC", "sample_method": "greedy"}, mode="sample")
+    assert torch.equal(seq2, mseq2) and torch.equal(pn2, mpn2) and torch.equal(pl2, mpl2)
+    ns["_lib"].bofi_engine_destroy(ref_self._bofi)
 
 
 def test_bounding_loop_with_fewer_iterations_enqueued(weight_cache, manifest):

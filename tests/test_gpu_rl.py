@@ -379,6 +379,40 @@ def test_reference_estimator_draws_every_token_from_the_gradient_pass(graph, wei
     assert float((a - b)[live].abs().max()) > 1e-3
 
 
+def test_reference_estimator_with_a_full_graph_cache(weight_cache, manifest):
+    """once the trainer's graph cache holds max_graphs entries (a normal XE run fills it: the key carries the max-phrase / max-token buckets and the GLAT
+    rate) the reference-estimator step's gradient pass runs eagerly -- and must still find its own log-probs at the drawn tokens (the "picked" buffers of the dict IT filled),
+    whatever a replay left behind earlier: gap 0.0, weights moved, no AttributeError / stale buffers."""
+    from boficap_amd.trainer import XETrainer
+    cfg, sd, model = _model(weight_cache, manifest)
+    opt = cfg.to_opt()
+    opt.noamopt, opt.learning_rate = False, 1e-4
+    model.opt.bofi_rl_reference_estimator = True
+    att = _images().cuda()
+
+    def score(seq):
+        return (seq == 11).float().sum(1) / (seq > 0).float().sum(1).clamp(min=1)
+
+    model.train()
+    for leftover in (False, True):
+        tr = XETrainer(model, opt, graph=True)
+        if leftover:                                                            # a replayed step first: _rl_static then points at THAT graph's buffers (another sample_n)
+            tr.rl_step(att, None, score, sample_n=2, temperature=1.0)
+            assert tr._last_rl["gradient_pass_replayed"] and tr._last_rl["reference_gap"] == 0.0
+        while len(tr._graphs) < tr.max_graphs:                                   # what a run of XE steps with different phrase buckets leaves
+            tr._graphs[("filler", len(tr._graphs))] = None
+        w0 = tr.bucket.flat.clone()
+        for _ in range(2):
+            loss, rs, rn = tr.rl_step(att, None, score, sample_n=3, temperature=1.0)
+            last = tr._last_rl
+            assert torch.isfinite(loss) and last["reference_gap"] == 0.0, last["reference_gap"]
+            assert last["gradient_pass_replayed"]                               # (the step takes the replay branch; the replay itself fell back to the eager pass)
+            assert tr._rl_static is not None and tuple(tr._rl_static["picked_saic"].shape) == (att.size(0) * 3, cfg.seq_length)
+            assert float(tr._rl_static["picked_saic"].abs().max()) > 0
+        assert len(tr._graphs) == tr.max_graphs
+        assert float((tr.bucket.flat - w0).abs().max()) > 0
+
+
 def test_reference_estimator_cold_and_without_dropout_is_the_greedy_decode(weight_cache, manifest):
     """The phrase-by-phrase process of the reference-estimator step (engine bounding step -> training-forward rows -> draw -> words handed back to the
     engine) at temperature -> 0 in eval mode is core_SAIC's greedy decode (and the greedy fill of the non-autoregressive layout): layouts and tokens
