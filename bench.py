@@ -613,15 +613,14 @@ def run_rl(args, ctx, log, cpu=True):
     return res
 
 
-def cpu_baseline_refine(cfg, sd, rounds, seed, budget_s=15.0):
+def cpu_baseline_refine(cfg, sd, rounds, seed, budget_s=15.0, batch=256):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import boficap_oracle as O
     from boficap_amd import weights as W
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("BOFI_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     w = O.as_torch(sd)
-    batch = 64
-    att = torch.from_numpy(W.synthetic_att_feats(batch, 36, cfg.att_feat_size, seed=seed))
+    att = torch.from_numpy(W.synthetic_att_feats(batch, 36, cfg.att_feat_size, seed=seed))      # (the SAME workload as the GPU leg: its batch size -- 256 for config 5)
     with torch.no_grad():
         O.sample_naic_refine(w, cfg, att, rounds=rounds)
         times, t_end = [], time.time() + budget_s
@@ -915,7 +914,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
     log(f"gpu done: {res['value']} images/sec")
     if cpu and world == 1:
         refine_rounds, batch_n, budget_s = args.refine, args.batch, args.cpu_budget
-        _cpu_leg(res, (lambda: cpu_baseline_refine(cfg, sd, refine_rounds, ATT_SEED, budget_s=budget_s)) if refine_rounds
+        _cpu_leg(res, (lambda: cpu_baseline_refine(cfg, sd, refine_rounds, ATT_SEED, budget_s=budget_s, batch=batch_n)) if refine_rounds
                  else (lambda: cpu_baseline(cfg, sd, batch_n, ATT_SEED, budget_s=budget_s)))
     del engines, outs, eng
     return res
@@ -1018,6 +1017,15 @@ def main():
             import copy
             raw = {}
             torch.cuda.empty_cache()
+            # steady state: the headline's timed region is what the caller asked for -- the driver's `--steps 20` holds 4 launches of 5 batches,
+            # a quarter of the images in flight the chip is fullest at; this is the same workload through 320 steps at 16 batches per launch (what `python bench.py` and
+            # tools/eval.py run), driver-run beside it.  `value` stays the region the flags asked for.
+            if args.coalesce == 16 and args.steps >= 320:
+                raw["naic_steady_state"] = res                   # (the headline region IS the steady-state shape)
+            else:
+                a = copy.copy(args); a.coalesce, a.steps, a.warmup, a.from_host = 16, 320, 64, False
+                raw["naic_steady_state"] = run_naic(a, ctx, log, False, False)
+                torch.cuda.empty_cache()
             a = copy.copy(args); a.coalesce, a.steps, a.warmup = 1, 80, 16       # one batch of 64 per launch, 4 launches in flight (round-1 headline form)
             raw["naic_one_batch_per_launch"] = run_naic(a, ctx, log, False, False)
             torch.cuda.empty_cache()
@@ -1033,12 +1041,15 @@ def main():
             sec = {k: _compact(v) for k, v in raw.items()}
             res["secondary"] = sec
             # the driver's record keeps `config` whole: the secondary headline scalars ride there too
-            res["config"].update(one_batch_per_launch_img_s=sec["naic_one_batch_per_launch"]["value"],
+            res["config"].update(steady_state_img_s=sec["naic_steady_state"]["value"], steady_state_ms_per_step=sec["naic_steady_state"]["ms_per_step"],
+                                 steady_state_roofline_frac=sec["naic_steady_state"]["roofline"].get("frac"),
+                                 one_batch_per_launch_img_s=sec["naic_one_batch_per_launch"]["value"],
                                  xe_config3_ms_per_step=sec["xe_config3"]["ms_per_step"], xe_config3_img_s=sec["xe_config3"]["value"],
                                  xe_config3_frac_executed=sec["xe_config3"]["roofline"].get("frac_executed"),
                                  rl_config4_ms_per_step=sec["rl_config4"]["ms_per_step"],
                                  refine_config5_img_s=sec["refine_config5"]["value"], refine_config5_ms_per_step=sec["refine_config5"]["ms_per_step"])
-            res["secondary_note"] = ("naic_one_batch_per_launch: the headline workload with one batch of 64 per engine launch; then "
+            res["secondary_note"] = ("naic_steady_state: the headline workload through 320 steps at 16 batches per launch, 4 launches in flight (the shape `python bench.py` "
+                                     "and tools/eval.py run; the headline `value` is the region the flags asked for); naic_one_batch_per_launch: the headline workload with one batch of 64 per engine launch; then "
                                      "driver-run lines of BASELINE configs 3, 4, 5 (short runs in the same process, after the headline measurement; every CPU-oracle "
                                      "leg after all of them); config 5's 'autoregressive fallback' has no counterpart: a UIC checkpoint has no AR decode path in the reference "
                                      "(TransformerModel.py:1791-1804 needs EncoderDecoder.decode, :1287-1310)")

@@ -124,6 +124,11 @@ struct RbFfnArgs {
     // optional: the LayerNorm-folded projection that reads this sublayer's output (the next layer's q|k|v, the stacked cross K|V) computed from the
     // closed block while it is still in LDS: pj_y[M][pj_ldy] bf16 = W_pj . LN(y) + c_pj (what launch_rb_gemm would compute from y)
     const rb_u32x4* pj_wp; const float* pj_c; const float* pj_cs; void* pj_y; int pj_ldy, pj_N;
+    // optional HEAD segment (round 6): the attention sublayer's output projection and residual in front of the feed-forward sublayer, from the attention CORE's context rows:
+    //   x1 = x + W_o . ctx + b_o;   y = x1 + w_2 . relu(w_1 . LN(x1) + b_1) + b_2
+    // (SublayerConnection around MultiHeadedAttention's last Linear, TransformerModel.py:1361-1363, 1467, then :1477-1478): head_ctx [M][head_ldc] bf16 (the heads' outputs
+    // side by side, what launch_attention writes), head_wop W_o fragment-major, head_bo [512].  x1 never exists in memory.  The 80-row kernel, one block per workgroup.
+    const uint16_t* head_ctx; int head_ldc; const rb_u32x4* head_wop; const float* head_bo;
 };
 struct RbAttnArgs {
     const uint16_t* q; int ldq;               // [B*Lq][ldq], head h at columns h*64

@@ -531,11 +531,28 @@ struct bofi_engine {
         return v && (v == 2 || in_flight != 1) && ffn_sublayer_ok(w1, w2, M) && fold_rb_ok(pj, M) && pj.Npad >= 512 && (!maxn || pj.Npad <= maxn) && !exp_skip("ffn") &&
                !exp_skip("qkv") && !exp_skip("kv");
     }
+    // The attention sublayer SPLIT (round 6): the attention core as the light kernel of attn_bf16.hip (context rows to memory as bf16: no W_o stream, no
+    // 80-120 KB of LDS, many workgroups per CU) and W_o + residual as the HEAD segment of the feed-forward launch that follows (rb_ffn5_kernel<.., HEAD>: 80 rows per weight
+    // byte, x1 never in memory) instead of rb_attn_kernel's attention + W_o + residual in one workgroup.  Gate (profiles/r06_gate_attn_split.txt, four streams): the encoder's
+    // sublayer 21.4 -> 11.6 + 1.0 us, the filling pass's cross-attention 14.8 -> 7.9 + 2.2 us per 320 images -- four streams of ONE kernel each.  Inside the decode
+    // (profiles/r06_attn_split_ab.txt, r06_split{0,1}_kernel_stats.txt) the cores save 132 us of kernel time per 320 images (30.1 -> 19.6 and 37.8 -> 22.4 us per launch
+    // in flight) and the head segment costs 116 (115 -> 126 us per feed-forward launch: the producers wait while the consumers run W_o): +1.2 % at 1 024 images per
+    // launch, where a launch's blocks come in several waves per CU and hide the longer chain, -1 ... -4 % at 320, where they do not.  Hence BOFI_RB_ATTN_SPLIT (re-read
+    // after bofi_reload_env): 0 = never, 1 (default) = when launches overlap AND the launch holds at least BOFI_RB_ATTN_SPLIT_MIN_B (512) images, 2 = always.  Needs the
+    // feed-forward sublayer directly behind the attention sublayer and no consumer of the bf16 copy / statistics.
+    bool attn_split_ok(const bofi::AttnArgs& at, const Lin& o, const Lin& w1, const Lin& w2) const {
+        const int v = BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT", 1);
+        const int M = at.B * at.Lq;
+        return v && (v == 2 || (in_flight != 1 && at.B >= BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT_MIN_B", 512))) && BOFI_ENV_INT("BOFI_RB_ATTN", 1) != 0 && rb_ok() && o.wp &&
+               ffn_sublayer_ok(w1, w2, M) && !at.skip_if_ge && at.kdiv <= 1 &&
+               !at.q_start && !at.drop_thresh && at.Lq <= 128 && at.Lk <= 128 && !exp_skip("attn") && !exp_skip("ffn");
+    }
     int ffn_sublayer(const Lin& w1, const Lin& w2, float* x, void* xb, float* stats, int M, hipStream_t s, const Lin* pj = nullptr, void* pj_y = nullptr,
-                     int pj_ldy = 0) {
+                     int pj_ldy = 0, const Lin* head = nullptr, const void* head_ctx = nullptr) {
         if (!ffn_sublayer_ok(w1, w2, M)) return -1;
         if (exp_skip("ffn")) return BOFI_OK;
         bofi::RbFfnArgs a{};
+        if (head) { a.head_wop = (const bofi::u32x4*)head->wp; a.head_bo = head->b; a.head_ctx = (const uint16_t*)head_ctx; a.head_ldc = cfg.d_model; }
         if (pj) { a.pj_wp = (const bofi::u32x4*)pj->wp; a.pj_c = pj->b; a.pj_cs = pj->cs; a.pj_y = pj_y; a.pj_ldy = pj_ldy; a.pj_N = pj->Npad; }
         a.x = x; a.ldx = cfg.d_model; a.w1p = (const bofi::u32x4*)w1.wp; a.c1 = w1.b; a.cs1 = w1.cs; a.w2p = (const bofi::u32x4*)w2.wp; a.b2 = w2.b;
         a.y = x; a.ldy = cfg.d_model; a.yb = (uint16_t*)xb; a.stats_out = stats; a.M = M; a.dff = cfg.d_ff;
@@ -585,7 +602,9 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         a.ldq = a.ldk = a.ldv = 3 * d; a.out = ctx; a.ldo = d; a.dtype = dt; a.B = B; a.H = cfg.heads; a.Lq = R; a.Lk = R;
         a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
         const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2, M);
-        int rc = attn_sublayer(a, l.o, x_enc, xb_enc, st_enc, !ffn_rb, s);
+        const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;      // (consumers of this layer's output that read the copy + statistics: tiled GEMMs)
+        const bool split = ffn_rb && !need_copy && attn_split_ok(a, l.o, l.w1, l.w2);      // attention core now, W_o + residual as the head of the feed-forward launch
+        int rc = split ? bofi::launch_attention(a, s) : attn_sublayer(a, l.o, x_enc, xb_enc, st_enc, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {
             ENG_OK(bofi::launch_attention(a, s));
@@ -593,12 +612,12 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
             ENG_OK(linear(ctx, dt, d, l.o, x_enc, BOFI_DT_F32, d, M, o, s));
         }
         {   // the consumers of this layer's output: the next layer's q|k|v (or the stacked cross K|V): tiled GEMMs read the copy + statistics
-            const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;
             const bool last = li + 1 == enc.size();
             const Lin& nxt = last ? kv_all : enc[li + 1].qkv;
             proj_made = !need_copy && ffn_proj_ok(l.w1, l.w2, nxt, M);
-            rc = !ffn_rb ? -1 : proj_made ? ffn_sublayer(l.w1, l.w2, x_enc, nullptr, nullptr, M, s, &nxt, last ? kv : qkv, last ? kv_all.N : 3 * d)
-                                          : ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s); }
+            const Lin* head = split ? &l.o : nullptr;
+            rc = !ffn_rb ? -1 : proj_made ? ffn_sublayer(l.w1, l.w2, x_enc, nullptr, nullptr, M, s, &nxt, last ? kv : qkv, last ? kv_all.N : 3 * d, head, ctx)
+                                          : ffn_sublayer(l.w1, l.w2, x_enc, need_copy ? xb_enc : nullptr, need_copy ? st_enc : nullptr, M, s, nullptr, nullptr, 0, head, ctx); }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_enc; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }
@@ -763,6 +782,8 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         a.klen_shared_last = (flags & BOFI_FLAG_STRICT_Q1) ? (q1_group > 0 ? q1_group : B) : 0;
         const bool q_rb = fold_rb_ok(l.q_src, M);
         const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2, M);
+        const bool need_copy_out = !(fold_rb_ok(l.qkv, M) && gen_rb);      // (a consumer of this layer's output reads the bf16 copy + statistics: a tiled GEMM)
+        bool cross_split = false;
         // both attention sublayers as one launch (rb_dec_attn_kernel): the block stays in LDS between them, the cross-attention's queries never exist in memory
         int rc = dec_attn_sublayers(a, l, att_len, li, R, !ffn_rb, s);
         if (rc > 0) return rc;
@@ -786,7 +807,8 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
         c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
         c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0;
-        rc = attn_sublayer(c, l.o_src, x_fill, xb_fill, st_fill, !ffn_rb, s);
+        cross_split = ffn_rb && !need_copy_out && attn_split_ok(c, l.o_src, l.w1, l.w2);      // the cross-attention's core now, its W_o + residual as the head of the feed-forward launch
+        rc = cross_split ? bofi::launch_attention(c, s) : attn_sublayer(c, l.o_src, x_fill, xb_fill, st_fill, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {
             ENG_OK(bofi::launch_attention(c, s));
@@ -795,10 +817,11 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         }
         }
         {   // next consumer: the next layer's q|k|v or the generator
-            const bool need_copy = !(fold_rb_ok(l.qkv, M) && gen_rb);
+            const bool need_copy = need_copy_out;
             proj_made = !need_copy && li + 1 < dec.size() && ffn_proj_ok(l.w1, l.w2, dec[li + 1].qkv, M);
-            rc = !ffn_rb ? -1 : proj_made ? ffn_sublayer(l.w1, l.w2, x_fill, nullptr, nullptr, M, s, &dec[li + 1].qkv, qkv, 3 * d)
-                                          : ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s); }
+            const Lin* head = cross_split ? &l.o_src : nullptr;
+            rc = !ffn_rb ? -1 : proj_made ? ffn_sublayer(l.w1, l.w2, x_fill, nullptr, nullptr, M, s, &dec[li + 1].qkv, qkv, 3 * d, head, ctx)
+                                          : ffn_sublayer(l.w1, l.w2, x_fill, need_copy ? xb_fill : nullptr, need_copy ? st_fill : nullptr, M, s, nullptr, nullptr, 0, head, ctx); }
         if (rc > 0) return rc;
         if (rc < 0) {
             { LinOpt o; o.relu = 1; o.ln_stats = st_fill; ENG_OK(linear(xa, dt, d, l.w1, hdn, dt, cfg.d_ff, M, o, s)); }

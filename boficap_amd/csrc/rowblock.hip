@@ -485,7 +485,9 @@ constexpr int R5_B2 = R5_FLAG + 64;                                    // b_2 [5
 constexpr int R5_LDS = R5_B2 + 2048;
 constexpr int R5_PJS = R5_LDS;                                         // projection tail: per consumer wavefront (sum, sum of squares) of its 128 columns of every row [4][80]
 constexpr int R5_LDS_PJ = R5_PJS + 4 * R5_ROWS * 8;
-static_assert(R5_LDS_PJ <= 160 * 1024, "one workgroup per CU");
+constexpr int R5_BO = R5_LDS_PJ;                                       // head segment: b_o [512]
+constexpr int R5_LDS_HEAD = R5_BO + 2048;
+static_assert(R5_LDS_HEAD <= 160 * 1024, "one workgroup per CU");
 static_assert(8 * RbGemmCfg<false, 5>::STG + 8 * 512 <= R5_SLOTS * R5_SLOT, "the tail's staging and constants fit the hidden ring");
 
 // The projection tail of rb_ffn5_kernel<PROJ>: pj_y = W_pj . LN(y) + c_pj for the block the consumers just closed (bf16 rows back in the block's LDS, their
@@ -526,9 +528,15 @@ __device__ __forceinline__ void rb_ffn5_proj_tail(const u32x4* pj_wp, const floa
                              (int)blockIdx.x * R5_ROWS, wave, lane, wave, 8, wb);
 }
 
-template <bool EXTRA, bool STAMPS, bool PROJ = false, bool ONE = PROJ>   // ONE: one block per workgroup (no block loop: nothing is kept for a next block); EXTRA: the optional bf16 copy / partial sums are written; STAMPS: the developer timeline (BOFI_RB_DBG & 16);
+template <bool EXTRA, bool STAMPS, bool PROJ = false, bool ONE = PROJ, bool HEAD = false>   // ONE: one block per workgroup (no block loop: nothing is kept for a next block); EXTRA: the optional bf16 copy / partial sums are written; STAMPS: the developer timeline (BOFI_RB_DBG & 16);
                                                         // PROJ: the projection tail (a.pj_*; one block per workgroup)
+                                                        // HEAD (round 6): the attention sublayer's W_o + residual in FRONT of the feed-forward sublayer (a.head_*; one block per workgroup): the producers stage the
+                                                        // attention core's context rows as the block, the CONSUMERS -- whose accumulators start from the residual rows anyway -- run one 0.5-MB W_o segment over it
+                                                        // (x1 = x + W_o . ctx + b_o stays in their accumulators as the feed-forward's residual), put x1 back into the block as bf16 with their share of its row sums,
+                                                        // and the feed-forward runs as without a head.  The attention kernel in front of this one is then a light core (no W_o, no 80-120 KB of LDS, no idle weight
+                                                        // stream), W_o runs at 80 rows per weight byte and x1 never makes the round trip through memory.
 __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
+    static_assert(!HEAD || (ONE && !EXTRA && !STAMPS), "the head segment: one block per workgroup, plain outputs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;                                  // [80][512] bf16, swizzled, row pitch 1 024 B
     unsigned char* hr = smem + R5_HR;                          // 3 slots x [80][128] bf16, swizzled, row pitch 256 B
@@ -562,15 +570,22 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
     auto w2frag = [&](int step, int f) {
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, lo16 + (f & 3) * 1024, (int)((f >> 2) * w2j) + step * 4096 * wmul, 0));
     };
+    // (HEAD) the consumer's W_o stream, the same way: its two 64-column chunks of W_o [8 chunks][16 steps][4 tiles][64 lanes][16 B] one after the other
+    const __amdgpu_buffer_rsrc_t wor = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>((HEAD ? a.head_wop : a.w2p) + (size_t)(2 * __builtin_amdgcn_readfirstlane(w4)) * (16 * 256)), 0, 2 * 65536, 0x00020000);
+    auto wofrag = [&](int step, int f) {
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wor, lo16 + (f & 3) * 1024, (f >> 2) * 65536 + step * 4096, 0));
+    };
     if (producer) rb_prime<2, 8>(w1seg(0), wbuf);
     else {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int f = 0; f < 8; ++f) wbuf[p * 8 + f] = w2frag(p, f);
+            for (int f = 0; f < 8; ++f) wbuf[p * 8 + f] = HEAD ? wofrag(p, f) : w2frag(p, f);
     }
-    if (tid < 8) flags[tid] = 0u;
+    if (tid < 16) flags[tid] = 0u;                             // (HEAD: [7] context block staged, [8] consumers through with it, [9] x1 back in the block)
     reinterpret_cast<float*>(smem + R5_B2)[tid] = a.b2[tid];
+    if constexpr (HEAD) reinterpret_cast<float*>(smem + R5_BO)[tid] = a.head_bo[tid];
     __syncthreads();                                           // (the only workgroup barrier of the kernel)
 
     // (experiment, BOFI_RB_DBG & 64 / & 128: static issue priority for the producer / consumer wavefronts -- the two of a SIMD share its matrix pipe)
@@ -584,6 +599,38 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
             const int m0 = blk * R5_ROWS;
             if (blk != (int)blockIdx.x) { ++pb; rb_signal(flags + 6, lane); rb_wait_ge(flags + 6, 4u * pb); }      // every producer is through with the previous block
             RB3_STAMP(stamps, nst);                            // staging starts
+            if constexpr (HEAD) {
+                // the attention core's context rows ARE the block (bf16 already: a copy into the swizzled layout); then the consumers run W_o over it and hand x1 back
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass) {          // wavefront w4: rows 20*w4 .. +19, eight at a time, eight lanes per row, eight 16-byte chunks per lane
+                    const int lr = pass * 8 + (lane >> 3), r = w4 * 20 + lr, sub = lane & 7, m = m0 + r;
+                    const bool mine = lr < 20;
+                    u32x4 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = (mine && m < a.M) ? *reinterpret_cast<const u32x4*>(a.head_ctx + (size_t)m * a.head_ldc + (j * 8 + sub) * 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (mine) *reinterpret_cast<u32x4*>(xt + rb_off(r, j * 8 + sub)) = v[j];
+                }
+                rb_signal(flags + 7, lane);                    // (the consumers wait for all four producers' rows)
+                rb_wait_ge(flags + 9, 4u);                     // x1 is back in the block as bf16, the consumers' partial row sums beside it
+                const float2* pjs = reinterpret_cast<const float2*>(smem + R5_PJS);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {                  // (every producer derives the statistics itself: the same values to the same words -- the tail reads them too)
+                    const int r = i * 64 + lane;
+                    if (r < R5_ROWS) {
+                        const float2 p0 = pjs[r], p1 = pjs[R5_ROWS + r], p2 = pjs[2 * R5_ROWS + r], p3 = pjs[3 * R5_ROWS + r];
+                        const float sm = (p0.x + p1.x) + (p2.x + p3.x), sq = (p0.y + p1.y) + (p2.y + p3.y);
+                        const float mean = sm * (1.0f / 512.0f);
+                        const float var = fmaxf((sq - sm * mean) * (1.0f / 511.0f), 0.f);
+                        s_mean[r] = mean;
+                        s_rstd[r] = 1.0f / (sqrtf(var) + 1e-6f);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
 #pragma unroll
             for (int pass = 0; pass < 3; ++pass) {              // wavefront w4: rows 20*w4 .. +19, eight at a time, eight lanes per row
                 const int lr = pass * 8 + (lane >> 3), r = w4 * 20 + lr, sub = lane & 7, m = m0 + r;
@@ -608,6 +655,7 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
                 }
             }
             ++pb; rb_signal(flags + 6, lane); rb_wait_ge(flags + 6, 4u * pb);                                      // block and statistics complete
+            }
             RB3_STAMP(stamps, nst);                            // block staged
             float mu[5], rs[5];
 #pragma unroll
@@ -662,6 +710,76 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
                 const float4 v = *reinterpret_cast<const float4*>(xn + f * 16);
                 acc2[f][mt] = f32x4{v.x, v.y, v.z, v.w};
             }
+        }
+        if constexpr (HEAD) {
+            // ---- head segment: acc2 (= x) += W_o . ctx over the staged context block: 16 k-steps of this wavefront's 128 output columns
+            rb_wait_ge(flags + 7, 4u);
+            auto wo_steps = [&](int k4, bool more) {            // four k-steps of the segment; `more`: the ring is refilled two steps ahead (false: the segment's last two steps)
+                int hl = l15, hg = g;
+                asm volatile("" : "+v"(hl), "+v"(hg));
+                const int lb = hl * 1024 + (((hl >> 2) << 6) | ((hg ^ (hl & 3)) << 4));
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int kb = k4 * 4 + kq;
+                    const unsigned char* xp = smem + (lb ^ (kb << 6));
+#pragma unroll
+                    for (int mb = 0; mb < 5; mb += 2) {
+                        bf16x8 xa[2];
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2)
+                            if (mb + m2 < 5) xa[m2] = *reinterpret_cast<const bf16x8*>(xp + (mb + m2) * 16384);
+#pragma unroll
+                        for (int f = 0; f < 8; ++f)
+#pragma unroll
+                            for (int m2 = 0; m2 < 2; ++m2)
+                                if (mb + m2 < 5) acc2[f][mb + m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[(kq & 1) * 8 + f], xa[m2], acc2[f][mb + m2], 0, 0, 0);
+                    }
+                    if (more || kq < 2) {
+#pragma unroll
+                        for (int f = 0; f < 8; ++f) wbuf[(kq & 1) * 8 + f] = wofrag(kb + 2, f);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+#pragma unroll 1
+            for (int k4 = 0; k4 < 3; ++k4) wo_steps(k4, true);
+            wo_steps(3, false);                                 // (the w_2 ring is primed behind the hand-back below: its 64 registers are free for it, and the first hidden chunk is a segment away anyway)
+            rb_signal(flags + 8, lane);                        // this wavefront is through with the context block ...
+            // x1 = acc2 + b_o
+            {
+                const float* bol = reinterpret_cast<const float*>(smem + R5_BO) + w4 * 128 + g * 4;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bol + f * 16);
+#pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) { acc2[f][mt][0] += bb.x; acc2[f][mt][1] += bb.y; acc2[f][mt][2] += bb.z; acc2[f][mt][3] += bb.w; }
+                }
+            }
+            rb_wait_ge(flags + 8, 4u);                         // ... and so are the other three: the block may take x1
+            {
+                float2* pjs = reinterpret_cast<float2*>(smem + R5_PJS) + w4 * R5_ROWS;
+                int lv = l15, gv = g;
+                asm volatile("" : "+v"(lv), "+v"(gv));
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    const int r = mt * 16 + lv;
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        const f32x4 t = acc2[f][mt];
+                        sm += (t[0] + t[1]) + (t[2] + t[3]);
+                        sq += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+                        *reinterpret_cast<uint2*>(xt + rb_off(r, w4 * 16 + f * 2 + (gv >> 1)) + (gv & 1) * 8) = make_uint2(pack_bf16(t[0], t[1]), pack_bf16(t[2], t[3]));
+                    }
+                    sm = xor32_sum(xor16_sum(sm)); sq = xor32_sum(xor16_sum(sq));
+                    if (gv == 0) pjs[r] = make_float2(sm, sq);
+                }
+            }
+            rb_signal(flags + 9, lane);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int f = 0; f < 8; ++f) wbuf[p * 8 + f] = w2frag(p, f);
         }
         unsigned q = 0;
 #pragma unroll 1
@@ -796,7 +914,9 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_ffn5_kernel<false, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
         attr_set = true;
     }
     // knobs (read again after bofi_reload_env): BOFI_RB_FFN_V = 5 (default): 80-row blocks -- +3 % on the decode with launches in flight; 2: one
@@ -812,8 +932,13 @@ int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st) {
     }
     RbFfnArgs b = a;
     { const char* e = getenv("BOFI_RB_DBG"); b.dbg = e ? atoi(e) : 0; }
-    if (a.pj_wp) {                                            // with the projection tail: the 80-row kernel, one block per workgroup
-        if (!a.pj_c || !a.pj_cs || !a.pj_y || a.pj_N < 512 || a.pj_N % 64 || a.pj_ldy % 8 || a.yb || a.stats_out) return BOFI_ERR_ARG;
+    if (a.pj_wp && (!a.pj_c || !a.pj_cs || !a.pj_y || a.pj_N < 512 || a.pj_N % 64 || a.pj_ldy % 8 || a.yb || a.stats_out)) return BOFI_ERR_ARG;
+    if (a.head_wop) {                                         // with the attention sublayer's W_o + residual in front (and, optionally, the projection tail behind): one block per workgroup
+        if (!a.head_ctx || !a.head_bo || a.head_ldc % 8 || a.yb || a.stats_out) return BOFI_ERR_ARG;
+        if (a.pj_wp) hipLaunchKernelGGL((rb_ffn5_kernel<false, false, true, true, true>), dim3((a.M + R5_ROWS - 1) / R5_ROWS), dim3(512), R5_LDS_HEAD, st, b);
+        else hipLaunchKernelGGL((rb_ffn5_kernel<false, false, false, true, true>), dim3((a.M + R5_ROWS - 1) / R5_ROWS), dim3(512), R5_LDS_HEAD, st, b);
+        g_gemm_flops += 2.0 * a.M * 512.0 * 512.0 + (a.pj_wp ? 2.0 * a.M * 512.0 * a.pj_N : 0.0);
+    } else if (a.pj_wp) {                                     // with the projection tail: the 80-row kernel, one block per workgroup
         hipLaunchKernelGGL((rb_ffn5_kernel<false, false, true>), dim3((a.M + R5_ROWS - 1) / R5_ROWS), dim3(512), R5_LDS_PJ, st, b);
         g_gemm_flops += 2.0 * a.M * 512.0 * a.pj_N;
     } else if (version == 2 || a.M < v5_rows || (a.alone && !forced)) hipLaunchKernelGGL(rb_ffn2_kernel, dim3((a.M + 63) / 64), dim3(512), lds, st, b);
@@ -1791,6 +1916,18 @@ extern "C" int bofi_ffn_block(const float* x, int ldx, const void* w1p, const fl
     bofi::RbFfnArgs a{};
     a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
     a.yb = (bofi::bf16_t*)yb; a.stats_out = stats_out; a.M = M; a.dff = dff;
+    return bofi::launch_rb_ffn(a, (hipStream_t)stream);
+}
+
+extern "C" int bofi_attn_out_ffn_block(const float* x, int ldx, const void* ctx, int ldc, const void* wop, const float* bo, const void* w1p, const float* c1, const float* cs1,
+                                       const void* w2p, const float* b2, float* y, int ldy, int M, int dff, const void* pj_wp, const float* pj_c, const float* pj_cs, void* pj_y,
+                                       int pj_ldy, int pj_N, void* stream) {
+    if (!ctx || !wop || !bo) return BOFI_ERR_ARG;
+    bofi::RbFfnArgs a{};
+    a.x = x; a.ldx = ldx; a.w1p = (const bofi::u32x4*)w1p; a.c1 = c1; a.cs1 = cs1; a.w2p = (const bofi::u32x4*)w2p; a.b2 = b2; a.y = y; a.ldy = ldy;
+    a.M = M; a.dff = dff;
+    a.head_ctx = (const uint16_t*)ctx; a.head_ldc = ldc; a.head_wop = (const bofi::u32x4*)wop; a.head_bo = bo;
+    if (pj_wp) { a.pj_wp = (const bofi::u32x4*)pj_wp; a.pj_c = pj_c; a.pj_cs = pj_cs; a.pj_y = pj_y; a.pj_ldy = pj_ldy; a.pj_N = pj_N; }
     return bofi::launch_rb_ffn(a, (hipStream_t)stream);
 }
 

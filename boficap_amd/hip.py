@@ -106,6 +106,7 @@ SIGNATURES = {
     "bofi_ffn_block": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "bofi_ffn_linear_block": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "bofi_engine_fill_naic": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "bofi_attn_out_ffn_block": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 _lib = None

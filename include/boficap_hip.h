@@ -508,6 +508,16 @@ int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, co
 int bofi_ffn_linear_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
                           float* y, int ldy, int M, int dff, const void* pj_wp, const float* pj_c, const float* pj_cs, void* pj_y,
                           int pj_ldy, int pj_N, void* stream);
+/* bofi_attn_out_ffn_block (round 6): the SECOND half of an attention sublayer -- output projection, bias, residual (MultiHeadedAttention.forward's last Linear
+ *   TransformerModel.py:1467 behind SublayerConnection :1361-1363) -- as the HEAD segment of the feed-forward sublayer that follows it (:1477-1478; EncoderLayer :1374-1377,
+ *   DecoderLayer :1408-1413), ONE launch:   x1 = x + W_o ctx + b_o;   y = x1 + w_2 relu(w_1 LN(x1) + b_1) + b_2   [; pj_y = W_pj' LN(y) + c_pj as bofi_ffn_linear_block]
+ *   ctx: bf16 [M, ldc] -- the heads' attention outputs side by side, what bofi_attention writes (the attention CORE: no weights, a light kernel);  wop: W_o [512][512] in
+ *   bofi_pack_frag's layout, bo float32 [512];  the rest as bofi_ffn_block / bofi_ffn_linear_block (pj_wp NULL: no projection tail).  x1 never exists in memory: the
+ *   kernel's consumer wavefronts start their accumulators from x, run the W_o segment over the staged context block, and keep x1 as the feed-forward's residual.
+ *   Equal to bofi_attn_block's W_o half + bofi_ffn_block up to the summation order of the row statistics behind LN(x1).  80-row blocks, one per workgroup. */
+int bofi_attn_out_ffn_block(const float* x, int ldx, const void* ctx, int ldc, const void* wop, const float* bo, const void* w1p, const float* c1,
+                            const float* cs1, const void* w2p, const float* b2, float* y, int ldy, int M, int dff, const void* pj_wp, const float* pj_c,
+                            const float* pj_cs, void* pj_y, int pj_ldy, int pj_N, void* stream);
 
 /* Developer aid: copy one of the bounding iteration's workspace buffers ("by1", "byb", "st_b", "bq2", "bctx2", "by2", "bh", "by3")
  * into user memory (device to device, on `stream`). */

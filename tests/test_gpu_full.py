@@ -319,7 +319,7 @@ def test_full_q1_shortening_and_saic_multi_fixture(weight_cache, manifest):
 
 
 # ------------------------------------------------------------------------------------------------ bf16 tolerance on every image
-@pytest.mark.parametrize("config_name,tol,family", [("FULL", 2e-2, "tiled"), ("FULL", 2e-2, "row-block"), ("FULL", 2e-2, "five-launch"), ("TINY", 6e-2, "tiled")])
+@pytest.mark.parametrize("config_name,tol,family", [("FULL", 2e-2, "tiled"), ("FULL", 2e-2, "row-block"), ("FULL", 2e-2, "row-block-split"), ("FULL", 2e-2, "five-launch"), ("TINY", 6e-2, "tiled")])
 def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, family, weight_cache, monkeypatch):
     """north_star: logits within 2e-2 for bf16 -- shown on ALL images, nothing filtered: (1) the bound heads' log-probs of the
     first bounding step, (2) the fill pass with the float32 oracle's slot layout teacher-forced (bofi_engine_fill_naic), so
@@ -328,14 +328,17 @@ def test_bf16_logits_within_tolerance_on_every_image(config_name, tol, family, w
     family: 64 images are below the size from which the engine takes the row-block sublayer kernels -- "row-block" forces them
     (BOFI_RB_MIN_ROWS=0), so both kernel families are held to the same bars on the same images.  At the full size the bounding step is
     round 5's persistent loop kernel (fp16 operands from the float32 parameters, float32 self-attention tables); "five-launch" is the
-    chain of rounds 2-4 (bf16 operands; what a decode that runs alone still takes) on the tiled family."""
+    chain of rounds 2-4 (bf16 operands; what a decode that runs alone still takes) on the tiled family.  "row-block-split" (round 6): the row-block family with the
+    attention sublayers of the encoder and the filling pass's cross-attention SPLIT -- attention core as its own light launch, W_o + residual as the head segment of the
+    feed-forward launch (BOFI_RB_ATTN_SPLIT=2; what launches of >= 512 images take by default)."""
     from boficap_amd import hip as H
     from boficap_amd import weights as W
     from boficap_amd.engine import BofiEngine
-    monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0" if family == "row-block" else "1000000000")
+    monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0" if family.startswith("row-block") else "1000000000")
+    monkeypatch.setenv("BOFI_RB_ATTN_SPLIT", "2" if family == "row-block-split" else "0")
     monkeypatch.setenv("BOFI_BOUND_LOOP", "0" if family == "five-launch" else "2")
     H.lib().bofi_reload_env()
-    config_tag = config_name + ("_row_block" if family == "row-block" else "_five_launch" if family == "five-launch" else "")
+    config_tag = config_name + ("_row_block" if family == "row-block" else "_row_block_split" if family == "row-block-split" else "_five_launch" if family == "five-launch" else "")
     cfg, sd = weight_cache(config_name, 0, 1.0)
     w = O.as_torch(sd)
     B = 64
@@ -713,7 +716,7 @@ def test_xe_step_with_100_regions(weight_cache, manifest, dtype):
         record_parity("bf16_xe_100_regions_worst_relative_gradient_norm_error", worst, 5e-2)
 
 
-@pytest.mark.parametrize("family", ["row-block", "tiled", "by-size"])
+@pytest.mark.parametrize("family", ["row-block", "row-block-split", "tiled", "by-size"])
 def test_five_batches_per_launch_equal_their_own_decodes(weight_cache, family, monkeypatch):
     """The default bench workload: 5 batches of 64 images in ONE engine call (q1_group = 64, 320 images: the bounding iteration's row
     kernels take five 64-row blocks, the GEMMs other tiles than at 64 images) against every batch's own separate decode, bf16, full size.
@@ -726,7 +729,8 @@ def test_five_batches_per_launch_equal_their_own_decodes(weight_cache, family, m
     from boficap_amd.config import FULL as cfg
     from boficap_amd.engine import BofiEngine
     if family != "by-size":
-        monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0" if family == "row-block" else "1000000000")
+        monkeypatch.setenv("BOFI_RB_MIN_ROWS", "0" if family.startswith("row-block") else "1000000000")
+        monkeypatch.setenv("BOFI_RB_ATTN_SPLIT", "2" if family == "row-block-split" else "0")      # (round 6: the split attention sublayers at every size, or never)
     H.lib().bofi_reload_env()
     try:
         sd = W.make_state_dict(cfg, seed=0)

@@ -477,3 +477,85 @@ def test_attn_linear_block_is_the_two_launches(H, B, S, masks):
     ref = _layer_norm64(ya[rows_ok], gain, bln) @ (_bf(wqf).double() / gain.double()[None, :]).T + bq.double()
     assert (pb[rows_ok, :d].double() - ref).abs().max() < 6e-2
     assert torch.isnan(pb[~rows_ok, :d]).all()
+
+
+@pytest.mark.parametrize("M,dff,N", [(80, 2048, 0), (700, 2048, 1536), (6400, 2048, 1536), (333, 1024, 0), (11520, 2048, 7168)])
+def test_attn_out_ffn_block_is_the_two_halves(H, M, dff, N, monkeypatch):
+    """bofi_attn_out_ffn_block (rb_ffn5_kernel<.., HEAD>; round 6): x1 = x + W_o ctx + b_o as the head segment of the feed-forward launch, then the sublayer (and the
+    projection tail, N > 0) as without a head.  Against (1) the float64 statement of both sublayer halves (TransformerModel.py:1467 behind :1361-1363, then :1477-1478) and
+    (2) this library's own two kernels: x1 by the tiled GEMM with a residual epilogue (bofi_linear), the feed-forward by bofi_ffn_block on THAT x1 -- the head form differs
+    from them in the summation order of W_o's K loop (one MFMA chain against the tiled kernel's) and of the row statistics behind LN(x1): a few bf16 steps on hidden values.
+    Ragged last blocks, in place, NaN context rows stay in their rows."""
+    d = 512
+    g = _rng(M + dff + N + 7)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.2
+    ctx = (torch.randn(M, d, generator=g) * 0.7).to(torch.bfloat16)
+    wo, bo = (torch.randn(d, d, generator=g) / math.sqrt(d)).to(torch.bfloat16), torch.randn(d, generator=g) * 0.1
+    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w1, b1 = torch.randn(dff, d, generator=g) / math.sqrt(d), torch.randn(dff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, dff, generator=g) / math.sqrt(dff), torch.randn(d, generator=g) * 0.1
+    w1f, c1, cs1 = _fold(w1, b1, gain, bln)
+    xc, ctxc = x.cuda(), ctx.cuda()
+    wop, w1p, w2p = pack_frag(H, wo.cuda()), pack_frag(H, w1f.to(torch.bfloat16).cuda()), pack_frag(H, w2.to(torch.bfloat16).cuda())
+    boc, c1c, cs1c, b2c = bo.cuda(), c1.cuda(), cs1.cuda(), b2.cuda()
+    pj = None
+    if N:
+        gain2, bln2 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+        wj, bj = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g) * 0.1
+        wjf, cj, csj = _fold(wj, bj, gain2, bln2)
+        pj = (pack_frag(H, wjf.to(torch.bfloat16).cuda()), cj.cuda(), csj.cuda())
+    monkeypatch.setenv("BOFI_RB_FFN_V", "5")
+    H.lib().bofi_reload_env()
+    try:
+        def head(xin, yout, pout):
+            H.check(H.lib().bofi_attn_out_ffn_block(H.ptr(xin), d, H.ptr(ctxc), d, H.ptr(wop), H.ptr(boc), H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c),
+                                                    H.ptr(yout), d, M, dff, H.ptr(pj[0]) if pj else None, H.ptr(pj[1]) if pj else None, H.ptr(pj[2]) if pj else None,
+                                                    H.ptr(pout) if pj else None, N + 64 if pj else 0, N, H.stream_ptr()))
+        y1 = torch.full((M, d), float("nan"), device="cuda")
+        p1 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda") if N else None
+        head(xc, y1, p1)
+        # (2) the library's own halves: x1 = x + W_o ctx + b_o by the tiled GEMM, then the feed-forward kernel on it
+        x1 = torch.empty(M, d, device="cuda")
+        H.check(H.lib().bofi_linear(H.ptr(ctxc), 1, d, H.ptr(wo.cuda()), 1, H.ptr(boc), H.ptr(xc), d, H.ptr(x1), 0, d, M, d, d, 0, None, 0, H.stream_ptr()))
+        y0 = torch.full((M, d), float("nan"), device="cuda")
+        H.check(H.lib().bofi_ffn_block(H.ptr(x1), d, H.ptr(w1p), H.ptr(c1c), H.ptr(cs1c), H.ptr(w2p), H.ptr(b2c), H.ptr(y0), d, None, None, M, dff, H.stream_ptr()))
+        torch.cuda.synchronize()
+        # (1) float64
+        x1_ref = x.double() + ctx.double() @ wo.double().T + bo.double()
+        assert (x1.cpu().double() - x1_ref).abs().max() < 1e-4
+        hid = torch.relu(_layer_norm64(x1_ref.float(), gain, bln) @ (w1f.to(torch.bfloat16).double() / gain.double()[None, :]).T + b1.double())
+        y_ref = x1_ref + hid @ w2.to(torch.bfloat16).double().T + b2.double()
+        a, b = y1.cpu().double(), y0.cpu().double()
+        assert not torch.isnan(a).any()
+        e_ref, e_two = float((a - y_ref).abs().max()), float((a - b).abs().max())
+        print(f"M {M} dff {dff}: head form vs float64 {e_ref:.2e}; vs the two launches {e_two:.2e}; the two launches vs float64 {float((b - y_ref).abs().max()):.2e}")
+        assert e_ref < 3e-2 and e_two < 3e-2, (e_ref, e_two)       # (bf16 operands: hidden rows and LN(x1) rounded to 8 bits; the two-launch form sits at the same distance from float64)
+        if N:
+            assert (p1.cpu()[:, N:].float() == 7.0).all()
+            w_eff = wjf.double() / gain2.double()[None, :]
+            ref = _layer_norm64(y1.cpu(), gain2, bln2) @ w_eff.T + bj.double()
+            assert (p1.cpu()[:, :N].double() - ref).abs().max() < 6e-2
+        # in place, as the engine runs it: the same bits
+        x2 = xc.clone()
+        p2 = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda") if N else None
+        head(x2, x2, p2)
+        torch.cuda.synchronize()
+        assert torch.equal(x2.cpu(), y1.cpu())
+        if N:
+            assert torch.equal(p2.cpu().view(torch.int16), p1.cpu().view(torch.int16))
+        # a NaN context row (an image without visible keys: softmax over nothing, TransformerModel.py:1427-1429) stays in its row
+        if M > 100:
+            ctx_n = ctxc.clone(); ctx_n[81, 5] = float("nan")
+            ctxc_keep = ctxc
+            ctxc = ctx_n
+            y3 = torch.empty(M, d, device="cuda")
+            head(xc, y3, torch.empty_like(p1) if N else None)
+            torch.cuda.synchronize()
+            ctxc = ctxc_keep
+            bad = torch.isnan(y3).any(1).cpu()
+            assert bool(bad[81]) and int(bad.sum()) == 1
+            keep = torch.ones(M, dtype=torch.bool); keep[81] = False
+            assert torch.equal(y3.cpu()[keep], y1.cpu()[keep])
+    finally:
+        monkeypatch.delenv("BOFI_RB_FFN_V")
+        H.lib().bofi_reload_env()
