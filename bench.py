@@ -58,6 +58,12 @@ def dist_setup(args):
     # whole N > 1 path of this script (self-launch, sharding, barriers, the max over ranks, the XE exchange secondary); its numbers mean nothing
     # and the line says so (config.rehearsal)
     rehearsal = os.environ.get("BOFI_BENCH_REHEARSAL") == "1"
+    if os.environ.get("BOFI_BENCH_REHEARSAL") == "dry":      # the launcher / sharding / barrier / reduction plumbing of N ranks WITHOUT a GPU (run_dry): gloo on the CPU
+        if world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("gloo")
+        return rank, local_rank, world, torch.device("cpu")
     dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -839,11 +845,20 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
         del pipe, pool, hb
         torch.cuda.empty_cache()
     traffic, tnote = None, "no PMC pass committed for this configuration"
-    names = {1: ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",),
-             16: ("r05_hbm_traffic_coalesce16.json",),
-             5: ("r05_hbm_traffic_coalesce5.json", "r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
+    names = {1: ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"), 4: ("r02_hbm_traffic_coalesce4.json",),
+             16: ("r06_hbm_traffic_coalesce16.json", "r05_hbm_traffic_coalesce16.json"),
+             5: ("r06_hbm_traffic_coalesce5.json", "r05_hbm_traffic_coalesce5.json", "r04_hbm_traffic_coalesce5.json", "r03_hbm_traffic_coalesce5.json", "r02_hbm_traffic_coalesce5.json")}.get(C, ())
+    config5 = args.batch == 256 and args.refine == 3 and C == 1 and args.dtype == "bf16"      # (BASELINE config 5: its own PMC pass, profiles/r06_hbm_traffic_config5.json)
+    if config5:
+        names = ("r06_hbm_traffic_config5.json",)
     for name in names:                                          # HBM bytes per launch from the newest committed PMC run of this configuration
         tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath) and config5:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_step")
+            tnote = (f"HBM-side bytes per launch (one batch of 256, 3 refinement rounds), rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, "
+                     f"one launch at a time (profiles/{name})")
+            break
         if os.path.exists(tpath) and args.batch == 64 and args.dtype == "bf16" and not args.refine:
             with open(tpath) as f:
                 tj = json.load(f)
@@ -937,6 +952,45 @@ def _compact(res):
     return out
 
 
+def run_dry(args, ctx, log):
+    """BOFI_BENCH_REHEARSAL=dry: `python bench.py --gpus N` with the GPU work of every rank replaced by a sleep -- the multi-rank SHAPE of this script and nothing else
+    (self-launch through torch.distributed.run, WORLD_SIZE against --gpus, the process group, images sharded by rank, barrier-bracketed region, the MAX over ranks of
+    the elapsed time, value = every rank's images over that time, ONE line from rank 0, a rank that fails before the exchange -> a non-zero exit of the job).  What an
+    8-GPU scaling run exercises that no one-GPU box can (at most 6 processes may share its card); run on the CPU over gloo by tests/test_dp_gloo.py.  The line is
+    marked `rehearsal` and `data: none`: it measures nothing and is no product path (the decode has no CPU form: BofiHipError without the library or a device)."""
+    import torch.distributed as dist
+    from boficap_amd import dp
+    rank, local_rank, world, dev = ctx
+    fail = os.environ.get("BOFI_BENCH_DRY_FAIL_RANK")
+    lo, hi = dp.shard_range(args.batch * world * args.steps, rank, world)        # the images of the whole job, by rank (the decode shards with no collective)
+    if fail is not None and int(fail) == rank:
+        raise RuntimeError(f"rank {rank}: injected failure before the exchange (BOFI_BENCH_DRY_FAIL_RANK)")
+    per_step_s = 1e-3 * (1.0 + 0.25 * rank)                                        # the slowest rank sets the job's time
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(per_step_s * args.steps)
+    if world > 1:
+        dist.barrier()
+    elapsed = dp.reduce_scalar(time.perf_counter() - t0, "max", device=dev)
+    mine = torch.tensor([hi - lo], dtype=torch.int64)
+    shards = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(shards, mine)
+    else:
+        shards = [mine]
+    total = dp.reduce_scalar(float(hi - lo), "sum", device=dev)
+    if rank != 0:
+        return None
+    return {"metric": "DRY WALK of the multi-rank path (no GPU work): images/sec of sleeping ranks", "value": round(total / elapsed, 1), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "none", "data": "none",
+            "config": {"workload": "dry walk: every rank sleeps (1 + rank / 4) ms per step", "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                       "dist_backend": dist.get_backend() if world > 1 else None, "shard_images_per_rank": [int(t.item()) for t in shards],
+                       "images_per_step_per_gpu": args.batch, "slowest_rank_ms_per_step": round(1e3 * 1e-3 * (1.0 + 0.25 * (world - 1)), 4),
+                       "rehearsal": "dry: no GPU work, the launcher / sharding / barrier / reduction plumbing only"}}
+
+
 def choose_coalesce(steps: int, inflight: int) -> int:
     """Batches of 64 per engine launch for a timed region of ``steps`` batches on ``inflight`` streams: among 16, 20, 10, 8, 5, 4, 2 the count that divides the steps and
     spreads the launches evenly over the streams (fewest rounds x batches per launch), the first of equals; 1 when none divides."""
@@ -1006,6 +1060,15 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     cpu = not args.no_cpu_baseline
+    if os.environ.get("BOFI_BENCH_REHEARSAL") == "dry":
+        res = run_dry(args, ctx, log)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.mode == "xe":
         res = run_xe(args, ctx, log, cpu)
     elif args.mode == "rl":

@@ -157,15 +157,6 @@ struct RbGemmArgs {
 int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st);
 int launch_rb_ffn(const RbFfnArgs& a, hipStream_t st);
 int launch_rb_attn(const RbAttnArgs& a, hipStream_t st);           // -1: shape not covered
-// both attention sublayers of a decoder layer of the filling pass as one launch (self-attention -> W_o -> residual -> folded query projection ->
-// cross-attention -> W_o' -> residual; rowblock.hip): `self` as for launch_rb_attn with x == y (in place), Lq == Lk <= 20, one key count per image
-struct RbDecAttnArgs {
-    RbAttnArgs self;
-    const uint16_t* ck; const uint16_t* cv; int ldc, Lkc; const int* clen;       // cross-attention K / V [B*Lkc][ldc] (Lkc <= 48), regions per image or null
-    const rb_u32x4* wqp; const float* cq; const float* csq;                      // LayerNorm-folded query projection (fragment-major, folded bias, column sums)
-    const rb_u32x4* wo2p; const float* bo2;                                      // the cross-attention's output projection
-};
-int launch_rb_dec_attn(const RbDecAttnArgs& a, hipStream_t st);    // -1: shape not covered
 int launch_rb_pack_frag(const void* w, void* out, int N, int K, hipStream_t st);
 
 // ---- device-side weight repack (repack.hip)

@@ -77,7 +77,6 @@ struct BoundLoopArgs {
     int max_iters;                                        // iterations at most (seq_length; 1 for the stage API)
     int update;                                           // apply the slot bookkeeping and loop until the group's images are finished
     int dbg;                                              // developer aid (BOFI_BL_DBG = i + 1: in-kernel stamps of iteration i), set by the launcher
-    int xcds;                                             // 1..8 (BOFI_BL_XCDS, set by the launcher): the groups' workgroups on that many of the eight XCDs (8: every workgroup takes a group)
     int* sat;                                             // fp16 saturation word (round 6; NULL: a scratch word of the library): bit 0 is OR-ed in when an activation (attention context, hidden
                                                           // row) was clamped to +-65 504 on its way into an fp16 MFMA operand, bit 1 when the fp16 weight copies were clamped at pack time (*wsat != 0)
     const int* wsat;                                      // the pack-time word of launch_pack_frag16 (may be NULL)

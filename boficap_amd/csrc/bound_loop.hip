@@ -119,15 +119,9 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;      // (wave in a scalar register: stream pointers stay scalar)
     const int B = a.B, L = a.L, S = a.S, R = a.R, hh = a.hh, dff = a.dff;
-    // a.xcds < 8 (BOFI_BL_XCDS): the grid is 8 / xcds times larger and only workgroups blockIdx % 8 < xcds take a group -- workgroups go to the XCDs round-robin, so the
-    // groups then sit on `xcds` of the eight L2s (their 5.75 MB of weights per iteration are fetched into that many L2s instead of eight); correct whatever the dispatch order
-    int grp = blockIdx.x;
-    if (a.xcds < 8) {
-        const int r = (int)blockIdx.x & 7;
-        if (r >= a.xcds) return;
-        grp = ((int)blockIdx.x >> 3) * a.xcds + r;
-        if (grp * BL_G >= a.B) return;
-    }
+    // (one group per workgroup, spread over all eight XCDs by the dispatcher's round-robin: confining the groups to fewer L2s -- round 5's BOFI_BL_XCDS -- measured -4 / -11 / -17 %,
+    // profiles/r05_bound_loop_xcds_ab.txt, and left in round 6)
+    const int grp = blockIdx.x;
     const int b0 = grp * BL_G;
     const BoundState st = a.st;
     if (tid == 0 && a.wsat && *a.wsat) atomicOr(a.sat, 2);          // the fp16 weight copies themselves were clamped when they were packed
@@ -644,10 +638,8 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
         v.sat = scratch;
     }
     v.dbg = BOFI_ENV_INT("BOFI_BL_DBG", 0);
-    v.xcds = BOFI_ENV_INT("BOFI_BL_XCDS", 8);
-    if (v.xcds < 1 || v.xcds > 8) v.xcds = 8;
     const int groups = (a.B + BL_G - 1) / BL_G;
-    const int grid = v.xcds == 8 ? groups : (groups + v.xcds - 1) / v.xcds * 8;
+    const int grid = groups;
     if (a.R <= 36) hipLaunchKernelGGL(bound_loop_kernel<5>, dim3(grid), dim3(512), BL_SMEM, s, v);
     else if (a.R <= 64) hipLaunchKernelGGL(bound_loop_kernel<8>, dim3(grid), dim3(512), BL_SMEM, s, v);
     else hipLaunchKernelGGL(bound_loop_kernel<0>, dim3(grid), dim3(512), BL_SMEM, s, v);

@@ -479,29 +479,6 @@ struct bofi_engine {
         if (pj) { a.pj_wp = (const bofi::u32x4*)pj->wp; a.pj_c = pj->b; a.pj_cs = pj->cs; a.pj_y = (uint16_t*)pj_y; a.pj_ldy = pj_ldy; a.yb = nullptr; a.stats_out = nullptr; }
         return bofi::launch_rb_attn(a, s);
     }
-    // both attention sublayers of decoder layer `l` of the filling pass as ONE launch (rowblock.hip rb_dec_attn_kernel; `at`: the self-attention as attn_sublayer
-    // takes it).  -1: not its configuration or shape (the caller runs attn_sublayer + fold_linear_rb + attn_sublayer).  BOFI_RB_DEC_FUSE: 0 (default) = never,
-    // 1 = when launches overlap, 2 = always.  Off by default: alone the one launch takes 55 us against 60.5 for the three, but it streams three 0.5-MB weights per
-    // TWO images (1.5 MB per 40 rows; the three launches: 0.5 MB per 80 + 0.5 per 96 + 0.5 per 80 rows) and with launches in flight the weight bytes pulled
-    // through L2 are what counts: -3 % on the headline (profiles/r05_dec_attn_fused.txt)
-    template <class Layer>
-    int dec_attn_sublayers(const bofi::AttnArgs& at, const Layer& l, const int* att_len, size_t li, int R, bool want_copy, hipStream_t s) {
-        const int v = BOFI_ENV_INT("BOFI_RB_DEC_FUSE", 0);
-        const int M = at.B * at.Lq;
-        if (!v || (v != 2 && in_flight == 1) || BOFI_ENV_INT("BOFI_RB_ATTN", 1) == 0 || !rb_ok() || !l.o.wp || !l.o_src.wp || !fold_rb_ok(l.q_src, M) || l.q_src.Npad != 512 ||
-            at.skip_if_ge || at.kdiv > 1 || at.q_start || at.drop_thresh || at.klen_sq || at.Lq > 20 || R > 48 || M < rb_min_rows() || exp_skip("attn") || exp_skip("qkv"))
-            return -1;
-        const int d = cfg.d_model;
-        bofi::RbDecAttnArgs u{};
-        bofi::RbAttnArgs& a = u.self;
-        a.q = (const uint16_t*)at.q; a.ldq = at.ldq; a.k = (const uint16_t*)at.k; a.ldk = at.ldk; a.v = (const uint16_t*)at.v; a.ldv = at.ldv;
-        a.B = at.B; a.Lq = at.Lq; a.Lk = at.Lk; a.klen = at.klen; a.klen_sb = at.klen_sb; a.klen_sq = 0; a.klen_bias = at.klen_bias;
-        a.klen_shared_last = at.klen_shared_last; a.wop = (const bofi::u32x4*)l.o.wp; a.bo = l.o.b; a.x = x_fill; a.ldx = d; a.y = x_fill; a.ldy = d;
-        a.yb = want_copy ? (uint16_t*)xb_fill : nullptr; a.stats_out = want_copy ? st_fill : nullptr;
-        u.ck = (const uint16_t*)((const char*)kv + (size_t)(n_len + li) * 2 * d * tsz); u.cv = u.ck + d; u.ldc = kv_all.N; u.Lkc = R; u.clen = att_len;
-        u.wqp = (const bofi::u32x4*)l.q_src.wp; u.cq = l.q_src.b; u.csq = l.q_src.cs; u.wo2p = (const bofi::u32x4*)l.o_src.wp; u.bo2 = l.o_src.b;
-        return bofi::launch_rb_dec_attn(u, s);
-    }
     // a LayerNorm-folded projection (K = d_model) of the residual stream x32 as a row-block kernel: it reads the float32 stream itself
     // (no compute-dtype copy, no row statistics from the producer).  -1: not its configuration.
     bool fold_rb_ok(const Lin& l, int M) const {
@@ -784,10 +761,9 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2, M);
         const bool need_copy_out = !(fold_rb_ok(l.qkv, M) && gen_rb);      // (a consumer of this layer's output reads the bf16 copy + statistics: a tiled GEMM)
         bool cross_split = false;
-        // both attention sublayers as one launch (rb_dec_attn_kernel): the block stays in LDS between them, the cross-attention's queries never exist in memory
-        int rc = dec_attn_sublayers(a, l, att_len, li, R, !ffn_rb, s);
-        if (rc > 0) return rc;
-        if (rc < 0) {                                        // ... or as attention sublayer + folded query projection + attention sublayer
+        // (round 5's one-launch form of both attention sublayers, rb_dec_attn_kernel, lost 3 % in flight and left the library in round 6: dev/exp/rb_dec_attn_kernel.inc)
+        int rc;
+        {                                                    // attention sublayer (+ folded query projection) + attention sublayer
         const bool q_tail = attn_proj_ok(a, l.o, l.q_src);      // the cross-attention's query projection rides the self-attention launch
         rc = q_tail ? attn_sublayer(a, l.o, x_fill, nullptr, nullptr, false, s, &l.q_src, qs, d)
                     : attn_sublayer(a, l.o, x_fill, xb_fill, st_fill, !q_rb, s);   // (the query projection behind it is a folded GEMM)

@@ -1345,396 +1345,6 @@ int launch_rb_attn(const RbAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The two attention sublayers of a DECODER layer of the filling pass as one launch (round 5):
-//     y1 = x + W_o . selfattn(q, k, v) + b_o;   q' = W_q' . LN(y1) + c (LayerNorm folded);   x <- y1 + W_o' . crossattn(q', K, V) + b_o'
-// (DecoderLayer.forward TransformerModel.py:1398-1413 around MultiHeadedAttention.forward :1454-1467) for two images (<= 20 rows each) per
-// workgroup of eight wavefronts: the 40-row block never leaves the CU between the sublayers -- y1 goes to the stream once (float32, in the
-// accumulator layout, read back by the same lanes as the last projection's starting accumulators) and into the block as bf16 with its row
-// statistics; the cross-attention's queries never exist in memory: wavefront h computes columns h*64 .. +63 of q' = head h's queries, and a
-// lane's accumulator values ARE an MFMA operand of S^T = K Q^T once the head dimension is walked in the accumulator's order
-// (slot (s, g, j) <-> d = (2s + (j >> 2))*16 + g*4 + (j & 3); the K fragments are loaded in the same order: two 8-byte pieces per k-step).
-// The block's row tiles do not end where an image ends (rows 16..31 hold the end of image 0 and the start of image 1): the cross-attention
-// walks (tile, image) pairs in row order, masks the probabilities of the other image's columns to 0 and lets both pairs of a shared tile
-// accumulate into the same O^T tile.  Replaces rb_attn + rb_gemm<false, 6> + rb_attn: three launches, the q' tensor and one pass of the
-// stream through memory per decoder layer.  A row's result does not depend on what else is in the launch.
-struct RbDecArgs {
-    RbAttnArgs self;                          // q, k, v, key counts of the self-attention; wop / bo = its output projection; x = y = the stream (in place); yb / stats_out: optional copy of the RESULT
-    const uint16_t* ck; const uint16_t* cv; int ldc, Lkc; const int* clen;       // cross-attention keys / values [B*Lkc][ldc], regions per image (or null)
-    const u32x4* wqp; const float* cq; const float* csq;                         // folded query projection [512][512] fragment-major, bias, column sums
-    const u32x4* wo2p; const float* bo2;                                         // the cross-attention's output projection
-};
-
-template <int NKTC>     // key tiles of the cross-attention (2: <= 32 regions, 4: <= 48)
-__global__ __launch_bounds__(512, 4) void rb_dec_attn_kernel(RbDecArgs d) {
-    constexpr int W = 8, G = 2, MT = 3, NT = 4, OPF = 2;
-    constexpr int VRS = 32, VRC = NKTC == 4 ? 48 : 32, NKLC = NKTC == 4 ? 3 : NKTC;
-    constexpr int BODY = (W * VRC * RB_VROW * 2 > MT * 16384) ? W * VRC * RB_VROW * 2 : MT * 16384;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* blk = smem;                                              // [48 rows][512] bf16, swizzled (aliases the V tiles)
-    bf16_t* svs = reinterpret_cast<bf16_t*>(smem);
-    float* bo1 = reinterpret_cast<float*>(smem + BODY);                     // [512] each: b_o, b_o', c, cs
-    float* bo2 = bo1 + 512;
-    float* cqs = bo2 + 512;
-    float* css = cqs + 512;
-    float2* part = reinterpret_cast<float2*>(css + 512);                    // [8 wavefronts][48 rows] (sum, sum of squares) of 64 columns of y1
-    bf16_t* zrow = reinterpret_cast<bf16_t*>(part + 8 * 48);                // 256 B of zeros
-
-    const RbAttnArgs& a = d.self;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int img0 = blockIdx.x * G, nimg = min(G, a.B - img0), Lq = a.Lq;
-    RB_STAMP(a.dbg, wave, lane, 0);
-    bo1[tid] = a.bo[tid]; bo2[tid] = d.bo2[tid]; cqs[tid] = d.cq[tid]; css[tid] = d.csq[tid];
-    if (tid < 64) reinterpret_cast<uint32_t*>(zrow)[tid] = 0u;
-    __syncthreads();
-
-    // ---- self-attention: wavefront = head, two images one after the other
-    const int h = wave;
-    const int c0 = wave * 64;
-    {
-        bf16_t* sv = svs + wave * (VRS * RB_VROW);
-        f32x4 ot[G][4][2];
-#pragma unroll
-        for (int r = 0; r < G; ++r) {
-            if (r < nimg) rb_attn_head<2, 2>(a, img0 + r, h, lane, sv, zrow, ot[r]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                                    // every V tile is dead: the block may overwrite them
-#pragma unroll
-        for (int r = 0; r < G; ++r) {
-            if (r >= nimg) continue;
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                const int qrow = qi * 16 + l15;
-                if (qrow >= Lq) continue;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    *reinterpret_cast<uint2*>(blk + rb_off(r * Lq + qrow, h * 8 + dt * 2 + (g >> 1)) + (g & 1) * 8) =
-                        make_uint2(pack_bf16(ot[r][dt][qi][0], ot[r][dt][qi][1]), pack_bf16(ot[r][dt][qi][2], ot[r][dt][qi][3]));
-            }
-        }
-    }
-    RB_STAMP(a.dbg, wave, lane, 1);
-    const u32x4* wo1 = a.wop + (size_t)wave * (16 * 256) + lane;
-    const u32x4* wq = d.wqp + (size_t)wave * (16 * 256) + lane;
-    const u32x4* wo2 = d.wo2p + (size_t)wave * (16 * 256) + lane;
-    bf16x8 wb[OPF * NT];
-    rb_prime<NT, OPF>(wo1, wb);
-    __syncthreads();
-
-    // ---- y1 = x + W_o . block + b_o (accumulators start from the residual rows)
-    const int rows_live = nimg * Lq, m0 = img0 * Lq;
-    const int lbase = rb_lane_base(l15, g);
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float* xr = a.x + (size_t)(m0 + min(mt * 16 + l15, rows_live - 1)) * a.ldx + c0 + g * 4;      // (dead rows: the block's last live row -- never stored)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 v = *reinterpret_cast<const float4*>(xr + nt * 16);
-            acc[nt][mt] = f32x4{v.x, v.y, v.z, v.w};
-        }
-    }
-    rb_segment<MT, NT, OPF>(wo1, wo1, wb, smem, lbase, acc);                // (the ring's last requests re-read this stream's start: dropped)
-    RB_STAMP(a.dbg, wave, lane, 2);
-    float mu[MT], rs[MT];
-    {
-        float sm[MT], sq[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            sm[mt] = 0.f; sq[mt] = 0.f;
-            const int r = mt * 16 + l15;
-            float* yr = a.y + (size_t)(m0 + min(r, rows_live - 1)) * a.ldy + c0 + g * 4;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float4 bb = *reinterpret_cast<const float4*>(bo1 + c0 + nt * 16 + g * 4);
-                f32x4 t = acc[nt][mt];
-                t[0] += bb.x; t[1] += bb.y; t[2] += bb.z; t[3] += bb.w;
-                acc[nt][mt] = t;
-                if (r < rows_live) *reinterpret_cast<float4*>(yr + nt * 16) = make_float4(t[0], t[1], t[2], t[3]);
-                sm[mt] += (t[0] + t[1]) + (t[2] + t[3]);
-                sq[mt] += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
-            }
-            sm[mt] = xor32_sum(xor16_sum(sm[mt])); sq[mt] = xor32_sum(xor16_sum(sq[mt]));
-        }
-        __syncthreads();                                                    // every wavefront has left the segment: the block takes y1
-        rb_prime<NT, OPF>(wq, wb);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int r = mt * 16 + l15;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                *reinterpret_cast<uint2*>(blk + rb_off(r, wave * 8 + nt * 2 + (g >> 1)) + (g & 1) * 8) =
-                    make_uint2(pack_bf16(acc[nt][mt][0], acc[nt][mt][1]), pack_bf16(acc[nt][mt][2], acc[nt][mt][3]));
-            if (g == 0) part[wave * 48 + r] = make_float2(sm[mt], sq[mt]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { const float2 p = part[w * 48 + mt * 16 + l15]; s1 += p.x; s2 += p.y; }
-            const float mean = s1 * (1.0f / 512.0f);
-            const float var = fmaxf((s2 - s1 * mean) * (1.0f / 511.0f), 0.f);
-            mu[mt] = mean; rs[mt] = 1.0f / (sqrtf(var) + 1e-6f);
-            asm volatile("" : "+v"(mu[mt]), "+v"(rs[mt]));                  // (computed HERE: left to the scheduler, the 48 partial sums waited behind the next segment, spilled)
-        }
-    }
-    // ---- q' = fold(W_q' . y1): this wavefront's 64 columns = head h's queries, left in registers as the B operand of S^T = K Q^T
-    bf16x8 bq[MT][2];
-    {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb_segment<MT, NT, OPF>(wq, wq, wb, smem, lbase, acc);              // (the ring's last requests run into this stream's start: dropped)
-        int cofs = c0 + g * 4;
-        asm volatile("" : "+v"(cofs));                                      // (read ahead of the segment, the 32 constants were spilled across it)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 cc = *reinterpret_cast<const float4*>(cqs + cofs + nt * 16);
-            const float4 cs = *reinterpret_cast<const float4*>(css + cofs + nt * 16);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 t = acc[nt][mt];
-                const float v0 = rs[mt] * (t[0] - mu[mt] * cs.x) + cc.x, v1 = rs[mt] * (t[1] - mu[mt] * cs.y) + cc.y;
-                const float v2 = rs[mt] * (t[2] - mu[mt] * cs.z) + cc.z, v3 = rs[mt] * (t[3] - mu[mt] * cs.w) + cc.w;
-                const int j0 = (nt & 1) * 4;
-                bq[mt][nt >> 1][j0 + 0] = (short)f32_to_bf16(v0); bq[mt][nt >> 1][j0 + 1] = (short)f32_to_bf16(v1);
-                bq[mt][nt >> 1][j0 + 2] = (short)f32_to_bf16(v2); bq[mt][nt >> 1][j0 + 3] = (short)f32_to_bf16(v3);
-            }
-        }
-    }
-    RB_STAMP(a.dbg, wave, lane, 3);
-    __syncthreads();                                                        // the block is dead: the V tiles of the cross-attention overwrite it
-
-    // ---- cross-attention over the (tile, image) pairs in row order; a finished tile waits as bf16 for the block.  The tile loop is a REAL loop
-    // (the queries and the finished tiles rotate through their registers): unrolled, its six pair bodies' addresses were hoisted and spilled
-    uint2 ob[MT][4];
-    {
-        bf16_t* sv = svs + wave * (VRC * RB_VROW);
-        const int Lk = d.Lkc;
-        typedef __attribute__((ext_vector_type(4))) short s16x4;
-        bf16x8 ak[NKLC][2];
-#pragma unroll
-        for (int kj = 0; kj < NKLC; ++kj) { ak[kj][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; ak[kj][1] = ak[kj][0]; }
-        int klu = 0, cur = -1;
-        constexpr float SC = 0.125f * 1.44269504088896340736f;
-#pragma unroll 1
-        for (int t = 0; t < MT; ++t) {
-            f32x4 otc[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) otc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int i = 0; i < G; ++i) {
-                const int lo = max(16 * t, i * Lq), hi = min(16 * t + 16, (i + 1) * Lq);      // (wave-uniform)
-                if (lo >= hi || i >= nimg) continue;
-                int lnv = lane;
-                asm volatile("" : "+v"(lnv));
-                const int l15v = lnv & 15, gv = lnv >> 4;
-                if (cur != i) {                                             // this image's K fragments and V tile
-                    cur = i;
-                    const int img = img0 + i;
-                    const bf16_t* kg = d.ck + (size_t)img * Lk * d.ldc + h * 64 + gv * 4;
-                    const bf16_t* vg = d.cv + (size_t)img * Lk * d.ldc + h * 64;
-#pragma unroll
-                    for (int kj = 0; kj < NKLC; ++kj) {
-                        const int r = kj * 16 + l15v;
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            s16x4 p0 = s16x4{0, 0, 0, 0}, p1 = s16x4{0, 0, 0, 0};
-                            if (r < Lk) {
-                                p0 = *reinterpret_cast<const s16x4*>(kg + (size_t)r * d.ldc + (2 * s) * 16);
-                                p1 = *reinterpret_cast<const s16x4*>(kg + (size_t)r * d.ldc + (2 * s + 1) * 16);
-                            }
-                            ak[kj][s] = bf16x8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();                        // (the previous image's V^T reads were issued before these writes)
-#pragma unroll
-                    for (int it = 0; it < VRC * 8 / 64; ++it) {
-                        const int c = lnv + it * 64, r = c >> 3, ch = c & 7;
-                        *reinterpret_cast<u32x4*>(&sv[r * RB_VROW + ch * 8]) = r < Lk ? *reinterpret_cast<const u32x4*>(vg + (size_t)r * d.ldc + ch * 8) : u32x4{0u, 0u, 0u, 0u};
-                    }
-                    klu = Lk;
-                    if (d.clen) klu = __builtin_amdgcn_readfirstlane(max(0, min(d.clen[img], Lk)));
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                const int row = 16 * t + l15v;
-                const bool colv = row >= lo && row < hi;
-                f32x4 st[NKLC];
-#pragma unroll
-                for (int kj = 0; kj < NKLC; ++kj) {
-                    f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kj][0], bq[0][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kj][1], bq[0][1], c, 0, 0, 0);
-                    st[kj] = c;
-                }
-                float m = -INFINITY;
-#pragma unroll
-                for (int kj = 0; kj < NKLC; ++kj) {
-                    if (kj * 16 >= klu) continue;
-                    const bool whole = kj * 16 + 16 <= klu;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m = fmaxf(m, (whole || kj * 16 + gv * 4 + r < klu) ? st[kj][r] : -INFINITY);
-                }
-                m = xor32_max(xor16_max(m));
-                const float mb = m * SC;
-                float sum = 0.f;
-#pragma unroll
-                for (int kj = 0; kj < NKLC; ++kj) {
-                    if (kj * 16 >= klu) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) st[kj][r] = 0.f;
-                        continue;
-                    }
-                    const bool whole = kj * 16 + 16 <= klu;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kj][r], SC, -mb));
-                        if (!whole) e = (kj * 16 + gv * 4 + r < klu) ? e : 0.f;
-                        st[kj][r] = e;
-                        sum += e;
-                    }
-                }
-                sum = xor32_sum(xor16_sum(sum));
-                const float inv_sum = 1.0f / sum;                           // an image without regions: NaN for every key, as softmax over all -inf
-                bf16x8 bp[NKTC / 2];
-#pragma unroll
-                for (int s = 0; s < NKTC / 2; ++s) {
-                    bf16x8 f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int kj = 2 * s + (j >> 2), r = j & 3;
-                        float pv = 0.f;
-                        if (kj < NKLC) {
-                            pv = st[kj][r] * inv_sum;
-                            if ((kj + 1) * 16 > Lk && klu == 0 && kj * 16 + gv * 4 + r >= Lk) pv = 0.f;
-                        }
-                        f[j] = (short)f32_to_bf16(colv ? pv : 0.f);          // (the other image's rows of a shared tile take nothing from this one)
-                    }
-                    bp[s] = f;
-                }
-                const int tq = l15v >> 2, tp = l15v & 3;
-#pragma unroll
-                for (int s = 0; s < NKTC / 2; ++s)
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const bf16_t* a0p = &sv[(32 * s + 4 * gv + tq) * RB_VROW + dt * 16 + 4 * tp];
-                        const bf16_t* a1p = (NKTC == 4 && s == 1) ? zrow + dt * 16 + 4 * tp : a0p + 16 * RB_VROW;
-                        const rb_s16x4 vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rb_s16x4*)a0p);
-                        const rb_s16x4 vhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rb_s16x4*)a1p);
-                        bf16x8 av;
-                        av[0] = vlo[0]; av[1] = vlo[1]; av[2] = vlo[2]; av[3] = vlo[3];
-                        av[4] = vhi[0]; av[5] = vhi[1]; av[6] = vhi[2]; av[7] = vhi[3];
-                        otc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bp[s], otc[dt], 0, 0, 0);
-                    }
-            }
-            // rotate: the next tile's queries to the front, this tile's result to the back (after MT rounds ob[t] is tile t)
-#pragma unroll
-            for (int u = 0; u + 1 < MT; ++u) {
-                bq[u][0] = bq[u + 1][0]; bq[u][1] = bq[u + 1][1];
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) ob[u][dt] = ob[u + 1][dt];
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) ob[MT - 1][dt] = make_uint2(pack_bf16(otc[dt][0], otc[dt][1]), pack_bf16(otc[dt][2], otc[dt][3]));
-        }
-    }
-    RB_STAMP(a.dbg, wave, lane, 4);
-    __syncthreads();                                                        // every V tile is dead
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<uint2*>(blk + rb_off(t * 16 + l15, h * 8 + dt * 2 + (g >> 1)) + (g & 1) * 8) = ob[t][dt];
-    rb_prime<NT, OPF>(wo2, wb);
-    // ---- x = y1 + W_o' . block + b_o' (y1: this lane's own stores of above)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float* xr = a.y + (size_t)(m0 + min(mt * 16 + l15, rows_live - 1)) * a.ldy + c0 + g * 4;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 v = *reinterpret_cast<const float4*>(xr + nt * 16);
-            acc[nt][mt] = f32x4{v.x, v.y, v.z, v.w};
-        }
-    }
-    __syncthreads();
-    rb_segment<MT, NT, OPF>(wo2, wo2, wb, smem, lbase, acc);
-    RB_STAMP(a.dbg, wave, lane, 5);
-    __syncthreads();                                                        // the block is dead: each wavefront's staging rows lie in it
-    {
-        unsigned char* stg = smem + wave * (16 * 144);
-        const int er = lane >> 3, ec = lane & 7;
-        const size_t ystep = (size_t)8 * a.ldy;
-#pragma unroll
-        for (int half = 0; half < NT / 2; ++half) {            // 32 columns (two tiles) at a time
-            const int cb = c0 + half * 32 + ec * 4;
-            const float4 bb = *reinterpret_cast<const float4*>(bo2 + cb);
-            float* yp = a.y + (size_t)(m0 + er) * a.ldy + cb;
-            int rr = er;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 t = acc[half * 2 + nt][mt];
-                    *reinterpret_cast<float4*>(stg + l15 * 144 + nt * 64 + g * 16) = make_float4(t[0], t[1], t[2], t[3]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float4 sv2[2];
-#pragma unroll
-                for (int it = 0; it < 2; ++it) sv2[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + er) * 144 + ec * 16);
-#pragma unroll
-                for (int it = 0; it < 2; ++it, yp += ystep, rr += 8) {
-                    const float4 o = make_float4(sv2[it].x + bb.x, sv2[it].y + bb.y, sv2[it].z + bb.z, sv2[it].w + bb.w);
-                    const bool live = rr < rows_live;
-                    const size_t m = live ? (size_t)(m0 + rr) : 0;
-                    if (live) {
-                        *reinterpret_cast<float4*>(yp) = o;
-                        if (a.yb) *reinterpret_cast<uint2*>(a.yb + m * 512 + cb) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
-                    }
-                    if (a.stats_out) {
-                        const float s1 = oct_sum((o.x + o.y) + (o.z + o.w)), s2 = oct_sum((o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
-                        if (live && !ec) reinterpret_cast<float2*>(a.stats_out + m * 32)[cb >> 5] = make_float2(s1, s2);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    RB_STAMP(a.dbg, wave, lane, 6);
-}
-
-template <int NKTC>
-static int launch_rb_dec_attn_t(const RbDecArgs& d, hipStream_t st) {
-    constexpr int VRC = NKTC == 4 ? 48 : 32;
-    constexpr size_t body = (8 * VRC * RB_VROW * 2 > 3 * 16384) ? 8 * VRC * RB_VROW * 2 : 3 * 16384;
-    constexpr size_t lds = body + 4 * 2048 + 8 * 48 * 8 + 256;
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_dec_attn_kernel<NKTC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return BOFI_ERR_HIP;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((rb_dec_attn_kernel<NKTC>), dim3((d.self.B + 1) / 2), dim3(512), lds, st, d);
-    return hipGetLastError() == hipSuccess ? BOFI_OK : BOFI_ERR_HIP;
-}
-
-// -1: shape not covered (the caller keeps the three launches)
-int launch_rb_dec_attn(const RbDecAttnArgs& u, hipStream_t st) {
-    const RbAttnArgs& a = u.self;
-    if (!a.q || !a.k || !a.v || !a.wop || !a.bo || !a.x || a.y != a.x || a.ldy != a.ldx || !u.ck || !u.cv || !u.wqp || !u.cq || !u.csq || !u.wo2p || !u.bo2 || a.B < 1 ||
-        a.Lq < 1 || a.Lk != a.Lq || u.Lkc < 1 || a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || u.ldc % 8 || a.ldx % 4)
-        return BOFI_ERR_ARG;
-    if (a.Lq > 20 || u.Lkc > 48 || a.klen_sq) return -1;
-    RbDecArgs d{};
-    d.self = a; d.ck = u.ck; d.cv = u.cv; d.ldc = u.ldc; d.Lkc = u.Lkc; d.clen = u.clen; d.wqp = u.wqp; d.cq = u.cq; d.csq = u.csq; d.wo2p = u.wo2p; d.bo2 = u.bo2;
-    const int rc = u.Lkc <= 32 ? launch_rb_dec_attn_t<2>(d, st) : launch_rb_dec_attn_t<4>(d, st);
-    if (rc == BOFI_OK) g_gemm_flops += 3 * 2.0 * a.B * a.Lq * 512.0 * 512.0;
-    return rc;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
 // y[M][N] = epilogue(LN(x) . W^T) for K = 512 and any N % 64 == 0: the LayerNorm-folded projections of the path (q|k|v, the
 // cross-attention queries, the stacked cross K|V of all layers, the generator) as a row-block kernel: the block of the residual
 // stream is staged once (float32 -> bf16, row statistics on the way: no bf16 copy and no statistics from the producer), the eight
@@ -1812,8 +1422,8 @@ static int launch_rb_gemm_t(const RbGemmArgs& a, hipStream_t st) {
 
 int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
     if (a.M < 1 || a.N < 64 || a.N % 64 || !a.x || !a.wp || !a.c || !a.cs || !a.y || a.ldx % 4 || a.ldy % 8) return BOFI_ERR_ARG;
-    // developer knob (read again after bofi_reload_env): BOFI_RB_GEMM_MT = 4: 64-row blocks everywhere; 6 (default) / 8: 96- / 128-row blocks for bf16
-    // outputs from BOFI_RB_GEMM_MT8_ROWS rows on (below that the 64-row blocks' larger number of workgroups wins)
+    // developer knob (read again after bofi_reload_env): BOFI_RB_GEMM_MT = 4: 64-row blocks everywhere; 6 (default): 96-row blocks for bf16
+    // outputs from BOFI_RB_GEMM_MT8_ROWS rows on (below that the 64-row blocks' larger number of workgroups wins; round 4's 128-row form, <false, 8>, spilled 46 registers, never won and left in round 6)
     static int env_seen = -1, mt = 6, mt8_rows = 4096, mt_min_n = 0, gen6 = -1;
     if (env_seen != g_env_generation) {
         const char* e = getenv("BOFI_RB_GEMM_MT"); mt = e ? atoi(e) : 6;
@@ -1824,7 +1434,6 @@ int launch_rb_gemm(const RbGemmArgs& a, hipStream_t st) {
     }
     int rc;
     if (a.y_f32) rc = (mt == 6 && (gen6 > 0 || (gen6 < 0 && !a.alone)) && a.M >= mt8_rows) ? launch_rb_gemm_t<true, 6>(a, st) : launch_rb_gemm_t<true, 4>(a, st);
-    else if (mt == 8 && a.M >= mt8_rows && a.N >= mt_min_n) rc = launch_rb_gemm_t<false, 8>(a, st);
     else if (mt == 6 && a.M >= mt8_rows && a.N >= mt_min_n && !(a.alone && a.N < 2048)) rc = launch_rb_gemm_t<false, 6>(a, st);      // (alone: 96-row blocks only where they win alone)
     else rc = launch_rb_gemm_t<false, 4>(a, st);
     if (rc == BOFI_OK) g_gemm_flops += 2.0 * a.M * 512.0 * a.N;
@@ -1885,21 +1494,6 @@ extern "C" int bofi_attn_linear_block(const void* q, int ldq, const void* k, int
     a.pj_wp = (const bofi::u32x4*)pj_wp; a.pj_c = pj_c; a.pj_cs = pj_cs; a.pj_y = (bofi::bf16_t*)pj_y; a.pj_ldy = pj_ldy;
     { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int rc = bofi::launch_rb_attn(a, (hipStream_t)stream);
-    return rc < 0 ? BOFI_ERR_ARG : rc;
-}
-
-extern "C" int bofi_decoder_attn_block(const void* qkv, int ldqkv, int B, int S, const int* klen, int klen_bias, int klen_shared_last, const void* wo1p, const float* bo1,
-                                       const void* ck, const void* cv, int ldc, int R, const int* att_len, const void* wqp, const float* cq, const float* csq,
-                                       const void* wo2p, const float* bo2, float* x, int ldx, void* yb, float* stats_out, void* stream) {
-    bofi::RbDecAttnArgs u{};
-    bofi::RbAttnArgs& a = u.self;
-    a.q = (const bofi::bf16_t*)qkv; a.k = a.q + 512; a.v = a.q + 1024; a.ldq = a.ldk = a.ldv = ldqkv; a.B = B; a.Lq = a.Lk = S;
-    a.klen = klen; a.klen_sb = 1; a.klen_sq = 0; a.klen_bias = klen_bias; a.klen_shared_last = klen_shared_last;
-    a.wop = (const bofi::u32x4*)wo1p; a.bo = bo1; a.x = x; a.ldx = ldx; a.y = x; a.ldy = ldx; a.yb = (bofi::bf16_t*)yb; a.stats_out = stats_out;
-    { const char* e = getenv("BOFI_RB_DBG"); a.dbg = e ? atoi(e) : 0; }
-    u.ck = (const bofi::bf16_t*)ck; u.cv = (const bofi::bf16_t*)cv; u.ldc = ldc; u.Lkc = R; u.clen = att_len;
-    u.wqp = (const bofi::u32x4*)wqp; u.cq = cq; u.csq = csq; u.wo2p = (const bofi::u32x4*)wo2p; u.bo2 = bo2;
-    const int rc = bofi::launch_rb_dec_attn(u, (hipStream_t)stream);
     return rc < 0 ? BOFI_ERR_ARG : rc;
 }
 

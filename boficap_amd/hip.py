@@ -102,7 +102,6 @@ SIGNATURES = {
     "bofi_linear_block": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "bofi_engine_set_row_stats_out": (_I, [_P, _P, _P]),
     "bofi_attn_linear_block": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
-    "bofi_decoder_attn_block": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "bofi_ffn_block": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "bofi_ffn_linear_block": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "bofi_engine_fill_naic": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),

@@ -36,7 +36,8 @@ class Trace(TorchDispatchMode):
         if not any(v in name for v in VIEW):
             own = [f for f in traceback.extract_stack() if "boficap_amd" in f.filename and "xe_dispatch" not in f.filename]
             site = f"{os.path.basename(own[-1].filename)}:{own[-1].lineno} {own[-1].name}" if own else "(outside boficap_amd)"
-            sites[(name.replace("aten.", ""), site)] += 1
+            shp = ",".join("x".join(map(str, a.shape)) for a in args if torch.is_tensor(a)) if os.environ.get("XE_TRACE_SHAPES") else ""
+            sites[(name.replace("aten.", "") + (" [" + shp + "]" if shp else ""), site)] += 1
         return func(*args, **(kwargs or {}))
 
 with torch.autograd.set_multithreading_enabled(False):
@@ -45,4 +46,4 @@ with torch.autograd.set_multithreading_enabled(False):
 torch.cuda.synchronize()
 print(f"{sum(sites.values())} aten ops that are not views, by (op, innermost boficap_amd line):")
 for (op, site), n in sorted(sites.items(), key=lambda kv: (-kv[1], kv[0])):
-    print(f"{n:4d}  {op:34s} {site}")
+    print(f"{n:4d}  {op:60s} {site}")

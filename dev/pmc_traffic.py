@@ -14,8 +14,9 @@ def total(path, counter):
     return sum(per.values()), sorted(per.items(), key=lambda kv: -kv[1])[:6]
 
 
-if sys.argv[3] == "auto":                                    # engine launches in the trace = dispatches of bound_init_kernel
-    n = float(sqlite3.connect(sys.argv[1]).execute("select count(distinct dispatch_id) from counters_collection where kernel_name like '%bound_init_kernel%'").fetchone()[0])
+if sys.argv[3] == "auto" or sys.argv[3].startswith("auto:"):    # engine launches in the trace = dispatches of bound_init_kernel ("auto:NAME": of the kernel whose name contains NAME)
+    key = "bound_init_kernel" if sys.argv[3] == "auto" else sys.argv[3][5:]
+    n = float(sqlite3.connect(sys.argv[1]).execute("select count(distinct dispatch_id) from counters_collection where kernel_name like ?", ("%" + key + "%",)).fetchone()[0])
 else:
     n = float(sys.argv[3])
 f, ftop = total(sys.argv[1], "FETCH_SIZE")

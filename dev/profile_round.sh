@@ -6,7 +6,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
-TAG=${1:-r05}
+TAG=${1:-r06}
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-gemm-roofline --no-from-host"
@@ -24,6 +24,9 @@ run fetch16 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch16 -o fetch -- $B --coa
 run write16 --pmc WRITE_SIZE --kernel-trace -d $OUT/write16 -o write -- $B --coalesce 16 --inflight 1 --hint 4 --steps 64 --warmup 16
 run fetch1 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch1 -o fetch -- $B --coalesce 1 --inflight 1 --steps 20 --warmup 4
 run write1 --pmc WRITE_SIZE --kernel-trace -d $OUT/write1 -o write -- $B --coalesce 1 --inflight 1 --steps 20 --warmup 4
+# (config 5: batch 256 + 3 refinement rounds, one launch at a time -- VERDICT r5 item 6)
+run fetch5 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch5 -o fetch -- $B --batch 256 --refine 3 --coalesce 1 --inflight 1 --hint 4 --steps 12 --warmup 4
+run write5 --pmc WRITE_SIZE --kernel-trace -d $OUT/write5 -o write -- $B --batch 256 --refine 3 --coalesce 1 --inflight 1 --hint 4 --steps 12 --warmup 4
 run mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $OUT/mfma -o mfma -- $B --coalesce 5 --inflight 1 --hint 4 --steps 40 --warmup 10
 # 4. XE step
 run xe --kernel-trace --stats -d $OUT/xe -o xe -- python3 $R/bench.py --mode xe --steps 10 --warmup 3 --no-cpu-baseline
@@ -39,8 +42,9 @@ python dev/prof_timeline.py $(ls $OUT/tla/*kernel_trace.csv | head -1) > $OUT/${
 python dev/pmc_traffic.py $(db fetch) $(db write) auto > $OUT/${TAG}_hbm_traffic_coalesce5.json 2>&1
 python dev/pmc_traffic.py $(db fetch16) $(db write16) auto > $OUT/${TAG}_hbm_traffic_coalesce16.json 2>&1
 python dev/pmc_traffic.py $(db fetch1) $(db write1) auto > $OUT/${TAG}_hbm_traffic.json 2>&1
+python dev/pmc_traffic.py $(db fetch5) $(db write5) auto > $OUT/${TAG}_hbm_traffic_config5.json 2>&1
 python dev/pmc_summary.py $(db mfma) 14 > $OUT/${TAG}_mfma_util_pmc.json 2>&1
-python dev/prof_db.py $(db xe) 14 30 > $OUT/${TAG}_xe_step_kernel_stats.txt 2>&1
-python dev/pmc_traffic.py $(db xef) $(db xew) 10 > $OUT/${TAG}_xe_hbm_traffic.json 2>&1      # 6 + 2 steps + the eager tally pass + the capture warm-up
-rm -rf $OUT/ks4 $OUT/ks1 $OUT/tl $OUT/tla $OUT/fetch $OUT/write $OUT/fetch16 $OUT/write16 $OUT/fetch1 $OUT/write1 $OUT/mfma $OUT/xe $OUT/xef $OUT/xew
+python dev/prof_db.py $(db xe) auto:adam_step_kernel 30 > $OUT/${TAG}_xe_step_kernel_stats.txt 2>&1
+python dev/pmc_traffic.py $(db xef) $(db xew) auto:adam_step_kernel > $OUT/${TAG}_xe_hbm_traffic.json 2>&1      # 6 + 2 steps + the eager tally pass + the capture warm-up
+rm -rf $OUT/ks4 $OUT/ks1 $OUT/tl $OUT/tla $OUT/fetch $OUT/write $OUT/fetch16 $OUT/write16 $OUT/fetch1 $OUT/write1 $OUT/fetch5 $OUT/write5 $OUT/mfma $OUT/xe $OUT/xef $OUT/xew
 ls -la $OUT

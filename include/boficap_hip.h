@@ -488,17 +488,8 @@ int bofi_attn_block(const void* q, int ldq, const void* k, int ldk, const void* 
 int bofi_attn_linear_block(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int B, int Lq, int Lk, const int* klen, int klen_sb,
                            int klen_bias, int klen_shared_last, const void* wop, const float* bo, float* x, int ldx, const void* pj_wp, const float* pj_c,
                            const float* pj_cs, void* pj_y, int pj_ldy, void* stream);
-/* bofi_decoder_attn_block: BOTH attention sublayers of a decoder layer of the filling pass, ONE launch (DecoderLayer.forward TransformerModel.py:1398-1413:
- *   x <- x + self_attn(LN x); x <- x + src_attn(LN x, memory) -- sublayers 0 and 1 around MultiHeadedAttention.forward :1454-1467):
- *   y1 = x + W_o1 selfattn(q, k, v) + b_o1 with q | k | v = qkv[:, 0:512 | 512:1024 | 1024:1536] (bf16 [B*S, ldqkv], the LayerNorm-folded projection of x that the
- *   previous launch made), S <= 20 rows per image, key count klen[bi] + klen_bias per image (bi as bofi_attn_block's klen_shared_last; NULL: all S);
- *   q' = W_q' LN(y1) + c (wqp / cq / csq as bofi_linear_block's wp / c / cs, N = 512) -- never written to memory;
- *   x <- y1 + W_o2 crossattn(q', ck, cv) + b_o2 with ck / cv bf16 [B*R, ldc] (R <= 48), att_len[b] regions per image (NULL: all R).
- *   x float32 [B*S, ldx], in place; yb / stats_out as bofi_ffn_block (of the result).  What bofi_attn_block + bofi_linear_block + bofi_attn_block compute,
- *   up to the summation order of the row statistics behind q'. */
-int bofi_decoder_attn_block(const void* qkv, int ldqkv, int B, int S, const int* klen, int klen_bias, int klen_shared_last, const void* wo1p,
-                            const float* bo1, const void* ck, const void* cv, int ldc, int R, const int* att_len, const void* wqp, const float* cq,
-                            const float* csq, const void* wo2p, const float* bo2, float* x, int ldx, void* yb, float* stats_out, void* stream);
+/* (bofi_decoder_attn_block -- both attention sublayers of a decoder layer as one launch, round 5 -- lost 3 % with launches in flight and left the ABI in round 6:
+ *   dev/exp/rb_dec_attn_kernel.inc, profiles/r05_dec_attn_fused.txt, last shipped at commit 45884c1.) */
 int bofi_ffn_block(const float* x, int ldx, const void* w1p, const float* c1, const float* cs1, const void* w2p, const float* b2,
                    float* y, int ldy, void* yb, float* stats_out, int M, int dff, void* stream);
 /* bofi_ffn_linear_block: bofi_ffn_block followed by bofi_linear_block on its output, ONE launch -- the feed-forward sublayer and the

@@ -228,3 +228,33 @@ def test_exchange_in_two_phases_around_the_encoder_boundary_equals_the_flat_all_
         assert p.exitcode == 0
     assert boundary_ok and tiled and equal and empty
     assert 1 <= n_late <= 3 and 1 <= n_early <= 2
+
+
+def _bench_dry(n, *flags, env=None):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, BOFI_BENCH_REHEARSAL="dry", OMP_NUM_THREADS="1", **(env or {}))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), *flags], capture_output=True, text=True, timeout=600, cwd=root, env=e)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out.returncode, [json.loads(l) for l in lines], out.stderr
+
+
+def test_bench_eight_ranks_walk_the_multi_gpu_path_without_a_gpu():
+    """`python bench.py --gpus 8` as the driver starts it -- self-launch through torch.distributed.run, eight processes, gloo -- with the GPU work of
+    every rank replaced by a sleep (BOFI_BENCH_REHEARSAL=dry): the ranks the collective backend saw, the per-rank shard sizes, value = ALL ranks' images over the SLOWEST
+    rank's time, exactly one line from rank 0; and a rank that raises before the exchange ends the job with a non-zero status and no line.  (The N = 2 walk WITH the GPU
+    work is tests/test_gpu_bench.py; a one-GPU box cannot hold eight ranks.)  Replaces nn.DataParallel's scatter / gather, tools/train.py:97-101."""
+    rc, lines, err = _bench_dry(8, "--steps", "20", "--warmup", "5")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    d = lines[0]
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["dist_backend"] == "gloo" and "dry" in c["rehearsal"] and d["data"] == "none"
+    assert c["shard_images_per_rank"] == [64 * 20] * 8                             # images by rank, equal shards, every image once
+    assert abs(d["value"] - 8 * 64 * 20 / (d["ms_per_step"] * 20e-3)) <= 0.01 * d["value"]       # whole-job aggregate over the measured (max over ranks) time
+    assert d["ms_per_step"] >= c["slowest_rank_ms_per_step"] * 0.99                 # ... which is the SLOWEST rank's (rank 7 sleeps 2.75 ms per step, rank 0 one)
+    rc, lines, err = _bench_dry(8, "--steps", "20", "--warmup", "5", env={"BOFI_BENCH_DRY_FAIL_RANK": "5"})
+    assert rc != 0 and not lines and "injected failure" in err
+    rc, lines, err = _bench_dry(1, "--steps", "4", "--warmup", "1")
+    assert rc == 0 and lines[0]["n_gpus"] == 1 and lines[0]["config"]["shard_images_per_rank"] == [256]

@@ -318,7 +318,7 @@ def test_ffn_linear_block_is_the_two_launches(H, M, dff, N, monkeypatch):
 
 @pytest.mark.parametrize("M,N,relu", [(700, 1536, 0), (96, 64, 1), (6400, 512, 0), (333, 7168, 0)])
 def test_linear_block_rows_per_block_agree(H, M, N, relu, monkeypatch):
-    """rb_gemm_kernel<MT>: 64-, 96- and 128-row blocks (BOFI_RB_GEMM_MT = 4 / 6 / 8) give every output element the same sums -- bit for bit
+    """rb_gemm_kernel<MT>: 64- and 96-row blocks (BOFI_RB_GEMM_MT = 4 / 6; the 128-row form left in round 6) give every output element the same sums -- bit for bit
     (ragged last blocks, a wavefront staging fewer than eight rows in its last pass)."""
     d = 512
     g = _rng(M * 3 + N)
@@ -330,7 +330,7 @@ def test_linear_block_rows_per_block_agree(H, M, N, relu, monkeypatch):
     outs = []
     monkeypatch.setenv("BOFI_RB_GEMM_MT8_ROWS", "1")
     try:
-        for mt in (4, 6, 8):
+        for mt in (4, 6):
             monkeypatch.setenv("BOFI_RB_GEMM_MT", str(mt))
             H.lib().bofi_reload_env()
             y = torch.full((M, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
@@ -349,86 +349,6 @@ def test_linear_block_rows_per_block_agree(H, M, N, relu, monkeypatch):
         ref = torch.relu(ref)
     assert (outs[0][:, N:] == 7.0).all()
     assert (outs[0][:, :N].double() - ref).abs().max() < 6e-2
-
-
-@pytest.mark.parametrize("B,S,R,masks", [(9, 20, 36, "q1+len"), (64, 20, 36, "none"), (5, 17, 30, "q1+len"), (3, 12, 48, "len"), (1, 20, 20, "none"), (6, 5, 33, "q1+len"),
-                                         (7, 16, 36, "len")])
-def test_decoder_attn_block_is_the_three_launches(H, B, S, R, masks):
-    """bofi_decoder_attn_block (rb_dec_attn_kernel: self-attention -> W_o -> residual -> folded query projection -> cross-attention -> W_o' -> residual for two
-    images per workgroup, the queries of the cross-attention never in memory) against bofi_attn_block + bofi_linear_block + bofi_attn_block on the same inputs
-    (they differ in the summation order of the row statistics behind q': a bf16 rounding of a query here and there) and against the float64 sublayers.
-    Row tiles that hold the end of one image and the start of the next (S = 20, 17, 12, 5), whole tiles (16), an odd image count, empty key sets (NaN rows)."""
-    d = 512
-    g = _rng(B * 1000 + S * 50 + R)
-    qkv = torch.randn(B * S, 3 * d, generator=g).to(torch.bfloat16)
-    kvb = torch.randn(B * R, 4 * d, generator=g).to(torch.bfloat16)             # K at columns d .. 2d, V at 3d .. 4d of a wider tensor
-    wo1, bo1 = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g) * 0.1
-    wo2, bo2 = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g) * 0.1
-    gain, bln = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
-    wq, bq = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g) * 0.1
-    wqf, cq, csq = _fold(wq, bq, gain, bln)
-    x = torch.randn(B * S, d, generator=g)
-    klen_t = att_t = None
-    kl_bias = shared = 0
-    self_k, cross_k = torch.full((B, S), S), torch.full((B, S), R)
-    if "q1" in masks:
-        last = torch.randint(2, S + 2, (B,), generator=g)
-        if B > 4:
-            last[3] = 1                                                          # images 0..3 without keys: NaN rows (and NaN from there on)
-        grp_last = torch.tensor([min(B, (b // 4 + 1) * 4) - 1 for b in range(B)])
-        self_k, klen_t, kl_bias, shared = (last[grp_last] - 1)[:, None].expand(B, S), last.int(), -1, 4
-    if "len" in masks:
-        per = torch.randint(1, R + 1, (B,), generator=g)
-        cross_k, att_t = per[:, None].expand(B, S), per.int()
-    # float64 reference of the three stages (bf16 roundings where the kernels have them)
-    y1 = _attn_sublayer64(qkv[:, :d].float(), qkv[:, d:2 * d].float(), qkv[:, 2 * d:].float(), self_k, _bf(wo1), bo1, x, B, S, S)
-    qp = _layer_norm64(y1.float(), gain, bln) @ (_bf(wqf).double() / gain.double()[None, :]).T + bq.double()
-    ref = _attn_sublayer64(_bf(qp.float()), kvb[:, d:2 * d].float(), kvb[:, 3 * d:].float(), cross_k, _bf(wo2), bo2, y1.float(), B, S, R)
-
-    qd, kvd = qkv.cuda(), kvb.cuda()
-    wo1p, wo2p, wqp = (pack_frag(H, w.to(torch.bfloat16).cuda()) for w in (wo1, wo2, wqf))
-    bo1c, bo2c, cqc, csqc = bo1.cuda(), bo2.cuda(), cq.cuda(), csq.cuda()
-    klc = None if klen_t is None else klen_t.cuda()
-    atc = None if att_t is None else att_t.cuda()
-    L = H.lib()
-    # the three launches
-    xa = x.cuda()
-    qs = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
-    H.check(L.bofi_attn_block(H.ptr(qd), 3 * d, H.ptr(qd[:, d:]), 3 * d, H.ptr(qd[:, 2 * d:]), 3 * d, B, S, S, H.ptr(klc), 1 if klc is not None else 0, 0, kl_bias, shared,
-                              H.ptr(wo1p), H.ptr(bo1c), H.ptr(xa), d, H.ptr(xa), d, None, None, H.stream_ptr()))
-    H.check(L.bofi_linear_block(H.ptr(xa), d, H.ptr(wqp), H.ptr(cqc), H.ptr(csqc), H.ptr(qs), d, 0, B * S, d, 0, H.stream_ptr()))
-    H.check(L.bofi_attn_block(H.ptr(qs), d, H.ptr(kvd[:, d:]), 4 * d, H.ptr(kvd[:, 3 * d:]), 4 * d, B, S, R, H.ptr(atc), 1 if atc is not None else 0, 0, 0, 0,
-                              H.ptr(wo2p), H.ptr(bo2c), H.ptr(xa), d, H.ptr(xa), d, None, None, H.stream_ptr()))
-    # one launch
-    xb = x.cuda()
-    yb = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
-    st = torch.zeros(B * S, 16, 2, device="cuda")
-    H.check(L.bofi_decoder_attn_block(H.ptr(qd), 3 * d, B, S, H.ptr(klc), kl_bias, shared, H.ptr(wo1p), H.ptr(bo1c), H.ptr(kvd[:, d:]), H.ptr(kvd[:, 3 * d:]), 4 * d, R,
-                                      H.ptr(atc), H.ptr(wqp), H.ptr(cqc), H.ptr(csqc), H.ptr(wo2p), H.ptr(bo2c), H.ptr(xb), d, H.ptr(yb), H.ptr(st), H.stream_ptr()))
-    torch.cuda.synchronize()
-    three, one = xa.cpu().double(), xb.cpu().double()
-    nan_ref = torch.isnan(ref)
-    assert torch.equal(torch.isnan(three), nan_ref) and torch.equal(torch.isnan(one), nan_ref)
-    if "q1" in masks and B > 4:
-        assert nan_ref[:4 * S].all() and not nan_ref[4 * S:].any()
-    ok = ~nan_ref
-    assert (one[ok] - three[ok]).abs().max().item() < 2e-2
-    assert (one[ok] - ref[ok]).abs().max().item() < 6e-2 and (three[ok] - ref[ok]).abs().max().item() < 6e-2
-    assert ((one[ok] - three[ok]) != 0).double().mean().item() < 0.5             # most entries identical: only a rounding of a query differs
-    assert torch.equal(yb.cpu()[ok], xb.cpu().to(torch.bfloat16)[ok])
-    rows_ok = ok.all(1)
-    y3 = one[rows_ok].reshape(-1, 16, 32)
-    assert (st.cpu()[rows_ok][:, :, 0].double() - y3.sum(-1)).abs().max() < 1e-3
-    assert (st.cpu()[rows_ok][:, :, 1].double() - (y3 * y3).sum(-1)).abs().max() < 1e-2
-    # a row's result does not depend on its place in the launch: the last images alone
-    if B >= 3 and "q1" not in masks:
-        keep = slice((B - 1) * S, B * S)
-        xc = x[keep].cuda()
-        H.check(L.bofi_decoder_attn_block(H.ptr(qd[keep]), 3 * d, 1, S, None, 0, 0, H.ptr(wo1p), H.ptr(bo1c), H.ptr(kvd[(B - 1) * R:, d:]), H.ptr(kvd[(B - 1) * R:, 3 * d:]),
-                                          4 * d, R, H.ptr(None if atc is None else atc[B - 1:]), H.ptr(wqp), H.ptr(cqc), H.ptr(csqc), H.ptr(wo2p), H.ptr(bo2c), H.ptr(xc), d,
-                                          None, None, H.stream_ptr()))
-        torch.cuda.synchronize()
-        assert torch.equal(xc.cpu(), xb.cpu()[keep])
 
 
 @pytest.mark.parametrize("B,S,masks", [(9, 20, "q1"), (64, 20, "none"), (6, 17, "q1"), (3, 5, "none"), (5, 16, "q1")])
