@@ -14,7 +14,7 @@ struct BoundState {
     int* phrase_length;   // [B, L]
     int* phrase_syn;      // [B, L]
     int* ext_syn;         // [B, L]  extend_phrase_syn: [LEN] id at 0, label of the slot covering p
-    int* counters;        // [8]: 0 = images finished, 1 = bound iterations executed, (2, 3: the semi-autoregressive loop's halt / NaN words), 4 = fp16 saturation word of the
+    int* counters;        // [8]: 0 = images finished, 1 = bound iterations executed, (2, 3: the semi-autoregressive loop's halt / NaN words), 4 = fp16 saturation word, 5 = groups that ran as a pair of workgroups (diagnostic) of the
                           //      persistent bounding-loop kernel (BoundLoopArgs.sat), zeroed by launch_bound_init like the others
     int* klen;            // [B, L]  keys row r of the bound sequence may attend (tgt_mask rows are key prefixes, TransformerModel.py:1859-1867):
                           //         maintained for the dense (N_len >= 2) bounding pass; may be NULL
@@ -80,6 +80,12 @@ struct BoundLoopArgs {
     int* sat;                                             // fp16 saturation word (round 6; NULL: a scratch word of the library): bit 0 is OR-ed in when an activation (attention context, hidden
                                                           // row) was clamped to +-65 504 on its way into an fp16 MFMA operand, bit 1 when the fp16 weight copies were clamped at pack time (*wsat != 0)
     const int* wsat;                                      // the pack-time word of launch_pack_frag16 (may be NULL)
+    // two workgroups per group (round 6): the feed-forward's hidden units split in halves over a PAIR of workgroups -- each streams half of w_1 and w_2
+    // (2 of the iteration's 5.75 MB less per workgroup) and the two partial sums of y3 meet once per iteration through `xbuf` (write-through stores, agent-scope
+    // loads, no fences).  `xctl` [groups][4] unsigned, zeroed by the launcher: [0] the pair's state (0 unclaimed, 2 first workgroup running, 3 first went solo, 4 pair
+    // formed), [1] / [2] iteration counters of role 0 / 1.  `xbuf` [groups][2 parities][2 roles][16][512] float32.  NULL / NULL: one workgroup per group.
+    float* xbuf; unsigned* xctl;
+    int pair;                                             // set by the launcher: the grid holds two workgroups per group
 };
 int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s);
 struct Pack16Entry { const float* w[2]; const float* gain; void* out; int n_each, nsrc, K, Npad, blk0; };      // blk0: set by the launcher

@@ -54,7 +54,7 @@ constexpr int BL_OFF_X = BL_OFF_Y + BL_G * BL_YP * 4;    // fp16 [16][512] GEMM 
 constexpr int BL_OFF_BIG = BL_OFF_X + BL_G * 1024;       // 64 KiB: fp16 hidden rows [16][dff] | float32 queries + probabilities | heads' hidden + logits
 constexpr int BL_OFF_SCT = BL_OFF_BIG + 65536;           // float32 [L*10][8] self-attention scores of row 0 by (position, label, head)
 constexpr int BL_OFF_ST = BL_OFF_SCT + BL_LMAX * 10 * 8 * 4;       // int32 slot state: last, finished, phrase_num, att_len [16]; ext_syn, phrase_length, phrase_syn [16][24]; picks [16][2]
-constexpr int BL_ST_INTS = 4 * BL_G + 3 * BL_G * BL_LMAX + 2 * BL_G + BL_G + 16;
+constexpr int BL_ST_INTS = 4 * BL_G + 3 * BL_G * BL_LMAX + 2 * BL_G + BL_G + 16;      // (... + s_act[16 + 1] + the pair's role word s_act[BL_G + 1])
 constexpr int BL_SMEM = BL_OFF_ST + BL_ST_INTS * 4;
 
 __device__ __forceinline__ float bl_clamp16(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }      // (a NaN fails both tests and passes)
@@ -96,6 +96,13 @@ __device__ __forceinline__ void bl_seg(const u32x4* cur, const u32x4* nxt, int l
     }
 }
 
+// ---- the pair's exchange (two workgroups per group): 16-byte write-through stores and agent-scope loads (cache policy sc1: the two workgroups may sit on different XCDs,
+// whose L2s are not coherent with each other), relaxed agent-scope atomics for the state word and the iteration counters; no fences (dev/exp/grid_barrier_probe.hip: correct, 1.4 us)
+__device__ __forceinline__ unsigned bl_cas(unsigned* p, unsigned expect, unsigned want) {
+    __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;                                     // the value found
+}
+
 template <int NTT>      // the cross-attention's form: 5 = at most 36 regions (every BASELINE config), 8 = at most 64 (scores of an image in registers), 0 = any count (online softmax)
 __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -121,7 +128,26 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     const int B = a.B, L = a.L, S = a.S, R = a.R, hh = a.hh, dff = a.dff;
     // (one group per workgroup, spread over all eight XCDs by the dispatcher's round-robin: confining the groups to fewer L2s -- round 5's BOFI_BL_XCDS -- measured -4 / -11 / -17 %,
     // profiles/r05_bound_loop_xcds_ab.txt, and left in round 6)
-    const int grp = blockIdx.x;
+    // Two workgroups per group (a.pair): the first to arrive claims the group (role 0) and runs on; the second, if it arrives before the first reaches its first
+    // feed-forward stage, joins as role 1 -- else the first has gone solo by then (state 3) and the second leaves at once.  A workgroup only ever waits for a partner that
+    // is RUNNING (state 4): no co-residency assumption, no deadlock whatever else occupies the chip.  Results do not depend on the mode: solo computes the same two partial
+    // sums of y3 (hidden units [0, dff/2) and [dff/2, dff)) and adds them in the same order.
+    int grp = blockIdx.x, role = 0, paired = 0;                      // paired: 0 solo, 1 first of a pair not formed yet, 2 pair formed
+    unsigned* ctl = nullptr;
+    if (a.pair) {
+        grp = (int)blockIdx.x >> 1;
+        ctl = a.xctl + (size_t)grp * 4;
+        if (tid == 0) {
+            const unsigned prev = bl_cas(ctl, 0u, 2u);
+            int r = 0;
+            if (prev != 0u) r = (prev == 2u && bl_cas(ctl, 2u, 4u) == 2u) ? 1 : -1;
+            s_act[BL_G + 1] = r;
+        }
+        __syncthreads();
+        role = s_act[BL_G + 1];
+        if (role < 0) return;                                       // (uniform: the first workgroup runs this group alone)
+        paired = role == 1 ? 2 : 1;
+    }
     const int b0 = grp * BL_G;
     const BoundState st = a.st;
     if (tid == 0 && a.wsat && *a.wsat) atomicOr(a.sat, 2);          // the fp16 weight copies themselves were clamped when they were packed
@@ -132,7 +158,8 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
     const u32x4* wo_self_s = a.wo_self + (size_t)wave * 4096;       // (wave-uniform; the lane is added by the loads)
     const u32x4* wq_s = a.wq_src + (size_t)wave * 4096;
     const u32x4* wo_src_s = a.wo_src + (size_t)wave * 4096;
-    const u32x4* w1_s = a.w1 + (size_t)wave * nc1 * 4096;           // chunk cc at + cc*4096
+    // w_1: the FIRST chunk this workgroup's S6 runs (S5's ring requests it): hidden half 0, wavefront w's chunks there (half 1 for a pair's second workgroup); see S6
+    const u32x4* w1_s = a.w1 + (size_t)((nc1 & 1) ? wave * nc1 : (role == 1 ? 4 * nc1 : 0) + wave * (nc1 >> 1)) * 4096;
     const u32x4* w2_s = a.w2 + (size_t)wave * (dff >> 5) * 256;     // K segment sg at + sg*4096
     const u32x4* wh_s = a.wh + (size_t)(wave & 3) * 4096;           // the heads' hidden layers: 256 columns, wavefronts 0-3
     f16x8 wb[BL_PF * 4];
@@ -468,17 +495,36 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         norm_rows(lane);
         __syncthreads();
         BL_STAMP(8);
-        // ================= S6: h = relu(W1' . LN(y2) + c1): hidden columns (wave*nc1 + cc)*64 .. +63 =================
+        // ================= S6: h = relu(W1' . LN(y2) + c1) =================
+        // The hidden units come in two HALVES, [0, dff/2) and [dff/2, dff) (dff a multiple of 1 024; else one "half" holds them all): a pair's workgroup takes the half of its
+        // role, a workgroup that runs alone both, one after the other -- the two partial sums of y3 are kept apart either way and added in the same order.
+        // Half hf, wavefront w: hidden chunks (of 64 columns) hf*4*nc1 + w*ncw + cc, cc < ncw = nc1 / 2.
+        if (paired == 1) {                                            // the first workgroup of a pair decides HERE, once: has the partner arrived (4) or not (2 -> 3: alone from now on)?
+            if (tid == 0) s_act[BL_G + 1] = bl_cas(ctl, 2u, 3u) == 2u ? 0 : 2;
+            __syncthreads();
+            paired = s_act[BL_G + 1];
+        }
+        const bool split = !(nc1 & 1);
+        const int ncw = split ? nc1 >> 1 : nc1;                       // chunks of a wavefront per half / 512-unit segments of w_2 per half
+        const int nrun = (split && paired != 2) ? 2 * ncw : ncw;      // chunks this workgroup's wavefronts run: one half (a pair's workgroup) or both
+        // chunk j of this workgroup's walk -> index of the 64-column hidden chunk (half hf: chunks hf*4*nc1 + w*ncw + c)
+        auto chunk_of = [&](int j) {
+            if (!split) return wave * nc1 + j;
+            const int hf = paired == 2 ? role : (j >= ncw ? 1 : 0);
+            return hf * 4 * nc1 + wave * ncw + (j >= ncw ? j - ncw : j);
+        };
+        const int sg_first = (split && paired == 2) ? role * ncw : 0;   // the first w_2 segment S7 runs (its first steps are requested by S6's last chunk)
         bl_load_x(X16, xbase, xb);
 #pragma unroll 1
-        for (int cc = 0; cc < nc1; ++cc) {
-            const int hc = (wave * nc1 + cc) * 64 + g * 4;
+        for (int j = 0; j < nrun; ++j) {
+            const int ch = chunk_of(j);
+            const int hc = ch * 64 + g * 4;
             float4 cv[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.c1 + hc + nt * 16);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bl_seg(w1_s + (size_t)cc * 4096, cc + 1 < nc1 ? w1_s + (size_t)(cc + 1) * 4096 : w2_s, lane, wb, xb, acc);
+            bl_seg(a.w1 + (size_t)ch * 4096, j + 1 < nrun ? a.w1 + (size_t)chunk_of(j + 1) * 4096 : w2_s + (size_t)sg_first * 4096, lane, wb, xb, acc);
             float hmax = 0.f;                                                 // (hidden values are >= 0 after the ReLU: only the upper end can saturate)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -492,25 +538,67 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         }
         __syncthreads();
         BL_STAMP(9);
-        // ================= S7: y3 = y2 + W2 . h + b2 =================
+        // ================= S7: y3 = ((y2 + p0) + p1) + b2, p_hf = W2[:, half hf] . h[half hf] =================
+        // ONE summation order whatever the mode: a workgroup that runs alone adds p0 into the residual rows when half 0's segments are through and p1 (+ b2) after half 1's;
+        // a pair's workgroup holds its own partial sum in the accumulators and takes the partner's from the exchange.
         {
+            const int hbase = bl_lane_base(l15, g, dff * 2);
+            const int nseg = (split && paired != 2) ? 2 * ncw : ncw;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int j = 0; j < nseg; ++j) {
+                const int sg = sg_first + j;
+                bl_load_x(BIG, hbase ^ (sg << 10), xb);
+                const u32x4* nxt = j + 1 < nseg ? w2_s + (size_t)(sg + 1) * 4096 : (wave < 4 ? wh_s : wo_self_s);
+                bl_seg(w2_s + (size_t)sg * 4096, nxt, lane, wb, xb, acc);
+                if (split && paired != 2 && j == ncw - 1) {               // (alone: half 0 is through -> y2 + p0 into the residual rows; the accumulators start p1)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        float4* yp = reinterpret_cast<float4*>(Y + l15 * BL_YP + ncol + nt * 16);
+                        const float4 y = *yp;
+                        *yp = make_float4(y.x + acc[nt][0], y.y + acc[nt][1], y.z + acc[nt][2], y.w + acc[nt][3]);
+                        acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+            f32x4 othr[4];
+            if (paired == 2) {
+                // ---- the pair's exchange: my partial sum out (write-through), the partner's in; double-buffered by the iteration's parity (a workgroup passes exchange i only
+                // after its partner has WRITTEN partial i, i.e. has read partial i - 1: buffer (i + 1) & 1 is free by then)
+                float* slot = a.xbuf + ((size_t)grp * 2 + (it_done & 1)) * 2 * (BL_G * 512);      // (wave-uniform: a scalar buffer resource over both roles' tiles; the lane rides in the offset)
+                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 2 * BL_G * 512 * 4, 0x00020000);
+                const int lofs = (l15 * 512 + ncol) * 4, mine_o = role * (BL_G * 512 * 4) + lofs, othr_o = (1 - role) * (BL_G * 512 * 4) + lofs;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt]), xr, mine_o + nt * 64, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(ctl + 1 + role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok = false;
+                    for (int spin = 0; spin < (1 << 21); ++spin) {      // (the partner is running: this wait is its lag; the bound is a safety net against a lost workgroup)
+                        if (__hip_atomic_load(ctl + 2 - role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)it_done) { ok = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (!ok) atomicOr(a.sat, 4);                          // reported like a saturation: the caller decodes again without the loop kernel
+                }
+                __syncthreads();
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) othr[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, othr_o + nt * 64, 0, 16));
+            }
             float4 cv[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) cv[nt] = *reinterpret_cast<const float4*>(a.b2 + ncol + nt * 16);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int hbase = bl_lane_base(l15, g, dff * 2);
-#pragma unroll 1
-            for (int sg = 0; sg < nc1; ++sg) {
-                bl_load_x(BIG, hbase ^ (sg << 10), xb);
-                const u32x4* nxt = sg + 1 < nc1 ? w2_s + (size_t)(sg + 1) * 4096 : (wave < 4 ? wh_s : wo_self_s);
-                bl_seg(w2_s + (size_t)sg * 4096, nxt, lane, wb, xb, acc);
-            }
-#pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 float4* yp = reinterpret_cast<float4*>(Y + l15 * BL_YP + ncol + nt * 16);
                 const float4 y = *yp;
-                *yp = make_float4(y.x + (acc[nt][0] + cv[nt].x), y.y + (acc[nt][1] + cv[nt].y), y.z + (acc[nt][2] + cv[nt].z), y.w + (acc[nt][3] + cv[nt].w));
+                f32x4 t;
+                if (paired == 2) {                                         // ((y2 + p0) + p1) + b2
+                    const f32x4 p0 = role ? othr[nt] : acc[nt], p1 = role ? acc[nt] : othr[nt];
+                    t = f32x4{(y.x + p0[0]) + p1[0], (y.y + p0[1]) + p1[1], (y.z + p0[2]) + p1[2], (y.w + p0[3]) + p1[3]};
+                } else t = f32x4{y.x + acc[nt][0], y.y + acc[nt][1], y.z + acc[nt][2], y.w + acc[nt][3]};      // (alone: the rows hold y2 + p0 already, acc = p1; no halves: acc = the whole sum)
+                *yp = make_float4(t[0] + cv[nt].x, t[1] + cv[nt].y, t[2] + cv[nt].z, t[3] + cv[nt].w);
             }
         }
         __syncthreads();
@@ -596,6 +684,7 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         BL_STAMP(15);
     }
     if (a.dbg && blockIdx.x == 0 && tid == 0) { g_bl_stamps[1] = __builtin_amdgcn_s_memtime(); g_bl_stamps[31] = (unsigned long long)it_done; }
+    if (role == 1) return;                                        // (the pair's second workgroup holds the same state: the first one writes it back)
     if (a.update) {      // the group's slot state back to the engine's arrays (the filling pass and the export read them)
         for (int i = tid; i < BL_G * BL_LMAX; i += 512) {
             const int im = i / BL_LMAX, p = i - im * BL_LMAX;
@@ -611,8 +700,11 @@ __global__ __launch_bounds__(512) void bound_loop_kernel(BoundLoopArgs a) {
         int nf = 0;
         for (int i = 0; i < BL_G; ++i) nf += (b0 + i < B) ? s_fin[i] : 0;
         atomicAdd(&st.counters[0], nf);
+        if (paired == 2) atomicAdd(&st.counters[5], 1);                    // (diagnostic: groups whose loop ran as a pair of workgroups; read through bofi_engine_debug_copy "counters")
     }
 }
+
+__global__ void bl_zero_words_kernel(int* w, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) w[i] = 0; }
 
 int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
     if (a.B < 1 || a.R < 1 || a.R > 128 || a.L < 3 || a.L > BL_LMAX || a.S != a.L - 2 || a.hh < 1 || a.hh > 128 || 2 * a.hh > 256 || a.dff < 512 || a.dff > 2048 ||
@@ -639,7 +731,16 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
     }
     v.dbg = BOFI_ENV_INT("BOFI_BL_DBG", 0);
     const int groups = (a.B + BL_G - 1) / BL_G;
-    const int grid = groups;
+    // two workgroups per group (BOFI_BL_PAIR, re-read after bofi_reload_env: 0 = never, 1 (default) = launches of at most BOFI_BL_PAIR_MAX_B = 384 images, 2 = always): the
+    // whole loop only (the stage API evaluates one iteration), hidden units in two halves of whole 512-unit segments (dff 1 024 or 2 048), and the caller's exchange
+    // buffers.  The pair shortens the loop's LATENCY (815 -> 674 us per 320-image launch alone: each workgroup streams 3.75 instead of 5.75 MB per iteration, one 64-KB
+    // exchange) at the price of twice the CUs and of the iteration's other stages run twice: +2.1 % on the 20-step region (4 launches of 320 images, where the four loops
+    // coincide and most of the chip waits for them), -1.2 % at 640 and -2.5 % at 1 024 images per launch, where the loops hide under other launches' work
+    // (profiles/r06_bound_loop_pair_ab.txt).  Results are bit-identical either way.
+    const int pair_knob = BOFI_ENV_INT("BOFI_BL_PAIR", 1);
+    v.pair = (a.update && a.xbuf && a.xctl && !((a.dff >> 9) & 1) && pair_knob != 0 && (pair_knob == 2 || a.B <= BOFI_ENV_INT("BOFI_BL_PAIR_MAX_B", 384))) ? 1 : 0;
+    if (v.pair) hipLaunchKernelGGL(bl_zero_words_kernel, dim3((groups * 4 + 255) / 256), dim3(256), 0, s, reinterpret_cast<int*>(a.xctl), groups * 4);
+    const int grid = v.pair ? 2 * groups : groups;
     if (a.R <= 36) hipLaunchKernelGGL(bound_loop_kernel<5>, dim3(grid), dim3(512), BL_SMEM, s, v);
     else if (a.R <= 64) hipLaunchKernelGGL(bound_loop_kernel<8>, dim3(grid), dim3(512), BL_SMEM, s, v);
     else hipLaunchKernelGGL(bound_loop_kernel<0>, dim3(grid), dim3(512), BL_SMEM, s, v);

@@ -132,6 +132,7 @@ struct bofi_engine {
     int* live_max = nullptr;              // optional device word: max over decodes of their live-iteration counts (bofi_engine_set_live_iterations_max)
     int* sat_out = nullptr;               // optional device word: fp16 saturation status of the following NAIC decodes' bounding loop (bofi_engine_set_saturation_out)
     int loop_mode = -1;                   // bofi_engine_set_bound_loop: -1 = BOFI_BOUND_LOOP / hint decide, 0 = five-launch iterations, 2 = the persistent loop kernel
+    float* bl_xbuf = nullptr; unsigned* bl_xctl = nullptr;      // the loop kernel's pair exchange: partial sums and control words (workspace: one set per engine / fork)
     int* b_wsat = nullptr;                // [1] set by pack_frag16 when an fp16 weight copy was clamped (shared with forks, like the weights)
     hipStream_t run_stream = nullptr;     // a stream of the engine's own, offered to callers that keep several decodes in flight
     std::vector<GraphEntry> graphs;
@@ -300,6 +301,10 @@ struct bofi_engine {
     ENG_OK(dalloc(&st.last, Bm)); ENG_OK(dalloc(&st.finished, Bm)); ENG_OK(dalloc(&st.phrase_num, Bm));
     ENG_OK(dalloc(&st.phrase_length, Bm * L)); ENG_OK(dalloc(&st.phrase_syn, Bm * L));
     ENG_OK(dalloc(&st.ext_syn, Bm * L)); ENG_OK(dalloc(&st.counters, 8)); ENG_OK(dalloc(&st.klen, Bm * L));
+    if (c.dtype == BOFI_DT_BF16) {                                  // the loop kernel's pair exchange (bound_loop.hip): per group of 16 images 2 x 2 partial tiles + 4 control words
+        const size_t groups = (Bm + 15) / 16;
+        ENG_OK(dalloc(&bl_xbuf, groups * 4 * 16 * 512)); ENG_OK(dalloc(&bl_xctl, groups * 4));
+    }
     ENG_OK(dalloc(&sa.seq_last, Bm)); ENG_OK(dalloc(&sa.seq, Bm * L)); ENG_OK(dalloc(&sa.ext_len, Bm * L));
     ENG_OK(dalloc(&sa.ext_phrase, Bm * L)); ENG_OK(dalloc(&sa.klen_dec, Bm * L));
     ENG_OK(dalloc(&xw, Bm * L * d)); ENG_OK(dalloc((char**)&xwb, Bm * L * d, tsz)); ENG_OK(dalloc(&st_w, Bm * L * (d / 32) * 2));
@@ -402,6 +407,7 @@ struct bofi_engine {
         a.B = B; a.R = R; a.L = L; a.S = cfg.seq_length; a.hh = cfg.head_hidden; a.dff = cfg.d_ff;
         a.max_iters = update ? cfg.seq_length : 1; a.update = update;
         a.sat = st.counters + 4; a.wsat = b_wsat;             // (zeroed by launch_bound_init; the export hands it to the caller's word)
+        a.xbuf = bl_xbuf; a.xctl = bl_xctl;                    // (two workgroups per group when the launcher's conditions hold: BOFI_BL_PAIR)
         return bofi::launch_bound_loop(a, s);
     }
     // y1 (by1 / byb / st_b) -> y3 partial slabs (by3): query projection + cross-attention, Wo_src, FFN, as the direct-operand kernels
@@ -1210,7 +1216,8 @@ int bofi_engine_debug_copy(bofi_engine_t* e, const char* name, void* dst, int64_
     const std::string n = name;
     const void* src = n == "by1" ? (const void*)e->by1 : n == "byb" ? (const void*)e->byb : n == "st_b" ? (const void*)e->st_b :
                       n == "bq2" ? (const void*)e->bq2 : n == "bctx2" ? (const void*)e->bctx2 : n == "by2" ? (const void*)e->by2 :
-                      n == "bh" ? (const void*)e->bh : n == "by3" ? (const void*)e->by3 : n == "dbg_part" ? (const void*)e->dbg_part : nullptr;
+                      n == "bh" ? (const void*)e->bh : n == "by3" ? (const void*)e->by3 : n == "dbg_part" ? (const void*)e->dbg_part :
+                      n == "counters" ? (const void*)e->st.counters : nullptr;      // ("counters": int32 [8] of the last decode: [5] = groups whose bounding loop ran as a PAIR of workgroups)
     if (!src) return fail(BOFI_ERR_ARG, "unknown buffer");
     ENG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BOFI_OK;

@@ -255,7 +255,7 @@ class BofiEngine:
     def saturated(self, out: dict) -> int:
         """fp16 saturation status of the decode that produced ``out`` (a device -> host read: call it where the caller synchronises anyway): 0 = clean; bit 0 = the
         persistent bounding-loop kernel clamped an activation to +-65 504 on its way into an fp16 MFMA operand; bit 1 = its fp16 weight copies were clamped when they
-        were packed.  Either way the slot layout may differ from what bf16 operands (float32's exponent range) give: decode again under ``set_bound_loop(0)``
+        were packed; bit 2 = a pair of workgroups that share a group's feed-forward weights lost its exchange (a safety net: never seen).  Either way the slot layout may differ from what bf16 operands (float32's exponent range) give: decode again under ``set_bound_loop(0)``
         -- ``decode_naic_checked`` does both."""
         w = out.get("bound_saturated")
         return int(w) if w is not None else 0
@@ -271,8 +271,10 @@ class BofiEngine:
 
     def _redo_without_loop_kernel(self, sat: int, decode):
         import warnings
-        warnings.warn("boficap_amd: the fp16 bounding-loop kernel clamped " + ("its weight copies" if sat & 2 else "an activation") +
-                      " to +-65 504 (a bounding layer outside fp16's range); this decode is repeated with the five-launch bf16 iterations" +
+        what = ("clamped its weight copies to +-65 504 (a bounding layer outside fp16's range)" if sat & 2 else
+                "clamped an activation to +-65 504 (a bounding layer outside fp16's range)" if sat & 1 else
+                "lost a partner workgroup of a pair (exchange timed out: status bit 2)")
+        warnings.warn("boficap_amd: the fp16 bounding-loop kernel " + what + "; this decode is repeated with the five-launch bf16 iterations" +
                       (" and the engine stays on them until its weights change" if sat & 2 else ""), RuntimeWarning, stacklevel=3)
         before = getattr(self, "_loop_mode", -1)
         self.set_bound_loop(0)

@@ -360,7 +360,8 @@ int bofi_engine_set_live_iterations_max(bofi_engine_t* e, int* live_max);
  * layer leaves that range -- none here does: |y| < 30 -- would get a silently different slot layout where the bf16 kernels (same exponent range as float32) would not.
  * `word` (device int32, NULL = off -- the default, also of a fork): every following bofi_engine_decode_naic WRITES its status there (beside bound_iters): 0 = nothing was
  * clamped (always 0 when the decode ran the five-launch bf16 iterations), bit 0 = an activation (attention context or hidden row of the bounding layer) was clamped
- * during this decode, bit 1 = the fp16 weight copies were clamped when they were packed (finalize / refresh_device).  A caller that reads a non-zero word decodes that
+ * during this decode, bit 1 = the fp16 weight copies were clamped when they were packed (finalize / refresh_device), bit 2 = the kernel's pair exchange timed out (two workgroups share a group's
+ * feed-forward weights: a safety net against a lost workgroup, never observed).  A caller that reads a non-zero word decodes that
  * batch again under bofi_engine_set_bound_loop(e, 0) (boficap_amd/engine.py does, with a warning).  Per-call state, part of the graph key.
  * Replaces nothing in the reference (TransformerModel.py:357-383 runs in float32 there); it guards this library's own precision choice. */
 int bofi_engine_set_saturation_out(bofi_engine_t* e, int* word);

@@ -374,3 +374,64 @@ def test_fp16_saturation_is_reported_and_falls_back(weight_cache, monkeypatch):
     assert e3.bound_loop_active(R) and e3.saturated(e3.decode_naic(att, strict_q1=False)) == 0
     monkeypatch.undo()
     H.lib().bofi_reload_env()
+
+
+def test_pair_of_workgroups_per_group_is_bit_equal_to_one(weight_cache, monkeypatch):
+    """Round 6: two workgroups per group of 16 images share the feed-forward's weight stream -- each runs one half of the hidden units and the two partial
+    sums of y3 meet once per iteration through memory (BOFI_BL_PAIR: by default for launches of at most 384 images, 2 = always, 0 = never).  The first workgroup to arrive never waits for one that is not running (it goes on alone
+    when the partner has not arrived by its first feed-forward stage), and a workgroup that runs alone forms the SAME two partial sums in the same order: whatever the
+    dispatcher does, the decode's bits do not depend on it.  Shown: (1) pairs really form (the diagnostic counter), (2) BOFI_BL_PAIR=2 and =0 give identical slot layouts,
+    ids, iteration counts and log-probs, eager and as a replayed graph, ragged regions and a batch that is no multiple of 16, (3) several decodes in flight on forks."""
+    from boficap_amd import hip as H
+    from boficap_amd import weights as W
+    monkeypatch.setenv("BOFI_BOUND_LOOP", "2")
+    B, R = 150, 36
+    cfg, sd, eng = _engine(weight_cache, B, R)
+    att = torch.from_numpy(W.synthetic_att_feats(B, R, cfg.att_feat_size, seed=31)).cuda().to(torch.bfloat16)
+    lens = torch.full((B,), R, dtype=torch.int32); lens[3], lens[40], lens[149] = 11, 1, 30
+    lens = lens.cuda()
+
+    def pairs_formed(e):
+        buf = torch.zeros(8, dtype=torch.int32, device="cuda")
+        H.check(H.lib().bofi_engine_debug_copy(e._h, b"counters", H.ptr(buf), 32, H.stream_ptr()), "debug_copy")
+        torch.cuda.synchronize()
+        return int(buf[5])
+
+    runs = {}
+    for pair in ("2", "0"):
+        monkeypatch.setenv("BOFI_BL_PAIR", pair)
+        H.lib().bofi_reload_env()
+        outs, prev = [], None
+        for graph in (False, True, True):
+            r = eng.decode_naic(att, lens, strict_q1=False, graph=graph, out=prev if graph else None)      # (the second graph call replays the captured launch)
+            torch.cuda.synchronize()
+            assert eng.saturated(r) == 0
+            prev = r if graph else None
+            outs.append({k: v.clone() for k, v in r.items() if torch.is_tensor(v)})
+        n_pairs = pairs_formed(eng)
+        groups = (B + 15) // 16
+        assert (n_pairs > 0) == (pair == "2") and n_pairs <= groups, (pair, n_pairs)
+        print(f"BOFI_BL_PAIR={pair}: {n_pairs} of {groups} groups ran as a pair of workgroups")
+        for o in outs[1:]:
+            for k in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
+                assert torch.equal(o[k], outs[0][k]), (pair, k)
+        runs[pair] = outs[0]
+    for k in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
+        assert torch.equal(runs["2"][k], runs["0"][k]), k
+    assert torch.equal(runs["2"]["seq_logprob"].nan_to_num(), runs["0"]["seq_logprob"].nan_to_num())
+    # forks in flight: every fork owns its exchange buffers
+    monkeypatch.setenv("BOFI_BL_PAIR", "2")
+    H.lib().bofi_reload_env()
+    forks = [eng.fork() for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in forks]
+    res = []
+    torch.cuda.synchronize()
+    for f, s_ in zip(forks, streams):
+        with torch.cuda.stream(s_):
+            res.append(f.decode_naic(att, lens, strict_q1=False))
+    torch.cuda.synchronize()
+    for r in res:
+        for k in ("seq", "phrase_num", "phrase_length", "phrase_syn"):
+            assert torch.equal(r[k], runs["0"][k]), k
+    monkeypatch.undo()
+    H.lib().bofi_reload_env()
