@@ -906,7 +906,7 @@ def run_naic(args, ctx, log, cpu=True, gemm_roofline=True):
                                + (f", {args.refine} refinement rounds" if args.refine else ""),
                    "images_per_step_per_gpu": args.batch, "bound_iterations": T, "bound_iterations_enqueued": None if loop_kernel else (cap if cap else cfg.seq_length),
                    "bound_loop": ("one persistent kernel per 16 images runs every iteration of core_NAIC's loop and leaves when its images are finished (bound_loop.hip; "
-                                  "fp16 operands from the float32 parameters)" if loop_kernel else "five launches per iteration (bound_ops.hip, naic.hip)"),
+                                  "fp16 operands from the float32 parameters; launches of <= 384 images: TWO workgroups per group share the feed-forward's weight stream, bit-identical)" if loop_kernel else "five launches per iteration (bound_ops.hip, naic.hip)"),
                    "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("BOFI_")},
                    "iteration_budget": ("not applicable: the loop kernel ends by itself" if loop_kernel else f"{cap} of {cfg.seq_length} bounding iterations enqueued per decode (largest live count of the probe decodes + 1; the reference's loop "
                                         "stops when every image is finished, TransformerModel.py:1869); every decode folds its live-iteration count into a device word "
