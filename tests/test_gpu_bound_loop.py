@@ -376,7 +376,8 @@ def test_fp16_saturation_is_reported_and_falls_back(weight_cache, monkeypatch):
     H.lib().bofi_reload_env()
 
 
-def test_pair_of_workgroups_per_group_is_bit_equal_to_one(weight_cache, monkeypatch):
+@pytest.mark.parametrize("R", [36, 64, 100])
+def test_pair_of_workgroups_per_group_is_bit_equal_to_one(R, weight_cache, monkeypatch):
     """Round 6: two workgroups per group of 16 images share the feed-forward's weight stream -- each runs one half of the hidden units and the two partial
     sums of y3 meet once per iteration through memory (BOFI_BL_PAIR: by default for launches of at most 384 images, 2 = always, 0 = never).  The first workgroup to arrive never waits for one that is not running (it goes on alone
     when the partner has not arrived by its first feed-forward stage), and a workgroup that runs alone forms the SAME two partial sums in the same order: whatever the
@@ -385,10 +386,10 @@ def test_pair_of_workgroups_per_group_is_bit_equal_to_one(weight_cache, monkeypa
     from boficap_amd import hip as H
     from boficap_amd import weights as W
     monkeypatch.setenv("BOFI_BOUND_LOOP", "2")
-    B, R = 150, 36
+    B = 150                                                     # (R: every instantiation of the kernel -- <= 36, <= 64, any count)
     cfg, sd, eng = _engine(weight_cache, B, R)
     att = torch.from_numpy(W.synthetic_att_feats(B, R, cfg.att_feat_size, seed=31)).cuda().to(torch.bfloat16)
-    lens = torch.full((B,), R, dtype=torch.int32); lens[3], lens[40], lens[149] = 11, 1, 30
+    lens = torch.full((B,), R, dtype=torch.int32); lens[3], lens[40], lens[149] = 11, 1, R - 6
     lens = lens.cuda()
 
     def pairs_formed(e):
