@@ -601,17 +601,24 @@ __global__ __launch_bounds__(512) void rb_ffn5_kernel(RbFfnArgs a) {
             RB3_STAMP(stamps, nst);                            // staging starts
             if constexpr (HEAD) {
                 // the attention core's context rows ARE the block (bf16 already: a copy into the swizzled layout); then the consumers run W_o over it and hand x1 back
+                {   // wavefront w4: rows 20*w4 .. +19, eight at a time, eight lanes per row, eight 16-byte chunks per lane.  ALL THREE passes' loads are requested before the
+                    // first row is written (96 registers the producers do not need yet): one memory round trip in front of the consumers' W_o segment instead of three
+                    u32x4 v[3][8];
 #pragma unroll
-                for (int pass = 0; pass < 3; ++pass) {          // wavefront w4: rows 20*w4 .. +19, eight at a time, eight lanes per row, eight 16-byte chunks per lane
-                    const int lr = pass * 8 + (lane >> 3), r = w4 * 20 + lr, sub = lane & 7, m = m0 + r;
-                    const bool mine = lr < 20;
-                    u32x4 v[8];
+                    for (int pass = 0; pass < 3; ++pass) {
+                        const int lr = pass * 8 + (lane >> 3), sub = lane & 7, m = m0 + w4 * 20 + lr;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        v[j] = (mine && m < a.M) ? *reinterpret_cast<const u32x4*>(a.head_ctx + (size_t)m * a.head_ldc + (j * 8 + sub) * 8) : u32x4{0u, 0u, 0u, 0u};
+                        for (int j = 0; j < 8; ++j)
+                            v[pass][j] = (lr < 20 && m < a.M) ? *reinterpret_cast<const u32x4*>(a.head_ctx + (size_t)m * a.head_ldc + (j * 8 + sub) * 8) : u32x4{0u, 0u, 0u, 0u};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);             // (keeps the stores below from being interleaved with -- and waiting between -- the loads)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (mine) *reinterpret_cast<u32x4*>(xt + rb_off(r, j * 8 + sub)) = v[j];
+                    for (int pass = 0; pass < 3; ++pass) {
+                        const int lr = pass * 8 + (lane >> 3), r = w4 * 20 + lr, sub = lane & 7;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (lr < 20) *reinterpret_cast<u32x4*>(xt + rb_off(r, j * 8 + sub)) = v[pass][j];
+                    }
                 }
                 rb_signal(flags + 7, lane);                    // (the consumers wait for all four producers' rows)
                 rb_wait_ge(flags + 9, 4u);                     // x1 is back in the block as bf16, the consumers' partial row sums beside it

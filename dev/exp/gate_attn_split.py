@@ -110,7 +110,44 @@ def ffn_case(M, nstr):
     return res
 
 
+def head_case(M, nstr, N=1536):
+    """The BUILT head segment (rb_ffn5_kernel<.., HEAD>, round 6): feed-forward + projection tail without / with W_o + residual in front (bofi_ffn_linear_block against
+    bofi_attn_out_ffn_block), same streams."""
+    res = {}
+    dff = 2048
+    ws = []
+    for _ in range(2):
+        w1 = (torch.randn(dff, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        w2 = (torch.randn(d, dff, device=dev) / math.sqrt(dff)).to(torch.bfloat16)
+        wj = (torch.randn(N, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        wo = (torch.randn(d, d, device=dev) / math.sqrt(d)).to(torch.bfloat16)
+        ws.append((pack(w1), torch.randn(dff, device=dev), w1.float().sum(1), pack(w2), torch.randn(d, device=dev), pack(wj), torch.randn(N, device=dev), wj.float().sum(1), pack(wo), torch.randn(d, device=dev)))
+    for form in ("plain", "head"):
+        def make_run(si):
+            xs = [torch.randn(M, d, device=dev) for _ in range(2)]
+            cs = [torch.randn(M, d, device=dev).to(torch.bfloat16) for _ in range(2)]
+            ps = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+
+            def run(j):
+                w1p, c1, cs1, w2p, b2, wjp, cj, csj, wop, bo = ws[j % 2]
+                x, c, pj = xs[j % 2], cs[j % 2], ps[j % 2]
+                if form == "plain":
+                    H.check(H.lib().bofi_ffn_linear_block(H.ptr(x), d, H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, M, dff, H.ptr(wjp), H.ptr(cj), H.ptr(csj),
+                                                          H.ptr(pj), N, N, H.stream_ptr()))
+                else:
+                    H.check(H.lib().bofi_attn_out_ffn_block(H.ptr(x), d, H.ptr(c), d, H.ptr(wop), H.ptr(bo), H.ptr(w1p), H.ptr(c1), H.ptr(cs1), H.ptr(w2p), H.ptr(b2), H.ptr(x), d, M, dff,
+                                                            H.ptr(wjp), H.ptr(cj), H.ptr(csj), H.ptr(pj), N, N, H.stream_ptr()))
+            return run
+        res[form] = streams_time(make_run, nstr)
+    print(f"feed-forward + q|k|v tail M {M} x {nstr} stream(s): plain {res['plain']:6.2f} us | with the W_o head segment {res['head']:6.2f} us  (+{res['head'] - res['plain']:5.2f})", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "head":
+        for nstr in (1, 4):
+            head_case(320 * 36, nstr)
+            head_case(320 * 20, nstr)
+        sys.exit(0)
     B = 320
     tot = {}
     for nstr in (1, 4):
