@@ -18,6 +18,7 @@ struct BoundState {
                           //      persistent bounding-loop kernel (BoundLoopArgs.sat), zeroed by launch_bound_init like the others
     int* klen;            // [B, L]  keys row r of the bound sequence may attend (tgt_mask rows are key prefixes, TransformerModel.py:1859-1867):
                           //         maintained for the dense (N_len >= 2) bounding pass; may be NULL
+    unsigned* pair_ctl;   // [ceil(B / 16) * 4] control words of the loop kernel's workgroup pairs (BoundLoopArgs.xctl), zeroed by launch_bound_init with the rest; may be NULL
 };
 
 // Extra per-image state of core_SAIC (reference TransformerModel.py:1879-1896), int32 on the device.

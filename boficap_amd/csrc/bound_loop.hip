@@ -739,7 +739,8 @@ int launch_bound_loop(const BoundLoopArgs& a, hipStream_t s) {
     // (profiles/r06_bound_loop_pair_ab.txt).  Results are bit-identical either way.
     const int pair_knob = BOFI_ENV_INT("BOFI_BL_PAIR", 1);
     v.pair = (a.update && a.xbuf && a.xctl && !((a.dff >> 9) & 1) && pair_knob != 0 && (pair_knob == 2 || a.B <= BOFI_ENV_INT("BOFI_BL_PAIR_MAX_B", 384))) ? 1 : 0;
-    if (v.pair) hipLaunchKernelGGL(bl_zero_words_kernel, dim3((groups * 4 + 255) / 256), dim3(256), 0, s, reinterpret_cast<int*>(a.xctl), groups * 4);
+    if (v.pair && a.st.pair_ctl != a.xctl)                  // (the engine's launch_bound_init zeroes the control words with the slot state: no launch of its own)
+        hipLaunchKernelGGL(bl_zero_words_kernel, dim3((groups * 4 + 255) / 256), dim3(256), 0, s, reinterpret_cast<int*>(a.xctl), groups * 4);
     const int grid = v.pair ? 2 * groups : groups;
     if (a.R <= 36) hipLaunchKernelGGL(bound_loop_kernel<5>, dim3(grid), dim3(512), BL_SMEM, s, v);
     else if (a.R <= 64) hipLaunchKernelGGL(bound_loop_kernel<8>, dim3(grid), dim3(512), BL_SMEM, s, v);

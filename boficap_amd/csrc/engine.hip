@@ -304,6 +304,7 @@ struct bofi_engine {
     if (c.dtype == BOFI_DT_BF16) {                                  // the loop kernel's pair exchange (bound_loop.hip): per group of 16 images 2 x 2 partial tiles + 4 control words
         const size_t groups = (Bm + 15) / 16;
         ENG_OK(dalloc(&bl_xbuf, groups * 4 * 16 * 512)); ENG_OK(dalloc(&bl_xctl, groups * 4));
+        st.pair_ctl = bl_xctl;
     }
     ENG_OK(dalloc(&sa.seq_last, Bm)); ENG_OK(dalloc(&sa.seq, Bm * L)); ENG_OK(dalloc(&sa.ext_len, Bm * L));
     ENG_OK(dalloc(&sa.ext_phrase, Bm * L)); ENG_OK(dalloc(&sa.klen_dec, Bm * L));

@@ -15,6 +15,7 @@ namespace bofi {
 __global__ void bound_init_kernel(BoundState st, int B, int L, int pad_idx, int len_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 8) st.counters[i] = 0;
+    if (st.pair_ctl && i < ((B + 15) / 16) * 4) st.pair_ctl[i] = 0u;      // (the loop kernel's pair state and iteration counters: B * L >= B / 4 threads are there)
     if (i < B) { st.last[i] = 1; st.finished[i] = 0; st.phrase_num[i] = 0; }
     if (i < B * L) {
         st.phrase_length[i] = 0;
