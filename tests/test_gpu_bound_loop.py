@@ -402,17 +402,20 @@ def test_pair_of_workgroups_per_group_is_bit_equal_to_one(R, weight_cache, monke
     for pair in ("2", "0"):
         monkeypatch.setenv("BOFI_BL_PAIR", pair)
         H.lib().bofi_reload_env()
-        outs, prev = [], None
+        outs, prev, n_pairs = [], None, 0
+        groups = (B + 15) // 16
         for graph in (False, True, True):
             r = eng.decode_naic(att, lens, strict_q1=False, graph=graph, out=prev if graph else None)      # (the second graph call replays the captured launch)
             torch.cuda.synchronize()
             assert eng.saturated(r) == 0
             prev = r if graph else None
             outs.append({k: v.clone() for k, v in r.items() if torch.is_tensor(v)})
-        n_pairs = pairs_formed(eng)
-        groups = (B + 15) // 16
-        assert (n_pairs > 0) == (pair == "2") and n_pairs <= groups, (pair, n_pairs)
-        print(f"BOFI_BL_PAIR={pair}: {n_pairs} of {groups} groups ran as a pair of workgroups")
+            formed = pairs_formed(eng)                           # (of THIS decode: the counters are zeroed with the slot state)
+            assert formed <= groups
+            n_pairs += formed
+        # (whether a pair forms is the dispatcher's business -- a second workgroup that arrives late finds its group taken and leaves --: over three decodes some do)
+        assert (n_pairs > 0) == (pair == "2"), (pair, n_pairs)
+        print(f"BOFI_BL_PAIR={pair}: {n_pairs} of {3 * groups} groups (three decodes) ran as a pair of workgroups")
         for o in outs[1:]:
             for k in ("seq", "phrase_num", "phrase_length", "phrase_syn", "bound_iters"):
                 assert torch.equal(o[k], outs[0][k]), (pair, k)
