@@ -587,7 +587,7 @@ int bofi_engine::enqueue_encode(const void* feats, int feats_dtype, const int* a
         a.klen = att_len; a.klen_sb = 1; a.klen_sq = 0;
         const bool ffn_rb = ffn_sublayer_ok(l.w1, l.w2, M);
         const bool need_copy = !(fold_rb_ok(l.qkv, M) && fold_rb_ok(kv_all, M)) || memory_out_needs_copy;      // (consumers of this layer's output that read the copy + statistics: tiled GEMMs)
-        const bool split = ffn_rb && !need_copy && attn_split_ok(a, l.o, l.w1, l.w2);      // attention core now, W_o + residual as the head of the feed-forward launch
+        const bool split = ffn_rb && !need_copy && (BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT_WHICH", 3) & 1) && attn_split_ok(a, l.o, l.w1, l.w2);      // attention core now, W_o + residual as the head of the feed-forward launch
         int rc = split ? bofi::launch_attention(a, s) : attn_sublayer(a, l.o, x_enc, xb_enc, st_enc, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {
@@ -790,7 +790,7 @@ int bofi_engine::enqueue_fill(const int* att_len, int B, int R, int flags, int64
         c.k = (char*)kv + (size_t)(n_len + li) * 2 * d * tsz; c.v = (char*)kv + ((size_t)(n_len + li) * 2 * d + d) * tsz;
         c.ldk = c.ldv = kv_all.N; c.out = ctx; c.ldo = d; c.dtype = dt; c.B = B; c.H = cfg.heads; c.Lq = S; c.Lk = R;
         c.klen = att_len; c.klen_sb = 1; c.klen_sq = 0;
-        cross_split = ffn_rb && !need_copy_out && attn_split_ok(c, l.o_src, l.w1, l.w2);      // the cross-attention's core now, its W_o + residual as the head of the feed-forward launch
+        cross_split = ffn_rb && !need_copy_out && (BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT_WHICH", 3) & 2) && attn_split_ok(c, l.o_src, l.w1, l.w2);      // the cross-attention's core now, its W_o + residual as the head of the feed-forward launch
         rc = cross_split ? bofi::launch_attention(c, s) : attn_sublayer(c, l.o_src, x_fill, xb_fill, st_fill, !ffn_rb, s);
         if (rc > 0) return rc;
         if (rc < 0) {
