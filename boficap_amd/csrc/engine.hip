@@ -524,10 +524,13 @@ struct bofi_engine {
     // launch, where a launch's blocks come in several waves per CU and hide the longer chain, -1 ... -4 % at 320, where they do not.  Hence BOFI_RB_ATTN_SPLIT (re-read
     // after bofi_reload_env): 0 = never, 1 (default) = when launches overlap AND the launch holds at least BOFI_RB_ATTN_SPLIT_MIN_B (512) images, 2 = always.  Needs the
     // feed-forward sublayer directly behind the attention sublayer and no consumer of the bf16 copy / statistics.
+    // Shapes the fused sublayer kernel does not take (more than 48 keys or 40 queries: real bottom-up features have up to 100 regions) are split at EVERY launch size: the
+    // alternative there is the attention core + a tiled GEMM for W_o + the residual stream's round trip (profiles/r06_regions_sweep.txt).
     bool attn_split_ok(const bofi::AttnArgs& at, const Lin& o, const Lin& w1, const Lin& w2) const {
         const int v = BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT", 1);
         const int M = at.B * at.Lq;
-        return v && (v == 2 || (in_flight != 1 && at.B >= BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT_MIN_B", 512))) && BOFI_ENV_INT("BOFI_RB_ATTN", 1) != 0 && rb_ok() && o.wp &&
+        const bool beyond = (at.Lq > 40 || at.Lk > 48) && M >= rb_min_rows();
+        return v && (v == 2 || beyond || (in_flight != 1 && at.B >= BOFI_ENV_INT("BOFI_RB_ATTN_SPLIT_MIN_B", 512))) && BOFI_ENV_INT("BOFI_RB_ATTN", 1) != 0 && rb_ok() && o.wp &&
                ffn_sublayer_ok(w1, w2, M) && !at.skip_if_ge && at.kdiv <= 1 &&
                !at.q_start && !at.drop_thresh && at.Lq <= 128 && at.Lk <= 128 && !exp_skip("attn") && !exp_skip("ffn");
     }
